@@ -1,0 +1,88 @@
+"""ctypes binding of libag2v.so (C ABI declared in include/ag2v.h).
+
+The product path has no fallback: if the library is missing, or a kernel returns an error code, a RuntimeError is raised
+(the reference's convention is "raise, the training loop logs and continues", scripts/train.py:466-468).
+"""
+import ctypes
+import os
+from ctypes import c_float, c_int, c_longlong, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libag2v.so')
+
+_P = c_void_p
+_SIGS = {
+    # name: (restype, [argtypes])
+    'ag2v_conv2d_fwd': (c_int, [_P, _P, _P, _P, _P] + [c_int] * 9 + [_P]),
+    'ag2v_conv2d_dgrad': (c_int, [_P, _P, _P] + [c_int] * 9 + [_P]),
+    'ag2v_conv2d_wgrad': (c_int, [_P, _P, _P] + [c_int] * 9 + [_P]),
+    'ag2v_channel_sum': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    'ag2v_bn_workspace_floats': (c_size_t, [c_int, c_int, c_int]),
+    'ag2v_bn_stats': (c_int, [_P, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P]),
+    'ag2v_norm_apply': (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
+    'ag2v_norm_bwd': (c_int, [c_int] + [_P] * 11 + [c_int, c_int, c_int, c_float, _P, _P]),
+    'ag2v_instnorm_lrelu_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P]),
+    'ag2v_instnorm_lrelu_bwd': (c_int, [_P] * 6 + [c_int, c_int, c_float, _P]),
+    'ag2v_layout_render_fwd': (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [_P]),
+    'ag2v_layout_render_bwd': (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [_P]),
+    'ag2v_flow_warp_fwd': (c_int, [_P, _P, _P] + [c_int] * 4 + [_P]),
+    'ag2v_flow_warp_bwd': (c_int, [_P, _P, _P, _P, _P] + [c_int] * 4 + [_P]),
+    'ag2v_avgpool3s2_fwd': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    'ag2v_avgpool3s2_bwd': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    'ag2v_nearest_resize_fwd': (c_int, [_P, _P] + [c_int] * 5 + [_P]),
+    'ag2v_nearest_resize_bwd': (c_int, [_P, _P] + [c_int] * 5 + [_P]),
+    'ag2v_triple_gather_fwd': (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [_P]),
+    'ag2v_triple_gather_bwd': (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [_P]),
+    'ag2v_triple_pool_fwd': (c_int, [_P] * 5 + [c_int] * 5 + [_P]),
+    'ag2v_triple_pool_bwd': (c_int, [_P] * 6 + [c_int] * 5 + [_P]),
+    'ag2v_gemm_f32': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_longlong, c_longlong, c_longlong, c_longlong,
+                              c_int, c_int, c_int, _P]),
+    'ag2v_relu_bwd': (c_int, [_P, _P, _P, c_longlong, _P]),
+    'ag2v_col_sum': (c_int, [_P, _P, c_int, c_int, _P]),
+    'ag2v_embedding_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    'ag2v_embedding_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    'ag2v_act_fwd': (c_int, [c_int, _P, _P, c_longlong, c_float, _P]),
+    'ag2v_act_bwd': (c_int, [c_int, _P, _P, _P, c_longlong, c_float, _P]),
+    'ag2v_reduce_workspace_floats': (c_size_t, []),
+    'ag2v_reduce_fwd': (c_int, [c_int, _P, _P, c_longlong, c_float, _P, _P, _P]),
+    'ag2v_reduce_bwd': (c_int, [c_int, _P, _P, c_longlong, _P, c_float, _P, _P]),
+    'ag2v_spectral_workspace_floats': (c_size_t, [c_int]),
+    'ag2v_spectral_norm_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_float, c_int, _P, _P, _P, _P]),
+    'ag2v_spectral_norm_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P]),
+}
+EXPORTS = tuple(sorted(_SIGS))
+
+_lib = None
+
+
+def load():
+    """dlopen libag2v.so once; raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "ag2video_amd: %s not found -- build the HIP kernels first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C ag2video_amd/csrc). "
+            "There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+_ERR = {-1: 'AG2V_EINVAL (rejected argument)', -2: 'AG2V_EHIP (HIP launch error)'}
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point; non-zero => RuntimeError."""
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise RuntimeError("%s failed: %s" % (name, _ERR.get(rc, rc)))
+
+
+def query(name, *args):
+    return getattr(load(), name)(*args)

@@ -1,0 +1,262 @@
+// Action-graph kernels: GraphTripleConv gather / masked average pooling
+// (models/graph_models/graph.py:64-100), the small dense layers of build_mlp / nn.Linear (models/layers.py:6-25,
+// graph.py:70-71,103) on the fp32 matrix pipe, and embedding lookups (models/attribute_embed.py:38-45).
+//
+// The reference loops over the batch in Python and uses boolean-mask indexing (a device->host sync per sample per
+// layer).  Here every sample of the batch is handled in one launch: edges are read with coalesced index loads, and the
+// pooling is a segmented reduce over the (<= a few dozen) edges of each object -- one workgroup per (sample, object),
+// no atomics, deterministic order.
+#include "common.h"
+
+// triples[b,t,:] = [ obj[b, s(b,t), :Din] | pred[b,t,:Dp] | obj[b, o(b,t), :Din] ]     edges: int64 [B,T,2]
+__global__ __launch_bounds__(256) void triple_gather_fwd_kernel(const float* __restrict__ obj, const float* __restrict__ pred,
+                                                                const long long* __restrict__ edges, float* __restrict__ out,
+                                                                int O, int T, int Din, int Dp) {
+    const int bt = blockIdx.x;  // b*T + t
+    const int b = bt / T;
+    const int s = (int)edges[(size_t)bt * 2], o = (int)edges[(size_t)bt * 2 + 1];
+    const int Dt = 2 * Din + Dp;
+    const float* so = obj + ((size_t)b * O + s) * Din;
+    const float* oo = obj + ((size_t)b * O + o) * Din;
+    const float* pp = pred + (size_t)bt * Dp;
+    float* dst = out + (size_t)bt * Dt;
+    for (int i = threadIdx.x; i < Dt; i += 256) {
+        float v;
+        if (i < Din) v = so[i];
+        else if (i < Din + Dp) v = pp[i - Din];
+        else v = oo[i - Din - Dp];
+        dst[i] = v;
+    }
+}
+
+// adjoint of the gather: dobj[b,o,:] = sum_{t: s(t)=o} dtri[b,t,:Din] + sum_{t: o(t)=o} dtri[b,t,Din+Dp:], dpred = middle slice.
+// grid: (B*O) blocks for dobj; dpred is written by the first O-block of every sample.
+__global__ __launch_bounds__(256) void triple_gather_bwd_kernel(const float* __restrict__ dtri, const long long* __restrict__ edges,
+                                                                float* __restrict__ dobj, float* __restrict__ dpred, int O, int T,
+                                                                int Din, int Dp) {
+    const int bo = blockIdx.x;
+    const int b = bo / O, o = bo - b * O;
+    const int Dt = 2 * Din + Dp;
+    for (int i = threadIdx.x; i < Din; i += 256) {
+        float acc = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const size_t e = (size_t)b * T + t;
+            const int s = (int)edges[e * 2], oo = (int)edges[e * 2 + 1];
+            if (s == o) acc += dtri[e * Dt + i];
+            if (oo == o) acc += dtri[e * Dt + Din + Dp + i];
+        }
+        dobj[(size_t)bo * Din + i] = acc;
+    }
+    if (o == 0 && dpred) {
+        for (int t = 0; t < T; ++t) {
+            const size_t e = (size_t)b * T + t;
+            for (int i = threadIdx.x; i < Dp; i += 256) dpred[e * Dp + i] = dtri[e * Dt + Din + i];
+        }
+    }
+}
+
+// masked average pooling: pooled[b,o,:Hd] = (sum_{valid t, s(t)=o} newt[b,t,:Hd] + sum_{valid t, o(t)=o} newt[b,t,Hd+Dp:]) / count
+// count = number of valid incident edge endpoints (graph.py:94-99); rows with count 0 stay 0.  valid: uint8 [B,T].
+__global__ __launch_bounds__(256) void triple_pool_fwd_kernel(const float* __restrict__ newt, const long long* __restrict__ edges,
+                                                              const unsigned char* __restrict__ valid, float* __restrict__ pooled,
+                                                              float* __restrict__ counts, int O, int T, int Hd, int Dp) {
+    const int bo = blockIdx.x;
+    const int b = bo / O, o = bo - b * O;
+    const int Dt = 2 * Hd + Dp;
+    int cnt = 0;
+    for (int t = 0; t < T; ++t) {
+        const size_t e = (size_t)b * T + t;
+        if (!valid[e]) continue;
+        cnt += ((int)edges[e * 2] == o) + ((int)edges[e * 2 + 1] == o);
+    }
+    const float inv = cnt > 0 ? 1.0f / (float)cnt : 0.f;
+    for (int i = threadIdx.x; i < Hd; i += 256) {
+        float acc = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const size_t e = (size_t)b * T + t;
+            if (!valid[e]) continue;
+            if ((int)edges[e * 2] == o) acc += newt[e * Dt + i];
+            if ((int)edges[e * 2 + 1] == o) acc += newt[e * Dt + Hd + Dp + i];
+        }
+        pooled[(size_t)bo * Hd + i] = cnt > 0 ? acc / (float)cnt : acc;
+    }
+    (void)inv;
+    if (threadIdx.x == 0 && counts) counts[bo] = (float)cnt;
+}
+
+// adjoint: dnewt[b,t,:Hd] = valid ? dpooled[b,s(t)]/count[s(t)] : 0 ; dnewt[b,t,Hd+Dp:] likewise for o(t); the predicate slice
+// dnewt[b,t,Hd:Hd+Dp] receives dp_in (gradient of the returned new_p vectors) or 0.
+__global__ __launch_bounds__(256) void triple_pool_bwd_kernel(const float* __restrict__ dpooled, const float* __restrict__ dp_in,
+                                                              const long long* __restrict__ edges,
+                                                              const unsigned char* __restrict__ valid, const float* __restrict__ counts,
+                                                              float* __restrict__ dnewt, int O, int T, int Hd, int Dp) {
+    const int bt = blockIdx.x;
+    const int b = bt / T;
+    const int Dt = 2 * Hd + Dp;
+    const int s = (int)edges[(size_t)bt * 2], o = (int)edges[(size_t)bt * 2 + 1];
+    const bool v = valid[bt] != 0;
+    const float cs = counts[(size_t)b * O + s], co = counts[(size_t)b * O + o];
+    const float is = (v && cs > 0.f) ? 1.0f / cs : 0.f, io = (v && co > 0.f) ? 1.0f / co : 0.f;
+    const float* ds = dpooled + ((size_t)b * O + s) * Hd;
+    const float* dov = dpooled + ((size_t)b * O + o) * Hd;
+    float* dst = dnewt + (size_t)bt * Dt;
+    for (int i = threadIdx.x; i < Dt; i += 256) {
+        float g;
+        if (i < Hd) g = v ? ds[i] * is : 0.f;
+        else if (i < Hd + Dp) g = dp_in ? dp_in[(size_t)bt * Dp + (i - Hd)] : 0.f;
+        else g = v ? dov[i - Hd - Dp] * io : 0.f;
+        dst[i] = g;
+    }
+}
+
+// ---------------------------------------------------------------- small dense GEMM on v_mfma_f32_32x32x2_f32
+// C[M,N] = act( A * B + bias ),  A[m,k] = a[m*sam + k*sak],  B[k,n] = b[k*sbk + n*sbn],  C row-major (ldc).
+// 64x64 tile per 256-thread workgroup (4 waves, one 32x32 MFMA tile each), BK = 16.
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                       const float* __restrict__ bias, float* __restrict__ c, int M, int N, int K,
+                                                       long long sam, long long sak, long long sbk, long long sbn, int ldc, int relu,
+                                                       int accumulate) {
+    constexpr int BK = 16, LD = 64 + 4;
+    __shared__ float As[BK][LD];
+    __shared__ float Bs[BK][LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // each thread stages 4 A and 4 B elements: row (tid & 63), k = (tid >> 6) + 4*i
+    const int row = tid & 63, kq = tid >> 6;
+    for (int k0 = 0; k0 < K; k0 += BK) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kk = kq + 4 * i, kg = k0 + kk;
+            const int m = m0 + row, n = n0 + row;
+            As[kk][row] = (m < M && kg < K) ? a[(long long)m * sam + (long long)kg * sak] : 0.f;
+            Bs[kk][row] = (n < N && kg < K) ? b[(long long)kg * sbk + (long long)n * sbn] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            const int kk = 2 * s + (lane >> 5);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[kk][wm0 + (lane & 31)], Bs[kk][wn0 + (lane & 31)], acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int n = n0 + wn0 + (lane & 31);
+    if (n < N) {
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m < M) {
+                float v = acc[r] + bv;
+                float* dst = c + (size_t)m * ldc + n;
+                if (accumulate) v += *dst;
+                if (relu) v = fmaxf(v, 0.f);
+                *dst = v;
+            }
+        }
+    }
+}
+
+// g = dy * (y > 0)   (ReLU backward), and column sums for bias gradients
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ g,
+                                                       long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) g[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+__global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int M, int N) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) s += x[(size_t)m * N + n];
+    out[n] = s;
+}
+
+// ---------------------------------------------------------------- embedding
+__global__ __launch_bounds__(256) void embedding_fwd_kernel(const long long* __restrict__ idx, const float* __restrict__ table,
+                                                            float* __restrict__ out, int D, int out_stride, int out_off) {
+    const long long r = idx[blockIdx.x];
+    for (int i = threadIdx.x; i < D; i += 256) out[(size_t)blockIdx.x * out_stride + out_off + i] = table[(size_t)r * D + i];
+}
+// dtable[v,:] = sum_{i: idx[i]=v} dout[i,:]  -- one workgroup per vocabulary row (tables have <= a few dozen rows)
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const long long* __restrict__ idx, const float* __restrict__ dout,
+                                                            float* __restrict__ dtable, int n, int D, int in_stride, int in_off) {
+    const long long v = blockIdx.x;
+    for (int i = threadIdx.x; i < D; i += 256) {
+        float acc = 0.f;
+        for (int r = 0; r < n; ++r)
+            if (idx[r] == v) acc += dout[(size_t)r * in_stride + in_off + i];
+        dtable[(size_t)v * D + i] = acc;
+    }
+}
+
+// ================================================================ C ABI
+extern "C" int ag2v_triple_gather_fwd(const float* obj, const float* pred, const long long* edges, float* out, int B, int O, int T,
+                                      int Din, int Dp, void* stream) {
+    if (!obj || !pred || !edges || !out || B <= 0 || O <= 0 || T <= 0 || Din <= 0 || Dp <= 0) return AG2V_EINVAL;
+    hipLaunchKernelGGL(triple_gather_fwd_kernel, dim3(B * T), dim3(256), 0, (hipStream_t)stream, obj, pred, edges, out, O, T, Din, Dp);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+extern "C" int ag2v_triple_gather_bwd(const float* dtri, const long long* edges, float* dobj, float* dpred, int B, int O, int T,
+                                      int Din, int Dp, void* stream) {
+    if (!dtri || !edges || !dobj || B <= 0 || O <= 0 || T <= 0 || Din <= 0 || Dp <= 0) return AG2V_EINVAL;
+    hipLaunchKernelGGL(triple_gather_bwd_kernel, dim3(B * O), dim3(256), 0, (hipStream_t)stream, dtri, edges, dobj, dpred, O, T, Din, Dp);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+extern "C" int ag2v_triple_pool_fwd(const float* newt, const long long* edges, const unsigned char* valid, float* pooled, float* counts,
+                                    int B, int O, int T, int Hd, int Dp, void* stream) {
+    if (!newt || !edges || !valid || !pooled || !counts || B <= 0 || O <= 0 || T <= 0 || Hd <= 0 || Dp < 0) return AG2V_EINVAL;
+    hipLaunchKernelGGL(triple_pool_fwd_kernel, dim3(B * O), dim3(256), 0, (hipStream_t)stream, newt, edges, valid, pooled, counts, O, T, Hd, Dp);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+extern "C" int ag2v_triple_pool_bwd(const float* dpooled, const float* dp_in, const long long* edges, const unsigned char* valid,
+                                    const float* counts, float* dnewt, int B, int O, int T, int Hd, int Dp, void* stream) {
+    if (!dpooled || !edges || !valid || !counts || !dnewt || B <= 0 || O <= 0 || T <= 0 || Hd <= 0 || Dp < 0) return AG2V_EINVAL;
+    hipLaunchKernelGGL(triple_pool_bwd_kernel, dim3(B * T), dim3(256), 0, (hipStream_t)stream, dpooled, dp_in, edges, valid, counts, dnewt, O, T, Hd, Dp);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+
+// Generic strided GEMM (see gemm_f32_kernel).  The three uses of a Linear layer y = x W^T + b (x[M,K], W[N,K]):
+//   forward   C=y [M,N]:  A=x (sam=K,sak=1),  B=W^T (sbk=1,sbn=K), bias, relu
+//   dgrad     C=dx[M,K]:  A=g (sam=N,sak=1),  B=W   (sbk=K,sbn=1)
+//   wgrad     C=dW[N,K]:  A=g^T (sam=1,sak=N), B=x  (sbk=K,sbn=1)
+extern "C" int ag2v_gemm_f32(const float* a, const float* b, const float* bias, float* c, int M, int N, int K, long long sam,
+                             long long sak, long long sbk, long long sbn, int ldc, int relu, int accumulate, void* stream) {
+    if (!a || !b || !c || M <= 0 || N <= 0 || K <= 0 || ldc < N) return AG2V_EINVAL;
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3(ceil_div(N, 64), ceil_div(M, 64)), dim3(256), 0, (hipStream_t)stream, a, b, bias, c, M,
+                       N, K, sam, sak, sbk, sbn, ldc, relu, accumulate);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+extern "C" int ag2v_relu_bwd(const float* dy, const float* y, float* g, long long n, void* stream) {
+    if (!dy || !y || !g || n <= 0) return AG2V_EINVAL;
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, y, g, n);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+extern "C" int ag2v_col_sum(const float* x, float* out, int M, int N, void* stream) {
+    if (!x || !out || M <= 0 || N <= 0) return AG2V_EINVAL;
+    hipLaunchKernelGGL(col_sum_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream, x, out, M, N);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+extern "C" int ag2v_embedding_fwd(const long long* idx, const float* table, float* out, int n, int D, int out_stride, int out_off,
+                                  void* stream) {
+    if (!idx || !table || !out || n <= 0 || D <= 0) return AG2V_EINVAL;
+    hipLaunchKernelGGL(embedding_fwd_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, idx, table, out, D, out_stride, out_off);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+extern "C" int ag2v_embedding_bwd(const long long* idx, const float* dout, float* dtable, int n, int V, int D, int in_stride,
+                                  int in_off, void* stream) {
+    if (!idx || !dout || !dtable || n <= 0 || V <= 0 || D <= 0) return AG2V_EINVAL;
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(V), dim3(256), 0, (hipStream_t)stream, idx, dout, dtable, n, D, in_stride, in_off);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}

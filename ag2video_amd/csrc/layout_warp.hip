@@ -1,0 +1,362 @@
+// Layout render (box splat), optical-flow warp and the small resampling kernels of the AG2Video hot path.
+//
+//  * layout render: closed form of boxes_to_layout (models/layout.py:28-63,98-130,205-237): every object's D-vector is
+//    painted into its box by bilinear sampling of a constant 8x8 image (align_corners=True, zero padding) and objects are
+//    summed:  out[d,y,x] = sum_o v[o,d] * tau(7 (X_x - x0_o)/w_o) * tau(7 (Y_y - y0_o)/h_o),  tau(i) = clamp(min(i+1, 8-i), 0, 1).
+//    The reference materialises [n_obj, D, H, W]; here one pass writes [D, H, W] once (write-bandwidth bound) and the
+//    backward reads only each object's support rectangle.
+//  * flow warp: resample/get_grid (models/utils.py:113-140): grid_sample(bilinear, border, align_corners=False).
+//  * avg_pool2d(3, s2, p1, count_include_pad=False) (discriminator.py:270-271), nearest x2 upsample
+//    (spade_generator.py:36,55-70; flows_generator.py:47), nearest resize of the segmap (normalization.py:102).
+#include "common.h"
+
+#define MAXO 16
+
+__device__ __forceinline__ float lin01(int i, int steps) {
+    // torch.linspace(0, 1, steps)[i]: symmetric evaluation (start + i*step | end - (steps-1-i)*step)
+    if (steps == 1) return 0.f;
+    const float step = 1.0f / (float)(steps - 1);
+    return (i < steps / 2) ? step * (float)i : 1.0f - step * (float)(steps - 1 - i);
+}
+__device__ __forceinline__ float tau8(float pos, float lo, float extent) {
+    // grid = ((P - lo)/extent)*2 - 1 ; sample position in the 8-px image (align_corners=True): ((g+1)/2)*7
+    const float g = ((pos - lo) / extent) * 2.0f - 1.0f;
+    const float i = ((g + 1.0f) * 0.5f) * 7.0f;
+    return fminf(fmaxf(fminf(i + 1.0f, 8.0f - i), 0.0f), 1.0f);
+}
+
+// grid: (ceil(H/4), BT, DSPLIT); 4 waves, wave w renders row y = 4*blockIdx.x + w for the block's channel range.
+__global__ __launch_bounds__(256) void layout_render_fwd_kernel(const float* __restrict__ vecs, const float* __restrict__ boxes,
+                                                                const int* __restrict__ keep, float* __restrict__ out, int O,
+                                                                int D, int H, int W, int dper) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int y = blockIdx.x * 4 + wave;
+    const int bt = blockIdx.y;
+    const int d0 = blockIdx.z * dper, d1 = min(D, d0 + dper);
+    if (y >= H) return;
+    const float Y = lin01(y, H);
+    float tyv[MAXO];
+    float bx0[MAXO], bw[MAXO];
+#pragma unroll
+    for (int o = 0; o < MAXO; ++o) {
+        tyv[o] = 0.f; bx0[o] = 0.f; bw[o] = 1.f;
+        if (o < O) {
+            const float* b = boxes + ((size_t)bt * O + o) * 4;
+            const float x0 = b[0], y0 = b[1], ww = b[2], hh = b[3];
+            const bool legal = (x0 != 0.f) || (y0 != 0.f) || (ww != 0.f) || (hh != 0.f);
+            if (legal && keep[(size_t)bt * O + o] != 0) {
+                tyv[o] = tau8(Y, y0, hh);
+                bx0[o] = x0; bw[o] = ww;
+            }
+        }
+    }
+    const int W4 = W >> 2;
+    for (int xq = lane; xq < W4; xq += 64) {
+        float tx[MAXO][4];
+#pragma unroll
+        for (int o = 0; o < MAXO; ++o)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tx[o][j] = (tyv[o] != 0.f) ? tau8(lin01(xq * 4 + j, W), bx0[o], bw[o]) * tyv[o] : 0.f;
+        for (int d = d0; d < d1; ++d) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+            for (int o = 0; o < MAXO; ++o) {
+                if (tyv[o] != 0.f) {  // wave-uniform
+                    const float v = vecs[((size_t)bt * O + o) * D + d];
+                    a0 += v * tx[o][0]; a1 += v * tx[o][1]; a2 += v * tx[o][2]; a3 += v * tx[o][3];
+                }
+            }
+            *reinterpret_cast<float4*>(out + (((size_t)bt * D + d) * H + y) * W + xq * 4) = make_float4(a0, a1, a2, a3);
+        }
+    }
+}
+
+// grid: (O, BT, ceil(D/32)); wave w reduces channels d = 32*blockIdx.z + w + 4*i over the object's support rectangle.
+__global__ __launch_bounds__(256) void layout_render_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ boxes,
+                                                                const int* __restrict__ keep, float* __restrict__ dvecs, int O,
+                                                                int D, int H, int W) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int o = blockIdx.x, bt = blockIdx.y;
+    const float* b = boxes + ((size_t)bt * O + o) * 4;
+    const float x0 = b[0], y0 = b[1], ww = b[2], hh = b[3];
+    const bool legal = (x0 != 0.f) || (y0 != 0.f) || (ww != 0.f) || (hh != 0.f);
+    const bool active = legal && keep[(size_t)bt * O + o] != 0;
+    for (int i = 0; i < 8; ++i) {
+        const int d = blockIdx.z * 32 + wave + 4 * i;
+        if (d >= D) break;
+        float acc = 0.f;
+        if (active) {
+            for (int xb = 0; xb < W; xb += 64) {
+                const int x = xb + lane;
+                const float txv = (x < W) ? tau8(lin01(x, W), x0, ww) : 0.f;
+                if (__ballot(txv != 0.f) == 0ull) continue;  // wave-uniform skip of empty column blocks
+                const float* dp = dout + ((size_t)bt * D + d) * H * W + x;
+                for (int y = 0; y < H; ++y) {
+                    const float tyv = tau8(lin01(y, H), y0, hh);  // wave-uniform
+                    if (tyv != 0.f && txv != 0.f) acc += dp[(size_t)y * W] * (txv * tyv);
+                }
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) dvecs[((size_t)bt * O + o) * D + d] = acc;
+    }
+}
+
+// ---------------------------------------------------------------- flow warp
+struct WarpTap { int x0, y0, x1, y1; float fx, fy, mx, my; };
+__device__ __forceinline__ WarpTap warp_tap(float fxv, float fyv, int x, int y, int H, int W) {
+    // get_grid: linspace(-1,1); flow normalised by (W-1)/2, (H-1)/2; unnormalise with align_corners=False; border clip
+    auto lin11 = [](int i, int steps) -> float {
+        if (steps == 1) return -1.f;
+        const float step = 2.0f / (float)(steps - 1);
+        return (i < steps / 2) ? -1.0f + step * (float)i : 1.0f - step * (float)(steps - 1 - i);
+    };
+    const float gx = lin11(x, W) + fxv / (((float)W - 1.0f) / 2.0f);
+    const float gy = lin11(y, H) + fyv / (((float)H - 1.0f) / 2.0f);
+    float ix = ((gx + 1.0f) * (float)W - 1.0f) / 2.0f;
+    float iy = ((gy + 1.0f) * (float)H - 1.0f) / 2.0f;
+    WarpTap t;
+    t.mx = 1.f; t.my = 1.f;
+    if (ix <= 0.f) { ix = 0.f; t.mx = 0.f; } else if (ix >= (float)(W - 1)) { ix = (float)(W - 1); t.mx = 0.f; }
+    if (iy <= 0.f) { iy = 0.f; t.my = 0.f; } else if (iy >= (float)(H - 1)) { iy = (float)(H - 1); t.my = 0.f; }
+    const float flx = floorf(ix), fly = floorf(iy);
+    t.x0 = (int)flx; t.y0 = (int)fly; t.x1 = t.x0 + 1; t.y1 = t.y0 + 1;
+    t.fx = ix - flx; t.fy = iy - fly;
+    return t;
+}
+
+__global__ __launch_bounds__(256) void flow_warp_fwd_kernel(const float* __restrict__ img, const float* __restrict__ flow,
+                                                            float* __restrict__ out, int N, int C, int H, int W) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)N * H * W;
+    if (idx >= total) return;
+    const int HW = H * W;
+    const int n = (int)(idx / HW);
+    const int p = (int)(idx - (long long)n * HW);
+    const int y = p / W, x = p - y * W;
+    const float* fl = flow + (size_t)n * 2 * HW;
+    const WarpTap t = warp_tap(fl[p], fl[HW + p], x, y, H, W);
+    const bool x1ok = t.x1 < W, y1ok = t.y1 < H;
+    const float wnw = (1.f - t.fx) * (1.f - t.fy), wne = t.fx * (1.f - t.fy), wsw = (1.f - t.fx) * t.fy, wse = t.fx * t.fy;
+    for (int c = 0; c < C; ++c) {
+        const float* ip = img + ((size_t)n * C + c) * HW;
+        float v = ip[t.y0 * W + t.x0] * wnw;
+        if (x1ok) v += ip[t.y0 * W + t.x1] * wne;
+        if (y1ok) v += ip[t.y1 * W + t.x0] * wsw;
+        if (x1ok && y1ok) v += ip[t.y1 * W + t.x1] * wse;
+        out[((size_t)n * C + c) * HW + p] = v;
+    }
+}
+
+// dflow always; dimg (pre-zeroed, atomics) when non-null
+__global__ __launch_bounds__(256) void flow_warp_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ img,
+                                                            const float* __restrict__ flow, float* __restrict__ dflow,
+                                                            float* __restrict__ dimg, int N, int C, int H, int W) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)N * H * W;
+    if (idx >= total) return;
+    const int HW = H * W;
+    const int n = (int)(idx / HW);
+    const int p = (int)(idx - (long long)n * HW);
+    const int y = p / W, x = p - y * W;
+    const float* fl = flow + (size_t)n * 2 * HW;
+    const WarpTap t = warp_tap(fl[p], fl[HW + p], x, y, H, W);
+    const bool x1ok = t.x1 < W, y1ok = t.y1 < H;
+    const float wnw = (1.f - t.fx) * (1.f - t.fy), wne = t.fx * (1.f - t.fy), wsw = (1.f - t.fx) * t.fy, wse = t.fx * t.fy;
+    float gix = 0.f, giy = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const size_t pl = ((size_t)n * C + c) * HW;
+        const float g = dout[pl + p];
+        const float* ip = img + pl;
+        const float vnw = ip[t.y0 * W + t.x0];
+        const float vne = x1ok ? ip[t.y0 * W + t.x1] : 0.f;
+        const float vsw = y1ok ? ip[t.y1 * W + t.x0] : 0.f;
+        const float vse = (x1ok && y1ok) ? ip[t.y1 * W + t.x1] : 0.f;
+        gix += g * ((vne - vnw) * (1.f - t.fy) + (vse - vsw) * t.fy);
+        giy += g * ((vsw - vnw) * (1.f - t.fx) + (vse - vne) * t.fx);
+        if (dimg) {
+            float* dp = dimg + pl;
+            atomicAdd(dp + t.y0 * W + t.x0, g * wnw);
+            if (x1ok) atomicAdd(dp + t.y0 * W + t.x1, g * wne);
+            if (y1ok) atomicAdd(dp + t.y1 * W + t.x0, g * wsw);
+            if (x1ok && y1ok) atomicAdd(dp + t.y1 * W + t.x1, g * wse);
+        }
+    }
+    // d(ix)/d(flow_x) = (W/2) * clip' / ((W-1)/2)
+    float* df = dflow + (size_t)n * 2 * HW;
+    df[p] = gix * t.mx * ((float)W * 0.5f) / (((float)W - 1.0f) / 2.0f);
+    df[HW + p] = giy * t.my * ((float)H * 0.5f) / (((float)H - 1.0f) / 2.0f);
+}
+
+// ---------------------------------------------------------------- avg_pool2d(3, stride 2, pad 1, count_include_pad=False)
+__global__ __launch_bounds__(256) void avgpool3s2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long total,
+                                                             int H, int W, int OH, int OW) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int ox = (int)(idx % OW);
+    const long long r = idx / OW;
+    const int oy = (int)(r % OH);
+    const long long nc = r / OH;
+    const float* xp = x + (size_t)nc * H * W;
+    float s = 0.f;
+    int cnt = 0;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int iy = 2 * oy - 1 + dy;
+        if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int ix = 2 * ox - 1 + dx;
+            if ((unsigned)ix >= (unsigned)W) continue;
+            s += xp[iy * W + ix];
+            ++cnt;
+        }
+    }
+    y[idx] = s / (float)cnt;
+}
+
+__device__ __forceinline__ int pool_cnt(int o, int L) {  // valid taps of window o along a length-L axis
+    int c = 0;
+    for (int d = 0; d < 3; ++d) { const int i = 2 * o - 1 + d; c += ((unsigned)i < (unsigned)L) ? 1 : 0; }
+    return c;
+}
+__global__ __launch_bounds__(256) void avgpool3s2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, long long total,
+                                                             int H, int W, int OH, int OW) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int ix = (int)(idx % W);
+    const long long r = idx / W;
+    const int iy = (int)(r % H);
+    const long long nc = r / H;
+    const float* dp = dy + (size_t)nc * OH * OW;
+    float s = 0.f;
+    // windows oy with 2*oy-1 <= iy <= 2*oy+1
+    for (int oy = iy / 2; oy <= (iy + 1) / 2; ++oy) {
+        if (oy >= OH) continue;
+        const int cy = pool_cnt(oy, H);
+        for (int ox = ix / 2; ox <= (ix + 1) / 2; ++ox) {
+            if (ox >= OW) continue;
+            s += dp[oy * OW + ox] / (float)(cy * pool_cnt(ox, W));
+        }
+    }
+    dx[idx] = s;
+}
+
+// ---------------------------------------------------------------- nearest resize (gather) and its adjoint
+__device__ __forceinline__ int nearest_src(int o, int in, int out) {
+    if (in == out) return o;
+    if (out == 2 * in) return o >> 1;
+    const float scale = (float)in / (float)out;
+    const int s = (int)floorf((float)o * scale);
+    return s < in - 1 ? s : in - 1;
+}
+__global__ __launch_bounds__(256) void nearest_resize_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long total,
+                                                                 int H, int W, int OH, int OW) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int ox = (int)(idx % OW);
+    const long long r = idx / OW;
+    const int oy = (int)(r % OH);
+    const long long nc = r / OH;
+    y[idx] = x[(size_t)nc * H * W + (size_t)nearest_src(oy, H, OH) * W + nearest_src(ox, W, OW)];
+}
+// adjoint: dx[iy,ix] = sum of dy over all outputs that read (iy,ix).  One thread per INPUT element; the candidate outputs
+// are found by scanning the (small) preimage range, so no atomics and no memset are needed.
+__global__ __launch_bounds__(256) void nearest_resize_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, long long total,
+                                                                 int H, int W, int OH, int OW) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int ix = (int)(idx % W);
+    const long long r = idx / W;
+    const int iy = (int)(r % H);
+    const long long nc = r / H;
+    const float* dp = dy + (size_t)nc * OH * OW;
+    // outputs o with nearest_src(o) == i lie in [i*out/in - 1, (i+1)*out/in + 1]
+    const int oy_lo = max(0, (int)((long long)iy * OH / H) - 1), oy_hi = min(OH - 1, (int)((long long)(iy + 1) * OH / H) + 1);
+    const int ox_lo = max(0, (int)((long long)ix * OW / W) - 1), ox_hi = min(OW - 1, (int)((long long)(ix + 1) * OW / W) + 1);
+    float s = 0.f;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+        if (nearest_src(oy, H, OH) != iy) continue;
+        for (int ox = ox_lo; ox <= ox_hi; ++ox)
+            if (nearest_src(ox, W, OW) == ix) s += dp[oy * OW + ox];
+    }
+    dx[idx] = s;
+}
+
+// ================================================================ C ABI
+extern "C" int ag2v_layout_render_fwd(const float* vecs, const float* boxes, const int* keep, float* out, int BT, int O, int D,
+                                      int H, int W, void* stream) {
+    if (!vecs || !boxes || !keep || !out || BT <= 0 || O <= 0 || O > MAXO || D <= 0 || H <= 0 || W <= 0 || (W & 3)) return AG2V_EINVAL;
+    if (BT > 65535) return AG2V_EINVAL;
+    int dsplit = 1;
+    const int rows = ceil_div(H, 4);
+    while ((long long)rows * BT * dsplit < 2048 && dsplit < 16 && D / (dsplit * 2) >= 8) dsplit *= 2;
+    const int dper = ceil_div(D, dsplit);
+    hipLaunchKernelGGL(layout_render_fwd_kernel, dim3(rows, BT, dsplit), dim3(256), 0, (hipStream_t)stream, vecs, boxes, keep, out,
+                       O, D, H, W, dper);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+
+extern "C" int ag2v_layout_render_bwd(const float* dout, const float* boxes, const int* keep, float* dvecs, int BT, int O, int D,
+                                      int H, int W, void* stream) {
+    if (!dout || !boxes || !keep || !dvecs || BT <= 0 || O <= 0 || O > MAXO || D <= 0 || H <= 0 || W <= 0) return AG2V_EINVAL;
+    if (BT > 65535) return AG2V_EINVAL;
+    hipLaunchKernelGGL(layout_render_bwd_kernel, dim3(O, BT, ceil_div(D, 32)), dim3(256), 0, (hipStream_t)stream, dout, boxes,
+                       keep, dvecs, O, D, H, W);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+
+extern "C" int ag2v_flow_warp_fwd(const float* img, const float* flow, float* out, int N, int C, int H, int W, void* stream) {
+    if (!img || !flow || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0) return AG2V_EINVAL;
+    const long long total = (long long)N * H * W;
+    hipLaunchKernelGGL(flow_warp_fwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, img, flow, out, N, C, H, W);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+
+extern "C" int ag2v_flow_warp_bwd(const float* dout, const float* img, const float* flow, float* dflow, float* dimg, int N, int C,
+                                  int H, int W, void* stream) {
+    if (!dout || !img || !flow || !dflow || N <= 0 || C <= 0 || H <= 0 || W <= 0) return AG2V_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dimg && hipMemsetAsync(dimg, 0, (size_t)N * C * H * W * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
+    const long long total = (long long)N * H * W;
+    hipLaunchKernelGGL(flow_warp_bwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, dout, img, flow, dflow, dimg, N, C, H, W);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+
+extern "C" int ag2v_avgpool3s2_fwd(const float* x, float* y, int NC, int H, int W, void* stream) {
+    if (!x || !y || NC <= 0 || H <= 0 || W <= 0) return AG2V_EINVAL;
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    const long long total = (long long)NC * OH * OW;
+    hipLaunchKernelGGL(avgpool3s2_fwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, total, H, W, OH, OW);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+
+extern "C" int ag2v_avgpool3s2_bwd(const float* dy, float* dx, int NC, int H, int W, void* stream) {
+    if (!dy || !dx || NC <= 0 || H <= 0 || W <= 0) return AG2V_EINVAL;
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    const long long total = (long long)NC * H * W;
+    hipLaunchKernelGGL(avgpool3s2_bwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, total, H, W, OH, OW);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+
+extern "C" int ag2v_nearest_resize_fwd(const float* x, float* y, int NC, int H, int W, int OH, int OW, void* stream) {
+    if (!x || !y || NC <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return AG2V_EINVAL;
+    const long long total = (long long)NC * OH * OW;
+    hipLaunchKernelGGL(nearest_resize_fwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, total, H, W, OH, OW);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+
+extern "C" int ag2v_nearest_resize_bwd(const float* dy, float* dx, int NC, int H, int W, int OH, int OW, void* stream) {
+    if (!dy || !dx || NC <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return AG2V_EINVAL;
+    const long long total = (long long)NC * H * W;
+    hipLaunchKernelGGL(nearest_resize_bwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, total, H, W, OH, OW);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}

@@ -1,0 +1,414 @@
+// Normalisation kernels of the AG2Video hot path (HBM-bound):
+//   * batch statistics (per channel over N,H,W) with a robust two-pass-in-registers + Chan combine
+//       reference: F.batch_norm fallback of _SynchronizedBatchNorm (sync_batchnorm/batchnorm.py:63-68)
+//   * fused  BN(affine) -> LeakyReLU            (flow net / conv_dim_in: normalization.py:39-46, generator.py:26-33)
+//   * fused  SPADE: BN(no affine) * (1+gamma) + beta [-> LeakyReLU]   (normalization.py:96-110, architecture.py:53-68)
+//   * InstanceNorm2d(affine=False) -> LeakyReLU (discriminator.py:374 via normalization.py:43-44)
+//   and their backward passes, plus the per-channel sum used for conv bias gradients.
+// All tensors NCHW fp32 contiguous.  One workgroup owns one <=4096-element chunk of one (n,c) plane, so the
+// per-channel parameters are scalars and every access is a coalesced float4 (or dword when H*W % 4 != 0).
+#include "common.h"
+
+#define CHUNK 4096  // elements per workgroup (16 per thread)
+
+__device__ __forceinline__ float lrelu_f(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+// load up to 16 elements/thread of plane chunk [start, start+cnt) into v[], returns #valid via mask bits
+template <bool VEC>
+__device__ __forceinline__ void load16(const float* __restrict__ p, int cnt, float (&v)[16], unsigned& mask) {
+    mask = 0;
+    if (VEC) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = (i * 256 + threadIdx.x) * 4;
+            if (e < cnt) {
+                const float4 t = *reinterpret_cast<const float4*>(p + e);
+                v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
+                mask |= 0xFu << (4 * i);
+            } else {
+                v[4 * i] = v[4 * i + 1] = v[4 * i + 2] = v[4 * i + 3] = 0.f;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int e = i * 256 + threadIdx.x;
+            if (e < cnt) { v[i] = p[e]; mask |= 1u << i; } else v[i] = 0.f;
+        }
+    }
+}
+template <bool VEC>
+__device__ __forceinline__ void store16(float* __restrict__ p, int cnt, const float (&v)[16]) {
+    if (VEC) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = (i * 256 + threadIdx.x) * 4;
+            if (e < cnt) *reinterpret_cast<float4*>(p + e) = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int e = i * 256 + threadIdx.x;
+            if (e < cnt) p[e] = v[i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------- batch statistics
+// partial[(c*nparts + part)*3 + {0,1,2}] = {count, mean, M2}
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
+                                                               int N, int C, int HW, int nchunk) {
+    __shared__ float sh[4];
+    const int bid = blockIdx.x;
+    const int chunk = bid % nchunk, nc = bid / nchunk;
+    const int n = nc / C, c = nc - n * C;
+    const int start = chunk * CHUNK;
+    const int cnt = min(CHUNK, HW - start);
+    float v[16];
+    unsigned mask;
+    load16<VEC>(x + (size_t)nc * HW + start, cnt, v, mask);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += v[i];
+    s = block_sum_256(s, sh);
+    const float mean = s / (float)cnt;
+    float m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float d = v[i] - mean;
+        m2 += ((mask >> i) & 1u) ? d * d : 0.f;
+    }
+    m2 = block_sum_256(m2, sh);
+    if (threadIdx.x == 0) {
+        const int nparts = N * nchunk;
+        float* o = partial + ((size_t)c * nparts + (size_t)n * nchunk + chunk) * 3;
+        o[0] = (float)cnt; o[1] = mean; o[2] = m2;
+    }
+}
+
+// One thread per channel: Chan's parallel combine in double; writes mean / invstd (biased var, +eps) and updates the
+// running statistics exactly as F.batch_norm(training=True, momentum) does (unbiased var in the running buffer).
+__global__ void bn_stats_finalize_kernel(const float* __restrict__ partial, int C, int nparts, float eps, float momentum,
+                                         float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                         float* __restrict__ running_mean, float* __restrict__ running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float* p = partial + (size_t)c * nparts * 3;
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    for (int i = 0; i < nparts; ++i) {
+        const double nb = p[3 * i], mb = p[3 * i + 1], m2b = p[3 * i + 2];
+        const double nt = n + nb;
+        const double d = mb - mean;
+        mean += d * (nb / nt);
+        m2 += m2b + d * d * (n * nb / nt);
+        n = nt;
+    }
+    const double var = m2 / n;
+    mean_out[c] = (float)mean;
+    invstd_out[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unb = (n > 1.0) ? m2 / (n - 1.0) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+    }
+}
+
+// ---------------------------------------------------------------- fused normalise (+affine | +SPADE) (+LeakyReLU)
+// MODE 0: y = lrelu((x-mean)*invstd*w[c] + b[c]);  MODE 1: y = lrelu((x-mean)*invstd*(1+gamma) + beta)
+template <int MODE, bool VEC>
+__global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd, const float* __restrict__ w,
+                                                         const float* __restrict__ b, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ y, int C,
+                                                         int HW, int nchunk, float slope) {
+    const int bid = blockIdx.x;
+    const int chunk = bid % nchunk, nc = bid / nchunk;
+    const int c = nc % C;
+    const int start = chunk * CHUNK;
+    const int cnt = min(CHUNK, HW - start);
+    const size_t off = (size_t)nc * HW + start;
+    const float mu = mean[c], is = invstd[c];
+    float v[16], g[16], be[16];
+    unsigned mask;
+    load16<VEC>(x + off, cnt, v, mask);
+    if (MODE == 1) {
+        load16<VEC>(gamma + off, cnt, g, mask);
+        load16<VEC>(beta + off, cnt, be, mask);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = lrelu_f((v[i] - mu) * is * (1.f + g[i]) + be[i], slope);
+    } else {
+        const float sc = is * (w ? w[c] : 1.f), sh = b ? b[c] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = lrelu_f((v[i] - mu) * sc + sh, slope);
+    }
+    store16<VEC>(y + off, cnt, v);
+}
+
+// backward pass 1: per (c, part) partial sums  s1 = sum dxhat, s2 = sum dxhat * xhat
+//   MODE 0: dxhat = g (weight applied in pass 2);  MODE 1: dxhat = g * (1 + gamma);   g = dy * lrelu'(y)
+template <int MODE, bool VEC>
+__global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                              const float* __restrict__ x, const float* __restrict__ gamma,
+                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                              float* __restrict__ partial, int N, int C, int HW, int nchunk,
+                                                              float slope) {
+    __shared__ float sh[4];
+    const int bid = blockIdx.x;
+    const int chunk = bid % nchunk, nc = bid / nchunk;
+    const int n = nc / C, c = nc - n * C;
+    const int start = chunk * CHUNK;
+    const int cnt = min(CHUNK, HW - start);
+    const size_t off = (size_t)nc * HW + start;
+    const float mu = mean[c], is = invstd[c];
+    float g[16], xv[16], t[16];
+    unsigned mask;
+    load16<VEC>(dy + off, cnt, g, mask);
+    if (slope != 1.f) {
+        load16<VEC>(y + off, cnt, t, mask);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) g[i] = t[i] > 0.f ? g[i] : g[i] * slope;
+    }
+    load16<VEC>(x + off, cnt, xv, mask);
+    if (MODE == 1) {
+        load16<VEC>(gamma + off, cnt, t, mask);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) g[i] *= (1.f + t[i]);
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        s1 += g[i];  // invalid lanes hold g == 0
+        s2 += g[i] * ((xv[i] - mu) * is);
+    }
+    s1 = block_sum_256(s1, sh);
+    s2 = block_sum_256(s2, sh);
+    if (threadIdx.x == 0) {
+        const int nparts = N * nchunk;
+        float* o = partial + ((size_t)c * nparts + (size_t)n * nchunk + chunk) * 2;
+        o[0] = s1; o[1] = s2;
+    }
+}
+
+// sums[c*2+{0,1}] = sum over parts (double accumulate)
+__global__ void pair_sum_finalize_kernel(const float* __restrict__ partial, int C, int nparts, float* __restrict__ sums) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float* p = partial + (size_t)c * nparts * 2;
+    double a = 0.0, b = 0.0;
+    for (int i = 0; i < nparts; ++i) { a += p[2 * i]; b += p[2 * i + 1]; }
+    sums[2 * c] = (float)a;
+    sums[2 * c + 1] = (float)b;
+}
+
+// backward pass 2.
+//   MODE 0: dx = w*invstd*(g - s1/n - xhat*s2/n)                    (dw = s2, db = s1 are read from sums by the host)
+//   MODE 1: dgamma = g*xhat, dbeta = g, dx = invstd*(g(1+gamma) - s1/n - xhat*s2/n)
+template <int MODE, bool VEC>
+__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                             const float* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ w, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, const float* __restrict__ sums,
+                                                             float* __restrict__ dx, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, int C, int HW, int nchunk,
+                                                             float inv_count, float slope) {
+    const int bid = blockIdx.x;
+    const int chunk = bid % nchunk, nc = bid / nchunk;
+    const int c = nc % C;
+    const int start = chunk * CHUNK;
+    const int cnt = min(CHUNK, HW - start);
+    const size_t off = (size_t)nc * HW + start;
+    const float mu = mean[c], is = invstd[c];
+    const float m1 = sums[2 * c] * inv_count, m2 = sums[2 * c + 1] * inv_count;
+    float g[16], xv[16], t[16];
+    unsigned mask;
+    load16<VEC>(dy + off, cnt, g, mask);
+    if (slope != 1.f) {
+        load16<VEC>(y + off, cnt, t, mask);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) g[i] = t[i] > 0.f ? g[i] : g[i] * slope;
+    }
+    load16<VEC>(x + off, cnt, xv, mask);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) xv[i] = (xv[i] - mu) * is;  // xhat
+    if (MODE == 1) {
+        load16<VEC>(gamma + off, cnt, t, mask);
+        float dg[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dg[i] = g[i] * xv[i];
+        store16<VEC>(dgamma + off, cnt, dg);
+        store16<VEC>(dbeta + off, cnt, g);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) g[i] = is * (g[i] * (1.f + t[i]) - m1 - xv[i] * m2);
+    } else {
+        const float sc = is * (w ? w[c] : 1.f);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) g[i] = sc * (g[i] - m1 - xv[i] * m2);
+    }
+    store16<VEC>(dx + off, cnt, g);
+}
+
+// ---------------------------------------------------------------- instance norm (+LeakyReLU): one workgroup per (n,c) plane
+__global__ __launch_bounds__(256) void instnorm_lrelu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                 float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                                                 int HW, float eps, float slope) {
+    __shared__ float sh[4];
+    const size_t off = (size_t)blockIdx.x * HW;
+    const float* xp = x + off;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < HW; i += 256) s += xp[i];
+    s = block_sum_256(s, sh);
+    const float mu = s / (float)HW;
+    float m2 = 0.f;
+    for (int i = threadIdx.x; i < HW; i += 256) { const float d = xp[i] - mu; m2 += d * d; }
+    m2 = block_sum_256(m2, sh);
+    const float is = 1.0f / sqrtf(m2 / (float)HW + eps);
+    float* yp = y + off;
+    for (int i = threadIdx.x; i < HW; i += 256) yp[i] = lrelu_f((xp[i] - mu) * is, slope);
+    if (threadIdx.x == 0) { mean_out[blockIdx.x] = mu; invstd_out[blockIdx.x] = is; }
+}
+
+__global__ __launch_bounds__(256) void instnorm_lrelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                                 const float* __restrict__ x, const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd, float* __restrict__ dx,
+                                                                 int HW, float slope) {
+    __shared__ float sh[4];
+    const size_t off = (size_t)blockIdx.x * HW;
+    const float mu = mean[blockIdx.x], is = invstd[blockIdx.x];
+    const float *dyp = dy + off, *yp = y + off, *xp = x + off;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+        const float g = yp[i] > 0.f ? dyp[i] : dyp[i] * slope;
+        s1 += g;
+        s2 += g * ((xp[i] - mu) * is);
+    }
+    s1 = block_sum_256(s1, sh) / (float)HW;
+    s2 = block_sum_256(s2, sh) / (float)HW;
+    float* dxp = dx + off;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+        const float g = yp[i] > 0.f ? dyp[i] : dyp[i] * slope;
+        dxp[i] = is * (g - s1 - ((xp[i] - mu) * is) * s2);
+    }
+}
+
+// ---------------------------------------------------------------- per-channel sum over (N, H*W): conv bias gradient
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int C,
+                                                          int HW) {
+    __shared__ float sh[4];
+    const int c = blockIdx.x;
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const float* p = x + ((size_t)n * C + c) * HW;
+        for (int i = threadIdx.x; i < HW; i += 256) s += p[i];
+    }
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) out[c] = s;
+}
+
+// ================================================================ C ABI
+static inline bool vec_ok(int HW, const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr,
+                          const void* e = nullptr, const void* f = nullptr, const void* g = nullptr) {
+    auto al = [](const void* p) { return p == nullptr || (((uintptr_t)p) & 15) == 0; };
+    return (HW % 4 == 0) && al(a) && al(b) && al(c) && al(d) && al(e) && al(f) && al(g);
+}
+
+extern "C" size_t ag2v_bn_workspace_floats(int N, int C, int HW) {
+    const int nchunk = ceil_div(HW, CHUNK);
+    return (size_t)C * N * nchunk * 3 + 2 * (size_t)C;
+}
+
+// Batch statistics of x[N,C,H*W]: mean/invstd (biased variance + eps) and, when running_* are non-null,
+// the momentum update of the running buffers.  workspace: ag2v_bn_workspace_floats() floats.
+extern "C" int ag2v_bn_stats(const float* x, int N, int C, int HW, float eps, float momentum, float* mean, float* invstd,
+                             float* running_mean, float* running_var, float* workspace, void* stream) {
+    if (!x || !mean || !invstd || !workspace || N <= 0 || C <= 0 || HW <= 0) return AG2V_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int nchunk = ceil_div(HW, CHUNK);
+    const long long nblk = (long long)N * C * nchunk;
+    if (nblk >= (1LL << 31)) return AG2V_EINVAL;
+    if (vec_ok(HW, x))
+        hipLaunchKernelGGL(bn_stats_partial_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, st, x, workspace, N, C, HW, nchunk);
+    else
+        hipLaunchKernelGGL(bn_stats_partial_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, st, x, workspace, N, C, HW, nchunk);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, workspace, C, N * nchunk, eps, momentum,
+                       mean, invstd, running_mean, running_var);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+
+// mode 0: y = lrelu((x-mean)*invstd*w + b) (w/b may be null); mode 1: y = lrelu(xhat*(1+gamma)+beta). slope 1 => no activation.
+extern "C" int ag2v_norm_apply(int mode, const float* x, const float* mean, const float* invstd, const float* w, const float* b,
+                               const float* gamma, const float* beta, float* y, int N, int C, int HW, float slope, void* stream) {
+    if (!x || !mean || !invstd || !y || N <= 0 || C <= 0 || HW <= 0) return AG2V_EINVAL;
+    if (mode == 1 && (!gamma || !beta)) return AG2V_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int nchunk = ceil_div(HW, CHUNK);
+    const long long nblk = (long long)N * C * nchunk;
+    if (nblk >= (1LL << 31)) return AG2V_EINVAL;
+    const bool v = vec_ok(HW, x, y, gamma, beta);
+    dim3 g((unsigned)nblk), t(256);
+    if (mode == 0) {
+        if (v) hipLaunchKernelGGL((norm_apply_kernel<0, true>), g, t, 0, st, x, mean, invstd, w, b, gamma, beta, y, C, HW, nchunk, slope);
+        else hipLaunchKernelGGL((norm_apply_kernel<0, false>), g, t, 0, st, x, mean, invstd, w, b, gamma, beta, y, C, HW, nchunk, slope);
+    } else {
+        if (v) hipLaunchKernelGGL((norm_apply_kernel<1, true>), g, t, 0, st, x, mean, invstd, w, b, gamma, beta, y, C, HW, nchunk, slope);
+        else hipLaunchKernelGGL((norm_apply_kernel<1, false>), g, t, 0, st, x, mean, invstd, w, b, gamma, beta, y, C, HW, nchunk, slope);
+    }
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+
+// Backward of ag2v_norm_apply with batch statistics (training mode).
+//   sums[2C] receives (sum dxhat, sum dxhat*xhat) per channel: for mode 0 these are (dbias, dweight).
+//   mode 1 additionally writes dgamma/dbeta (same shape as x).  y is the forward output (activation sign); may be null if slope==1.
+extern "C" int ag2v_norm_bwd(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* w,
+                             const float* mean, const float* invstd, float* dx, float* dgamma, float* dbeta, float* sums,
+                             int N, int C, int HW, float slope, float* workspace, void* stream) {
+    if (!dy || !x || !mean || !invstd || !dx || !sums || !workspace || N <= 0 || C <= 0 || HW <= 0) return AG2V_EINVAL;
+    if (slope != 1.f && !y) return AG2V_EINVAL;
+    if (mode == 1 && (!gamma || !dgamma || !dbeta)) return AG2V_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int nchunk = ceil_div(HW, CHUNK);
+    const long long nblk = (long long)N * C * nchunk;
+    if (nblk >= (1LL << 31)) return AG2V_EINVAL;
+    const bool v = vec_ok(HW, dy, y, x, gamma, dx, dgamma, dbeta);
+    dim3 g((unsigned)nblk), t(256);
+    const float inv_count = 1.0f / ((float)N * (float)HW);
+#define LAUNCH_BWD(M, V)                                                                                                         \
+    hipLaunchKernelGGL((norm_bwd_reduce_kernel<M, V>), g, t, 0, st, dy, y, x, gamma, mean, invstd, workspace, N, C, HW, nchunk, \
+                       slope);                                                                                                   \
+    hipLaunchKernelGGL(pair_sum_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, workspace, C, N* nchunk, sums);         \
+    hipLaunchKernelGGL((norm_bwd_apply_kernel<M, V>), g, t, 0, st, dy, y, x, gamma, w, mean, invstd, sums, dx, dgamma, dbeta, C, \
+                       HW, nchunk, inv_count, slope);
+    if (mode == 0) {
+        if (v) { LAUNCH_BWD(0, true) } else { LAUNCH_BWD(0, false) }
+    } else {
+        if (v) { LAUNCH_BWD(1, true) } else { LAUNCH_BWD(1, false) }
+    }
+#undef LAUNCH_BWD
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+
+extern "C" int ag2v_instnorm_lrelu_fwd(const float* x, float* y, float* mean, float* invstd, int NC, int HW, float eps,
+                                       float slope, void* stream) {
+    if (!x || !y || !mean || !invstd || NC <= 0 || HW <= 0) return AG2V_EINVAL;
+    hipLaunchKernelGGL(instnorm_lrelu_fwd_kernel, dim3(NC), dim3(256), 0, (hipStream_t)stream, x, y, mean, invstd, HW, eps, slope);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+
+extern "C" int ag2v_instnorm_lrelu_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
+                                       float* dx, int NC, int HW, float slope, void* stream) {
+    if (!dy || !y || !x || !mean || !invstd || !dx || NC <= 0 || HW <= 0) return AG2V_EINVAL;
+    hipLaunchKernelGGL(instnorm_lrelu_bwd_kernel, dim3(NC), dim3(256), 0, (hipStream_t)stream, dy, y, x, mean, invstd, dx, HW, slope);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+
+extern "C" int ag2v_channel_sum(const float* x, float* out, int N, int C, int HW, void* stream) {
+    if (!x || !out || N <= 0 || C <= 0 || HW <= 0) return AG2V_EINVAL;
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, out, N, C, HW);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}

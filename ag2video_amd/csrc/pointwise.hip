@@ -1,0 +1,226 @@
+// Pointwise activations, loss reductions and the spectral-norm power-iteration step.
+//   * LeakyReLU / tanh forward+backward (spade_generator.py:78-80, discriminator.py:368-379)
+//   * mean reductions of the GAN losses: hinge (networks/loss.py:57-76), L1 feature matching / flow-warp
+//     (loss_model.py:84,97)
+//   * torch.nn.utils.spectral_norm train-mode forward: v <- normalize(W^T u), u <- normalize(W v), sigma = u.(W v),
+//     W_bar = W / sigma, and its backward  dW = (dW_bar - (sum dW_bar*W_bar) u v^T) / sigma.
+#include "common.h"
+
+// ---------------------------------------------------------------- activations
+// op 0: leaky relu(slope)   op 1: tanh
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long n, int op,
+                                                      float slope) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        float4 v = *reinterpret_cast<const float4*>(x + i);
+        if (op == 0) {
+            v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
+            v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
+        } else {
+            v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w);
+        }
+        *reinterpret_cast<float4*>(y + i) = v;
+    } else {
+        for (long long j = i; j < n; ++j) {
+            const float t = x[j];
+            y[j] = (op == 0) ? (t > 0.f ? t : t * slope) : tanhf(t);
+        }
+    }
+}
+// dx = dy * f'(.)  expressed through the forward OUTPUT y: lrelu: y>0 ? 1 : slope ; tanh: 1 - y^2
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx,
+                                                      long long n, int op, float slope) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float yy = y[i], g = dy[i];
+    dx[i] = (op == 0) ? (yy > 0.f ? g : g * slope) : g * (1.f - yy * yy);
+}
+
+// ---------------------------------------------------------------- mean reductions
+// op 0: sum |a-b|      op 1: sum a            op 2: sum min(a-1,0)      op 3: sum min(-a-1,0)
+__device__ __forceinline__ float red_term(int op, float a, float b) {
+    switch (op) {
+        case 0: return fabsf(a - b);
+        case 1: return a;
+        case 2: return fminf(a - 1.f, 0.f);
+        default: return fminf(-a - 1.f, 0.f);
+    }
+}
+__global__ __launch_bounds__(256) void reduce_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n,
+                                                             int op, float* __restrict__ partial) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        s += red_term(op, a[i], b ? b[i] : 0.f);
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void reduce_final_kernel(const float* __restrict__ partial, int np, float scale, float* __restrict__ out) {
+    __shared__ double shd[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < np; i += 256) s += partial[i];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) shd[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (float)((shd[0] + shd[1] + shd[2] + shd[3]) * (double)scale);
+}
+// da = gscale * gout[0] * d(term)/da
+__global__ __launch_bounds__(256) void reduce_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n, int op,
+                                                         const float* __restrict__ gout, float scale, float* __restrict__ da) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float g = gout[0] * scale;
+    const float av = a[i];
+    float d;
+    switch (op) {
+        case 0: { const float df = av - b[i]; d = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f); } break;
+        case 1: d = 1.f; break;
+        case 2: d = (av - 1.f < 0.f) ? 1.f : 0.f; break;
+        default: d = (-av - 1.f < 0.f) ? -1.f : 0.f; break;
+    }
+    da[i] = g * d;
+}
+
+// ---------------------------------------------------------------- spectral norm (W viewed as [M, R], row-major)
+__global__ __launch_bounds__(256) void sn_wtu_kernel(const float* __restrict__ w, const float* __restrict__ u, float* __restrict__ v,
+                                                     int M, int R) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) s += w[(size_t)m * R + r] * u[m];
+    v[r] = s;
+}
+// x <- x / max(||x||, eps) (single workgroup)
+__global__ __launch_bounds__(256) void sn_normalize_kernel(float* __restrict__ x, int n, float eps) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += x[i] * x[i];
+    s = block_sum_256(s, sh);
+    const float inv = 1.0f / fmaxf(sqrtf(s), eps);
+    for (int i = threadIdx.x; i < n; i += 256) x[i] *= inv;
+}
+// out[m] = sum_r W[m,r] v[r] : one wave per row
+__global__ __launch_bounds__(256) void sn_wv_kernel(const float* __restrict__ w, const float* __restrict__ v, float* __restrict__ out,
+                                                    int M, int R) {
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int lane = threadIdx.x & 63;
+    float s = 0.f;
+    for (int r = lane; r < R; r += 64) s += w[(size_t)m * R + r] * v[r];
+    s = wave_sum(s);
+    if (lane == 0) out[m] = s;
+}
+// u <- normalize(wv) when update_u; sigma = u . wv   (single workgroup)
+__global__ __launch_bounds__(256) void sn_sigma_kernel(float* __restrict__ u, const float* __restrict__ wv, int M, float eps,
+                                                       int update_u, float* __restrict__ sigma) {
+    __shared__ float sh[4];
+    if (update_u) {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < M; i += 256) s += wv[i] * wv[i];
+        s = block_sum_256(s, sh);
+        const float inv = 1.0f / fmaxf(sqrtf(s), eps);
+        for (int i = threadIdx.x; i < M; i += 256) u[i] = wv[i] * inv;
+        __syncthreads();
+    }
+    float d = 0.f;
+    for (int i = threadIdx.x; i < M; i += 256) d += u[i] * wv[i];
+    d = block_sum_256(d, sh);
+    if (threadIdx.x == 0) sigma[0] = d;
+}
+__global__ __launch_bounds__(256) void sn_scale_kernel(const float* __restrict__ w, const float* __restrict__ sigma, float* __restrict__ wbar,
+                                                       long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) wbar[i] = w[i] / sigma[0];
+}
+__global__ __launch_bounds__(256) void sn_bwd_kernel(const float* __restrict__ dwbar, const float* __restrict__ u, const float* __restrict__ v,
+                                                     const float* __restrict__ sigma, const float* __restrict__ dot, float* __restrict__ dw,
+                                                     int M, int R) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)M * R) return;
+    const int m = (int)(i / R), r = (int)(i - (long long)m * R);
+    dw[i] = (dwbar[i] - dot[0] * u[m] * v[r]) / sigma[0];
+}
+__global__ __launch_bounds__(256) void dot_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n,
+                                                          float* __restrict__ partial) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += a[i] * b[i];
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// ================================================================ C ABI
+extern "C" int ag2v_act_fwd(int op, const float* x, float* y, long long n, float slope, void* stream) {
+    if (!x || !y || n <= 0 || op < 0 || op > 1) return AG2V_EINVAL;
+    if ((((uintptr_t)x) | ((uintptr_t)y)) & 15) return AG2V_EINVAL;
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(ceil_div(n, 1024)), dim3(256), 0, (hipStream_t)stream, x, y, n, op, slope);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+extern "C" int ag2v_act_bwd(int op, const float* dy, const float* y, float* dx, long long n, float slope, void* stream) {
+    if (!dy || !y || !dx || n <= 0 || op < 0 || op > 1) return AG2V_EINVAL;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, n, op, slope);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+
+#define RED_BLOCKS 1024
+extern "C" size_t ag2v_reduce_workspace_floats() { return RED_BLOCKS; }
+
+// out[0] = scale * sum_i term_op(a[i], b[i]);   workspace: ag2v_reduce_workspace_floats() floats
+extern "C" int ag2v_reduce_fwd(int op, const float* a, const float* b, long long n, float scale, float* out, float* workspace,
+                               void* stream) {
+    if (!a || !out || !workspace || n <= 0 || op < 0 || op > 3 || (op == 0 && !b)) return AG2V_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    int nb = ceil_div(n, 256 * 8);
+    if (nb > RED_BLOCKS) nb = RED_BLOCKS;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(reduce_partial_kernel, dim3(nb), dim3(256), 0, st, a, b, n, op, workspace);
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, st, workspace, nb, scale, out);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+extern "C" int ag2v_reduce_bwd(int op, const float* a, const float* b, long long n, const float* gout, float scale, float* da,
+                               void* stream) {
+    if (!a || !gout || !da || n <= 0 || op < 0 || op > 3 || (op == 0 && !b)) return AG2V_EINVAL;
+    hipLaunchKernelGGL(reduce_bwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, n, op, gout, scale, da);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+
+extern "C" size_t ag2v_spectral_workspace_floats(int M) { return (size_t)M + RED_BLOCKS; }
+
+// W[M,R] (flattened conv weight).  power_iter != 0: one in-place power iteration on u[M], v[R] first (training mode).
+// Writes sigma[0] and W_bar = W / sigma.  workspace: ag2v_spectral_workspace_floats(M).
+extern "C" int ag2v_spectral_norm_fwd(const float* w, float* u, float* v, int M, int R, float eps, int power_iter, float* wbar,
+                                      float* sigma, float* workspace, void* stream) {
+    if (!w || !u || !v || !wbar || !sigma || !workspace || M <= 0 || R <= 0) return AG2V_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    float* wv = workspace;
+    if (power_iter) {
+        hipLaunchKernelGGL(sn_wtu_kernel, dim3(ceil_div(R, 256)), dim3(256), 0, st, w, u, v, M, R);
+        hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(256), 0, st, v, R, eps);
+    }
+    hipLaunchKernelGGL(sn_wv_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, w, v, wv, M, R);
+    hipLaunchKernelGGL(sn_sigma_kernel, dim3(1), dim3(256), 0, st, u, wv, M, eps, power_iter, sigma);
+    const long long n = (long long)M * R;
+    hipLaunchKernelGGL(sn_scale_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, w, sigma, wbar, n);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+// dW = (dW_bar - <dW_bar, W_bar> u v^T) / sigma     (u, v: the vectors the forward used)
+extern "C" int ag2v_spectral_norm_bwd(const float* dwbar, const float* wbar, const float* u, const float* v, const float* sigma,
+                                      int M, int R, float* dw, float* workspace, void* stream) {
+    if (!dwbar || !wbar || !u || !v || !sigma || !dw || !workspace || M <= 0 || R <= 0) return AG2V_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const long long n = (long long)M * R;
+    int nb = ceil_div(n, 256 * 8);
+    if (nb > RED_BLOCKS) nb = RED_BLOCKS;
+    float* partial = workspace + M;
+    float* dot = workspace;  // reuse first float
+    hipLaunchKernelGGL(dot_partial_kernel, dim3(nb), dim3(256), 0, st, dwbar, wbar, n, partial);
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, st, partial, nb, 1.0f, dot);
+    hipLaunchKernelGGL(sn_bwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, dwbar, u, v, sigma, dot, dw, M, R);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}

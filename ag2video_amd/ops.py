@@ -1,0 +1,528 @@
+"""Host-side operators: torch.autograd.Function wrappers over the libag2v.so C ABI (include/ag2v.h).
+
+PyTorch supplies device memory, the current HIP stream and the autograd tape; all arithmetic of these operators runs
+in the hand-written gfx950 kernels of ag2video_amd/csrc.  Every operator requires CUDA(HIP) fp32 tensors and raises
+otherwise -- there is no CPU path in the product (tests/ check these operators against oracle/ on the GPU).
+"""
+import torch
+
+from . import _lib
+
+_P = _lib.c_void_p
+
+
+def _ptr(t):
+    return None if t is None else _P(t.data_ptr())
+
+
+def _stream():
+    return _P(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("ag2video_amd.ops: expected a HIP device tensor, got %s (no CPU fallback)" % t.device)
+        if t.dtype != torch.float32:
+            raise RuntimeError("ag2video_amd.ops: expected float32, got %s" % t.dtype)
+
+
+def _c(t):
+    return None if t is None else t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------ convolution
+class _Conv2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, residual, stride, pad):
+        x, w, bias, residual = _c(x), _c(w), _c(bias), _c(residual)
+        _chk(x, w, bias, residual)
+        N, C, H, W = x.shape
+        K, C2, R, S = w.shape
+        if C2 != C:
+            raise RuntimeError("conv2d: input has %d channels, weight expects %d" % (C, C2))
+        OH = (H + 2 * pad - R) // stride + 1
+        OW = (W + 2 * pad - S) // stride + 1
+        y = torch.empty((N, K, OH, OW), device=x.device, dtype=torch.float32)
+        _lib.call('ag2v_conv2d_fwd', _ptr(x), _ptr(w), _ptr(bias), _ptr(residual), _ptr(y),
+                  N, C, H, W, K, R, S, stride, pad, _stream())
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, pad, bias is not None, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, pad, has_bias, has_res = ctx.cfg
+        dy = dy.contiguous()
+        N, C, H, W = x.shape
+        K, _, R, S = w.shape
+        dx = dw = db = dres = None
+        st = _stream()
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _lib.call('ag2v_conv2d_dgrad', _ptr(dy), _ptr(w), _ptr(dx), N, C, H, W, K, R, S, stride, pad, st)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            _lib.call('ag2v_conv2d_wgrad', _ptr(dy), _ptr(x), _ptr(dw), N, C, H, W, K, R, S, stride, pad, st)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(K, device=dy.device, dtype=torch.float32)
+            _lib.call('ag2v_channel_sum', _ptr(dy), _ptr(db), N, K, dy.shape[2] * dy.shape[3], st)
+        if has_res and ctx.needs_input_grad[3]:
+            dres = dy
+        return dx, dw, db, dres, None, None
+
+
+def conv2d(x, w, bias=None, stride=1, pad=0, residual=None):
+    """y = conv2d(x, w) + bias + residual   (NCHW, square stride/pad)."""
+    return _Conv2d.apply(x, w, bias, residual, int(stride), int(pad))
+
+
+# ------------------------------------------------------------------------------------------------ spectral norm
+class _SpectralWeight(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w_orig, u, v, training, eps):
+        w = _c(w_orig)
+        _chk(w, u, v)
+        M = w.shape[0]
+        R = w.numel() // M
+        wbar = torch.empty_like(w)
+        sigma = torch.empty(1, device=w.device, dtype=torch.float32)
+        ws = torch.empty(_lib.query('ag2v_spectral_workspace_floats', M), device=w.device, dtype=torch.float32)
+        _lib.call('ag2v_spectral_norm_fwd', _ptr(w), _ptr(u), _ptr(v), M, R, float(eps), 1 if training else 0,
+                  _ptr(wbar), _ptr(sigma), _ptr(ws), _stream())
+        # the buffers keep advancing in later calls; the tape needs the vectors this call used
+        ctx.save_for_backward(wbar, u.clone(), v.clone(), sigma)
+        return wbar
+
+    @staticmethod
+    def backward(ctx, dwbar):
+        wbar, u, v, sigma = ctx.saved_tensors
+        dwbar = dwbar.contiguous()
+        M = wbar.shape[0]
+        R = wbar.numel() // M
+        dw = torch.empty_like(wbar)
+        ws = torch.empty(_lib.query('ag2v_spectral_workspace_floats', M), device=wbar.device, dtype=torch.float32)
+        _lib.call('ag2v_spectral_norm_bwd', _ptr(dwbar), _ptr(wbar), _ptr(u), _ptr(v), _ptr(sigma), M, R, _ptr(dw), _ptr(ws),
+                  _stream())
+        return dw, None, None, None, None
+
+
+def spectral_weight(w_orig, u, v, training=True, eps=1e-12):
+    """W / sigma(W) with one in-place power iteration on (u, v) in training mode."""
+    return _SpectralWeight.apply(w_orig, u, v, bool(training), float(eps))
+
+
+# ------------------------------------------------------------------------------------------------ batch norm family
+def _bn_stats(x, running_mean, running_var, training, momentum, eps):
+    N, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (N * C)
+    if training:
+        mean = torch.empty(C, device=x.device, dtype=torch.float32)
+        invstd = torch.empty(C, device=x.device, dtype=torch.float32)
+        ws = torch.empty(_lib.query('ag2v_bn_workspace_floats', N, C, HW), device=x.device, dtype=torch.float32)
+        _lib.call('ag2v_bn_stats', _ptr(x), N, C, HW, float(eps), float(momentum), _ptr(mean), _ptr(invstd),
+                  _ptr(running_mean), _ptr(running_var), _ptr(ws), _stream())
+    else:
+        mean = running_mean
+        invstd = torch.rsqrt(running_var + eps)
+    return mean, invstd, N, C, HW
+
+
+class _NormAct(torch.autograd.Function):
+    """mode 0: BN(affine w,b) -> LeakyReLU(slope); mode 1: SPADE BN*(1+gamma)+beta -> LeakyReLU(slope)."""
+
+    @staticmethod
+    def forward(ctx, mode, x, p0, p1, running_mean, running_var, training, momentum, eps, slope):
+        x, p0, p1 = _c(x), _c(p0), _c(p1)
+        _chk(x, p0, p1)
+        mean, invstd, N, C, HW = _bn_stats(x, running_mean, running_var, training, momentum, eps)
+        y = torch.empty_like(x)
+        if mode == 0:
+            _lib.call('ag2v_norm_apply', 0, _ptr(x), _ptr(mean), _ptr(invstd), _ptr(p0), _ptr(p1), None, None, _ptr(y),
+                      N, C, HW, float(slope), _stream())
+        else:
+            _lib.call('ag2v_norm_apply', 1, _ptr(x), _ptr(mean), _ptr(invstd), None, None, _ptr(p0), _ptr(p1), _ptr(y),
+                      N, C, HW, float(slope), _stream())
+        ctx.save_for_backward(x, y if slope != 1.0 else None, p0, mean, invstd)
+        ctx.cfg = (mode, training, slope, N, C, HW)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, p0, mean, invstd = ctx.saved_tensors
+        mode, training, slope, N, C, HW = ctx.cfg
+        if not training:
+            raise RuntimeError("norm backward is only implemented for batch statistics (training mode)")
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        sums = torch.empty((C, 2), device=x.device, dtype=torch.float32)
+        ws = torch.empty(_lib.query('ag2v_bn_workspace_floats', N, C, HW), device=x.device, dtype=torch.float32)
+        if mode == 0:
+            _lib.call('ag2v_norm_bwd', 0, _ptr(dy), _ptr(y), _ptr(x), None, _ptr(p0), _ptr(mean), _ptr(invstd), _ptr(dx),
+                      None, None, _ptr(sums), N, C, HW, float(slope), _ptr(ws), _stream())
+            dw = sums[:, 1].contiguous() if p0 is not None else None
+            db = sums[:, 0].contiguous() if p0 is not None else None
+            return None, dx, dw, db, None, None, None, None, None, None
+        dgamma = torch.empty_like(x)
+        dbeta = torch.empty_like(x)
+        _lib.call('ag2v_norm_bwd', 1, _ptr(dy), _ptr(y), _ptr(x), _ptr(p0), None, _ptr(mean), _ptr(invstd), _ptr(dx),
+                  _ptr(dgamma), _ptr(dbeta), _ptr(sums), N, C, HW, float(slope), _ptr(ws), _stream())
+        return None, dx, dgamma, dbeta, None, None, None, None, None, None
+
+
+def batchnorm_act(x, weight, bias, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0):
+    """F.batch_norm (batch statistics + running-stat update when training) followed by LeakyReLU(slope)."""
+    return _NormAct.apply(0, x, weight, bias, running_mean, running_var, bool(training), float(momentum), float(eps),
+                          float(slope))
+
+
+def spade_norm(x, gamma, beta, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0):
+    """SPADE modulation: BN_noaffine(x) * (1 + gamma) + beta, then LeakyReLU(slope)."""
+    return _NormAct.apply(1, x, gamma, beta, running_mean, running_var, bool(training), float(momentum), float(eps),
+                          float(slope))
+
+
+class _InstNormLReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps, slope):
+        x = _c(x)
+        _chk(x)
+        N, C = x.shape[0], x.shape[1]
+        HW = x.numel() // (N * C)
+        y = torch.empty_like(x)
+        mean = torch.empty(N * C, device=x.device, dtype=torch.float32)
+        invstd = torch.empty(N * C, device=x.device, dtype=torch.float32)
+        _lib.call('ag2v_instnorm_lrelu_fwd', _ptr(x), _ptr(y), _ptr(mean), _ptr(invstd), N * C, HW, float(eps), float(slope),
+                  _stream())
+        ctx.save_for_backward(x, y, mean, invstd)
+        ctx.cfg = (slope, N * C, HW)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean, invstd = ctx.saved_tensors
+        slope, NC, HW = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        _lib.call('ag2v_instnorm_lrelu_bwd', _ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(dx), NC, HW,
+                  float(slope), _stream())
+        return dx, None, None
+
+
+def instnorm_lrelu(x, eps=1e-5, slope=0.2):
+    return _InstNormLReLU.apply(x, float(eps), float(slope))
+
+
+# ------------------------------------------------------------------------------------------------ layout render / warp
+class _LayoutRender(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vecs, boxes, keep, H, W):
+        vecs, boxes = _c(vecs), _c(boxes)
+        _chk(vecs, boxes)
+        keep = keep.to(torch.int32).contiguous()
+        BT, O, D = vecs.shape
+        out = torch.empty((BT, D, H, W), device=vecs.device, dtype=torch.float32)
+        _lib.call('ag2v_layout_render_fwd', _ptr(vecs), _ptr(boxes), _ptr(keep), _ptr(out), BT, O, D, H, W, _stream())
+        ctx.save_for_backward(boxes, keep)
+        ctx.cfg = (BT, O, D, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        boxes, keep = ctx.saved_tensors
+        BT, O, D, H, W = ctx.cfg
+        dout = dout.contiguous()
+        dvecs = torch.empty((BT, O, D), device=dout.device, dtype=torch.float32)
+        _lib.call('ag2v_layout_render_bwd', _ptr(dout), _ptr(boxes), _ptr(keep), _ptr(dvecs), BT, O, D, H, W, _stream())
+        return dvecs, None, None, None, None
+
+
+def layout_render(vecs, boxes, keep, H, W):
+    """vecs[BT,O,D], boxes[BT,O,4] (x0,y0,w,h), keep[BT,O] -> [BT,D,H,W]; gradient flows to vecs only (as in the reference:
+    the boxes are ground truth or detached, meta_models.py:53)."""
+    return _LayoutRender.apply(vecs, boxes, keep, int(H), int(W))
+
+
+class _FlowWarp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, flow):
+        img, flow = _c(img), _c(flow)
+        _chk(img, flow)
+        N, C, H, W = img.shape
+        out = torch.empty_like(img)
+        _lib.call('ag2v_flow_warp_fwd', _ptr(img), _ptr(flow), _ptr(out), N, C, H, W, _stream())
+        ctx.save_for_backward(img, flow)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        img, flow = ctx.saved_tensors
+        N, C, H, W = img.shape
+        dout = dout.contiguous()
+        dflow = torch.empty_like(flow)
+        dimg = torch.empty_like(img) if ctx.needs_input_grad[0] else None
+        _lib.call('ag2v_flow_warp_bwd', _ptr(dout), _ptr(img), _ptr(flow), _ptr(dflow), _ptr(dimg), N, C, H, W, _stream())
+        return dimg, dflow
+
+
+def flow_warp(img, flow):
+    return _FlowWarp.apply(img, flow)
+
+
+class _AvgPool3s2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        _chk(x)
+        N, C, H, W = x.shape
+        y = torch.empty((N, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), device=x.device, dtype=torch.float32)
+        _lib.call('ag2v_avgpool3s2_fwd', _ptr(x), _ptr(y), N * C, H, W, _stream())
+        ctx.shape = (N, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, C, H, W = ctx.shape
+        dy = dy.contiguous()
+        dx = torch.empty((N, C, H, W), device=dy.device, dtype=torch.float32)
+        _lib.call('ag2v_avgpool3s2_bwd', _ptr(dy), _ptr(dx), N * C, H, W, _stream())
+        return dx
+
+
+def avgpool3s2(x):
+    return _AvgPool3s2.apply(x)
+
+
+class _NearestResize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, OH, OW):
+        x = _c(x)
+        _chk(x)
+        N, C, H, W = x.shape
+        y = torch.empty((N, C, OH, OW), device=x.device, dtype=torch.float32)
+        _lib.call('ag2v_nearest_resize_fwd', _ptr(x), _ptr(y), N * C, H, W, OH, OW, _stream())
+        ctx.shape = (N, C, H, W, OH, OW)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, C, H, W, OH, OW = ctx.shape
+        dy = dy.contiguous()
+        dx = torch.empty((N, C, H, W), device=dy.device, dtype=torch.float32)
+        _lib.call('ag2v_nearest_resize_bwd', _ptr(dy), _ptr(dx), N * C, H, W, OH, OW, _stream())
+        return dx, None, None
+
+
+def nearest_resize(x, OH, OW):
+    if x.shape[2] == OH and x.shape[3] == OW:
+        return x
+    return _NearestResize.apply(x, int(OH), int(OW))
+
+
+def upsample2x(x):
+    return _NearestResize.apply(x, int(x.shape[2] * 2), int(x.shape[3] * 2))
+
+
+# ------------------------------------------------------------------------------------------------ graph ops
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, relu):
+        x, w, b = _c(x), _c(w), _c(b)
+        _chk(x, w, b)
+        M, K = x.shape
+        N = w.shape[0]
+        y = torch.empty((M, N), device=x.device, dtype=torch.float32)
+        _lib.call('ag2v_gemm_f32', _ptr(x), _ptr(w), _ptr(b), _ptr(y), M, N, K, K, 1, 1, K, N, 1 if relu else 0, 0, _stream())
+        ctx.save_for_backward(x, w, y if relu else None)
+        ctx.cfg = (relu, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        relu, has_b = ctx.cfg
+        M, K = x.shape
+        N = w.shape[0]
+        st = _stream()
+        g = dy.contiguous()
+        if relu:
+            g2 = torch.empty_like(g)
+            _lib.call('ag2v_relu_bwd', _ptr(g), _ptr(y), _ptr(g2), g.numel(), st)
+            g = g2
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _lib.call('ag2v_gemm_f32', _ptr(g), _ptr(w), None, _ptr(dx), M, K, N, N, 1, K, 1, K, 0, 0, st)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            _lib.call('ag2v_gemm_f32', _ptr(g), _ptr(x), None, _ptr(dw), N, K, M, 1, N, K, 1, K, 0, 0, st)
+        if has_b and ctx.needs_input_grad[2]:
+            db = torch.empty(N, device=g.device, dtype=torch.float32)
+            _lib.call('ag2v_col_sum', _ptr(g), _ptr(db), M, N, st)
+        return dx, dw, db, None
+
+
+def linear(x, w, b=None, relu=False):
+    """y = [relu](x @ w.T + b) for x[..., K], w[N, K]."""
+    shp = x.shape
+    y = _Linear.apply(x.reshape(-1, shp[-1]), w, b, bool(relu))
+    return y.reshape(*shp[:-1], w.shape[0])
+
+
+class _TripleGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, obj, pred, edges):
+        obj, pred = _c(obj), _c(pred)
+        _chk(obj, pred)
+        edges = edges.to(torch.int64).contiguous()
+        B, O, Din = obj.shape
+        T, Dp = pred.shape[1], pred.shape[2]
+        out = torch.empty((B, T, 2 * Din + Dp), device=obj.device, dtype=torch.float32)
+        _lib.call('ag2v_triple_gather_fwd', _ptr(obj), _ptr(pred), _ptr(edges), _ptr(out), B, O, T, Din, Dp, _stream())
+        ctx.save_for_backward(edges)
+        ctx.cfg = (B, O, T, Din, Dp)
+        return out
+
+    @staticmethod
+    def backward(ctx, dtri):
+        (edges,) = ctx.saved_tensors
+        B, O, T, Din, Dp = ctx.cfg
+        dtri = dtri.contiguous()
+        dobj = torch.empty((B, O, Din), device=dtri.device, dtype=torch.float32)
+        dpred = torch.empty((B, T, Dp), device=dtri.device, dtype=torch.float32)
+        _lib.call('ag2v_triple_gather_bwd', _ptr(dtri), _ptr(edges), _ptr(dobj), _ptr(dpred), B, O, T, Din, Dp, _stream())
+        return dobj, dpred, None
+
+
+def triple_gather(obj, pred, edges):
+    """[obj[s] | pred | obj[o]] rows for every edge (graph.py:64-70)."""
+    return _TripleGather.apply(obj, pred, edges)
+
+
+class _TriplePool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, newt, edges, valid, O, Hd, Dp):
+        newt = _c(newt)
+        _chk(newt)
+        edges = edges.to(torch.int64).contiguous()
+        valid = valid.to(torch.uint8).contiguous()
+        B, T = newt.shape[0], newt.shape[1]
+        pooled = torch.empty((B, O, Hd), device=newt.device, dtype=torch.float32)
+        counts = torch.empty((B, O), device=newt.device, dtype=torch.float32)
+        _lib.call('ag2v_triple_pool_fwd', _ptr(newt), _ptr(edges), _ptr(valid), _ptr(pooled), _ptr(counts), B, O, T, Hd, Dp,
+                  _stream())
+        ctx.save_for_backward(edges, valid, counts)
+        ctx.cfg = (B, O, T, Hd, Dp)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        edges, valid, counts = ctx.saved_tensors
+        B, O, T, Hd, Dp = ctx.cfg
+        dpooled = dpooled.contiguous()
+        dnewt = torch.empty((B, T, 2 * Hd + Dp), device=dpooled.device, dtype=torch.float32)
+        _lib.call('ag2v_triple_pool_bwd', _ptr(dpooled), None, _ptr(edges), _ptr(valid), _ptr(counts), _ptr(dnewt), B, O, T,
+                  Hd, Dp, _stream())
+        return dnewt, None, None, None, None, None
+
+
+def triple_pool(newt, edges, valid, O, Hd, Dp):
+    """Masked average pooling of the subject/object halves of new triple vectors onto objects (graph.py:79-100)."""
+    return _TriplePool.apply(newt, edges, valid, int(O), int(Hd), int(Dp))
+
+
+class _Embedding(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, idx, table):
+        table = _c(table)
+        _chk(table)
+        idx = idx.to(torch.int64).contiguous()
+        n = idx.numel()
+        D = table.shape[1]
+        out = torch.empty((n, D), device=table.device, dtype=torch.float32)
+        _lib.call('ag2v_embedding_fwd', _ptr(idx), _ptr(table), _ptr(out), n, D, D, 0, _stream())
+        ctx.save_for_backward(idx)
+        ctx.cfg = (n, table.shape[0], D, tuple(idx.shape))
+        return out.view(*idx.shape, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        n, V, D, _ = ctx.cfg
+        dout = dout.contiguous()
+        dtable = torch.empty((V, D), device=dout.device, dtype=torch.float32)
+        _lib.call('ag2v_embedding_bwd', _ptr(idx), _ptr(dout), _ptr(dtable), n, V, D, D, 0, _stream())
+        return None, dtable
+
+
+def embedding(idx, table):
+    return _Embedding.apply(idx, table)
+
+
+# ------------------------------------------------------------------------------------------------ pointwise / losses
+class _Act(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, op, slope):
+        x = _c(x)
+        _chk(x)
+        y = torch.empty_like(x)
+        _lib.call('ag2v_act_fwd', op, _ptr(x), _ptr(y), x.numel(), float(slope), _stream())
+        ctx.save_for_backward(y)
+        ctx.cfg = (op, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        op, slope = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.empty_like(y)
+        _lib.call('ag2v_act_bwd', op, _ptr(dy), _ptr(y), _ptr(dx), y.numel(), float(slope), _stream())
+        return dx, None, None
+
+
+def leaky_relu(x, slope=0.2):
+    return _Act.apply(x, 0, float(slope))
+
+
+def tanh(x):
+    return _Act.apply(x, 1, 0.0)
+
+
+class _Reduce(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, op, a, b, scale):
+        a, b = _c(a), _c(b)
+        _chk(a, b)
+        out = torch.empty(1, device=a.device, dtype=torch.float32)
+        ws = torch.empty(_lib.query('ag2v_reduce_workspace_floats'), device=a.device, dtype=torch.float32)
+        _lib.call('ag2v_reduce_fwd', op, _ptr(a), _ptr(b), a.numel(), float(scale), _ptr(out), _ptr(ws), _stream())
+        ctx.save_for_backward(a, b)
+        ctx.cfg = (op, scale)
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        a, b = ctx.saved_tensors
+        op, scale = ctx.cfg
+        gout = gout.contiguous().view(1)
+        da = torch.empty_like(a)
+        _lib.call('ag2v_reduce_bwd', op, _ptr(a), _ptr(b), a.numel(), _ptr(gout), float(scale), _ptr(da), _stream())
+        db = None
+        if b is not None and ctx.needs_input_grad[2]:
+            db = -da
+        return None, da, db, None
+
+
+def l1_mean(a, b):
+    """mean |a - b|  (nn.L1Loss)."""
+    return _Reduce.apply(0, a, b, 1.0 / a.numel())
+
+
+def hinge_mean(x, kind):
+    """GANLoss hinge (networks/loss.py:57-76): kind 'g': -mean(x); 'd_real': -mean(min(x-1,0)); 'd_fake': -mean(min(-x-1,0))."""
+    op = {'g': 1, 'd_real': 2, 'd_fake': 3}[kind]
+    return _Reduce.apply(op, x, None, -1.0 / x.numel())

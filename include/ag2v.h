@@ -1,0 +1,118 @@
+/* ag2v.h -- C ABI of libag2v.so: the MI355X (gfx950) kernels of the AG2Video training step.
+ *
+ * The reference (roeiherz/AG2Video) has no FFI for this path: it is plain torch.nn modules whose arithmetic is
+ * stock ATen.  Each entry point below replaces the ATen call site(s) cited next to it; file:line are
+ * relative to the reference checkout.  Conventions:
+ *   - every tensor is a raw device pointer to contiguous fp32 (NCHW for images) unless stated (int64 indices, uint8/int32 masks);
+ *   - the caller owns all memory; no entry point allocates, frees or synchronises; kernels are enqueued on `stream`
+ *     (a hipStream_t passed as void*) and are safe to capture in a hipGraph;
+ *   - scratch memory is passed in as `workspace` and sized by the matching ag2v_*_workspace_floats();
+ *   - return value: 0 on success, AG2V_EINVAL (-1) for a rejected argument, AG2V_EHIP (-2) for a HIP launch error
+ *     (the Python host turns non-zero into RuntimeError, matching the reference's "raise, never abort" convention,
+ *     scripts/train.py:466-468).
+ */
+#ifndef AG2V_H
+#define AG2V_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AG2V_OK 0
+#define AG2V_EINVAL (-1)
+#define AG2V_EHIP (-2)
+
+/* ---- convolution: nn.Conv2d forward/backward (aten.convolution) ------------------------------------------------
+ * call sites: generator.py:30; flows_generator.py:32-54,82-85; spade_generator.py:16-34; architecture.py:29-32;
+ * normalization.py:90-94; discriminator.py:368-379.   x[N,C,H,W], w[K,C,R,S], y[N,K,OH,OW], OH=(H+2p-R)/s+1.
+ * fwd: y = conv(x,w) (+bias[K]) (+residual, same shape as y).  dgrad: dx from dy.  wgrad: dw from dy,x. */
+int ag2v_conv2d_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y,
+                    int N, int C, int H, int W, int K, int R, int S, int stride, int pad, void* stream);
+int ag2v_conv2d_dgrad(const float* dy, const float* w, float* dx,
+                      int N, int C, int H, int W, int K, int R, int S, int stride, int pad, void* stream);
+int ag2v_conv2d_wgrad(const float* dy, const float* x, float* dw,
+                      int N, int C, int H, int W, int K, int R, int S, int stride, int pad, void* stream);
+/* out[c] = sum over n,hw of x[n,c,hw]: conv bias gradient */
+int ag2v_channel_sum(const float* x, float* out, int N, int C, int HW, void* stream);
+
+/* ---- batch norm / SPADE / instance norm -------------------------------------------------------------------------
+ * F.batch_norm(training) in sync_batchnorm/batchnorm.py:63-68; SPADE.forward normalization.py:96-110;
+ * nn.InstanceNorm2d + LeakyReLU discriminator.py:374 (via normalization.py:43-44). */
+size_t ag2v_bn_workspace_floats(int N, int C, int HW);
+int ag2v_bn_stats(const float* x, int N, int C, int HW, float eps, float momentum, float* mean, float* invstd,
+                  float* running_mean, float* running_var, float* workspace, void* stream);
+/* mode 0: y = lrelu((x-mean)*invstd*w[c] + b[c], slope); mode 1: y = lrelu(xhat*(1+gamma)+beta, slope); slope 1 = identity */
+int ag2v_norm_apply(int mode, const float* x, const float* mean, const float* invstd, const float* w, const float* b,
+                    const float* gamma, const float* beta, float* y, int N, int C, int HW, float slope, void* stream);
+int ag2v_norm_bwd(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* w,
+                  const float* mean, const float* invstd, float* dx, float* dgamma, float* dbeta, float* sums,
+                  int N, int C, int HW, float slope, float* workspace, void* stream);
+int ag2v_instnorm_lrelu_fwd(const float* x, float* y, float* mean, float* invstd, int NC, int HW, float eps, float slope,
+                            void* stream);
+int ag2v_instnorm_lrelu_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
+                            float* dx, int NC, int HW, float slope, void* stream);
+
+/* ---- layout render: boxes_to_layout models/layout.py:28-63 (+_boxes_to_grid :98-130, _pool_samples :205-237) -----
+ * vecs[BT,O,D], boxes[BT,O,4] xywh, keep[BT,O] int32 (remove_dummy_objects models/utils.py:95-102) -> out[BT,D,H,W] */
+int ag2v_layout_render_fwd(const float* vecs, const float* boxes, const int* keep, float* out, int BT, int O, int D, int H,
+                           int W, void* stream);
+int ag2v_layout_render_bwd(const float* dout, const float* boxes, const int* keep, float* dvecs, int BT, int O, int D, int H,
+                           int W, void* stream);
+
+/* ---- flow warp: resample/get_grid models/utils.py:113-140 (grid_sample bilinear, border, align_corners=False) --- */
+int ag2v_flow_warp_fwd(const float* img, const float* flow, float* out, int N, int C, int H, int W, void* stream);
+int ag2v_flow_warp_bwd(const float* dout, const float* img, const float* flow, float* dflow, float* dimg /*nullable*/,
+                       int N, int C, int H, int W, void* stream);
+
+/* ---- resampling: avg_pool2d(3,2,1,count_include_pad=False) discriminator.py:270-271; nearest F.interpolate /
+ * nn.Upsample(scale_factor=2) normalization.py:102, spade_generator.py:36,55-70, flows_generator.py:47 ------------- */
+int ag2v_avgpool3s2_fwd(const float* x, float* y, int NC, int H, int W, void* stream);
+int ag2v_avgpool3s2_bwd(const float* dy, float* dx, int NC, int H, int W, void* stream);
+int ag2v_nearest_resize_fwd(const float* x, float* y, int NC, int H, int W, int OH, int OW, void* stream);
+int ag2v_nearest_resize_bwd(const float* dy, float* dx, int NC, int H, int W, int OH, int OW, void* stream);
+
+/* ---- action-graph convolution: GraphTripleConv.forward models/graph_models/graph.py:41-107 ---------------------
+ * edges int64 [B,T,2]; valid uint8 [B,T] (pred_indicators).  gather: graph.py:64-68; pool: graph.py:79-100 */
+int ag2v_triple_gather_fwd(const float* obj, const float* pred, const long long* edges, float* out, int B, int O, int T,
+                           int Din, int Dp, void* stream);
+int ag2v_triple_gather_bwd(const float* dtri, const long long* edges, float* dobj, float* dpred /*nullable*/, int B, int O,
+                           int T, int Din, int Dp, void* stream);
+int ag2v_triple_pool_fwd(const float* newt, const long long* edges, const unsigned char* valid, float* pooled, float* counts,
+                         int B, int O, int T, int Hd, int Dp, void* stream);
+int ag2v_triple_pool_bwd(const float* dpooled, const float* dp_in /*nullable*/, const long long* edges,
+                         const unsigned char* valid, const float* counts, float* dnewt, int B, int O, int T, int Hd, int Dp,
+                         void* stream);
+/* nn.Linear / build_mlp (models/layers.py:6-25): strided fp32 GEMM  C = act(A*B + bias) */
+int ag2v_gemm_f32(const float* a, const float* b, const float* bias, float* c, int M, int N, int K, long long sam,
+                  long long sak, long long sbk, long long sbn, int ldc, int relu, int accumulate, void* stream);
+int ag2v_relu_bwd(const float* dy, const float* y, float* g, long long n, void* stream);
+int ag2v_col_sum(const float* x, float* out, int M, int N, void* stream);
+/* nn.Embedding (models/attribute_embed.py:38-45, graph_models/model.py:143,154) */
+int ag2v_embedding_fwd(const long long* idx, const float* table, float* out, int n, int D, int out_stride, int out_off,
+                       void* stream);
+int ag2v_embedding_bwd(const long long* idx, const float* dout, float* dtable, int n, int V, int D, int in_stride, int in_off,
+                       void* stream);
+
+/* ---- pointwise + losses: F.leaky_relu / tanh (spade_generator.py:78-80); GANLoss hinge networks/loss.py:57-76;
+ * L1 feature matching / flow-warp loss_model.py:84,97 ------------------------------------------------------------- */
+int ag2v_act_fwd(int op /*0 lrelu, 1 tanh*/, const float* x, float* y, long long n, float slope, void* stream);
+int ag2v_act_bwd(int op, const float* dy, const float* y, float* dx, long long n, float slope, void* stream);
+size_t ag2v_reduce_workspace_floats(void);
+/* op 0: sum|a-b|  1: sum a  2: sum min(a-1,0)  3: sum min(-a-1,0);  out[0] = scale * sum */
+int ag2v_reduce_fwd(int op, const float* a, const float* b, long long n, float scale, float* out, float* workspace,
+                    void* stream);
+int ag2v_reduce_bwd(int op, const float* a, const float* b, long long n, const float* gout, float scale, float* da,
+                    void* stream);
+
+/* ---- spectral norm: torch.nn.utils.spectral_norm forward pre-hook (call sites architecture.py:35-39,
+ * flows_generator.py:79-85, normalization.py:26-27) ---------------------------------------------------------------- */
+size_t ag2v_spectral_workspace_floats(int M);
+int ag2v_spectral_norm_fwd(const float* w, float* u, float* v, int M, int R, float eps, int power_iter, float* wbar,
+                           float* sigma, float* workspace, void* stream);
+int ag2v_spectral_norm_bwd(const float* dwbar, const float* wbar, const float* u, const float* v, const float* sigma, int M,
+                           int R, float* dw, float* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AG2V_H */

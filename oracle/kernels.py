@@ -1,0 +1,173 @@
+"""ORACLE (test infrastructure, not product code): CPU restatement of every operator on the AG2Video hot path.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.  Each function restates,
+in plain PyTorch-CPU fp32, the arithmetic of the reference call site it cites (file:line relative to the reference
+checkout) with the same signature as the matching ag2video_amd.ops operator, so the parity tests read
+``ops.f(*args) ~= oracle.kernels.f(*args)`` forward and (through autograd) backward.
+
+Pinning: oracle/model.py composes these into the full training step, which tests/test_oracle_golden.py checks against
+tests/golden/toy64_step.npz -- outputs of the unmodified reference modules run in the build container
+(tests/golden/make_golden.py).  The tolerance of every comparison is stated in the test that makes it.
+"""
+import torch
+import torch.nn.functional as F
+
+
+def conv2d(x, w, bias=None, stride=1, pad=0, residual=None):
+    """nn.Conv2d.forward (aten.convolution), e.g. generator.py:30, architecture.py:29-32, discriminator.py:368-379."""
+    y = F.conv2d(x, w, bias, stride=stride, padding=pad)
+    return y if residual is None else y + residual
+
+
+def spectral_weight(w_orig, u, v, training=True, eps=1e-12):
+    """torch.nn.utils.spectral_norm.SpectralNorm.compute_weight (n_power_iterations=1) as applied at
+    architecture.py:35-39, flows_generator.py:79-85, normalization.py:26-27.  u, v are updated in place in training."""
+    wm = w_orig.reshape(w_orig.shape[0], -1)
+    if training:
+        with torch.no_grad():
+            v.copy_(F.normalize(torch.mv(wm.t(), u), dim=0, eps=eps))
+            u.copy_(F.normalize(torch.mv(wm, v), dim=0, eps=eps))
+    uc, vc = u.clone(), v.clone()
+    sigma = torch.dot(uc, torch.mv(wm, vc))
+    return w_orig / sigma
+
+
+def _lrelu(y, slope):
+    return y if slope == 1.0 else F.leaky_relu(y, slope)
+
+
+def batchnorm_act(x, weight, bias, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0):
+    """_SynchronizedBatchNorm single-device path = F.batch_norm (sync_batchnorm/batchnorm.py:63-68) + LeakyReLU
+    (generator.py:26-33, flows_generator.py:30-54)."""
+    return _lrelu(F.batch_norm(x, running_mean, running_var, weight, bias, training, momentum, eps), slope)
+
+
+def spade_norm(x, gamma, beta, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0):
+    """SPADE.forward normalization.py:99,108 (+ actvn architecture.py:53-54,68)."""
+    n = F.batch_norm(x, running_mean, running_var, None, None, training, momentum, eps)
+    return _lrelu(n * (1 + gamma) + beta, slope)
+
+
+def instnorm_lrelu(x, eps=1e-5, slope=0.2):
+    """nn.InstanceNorm2d(affine=False) + LeakyReLU(0.2) (normalization.py:43-44, discriminator.py:374-377)."""
+    return F.leaky_relu(F.instance_norm(x, eps=eps), slope)
+
+
+def boxes_to_layout_single(vecs, boxes, H, W):
+    """boxes_to_layout for one frame, exactly the reference's sequence of ops (models/layout.py:28-63,98-130,205-237)."""
+    legal = (boxes != 0).any(dim=-1)
+    boxes = boxes[legal]
+    vecs = vecs[legal]
+    O, D = vecs.shape
+    b = boxes.view(O, 4, 1, 1)
+    x0, y0, ww, hh = b[:, 0], b[:, 1], b[:, 2], b[:, 3]
+    X = torch.linspace(0, 1, steps=W).view(1, 1, W).to(boxes)
+    Y = torch.linspace(0, 1, steps=H).view(1, H, 1).to(boxes)
+    X = ((X - x0) / ww).expand(O, H, W)
+    Y = ((Y - y0) / hh).expand(O, H, W)
+    grid = torch.stack([X, Y], dim=3).mul(2).sub(1)
+    img_in = vecs.view(O, D, 1, 1).expand(O, D, 8, 8)
+    sampled = F.grid_sample(img_in, grid, align_corners=True)
+    return sampled.sum(dim=0, keepdim=True)  # _pool_samples with a single image (scatter_add to row 0)
+
+
+def layout_render(vecs, boxes, keep, H, W):
+    """Batched boxes_to_layout: vecs[BT,O,D], boxes[BT,O,4], keep[BT,O] -> [BT,D,H,W] (generator.py:38-51)."""
+    outs = []
+    for i in range(vecs.shape[0]):
+        m = keep[i].bool()
+        if int(m.sum()) == 0:
+            outs.append(torch.zeros(1, vecs.shape[2], H, W, dtype=vecs.dtype) + 0 * vecs[i].sum())
+        else:
+            outs.append(boxes_to_layout_single(vecs[i][m], boxes[i][m], H, W))
+    return torch.cat(outs, dim=0)
+
+
+def flow_warp(img, flow):
+    """resample + get_grid (models/utils.py:113-140), ALIGN_CORNERS=False (data/args.py:228)."""
+    b, c, h, w = img.shape
+    hor = torch.linspace(-1.0, 1.0, w).view(1, 1, 1, w).expand(b, 1, h, w)
+    ver = torch.linspace(-1.0, 1.0, h).view(1, 1, h, 1).expand(b, 1, h, w)
+    grid = torch.cat([hor, ver], 1)
+    fl = torch.cat([flow[:, 0:1] / ((w - 1.0) / 2.0), flow[:, 1:2] / ((h - 1.0) / 2.0)], dim=1)
+    return F.grid_sample(img, (grid + fl).permute(0, 2, 3, 1), mode='bilinear', padding_mode='border', align_corners=False)
+
+
+def avgpool3s2(x):
+    """MultiscaleActionDiscriminator.downsample (discriminator.py:270-271)."""
+    return F.avg_pool2d(x, kernel_size=3, stride=2, padding=[1, 1], count_include_pad=False)
+
+
+def nearest_resize(x, OH, OW):
+    """F.interpolate(..., size, mode='nearest') (normalization.py:102, spade_generator.py:55)."""
+    return F.interpolate(x, size=(OH, OW), mode='nearest')
+
+
+def upsample2x(x):
+    """nn.Upsample(scale_factor=2) (spade_generator.py:36, flows_generator.py:47)."""
+    return F.interpolate(x, scale_factor=2, mode='nearest')
+
+
+def linear(x, w, b=None, relu=False):
+    """nn.Linear (+ReLU) of build_mlp (models/layers.py:6-25)."""
+    y = F.linear(x, w, b)
+    return F.relu(y) if relu else y
+
+
+def triple_gather(obj, pred, edges):
+    """graph.py:64-70."""
+    B = obj.shape[0]
+    s_idx, o_idx = edges[:, :, 0].contiguous(), edges[:, :, 1].contiguous()
+    cs = torch.stack([obj[b, s_idx[b], :] for b in range(B)])
+    co = torch.stack([obj[b, o_idx[b], :] for b in range(B)])
+    return torch.cat([cs, pred, co], dim=-1)
+
+
+def triple_pool(newt, edges, valid, O, Hd, Dp):
+    """graph.py:73-101 (avg pooling with masked triplets)."""
+    B, T = newt.shape[0], newt.shape[1]
+    new_s, new_o = newt[:, :, :Hd], newt[:, :, Hd + Dp:]
+    s_idx, o_idx = edges[:, :, 0].contiguous(), edges[:, :, 1].contiguous()
+    outs = []
+    for b in range(B):
+        ind = valid[b].bool()
+        ss, so = s_idx[b][ind], o_idx[b][ind]
+        ns, no = new_s[b][ind], new_o[b][ind]
+        pooled = torch.zeros(O, Hd, dtype=newt.dtype)
+        pooled = pooled.scatter_add(0, ss.view(-1, 1).expand_as(ns), ns)
+        pooled = pooled.scatter_add(0, so.view(-1, 1).expand_as(no), no)
+        counts = torch.zeros(O, dtype=newt.dtype)
+        ones = torch.ones(T, dtype=newt.dtype)
+        counts = counts.scatter_add(0, ss, ones)
+        counts = counts.scatter_add(0, so, ones)
+        mask = counts > 0
+        pooled = torch.where(mask.view(-1, 1), pooled / counts.clamp(min=1).view(-1, 1), pooled)
+        outs.append(pooled)
+    return torch.stack(outs, dim=0)
+
+
+def embedding(idx, table):
+    """nn.Embedding (attribute_embed.py:38-45)."""
+    return F.embedding(idx, table)
+
+
+def leaky_relu(x, slope=0.2):
+    return F.leaky_relu(x, slope)
+
+
+def tanh(x):
+    return torch.tanh(x)
+
+
+def l1_mean(a, b):
+    """nn.L1Loss (loss_model.py:31,39)."""
+    return F.l1_loss(a, b)
+
+
+def hinge_mean(x, kind):
+    """GANLoss.loss hinge branch (networks/loss.py:64-76)."""
+    if kind == 'g':
+        return -torch.mean(x)
+    if kind == 'd_real':
+        return -torch.mean(torch.min(x - 1, torch.zeros_like(x)))
+    return -torch.mean(torch.min(-x - 1, torch.zeros_like(x)))

@@ -1,0 +1,299 @@
+"""Parity of every HIP operator (through the C ABI, via ag2video_amd.ops) against the CPU oracle (oracle/kernels.py),
+forward and backward, on seeded inputs.
+
+Tolerance (stated once): max|got - ref| <= TOL * max|ref| with TOL = 2e-4 for every tensor compared -- an order tighter
+than BASELINE.json's 1e-3 relative fp32 bound, so that errors cannot pile up across the ~100 layers of the step.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-4
+
+
+def _cmp(name, got, ref, tol=TOL):
+    got = got.detach().cpu().double()
+    ref = ref.detach().cpu().double()
+    assert got.shape == ref.shape, "%s: shape %s vs %s" % (name, tuple(got.shape), tuple(ref.shape))
+    assert torch.isfinite(got).all(), "%s: non-finite output" % name
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item() + 1e-20
+    assert err <= tol * scale, "%s: max err %.3e, ref scale %.3e (rel %.2e)" % (name, err, scale, err / scale)
+
+
+def _run_pair(fn_gpu, fn_cpu, tensors, device, nondiff=(), name='op', tol=TOL, out_weights_seed=3):
+    """tensors: dict name -> cpu tensor (float tensors get grads unless listed in nondiff)."""
+    cpu_in, gpu_in = {}, {}
+    for k, t in tensors.items():
+        if torch.is_tensor(t):
+            diff = t.is_floating_point() and k not in nondiff
+            cpu_in[k] = t.clone().requires_grad_(diff)
+            gpu_in[k] = t.clone().to(device).requires_grad_(diff)
+        else:
+            cpu_in[k] = gpu_in[k] = t
+    ref = fn_cpu(**cpu_in)
+    got = fn_gpu(**gpu_in)
+    _cmp(name + '.fwd', got, ref, tol)
+    g = torch.Generator().manual_seed(out_weights_seed)
+    wgt = torch.randn(ref.shape, generator=g)
+    (ref * wgt).sum().backward()
+    (got * wgt.to(device)).sum().backward()
+    for k in tensors:
+        if torch.is_tensor(cpu_in[k]) and cpu_in[k].requires_grad:
+            assert gpu_in[k].grad is not None, "%s: no grad for %s" % (name, k)
+            _cmp(name + '.grad_' + k, gpu_in[k].grad, cpu_in[k].grad, tol)
+    return got, ref
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+CONV_CASES = [
+    # N, C, H, W, K, R, S, stride, pad, bias, residual
+    (2, 5, 9, 11, 7, 3, 3, 1, 1, True, False),
+    (2, 16, 16, 16, 40, 3, 3, 1, 1, True, True),
+    (1, 24, 20, 20, 130, 3, 3, 1, 1, False, False),
+    (2, 19, 17, 17, 8, 4, 4, 2, 2, True, False),
+    (2, 8, 9, 9, 16, 4, 4, 1, 2, True, False),
+    (2, 32, 8, 8, 16, 1, 1, 1, 0, False, False),
+    (1, 1027, 16, 16, 32, 3, 3, 1, 1, False, False),
+    (2, 8, 16, 16, 16, 3, 3, 2, 1, False, False),
+    (4, 64, 64, 64, 64, 3, 3, 1, 1, True, False),
+    (3, 259, 33, 33, 64, 4, 4, 2, 2, True, False),
+    (2, 130, 12, 12, 3, 3, 3, 1, 1, True, False),
+    (2, 3, 16, 16, 200, 3, 3, 1, 1, True, False),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv2d(case, device):
+    from ag2video_amd import ops
+    from oracle import kernels as K
+    N, C, H, W, Ko, R, S, st, pad, bias, res = case
+    x = _rand(N, C, H, W, seed=1)
+    w = _rand(Ko, C, R, S, seed=2, scale=(C * R * S) ** -0.5)
+    t = {'x': x, 'w': w, 'bias': _rand(Ko, seed=3) if bias else None, 'stride': st, 'pad': pad}
+    if res:
+        OH, OW = (H + 2 * pad - R) // st + 1, (W + 2 * pad - S) // st + 1
+        t['residual'] = _rand(N, Ko, OH, OW, seed=4)
+    else:
+        t['residual'] = None
+    _run_pair(ops.conv2d, K.conv2d, t, device, name='conv2d')
+
+
+@pytest.mark.parametrize("shape", [(40, 16, 3, 3), (130, 1027, 3, 3), (16, 8, 4, 4), (8, 16, 1, 1)])
+@pytest.mark.parametrize("training", [True, False])
+def test_spectral_weight(shape, training, device):
+    from ag2video_amd import ops
+    from oracle import kernels as K
+    w = _rand(*shape, seed=5, scale=0.1)
+    M, R = shape[0], shape[1] * shape[2] * shape[3]
+    u = torch.nn.functional.normalize(_rand(M, seed=6), dim=0)
+    v = torch.nn.functional.normalize(_rand(R, seed=7), dim=0)
+    uc, vc = u.clone(), v.clone()
+    ug, vg = u.clone().to(device), v.clone().to(device)
+    wc = w.clone().requires_grad_(True)
+    wg = w.clone().to(device).requires_grad_(True)
+    ref = K.spectral_weight(wc, uc, vc, training)
+    got = ops.spectral_weight(wg, ug, vg, training)
+    _cmp('sn.fwd', got, ref)
+    _cmp('sn.u', ug, uc)
+    _cmp('sn.v', vg, vc)
+    wgt = _rand(*shape, seed=8)
+    (ref * wgt).sum().backward()
+    (got * wgt.to(device)).sum().backward()
+    _cmp('sn.grad_w', wg.grad, wc.grad)
+    # a second call keeps iterating on the updated buffers
+    ref2 = K.spectral_weight(wc, uc, vc, training)
+    got2 = ops.spectral_weight(wg, ug, vg, training)
+    _cmp('sn.fwd2', got2, ref2)
+
+
+NORM_SHAPES = [(2, 8, 2, 2), (2, 16, 8, 8), (3, 5, 7, 9), (2, 4, 96, 96), (4, 33, 64, 64)]
+
+
+@pytest.mark.parametrize("shape", NORM_SHAPES, ids=str)
+@pytest.mark.parametrize("slope", [0.2, 1.0])
+def test_batchnorm_act(shape, slope, device):
+    from ag2video_amd import ops
+    from oracle import kernels as K
+    C = shape[1]
+    x = _rand(*shape, seed=1) * 1.7 + 0.6
+    t = {'x': x, 'weight': 1 + 0.1 * _rand(C, seed=2), 'bias': 0.1 * _rand(C, seed=3)}
+    rm_c, rv_c = torch.zeros(C), torch.ones(C)
+    rm_g, rv_g = torch.zeros(C, device=device), torch.ones(C, device=device)
+    _run_pair(lambda **k: ops.batchnorm_act(k['x'], k['weight'], k['bias'], rm_g, rv_g, True, 0.1, 1e-5, slope),
+              lambda **k: K.batchnorm_act(k['x'], k['weight'], k['bias'], rm_c, rv_c, True, 0.1, 1e-5, slope),
+              t, device, name='bn_act')
+    _cmp('bn.running_mean', rm_g, rm_c)
+    _cmp('bn.running_var', rv_g, rv_c)
+
+
+@pytest.mark.parametrize("shape", NORM_SHAPES, ids=str)
+@pytest.mark.parametrize("slope", [0.2, 1.0])
+def test_spade_norm(shape, slope, device):
+    from ag2video_amd import ops
+    from oracle import kernels as K
+    C = shape[1]
+    t = {'x': _rand(*shape, seed=1) * 1.3 - 0.4, 'gamma': 0.5 * _rand(*shape, seed=2), 'beta': 0.5 * _rand(*shape, seed=3)}
+    rm_c, rv_c = torch.zeros(C), torch.ones(C)
+    rm_g, rv_g = torch.zeros(C, device=device), torch.ones(C, device=device)
+    _run_pair(lambda **k: ops.spade_norm(k['x'], k['gamma'], k['beta'], rm_g, rv_g, True, 0.1, 1e-5, slope),
+              lambda **k: K.spade_norm(k['x'], k['gamma'], k['beta'], rm_c, rv_c, True, 0.1, 1e-5, slope),
+              t, device, name='spade')
+    _cmp('spade.running_mean', rm_g, rm_c)
+    _cmp('spade.running_var', rv_g, rv_c)
+
+
+def test_norm_eval_mode(device):
+    from ag2video_amd import ops
+    from oracle import kernels as K
+    x = _rand(2, 6, 8, 8, seed=1)
+    rm, rv = 0.2 * _rand(6, seed=2), 1 + 0.3 * torch.rand(6, generator=torch.Generator().manual_seed(3))
+    w, b = 1 + 0.1 * _rand(6, seed=4), 0.1 * _rand(6, seed=5)
+    ref = K.batchnorm_act(x, w, b, rm.clone(), rv.clone(), False, 0.1, 1e-5, 0.2)
+    got = ops.batchnorm_act(x.to(device), w.to(device), b.to(device), rm.to(device), rv.to(device), False, 0.1, 1e-5, 0.2)
+    _cmp('bn.eval', got, ref)
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 9, 9), (3, 16, 33, 33), (2, 4, 129, 129), (5, 7, 6, 5)], ids=str)
+def test_instnorm_lrelu(shape, device):
+    from ag2video_amd import ops
+    from oracle import kernels as K
+    t = {'x': _rand(*shape, seed=1) * 2 + 0.3}
+    _run_pair(ops.instnorm_lrelu, K.instnorm_lrelu, t, device, name='instnorm')
+
+
+def _boxes(BT, O, seed):
+    g = torch.Generator().manual_seed(seed)
+    w = 0.094 + (0.22 - 0.094) * torch.rand(BT, O, generator=g)
+    h = 0.125 + (0.29 - 0.125) * torch.rand(BT, O, generator=g)
+    x0 = torch.rand(BT, O, generator=g) * (1 - w)
+    y0 = torch.rand(BT, O, generator=g) * (1 - h)
+    return torch.stack([x0, y0, w, h], dim=-1)
+
+
+@pytest.mark.parametrize("cfg", [(3, 5, 16, 32, 32), (4, 11, 40, 64, 64), (2, 7, 520, 24, 40)], ids=str)
+def test_layout_render(cfg, device):
+    from ag2video_amd import ops
+    from oracle import kernels as K
+    BT, O, D, H, W = cfg
+    boxes = _boxes(BT, O, 11)
+    boxes[0, 1] = 0.0                       # an all-zero ("illegal") box is dropped (layout.py:40-42)
+    boxes[1, 0] = torch.tensor([0.0, 0.0, 1.0, 1.0])   # full-image box
+    boxes[BT - 1, O - 1] = -1.0             # collate padding
+    keep = torch.ones(BT, O, dtype=torch.int32)
+    keep[:, O - 1] = 0
+    keep[0, 2] = 0
+    t = {'vecs': _rand(BT, O, D, seed=12), 'boxes': boxes, 'keep': keep, 'H': H, 'W': W}
+    _run_pair(ops.layout_render, K.layout_render, t, device, nondiff=('boxes',), name='layout')
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 16, 16), (3, 3, 33, 20), (2, 3, 64, 64)], ids=str)
+@pytest.mark.parametrize("mag", [0.5, 6.0, 40.0])
+def test_flow_warp(shape, mag, device):
+    from ag2video_amd import ops
+    from oracle import kernels as K
+    N, C, H, W = shape
+    t = {'img': _rand(N, C, H, W, seed=1), 'flow': _rand(N, 2, H, W, seed=2) * mag}
+    _run_pair(ops.flow_warp, K.flow_warp, t, device, name='warp', tol=1e-3)
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 16, 16), (3, 4, 17, 9), (1, 2, 64, 64)], ids=str)
+def test_avgpool3s2(shape, device):
+    from ag2video_amd import ops
+    from oracle import kernels as K
+    _run_pair(ops.avgpool3s2, K.avgpool3s2, {'x': _rand(*shape, seed=1)}, device, name='avgpool')
+
+
+@pytest.mark.parametrize("cfg", [((2, 6, 64, 64), 2, 2), ((2, 6, 64, 64), 32, 32), ((1, 3, 32, 32), 64, 64),
+                                 ((2, 4, 48, 48), 16, 16), ((1, 2, 30, 20), 7, 9)], ids=str)
+def test_nearest_resize(cfg, device):
+    from ag2video_amd import ops
+    from oracle import kernels as K
+    shape, OH, OW = cfg
+    _run_pair(ops.nearest_resize, K.nearest_resize, {'x': _rand(*shape, seed=1), 'OH': OH, 'OW': OW}, device, name='nearest')
+
+
+def test_upsample2x(device):
+    from ag2video_amd import ops
+    from oracle import kernels as K
+    _run_pair(ops.upsample2x, K.upsample2x, {'x': _rand(2, 5, 9, 12, seed=1)}, device, name='up2x')
+
+
+@pytest.mark.parametrize("cfg", [(17, 516, 512, True, True), (136, 1152, 64, True, True), (88, 64, 4, False, True),
+                                 (5, 132, 70, True, False), (200, 128, 1152, True, True)], ids=str)
+def test_linear(cfg, device):
+    from ag2video_amd import ops
+    from oracle import kernels as K
+    M, Kd, N, relu, bias = cfg
+    t = {'x': _rand(M, Kd, seed=1), 'w': _rand(N, Kd, seed=2, scale=Kd ** -0.5), 'b': _rand(N, seed=3) if bias else None,
+         'relu': relu}
+    _run_pair(ops.linear, K.linear, t, device, name='linear')
+
+
+def _edges(B, T, O, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(0, O, (B, T, 2), generator=g, dtype=torch.int64)
+
+
+@pytest.mark.parametrize("cfg", [(2, 6, 9, 64, 128), (3, 11, 17, 512, 128), (1, 3, 1, 40, 24)], ids=str)
+def test_triple_gather(cfg, device):
+    from ag2video_amd import ops
+    from oracle import kernels as K
+    B, O, T, Din, Dp = cfg
+    t = {'obj': _rand(B, O, Din, seed=1), 'pred': _rand(B, T, Dp, seed=2), 'edges': _edges(B, T, O, 3)}
+    _run_pair(ops.triple_gather, K.triple_gather, t, device, name='gather')
+
+
+@pytest.mark.parametrize("cfg", [(2, 6, 9, 64, 128), (3, 11, 17, 512, 128), (2, 4, 5, 32, 16)], ids=str)
+def test_triple_pool(cfg, device):
+    from ag2video_amd import ops
+    from oracle import kernels as K
+    B, O, T, Hd, Dp = cfg
+    valid = torch.rand(B, T, generator=torch.Generator().manual_seed(5)) > 0.3
+    valid[0, :] = True
+    if B > 1:
+        valid[1, :] = False       # a sample whose edges are all padding: pooled stays zero
+    t = {'newt': _rand(B, T, 2 * Hd + Dp, seed=1), 'edges': _edges(B, T, O, 3), 'valid': valid, 'O': O, 'Hd': Hd, 'Dp': Dp}
+    _run_pair(ops.triple_pool, K.triple_pool, t, device, name='pool')
+
+
+def test_embedding(device):
+    from ag2video_amd import ops
+    from oracle import kernels as K
+    idx = torch.randint(0, 10, (3, 7), generator=torch.Generator().manual_seed(1))
+    t = {'idx': idx, 'table': _rand(10, 96, seed=2)}
+    _run_pair(ops.embedding, K.embedding, t, device, name='embedding')
+
+
+@pytest.mark.parametrize("n", [5, 1024, 70001])
+def test_activations(n, device):
+    from ag2video_amd import ops
+    from oracle import kernels as K
+    _run_pair(ops.leaky_relu, K.leaky_relu, {'x': _rand(n, seed=1), 'slope': 0.2}, device, name='lrelu')
+    _run_pair(ops.tanh, K.tanh, {'x': _rand(n, seed=1)}, device, name='tanh')
+
+
+@pytest.mark.parametrize("shape", [(7,), (2, 1, 35, 35), (3, 16, 65, 65)], ids=str)
+def test_losses(shape, device):
+    from ag2video_amd import ops
+    from oracle import kernels as K
+    a, b = _rand(*shape, seed=1), _rand(*shape, seed=2)
+    _run_pair(ops.l1_mean, K.l1_mean, {'a': a, 'b': b}, device, nondiff=('b',), name='l1')
+    for kind in ('g', 'd_real', 'd_fake'):
+        _run_pair(ops.hinge_mean, K.hinge_mean, {'x': a * 2, 'kind': kind}, device, name='hinge_' + kind)
+
+
+def test_errors_raise(device):
+    """Bad arguments and CPU tensors raise RuntimeError (never abort, never fall back)."""
+    from ag2video_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.conv2d(torch.randn(1, 3, 8, 8), torch.randn(4, 3, 3, 3))          # CPU tensors
+    with pytest.raises(RuntimeError):
+        ops.conv2d(torch.randn(1, 3, 8, 8, device=device), torch.randn(4, 5, 3, 3, device=device))  # channel mismatch
+    with pytest.raises(RuntimeError):
+        ops.layout_render(torch.randn(1, 40, 8, device=device), torch.rand(1, 40, 4, device=device),
+                          torch.ones(1, 40, dtype=torch.int32, device=device), 16, 16)  # > MAXO objects
