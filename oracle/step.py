@@ -1,0 +1,66 @@
+"""ORACLE (test infrastructure): the reference training iteration (scripts/train.py:440-493) over oracle/model.py.
+
+Used by tests (golden pinning, GPU end-to-end parity), __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+"""
+import json
+import os
+
+import torch
+
+from . import model as M
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class OracleTrainer(object):
+    def __init__(self, opt, key_shapes_G, key_shapes_D, wseed):
+        self.opt = opt
+        self.G = M.make_state(key_shapes_G, wseed, 'G.')
+        self.D = M.make_state(key_shapes_D, wseed, 'D.')
+        lr, b1 = opt.learning_rate, opt.beta1
+        graph_params = M.params_of(self.G, 'acts_to_boxes.')
+        gen_params = [t for n, t in self.G.items() if t.requires_grad and not n.startswith('acts_to_boxes.')]
+        self.opt_graph = torch.optim.Adam(graph_params, lr=lr, betas=(b1, 0.999))
+        self.opt_gen = torch.optim.Adam(gen_params, lr=lr, betas=(b1, 0.999))
+        self.opt_d = torch.optim.Adam(M.params_of(self.D), lr=lr, betas=(b1, 0.999))
+
+    def gd_step(self, batch, apply_updates=True):
+        """G step then D step on one clip batch; returns (model_out, G_losses, D_losses)."""
+        opt = self.opt
+        imgs, objs, boxes, triplets, actions = batch[:5]
+        model_out = M.generator_forward(self.G, opt, imgs, objs, triplets, actions, boxes, training=True, use_gt=True)
+        G_losses = M.generator_loss(self.D, opt, batch, model_out)
+        G_losses = {k: v.mean() for k, v in G_losses.items()}
+        self.opt_gen.zero_grad()
+        G_losses['total_loss'].backward()
+        self.last_G_grads = {n: (None if t.grad is None else t.grad.clone()) for n, t in self.G.items() if t.requires_grad}
+        if apply_updates:
+            self.opt_gen.step()
+        D_losses = M.discriminator_loss(self.D, opt, batch, model_out)
+        D_losses = {k: v.mean() for k, v in D_losses.items()}
+        self.opt_d.zero_grad()
+        D_losses['total_img_loss'].backward()
+        self.last_D_grads = {n: (None if t.grad is None else t.grad.clone()) for n, t in self.D.items() if t.requires_grad}
+        if apply_updates:
+            self.opt_d.step()
+        return model_out, G_losses, D_losses
+
+    def graph_step(self, batch, apply_updates=True):
+        imgs, objs, boxes, triplets, actions = batch[:5]
+        boxes_pred = M.generator_forward(self.G, self.opt, imgs, objs, triplets, actions, boxes, training=True, graph_only=True)
+        L = M.graph_loss(self.opt, batch, boxes_pred)
+        L = {k: v.mean() for k, v in L.items()}
+        self.opt_graph.zero_grad()
+        L['total_loss'].backward()
+        self.last_graph_grads = {n: (None if t.grad is None else t.grad.clone()) for n, t in self.G.items()
+                                 if t.requires_grad and n.startswith('acts_to_boxes.')}
+        if apply_updates:
+            self.opt_graph.step()
+        return boxes_pred, L
+
+
+def toy_key_shapes():
+    """state_dict key -> shape tables of the toy configuration (written by tests/golden/make_golden.py)."""
+    p = os.path.join(os.path.dirname(HERE), 'tests', 'golden', 'toy64_state_keys.json')
+    ks = json.load(open(p))
+    return ks['model'], ks['d_img'], ks['gans_model']

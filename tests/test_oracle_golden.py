@@ -1,0 +1,127 @@
+"""Pins the CPU oracle (oracle/model.py) against golden vectors produced by the unmodified reference modules
+(tests/golden/toy64_step.npz; generator script tests/golden/make_golden.py): two full training iterations
+(G step, D step, graph step) at the toy configuration 64x64, B=2, F=3.
+
+Tolerances: losses 2e-4 relative; output tensors max-abs error <= 2e-4 * max|ref|; gradient / post-step parameter
+statistics (abs-sum, L2) 2e-3 relative plus an absolute floor of 2e-6 per element (conv biases in front of a batch norm
+have an exactly-zero true gradient: what is stored there is rounding noise).  Gradients that pass through the optical
+-flow warp (every flows_network parameter) are held to 5e-2 only: d(warp)/d(flow) is piecewise constant in the sampling
+cell, and the same algorithm run in fp32 and in fp64 already differs by 1-3 % on them (measured: down_flow.0.1.bias
+abs-sum 2.749 fp32 / 2.840 fp64 / 2.759 reference), so a tighter bound would test the rounding, not the restatement.  Full gradient tensors are compared at 5e-3 of their
+max: the L1 / hinge / LeakyReLU derivatives are sign functions, so ulp-level forward differences flip individual terms.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, 'golden', 'toy64_step.npz')
+
+
+@pytest.fixture(scope='module')
+def gold():
+    return np.load(GOLD, allow_pickle=False)
+
+
+def _opt(gold):
+    from ag2video_amd.data.args import make_opt
+    from ag2video_amd.data.vocab import cater_vocab
+    flags = json.loads(str(gold['meta.flags']))
+    return make_opt(cater_vocab(), flags), json.loads(str(gold['meta.toy']))
+
+
+def _stats(t):
+    t = t.detach().double()
+    return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().sqrt().item()])
+
+
+def _close_stats(name, got, ref, rel=2e-3, numel=1, per_elem=2e-6):
+    if 'flows_network' in name and 'grad' in name:
+        rel = 5e-2
+    floors = (0.0, per_elem * numel, per_elem * numel ** 0.5)
+    for i in (1, 2):
+        assert abs(got[i] - ref[i]) <= rel * abs(ref[i]) + floors[i], "%s stat %d: %r vs %r" % (name, i, got, ref)
+
+
+def _close(name, got, ref, tol=2e-4):
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, name
+    err = np.abs(got - ref).max()
+    assert err <= tol * (np.abs(ref).max() + 1e-12), "%s: err %.3e scale %.3e" % (name, err, np.abs(ref).max())
+
+
+def test_state_key_tables():
+    from oracle.step import toy_key_shapes
+    g, d, lm = toy_key_shapes()
+    assert len(g) == 492 and len(d) == 56 and len(lm) == 112      # SURVEY.md 8b [probe]
+
+
+def test_oracle_matches_reference_two_iterations(gold):
+    torch.set_num_threads(8)
+    from ag2video_amd.data.synthetic import make_clip_batch
+    from oracle.step import OracleTrainer, toy_key_shapes
+    opt, toy = _opt(gold)
+    kg, kd, _ = toy_key_shapes()
+    tr = OracleTrainer(opt, kg, kd, toy['wseed'])
+    for it in range(2):
+        batch = make_clip_batch(opt.vocab, toy['batch'], toy['frames'], tuple(toy['size']), seed=toy['seed'] + it)
+        model_out, GL, DL = tr.gd_step(batch)
+        p = 'it%d.' % it
+        ltol = 2e-4 if it == 0 else 1e-3   # iteration 1 starts from Adam-updated weights (sign-of-gradient steps)
+        for k, v in GL.items():
+            ref = float(gold[p + 'G_loss.' + k])
+            assert abs(v.item() - ref) <= ltol * max(1.0, abs(ref)), (p, k, v.item(), ref)
+        for k, v in DL.items():
+            ref = float(gold[p + 'D_loss.' + k])
+            assert abs(v.item() - ref) <= ltol * max(1.0, abs(ref)), (p, k, v.item(), ref)
+        if it == 0:
+            imgs_pred, boxes_pred, flows, conf, adata = model_out
+            _close('imgs_pred', imgs_pred.detach().numpy(), gold['imgs_pred'])
+            _close('boxes_pred', boxes_pred.detach().numpy(), gold['boxes_pred'])
+            _close('flows_pred', flows.detach().numpy(), gold['flows_pred'], 5e-4)
+            assert np.mean(conf.numpy() != gold['conf_pred']) < 1e-3
+            assert (adata[1].numpy() == gold['temporal_triplets']).all()
+            _close('relative_timesteps', adata[2].numpy(), gold['relative_timesteps'], 1e-6)
+            for n, g in tr.last_G_grads.items():
+                key = 'G_grad.' + n
+                if g is None:
+                    assert key not in gold.files, n
+                    continue
+                if key in gold.files:
+                    _close_stats(key, _stats(g), gold[key], 2e-3, g.numel())
+            L2V = 'layout_to_video.module.'
+            _close('grad conv_img', tr.last_G_grads[L2V + 'netG.conv_img.weight'].numpy(),
+                   gold['G_grad_full.netG.conv_img.weight'], 5e-3)
+            _close('grad up_3.conv_1', tr.last_G_grads[L2V + 'netG.up_3.conv_1.weight_orig'].numpy(),
+                   gold['G_grad_full.up_3.conv_1.weight_orig'], 5e-3)
+            _close('grad acts_embeddings', tr.last_G_grads['acts_to_objs.module.acts_embeddings.weight'].numpy(),
+                   gold['G_grad_full.acts_to_objs.acts_embeddings'], 5e-3)
+            _close('grad conv_flow', tr.last_G_grads[L2V + 'flows_network.conv_flow.0.weight'].numpy(),
+                   gold['G_grad_full.flows.conv_flow.weight'], 5e-2)
+            for n, g in tr.last_D_grads.items():
+                key = 'D_grad.' + n
+                if g is not None and key in gold.files:
+                    _close_stats(key, _stats(g), gold[key], 2e-3, g.numel())
+            _close('grad D model4', tr.last_D_grads['discriminator_1.model4.0.weight'].numpy(),
+                   gold['D_grad_full.discriminator_1.model4.0.weight'], 5e-3)
+        gb = make_clip_batch(opt.vocab, toy['batch'], toy['graph_frames'], tuple(toy['size']), seed=toy['seed'] + 100 + it)
+        boxes_pred_g, GGL = tr.graph_step(gb)
+        for k, v in GGL.items():
+            ref = float(gold[p + 'graph_loss.' + k])
+            assert abs(v.item() - ref) <= ltol * max(1.0, abs(ref)), (p, k, v.item(), ref)
+        if it == 0:
+            _close('graph.boxes_pred', boxes_pred_g.detach().numpy(), gold['graph.boxes_pred'])
+        # parameters, spectral-norm u/v and BN running statistics after the optimizer steps.  Adam's first updates are
+        # +-lr per element whatever the gradient's size, so a parameter whose true gradient is zero (a conv bias in front
+        # of a batch norm: its stored gradient is rounding noise) moves by lr in a noise-determined direction: the
+        # per-element floor is lr per step taken.
+        adam_floor = 1.2 * opt.learning_rate * (it + 1)
+        srel = 1e-3 if it == 0 else 5e-3      # iteration 1 inherits iteration 0's sign-flip differences
+        for n, t in tr.G.items():
+            _close_stats(p + 'G_state.' + n, _stats(t.float()), gold[p + 'G_state.' + n], srel, t.numel(), adam_floor)
+        for n, t in tr.D.items():
+            _close_stats(p + 'D_state.' + n, _stats(t.float()), gold[p + 'D_state.' + n], srel, t.numel(), adam_floor)
