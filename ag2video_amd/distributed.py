@@ -1,0 +1,86 @@
+"""Multi-GPU data parallelism: one process per GPU, torch.distributed over RCCL/xGMI ("nccl" backend on ROCm).
+
+The reference is single-process torch.nn.DataParallel: every forward broadcasts all parameters from GPU 0 (518 MB for G)
+and every backward reduce-adds all gradients onto GPU 0.  Here replicas stay resident; the only
+data-path collective is one gradient all-reduce per optimizer step, issued over flat buckets sized for the
+point-to-point xGMI fabric (7 links x ~153 GB/s per GPU: large buckets amortise the per-collective latency, and
+RCCL stripes a large all-reduce over all links).  The step's compute is seconds while 500 MB of gradients take
+~1-6 ms, so buckets are reduced right after backward on the compute stream (DESIGN.md "Multi-GPU").
+Batch-norm statistics stay per process (per-GPU batch of 8 clips): see sync_batchnorm.py.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+BUCKET_BYTES = 128 << 20
+
+
+def is_dist():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from torchrun's environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not (dist.is_available() and dist.is_initialized()):
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def _buckets(tensors, bucket_bytes):
+    cur, size = [], 0
+    for t in tensors:
+        n = t.numel() * t.element_size()
+        if cur and size + n > bucket_bytes:
+            yield cur
+            cur, size = [], 0
+        cur.append(t)
+        size += n
+    if cur:
+        yield cur
+
+
+@torch.no_grad()
+def average_gradients(params, bucket_bytes=BUCKET_BYTES):
+    """grad <- mean over ranks, through flat fp32 buckets (one all-reduce per bucket).  No-op on a single process."""
+    if not is_dist():
+        return
+    world = dist.get_world_size()
+    grads = [p.grad for p in params if p.grad is not None]
+    for bucket in _buckets(grads, bucket_bytes):
+        flat = torch.cat([g.reshape(-1) for g in bucket])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(world)
+        off = 0
+        for g in bucket:
+            n = g.numel()
+            g.copy_(flat[off:off + n].view_as(g))
+            off += n
+
+
+@torch.no_grad()
+def broadcast_parameters(tensors, src=0):
+    """Make every rank start from rank 0's parameters and buffers (the reference re-broadcasts every forward)."""
+    if not is_dist():
+        return
+    for t in tensors:
+        if t.is_floating_point() or t.dtype in (torch.int64, torch.int32):
+            dist.broadcast(t, src=src)
+
+
+def max_over_ranks(value, device):
+    if not is_dist():
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

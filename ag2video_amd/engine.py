@@ -1,0 +1,81 @@
+"""One training iteration of the reference loop (scripts/train.py:362-375,440-493) as a reusable object.
+
+Builds the three pieces the reference's ``main`` builds -- ``AG2VideoModel``, ``MetaDiscriminatorModel`` (with its Adam)
+and ``LossModel`` wrapped in ``DataParallelWithCallback`` -- plus the generator / graph optimizers with the reference's
+parameter partition (train.py:365-368), and exposes the G step, D step and graph step in the reference's order.
+scripts/train.py, bench.py, __graft_entry__.smoke() and the tests all drive this object.
+"""
+import torch
+
+from . import distributed as dist_utils
+from .models.meta_models import AG2VideoModel, MetaDiscriminatorModel
+from .models.spade_models.loss_model import LossModel
+from .models.spade_models.networks.sync_batchnorm import DataParallelWithCallback
+from .models.utils import batch_to
+
+
+class TrainStep(object):
+    def __init__(self, opt, device, weights_seed=None):
+        self.opt = opt
+        self.device = device
+        self.model = AG2VideoModel(opt, device)
+        self.model.float()
+        self.discriminator = MetaDiscriminatorModel(opt)
+        self.discriminator.to(device)
+        self.gans_model = DataParallelWithCallback(LossModel(opt, discriminator=self.discriminator),
+                                                   device_ids=opt.gpu_ids).to(device)
+        if weights_seed is not None:
+            from .weights import closed_form_fill_
+            closed_form_fill_(self.model, seed=weights_seed, prefix='G.')
+            closed_form_fill_(self.discriminator.img_discriminator, seed=weights_seed, prefix='D.')
+        lr, b1 = opt.learning_rate, opt.beta1
+        graph_params = list(self.model.acts_to_boxes.parameters())
+        graph_ids = set(id(p) for p in graph_params)
+        gen_params = [p for p in self.model.parameters() if id(p) not in graph_ids]   # train.py:367
+        self.optimizer_graph = torch.optim.Adam(graph_params, lr=lr, betas=(b1, 0.999))
+        self.optimizer_generator = torch.optim.Adam(gen_params, lr=lr, betas=(b1, 0.999))
+        # the discriminator's Adam was built before .to(device); rebuild it over the moved parameters
+        self.discriminator.optimizer_d_img = torch.optim.Adam(list(self.discriminator.img_discriminator.parameters()),
+                                                              lr=lr, betas=(b1, 0.999))
+        self._gen_params, self._graph_params = gen_params, graph_params
+        self._d_params = list(self.discriminator.img_discriminator.parameters())
+        for m in (self.model, self.discriminator):
+            m.train()
+        dist_utils.broadcast_parameters(list(self.model.parameters()) + self._d_params +
+                                        list(self.model.buffers()) + list(self.discriminator.buffers()))
+
+    def to_device(self, batch):
+        return batch_to(batch, self.device)
+
+    def gd_step(self, batch, apply_updates=True):
+        """Generator step then discriminator step on one clip batch (train.py:446-464, 522-525)."""
+        imgs, objs, boxes, triplets, actions, video_id = batch
+        model_out = self.model(imgs, objs, triplets, actions, boxes_gt=boxes, test_mode=False, use_gt=True)
+        G_losses = self.gans_model(batch, model_out, mode="compute_generator_loss")
+        G_losses = {k: v.mean() for k, v in G_losses.items()}
+        self.optimizer_generator.zero_grad()
+        G_losses["total_loss"].backward()
+        dist_utils.average_gradients(self._gen_params)
+        if apply_updates:
+            self.optimizer_generator.step()
+        D_losses = self.gans_model(batch, model_out, mode="compute_discriminator_loss")
+        D_losses = {k: v.mean() for k, v in D_losses.items()}
+        self.discriminator.optimizer_d_img.zero_grad()
+        D_losses["total_img_loss"].backward()
+        dist_utils.average_gradients(self._d_params)
+        if apply_updates:
+            self.discriminator.optimizer_d_img.step()
+        return model_out, G_losses, D_losses
+
+    def graph_step(self, batch, apply_updates=True):
+        """Box-prediction step on a (longer) clip (train.py:483-493)."""
+        imgs, objs, boxes, triplets, actions, video_id = batch
+        boxes_pred = self.model(imgs, objs, triplets, actions, boxes_gt=boxes, test_mode=False, graph_only=True)
+        L = self.gans_model(batch, boxes_pred, mode="compute_graph_loss")
+        L = {k: v.mean() for k, v in L.items()}
+        self.optimizer_graph.zero_grad()
+        L["total_loss"].backward()
+        dist_utils.average_gradients(self._graph_params)
+        if apply_updates:
+            self.optimizer_graph.step()
+        return boxes_pred, L

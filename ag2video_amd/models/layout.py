@@ -1,0 +1,30 @@
+"""Box -> layout rendering (reference: models/layout.py:28-63 boxes_to_layout and the b x t Python loops that call it,
+generator.py:37-54, discriminator.py:321-336)."""
+import torch
+
+from .. import ops
+from .utils import remove_dummy_objects
+
+
+def boxes_to_layout(vecs, boxes, H, W=None, keep=None):
+    """Single frame: vecs [O, D], boxes [O, 4] (x0, y0, w, h in [0,1]) -> [1, D, H, W]."""
+    W = H if W is None else W
+    if keep is None:
+        keep = torch.ones(vecs.shape[0], dtype=torch.int32, device=vecs.device)
+    return ops.layout_render(vecs.unsqueeze(0), boxes.unsqueeze(0), keep.unsqueeze(0), H, W)
+
+
+def render_clip_layouts(vecs, boxes, objs, vocab, H, W, frame_major=True):
+    """All (sample, frame) layouts of a clip in ONE launch.
+
+    vecs [B, F, O, D], boxes [B, F, O, 4], objs [B, O, A] -> list of F tensors [B, D, H, W] (frame_major) so that every
+    frame is a contiguous NCHW tensor and the per-frame-step concatenations never touch the other frames.
+    Dummy objects (padding / __image__) are masked with ``remove_dummy_objects`` as at generator.py:39-44 -- as a mask
+    handed to the kernel instead of boolean indexing (which forces a device->host sync in the reference)."""
+    B, Fr, O, D = vecs.shape
+    keep = remove_dummy_objects(objs, vocab)                       # [B, O]
+    keep = keep.unsqueeze(0).expand(Fr, B, O).reshape(Fr * B, O).to(torch.int32)
+    v = vecs.transpose(0, 1).reshape(Fr * B, O, D)
+    b = boxes.transpose(0, 1).reshape(Fr * B, O, 4)
+    out = ops.layout_render(v, b, keep, H, W)                      # [F*B, D, H, W]
+    return list(out.view(Fr, B, D, H, W).unbind(0))

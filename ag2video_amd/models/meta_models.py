@@ -1,0 +1,52 @@
+"""Model facade with the reference's module surface (reference: models/meta_models.py:9-72).
+
+``AG2VideoModel(opt, device)`` and ``MetaDiscriminatorModel(opt)`` expose the same attributes, forward signature,
+return tuples and state_dict keys (492 / 56 keys at any width) as the reference, so scripts/train.py's loop drives them
+unchanged; underneath, every layer runs on the gfx950 HIP kernels of ag2video_amd/csrc.
+"""
+import torch
+import torch.nn as nn
+
+from .graph_models.model import models
+from .spade_models.networks.discriminator import MultiscaleActionDiscriminator
+from .spade_models.networks.generator import Layout2VidGenerator
+from .spade_models.networks.sync_batchnorm import DataParallelWithCallback
+
+
+class AG2VideoModel(nn.Module):
+    def __init__(self, opt, device):
+        super().__init__()
+        self.args = vars(opt)
+        self.vocab = self.args["vocab"]
+        ids = self.args['gpu_ids']
+        self.acts_to_boxes = DataParallelWithCallback(models[self.args["layout_arch"]](opt), device_ids=ids).to(device)
+        if not self.args.get("coupled_motion_apperance"):
+            objs_model = "graph" if self.args["layout_arch"] == 'gt_layout' else self.args["layout_arch"]
+            self.acts_to_objs = DataParallelWithCallback(models[objs_model](opt), device_ids=ids).to(device)
+        self.layout_to_video = DataParallelWithCallback(Layout2VidGenerator(opt), device_ids=ids).to(device)
+
+    def forward(self, imgs, objs, triplets, actions, boxes_gt=None, test_mode=False, use_gt=False, graph_only=False):
+        """-> (imgs_pred, boxes_pred, flows_pred, conf_pred, actions_data), or boxes_pred when graph_only."""
+        obj_vecs, boxes_pred, actions_data = self.acts_to_boxes(objs, triplets, actions, boxes_gt, test_mode=test_mode)
+        if graph_only:
+            return boxes_pred
+        if not self.args.get("coupled_motion_apperance"):
+            # default: motion (boxes) and appearance (object vectors) come from two separately parameterised nets
+            obj_vecs, _, actions_data = self.acts_to_objs(objs, triplets, actions, boxes_gt, test_mode=test_mode)
+        boxes_in = boxes_gt if use_gt else boxes_pred.detach()
+        imgs_pred, flows_pred, conf_pred = self.layout_to_video(imgs, objs, obj_vecs, boxes_in, test_mode=test_mode)
+        return imgs_pred, boxes_pred, flows_pred, conf_pred, actions_data
+
+
+class MetaDiscriminatorModel(nn.Module):
+    def __init__(self, opt):
+        super().__init__()
+        self.args = vars(opt)
+        self.init_act_discriminator(opt)
+
+    def init_act_discriminator(self, opt):
+        self.img_discriminator = MultiscaleActionDiscriminator(opt)
+        self.img_discriminator.float()
+        self.img_discriminator.train()
+        self.optimizer_d_img = torch.optim.Adam(list(self.img_discriminator.parameters()), lr=opt.learning_rate,
+                                                betas=(opt.beta1, 0.999))

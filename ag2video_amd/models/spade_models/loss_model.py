@@ -1,0 +1,106 @@
+"""Loss facade (reference: models/spade_models/loss_model.py:14-149)."""
+import contextlib
+
+import torch
+import torch.nn.functional as F
+
+from ... import ops
+from ..utils import resample
+from .networks.loss import GANLoss
+
+
+@contextlib.contextmanager
+def _params_frozen(module):
+    """The generator step back-propagates *through* the discriminator; the gradients it would deposit in the
+    discriminator's own parameters are discarded by optimizer_d_img.zero_grad() before they are ever read
+    (scripts/train.py:457-459,522-524), so their weight-gradient kernels are skipped altogether."""
+    ps = [p for p in module.parameters() if p.requires_grad]
+    for p in ps:
+        p.requires_grad_(False)
+    try:
+        yield
+    finally:
+        for p in ps:
+            p.requires_grad_(True)
+
+
+class LossModel(torch.nn.Module):
+    def __init__(self, opt, discriminator):
+        super().__init__()
+        self.opt = opt
+        self.n_frames_G = opt.n_frames_G
+        self.n_frames_D = opt.n_frames_D
+        self.discriminator = discriminator
+        if hasattr(discriminator, 'img_discriminator'):
+            self.netD_img = discriminator.img_discriminator
+        self.criterionGAN = GANLoss(opt.gan_mode, opt=opt)
+        if not opt.no_vgg_loss:
+            raise NotImplementedError("VGG perceptual loss needs pretrained VGG19 weights (no network here); "
+                                      "run with --no_vgg_loss (SURVEY.md 2.1 row 6)")
+
+    def compute_graph_loss(self, batch, boxes_pred):
+        """Masked smooth-L1 on predicted boxes (loss_model.py:41-60); a few thousand elements: host-side torch ops."""
+        imgs, objs, boxes, triplets, actions, video_id = batch
+        bp = boxes_pred[:, 1:].contiguous().view(-1, 4)
+        bg = boxes[:, 1:].contiguous().view(-1, 4)
+        flat = F.smooth_l1_loss(bp, bg, reduction='none') * self.opt.bbox_pred_loss_weight
+        fo = objs.unsqueeze(1).repeat(1, boxes.size(1) - 1, 1, 1).view(-1, objs.size(-1))
+        if objs.size(-1) > 1:
+            mask = (fo.sum(1) != 0).repeat(4, 1).permute(1, 0)
+        else:
+            mask = (fo != 0)
+        G = {"bbox_pred": (flat * mask.to(flat.dtype)).mean()}
+        G['total_loss'] = torch.stack(list(G.values()), dim=0).sum()
+        return G
+
+    def compute_generator_loss(self, batch, model_out):
+        imgs, objs, boxes, triplets, actions, video_id = batch
+        imgs_pred, boxes_pred, flows_pred, conf_pred, actions_data = model_out
+        nc = self.n_frames_G - 1
+        r_imgs, r_boxes, r_pred = imgs[:, nc:], boxes[:, nc:], imgs_pred[:, nc:]
+        r_adata = [item[:, nc:] for item in actions_data]
+        G = {}
+        with _params_frozen(self.netD_img):
+            fake = self.netD_img(r_pred, objs, r_boxes, r_adata)
+        G['GAN_Img'] = self.criterionGAN(fake, True, for_discriminator=False).squeeze(0) * \
+            self.opt.discriminator_img_loss_weight
+        if not self.opt.no_ganFeat_loss:
+            with torch.no_grad():           # the real features are only used detached (loss_model.py:84)
+                real = self.netD_img(r_imgs, objs, r_boxes, r_adata)
+            num_D = len(fake)
+            feat = torch.zeros(1, device=imgs.device, dtype=torch.float32)
+            for i in range(num_D):
+                for j in range(len(fake[i]) - 1):
+                    feat = feat + ops.l1_mean(fake[i][j], real[i][j].detach()) * self.opt.lambda_feat / num_D
+            G['GAN_Feat'] = feat.squeeze(0)
+        b, t, c, h, w = imgs.size()
+        prev = imgs[:, nc - 1:-1].contiguous().view(-1, c, h, w)
+        nxt = imgs[:, nc:].contiguous().view(-1, c, h, w)
+        fl = flows_pred[:, nc - 1:-1].contiguous().view(-1, 2, h, w)
+        G["loss_F_Warp"] = ops.l1_mean(resample(prev, fl), nxt) * self.opt.lambda_F_warp
+        G['total_loss'] = torch.stack(list(G.values()), dim=0).sum()
+        return G
+
+    def compute_discriminator_loss(self, batch, model_out):
+        imgs, objs, boxes, triplets, actions, _ = batch
+        imgs_pred, boxes_pred, flows_pred, conf_pred, actions_data = model_out
+        nc = self.n_frames_G - 1
+        r_adata = [item[:, nc:] for item in actions_data]
+        fake = self.netD_img(imgs_pred[:, nc:].detach(), objs, boxes[:, nc:], r_adata)
+        real = self.netD_img(imgs[:, nc:], objs, boxes[:, nc:], r_adata)
+        D = {"D_img_fake": self.criterionGAN(fake, False, for_discriminator=True),
+             "D_img_real": self.criterionGAN(real, True, for_discriminator=True)}
+        D["total_img_loss"] = torch.stack(list(D.values()), dim=0).sum()
+        return D
+
+    def use_gpu(self):
+        return len(self.opt.gpu_ids) > 0
+
+    def forward(self, batch, model_out, mode):
+        if mode == "compute_discriminator_loss":
+            return self.compute_discriminator_loss(batch, model_out)
+        if mode == "compute_generator_loss":
+            return self.compute_generator_loss(batch, model_out)
+        if mode == "compute_graph_loss":
+            return self.compute_graph_loss(batch, model_out)
+        raise ValueError("unknown LossModel mode %r" % (mode,))

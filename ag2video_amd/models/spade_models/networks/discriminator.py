@@ -1,0 +1,120 @@
+"""Action-conditioned multiscale PatchGAN discriminator
+(reference: networks/discriminator.py:212-399, the only discriminator classes training instantiates)."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .... import ops
+from ...attribute_embed import AttributeEmbeddings
+from ...graph_models.graph import GraphTripleConv
+from ...graph_models.model import action_edge_vectors
+from ...layers import Conv2d, Embedding, FusedMLP, Linear
+from ...layout import render_clip_layouts
+from .normalization import get_nonspade_norm_layer
+
+
+class NLayerActionDiscriminator(nn.Module):
+    """PatchGAN: conv4x4 s2 + lrelu; (SN-conv4x4 + InstanceNorm + lrelu) x (n_layers_D-1); conv4x4 -> 1 channel.
+    Children are model0..model{n}: same nesting (hence state_dict keys) as discriminator.py:357-384."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        kw = 4
+        padw = int(np.ceil((kw - 1.0) / 2))
+        nf = opt.ndf
+        input_nc = self.compute_D_input_nc()
+        norm_layer = get_nonspade_norm_layer(opt, opt.norm_D)
+        sequence = [[Conv2d(input_nc, nf, kernel_size=kw, stride=2, padding=padw), nn.LeakyReLU(0.2, False)]]
+        for n in range(1, opt.n_layers_D):
+            nf_prev, nf = nf, min(nf * 2, 512)
+            stride = 1 if n == opt.n_layers_D - 1 else 2
+            sequence += [[norm_layer(nn.Conv2d(nf_prev, nf, kernel_size=kw, stride=stride, padding=padw)),
+                          nn.LeakyReLU(0.2, False)]]
+        sequence += [[Conv2d(nf, 1, kernel_size=kw, stride=1, padding=padw)]]
+        for n in range(len(sequence)):
+            self.add_module('model' + str(n), nn.Sequential(*sequence[n]))
+
+    def compute_D_input_nc(self):
+        emb = self.opt.gconv_dim if self.opt.use_actions_loss else self.opt.semantic_nc
+        return emb * 2 + 3
+
+    def forward(self, x):
+        results = []
+        for sub in self.children():
+            first = sub[0]
+            if isinstance(first, nn.Sequential):            # SN conv -> instance norm (+ fused LeakyReLU)
+                x = first[1](first[0](x), slope=0.2)
+            else:
+                x = first(x)
+                if len(sub) > 1:                            # model0: conv + LeakyReLU
+                    x = ops.leaky_relu(x, 0.2)
+            results.append(x)
+        if not self.opt.no_ganFeat_loss:
+            return results
+        return results[-1]
+
+
+class MultiscaleActionDiscriminator(nn.Module):
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        for i in range(opt.num_D):
+            self.add_module('discriminator_%d' % i, NLayerActionDiscriminator(opt))
+        emb = opt.embedding_dim
+        self.attribute_embedding = AttributeEmbeddings(opt.vocab['attributes'], emb)
+        self.pred_embeddings = Embedding(len(opt.vocab['pred_idx_to_name']), emb)
+        self.acts_embeddings = Embedding(len(opt.vocab['action_idx_to_name']), emb)
+        num_attributes = len(opt.vocab['attributes'].keys())
+        obj_input_dim = num_attributes * emb
+        first = dict(obj_input_dim=obj_input_dim, object_output_dim=opt.gconv_dim, predicate_input_dim=emb,
+                     predicate_output_dim=opt.gconv_dim, hidden_dim=opt.gconv_hidden_dim, num_attributes=num_attributes,
+                     mlp_normalization=opt.mlp_normalization, pooling=opt.gconv_pooling, loc_dim=4)
+        general = dict(first, obj_input_dim=first["object_output_dim"], predicate_input_dim=opt.gconv_dim)
+        self.gconvs = nn.ModuleList([GraphTripleConv(**first), GraphTripleConv(**general)])
+        self.obj_vecs_net = FusedMLP(Linear(emb + 4, obj_input_dim, bias=False), nn.ReLU(inplace=True),
+                                     Linear(obj_input_dim, obj_input_dim, bias=False), nn.ReLU())
+        self.pre_obj_vecs_net = FusedMLP(Linear(obj_input_dim, emb, bias=False), nn.ReLU(inplace=True),
+                                         Linear(emb, emb, bias=False), nn.ReLU())
+        self.fc_objs_vecs = Linear(opt.gconv_dim + opt.semantic_nc, opt.gconv_dim * 2)
+
+    def downsample(self, x):
+        return ops.avgpool3s2(x)
+
+    def get_obj_vecs(self, objs, layout_boxes, actions_data):
+        """Recurrent 2-layer graph net over action edges only (discriminator.py:273-313)."""
+        triplets, temporal_triplets, rel, locs = actions_data
+        x_end, y_end = locs[:, :, :, 0], locs[:, :, :, 1]
+        pad = self.opt.vocab["action_name_to_idx"]["__padding__"]
+        ov = self.pre_obj_vecs_net(self.attribute_embedding(objs))
+        out = []
+        for t in range(layout_boxes.size(1)):
+            at = temporal_triplets[:, t]
+            ov = self.obj_vecs_net(torch.cat([ov, layout_boxes[:, t]], dim=-1))
+            s, a, o = at[..., 0], at[..., 1], at[..., 2]
+            edges = torch.stack([s, o], dim=-1).long()
+            ind = a != pad
+            pv = action_edge_vectors(self.acts_embeddings, a, x_end[:, t], y_end[:, t], rel[:, t])
+            for gconv in self.gconvs:
+                ov, pv = gconv(ov, pv, edges, ind)
+            out.append(ov)
+        return torch.stack(out, dim=1)
+
+    def forward(self, img, objs, layout_boxes, actions_data):
+        """img [B,T,3,H,W], layout_boxes [B,T,O,4] -> num_D lists of n_layers_D+1 feature maps over [B*T, ...]."""
+        H = self.opt.image_size[0]
+        ov = self.get_obj_vecs(objs, layout_boxes, actions_data)
+        att = self.attribute_embedding(objs)
+        B, T = ov.size(0), ov.size(1)
+        v = self.fc_objs_vecs(torch.cat([att.unsqueeze(1).expand(B, T, att.size(1), att.size(2)), ov], dim=-1))
+        segs = render_clip_layouts(v, layout_boxes, objs, self.opt.vocab, H, H, frame_major=True)   # T x [B, 256, H, W]
+        seg = torch.stack(segs, dim=1)                                                              # [B, T, 256, H, W]
+        x = torch.cat([img, seg], dim=2)
+        x = x.view(B * T, x.size(2), H, H)
+        result = []
+        for name, D in self.named_children():
+            if name.startswith('discriminator'):
+                out = D(x)
+                result.append(out if not self.opt.no_ganFeat_loss else [out])
+                x = self.downsample(x)
+        return result

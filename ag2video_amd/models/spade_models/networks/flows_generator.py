@@ -1,0 +1,74 @@
+"""Optical-flow generator (reference: networks/flows_generator.py:14-109)."""
+import torch.nn as nn
+
+from .... import ops
+from ...layers import Conv2d
+from .normalization import SpectralConv2d, get_nonspade_norm_layer
+from .sync_batchnorm import SynchronizedBatchNorm2d
+
+
+class FlowResnetBlock(nn.Module):
+    """The non-SPADE ``SPADEResnetBlock`` of flows_generator.py:71-109 with norm='spectralsyncbatch':
+    BN -> lrelu -> SN-conv3x3 (twice) + identity shortcut (fin == fout, stride 1 at every call site)."""
+
+    def __init__(self, fin, fout):
+        super().__init__()
+        assert fin == fout, "flow residual blocks are square (flows_generator.py:40-42)"
+        fhidden = min(fin, fout)
+        self.conv_0 = SpectralConv2d(fin, fhidden, 3, stride=1, padding=1)
+        self.conv_1 = SpectralConv2d(fhidden, fout, 3, padding=1)
+        self.bn_0 = SynchronizedBatchNorm2d(fin)
+        self.bn_1 = SynchronizedBatchNorm2d(fhidden)
+
+    def forward(self, x):
+        dx = self.conv_0(self.bn_0(x, slope=0.2))
+        return self.conv_1(self.bn_1(dx, slope=0.2), residual=x)
+
+
+class FlowsGenerator(nn.Module):
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        nc = opt.n_frames_G - 1
+        input_nc = (opt.gconv_dim * 4) * opt.n_frames_G + nc * 3
+        self.flow_multiplier = opt.flow_multiplier
+        nf, nd = opt.nff, opt.n_downsample_F
+        ch = [min(1024, nf * (2 ** i)) for i in range(nd + 1)]
+        if opt.flow_deconv:
+            raise NotImplementedError("--flow_deconv (ConvTranspose2d) is not the default path (data/args.py:74)")
+        norm_layer = get_nonspade_norm_layer(opt, opt.norm_F)
+        act = lambda: nn.LeakyReLU(0.2, True)   # index placeholders: the activation is fused into the norm kernel
+        down = [norm_layer(nn.Conv2d(input_nc, nf, kernel_size=3, padding=1)), act()]
+        for i in range(nd):
+            down += [norm_layer(nn.Conv2d(ch[i], ch[i + 1], kernel_size=3, padding=1, stride=2)), act()]
+        ch_r = min(1024, nf * (2 ** nd))
+        res = [FlowResnetBlock(ch_r, ch_r) for _ in range(opt.n_blocks_F)]
+        up = []
+        for i in reversed(range(nd)):
+            up += [nn.Upsample(scale_factor=2), norm_layer(nn.Conv2d(ch[i + 1], ch[i], kernel_size=3, padding=1)), act()]
+        self.down_flow = nn.Sequential(*down)
+        self.res_flow = nn.Sequential(*res)
+        self.up_flow = nn.Sequential(*up)
+        self.conv_flow = nn.Sequential(Conv2d(nf, 2, kernel_size=3, padding=1))
+        # conv_w: parameters exist in the reference state_dict; its output is computed and discarded there
+        # (generator.py:75), so it receives no gradient and is not evaluated here.
+        self.conv_w = nn.Sequential(Conv2d(nf, 1, kernel_size=3, padding=1), nn.Sigmoid())
+
+    @staticmethod
+    def _conv_bn_act(seq, x):
+        return seq[1](seq[0](x), slope=0.2)
+
+    def forward(self, label):
+        x = label
+        for m in self.down_flow:
+            if isinstance(m, nn.Sequential):
+                x = self._conv_bn_act(m, x)
+        for blk in self.res_flow:
+            x = blk(x)
+        for m in self.up_flow:
+            if isinstance(m, nn.Upsample):
+                x = ops.upsample2x(x)
+            elif isinstance(m, nn.Sequential):
+                x = self._conv_bn_act(m, x)
+        flow = self.conv_flow[0](x) * self.flow_multiplier
+        return None, flow

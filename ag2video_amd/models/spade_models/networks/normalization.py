@@ -1,0 +1,102 @@
+"""Normalisation layers (reference: networks/normalization.py:16-110)."""
+import re
+
+import torch
+import torch.nn as nn
+
+from .... import ops
+from ...layers import Conv2d
+from .sync_batchnorm import SynchronizedBatchNorm2d
+
+
+class SpectralConv2d(nn.Module):
+    """Conv2d under torch.nn.utils.spectral_norm: parameters ``weight_orig`` (+ ``bias``), buffers ``weight_u`` /
+    ``weight_v``; every training-mode forward advances the power iteration by one step and convolves with
+    weight_orig / sigma (normalization.py:26-27, architecture.py:35-39, flows_generator.py:79-85)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, eps=1e-12):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding, self.eps = kernel_size, stride, padding, eps
+        ref = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=bias)  # default init
+        self.weight_orig = nn.Parameter(ref.weight.detach().clone())
+        if bias:
+            self.bias = nn.Parameter(ref.bias.detach().clone())
+        else:
+            self.register_parameter('bias', None)
+        w = self.weight_orig
+        u = torch.nn.functional.normalize(w.new_empty(out_channels).normal_(0, 1), dim=0, eps=eps)
+        v = torch.nn.functional.normalize(w.new_empty(w.numel() // out_channels).normal_(0, 1), dim=0, eps=eps)
+        self.register_buffer('weight_u', u)
+        self.register_buffer('weight_v', v)
+
+    def drop_bias(self):
+        """get_nonspade_norm_layer removes the bias of a conv that feeds a norm layer (normalization.py:35-37)."""
+        self.bias = None
+
+    def effective_weight(self):
+        return ops.spectral_weight(self.weight_orig, self.weight_u, self.weight_v, self.training, self.eps)
+
+    def forward(self, x, residual=None):
+        return ops.conv2d(x, self.effective_weight(), self.bias, self.stride, self.padding, residual)
+
+
+class InstanceNormLReLU(nn.Module):
+    """nn.InstanceNorm2d(affine=False) fused with the LeakyReLU(0.2) that follows it in the discriminator
+    (normalization.py:43-44, discriminator.py:374-377).  No parameters, no buffers."""
+
+    def __init__(self, num_features, eps=1e-5):
+        super().__init__()
+        self.num_features, self.eps = num_features, eps
+
+    def forward(self, x, slope=0.2):
+        return ops.instnorm_lrelu(x, self.eps, slope)
+
+
+def get_nonspade_norm_layer(opt, norm_type='instance'):
+    """Returns add_norm_layer(conv_module) -> nn.Sequential(spectral conv, norm) (normalization.py:16-50).
+    ``layer`` is described by its constructor arguments (a torch.nn.Conv2d instance is accepted and re-created)."""
+
+    def add_norm_layer(layer):
+        assert norm_type.startswith('spectral'), "only spectral* norm types are on the hot path (data/args.py:103-109)"
+        sub = norm_type[len('spectral'):]
+        conv = SpectralConv2d(layer.in_channels, layer.out_channels, layer.kernel_size[0], stride=layer.stride[0],
+                              padding=layer.padding[0], bias=layer.bias is not None)
+        if sub == 'none' or len(sub) == 0:
+            return conv
+        conv.drop_bias()
+        if sub in ('batch', 'sync_batch', 'syncbatch'):
+            norm = SynchronizedBatchNorm2d(layer.out_channels, affine=True)
+        elif sub == 'instance':
+            norm = InstanceNormLReLU(layer.out_channels)
+        else:
+            raise ValueError('normalization layer %s is not recognized' % sub)
+        return nn.Sequential(conv, norm)
+
+    return add_norm_layer
+
+
+class SPADE(nn.Module):
+    """Spatially-adaptive normalisation (normalization.py:66-110): x_hat * (1 + gamma(seg)) + beta(seg)."""
+
+    def __init__(self, config_text, norm_nc, label_nc):
+        super().__init__()
+        assert config_text.startswith('spade')
+        parsed = re.search(r'spade(\D+)(\d)x\d', config_text)
+        kind, ks = str(parsed.group(1)), int(parsed.group(2))
+        if kind not in ('syncbatch', 'batch'):
+            raise ValueError('%s is not a param-free norm on the hot path (norm_G default spadesyncbatch3x3)' % kind)
+        self.param_free_norm = SynchronizedBatchNorm2d(norm_nc, affine=False)
+        nhidden = 128
+        pw = ks // 2
+        self.mlp_shared = nn.Sequential(Conv2d(label_nc, nhidden, kernel_size=ks, padding=pw), nn.ReLU())
+        self.mlp_gamma = Conv2d(nhidden, norm_nc, kernel_size=ks, padding=pw)
+        self.mlp_beta = Conv2d(nhidden, norm_nc, kernel_size=ks, padding=pw)
+
+    def forward(self, x, segmap, slope=1.0):
+        """slope: LeakyReLU fused behind the modulation (the caller's actvn, architecture.py:53-54); 1.0 = none."""
+        seg = ops.nearest_resize(segmap, x.shape[2], x.shape[3])
+        actv = ops.leaky_relu(self.mlp_shared[0](seg), 0.0)
+        gamma = self.mlp_gamma(actv)
+        beta = self.mlp_beta(actv)
+        return self.param_free_norm.modulate(x, gamma, beta, slope)

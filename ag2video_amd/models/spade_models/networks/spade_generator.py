@@ -1,0 +1,54 @@
+"""SPADE decoder (reference: networks/spade_generator.py:8-81)."""
+import torch.nn as nn
+
+from .... import ops
+from ...layers import Conv2d
+from .architecture import SPADEResnetBlock
+
+
+class SPADEGenerator(nn.Module):
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        nf = opt.ngf
+        self.sw, self.sh = self.compute_latent_vector_size(opt)
+        self.fc = Conv2d(opt.semantic_nc, 16 * nf, 3, padding=1)
+        self.head_0 = SPADEResnetBlock(16 * nf, 16 * nf, opt)
+        self.G_middle_0 = SPADEResnetBlock(16 * nf, 16 * nf, opt)
+        self.G_middle_1 = SPADEResnetBlock(16 * nf, 16 * nf, opt)
+        self.up_0 = SPADEResnetBlock(16 * nf, 8 * nf, opt)
+        self.up_1 = SPADEResnetBlock(8 * nf, 4 * nf, opt)
+        self.up_2 = SPADEResnetBlock(4 * nf, 2 * nf, opt)
+        self.up_3 = SPADEResnetBlock(2 * nf, 1 * nf, opt)
+        final_nc = nf
+        if opt.num_upsampling_layers == 'most':
+            self.up_4 = SPADEResnetBlock(1 * nf, nf // 2, opt)
+            final_nc = nf // 2
+        self.conv_img = Conv2d(final_nc, 3, 3, padding=1)
+
+    @staticmethod
+    def compute_latent_vector_size(opt):
+        n = {'normal': 5, 'more': 6, 'most': 7}.get(opt.num_upsampling_layers)
+        if n is None:
+            raise ValueError('opt.num_upsampling_layers [%s] not recognized' % opt.num_upsampling_layers)
+        sw = opt.image_size[0] // (2 ** n)
+        sh = round(sw / opt.aspect_ratio)
+        return sw, sh
+
+    def forward(self, layout):
+        x = ops.nearest_resize(layout, self.sh, self.sw)
+        x = self.fc(x)
+        x = self.head_0(x, layout)
+        x = ops.upsample2x(x)
+        x = self.G_middle_0(x, layout)
+        if self.opt.num_upsampling_layers in ('more', 'most'):
+            x = ops.upsample2x(x)
+        x = self.G_middle_1(x, layout)
+        for blk in (self.up_0, self.up_1, self.up_2, self.up_3):
+            x = ops.upsample2x(x)
+            x = blk(x, layout)
+        if self.opt.num_upsampling_layers == 'most':
+            x = ops.upsample2x(x)
+            x = self.up_4(x, layout)
+        x = self.conv_img(ops.leaky_relu(x, 0.2))
+        return ops.tanh(x)

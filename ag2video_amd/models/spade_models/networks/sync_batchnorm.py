@@ -1,0 +1,50 @@
+"""Data-parallel glue with the reference's names (reference: networks/sync_batchnorm/{replicate,batchnorm}.py).
+
+The reference is single-process torch.nn.DataParallel (threads + NCCL broadcast of every parameter every forward,
+replicate.py:50-67).  This build runs one process per GPU: the wrapper below only reproduces the ``.module`` attribute
+(hence the ``.module.`` infix of every state_dict key); gradient averaging is done once per step by
+ag2video_amd.distributed over RCCL.  Batch-norm statistics are per process, i.e. the single-device formula
+F.batch_norm ((var+eps)^-1/2, batchnorm.py:63-68) at every world size (DESIGN.md "Multi-GPU").
+"""
+import torch
+import torch.nn as nn
+
+from .... import ops
+
+
+class DataParallelWithCallback(nn.Module):
+    def __init__(self, module, device_ids=None):
+        super().__init__()
+        self.module = module
+        self.device_ids = list(device_ids) if device_ids else []
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+
+class SynchronizedBatchNorm2d(nn.Module):
+    """Batch norm over (N,H,W) with optional affine, fused with the LeakyReLU that follows it at every call site.
+    Parameter / buffer names are those of torch.nn.BatchNorm2d.  num_batches_tracked is registered but never advanced,
+    exactly like the reference's forward (it calls F.batch_norm directly, batchnorm.py:63-68)."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True):
+        super().__init__()
+        self.num_features, self.eps, self.momentum, self.affine = num_features, eps, momentum, affine
+        if affine:
+            self.weight = nn.Parameter(torch.ones(num_features))
+            self.bias = nn.Parameter(torch.zeros(num_features))
+        else:
+            self.register_parameter('weight', None)
+            self.register_parameter('bias', None)
+        self.register_buffer('running_mean', torch.zeros(num_features))
+        self.register_buffer('running_var', torch.ones(num_features))
+        self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
+
+    def forward(self, x, slope=1.0):
+        return ops.batchnorm_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
+                                 self.momentum, self.eps, slope)
+
+    def modulate(self, x, gamma, beta, slope=1.0):
+        """SPADE use: normalise without affine and apply (1+gamma), beta in the same pass."""
+        return ops.spade_norm(x, gamma, beta, self.running_mean, self.running_var, self.training, self.momentum, self.eps,
+                              slope)

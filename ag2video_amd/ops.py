@@ -33,6 +33,43 @@ def _c(t):
     return None if t is None else t.contiguous()
 
 
+# ---- optional per-launch timing of the convolution kernels (bench.py's roofline leg): HIP events on the launch stream
+_TIMING = None
+
+
+def enable_kernel_timing(flag=True):
+    """Start (True) / stop (False) recording a HIP event pair around every convolution kernel launch."""
+    global _TIMING
+    _TIMING = [] if flag else None
+
+
+def _conv_label(mode, M):
+    return "conv_%s_bm%d" % (mode, 32 if M <= 32 else (64 if M <= 64 else 128))
+
+
+def _launch(name, label, flops, *args):
+    if _TIMING is None:
+        _lib.call(name, *args)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _lib.call(name, *args)
+    e1.record()
+    _TIMING.append((label, flops, e0, e1))
+
+
+def kernel_timing_summary():
+    """{label: {launches, flops, ms}} for everything recorded since enable_kernel_timing(True); synchronises."""
+    torch.cuda.synchronize()
+    out = {}
+    for label, flops, e0, e1 in (_TIMING or []):
+        d = out.setdefault(label, {'launches': 0, 'flops': 0.0, 'ms': 0.0})
+        d['launches'] += 1
+        d['flops'] += flops
+        d['ms'] += e0.elapsed_time(e1)
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ convolution
 class _Conv2d(torch.autograd.Function):
     @staticmethod
@@ -46,8 +83,8 @@ class _Conv2d(torch.autograd.Function):
         OH = (H + 2 * pad - R) // stride + 1
         OW = (W + 2 * pad - S) // stride + 1
         y = torch.empty((N, K, OH, OW), device=x.device, dtype=torch.float32)
-        _lib.call('ag2v_conv2d_fwd', _ptr(x), _ptr(w), _ptr(bias), _ptr(residual), _ptr(y),
-                  N, C, H, W, K, R, S, stride, pad, _stream())
+        _launch('ag2v_conv2d_fwd', _conv_label('fwd', K), 2.0 * N * K * OH * OW * C * R * S,
+                _ptr(x), _ptr(w), _ptr(bias), _ptr(residual), _ptr(y), N, C, H, W, K, R, S, stride, pad, _stream())
         ctx.save_for_backward(x, w)
         ctx.cfg = (stride, pad, bias is not None, residual is not None)
         return y
@@ -61,12 +98,15 @@ class _Conv2d(torch.autograd.Function):
         K, _, R, S = w.shape
         dx = dw = db = dres = None
         st = _stream()
+        flops = 2.0 * N * K * dy.shape[2] * dy.shape[3] * C * R * S      # algorithmic (dense-conv) FLOPs of each pass
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _lib.call('ag2v_conv2d_dgrad', _ptr(dy), _ptr(w), _ptr(dx), N, C, H, W, K, R, S, stride, pad, st)
+            _launch('ag2v_conv2d_dgrad', _conv_label('dgrad', C), flops,
+                    _ptr(dy), _ptr(w), _ptr(dx), N, C, H, W, K, R, S, stride, pad, st)
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
-            _lib.call('ag2v_conv2d_wgrad', _ptr(dy), _ptr(x), _ptr(dw), N, C, H, W, K, R, S, stride, pad, st)
+            _launch('ag2v_conv2d_wgrad', _conv_label('wgrad', K), flops,
+                    _ptr(dy), _ptr(x), _ptr(dw), N, C, H, W, K, R, S, stride, pad, st)
         if has_bias and ctx.needs_input_grad[2]:
             db = torch.empty(K, device=dy.device, dtype=torch.float32)
             _lib.call('ag2v_channel_sum', _ptr(dy), _ptr(db), N, K, dy.shape[2] * dy.shape[3], st)

@@ -1,0 +1,153 @@
+#!/usr/bin/env python
+"""Benchmark of the AG2Video training step (generator + discriminator forward/backward + Adam) on MI355X.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1            # c3: CATER 256x256, 16 frames, batch 8 per GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W               # one rank per GPU over RCCL, weak scaling
+
+A "step" is one pass of scripts/train.py:446-464,522-525 (G fwd, G loss incl. two D passes, G bwd, Adam(G), D loss with two
+D passes, D bwd, Adam(D)) over one synthetic CATER-shaped clip batch that is already resident in HBM.  Rank 0 prints ONE
+JSON line: frames/sec/node plus the roofline figures of the dominant kernel and a CPU baseline (the oracle's step timed
+on the host cores at a bounded size).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+
+CONFIGS = {
+    # name: (image side, frames, per-GPU batch, extra flags)
+    'c1': (64, 4, 1, []),
+    'c2': (128, 8, 4, []),
+    'c3': (256, 16, 8, []),
+    'toy': (64, 3, 2, ['--ngf', '8', '--ndf', '8', '--nff', '8', '--gconv_hidden_dim', '64']),
+}
+PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def make_opt(cfg):
+    from ag2video_amd.data.args import make_opt as _mk
+    from ag2video_amd.data.vocab import cater_vocab
+    side, frames, batch, extra = CONFIGS[cfg]
+    flags = ['--no_vgg_loss', '--image_size', '%d,%d' % (side, side), '--batch_size', str(batch), '--gpu_ids', '0'] + extra
+    return _mk(cater_vocab(), flags), side, frames, batch
+
+
+def cpu_baseline(shapes_G, shapes_D, wseed):
+    """The oracle (CPU restatement of the reference step) timed on this host's cores on a bounded sample."""
+    from ag2video_amd.data.synthetic import make_clip_batch
+    from oracle.step import OracleTrainer
+    opt, side, frames, batch = make_opt('c1')
+    opt.gpu_ids = []
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    tr = OracleTrainer(opt, shapes_G, shapes_D, wseed)
+    b = make_clip_batch(opt.vocab, batch, frames, (side, side), seed=1234)
+    t0 = time.time()
+    tr.gd_step(b)
+    dt = time.time() - t0
+    return {"value": round(batch * frames / dt, 4), "unit": "frames/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "1 full step (G fwd+loss+bwd+Adam, D loss+bwd+Adam) of config c1: 64x64, 4 frames, batch 1, default "
+                      "widths, on the oracle (PyTorch-CPU restatement of the reference); %.1f s" % dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--config', default='c3', choices=sorted(CONFIGS))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    args = ap.parse_args()
+
+    from ag2video_amd import distributed as D
+    from ag2video_amd import ops
+    from ag2video_amd.data.synthetic import make_clip_batch
+    from ag2video_amd.engine import TrainStep
+    rank, world, local = D.init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    opt, side, frames, batch = make_opt(args.config)
+    opt.gpu_ids = [local]
+    ts = TrainStep(opt, device, weights_seed=0)
+    clip = ts.to_device(make_clip_batch(opt.vocab, batch, frames, (side, side), seed=1234 + rank))
+    torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ts.gd_step(clip)
+    torch.cuda.synchronize()
+    if D.is_dist():
+        torch.distributed.barrier()
+    if not args.no_kernel_timing:
+        ops.enable_kernel_timing(True)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(args.steps):
+        model_out, GL, DL = ts.gd_step(clip)
+    torch.cuda.synchronize()
+    if D.is_dist():
+        torch.distributed.barrier()
+    dt = D.max_over_ranks(time.time() - t0, device)
+    timing = ops.kernel_timing_summary() if not args.no_kernel_timing else {}
+    ops.enable_kernel_timing(False)
+    finite = all(bool(torch.isfinite(v).all()) for v in list(GL.values()) + list(DL.values()))
+
+    # graph-only step (train.py:471-493), reported separately
+    gclip = ts.to_device(make_clip_batch(opt.vocab, batch, frames, (side, side), seed=4321 + rank))
+    ts.graph_step(gclip)
+    torch.cuda.synchronize()
+    tg = time.time()
+    ts.graph_step(gclip)
+    torch.cuda.synchronize()
+    graph_ms = (time.time() - tg) * 1e3
+
+    if rank != 0:
+        return
+    ms_per_step = dt / args.steps * 1e3
+    value = world * batch * frames * args.steps / dt
+    roof = None
+    if timing:
+        dom = max(timing, key=lambda k: timing[k]['ms'])
+        t = timing[dom]
+        achieved = t['flops'] / (t['ms'] * 1e-3) / 1e12
+        conv_ms = sum(v['ms'] for v in timing.values())
+        conv_fl = sum(v['flops'] for v in timing.values())
+        roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                "launches": t['launches'], "avg_launch_ms": round(t['ms'] / t['launches'], 4),
+                "flops_per_launch": t['flops'] / t['launches'],
+                "all_conv_kernels": {"achieved": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
+                                     "share_of_step_time": round(conv_ms / (dt * 1e3), 4),
+                                     "by_kernel": {k: {"ms": round(v['ms'], 2), "tflops": round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2),
+                                                       "launches": v['launches']} for k, v in sorted(timing.items())}}}
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        shapes_G = {k: list(v.shape) for k, v in ts.model.state_dict().items()}
+        shapes_D = {k: list(v.shape) for k, v in ts.discriminator.img_discriminator.state_dict().items()}
+        cpu = cpu_baseline(shapes_G, shapes_D, 0)
+    line = {
+        "metric": "frames/sec/node (gen+disc fwd+bwd), CATER %dx%dx%df" % (side, side, frames),
+        "value": round(value, 3), "unit": "frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic CATER-shaped clips (seeded), closed-form random-init weights",
+        "config": {"workload": "%s: CATER %dx%d, %d frames, batch %d per GPU, full G+D train step, VGG loss off"
+                   % (args.config, side, side, frames, batch), "global_batch": world * batch, "parallelism": "dp%d" % world},
+        "roofline": roof, "cpu_baseline": cpu,
+        "extra": {"graph_step_ms": round(graph_ms, 2), "losses_finite": finite,
+                  "generated_frames_per_sec": round(world * batch * (frames - 1) * args.steps / dt, 3),
+                  "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)},
+    }
+    print(json.dumps(line), flush=True)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,22 @@
+"""TEST-ONLY: lets the CPU suite exercise the product's *host* orchestration (ag2video_amd/models, engine) without a GPU by
+temporarily substituting the oracle's CPU restatements for the HIP operators.  The product package itself has no such
+switch; this context manager lives in tests/ and is never used on the GPU path."""
+import contextlib
+
+OPS = ['conv2d', 'spectral_weight', 'batchnorm_act', 'spade_norm', 'instnorm_lrelu', 'layout_render', 'flow_warp',
+       'avgpool3s2', 'nearest_resize', 'upsample2x', 'linear', 'triple_gather', 'triple_pool', 'embedding', 'leaky_relu',
+       'tanh', 'l1_mean', 'hinge_mean']
+
+
+@contextlib.contextmanager
+def oracle_ops():
+    from ag2video_amd import ops
+    from oracle import kernels as K
+    saved = {n: getattr(ops, n) for n in OPS}
+    try:
+        for n in OPS:
+            setattr(ops, n, getattr(K, n))
+        yield
+    finally:
+        for n, f in saved.items():
+            setattr(ops, n, f)

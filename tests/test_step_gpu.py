@@ -1,0 +1,117 @@
+"""End-to-end parity of the product training step on the GPU (HIP kernels through the C ABI) against
+(a) the golden vectors of the unmodified reference (tests/golden/toy64_step.npz) and (b) the CPU oracle on a second
+configuration.  Tolerances: losses and output tensors 1e-3 relative (BASELINE.json north_star); gradient statistics as in
+tests/test_oracle_golden.py (2e-3; 5e-2 through the flow warp, whose derivative is piecewise constant)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _setup():
+    from ag2video_amd.data.args import make_opt
+    from ag2video_amd.data.vocab import cater_vocab
+    gold = np.load(os.path.join(HERE, 'golden', 'toy64_step.npz'), allow_pickle=False)
+    opt = make_opt(cater_vocab(), json.loads(str(gold['meta.flags'])))
+    return gold, opt, json.loads(str(gold['meta.toy']))
+
+
+def _stats(t):
+    t = t.detach().double().cpu()
+    return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().sqrt().item()])
+
+
+def test_train_step_matches_reference_golden(device):
+    from ag2video_amd.data.synthetic import make_clip_batch
+    from ag2video_amd.engine import TrainStep
+    gold, opt, toy = _setup()
+    opt.gpu_ids = [0]
+    ts = TrainStep(opt, device, weights_seed=toy['wseed'])
+    worst = {}
+    for it in range(2):
+        batch = ts.to_device(make_clip_batch(opt.vocab, toy['batch'], toy['frames'], tuple(toy['size']), seed=toy['seed'] + it))
+        model_out, GL, DL = ts.gd_step(batch)
+        p = 'it%d.' % it
+        for k, v in list(GL.items()) + list(DL.items()):
+            key = p + ('G_loss.' if k in GL else 'D_loss.') + k
+            ref = float(gold[key])
+            assert abs(v.item() - ref) <= 1e-3 * max(1.0, abs(ref)), (key, v.item(), ref)
+        if it == 0:
+            for name, got in zip(('imgs_pred', 'boxes_pred', 'flows_pred'), model_out[:3]):
+                ref = gold[name]
+                err = np.abs(got.detach().cpu().numpy() - ref).max()
+                worst[name] = err / np.abs(ref).max()
+                assert err <= 1e-3 * np.abs(ref).max(), (name, err, np.abs(ref).max())
+            assert np.mean(model_out[3].cpu().numpy() != gold['conf_pred']) < 2e-3
+            assert (model_out[4][1].cpu().numpy() == gold['temporal_triplets']).all()
+            bad = []
+            for n, prm in ts.model.named_parameters():
+                key = 'G_grad.' + n
+                if prm.grad is None or key not in gold.files:
+                    continue
+                got, ref = _stats(prm.grad), gold[key]
+                rel = 5e-2 if 'flows_network' in n else 3e-3
+                floor = 2e-6 * prm.numel()
+                if abs(got[1] - ref[1]) > rel * abs(ref[1]) + floor:
+                    bad.append((n, got[1], ref[1]))
+            assert not bad, bad[:10]
+            g = ts.model.layout_to_video.module.netG.conv_img.weight.grad.cpu().numpy()
+            ref = gold['G_grad_full.netG.conv_img.weight']
+            assert np.abs(g - ref).max() <= 5e-3 * np.abs(ref).max()
+            badd = []
+            for n, prm in ts.discriminator.img_discriminator.named_parameters():
+                key = 'D_grad.' + n
+                if prm.grad is None or key not in gold.files:
+                    continue
+                got, ref = _stats(prm.grad), gold[key]
+                if abs(got[1] - ref[1]) > 3e-3 * abs(ref[1]) + 2e-6 * prm.numel():
+                    badd.append((n, got[1], ref[1]))
+            assert not badd, badd[:10]
+        gb = ts.to_device(make_clip_batch(opt.vocab, toy['batch'], toy['graph_frames'], tuple(toy['size']),
+                                          seed=toy['seed'] + 100 + it))
+        boxes_pred, GGL = ts.graph_step(gb)
+        for k, v in GGL.items():
+            ref = float(gold[p + 'graph_loss.' + k])
+            assert abs(v.item() - ref) <= 1e-3 * max(1.0, abs(ref)), (k, v.item(), ref)
+        if it == 0:
+            ref = gold['graph.boxes_pred']
+            assert np.abs(boxes_pred.detach().cpu().numpy() - ref).max() <= 1e-3 * np.abs(ref).max()
+    sd = ts.model.state_dict()
+    for k in ('layout_to_video.module.conv_dim_in.0.0.weight_u', 'layout_to_video.module.netG.up_3.norm_0.param_free_norm.running_var',
+              'layout_to_video.module.netG.head_0.conv_1.weight_v'):
+        got, ref = _stats(sd[k]), gold['it1.G_state.' + k]
+        assert np.allclose(got[1:], ref[1:], rtol=5e-3, atol=1e-6), (k, got, ref)
+    print('worst output errors (relative to max):', worst)
+
+
+@pytest.mark.parametrize("cfg", [dict(side=32, frames=4, batch=3, flags=['--ngf', '16', '--ndf', '8', '--nff', '8',
+                                                                       '--gconv_hidden_dim', '128'])], ids=['32px_f4_b3'])
+def test_train_step_matches_oracle_other_shape(cfg, device):
+    """A second shape (odd batch, 4 frames, 32 px) against the CPU oracle run in the same process."""
+    from ag2video_amd.data.args import make_opt
+    from ag2video_amd.data.synthetic import make_clip_batch
+    from ag2video_amd.data.vocab import cater_vocab
+    from ag2video_amd.engine import TrainStep
+    from oracle.step import OracleTrainer
+    flags = ['--no_vgg_loss', '--image_size', '%d,%d' % (cfg['side'], cfg['side']), '--batch_size', str(cfg['batch'])] + cfg['flags']
+    opt = make_opt(cater_vocab(), flags + ['--gpu_ids', '0'])
+    ts = TrainStep(opt, device, weights_seed=3)
+    shapes_G = {k: list(v.shape) for k, v in ts.model.state_dict().items()}
+    shapes_D = {k: list(v.shape) for k, v in ts.discriminator.img_discriminator.state_dict().items()}
+    orc = OracleTrainer(opt, shapes_G, shapes_D, 3)
+    cpu_batch = make_clip_batch(opt.vocab, cfg['batch'], cfg['frames'], (cfg['side'], cfg['side']), seed=77, max_objs=7)
+    mo_r, GL_r, DL_r = orc.gd_step(cpu_batch)
+    mo, GL, DL = ts.gd_step(ts.to_device(cpu_batch))
+    for k in GL_r:
+        assert abs(GL[k].item() - GL_r[k].item()) <= 1e-3 * max(1.0, abs(GL_r[k].item())), (k, GL[k].item(), GL_r[k].item())
+    for k in DL_r:
+        assert abs(DL[k].item() - DL_r[k].item()) <= 1e-3 * max(1.0, abs(DL_r[k].item())), (k, DL[k].item(), DL_r[k].item())
+    for i, name in enumerate(('imgs_pred', 'boxes_pred', 'flows_pred')):
+        ref = mo_r[i].detach().numpy()
+        err = np.abs(mo[i].detach().cpu().numpy() - ref).max()
+        assert err <= 1e-3 * np.abs(ref).max(), (name, err)
