@@ -76,56 +76,70 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     const int n_img = pix / (PH * PW);
     const int prem = pix - n_img * (PH * PW);
     const int py = prem / PW, px = prem - py * PW;
-    const float* bbase;
+    // Source plane geometry: FWD gathers x[N,C,H,W]; DGRAD gathers dy[N,K,OH,OW].
+    const int SH = (MODE == MODE_FWD) ? p.H : p.OH, SW = (MODE == MODE_FWD) ? p.W : p.OW;
+    const int SC = (MODE == MODE_FWD) ? p.C : p.K;
+    const int SHW = SH * SW;
+    // Per-pixel tap table: bit (r*S+s) of vmask says tap (r,s) reads inside the source plane; the tap's address is
+    // bptr + chan*SHW + toff(r,s) with a wave-uniform (scalar) chan/tap part.  FWD (and stride-1 DGRAD) taps are affine
+    // in (r,s); a strided DGRAD tap ((y+pad-r)/st) is not, so it keeps a per-lane offset computed per element.
+    const float* bptr = p.b_src + (size_t)n_img * SC * SHW;
+    unsigned vmask = 0;
     int y0, x0;
     if (MODE == MODE_FWD) {
-        bbase = p.b_src + (size_t)n_img * p.C * p.H * p.W;
         y0 = py * p.stride - p.pad;
         x0 = px * p.stride - p.pad;
     } else {
-        bbase = p.b_src + (size_t)n_img * p.K * p.OH * p.OW;
         y0 = py + p.pad;
         x0 = px + p.pad;
     }
+    if (pvalid) {
+        for (int r = 0; r < p.R; ++r)
+            for (int s2 = 0; s2 < p.S; ++s2) {
+                bool ok;
+                if (MODE == MODE_FWD) {
+                    ok = (unsigned)(y0 + r) < (unsigned)SH && (unsigned)(x0 + s2) < (unsigned)SW;
+                } else {
+                    const int ty = y0 - r, tx = x0 - s2;
+                    ok = ty >= 0 && tx >= 0 && (ty % p.stride) == 0 && (tx % p.stride) == 0 && (ty / p.stride) < SH &&
+                         (tx / p.stride) < SW;
+                }
+                if (ok) vmask |= 1u << (r * p.S + s2);
+            }
+    }
+    const bool affine = (MODE == MODE_FWD) || p.stride == 1;
+    if (affine) bptr += (MODE == MODE_FWD) ? (y0 * SW + x0) : (y0 * SW + x0);   // tap (0,0); may point before the plane
     // ---- A load state
     const int ma = tid / TPR, kka0 = (tid % TPR) * EA;
     const bool mvalid = (m0 + ma) < p.M;
+    const float* aptr = p.a_src + ((MODE == MODE_FWD) ? (size_t)(m0 + ma) * p.KG : (size_t)(m0 + ma) * RS);
 
-    // kg is wave-uniform for the B gather (all lanes of a wave share the k-row), so the (c,r,s) decode and the
-    // channel/tap offset live in scalar registers; only the bounds test and the final add are per lane.
+    // kg is wave-uniform for the B gather (all lanes of a wave share the k-row): the (c,r,s) decode, the tap bit and
+    // the channel/tap offset are scalar; per lane only the mask test and one 64-bit add remain.
     auto fetchB = [&](int kg_lane) -> float {
         const int kg = __builtin_amdgcn_readfirstlane(kg_lane);
         int c, r, s;
         decode_crs(kg, RS, p.S, c, r, s);
+        const bool ok = ((vmask >> (r * p.S + s)) & 1u) && kg < p.KG;
         if (MODE == MODE_FWD) {
-            const int iy = y0 + r, ix = x0 + s;
-            const bool ok = pvalid && kg < p.KG && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            return ok ? bbase[((size_t)c * p.H + iy) * p.W + ix] : 0.f;
+            const int koff = c * SHW + r * SW + s;
+            return ok ? bptr[koff] : 0.f;
+        } else if (affine) {
+            const int koff = c * SHW - r * SW - s;
+            return ok ? bptr[koff] : 0.f;
         } else {
-            const int ty = y0 - r, tx = x0 - s;
-            int oy = ty, ox = tx;
-            bool ok = pvalid && kg < p.KG && ty >= 0 && tx >= 0;
-            if (p.stride == 2) {
-                oy = ty >> 1;
-                ox = tx >> 1;
-                ok = ok && !((ty | tx) & 1);
-            } else if (p.stride != 1) {
-                oy = ty / p.stride;
-                ox = tx / p.stride;
-                ok = ok && (oy * p.stride == ty) && (ox * p.stride == tx);
-            }
-            ok = ok && oy < p.OH && ox < p.OW;
-            return ok ? bbase[((size_t)c * p.OH + oy) * p.OW + ox] : 0.f;
+            const int oy = (y0 - r) / p.stride, ox = (x0 - s) / p.stride;
+            return ok ? bptr[c * SHW + oy * SW + ox] : 0.f;
         }
     };
     auto fetchA = [&](int kg) -> float {
         const bool ok = mvalid && kg < p.KG;
         if (MODE == MODE_FWD) {
-            return ok ? p.a_src[(size_t)(m0 + ma) * p.KG + kg] : 0.f;
+            return ok ? aptr[kg] : 0.f;
         } else {
             const int k = div_small(kg, RS);
             const int rs = kg - k * RS;
-            return ok ? p.a_src[((size_t)k * p.C + (m0 + ma)) * RS + rs] : 0.f;
+            return ok ? aptr[(size_t)k * p.C * RS + rs] : 0.f;
         }
     };
 
@@ -332,6 +346,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvArgs p) {
     }
 }
 
+// wt[c][k][r][s] = w[k][c][R-1-r][S-1-s]: with it a stride-1 data gradient is a plain forward convolution of dy
+// (pad' = R-1-pad), so it runs on the forward kernel with contiguous weight rows.
+__global__ __launch_bounds__(256) void weight_flip_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int K,
+                                                                    int C, int RS) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)K * C * RS) return;
+    const int rs = (int)(i % RS);
+    const long long t = i / RS;
+    const int k = (int)(t % K), c = (int)(t / K);
+    wt[i] = w[((size_t)k * C + c) * RS + (RS - 1 - rs)];
+}
+
 static int conv_out_dim(int in, int k, int stride, int pad) { return (in + 2 * pad - k) / stride + 1; }
 
 template <int MODE>
@@ -367,9 +393,29 @@ extern "C" int ag2v_conv2d_fwd(const float* x, const float* w, const float* bias
     return launch_igemm<MODE_FWD>(a, (hipStream_t)stream);
 }
 
+extern "C" size_t ag2v_conv2d_dgrad_workspace_floats(int C, int K, int R, int S, int stride) {
+    return stride == 1 ? (size_t)C * K * R * S : 0;
+}
+
 extern "C" int ag2v_conv2d_dgrad(const float* dy, const float* w, float* dx,
-                                 int N, int C, int H, int W, int K, int R, int S, int stride, int pad, void* stream) {
+                                 int N, int C, int H, int W, int K, int R, int S, int stride, int pad, float* workspace,
+                                 void* stream) {
     if (!dy || !w || !dx || N <= 0 || C <= 0 || K <= 0 || stride <= 0) return AG2V_EINVAL;
+    if (stride == 1 && workspace && pad <= R - 1 && pad <= S - 1 && R == S) {
+        // dX = conv_fwd(dY, flip-transpose(W), pad' = R-1-pad)
+        hipStream_t st = (hipStream_t)stream;
+        const long long nw = (long long)K * C * R * S;
+        hipLaunchKernelGGL(weight_flip_transpose_kernel, dim3(ceil_div(nw, 256)), dim3(256), 0, st, w, workspace, K, C, R * S);
+        const int OH = conv_out_dim(H, R, 1, pad), OW = conv_out_dim(W, S, 1, pad);
+        if (OH <= 0 || OW <= 0) return AG2V_EINVAL;
+        ConvArgs f{};
+        f.a_src = workspace; f.b_src = dy; f.out = dx;
+        f.N = N; f.C = K; f.H = OH; f.W = OW; f.K = C; f.R = R; f.S = S; f.stride = 1; f.pad = R - 1 - pad;
+        f.OH = H; f.OW = W;
+        if ((long long)N * H * W >= (1LL << 31) || (long long)K * R * S >= (1LL << 31)) return AG2V_EINVAL;
+        f.M = C; f.NG = N * H * W; f.KG = K * R * S;
+        return launch_igemm<MODE_FWD>(f, st);
+    }
     ConvArgs a{};
     a.a_src = w; a.b_src = dy; a.out = dx;
     a.N = N; a.C = C; a.H = H; a.W = W; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad;

@@ -101,8 +101,10 @@ class _Conv2d(torch.autograd.Function):
         flops = 2.0 * N * K * dy.shape[2] * dy.shape[3] * C * R * S      # algorithmic (dense-conv) FLOPs of each pass
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
+            nws = _lib.query('ag2v_conv2d_dgrad_workspace_floats', C, K, R, S, stride)
+            ws = torch.empty(nws, device=dy.device, dtype=torch.float32) if nws else None
             _launch('ag2v_conv2d_dgrad', _conv_label('dgrad', C), flops,
-                    _ptr(dy), _ptr(w), _ptr(dx), N, C, H, W, K, R, S, stride, pad, st)
+                    _ptr(dy), _ptr(w), _ptr(dx), N, C, H, W, K, R, S, stride, pad, _ptr(ws), st)
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
             _launch('ag2v_conv2d_wgrad', _conv_label('wgrad', K), flops,

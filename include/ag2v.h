@@ -28,8 +28,9 @@ extern "C" {
  * fwd: y = conv(x,w) (+bias[K]) (+residual, same shape as y).  dgrad: dx from dy.  wgrad: dw from dy,x. */
 int ag2v_conv2d_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y,
                     int N, int C, int H, int W, int K, int R, int S, int stride, int pad, void* stream);
+size_t ag2v_conv2d_dgrad_workspace_floats(int C, int K, int R, int S, int stride);
 int ag2v_conv2d_dgrad(const float* dy, const float* w, float* dx,
-                      int N, int C, int H, int W, int K, int R, int S, int stride, int pad, void* stream);
+                      int N, int C, int H, int W, int K, int R, int S, int stride, int pad, float* workspace, void* stream);
 int ag2v_conv2d_wgrad(const float* dy, const float* x, float* dw,
                       int N, int C, int H, int W, int K, int R, int S, int stride, int pad, void* stream);
 /* out[c] = sum over n,hw of x[n,c,hw]: conv bias gradient */
