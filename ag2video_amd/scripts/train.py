@@ -1,0 +1,123 @@
+"""Training loop counterpart of the reference's scripts/train.py (main: :335-513, checkpoints :27-57,528-543) on
+seeded synthetic CATER-shaped clips (the real datasets need files/network that are out of scope).
+
+    python -m ag2video_amd.scripts.train --batch_size 2 --image_size 64,64 --num_iterations 10 --no_vgg_loss
+    torchrun --nproc-per-node 8 --master-addr 127.0.0.1 -m ag2video_amd.scripts.train ...     # one rank per GPU
+
+Same flags, step order (G step -> D step -> graph step on a 4x longer clip), NaN guard, per-step try/except, loss-dict
+keys and checkpoint dictionary keys as the reference.
+"""
+import json
+import logging
+import os
+
+import torch
+
+from .. import distributed as D
+from ..data.args import get_args, init_args
+from ..data.synthetic import make_clip_batch
+from ..data.vocab import cater_vocab, smth_vocab
+from ..engine import TrainStep
+
+
+def save_checkpoint(args, path, ts, epoch, t):
+    """Checkpoint dictionary with the reference's keys (scripts/train.py:528-543)."""
+    ckpt = {
+        'model_state': ts.model.state_dict(),
+        'gans_model_state': ts.gans_model.state_dict(),
+        'd_img_state': ts.discriminator.img_discriminator.state_dict(),
+        'd_img_optim_state': ts.discriminator.optimizer_d_img.state_dict(),
+        'optim_state_gen': ts.optimizer_generator.state_dict(),
+        'optim_state_graph': ts.optimizer_graph.state_dict(),
+        'vocab': args.vocab,
+        'counters': {'t': t, 'epoch': epoch},
+    }
+    torch.save(ckpt, path)
+
+
+def restore_checkpoint(args, ts, path):
+    """scripts/train.py:27-57 (optimizer state is mapped to the device by load_state_dict)."""
+    ckpt = torch.load(path, map_location=ts.device, weights_only=False)
+    ts.model.load_state_dict(ckpt['model_state'])
+    ts.gans_model.load_state_dict(ckpt['gans_model_state'])
+    ts.discriminator.img_discriminator.load_state_dict(ckpt['d_img_state'])
+    ts.discriminator.optimizer_d_img.load_state_dict(ckpt['d_img_optim_state'])
+    ts.optimizer_generator.load_state_dict(ckpt['optim_state_gen'])
+    if 'optim_state_graph' in ckpt:
+        ts.optimizer_graph.load_state_dict(ckpt['optim_state_graph'])
+    return ckpt['vocab'], ckpt['counters']['epoch'], ckpt['counters']['t']
+
+
+def main(args):
+    logger = logging.getLogger(__name__)
+    rank, world, local = D.init_from_env()
+    args.vocab = smth_vocab() if args.dataset == 'smth_else' else cater_vocab()
+    init_args(args)
+    if not torch.cuda.is_available():
+        raise RuntimeError("ag2video_amd.scripts.train needs an MI355X: there is no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    args.gpu_ids = [local]
+    if rank == 0:
+        os.makedirs(args.output_dir, exist_ok=True)
+        json.dump({k: v for k, v in vars(args).items() if k != 'vocab'}, open(os.path.join(args.output_dir, 'run_args.json'), 'w'))
+    ts = TrainStep(args, device)
+    epoch, t = 0, 0
+    ckpt_path = os.path.join(args.output_dir, 'latest.pt')
+    if args.restore_checkpoint and os.path.exists(ckpt_path):
+        args.vocab, epoch, t = restore_checkpoint(args, ts, ckpt_path)
+    lo, hi = args.synthetic_objects
+    F_short, F_long = args.frames_per_action, 4 * args.frames_per_action_graph     # dataset_params.py:166-170
+    G_losses, D_losses = {}, {}
+    while t < args.num_iterations:
+        if t % args.checkpoint_every == 0 and rank == 0:
+            save_checkpoint(args, os.path.join(args.output_dir, 'itr_%s.pt' % t), ts, epoch, t)
+        seed = args.seed + 1000003 * t + rank
+        if not args.graph_only:
+            try:
+                batch = ts.to_device(make_clip_batch(args.vocab, args.batch_size, F_short, args.image_size, seed=seed,
+                                                     min_objs=lo, max_objs=hi))
+                ts.model.zero_grad(set_to_none=True)
+                model_out = ts.model(batch[0], batch[1], batch[3], batch[4], boxes_gt=batch[2], test_mode=False, use_gt=True)
+                G_losses = ts.gans_model(batch, model_out, mode="compute_generator_loss")
+                G_losses = {k: v.mean() for k, v in G_losses.items()}
+                if torch.isnan(G_losses['GAN_Img']) or ('GAN_Feat' in G_losses and torch.isnan(G_losses['GAN_Feat'])):
+                    print("Error: video_id {} is NAN!".format(batch[5]))          # train.py:450-453
+                    t += 1
+                    continue
+                ts.optimizer_generator.zero_grad()
+                G_losses["total_loss"].backward()
+                D.average_gradients(ts._gen_params)
+                ts.optimizer_generator.step()
+                D_losses = ts.gans_model(batch, model_out, mode="compute_discriminator_loss")
+                D_losses = {k: v.mean() for k, v in D_losses.items()}
+                ts.discriminator.optimizer_d_img.zero_grad()
+                D_losses["total_img_loss"].backward()
+                D.average_gradients(ts._d_params)
+                ts.discriminator.optimizer_d_img.step()
+            except Exception as e:                                                     # train.py:466-468
+                print("Error in video_id: {}".format(seed))
+                logger.exception(e)
+        G_graph_losses = {}
+        try:
+            gbatch = ts.to_device(make_clip_batch(args.vocab, args.batch_size, F_long, args.image_size, seed=seed + 7,
+                                                  min_objs=lo, max_objs=hi))
+            _, G_graph_losses = ts.graph_step(gbatch)
+        except Exception as e:
+            print("Error in video_id: {}".format(seed + 7))
+            logger.exception(e)
+        if t % args.print_every == 0 and rank == 0:
+            print('t = %d / %d' % (t, args.num_iterations))
+            for name, val in G_graph_losses.items():
+                print(' Graph [%s]: %.4f' % (name, val))
+            for name, val in G_losses.items():
+                print(' G [%s]: %.4f' % (name, val))
+            for name, val in D_losses.items():
+                print(' D [%s]: %.4f' % (name, val))
+        t += 1
+    if rank == 0:
+        save_checkpoint(args, ckpt_path, ts, epoch, t)
+
+
+if __name__ == '__main__':
+    main(get_args())

@@ -9,6 +9,12 @@ have an exactly-zero true gradient: what is stored there is rounding noise).  Gr
 cell, and the same algorithm run in fp32 and in fp64 already differs by 1-3 % on them (measured: down_flow.0.1.bias
 abs-sum 2.749 fp32 / 2.840 fp64 / 2.759 reference), so a tighter bound would test the rounding, not the restatement.  Full gradient tensors are compared at 5e-3 of their
 max: the L1 / hinge / LeakyReLU derivatives are sign functions, so ulp-level forward differences flip individual terms.
+
+CHAOS note (iteration 1): Adam's first update is lr*sign(g) for every element, so every weight whose gradient is below
+the rounding noise moves by +-1e-4 in a direction that depends on summation order.  Measured: the very same oracle run
+on another host CPU (the GPU box: different core count / oneDNN blocking) gives it1 GAN_Feat 4.8032 against 4.7847 in
+the fixture (0.39 %), and the GPU differs from *that* oracle by 0.04 %.  Iteration 1 is therefore only sanity-checked at
+2e-2; parity is gated on iteration 0 (same weights bit for bit), where everything is held to the bounds above.
 """
 import json
 import os
@@ -71,7 +77,7 @@ def test_oracle_matches_reference_two_iterations(gold):
         batch = make_clip_batch(opt.vocab, toy['batch'], toy['frames'], tuple(toy['size']), seed=toy['seed'] + it)
         model_out, GL, DL = tr.gd_step(batch)
         p = 'it%d.' % it
-        ltol = 2e-4 if it == 0 else 1e-3   # iteration 1 starts from Adam-updated weights (sign-of-gradient steps)
+        ltol = 2e-4 if it == 0 else 2e-2   # iteration 1: see CHAOS note in the module docstring
         for k, v in GL.items():
             ref = float(gold[p + 'G_loss.' + k])
             assert abs(v.item() - ref) <= ltol * max(1.0, abs(ref)), (p, k, v.item(), ref)
@@ -120,7 +126,7 @@ def test_oracle_matches_reference_two_iterations(gold):
         # of a batch norm: its stored gradient is rounding noise) moves by lr in a noise-determined direction: the
         # per-element floor is lr per step taken.
         adam_floor = 1.2 * opt.learning_rate * (it + 1)
-        srel = 1e-3 if it == 0 else 5e-3      # iteration 1 inherits iteration 0's sign-flip differences
+        srel = 1e-3 if it == 0 else 2e-2      # iteration 1: see CHAOS note in the module docstring
         for n, t in tr.G.items():
             _close_stats(p + 'G_state.' + n, _stats(t.float()), gold[p + 'G_state.' + n], srel, t.numel(), adam_floor)
         for n, t in tr.D.items():
