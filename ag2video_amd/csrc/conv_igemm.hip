@@ -114,22 +114,32 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     const bool mvalid = (m0 + ma) < p.M;
     const float* aptr = p.a_src + ((MODE == MODE_FWD) ? (size_t)(m0 + ma) * p.KG : (size_t)(m0 + ma) * RS);
 
-    // kg is wave-uniform for the B gather (all lanes of a wave share the k-row): the (c,r,s) decode, the tap bit and
-    // the channel/tap offset are scalar; per lane only the mask test and one 64-bit add remain.
-    auto fetchB = [&](int kg_lane) -> float {
-        const int kg = __builtin_amdgcn_readfirstlane(kg_lane);
-        int c, r, s;
-        decode_crs(kg, RS, p.S, c, r, s);
-        const bool ok = ((vmask >> (r * p.S + s)) & 1u) && kg < p.KG;
-        if (MODE == MODE_FWD) {
-            const int koff = c * SHW + r * SW + s;
-            return ok ? bptr[koff] : 0.f;
-        } else if (affine) {
-            const int koff = c * SHW - r * SW - s;
-            return ok ? bptr[koff] : 0.f;
+    // K-index decode table: the 16 k-rows of a K-tile are decoded ONCE per workgroup (16 lanes in parallel) into LDS as
+    // {offset of (chan,tap) inside a source image, tap bit | r<<16 | s<<20}; every gathered element then costs one
+    // broadcast ds_read_b64, a mask test and one 64-bit add.  (A per-element scalar decode cost ~10 SALU per MFMA.)
+    __shared__ int2 tab[2][BK];
+    auto build_tab = [&](int kt) {
+        if (tid < BK) {
+            const int kg = kt * BK + tid;
+            int c, r, s2;
+            decode_crs(kg, RS, p.S, c, r, s2);
+            int koff;
+            if (MODE == MODE_FWD) koff = c * SHW + r * SW + s2;
+            else if (affine) koff = c * SHW - r * SW - s2;
+            else koff = c * SHW;
+            const unsigned bit = (kg < p.KG) ? (1u << (r * p.S + s2)) : 0u;
+            tab[kt & 1][tid] = make_int2(koff, (int)(bit | ((unsigned)r << 16) | ((unsigned)s2 << 20)));
+        }
+    };
+    auto fetchB = [&](int kt, int kk) -> float {
+        const int2 e = tab[kt & 1][kk];
+        const bool ok = (vmask & (unsigned)e.y & 0xFFFFu) != 0u;
+        if (MODE == MODE_FWD || affine) {
+            return ok ? bptr[e.x] : 0.f;
         } else {
-            const int oy = (y0 - r) / p.stride, ox = (x0 - s) / p.stride;
-            return ok ? bptr[c * SHW + oy * SW + ox] : 0.f;
+            const int r = (e.y >> 16) & 15, s2 = (e.y >> 20) & 15;
+            const int oy = (y0 - r) / p.stride, ox = (x0 - s2) / p.stride;
+            return ok ? bptr[e.x + oy * SW + ox] : 0.f;
         }
     };
     auto fetchA = [&](int kg) -> float {
@@ -153,10 +163,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 
     float ra[EA], rb[EB];
     const int nk = (p.KG + BK - 1) / BK;
+    build_tab(0);
+    __syncthreads();
+    build_tab(1);
 #pragma unroll
     for (int i = 0; i < EA; ++i) ra[i] = fetchA(kka0 + i);
 #pragma unroll
-    for (int i = 0; i < EB; ++i) rb[i] = fetchB(kkb0 + KSB * i);
+    for (int i = 0; i < EB; ++i) rb[i] = fetchB(0, kkb0 + KSB * i);
 #pragma unroll
     for (int i = 0; i < EA; ++i) As[0][kka0 + i][ma] = ra[i];
 #pragma unroll
@@ -171,7 +184,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
             for (int i = 0; i < EA; ++i) ra[i] = fetchA(k0 + kka0 + i);
 #pragma unroll
-            for (int i = 0; i < EB; ++i) rb[i] = fetchB(k0 + kkb0 + KSB * i);
+            for (int i = 0; i < EB; ++i) rb[i] = fetchB(kt + 1, kkb0 + KSB * i);
+            build_tab(kt + 2);   // tab[kt&1] was last read while fetching tile kt, i.e. before the previous barrier
         }
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
@@ -382,7 +396,7 @@ static int launch_igemm(ConvArgs& a, hipStream_t st) {
 
 extern "C" int ag2v_conv2d_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y,
                                int N, int C, int H, int W, int K, int R, int S, int stride, int pad, void* stream) {
-    if (!x || !w || !y || N <= 0 || C <= 0 || K <= 0 || stride <= 0) return AG2V_EINVAL;
+    if (!x || !w || !y || N <= 0 || C <= 0 || K <= 0 || stride <= 0 || R * S > 16) return AG2V_EINVAL;
     ConvArgs a{};
     a.a_src = w; a.b_src = x; a.out = y; a.bias = bias; a.residual = residual;
     a.N = N; a.C = C; a.H = H; a.W = W; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad;
@@ -400,7 +414,7 @@ extern "C" size_t ag2v_conv2d_dgrad_workspace_floats(int C, int K, int R, int S,
 extern "C" int ag2v_conv2d_dgrad(const float* dy, const float* w, float* dx,
                                  int N, int C, int H, int W, int K, int R, int S, int stride, int pad, float* workspace,
                                  void* stream) {
-    if (!dy || !w || !dx || N <= 0 || C <= 0 || K <= 0 || stride <= 0) return AG2V_EINVAL;
+    if (!dy || !w || !dx || N <= 0 || C <= 0 || K <= 0 || stride <= 0 || R * S > 16) return AG2V_EINVAL;
     if (stride == 1 && workspace && pad <= R - 1 && pad <= S - 1 && R == S) {
         // dX = conv_fwd(dY, flip-transpose(W), pad' = R-1-pad)
         hipStream_t st = (hipStream_t)stream;

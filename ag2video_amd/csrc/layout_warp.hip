@@ -102,6 +102,157 @@ __global__ __launch_bounds__(256) void layout_render_bwd_kernel(const float* __r
     }
 }
 
+// ---------------------------------------------------------------- layout convolution (low-rank form)
+// A layout is rank-<=n_obj:  seg[d,y,x] = sum_j v[j,d] * w_j(y,x),  w_j = ty_j (x) tx_j.  A convolution of it,
+//   Y[k,oy,ox] = sum_{d,r,s} Wt[k,d,r,s] * seg[d, oy*st+r-pad, ox*st+s-pad],
+// therefore equals  sum_j sum_{r,s} U[j,k,r,s] * w_j(oy*st+r-pad, ox*st+s-pad)  with  U[j,k,r,s] = sum_d Wt[k,d,r,s] v[j,d]
+// (a tiny GEMM done by the caller).  This kernel evaluates that sum directly -- the [D,H,W] layout (1024 x 256 x 256 floats
+// per sample and frame pair in the generator) is never materialised and ~99 % of the dense convolution's FLOPs disappear
+// ("layout tensors are huge and low-rank").  Reference call sites: the seg channels of
+// generator.py:74,82-83 (conv_dim_in) and flows_generator.py:32 (down_flow[0]).  Zero padding: w_j is 0 outside [0,H)x[0,W).
+// U: [NB, J, K, R*R]; boxes [NB, J, 4]; keep [NB, J]; residual/out [NB, K, OH, OW].
+template <int R>
+__device__ __forceinline__ void lc_taps_y(float (&tyr)[R], int oy, int stride, int pad, int H, float y0, float hh, bool active) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int yy = oy * stride + r - pad;
+        tyr[r] = (active && (unsigned)yy < (unsigned)H) ? tau8(lin01(yy, H), y0, hh) : 0.f;
+    }
+}
+
+template <int R, int KPER>
+__global__ __launch_bounds__(256) void layout_conv_fwd_kernel(const float* __restrict__ U, const float* __restrict__ boxes,
+                                                              const int* __restrict__ keep, const float* __restrict__ residual,
+                                                              float* __restrict__ out, int J, int K, int H, int W, int OH, int OW,
+                                                              int stride, int pad) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int oy = blockIdx.x * 4 + wave;
+    const int n = blockIdx.y;
+    const int k0 = blockIdx.z * KPER;
+    if (oy >= OH) return;
+    const int nq = (OW + 3) >> 2;
+    for (int xq = lane; xq < nq; xq += 64) {
+        float acc[KPER][4];
+#pragma unroll
+        for (int kk = 0; kk < KPER; ++kk)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ox = xq * 4 + q;
+                acc[kk][q] = (residual && (k0 + kk) < K && ox < OW)
+                                 ? residual[(((size_t)n * K + k0 + kk) * OH + oy) * OW + ox] : 0.f;
+            }
+        for (int j = 0; j < J; ++j) {
+            const float* b = boxes + ((size_t)n * J + j) * 4;
+            const float x0 = b[0], y0 = b[1], ww = b[2], hh = b[3];
+            const bool legal = (x0 != 0.f) || (y0 != 0.f) || (ww != 0.f) || (hh != 0.f);
+            const bool active = legal && keep[(size_t)n * J + j] != 0;
+            float tyr[R];
+            lc_taps_y<R>(tyr, oy, stride, pad, H, y0, hh, active);
+            float tysum = 0.f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) tysum += fabsf(tyr[r]);
+            if (tysum == 0.f) continue;  // wave-uniform
+            float txs[R][4];
+            float txsum = 0.f;
+#pragma unroll
+            for (int s = 0; s < R; ++s)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int xx = (xq * 4 + q) * stride + s - pad;
+                    txs[s][q] = ((unsigned)xx < (unsigned)W) ? tau8(lin01(xx, W), x0, ww) : 0.f;
+                    txsum += fabsf(txs[s][q]);
+                }
+            if (__ballot(txsum != 0.f) == 0ull) continue;
+            const float* uj = U + (((size_t)n * J + j) * K + k0) * (R * R);
+#pragma unroll
+            for (int kk = 0; kk < KPER; ++kk) {
+                if (k0 + kk < K) {
+                    const float* u = uj + kk * (R * R);
+#pragma unroll
+                    for (int s = 0; s < R; ++s) {
+                        float cs = 0.f;
+#pragma unroll
+                        for (int r = 0; r < R; ++r) cs += tyr[r] * u[r * R + s];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[kk][q] += cs * txs[s][q];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < KPER; ++kk) {
+            if (k0 + kk >= K) continue;
+            float* o = out + (((size_t)n * K + k0 + kk) * OH + oy) * OW + xq * 4;
+            if ((OW & 3) == 0) {
+                *reinterpret_cast<float4*>(o) = make_float4(acc[kk][0], acc[kk][1], acc[kk][2], acc[kk][3]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (xq * 4 + q < OW) o[q] = acc[kk][q];
+            }
+        }
+    }
+}
+
+// dU[n,j,k,r,s] = sum_{oy,ox} dout[n,k,oy,ox] * ty_j(oy*st+r-pad) * tx_j(ox*st+s-pad): grid (J, NB, ceil(K/32)),
+// wave w reduces channels k = 32*blockIdx.z + w + 4*i; only the rows / 64-column blocks the object touches are read.
+template <int R>
+__global__ __launch_bounds__(256) void layout_conv_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ boxes,
+                                                              const int* __restrict__ keep, float* __restrict__ dU, int J, int K,
+                                                              int H, int W, int OH, int OW, int stride, int pad) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.x, n = blockIdx.y;
+    const float* b = boxes + ((size_t)n * J + j) * 4;
+    const float x0 = b[0], y0 = b[1], ww = b[2], hh = b[3];
+    const bool legal = (x0 != 0.f) || (y0 != 0.f) || (ww != 0.f) || (hh != 0.f);
+    const bool active = legal && keep[(size_t)n * J + j] != 0;
+    for (int i = 0; i < 8; ++i) {
+        const int k = blockIdx.z * 32 + wave + 4 * i;
+        if (k >= K) break;
+        float acc[R][R];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int s = 0; s < R; ++s) acc[r][s] = 0.f;
+        if (active) {
+            for (int xb = 0; xb < OW; xb += 64) {
+                const int ox = xb + lane;
+                float txs[R];
+                float txsum = 0.f;
+#pragma unroll
+                for (int s = 0; s < R; ++s) {
+                    const int xx = ox * stride + s - pad;
+                    txs[s] = (ox < OW && (unsigned)xx < (unsigned)W) ? tau8(lin01(xx, W), x0, ww) : 0.f;
+                    txsum += fabsf(txs[s]);
+                }
+                if (__ballot(txsum != 0.f) == 0ull) continue;
+                const float* dp = dout + ((size_t)n * K + k) * OH * OW + ox;
+                for (int oy = 0; oy < OH; ++oy) {
+                    float tyr[R];
+                    lc_taps_y<R>(tyr, oy, stride, pad, H, y0, hh, true);
+                    float tysum = 0.f;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) tysum += fabsf(tyr[r]);
+                    if (tysum == 0.f) continue;  // wave-uniform
+                    const float g = (txsum != 0.f) ? dp[(size_t)oy * OW] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+#pragma unroll
+                        for (int s = 0; s < R; ++s) acc[r][s] += g * tyr[r] * txs[s];
+                }
+            }
+        }
+        float* o = dU + (((size_t)n * J + j) * K + k) * (R * R);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int s = 0; s < R; ++s) {
+                const float v = wave_sum(acc[r][s]);
+                if (lane == 0) o[r * R + s] = v;
+            }
+    }
+}
+
 // ---------------------------------------------------------------- flow warp
 struct WarpTap { int x0, y0, x1, y1; float fx, fy, mx, my; };
 __device__ __forceinline__ WarpTap warp_tap(float fxv, float fyv, int x, int y, int H, int W) {
@@ -304,6 +455,41 @@ extern "C" int ag2v_layout_render_bwd(const float* dout, const float* boxes, con
     if (BT > 65535) return AG2V_EINVAL;
     hipLaunchKernelGGL(layout_render_bwd_kernel, dim3(O, BT, ceil_div(D, 32)), dim3(256), 0, (hipStream_t)stream, dout, boxes,
                        keep, dvecs, O, D, H, W);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+
+extern "C" int ag2v_layout_conv_fwd(const float* U, const float* boxes, const int* keep, const float* residual, float* out,
+                                    int NB, int J, int K, int H, int W, int R, int stride, int pad, void* stream) {
+    if (!U || !boxes || !keep || !out || NB <= 0 || J <= 0 || K <= 0 || H <= 0 || W <= 0 || stride <= 0 || NB > 65535) return AG2V_EINVAL;
+    if (R != 3 && R != 4) return AG2V_EINVAL;
+    const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - R) / stride + 1;
+    if (OH <= 0 || OW <= 0) return AG2V_EINVAL;
+    constexpr int KPER = 16;
+    dim3 grid(ceil_div(OH, 4), NB, ceil_div(K, KPER));
+    if (R == 3)
+        hipLaunchKernelGGL((layout_conv_fwd_kernel<3, KPER>), grid, dim3(256), 0, (hipStream_t)stream, U, boxes, keep, residual, out,
+                           J, K, H, W, OH, OW, stride, pad);
+    else
+        hipLaunchKernelGGL((layout_conv_fwd_kernel<4, KPER>), grid, dim3(256), 0, (hipStream_t)stream, U, boxes, keep, residual, out,
+                           J, K, H, W, OH, OW, stride, pad);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+
+extern "C" int ag2v_layout_conv_bwd(const float* dout, const float* boxes, const int* keep, float* dU, int NB, int J, int K, int H,
+                                    int W, int R, int stride, int pad, void* stream) {
+    if (!dout || !boxes || !keep || !dU || NB <= 0 || J <= 0 || K <= 0 || H <= 0 || W <= 0 || stride <= 0 || NB > 65535) return AG2V_EINVAL;
+    if (R != 3 && R != 4) return AG2V_EINVAL;
+    const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - R) / stride + 1;
+    if (OH <= 0 || OW <= 0) return AG2V_EINVAL;
+    dim3 grid(J, NB, ceil_div(K, 32));
+    if (R == 3)
+        hipLaunchKernelGGL(layout_conv_bwd_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, dout, boxes, keep, dU, J, K, H, W, OH,
+                           OW, stride, pad);
+    else
+        hipLaunchKernelGGL(layout_conv_bwd_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, dout, boxes, keep, dU, J, K, H, W, OH,
+                           OW, stride, pad);
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
 }

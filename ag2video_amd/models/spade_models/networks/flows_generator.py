@@ -3,6 +3,7 @@ import torch.nn as nn
 
 from .... import ops
 from ...layers import Conv2d
+from ...layout import layout_conv_lowrank
 from .normalization import SpectralConv2d, get_nonspade_norm_layer
 from .sync_batchnorm import SynchronizedBatchNorm2d
 
@@ -58,11 +59,25 @@ class FlowsGenerator(nn.Module):
     def _conv_bn_act(seq, x):
         return seq[1](seq[0](x), slope=0.2)
 
-    def forward(self, label):
+    def forward(self, label=None, layout=None, prev=None):
+        """Either ``label`` = cat[layouts, previous frames] (dense first conv, as flows_generator.py:62-68), or
+        ``layout`` = (vecs_list, boxes_list, keep, H) + ``prev`` [B, 3*nc, H, W]: the first conv then treats its layout
+        channels in low-rank form (models/layout.py:layout_conv_lowrank) and only the image channels densely."""
+        first = True
         x = label
         for m in self.down_flow:
             if isinstance(m, nn.Sequential):
-                x = self._conv_bn_act(m, x)
+                if first and layout is not None:
+                    vecs_list, boxes_list, keep, H = layout
+                    conv, bn = m[0], m[1]
+                    w = conv.effective_weight()
+                    nseg = w.shape[1] - prev.shape[1]
+                    y = ops.conv2d(prev, w[:, nseg:], None, conv.stride, conv.padding)
+                    y = layout_conv_lowrank(w[:, :nseg], vecs_list, boxes_list, keep, H, H, conv.stride, conv.padding, residual=y)
+                    x = bn(y, slope=0.2)
+                else:
+                    x = self._conv_bn_act(m, x)
+                first = False
         for blk in self.res_flow:
             x = blk(x)
         for m in self.up_flow:

@@ -288,6 +288,44 @@ def layout_render(vecs, boxes, keep, H, W):
     return _LayoutRender.apply(vecs, boxes, keep, int(H), int(W))
 
 
+class _LayoutConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, U, boxes, keep, residual, H, W, R, stride, pad):
+        U, boxes, residual = _c(U), _c(boxes), _c(residual)
+        _chk(U, boxes, residual)
+        keep = keep.to(torch.int32).contiguous()
+        NB, J, K, RS = U.shape
+        if RS != R * R:
+            raise RuntimeError("layout_conv: U has %d taps, expected %d" % (RS, R * R))
+        OH = (H + 2 * pad - R) // stride + 1
+        OW = (W + 2 * pad - R) // stride + 1
+        out = torch.empty((NB, K, OH, OW), device=U.device, dtype=torch.float32)
+        _lib.call('ag2v_layout_conv_fwd', _ptr(U), _ptr(boxes), _ptr(keep), _ptr(residual), _ptr(out), NB, J, K, H, W, R, stride,
+                  pad, _stream())
+        ctx.save_for_backward(boxes, keep)
+        ctx.cfg = (NB, J, K, H, W, R, stride, pad, residual is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        boxes, keep = ctx.saved_tensors
+        NB, J, K, H, W, R, stride, pad, has_res = ctx.cfg
+        dout = dout.contiguous()
+        dU = None
+        if ctx.needs_input_grad[0]:
+            dU = torch.empty((NB, J, K, R * R), device=dout.device, dtype=torch.float32)
+            _lib.call('ag2v_layout_conv_bwd', _ptr(dout), _ptr(boxes), _ptr(keep), _ptr(dU), NB, J, K, H, W, R, stride, pad,
+                      _stream())
+        dres = dout if (has_res and ctx.needs_input_grad[3]) else None
+        return dU, None, None, dres, None, None, None, None, None
+
+
+def layout_conv(U, boxes, keep, H, W, R=3, stride=1, pad=1, residual=None):
+    """Convolution of a box layout in its low-rank form (see csrc/layout_warp.hip): U[NB,J,K,R*R] are the filter taps already
+    contracted with each object's vector; out = residual + sum_j sum_rs U[:,j,:,rs] * w_j(shifted)."""
+    return _LayoutConv.apply(U, boxes, keep, residual, int(H), int(W), int(R), int(stride), int(pad))
+
+
 class _FlowWarp(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img, flow):

@@ -83,6 +83,23 @@ def layout_render(vecs, boxes, keep, H, W):
     return torch.cat(outs, dim=0)
 
 
+def layout_conv(U, boxes, keep, H, W, R=3, stride=1, pad=1, residual=None):
+    """Checker for the low-rank layout convolution: render each object's weight map w_j with the reference's own
+    boxes_to_layout arithmetic (models/layout.py:28-63, vectors = identity) and convolve it densely with U as the filter."""
+    NB, J, K, _ = U.shape
+    outs = []
+    eye = torch.eye(J, dtype=U.dtype)
+    for n in range(NB):
+        wmaps = torch.zeros(1, J, H, W, dtype=U.dtype)
+        for j in range(J):
+            if bool(keep[n, j]) and bool((boxes[n, j] != 0).any()):
+                wmaps[0, j] = boxes_to_layout_single(eye[j:j + 1, j:j + 1], boxes[n, j:j + 1], H, W)[0, 0]
+        filt = U[n].permute(1, 0, 2).reshape(K, J, R, R)
+        outs.append(F.conv2d(wmaps, filt, None, stride=stride, padding=pad))
+    y = torch.cat(outs, dim=0)
+    return y if residual is None else y + residual
+
+
 def flow_warp(img, flow):
     """resample + get_grid (models/utils.py:113-140), ALIGN_CORNERS=False (data/args.py:228)."""
     b, c, h, w = img.shape
