@@ -24,10 +24,13 @@ struct ConvArgs {
     const float* residual;  // FWD: same shape as y, or null
     int N, C, H, W;         // input image
     int K, R, S, OH, OW;    // filters / output image
-    int stride, pad;
+    int stride, pad;        // pad = padding along y
+    int pad_w;              // padding along x (== pad except for the parity sub-filters of a strided dgrad)
+    int o_mul, o_add_y, o_add_x, o_H, o_W;  // FWD output placement: (oy,ox) -> (oy*o_mul+o_add_y, ox*o_mul+o_add_x) in [o_H,o_W]
     int M, NG, KG;          // GEMM dims of this mode
     int tiles_m, tiles_n;
     int splitk, kchunk;     // WGRAD: number of pixel-range splits, pixels per split (multiple of 16)
+                            // FWD/DGRAD: number of K-range splits (grid.y), K-tiles per split; >1 => atomic epilogue
 };
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1 };
@@ -88,10 +91,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     int y0, x0;
     if (MODE == MODE_FWD) {
         y0 = py * p.stride - p.pad;
-        x0 = px * p.stride - p.pad;
+        x0 = px * p.stride - p.pad_w;
     } else {
         y0 = py + p.pad;
-        x0 = px + p.pad;
+        x0 = px + p.pad_w;
     }
     if (pvalid) {
         for (int r = 0; r < p.R; ++r)
@@ -162,14 +165,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float ra[EA], rb[EB];
-    const int nk = (p.KG + BK - 1) / BK;
-    build_tab(0);
+    const int nk_all = (p.KG + BK - 1) / BK;
+    const int kt0 = (p.splitk > 1) ? blockIdx.y * p.kchunk : 0;          // small-N layers: split the K loop over grid.y
+    const int nk = (p.splitk > 1) ? min(nk_all, kt0 + p.kchunk) : nk_all;
+    if (kt0 >= nk) return;  // uniform per workgroup
+    build_tab(kt0);
     __syncthreads();
-    build_tab(1);
+    build_tab(kt0 + 1);
 #pragma unroll
-    for (int i = 0; i < EA; ++i) ra[i] = fetchA(kka0 + i);
+    for (int i = 0; i < EA; ++i) ra[i] = fetchA(kt0 * BK + kka0 + i);
 #pragma unroll
-    for (int i = 0; i < EB; ++i) rb[i] = fetchB(0, kkb0 + KSB * i);
+    for (int i = 0; i < EB; ++i) rb[i] = fetchB(kt0, kkb0 + KSB * i);
 #pragma unroll
     for (int i = 0; i < EA; ++i) As[0][kka0 + i][ma] = ra[i];
 #pragma unroll
@@ -177,7 +183,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     __syncthreads();
 
     int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = kt0; kt < nk; ++kt) {
         const bool more = (kt + 1) < nk;
         if (more) {
             const int k0 = (kt + 1) * BK;
@@ -213,13 +219,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 
     // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31 (pixel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     const int OUTC = (MODE == MODE_FWD) ? p.K : p.C;
-    const int plane = PH * PW;
+    const int gplane = PH * PW;                                    // pixels of the GEMM's pixel space per image
+    const int plane = (MODE == MODE_FWD) ? p.o_H * p.o_W : gplane;  // elements of one output channel plane
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int opix = n0 + wn0 + j * 32 + (lane & 31);
         if (opix >= p.NG) continue;
-        const int on = opix / plane;
-        const int orem = opix - on * plane;
+        const int on = opix / gplane;
+        int orem = opix - on * gplane;
+        if (MODE == MODE_FWD && (p.o_mul != 1 || p.o_add_y != 0 || p.o_add_x != 0 || p.o_W != PW)) {
+            const int qy = orem / PW, qx = orem - qy * PW;
+            const int yy = qy * p.o_mul + p.o_add_y, xx = qx * p.o_mul + p.o_add_x;
+            if ((unsigned)yy >= (unsigned)p.o_H || (unsigned)xx >= (unsigned)p.o_W) continue;
+            orem = yy * p.o_W + xx;
+        }
         float* obase = p.out + (size_t)on * OUTC * plane + orem;
         const float* rbase = (MODE == MODE_FWD && p.residual) ? p.residual + (size_t)on * OUTC * plane + orem : nullptr;
 #pragma unroll
@@ -229,11 +242,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
                 const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m < p.M) {
                     float v = acc[i][j][r];
-                    if (MODE == MODE_FWD) {
+                    if (MODE == MODE_FWD && kt0 == 0) {
                         if (p.bias) v += p.bias[m];
                         if (rbase) v += rbase[(size_t)m * plane];
                     }
-                    obase[(size_t)m * plane] = v;
+                    if (p.splitk > 1)
+                        atomicAdd(obase + (size_t)m * plane, v);
+                    else
+                        obase[(size_t)m * plane] = v;
                 }
             }
         }
@@ -372,24 +388,54 @@ __global__ __launch_bounds__(256) void weight_flip_transpose_kernel(const float*
     wt[i] = w[((size_t)k * C + c) * RS + (RS - 1 - rs)];
 }
 
+// Sub-filter of parity class (py,px) of a stride-2 data gradient, flipped and transposed for the forward kernel:
+//   wt[c][k][r''][s''] = w[k][c][py + 2*(Rc-1-r'')][px + 2*(Sc-1-s'')]
+__global__ __launch_bounds__(256) void weight_parity_flip_kernel(const float* __restrict__ w, float* __restrict__ wt, int K, int C,
+                                                                 int R, int S, int py, int px, int Rc, int Sc) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)K * C * Rc * Sc) return;
+    const int s2 = (int)(i % Sc);
+    long long t = i / Sc;
+    const int r2 = (int)(t % Rc);
+    t /= Rc;
+    const int k = (int)(t % K), c = (int)(t / K);
+    const int r = py + 2 * (Rc - 1 - r2), s = px + 2 * (Sc - 1 - s2);
+    wt[i] = w[(((size_t)k * C + c) * R + r) * S + s];
+}
+
 static int conv_out_dim(int in, int k, int stride, int pad) { return (in + 2 * pad - k) / stride + 1; }
 
 template <int MODE>
-static int launch_igemm(ConvArgs& a, hipStream_t st) {
+static int launch_igemm(ConvArgs& a, hipStream_t st, bool out_zeroed = false) {
     if (a.M <= 0 || a.NG <= 0 || a.KG <= 0) return AG2V_EINVAL;
-    if (a.M <= 32) {
-        a.tiles_m = ceil_div(a.M, 32);
-        a.tiles_n = ceil_div(a.NG, 256);
-        hipLaunchKernelGGL((conv_igemm_kernel<MODE, 32, 256, 1, 4>), dim3(a.tiles_m * a.tiles_n), dim3(256), 0, st, a);
-    } else if (a.M <= 64) {
-        a.tiles_m = ceil_div(a.M, 64);
-        a.tiles_n = ceil_div(a.NG, 256);
-        hipLaunchKernelGGL((conv_igemm_kernel<MODE, 64, 256, 1, 4>), dim3(a.tiles_m * a.tiles_n), dim3(256), 0, st, a);
-    } else {
-        a.tiles_m = ceil_div(a.M, 128);
-        a.tiles_n = ceil_div(a.NG, 128);
-        hipLaunchKernelGGL((conv_igemm_kernel<MODE, 128, 128, 2, 2>), dim3(a.tiles_m * a.tiles_n), dim3(256), 0, st, a);
+    if (a.o_mul == 0) { a.o_mul = 1; a.o_add_y = 0; a.o_add_x = 0; a.o_H = a.OH; a.o_W = a.OW; }
+    const int bm = (a.M <= 32) ? 32 : (a.M <= 64 ? 64 : 128);
+    const int bn = (bm == 128) ? 128 : 256;
+    a.tiles_m = ceil_div(a.M, bm);
+    a.tiles_n = ceil_div(a.NG, bn);
+    // Layers with few output pixels (8x8 ... 32x32 maps) have fewer tiles than the chip has CUs while their K loop is
+    // thousands of steps long: split K over grid.y and accumulate with fp32 atomics into the zeroed output.
+    const int tiles = a.tiles_m * a.tiles_n, nk = ceil_div(a.KG, 16);
+    a.splitk = 1; a.kchunk = nk;
+    if (tiles < 384 && nk >= 16) {
+        int sk = ceil_div(768, tiles);
+        if (sk > nk / 8) sk = nk / 8;
+        if (sk > 1) {
+            a.kchunk = ceil_div(nk, sk);
+            a.splitk = ceil_div(nk, a.kchunk);
+        }
     }
+    if (a.splitk > 1 && !out_zeroed) {
+        const size_t out_elems = (MODE == MODE_FWD) ? (size_t)a.N * a.K * a.o_H * a.o_W : (size_t)a.N * a.C * a.H * a.W;
+        if (hipMemsetAsync(a.out, 0, out_elems * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
+    }
+    dim3 grid(tiles, a.splitk);
+    if (bm == 32)
+        hipLaunchKernelGGL((conv_igemm_kernel<MODE, 32, 256, 1, 4>), grid, dim3(256), 0, st, a);
+    else if (bm == 64)
+        hipLaunchKernelGGL((conv_igemm_kernel<MODE, 64, 256, 1, 4>), grid, dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<MODE, 128, 128, 2, 2>), grid, dim3(256), 0, st, a);
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
 }
@@ -399,7 +445,7 @@ extern "C" int ag2v_conv2d_fwd(const float* x, const float* w, const float* bias
     if (!x || !w || !y || N <= 0 || C <= 0 || K <= 0 || stride <= 0 || R * S > 16) return AG2V_EINVAL;
     ConvArgs a{};
     a.a_src = w; a.b_src = x; a.out = y; a.bias = bias; a.residual = residual;
-    a.N = N; a.C = C; a.H = H; a.W = W; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad;
+    a.N = N; a.C = C; a.H = H; a.W = W; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.pad_w = pad;
     a.OH = conv_out_dim(H, R, stride, pad); a.OW = conv_out_dim(W, S, stride, pad);
     if (a.OH <= 0 || a.OW <= 0) return AG2V_EINVAL;
     if ((long long)N * a.OH * a.OW >= (1LL << 31) || (long long)C * R * S >= (1LL << 31)) return AG2V_EINVAL;
@@ -408,7 +454,7 @@ extern "C" int ag2v_conv2d_fwd(const float* x, const float* w, const float* bias
 }
 
 extern "C" size_t ag2v_conv2d_dgrad_workspace_floats(int C, int K, int R, int S, int stride) {
-    return stride == 1 ? (size_t)C * K * R * S : 0;
+    return (stride == 1 || stride == 2) ? (size_t)C * K * R * S : 0;
 }
 
 extern "C" int ag2v_conv2d_dgrad(const float* dy, const float* w, float* dx,
@@ -424,15 +470,43 @@ extern "C" int ag2v_conv2d_dgrad(const float* dy, const float* w, float* dx,
         if (OH <= 0 || OW <= 0) return AG2V_EINVAL;
         ConvArgs f{};
         f.a_src = workspace; f.b_src = dy; f.out = dx;
-        f.N = N; f.C = K; f.H = OH; f.W = OW; f.K = C; f.R = R; f.S = S; f.stride = 1; f.pad = R - 1 - pad;
+        f.N = N; f.C = K; f.H = OH; f.W = OW; f.K = C; f.R = R; f.S = S; f.stride = 1; f.pad = R - 1 - pad; f.pad_w = S - 1 - pad;
         f.OH = H; f.OW = W;
         if ((long long)N * H * W >= (1LL << 31) || (long long)K * R * S >= (1LL << 31)) return AG2V_EINVAL;
         f.M = C; f.NG = N * H * W; f.KG = K * R * S;
         return launch_igemm<MODE_FWD>(f, st);
     }
+    if (stride == 2 && workspace) {
+        // Stride-2 data gradient by output-pixel parity: pixels with (y+pad)%2 == py, (x+pad)%2 == px only see the taps
+        // r = py + 2r', s = px + 2s', i.e. each class is a stride-1 correlation of dY with a (R/2 x S/2) sub-filter
+        // -> four forward-kernel launches with 1/4 of the taps each instead of one launch that multiplies 3/4 zeros.
+        hipStream_t st = (hipStream_t)stream;
+        const int OH = conv_out_dim(H, R, 2, pad), OW = conv_out_dim(W, S, 2, pad);
+        if (OH <= 0 || OW <= 0) return AG2V_EINVAL;
+        if (hipMemsetAsync(dx, 0, (size_t)N * C * H * W * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
+        float* wt = workspace;
+        for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px) {
+                const int Rc = (R - py + 1) / 2, Sc = (S - px + 1) / 2;   // taps r in [0,R) with r%2 == py
+                if (Rc <= 0 || Sc <= 0) continue;
+                const long long nw = (long long)K * C * Rc * Sc;
+                hipLaunchKernelGGL(weight_parity_flip_kernel, dim3(ceil_div(nw, 256)), dim3(256), 0, st, w, wt, K, C, R, S, py, px, Rc, Sc);
+                ConvArgs f{};
+                f.a_src = wt; f.b_src = dy; f.out = dx;
+                f.N = N; f.C = K; f.H = OH; f.W = OW; f.K = C; f.R = Rc; f.S = Sc; f.stride = 1; f.pad = Rc - 1; f.pad_w = Sc - 1;
+                f.OH = OH + Rc - 1; f.OW = OW + Sc - 1;
+                f.o_mul = 2; f.o_add_y = py - pad; f.o_add_x = px - pad; f.o_H = H; f.o_W = W;
+                if ((long long)N * f.OH * f.OW >= (1LL << 31)) return AG2V_EINVAL;
+                f.M = C; f.NG = N * f.OH * f.OW; f.KG = K * Rc * Sc;
+                const int rc = launch_igemm<MODE_FWD>(f, st, true);
+                if (rc != AG2V_OK) return rc;
+                wt += nw;
+            }
+        return AG2V_OK;
+    }
     ConvArgs a{};
     a.a_src = w; a.b_src = dy; a.out = dx;
-    a.N = N; a.C = C; a.H = H; a.W = W; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad;
+    a.N = N; a.C = C; a.H = H; a.W = W; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.pad_w = pad;
     a.OH = conv_out_dim(H, R, stride, pad); a.OW = conv_out_dim(W, S, stride, pad);
     if (a.OH <= 0 || a.OW <= 0) return AG2V_EINVAL;
     if ((long long)N * H * W >= (1LL << 31) || (long long)K * R * S >= (1LL << 31)) return AG2V_EINVAL;
@@ -446,7 +520,7 @@ extern "C" int ag2v_conv2d_wgrad(const float* dy, const float* x, float* dw,
     hipStream_t st = (hipStream_t)stream;
     ConvArgs a{};
     a.a_src = dy; a.b_src = x; a.out = dw;
-    a.N = N; a.C = C; a.H = H; a.W = W; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad;
+    a.N = N; a.C = C; a.H = H; a.W = W; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.pad_w = pad;
     a.OH = conv_out_dim(H, R, stride, pad); a.OW = conv_out_dim(W, S, stride, pad);
     if (a.OH <= 0 || a.OW <= 0) return AG2V_EINVAL;
     const long long Q = (long long)N * a.OH * a.OW;

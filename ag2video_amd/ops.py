@@ -47,7 +47,7 @@ def _conv_label(mode, M):
     return "conv_%s_bm%d" % (mode, 32 if M <= 32 else (64 if M <= 64 else 128))
 
 
-def _launch(name, label, flops, *args):
+def _launch(name, label, flops, *args, shape=None):
     if _TIMING is None:
         _lib.call(name, *args)
         return
@@ -55,14 +55,16 @@ def _launch(name, label, flops, *args):
     e0.record()
     _lib.call(name, *args)
     e1.record()
-    _TIMING.append((label, flops, e0, e1))
+    _TIMING.append((label, flops, e0, e1, shape))
 
 
-def kernel_timing_summary():
+def kernel_timing_summary(by_shape=False):
     """{label: {launches, flops, ms}} for everything recorded since enable_kernel_timing(True); synchronises."""
     torch.cuda.synchronize()
     out = {}
-    for label, flops, e0, e1 in (_TIMING or []):
+    for label, flops, e0, e1, shape in (_TIMING or []):
+        if by_shape:
+            label = "%s %s" % (label, shape)
         d = out.setdefault(label, {'launches': 0, 'flops': 0.0, 'ms': 0.0})
         d['launches'] += 1
         d['flops'] += flops
@@ -84,7 +86,8 @@ class _Conv2d(torch.autograd.Function):
         OW = (W + 2 * pad - S) // stride + 1
         y = torch.empty((N, K, OH, OW), device=x.device, dtype=torch.float32)
         _launch('ag2v_conv2d_fwd', _conv_label('fwd', K), 2.0 * N * K * OH * OW * C * R * S,
-                _ptr(x), _ptr(w), _ptr(bias), _ptr(residual), _ptr(y), N, C, H, W, K, R, S, stride, pad, _stream())
+                _ptr(x), _ptr(w), _ptr(bias), _ptr(residual), _ptr(y), N, C, H, W, K, R, S, stride, pad, _stream(),
+                shape=(N, C, H, W, K, R, stride))
         ctx.save_for_backward(x, w)
         ctx.cfg = (stride, pad, bias is not None, residual is not None)
         return y
@@ -104,11 +107,13 @@ class _Conv2d(torch.autograd.Function):
             nws = _lib.query('ag2v_conv2d_dgrad_workspace_floats', C, K, R, S, stride)
             ws = torch.empty(nws, device=dy.device, dtype=torch.float32) if nws else None
             _launch('ag2v_conv2d_dgrad', _conv_label('dgrad', C), flops,
-                    _ptr(dy), _ptr(w), _ptr(dx), N, C, H, W, K, R, S, stride, pad, _ptr(ws), st)
+                    _ptr(dy), _ptr(w), _ptr(dx), N, C, H, W, K, R, S, stride, pad, _ptr(ws), st,
+                    shape=(N, C, H, W, K, R, stride))
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
             _launch('ag2v_conv2d_wgrad', _conv_label('wgrad', K), flops,
-                    _ptr(dy), _ptr(x), _ptr(dw), N, C, H, W, K, R, S, stride, pad, st)
+                    _ptr(dy), _ptr(x), _ptr(dw), N, C, H, W, K, R, S, stride, pad, st,
+                    shape=(N, C, H, W, K, R, stride))
         if has_bias and ctx.needs_input_grad[2]:
             db = torch.empty(K, device=dy.device, dtype=torch.float32)
             _lib.call('ag2v_channel_sum', _ptr(dy), _ptr(db), N, K, dy.shape[2] * dy.shape[3], st)

@@ -98,6 +98,10 @@ def main():
         torch.distributed.barrier()
     dt = D.max_over_ranks(time.time() - t0, device)
     timing = ops.kernel_timing_summary() if not args.no_kernel_timing else {}
+    if os.environ.get('AG2V_TIMING_DETAIL') and rank == 0:
+        det = ops.kernel_timing_summary(by_shape=True)
+        for k, v in sorted(det.items(), key=lambda kv: -kv[1]['ms'])[:45]:
+            print('DETAIL %8.1f ms %5d launches %6.1f TF  %s' % (v['ms'], v['launches'], v['flops'] / (v['ms'] * 1e-3) / 1e12, k), file=sys.stderr)
     ops.enable_kernel_timing(False)
     finite = all(bool(torch.isfinite(v).all()) for v in list(GL.values()) + list(DL.values()))
 

@@ -64,6 +64,10 @@ CONV_CASES = [
     (3, 259, 33, 33, 64, 4, 4, 2, 2, True, False),
     (2, 130, 12, 12, 3, 3, 3, 1, 1, True, False),
     (2, 3, 16, 16, 200, 3, 3, 1, 1, True, False),
+    (2, 64, 8, 8, 48, 3, 3, 1, 1, True, True),        # few pixels, long K loop: split-K (atomic epilogue) path
+    (4, 128, 16, 16, 200, 3, 3, 1, 1, True, False),
+    (2, 40, 9, 9, 150, 1, 1, 2, 0, False, False),     # 1x1 stride 2: three of the four parity classes are empty
+    (2, 12, 20, 18, 24, 3, 3, 2, 1, True, False),
 ]
 
 
