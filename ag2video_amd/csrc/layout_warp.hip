@@ -422,6 +422,17 @@ __global__ __launch_bounds__(256) void nearest_resize_bwd_kernel(const float* __
     const int iy = (int)(r % H);
     const long long nc = r / H;
     const float* dp = dy + (size_t)nc * OH * OW;
+    if (H % OH == 0 && W % OW == 0 && H >= OH && W >= OW) {
+        // integer down-sampling factor f: output o reads input o*f, so only inputs on the f-grid receive a gradient
+        const int fy = H / OH, fx = W / OW;
+        dx[idx] = (iy % fy == 0 && ix % fx == 0) ? dp[(iy / fy) * OW + (ix / fx)] : 0.f;
+        return;
+    }
+    if (OH == 2 * H && OW == 2 * W) {  // nearest x2 up-sampling: each input is read by a 2x2 output block
+        const float* q = dp + (size_t)(2 * iy) * OW + 2 * ix;
+        dx[idx] = (q[0] + q[1]) + (q[OW] + q[OW + 1]);
+        return;
+    }
     // outputs o with nearest_src(o) == i lie in [i*out/in - 1, (i+1)*out/in + 1]
     const int oy_lo = max(0, (int)((long long)iy * OH / H) - 1), oy_hi = min(OH - 1, (int)((long long)(iy + 1) * OH / H) + 1);
     const int ox_lo = max(0, (int)((long long)ix * OW / W) - 1), ox_hi = min(OW - 1, (int)((long long)(ix + 1) * OW / W) + 1);

@@ -292,17 +292,25 @@ __global__ __launch_bounds__(256) void instnorm_lrelu_bwd_kernel(const float* __
 }
 
 // ---------------------------------------------------------------- per-channel sum over (N, H*W): conv bias gradient
+// grid (C, nsplit): split s sums images n = s, s+nsplit, ...; nsplit > 1 accumulates with one atomic per workgroup
 __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int C,
-                                                          int HW) {
+                                                          int HW, int nsplit) {
     __shared__ float sh[4];
     const int c = blockIdx.x;
     float s = 0.f;
-    for (int n = 0; n < N; ++n) {
+    for (int n = blockIdx.y; n < N; n += nsplit) {
         const float* p = x + ((size_t)n * C + c) * HW;
-        for (int i = threadIdx.x; i < HW; i += 256) s += p[i];
+        if ((HW & 3) == 0 && ((((uintptr_t)p) & 15) == 0)) {
+            const float4* p4 = reinterpret_cast<const float4*>(p);
+            for (int i = threadIdx.x; i < (HW >> 2); i += 256) { const float4 v = p4[i]; s += (v.x + v.y) + (v.z + v.w); }
+        } else {
+            for (int i = threadIdx.x; i < HW; i += 256) s += p[i];
+        }
     }
     s = block_sum_256(s, sh);
-    if (threadIdx.x == 0) out[c] = s;
+    if (threadIdx.x == 0) {
+        if (nsplit > 1) atomicAdd(out + c, s); else out[c] = s;
+    }
 }
 
 // ================================================================ C ABI
@@ -408,7 +416,14 @@ extern "C" int ag2v_instnorm_lrelu_bwd(const float* dy, const float* y, const fl
 
 extern "C" int ag2v_channel_sum(const float* x, float* out, int N, int C, int HW, void* stream) {
     if (!x || !out || N <= 0 || C <= 0 || HW <= 0) return AG2V_EINVAL;
-    hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, out, N, C, HW);
+    hipStream_t st = (hipStream_t)stream;
+    int nsplit = 1;
+    if ((long long)C < 1024 && (long long)HW * N >= (1 << 16)) {
+        nsplit = ceil_div(1024, C);
+        if (nsplit > N) nsplit = N;
+    }
+    if (nsplit > 1 && hipMemsetAsync(out, 0, (size_t)C * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(C, nsplit), dim3(256), 0, st, x, out, N, C, HW, nsplit);
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
 }

@@ -82,13 +82,15 @@ __global__ __launch_bounds__(256) void reduce_bwd_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------- spectral norm (W viewed as [M, R], row-major)
+// v[r] (+)= sum_{m in this row slice} W[m,r] u[m]; grid (ceil(R/256), msplit); msplit > 1 accumulates atomically into zeroed v
 __global__ __launch_bounds__(256) void sn_wtu_kernel(const float* __restrict__ w, const float* __restrict__ u, float* __restrict__ v,
-                                                     int M, int R) {
+                                                     int M, int R, int mchunk) {
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= R) return;
+    const int m0 = blockIdx.y * mchunk, m1 = min(M, m0 + mchunk);
     float s = 0.f;
-    for (int m = 0; m < M; ++m) s += w[(size_t)m * R + r] * u[m];
-    v[r] = s;
+    for (int m = m0; m < m1; ++m) s += w[(size_t)m * R + r] * u[m];
+    if (gridDim.y > 1) atomicAdd(v + r, s); else v[r] = s;
 }
 // x <- x / max(||x||, eps) (single workgroup)
 __global__ __launch_bounds__(256) void sn_normalize_kernel(float* __restrict__ x, int n, float eps) {
@@ -198,7 +200,13 @@ extern "C" int ag2v_spectral_norm_fwd(const float* w, float* u, float* v, int M,
     hipStream_t st = (hipStream_t)stream;
     float* wv = workspace;
     if (power_iter) {
-        hipLaunchKernelGGL(sn_wtu_kernel, dim3(ceil_div(R, 256)), dim3(256), 0, st, w, u, v, M, R);
+        int msplit = 1;
+        const int rb = ceil_div(R, 256);
+        if (rb < 256 && M >= 64) { msplit = ceil_div(512, rb); if (msplit > M / 16) msplit = M / 16; if (msplit < 1) msplit = 1; }
+        const int mchunk = ceil_div(M, msplit);
+        msplit = ceil_div(M, mchunk);
+        if (msplit > 1 && hipMemsetAsync(v, 0, (size_t)R * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
+        hipLaunchKernelGGL(sn_wtu_kernel, dim3(rb, msplit), dim3(256), 0, st, w, u, v, M, R, mchunk);
         hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(256), 0, st, v, R, eps);
     }
     hipLaunchKernelGGL(sn_wv_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, w, v, wv, M, R);

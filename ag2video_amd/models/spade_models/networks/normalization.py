@@ -76,6 +76,20 @@ def get_nonspade_norm_layer(opt, norm_type='instance'):
     return add_norm_layer
 
 
+class SegmapPyramid(object):
+    """Memo of F.interpolate(segmap, size, 'nearest') per target size for one decoder pass (autograd sums the uses)."""
+
+    def __init__(self, segmap):
+        self.segmap = segmap
+        self._cache = {}
+
+    def at(self, h, w):
+        key = (int(h), int(w))
+        if key not in self._cache:
+            self._cache[key] = ops.nearest_resize(self.segmap, key[0], key[1])
+        return self._cache[key]
+
+
 class SPADE(nn.Module):
     """Spatially-adaptive normalisation (normalization.py:66-110): x_hat * (1 + gamma(seg)) + beta(seg)."""
 
@@ -94,8 +108,13 @@ class SPADE(nn.Module):
         self.mlp_beta = Conv2d(nhidden, norm_nc, kernel_size=ks, padding=pw)
 
     def forward(self, x, segmap, slope=1.0):
-        """slope: LeakyReLU fused behind the modulation (the caller's actvn, architecture.py:53-54); 1.0 = none."""
-        seg = ops.nearest_resize(segmap, x.shape[2], x.shape[3])
+        """slope: LeakyReLU fused behind the modulation (the caller's actvn, architecture.py:53-54); 1.0 = none.
+        ``segmap`` may be a SegmapPyramid: every SPADE of a decoder pass resizes the same map to one of six sizes, so
+        the nearest-neighbour resize (normalization.py:102) is done once per size instead of once per SPADE."""
+        if isinstance(segmap, SegmapPyramid):
+            seg = segmap.at(x.shape[2], x.shape[3])
+        else:
+            seg = ops.nearest_resize(segmap, x.shape[2], x.shape[3])
         actv = ops.leaky_relu(self.mlp_shared[0](seg), 0.0)
         gamma = self.mlp_gamma(actv)
         beta = self.mlp_beta(actv)

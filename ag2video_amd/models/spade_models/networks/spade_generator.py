@@ -4,6 +4,7 @@ import torch.nn as nn
 from .... import ops
 from ...layers import Conv2d
 from .architecture import SPADEResnetBlock
+from .normalization import SegmapPyramid
 
 
 class SPADEGenerator(nn.Module):
@@ -36,7 +37,8 @@ class SPADEGenerator(nn.Module):
         return sw, sh
 
     def forward(self, layout):
-        x = ops.nearest_resize(layout, self.sh, self.sw)
+        layout = SegmapPyramid(layout)
+        x = layout.at(self.sh, self.sw)
         x = self.fc(x)
         x = self.head_0(x, layout)
         x = ops.upsample2x(x)
