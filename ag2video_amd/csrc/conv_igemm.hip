@@ -7,41 +7,42 @@
 //   discriminator 4x4 s2/s1 p2  models/spade_models/networks/discriminator.py:368-379
 // forward, data gradient and weight gradient (what autograd derives from aten.convolution there).
 //
-// GEMM views (NCHW fp32, weights [K,C,R,S]):
-//   FWD   Y[k,(n,oy,ox)]  = sum_{c,r,s} Wt[k,(c,r,s)] * X[n,c,oy*st+r-pad,ox*st+s-pad]
-//   DGRAD dX[c,(n,y,x)]   = sum_{k,r,s} Wt[k,c,r,s]   * dY[n,k,(y+pad-r)/st,(x+pad-s)/st]   (divisible taps only)
-//   WGRAD dW[k,(c,r,s)]   = sum_{n,oy,ox} dY[n,k,oy,ox] * X[n,c,oy*st+r-pad,ox*st+s-pad]     (split over pixels)
-// The B operand is gathered straight from the NCHW tensor with lanes along the pixel index (coalesced rows),
-// staged through LDS as [k][m]/[k][n] so every MFMA operand read is a conflict-free ds_read_b32, and the next
-// K-tile's global loads are in flight while the current tile's 32 MFMAs per wave issue.
+// One forward kernel serves the forward pass AND every data gradient:
+//   FWD    Y[k,(n,oy,ox)] = sum_{c,r,s} At[(c,r,s),k] * X[n,c,oy*st+r-pad,ox*st+s-pad]          At = W^T      (prep kernel)
+//   DGRAD  for each output-pixel parity class (py,px) of the stride:  dX[c, class pixels] =
+//          conv_stride1(dY, sub-filter r = py+st*r', s = px+st*s', flipped)                      At = sub-filter^T (prep kernel)
+//          (stride 1: one class = the classic flipped-filter identity; stride 2: four classes with 1/4 of the taps each,
+//           instead of multiplying 3/4 structural zeros)
+//   WGRAD  dW[k,(c,r,s)]  = sum_{n,oy,ox} dY[n,k,oy,ox] * X[n,c,oy*st+r-pad,ox*st+s-pad]         (own kernel, split over pixels)
+// Both operands reach LDS through fully coalesced loads (lanes along m for the k-major weights, lanes along the pixel index
+// for the activation gather), are staged as [k][m] / [k][n] so every MFMA operand read is a conflict-free ds_read_b32, and
+// the next K-tile's global loads are in flight while the current tile's 32 MFMAs per wave issue.
 #include "common.h"
 
 struct ConvArgs {
-    const float* a_src;     // weights (FWD/DGRAD) | dy (WGRAD)
-    const float* b_src;     // x (FWD) | dy (DGRAD) | x (WGRAD)
-    float* out;             // y | dx | dw
-    const float* bias;      // FWD: [K] or null
-    const float* residual;  // FWD: same shape as y, or null
-    int N, C, H, W;         // input image
-    int K, R, S, OH, OW;    // filters / output image
+    const float* a_src;     // igemm: At [KG][M] (k-major weights) | wgrad: dy
+    const float* b_src;     // gathered tensor [N, C, H, W]
+    float* out;
+    const float* bias;      // [M] or null (igemm)
+    const float* residual;  // same shape as out, or null (igemm)
+    int N, C, H, W;         // gathered tensor
+    int K, R, S, OH, OW;    // output channels / filter / GEMM pixel space (igemm);  filters / dy image (wgrad)
     int stride, pad;        // pad = padding along y
-    int pad_w;              // padding along x (== pad except for the parity sub-filters of a strided dgrad)
-    int o_mul, o_add_y, o_add_x, o_H, o_W;  // FWD output placement: (oy,ox) -> (oy*o_mul+o_add_y, ox*o_mul+o_add_x) in [o_H,o_W]
-    int M, NG, KG;          // GEMM dims of this mode
+    int pad_w;              // padding along x (differs from pad only for the parity sub-filters of a strided dgrad)
+    int o_mul, o_add_y, o_add_x, o_H, o_W;  // output placement: (oy,ox) -> (oy*o_mul+o_add_y, ox*o_mul+o_add_x) in [o_H,o_W]
+    int M, NG, KG;          // GEMM dims
     int tiles_m, tiles_n;
-    int splitk, kchunk;     // WGRAD: number of pixel-range splits, pixels per split (multiple of 16)
-                            // FWD/DGRAD: number of K-range splits (grid.y), K-tiles per split; >1 => atomic epilogue
+    int splitk, kchunk;     // igemm: K-range splits (grid.y) in K-tiles; wgrad: pixel-range splits, pixels per split
 };
 
-enum { MODE_FWD = 0, MODE_DGRAD = 1 };
-
-// Division by the filter footprint: 1x1, 3x3 and 4x4 (the only shapes on the path) get constant divisors.
+// Division by the filter footprint: the shapes on the path get constant divisors.
 __device__ __forceinline__ int div_small(int v, int d) {
     if (d == 9) return v / 9;
     if (d == 16) return v >> 4;
     if (d == 1) return v;
     if (d == 3) return v / 3;
     if (d == 4) return v >> 2;
+    if (d == 2) return v >> 1;
     return v / d;
 }
 __device__ __forceinline__ void decode_crs(int kg, int RS, int S, int& c, int& r, int& s) {
@@ -51,18 +52,20 @@ __device__ __forceinline__ void decode_crs(int kg, int RS, int S, int& c, int& r
     s = rs - r * S;
 }
 
-template <int MODE, int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     constexpr int BK = 16;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int LDA = BM + 4, LDB = BN + 4;
-    constexpr int EA = BM * BK / 256;   // A elements per thread: EA consecutive k of one row
-    constexpr int TPR = BK / EA;        // threads per A row
-    constexpr int EB = BK * BN / 256;   // B elements per thread: one pixel column, EB k-rows
-    constexpr int KSB = 256 / BN;       // k-row step between a thread's B elements
+    constexpr int EA = BM * BK / 256, KSA = 256 / BM;   // A: one m column, EA k-rows (step KSA) per thread
+    constexpr int EB = BK * BN / 256, KSB = 256 / BN;   // B: one pixel column, EB k-rows (step KSB) per thread
     static_assert(TM >= 1 && TN >= 1, "tile");
     __shared__ float As[2][BK][LDA];
     __shared__ float Bs[2][BK][LDB];
+    // K-index decode table: the 16 k-rows of a K-tile are decoded ONCE per workgroup (16 lanes in parallel) into LDS as
+    // {offset of (chan,tap) inside a source image, tap bit}; every gathered element then costs one broadcast ds_read_b64,
+    // a mask test and one 64-bit add.  (A per-element scalar decode cost ~10 SALU instructions per MFMA.)
+    __shared__ int2 tab[2][BK];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lid = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
@@ -70,91 +73,43 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int wm0 = (wave / WN) * (TM * 32), wn0 = (wave % WN) * (TN * 32);
     const int RS = p.R * p.S;
+    const int SHW = p.H * p.W;
 
     // ---- B gather state: this thread owns pixel column jb of the tile for the whole K loop
     const int jb = tid % BN, kkb0 = tid / BN;
-    const int PH = (MODE == MODE_FWD) ? p.OH : p.H, PW = (MODE == MODE_FWD) ? p.OW : p.W;
     const int pix = n0 + jb;
     const bool pvalid = pix < p.NG;
-    const int n_img = pix / (PH * PW);
-    const int prem = pix - n_img * (PH * PW);
-    const int py = prem / PW, px = prem - py * PW;
-    // Source plane geometry: FWD gathers x[N,C,H,W]; DGRAD gathers dy[N,K,OH,OW].
-    const int SH = (MODE == MODE_FWD) ? p.H : p.OH, SW = (MODE == MODE_FWD) ? p.W : p.OW;
-    const int SC = (MODE == MODE_FWD) ? p.C : p.K;
-    const int SHW = SH * SW;
-    // Per-pixel tap table: bit (r*S+s) of vmask says tap (r,s) reads inside the source plane; the tap's address is
-    // bptr + chan*SHW + toff(r,s) with a wave-uniform (scalar) chan/tap part.  FWD (and stride-1 DGRAD) taps are affine
-    // in (r,s); a strided DGRAD tap ((y+pad-r)/st) is not, so it keeps a per-lane offset computed per element.
-    const float* bptr = p.b_src + (size_t)n_img * SC * SHW;
+    const int n_img = pix / (p.OH * p.OW);
+    const int prem = pix - n_img * (p.OH * p.OW);
+    const int py = prem / p.OW, px = prem - py * p.OW;
+    const int y0 = py * p.stride - p.pad, x0 = px * p.stride - p.pad_w;
+    // bit (r*S+s) of vmask: tap (r,s) of this pixel reads inside the source plane; its address is bptr + chan*SHW + r*W + s
     unsigned vmask = 0;
-    int y0, x0;
-    if (MODE == MODE_FWD) {
-        y0 = py * p.stride - p.pad;
-        x0 = px * p.stride - p.pad_w;
-    } else {
-        y0 = py + p.pad;
-        x0 = px + p.pad_w;
-    }
     if (pvalid) {
         for (int r = 0; r < p.R; ++r)
-            for (int s2 = 0; s2 < p.S; ++s2) {
-                bool ok;
-                if (MODE == MODE_FWD) {
-                    ok = (unsigned)(y0 + r) < (unsigned)SH && (unsigned)(x0 + s2) < (unsigned)SW;
-                } else {
-                    const int ty = y0 - r, tx = x0 - s2;
-                    ok = ty >= 0 && tx >= 0 && (ty % p.stride) == 0 && (tx % p.stride) == 0 && (ty / p.stride) < SH &&
-                         (tx / p.stride) < SW;
-                }
-                if (ok) vmask |= 1u << (r * p.S + s2);
-            }
+            for (int s2 = 0; s2 < p.S; ++s2)
+                if ((unsigned)(y0 + r) < (unsigned)p.H && (unsigned)(x0 + s2) < (unsigned)p.W) vmask |= 1u << (r * p.S + s2);
     }
-    const bool affine = (MODE == MODE_FWD) || p.stride == 1;
-    if (affine) bptr += (MODE == MODE_FWD) ? (y0 * SW + x0) : (y0 * SW + x0);   // tap (0,0); may point before the plane
-    // ---- A load state
-    const int ma = tid / TPR, kka0 = (tid % TPR) * EA;
-    const bool mvalid = (m0 + ma) < p.M;
-    const float* aptr = p.a_src + ((MODE == MODE_FWD) ? (size_t)(m0 + ma) * p.KG : (size_t)(m0 + ma) * RS);
+    const float* bptr = p.b_src + (size_t)n_img * p.C * SHW + (y0 * p.W + x0);  // tap (0,0); may point before the plane
+    // ---- A load state: k-major weights, lanes along m
+    const int am = tid % BM, akk0 = tid / BM;
+    const bool mvalid = (m0 + am) < p.M;
+    const float* aptr = p.a_src + m0 + am;
 
-    // K-index decode table: the 16 k-rows of a K-tile are decoded ONCE per workgroup (16 lanes in parallel) into LDS as
-    // {offset of (chan,tap) inside a source image, tap bit | r<<16 | s<<20}; every gathered element then costs one
-    // broadcast ds_read_b64, a mask test and one 64-bit add.  (A per-element scalar decode cost ~10 SALU per MFMA.)
-    __shared__ int2 tab[2][BK];
     auto build_tab = [&](int kt) {
         if (tid < BK) {
             const int kg = kt * BK + tid;
             int c, r, s2;
             decode_crs(kg, RS, p.S, c, r, s2);
-            int koff;
-            if (MODE == MODE_FWD) koff = c * SHW + r * SW + s2;
-            else if (affine) koff = c * SHW - r * SW - s2;
-            else koff = c * SHW;
             const unsigned bit = (kg < p.KG) ? (1u << (r * p.S + s2)) : 0u;
-            tab[kt & 1][tid] = make_int2(koff, (int)(bit | ((unsigned)r << 16) | ((unsigned)s2 << 20)));
+            tab[kt & 1][tid] = make_int2(c * SHW + r * p.W + s2, (int)bit);
         }
     };
     auto fetchB = [&](int kt, int kk) -> float {
         const int2 e = tab[kt & 1][kk];
-        const bool ok = (vmask & (unsigned)e.y & 0xFFFFu) != 0u;
-        if (MODE == MODE_FWD || affine) {
-            return ok ? bptr[e.x] : 0.f;
-        } else {
-            const int r = (e.y >> 16) & 15, s2 = (e.y >> 20) & 15;
-            const int oy = (y0 - r) / p.stride, ox = (x0 - s2) / p.stride;
-            return ok ? bptr[e.x + oy * SW + ox] : 0.f;
-        }
+        return (vmask & (unsigned)e.y) ? bptr[e.x] : 0.f;
     };
-    auto fetchA = [&](int kg) -> float {
-        const bool ok = mvalid && kg < p.KG;
-        if (MODE == MODE_FWD) {
-            return ok ? aptr[kg] : 0.f;
-        } else {
-            const int k = div_small(kg, RS);
-            const int rs = kg - k * RS;
-            return ok ? aptr[(size_t)k * p.C * RS + rs] : 0.f;
-        }
-    };
+    auto fetchA = [&](int kg) -> float { return (mvalid && kg < p.KG) ? aptr[(size_t)kg * p.M] : 0.f; };
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -166,18 +121,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 
     float ra[EA], rb[EB];
     const int nk_all = (p.KG + BK - 1) / BK;
-    const int kt0 = (p.splitk > 1) ? blockIdx.y * p.kchunk : 0;          // small-N layers: split the K loop over grid.y
+    const int kt0 = (p.splitk > 1) ? blockIdx.y * p.kchunk : 0;  // small-N layers: the K loop is split over grid.y
     const int nk = (p.splitk > 1) ? min(nk_all, kt0 + p.kchunk) : nk_all;
     if (kt0 >= nk) return;  // uniform per workgroup
     build_tab(kt0);
     __syncthreads();
     build_tab(kt0 + 1);
 #pragma unroll
-    for (int i = 0; i < EA; ++i) ra[i] = fetchA(kt0 * BK + kka0 + i);
+    for (int i = 0; i < EA; ++i) ra[i] = fetchA(kt0 * BK + akk0 + KSA * i);
 #pragma unroll
     for (int i = 0; i < EB; ++i) rb[i] = fetchB(kt0, kkb0 + KSB * i);
 #pragma unroll
-    for (int i = 0; i < EA; ++i) As[0][kka0 + i][ma] = ra[i];
+    for (int i = 0; i < EA; ++i) As[0][akk0 + KSA * i][am] = ra[i];
 #pragma unroll
     for (int i = 0; i < EB; ++i) Bs[0][kkb0 + KSB * i][jb] = rb[i];
     __syncthreads();
@@ -188,10 +143,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         if (more) {
             const int k0 = (kt + 1) * BK;
 #pragma unroll
-            for (int i = 0; i < EA; ++i) ra[i] = fetchA(k0 + kka0 + i);
+            for (int i = 0; i < EA; ++i) ra[i] = fetchA(k0 + akk0 + KSA * i);
 #pragma unroll
             for (int i = 0; i < EB; ++i) rb[i] = fetchB(kt + 1, kkb0 + KSB * i);
-            build_tab(kt + 2);   // tab[kt&1] was last read while fetching tile kt, i.e. before the previous barrier
+            build_tab(kt + 2);  // tab[kt&1] was last read while fetching tile kt, i.e. before the previous barrier
         }
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
@@ -209,7 +164,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         }
         if (more) {
 #pragma unroll
-            for (int i = 0; i < EA; ++i) As[cur ^ 1][kka0 + i][ma] = ra[i];
+            for (int i = 0; i < EA; ++i) As[cur ^ 1][akk0 + KSA * i][am] = ra[i];
 #pragma unroll
             for (int i = 0; i < EB; ++i) Bs[cur ^ 1][kkb0 + KSB * i][jb] = rb[i];
         }
@@ -218,23 +173,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     }
 
     // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31 (pixel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    const int OUTC = (MODE == MODE_FWD) ? p.K : p.C;
-    const int gplane = PH * PW;                                    // pixels of the GEMM's pixel space per image
-    const int plane = (MODE == MODE_FWD) ? p.o_H * p.o_W : gplane;  // elements of one output channel plane
+    const int gplane = p.OH * p.OW;   // pixels of the GEMM's pixel space per image
+    const int plane = p.o_H * p.o_W;  // elements of one output channel plane
+    const bool mapped = (p.o_mul != 1 || p.o_add_y != 0 || p.o_add_x != 0 || p.o_W != p.OW);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int opix = n0 + wn0 + j * 32 + (lane & 31);
         if (opix >= p.NG) continue;
         const int on = opix / gplane;
         int orem = opix - on * gplane;
-        if (MODE == MODE_FWD && (p.o_mul != 1 || p.o_add_y != 0 || p.o_add_x != 0 || p.o_W != PW)) {
-            const int qy = orem / PW, qx = orem - qy * PW;
+        if (mapped) {
+            const int qy = orem / p.OW, qx = orem - qy * p.OW;
             const int yy = qy * p.o_mul + p.o_add_y, xx = qx * p.o_mul + p.o_add_x;
             if ((unsigned)yy >= (unsigned)p.o_H || (unsigned)xx >= (unsigned)p.o_W) continue;
             orem = yy * p.o_W + xx;
         }
-        float* obase = p.out + (size_t)on * OUTC * plane + orem;
-        const float* rbase = (MODE == MODE_FWD && p.residual) ? p.residual + (size_t)on * OUTC * plane + orem : nullptr;
+        float* obase = p.out + (size_t)on * p.M * plane + orem;
+        const float* rbase = p.residual ? p.residual + (size_t)on * p.M * plane + orem : nullptr;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -242,7 +197,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
                 const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m < p.M) {
                     float v = acc[i][j][r];
-                    if (MODE == MODE_FWD && kt0 == 0) {
+                    if (kt0 == 0) {
                         if (p.bias) v += p.bias[m];
                         if (rbase) v += rbase[(size_t)m * plane];
                     }
@@ -376,38 +331,49 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvArgs p) {
     }
 }
 
-// wt[c][k][r][s] = w[k][c][R-1-r][S-1-s]: with it a stride-1 data gradient is a plain forward convolution of dy
-// (pad' = R-1-pad), so it runs on the forward kernel with contiguous weight rows.
-__global__ __launch_bounds__(256) void weight_flip_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int K,
-                                                                    int C, int RS) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long long)K * C * RS) return;
-    const int rs = (int)(i % RS);
-    const long long t = i / RS;
-    const int k = (int)(t % K), c = (int)(t / K);
-    wt[i] = w[((size_t)k * C + c) * RS + (RS - 1 - rs)];
+// ---------------------------------------------------------------- weight preparation (k-major A operands)
+// at[col][row] = w[row][col]  (w: [rows][cols] row-major): 32x32 LDS tiles, coalesced on both sides.
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ w, float* __restrict__ at, int rows, int cols) {
+    __shared__ float t[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        t[ty + 8 * i][tx] = (r < rows && c < cols) ? w[(size_t)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (c < cols && r < rows) at[(size_t)c * rows + r] = t[tx][ty + 8 * i];
+    }
 }
 
-// Sub-filter of parity class (py,px) of a stride-2 data gradient, flipped and transposed for the forward kernel:
-//   wt[c][k][r''][s''] = w[k][c][py + 2*(Rc-1-r'')][px + 2*(Sc-1-s'')]
-__global__ __launch_bounds__(256) void weight_parity_flip_kernel(const float* __restrict__ w, float* __restrict__ wt, int K, int C,
-                                                                 int R, int S, int py, int px, int Rc, int Sc) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long long)K * C * Rc * Sc) return;
-    const int s2 = (int)(i % Sc);
-    long long t = i / Sc;
-    const int r2 = (int)(t % Rc);
-    t /= Rc;
-    const int k = (int)(t % K), c = (int)(t / K);
-    const int r = py + 2 * (Rc - 1 - r2), s = px + 2 * (Sc - 1 - s2);
-    wt[i] = w[(((size_t)k * C + c) * R + r) * S + s];
+// Data-gradient sub-filter of pixel class (py,px), flipped, k-major:
+//   at[((k*Rc + r2)*Sc + s2)*C + c] = w[k][c][py + st*(Rc-1-r2)][px + st*(Sc-1-s2)]
+// grid (ceil(C/64), K): the 64*R*S contiguous source floats of (k, c-chunk) go through LDS, rows are written coalesced.
+__global__ __launch_bounds__(256) void dgrad_weight_prep_kernel(const float* __restrict__ w, float* __restrict__ at, int K, int C,
+                                                                int R, int S, int py, int px, int st, int Rc, int Sc) {
+    __shared__ float t[64 * 16];
+    const int RS = R * S;
+    const int c0 = blockIdx.x * 64, k = blockIdx.y;
+    const int nc = min(64, C - c0);
+    const float* src = w + ((size_t)k * C + c0) * RS;
+    for (int i = threadIdx.x; i < nc * RS; i += 256) t[i] = src[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    for (int tap = grp; tap < Rc * Sc; tap += 4) {
+        const int r2 = tap / Sc, s2 = tap - r2 * Sc;
+        const int r = py + st * (Rc - 1 - r2), s = px + st * (Sc - 1 - s2);
+        if (lane < nc) at[((size_t)(k * Rc + r2) * Sc + s2) * C + c0 + lane] = t[lane * RS + r * S + s];
+    }
 }
 
 static int conv_out_dim(int in, int k, int stride, int pad) { return (in + 2 * pad - k) / stride + 1; }
 
-template <int MODE>
 static int launch_igemm(ConvArgs& a, hipStream_t st, bool out_zeroed = false) {
-    if (a.M <= 0 || a.NG <= 0 || a.KG <= 0) return AG2V_EINVAL;
+    if (a.M <= 0 || a.NG <= 0 || a.KG <= 0 || a.R * a.S > 16) return AG2V_EINVAL;
     if (a.o_mul == 0) { a.o_mul = 1; a.o_add_y = 0; a.o_add_x = 0; a.o_H = a.OH; a.o_W = a.OW; }
     const int bm = (a.M <= 32) ? 32 : (a.M <= 64 ? 64 : 128);
     const int bn = (bm == 128) ? 128 : 256;
@@ -426,92 +392,80 @@ static int launch_igemm(ConvArgs& a, hipStream_t st, bool out_zeroed = false) {
         }
     }
     if (a.splitk > 1 && !out_zeroed) {
-        const size_t out_elems = (MODE == MODE_FWD) ? (size_t)a.N * a.K * a.o_H * a.o_W : (size_t)a.N * a.C * a.H * a.W;
-        if (hipMemsetAsync(a.out, 0, out_elems * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
+        if (hipMemsetAsync(a.out, 0, (size_t)a.N * a.M * a.o_H * a.o_W * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
     }
     dim3 grid(tiles, a.splitk);
     if (bm == 32)
-        hipLaunchKernelGGL((conv_igemm_kernel<MODE, 32, 256, 1, 4>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((conv_igemm_kernel<32, 256, 1, 4>), grid, dim3(256), 0, st, a);
     else if (bm == 64)
-        hipLaunchKernelGGL((conv_igemm_kernel<MODE, 64, 256, 1, 4>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((conv_igemm_kernel<64, 256, 1, 4>), grid, dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL((conv_igemm_kernel<MODE, 128, 128, 2, 2>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, a);
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
 }
 
+extern "C" size_t ag2v_conv2d_workspace_floats(int C, int K, int R, int S) { return (size_t)C * K * R * S; }
+
+// y = conv(x, w) (+bias) (+residual).  workspace: ag2v_conv2d_workspace_floats() floats (k-major copy of the weights).
 extern "C" int ag2v_conv2d_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y,
-                               int N, int C, int H, int W, int K, int R, int S, int stride, int pad, void* stream) {
-    if (!x || !w || !y || N <= 0 || C <= 0 || K <= 0 || stride <= 0 || R * S > 16) return AG2V_EINVAL;
+                               int N, int C, int H, int W, int K, int R, int S, int stride, int pad, float* workspace,
+                               void* stream) {
+    if (!x || !w || !y || !workspace || N <= 0 || C <= 0 || K <= 0 || stride <= 0 || R * S > 16) return AG2V_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
     ConvArgs a{};
-    a.a_src = w; a.b_src = x; a.out = y; a.bias = bias; a.residual = residual;
+    a.b_src = x; a.out = y; a.bias = bias; a.residual = residual;
     a.N = N; a.C = C; a.H = H; a.W = W; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.pad_w = pad;
     a.OH = conv_out_dim(H, R, stride, pad); a.OW = conv_out_dim(W, S, stride, pad);
     if (a.OH <= 0 || a.OW <= 0) return AG2V_EINVAL;
-    if ((long long)N * a.OH * a.OW >= (1LL << 31) || (long long)C * R * S >= (1LL << 31)) return AG2V_EINVAL;
+    if ((long long)N * a.OH * a.OW >= (1LL << 31) || (long long)C * R * S >= (1LL << 31) ||
+        (long long)C * H * W >= (1LL << 31)) return AG2V_EINVAL;
     a.M = K; a.NG = N * a.OH * a.OW; a.KG = C * R * S;
-    return launch_igemm<MODE_FWD>(a, (hipStream_t)stream);
+    hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(a.KG, 32), ceil_div(K, 32)), dim3(256), 0, st, w, workspace, K, a.KG);
+    a.a_src = workspace;
+    return launch_igemm(a, st);
 }
 
-extern "C" size_t ag2v_conv2d_dgrad_workspace_floats(int C, int K, int R, int S, int stride) {
-    return (stride == 1 || stride == 2) ? (size_t)C * K * R * S : 0;
-}
-
+// dx = d conv / d x.  For each pixel class (py,px) of the stride one forward-kernel launch over dy with the class's
+// flipped sub-filter.  workspace: ag2v_conv2d_workspace_floats() floats.
 extern "C" int ag2v_conv2d_dgrad(const float* dy, const float* w, float* dx,
                                  int N, int C, int H, int W, int K, int R, int S, int stride, int pad, float* workspace,
                                  void* stream) {
-    if (!dy || !w || !dx || N <= 0 || C <= 0 || K <= 0 || stride <= 0 || R * S > 16) return AG2V_EINVAL;
-    if (stride == 1 && workspace && pad <= R - 1 && pad <= S - 1 && R == S) {
-        // dX = conv_fwd(dY, flip-transpose(W), pad' = R-1-pad)
-        hipStream_t st = (hipStream_t)stream;
-        const long long nw = (long long)K * C * R * S;
-        hipLaunchKernelGGL(weight_flip_transpose_kernel, dim3(ceil_div(nw, 256)), dim3(256), 0, st, w, workspace, K, C, R * S);
-        const int OH = conv_out_dim(H, R, 1, pad), OW = conv_out_dim(W, S, 1, pad);
-        if (OH <= 0 || OW <= 0) return AG2V_EINVAL;
-        ConvArgs f{};
-        f.a_src = workspace; f.b_src = dy; f.out = dx;
-        f.N = N; f.C = K; f.H = OH; f.W = OW; f.K = C; f.R = R; f.S = S; f.stride = 1; f.pad = R - 1 - pad; f.pad_w = S - 1 - pad;
-        f.OH = H; f.OW = W;
-        if ((long long)N * H * W >= (1LL << 31) || (long long)K * R * S >= (1LL << 31)) return AG2V_EINVAL;
-        f.M = C; f.NG = N * H * W; f.KG = K * R * S;
-        return launch_igemm<MODE_FWD>(f, st);
-    }
-    if (stride == 2 && workspace) {
-        // Stride-2 data gradient by output-pixel parity: pixels with (y+pad)%2 == py, (x+pad)%2 == px only see the taps
-        // r = py + 2r', s = px + 2s', i.e. each class is a stride-1 correlation of dY with a (R/2 x S/2) sub-filter
-        // -> four forward-kernel launches with 1/4 of the taps each instead of one launch that multiplies 3/4 zeros.
-        hipStream_t st = (hipStream_t)stream;
-        const int OH = conv_out_dim(H, R, 2, pad), OW = conv_out_dim(W, S, 2, pad);
-        if (OH <= 0 || OW <= 0) return AG2V_EINVAL;
-        if (hipMemsetAsync(dx, 0, (size_t)N * C * H * W * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
-        float* wt = workspace;
-        for (int py = 0; py < 2; ++py)
-            for (int px = 0; px < 2; ++px) {
-                const int Rc = (R - py + 1) / 2, Sc = (S - px + 1) / 2;   // taps r in [0,R) with r%2 == py
-                if (Rc <= 0 || Sc <= 0) continue;
-                const long long nw = (long long)K * C * Rc * Sc;
-                hipLaunchKernelGGL(weight_parity_flip_kernel, dim3(ceil_div(nw, 256)), dim3(256), 0, st, w, wt, K, C, R, S, py, px, Rc, Sc);
-                ConvArgs f{};
-                f.a_src = wt; f.b_src = dy; f.out = dx;
-                f.N = N; f.C = K; f.H = OH; f.W = OW; f.K = C; f.R = Rc; f.S = Sc; f.stride = 1; f.pad = Rc - 1; f.pad_w = Sc - 1;
-                f.OH = OH + Rc - 1; f.OW = OW + Sc - 1;
-                f.o_mul = 2; f.o_add_y = py - pad; f.o_add_x = px - pad; f.o_H = H; f.o_W = W;
-                if ((long long)N * f.OH * f.OW >= (1LL << 31)) return AG2V_EINVAL;
-                f.M = C; f.NG = N * f.OH * f.OW; f.KG = K * Rc * Sc;
-                const int rc = launch_igemm<MODE_FWD>(f, st, true);
-                if (rc != AG2V_OK) return rc;
-                wt += nw;
-            }
-        return AG2V_OK;
-    }
-    ConvArgs a{};
-    a.a_src = w; a.b_src = dy; a.out = dx;
-    a.N = N; a.C = C; a.H = H; a.W = W; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.pad_w = pad;
-    a.OH = conv_out_dim(H, R, stride, pad); a.OW = conv_out_dim(W, S, stride, pad);
-    if (a.OH <= 0 || a.OW <= 0) return AG2V_EINVAL;
-    if ((long long)N * H * W >= (1LL << 31) || (long long)K * R * S >= (1LL << 31)) return AG2V_EINVAL;
-    a.M = C; a.NG = N * H * W; a.KG = K * R * S;
-    return launch_igemm<MODE_DGRAD>(a, (hipStream_t)stream);
+    if (!dy || !w || !dx || !workspace || N <= 0 || C <= 0 || K <= 0 || stride <= 0 || R * S > 16) return AG2V_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int OH = conv_out_dim(H, R, stride, pad), OW = conv_out_dim(W, S, stride, pad);
+    if (OH <= 0 || OW <= 0) return AG2V_EINVAL;
+    if ((long long)K * OH * OW >= (1LL << 31)) return AG2V_EINVAL;
+    // With stride > 1 several classes write disjoint pixels of dx (one of them may be empty when R < stride) and a class
+    // may take the atomic split-K epilogue: zero dx once up front.  Stride 1 is a single class covering every pixel.
+    const bool multi = (stride > 1);
+    if (multi && hipMemsetAsync(dx, 0, (size_t)N * C * H * W * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
+    float* at = workspace;
+    for (int py = 0; py < stride; ++py)
+        for (int px = 0; px < stride; ++px) {
+            // class (py,px): pixels y = ay + stride*q, x = ax + stride*q' with (y+pad)%stride == py; they see the taps
+            // r = py + stride*r', r' < Rc, at dy row (y+pad-py)/stride - r' = q + q0y - r'.
+            const int Rc = (R - py + stride - 1) / stride, Sc = (S - px + stride - 1) / stride;
+            if (Rc <= 0 || Sc <= 0) continue;
+            const int q0y = (pad > py) ? (pad - py + stride - 1) / stride : 0;
+            const int q0x = (pad > px) ? (pad - px + stride - 1) / stride : 0;
+            const int ay = q0y * stride + py - pad, ax = q0x * stride + px - pad;
+            if (ay >= H || ax >= W) continue;
+            hipLaunchKernelGGL(dgrad_weight_prep_kernel, dim3(ceil_div(C, 64), K), dim3(256), 0, st, w, at, K, C, R, S, py, px,
+                               stride, Rc, Sc);
+            ConvArgs f{};
+            f.a_src = at; f.b_src = dy; f.out = dx;
+            f.N = N; f.C = K; f.H = OH; f.W = OW; f.K = C; f.R = Rc; f.S = Sc; f.stride = 1;
+            f.pad = Rc - 1 - q0y; f.pad_w = Sc - 1 - q0x;
+            f.OH = (H - ay + stride - 1) / stride; f.OW = (W - ax + stride - 1) / stride;
+            f.o_mul = stride; f.o_add_y = ay; f.o_add_x = ax; f.o_H = H; f.o_W = W;
+            if ((long long)N * f.OH * f.OW >= (1LL << 31)) return AG2V_EINVAL;
+            f.M = C; f.NG = N * f.OH * f.OW; f.KG = K * Rc * Sc;
+            const int rc = launch_igemm(f, st, multi);
+            if (rc != AG2V_OK) return rc;
+            at += (size_t)K * C * Rc * Sc;
+        }
+    return AG2V_OK;
 }
 
 extern "C" int ag2v_conv2d_wgrad(const float* dy, const float* x, float* dw,

@@ -85,8 +85,9 @@ class _Conv2d(torch.autograd.Function):
         OH = (H + 2 * pad - R) // stride + 1
         OW = (W + 2 * pad - S) // stride + 1
         y = torch.empty((N, K, OH, OW), device=x.device, dtype=torch.float32)
+        ws = torch.empty(_lib.query('ag2v_conv2d_workspace_floats', C, K, R, S), device=x.device, dtype=torch.float32)
         _launch('ag2v_conv2d_fwd', _conv_label('fwd', K), 2.0 * N * K * OH * OW * C * R * S,
-                _ptr(x), _ptr(w), _ptr(bias), _ptr(residual), _ptr(y), N, C, H, W, K, R, S, stride, pad, _stream(),
+                _ptr(x), _ptr(w), _ptr(bias), _ptr(residual), _ptr(y), N, C, H, W, K, R, S, stride, pad, _ptr(ws), _stream(),
                 shape=(N, C, H, W, K, R, stride))
         ctx.save_for_backward(x, w)
         ctx.cfg = (stride, pad, bias is not None, residual is not None)
@@ -104,8 +105,7 @@ class _Conv2d(torch.autograd.Function):
         flops = 2.0 * N * K * dy.shape[2] * dy.shape[3] * C * R * S      # algorithmic (dense-conv) FLOPs of each pass
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            nws = _lib.query('ag2v_conv2d_dgrad_workspace_floats', C, K, R, S, stride)
-            ws = torch.empty(nws, device=dy.device, dtype=torch.float32) if nws else None
+            ws = torch.empty(_lib.query('ag2v_conv2d_workspace_floats', C, K, R, S), device=dy.device, dtype=torch.float32)
             _launch('ag2v_conv2d_dgrad', _conv_label('dgrad', C), flops,
                     _ptr(dy), _ptr(w), _ptr(dx), N, C, H, W, K, R, S, stride, pad, _ptr(ws), st,
                     shape=(N, C, H, W, K, R, stride))

@@ -26,9 +26,9 @@ extern "C" {
  * call sites: generator.py:30; flows_generator.py:32-54,82-85; spade_generator.py:16-34; architecture.py:29-32;
  * normalization.py:90-94; discriminator.py:368-379.   x[N,C,H,W], w[K,C,R,S], y[N,K,OH,OW], OH=(H+2p-R)/s+1.
  * fwd: y = conv(x,w) (+bias[K]) (+residual, same shape as y).  dgrad: dx from dy.  wgrad: dw from dy,x. */
+size_t ag2v_conv2d_workspace_floats(int C, int K, int R, int S);  /* k-major copy of the (sub-)filters; fwd and dgrad */
 int ag2v_conv2d_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y,
-                    int N, int C, int H, int W, int K, int R, int S, int stride, int pad, void* stream);
-size_t ag2v_conv2d_dgrad_workspace_floats(int C, int K, int R, int S, int stride);
+                    int N, int C, int H, int W, int K, int R, int S, int stride, int pad, float* workspace, void* stream);
 int ag2v_conv2d_dgrad(const float* dy, const float* w, float* dx,
                       int N, int C, int H, int W, int K, int R, int S, int stride, int pad, float* workspace, void* stream);
 int ag2v_conv2d_wgrad(const float* dy, const float* x, float* dw,

@@ -29,12 +29,12 @@ for name, N, C, H, W, K, R, st, pad in SHAPES:
     dy = torch.randn(N, K, OH, OH, device=dev)
     dx = torch.empty_like(x)
     dw = torch.empty_like(w)
-    wsb = torch.empty(max(1, _lib.query('ag2v_conv2d_dgrad_workspace_floats', C, K, R, R, st)), device=dev)
+    wsb = torch.empty(max(1, _lib.query('ag2v_conv2d_workspace_floats', C, K, R, R)), device=dev)
     flops = 2.0 * N * K * OH * OH * C * R * R
     def run(which):
         s = _stream()
         if which == 'fwd':
-            _lib.call('ag2v_conv2d_fwd', _ptr(x), _ptr(w), None, None, _ptr(y), N, C, H, W, K, R, R, st, pad, s)
+            _lib.call('ag2v_conv2d_fwd', _ptr(x), _ptr(w), None, None, _ptr(y), N, C, H, W, K, R, R, st, pad, _ptr(wsb), s)
         elif which == 'dgrad':
             _lib.call('ag2v_conv2d_dgrad', _ptr(dy), _ptr(w), _ptr(dx), N, C, H, W, K, R, R, st, pad, _ptr(wsb), s)
         else:
