@@ -40,21 +40,46 @@ def make_opt(cfg):
     return _mk(cater_vocab(), flags), side, frames, batch
 
 
-def cpu_baseline(shapes_G, shapes_D, wseed):
-    """The oracle (CPU restatement of the reference step) timed on this host's cores on a bounded sample."""
+def cpu_baseline_child():
+    """Runs in a child process without a GPU: the oracle (CPU restatement of the reference step) timed on this host's
+    cores on a bounded sample -- one full step of config c1 (64x64, 4 frames, batch 1, default widths)."""
     from ag2video_amd.data.synthetic import make_clip_batch
+    from ag2video_amd.models.meta_models import AG2VideoModel, MetaDiscriminatorModel
     from oracle.step import OracleTrainer
     opt, side, frames, batch = make_opt('c1')
     opt.gpu_ids = []
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
-    tr = OracleTrainer(opt, shapes_G, shapes_D, wseed)
+    threads = max(1, min(16, os.cpu_count() or 1))   # the step is thousands of small ops: more threads only add barriers
+    torch.set_num_threads(threads)
+    cpu = torch.device('cpu')
+    shapes_G = {k: list(v.shape) for k, v in AG2VideoModel(opt, cpu).state_dict().items()}
+    shapes_D = {k: list(v.shape) for k, v in MetaDiscriminatorModel(opt).img_discriminator.state_dict().items()}
+    tr = OracleTrainer(opt, shapes_G, shapes_D, 0)
     b = make_clip_batch(opt.vocab, batch, frames, (side, side), seed=1234)
     t0 = time.time()
     tr.gd_step(b)
     dt = time.time() - t0
-    return {"value": round(batch * frames / dt, 4), "unit": "frames/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "1 full step (G fwd+loss+bwd+Adam, D loss+bwd+Adam) of config c1: 64x64, 4 frames, batch 1, default "
-                      "widths, on the oracle (PyTorch-CPU restatement of the reference); %.1f s" % dt}
+    print(json.dumps({"value": round(batch * frames / dt, 4), "unit": "frames/sec", "cores": threads, "kind": "port",
+                      "sample": "1 full step (G fwd+loss+bwd+Adam, D loss+bwd+Adam) of config c1: 64x64, 4 frames, batch 1, "
+                                "default widths, on the oracle (PyTorch-CPU restatement of the reference); %.1f s" % dt}), flush=True)
+
+
+def cpu_baseline(timeout_s=240):
+    """Spawn the CPU baseline as a child process (bounded wall time; the GPU process itself never runs the oracle)."""
+    import subprocess
+    env = dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='', OMP_NUM_THREADS='16', MKL_NUM_THREADS='16')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-only'], env=env, capture_output=True,
+                             text=True, timeout=timeout_s)
+        for line in reversed(out.stdout.strip().splitlines()):
+            if line.startswith('{'):
+                return json.loads(line)
+        return {"value": None, "unit": "frames/sec", "cores": None, "kind": "port",
+                "sample": "cpu baseline child failed: %s" % (out.stderr.strip()[-200:],)}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "frames/sec", "cores": None, "kind": "port",
+                "sample": "cpu baseline child exceeded %d s and was stopped" % timeout_s}
 
 
 def main():
@@ -64,8 +89,12 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--config', default='c3', choices=sorted(CONFIGS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline-only', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     args = ap.parse_args()
+    if args.cpu_baseline_only:
+        cpu_baseline_child()
+        return
 
     from ag2video_amd import distributed as D
     from ag2video_amd import ops
@@ -135,9 +164,7 @@ def main():
                                                        "launches": v['launches']} for k, v in sorted(timing.items())}}}
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        shapes_G = {k: list(v.shape) for k, v in ts.model.state_dict().items()}
-        shapes_D = {k: list(v.shape) for k, v in ts.discriminator.img_discriminator.state_dict().items()}
-        cpu = cpu_baseline(shapes_G, shapes_D, 0)
+        cpu = cpu_baseline()
     line = {
         "metric": "frames/sec/node (gen+disc fwd+bwd), CATER %dx%dx%df" % (side, side, frames),
         "value": round(value, 3), "unit": "frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
