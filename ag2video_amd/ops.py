@@ -191,8 +191,10 @@ class _NormAct(torch.autograd.Function):
             _lib.call('ag2v_norm_apply', 0, _ptr(x), _ptr(mean), _ptr(invstd), _ptr(p0), _ptr(p1), None, None, _ptr(y),
                       N, C, HW, float(slope), _stream())
         else:
-            _lib.call('ag2v_norm_apply', 1, _ptr(x), _ptr(mean), _ptr(invstd), None, None, _ptr(p0), _ptr(p1), _ptr(y),
-                      N, C, HW, float(slope), _stream())
+            # timed as an HBM-bound kernel: algorithmic bytes = x, gamma, beta read + y written (4 tensors), recorded in
+            # the "flops" slot of the timing record
+            _launch('ag2v_norm_apply', 'spade_norm_apply', 4.0 * x.numel() * 4, 1, _ptr(x), _ptr(mean), _ptr(invstd), None, None,
+                    _ptr(p0), _ptr(p1), _ptr(y), N, C, HW, float(slope), _stream(), shape=(N, C, HW))
         ctx.save_for_backward(x, y if slope != 1.0 else None, p0, mean, invstd)
         ctx.cfg = (mode, training, slope, N, C, HW)
         return y

@@ -30,6 +30,7 @@ CONFIGS = {
     'toy': (64, 3, 2, ['--ngf', '8', '--ndf', '8', '--nff', '8', '--gconv_hidden_dim', '64']),
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0              # same guide: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
 def make_opt(cfg):
@@ -148,6 +149,14 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = world * batch * frames * args.steps / dt
     roof = None
+    roof_hbm = None
+    if 'spade_norm_apply' in timing:
+        t = timing.pop('spade_norm_apply')
+        gbs = t['flops'] / (t['ms'] * 1e-3) / 1e9          # the record's work slot holds algorithmic bytes for this kernel
+        roof_hbm = {"bound": "hbm", "kernel": "norm_apply_kernel<1,true> (SPADE modulation + LeakyReLU)", "achieved": round(gbs, 1),
+                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "launches": t['launches'],
+                    "avg_launch_ms": round(t['ms'] / t['launches'], 4),
+                    "traffic": "rocprofv3 PMC (profiles/r01/pmc): FETCH_SIZE*2 + WRITE_SIZE = 3x + 1x tensor bytes = algorithmic"}
     if timing:
         dom = max(timing, key=lambda k: timing[k]['ms'])
         t = timing[dom]
@@ -172,7 +181,7 @@ def main():
         "dtype": "f32", "data": "synthetic CATER-shaped clips (seeded), closed-form random-init weights",
         "config": {"workload": "%s: CATER %dx%d, %d frames, batch %d per GPU, full G+D train step, VGG loss off"
                    % (args.config, side, side, frames, batch), "global_batch": world * batch, "parallelism": "dp%d" % world},
-        "roofline": roof, "cpu_baseline": cpu,
+        "roofline": roof, "roofline_hbm": roof_hbm, "cpu_baseline": cpu,
         "extra": {"graph_step_ms": round(graph_ms, 2), "losses_finite": finite,
                   "generated_frames_per_sec": round(world * batch * (frames - 1) * args.steps / dt, 3),
                   "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)},

@@ -120,3 +120,51 @@ def test_train_step_matches_oracle_other_shape(cfg, device):
         ref = mo_r[i].detach().numpy()
         err = np.abs(mo[i].detach().cpu().numpy() - ref).max()
         assert err <= 1e-3 * np.abs(ref).max(), (name, err)
+
+
+def _pair(flags, vocab, wseed, device):
+    from ag2video_amd.data.args import make_opt
+    from ag2video_amd.engine import TrainStep
+    from oracle.step import OracleTrainer
+    opt = make_opt(vocab, flags + ['--gpu_ids', '0', '--no_vgg_loss'])
+    ts = TrainStep(opt, device, weights_seed=wseed)
+    shapes_G = {k: list(v.shape) for k, v in ts.model.state_dict().items()}
+    shapes_D = {k: list(v.shape) for k, v in ts.discriminator.img_discriminator.state_dict().items()}
+    return opt, ts, OracleTrainer(opt, shapes_G, shapes_D, wseed)
+
+
+def test_inference_path_matches_oracle(device):
+    """test_mode=True, use_gt=False (scripts/test.py's path): frames are generated autoregressively from the model's own
+    previous output and from *predicted* boxes.  Norm layers stay in batch-statistics mode: with freshly initialised running
+    statistics (mean 0, var 1) nothing normalises the closed-form weights and both sides overflow; the eval-mode norm
+    kernels are covered by test_ops_gpu.py::test_norm_eval_mode."""
+    from ag2video_amd.data.synthetic import make_clip_batch
+    from ag2video_amd.data.vocab import cater_vocab
+    from oracle import model as M
+    opt, ts, orc = _pair(['--image_size', '64,64', '--batch_size', '2', '--ngf', '8', '--ndf', '8', '--nff', '8',
+                          '--gconv_hidden_dim', '64'], cater_vocab(), 9, device)
+    clip = make_clip_batch(opt.vocab, 2, 4, (64, 64), seed=5)
+    imgs, objs, boxes, triplets, actions = clip[:5]
+    with torch.no_grad():
+        ref = M.generator_forward(orc.G, opt, imgs, objs, triplets, actions, boxes, training=True, use_gt=False, test_mode=True)
+        d = ts.to_device(clip)
+        got = ts.model(d[0], d[1], d[3], d[4], boxes_gt=d[2], test_mode=True, use_gt=False)
+    for i, name in enumerate(('imgs_pred', 'boxes_pred', 'flows_pred')):
+        r = ref[i].numpy()
+        err = np.abs(got[i].cpu().numpy() - r).max()
+        assert np.isfinite(r).all() and err <= 1e-3 * np.abs(r).max(), (name, err, np.abs(r).max())
+
+
+def test_single_attribute_vocab_step(device):
+    """Something-Else shaped vocabulary: one attribute => semantic_nc = 128, no attribute_fc_gen, 2-3 objects per clip."""
+    from ag2video_amd.data.synthetic import make_clip_batch
+    from ag2video_amd.data.vocab import smth_vocab
+    opt, ts, orc = _pair(['--image_size', '64,64', '--batch_size', '2', '--ngf', '8', '--ndf', '8', '--nff', '8',
+                          '--gconv_hidden_dim', '64'], smth_vocab(12), 4, device)
+    assert opt.semantic_nc == 128
+    clip = make_clip_batch(opt.vocab, 2, 3, (64, 64), seed=21, min_objs=2, max_objs=3, max_actions=2)
+    _, GL_r, DL_r = orc.gd_step(clip)
+    _, GL, DL = ts.gd_step(ts.to_device(clip))
+    for got, ref in ((GL, GL_r), (DL, DL_r)):
+        for k in ref:
+            assert abs(got[k].item() - ref[k].item()) <= 1e-3 * max(1.0, abs(ref[k].item())), (k, got[k].item(), ref[k].item())
