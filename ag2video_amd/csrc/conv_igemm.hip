@@ -53,7 +53,7 @@ __device__ __forceinline__ void decode_crs(int kg, int RS, int S, int& c, int& r
 }
 
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
+__global__ __launch_bounds__(256, 4) void conv_igemm_kernel(ConvArgs p) {
     constexpr int BK = 16;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int LDA = BM + 4, LDB = BN + 4;
@@ -235,14 +235,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvArgs p) {
 
     const int qq = tid & 15, rg = tid >> 4;
     // hoisted column decode: j -> (c, r-pad, s-pad)
-    int boff[EB], bdr[EB], bds[EB];
+    int boff[EB], bpk[EB];   // bpk: (r-pad+64) | (s-pad+64)<<8 | valid<<16
 #pragma unroll
     for (int i = 0; i < EB; ++i) {
         const int j = n0 + rg + 16 * i;
         int c, r, s;
         decode_crs(j, RS, p.S, c, r, s);
-        bdr[i] = (j < p.NG) ? (r - p.pad) : (1 << 28);  // invalid column => always out of bounds
-        bds[i] = s - p.pad;
+        bpk[i] = ((r - p.pad + 64) & 255) | (((s - p.pad + 64) & 255) << 8) | ((j < p.NG) ? (1 << 16) : 0);
         boff[i] = c * HW + (r - p.pad) * p.W + (s - p.pad);
     }
 
@@ -271,8 +270,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvArgs p) {
         }
 #pragma unroll
         for (int i = 0; i < EB; ++i) {
-            const int iy = yb + bdr[i], ix = xb + bds[i];
-            const bool ok = qvalid && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const int iy = yb + (bpk[i] & 255) - 64, ix = xb + ((bpk[i] >> 8) & 255) - 64;
+            const bool ok = qvalid && (bpk[i] >> 16) && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
             rb[i] = ok ? bp[boff[i]] : 0.f;
         }
     };
