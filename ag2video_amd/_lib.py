@@ -26,8 +26,8 @@ _SIGS = {
     'ag2v_instnorm_lrelu_bwd': (c_int, [_P] * 6 + [c_int, c_int, c_float, _P]),
     'ag2v_layout_render_fwd': (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [_P]),
     'ag2v_layout_render_bwd': (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [_P]),
-    'ag2v_layout_conv_fwd': (c_int, [_P, _P, _P, _P, _P] + [c_int] * 8 + [_P]),
-    'ag2v_layout_conv_bwd': (c_int, [_P, _P, _P, _P] + [c_int] * 8 + [_P]),
+    'ag2v_layout_conv_fwd': (c_int, [_P, _P, _P, _P, _P] + [c_int] * 9 + [_P]),
+    'ag2v_layout_conv_bwd': (c_int, [_P, _P, _P, _P] + [c_int] * 9 + [_P]),
     'ag2v_flow_warp_fwd': (c_int, [_P, _P, _P] + [c_int] * 4 + [_P]),
     'ag2v_flow_warp_bwd': (c_int, [_P, _P, _P, _P, _P] + [c_int] * 4 + [_P]),
     'ag2v_avgpool3s2_fwd': (c_int, [_P, _P, c_int, c_int, c_int, _P]),

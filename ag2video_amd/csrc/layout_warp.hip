@@ -111,20 +111,37 @@ __global__ __launch_bounds__(256) void layout_render_bwd_kernel(const float* __r
 // ("layout tensors are huge and low-rank").  Reference call sites: the seg channels of
 // generator.py:74,82-83 (conv_dim_in) and flows_generator.py:32 (down_flow[0]).  Zero padding: w_j is 0 outside [0,H)x[0,W).
 // U: [NB, J, K, R*R]; boxes [NB, J, 4]; keep [NB, J]; residual/out [NB, K, OH, OW].
+// 1-D box profile at index i of the map the convolution sees.  pool == 0: the full-resolution profile tau8(lin01(i, L)).
+// pool == 1: the map is avg_pool2d(3, stride 2, pad 1, count_include_pad=False) of the layout (the discriminator's second
+// scale, discriminator.py:270-271,351); pooling a separable map is separable, so the pooled profile is the average of the
+// valid taps 2i-1..2i+1 of the full-resolution profile (L = full-resolution length).
+__device__ __forceinline__ float lc_profile(int i, int L, int pool, float lo, float ext) {
+    if (!pool) return tau8(lin01(i, L), lo, ext);
+    float s = 0.f;
+    int c = 0;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int k = 2 * i - 1 + d;
+        if ((unsigned)k < (unsigned)L) { s += tau8(lin01(k, L), lo, ext); ++c; }
+    }
+    return s / (float)c;
+}
+
 template <int R>
-__device__ __forceinline__ void lc_taps_y(float (&tyr)[R], int oy, int stride, int pad, int H, float y0, float hh, bool active) {
+__device__ __forceinline__ void lc_taps_y(float (&tyr)[R], int oy, int stride, int pad, int Hm, int H, int pool, float y0, float hh,
+                                          bool active) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int yy = oy * stride + r - pad;
-        tyr[r] = (active && (unsigned)yy < (unsigned)H) ? tau8(lin01(yy, H), y0, hh) : 0.f;
+        tyr[r] = (active && (unsigned)yy < (unsigned)Hm) ? lc_profile(yy, H, pool, y0, hh) : 0.f;
     }
 }
 
 template <int R, int KPER>
 __global__ __launch_bounds__(256) void layout_conv_fwd_kernel(const float* __restrict__ U, const float* __restrict__ boxes,
                                                               const int* __restrict__ keep, const float* __restrict__ residual,
-                                                              float* __restrict__ out, int J, int K, int H, int W, int OH, int OW,
-                                                              int stride, int pad) {
+                                                              float* __restrict__ out, int J, int K, int H, int W, int Hm, int Wm,
+                                                              int pool, int OH, int OW, int stride, int pad) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int oy = blockIdx.x * 4 + wave;
     const int n = blockIdx.y;
@@ -147,7 +164,7 @@ __global__ __launch_bounds__(256) void layout_conv_fwd_kernel(const float* __res
             const bool legal = (x0 != 0.f) || (y0 != 0.f) || (ww != 0.f) || (hh != 0.f);
             const bool active = legal && keep[(size_t)n * J + j] != 0;
             float tyr[R];
-            lc_taps_y<R>(tyr, oy, stride, pad, H, y0, hh, active);
+            lc_taps_y<R>(tyr, oy, stride, pad, Hm, H, pool, y0, hh, active);
             float tysum = 0.f;
 #pragma unroll
             for (int r = 0; r < R; ++r) tysum += fabsf(tyr[r]);
@@ -159,7 +176,7 @@ __global__ __launch_bounds__(256) void layout_conv_fwd_kernel(const float* __res
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int xx = (xq * 4 + q) * stride + s - pad;
-                    txs[s][q] = ((unsigned)xx < (unsigned)W) ? tau8(lin01(xx, W), x0, ww) : 0.f;
+                    txs[s][q] = ((unsigned)xx < (unsigned)Wm) ? lc_profile(xx, W, pool, x0, ww) : 0.f;
                     txsum += fabsf(txs[s][q]);
                 }
             if (__ballot(txsum != 0.f) == 0ull) continue;
@@ -199,7 +216,8 @@ __global__ __launch_bounds__(256) void layout_conv_fwd_kernel(const float* __res
 template <int R>
 __global__ __launch_bounds__(256) void layout_conv_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ boxes,
                                                               const int* __restrict__ keep, float* __restrict__ dU, int J, int K,
-                                                              int H, int W, int OH, int OW, int stride, int pad) {
+                                                              int H, int W, int Hm, int Wm, int pool, int OH, int OW, int stride,
+                                                              int pad) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = blockIdx.x, n = blockIdx.y;
     const float* b = boxes + ((size_t)n * J + j) * 4;
@@ -222,14 +240,14 @@ __global__ __launch_bounds__(256) void layout_conv_bwd_kernel(const float* __res
 #pragma unroll
                 for (int s = 0; s < R; ++s) {
                     const int xx = ox * stride + s - pad;
-                    txs[s] = (ox < OW && (unsigned)xx < (unsigned)W) ? tau8(lin01(xx, W), x0, ww) : 0.f;
+                    txs[s] = (ox < OW && (unsigned)xx < (unsigned)Wm) ? lc_profile(xx, W, pool, x0, ww) : 0.f;
                     txsum += fabsf(txs[s]);
                 }
                 if (__ballot(txsum != 0.f) == 0ull) continue;
                 const float* dp = dout + ((size_t)n * K + k) * OH * OW + ox;
                 for (int oy = 0; oy < OH; ++oy) {
                     float tyr[R];
-                    lc_taps_y<R>(tyr, oy, stride, pad, H, y0, hh, true);
+                    lc_taps_y<R>(tyr, oy, stride, pad, Hm, H, pool, y0, hh, true);
                     float tysum = 0.f;
 #pragma unroll
                     for (int r = 0; r < R; ++r) tysum += fabsf(tyr[r]);
@@ -471,36 +489,38 @@ extern "C" int ag2v_layout_render_bwd(const float* dout, const float* boxes, con
 }
 
 extern "C" int ag2v_layout_conv_fwd(const float* U, const float* boxes, const int* keep, const float* residual, float* out,
-                                    int NB, int J, int K, int H, int W, int R, int stride, int pad, void* stream) {
+                                    int NB, int J, int K, int H, int W, int R, int stride, int pad, int pool, void* stream) {
     if (!U || !boxes || !keep || !out || NB <= 0 || J <= 0 || K <= 0 || H <= 0 || W <= 0 || stride <= 0 || NB > 65535) return AG2V_EINVAL;
-    if (R != 3 && R != 4) return AG2V_EINVAL;
-    const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - R) / stride + 1;
+    if ((R != 3 && R != 4) || pool < 0 || pool > 1) return AG2V_EINVAL;
+    const int Hm = pool ? (H - 1) / 2 + 1 : H, Wm = pool ? (W - 1) / 2 + 1 : W;   // size of the map the convolution sees
+    const int OH = (Hm + 2 * pad - R) / stride + 1, OW = (Wm + 2 * pad - R) / stride + 1;
     if (OH <= 0 || OW <= 0) return AG2V_EINVAL;
     constexpr int KPER = 16;
     dim3 grid(ceil_div(OH, 4), NB, ceil_div(K, KPER));
     if (R == 3)
         hipLaunchKernelGGL((layout_conv_fwd_kernel<3, KPER>), grid, dim3(256), 0, (hipStream_t)stream, U, boxes, keep, residual, out,
-                           J, K, H, W, OH, OW, stride, pad);
+                           J, K, H, W, Hm, Wm, pool, OH, OW, stride, pad);
     else
         hipLaunchKernelGGL((layout_conv_fwd_kernel<4, KPER>), grid, dim3(256), 0, (hipStream_t)stream, U, boxes, keep, residual, out,
-                           J, K, H, W, OH, OW, stride, pad);
+                           J, K, H, W, Hm, Wm, pool, OH, OW, stride, pad);
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
 }
 
 extern "C" int ag2v_layout_conv_bwd(const float* dout, const float* boxes, const int* keep, float* dU, int NB, int J, int K, int H,
-                                    int W, int R, int stride, int pad, void* stream) {
+                                    int W, int R, int stride, int pad, int pool, void* stream) {
     if (!dout || !boxes || !keep || !dU || NB <= 0 || J <= 0 || K <= 0 || H <= 0 || W <= 0 || stride <= 0 || NB > 65535) return AG2V_EINVAL;
-    if (R != 3 && R != 4) return AG2V_EINVAL;
-    const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - R) / stride + 1;
+    if ((R != 3 && R != 4) || pool < 0 || pool > 1) return AG2V_EINVAL;
+    const int Hm = pool ? (H - 1) / 2 + 1 : H, Wm = pool ? (W - 1) / 2 + 1 : W;
+    const int OH = (Hm + 2 * pad - R) / stride + 1, OW = (Wm + 2 * pad - R) / stride + 1;
     if (OH <= 0 || OW <= 0) return AG2V_EINVAL;
     dim3 grid(J, NB, ceil_div(K, 32));
     if (R == 3)
-        hipLaunchKernelGGL(layout_conv_bwd_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, dout, boxes, keep, dU, J, K, H, W, OH,
-                           OW, stride, pad);
+        hipLaunchKernelGGL(layout_conv_bwd_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, dout, boxes, keep, dU, J, K, H, W, Hm,
+                           Wm, pool, OH, OW, stride, pad);
     else
-        hipLaunchKernelGGL(layout_conv_bwd_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, dout, boxes, keep, dU, J, K, H, W, OH,
-                           OW, stride, pad);
+        hipLaunchKernelGGL(layout_conv_bwd_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, dout, boxes, keep, dU, J, K, H, W, Hm,
+                           Wm, pool, OH, OW, stride, pad);
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
 }

@@ -30,7 +30,7 @@ def render_clip_layouts(vecs, boxes, objs, vocab, H, W, frame_major=True):
     return list(out.view(Fr, B, D, H, W).unbind(0))
 
 
-def layout_conv_lowrank(weight, vecs_list, boxes_list, keep, H, W, stride=1, pad=1, residual=None):
+def layout_conv_lowrank(weight, vecs_list, boxes_list, keep, H, W, stride=1, pad=1, residual=None, pool=0):
     """conv2d(concat_f layout_f, weight) WITHOUT materialising the layouts.
 
     A layout is a sum over objects of (vector) x (separable box weight map) (boxes_to_layout, models/layout.py:28-63), so a
@@ -47,4 +47,4 @@ def layout_conv_lowrank(weight, vecs_list, boxes_list, keep, H, W, stride=1, pad
     U = torch.cat(Us, dim=1)
     boxes = torch.cat(list(boxes_list), dim=1)
     keep_all = keep.to(torch.int32).repeat(1, len(vecs_list))
-    return ops.layout_conv(U, boxes, keep_all, H, W, R, stride, pad, residual)
+    return ops.layout_conv(U, boxes, keep_all, H, W, R, stride, pad, residual, pool)

@@ -9,7 +9,8 @@ from ...attribute_embed import AttributeEmbeddings
 from ...graph_models.graph import GraphTripleConv
 from ...graph_models.model import action_edge_vectors
 from ...layers import Conv2d, Embedding, FusedMLP, Linear
-from ...layout import render_clip_layouts
+from ...layout import layout_conv_lowrank, render_clip_layouts
+from ...utils import remove_dummy_objects
 from .normalization import get_nonspade_norm_layer
 
 
@@ -39,14 +40,16 @@ class NLayerActionDiscriminator(nn.Module):
         emb = self.opt.gconv_dim if self.opt.use_actions_loss else self.opt.semantic_nc
         return emb * 2 + 3
 
-    def forward(self, x):
+    def forward(self, x=None, first_conv=None):
+        """x: the 259-channel input; or first_conv: the pre-activation output of model0's convolution computed by the caller
+        (MultiscaleActionDiscriminator evaluates its layout channels in low-rank form)."""
         results = []
-        for sub in self.children():
+        for idx, sub in enumerate(self.children()):
             first = sub[0]
             if isinstance(first, nn.Sequential):            # SN conv -> instance norm (+ fused LeakyReLU)
                 x = first[1](first[0](x), slope=0.2)
             else:
-                x = first(x)
+                x = first_conv if (idx == 0 and first_conv is not None) else first(x)
                 if len(sub) > 1:                            # model0: conv + LeakyReLU
                     x = ops.leaky_relu(x, 0.2)
             results.append(x)
@@ -107,11 +110,34 @@ class MultiscaleActionDiscriminator(nn.Module):
         att = self.attribute_embedding(objs)
         B, T = ov.size(0), ov.size(1)
         v = self.fc_objs_vecs(torch.cat([att.unsqueeze(1).expand(B, T, att.size(1), att.size(2)), ov], dim=-1))
+        low_rank = getattr(self.opt, 'low_rank_layout', True) and self.opt.num_D <= 2
+        result = []
+        if low_rank:
+            # The 256 layout channels of the 259-channel input are a sum over objects of (vector) x (box weight map): both
+            # scales' first convolutions take them in low-rank form (scale 1 with the pooled box profiles), so neither the
+            # [B*T, 259, H, W] input nor its pooled copy is ever built; only the 3 image channels are convolved densely.
+            keep = remove_dummy_objects(objs, self.opt.vocab)                                   # [B, O]
+            keep = keep.unsqueeze(1).expand(B, T, keep.size(1)).reshape(B * T, -1)
+            vf = v.reshape(B * T, v.size(2), v.size(3))
+            bf = layout_boxes.reshape(B * T, layout_boxes.size(2), 4)
+            x_img = img.reshape(B * T, img.size(2), H, H)
+            scale = 0
+            for name, D in self.named_children():
+                if name.startswith('discriminator'):
+                    conv = D.model0[0]
+                    nimg = x_img.size(1)
+                    y = ops.conv2d(x_img, conv.weight[:, :nimg], conv.bias, conv.stride[0], conv.padding[0])
+                    y = layout_conv_lowrank(conv.weight[:, nimg:], [vf], [bf], keep, H, H, conv.stride[0], conv.padding[0],
+                                            residual=y, pool=scale)
+                    out = D(first_conv=y)
+                    result.append(out if not self.opt.no_ganFeat_loss else [out])
+                    x_img = self.downsample(x_img)
+                    scale += 1
+            return result
         segs = render_clip_layouts(v, layout_boxes, objs, self.opt.vocab, H, H, frame_major=True)   # T x [B, 256, H, W]
         seg = torch.stack(segs, dim=1)                                                              # [B, T, 256, H, W]
         x = torch.cat([img, seg], dim=2)
         x = x.view(B * T, x.size(2), H, H)
-        result = []
         for name, D in self.named_children():
             if name.startswith('discriminator'):
                 out = D(x)

@@ -297,40 +297,42 @@ def layout_render(vecs, boxes, keep, H, W):
 
 class _LayoutConv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, U, boxes, keep, residual, H, W, R, stride, pad):
+    def forward(ctx, U, boxes, keep, residual, H, W, R, stride, pad, pool):
         U, boxes, residual = _c(U), _c(boxes), _c(residual)
         _chk(U, boxes, residual)
         keep = keep.to(torch.int32).contiguous()
         NB, J, K, RS = U.shape
         if RS != R * R:
             raise RuntimeError("layout_conv: U has %d taps, expected %d" % (RS, R * R))
-        OH = (H + 2 * pad - R) // stride + 1
-        OW = (W + 2 * pad - R) // stride + 1
+        Hm, Wm = ((H - 1) // 2 + 1, (W - 1) // 2 + 1) if pool else (H, W)
+        OH = (Hm + 2 * pad - R) // stride + 1
+        OW = (Wm + 2 * pad - R) // stride + 1
         out = torch.empty((NB, K, OH, OW), device=U.device, dtype=torch.float32)
         _lib.call('ag2v_layout_conv_fwd', _ptr(U), _ptr(boxes), _ptr(keep), _ptr(residual), _ptr(out), NB, J, K, H, W, R, stride,
-                  pad, _stream())
+                  pad, pool, _stream())
         ctx.save_for_backward(boxes, keep)
-        ctx.cfg = (NB, J, K, H, W, R, stride, pad, residual is not None)
+        ctx.cfg = (NB, J, K, H, W, R, stride, pad, pool, residual is not None)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         boxes, keep = ctx.saved_tensors
-        NB, J, K, H, W, R, stride, pad, has_res = ctx.cfg
+        NB, J, K, H, W, R, stride, pad, pool, has_res = ctx.cfg
         dout = dout.contiguous()
         dU = None
         if ctx.needs_input_grad[0]:
             dU = torch.empty((NB, J, K, R * R), device=dout.device, dtype=torch.float32)
-            _lib.call('ag2v_layout_conv_bwd', _ptr(dout), _ptr(boxes), _ptr(keep), _ptr(dU), NB, J, K, H, W, R, stride, pad,
+            _lib.call('ag2v_layout_conv_bwd', _ptr(dout), _ptr(boxes), _ptr(keep), _ptr(dU), NB, J, K, H, W, R, stride, pad, pool,
                       _stream())
         dres = dout if (has_res and ctx.needs_input_grad[3]) else None
-        return dU, None, None, dres, None, None, None, None, None
+        return dU, None, None, dres, None, None, None, None, None, None
 
 
-def layout_conv(U, boxes, keep, H, W, R=3, stride=1, pad=1, residual=None):
+def layout_conv(U, boxes, keep, H, W, R=3, stride=1, pad=1, residual=None, pool=0):
     """Convolution of a box layout in its low-rank form (see csrc/layout_warp.hip): U[NB,J,K,R*R] are the filter taps already
-    contracted with each object's vector; out = residual + sum_j sum_rs U[:,j,:,rs] * w_j(shifted)."""
-    return _LayoutConv.apply(U, boxes, keep, residual, int(H), int(W), int(R), int(stride), int(pad))
+    contracted with each object's vector; out = residual + sum_j sum_rs U[:,j,:,rs] * w_j(shifted).  pool=1: the convolution
+    runs on the 3x3/stride-2 average-pooled layout (the discriminator's second scale)."""
+    return _LayoutConv.apply(U, boxes, keep, residual, int(H), int(W), int(R), int(stride), int(pad), int(pool))
 
 
 class _FlowWarp(torch.autograd.Function):

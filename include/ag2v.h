@@ -63,10 +63,11 @@ int ag2v_layout_render_bwd(const float* dout, const float* boxes, const int* kee
 /* layout convolution in low-rank form: conv(layout, Wt) with layout = sum_j v_j (x) w_j evaluated as
  * out = residual + sum_j sum_rs U[n,j,k,rs] * w_j(oy*st+r-pad, ox*st+s-pad),  U = Wt . v  (caller's GEMM);  R = 3 or 4 (square).
  * Replaces the layout channels of generator.py:74,82-83 (conv_dim_in) and flows_generator.py:32 (down_flow[0]). */
+/* pool = 1: the convolution sees avg_pool2d(3,2,1,count_include_pad=False)(layout) (discriminator.py:270-271,351) */
 int ag2v_layout_conv_fwd(const float* U, const float* boxes, const int* keep, const float* residual /*nullable*/, float* out,
-                         int NB, int J, int K, int H, int W, int R, int stride, int pad, void* stream);
+                         int NB, int J, int K, int H, int W, int R, int stride, int pad, int pool, void* stream);
 int ag2v_layout_conv_bwd(const float* dout, const float* boxes, const int* keep, float* dU, int NB, int J, int K, int H, int W,
-                         int R, int stride, int pad, void* stream);
+                         int R, int stride, int pad, int pool, void* stream);
 
 /* ---- flow warp: resample/get_grid models/utils.py:113-140 (grid_sample bilinear, border, align_corners=False) --- */
 int ag2v_flow_warp_fwd(const float* img, const float* flow, float* out, int N, int C, int H, int W, void* stream);

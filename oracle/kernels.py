@@ -83,7 +83,7 @@ def layout_render(vecs, boxes, keep, H, W):
     return torch.cat(outs, dim=0)
 
 
-def layout_conv(U, boxes, keep, H, W, R=3, stride=1, pad=1, residual=None):
+def layout_conv(U, boxes, keep, H, W, R=3, stride=1, pad=1, residual=None, pool=0):
     """Checker for the low-rank layout convolution: render each object's weight map w_j with the reference's own
     boxes_to_layout arithmetic (models/layout.py:28-63, vectors = identity) and convolve it densely with U as the filter."""
     NB, J, K, _ = U.shape
@@ -94,6 +94,8 @@ def layout_conv(U, boxes, keep, H, W, R=3, stride=1, pad=1, residual=None):
         for j in range(J):
             if bool(keep[n, j]) and bool((boxes[n, j] != 0).any()):
                 wmaps[0, j] = boxes_to_layout_single(eye[j:j + 1, j:j + 1], boxes[n, j:j + 1], H, W)[0, 0]
+        if pool:
+            wmaps = avgpool3s2(wmaps)          # discriminator.py:270-271,351: the second scale sees the pooled input
         filt = U[n].permute(1, 0, 2).reshape(K, J, R, R)
         outs.append(F.conv2d(wmaps, filt, None, stride=stride, padding=pad))
     y = torch.cat(outs, dim=0)

@@ -195,21 +195,23 @@ def test_layout_render(cfg, device):
     _run_pair(ops.layout_render, K.layout_render, t, device, nondiff=('boxes',), name='layout')
 
 
-@pytest.mark.parametrize("cfg", [(2, 6, 20, 32, 32, 3, 1, 1), (3, 22, 40, 64, 64, 3, 1, 1), (2, 5, 9, 32, 32, 4, 2, 2),
-                                 (1, 9, 33, 24, 40, 3, 1, 1)], ids=str)
+@pytest.mark.parametrize("cfg", [(2, 6, 20, 32, 32, 3, 1, 1, 0), (3, 22, 40, 64, 64, 3, 1, 1, 0), (2, 5, 9, 32, 32, 4, 2, 2, 0),
+                                 (1, 9, 33, 24, 40, 3, 1, 1, 0), (3, 7, 12, 64, 64, 4, 2, 2, 1), (2, 4, 8, 33, 29, 4, 2, 2, 1)],
+                         ids=str)
 def test_layout_conv(cfg, device):
     from ag2video_amd import ops
     from oracle import kernels as K
-    NB, J, Kc, H, W, R, st, pad = cfg
+    NB, J, Kc, H, W, R, st, pad, pool = cfg
     boxes = _boxes(NB, J, 21)
     boxes[0, 1] = 0.0
     boxes[NB - 1, 0] = torch.tensor([0.0, 0.0, 1.0, 1.0])
     boxes[0, J - 1] = -1.0
     keep = torch.ones(NB, J, dtype=torch.int32)
     keep[:, J - 1] = 0
-    OH, OW = (H + 2 * pad - R) // st + 1, (W + 2 * pad - R) // st + 1
+    Hm, Wm = ((H - 1) // 2 + 1, (W - 1) // 2 + 1) if pool else (H, W)
+    OH, OW = (Hm + 2 * pad - R) // st + 1, (Wm + 2 * pad - R) // st + 1
     t = {'U': _rand(NB, J, Kc, R * R, seed=22), 'boxes': boxes, 'keep': keep, 'H': H, 'W': W, 'R': R, 'stride': st, 'pad': pad,
-         'residual': _rand(NB, Kc, OH, OW, seed=23)}
+         'residual': _rand(NB, Kc, OH, OW, seed=23), 'pool': pool}
     _run_pair(ops.layout_conv, K.layout_conv, t, device, nondiff=('boxes',), name='layout_conv')
 
 
