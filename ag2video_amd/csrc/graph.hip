@@ -117,31 +117,53 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                                                        long long sam, long long sak, long long sbk, long long sbn, int ldc, int relu,
                                                        int accumulate) {
     constexpr int BK = 16, LD = 64 + 4;
-    __shared__ float As[BK][LD];
-    __shared__ float Bs[BK][LD];
+    __shared__ float As[2][BK][LD];
+    __shared__ float Bs[2][BK][LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
     const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    // each thread stages 4 A and 4 B elements: row (tid & 63), k = (tid >> 6) + 4*i
-    const int row = tid & 63, kq = tid >> 6;
-    for (int k0 = 0; k0 < K; k0 += BK) {
+    // Each thread stages 4 A and 4 B elements per K-tile.  Lanes run along whichever index is contiguous in memory:
+    // k-contiguous operand -> (kk = tid & 15, row = (tid >> 4) + 16 i); otherwise (row = tid & 63, kk = (tid >> 6) + 4 i).
+    const bool a_kc = (sak == 1), b_kc = (sbk == 1);
+    float ra[4], rb[4];
+    auto fetch = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int kk = kq + 4 * i, kg = k0 + kk;
-            const int m = m0 + row, n = n0 + row;
-            As[kk][row] = (m < M && kg < K) ? a[(long long)m * sam + (long long)kg * sak] : 0.f;
-            Bs[kk][row] = (n < N && kg < K) ? b[(long long)kg * sbk + (long long)n * sbn] : 0.f;
+            const int akk = a_kc ? (tid & 15) : ((tid >> 6) + 4 * i), arow = a_kc ? ((tid >> 4) + 16 * i) : (tid & 63);
+            const int bkk = b_kc ? (tid & 15) : ((tid >> 6) + 4 * i), brow = b_kc ? ((tid >> 4) + 16 * i) : (tid & 63);
+            const int m = m0 + arow, n = n0 + brow;
+            ra[i] = (m < M && k0 + akk < K) ? a[(long long)m * sam + (long long)(k0 + akk) * sak] : 0.f;
+            rb[i] = (n < N && k0 + bkk < K) ? b[(long long)(k0 + bkk) * sbk + (long long)n * sbn] : 0.f;
         }
-        __syncthreads();
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int akk = a_kc ? (tid & 15) : ((tid >> 6) + 4 * i), arow = a_kc ? ((tid >> 4) + 16 * i) : (tid & 63);
+            const int bkk = b_kc ? (tid & 15) : ((tid >> 6) + 4 * i), brow = b_kc ? ((tid >> 4) + 16 * i) : (tid & 63);
+            As[buf][akk][arow] = ra[i];
+            Bs[buf][bkk][brow] = rb[i];
+        }
+    };
+    const int nk = (K + BK - 1) / BK;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = (kt + 1) < nk;
+        if (more) fetch((kt + 1) * BK);        // next tile's loads are in flight during this tile's MFMAs
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
             const int kk = 2 * s + (lane >> 5);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[kk][wm0 + (lane & 31)], Bs[kk][wn0 + (lane & 31)], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[cur][kk][wm0 + (lane & 31)], Bs[cur][kk][wn0 + (lane & 31)], acc, 0, 0, 0);
         }
+        if (more) stash(cur ^ 1);
         __syncthreads();
+        cur ^= 1;
     }
     const int n = n0 + wn0 + (lane & 31);
     if (n < N) {

@@ -17,7 +17,11 @@ BUCKET_BYTES = 128 << 20
 
 
 def is_dist():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    """True when the collectives must run: world size > 1 (or AG2V_FORCE_DIST=1, used to exercise the RCCL code path on
+    a single GPU)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get('AG2V_FORCE_DIST') == '1' 
 
 
 def init_from_env(backend=None):
@@ -25,7 +29,8 @@ def init_from_env(backend=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not (dist.is_available() and dist.is_initialized()):
+    force = os.environ.get('AG2V_FORCE_DIST') == '1' and 'RANK' in os.environ
+    if (world > 1 or force) and not (dist.is_available() and dist.is_initialized()):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -76,6 +81,11 @@ def broadcast_parameters(tensors, src=0):
     for t in tensors:
         if t.is_floating_point() or t.dtype in (torch.int64, torch.int32):
             dist.broadcast(t, src=src)
+
+
+def shutdown():
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
 
 
 def max_over_ranks(value, device):

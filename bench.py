@@ -145,6 +145,7 @@ def main():
     graph_ms = (time.time() - tg) * 1e3
 
     if rank != 0:
+        D.shutdown()
         return
     ms_per_step = dt / args.steps * 1e3
     value = world * batch * frames * args.steps / dt
@@ -187,6 +188,7 @@ def main():
                   "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)},
     }
     print(json.dumps(line), flush=True)
+    D.shutdown()
 
 
 if __name__ == '__main__':
