@@ -5,6 +5,7 @@
 //   * torch.nn.utils.spectral_norm train-mode forward: v <- normalize(W^T u), u <- normalize(W v), sigma = u.(W v),
 //     W_bar = W / sigma, and its backward  dW = (dW_bar - (sum dW_bar*W_bar) u v^T) / sigma.
 #include "common.h"
+#include <math.h>
 
 // ---------------------------------------------------------------- activations
 // op 0: leaky relu(slope)   op 1: tanh
@@ -229,6 +230,51 @@ extern "C" int ag2v_spectral_norm_bwd(const float* dwbar, const float* wbar, con
     hipLaunchKernelGGL(dot_partial_kernel, dim3(nb), dim3(256), 0, st, dwbar, wbar, n, partial);
     hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, st, partial, nb, 1.0f, dot);
     hipLaunchKernelGGL(sn_bwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, dwbar, u, v, sigma, dot, dw, M, R);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+
+// ---------------------------------------------------------------- fused Adam over a flat parameter buffer (K15)
+// torch.optim.Adam (scripts/train.py:365-368, meta_models.py:70-72; weight_decay 0, amsgrad off):
+//   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= (lr / (1-b1^t)) * m / (sqrt(v) / sqrt(1-b2^t) + eps)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
+                                                   float bc1, float bc2_sqrt) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    const float step = lr / bc1;
+    if (i + 3 < n) {
+        float4 pv = *reinterpret_cast<float4*>(p + i);
+        const float4 gv = *reinterpret_cast<const float4*>(g + i);
+        float4 mv = *reinterpret_cast<float4*>(m + i), vv = *reinterpret_cast<float4*>(v + i);
+#define ADAM1(P, G, M, V)                                  \
+    M = b1 * M + (1.f - b1) * G;                           \
+    V = b2 * V + (1.f - b2) * G * G;                       \
+    P -= step * M / (sqrtf(V) / bc2_sqrt + eps);
+        ADAM1(pv.x, gv.x, mv.x, vv.x) ADAM1(pv.y, gv.y, mv.y, vv.y) ADAM1(pv.z, gv.z, mv.z, vv.z) ADAM1(pv.w, gv.w, mv.w, vv.w)
+        *reinterpret_cast<float4*>(p + i) = pv;
+        *reinterpret_cast<float4*>(m + i) = mv;
+        *reinterpret_cast<float4*>(v + i) = vv;
+    } else {
+        for (long long j = i; j < n; ++j) {
+            float P = p[j], M = m[j], V = v[j];
+            const float G = g[j];
+            ADAM1(P, G, M, V)
+            p[j] = P; m[j] = M; v[j] = V;
+        }
+    }
+#undef ADAM1
+}
+
+// One Adam step on flat fp32 buffers (16-byte aligned).  step_index >= 1 (bias corrections computed on the host side of the ABI).
+extern "C" int ag2v_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                              float eps, int step_index, void* stream) {
+    if (!p || !g || !m || !v || n <= 0 || step_index < 1) return AG2V_EINVAL;
+    if ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) return AG2V_EINVAL;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step_index);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step_index);
+    hipLaunchKernelGGL(adam_kernel, dim3(ceil_div(n, 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
+                       (float)bc1, (float)sqrt(bc2));
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
 }

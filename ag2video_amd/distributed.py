@@ -38,7 +38,10 @@ def init_from_env(backend=None):
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         if backend == 'nccl':
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if backend == 'nccl':
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
 
@@ -56,11 +59,20 @@ def _buckets(tensors, bucket_bytes):
 
 
 @torch.no_grad()
-def average_gradients(params, bucket_bytes=BUCKET_BYTES):
-    """grad <- mean over ranks, through flat fp32 buckets (one all-reduce per bucket).  No-op on a single process."""
+def average_gradients(params, bucket_bytes=BUCKET_BYTES, flat=None):
+    """grad <- mean over ranks.  ``flat``: the optimizer's flat gradient buffer (ag2video_amd.optim.FusedAdam) -- reduced in
+    place in bucket-sized chunks, no copies; otherwise per-parameter gradients are packed into flat buckets.
+    No-op on a single process."""
     if not is_dist():
         return
     world = dist.get_world_size()
+    if flat is not None:
+        step = max(1, bucket_bytes // flat.element_size())
+        for off in range(0, flat.numel(), step):
+            chunk = flat[off:off + step]
+            dist.all_reduce(chunk, op=dist.ReduceOp.SUM)
+            chunk.div_(world)
+        return
     grads = [p.grad for p in params if p.grad is not None]
     for bucket in _buckets(grads, bucket_bytes):
         flat = torch.cat([g.reshape(-1) for g in bucket])

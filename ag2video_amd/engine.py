@@ -32,11 +32,17 @@ class TrainStep(object):
         graph_params = list(self.model.acts_to_boxes.parameters())
         graph_ids = set(id(p) for p in graph_params)
         gen_params = [p for p in self.model.parameters() if id(p) not in graph_ids]   # train.py:367
-        self.optimizer_graph = torch.optim.Adam(graph_params, lr=lr, betas=(b1, 0.999))
-        self.optimizer_generator = torch.optim.Adam(gen_params, lr=lr, betas=(b1, 0.999))
+        # Adam as in train.py:365-368 / meta_models.py:70-72; on the GPU the fused flat-buffer implementation (one kernel
+        # per step).  (torch.optim.Adam is only used when the modules live on the CPU, i.e. in the host-logic tests.)
+        if torch.device(device).type == 'cuda':
+            from .optim import FusedAdam as Adam
+        else:
+            Adam = torch.optim.Adam
+        self.optimizer_graph = Adam(graph_params, lr=lr, betas=(b1, 0.999))
+        self.optimizer_generator = Adam(gen_params, lr=lr, betas=(b1, 0.999))
         # the discriminator's Adam was built before .to(device); rebuild it over the moved parameters
-        self.discriminator.optimizer_d_img = torch.optim.Adam(list(self.discriminator.img_discriminator.parameters()),
-                                                              lr=lr, betas=(b1, 0.999))
+        self.discriminator.optimizer_d_img = Adam(list(self.discriminator.img_discriminator.parameters()),
+                                                  lr=lr, betas=(b1, 0.999))
         self._gen_params, self._graph_params = gen_params, graph_params
         self._d_params = list(self.discriminator.img_discriminator.parameters())
         for m in (self.model, self.discriminator):
@@ -55,14 +61,14 @@ class TrainStep(object):
         G_losses = {k: v.mean() for k, v in G_losses.items()}
         self.optimizer_generator.zero_grad()
         G_losses["total_loss"].backward()
-        dist_utils.average_gradients(self._gen_params)
+        dist_utils.average_gradients(self._gen_params, flat=getattr(self.optimizer_generator, 'flat_grad', None))
         if apply_updates:
             self.optimizer_generator.step()
         D_losses = self.gans_model(batch, model_out, mode="compute_discriminator_loss")
         D_losses = {k: v.mean() for k, v in D_losses.items()}
         self.discriminator.optimizer_d_img.zero_grad()
         D_losses["total_img_loss"].backward()
-        dist_utils.average_gradients(self._d_params)
+        dist_utils.average_gradients(self._d_params, flat=getattr(self.discriminator.optimizer_d_img, 'flat_grad', None))
         if apply_updates:
             self.discriminator.optimizer_d_img.step()
         return model_out, G_losses, D_losses
@@ -75,7 +81,7 @@ class TrainStep(object):
         L = {k: v.mean() for k, v in L.items()}
         self.optimizer_graph.zero_grad()
         L["total_loss"].backward()
-        dist_utils.average_gradients(self._graph_params)
+        dist_utils.average_gradients(self._graph_params, flat=getattr(self.optimizer_graph, 'flat_grad', None))
         if apply_updates:
             self.optimizer_graph.step()
         return boxes_pred, L

@@ -122,6 +122,11 @@ int ag2v_spectral_norm_fwd(const float* w, float* u, float* v, int M, int R, flo
 int ag2v_spectral_norm_bwd(const float* dwbar, const float* wbar, const float* u, const float* v, const float* sigma, int M,
                            int R, float* dw, float* workspace, void* stream);
 
+/* ---- fused Adam over a flat fp32 buffer: torch.optim.Adam as configured at scripts/train.py:365-368 and
+ * meta_models.py:70-72 (weight_decay 0, amsgrad off); step_index >= 1 --------------------------------------------- */
+int ag2v_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                   int step_index, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
