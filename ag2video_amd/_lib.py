@@ -13,6 +13,8 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libag2v.so')
 _P = c_void_p
 _SIGS = {
     # name: (restype, [argtypes])
+    'ag2v_set_conv_precision': (c_int, [c_int]),
+    'ag2v_get_conv_precision': (c_int, []),
     'ag2v_conv2d_workspace_floats': (c_size_t, [c_int] * 4),
     'ag2v_conv2d_fwd': (c_int, [_P, _P, _P, _P, _P] + [c_int] * 9 + [_P, _P]),
     'ag2v_conv2d_dgrad': (c_int, [_P, _P, _P] + [c_int] * 9 + [_P, _P]),

@@ -735,11 +735,23 @@ __global__ __launch_bounds__(256) void dgrad_weight_prep_kernel(const float* __r
 
 static int conv_out_dim(int in, int k, int stride, int pad) { return (in + 2 * pad - k) / stride + 1; }
 
-// Precision of the igemm: 0 = exact fp32 MFMA (default), 1 = bf16x3 split (AG2V_CONV_PRECISION=bf16x3) for GEMMs with M > 64.
+// Precision of the 128-row igemm / wgrad tiles (GEMMs with M > 64): 1 = bf16x3 split (default: fp32-level accuracy, ~1e-5
+// relative per product, at up to 16/3 of the fp32 MFMA rate), 0 = exact fp32 MFMA (bit-for-bit fmaf chains).
+// Process-wide setting: ag2v_set_conv_precision(), or the environment variable AG2V_CONV_PRECISION=fp32|bf16x3 read once.
+static int g_conv_precision = -1;
 static int conv_precision() {
-    static const int v = [] { const char* e = getenv("AG2V_CONV_PRECISION"); return (e && !strcmp(e, "bf16x3")) ? 1 : 0; }();
-    return v;
+    if (g_conv_precision < 0) {
+        const char* e = getenv("AG2V_CONV_PRECISION");
+        g_conv_precision = (e && !strcmp(e, "fp32")) ? 0 : 1;
+    }
+    return g_conv_precision;
 }
+extern "C" int ag2v_set_conv_precision(int mode) {
+    if (mode != 0 && mode != 1) return AG2V_EINVAL;
+    g_conv_precision = mode;
+    return AG2V_OK;
+}
+extern "C" int ag2v_get_conv_precision(void) { return conv_precision(); }
 static bool use_bf16x3(int M) { return conv_precision() == 1 && M > 64; }
 
 static int launch_igemm(ConvArgs& a, hipStream_t st, bool out_zeroed = false) {

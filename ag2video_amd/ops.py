@@ -33,6 +33,19 @@ def _c(t):
     return None if t is None else t.contiguous()
 
 
+_PRECISIONS = {'fp32': 0, 'bf16x3': 1}
+
+
+def set_conv_precision(name):
+    """'bf16x3' (default): conv GEMMs with >64 output channels multiply 3-term bf16 splits on the bf16 MFMA pipe with fp32
+    accumulation (fp32-level accuracy, ~1.6-2x the exact path); 'fp32': exact fp32 MFMA everywhere."""
+    _lib.call('ag2v_set_conv_precision', _PRECISIONS[name])
+
+
+def get_conv_precision():
+    return {v: k for k, v in _PRECISIONS.items()}[_lib.query('ag2v_get_conv_precision')]
+
+
 # ---- optional per-launch timing of the convolution kernels (bench.py's roofline leg): HIP events on the launch stream
 _TIMING = None
 
@@ -44,7 +57,9 @@ def enable_kernel_timing(flag=True):
 
 
 def _conv_label(mode, M):
-    return "conv_%s_bm%d" % (mode, 32 if M <= 32 else (64 if M <= 64 else 128))
+    bm = 32 if M <= 32 else (64 if M <= 64 else 128)
+    prec = get_conv_precision() if bm == 128 else 'fp32'
+    return "conv_%s_bm%d_%s" % (mode, bm, prec)
 
 
 def _launch(name, label, flops, *args, shape=None):

@@ -30,6 +30,7 @@ CONFIGS = {
     'toy': (64, 3, 2, ['--ngf', '8', '--ndf', '8', '--nff', '8', '--gconv_hidden_dim', '64']),
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # same guide: dense bf16 MFMA peak; the bf16x3 path issues 3 MFMAs per product => /3
 PEAK_HBM_GBS = 8000.0              # same guide: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
@@ -92,6 +93,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-only', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--precision', default='bf16x3', choices=['bf16x3', 'fp32'],
+                    help='arithmetic of the 128-row conv MFMA tiles (both hold the 1e-3 parity bound; tests/test_step_gpu.py)')
+    ap.add_argument('--no-fp32-leg', action='store_true', help='skip the extra exact-fp32 step used for roofline_exact_fp32')
     args = ap.parse_args()
     if args.cpu_baseline_only:
         cpu_baseline_child()
@@ -108,6 +112,7 @@ def main():
     device = torch.device('cuda', local)
     opt, side, frames, batch = make_opt(args.config)
     opt.gpu_ids = [local]
+    ops.set_conv_precision(args.precision)
     ts = TrainStep(opt, device, weights_seed=0)
     clip = ts.to_device(make_clip_batch(opt.vocab, batch, frames, (side, side), seed=1234 + rank))
     torch.cuda.synchronize()
@@ -144,12 +149,47 @@ def main():
     torch.cuda.synchronize()
     graph_ms = (time.time() - tg) * 1e3
 
+    fp32_leg = None
+    if args.precision == 'bf16x3' and not args.no_fp32_leg and not args.no_kernel_timing and world == 1:
+        ops.set_conv_precision('fp32')
+        ts.gd_step(clip)                       # warm-up in the exact mode
+        torch.cuda.synchronize()
+        ops.enable_kernel_timing(True)
+        t1 = time.time()
+        ts.gd_step(clip)
+        torch.cuda.synchronize()
+        fp32_leg = {'ms': (time.time() - t1) * 1e3, 'timing': ops.kernel_timing_summary()}
+        ops.enable_kernel_timing(False)
+        ops.set_conv_precision(args.precision)
+
     if rank != 0:
         D.shutdown()
         return
     ms_per_step = dt / args.steps * 1e3
     value = world * batch * frames * args.steps / dt
-    roof = None
+    def conv_roofline(tm, wall_ms):
+        """Roofline block of the dominant conv kernel of a timing summary (work slot = dense-conv algorithmic FLOPs)."""
+        tm = {k: v for k, v in tm.items() if k.startswith('conv_')}
+        if not tm:
+            return None
+        dom = max(tm, key=lambda k: tm[k]['ms'])
+        t = tm[dom]
+        split = dom.endswith('bf16x3')
+        peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if split else PEAK_FP32_MFMA_TFLOPS
+        achieved = t['flops'] / (t['ms'] * 1e-3) / 1e12
+        conv_ms = sum(v['ms'] for v in tm.values())
+        conv_fl = sum(v['flops'] for v in tm.values())
+        return {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": None,
+                "peak_basis": ("bf16 dense MFMA 2500 TF / 3 MFMAs per fp32-equivalent product" if split
+                               else "v_mfma_f32_32x32x2_f32 dense peak"),
+                "launches": t['launches'], "avg_launch_ms": round(t['ms'] / t['launches'], 4),
+                "flops_per_launch": t['flops'] / t['launches'],
+                "all_conv_kernels": {"achieved": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
+                                     "share_of_step_time": round(conv_ms / wall_ms, 4),
+                                     "by_kernel": {k: {"ms": round(v['ms'], 2), "tflops": round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2),
+                                                       "launches": v['launches']} for k, v in sorted(tm.items())}}}
+
     roof_hbm = None
     if 'spade_norm_apply' in timing:
         t = timing.pop('spade_norm_apply')
@@ -158,20 +198,13 @@ def main():
                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "launches": t['launches'],
                     "avg_launch_ms": round(t['ms'] / t['launches'], 4),
                     "traffic": "rocprofv3 PMC (profiles/r01/pmc): FETCH_SIZE*2 + WRITE_SIZE = 3x + 1x tensor bytes = algorithmic"}
-    if timing:
-        dom = max(timing, key=lambda k: timing[k]['ms'])
-        t = timing[dom]
-        achieved = t['flops'] / (t['ms'] * 1e-3) / 1e12
-        conv_ms = sum(v['ms'] for v in timing.values())
-        conv_fl = sum(v['flops'] for v in timing.values())
-        roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                "launches": t['launches'], "avg_launch_ms": round(t['ms'] / t['launches'], 4),
-                "flops_per_launch": t['flops'] / t['launches'],
-                "all_conv_kernels": {"achieved": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
-                                     "share_of_step_time": round(conv_ms / (dt * 1e3), 4),
-                                     "by_kernel": {k: {"ms": round(v['ms'], 2), "tflops": round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2),
-                                                       "launches": v['launches']} for k, v in sorted(timing.items())}}}
+    roof = conv_roofline(timing, dt * 1e3) if timing else None
+    roof_fp32 = None
+    if fp32_leg is not None:
+        roof_fp32 = conv_roofline(fp32_leg['timing'], fp32_leg['ms'])
+        if roof_fp32 is not None:
+            roof_fp32["ms_per_step"] = round(fp32_leg['ms'], 2)
+            roof_fp32["note"] = "one extra step with --precision fp32 (exact fp32 MFMA everywhere); not part of `value`"
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
@@ -179,10 +212,11 @@ def main():
         "metric": "frames/sec/node (gen+disc fwd+bwd), CATER %dx%dx%df" % (side, side, frames),
         "value": round(value, 3), "unit": "frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic CATER-shaped clips (seeded), closed-form random-init weights",
+        "dtype": ("f32 (conv products as 3-term bf16 splits on the bf16 MFMA pipe, fp32 accumulate; everything else fp32)"
+                  if args.precision == 'bf16x3' else "f32"), "data": "synthetic CATER-shaped clips (seeded), closed-form random-init weights",
         "config": {"workload": "%s: CATER %dx%d, %d frames, batch %d per GPU, full G+D train step, VGG loss off"
                    % (args.config, side, side, frames, batch), "global_batch": world * batch, "parallelism": "dp%d" % world},
-        "roofline": roof, "roofline_hbm": roof_hbm, "cpu_baseline": cpu,
+        "roofline": roof, "roofline_exact_fp32": roof_fp32, "roofline_hbm": roof_hbm, "cpu_baseline": cpu,
         "extra": {"graph_step_ms": round(graph_ms, 2), "losses_finite": finite,
                   "generated_frames_per_sec": round(world * batch * (frames - 1) * args.steps / dt, 3),
                   "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)},

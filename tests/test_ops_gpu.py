@@ -71,8 +71,18 @@ CONV_CASES = [
 ]
 
 
+@pytest.fixture(params=['fp32', 'bf16x3'])
+def precision(request):
+    """Both arithmetic modes of the 128-row conv tiles are held to the same bound (2e-4 of max|ref|)."""
+    from ag2video_amd import ops
+    old = ops.get_conv_precision()
+    ops.set_conv_precision(request.param)
+    yield request.param
+    ops.set_conv_precision(old)
+
+
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
-def test_conv2d(case, device):
+def test_conv2d(case, precision, device):
     from ag2video_amd import ops
     from oracle import kernels as K
     N, C, H, W, Ko, R, S, st, pad, bias, res = case

@@ -30,9 +30,13 @@ def _stats(t):
     return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().sqrt().item()])
 
 
-def test_train_step_matches_reference_golden(device):
+@pytest.mark.parametrize("prec", ['bf16x3', 'fp32'])
+def test_train_step_matches_reference_golden(prec, device):
+    """Both conv arithmetic modes (default bf16x3 split products; exact fp32 MFMA) against the reference golden vectors."""
+    from ag2video_amd import ops
     from ag2video_amd.data.synthetic import make_clip_batch
     from ag2video_amd.engine import TrainStep
+    ops.set_conv_precision(prec)
     gold, opt, toy = _setup()
     opt.gpu_ids = [0]
     ts = TrainStep(opt, device, weights_seed=toy['wseed'])
@@ -91,7 +95,8 @@ def test_train_step_matches_reference_golden(device):
               'layout_to_video.module.netG.head_0.conv_1.weight_v'):
         got, ref = _stats(sd[k]), gold['it1.G_state.' + k]
         assert np.allclose(got[1:], ref[1:], rtol=3e-2, atol=1e-6), (k, got, ref)
-    print('worst output errors (relative to max):', worst)
+    print('worst output errors (relative to max) [%s]:' % prec, worst)
+    ops.set_conv_precision('bf16x3')
 
 
 @pytest.mark.parametrize("cfg", [dict(side=64, frames=4, batch=3, flags=['--ngf', '16', '--ndf', '8', '--nff', '8',
