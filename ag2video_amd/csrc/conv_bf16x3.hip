@@ -1,0 +1,606 @@
+// Convolution on the bf16 matrix pipe with fp32-level accuracy ("bf16x3"), gfx950.
+//
+// Every fp32 operand is split as x = hi + lo (+O(2^-18|x|)), hi = bf16(x), lo = bf16(x - hi); a product is evaluated as
+// a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16 (exact 16-bit products, fp32 accumulation).  The dropped
+// a_lo*b_lo term and the split residuals are <= ~1e-5 relative -- two orders inside the 1e-3 parity bound of the step and
+// inside the 2e-4 bound of the kernel tests (tests/test_ops_gpu.py runs every conv case in both arithmetic modes) -- while the
+// bf16 pipe runs 16x the fp32 MFMA rate, i.e. 16/3 of it per fp32-equivalent product.
+//
+// Structure (both kernels): 512 threads = 8 waves, each wave a 64x64 sub-tile (2x2 MFMA tiles); block tile 256x128 or
+// 128x256, K-tile 32 (two MFMA k-steps => 24 MFMAs per wave between barriers); LDS holds the hi and lo images of both
+// operands as k-contiguous rows of 32 bf16 (+8 pad = 80 B: ds_read_b128 / ds_write_b128 conflict-free), double-buffered;
+// global loads run two K-tiles ahead through two register sets.  Per iteration (ONE barrier):
+//     load tile t+2 -> regs[t&1]   |   24 MFMAs on LDS[t&1]   |   split+pack regs[(t+1)&1] -> LDS[(t+1)&1]   |   barrier
+// The weight operand of the forward/dgrad kernel arrives pre-split (packed hi:lo words, k-major) from the prep kernels, so
+// its in-kernel cost is two v_perm per pair; activations are split in-kernel (v_cvt_pk_bf16_f32).
+#include "conv_common.h"
+
+#define NT 512
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(NT, 2) void conv_igemm_bf16x3_kernel(ConvArgs p) {
+    constexpr int BK = 32, LDK = 40;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int AP = NT / BM, AK = BK / AP;   // A: thread = (m column, k part): AK consecutive k
+    constexpr int BP = NT / BN, BKK = BK / BP;  // B: thread = (pixel column, k part): BKK consecutive k
+    static_assert(WM * WN == 8 && TM == 2 && TN == 2, "8 waves of 64x64");
+    static_assert(AK % 8 == 0 && BKK % 8 == 0, "16-byte LDS stores");
+    __shared__ __attribute__((aligned(16))) unsigned short Ahi[2][BM * LDK];
+    __shared__ __attribute__((aligned(16))) unsigned short Alo[2][BM * LDK];
+    __shared__ __attribute__((aligned(16))) unsigned short Bhi[2][BN * LDK];
+    __shared__ __attribute__((aligned(16))) unsigned short Blo[2][BN * LDK];
+    __shared__ int2 tab[4][BK];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lid = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int tile_m = lid % p.tiles_m, tile_n = lid / p.tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int wm0 = (wave / WN) * 64, wn0 = (wave % WN) * 64;
+    const int RS = p.R * p.S;
+    const int SHW = p.H * p.W;
+
+    // ---- B gather state
+    const int bcol = tid % BN, bpart = tid / BN;
+    const int pix = n0 + bcol;
+    const bool pvalid = pix < p.NG;
+    const int n_img = pix / (p.OH * p.OW);
+    const int prem = pix - n_img * (p.OH * p.OW);
+    const int py = prem / p.OW, px = prem - py * p.OW;
+    const int y0 = py * p.stride - p.pad, x0 = px * p.stride - p.pad_w;
+    unsigned vmask = 0;
+    if (pvalid) {
+        for (int r = 0; r < p.R; ++r)
+            for (int s2 = 0; s2 < p.S; ++s2)
+                if ((unsigned)(y0 + r) < (unsigned)p.H && (unsigned)(x0 + s2) < (unsigned)p.W) vmask |= 1u << (r * p.S + s2);
+    }
+    const float* bptr = p.b_src + (size_t)n_img * p.C * SHW + (y0 * p.W + x0);
+    // ---- A load state (pre-split packed weights, k-major)
+    const int acol = tid % BM, apart = tid / BM;
+    const bool mvalid = (m0 + acol) < p.M;
+    const unsigned* aptr = reinterpret_cast<const unsigned*>(p.a_src) + m0 + acol;
+
+    auto build_tab = [&](int kt) {
+        if (tid < BK) {
+            const int kg = kt * BK + tid;
+            int c, r, s2;
+            decode_crs(kg, RS, p.S, c, r, s2);
+            const unsigned bit = (kg < p.KG) ? (1u << (r * p.S + s2)) : 0u;
+            tab[kt & 3][tid] = make_int2(c * SHW + r * p.W + s2, (int)bit);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto fetch = [&](int kt, unsigned (&ra)[AK], float (&rb)[BKK]) {
+        const int ka = kt * BK + AK * apart;
+#pragma unroll
+        for (int i = 0; i < AK; ++i) ra[i] = (mvalid && (ka + i) < p.KG) ? aptr[(size_t)(ka + i) * p.M] : 0u;
+#pragma unroll
+        for (int i = 0; i < BKK; ++i) {
+            const int2 e = tab[kt & 3][BKK * bpart + i];
+            rb[i] = (vmask & (unsigned)e.y) ? bptr[e.x] : 0.f;
+        }
+    };
+    auto stash = [&](int buf, const unsigned (&ra)[AK], const float (&rb)[BKK]) {
+#pragma unroll
+        for (int g = 0; g < AK / 8; ++g) {
+            unsigned h[4], l[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                h[i] = __builtin_amdgcn_perm(ra[8 * g + 2 * i + 1], ra[8 * g + 2 * i], 0x07060302u);   // {hi(k odd), hi(k even)}
+                l[i] = __builtin_amdgcn_perm(ra[8 * g + 2 * i + 1], ra[8 * g + 2 * i], 0x05040100u);   // {lo(k odd), lo(k even)}
+            }
+            const int off = acol * LDK + AK * apart + 8 * g;   // bf16 elements; 16-byte aligned
+            *reinterpret_cast<uint4*>(&Ahi[buf][off]) = make_uint4(h[0], h[1], h[2], h[3]);
+            *reinterpret_cast<uint4*>(&Alo[buf][off]) = make_uint4(l[0], l[1], l[2], l[3]);
+        }
+#pragma unroll
+        for (int g = 0; g < BKK / 8; ++g) {
+            unsigned h[4], l[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) split2(rb[8 * g + 2 * i], rb[8 * g + 2 * i + 1], h[i], l[i]);
+            const int off = bcol * LDK + BKK * bpart + 8 * g;
+            *reinterpret_cast<uint4*>(&Bhi[buf][off]) = make_uint4(h[0], h[1], h[2], h[3]);
+            *reinterpret_cast<uint4*>(&Blo[buf][off]) = make_uint4(l[0], l[1], l[2], l[3]);
+        }
+    };
+    const int fr = lane & 31, fh = lane >> 5;
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 ahi[TM], alo[TM], bhi[TN], blo[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int o = (wm0 + i * 32 + fr) * LDK + ks * 16 + 8 * fh;
+                ahi[i] = *reinterpret_cast<const bf16x8*>(&Ahi[buf][o]);
+                alo[i] = *reinterpret_cast<const bf16x8*>(&Alo[buf][o]);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int o = (wn0 + j * 32 + fr) * LDK + ks * 16 + 8 * fh;
+                bhi[j] = *reinterpret_cast<const bf16x8*>(&Bhi[buf][o]);
+                blo[j] = *reinterpret_cast<const bf16x8*>(&Blo[buf][o]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[i], bhi[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], blo[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], bhi[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+
+    const int nk_all = (p.KG + BK - 1) / BK;
+    const int kt0 = (p.splitk > 1) ? blockIdx.y * p.kchunk : 0;
+    const int nk = (p.splitk > 1) ? min(nk_all, kt0 + p.kchunk) : nk_all;
+    if (kt0 >= nk) return;  // uniform per workgroup
+    unsigned ra0[AK], ra1[AK];
+    float rb0[BKK], rb1[BKK];
+    build_tab(kt0);
+    build_tab(kt0 + 1);
+    build_tab(kt0 + 2);
+    __syncthreads();
+    fetch(kt0, ra0, rb0);
+    stash(0, ra0, rb0);          // tile kt0 -> LDS buffer 0
+    fetch(kt0 + 1, ra1, rb1);    // tile kt0+1 -> register set 1 (rows past KG read as zero)
+    __syncthreads();
+    // relative iteration it: tile kt0+it sits in LDS buffer it&1, tile kt0+it+1 in register set (it+1)&1
+    for (int kt = kt0; kt < nk; kt += 2) {
+        fetch(kt + 2, ra0, rb0);
+        build_tab(kt + 3);       // slot (kt+3)&3 held tile kt-1's table, last read two iterations ago
+        compute(0);
+        stash(1, ra1, rb1);
+        __syncthreads();
+        if (kt + 1 >= nk) break;
+        fetch(kt + 3, ra1, rb1);
+        build_tab(kt + 4);
+        compute(1);
+        stash(0, ra0, rb0);
+        __syncthreads();
+    }
+
+    // ---- epilogue (C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5))
+    const int gplane = p.OH * p.OW;
+    const int plane = p.o_H * p.o_W;
+    const bool mapped = (p.o_mul != 1 || p.o_add_y != 0 || p.o_add_x != 0 || p.o_W != p.OW);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int opix = n0 + wn0 + j * 32 + (lane & 31);
+        if (opix >= p.NG) continue;
+        const int on = opix / gplane;
+        int orem = opix - on * gplane;
+        if (mapped) {
+            const int qy = orem / p.OW, qx = orem - qy * p.OW;
+            const int yy = qy * p.o_mul + p.o_add_y, xx = qx * p.o_mul + p.o_add_x;
+            if ((unsigned)yy >= (unsigned)p.o_H || (unsigned)xx >= (unsigned)p.o_W) continue;
+            orem = yy * p.o_W + xx;
+        }
+        float* obase = p.out + (size_t)on * p.M * plane + orem;
+        const float* rbase = p.residual ? p.residual + (size_t)on * p.M * plane + orem : nullptr;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < p.M) {
+                    float v = acc[i][j][r];
+                    if (kt0 == 0) {
+                        if (p.bias) v += p.bias[m];
+                        if (rbase) v += rbase[(size_t)m * plane];
+                    }
+                    if (p.splitk > 1)
+                        atomicAdd(obase + (size_t)m * plane, v);
+                    else
+                        obase[(size_t)m * plane] = v;
+                }
+            }
+        }
+    }
+}
+
+// Weight gradient: dW[m,j] = sum_q dY[m,q] * Xg[q,j], q = (n,oy,ox), j = (c,r,s).  Both operands are activations (split
+// in-kernel).  A thread owns one PAIR of consecutive pixels q for BM/32 rows of dY and BN/32 columns of the gather, so each
+// (hi | lo) pair is one packed ds_write_b32 into the k-contiguous LDS rows.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(NT, 2) void conv_wgrad_bf16x3_kernel(ConvArgs p) {
+    constexpr int BK = 32, LDK = 40;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int RA = BM / 32, RB = BN / 32;   // rows of dY / gather columns per thread
+    static_assert(WM * WN == 8 && TM == 2 && TN == 2, "8 waves of 64x64");
+    __shared__ __attribute__((aligned(16))) unsigned short Ahi[2][BM * LDK];
+    __shared__ __attribute__((aligned(16))) unsigned short Alo[2][BM * LDK];
+    __shared__ __attribute__((aligned(16))) unsigned short Bhi[2][BN * LDK];
+    __shared__ __attribute__((aligned(16))) unsigned short Blo[2][BN * LDK];
+    __shared__ int4 qtab[4][BK];   // per pixel q of a K-tile: {x offset of tap (0,0), dY offset, (yb<<16)|xb, valid}
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lid = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int tile_m = lid % p.tiles_m, tile_n = lid / p.tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int wm0 = (wave / WN) * 64, wn0 = (wave % WN) * 64;
+    const int RS = p.R * p.S;
+    const int OHW = p.OH * p.OW, HW = p.H * p.W;
+    const int Q = p.N * OHW;
+    const int qs = blockIdx.y * p.kchunk;
+    const int qe = min(qs + p.kchunk, Q);
+    if (qs >= qe) return;
+
+    const int qp = tid & 15, rg = tid >> 4;   // pixel pair (2qp, 2qp+1) of the K-tile; rows / columns rg + 32 i
+    int aoff[RA], boff[RB], bpk[RB];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int m = m0 + rg + 32 * i;
+        aoff[i] = (m < p.M) ? m * OHW : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int j = n0 + rg + 32 * i;
+        int c, r, s;
+        decode_crs(j, RS, p.S, c, r, s);
+        bpk[i] = ((r - p.pad + 64) & 255) | (((s - p.pad + 64) & 255) << 8) | ((j < p.NG) ? (1 << 16) : 0);
+        boff[i] = c * HW + (r - p.pad) * p.W + (s - p.pad);
+    }
+    auto build_tab = [&](int t) {   // t = tile index relative to qs
+        if (tid < BK) {
+            const int q = qs + t * BK + tid;
+            const bool v = q < qe;
+            const int qc = v ? q : qs;
+            const int n = qc / OHW;
+            const int pixl = qc - n * OHW;
+            const int oy = pixl / p.OW, ox = pixl - oy * p.OW;
+            const int yb = oy * p.stride, xb = ox * p.stride;
+            qtab[t & 3][tid] = make_int4(n * p.C * HW + yb * p.W + xb, n * p.K * OHW + pixl, (yb << 16) | xb, v ? 1 : 0);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto fetch = [&](int t, float (&ra)[2 * RA], float (&rb)[2 * RB]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int4 e = qtab[t & 3][2 * qp + h];
+            const int yb = e.z >> 16, xb = e.z & 0xFFFF;
+#pragma unroll
+            for (int i = 0; i < RA; ++i) ra[2 * i + h] = (e.w && aoff[i] >= 0) ? p.a_src[(size_t)e.y + aoff[i]] : 0.f;
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                const int iy = yb + (bpk[i] & 255) - 64, ix = xb + ((bpk[i] >> 8) & 255) - 64;
+                const bool ok = e.w && (bpk[i] >> 16) && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                rb[2 * i + h] = ok ? p.b_src[(size_t)e.x + boff[i]] : 0.f;
+            }
+        }
+    };
+    auto stash = [&](int buf, const float (&ra)[2 * RA], const float (&rb)[2 * RB]) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            unsigned hi, lo;
+            const int off = (rg + 32 * i) * LDK + 2 * qp;
+            split2(ra[2 * i], ra[2 * i + 1], hi, lo);
+            *reinterpret_cast<unsigned*>(&Ahi[buf][off]) = hi;
+            *reinterpret_cast<unsigned*>(&Alo[buf][off]) = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            unsigned hi, lo;
+            const int off = (rg + 32 * i) * LDK + 2 * qp;
+            split2(rb[2 * i], rb[2 * i + 1], hi, lo);
+            *reinterpret_cast<unsigned*>(&Bhi[buf][off]) = hi;
+            *reinterpret_cast<unsigned*>(&Blo[buf][off]) = lo;
+        }
+    };
+    const int fr = lane & 31, fh = lane >> 5;
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 ahi[TM], alo[TM], bhi[TN], blo[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int o = (wm0 + i * 32 + fr) * LDK + ks * 16 + 8 * fh;
+                ahi[i] = *reinterpret_cast<const bf16x8*>(&Ahi[buf][o]);
+                alo[i] = *reinterpret_cast<const bf16x8*>(&Alo[buf][o]);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int o = (wn0 + j * 32 + fr) * LDK + ks * 16 + 8 * fh;
+                bhi[j] = *reinterpret_cast<const bf16x8*>(&Bhi[buf][o]);
+                blo[j] = *reinterpret_cast<const bf16x8*>(&Blo[buf][o]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[i], bhi[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], blo[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], bhi[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+
+    const int nt = (qe - qs + BK - 1) / BK;
+    float ra0[2 * RA], ra1[2 * RA], rb0[2 * RB], rb1[2 * RB];
+    build_tab(0);
+    build_tab(1);
+    build_tab(2);
+    __syncthreads();
+    fetch(0, ra0, rb0);
+    stash(0, ra0, rb0);
+    fetch(1, ra1, rb1);
+    __syncthreads();
+    for (int t = 0; t < nt; t += 2) {
+        fetch(t + 2, ra0, rb0);
+        build_tab(t + 3);
+        compute(0);
+        stash(1, ra1, rb1);
+        __syncthreads();
+        if (t + 1 >= nt) break;
+        fetch(t + 3, ra1, rb1);
+        build_tab(t + 4);
+        compute(1);
+        stash(0, ra0, rb0);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int colj = n0 + wn0 + j * 32 + (lane & 31);
+        if (colj >= p.NG) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < p.M) {
+                    float* dst = p.out + (size_t)m * p.NG + colj;
+                    if (p.splitk > 1)
+                        atomicAdd(dst, acc[i][j][r]);
+                    else
+                        *dst = acc[i][j][r];
+                }
+            }
+        }
+    }
+}
+
+// 4-wave 128x128 variant (K-tile 16) for layers with <= 128 output channels (a 256-row tile would be half empty):
+// Weight gradient on the bf16x3 path: dW[m,j] = sum_q dY[m,q] * Xg[q,j], q = (n,oy,ox), j = (c,r,s).  Both operands are
+// activations (split in-kernel).  A thread owns one PAIR of consecutive pixels q for 4 rows of dY and 4 columns of the
+// gather, so each (hi | lo) pair is one packed ds_write_b32 into the k-contiguous LDS rows the MFMA fragments read.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16x3_4w_kernel(ConvArgs p) {
+    constexpr int BK = 16, LDK = 24;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    static_assert(BM == 128 && BN == 128, "thread mapping assumes a 128x128 tile");
+    __shared__ __attribute__((aligned(16))) unsigned short Ahi[2][BM * LDK];
+    __shared__ __attribute__((aligned(16))) unsigned short Alo[2][BM * LDK];
+    __shared__ __attribute__((aligned(16))) unsigned short Bhi[2][BN * LDK];
+    __shared__ __attribute__((aligned(16))) unsigned short Blo[2][BN * LDK];
+    __shared__ int4 qtab[4][BK];   // per pixel q of a K-tile: {x offset of tap (0,0), dY offset, (yb<<16)|xb, valid}
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lid = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int tile_m = lid % p.tiles_m, tile_n = lid / p.tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int wm0 = (wave / WN) * (TM * 32), wn0 = (wave % WN) * (TN * 32);
+    const int RS = p.R * p.S;
+    const int OHW = p.OH * p.OW, HW = p.H * p.W;
+    const int Q = p.N * OHW;
+    const int qs = blockIdx.y * p.kchunk;
+    const int qe = min(qs + p.kchunk, Q);
+    if (qs >= qe) return;
+
+    const int qp = tid & 7, rg = tid >> 3;   // pixel pair (2qp, 2qp+1) of the K-tile; rows / columns rg + 32 i
+    int boff[4], bpk[4], aoff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = n0 + rg + 32 * i;
+        int c, r, s;
+        decode_crs(j, RS, p.S, c, r, s);
+        bpk[i] = ((r - p.pad + 64) & 255) | (((s - p.pad + 64) & 255) << 8) | ((j < p.NG) ? (1 << 16) : 0);
+        boff[i] = c * HW + (r - p.pad) * p.W + (s - p.pad);
+        const int m = m0 + rg + 32 * i;
+        aoff[i] = (m < p.M) ? m * OHW : -1;
+    }
+    auto build_tab = [&](int t) {   // t = tile index relative to qs
+        if (tid < BK) {
+            const int q = qs + t * BK + tid;
+            const bool v = q < qe;
+            const int qc = v ? q : qs;
+            const int n = qc / OHW;
+            const int pixl = qc - n * OHW;
+            const int oy = pixl / p.OW, ox = pixl - oy * p.OW;
+            const int yb = oy * p.stride, xb = ox * p.stride;
+            qtab[t & 3][tid] = make_int4(n * p.C * HW + yb * p.W + xb, n * p.K * OHW + pixl, (yb << 16) | xb, v ? 1 : 0);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto fetch = [&](int t, float (&ra)[8], float (&rb)[8]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int4 e = qtab[t & 3][2 * qp + h];
+            const int yb = e.z >> 16, xb = e.z & 0xFFFF;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ra[2 * i + h] = (e.w && aoff[i] >= 0) ? p.a_src[(size_t)e.y + aoff[i]] : 0.f;
+                const int iy = yb + (bpk[i] & 255) - 64, ix = xb + ((bpk[i] >> 8) & 255) - 64;
+                const bool ok = e.w && (bpk[i] >> 16) && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                rb[2 * i + h] = ok ? p.b_src[(size_t)e.x + boff[i]] : 0.f;
+            }
+        }
+    };
+    auto stash = [&](int buf, const float (&ra)[8], const float (&rb)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned hi, lo;
+            const int off = (rg + 32 * i) * LDK + 2 * qp;
+            split2(ra[2 * i], ra[2 * i + 1], hi, lo);
+            *reinterpret_cast<unsigned*>(&Ahi[buf][off]) = hi;
+            *reinterpret_cast<unsigned*>(&Alo[buf][off]) = lo;
+            split2(rb[2 * i], rb[2 * i + 1], hi, lo);
+            *reinterpret_cast<unsigned*>(&Bhi[buf][off]) = hi;
+            *reinterpret_cast<unsigned*>(&Blo[buf][off]) = lo;
+        }
+    };
+    const int fr = lane & 31, fh = lane >> 5;
+    auto compute = [&](int buf) {
+        bf16x8 ahi[TM], alo[TM], bhi[TN], blo[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int o = (wm0 + i * 32 + fr) * LDK + 8 * fh;
+            ahi[i] = *reinterpret_cast<const bf16x8*>(&Ahi[buf][o]);
+            alo[i] = *reinterpret_cast<const bf16x8*>(&Alo[buf][o]);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int o = (wn0 + j * 32 + fr) * LDK + 8 * fh;
+            bhi[j] = *reinterpret_cast<const bf16x8*>(&Bhi[buf][o]);
+            blo[j] = *reinterpret_cast<const bf16x8*>(&Blo[buf][o]);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[i], bhi[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], blo[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], bhi[j], acc[i][j], 0, 0, 0);
+            }
+    };
+
+    const int nt = (qe - qs + BK - 1) / BK;
+    float ra0[8], ra1[8], rb0[8], rb1[8];
+    build_tab(0);
+    build_tab(1);
+    build_tab(2);
+    __syncthreads();
+    fetch(0, ra0, rb0);
+    stash(0, ra0, rb0);
+    fetch(1, ra1, rb1);
+    __syncthreads();
+    for (int t = 0; t < nt; t += 2) {
+        fetch(t + 2, ra0, rb0);
+        build_tab(t + 3);
+        compute(0);
+        stash(1, ra1, rb1);
+        __syncthreads();
+        if (t + 1 >= nt) break;
+        fetch(t + 3, ra1, rb1);
+        build_tab(t + 4);
+        compute(1);
+        stash(0, ra0, rb0);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int colj = n0 + wn0 + j * 32 + (lane & 31);
+        if (colj >= p.NG) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < p.M) {
+                    float* dst = p.out + (size_t)m * p.NG + colj;
+                    if (p.splitk > 1)
+                        atomicAdd(dst, acc[i][j][r]);
+                    else
+                        *dst = acc[i][j][r];
+                }
+            }
+        }
+    }
+}
+
+// ================================================================ launchers
+int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed) {
+    const bool tall = a.M >= 192;                 // 256 x 128 tile when there are enough output channels, else 128 x 256
+    const int bm = tall ? 256 : 128, bn = tall ? 128 : 256;
+    a.tiles_m = ceil_div(a.M, bm);
+    a.tiles_n = ceil_div(a.NG, bn);
+    const int tiles = a.tiles_m * a.tiles_n, nk = ceil_div(a.KG, 32);
+    a.splitk = 1; a.kchunk = nk;
+    if (tiles < 256 && nk >= 8) {                 // one 8-wave workgroup per CU: fill the chip through split-K
+        int sk = ceil_div(512, tiles);
+        if (sk > nk / 4) sk = nk / 4;
+        if (sk > 1) {
+            a.kchunk = ceil_div(nk, sk);
+            a.splitk = ceil_div(nk, a.kchunk);
+        }
+    }
+    if (a.splitk > 1 && !out_zeroed) {
+        if (hipMemsetAsync(a.out, 0, (size_t)a.N * a.M * a.o_H * a.o_W * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
+    }
+    dim3 grid(tiles, a.splitk);
+    if (tall)
+        hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<256, 128, 4, 2>), grid, dim3(NT), 0, st, a);
+    else
+        hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<128, 256, 2, 4>), grid, dim3(NT), 0, st, a);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+
+int launch_wgrad_bf16x3(ConvArgs& a, hipStream_t st) {
+    if (a.M < 192) {   // <= 128 output channels: 4-wave 128x128 tiles, up to 2 workgroups per SIMD
+        a.tiles_m = ceil_div(a.M, 128);
+        a.tiles_n = ceil_div(a.NG, 128);
+        const int tiles = a.tiles_m * a.tiles_n;
+        const long long Q = a.KG;
+        int splitk = ceil_div(1536, tiles);
+        const int max_split = (int)((Q + 511) / 512);
+        if (splitk > max_split) splitk = max_split;
+        if (splitk < 1) splitk = 1;
+        int kchunk = (int)((Q + splitk - 1) / splitk);
+        kchunk = ((kchunk + 15) / 16) * 16;
+        splitk = (int)((Q + kchunk - 1) / kchunk);
+        a.splitk = splitk; a.kchunk = kchunk;
+        if (splitk > 1 && hipMemsetAsync(a.out, 0, (size_t)a.M * a.NG * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
+        hipLaunchKernelGGL((conv_wgrad_bf16x3_4w_kernel<128, 128, 2, 2>), dim3(tiles, splitk), dim3(256), 0, st, a);
+        AG2V_CHECK_LAUNCH();
+        return AG2V_OK;
+    }
+    const bool tall = true;
+    const int bm = tall ? 256 : 128, bn = tall ? 128 : 256;
+    a.tiles_m = ceil_div(a.M, bm);
+    a.tiles_n = ceil_div(a.NG, bn);
+    const int tiles = a.tiles_m * a.tiles_n;
+    const long long Q = a.KG;
+    int splitk = ceil_div(768, tiles);            // ~3 workgroups of 8 waves per CU in flight
+    const int max_split = (int)((Q + 1023) / 1024);
+    if (splitk > max_split) splitk = max_split;
+    if (splitk < 1) splitk = 1;
+    int kchunk = (int)((Q + splitk - 1) / splitk);
+    kchunk = ((kchunk + 31) / 32) * 32;
+    splitk = (int)((Q + kchunk - 1) / kchunk);
+    a.splitk = splitk; a.kchunk = kchunk;
+    if (splitk > 1) {
+        if (hipMemsetAsync(a.out, 0, (size_t)a.M * a.NG * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
+    }
+    dim3 grid(tiles, splitk);
+    if (tall)
+        hipLaunchKernelGGL((conv_wgrad_bf16x3_kernel<256, 128, 4, 2>), grid, dim3(NT), 0, st, a);
+    else
+        hipLaunchKernelGGL((conv_wgrad_bf16x3_kernel<128, 256, 2, 4>), grid, dim3(NT), 0, st, a);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}

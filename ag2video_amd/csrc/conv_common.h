@@ -1,0 +1,66 @@
+// Shared declarations of the convolution kernels (conv_igemm.hip: exact fp32 MFMA; conv_bf16x3.hip: split bf16 MFMA).
+#pragma once
+#include "common.h"
+
+struct ConvArgs {
+    const float* a_src;     // igemm: At [KG][M] (k-major weights) | wgrad: dy
+    const float* b_src;     // gathered tensor [N, C, H, W]
+    float* out;
+    const float* bias;      // [M] or null (igemm)
+    const float* residual;  // same shape as out, or null (igemm)
+    int N, C, H, W;         // gathered tensor
+    int K, R, S, OH, OW;    // output channels / filter / GEMM pixel space (igemm);  filters / dy image (wgrad)
+    int stride, pad;        // pad = padding along y
+    int pad_w;              // padding along x (differs from pad only for the parity sub-filters of a strided dgrad)
+    int o_mul, o_add_y, o_add_x, o_H, o_W;  // output placement: (oy,ox) -> (oy*o_mul+o_add_y, ox*o_mul+o_add_x) in [o_H,o_W]
+    int M, NG, KG;          // GEMM dims
+    int tiles_m, tiles_n;
+    int splitk, kchunk;     // igemm: K-range splits (grid.y) in K-tiles; wgrad: pixel-range splits, pixels per split
+};
+
+// Division by the filter footprint: the shapes on the path get constant divisors.
+__device__ __forceinline__ int div_small(int v, int d) {
+    if (d == 9) return v / 9;
+    if (d == 16) return v >> 4;
+    if (d == 1) return v;
+    if (d == 3) return v / 3;
+    if (d == 4) return v >> 2;
+    if (d == 2) return v >> 1;
+    return v / d;
+}
+__device__ __forceinline__ void decode_crs(int kg, int RS, int S, int& c, int& r, int& s) {
+    c = div_small(kg, RS);
+    const int rs = kg - c * RS;
+    r = div_small(rs, S);
+    s = rs - r * S;
+}
+
+
+// ---------------------------------------------------------------- bf16x3 split-precision helpers
+// x = hi + lo + O(2^-18 |x|) with hi = bf16(x), lo = bf16(x - hi);  a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi (the dropped
+// a_lo*b_lo term is <= 2^-18 |a b|), i.e. three bf16 MFMAs (exact 16-bit products, fp32 accumulation) reproduce an fp32
+// product to ~1e-5 relative -- two orders inside the 1e-3 parity bound -- at 16/3 of the fp32 MFMA rate.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+    const f32x2 v = {x0, x1};
+    const bf16x2 h = __builtin_convertvector(v, bf16x2);
+    const f32x2 hf = __builtin_convertvector(h, f32x2);
+    const bf16x2 l = __builtin_convertvector(v - hf, bf16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+// one fp32 -> packed word (hi bf16 in the upper half, lo bf16 in the lower half); used for the pre-split weight operand
+__device__ __forceinline__ float pack_split(float x) {
+    const __bf16 h = (__bf16)x;
+    const __bf16 l = (__bf16)(x - (float)h);
+    const unsigned w = ((unsigned)__builtin_bit_cast(unsigned short, h) << 16) | (unsigned)__builtin_bit_cast(unsigned short, l);
+    return __uint_as_float(w);
+}
+
+
+// launchers implemented in conv_bf16x3.hip
+int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed);
+int launch_wgrad_bf16x3(ConvArgs& a, hipStream_t st);

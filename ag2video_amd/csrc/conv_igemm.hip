@@ -17,42 +17,9 @@
 // Both operands reach LDS through fully coalesced loads (lanes along m for the k-major weights, lanes along the pixel index
 // for the activation gather), are staged as [k][m] / [k][n] so every MFMA operand read is a conflict-free ds_read_b32, and
 // the next K-tile's global loads are in flight while the current tile's 32 MFMAs per wave issue.
-#include "common.h"
+#include "conv_common.h"
 #include <stdlib.h>
 #include <string.h>
-
-struct ConvArgs {
-    const float* a_src;     // igemm: At [KG][M] (k-major weights) | wgrad: dy
-    const float* b_src;     // gathered tensor [N, C, H, W]
-    float* out;
-    const float* bias;      // [M] or null (igemm)
-    const float* residual;  // same shape as out, or null (igemm)
-    int N, C, H, W;         // gathered tensor
-    int K, R, S, OH, OW;    // output channels / filter / GEMM pixel space (igemm);  filters / dy image (wgrad)
-    int stride, pad;        // pad = padding along y
-    int pad_w;              // padding along x (differs from pad only for the parity sub-filters of a strided dgrad)
-    int o_mul, o_add_y, o_add_x, o_H, o_W;  // output placement: (oy,ox) -> (oy*o_mul+o_add_y, ox*o_mul+o_add_x) in [o_H,o_W]
-    int M, NG, KG;          // GEMM dims
-    int tiles_m, tiles_n;
-    int splitk, kchunk;     // igemm: K-range splits (grid.y) in K-tiles; wgrad: pixel-range splits, pixels per split
-};
-
-// Division by the filter footprint: the shapes on the path get constant divisors.
-__device__ __forceinline__ int div_small(int v, int d) {
-    if (d == 9) return v / 9;
-    if (d == 16) return v >> 4;
-    if (d == 1) return v;
-    if (d == 3) return v / 3;
-    if (d == 4) return v >> 2;
-    if (d == 2) return v >> 1;
-    return v / d;
-}
-__device__ __forceinline__ void decode_crs(int kg, int RS, int S, int& c, int& r, int& s) {
-    c = div_small(kg, RS);
-    const int rs = kg - c * RS;
-    r = div_small(rs, S);
-    s = rs - r * S;
-}
 
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256, 4) void conv_igemm_kernel(ConvArgs p) {
@@ -332,364 +299,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvArgs p) {
     }
 }
 
-// ---------------------------------------------------------------- bf16x3 split-precision path
-// x = hi + lo + O(2^-18 |x|) with hi = bf16(x), lo = bf16(x - hi);  a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi (the dropped
-// a_lo*b_lo term is <= 2^-18 |a b|), i.e. three bf16 MFMAs (exact 16-bit products, fp32 accumulation) reproduce an fp32
-// product to ~1e-5 relative -- two orders inside the 1e-3 parity bound -- at 16/3 of the fp32 MFMA rate.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo) {
-    const f32x2 v = {x0, x1};
-    const bf16x2 h = __builtin_convertvector(v, bf16x2);
-    const f32x2 hf = __builtin_convertvector(h, f32x2);
-    const bf16x2 l = __builtin_convertvector(v - hf, bf16x2);
-    hi = __builtin_bit_cast(unsigned, h);
-    lo = __builtin_bit_cast(unsigned, l);
-}
-// one fp32 -> packed word (hi bf16 in the upper half, lo bf16 in the lower half); used for the pre-split weight operand
-__device__ __forceinline__ float pack_split(float x) {
-    const __bf16 h = (__bf16)x;
-    const __bf16 l = (__bf16)(x - (float)h);
-    const unsigned w = ((unsigned)__builtin_bit_cast(unsigned short, h) << 16) | (unsigned)__builtin_bit_cast(unsigned short, l);
-    return __uint_as_float(w);
-}
-
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256, 3) void conv_igemm_bf16x3_kernel(ConvArgs p) {
-    // K-tile = 16 (one MFMA k-step).  Pipeline per iteration kt (ONE barrier):
-    //   issue the global loads of tile kt+2 into register set (kt&1)  |  12 MFMAs per wave on LDS buffer (kt&1)
-    //   | split/pack tile kt+1 (register set (kt+1)&1, loaded one iteration ago) into LDS buffer (kt+1)&1 | barrier
-    // so every load has a whole iteration of other waves' MFMAs to land, and no wave waits for the others before staging.
-    constexpr int BK = 16, LDK = 24;  // LDS rows: 16 bf16 of one m / n + 8 pad = 48 B (conflict-free ds_read/write_b128)
-    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    static_assert(BM == 128 && BN == 128, "thread mapping assumes a 128x128 tile");
-    __shared__ __attribute__((aligned(16))) unsigned short Ahi[2][BM * LDK];
-    __shared__ __attribute__((aligned(16))) unsigned short Alo[2][BM * LDK];
-    __shared__ __attribute__((aligned(16))) unsigned short Bhi[2][BN * LDK];
-    __shared__ __attribute__((aligned(16))) unsigned short Blo[2][BN * LDK];
-    __shared__ int2 tab[4][BK];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lid = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-    const int tile_m = lid % p.tiles_m, tile_n = lid / p.tiles_m;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int wm0 = (wave / WN) * (TM * 32), wn0 = (wave % WN) * (TN * 32);
-    const int RS = p.R * p.S;
-    const int SHW = p.H * p.W;
-
-    // thread -> (column of the tile, half of the K-tile): 8 consecutive k of one m (A) and of one pixel (B)
-    const int col = tid & 127, khalf = tid >> 7;
-    const int pix = n0 + col;
-    const bool pvalid = pix < p.NG;
-    const int n_img = pix / (p.OH * p.OW);
-    const int prem = pix - n_img * (p.OH * p.OW);
-    const int py = prem / p.OW, px = prem - py * p.OW;
-    const int y0 = py * p.stride - p.pad, x0 = px * p.stride - p.pad_w;
-    unsigned vmask = 0;
-    if (pvalid) {
-        for (int r = 0; r < p.R; ++r)
-            for (int s2 = 0; s2 < p.S; ++s2)
-                if ((unsigned)(y0 + r) < (unsigned)p.H && (unsigned)(x0 + s2) < (unsigned)p.W) vmask |= 1u << (r * p.S + s2);
-    }
-    const float* bptr = p.b_src + (size_t)n_img * p.C * SHW + (y0 * p.W + x0);
-    const bool mvalid = (m0 + col) < p.M;
-    const unsigned* aptr = reinterpret_cast<const unsigned*>(p.a_src) + m0 + col;   // pre-split packed weights, k-major
-
-    auto build_tab = [&](int kt) {
-        if (tid < BK) {
-            const int kg = kt * BK + tid;
-            int c, r, s2;
-            decode_crs(kg, RS, p.S, c, r, s2);
-            const unsigned bit = (kg < p.KG) ? (1u << (r * p.S + s2)) : 0u;
-            tab[kt & 3][tid] = make_int2(c * SHW + r * p.W + s2, (int)bit);
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    auto fetch = [&](int kt, unsigned (&ra)[8], float (&rb)[8]) {
-        const int k0 = kt * BK + 8 * khalf;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) ra[i] = (mvalid && (k0 + i) < p.KG) ? aptr[(size_t)(k0 + i) * p.M] : 0u;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int2 e = tab[kt & 3][8 * khalf + i];
-            rb[i] = (vmask & (unsigned)e.y) ? bptr[e.x] : 0.f;
-        }
-    };
-    auto stash = [&](int buf, const unsigned (&ra)[8], const float (&rb)[8]) {
-        unsigned ah[4], al[4], bh[4], bl[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ah[i] = __builtin_amdgcn_perm(ra[2 * i + 1], ra[2 * i], 0x07060302u);   // {hi(k odd), hi(k even)}
-            al[i] = __builtin_amdgcn_perm(ra[2 * i + 1], ra[2 * i], 0x05040100u);   // {lo(k odd), lo(k even)}
-            split2(rb[2 * i], rb[2 * i + 1], bh[i], bl[i]);
-        }
-        const int off = col * LDK + 8 * khalf;   // in bf16 elements; 16-byte aligned
-        *reinterpret_cast<uint4*>(&Ahi[buf][off]) = make_uint4(ah[0], ah[1], ah[2], ah[3]);
-        *reinterpret_cast<uint4*>(&Alo[buf][off]) = make_uint4(al[0], al[1], al[2], al[3]);
-        *reinterpret_cast<uint4*>(&Bhi[buf][off]) = make_uint4(bh[0], bh[1], bh[2], bh[3]);
-        *reinterpret_cast<uint4*>(&Blo[buf][off]) = make_uint4(bl[0], bl[1], bl[2], bl[3]);
-    };
-    const int fr = lane & 31, fh = lane >> 5;
-    auto compute = [&](int buf) {
-        bf16x8 ahi[TM], alo[TM], bhi[TN], blo[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int o = (wm0 + i * 32 + fr) * LDK + 8 * fh;
-            ahi[i] = *reinterpret_cast<const bf16x8*>(&Ahi[buf][o]);
-            alo[i] = *reinterpret_cast<const bf16x8*>(&Alo[buf][o]);
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int o = (wn0 + j * 32 + fr) * LDK + 8 * fh;
-            bhi[j] = *reinterpret_cast<const bf16x8*>(&Bhi[buf][o]);
-            blo[j] = *reinterpret_cast<const bf16x8*>(&Blo[buf][o]);
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[i], bhi[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], blo[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], bhi[j], acc[i][j], 0, 0, 0);
-            }
-    };
-
-    const int nk_all = (p.KG + BK - 1) / BK;
-    const int kt0 = (p.splitk > 1) ? blockIdx.y * p.kchunk : 0;
-    const int nk = (p.splitk > 1) ? min(nk_all, kt0 + p.kchunk) : nk_all;
-    if (kt0 >= nk) return;
-    unsigned ra0[8], ra1[8];
-    float rb0[8], rb1[8];
-    build_tab(kt0);
-    build_tab(kt0 + 1);
-    build_tab(kt0 + 2);
-    __syncthreads();
-    fetch(kt0, ra0, rb0);
-    stash(0, ra0, rb0);                       // tile kt0 -> LDS buffer 0
-    fetch(kt0 + 1, ra1, rb1);                 // tile kt0+1 -> register set 1 (k >= KG reads as zero)
-    __syncthreads();
-
-    // iteration `it` (relative index): tile kt0+it is in LDS buffer it&1, tile kt0+it+1 in register set (it+1)&1
-    for (int kt = kt0; kt < nk; kt += 2) {
-        // ---- even relative iteration: compute buffer 0, stage set 1 -> buffer 1, load tile kt+2 -> set 0
-        fetch(kt + 2, ra0, rb0);
-        build_tab(kt + 3);
-        compute(0);
-        stash(1, ra1, rb1);
-        __syncthreads();
-        if (kt + 1 >= nk) break;
-        // ---- odd relative iteration: compute buffer 1, stage set 0 -> buffer 0, load tile kt+3 -> set 1
-        fetch(kt + 3, ra1, rb1);
-        build_tab(kt + 4);
-        compute(1);
-        stash(0, ra0, rb0);
-        __syncthreads();
-    }
-
-    const int gplane = p.OH * p.OW;
-    const int plane = p.o_H * p.o_W;
-    const bool mapped = (p.o_mul != 1 || p.o_add_y != 0 || p.o_add_x != 0 || p.o_W != p.OW);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int opix = n0 + wn0 + j * 32 + (lane & 31);
-        if (opix >= p.NG) continue;
-        const int on = opix / gplane;
-        int orem = opix - on * gplane;
-        if (mapped) {
-            const int qy = orem / p.OW, qx = orem - qy * p.OW;
-            const int yy = qy * p.o_mul + p.o_add_y, xx = qx * p.o_mul + p.o_add_x;
-            if ((unsigned)yy >= (unsigned)p.o_H || (unsigned)xx >= (unsigned)p.o_W) continue;
-            orem = yy * p.o_W + xx;
-        }
-        float* obase = p.out + (size_t)on * p.M * plane + orem;
-        const float* rbase = p.residual ? p.residual + (size_t)on * p.M * plane + orem : nullptr;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m < p.M) {
-                    float v = acc[i][j][r];
-                    if (kt0 == 0) {
-                        if (p.bias) v += p.bias[m];
-                        if (rbase) v += rbase[(size_t)m * plane];
-                    }
-                    if (p.splitk > 1)
-                        atomicAdd(obase + (size_t)m * plane, v);
-                    else
-                        obase[(size_t)m * plane] = v;
-                }
-            }
-        }
-    }
-}
-
-// Weight gradient on the bf16x3 path: dW[m,j] = sum_q dY[m,q] * Xg[q,j], q = (n,oy,ox), j = (c,r,s).  Both operands are
-// activations (split in-kernel).  A thread owns one PAIR of consecutive pixels q for 4 rows of dY and 4 columns of the
-// gather, so each (hi | lo) pair is one packed ds_write_b32 into the k-contiguous LDS rows the MFMA fragments read.
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16x3_kernel(ConvArgs p) {
-    constexpr int BK = 16, LDK = 24;
-    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    static_assert(BM == 128 && BN == 128, "thread mapping assumes a 128x128 tile");
-    __shared__ __attribute__((aligned(16))) unsigned short Ahi[2][BM * LDK];
-    __shared__ __attribute__((aligned(16))) unsigned short Alo[2][BM * LDK];
-    __shared__ __attribute__((aligned(16))) unsigned short Bhi[2][BN * LDK];
-    __shared__ __attribute__((aligned(16))) unsigned short Blo[2][BN * LDK];
-    __shared__ int4 qtab[4][BK];   // per pixel q of a K-tile: {x offset of tap (0,0), dY offset, (yb<<16)|xb, valid}
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lid = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-    const int tile_m = lid % p.tiles_m, tile_n = lid / p.tiles_m;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int wm0 = (wave / WN) * (TM * 32), wn0 = (wave % WN) * (TN * 32);
-    const int RS = p.R * p.S;
-    const int OHW = p.OH * p.OW, HW = p.H * p.W;
-    const int Q = p.N * OHW;
-    const int qs = blockIdx.y * p.kchunk;
-    const int qe = min(qs + p.kchunk, Q);
-    if (qs >= qe) return;
-
-    const int qp = tid & 7, rg = tid >> 3;   // pixel pair (2qp, 2qp+1) of the K-tile; rows / columns rg + 32 i
-    int boff[4], bpk[4], aoff[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int j = n0 + rg + 32 * i;
-        int c, r, s;
-        decode_crs(j, RS, p.S, c, r, s);
-        bpk[i] = ((r - p.pad + 64) & 255) | (((s - p.pad + 64) & 255) << 8) | ((j < p.NG) ? (1 << 16) : 0);
-        boff[i] = c * HW + (r - p.pad) * p.W + (s - p.pad);
-        const int m = m0 + rg + 32 * i;
-        aoff[i] = (m < p.M) ? m * OHW : -1;
-    }
-    auto build_tab = [&](int t) {   // t = tile index relative to qs
-        if (tid < BK) {
-            const int q = qs + t * BK + tid;
-            const bool v = q < qe;
-            const int qc = v ? q : qs;
-            const int n = qc / OHW;
-            const int pixl = qc - n * OHW;
-            const int oy = pixl / p.OW, ox = pixl - oy * p.OW;
-            const int yb = oy * p.stride, xb = ox * p.stride;
-            qtab[t & 3][tid] = make_int4(n * p.C * HW + yb * p.W + xb, n * p.K * OHW + pixl, (yb << 16) | xb, v ? 1 : 0);
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    auto fetch = [&](int t, float (&ra)[8], float (&rb)[8]) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int4 e = qtab[t & 3][2 * qp + h];
-            const int yb = e.z >> 16, xb = e.z & 0xFFFF;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ra[2 * i + h] = (e.w && aoff[i] >= 0) ? p.a_src[(size_t)e.y + aoff[i]] : 0.f;
-                const int iy = yb + (bpk[i] & 255) - 64, ix = xb + ((bpk[i] >> 8) & 255) - 64;
-                const bool ok = e.w && (bpk[i] >> 16) && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                rb[2 * i + h] = ok ? p.b_src[(size_t)e.x + boff[i]] : 0.f;
-            }
-        }
-    };
-    auto stash = [&](int buf, const float (&ra)[8], const float (&rb)[8]) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            unsigned hi, lo;
-            const int off = (rg + 32 * i) * LDK + 2 * qp;
-            split2(ra[2 * i], ra[2 * i + 1], hi, lo);
-            *reinterpret_cast<unsigned*>(&Ahi[buf][off]) = hi;
-            *reinterpret_cast<unsigned*>(&Alo[buf][off]) = lo;
-            split2(rb[2 * i], rb[2 * i + 1], hi, lo);
-            *reinterpret_cast<unsigned*>(&Bhi[buf][off]) = hi;
-            *reinterpret_cast<unsigned*>(&Blo[buf][off]) = lo;
-        }
-    };
-    const int fr = lane & 31, fh = lane >> 5;
-    auto compute = [&](int buf) {
-        bf16x8 ahi[TM], alo[TM], bhi[TN], blo[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int o = (wm0 + i * 32 + fr) * LDK + 8 * fh;
-            ahi[i] = *reinterpret_cast<const bf16x8*>(&Ahi[buf][o]);
-            alo[i] = *reinterpret_cast<const bf16x8*>(&Alo[buf][o]);
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int o = (wn0 + j * 32 + fr) * LDK + 8 * fh;
-            bhi[j] = *reinterpret_cast<const bf16x8*>(&Bhi[buf][o]);
-            blo[j] = *reinterpret_cast<const bf16x8*>(&Blo[buf][o]);
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[i], bhi[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], blo[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], bhi[j], acc[i][j], 0, 0, 0);
-            }
-    };
-
-    const int nt = (qe - qs + BK - 1) / BK;
-    float ra0[8], ra1[8], rb0[8], rb1[8];
-    build_tab(0);
-    build_tab(1);
-    build_tab(2);
-    __syncthreads();
-    fetch(0, ra0, rb0);
-    stash(0, ra0, rb0);
-    fetch(1, ra1, rb1);
-    __syncthreads();
-    for (int t = 0; t < nt; t += 2) {
-        fetch(t + 2, ra0, rb0);
-        build_tab(t + 3);
-        compute(0);
-        stash(1, ra1, rb1);
-        __syncthreads();
-        if (t + 1 >= nt) break;
-        fetch(t + 3, ra1, rb1);
-        build_tab(t + 4);
-        compute(1);
-        stash(0, ra0, rb0);
-        __syncthreads();
-    }
-
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int colj = n0 + wn0 + j * 32 + (lane & 31);
-        if (colj >= p.NG) continue;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m < p.M) {
-                    float* dst = p.out + (size_t)m * p.NG + colj;
-                    if (p.splitk > 1)
-                        atomicAdd(dst, acc[i][j][r]);
-                    else
-                        *dst = acc[i][j][r];
-                }
-            }
-        }
-    }
-}
-
 // ---------------------------------------------------------------- weight preparation (k-major A operands)
 // at[col][row] = w[row][col]  (w: [rows][cols] row-major): 32x32 LDS tiles, coalesced on both sides.
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ w, float* __restrict__ at, int rows, int cols,
@@ -757,8 +366,8 @@ static bool use_bf16x3(int M) { return conv_precision() == 1 && M > 64; }
 static int launch_igemm(ConvArgs& a, hipStream_t st, bool out_zeroed = false) {
     if (a.M <= 0 || a.NG <= 0 || a.KG <= 0 || a.R * a.S > 16) return AG2V_EINVAL;
     if (a.o_mul == 0) { a.o_mul = 1; a.o_add_y = 0; a.o_add_x = 0; a.o_H = a.OH; a.o_W = a.OW; }
+    if (use_bf16x3(a.M)) return launch_igemm_bf16x3(a, st, out_zeroed);
     const int bm = (a.M <= 32) ? 32 : (a.M <= 64 ? 64 : 128);
-    const bool split = use_bf16x3(a.M);
     const int bk = 16;
     const int bn = (bm == 128) ? 128 : 256;
     a.tiles_m = ceil_div(a.M, bm);
@@ -783,8 +392,6 @@ static int launch_igemm(ConvArgs& a, hipStream_t st, bool out_zeroed = false) {
         hipLaunchKernelGGL((conv_igemm_kernel<32, 256, 1, 4>), grid, dim3(256), 0, st, a);
     else if (bm == 64)
         hipLaunchKernelGGL((conv_igemm_kernel<64, 256, 1, 4>), grid, dim3(256), 0, st, a);
-    else if (split)
-        hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, a);
     else
         hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, a);
     AG2V_CHECK_LAUNCH();
@@ -867,6 +474,7 @@ extern "C" int ag2v_conv2d_wgrad(const float* dy, const float* x, float* dw,
     const long long Q = (long long)N * a.OH * a.OW;
     if (Q >= (1LL << 31) || (long long)C * H * W >= (1LL << 31)) return AG2V_EINVAL;
     a.M = K; a.NG = C * R * S; a.KG = (int)Q;
+    if (use_bf16x3(a.M) && (long long)N * K * a.OH * a.OW < (1LL << 31)) return launch_wgrad_bf16x3(a, st);
     int bm = (a.M <= 32) ? 32 : (a.M <= 64 ? 64 : 128);
     a.tiles_m = ceil_div(a.M, bm);
     a.tiles_n = ceil_div(a.NG, 128);
@@ -888,8 +496,6 @@ extern "C" int ag2v_conv2d_wgrad(const float* dy, const float* x, float* dw,
         hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4>), grid, dim3(256), 0, st, a);
     else if (bm == 64)
         hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 2, 2>), grid, dim3(256), 0, st, a);
-    else if (use_bf16x3(a.M) && (long long)N * K * a.OH * a.OW < (1LL << 31))
-        hipLaunchKernelGGL((conv_wgrad_bf16x3_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, a);
     else
         hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, a);
     AG2V_CHECK_LAUNCH();
