@@ -224,6 +224,34 @@ __global__ __launch_bounds__(256) void layout_conv_bwd_kernel(const float* __res
     const float x0 = b[0], y0 = b[1], ww = b[2], hh = b[3];
     const bool legal = (x0 != 0.f) || (y0 != 0.f) || (ww != 0.f) || (hh != 0.f);
     const bool active = legal && keep[(size_t)n * J + j] != 0;
+    // Support of the object in output coordinates, found once per wave: rows / 64-column blocks where some tap is nonzero.
+    int oy_lo = OH, oy_hi = -1;
+    unsigned xblk_mask = 0;   // bit b: column block [64b, 64b+64) has a nonzero tap (OW <= 2048)
+    if (active) {
+        for (int base = 0; base < OH; base += 64) {
+            const int oy = base + lane;
+            float tyr[R];
+            lc_taps_y<R>(tyr, oy, stride, pad, Hm, H, pool, y0, hh, oy < OH);
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) t += fabsf(tyr[r]);
+            const unsigned long long b = __ballot(t != 0.f);
+            if (b) {
+                oy_lo = min(oy_lo, base + (int)__builtin_ctzll(b));
+                oy_hi = max(oy_hi, base + 63 - (int)__builtin_clzll(b));
+            }
+        }
+        for (int xb = 0; xb < OW && xb < 2048; xb += 64) {
+            const int ox = xb + lane;
+            float t = 0.f;
+#pragma unroll
+            for (int s = 0; s < R; ++s) {
+                const int xx = ox * stride + s - pad;
+                t += (ox < OW && (unsigned)xx < (unsigned)Wm) ? fabsf(lc_profile(xx, W, pool, x0, ww)) : 0.f;
+            }
+            if (__ballot(t != 0.f)) xblk_mask |= 1u << (xb >> 6);
+        }
+    }
     for (int i = 0; i < 8; ++i) {
         const int k = blockIdx.z * 32 + wave + 4 * i;
         if (k >= K) break;
@@ -232,8 +260,9 @@ __global__ __launch_bounds__(256) void layout_conv_bwd_kernel(const float* __res
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int s = 0; s < R; ++s) acc[r][s] = 0.f;
-        if (active) {
+        if (active && oy_hi >= oy_lo) {
             for (int xb = 0; xb < OW; xb += 64) {
+                if (xb < 2048 && !((xblk_mask >> (xb >> 6)) & 1u)) continue;   // wave-uniform
                 const int ox = xb + lane;
                 float txs[R];
                 float txsum = 0.f;
@@ -243,15 +272,10 @@ __global__ __launch_bounds__(256) void layout_conv_bwd_kernel(const float* __res
                     txs[s] = (ox < OW && (unsigned)xx < (unsigned)Wm) ? lc_profile(xx, W, pool, x0, ww) : 0.f;
                     txsum += fabsf(txs[s]);
                 }
-                if (__ballot(txsum != 0.f) == 0ull) continue;
                 const float* dp = dout + ((size_t)n * K + k) * OH * OW + ox;
-                for (int oy = 0; oy < OH; ++oy) {
+                for (int oy = oy_lo; oy <= oy_hi; ++oy) {
                     float tyr[R];
                     lc_taps_y<R>(tyr, oy, stride, pad, Hm, H, pool, y0, hh, true);
-                    float tysum = 0.f;
-#pragma unroll
-                    for (int r = 0; r < R; ++r) tysum += fabsf(tyr[r]);
-                    if (tysum == 0.f) continue;  // wave-uniform
                     const float g = (txsum != 0.f) ? dp[(size_t)oy * OW] : 0.f;
 #pragma unroll
                     for (int r = 0; r < R; ++r)
