@@ -53,11 +53,13 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_bf16x3_kernel(ConvArgs p) {
             for (int s2 = 0; s2 < p.S; ++s2)
                 if ((unsigned)(y0 + r) < (unsigned)p.H && (unsigned)(x0 + s2) < (unsigned)p.W) vmask |= 1u << (r * p.S + s2);
     }
-    const float* bptr = p.b_src + (size_t)n_img * p.C * SHW + (y0 * p.W + x0);
+    const int bbase = n_img * p.C * SHW + (y0 * p.W + x0);   // element offset of tap (0,0); only used when the tap is valid
+    const __amdgpu_buffer_rsrc_t brs = make_rsrc(p.b_src, p.b_bytes);
     // ---- A load state (pre-split packed weights, k-major)
     const int acol = tid % BM, apart = tid / BM;
     const bool mvalid = (m0 + acol) < p.M;
-    const unsigned* aptr = reinterpret_cast<const unsigned*>(p.a_src) + m0 + acol;
+    const int abase = m0 + acol;
+    const __amdgpu_buffer_rsrc_t ars = make_rsrc(p.a_src, p.a_bytes);
 
     auto build_tab = [&](int kt) {
         if (tid < BK) {
@@ -80,11 +82,12 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_bf16x3_kernel(ConvArgs p) {
     auto fetch = [&](int kt, unsigned (&ra)[AK], float (&rb)[BKK]) {
         const int ka = kt * BK + AK * apart;
 #pragma unroll
-        for (int i = 0; i < AK; ++i) ra[i] = (mvalid && (ka + i) < p.KG) ? aptr[(size_t)(ka + i) * p.M] : 0u;
+        for (int i = 0; i < AK; ++i)   // rows past KG lie past the descriptor's end (a_bytes = KG*M*4) and read as 0
+            ra[i] = bload_u32(ars, mvalid ? (unsigned)(abase + (ka + i) * p.M) * 4u : 0xFFFFFFFFu);
 #pragma unroll
         for (int i = 0; i < BKK; ++i) {
             const int2 e = tab[kt & 3][BKK * bpart + i];
-            rb[i] = (vmask & (unsigned)e.y) ? bptr[e.x] : 0.f;
+            rb[i] = bload_f32(brs, (vmask & (unsigned)e.y) ? (unsigned)(bbase + e.x) * 4u : 0xFFFFFFFFu);
         }
     };
     auto stash = [&](int buf, const unsigned (&ra)[AK], const float (&rb)[BKK]) {
@@ -232,6 +235,7 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_bf16x3_kernel(ConvArgs p) {
     const int qs = blockIdx.y * p.kchunk;
     const int qe = min(qs + p.kchunk, Q);
     if (qs >= qe) return;
+    const __amdgpu_buffer_rsrc_t ars = make_rsrc(p.a_src, p.a_bytes), brs = make_rsrc(p.b_src, p.b_bytes);
 
     const int qp = tid & 15, rg = tid >> 4;   // pixel pair (2qp, 2qp+1) of the K-tile; rows / columns rg + 32 i
     int aoff[RA], boff[RB], bpk[RB];
@@ -275,12 +279,13 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_bf16x3_kernel(ConvArgs p) {
             const int4 e = qtab[t & 3][2 * qp + h];
             const int yb = e.z >> 16, xb = e.z & 0xFFFF;
 #pragma unroll
-            for (int i = 0; i < RA; ++i) ra[2 * i + h] = (e.w && aoff[i] >= 0) ? p.a_src[(size_t)e.y + aoff[i]] : 0.f;
+            for (int i = 0; i < RA; ++i)
+                ra[2 * i + h] = bload_f32(ars, (e.w && aoff[i] >= 0) ? (unsigned)(e.y + aoff[i]) * 4u : 0xFFFFFFFFu);
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
                 const int iy = yb + (bpk[i] & 255) - 64, ix = xb + ((bpk[i] >> 8) & 255) - 64;
                 const bool ok = e.w && (bpk[i] >> 16) && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                rb[2 * i + h] = ok ? p.b_src[(size_t)e.x + boff[i]] : 0.f;
+                rb[2 * i + h] = bload_f32(brs, ok ? (unsigned)(e.x + boff[i]) * 4u : 0xFFFFFFFFu);
             }
         }
     };
@@ -375,163 +380,6 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_bf16x3_kernel(ConvArgs p) {
     }
 }
 
-// 4-wave 128x128 variant (K-tile 16) for layers with <= 128 output channels (a 256-row tile would be half empty):
-// Weight gradient on the bf16x3 path: dW[m,j] = sum_q dY[m,q] * Xg[q,j], q = (n,oy,ox), j = (c,r,s).  Both operands are
-// activations (split in-kernel).  A thread owns one PAIR of consecutive pixels q for 4 rows of dY and 4 columns of the
-// gather, so each (hi | lo) pair is one packed ds_write_b32 into the k-contiguous LDS rows the MFMA fragments read.
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16x3_4w_kernel(ConvArgs p) {
-    constexpr int BK = 16, LDK = 24;
-    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    static_assert(BM == 128 && BN == 128, "thread mapping assumes a 128x128 tile");
-    __shared__ __attribute__((aligned(16))) unsigned short Ahi[2][BM * LDK];
-    __shared__ __attribute__((aligned(16))) unsigned short Alo[2][BM * LDK];
-    __shared__ __attribute__((aligned(16))) unsigned short Bhi[2][BN * LDK];
-    __shared__ __attribute__((aligned(16))) unsigned short Blo[2][BN * LDK];
-    __shared__ int4 qtab[4][BK];   // per pixel q of a K-tile: {x offset of tap (0,0), dY offset, (yb<<16)|xb, valid}
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lid = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-    const int tile_m = lid % p.tiles_m, tile_n = lid / p.tiles_m;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int wm0 = (wave / WN) * (TM * 32), wn0 = (wave % WN) * (TN * 32);
-    const int RS = p.R * p.S;
-    const int OHW = p.OH * p.OW, HW = p.H * p.W;
-    const int Q = p.N * OHW;
-    const int qs = blockIdx.y * p.kchunk;
-    const int qe = min(qs + p.kchunk, Q);
-    if (qs >= qe) return;
-
-    const int qp = tid & 7, rg = tid >> 3;   // pixel pair (2qp, 2qp+1) of the K-tile; rows / columns rg + 32 i
-    int boff[4], bpk[4], aoff[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int j = n0 + rg + 32 * i;
-        int c, r, s;
-        decode_crs(j, RS, p.S, c, r, s);
-        bpk[i] = ((r - p.pad + 64) & 255) | (((s - p.pad + 64) & 255) << 8) | ((j < p.NG) ? (1 << 16) : 0);
-        boff[i] = c * HW + (r - p.pad) * p.W + (s - p.pad);
-        const int m = m0 + rg + 32 * i;
-        aoff[i] = (m < p.M) ? m * OHW : -1;
-    }
-    auto build_tab = [&](int t) {   // t = tile index relative to qs
-        if (tid < BK) {
-            const int q = qs + t * BK + tid;
-            const bool v = q < qe;
-            const int qc = v ? q : qs;
-            const int n = qc / OHW;
-            const int pixl = qc - n * OHW;
-            const int oy = pixl / p.OW, ox = pixl - oy * p.OW;
-            const int yb = oy * p.stride, xb = ox * p.stride;
-            qtab[t & 3][tid] = make_int4(n * p.C * HW + yb * p.W + xb, n * p.K * OHW + pixl, (yb << 16) | xb, v ? 1 : 0);
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    auto fetch = [&](int t, float (&ra)[8], float (&rb)[8]) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int4 e = qtab[t & 3][2 * qp + h];
-            const int yb = e.z >> 16, xb = e.z & 0xFFFF;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ra[2 * i + h] = (e.w && aoff[i] >= 0) ? p.a_src[(size_t)e.y + aoff[i]] : 0.f;
-                const int iy = yb + (bpk[i] & 255) - 64, ix = xb + ((bpk[i] >> 8) & 255) - 64;
-                const bool ok = e.w && (bpk[i] >> 16) && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                rb[2 * i + h] = ok ? p.b_src[(size_t)e.x + boff[i]] : 0.f;
-            }
-        }
-    };
-    auto stash = [&](int buf, const float (&ra)[8], const float (&rb)[8]) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            unsigned hi, lo;
-            const int off = (rg + 32 * i) * LDK + 2 * qp;
-            split2(ra[2 * i], ra[2 * i + 1], hi, lo);
-            *reinterpret_cast<unsigned*>(&Ahi[buf][off]) = hi;
-            *reinterpret_cast<unsigned*>(&Alo[buf][off]) = lo;
-            split2(rb[2 * i], rb[2 * i + 1], hi, lo);
-            *reinterpret_cast<unsigned*>(&Bhi[buf][off]) = hi;
-            *reinterpret_cast<unsigned*>(&Blo[buf][off]) = lo;
-        }
-    };
-    const int fr = lane & 31, fh = lane >> 5;
-    auto compute = [&](int buf) {
-        bf16x8 ahi[TM], alo[TM], bhi[TN], blo[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int o = (wm0 + i * 32 + fr) * LDK + 8 * fh;
-            ahi[i] = *reinterpret_cast<const bf16x8*>(&Ahi[buf][o]);
-            alo[i] = *reinterpret_cast<const bf16x8*>(&Alo[buf][o]);
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int o = (wn0 + j * 32 + fr) * LDK + 8 * fh;
-            bhi[j] = *reinterpret_cast<const bf16x8*>(&Bhi[buf][o]);
-            blo[j] = *reinterpret_cast<const bf16x8*>(&Blo[buf][o]);
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[i], bhi[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], blo[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], bhi[j], acc[i][j], 0, 0, 0);
-            }
-    };
-
-    const int nt = (qe - qs + BK - 1) / BK;
-    float ra0[8], ra1[8], rb0[8], rb1[8];
-    build_tab(0);
-    build_tab(1);
-    build_tab(2);
-    __syncthreads();
-    fetch(0, ra0, rb0);
-    stash(0, ra0, rb0);
-    fetch(1, ra1, rb1);
-    __syncthreads();
-    for (int t = 0; t < nt; t += 2) {
-        fetch(t + 2, ra0, rb0);
-        build_tab(t + 3);
-        compute(0);
-        stash(1, ra1, rb1);
-        __syncthreads();
-        if (t + 1 >= nt) break;
-        fetch(t + 3, ra1, rb1);
-        build_tab(t + 4);
-        compute(1);
-        stash(0, ra0, rb0);
-        __syncthreads();
-    }
-
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int colj = n0 + wn0 + j * 32 + (lane & 31);
-        if (colj >= p.NG) continue;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m < p.M) {
-                    float* dst = p.out + (size_t)m * p.NG + colj;
-                    if (p.splitk > 1)
-                        atomicAdd(dst, acc[i][j][r]);
-                    else
-                        *dst = acc[i][j][r];
-                }
-            }
-        }
-    }
-}
-
 // ================================================================ launchers
 int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed) {
     const bool tall = a.M >= 192;                 // 256 x 128 tile when there are enough output channels, else 128 x 256
@@ -561,25 +409,7 @@ int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed) {
 }
 
 int launch_wgrad_bf16x3(ConvArgs& a, hipStream_t st) {
-    if (a.M < 192) {   // <= 128 output channels: 4-wave 128x128 tiles, up to 2 workgroups per SIMD
-        a.tiles_m = ceil_div(a.M, 128);
-        a.tiles_n = ceil_div(a.NG, 128);
-        const int tiles = a.tiles_m * a.tiles_n;
-        const long long Q = a.KG;
-        int splitk = ceil_div(1536, tiles);
-        const int max_split = (int)((Q + 511) / 512);
-        if (splitk > max_split) splitk = max_split;
-        if (splitk < 1) splitk = 1;
-        int kchunk = (int)((Q + splitk - 1) / splitk);
-        kchunk = ((kchunk + 15) / 16) * 16;
-        splitk = (int)((Q + kchunk - 1) / kchunk);
-        a.splitk = splitk; a.kchunk = kchunk;
-        if (splitk > 1 && hipMemsetAsync(a.out, 0, (size_t)a.M * a.NG * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
-        hipLaunchKernelGGL((conv_wgrad_bf16x3_4w_kernel<128, 128, 2, 2>), dim3(tiles, splitk), dim3(256), 0, st, a);
-        AG2V_CHECK_LAUNCH();
-        return AG2V_OK;
-    }
-    const bool tall = true;
+    const bool tall = a.M >= 192;
     const int bm = tall ? 256 : 128, bn = tall ? 128 : 256;
     a.tiles_m = ceil_div(a.M, bm);
     a.tiles_n = ceil_div(a.NG, bn);

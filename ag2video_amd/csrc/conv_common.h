@@ -15,6 +15,7 @@ struct ConvArgs {
     int o_mul, o_add_y, o_add_x, o_H, o_W;  // output placement: (oy,ox) -> (oy*o_mul+o_add_y, ox*o_mul+o_add_x) in [o_H,o_W]
     int M, NG, KG;          // GEMM dims
     int tiles_m, tiles_n;
+    unsigned a_bytes, b_bytes;  // byte sizes of a_src / b_src (bf16x3 kernels address them through 32-bit buffer offsets)
     int splitk, kchunk;     // igemm: K-range splits (grid.y) in K-tiles; wgrad: pixel-range splits, pixels per split
 };
 
@@ -60,6 +61,18 @@ __device__ __forceinline__ float pack_split(float x) {
     return __uint_as_float(w);
 }
 
+
+// Raw buffer loads: a wave-uniform descriptor in SGPRs + a 32-bit byte offset per lane (no 64-bit address VGPRs); an offset
+// >= the descriptor's byte count reads as 0, which is how masked taps / padded rows are fetched (offset 0xFFFFFFFF).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ unsigned bload_u32(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0);
+}
+__device__ __forceinline__ float bload_f32(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
 
 // launchers implemented in conv_bf16x3.hip
 int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed);

@@ -362,11 +362,12 @@ extern "C" int ag2v_set_conv_precision(int mode) {
 }
 extern "C" int ag2v_get_conv_precision(void) { return conv_precision(); }
 static bool use_bf16x3(int M) { return conv_precision() == 1 && M > 64; }
+static const long long kBufMax = (1LL << 32) - 64;   // raw buffer descriptors cover < 4 GiB
 
-static int launch_igemm(ConvArgs& a, hipStream_t st, bool out_zeroed = false) {
+static int launch_igemm(ConvArgs& a, hipStream_t st, bool out_zeroed, bool split) {
     if (a.M <= 0 || a.NG <= 0 || a.KG <= 0 || a.R * a.S > 16) return AG2V_EINVAL;
     if (a.o_mul == 0) { a.o_mul = 1; a.o_add_y = 0; a.o_add_x = 0; a.o_H = a.OH; a.o_W = a.OW; }
-    if (use_bf16x3(a.M)) return launch_igemm_bf16x3(a, st, out_zeroed);
+    if (split) return launch_igemm_bf16x3(a, st, out_zeroed);
     const int bm = (a.M <= 32) ? 32 : (a.M <= 64 ? 64 : 128);
     const int bk = 16;
     const int bn = (bm == 128) ? 128 : 256;
@@ -414,10 +415,13 @@ extern "C" int ag2v_conv2d_fwd(const float* x, const float* w, const float* bias
     if ((long long)N * a.OH * a.OW >= (1LL << 31) || (long long)C * R * S >= (1LL << 31) ||
         (long long)C * H * W >= (1LL << 31)) return AG2V_EINVAL;
     a.M = K; a.NG = N * a.OH * a.OW; a.KG = C * R * S;
+    const long long abytes = (long long)a.KG * K * 4, bbytes = (long long)N * C * H * W * 4;
+    const bool split = use_bf16x3(K) && abytes < kBufMax && bbytes < kBufMax;
+    a.a_bytes = (unsigned)abytes; a.b_bytes = (unsigned)bbytes;
     hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(a.KG, 32), ceil_div(K, 32)), dim3(256), 0, st, w, workspace, K, a.KG,
-                       use_bf16x3(K) ? 1 : 0);
+                       split ? 1 : 0);
     a.a_src = workspace;
-    return launch_igemm(a, st);
+    return launch_igemm(a, st, false, split);
 }
 
 // dx = d conv / d x.  For each pixel class (py,px) of the stride one forward-kernel launch over dy with the class's
@@ -445,8 +449,10 @@ extern "C" int ag2v_conv2d_dgrad(const float* dy, const float* w, float* dx,
             const int q0x = (pad > px) ? (pad - px + stride - 1) / stride : 0;
             const int ay = q0y * stride + py - pad, ax = q0x * stride + px - pad;
             if (ay >= H || ax >= W) continue;
+            const long long abytes = (long long)K * C * Rc * Sc * 4, bbytes = (long long)N * K * OH * OW * 4;
+            const bool split = use_bf16x3(C) && abytes < kBufMax && bbytes < kBufMax;
             hipLaunchKernelGGL(dgrad_weight_prep_kernel, dim3(ceil_div(C, 64), K), dim3(256), 0, st, w, at, K, C, R, S, py, px,
-                               stride, Rc, Sc, use_bf16x3(C) ? 1 : 0);
+                               stride, Rc, Sc, split ? 1 : 0);
             ConvArgs f{};
             f.a_src = at; f.b_src = dy; f.out = dx;
             f.N = N; f.C = K; f.H = OH; f.W = OW; f.K = C; f.R = Rc; f.S = Sc; f.stride = 1;
@@ -455,7 +461,8 @@ extern "C" int ag2v_conv2d_dgrad(const float* dy, const float* w, float* dx,
             f.o_mul = stride; f.o_add_y = ay; f.o_add_x = ax; f.o_H = H; f.o_W = W;
             if ((long long)N * f.OH * f.OW >= (1LL << 31)) return AG2V_EINVAL;
             f.M = C; f.NG = N * f.OH * f.OW; f.KG = K * Rc * Sc;
-            const int rc = launch_igemm(f, st, multi);
+            f.a_bytes = (unsigned)abytes; f.b_bytes = (unsigned)bbytes;
+            const int rc = launch_igemm(f, st, multi, split);
             if (rc != AG2V_OK) return rc;
             at += (size_t)K * C * Rc * Sc;
         }
@@ -474,7 +481,13 @@ extern "C" int ag2v_conv2d_wgrad(const float* dy, const float* x, float* dw,
     const long long Q = (long long)N * a.OH * a.OW;
     if (Q >= (1LL << 31) || (long long)C * H * W >= (1LL << 31)) return AG2V_EINVAL;
     a.M = K; a.NG = C * R * S; a.KG = (int)Q;
-    if (use_bf16x3(a.M) && (long long)N * K * a.OH * a.OW < (1LL << 31)) return launch_wgrad_bf16x3(a, st);
+    {
+        const long long abytes = (long long)N * K * a.OH * a.OW * 4, bbytes = (long long)N * C * H * W * 4;
+        if (use_bf16x3(a.M) && abytes < kBufMax && bbytes < kBufMax) {
+            a.a_bytes = (unsigned)abytes; a.b_bytes = (unsigned)bbytes;
+            return launch_wgrad_bf16x3(a, st);
+        }
+    }
     int bm = (a.M <= 32) ? 32 : (a.M <= 64 ? 64 : 128);
     a.tiles_m = ceil_div(a.M, bm);
     a.tiles_n = ceil_div(a.NG, 128);
