@@ -57,8 +57,8 @@ def enable_kernel_timing(flag=True):
 
 
 def _conv_label(mode, M):
-    bm = 32 if M <= 32 else (64 if M <= 64 else 128)
-    prec = get_conv_precision() if bm == 128 else 'fp32'
+    prec = get_conv_precision() if M >= 48 else 'fp32'      # the library sends GEMMs with >= 48 rows to the bf16x3 tiles
+    bm = 32 if M <= 32 else (64 if (M <= 64 and prec == 'fp32') else 128)
     return "conv_%s_bm%d_%s" % (mode, bm, prec)
 
 

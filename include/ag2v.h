@@ -26,7 +26,7 @@ extern "C" {
  * call sites: generator.py:30; flows_generator.py:32-54,82-85; spade_generator.py:16-34; architecture.py:29-32;
  * normalization.py:90-94; discriminator.py:368-379.   x[N,C,H,W], w[K,C,R,S], y[N,K,OH,OW], OH=(H+2p-R)/s+1.
  * fwd: y = conv(x,w) (+bias[K]) (+residual, same shape as y).  dgrad: dx from dy.  wgrad: dw from dy,x. */
-/* Arithmetic of the 128-row MFMA tiles (GEMM M > 64): 1 (default) = bf16x3 split products, fp32 accumulation (each fp32
+/* Arithmetic of the 128/256-row MFMA tiles (GEMM M >= 48): 1 (default) = bf16x3 split products, fp32 accumulation (each fp32
  * operand = bf16 hi + bf16 lo, a*b = hi*hi + hi*lo + lo*hi: ~1e-5 relative per product); 0 = exact fp32 MFMA.  Process-wide. */
 int ag2v_set_conv_precision(int mode);
 int ag2v_get_conv_precision(void);
