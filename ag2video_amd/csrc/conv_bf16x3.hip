@@ -14,6 +14,7 @@
 // The weight operand of the forward/dgrad kernel arrives pre-split (packed hi:lo words, k-major) from the prep kernels, so
 // its in-kernel cost is two v_perm per pair; activations are split in-kernel (v_cvt_pk_bf16_f32).
 #include "conv_common.h"
+#include <stdlib.h>
 
 #define NT 512
 
@@ -171,6 +172,232 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_bf16x3_kernel(ConvArgs p) {
     }
 
     // ---- epilogue (C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5))
+    const int gplane = p.OH * p.OW;
+    const int plane = p.o_H * p.o_W;
+    const bool mapped = (p.o_mul != 1 || p.o_add_y != 0 || p.o_add_x != 0 || p.o_W != p.OW);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int opix = n0 + wn0 + j * 32 + (lane & 31);
+        if (opix >= p.NG) continue;
+        const int on = opix / gplane;
+        int orem = opix - on * gplane;
+        if (mapped) {
+            const int qy = orem / p.OW, qx = orem - qy * p.OW;
+            const int yy = qy * p.o_mul + p.o_add_y, xx = qx * p.o_mul + p.o_add_x;
+            if ((unsigned)yy >= (unsigned)p.o_H || (unsigned)xx >= (unsigned)p.o_W) continue;
+            orem = yy * p.o_W + xx;
+        }
+        float* obase = p.out + (size_t)on * p.M * plane + orem;
+        const float* rbase = p.residual ? p.residual + (size_t)on * p.M * plane + orem : nullptr;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < p.M) {
+                    float v = acc[i][j][r];
+                    if (kt0 == 0) {
+                        if (p.bias) v += p.bias[m];
+                        if (rbase) v += rbase[(size_t)m * plane];
+                    }
+                    if (p.splitk > 1)
+                        atomicAdd(obase + (size_t)m * plane, v);
+                    else
+                        obase[(size_t)m * plane] = v;
+                }
+            }
+        }
+    }
+}
+
+// Wave-specialised form of the kernel above.  PMC on the homogeneous 8-wave kernel: 7 VALU per MFMA, the MFMA pipe 32 % busy,
+// waves 51 % in s_waitcnt / barrier -- all waves of a workgroup march through "MFMA phase" and "split+stage phase" together,
+// so the matrix pipe idles while every wave converts.  Here waves 0-3 (one per SIMD) are PRODUCERS: they issue all global
+// loads (two K-tiles ahead), split/pack and write LDS; waves 4-7 (one per SIMD) are CONSUMERS: they only read fragments and
+// issue MFMAs (128x64 sub-tile each, 48 MFMAs per K-tile).  A SIMD therefore always has one VALU-bound and one MFMA-bound
+// wave, which the hardware runs concurrently (separate pipes); one workgroup barrier per K-tile hands the buffers over.
+template <int BM, int BN, int CWM, int CWN, int NPW>
+__global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_kernel(ConvArgs p) {
+    constexpr int BK = 32, LDK = 40, NP = NPW * 64;       // NP producer threads
+    constexpr int TM = BM / CWM / 32, TN = BN / CWN / 32;  // consumer wave tile in 32x32 MFMA tiles
+    constexpr int AP = NP / BM > 0 ? NP / BM : 1, AK = BK / AP;
+    constexpr int BP = NP / BN > 0 ? NP / BN : 1, BKK = BK / BP;
+    constexpr int ACOLS = BM / (NP / AP), BCOLS = BN / (NP / BP);   // columns per producer thread (1 or 2 when the tile side is 256)
+    static_assert(BM % (CWM * 32) == 0 && BN % (CWN * 32) == 0, "consumer wave tiles");
+    static_assert(AK % 8 == 0 && BKK % 8 == 0, "16-byte LDS stores");
+    __shared__ __attribute__((aligned(16))) unsigned short Ahi[2][BM * LDK];
+    __shared__ __attribute__((aligned(16))) unsigned short Alo[2][BM * LDK];
+    __shared__ __attribute__((aligned(16))) unsigned short Bhi[2][BN * LDK];
+    __shared__ __attribute__((aligned(16))) unsigned short Blo[2][BN * LDK];
+    __shared__ int2 tab[4][BK];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wave < NPW;
+    const int lid = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int tile_m = lid % p.tiles_m, tile_n = lid / p.tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int RS = p.R * p.S;
+    const int SHW = p.H * p.W;
+
+    const int nk_all = (p.KG + BK - 1) / BK;
+    const int kt0 = (p.splitk > 1) ? blockIdx.y * p.kchunk : 0;
+    const int nk = (p.splitk > 1) ? min(nk_all, kt0 + p.kchunk) : nk_all;
+    if (kt0 >= nk) return;  // uniform per workgroup
+
+    // ------------------------------------------------------------------ pipeline
+    // The two roles are separate code regions (register live ranges do not add up); each executes exactly the same
+    // sequence of workgroup barriers: 2 in the prologue, then one per K-tile.
+    if (producer) {
+        // ------------------------------------------------------------------ producer state (threads 0..255)
+        const __amdgpu_buffer_rsrc_t ars = make_rsrc(p.a_src, p.a_bytes), brs = make_rsrc(p.b_src, p.b_bytes);
+        const int ptid = tid & (NP - 1);
+        // A: thread -> ACOLS columns (m), one k part of AK consecutive k each
+        const int acol0 = ptid % (BM / ACOLS), apart = ptid / (BM / ACOLS) % AP;
+        // B: thread -> BCOLS pixel columns, one k part of BKK consecutive k each
+        const int bcol0 = ptid % (BN / BCOLS), bpart = ptid / (BN / BCOLS) % BP;
+        int bbase[BCOLS];
+        unsigned vmask[BCOLS];
+    #pragma unroll
+        for (int c = 0; c < BCOLS; ++c) {
+            const int pix = n0 + bcol0 + c * (BN / BCOLS);
+            vmask[c] = 0;
+            bbase[c] = 0;
+            if (pix < p.NG) {
+                const int n_img = pix / (p.OH * p.OW);
+                const int prem = pix - n_img * (p.OH * p.OW);
+                const int py = prem / p.OW, px = prem - py * p.OW;
+                const int y0 = py * p.stride - p.pad, x0 = px * p.stride - p.pad_w;
+                for (int r = 0; r < p.R; ++r)
+                    for (int s2 = 0; s2 < p.S; ++s2)
+                        if ((unsigned)(y0 + r) < (unsigned)p.H && (unsigned)(x0 + s2) < (unsigned)p.W) vmask[c] |= 1u << (r * p.S + s2);
+                bbase[c] = n_img * p.C * SHW + (y0 * p.W + x0);
+            }
+        }
+        auto build_tab = [&](int kt) {
+            if (tid < BK) {
+                const int kg = kt * BK + tid;
+                int c, r, s2;
+                decode_crs(kg, RS, p.S, c, r, s2);
+                const unsigned bit = (kg < p.KG) ? (1u << (r * p.S + s2)) : 0u;
+                tab[kt & 3][tid] = make_int2(c * SHW + r * p.W + s2, (int)bit);
+            }
+        };
+        auto fetch = [&](int kt, unsigned (&ra)[ACOLS][AK], float (&rb)[BCOLS][BKK]) {
+            const int ka = kt * BK + AK * apart;
+    #pragma unroll
+            for (int c = 0; c < ACOLS; ++c) {
+                const int m = m0 + acol0 + c * (BM / ACOLS);
+    #pragma unroll
+                for (int i = 0; i < AK; ++i) ra[c][i] = bload_u32(ars, (m < p.M) ? (unsigned)(m + (ka + i) * p.M) * 4u : 0xFFFFFFFFu);
+            }
+    #pragma unroll
+            for (int i = 0; i < BKK; ++i) {
+                const int2 e = tab[kt & 3][BKK * bpart + i];
+    #pragma unroll
+                for (int c = 0; c < BCOLS; ++c)
+                    rb[c][i] = bload_f32(brs, (vmask[c] & (unsigned)e.y) ? (unsigned)(bbase[c] + e.x) * 4u : 0xFFFFFFFFu);
+            }
+        };
+        auto stash = [&](int buf, const unsigned (&ra)[ACOLS][AK], const float (&rb)[BCOLS][BKK]) {
+    #pragma unroll
+            for (int c = 0; c < ACOLS; ++c)
+    #pragma unroll
+                for (int g = 0; g < AK / 8; ++g) {
+                    unsigned h[4], l[4];
+    #pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        h[i] = __builtin_amdgcn_perm(ra[c][8 * g + 2 * i + 1], ra[c][8 * g + 2 * i], 0x07060302u);
+                        l[i] = __builtin_amdgcn_perm(ra[c][8 * g + 2 * i + 1], ra[c][8 * g + 2 * i], 0x05040100u);
+                    }
+                    const int off = (acol0 + c * (BM / ACOLS)) * LDK + AK * apart + 8 * g;
+                    *reinterpret_cast<uint4*>(&Ahi[buf][off]) = make_uint4(h[0], h[1], h[2], h[3]);
+                    *reinterpret_cast<uint4*>(&Alo[buf][off]) = make_uint4(l[0], l[1], l[2], l[3]);
+                }
+    #pragma unroll
+            for (int c = 0; c < BCOLS; ++c)
+    #pragma unroll
+                for (int g = 0; g < BKK / 8; ++g) {
+                    unsigned h[4], l[4];
+    #pragma unroll
+                    for (int i = 0; i < 4; ++i) split2(rb[c][8 * g + 2 * i], rb[c][8 * g + 2 * i + 1], h[i], l[i]);
+                    const int off = (bcol0 + c * (BN / BCOLS)) * LDK + BKK * bpart + 8 * g;
+                    *reinterpret_cast<uint4*>(&Bhi[buf][off]) = make_uint4(h[0], h[1], h[2], h[3]);
+                    *reinterpret_cast<uint4*>(&Blo[buf][off]) = make_uint4(l[0], l[1], l[2], l[3]);
+                }
+        };
+
+        unsigned ra0[ACOLS][AK], ra1[ACOLS][AK];
+        float rb0[BCOLS][BKK], rb1[BCOLS][BKK];
+        build_tab(kt0);
+        build_tab(kt0 + 1);
+        build_tab(kt0 + 2);
+        __syncthreads();
+        fetch(kt0, ra0, rb0);
+        stash(0, ra0, rb0);
+        fetch(kt0 + 1, ra1, rb1);
+        __syncthreads();
+        for (int kt = kt0; kt < nk; kt += 2) {
+            fetch(kt + 2, ra0, rb0);
+            build_tab(kt + 3);
+            stash(1, ra1, rb1);
+            __syncthreads();
+            if (kt + 1 >= nk) break;
+            fetch(kt + 3, ra1, rb1);
+            build_tab(kt + 4);
+            stash(0, ra0, rb0);
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ------------------------------------------------------------------ consumer state (waves 4..7)
+    const int cw = wave - NPW;
+    const int wm0 = (cw / CWN) * (TM * 32), wn0 = (cw % CWN) * (TN * 32);
+    const int fr = lane & 31, fh = lane >> 5;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 bhi[TN], blo[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int o = (wn0 + j * 32 + fr) * LDK + ks * 16 + 8 * fh;
+                bhi[j] = *reinterpret_cast<const bf16x8*>(&Bhi[buf][o]);
+                blo[j] = *reinterpret_cast<const bf16x8*>(&Blo[buf][o]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int o = (wm0 + i * 32 + fr) * LDK + ks * 16 + 8 * fh;
+                const bf16x8 ahi = *reinterpret_cast<const bf16x8*>(&Ahi[buf][o]);
+                const bf16x8 alo = *reinterpret_cast<const bf16x8*>(&Alo[buf][o]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    __syncthreads();
+    __syncthreads();
+    for (int kt = kt0; kt < nk; kt += 2) {
+        compute(0);
+        __syncthreads();
+        if (kt + 1 >= nk) break;
+        compute(1);
+        __syncthreads();
+    }
+
+    // ---- epilogue (consumers): C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     const int gplane = p.OH * p.OW;
     const int plane = p.o_H * p.o_W;
     const bool mapped = (p.o_mul != 1 || p.o_add_y != 0 || p.o_add_x != 0 || p.o_W != p.OW);
@@ -400,10 +627,26 @@ int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed) {
         if (hipMemsetAsync(a.out, 0, (size_t)a.N * a.M * a.o_H * a.o_W * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
     }
     dim3 grid(tiles, a.splitk);
-    if (tall)
-        hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<256, 128, 4, 2>), grid, dim3(NT), 0, st, a);
-    else
-        hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<128, 256, 2, 4>), grid, dim3(NT), 0, st, a);
+    static const bool homogeneous = getenv("AG2V_BF16X3_HOMOGENEOUS") != nullptr;   // A/B switch: all 8 waves do everything
+    if (homogeneous) {
+        if (tall)
+            hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<256, 128, 4, 2>), grid, dim3(NT), 0, st, a);
+        else
+            hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<128, 256, 2, 4>), grid, dim3(NT), 0, st, a);
+    } else {
+        static const bool ws44 = getenv("AG2V_BF16X3_WS44") != nullptr;   // 4 producer + 4 consumer waves
+        if (ws44) {
+            if (tall)
+                hipLaunchKernelGGL((conv_igemm_bf16x3_ws_kernel<256, 128, 2, 2, 4>), grid, dim3(512), 0, st, a);
+            else
+                hipLaunchKernelGGL((conv_igemm_bf16x3_ws_kernel<128, 256, 1, 4, 4>), grid, dim3(512), 0, st, a);
+        } else {
+            if (tall)
+                hipLaunchKernelGGL((conv_igemm_bf16x3_ws_kernel<256, 128, 4, 2, 8>), grid, dim3(1024), 0, st, a);
+            else
+                hipLaunchKernelGGL((conv_igemm_bf16x3_ws_kernel<128, 256, 2, 4, 8>), grid, dim3(1024), 0, st, a);
+        }
+    }
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
 }
