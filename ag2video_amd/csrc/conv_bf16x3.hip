@@ -389,11 +389,8 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
 
     __syncthreads();
     __syncthreads();
-    for (int kt = kt0; kt < nk; kt += 2) {
-        compute(0);
-        __syncthreads();
-        if (kt + 1 >= nk) break;
-        compute(1);
+    for (int kt = kt0; kt < nk; ++kt) {
+        compute((kt - kt0) & 1);
         __syncthreads();
     }
 
@@ -607,6 +604,183 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_bf16x3_kernel(ConvArgs p) {
     }
 }
 
+// Wave-specialised weight gradient (same producer / consumer split as conv_igemm_bf16x3_ws_kernel): 8 producer waves own
+// the pixel-pair loads, the split and the packed ds_write_b32; 8 consumer waves (64x64 each) only read fragments and issue MFMAs.
+template <int BM, int BN, int CWM, int CWN, int NPW>
+__global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_ws_kernel(ConvArgs p) {
+    constexpr int BK = 32, LDK = 40, NP = NPW * 64;
+    constexpr int TM = BM / CWM / 32, TN = BN / CWN / 32;
+    constexpr int NRG = NP / 16;                     // row groups: a producer thread = (pixel pair, row group)
+    constexpr int RA = BM / NRG, RB = BN / NRG;      // rows of dY / gather columns per producer thread
+    static_assert(BM % NRG == 0 && BN % NRG == 0, "producer mapping");
+    __shared__ __attribute__((aligned(16))) unsigned short Ahi[2][BM * LDK];
+    __shared__ __attribute__((aligned(16))) unsigned short Alo[2][BM * LDK];
+    __shared__ __attribute__((aligned(16))) unsigned short Bhi[2][BN * LDK];
+    __shared__ __attribute__((aligned(16))) unsigned short Blo[2][BN * LDK];
+    __shared__ int4 qtab[4][BK];   // per pixel q of a K-tile: {x offset of tap (0,0), dY offset, (yb<<16)|xb, valid}
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wave < NPW;
+    const int lid = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int tile_m = lid % p.tiles_m, tile_n = lid / p.tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int RS = p.R * p.S;
+    const int OHW = p.OH * p.OW, HW = p.H * p.W;
+    const int Q = p.N * OHW;
+    const int qs = blockIdx.y * p.kchunk;
+    const int qe = min(qs + p.kchunk, Q);
+    if (qs >= qe) return;
+    const int nt = (qe - qs + BK - 1) / BK;
+
+    if (producer) {
+        const __amdgpu_buffer_rsrc_t ars = make_rsrc(p.a_src, p.a_bytes), brs = make_rsrc(p.b_src, p.b_bytes);
+        const int qp = tid & 15, rg = tid >> 4;   // pixel pair (2qp, 2qp+1) of the K-tile; rows / columns rg + NRG i
+        int aoff[RA], boff[RB], bpk[RB];
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int m = m0 + rg + NRG * i;
+            aoff[i] = (m < p.M) ? m * OHW : -1;
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int j = n0 + rg + NRG * i;
+            int c, r, s;
+            decode_crs(j, RS, p.S, c, r, s);
+            bpk[i] = ((r - p.pad + 64) & 255) | (((s - p.pad + 64) & 255) << 8) | ((j < p.NG) ? (1 << 16) : 0);
+            boff[i] = c * HW + (r - p.pad) * p.W + (s - p.pad);
+        }
+        auto build_tab = [&](int t) {   // t = tile index relative to qs
+            if (tid < BK) {
+                const int q = qs + t * BK + tid;
+                const bool v = q < qe;
+                const int qc = v ? q : qs;
+                const int n = qc / OHW;
+                const int pixl = qc - n * OHW;
+                const int oy = pixl / p.OW, ox = pixl - oy * p.OW;
+                const int yb = oy * p.stride, xb = ox * p.stride;
+                qtab[t & 3][tid] = make_int4(n * p.C * HW + yb * p.W + xb, n * p.K * OHW + pixl, (yb << 16) | xb, v ? 1 : 0);
+            }
+        };
+        auto fetch = [&](int t, float (&ra)[2 * RA], float (&rb)[2 * RB]) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int4 e = qtab[t & 3][2 * qp + h];
+                const int yb = e.z >> 16, xb = e.z & 0xFFFF;
+#pragma unroll
+                for (int i = 0; i < RA; ++i)
+                    ra[2 * i + h] = bload_f32(ars, (e.w && aoff[i] >= 0) ? (unsigned)(e.y + aoff[i]) * 4u : 0xFFFFFFFFu);
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    const int iy = yb + (bpk[i] & 255) - 64, ix = xb + ((bpk[i] >> 8) & 255) - 64;
+                    const bool ok = e.w && (bpk[i] >> 16) && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                    rb[2 * i + h] = bload_f32(brs, ok ? (unsigned)(e.x + boff[i]) * 4u : 0xFFFFFFFFu);
+                }
+            }
+        };
+        auto stash = [&](int buf, const float (&ra)[2 * RA], const float (&rb)[2 * RB]) {
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                unsigned hi, lo;
+                const int off = (rg + NRG * i) * LDK + 2 * qp;
+                split2(ra[2 * i], ra[2 * i + 1], hi, lo);
+                *reinterpret_cast<unsigned*>(&Ahi[buf][off]) = hi;
+                *reinterpret_cast<unsigned*>(&Alo[buf][off]) = lo;
+            }
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                unsigned hi, lo;
+                const int off = (rg + NRG * i) * LDK + 2 * qp;
+                split2(rb[2 * i], rb[2 * i + 1], hi, lo);
+                *reinterpret_cast<unsigned*>(&Bhi[buf][off]) = hi;
+                *reinterpret_cast<unsigned*>(&Blo[buf][off]) = lo;
+            }
+        };
+        float ra0[2 * RA], ra1[2 * RA], rb0[2 * RB], rb1[2 * RB];
+        build_tab(0);
+        build_tab(1);
+        build_tab(2);
+        __syncthreads();
+        fetch(0, ra0, rb0);
+        stash(0, ra0, rb0);
+        fetch(1, ra1, rb1);
+        __syncthreads();
+        for (int t = 0; t < nt; t += 2) {
+            fetch(t + 2, ra0, rb0);
+            build_tab(t + 3);
+            stash(1, ra1, rb1);
+            __syncthreads();
+            if (t + 1 >= nt) break;
+            fetch(t + 3, ra1, rb1);
+            build_tab(t + 4);
+            stash(0, ra0, rb0);
+            __syncthreads();
+        }
+        return;
+    }
+
+    const int cw = wave - NPW;
+    const int wm0 = (cw / CWN) * (TM * 32), wn0 = (cw % CWN) * (TN * 32);
+    const int fr = lane & 31, fh = lane >> 5;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 bhi[TN], blo[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int o = (wn0 + j * 32 + fr) * LDK + ks * 16 + 8 * fh;
+                bhi[j] = *reinterpret_cast<const bf16x8*>(&Bhi[buf][o]);
+                blo[j] = *reinterpret_cast<const bf16x8*>(&Blo[buf][o]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int o = (wm0 + i * 32 + fr) * LDK + ks * 16 + 8 * fh;
+                const bf16x8 ahi = *reinterpret_cast<const bf16x8*>(&Ahi[buf][o]);
+                const bf16x8 alo = *reinterpret_cast<const bf16x8*>(&Alo[buf][o]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+    };
+    __syncthreads();
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        compute(t & 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int colj = n0 + wn0 + j * 32 + (lane & 31);
+        if (colj >= p.NG) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < p.M) {
+                    float* dst = p.out + (size_t)m * p.NG + colj;
+                    if (p.splitk > 1)
+                        atomicAdd(dst, acc[i][j][r]);
+                    else
+                        *dst = acc[i][j][r];
+                }
+            }
+        }
+    }
+}
+
 // ================================================================ launchers
 int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed) {
     const bool tall = a.M >= 192;                 // 256 x 128 tile when there are enough output channels, else 128 x 256
@@ -670,10 +844,18 @@ int launch_wgrad_bf16x3(ConvArgs& a, hipStream_t st) {
         if (hipMemsetAsync(a.out, 0, (size_t)a.M * a.NG * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
     }
     dim3 grid(tiles, splitk);
-    if (tall)
-        hipLaunchKernelGGL((conv_wgrad_bf16x3_kernel<256, 128, 4, 2>), grid, dim3(NT), 0, st, a);
-    else
-        hipLaunchKernelGGL((conv_wgrad_bf16x3_kernel<128, 256, 2, 4>), grid, dim3(NT), 0, st, a);
+    static const bool homogeneous = getenv("AG2V_BF16X3_HOMOGENEOUS") != nullptr;
+    if (homogeneous) {
+        if (tall)
+            hipLaunchKernelGGL((conv_wgrad_bf16x3_kernel<256, 128, 4, 2>), grid, dim3(NT), 0, st, a);
+        else
+            hipLaunchKernelGGL((conv_wgrad_bf16x3_kernel<128, 256, 2, 4>), grid, dim3(NT), 0, st, a);
+    } else {
+        if (tall)
+            hipLaunchKernelGGL((conv_wgrad_bf16x3_ws_kernel<256, 128, 4, 2, 8>), grid, dim3(1024), 0, st, a);
+        else
+            hipLaunchKernelGGL((conv_wgrad_bf16x3_ws_kernel<128, 256, 2, 4, 8>), grid, dim3(1024), 0, st, a);
+    }
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
 }

@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void dgrad_weight_prep_kernel(const float* __r
 
 static int conv_out_dim(int in, int k, int stride, int pad) { return (in + 2 * pad - k) / stride + 1; }
 
-// Precision of the 128/256-row igemm / wgrad tiles (GEMMs with M >= 48; a 64-row GEMM runs a half-masked 128-row tile): 1 = bf16x3 split (default: fp32-level accuracy, ~1e-5
+// Precision of the 128/256-row igemm / wgrad tiles (GEMMs with M >= bf16x3_min_rows()): 1 = bf16x3 split (default: fp32-level accuracy, ~1e-5
 // relative per product, at up to 16/3 of the fp32 MFMA rate), 0 = exact fp32 MFMA (bit-for-bit fmaf chains).
 // Process-wide setting: ag2v_set_conv_precision(), or the environment variable AG2V_CONV_PRECISION=fp32|bf16x3 read once.
 static int g_conv_precision = -1;
@@ -361,7 +361,15 @@ extern "C" int ag2v_set_conv_precision(int mode) {
     return AG2V_OK;
 }
 extern "C" int ag2v_get_conv_precision(void) { return conv_precision(); }
-static bool use_bf16x3(int M) { return conv_precision() == 1 && M >= 48; }
+// GEMMs with fewer rows stay on the exact-fp32 32/64-row tiles (AG2V_BF16X3_MIN_M overrides, for A/B runs).  The 64-row layers
+// are the full-resolution tails of the flow and image decoders: on the random-init toy their 1e-5 split error is amplified
+// ~100x by the flow warp (imgs_pred 1.3e-3 vs 2.4e-4 against the reference golden, tolerance 1e-3), for a 1 % step-time gain,
+// so they keep exact fp32.
+static int bf16x3_min_rows() {
+    static const int v = [] { const char* e = getenv("AG2V_BF16X3_MIN_M"); return (e && atoi(e) > 0) ? atoi(e) : 128; }();
+    return v;
+}
+static bool use_bf16x3(int M) { return conv_precision() == 1 && M >= bf16x3_min_rows(); }
 static const long long kBufMax = (1LL << 32) - 64;   // raw buffer descriptors cover < 4 GiB
 
 static int launch_igemm(ConvArgs& a, hipStream_t st, bool out_zeroed, bool split) {

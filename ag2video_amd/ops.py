@@ -4,6 +4,8 @@ PyTorch supplies device memory, the current HIP stream and the autograd tape; al
 in the hand-written gfx950 kernels of ag2video_amd/csrc.  Every operator requires CUDA(HIP) fp32 tensors and raises
 otherwise -- there is no CPU path in the product (tests/ check these operators against oracle/ on the GPU).
 """
+import os
+
 import torch
 
 from . import _lib
@@ -56,8 +58,11 @@ def enable_kernel_timing(flag=True):
     _TIMING = [] if flag else None
 
 
+_BF16X3_MIN_M = int(os.environ.get('AG2V_BF16X3_MIN_M', '128') or 128)   # mirrors bf16x3_min_rows() in csrc/conv_igemm.hip
+
+
 def _conv_label(mode, M):
-    prec = get_conv_precision() if M >= 48 else 'fp32'      # the library sends GEMMs with >= 48 rows to the bf16x3 tiles
+    prec = get_conv_precision() if M >= _BF16X3_MIN_M else 'fp32'   # the library sends GEMMs with >= 128 rows to the bf16x3 tiles
     bm = 32 if M <= 32 else (64 if (M <= 64 and prec == 'fp32') else 128)
     return "conv_%s_bm%d_%s" % (mode, bm, prec)
 
