@@ -258,7 +258,7 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
         const int bcol0 = ptid % (BN / BCOLS), bpart = ptid / (BN / BCOLS) % BP;
         int bbase[BCOLS];
         unsigned vmask[BCOLS];
-    #pragma unroll
+#pragma unroll
         for (int c = 0; c < BCOLS; ++c) {
             const int pix = n0 + bcol0 + c * (BN / BCOLS);
             vmask[c] = 0;
@@ -284,28 +284,36 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
             }
         };
         auto fetch = [&](int kt, unsigned (&ra)[ACOLS][AK], float (&rb)[BCOLS][BKK]) {
+            // all table entries of this thread's k part first, in one batch: left to itself the compiler reads each entry
+            // inside the address select of its load (two dependent LDS round trips and an exec branch per load; 173 cycles
+            // per B load against 44 per A load on the in-kernel clocks of tools/ubench/igemm_stamps.hip)
+            int2 e[BKK];
+#pragma unroll
+            for (int i = 0; i < BKK; ++i) e[i] = tab[kt & 3][BKK * bpart + i];
+            asm volatile("" ::: "memory");
             const int ka = kt * BK + AK * apart;
-    #pragma unroll
+#pragma unroll
             for (int c = 0; c < ACOLS; ++c) {
                 const int m = m0 + acol0 + c * (BM / ACOLS);
-    #pragma unroll
+#pragma unroll
                 for (int i = 0; i < AK; ++i) ra[c][i] = bload_u32(ars, (m < p.M) ? (unsigned)(m + (ka + i) * p.M) * 4u : 0xFFFFFFFFu);
             }
-    #pragma unroll
+#pragma unroll
             for (int i = 0; i < BKK; ++i) {
-                const int2 e = tab[kt & 3][BKK * bpart + i];
-    #pragma unroll
-                for (int c = 0; c < BCOLS; ++c)
-                    rb[c][i] = bload_f32(brs, (vmask[c] & (unsigned)e.y) ? (unsigned)(bbase[c] + e.x) * 4u : 0xFFFFFFFFu);
+#pragma unroll
+                for (int c = 0; c < BCOLS; ++c) {
+                    const unsigned off = (unsigned)(bbase[c] + e[i].x) * 4u;
+                    rb[c][i] = bload_f32(brs, (vmask[c] & (unsigned)e[i].y) ? off : 0xFFFFFFFFu);
+                }
             }
         };
         auto stash = [&](int buf, const unsigned (&ra)[ACOLS][AK], const float (&rb)[BCOLS][BKK]) {
-    #pragma unroll
+#pragma unroll
             for (int c = 0; c < ACOLS; ++c)
-    #pragma unroll
+#pragma unroll
                 for (int g = 0; g < AK / 8; ++g) {
                     unsigned h[4], l[4];
-    #pragma unroll
+#pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         h[i] = __builtin_amdgcn_perm(ra[c][8 * g + 2 * i + 1], ra[c][8 * g + 2 * i], 0x07060302u);
                         l[i] = __builtin_amdgcn_perm(ra[c][8 * g + 2 * i + 1], ra[c][8 * g + 2 * i], 0x05040100u);
@@ -314,12 +322,12 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
                     *reinterpret_cast<uint4*>(&Ahi[buf][off]) = make_uint4(h[0], h[1], h[2], h[3]);
                     *reinterpret_cast<uint4*>(&Alo[buf][off]) = make_uint4(l[0], l[1], l[2], l[3]);
                 }
-    #pragma unroll
+#pragma unroll
             for (int c = 0; c < BCOLS; ++c)
-    #pragma unroll
+#pragma unroll
                 for (int g = 0; g < BKK / 8; ++g) {
                     unsigned h[4], l[4];
-    #pragma unroll
+#pragma unroll
                     for (int i = 0; i < 4; ++i) split2(rb[c][8 * g + 2 * i], rb[c][8 * g + 2 * i + 1], h[i], l[i]);
                     const int off = (bcol0 + c * (BN / BCOLS)) * LDK + BKK * bpart + 8 * g;
                     *reinterpret_cast<uint4*>(&Bhi[buf][off]) = make_uint4(h[0], h[1], h[2], h[3]);
@@ -329,25 +337,59 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
 
         unsigned ra0[ACOLS][AK], ra1[ACOLS][AK];
         float rb0[BCOLS][BKK], rb1[BCOLS][BKK];
+        // Register set 0 / 1 holds the even / odd K-tiles (relative to kt0).  Iteration t splits + stores tile t (loaded two
+        // iterations ago) into LDS buffer t&1, then refills the same registers with tile t+2 and meets the consumers at the
+        // barrier; the consumers multiply tile t after that barrier.  Every load has two full iterations to land and a
+        // register set is never written while its loads are in flight.  (The loop starts on the older set and the two
+        // prologue fetches are pinned in order, so that the compiler's vmcnt waits at the loop head stay partial.)
         build_tab(kt0);
         build_tab(kt0 + 1);
         build_tab(kt0 + 2);
+        build_tab(kt0 + 3);
         __syncthreads();
         fetch(kt0, ra0, rb0);
-        stash(0, ra0, rb0);
+        __builtin_amdgcn_sched_barrier(0);
         fetch(kt0 + 1, ra1, rb1);
-        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef AG2V_STAMPS
+        unsigned long long sa[3] = {0, 0, 0};
+#define STAMP(v) __builtin_amdgcn_sched_barrier(0); const unsigned long long v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
+#else
+#define STAMP(v)
+#endif
+        // No exit in the middle of the pair: a K-range with an odd tile count runs one surplus half-iteration (it stores a
+        // tile the consumers never multiply).  A mid-loop break merges "set 0 just refilled" into the loop-head state and the
+        // compiler then drains vmcnt to 0 at the top of every iteration.
         for (int kt = kt0; kt < nk; kt += 2) {
-            fetch(kt + 2, ra0, rb0);
-            build_tab(kt + 3);
-            stash(1, ra1, rb1);
-            __syncthreads();
-            if (kt + 1 >= nk) break;
-            fetch(kt + 3, ra1, rb1);
-            build_tab(kt + 4);
+            STAMP(c0)
             stash(0, ra0, rb0);
+            STAMP(c1)
+            build_tab(kt + 4);
+            fetch(kt + 2, ra0, rb0);
+            STAMP(c2)
             __syncthreads();
+            STAMP(c3)
+#ifdef AG2V_STAMPS
+            sa[0] += c2 - c1; sa[1] += c1 - c0; sa[2] += c3 - c2;
+#endif
+            STAMP(d0)
+            stash(1, ra1, rb1);
+            STAMP(d1)
+            build_tab(kt + 5);
+            fetch(kt + 3, ra1, rb1);
+            STAMP(d2)
+            __syncthreads();
+            STAMP(d3)
+#ifdef AG2V_STAMPS
+            sa[0] += d2 - d1; sa[1] += d1 - d0; sa[2] += d3 - d2;
+#endif
         }
+#ifdef AG2V_STAMPS
+        if (lane == 0 && p.stamps) {
+            unsigned long long* o = p.stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + wave) * 4;
+            o[0] = sa[0]; o[1] = sa[1]; o[2] = sa[2]; o[3] = nk - kt0;
+        }
+#endif
         return;
     }
 
@@ -388,11 +430,27 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
     };
 
     __syncthreads();
-    __syncthreads();
-    for (int kt = kt0; kt < nk; ++kt) {
-        compute((kt - kt0) & 1);
-        __syncthreads();
+#ifdef AG2V_STAMPS
+    unsigned long long sc[2] = {0, 0};
+#endif
+    const int nk2 = kt0 + ((nk - kt0 + 1) & ~1);   // the producers run an even number of iterations
+    for (int kt = kt0; kt < nk2; ++kt) {
+        STAMP(e0)
+        __syncthreads();   // tile kt is in LDS buffer (kt - kt0) & 1
+        STAMP(e1)
+        if (kt < nk) compute((kt - kt0) & 1);
+        STAMP(e2)
+#ifdef AG2V_STAMPS
+        sc[0] += e2 - e1; sc[1] += e1 - e0;
+#endif
     }
+#ifdef AG2V_STAMPS
+    if (lane == 0 && p.stamps) {
+        unsigned long long* o = p.stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + wave) * 4;
+        o[0] = sc[0]; o[1] = sc[1]; o[2] = 0; o[3] = nk - kt0;
+    }
+#endif
+#undef STAMP
 
     // ---- epilogue (consumers): C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     const int gplane = p.OH * p.OW;
@@ -663,18 +721,26 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_ws_k
             }
         };
         auto fetch = [&](int t, float (&ra)[2 * RA], float (&rb)[2 * RB]) {
+            // both table entries first; validity as bitwise (branch-free) predicates: with && the compiler builds an exec
+            // branch around every load
+            const int4 e0 = qtab[t & 3][2 * qp], e1 = qtab[t & 3][2 * qp + 1];
+            asm volatile("" ::: "memory");
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int4 e = qtab[t & 3][2 * qp + h];
+                const int4 e = h ? e1 : e0;
                 const int yb = e.z >> 16, xb = e.z & 0xFFFF;
 #pragma unroll
-                for (int i = 0; i < RA; ++i)
-                    ra[2 * i + h] = bload_f32(ars, (e.w && aoff[i] >= 0) ? (unsigned)(e.y + aoff[i]) * 4u : 0xFFFFFFFFu);
+                for (int i = 0; i < RA; ++i) {
+                    const bool ok = (e.w != 0) & (aoff[i] >= 0);
+                    const unsigned off = (unsigned)(e.y + aoff[i]) * 4u;
+                    ra[2 * i + h] = bload_f32(ars, ok ? off : 0xFFFFFFFFu);
+                }
 #pragma unroll
                 for (int i = 0; i < RB; ++i) {
                     const int iy = yb + (bpk[i] & 255) - 64, ix = xb + ((bpk[i] >> 8) & 255) - 64;
-                    const bool ok = e.w && (bpk[i] >> 16) && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                    rb[2 * i + h] = bload_f32(brs, ok ? (unsigned)(e.x + boff[i]) * 4u : 0xFFFFFFFFu);
+                    const bool ok = (e.w != 0) & ((bpk[i] >> 16) != 0) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+                    const unsigned off = (unsigned)(e.x + boff[i]) * 4u;
+                    rb[2 * i + h] = bload_f32(brs, ok ? off : 0xFFFFFFFFu);
                 }
             }
         };
@@ -697,23 +763,24 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_ws_k
             }
         };
         float ra0[2 * RA], ra1[2 * RA], rb0[2 * RB], rb1[2 * RB];
+        // stash tile t, refill its registers with tile t+2 (pipeline of conv_igemm_bf16x3_ws_kernel)
         build_tab(0);
         build_tab(1);
         build_tab(2);
+        build_tab(3);
         __syncthreads();
         fetch(0, ra0, rb0);
-        stash(0, ra0, rb0);
+        __builtin_amdgcn_sched_barrier(0);
         fetch(1, ra1, rb1);
-        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
         for (int t = 0; t < nt; t += 2) {
-            fetch(t + 2, ra0, rb0);
-            build_tab(t + 3);
-            stash(1, ra1, rb1);
-            __syncthreads();
-            if (t + 1 >= nt) break;
-            fetch(t + 3, ra1, rb1);
-            build_tab(t + 4);
             stash(0, ra0, rb0);
+            build_tab(t + 4);
+            fetch(t + 2, ra0, rb0);
+            __syncthreads();
+            stash(1, ra1, rb1);      // (no mid-pair exit: see conv_igemm_bf16x3_ws_kernel)
+            build_tab(t + 5);
+            fetch(t + 3, ra1, rb1);
             __syncthreads();
         }
         return;
@@ -754,10 +821,9 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_ws_k
         }
     };
     __syncthreads();
-    __syncthreads();
-    for (int t = 0; t < nt; ++t) {
-        compute(t & 1);
-        __syncthreads();
+    for (int t = 0; t < ((nt + 1) & ~1); ++t) {   // the producers run an even number of iterations
+        __syncthreads();   // tile t is in LDS buffer t & 1
+        if (t < nt) compute(t & 1);
     }
 
 #pragma unroll

@@ -17,6 +17,9 @@ struct ConvArgs {
     int tiles_m, tiles_n;
     unsigned a_bytes, b_bytes;  // byte sizes of a_src / b_src (bf16x3 kernels address them through 32-bit buffer offsets)
     int splitk, kchunk;     // igemm: K-range splits (grid.y) in K-tiles; wgrad: pixel-range splits, pixels per split
+#ifdef AG2V_STAMPS
+    unsigned long long* stamps;   // diagnostic build only (tools/ubench/igemm_stamps.hip): per-wave phase clocks
+#endif
 };
 
 // Division by the filter footprint: the shapes on the path get constant divisors.
