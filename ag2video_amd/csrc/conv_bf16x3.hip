@@ -847,7 +847,232 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_ws_k
     }
 }
 
+// Weight gradient for stride-1 convolutions with OW % 8 == 0: the K dimension of this GEMM is the pixel index q, which is
+// contiguous in memory for both operands (rows of dY; rows of x shifted by the tap), so a producer thread owns 8 consecutive
+// pixels of one row: two 16-byte buffer loads (4-byte aligned for the shifted x rows), 4 pair splits, and one 16-byte LDS store
+// for the hi and the lo image each -- against 8 dword loads and 8 ds_write_b32 in conv_wgrad_bf16x3_ws_kernel.  Only the first /
+// last element of a run can fall outside the image (pad <= 8 - ... checked by the launcher: pad <= S - 1 <= 7); such runs are
+// flagged per K-tile by the table builder and patched after the load.
+template <int BM, int BN, int CWM, int CWN, int NPW>
+__global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_v_kernel(ConvArgs p) {
+    constexpr int BK = 32, LDK = 40, NP = NPW * 64;
+    constexpr int TM = BM / CWM / 32, TN = BN / CWN / 32;
+    constexpr int RPT = NP / 4;                       // rows covered by one pass of the producer threads (4 runs of 8 q per row)
+    constexpr int NA = BM / RPT, NB = BN / RPT;       // A / B rows per producer thread
+    static_assert(BM % RPT == 0 && BN % RPT == 0, "producer mapping");
+    __shared__ __attribute__((aligned(16))) unsigned short Ahi[2][BM * LDK];
+    __shared__ __attribute__((aligned(16))) unsigned short Alo[2][BM * LDK];
+    __shared__ __attribute__((aligned(16))) unsigned short Bhi[2][BN * LDK];
+    __shared__ __attribute__((aligned(16))) unsigned short Blo[2][BN * LDK];
+    __shared__ int4 qtab[4][4];   // per run of 8 pixels of a K-tile: {x offset of tap (0,0), dY offset, (yb<<16)|xb, flags}
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wave < NPW;
+    const int lid = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int tile_m = lid % p.tiles_m, tile_n = lid / p.tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int RS = p.R * p.S;
+    const int OHW = p.OH * p.OW, HW = p.H * p.W;
+    const int Q = p.N * OHW;
+    const int qs = blockIdx.y * p.kchunk;
+    const int qe = min(qs + p.kchunk, Q);
+    if (qs >= qe) return;
+    const int nt = (qe - qs + BK - 1) / BK;
+
+    if (producer) {
+        const __amdgpu_buffer_rsrc_t ars = make_rsrc(p.a_src, p.a_bytes), brs = make_rsrc(p.b_src, p.b_bytes);
+        const int run = tid & 3, row = tid >> 2;      // run of 8 pixels inside the K-tile; rows / columns row + RPT i
+        int aoff[NA], boff[NB], bdy[NB], bdx[NB];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int m = m0 + row + RPT * i;
+            aoff[i] = (m < p.M) ? m * OHW : -1;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int j = n0 + row + RPT * i;
+            int c, r, s;
+            decode_crs(j, RS, p.S, c, r, s);
+            bdy[i] = (j < p.NG) ? r - p.pad : -(1 << 20);     // an invalid column never passes the row test
+            bdx[i] = s - p.pad;
+            boff[i] = c * HW + (r - p.pad) * p.W + (s - p.pad);
+        }
+        auto build_tab = [&](int t) {   // t = tile index relative to qs
+            if (tid < 4) {
+                const int q = qs + t * BK + tid * 8;
+                const bool v = q < qe;   // Q % 8 == 0 and qs % 8 == 0: a run is entirely inside or outside the range
+                const int qc = v ? q : qs;
+                const int n = qc / OHW;
+                const int pixl = qc - n * OHW;
+                const int oy = pixl / p.OW, ox = pixl - oy * p.OW;
+                // border run: some tap column reaches outside [0, W) for its first or last pixels
+                const bool border = (ox - p.pad < 0) | (ox + 7 + (p.S - 1 - p.pad) >= p.W);
+                qtab[t & 3][tid] = make_int4(n * p.C * HW + oy * p.W + ox, n * p.K * OHW + pixl, (oy << 16) | ox,
+                                             (v ? 1 : 0) | (border ? 2 : 0));
+            }
+        };
+        // fix word: bit (2 i) / (2 i + 1) set when B row i needs its leading / trailing elements patched (see stash)
+        auto fetch = [&](int t, u32x4 (&ra)[NA][2], u32x4 (&rb)[NB][2], int& fixw, int& fixx) {
+            const int4 e = qtab[t & 3][run];
+            asm volatile("" ::: "memory");
+            const int yb = e.z >> 16, xb = e.z & 0xFFFF;
+            const bool valid = (e.w & 1) != 0;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const bool ok = valid & (aoff[i] >= 0);
+                const unsigned off = ok ? (unsigned)(e.y + aoff[i]) * 4u : 0xFFFFFFE0u;
+                ra[i][0] = bload_u32x4(ars, off);
+                ra[i][1] = bload_u32x4(ars, off + 16u);
+            }
+            fixw = (e.w & 2) ? 1 : 0;
+            fixx = xb;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int iy = yb + bdy[i];
+                const bool ok = valid & ((unsigned)iy < (unsigned)p.H);
+                const int o = e.x + boff[i];
+                if (__builtin_expect(ok & (o < 0), 0)) {
+                    // the run starts before the first element of the tensor (image 0, channel 0, row 0, x = -1..): element loads
+                    unsigned v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = bload_u32(brs, (o + k >= 0) ? (unsigned)(o + k) * 4u : 0xFFFFFFFFu);
+                    rb[i][0] = u32x4{v[0], v[1], v[2], v[3]};
+                    rb[i][1] = u32x4{v[4], v[5], v[6], v[7]};
+                } else {
+                    const unsigned off = ok ? (unsigned)o * 4u : 0xFFFFFFE0u;
+                    rb[i][0] = bload_u32x4(brs, off);
+                    rb[i][1] = bload_u32x4(brs, off + 16u);
+                }
+            }
+        };
+        auto store_row = [&](unsigned short* hi_img, unsigned short* lo_img, int r, const u32x4 (&v)[2]) {
+            unsigned h[4], l[4];
+            split2(__uint_as_float(v[0][0]), __uint_as_float(v[0][1]), h[0], l[0]);
+            split2(__uint_as_float(v[0][2]), __uint_as_float(v[0][3]), h[1], l[1]);
+            split2(__uint_as_float(v[1][0]), __uint_as_float(v[1][1]), h[2], l[2]);
+            split2(__uint_as_float(v[1][2]), __uint_as_float(v[1][3]), h[3], l[3]);
+            const int off = r * LDK + 8 * run;
+            *reinterpret_cast<uint4*>(&hi_img[off]) = make_uint4(h[0], h[1], h[2], h[3]);
+            *reinterpret_cast<uint4*>(&lo_img[off]) = make_uint4(l[0], l[1], l[2], l[3]);
+        };
+        auto stash = [&](int buf, const u32x4 (&ra)[NA][2], u32x4 (&rb)[NB][2], int fixw, int fixx) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) store_row(Ahi[buf], Alo[buf], row + RPT * i, ra[i]);
+            if (fixw) {   // (almost) wave-uniform: the 4 runs of a K-tile are 32 consecutive pixels
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    const int ix0 = fixx + bdx[i];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if ((unsigned)(ix0 + k) >= (unsigned)p.W) rb[i][k >> 2][k & 3] = 0u;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) store_row(Bhi[buf], Blo[buf], row + RPT * i, rb[i]);
+        };
+        u32x4 ra0[NA][2], ra1[NA][2], rb0[NB][2], rb1[NB][2];
+        int fw0, fx0, fw1, fx1;
+        build_tab(0);
+        build_tab(1);
+        build_tab(2);
+        build_tab(3);
+        __syncthreads();
+        fetch(0, ra0, rb0, fw0, fx0);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(1, ra1, rb1, fw1, fx1);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int t = 0; t < nt; t += 2) {       // pipeline of conv_igemm_bf16x3_ws_kernel
+            stash(0, ra0, rb0, fw0, fx0);
+            build_tab(t + 4);
+            fetch(t + 2, ra0, rb0, fw0, fx0);
+            __syncthreads();
+            stash(1, ra1, rb1, fw1, fx1);
+            build_tab(t + 5);
+            fetch(t + 3, ra1, rb1, fw1, fx1);
+            __syncthreads();
+        }
+        return;
+    }
+
+    const int cw = wave - NPW;
+    const int wm0 = (cw / CWN) * (TM * 32), wn0 = (cw % CWN) * (TN * 32);
+    const int fr = lane & 31, fh = lane >> 5;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 bhi[TN], blo[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int o = (wn0 + j * 32 + fr) * LDK + ks * 16 + 8 * fh;
+                bhi[j] = *reinterpret_cast<const bf16x8*>(&Bhi[buf][o]);
+                blo[j] = *reinterpret_cast<const bf16x8*>(&Blo[buf][o]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int o = (wm0 + i * 32 + fr) * LDK + ks * 16 + 8 * fh;
+                const bf16x8 ahi = *reinterpret_cast<const bf16x8*>(&Ahi[buf][o]);
+                const bf16x8 alo = *reinterpret_cast<const bf16x8*>(&Alo[buf][o]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+    };
+    __syncthreads();
+    for (int t = 0; t < ((nt + 1) & ~1); ++t) {   // the producers run an even number of iterations
+        __syncthreads();   // tile t is in LDS buffer t & 1
+        if (t < nt) compute(t & 1);
+    }
+
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int colj = n0 + wn0 + j * 32 + (lane & 31);
+        if (colj >= p.NG) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < p.M) {
+                    float* dst = p.out + (size_t)m * p.NG + colj;
+                    if (p.splitk > 1)
+                        atomicAdd(dst, acc[i][j][r]);
+                    else
+                        *dst = acc[i][j][r];
+                }
+            }
+        }
+    }
+}
+
 // ================================================================ launchers
+// One 16-wave workgroup occupies a CU (124 KB LDS), so a launch runs in rounds of 256 workgroups.  Pick the number of K-range
+// splits that minimises  rounds * (K-tiles per split + overhead)  -- overhead ~ 8 K-tiles for the exposed first loads, the
+// epilogue and (with splits) its atomics -- instead of a fixed "fill the chip" factor that can leave a nearly empty last round.
+static int pick_splits(int tiles, int nk, int max_splits) {
+    int best = 1;
+    long long best_cost = -1;
+    for (int sk = 1; sk <= max_splits; ++sk) {
+        const int chunk = ceil_div(nk, sk);
+        if (sk > 1 && ceil_div(nk, chunk) != sk) continue;          // same chunking as a smaller split count
+        const long long rounds = ceil_div(tiles * sk, 256);
+        const long long cost = rounds * (chunk + (sk > 1 ? 12 : 8));
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = sk; }
+    }
+    return best;
+}
+
 int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed) {
     const bool tall = a.M >= 192;                 // 256 x 128 tile when there are enough output channels, else 128 x 256
     const int bm = tall ? 256 : 128, bn = tall ? 128 : 256;
@@ -855,9 +1080,8 @@ int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed) {
     a.tiles_n = ceil_div(a.NG, bn);
     const int tiles = a.tiles_m * a.tiles_n, nk = ceil_div(a.KG, 32);
     a.splitk = 1; a.kchunk = nk;
-    if (tiles < 256 && nk >= 8) {                 // one 8-wave workgroup per CU: fill the chip through split-K
-        int sk = ceil_div(512, tiles);
-        if (sk > nk / 4) sk = nk / 4;
+    if (tiles < 1024 && nk >= 8) {
+        const int sk = pick_splits(tiles, nk, nk / 4 < 64 ? nk / 4 : 64);
         if (sk > 1) {
             a.kchunk = ceil_div(nk, sk);
             a.splitk = ceil_div(nk, a.kchunk);
@@ -898,12 +1122,9 @@ int launch_wgrad_bf16x3(ConvArgs& a, hipStream_t st) {
     a.tiles_n = ceil_div(a.NG, bn);
     const int tiles = a.tiles_m * a.tiles_n;
     const long long Q = a.KG;
-    int splitk = ceil_div(768, tiles);            // ~3 workgroups of 8 waves per CU in flight
-    const int max_split = (int)((Q + 1023) / 1024);
-    if (splitk > max_split) splitk = max_split;
-    if (splitk < 1) splitk = 1;
-    int kchunk = (int)((Q + splitk - 1) / splitk);
-    kchunk = ((kchunk + 31) / 32) * 32;
+    const int nq = (int)((Q + 31) / 32);          // K-tiles (32 pixels each)
+    int splitk = pick_splits(tiles, nq, nq / 8 < 256 ? (nq / 8 > 0 ? nq / 8 : 1) : 256);
+    int kchunk = ceil_div(nq, splitk) * 32;
     splitk = (int)((Q + kchunk - 1) / kchunk);
     a.splitk = splitk; a.kchunk = kchunk;
     if (splitk > 1) {
@@ -916,6 +1137,13 @@ int launch_wgrad_bf16x3(ConvArgs& a, hipStream_t st) {
             hipLaunchKernelGGL((conv_wgrad_bf16x3_kernel<256, 128, 4, 2>), grid, dim3(NT), 0, st, a);
         else
             hipLaunchKernelGGL((conv_wgrad_bf16x3_kernel<128, 256, 2, 4>), grid, dim3(NT), 0, st, a);
+    } else if (a.stride == 1 && a.OW % 8 == 0 && a.W >= 8 && a.pad <= 7 && a.S - 1 - a.pad <= 7 &&
+               getenv("AG2V_WGRAD_SCALAR_LOADS") == nullptr) {
+        // 16-byte loads along the pixel index (runs of 8 pixels never straddle an image row)
+        if (tall)
+            hipLaunchKernelGGL((conv_wgrad_bf16x3_v_kernel<256, 128, 4, 2, 8>), grid, dim3(1024), 0, st, a);
+        else
+            hipLaunchKernelGGL((conv_wgrad_bf16x3_v_kernel<128, 256, 2, 4, 8>), grid, dim3(1024), 0, st, a);
     } else {
         if (tall)
             hipLaunchKernelGGL((conv_wgrad_bf16x3_ws_kernel<256, 128, 4, 2, 8>), grid, dim3(1024), 0, st, a);

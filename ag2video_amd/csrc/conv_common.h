@@ -77,6 +77,13 @@ __device__ __forceinline__ float bload_f32(__amdgpu_buffer_rsrc_t r, unsigned by
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
 }
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// 16-byte raw buffer load (4-byte alignment suffices; range checking is per dword at the END of the buffer, but an offset
+// that wraps below 0 reads 0 in all four dwords -- tools/ubench/loads.hip)
+__device__ __forceinline__ u32x4 bload_u32x4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+}
+
 // launchers implemented in conv_bf16x3.hip
 int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed);
 int launch_wgrad_bf16x3(ConvArgs& a, hipStream_t st);

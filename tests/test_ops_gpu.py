@@ -68,6 +68,12 @@ CONV_CASES = [
     (4, 128, 16, 16, 200, 3, 3, 1, 1, True, False),
     (2, 40, 9, 9, 150, 1, 1, 2, 0, False, False),     # 1x1 stride 2: three of the four parity classes are empty
     (2, 12, 20, 18, 24, 3, 3, 2, 1, True, False),
+    # >= 128 output channels, stride 1, OW % 8 == 0: weight gradient through the 16-byte-load kernel (runs of 8 pixels)
+    (2, 24, 8, 24, 136, 3, 3, 1, 1, True, False),     # H != W
+    (2, 12, 7, 15, 130, 4, 4, 1, 2, False, False),    # pad 2: two leading / one trailing element of a border run outside
+    (3, 16, 8, 8, 256, 1, 1, 1, 0, False, False),     # 1x1
+    (2, 10, 12, 10, 128, 3, 3, 1, 0, True, False),    # pad 0, OW = 8 < W
+    (1, 5, 40, 40, 192, 3, 3, 1, 1, False, True),     # pixel count not a multiple of the K-tile of a split
 ]
 
 
