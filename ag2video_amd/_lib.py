@@ -36,6 +36,7 @@ _SIGS = {
     'ag2v_avgpool3s2_bwd': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     'ag2v_nearest_resize_fwd': (c_int, [_P, _P] + [c_int] * 5 + [_P]),
     'ag2v_nearest_resize_bwd': (c_int, [_P, _P] + [c_int] * 5 + [_P]),
+    'ag2v_nearest_pyramid_bwd': (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P]),
     'ag2v_triple_gather_fwd': (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [_P]),
     'ag2v_triple_gather_bwd': (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [_P]),
     'ag2v_triple_pool_fwd': (c_int, [_P] * 5 + [c_int] * 5 + [_P]),

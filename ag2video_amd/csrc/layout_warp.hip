@@ -487,6 +487,39 @@ __global__ __launch_bounds__(256) void nearest_resize_bwd_kernel(const float* __
     dx[idx] = s;
 }
 
+// Adjoint of a nearest-neighbour pyramid: one full-resolution map x[NC,H,W] was down-sampled (integer factors) to up to 8
+// levels, each used by some SPADE layers (normalization.py:102 -- F.interpolate(segmap, size, 'nearest') in every SPADE).
+// dx = g_full + sum_l scatter(g_l): level l with factors (fy, fx) sends g_l[y, x] to dx[y*fy, x*fx].  One pass: every dx
+// element is written once (4 consecutive x per thread), instead of one full-size scatter + one full-size add per level.
+struct PyramidLevels {
+    const float* g[8];
+    int h[8], w[8], fy[8], fx[8];
+    int n;
+};
+__global__ __launch_bounds__(256) void nearest_pyramid_bwd_kernel(const float* __restrict__ g_full, PyramidLevels lv,
+                                                                  float* __restrict__ dx, long long total4, int H, int W) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;   // one float4 of dx
+    if (idx >= total4) return;
+    const int W4 = W >> 2;
+    const int x0 = (int)(idx % W4) * 4;
+    const long long r = idx / W4;
+    const int y = (int)(r % H);
+    const long long nc = r / H;
+    float4 v = g_full ? reinterpret_cast<const float4*>(g_full)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float* ve = reinterpret_cast<float*>(&v);
+    for (int l = 0; l < lv.n; ++l) {
+        const int fy = lv.fy[l], fx = lv.fx[l];
+        if (y % fy) continue;
+        const float* gp = lv.g[l] + ((size_t)nc * lv.h[l] + y / fy) * lv.w[l];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int x = x0 + e;
+            if (x % fx == 0) ve[e] += gp[x / fx];
+        }
+    }
+    reinterpret_cast<float4*>(dx)[idx] = v;
+}
+
 // ================================================================ C ABI
 extern "C" int ag2v_layout_render_fwd(const float* vecs, const float* boxes, const int* keep, float* out, int BT, int O, int D,
                                       int H, int W, void* stream) {
@@ -598,6 +631,26 @@ extern "C" int ag2v_nearest_resize_bwd(const float* dy, float* dx, int NC, int H
     if (!dy || !dx || NC <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return AG2V_EINVAL;
     const long long total = (long long)NC * H * W;
     hipLaunchKernelGGL(nearest_resize_bwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, total, H, W, OH, OW);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+
+// dx[NC,H,W] = g_full (nullable) + sum over levels of the nearest-neighbour scatter of g_levels[l] ([NC, hs[l], ws[l]]; H % hs[l] == 0,
+// W % ws[l] == 0; null entries are skipped).  g_levels / hs / ws are HOST arrays of n_levels (<= 8) entries.
+extern "C" int ag2v_nearest_pyramid_bwd(const float* g_full, const float* const* g_levels, const int* hs, const int* ws, int n_levels,
+                                        float* dx, int NC, int H, int W, void* stream) {
+    if (!dx || NC <= 0 || H <= 0 || W <= 0 || (W & 3) || n_levels < 0 || n_levels > 8 || (n_levels && (!g_levels || !hs || !ws)))
+        return AG2V_EINVAL;
+    PyramidLevels lv{};
+    for (int l = 0; l < n_levels; ++l) {
+        if (!g_levels[l]) continue;
+        if (hs[l] <= 0 || ws[l] <= 0 || H % hs[l] || W % ws[l]) return AG2V_EINVAL;
+        lv.g[lv.n] = g_levels[l]; lv.h[lv.n] = hs[l]; lv.w[lv.n] = ws[l]; lv.fy[lv.n] = H / hs[l]; lv.fx[lv.n] = W / ws[l];
+        ++lv.n;
+    }
+    const long long total4 = (long long)NC * H * (W >> 2);
+    hipLaunchKernelGGL(nearest_pyramid_bwd_kernel, dim3(ceil_div(total4, 256)), dim3(256), 0, (hipStream_t)stream, g_full, lv, dx,
+                       total4, H, W);
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
 }

@@ -77,11 +77,18 @@ def get_nonspade_norm_layer(opt, norm_type='instance'):
 
 
 class SegmapPyramid(object):
-    """Memo of F.interpolate(segmap, size, 'nearest') per target size for one decoder pass (autograd sums the uses)."""
+    """F.interpolate(segmap, size, 'nearest') for every SPADE of one decoder pass (normalization.py:102).  Each SPADE of the
+    reference resizes the same map again; here the map is resized once per size, and -- when ``sizes`` lists the decoder's
+    resolutions up front -- all sizes belong to one autograd node whose backward writes the map's gradient in a single pass
+    (ops.nearest_pyramid) instead of one full-size scatter and one full-size accumulation per size."""
 
-    def __init__(self, segmap):
+    def __init__(self, segmap, sizes=None):
         self.segmap = segmap
         self._cache = {}
+        if sizes:
+            sizes = sorted(set((int(h), int(w)) for (h, w) in sizes))
+            for key, t in zip(sizes, ops.nearest_pyramid(segmap, sizes)):
+                self._cache[key] = t
 
     def at(self, h, w):
         key = (int(h), int(w))

@@ -36,8 +36,13 @@ class SPADEGenerator(nn.Module):
         sh = round(sw / opt.aspect_ratio)
         return sw, sh
 
+    def pyramid_sizes(self, H, W):
+        """Resolutions at which forward() evaluates SPADE layers: (sh, sw) doubled once per up-sampling."""
+        n_up = {'normal': 5, 'more': 6, 'most': 7}[self.opt.num_upsampling_layers]
+        return [(self.sh << i, self.sw << i) for i in range(n_up + 1)]
+
     def forward(self, layout):
-        layout = SegmapPyramid(layout)
+        layout = SegmapPyramid(layout, self.pyramid_sizes(layout.shape[2], layout.shape[3]))
         x = layout.at(self.sh, self.sw)
         x = self.fc(x)
         x = self.head_0(x, layout)

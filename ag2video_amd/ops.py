@@ -431,6 +431,63 @@ def nearest_resize(x, OH, OW):
     return _NearestResize.apply(x, int(OH), int(OW))
 
 
+class _NearestPyramid(torch.autograd.Function):
+    """All nearest-neighbour resizes of one map in one node: forward = one resize per requested size (the full size is the
+    map itself); backward = ONE kernel that writes every element of the map's gradient once."""
+
+    @staticmethod
+    def forward(ctx, x, sizes):
+        x = _c(x)
+        _chk(x)
+        N, C, H, W = x.shape
+        outs = []
+        for (h, w) in sizes:
+            if (h, w) == (H, W):
+                outs.append(x.view_as(x))
+                continue
+            y = torch.empty((N, C, h, w), device=x.device, dtype=torch.float32)
+            _lib.call('ag2v_nearest_resize_fwd', _ptr(x), _ptr(y), N * C, H, W, h, w, _stream())
+            outs.append(y)
+        ctx.cfg = (N, C, H, W, tuple(sizes))
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        import ctypes
+        N, C, H, W, sizes = ctx.cfg
+        g_full = None
+        lv, hs, ws, keep = [], [], [], []
+        for (h, w), g in zip(sizes, grads):
+            if g is None:
+                continue
+            g = g.contiguous()
+            keep.append(g)
+            if (h, w) == (H, W):
+                g_full = g if g_full is None else g_full + g
+            else:
+                lv.append(g.data_ptr()); hs.append(h); ws.append(w)
+        dev = keep[0].device
+        dx = torch.empty((N, C, H, W), device=dev, dtype=torch.float32)
+        n = len(lv)
+        arr_p = (ctypes.c_void_p * max(n, 1))(*lv)
+        arr_h = (ctypes.c_int * max(n, 1))(*hs)
+        arr_w = (ctypes.c_int * max(n, 1))(*ws)
+        _lib.call('ag2v_nearest_pyramid_bwd', _ptr(g_full), ctypes.cast(arr_p, ctypes.c_void_p), ctypes.cast(arr_h, ctypes.c_void_p),
+                  ctypes.cast(arr_w, ctypes.c_void_p), n, _ptr(dx), N * C, H, W, _stream())
+        return dx, None
+
+
+def nearest_pyramid(x, sizes):
+    """Nearest-neighbour resizes of x (NCHW) to each (h, w) of ``sizes`` -- every one an integer down-sampling of x or x's own
+    size, W % 4 == 0 and at most 8 levels -- as one autograd node with a fused backward.  Returns a tuple of tensors."""
+    H, W = int(x.shape[2]), int(x.shape[3])
+    sizes = tuple((int(h), int(w)) for (h, w) in sizes)
+    ok = (W % 4 == 0) and len(sizes) <= 8 and all(H % h == 0 and W % w == 0 for (h, w) in sizes)
+    if not ok:
+        return tuple(nearest_resize(x, h, w) for (h, w) in sizes)
+    return _NearestPyramid.apply(x, sizes)
+
+
 def upsample2x(x):
     return _NearestResize.apply(x, int(x.shape[2] * 2), int(x.shape[3] * 2))
 

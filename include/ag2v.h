@@ -84,6 +84,11 @@ int ag2v_avgpool3s2_fwd(const float* x, float* y, int NC, int H, int W, void* st
 int ag2v_avgpool3s2_bwd(const float* dy, float* dx, int NC, int H, int W, void* stream);
 int ag2v_nearest_resize_fwd(const float* x, float* y, int NC, int H, int W, int OH, int OW, void* stream);
 int ag2v_nearest_resize_bwd(const float* dy, float* dx, int NC, int H, int W, int OH, int OW, void* stream);
+/* Adjoint of the whole nearest-neighbour pyramid of one segmentation map (every SPADE of a decoder pass interpolates the same map,
+ * normalization.py:102): dx = g_full (nullable) + sum_l scatter(g_levels[l]); g_levels / hs / ws are host arrays of n_levels <= 8
+ * entries (null level pointers are skipped), every level an integer down-sampling of H x W; W % 4 == 0. */
+int ag2v_nearest_pyramid_bwd(const float* g_full, const float* const* g_levels, const int* hs, const int* ws, int n_levels,
+                             float* dx, int NC, int H, int W, void* stream);
 
 /* ---- action-graph convolution: GraphTripleConv.forward models/graph_models/graph.py:41-107 ---------------------
  * edges int64 [B,T,2]; valid uint8 [B,T] (pred_indicators).  gather: graph.py:64-68; pool: graph.py:79-100 */

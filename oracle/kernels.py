@@ -122,6 +122,11 @@ def nearest_resize(x, OH, OW):
     return F.interpolate(x, size=(OH, OW), mode='nearest')
 
 
+def nearest_pyramid(x, sizes):
+    """The per-SPADE F.interpolate(segmap, size, 'nearest') calls of one decoder pass (normalization.py:102), one per size."""
+    return tuple(nearest_resize(x, h, w) for (h, w) in sizes)
+
+
 def upsample2x(x):
     """nn.Upsample(scale_factor=2) (spade_generator.py:36, flows_generator.py:47)."""
     return F.interpolate(x, scale_factor=2, mode='nearest')

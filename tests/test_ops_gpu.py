@@ -257,6 +257,33 @@ def test_nearest_resize(cfg, device):
     _run_pair(ops.nearest_resize, K.nearest_resize, {'x': _rand(*shape, seed=1), 'OH': OH, 'OW': OW}, device, name='nearest')
 
 
+@pytest.mark.parametrize("cfg", [((2, 6, 64, 64), [(2, 2), (4, 4), (8, 8), (16, 16), (32, 32), (64, 64)], None),
+                                 ((1, 3, 32, 64), [(32, 64), (4, 8), (16, 32)], (4, 8)),       # one level never used
+                                 ((2, 5, 48, 24), [(16, 8), (48, 24), (24, 12)], None),        # factor 3, non power of two
+                                 ((1, 2, 30, 20), [(7, 9), (30, 20)], None)], ids=str)         # not an integer pyramid: fallback
+def test_nearest_pyramid(cfg, device):
+    """ops.nearest_pyramid (fused backward over all levels) against one oracle nearest_resize per level."""
+    from ag2video_amd import ops
+    from oracle import kernels as K
+    shape, sizes, unused = cfg
+    x = _rand(*shape, seed=1)
+    xc, xg = x.clone().requires_grad_(True), x.clone().to(device).requires_grad_(True)
+    got = ops.nearest_pyramid(xg, sizes)
+    assert len(got) == len(sizes)
+    lref, lgot = 0.0, 0.0
+    for i, ((h, w), yg) in enumerate(zip(sizes, got)):
+        yr = K.nearest_resize(xc, h, w)
+        _cmp('pyramid.fwd%d' % i, yg, yr, TOL)
+        if (h, w) == unused:
+            continue
+        wgt = _rand(*yr.shape, seed=10 + i)
+        lref = lref + (yr * wgt).sum() * (i + 1)
+        lgot = lgot + (yg * wgt.to(device)).sum() * (i + 1)
+    lref.backward()
+    lgot.backward()
+    _cmp('pyramid.grad', xg.grad, xc.grad, TOL)
+
+
 def test_upsample2x(device):
     from ag2video_amd import ops
     from oracle import kernels as K
