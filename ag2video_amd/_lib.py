@@ -15,6 +15,8 @@ _SIGS = {
     # name: (restype, [argtypes])
     'ag2v_set_conv_precision': (c_int, [c_int]),
     'ag2v_get_conv_precision': (c_int, []),
+    'ag2v_set_bf16x3_min_rows': (c_int, [c_int]),
+    'ag2v_get_bf16x3_min_rows': (c_int, []),
     'ag2v_conv2d_workspace_floats': (c_size_t, [c_int] * 4),
     'ag2v_conv2d_fwd': (c_int, [_P, _P, _P, _P, _P] + [c_int] * 9 + [_P, _P]),
     'ag2v_conv2d_dgrad': (c_int, [_P, _P, _P] + [c_int] * 9 + [_P, _P]),

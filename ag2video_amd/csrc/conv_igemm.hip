@@ -365,10 +365,20 @@ extern "C" int ag2v_get_conv_precision(void) { return conv_precision(); }
 // are the full-resolution tails of the flow and image decoders: on the random-init toy their 1e-5 split error is amplified
 // ~100x by the flow warp (imgs_pred 1.3e-3 vs 2.4e-4 against the reference golden, tolerance 1e-3), for a 1 % step-time gain,
 // so they keep exact fp32.
+static int g_bf16x3_min_rows = -1;
 static int bf16x3_min_rows() {
-    static const int v = [] { const char* e = getenv("AG2V_BF16X3_MIN_M"); return (e && atoi(e) > 0) ? atoi(e) : 128; }();
-    return v;
+    if (g_bf16x3_min_rows < 0) {
+        const char* e = getenv("AG2V_BF16X3_MIN_M");
+        g_bf16x3_min_rows = (e && atoi(e) > 0) ? atoi(e) : 128;
+    }
+    return g_bf16x3_min_rows;
 }
+extern "C" int ag2v_set_bf16x3_min_rows(int rows) {
+    if (rows < 1) return AG2V_EINVAL;
+    g_bf16x3_min_rows = rows;
+    return AG2V_OK;
+}
+extern "C" int ag2v_get_bf16x3_min_rows(void) { return bf16x3_min_rows(); }
 static bool use_bf16x3(int M) { return conv_precision() == 1 && M >= bf16x3_min_rows(); }
 static const long long kBufMax = (1LL << 32) - 64;   // raw buffer descriptors cover < 4 GiB
 

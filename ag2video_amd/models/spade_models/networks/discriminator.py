@@ -105,6 +105,10 @@ class MultiscaleActionDiscriminator(nn.Module):
 
     def forward(self, img, objs, layout_boxes, actions_data):
         """img [B,T,3,H,W], layout_boxes [B,T,O,4] -> num_D lists of n_layers_D+1 feature maps over [B*T, ...]."""
+        with ops.bf16x3_min_rows(48):      # the 64-channel first layers too (no warp downstream: ops.bf16x3_min_rows)
+            return self._forward(img, objs, layout_boxes, actions_data)
+
+    def _forward(self, img, objs, layout_boxes, actions_data):
         H = self.opt.image_size[0]
         ov = self.get_obj_vecs(objs, layout_boxes, actions_data)
         att = self.attribute_embedding(objs)

@@ -58,13 +58,50 @@ def enable_kernel_timing(flag=True):
     _TIMING = [] if flag else None
 
 
-_BF16X3_MIN_M = int(os.environ.get('AG2V_BF16X3_MIN_M', '128') or 128)   # mirrors bf16x3_min_rows() in csrc/conv_igemm.hip
+# ---- which GEMMs take the bf16x3 tiles.  The library default (128 rows, AG2V_BF16X3_MIN_M) is the conservative policy; the
+# model code lowers it for the image decoder and the discriminator, and keeps 128 inside the flow network: there the
+# 64-channel full-resolution tail feeds the warp, which amplifies its 1e-5 split error ~100x on the reference golden toy
+# (imgs_pred 1.3e-3 against a 1e-3 tolerance), everywhere else the error stays at 1e-5.
+_MIN_ROWS_STACK = []
 
 
-def _conv_label(mode, M):
-    prec = get_conv_precision() if M >= _BF16X3_MIN_M else 'fp32'   # the library sends GEMMs with >= 128 rows to the bf16x3 tiles
+class bf16x3_min_rows(object):
+    """Context manager: convolutions *created* inside (forward and, later, their backward) send GEMMs with at least ``rows``
+    rows to the bf16x3 tiles."""
+
+    def __init__(self, rows):
+        self.rows = int(rows)
+
+    def __enter__(self):
+        _MIN_ROWS_STACK.append(self.rows)
+        return self
+
+    def __exit__(self, *exc):
+        _MIN_ROWS_STACK.pop()
+        return False
+
+
+def _current_min_rows():
+    return _MIN_ROWS_STACK[-1] if _MIN_ROWS_STACK else None
+
+
+def _conv_label(mode, M, min_rows=None):
+    lim = min_rows if min_rows is not None else _lib.query('ag2v_get_bf16x3_min_rows')
+    prec = get_conv_precision() if M >= lim else 'fp32'
     bm = 32 if M <= 32 else (64 if (M <= 64 and prec == 'fp32') else 128)
     return "conv_%s_bm%d_%s" % (mode, bm, prec)
+
+
+def _conv_launch(min_rows, name, label, flops, *args, shape=None):
+    """_launch with the library's bf16x3 row threshold set to ``min_rows`` for this call (None: library default)."""
+    if min_rows is None:
+        return _launch(name, label, flops, *args, shape=shape)
+    old = _lib.query('ag2v_get_bf16x3_min_rows')
+    _lib.call('ag2v_set_bf16x3_min_rows', min_rows)
+    try:
+        _launch(name, label, flops, *args, shape=shape)
+    finally:
+        _lib.call('ag2v_set_bf16x3_min_rows', old)
 
 
 def _launch(name, label, flops, *args, shape=None):
@@ -106,17 +143,18 @@ class _Conv2d(torch.autograd.Function):
         OW = (W + 2 * pad - S) // stride + 1
         y = torch.empty((N, K, OH, OW), device=x.device, dtype=torch.float32)
         ws = torch.empty(_lib.query('ag2v_conv2d_workspace_floats', C, K, R, S), device=x.device, dtype=torch.float32)
-        _launch('ag2v_conv2d_fwd', _conv_label('fwd', K), 2.0 * N * K * OH * OW * C * R * S,
-                _ptr(x), _ptr(w), _ptr(bias), _ptr(residual), _ptr(y), N, C, H, W, K, R, S, stride, pad, _ptr(ws), _stream(),
-                shape=(N, C, H, W, K, R, stride))
+        mr = _current_min_rows()
+        _conv_launch(mr, 'ag2v_conv2d_fwd', _conv_label('fwd', K, mr), 2.0 * N * K * OH * OW * C * R * S,
+                     _ptr(x), _ptr(w), _ptr(bias), _ptr(residual), _ptr(y), N, C, H, W, K, R, S, stride, pad, _ptr(ws), _stream(),
+                     shape=(N, C, H, W, K, R, stride))
         ctx.save_for_backward(x, w)
-        ctx.cfg = (stride, pad, bias is not None, residual is not None)
+        ctx.cfg = (stride, pad, bias is not None, residual is not None, mr)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        stride, pad, has_bias, has_res = ctx.cfg
+        stride, pad, has_bias, has_res, mr = ctx.cfg
         dy = dy.contiguous()
         N, C, H, W = x.shape
         K, _, R, S = w.shape
@@ -126,14 +164,14 @@ class _Conv2d(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             ws = torch.empty(_lib.query('ag2v_conv2d_workspace_floats', C, K, R, S), device=dy.device, dtype=torch.float32)
-            _launch('ag2v_conv2d_dgrad', _conv_label('dgrad', C), flops,
-                    _ptr(dy), _ptr(w), _ptr(dx), N, C, H, W, K, R, S, stride, pad, _ptr(ws), st,
-                    shape=(N, C, H, W, K, R, stride))
+            _conv_launch(mr, 'ag2v_conv2d_dgrad', _conv_label('dgrad', C, mr), flops,
+                         _ptr(dy), _ptr(w), _ptr(dx), N, C, H, W, K, R, S, stride, pad, _ptr(ws), st,
+                         shape=(N, C, H, W, K, R, stride))
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
-            _launch('ag2v_conv2d_wgrad', _conv_label('wgrad', K), flops,
-                    _ptr(dy), _ptr(x), _ptr(dw), N, C, H, W, K, R, S, stride, pad, st,
-                    shape=(N, C, H, W, K, R, stride))
+            _conv_launch(mr, 'ag2v_conv2d_wgrad', _conv_label('wgrad', K, mr), flops,
+                         _ptr(dy), _ptr(x), _ptr(dw), N, C, H, W, K, R, S, stride, pad, st,
+                         shape=(N, C, H, W, K, R, stride))
         if has_bias and ctx.needs_input_grad[2]:
             db = torch.empty(K, device=dy.device, dtype=torch.float32)
             _lib.call('ag2v_channel_sum', _ptr(dy), _ptr(db), N, K, dy.shape[2] * dy.shape[3], st)

@@ -30,6 +30,11 @@ extern "C" {
  * operand = bf16 hi + bf16 lo, a*b = hi*hi + hi*lo + lo*hi: ~1e-5 relative per product); 0 = exact fp32 MFMA.  Process-wide. */
 int ag2v_set_conv_precision(int mode);
 int ag2v_get_conv_precision(void);
+/* In bf16x3 mode, GEMMs with fewer rows (output channels; input channels for the data gradient) than this stay on the exact
+ * fp32 tiles.  Default 128 (AG2V_BF16X3_MIN_M overrides at start-up); the host side lowers it outside the flow network, whose
+ * full-resolution 64-channel tail feeds the warp (ag2video_amd/ops.py: bf16x3_min_rows). */
+int ag2v_set_bf16x3_min_rows(int rows);
+int ag2v_get_bf16x3_min_rows(void);
 size_t ag2v_conv2d_workspace_floats(int C, int K, int R, int S);  /* k-major copy of the (sub-)filters; fwd and dgrad */
 int ag2v_conv2d_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y,
                     int N, int C, int H, int W, int K, int R, int S, int stride, int pad, float* workspace, void* stream);
