@@ -111,20 +111,29 @@ __global__ __launch_bounds__(256) void triple_pool_bwd_kernel(const float* __res
 
 // ---------------------------------------------------------------- small dense GEMM on v_mfma_f32_32x32x2_f32
 // C[M,N] = act( A * B + bias ),  A[m,k] = a[m*sam + k*sak],  B[k,n] = b[k*sbk + n*sbn],  C row-major (ldc).
-// 64x64 tile per 256-thread workgroup (4 waves, one 32x32 MFMA tile each), BK = 16.
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                       const float* __restrict__ bias, float* __restrict__ c, int M, int N, int K,
-                                                       long long sam, long long sak, long long sbk, long long sbn, int ldc, int relu,
-                                                       int accumulate) {
+// 64x64 tile per workgroup; KS groups of 4 waves (one 32x32 MFMA tile per wave) split the K range of the tile between them
+// and are summed through LDS: the graph nets' GEMMs have 1-11 row tiles and K up to 1152, so the serial K loop, not the
+// chip, bounds a launch (25 us at KS = 1).  BK = 16.
+template <int KS>
+__global__ __launch_bounds__(256 * KS) void gemm_f32_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                            const float* __restrict__ bias, float* __restrict__ c, int M, int N,
+                                                            int K, long long sam, long long sak, long long sbk, long long sbn,
+                                                            int ldc, int relu, int accumulate) {
     constexpr int BK = 16, LD = 64 + 4;
-    __shared__ float As[2][BK][LD];
-    __shared__ float Bs[2][BK][LD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float As[KS][2][BK][LD];
+    __shared__ float Bs[KS][2][BK][LD];
+    __shared__ float red[KS > 1 ? KS - 1 : 1][4][16][64];
+    const int kg = threadIdx.x >> 8;            // K group
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
     const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int nk_all = (K + BK - 1) / BK;
+    const int nk = (nk_all + KS - 1) / KS;      // K-tiles per group (the same trip count for every group: uniform barriers)
+    const int kbase = kg * nk * BK;
+    const int kend = min(K, kbase + nk * BK);
     // Each thread stages 4 A and 4 B elements per K-tile.  Lanes run along whichever index is contiguous in memory:
     // k-contiguous operand -> (kk = tid & 15, row = (tid >> 4) + 16 i); otherwise (row = tid & 63, kk = (tid >> 6) + 4 i).
     const bool a_kc = (sak == 1), b_kc = (sbk == 1);
@@ -135,8 +144,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
             const int akk = a_kc ? (tid & 15) : ((tid >> 6) + 4 * i), arow = a_kc ? ((tid >> 4) + 16 * i) : (tid & 63);
             const int bkk = b_kc ? (tid & 15) : ((tid >> 6) + 4 * i), brow = b_kc ? ((tid >> 4) + 16 * i) : (tid & 63);
             const int m = m0 + arow, n = n0 + brow;
-            ra[i] = (m < M && k0 + akk < K) ? a[(long long)m * sam + (long long)(k0 + akk) * sak] : 0.f;
-            rb[i] = (n < N && k0 + bkk < K) ? b[(long long)(k0 + bkk) * sbk + (long long)n * sbn] : 0.f;
+            ra[i] = (m < M && k0 + akk < kend) ? a[(long long)m * sam + (long long)(k0 + akk) * sak] : 0.f;
+            rb[i] = (n < N && k0 + bkk < kend) ? b[(long long)(k0 + bkk) * sbk + (long long)n * sbn] : 0.f;
         }
     };
     auto stash = [&](int buf) {
@@ -144,26 +153,38 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         for (int i = 0; i < 4; ++i) {
             const int akk = a_kc ? (tid & 15) : ((tid >> 6) + 4 * i), arow = a_kc ? ((tid >> 4) + 16 * i) : (tid & 63);
             const int bkk = b_kc ? (tid & 15) : ((tid >> 6) + 4 * i), brow = b_kc ? ((tid >> 4) + 16 * i) : (tid & 63);
-            As[buf][akk][arow] = ra[i];
-            Bs[buf][bkk][brow] = rb[i];
+            As[kg][buf][akk][arow] = ra[i];
+            Bs[kg][buf][bkk][brow] = rb[i];
         }
     };
-    const int nk = (K + BK - 1) / BK;
-    fetch(0);
+    fetch(kbase);
     stash(0);
     __syncthreads();
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = (kt + 1) < nk;
-        if (more) fetch((kt + 1) * BK);        // next tile's loads are in flight during this tile's MFMAs
+        if (more) fetch(kbase + (kt + 1) * BK);        // next tile's loads are in flight during this tile's MFMAs
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
             const int kk = 2 * s + (lane >> 5);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[cur][kk][wm0 + (lane & 31)], Bs[cur][kk][wn0 + (lane & 31)], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[kg][cur][kk][wm0 + (lane & 31)], Bs[kg][cur][kk][wn0 + (lane & 31)], acc, 0,
+                                                       0, 0);
         }
         if (more) stash(cur ^ 1);
         __syncthreads();
         cur ^= 1;
+    }
+    if (KS > 1) {
+        if (kg > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[kg - 1][wave][r][lane] = acc[r];
+        }
+        __syncthreads();
+        if (kg > 0) return;
+#pragma unroll
+        for (int g = 0; g < KS - 1; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += red[g][wave][r][lane];
     }
     const int n = n0 + wn0 + (lane & 31);
     if (n < N) {
@@ -251,8 +272,13 @@ extern "C" int ag2v_triple_pool_bwd(const float* dpooled, const float* dp_in, co
 extern "C" int ag2v_gemm_f32(const float* a, const float* b, const float* bias, float* c, int M, int N, int K, long long sam,
                              long long sak, long long sbk, long long sbn, int ldc, int relu, int accumulate, void* stream) {
     if (!a || !b || !c || M <= 0 || N <= 0 || K <= 0 || ldc < N) return AG2V_EINVAL;
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3(ceil_div(N, 64), ceil_div(M, 64)), dim3(256), 0, (hipStream_t)stream, a, b, bias, c, M,
-                       N, K, sam, sak, sbk, sbn, ldc, relu, accumulate);
+    const dim3 grid(ceil_div(N, 64), ceil_div(M, 64));
+    if (K >= 256 && (long long)grid.x * grid.y < 512)   // few tiles, long K: four K groups per tile
+        hipLaunchKernelGGL(gemm_f32_kernel<4>, grid, dim3(1024), 0, (hipStream_t)stream, a, b, bias, c, M, N, K, sam, sak, sbk, sbn, ldc,
+                           relu, accumulate);
+    else
+        hipLaunchKernelGGL(gemm_f32_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a, b, bias, c, M, N, K, sam, sak, sbk, sbn, ldc,
+                           relu, accumulate);
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
 }
