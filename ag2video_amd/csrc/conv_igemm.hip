@@ -382,10 +382,111 @@ extern "C" int ag2v_get_bf16x3_min_rows(void) { return bf16x3_min_rows(); }
 static bool use_bf16x3(int M) { return conv_precision() == 1 && M >= bf16x3_min_rows(); }
 static const long long kBufMax = (1LL << 32) - 64;   // raw buffer descriptors cover < 4 GiB
 
+
+// ---------------------------------------------------------------- convolutions with <= 4 output rows (stride 1)
+// The 3-channel data gradient of the decoder's first convolution (512 -> 3 at 256x256), conv_img / conv_flow (64 -> 3 / 2) and
+// the discriminators' last layer (512 -> 1) have 1-4 GEMM rows: on a 32-row MFMA tile > 87 % of the matrix work is padding
+// (6 TF measured).  Here a thread owns 4 consecutive output pixels x all rows and walks (c, r) with plain FMAs: S + 3 input
+// values feed 4 S MR FMAs; weights (k-major [c][r][s][m]) are wave-uniform scalar loads; the input is read through the L1.
+template <int MR, int S>   // MR = exact row count, S x S taps
+__global__ __launch_bounds__(256) void conv_fewrow_kernel(ConvArgs p) {
+    // lane = group of 4 output pixels, wave = quarter of the input channels; the four partial sums meet in LDS
+    __shared__ float red[3][MR * 4][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: the weight reads become scalar loads
+    const int groups_x = (p.OW + 3) >> 2;
+    const long long total = (long long)p.N * p.OH * groups_x;
+    // consecutive image rows share S-1 of their S input rows: keep them on one XCD's L2 (blocks are dealt round-robin)
+    long long gid = (long long)xcd_remap(blockIdx.x, gridDim.x) * 64 + lane;
+    const bool live = gid < total;
+    if (!live) gid = total - 1;
+    const int xg = (int)(gid % groups_x);
+    const long long t = gid / groups_x;
+    const int oy = (int)(t % p.OH), n = (int)(t / p.OH);
+    const int ox0 = xg * 4;
+    const __amdgpu_buffer_rsrc_t brs = make_rsrc(p.b_src, p.b_bytes);
+    float acc[MR][4];
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[m][j] = 0.f;
+    // byte offsets; an invalid column / row contributes 0xF0000000, so the sum stays >= 0xE0000000 > buffer size (launcher)
+    const int x0 = ox0 - p.pad_w;
+    unsigned coff[S + 3], roff[S];
+#pragma unroll
+    for (int i = 0; i < S + 3; ++i) coff[i] = ((unsigned)(x0 + i) < (unsigned)p.W) ? (unsigned)(x0 + i) * 4u : 0xF0000000u;
+    const int HW = p.H * p.W;
+#pragma unroll
+    for (int r = 0; r < S; ++r) {
+        const int iy = oy - p.pad + r;
+        roff[r] = ((unsigned)iy < (unsigned)p.H) ? (unsigned)(n * p.C * HW + iy * p.W) * 4u : 0xF0000000u;
+    }
+    const float* __restrict__ wt = p.a_src;
+    const int cper = (p.C + 3) >> 2;
+    const int c_lo = wave * cper, c_hi = min(p.C, c_lo + cper);
+    for (int c = c_lo; c < c_hi; ++c) {
+        const unsigned cb = (unsigned)(c * HW) * 4u;
+        float v[S][S + 3];
+#pragma unroll
+        for (int r = 0; r < S; ++r)
+#pragma unroll
+            for (int i = 0; i < S + 3; ++i) v[r][i] = bload_f32(brs, roff[r] + cb + coff[i]);
+        const float* wc = wt + (size_t)c * (S * S * MR);
+#pragma unroll
+        for (int r = 0; r < S; ++r)
+#pragma unroll
+            for (int s2 = 0; s2 < S; ++s2)
+#pragma unroll
+                for (int m = 0; m < MR; ++m) {
+                    const float wv = wc[(r * S + s2) * MR + m];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[m][j] = fmaf(wv, v[r][s2 + j], acc[m][j]);
+                }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) red[wave - 1][m * 4 + j][lane] = acc[m][j];
+    }
+    __syncthreads();
+    if (wave > 0 || !live) return;
+    const int plane = p.OH * p.OW;
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+        const float bv = p.bias ? p.bias[m] : 0.f;
+        const size_t o = ((size_t)n * MR + m) * plane + (size_t)oy * p.OW + ox0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float sum = acc[m][j] + (red[0][m * 4 + j][lane] + red[1][m * 4 + j][lane] + red[2][m * 4 + j][lane]);
+            if (ox0 + j < p.OW) p.out[o + j] = sum + bv + (p.residual ? p.residual[o + j] : 0.f);
+        }
+    }
+}
+template <int MR>
+static bool launch_fewrow(const ConvArgs& a, hipStream_t st) {
+    if (a.R != a.S) return false;
+    const long long total = (long long)a.N * a.OH * ((a.OW + 3) >> 2);
+    const dim3 grid((unsigned)ceil_div(total, 64LL));
+    switch (a.S) {
+        case 1: hipLaunchKernelGGL((conv_fewrow_kernel<MR, 1>), grid, dim3(256), 0, st, a); return true;
+        case 3: hipLaunchKernelGGL((conv_fewrow_kernel<MR, 3>), grid, dim3(256), 0, st, a); return true;
+        case 4: hipLaunchKernelGGL((conv_fewrow_kernel<MR, 4>), grid, dim3(256), 0, st, a); return true;
+        default: return false;
+    }
+}
+
 static int launch_igemm(ConvArgs& a, hipStream_t st, bool out_zeroed, bool split) {
     if (a.M <= 0 || a.NG <= 0 || a.KG <= 0 || a.R * a.S > 16) return AG2V_EINVAL;
     if (a.o_mul == 0) { a.o_mul = 1; a.o_add_y = 0; a.o_add_x = 0; a.o_H = a.OH; a.o_W = a.OW; }
     if (split) return launch_igemm_bf16x3(a, st, out_zeroed);
+    if (a.M <= 4 && a.stride == 1 && a.o_mul == 1 && a.o_add_y == 0 && a.o_add_x == 0 && a.o_W == a.OW && a.o_H == a.OH &&
+        (long long)a.N * a.C * a.H * a.W * 4 < 0xE0000000LL && getenv("AG2V_NO_FEWROW") == nullptr) {
+        a.b_bytes = (unsigned)((long long)a.N * a.C * a.H * a.W * 4);
+        const bool ok = a.M == 1 ? launch_fewrow<1>(a, st) : a.M == 2 ? launch_fewrow<2>(a, st)
+                      : a.M == 3 ? launch_fewrow<3>(a, st) : launch_fewrow<4>(a, st);
+        if (ok) { AG2V_CHECK_LAUNCH(); return AG2V_OK; }
+    }
     const int bm = (a.M <= 32) ? 32 : (a.M <= 64 ? 64 : 128);
     const int bk = 16;
     const int bn = (bm == 128) ? 128 : 256;

@@ -74,6 +74,10 @@ CONV_CASES = [
     (3, 16, 8, 8, 256, 1, 1, 1, 0, False, False),     # 1x1
     (2, 10, 12, 10, 128, 3, 3, 1, 0, True, False),    # pad 0, OW = 8 < W
     (1, 5, 40, 40, 192, 3, 3, 1, 1, False, True),     # pixel count not a multiple of the K-tile of a split
+    # <= 4 output rows, stride 1: the few-row FMA kernel (forward here; data gradient for <= 4 input channels)
+    (3, 20, 9, 9, 1, 4, 4, 1, 2, True, False),        # the discriminators' last layer: OW = 10, not a multiple of 4
+    (2, 16, 8, 12, 2, 1, 1, 1, 0, True, True),
+    (2, 4, 11, 13, 4, 3, 3, 1, 1, False, False),
 ]
 
 
