@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
                                                          const float* __restrict__ invstd, const float* __restrict__ w,
                                                          const float* __restrict__ b, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* __restrict__ y, int C,
-                                                         int HW, int nchunk, float slope) {
+                                                         int HW, int nchunk, float slope, long long gbx) {
     const int bid = blockIdx.x;
     const int chunk = bid % nchunk, nc = bid / nchunk;
     const int c = nc % C;
@@ -133,8 +133,9 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
     unsigned mask;
     load16<VEC>(x + off, cnt, v, mask);
     if (MODE == 1) {
-        load16<VEC>(gamma + off, cnt, g, mask);
-        load16<VEC>(beta + off, cnt, be, mask);
+        const size_t goff = off + (size_t)(nc / C) * gbx;   // gbx = C*HW when gamma | beta are the halves of one [N,2C,HW] tensor
+        load16<VEC>(gamma + goff, cnt, g, mask);
+        load16<VEC>(beta + goff, cnt, be, mask);
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = lrelu_f((v[i] - mu) * is * (1.f + g[i]) + be[i], slope);
     } else {
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __res
                                                               const float* __restrict__ x, const float* __restrict__ gamma,
                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
                                                               float* __restrict__ partial, int N, int C, int HW, int nchunk,
-                                                              float slope) {
+                                                              float slope, long long gbx) {
     __shared__ float sh[4];
     const int bid = blockIdx.x;
     const int chunk = bid % nchunk, nc = bid / nchunk;
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __res
     }
     load16<VEC>(x + off, cnt, xv, mask);
     if (MODE == 1) {
-        load16<VEC>(gamma + off, cnt, t, mask);
+        load16<VEC>(gamma + off + (size_t)n * gbx, cnt, t, mask);
 #pragma unroll
         for (int i = 0; i < 16; ++i) g[i] *= (1.f + t[i]);
     }
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
                                                              const float* __restrict__ invstd, const float* __restrict__ sums,
                                                              float* __restrict__ dx, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta, int C, int HW, int nchunk,
-                                                             float inv_count, float slope) {
+                                                             float inv_count, float slope, long long gbx) {
     const int bid = blockIdx.x;
     const int chunk = bid % nchunk, nc = bid / nchunk;
     const int c = nc % C;
@@ -232,12 +233,13 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
 #pragma unroll
     for (int i = 0; i < 16; ++i) xv[i] = (xv[i] - mu) * is;  // xhat
     if (MODE == 1) {
-        load16<VEC>(gamma + off, cnt, t, mask);
+        const size_t goff = off + (size_t)(nc / C) * gbx;
+        load16<VEC>(gamma + goff, cnt, t, mask);
         float dg[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) dg[i] = g[i] * xv[i];
-        store16<VEC>(dgamma + off, cnt, dg);
-        store16<VEC>(dbeta + off, cnt, g);
+        store16<VEC>(dgamma + goff, cnt, dg);
+        store16<VEC>(dbeta + goff, cnt, g);
 #pragma unroll
         for (int i = 0; i < 16; ++i) g[i] = is * (g[i] * (1.f + t[i]) - m1 - xv[i] * m2);
     } else {
@@ -348,19 +350,20 @@ extern "C" int ag2v_bn_stats(const float* x, int N, int C, int HW, float eps, fl
 extern "C" int ag2v_norm_apply(int mode, const float* x, const float* mean, const float* invstd, const float* w, const float* b,
                                const float* gamma, const float* beta, float* y, int N, int C, int HW, float slope, void* stream) {
     if (!x || !mean || !invstd || !y || N <= 0 || C <= 0 || HW <= 0) return AG2V_EINVAL;
-    if (mode == 1 && (!gamma || !beta)) return AG2V_EINVAL;
+    if (mode < 0 || mode > 2 || (mode >= 1 && (!gamma || !beta))) return AG2V_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int nchunk = ceil_div(HW, CHUNK);
     const long long nblk = (long long)N * C * nchunk;
     if (nblk >= (1LL << 31)) return AG2V_EINVAL;
     const bool v = vec_ok(HW, x, y, gamma, beta);
+    const long long gbx = (mode == 2) ? (long long)C * HW : 0;   // mode 2: gamma / beta are the halves of one [N,2C,HW] tensor
     dim3 g((unsigned)nblk), t(256);
     if (mode == 0) {
-        if (v) hipLaunchKernelGGL((norm_apply_kernel<0, true>), g, t, 0, st, x, mean, invstd, w, b, gamma, beta, y, C, HW, nchunk, slope);
-        else hipLaunchKernelGGL((norm_apply_kernel<0, false>), g, t, 0, st, x, mean, invstd, w, b, gamma, beta, y, C, HW, nchunk, slope);
+        if (v) hipLaunchKernelGGL((norm_apply_kernel<0, true>), g, t, 0, st, x, mean, invstd, w, b, gamma, beta, y, C, HW, nchunk, slope, gbx);
+        else hipLaunchKernelGGL((norm_apply_kernel<0, false>), g, t, 0, st, x, mean, invstd, w, b, gamma, beta, y, C, HW, nchunk, slope, gbx);
     } else {
-        if (v) hipLaunchKernelGGL((norm_apply_kernel<1, true>), g, t, 0, st, x, mean, invstd, w, b, gamma, beta, y, C, HW, nchunk, slope);
-        else hipLaunchKernelGGL((norm_apply_kernel<1, false>), g, t, 0, st, x, mean, invstd, w, b, gamma, beta, y, C, HW, nchunk, slope);
+        if (v) hipLaunchKernelGGL((norm_apply_kernel<1, true>), g, t, 0, st, x, mean, invstd, w, b, gamma, beta, y, C, HW, nchunk, slope, gbx);
+        else hipLaunchKernelGGL((norm_apply_kernel<1, false>), g, t, 0, st, x, mean, invstd, w, b, gamma, beta, y, C, HW, nchunk, slope, gbx);
     }
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
@@ -374,20 +377,21 @@ extern "C" int ag2v_norm_bwd(int mode, const float* dy, const float* y, const fl
                              int N, int C, int HW, float slope, float* workspace, void* stream) {
     if (!dy || !x || !mean || !invstd || !dx || !sums || !workspace || N <= 0 || C <= 0 || HW <= 0) return AG2V_EINVAL;
     if (slope != 1.f && !y) return AG2V_EINVAL;
-    if (mode == 1 && (!gamma || !dgamma || !dbeta)) return AG2V_EINVAL;
+    if (mode < 0 || mode > 2 || (mode >= 1 && (!gamma || !dgamma || !dbeta))) return AG2V_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int nchunk = ceil_div(HW, CHUNK);
     const long long nblk = (long long)N * C * nchunk;
     if (nblk >= (1LL << 31)) return AG2V_EINVAL;
     const bool v = vec_ok(HW, dy, y, x, gamma, dx, dgamma, dbeta);
+    const long long gbx = (mode == 2) ? (long long)C * HW : 0;   // mode 2: gamma, dgamma / dbeta are halves of [N,2C,HW] tensors
     dim3 g((unsigned)nblk), t(256);
     const float inv_count = 1.0f / ((float)N * (float)HW);
 #define LAUNCH_BWD(M, V)                                                                                                         \
     hipLaunchKernelGGL((norm_bwd_reduce_kernel<M, V>), g, t, 0, st, dy, y, x, gamma, mean, invstd, workspace, N, C, HW, nchunk, \
-                       slope);                                                                                                   \
+                       slope, gbx);                                                                                              \
     hipLaunchKernelGGL(pair_sum_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, workspace, C, N* nchunk, sums);         \
     hipLaunchKernelGGL((norm_bwd_apply_kernel<M, V>), g, t, 0, st, dy, y, x, gamma, w, mean, invstd, sums, dx, dgamma, dbeta, C, \
-                       HW, nchunk, inv_count, slope);
+                       HW, nchunk, inv_count, slope, gbx);
     if (mode == 0) {
         if (v) { LAUNCH_BWD(0, true) } else { LAUNCH_BWD(0, false) }
     } else {

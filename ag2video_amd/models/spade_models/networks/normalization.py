@@ -123,6 +123,25 @@ class SPADE(nn.Module):
         else:
             seg = ops.nearest_resize(segmap, x.shape[2], x.shape[3])
         actv = ops.leaky_relu(self.mlp_shared[0](seg), 0.0)
-        gamma = self.mlp_gamma(actv)
-        beta = self.mlp_beta(actv)
-        return self.param_free_norm.modulate(x, gamma, beta, slope)
+        # mlp_gamma and mlp_beta read the same activation: one convolution with 2C output rows (a GEMM with twice the rows
+        # for the same operand traffic, one data gradient instead of two plus their sum), whose output the modulation kernel
+        # reads in place as gamma | beta.  The parameters stay separate (state_dict names of the reference).
+        w, b = self._fused_gamma_beta()
+        gb = ops.conv2d(actv, w, b, self.mlp_gamma.stride[0], self.mlp_gamma.padding[0])
+        return self.param_free_norm.modulate_fused(x, gb, slope)
+
+    def _fused_gamma_beta(self):
+        """cat(mlp_gamma, mlp_beta) weights / biases, rebuilt when a parameter changed (optimizer step, load_state_dict) or the
+        autograd mode did; within one training step every frame's forward shares the node (one cat backward per step)."""
+        ps = (self.mlp_gamma.weight, self.mlp_beta.weight, self.mlp_gamma.bias, self.mlp_beta.bias)
+        key = tuple((p.data_ptr(), p._version) for p in ps) + (ops.param_epoch(), torch.is_grad_enabled())
+        if getattr(self, '_gb_key', None) != key:
+            w, b = torch.cat([ps[0], ps[1]], dim=0), torch.cat([ps[2], ps[3]], dim=0)
+            if w.requires_grad:
+                w.register_hook(self._drop_fused)      # its graph is consumed by the backward: rebuild for the next forward
+            self._gb_cache, self._gb_key = (w, b), key
+        return self._gb_cache
+
+    def _drop_fused(self, grad):
+        self._gb_key = None
+        return None

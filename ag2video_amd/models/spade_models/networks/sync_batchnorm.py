@@ -48,3 +48,7 @@ class SynchronizedBatchNorm2d(nn.Module):
         """SPADE use: normalise without affine and apply (1+gamma), beta in the same pass."""
         return ops.spade_norm(x, gamma, beta, self.running_mean, self.running_var, self.training, self.momentum, self.eps,
                               slope)
+
+    def modulate_fused(self, x, gb, slope=1.0):
+        """modulate() with gamma | beta as the channel halves of one [N, 2C, H, W] tensor."""
+        return ops.spade_norm_fused(x, gb, self.running_mean, self.running_var, self.training, self.momentum, self.eps, slope)

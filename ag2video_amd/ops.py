@@ -58,6 +58,19 @@ def enable_kernel_timing(flag=True):
     _TIMING = [] if flag else None
 
 
+# ---- parameter epoch: bumped by the fused optimizer (its kernels update parameters through raw pointers, which does not
+# advance torch's per-tensor version counters); caches of tensors derived from parameters key on it.
+_PARAM_EPOCH = [0]
+
+
+def bump_param_epoch():
+    _PARAM_EPOCH[0] += 1
+
+
+def param_epoch():
+    return _PARAM_EPOCH[0]
+
+
 # ---- which GEMMs take the bf16x3 tiles.  The library default (128 rows, AG2V_BF16X3_MIN_M) is the conservative policy; the
 # model code lowers it for the image decoder and the discriminator, and keeps 128 inside the flow network: there the
 # 64-channel full-resolution tail feeds the warp, which amplifies its 1e-5 split error ~100x on the reference golden toy
@@ -236,8 +249,13 @@ def _bn_stats(x, running_mean, running_var, training, momentum, eps):
     return mean, invstd, N, C, HW
 
 
+def _ptr_off(t, elems):
+    return _P(t.data_ptr() + 4 * elems)
+
+
 class _NormAct(torch.autograd.Function):
-    """mode 0: BN(affine w,b) -> LeakyReLU(slope); mode 1: SPADE BN*(1+gamma)+beta -> LeakyReLU(slope)."""
+    """mode 0: BN(affine w,b) -> LeakyReLU(slope); mode 1: SPADE BN*(1+gamma)+beta -> LeakyReLU(slope); mode 2: as 1 with
+    gamma | beta delivered as the two channel halves of ONE tensor p0 = [N, 2C, H, W] (the output of the fused gamma/beta conv)."""
 
     @staticmethod
     def forward(ctx, mode, x, p0, p1, running_mean, running_var, training, momentum, eps, slope):
@@ -249,10 +267,13 @@ class _NormAct(torch.autograd.Function):
             _lib.call('ag2v_norm_apply', 0, _ptr(x), _ptr(mean), _ptr(invstd), _ptr(p0), _ptr(p1), None, None, _ptr(y),
                       N, C, HW, float(slope), _stream())
         else:
+            if mode == 2 and tuple(p0.shape) != (N, 2 * C) + tuple(x.shape[2:]):
+                raise RuntimeError("spade_norm_fused: gamma|beta tensor must be [N, 2C, H, W]")
+            g_ptr, b_ptr = (_ptr(p0), _ptr(p1)) if mode == 1 else (_ptr(p0), _ptr_off(p0, C * HW))
             # timed as an HBM-bound kernel: algorithmic bytes = x, gamma, beta read + y written (4 tensors), recorded in
             # the "flops" slot of the timing record
-            _launch('ag2v_norm_apply', 'spade_norm_apply', 4.0 * x.numel() * 4, 1, _ptr(x), _ptr(mean), _ptr(invstd), None, None,
-                    _ptr(p0), _ptr(p1), _ptr(y), N, C, HW, float(slope), _stream(), shape=(N, C, HW))
+            _launch('ag2v_norm_apply', 'spade_norm_apply', 4.0 * x.numel() * 4, mode, _ptr(x), _ptr(mean), _ptr(invstd), None, None,
+                    g_ptr, b_ptr, _ptr(y), N, C, HW, float(slope), _stream(), shape=(N, C, HW))
         ctx.save_for_backward(x, y if slope != 1.0 else None, p0, mean, invstd)
         ctx.cfg = (mode, training, slope, N, C, HW)
         return y
@@ -273,6 +294,11 @@ class _NormAct(torch.autograd.Function):
             dw = sums[:, 1].contiguous() if p0 is not None else None
             db = sums[:, 0].contiguous() if p0 is not None else None
             return None, dx, dw, db, None, None, None, None, None, None
+        if mode == 2:
+            dgb = torch.empty_like(p0)
+            _lib.call('ag2v_norm_bwd', 2, _ptr(dy), _ptr(y), _ptr(x), _ptr(p0), None, _ptr(mean), _ptr(invstd), _ptr(dx),
+                      _ptr(dgb), _ptr_off(dgb, C * HW), _ptr(sums), N, C, HW, float(slope), _ptr(ws), _stream())
+            return None, dx, dgb, None, None, None, None, None, None, None
         dgamma = torch.empty_like(x)
         dbeta = torch.empty_like(x)
         _lib.call('ag2v_norm_bwd', 1, _ptr(dy), _ptr(y), _ptr(x), _ptr(p0), None, _ptr(mean), _ptr(invstd), _ptr(dx),
@@ -289,6 +315,13 @@ def batchnorm_act(x, weight, bias, running_mean, running_var, training=True, mom
 def spade_norm(x, gamma, beta, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0):
     """SPADE modulation: BN_noaffine(x) * (1 + gamma) + beta, then LeakyReLU(slope)."""
     return _NormAct.apply(1, x, gamma, beta, running_mean, running_var, bool(training), float(momentum), float(eps),
+                          float(slope))
+
+
+def spade_norm_fused(x, gb, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0):
+    """spade_norm with gamma = gb[:, :C] and beta = gb[:, C:] read in place from the [N, 2C, H, W] output of one convolution
+    (and their gradients written in place into one [N, 2C, H, W] tensor)."""
+    return _NormAct.apply(2, x, gb, None, running_mean, running_var, bool(training), float(momentum), float(eps),
                           float(slope))
 
 

@@ -10,7 +10,7 @@ buffer (no bucket copies).  state_dict()/load_state_dict() keep torch.optim.Adam
 import torch
 
 from . import _lib
-from .ops import _ptr, _stream
+from .ops import _ptr, _stream, bump_param_epoch
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -67,6 +67,7 @@ class FusedAdam(torch.optim.Optimizer):
         _lib.call('ag2v_adam_step', _ptr(self.flat_param), _ptr(self.flat_grad), _ptr(self.flat_m), _ptr(self.flat_v),
                   self.flat_param.numel(), float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']),
                   int(self._step), _stream())
+        bump_param_epoch()     # the kernel wrote the parameters through raw pointers: invalidate derived-tensor caches
         return loss
 
     # ---- torch.optim.Adam-compatible (de)serialisation

@@ -51,7 +51,9 @@ int ag2v_channel_sum(const float* x, float* out, int N, int C, int HW, void* str
 size_t ag2v_bn_workspace_floats(int N, int C, int HW);
 int ag2v_bn_stats(const float* x, int N, int C, int HW, float eps, float momentum, float* mean, float* invstd,
                   float* running_mean, float* running_var, float* workspace, void* stream);
-/* mode 0: y = lrelu((x-mean)*invstd*w[c] + b[c], slope); mode 1: y = lrelu(xhat*(1+gamma)+beta, slope); slope 1 = identity */
+/* mode 0: y = lrelu((x-mean)*invstd*w[c] + b[c], slope); mode 1: y = lrelu(xhat*(1+gamma)+beta, slope); slope 1 = identity.
+ * mode 2 = mode 1 with gamma and beta (and, in ag2v_norm_bwd, dgamma and dbeta) being the two channel halves of one
+ * [N, 2C, HW] tensor: pass the pointers of the halves' first elements; element (n, c, i) is read at n*2C*HW + c*HW + i. */
 int ag2v_norm_apply(int mode, const float* x, const float* mean, const float* invstd, const float* w, const float* b,
                     const float* gamma, const float* beta, float* y, int N, int C, int HW, float slope, void* stream);
 int ag2v_norm_bwd(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* w,

@@ -48,6 +48,13 @@ def spade_norm(x, gamma, beta, running_mean, running_var, training=True, momentu
     return _lrelu(n * (1 + gamma) + beta, slope)
 
 
+
+def spade_norm_fused(x, gb, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0):
+    """spade_norm with gamma | beta stacked along channels (the product runs mlp_gamma and mlp_beta, normalization.py:105-106,
+    as one convolution)."""
+    C = x.shape[1]
+    return spade_norm(x, gb[:, :C], gb[:, C:], running_mean, running_var, training, momentum, eps, slope)
+
 def instnorm_lrelu(x, eps=1e-5, slope=0.2):
     """nn.InstanceNorm2d(affine=False) + LeakyReLU(0.2) (normalization.py:43-44, discriminator.py:374-377)."""
     return F.leaky_relu(F.instance_norm(x, eps=eps), slope)

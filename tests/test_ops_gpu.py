@@ -171,6 +171,23 @@ def test_spade_norm(shape, slope, device):
     _cmp('spade.running_var', rv_g, rv_c)
 
 
+@pytest.mark.parametrize("shape", NORM_SHAPES, ids=str)
+@pytest.mark.parametrize("slope", [0.2, 1.0])
+def test_spade_norm_fused(shape, slope, device):
+    """gamma | beta read in place from one [N, 2C, H, W] tensor (the fused mlp_gamma / mlp_beta convolution's output)."""
+    from ag2video_amd import ops
+    from oracle import kernels as K
+    N, C = shape[0], shape[1]
+    t = {'x': _rand(*shape, seed=1) * 1.3 - 0.4, 'gb': 0.5 * _rand(N, 2 * C, *shape[2:], seed=2)}
+    rm_c, rv_c = torch.zeros(C), torch.ones(C)
+    rm_g, rv_g = torch.zeros(C, device=device), torch.ones(C, device=device)
+    _run_pair(lambda **k: ops.spade_norm_fused(k['x'], k['gb'], rm_g, rv_g, True, 0.1, 1e-5, slope),
+              lambda **k: K.spade_norm_fused(k['x'], k['gb'], rm_c, rv_c, True, 0.1, 1e-5, slope),
+              t, device, name='spade_fused')
+    _cmp('spade_fused.running_mean', rm_g, rm_c)
+    _cmp('spade_fused.running_var', rv_g, rv_c)
+
+
 def test_norm_eval_mode(device):
     from ag2video_amd import ops
     from oracle import kernels as K
