@@ -216,7 +216,7 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_bf16x3_kernel(ConvArgs p) {
 // loads (two K-tiles ahead), split/pack and write LDS; waves 4-7 (one per SIMD) are CONSUMERS: they only read fragments and
 // issue MFMAs (128x64 sub-tile each, 48 MFMAs per K-tile).  A SIMD therefore always has one VALU-bound and one MFMA-bound
 // wave, which the hardware runs concurrently (separate pipes); one workgroup barrier per K-tile hands the buffers over.
-template <int BM, int BN, int CWM, int CWN, int NPW>
+template <int BM, int BN, int CWM, int CWN, int NPW, bool MF16>
 __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_kernel(ConvArgs p) {
     constexpr int BK = 32, LDK = 40, NP = NPW * 64;       // NP producer threads
     constexpr int TM = BM / CWM / 32, TN = BN / CWN / 32;  // consumer wave tile in 32x32 MFMA tiles
@@ -396,34 +396,48 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
     // ------------------------------------------------------------------ consumer state (waves 4..7)
     const int cw = wave - NPW;
     const int wm0 = (cw / CWN) * (TM * 32), wn0 = (cw % CWN) * (TN * 32);
-    const int fr = lane & 31, fh = lane >> 5;
-    f32x16 acc[TM][TN];
+    // Two MFMA shapes.  32x32x16 (two k-steps per K-tile) and 16x16x32 (one instruction spans the K-tile; lane l holds row
+    // l & 15, k = 8 (l >> 4) .. + 7; C/D: col = lane & 15, row = 4 (lane >> 4) + reg).  Same LDS reads and MFMA cycles per
+    // K-tile; the chip holds a higher clock on the 16x16 shape but it occupies the SIMD's issue port for 8 of its 16 cycles:
+    // measured +3..6 % on the 256x128 tile and -16 % on the producer-heavier 128x256 tile, so MF16 is set for the former only.
+    constexpr int EM = MF16 ? TM * 2 : TM, EN = MF16 ? TN * 2 : TN;     // accumulator tiles per consumer wave
+    constexpr int ER = MF16 ? 16 : 32;                                  // rows = columns of one accumulator tile
+    constexpr int EREGS = MF16 ? 4 : 16;
+    typedef float accv __attribute__((ext_vector_type(EREGS)));
+    accv acc[EM][EN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < EM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < EN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < EREGS; ++r) acc[i][j][r] = 0.f;
+    const int fr = lane & (ER - 1), fq = lane / ER;
     auto compute = [&](int buf) {
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8 bhi[TN], blo[TN];
+        for (int ks = 0; ks < (MF16 ? 1 : BK / 16); ++ks) {
+            bf16x8 bhi[EN], blo[EN];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int o = (wn0 + j * 32 + fr) * LDK + ks * 16 + 8 * fh;
+            for (int j = 0; j < EN; ++j) {
+                const int o = (wn0 + j * ER + fr) * LDK + ks * 16 + 8 * fq;
                 bhi[j] = *reinterpret_cast<const bf16x8*>(&Bhi[buf][o]);
                 blo[j] = *reinterpret_cast<const bf16x8*>(&Blo[buf][o]);
             }
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int o = (wm0 + i * 32 + fr) * LDK + ks * 16 + 8 * fh;
+            for (int i = 0; i < EM; ++i) {
+                const int o = (wm0 + i * ER + fr) * LDK + ks * 16 + 8 * fq;
                 const bf16x8 ahi = *reinterpret_cast<const bf16x8*>(&Ahi[buf][o]);
                 const bf16x8 alo = *reinterpret_cast<const bf16x8*>(&Alo[buf][o]);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < EN; ++j) {
+                    if constexpr (MF16) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo, bhi[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, blo[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, bhi[j], acc[i][j], 0, 0, 0);
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi[j], acc[i][j], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -452,13 +466,13 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
 #endif
 #undef STAMP
 
-    // ---- epilogue (consumers): C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // ---- epilogue (consumers)
     const int gplane = p.OH * p.OW;
     const int plane = p.o_H * p.o_W;
     const bool mapped = (p.o_mul != 1 || p.o_add_y != 0 || p.o_add_x != 0 || p.o_W != p.OW);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int opix = n0 + wn0 + j * 32 + (lane & 31);
+    for (int j = 0; j < EN; ++j) {
+        const int opix = n0 + wn0 + j * ER + (lane & (ER - 1));
         if (opix >= p.NG) continue;
         const int on = opix / gplane;
         int orem = opix - on * gplane;
@@ -471,10 +485,11 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
         float* obase = p.out + (size_t)on * p.M * plane + orem;
         const float* rbase = p.residual ? p.residual + (size_t)on * p.M * plane + orem : nullptr;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int i = 0; i < EM; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            for (int r = 0; r < EREGS; ++r) {
+                const int m = MF16 ? m0 + wm0 + i * 16 + 4 * (lane >> 4) + r
+                                   : m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m < p.M) {
                     float v = acc[i][j][r];
                     if (kt0 == 0) {
@@ -853,7 +868,7 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_ws_k
 // for the hi and the lo image each -- against 8 dword loads and 8 ds_write_b32 in conv_wgrad_bf16x3_ws_kernel.  Only the first /
 // last element of a run can fall outside the image (pad <= 8 - ... checked by the launcher: pad <= S - 1 <= 7); such runs are
 // flagged per K-tile by the table builder and patched after the load.
-template <int BM, int BN, int CWM, int CWN, int NPW>
+template <int BM, int BN, int CWM, int CWN, int NPW, bool MF16>
 __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_v_kernel(ConvArgs p) {
     constexpr int BK = 32, LDK = 40, NP = NPW * 64;
     constexpr int TM = BM / CWM / 32, TN = BN / CWN / 32;
@@ -997,34 +1012,44 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_v_ke
 
     const int cw = wave - NPW;
     const int wm0 = (cw / CWN) * (TM * 32), wn0 = (cw % CWN) * (TN * 32);
-    const int fr = lane & 31, fh = lane >> 5;
-    f32x16 acc[TM][TN];
+    // MFMA shape: see conv_igemm_bf16x3_ws_kernel
+    constexpr int EM = MF16 ? TM * 2 : TM, EN = MF16 ? TN * 2 : TN;
+    constexpr int ER = MF16 ? 16 : 32, EREGS = MF16 ? 4 : 16;
+    typedef float accv __attribute__((ext_vector_type(EREGS)));
+    accv acc[EM][EN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < EM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < EN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < EREGS; ++r) acc[i][j][r] = 0.f;
+    const int fr = lane & (ER - 1), fq = lane / ER;
     auto compute = [&](int buf) {
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8 bhi[TN], blo[TN];
+        for (int ks = 0; ks < (MF16 ? 1 : BK / 16); ++ks) {
+            bf16x8 bhi[EN], blo[EN];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int o = (wn0 + j * 32 + fr) * LDK + ks * 16 + 8 * fh;
+            for (int j = 0; j < EN; ++j) {
+                const int o = (wn0 + j * ER + fr) * LDK + ks * 16 + 8 * fq;
                 bhi[j] = *reinterpret_cast<const bf16x8*>(&Bhi[buf][o]);
                 blo[j] = *reinterpret_cast<const bf16x8*>(&Blo[buf][o]);
             }
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int o = (wm0 + i * 32 + fr) * LDK + ks * 16 + 8 * fh;
+            for (int i = 0; i < EM; ++i) {
+                const int o = (wm0 + i * ER + fr) * LDK + ks * 16 + 8 * fq;
                 const bf16x8 ahi = *reinterpret_cast<const bf16x8*>(&Ahi[buf][o]);
                 const bf16x8 alo = *reinterpret_cast<const bf16x8*>(&Alo[buf][o]);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < EN; ++j) {
+                    if constexpr (MF16) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo, bhi[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, blo[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, bhi[j], acc[i][j], 0, 0, 0);
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi[j], acc[i][j], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -1036,14 +1061,15 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_v_ke
     }
 
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int colj = n0 + wn0 + j * 32 + (lane & 31);
+    for (int j = 0; j < EN; ++j) {
+        const int colj = n0 + wn0 + j * ER + (lane & (ER - 1));
         if (colj >= p.NG) continue;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int i = 0; i < EM; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            for (int r = 0; r < EREGS; ++r) {
+                const int m = MF16 ? m0 + wm0 + i * 16 + 4 * (lane >> 4) + r
+                                   : m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m < p.M) {
                     float* dst = p.out + (size_t)m * p.NG + colj;
                     if (p.splitk > 1)
@@ -1098,18 +1124,10 @@ int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed) {
         else
             hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<128, 256, 2, 4>), grid, dim3(NT), 0, st, a);
     } else {
-        static const bool ws44 = getenv("AG2V_BF16X3_WS44") != nullptr;   // 4 producer + 4 consumer waves
-        if (ws44) {
-            if (tall)
-                hipLaunchKernelGGL((conv_igemm_bf16x3_ws_kernel<256, 128, 2, 2, 4>), grid, dim3(512), 0, st, a);
-            else
-                hipLaunchKernelGGL((conv_igemm_bf16x3_ws_kernel<128, 256, 1, 4, 4>), grid, dim3(512), 0, st, a);
-        } else {
-            if (tall)
-                hipLaunchKernelGGL((conv_igemm_bf16x3_ws_kernel<256, 128, 4, 2, 8>), grid, dim3(1024), 0, st, a);
-            else
-                hipLaunchKernelGGL((conv_igemm_bf16x3_ws_kernel<128, 256, 2, 4, 8>), grid, dim3(1024), 0, st, a);
-        }
+        if (tall)
+            hipLaunchKernelGGL((conv_igemm_bf16x3_ws_kernel<256, 128, 4, 2, 8, true>), grid, dim3(1024), 0, st, a);
+        else
+            hipLaunchKernelGGL((conv_igemm_bf16x3_ws_kernel<128, 256, 2, 4, 8, false>), grid, dim3(1024), 0, st, a);
     }
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
@@ -1140,10 +1158,15 @@ int launch_wgrad_bf16x3(ConvArgs& a, hipStream_t st) {
     } else if (a.stride == 1 && a.OW % 8 == 0 && a.W >= 8 && a.pad <= 7 && a.S - 1 - a.pad <= 7 &&
                getenv("AG2V_WGRAD_SCALAR_LOADS") == nullptr) {
         // 16-byte loads along the pixel index (runs of 8 pixels never straddle an image row)
-        if (tall)
-            hipLaunchKernelGGL((conv_wgrad_bf16x3_v_kernel<256, 128, 4, 2, 8>), grid, dim3(1024), 0, st, a);
+        static const bool w16 = getenv("AG2V_WGRAD_MF32") == nullptr;    // 16x16x32 MFMAs in the consumers (+3..9 % here); A/B switch
+        if (tall && w16)
+            hipLaunchKernelGGL((conv_wgrad_bf16x3_v_kernel<256, 128, 4, 2, 8, true>), grid, dim3(1024), 0, st, a);
+        else if (tall)
+            hipLaunchKernelGGL((conv_wgrad_bf16x3_v_kernel<256, 128, 4, 2, 8, false>), grid, dim3(1024), 0, st, a);
+        else if (w16)
+            hipLaunchKernelGGL((conv_wgrad_bf16x3_v_kernel<128, 256, 2, 4, 8, true>), grid, dim3(1024), 0, st, a);
         else
-            hipLaunchKernelGGL((conv_wgrad_bf16x3_v_kernel<128, 256, 2, 4, 8>), grid, dim3(1024), 0, st, a);
+            hipLaunchKernelGGL((conv_wgrad_bf16x3_v_kernel<128, 256, 2, 4, 8, false>), grid, dim3(1024), 0, st, a);
     } else {
         if (tall)
             hipLaunchKernelGGL((conv_wgrad_bf16x3_ws_kernel<256, 128, 4, 2, 8>), grid, dim3(1024), 0, st, a);
