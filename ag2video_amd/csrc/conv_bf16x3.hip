@@ -362,10 +362,14 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
         // compiler then drains vmcnt to 0 at the top of every iteration.
         for (int kt = kt0; kt < nk; kt += 2) {
             STAMP(c0)
+#ifndef AG2V_DIAG_NO_PRODUCER_WORK      // tools/ubench/igemm_stamps.hip: consumers alone / producers alone
             stash(0, ra0, rb0);
+#endif
             STAMP(c1)
+#ifndef AG2V_DIAG_NO_PRODUCER_WORK
             build_tab(kt + 4);
             fetch(kt + 2, ra0, rb0);
+#endif
             STAMP(c2)
             __syncthreads();
             STAMP(c3)
@@ -373,10 +377,14 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
             sa[0] += c2 - c1; sa[1] += c1 - c0; sa[2] += c3 - c2;
 #endif
             STAMP(d0)
+#ifndef AG2V_DIAG_NO_PRODUCER_WORK
             stash(1, ra1, rb1);
+#endif
             STAMP(d1)
+#ifndef AG2V_DIAG_NO_PRODUCER_WORK
             build_tab(kt + 5);
             fetch(kt + 3, ra1, rb1);
+#endif
             STAMP(d2)
             __syncthreads();
             STAMP(d3)
@@ -452,7 +460,9 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
         STAMP(e0)
         __syncthreads();   // tile kt is in LDS buffer (kt - kt0) & 1
         STAMP(e1)
+#ifndef AG2V_DIAG_NO_CONSUMER_WORK
         if (kt < nk) compute((kt - kt0) & 1);
+#endif
         STAMP(e2)
 #ifdef AG2V_STAMPS
         sc[0] += e2 - e1; sc[1] += e1 - e0;
@@ -1087,6 +1097,8 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_v_ke
 // splits that minimises  rounds * (K-tiles per split + overhead)  -- overhead ~ 8 K-tiles for the exposed first loads, the
 // epilogue and (with splits) its atomics -- instead of a fixed "fill the chip" factor that can leave a nearly empty last round.
 static int pick_splits(int tiles, int nk, int max_splits) {
+    static const int forced = [] { const char* e = getenv("AG2V_FORCE_SPLITS"); return e ? atoi(e) : 0; }();   // tuning aid
+    if (forced > 0) return forced < max_splits ? forced : (max_splits > 0 ? max_splits : 1);
     int best = 1;
     long long best_cost = -1;
     for (int sk = 1; sk <= max_splits; ++sk) {

@@ -16,6 +16,9 @@ SHAPES = [  # name, N, C, H, W, K, R, stride, pad
     ('d_model0', 32, 259, 256, 256, 64, 4, 2, 2),
     ('d_model1', 32, 64, 129, 129, 128, 4, 2, 2),
     ('conv_img', 8, 64, 256, 256, 3, 3, 1, 1),
+    ('flow_res_32', 8, 256, 32, 32, 256, 3, 1, 1),
+    ('spade_shared_64', 8, 512, 64, 64, 128, 3, 1, 1),
+    ('g_mid_16_1024_128', 8, 128, 16, 16, 1024, 3, 1, 1),
 ]
 if len(sys.argv) > 1:
     SHAPES = [s for s in SHAPES if s[0] in sys.argv[1:]]
@@ -42,7 +45,7 @@ for name, N, C, H, W, K, R, st, pad in SHAPES:
     for which in ('fwd', 'dgrad', 'wgrad'):
         run(which); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 3
+        reps = 10
         e0.record()
         for _ in range(reps): run(which)
         e1.record(); torch.cuda.synchronize()
