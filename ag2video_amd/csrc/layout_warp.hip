@@ -146,15 +146,44 @@ __global__ __launch_bounds__(256) void layout_conv_fwd_kernel(const float* __res
     const int oy = blockIdx.x * 4 + wave;
     const int n = blockIdx.y;
     const int k0 = blockIdx.z * KPER;
+    // column profiles tx_j(x) of every object of this image, evaluated once per workgroup (the pooled profile costs three
+    // tau8 evaluations per value and every output pixel needs R of them per object)
+    constexpr int TJ = 16, TW = 264;
+    __shared__ float txp[TJ][TW];
+    const bool tabled = (J <= TJ) && (Wm <= TW);
+    if (tabled) {
+        for (int idx = threadIdx.x; idx < J * Wm; idx += 256) {
+            const int j = idx / Wm, xx = idx - j * Wm;
+            const float* b = boxes + ((size_t)n * J + j) * 4;
+            txp[j][xx] = lc_profile(xx, W, pool, b[0], b[2]);
+        }
+    }
+    __syncthreads();
     if (oy >= OH) return;
+    // row taps ty_j(oy * stride + r - pad) of every object, one (j, r) per lane, read back with readlane in the object loop:
+    // evaluated redundantly by all 64 lanes for all J objects they cost more than the FMAs of the 2-3 objects a row touches
+    const bool lane_taps = J * R <= 64;
+    float my_ty = 0.f;
+    if (lane_taps && lane < J * R) {
+        const int jj = lane / R, rr = lane - jj * R;
+        const float* b = boxes + ((size_t)n * J + jj) * 4;
+        const float bx = b[0], by = b[1], bw = b[2], bh = b[3];
+        const bool act = ((bx != 0.f) || (by != 0.f) || (bw != 0.f) || (bh != 0.f)) && keep[(size_t)n * J + jj] != 0;
+        const int yy = oy * stride + rr - pad;
+        my_ty = (act && (unsigned)yy < (unsigned)Hm) ? lc_profile(yy, H, pool, by, bh) : 0.f;
+    }
     const int nq = (OW + 3) >> 2;
-    for (int xq = lane; xq < nq; xq += 64) {
+    // pixel q of thread-iteration xq: 4 consecutive pixels (one 16-byte access) when rows are 16-byte aligned, else the
+    // lane-contiguous pixels xq_block * 256 + lane + 64 q (coalesced 4-byte accesses; OW = 129 in the discriminator)
+    const bool vec = (OW & 3) == 0;
+    auto px = [&](int xq, int q) -> int { return vec ? xq * 4 + q : (xq >> 6) * 256 + (xq & 63) + 64 * q; };
+    for (int xq = lane; vec ? (xq < nq) : ((xq >> 6) * 256 < OW); xq += 64) {
         float acc[KPER][4];
 #pragma unroll
         for (int kk = 0; kk < KPER; ++kk)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int ox = xq * 4 + q;
+                const int ox = px(xq, q);
                 acc[kk][q] = (residual && (k0 + kk) < K && ox < OW)
                                  ? residual[(((size_t)n * K + k0 + kk) * OH + oy) * OW + ox] : 0.f;
             }
@@ -164,7 +193,13 @@ __global__ __launch_bounds__(256) void layout_conv_fwd_kernel(const float* __res
             const bool legal = (x0 != 0.f) || (y0 != 0.f) || (ww != 0.f) || (hh != 0.f);
             const bool active = legal && keep[(size_t)n * J + j] != 0;
             float tyr[R];
-            lc_taps_y<R>(tyr, oy, stride, pad, Hm, H, pool, y0, hh, active);
+            if (lane_taps) {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    tyr[r] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_ty), j * R + r));
+            } else {
+                lc_taps_y<R>(tyr, oy, stride, pad, Hm, H, pool, y0, hh, active);
+            }
             float tysum = 0.f;
 #pragma unroll
             for (int r = 0; r < R; ++r) tysum += fabsf(tyr[r]);
@@ -175,8 +210,8 @@ __global__ __launch_bounds__(256) void layout_conv_fwd_kernel(const float* __res
             for (int s = 0; s < R; ++s)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int xx = (xq * 4 + q) * stride + s - pad;
-                    txs[s][q] = ((unsigned)xx < (unsigned)Wm) ? lc_profile(xx, W, pool, x0, ww) : 0.f;
+                    const int xx = px(xq, q) * stride + s - pad;
+                    txs[s][q] = ((unsigned)xx < (unsigned)Wm) ? (tabled ? txp[j][xx] : lc_profile(xx, W, pool, x0, ww)) : 0.f;
                     txsum += fabsf(txs[s][q]);
                 }
             if (__ballot(txsum != 0.f) == 0ull) continue;
@@ -199,13 +234,13 @@ __global__ __launch_bounds__(256) void layout_conv_fwd_kernel(const float* __res
 #pragma unroll
         for (int kk = 0; kk < KPER; ++kk) {
             if (k0 + kk >= K) continue;
-            float* o = out + (((size_t)n * K + k0 + kk) * OH + oy) * OW + xq * 4;
-            if ((OW & 3) == 0) {
-                *reinterpret_cast<float4*>(o) = make_float4(acc[kk][0], acc[kk][1], acc[kk][2], acc[kk][3]);
+            float* orow = out + (((size_t)n * K + k0 + kk) * OH + oy) * OW;
+            if (vec) {
+                *reinterpret_cast<float4*>(orow + xq * 4) = make_float4(acc[kk][0], acc[kk][1], acc[kk][2], acc[kk][3]);
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    if (xq * 4 + q < OW) o[q] = acc[kk][q];
+                    if (px(xq, q) < OW) orow[px(xq, q)] = acc[kk][q];
             }
         }
     }
@@ -252,14 +287,20 @@ __global__ __launch_bounds__(256) void layout_conv_bwd_kernel(const float* __res
             if (__ballot(t != 0.f)) xblk_mask |= 1u << (xb >> 6);
         }
     }
-    for (int i = 0; i < 8; ++i) {
-        const int k = blockIdx.z * 32 + wave + 4 * i;
-        if (k >= K) break;
-        float acc[R][R];
+    // The wave's 8 channels (k = 32 z + wave + 4 i) go through the support together, CH at a time: the row taps are evaluated once
+    // per row instead of once per (row, channel), and a row issues CH independent loads.
+    constexpr int CH = (R == 3) ? 8 : 4;
+    const size_t plane = (size_t)OH * OW;
+    for (int c0 = 0; c0 < 8; c0 += CH) {
+        const int kfirst = blockIdx.z * 32 + wave + 4 * c0;
+        if (kfirst >= K) break;
+        float acc[CH][R][R];
 #pragma unroll
-        for (int r = 0; r < R; ++r)
+        for (int ci = 0; ci < CH; ++ci)
 #pragma unroll
-            for (int s = 0; s < R; ++s) acc[r][s] = 0.f;
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int s = 0; s < R; ++s) acc[ci][r][s] = 0.f;
         if (active && oy_hi >= oy_lo) {
             for (int xb = 0; xb < OW; xb += 64) {
                 if (xb < 2048 && !((xblk_mask >> (xb >> 6)) & 1u)) continue;   // wave-uniform
@@ -272,26 +313,42 @@ __global__ __launch_bounds__(256) void layout_conv_bwd_kernel(const float* __res
                     txs[s] = (ox < OW && (unsigned)xx < (unsigned)Wm) ? lc_profile(xx, W, pool, x0, ww) : 0.f;
                     txsum += fabsf(txs[s]);
                 }
-                const float* dp = dout + ((size_t)n * K + k) * OH * OW + ox;
+                const bool col_live = txsum != 0.f;
+                const float* dp = dout + ((size_t)n * K + kfirst) * plane + ox;
                 for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+                    float g[CH];
+#pragma unroll
+                    for (int ci = 0; ci < CH; ++ci)
+                        g[ci] = (col_live && kfirst + 4 * ci < K) ? dp[(size_t)(4 * ci) * plane + (size_t)oy * OW] : 0.f;
                     float tyr[R];
                     lc_taps_y<R>(tyr, oy, stride, pad, Hm, H, pool, y0, hh, true);
-                    const float g = (txsum != 0.f) ? dp[(size_t)oy * OW] : 0.f;
+                    float w9[R][R];
 #pragma unroll
                     for (int r = 0; r < R; ++r)
 #pragma unroll
-                        for (int s = 0; s < R; ++s) acc[r][s] += g * tyr[r] * txs[s];
+                        for (int s = 0; s < R; ++s) w9[r][s] = tyr[r] * txs[s];
+#pragma unroll
+                    for (int ci = 0; ci < CH; ++ci)
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+#pragma unroll
+                            for (int s = 0; s < R; ++s) acc[ci][r][s] += g[ci] * w9[r][s];
                 }
             }
         }
-        float* o = dU + (((size_t)n * J + j) * K + k) * (R * R);
 #pragma unroll
-        for (int r = 0; r < R; ++r)
+        for (int ci = 0; ci < CH; ++ci) {
+            const int k = kfirst + 4 * ci;
+            if (k >= K) break;
+            float* o = dU + (((size_t)n * J + j) * K + k) * (R * R);
 #pragma unroll
-            for (int s = 0; s < R; ++s) {
-                const float v = wave_sum(acc[r][s]);
-                if (lane == 0) o[r * R + s] = v;
-            }
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int s = 0; s < R; ++s) {
+                    const float v = wave_sum(acc[ci][r][s]);
+                    if (lane == 0) o[r * R + s] = v;
+                }
+        }
     }
 }
 
