@@ -189,6 +189,7 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_bf16x3_kernel(ConvArgs p) {
         }
         float* obase = p.out + (size_t)on * p.M * plane + orem;
         const float* rbase = p.residual ? p.residual + (size_t)on * p.M * plane + orem : nullptr;
+        const float* mbase = (p.mask && p.splitk == 1) ? p.mask + (size_t)on * p.M * plane + orem : nullptr;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -199,6 +200,10 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_bf16x3_kernel(ConvArgs p) {
                     if (kt0 == 0) {
                         if (p.bias) v += p.bias[m];
                         if (rbase) v += rbase[(size_t)m * plane];
+                    }
+                    if (p.splitk == 1) {   // (a split-K launch applies these in a pass over the finished sums: launch_act_mask)
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        if (mbase) v = (mbase[(size_t)m * plane] > 0.f) ? v : 0.f;
                     }
                     if (p.splitk > 1)
                         atomicAdd(obase + (size_t)m * plane, v);
@@ -494,6 +499,7 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
         }
         float* obase = p.out + (size_t)on * p.M * plane + orem;
         const float* rbase = p.residual ? p.residual + (size_t)on * p.M * plane + orem : nullptr;
+        const float* mbase = (p.mask && p.splitk == 1) ? p.mask + (size_t)on * p.M * plane + orem : nullptr;
 #pragma unroll
         for (int i = 0; i < EM; ++i) {
 #pragma unroll
@@ -505,6 +511,10 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
                     if (kt0 == 0) {
                         if (p.bias) v += p.bias[m];
                         if (rbase) v += rbase[(size_t)m * plane];
+                    }
+                    if (p.splitk == 1) {   // (a split-K launch applies these in a pass over the finished sums: launch_act_mask)
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        if (mbase) v = (mbase[(size_t)m * plane] > 0.f) ? v : 0.f;
                     }
                     if (p.splitk > 1)
                         atomicAdd(obase + (size_t)m * plane, v);
@@ -1142,6 +1152,8 @@ int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed) {
             hipLaunchKernelGGL((conv_igemm_bf16x3_ws_kernel<128, 256, 2, 4, 8, false>), grid, dim3(1024), 0, st, a);
     }
     AG2V_CHECK_LAUNCH();
+    if (a.splitk > 1 && (a.relu || a.mask))
+        return launch_act_mask(a.out, a.mask, (long long)a.N * a.M * a.o_H * a.o_W, a.relu, st);
     return AG2V_OK;
 }
 

@@ -17,6 +17,8 @@ struct ConvArgs {
     int tiles_m, tiles_n;
     unsigned a_bytes, b_bytes;  // byte sizes of a_src / b_src (bf16x3 kernels address them through 32-bit buffer offsets)
     int splitk, kchunk;     // igemm: K-range splits (grid.y) in K-tiles; wgrad: pixel-range splits, pixels per split
+    const float* mask;      // igemm epilogue: out = (mask > 0) ? out : 0 (same shape as out) -- the ReLU backward of the conv's input
+    int relu;               // igemm epilogue: out = max(out, 0)
 #ifdef AG2V_STAMPS
     unsigned long long* stamps;   // diagnostic build only (tools/ubench/igemm_stamps.hip): per-wave phase clocks
 #endif
@@ -83,6 +85,10 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ u32x4 bload_u32x4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
     return __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
 }
+
+// out = relu ? max(out, 0) : out;  out = mask ? (mask > 0 ? out : 0) : out -- the epilogue of a split-K launch, whose workgroups
+// only hold partial sums (implemented in conv_igemm.hip)
+int launch_act_mask(float* out, const float* mask, long long n, int relu, hipStream_t st);
 
 // launchers implemented in conv_bf16x3.hip
 int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed);

@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256, 4) void conv_igemm_kernel(ConvArgs p) {
         }
         float* obase = p.out + (size_t)on * p.M * plane + orem;
         const float* rbase = p.residual ? p.residual + (size_t)on * p.M * plane + orem : nullptr;
+        const float* mbase = (p.mask && p.splitk == 1) ? p.mask + (size_t)on * p.M * plane + orem : nullptr;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -169,6 +170,10 @@ __global__ __launch_bounds__(256, 4) void conv_igemm_kernel(ConvArgs p) {
                     if (kt0 == 0) {
                         if (p.bias) v += p.bias[m];
                         if (rbase) v += rbase[(size_t)m * plane];
+                    }
+                    if (p.splitk == 1) {   // (a split-K launch applies these in a pass over the finished sums: launch_act_mask)
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        if (mbase) v = (mbase[(size_t)m * plane] > 0.f) ? v : 0.f;
                     }
                     if (p.splitk > 1)
                         atomicAdd(obase + (size_t)m * plane, v);
@@ -383,6 +388,34 @@ static bool use_bf16x3(int M) { return conv_precision() == 1 && M >= bf16x3_min_
 static const long long kBufMax = (1LL << 32) - 64;   // raw buffer descriptors cover < 4 GiB
 
 
+// ---------------------------------------------------------------- epilogue pass of split-K launches
+__global__ __launch_bounds__(256) void act_mask_kernel(float* __restrict__ out, const float* __restrict__ mask, long long n, int relu) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        float4 v = *reinterpret_cast<float4*>(out + i);
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (mask) {
+            const float4 m = *reinterpret_cast<const float4*>(mask + i);
+            v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+        }
+        *reinterpret_cast<float4*>(out + i) = v;
+    } else {
+        for (long long k = i; k < n; ++k) {
+            float v = out[k];
+            if (relu) v = fmaxf(v, 0.f);
+            if (mask) v = mask[k] > 0.f ? v : 0.f;
+            out[k] = v;
+        }
+    }
+}
+int launch_act_mask(float* out, const float* mask, long long n, int relu, hipStream_t st) {
+    if (n <= 0 || (!relu && !mask)) return AG2V_OK;
+    if ((((uintptr_t)out) & 15) || (mask && (((uintptr_t)mask) & 15))) return AG2V_EINVAL;
+    hipLaunchKernelGGL(act_mask_kernel, dim3((unsigned)ceil_div(ceil_div(n, 4LL), 256LL)), dim3(256), 0, st, out, mask, n, relu);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+
 // ---------------------------------------------------------------- convolutions with <= 4 output rows (stride 1)
 // The 3-channel data gradient of the decoder's first convolution (512 -> 3 at 256x256), conv_img / conv_flow (64 -> 3 / 2) and
 // the discriminators' last layer (512 -> 1) have 1-4 GEMM rows: on a 32-row MFMA tile > 87 % of the matrix work is padding
@@ -459,7 +492,12 @@ __global__ __launch_bounds__(256) void conv_fewrow_kernel(ConvArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float sum = acc[m][j] + (red[0][m * 4 + j][lane] + red[1][m * 4 + j][lane] + red[2][m * 4 + j][lane]);
-            if (ox0 + j < p.OW) p.out[o + j] = sum + bv + (p.residual ? p.residual[o + j] : 0.f);
+            if (ox0 + j < p.OW) {
+                float v = sum + bv + (p.residual ? p.residual[o + j] : 0.f);
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (p.mask) v = (p.mask[o + j] > 0.f) ? v : 0.f;
+                p.out[o + j] = v;
+            }
         }
     }
 }
@@ -515,19 +553,30 @@ static int launch_igemm(ConvArgs& a, hipStream_t st, bool out_zeroed, bool split
     else
         hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, a);
     AG2V_CHECK_LAUNCH();
+    if (a.splitk > 1 && (a.relu || a.mask))
+        return launch_act_mask(a.out, a.mask, (long long)a.N * a.M * a.o_H * a.o_W, a.relu, st);
     return AG2V_OK;
 }
 
 extern "C" size_t ag2v_conv2d_workspace_floats(int C, int K, int R, int S) { return (size_t)C * K * R * S; }
 
 // y = conv(x, w) (+bias) (+residual).  workspace: ag2v_conv2d_workspace_floats() floats (k-major copy of the weights).
+// relu != 0: y = max(conv + bias + residual, 0) (the ReLU behind SPADE's mlp_shared convolution, normalization.py:92-95)
+extern "C" int ag2v_conv2d_fwd_act(const float* x, const float* w, const float* bias, const float* residual, float* y,
+                                   int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int relu, float* workspace,
+                                   void* stream);
 extern "C" int ag2v_conv2d_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y,
                                int N, int C, int H, int W, int K, int R, int S, int stride, int pad, float* workspace,
                                void* stream) {
+    return ag2v_conv2d_fwd_act(x, w, bias, residual, y, N, C, H, W, K, R, S, stride, pad, 0, workspace, stream);
+}
+extern "C" int ag2v_conv2d_fwd_act(const float* x, const float* w, const float* bias, const float* residual, float* y,
+                                   int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int relu, float* workspace,
+                                   void* stream) {
     if (!x || !w || !y || !workspace || N <= 0 || C <= 0 || K <= 0 || stride <= 0 || R * S > 16) return AG2V_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     ConvArgs a{};
-    a.b_src = x; a.out = y; a.bias = bias; a.residual = residual;
+    a.b_src = x; a.out = y; a.bias = bias; a.residual = residual; a.relu = relu ? 1 : 0;
     a.N = N; a.C = C; a.H = H; a.W = W; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.pad_w = pad;
     a.OH = conv_out_dim(H, R, stride, pad); a.OW = conv_out_dim(W, S, stride, pad);
     if (a.OH <= 0 || a.OW <= 0) return AG2V_EINVAL;
@@ -545,9 +594,19 @@ extern "C" int ag2v_conv2d_fwd(const float* x, const float* w, const float* bias
 
 // dx = d conv / d x.  For each pixel class (py,px) of the stride one forward-kernel launch over dy with the class's
 // flipped sub-filter.  workspace: ag2v_conv2d_workspace_floats() floats.
+// mask (nullable, same shape as dx): dx = (mask > 0) ? dx : 0 -- the backward of a ReLU that produced this convolution's input
+// (SPADE: mlp_gamma / mlp_beta read relu(mlp_shared(seg)); mask = that activation), fused into the epilogue.
+extern "C" int ag2v_conv2d_dgrad_masked(const float* dy, const float* w, const float* mask, float* dx,
+                                        int N, int C, int H, int W, int K, int R, int S, int stride, int pad, float* workspace,
+                                        void* stream);
 extern "C" int ag2v_conv2d_dgrad(const float* dy, const float* w, float* dx,
                                  int N, int C, int H, int W, int K, int R, int S, int stride, int pad, float* workspace,
                                  void* stream) {
+    return ag2v_conv2d_dgrad_masked(dy, w, nullptr, dx, N, C, H, W, K, R, S, stride, pad, workspace, stream);
+}
+extern "C" int ag2v_conv2d_dgrad_masked(const float* dy, const float* w, const float* mask, float* dx,
+                                        int N, int C, int H, int W, int K, int R, int S, int stride, int pad, float* workspace,
+                                        void* stream) {
     if (!dy || !w || !dx || !workspace || N <= 0 || C <= 0 || K <= 0 || stride <= 0 || R * S > 16) return AG2V_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int OH = conv_out_dim(H, R, stride, pad), OW = conv_out_dim(W, S, stride, pad);
@@ -581,10 +640,12 @@ extern "C" int ag2v_conv2d_dgrad(const float* dy, const float* w, float* dx,
             if ((long long)N * f.OH * f.OW >= (1LL << 31)) return AG2V_EINVAL;
             f.M = C; f.NG = N * f.OH * f.OW; f.KG = K * Rc * Sc;
             f.a_bytes = (unsigned)abytes; f.b_bytes = (unsigned)bbytes;
+            f.mask = multi ? nullptr : mask;     // one class (stride 1): in the epilogue; several classes: one pass at the end
             const int rc = launch_igemm(f, st, multi, split);
             if (rc != AG2V_OK) return rc;
             at += (size_t)K * C * Rc * Sc;
         }
+    if (multi && mask) return launch_act_mask(dx, mask, (long long)N * C * H * W, 0, st);
     return AG2V_OK;
 }
 

@@ -122,12 +122,15 @@ class SPADE(nn.Module):
             seg = segmap.at(x.shape[2], x.shape[3])
         else:
             seg = ops.nearest_resize(segmap, x.shape[2], x.shape[3])
-        actv = ops.leaky_relu(self.mlp_shared[0](seg), 0.0)
+        # mlp_shared = Conv2d + ReLU: the ReLU rides in the convolution's epilogue and its backward in the epilogue of the
+        # gamma|beta convolution's data gradient (actv has no other consumer)
+        sh = self.mlp_shared[0]
+        actv = ops.conv2d(seg, sh.weight, sh.bias, sh.stride[0], sh.padding[0], relu=True, grad_premasked=True)
         # mlp_gamma and mlp_beta read the same activation: one convolution with 2C output rows (a GEMM with twice the rows
         # for the same operand traffic, one data gradient instead of two plus their sum), whose output the modulation kernel
         # reads in place as gamma | beta.  The parameters stay separate (state_dict names of the reference).
         w, b = self._fused_gamma_beta()
-        gb = ops.conv2d(actv, w, b, self.mlp_gamma.stride[0], self.mlp_gamma.padding[0])
+        gb = ops.conv2d(actv, w, b, self.mlp_gamma.stride[0], self.mlp_gamma.padding[0], relu_input=True)
         return self.param_free_norm.modulate_fused(x, gb, slope)
 
     def _fused_gamma_beta(self):

@@ -144,8 +144,13 @@ def kernel_timing_summary(by_shape=False):
 
 # ------------------------------------------------------------------------------------------------ convolution
 class _Conv2d(torch.autograd.Function):
+    """relu: y = max(conv, 0) in the forward epilogue; its backward masks dy with (y > 0) unless ``grad_premasked`` says the
+    consumer of y already did (see relu_input).  relu_input: x is itself a ReLU output whose only consumer is this convolution
+    and whose producer was called with grad_premasked=True: the data gradient is returned as (x > 0) ? dx : 0, i.e. the ReLU's
+    backward rides in this convolution's dgrad epilogue instead of a separate pass over dx."""
+
     @staticmethod
-    def forward(ctx, x, w, bias, residual, stride, pad):
+    def forward(ctx, x, w, bias, residual, stride, pad, relu, grad_premasked, relu_input):
         x, w, bias, residual = _c(x), _c(w), _c(bias), _c(residual)
         _chk(x, w, bias, residual)
         N, C, H, W = x.shape
@@ -157,29 +162,33 @@ class _Conv2d(torch.autograd.Function):
         y = torch.empty((N, K, OH, OW), device=x.device, dtype=torch.float32)
         ws = torch.empty(_lib.query('ag2v_conv2d_workspace_floats', C, K, R, S), device=x.device, dtype=torch.float32)
         mr = _current_min_rows()
-        _conv_launch(mr, 'ag2v_conv2d_fwd', _conv_label('fwd', K, mr), 2.0 * N * K * OH * OW * C * R * S,
-                     _ptr(x), _ptr(w), _ptr(bias), _ptr(residual), _ptr(y), N, C, H, W, K, R, S, stride, pad, _ptr(ws), _stream(),
-                     shape=(N, C, H, W, K, R, stride))
-        ctx.save_for_backward(x, w)
-        ctx.cfg = (stride, pad, bias is not None, residual is not None, mr)
+        _conv_launch(mr, 'ag2v_conv2d_fwd_act', _conv_label('fwd', K, mr), 2.0 * N * K * OH * OW * C * R * S,
+                     _ptr(x), _ptr(w), _ptr(bias), _ptr(residual), _ptr(y), N, C, H, W, K, R, S, stride, pad, 1 if relu else 0,
+                     _ptr(ws), _stream(), shape=(N, C, H, W, K, R, stride))
+        ctx.save_for_backward(x, w, y if (relu and not grad_premasked) else None)
+        ctx.cfg = (stride, pad, bias is not None, residual is not None, mr, relu, grad_premasked, relu_input)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
-        stride, pad, has_bias, has_res, mr = ctx.cfg
+        x, w, y = ctx.saved_tensors
+        stride, pad, has_bias, has_res, mr, relu, grad_premasked, relu_input = ctx.cfg
         dy = dy.contiguous()
         N, C, H, W = x.shape
         K, _, R, S = w.shape
         dx = dw = db = dres = None
         st = _stream()
+        if relu and not grad_premasked:
+            g = torch.empty_like(dy)
+            _lib.call('ag2v_act_bwd', 0, _ptr(dy), _ptr(y), _ptr(g), dy.numel(), 0.0, st)   # op 0 = LeakyReLU(slope 0)
+            dy = g
         flops = 2.0 * N * K * dy.shape[2] * dy.shape[3] * C * R * S      # algorithmic (dense-conv) FLOPs of each pass
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             ws = torch.empty(_lib.query('ag2v_conv2d_workspace_floats', C, K, R, S), device=dy.device, dtype=torch.float32)
-            _conv_launch(mr, 'ag2v_conv2d_dgrad', _conv_label('dgrad', C, mr), flops,
-                         _ptr(dy), _ptr(w), _ptr(dx), N, C, H, W, K, R, S, stride, pad, _ptr(ws), st,
-                         shape=(N, C, H, W, K, R, stride))
+            _conv_launch(mr, 'ag2v_conv2d_dgrad_masked', _conv_label('dgrad', C, mr), flops,
+                         _ptr(dy), _ptr(w), _ptr(x) if relu_input else None, _ptr(dx), N, C, H, W, K, R, S, stride, pad, _ptr(ws),
+                         st, shape=(N, C, H, W, K, R, stride))
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
             _conv_launch(mr, 'ag2v_conv2d_wgrad', _conv_label('wgrad', K, mr), flops,
@@ -190,12 +199,15 @@ class _Conv2d(torch.autograd.Function):
             _lib.call('ag2v_channel_sum', _ptr(dy), _ptr(db), N, K, dy.shape[2] * dy.shape[3], st)
         if has_res and ctx.needs_input_grad[3]:
             dres = dy
-        return dx, dw, db, dres, None, None
+        return dx, dw, db, dres, None, None, None, None, None
 
 
-def conv2d(x, w, bias=None, stride=1, pad=0, residual=None):
-    """y = conv2d(x, w) + bias + residual   (NCHW, square stride/pad)."""
-    return _Conv2d.apply(x, w, bias, residual, int(stride), int(pad))
+def conv2d(x, w, bias=None, stride=1, pad=0, residual=None, relu=False, grad_premasked=False, relu_input=False):
+    """y = conv2d(x, w) + bias + residual   (NCHW, square stride/pad); relu=True: y = max(y, 0).
+    grad_premasked / relu_input: see _Conv2d (the pair fuses the ReLU's backward into the consumer's data gradient)."""
+    if relu and residual is not None and grad_premasked:
+        raise RuntimeError("conv2d: grad_premasked with a residual input is not supported (the residual's gradient would be masked)")
+    return _Conv2d.apply(x, w, bias, residual, int(stride), int(pad), bool(relu), bool(grad_premasked), bool(relu_input))
 
 
 # ------------------------------------------------------------------------------------------------ spectral norm

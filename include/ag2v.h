@@ -40,6 +40,13 @@ int ag2v_conv2d_fwd(const float* x, const float* w, const float* bias, const flo
                     int N, int C, int H, int W, int K, int R, int S, int stride, int pad, float* workspace, void* stream);
 int ag2v_conv2d_dgrad(const float* dy, const float* w, float* dx,
                       int N, int C, int H, int W, int K, int R, int S, int stride, int pad, float* workspace, void* stream);
+/* ag2v_conv2d_fwd with y = max(., 0) when relu != 0 (SPADE's mlp_shared = Conv2d + ReLU, normalization.py:92-95), and
+ * ag2v_conv2d_dgrad with dx = (mask > 0) ? dx : 0 (mask nullable, shaped like dx): the backward of the ReLU that produced this
+ * convolution's input, applied in the epilogue (or in one pass over dx when the launch splits K / the stride has several classes). */
+int ag2v_conv2d_fwd_act(const float* x, const float* w, const float* bias, const float* residual, float* y,
+                        int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int relu, float* workspace, void* stream);
+int ag2v_conv2d_dgrad_masked(const float* dy, const float* w, const float* mask, float* dx,
+                             int N, int C, int H, int W, int K, int R, int S, int stride, int pad, float* workspace, void* stream);
 int ag2v_conv2d_wgrad(const float* dy, const float* x, float* dw,
                       int N, int C, int H, int W, int K, int R, int S, int stride, int pad, void* stream);
 /* out[c] = sum over n,hw of x[n,c,hw]: conv bias gradient */

@@ -13,10 +13,13 @@ import torch
 import torch.nn.functional as F
 
 
-def conv2d(x, w, bias=None, stride=1, pad=0, residual=None):
-    """nn.Conv2d.forward (aten.convolution), e.g. generator.py:30, architecture.py:29-32, discriminator.py:368-379."""
+def conv2d(x, w, bias=None, stride=1, pad=0, residual=None, relu=False, grad_premasked=False, relu_input=False):
+    """nn.Conv2d.forward (aten.convolution), e.g. generator.py:30, architecture.py:29-32, discriminator.py:368-379.
+    relu: the nn.ReLU that follows SPADE's mlp_shared convolution (normalization.py:92-95).  grad_premasked / relu_input only tell
+    the product where to apply that ReLU's backward; autograd does it here."""
     y = F.conv2d(x, w, bias, stride=stride, padding=pad)
-    return y if residual is None else y + residual
+    y = y if residual is None else y + residual
+    return F.relu(y) if relu else y
 
 
 def spectral_weight(w_orig, u, v, training=True, eps=1e-12):

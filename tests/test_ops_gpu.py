@@ -107,6 +107,29 @@ def test_conv2d(case, precision, device):
     _run_pair(ops.conv2d, K.conv2d, t, device, name='conv2d')
 
 
+@pytest.mark.parametrize("case", [(2, 24, 16, 16, 136, 3, 1, 1), (2, 130, 8, 8, 160, 3, 1, 1), (1, 20, 12, 12, 40, 3, 1, 1),
+                                  (2, 6, 9, 9, 3, 3, 1, 1), (2, 16, 10, 10, 24, 4, 2, 1)], ids=str)
+def test_conv2d_relu_pair(case, precision, device):
+    """SPADE's pattern: a = relu(conv(x, w1)) with the ReLU in the epilogue, y = conv(a, w2) whose data gradient applies the
+    ReLU's backward (relu=True / grad_premasked=True on the producer, relu_input=True on the consumer) -- against the oracle."""
+    from ag2video_amd import ops
+    from oracle import kernels as K
+    N, C, H, W, Km, R, st, pad = case
+    t = {'x': _rand(N, C, H, W, seed=1), 'w1': _rand(Km, C, R, R, seed=2, scale=(C * R * R) ** -0.5), 'b1': _rand(Km, seed=3),
+         'w2': _rand(2 * C, Km, 3, 3, seed=4, scale=(Km * 9) ** -0.5)}
+
+    def run(mod):
+        def f(x, w1, b1, w2):
+            a = mod.conv2d(x, w1, b1, st, pad, relu=True, grad_premasked=True)
+            return mod.conv2d(a, w2, None, 1, 1, relu_input=True)
+        return f
+    _run_pair(run(ops), run(K), t, device, name='conv_relu_pair')
+    # and the stand-alone epilogue ReLU (its own backward masks dy)
+    t2 = {'x': t['x'], 'w': t['w1'], 'bias': t['b1']}
+    _run_pair(lambda x, w, bias: ops.conv2d(x, w, bias, st, pad, relu=True), lambda x, w, bias: K.conv2d(x, w, bias, st, pad, relu=True),
+              t2, device, name='conv_relu')
+
+
 @pytest.mark.parametrize("shape", [(40, 16, 3, 3), (130, 1027, 3, 3), (16, 8, 4, 4), (8, 16, 1, 1)])
 @pytest.mark.parametrize("training", [True, False])
 def test_spectral_weight(shape, training, device):
