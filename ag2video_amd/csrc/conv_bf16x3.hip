@@ -715,13 +715,18 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_ws_k
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool producer = wave < NPW;
-    const int lid = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    // 1-D grid over (pixel-range split, tile), consecutive ids on one XCD: the tiles of one split read the same dY rows (and
+    // neighbouring x channels), so they share that XCD's L2 instead of fetching dY once per tile (PMC: 4.8 GB -> see profiles)
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int gl = xcd_remap(blockIdx.x, ntiles * p.splitk);
+    const int split = gl / ntiles;
+    const int lid = gl - split * ntiles;
     const int tile_m = lid % p.tiles_m, tile_n = lid / p.tiles_m;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int RS = p.R * p.S;
     const int OHW = p.OH * p.OW, HW = p.H * p.W;
     const int Q = p.N * OHW;
-    const int qs = blockIdx.y * p.kchunk;
+    const int qs = split * p.kchunk;
     const int qe = min(qs + p.kchunk, Q);
     if (qs >= qe) return;
     const int nt = (qe - qs + BK - 1) / BK;
@@ -904,13 +909,18 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_v_ke
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool producer = wave < NPW;
-    const int lid = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    // 1-D grid over (pixel-range split, tile), consecutive ids on one XCD: the tiles of one split read the same dY rows (and
+    // neighbouring x channels), so they share that XCD's L2 instead of fetching dY once per tile (PMC: 4.8 GB -> see profiles)
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int gl = xcd_remap(blockIdx.x, ntiles * p.splitk);
+    const int split = gl / ntiles;
+    const int lid = gl - split * ntiles;
     const int tile_m = lid % p.tiles_m, tile_n = lid / p.tiles_m;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int RS = p.R * p.S;
     const int OHW = p.OH * p.OW, HW = p.H * p.W;
     const int Q = p.N * OHW;
-    const int qs = blockIdx.y * p.kchunk;
+    const int qs = split * p.kchunk;
     const int qe = min(qs + p.kchunk, Q);
     if (qs >= qe) return;
     const int nt = (qe - qs + BK - 1) / BK;
@@ -1174,6 +1184,7 @@ int launch_wgrad_bf16x3(ConvArgs& a, hipStream_t st) {
     }
     dim3 grid(tiles, splitk);
     static const bool homogeneous = getenv("AG2V_BF16X3_HOMOGENEOUS") != nullptr;
+    if (!homogeneous) grid = dim3(tiles * splitk);     // the wave-specialised kernels decode (split, tile) themselves
     if (homogeneous) {
         if (tall)
             hipLaunchKernelGGL((conv_wgrad_bf16x3_kernel<256, 128, 4, 2>), grid, dim3(NT), 0, st, a);

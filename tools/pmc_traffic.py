@@ -17,5 +17,15 @@ for _ in range(3):
 xr = x.clone().requires_grad_(True)
 for _ in range(3):
     ops.leaky_relu(xr, 0.2).backward(g)                                  # act_bwd: reads 2 tensors, writes 1, 4 B/lane
+# bf16x3 wave-specialised kernels, forward + data gradient + weight gradient:
+#   SPADE mlp_shared 512 -> 128 (128x256 tile; x 1.07 GB, y / dy 0.27 GB) and a 256 -> 256 layer at 128x128 (256x128 tile; 134 MB each)
+xs.requires_grad_(True); w.requires_grad_(True)
+for _ in range(2):
+    o2 = ops.conv2d(xs, w, None, 1, 1)
+    o2.backward(torch.ones_like(o2))
+xt = torch.randn(8, 256, 128, 128, device=dev, requires_grad=True); wt = (torch.randn(256, 256, 3, 3, device=dev) * 0.01).requires_grad_(True)
+for _ in range(2):
+    o3 = ops.conv2d(xt, wt, None, 1, 1)
+    o3.backward(torch.ones_like(o3))
 torch.cuda.synchronize()
 print('tensor bytes', x.numel() * 4, 'conv in', xs.numel() * 4, 'conv out', o.numel() * 4)
