@@ -5,7 +5,7 @@ The product path has no fallback: if the library is missing, or a kernel returns
 """
 import ctypes
 import os
-from ctypes import c_float, c_int, c_longlong, c_size_t, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libag2v.so')
@@ -15,6 +15,7 @@ _SIGS = {
     # name: (restype, [argtypes])
     'ag2v_set_conv_precision': (c_int, [c_int]),
     'ag2v_get_conv_precision': (c_int, []),
+    'ag2v_last_conv_kernel': (c_char_p, []),
     'ag2v_set_bf16x3_min_rows': (c_int, [c_int]),
     'ag2v_get_bf16x3_min_rows': (c_int, []),
     'ag2v_conv2d_workspace_floats': (c_size_t, [c_int] * 4),

@@ -1152,14 +1152,14 @@ int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed) {
     static const bool homogeneous = getenv("AG2V_BF16X3_HOMOGENEOUS") != nullptr;   // A/B switch: all 8 waves do everything
     if (homogeneous) {
         if (tall)
-            hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<256, 128, 4, 2>), grid, dim3(NT), 0, st, a);
+            { set_last_conv_kernel("conv_igemm_bf16x3_kernel<256, 128, 4, 2>"); hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<256, 128, 4, 2>), grid, dim3(NT), 0, st, a); }
         else
-            hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<128, 256, 2, 4>), grid, dim3(NT), 0, st, a);
+            { set_last_conv_kernel("conv_igemm_bf16x3_kernel<128, 256, 2, 4>"); hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<128, 256, 2, 4>), grid, dim3(NT), 0, st, a); }
     } else {
         if (tall)
-            hipLaunchKernelGGL((conv_igemm_bf16x3_ws_kernel<256, 128, 4, 2, 8, true>), grid, dim3(1024), 0, st, a);
+            { set_last_conv_kernel("conv_igemm_bf16x3_ws_kernel<256, 128, 4, 2, 8, true>"); hipLaunchKernelGGL((conv_igemm_bf16x3_ws_kernel<256, 128, 4, 2, 8, true>), grid, dim3(1024), 0, st, a); }
         else
-            hipLaunchKernelGGL((conv_igemm_bf16x3_ws_kernel<128, 256, 2, 4, 8, false>), grid, dim3(1024), 0, st, a);
+            { set_last_conv_kernel("conv_igemm_bf16x3_ws_kernel<128, 256, 2, 4, 8, false>"); hipLaunchKernelGGL((conv_igemm_bf16x3_ws_kernel<128, 256, 2, 4, 8, false>), grid, dim3(1024), 0, st, a); }
     }
     AG2V_CHECK_LAUNCH();
     if (a.splitk > 1 && (a.relu || a.mask))
@@ -1187,26 +1187,26 @@ int launch_wgrad_bf16x3(ConvArgs& a, hipStream_t st) {
     if (!homogeneous) grid = dim3(tiles * splitk);     // the wave-specialised kernels decode (split, tile) themselves
     if (homogeneous) {
         if (tall)
-            hipLaunchKernelGGL((conv_wgrad_bf16x3_kernel<256, 128, 4, 2>), grid, dim3(NT), 0, st, a);
+            { set_last_conv_kernel("conv_wgrad_bf16x3_kernel<256, 128, 4, 2>"); hipLaunchKernelGGL((conv_wgrad_bf16x3_kernel<256, 128, 4, 2>), grid, dim3(NT), 0, st, a); }
         else
-            hipLaunchKernelGGL((conv_wgrad_bf16x3_kernel<128, 256, 2, 4>), grid, dim3(NT), 0, st, a);
+            { set_last_conv_kernel("conv_wgrad_bf16x3_kernel<128, 256, 2, 4>"); hipLaunchKernelGGL((conv_wgrad_bf16x3_kernel<128, 256, 2, 4>), grid, dim3(NT), 0, st, a); }
     } else if (a.stride == 1 && a.OW % 8 == 0 && a.W >= 8 && a.pad <= 7 && a.S - 1 - a.pad <= 7 &&
                getenv("AG2V_WGRAD_SCALAR_LOADS") == nullptr) {
         // 16-byte loads along the pixel index (runs of 8 pixels never straddle an image row)
         static const bool w16 = getenv("AG2V_WGRAD_MF32") == nullptr;    // 16x16x32 MFMAs in the consumers (+3..9 % here); A/B switch
         if (tall && w16)
-            hipLaunchKernelGGL((conv_wgrad_bf16x3_v_kernel<256, 128, 4, 2, 8, true>), grid, dim3(1024), 0, st, a);
+            { set_last_conv_kernel("conv_wgrad_bf16x3_v_kernel<256, 128, 4, 2, 8, true>"); hipLaunchKernelGGL((conv_wgrad_bf16x3_v_kernel<256, 128, 4, 2, 8, true>), grid, dim3(1024), 0, st, a); }
         else if (tall)
-            hipLaunchKernelGGL((conv_wgrad_bf16x3_v_kernel<256, 128, 4, 2, 8, false>), grid, dim3(1024), 0, st, a);
+            { set_last_conv_kernel("conv_wgrad_bf16x3_v_kernel<256, 128, 4, 2, 8, false>"); hipLaunchKernelGGL((conv_wgrad_bf16x3_v_kernel<256, 128, 4, 2, 8, false>), grid, dim3(1024), 0, st, a); }
         else if (w16)
-            hipLaunchKernelGGL((conv_wgrad_bf16x3_v_kernel<128, 256, 2, 4, 8, true>), grid, dim3(1024), 0, st, a);
+            { set_last_conv_kernel("conv_wgrad_bf16x3_v_kernel<128, 256, 2, 4, 8, true>"); hipLaunchKernelGGL((conv_wgrad_bf16x3_v_kernel<128, 256, 2, 4, 8, true>), grid, dim3(1024), 0, st, a); }
         else
-            hipLaunchKernelGGL((conv_wgrad_bf16x3_v_kernel<128, 256, 2, 4, 8, false>), grid, dim3(1024), 0, st, a);
+            { set_last_conv_kernel("conv_wgrad_bf16x3_v_kernel<128, 256, 2, 4, 8, false>"); hipLaunchKernelGGL((conv_wgrad_bf16x3_v_kernel<128, 256, 2, 4, 8, false>), grid, dim3(1024), 0, st, a); }
     } else {
         if (tall)
-            hipLaunchKernelGGL((conv_wgrad_bf16x3_ws_kernel<256, 128, 4, 2, 8>), grid, dim3(1024), 0, st, a);
+            { set_last_conv_kernel("conv_wgrad_bf16x3_ws_kernel<256, 128, 4, 2, 8>"); hipLaunchKernelGGL((conv_wgrad_bf16x3_ws_kernel<256, 128, 4, 2, 8>), grid, dim3(1024), 0, st, a); }
         else
-            hipLaunchKernelGGL((conv_wgrad_bf16x3_ws_kernel<128, 256, 2, 4, 8>), grid, dim3(1024), 0, st, a);
+            { set_last_conv_kernel("conv_wgrad_bf16x3_ws_kernel<128, 256, 2, 4, 8>"); hipLaunchKernelGGL((conv_wgrad_bf16x3_ws_kernel<128, 256, 2, 4, 8>), grid, dim3(1024), 0, st, a); }
     }
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;

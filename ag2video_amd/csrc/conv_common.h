@@ -90,6 +90,10 @@ __device__ __forceinline__ u32x4 bload_u32x4(__amdgpu_buffer_rsrc_t r, unsigned 
 // only hold partial sums (implemented in conv_igemm.hip)
 int launch_act_mask(float* out, const float* mask, long long n, int relu, hipStream_t st);
 
+// name of the main kernel of the most recent convolution entry point (as rocprofv3 prints it), for bench.py's per-kernel
+// timing table: ag2v_last_conv_kernel()
+void set_last_conv_kernel(const char* name);
+
 // launchers implemented in conv_bf16x3.hip
 int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed);
 int launch_wgrad_bf16x3(ConvArgs& a, hipStream_t st);

@@ -347,6 +347,10 @@ __global__ __launch_bounds__(256) void dgrad_weight_prep_kernel(const float* __r
     }
 }
 
+static const char* g_last_conv_kernel = "";
+void set_last_conv_kernel(const char* name) { g_last_conv_kernel = name; }
+extern "C" const char* ag2v_last_conv_kernel(void) { return g_last_conv_kernel; }
+
 static int conv_out_dim(int in, int k, int stride, int pad) { return (in + 2 * pad - k) / stride + 1; }
 
 // Precision of the 128/256-row igemm / wgrad tiles (GEMMs with M >= bf16x3_min_rows()): 1 = bf16x3 split (default: fp32-level accuracy, ~1e-5
@@ -523,7 +527,7 @@ static int launch_igemm(ConvArgs& a, hipStream_t st, bool out_zeroed, bool split
         a.b_bytes = (unsigned)((long long)a.N * a.C * a.H * a.W * 4);
         const bool ok = a.M == 1 ? launch_fewrow<1>(a, st) : a.M == 2 ? launch_fewrow<2>(a, st)
                       : a.M == 3 ? launch_fewrow<3>(a, st) : launch_fewrow<4>(a, st);
-        if (ok) { AG2V_CHECK_LAUNCH(); return AG2V_OK; }
+        if (ok) { set_last_conv_kernel("conv_fewrow_kernel"); AG2V_CHECK_LAUNCH(); return AG2V_OK; }
     }
     const int bm = (a.M <= 32) ? 32 : (a.M <= 64 ? 64 : 128);
     const int bk = 16;
@@ -546,12 +550,16 @@ static int launch_igemm(ConvArgs& a, hipStream_t st, bool out_zeroed, bool split
         if (hipMemsetAsync(a.out, 0, (size_t)a.N * a.M * a.o_H * a.o_W * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
     }
     dim3 grid(tiles, a.splitk);
-    if (bm == 32)
+    if (bm == 32) {
+        set_last_conv_kernel("conv_igemm_kernel<32, 256, 1, 4>");
         hipLaunchKernelGGL((conv_igemm_kernel<32, 256, 1, 4>), grid, dim3(256), 0, st, a);
-    else if (bm == 64)
+    } else if (bm == 64) {
+        set_last_conv_kernel("conv_igemm_kernel<64, 256, 1, 4>");
         hipLaunchKernelGGL((conv_igemm_kernel<64, 256, 1, 4>), grid, dim3(256), 0, st, a);
-    else
+    } else {
+        set_last_conv_kernel("conv_igemm_kernel<128, 128, 2, 2>");
         hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, a);
+    }
     AG2V_CHECK_LAUNCH();
     if (a.splitk > 1 && (a.relu || a.mask))
         return launch_act_mask(a.out, a.mask, (long long)a.N * a.M * a.o_H * a.o_W, a.relu, st);
@@ -686,11 +694,11 @@ extern "C" int ag2v_conv2d_wgrad(const float* dy, const float* x, float* dw,
     }
     dim3 grid(tiles, splitk);
     if (bm == 32)
-        hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4>), grid, dim3(256), 0, st, a);
+        { set_last_conv_kernel("conv_wgrad_kernel<32, 128, 1, 4>"); hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4>), grid, dim3(256), 0, st, a); }
     else if (bm == 64)
-        hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 2, 2>), grid, dim3(256), 0, st, a);
+        { set_last_conv_kernel("conv_wgrad_kernel<64, 128, 2, 2>"); hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 2, 2>), grid, dim3(256), 0, st, a); }
     else
-        hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, a);
+        { set_last_conv_kernel("conv_wgrad_kernel<128, 128, 2, 2>"); hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, a); }
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
 }

@@ -53,8 +53,11 @@ _TIMING = None
 
 
 def enable_kernel_timing(flag=True):
-    """Start (True) / stop (False) recording a HIP event pair around every convolution kernel launch."""
+    """Start (True) / stop (False) recording a HIP event pair around every convolution kernel launch.  Starting clears the
+    accumulated records."""
     global _TIMING
+    if flag:
+        _FOLDED.clear()
     _TIMING = [] if flag else None
 
 
@@ -99,10 +102,8 @@ def _current_min_rows():
 
 
 def _conv_label(mode, M, min_rows=None):
-    lim = min_rows if min_rows is not None else _lib.query('ag2v_get_bf16x3_min_rows')
-    prec = get_conv_precision() if M >= lim else 'fp32'
-    bm = 32 if M <= 32 else (64 if (M <= 64 and prec == 'fp32') else 128)
-    return "conv_%s_bm%d_%s" % (mode, bm, prec)
+    """Placeholder label; _launch replaces conv labels by the name of the kernel the library actually launched."""
+    return "conv_%s" % mode
 
 
 def _conv_launch(min_rows, name, label, flops, *args, shape=None):
@@ -117,28 +118,64 @@ def _conv_launch(min_rows, name, label, flops, *args, shape=None):
         _lib.call('ag2v_set_bf16x3_min_rows', old)
 
 
+_PAUSED = False
+
+
+def pause_kernel_timing(flag):
+    """Temporarily stop (True) / resume (False) recording without dropping what has been recorded."""
+    global _PAUSED
+    _PAUSED = bool(flag)
+
+
 def _launch(name, label, flops, *args, shape=None):
-    if _TIMING is None:
+    if _TIMING is None or _PAUSED:
         _lib.call(name, *args)
         return
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0 = _EVENT_POOL.pop() if _EVENT_POOL else torch.cuda.Event(enable_timing=True)
+    e1 = _EVENT_POOL.pop() if _EVENT_POOL else torch.cuda.Event(enable_timing=True)
     e0.record()
     _lib.call(name, *args)
     e1.record()
+    if name.startswith('ag2v_conv2d_'):
+        # key the record on the HIP kernel the library chose (tile shape / arithmetic / load path), as rocprofv3 names it; the
+        # pass (fwd / dgrad / wgrad) stays in front because forward and data gradient share the implicit-GEMM kernels
+        label = "%s:%s" % (label, _lib.query('ag2v_last_conv_kernel').decode())
     _TIMING.append((label, flops, e0, e1, shape))
+
+
+_EVENT_POOL = []      # HIP events are recycled across steps: creating ~20k of them inside a timed step costs ~2 %
+_FOLDED = {}          # records already converted to milliseconds: (label, shape) -> [launches, flops, ms]
+
+
+def fold_kernel_timing(keep=True):
+    """Synchronise, convert the event pairs recorded so far into accumulated milliseconds (keep=False: discard them, e.g. after a
+    warm-up step) and return the events to the pool.  bench.py calls it between timed steps so that a step's events are reused by
+    the next one."""
+    torch.cuda.synchronize()
+    if not _TIMING:
+        return
+    for label, flops, e0, e1, shape in _TIMING:
+        if keep:
+            d = _FOLDED.setdefault((label, shape), [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += flops
+            d[2] += e0.elapsed_time(e1)
+        _EVENT_POOL.append(e0)
+        _EVENT_POOL.append(e1)
+    del _TIMING[:]
 
 
 def kernel_timing_summary(by_shape=False):
     """{label: {launches, flops, ms}} for everything recorded since enable_kernel_timing(True); synchronises."""
-    torch.cuda.synchronize()
+    fold_kernel_timing(True)
     out = {}
-    for label, flops, e0, e1, shape in (_TIMING or []):
+    for (label, shape), (n, flops, ms) in _FOLDED.items():
         if by_shape:
             label = "%s %s" % (label, shape)
         d = out.setdefault(label, {'launches': 0, 'flops': 0.0, 'ms': 0.0})
-        d['launches'] += 1
+        d['launches'] += n
         d['flops'] += flops
-        d['ms'] += e0.elapsed_time(e1)
+        d['ms'] += ms
     return out
 
 

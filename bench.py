@@ -31,6 +31,22 @@ CONFIGS = {
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # same guide: dense bf16 MFMA peak; the bf16x3 path issues 3 MFMAs per product => /3
+# HBM-side traffic of the conv kernels from rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of tools/pmc_traffic.py,
+# FETCH_SIZE doubled per the gfx950 correction; CSVs under profiles/r01/pmc/*_v12_*): bytes per launch ON THE SHAPE NAMED, not an
+# average over the shapes of a training step.
+PMC_TRAFFIC = {
+    "conv_igemm_bf16x3_ws_kernel<128, 256, 2, 4, 8, false>": {
+        "bytes_per_launch": 1284.1e6 + 268.4e6,
+        "note": "SPADE mlp_shared forward 8x512x256x256 -> 128: FETCH 1284 MB + WRITE 268 MB vs 1076 MB + 268 MB algorithmic"},
+    "conv_igemm_bf16x3_ws_kernel<256, 128, 4, 2, 8, true>": {
+        "bytes_per_launch": 932.4e6 + 1193.6e6,
+        "note": "SPADE mlp_shared data gradient (dy 8x128x256x256 -> dx 512 ch): FETCH 932 MB + WRITE 1194 MB vs 271 MB + 1074 MB "
+                "algorithmic (dy re-read by the 2 row tiles and the 3x3 halo through a 4 MB L2)"},
+    "conv_wgrad_bf16x3_v_kernel<128, 256, 2, 4, 8, true>": {
+        "bytes_per_launch": 4820.4e6 + 33.0e6,
+        "note": "SPADE mlp_shared weight gradient: FETCH 4820 MB + WRITE 33 MB vs 1342 MB + 2.4 MB algorithmic, measured BEFORE the "
+                "XCD-aware (split, tile) mapping (dY was fetched once per column tile)"},
+}
 PEAK_HBM_GBS = 8000.0              # same guide: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
@@ -117,16 +133,24 @@ def main():
     clip = ts.to_device(make_clip_batch(opt.vocab, batch, frames, (side, side), seed=1234 + rank))
     torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
+        if not args.no_kernel_timing and i == args.warmup - 1:
+            ops.enable_kernel_timing(True)          # the last warm-up step also creates the HIP events the timed steps reuse
         ts.gd_step(clip)
     torch.cuda.synchronize()
     if D.is_dist():
         torch.distributed.barrier()
     if not args.no_kernel_timing:
-        ops.enable_kernel_timing(True)
+        if args.warmup > 0:
+            ops.fold_kernel_timing(keep=False)      # discard the warm-up records, keep their events
+        else:
+            ops.enable_kernel_timing(True)
     torch.cuda.synchronize()
     t0 = time.time()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        # HIP event pairs around every convolution call cost ~3 % of a step (20k stream markers): they are recorded during the
+        # LAST timed step only, which is enough for the per-kernel table (~10k launches)
+        ops.pause_kernel_timing(args.no_kernel_timing or i + 1 < args.steps)
         model_out, GL, DL = ts.gd_step(clip)
     torch.cuda.synchronize()
     if D.is_dist():
@@ -168,27 +192,42 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = world * batch * frames * args.steps / dt
     def conv_roofline(tm, wall_ms):
-        """Roofline block of the dominant conv kernel of a timing summary (work slot = dense-conv algorithmic FLOPs)."""
-        tm = {k: v for k, v in tm.items() if k.startswith('conv_')}
-        if not tm:
+        """Roofline block of the dominant conv kernel of a timing summary (work slot = dense-conv algorithmic FLOPs).
+        Timing records are keyed "conv_<pass>:<HIP kernel name>"; forward and data gradient share the implicit-GEMM kernels, so
+        the table is aggregated per HIP kernel -- the names and launch counts then line up with `rocprofv3 --kernel-trace --stats`
+        (profiles/); the event pair of a record also spans the weight-prep / memset launches of that call (a few microseconds)."""
+        per = {}
+        for k, v in tm.items():
+            if not k.startswith('conv_'):
+                continue
+            name = k.split(':', 1)[1] if ':' in k else k
+            d = per.setdefault(name, {'ms': 0.0, 'flops': 0.0, 'launches': 0, 'passes': {}})
+            d['ms'] += v['ms']; d['flops'] += v['flops']; d['launches'] += v['launches']
+            d['passes'][k.split(':', 1)[0]] = {'ms': round(v['ms'], 2), 'launches': v['launches'],
+                                               'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2)}
+        if not per:
             return None
-        dom = max(tm, key=lambda k: tm[k]['ms'])
-        t = tm[dom]
-        split = dom.endswith('bf16x3')
+        dom = max(per, key=lambda k: per[k]['ms'])
+        t = per[dom]
+        split = 'bf16x3' in dom
         peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if split else PEAK_FP32_MFMA_TFLOPS
         achieved = t['flops'] / (t['ms'] * 1e-3) / 1e12
-        conv_ms = sum(v['ms'] for v in tm.values())
-        conv_fl = sum(v['flops'] for v in tm.values())
+        conv_ms = sum(v['ms'] for v in per.values())
+        conv_fl = sum(v['flops'] for v in per.values())
+        pmc = PMC_TRAFFIC.get(dom)
         return {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": None,
-                "peak_basis": ("bf16 dense MFMA 2500 TF / 3 MFMAs per fp32-equivalent product" if split
-                               else "v_mfma_f32_32x32x2_f32 dense peak"),
+                "frac": round(achieved / peak, 4), "traffic": (pmc or {}).get('bytes_per_launch'),
+                "traffic_note": (pmc or {}).get('note', 'no PMC pass for this kernel'),
+                "peak_basis": ("bf16 dense MFMA 2500 TF (2.4 GHz) / 3 MFMAs per fp32-equivalent product; the kernel's own cycle counter shows "
+                               "1.53 GHz under this instruction mix (DESIGN.md 3.4), i.e. 531 TF MFMA-bound at the held clock"
+                               if split else "v_mfma_f32_32x32x2_f32 dense peak"),
                 "launches": t['launches'], "avg_launch_ms": round(t['ms'] / t['launches'], 4),
-                "flops_per_launch": t['flops'] / t['launches'],
+                "launches_cover": "one step (the last timed one)",
+                "flops_per_launch": t['flops'] / t['launches'], "passes": t['passes'],
                 "all_conv_kernels": {"achieved": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
                                      "share_of_step_time": round(conv_ms / wall_ms, 4),
                                      "by_kernel": {k: {"ms": round(v['ms'], 2), "tflops": round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2),
-                                                       "launches": v['launches']} for k, v in sorted(tm.items())}}}
+                                                       "launches": v['launches']} for k, v in sorted(per.items())}}}
 
     roof_hbm = None
     if 'spade_norm_apply' in timing:
@@ -198,7 +237,7 @@ def main():
                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "launches": t['launches'],
                     "avg_launch_ms": round(t['ms'] / t['launches'], 4),
                     "traffic": "rocprofv3 PMC (profiles/r01/pmc): FETCH_SIZE*2 + WRITE_SIZE = 3x + 1x tensor bytes = algorithmic"}
-    roof = conv_roofline(timing, dt * 1e3) if timing else None
+    roof = conv_roofline(timing, dt * 1e3 / args.steps) if timing else None     # the records cover the last timed step
     roof_fp32 = None
     if fp32_leg is not None:
         roof_fp32 = conv_roofline(fp32_leg['timing'], fp32_leg['ms'])

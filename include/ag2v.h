@@ -33,6 +33,9 @@ int ag2v_get_conv_precision(void);
 /* In bf16x3 mode, GEMMs with fewer rows (output channels; input channels for the data gradient) than this stay on the exact
  * fp32 tiles.  Default 128 (AG2V_BF16X3_MIN_M overrides at start-up); the host side lowers it outside the flow network, whose
  * full-resolution 64-channel tail feeds the warp (ag2video_amd/ops.py: bf16x3_min_rows). */
+/* Name (as rocprofv3 prints it) of the main kernel launched by the most recent ag2v_conv2d_* call of this process; bench.py keys
+ * its per-kernel HIP-event timing table on it so that it can be laid beside the rocprofv3 kernel statistics. */
+const char* ag2v_last_conv_kernel(void);
 int ag2v_set_bf16x3_min_rows(int rows);
 int ag2v_get_bf16x3_min_rows(void);
 size_t ag2v_conv2d_workspace_floats(int C, int K, int R, int S);  /* k-major copy of the (sub-)filters; fwd and dgrad */
