@@ -1148,6 +1148,7 @@ int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed) {
     if (a.splitk > 1 && !out_zeroed) {
         if (hipMemsetAsync(a.out, 0, (size_t)a.N * a.M * a.o_H * a.o_W * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
     }
+    if (a.splitk > 1 && a.residual == a.out) a.residual = nullptr;   // accumulating launch: the atomics already add onto out
     dim3 grid(tiles, a.splitk);
     static const bool homogeneous = getenv("AG2V_BF16X3_HOMOGENEOUS") != nullptr;   // A/B switch: all 8 waves do everything
     if (homogeneous) {

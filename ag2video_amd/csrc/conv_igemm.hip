@@ -549,6 +549,7 @@ static int launch_igemm(ConvArgs& a, hipStream_t st, bool out_zeroed, bool split
     if (a.splitk > 1 && !out_zeroed) {
         if (hipMemsetAsync(a.out, 0, (size_t)a.N * a.M * a.o_H * a.o_W * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
     }
+    if (a.splitk > 1 && a.residual == a.out) a.residual = nullptr;   // accumulating launch: the atomics already add onto out
     dim3 grid(tiles, a.splitk);
     if (bm == 32) {
         set_last_conv_kernel("conv_igemm_kernel<32, 256, 1, 4>");
@@ -607,6 +608,9 @@ extern "C" int ag2v_conv2d_fwd_act(const float* x, const float* w, const float* 
 extern "C" int ag2v_conv2d_dgrad_masked(const float* dy, const float* w, const float* mask, float* dx,
                                         int N, int C, int H, int W, int K, int R, int S, int stride, int pad, float* workspace,
                                         void* stream);
+extern "C" int ag2v_conv2d_dgrad_acc(const float* dy, const float* w, const float* mask, float* dx,
+                                     int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int accumulate,
+                                     float* workspace, void* stream);
 extern "C" int ag2v_conv2d_dgrad(const float* dy, const float* w, float* dx,
                                  int N, int C, int H, int W, int K, int R, int S, int stride, int pad, float* workspace,
                                  void* stream) {
@@ -615,7 +619,15 @@ extern "C" int ag2v_conv2d_dgrad(const float* dy, const float* w, float* dx,
 extern "C" int ag2v_conv2d_dgrad_masked(const float* dy, const float* w, const float* mask, float* dx,
                                         int N, int C, int H, int W, int K, int R, int S, int stride, int pad, float* workspace,
                                         void* stream) {
+    return ag2v_conv2d_dgrad_acc(dy, w, mask, dx, N, C, H, W, K, R, S, stride, pad, 0, workspace, stream);
+}
+// accumulate != 0: dx += (data gradient) instead of dx = : several convolutions that read the same tensor (the three SPADE
+// mlp_shared convolutions of a residual block) sum their input gradients without a separate pass per pair.  Not with a mask.
+extern "C" int ag2v_conv2d_dgrad_acc(const float* dy, const float* w, const float* mask, float* dx,
+                                     int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int accumulate,
+                                     float* workspace, void* stream) {
     if (!dy || !w || !dx || !workspace || N <= 0 || C <= 0 || K <= 0 || stride <= 0 || R * S > 16) return AG2V_EINVAL;
+    if (accumulate && mask) return AG2V_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int OH = conv_out_dim(H, R, stride, pad), OW = conv_out_dim(W, S, stride, pad);
     if (OH <= 0 || OW <= 0) return AG2V_EINVAL;
@@ -623,7 +635,7 @@ extern "C" int ag2v_conv2d_dgrad_masked(const float* dy, const float* w, const f
     // With stride > 1 several classes write disjoint pixels of dx (one of them may be empty when R < stride) and a class
     // may take the atomic split-K epilogue: zero dx once up front.  Stride 1 is a single class covering every pixel.
     const bool multi = (stride > 1);
-    if (multi && hipMemsetAsync(dx, 0, (size_t)N * C * H * W * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
+    if (multi && !accumulate && hipMemsetAsync(dx, 0, (size_t)N * C * H * W * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
     float* at = workspace;
     for (int py = 0; py < stride; ++py)
         for (int px = 0; px < stride; ++px) {
@@ -649,7 +661,10 @@ extern "C" int ag2v_conv2d_dgrad_masked(const float* dy, const float* w, const f
             f.M = C; f.NG = N * f.OH * f.OW; f.KG = K * Rc * Sc;
             f.a_bytes = (unsigned)abytes; f.b_bytes = (unsigned)bbytes;
             f.mask = multi ? nullptr : mask;     // one class (stride 1): in the epilogue; several classes: one pass at the end
-            const int rc = launch_igemm(f, st, multi, split);
+            // accumulate: a split-K launch adds onto the existing dx with its atomics (no zeroing); any other launch reads dx
+            // back as the epilogue's residual term (each element is read and written by the same thread)
+            f.residual = accumulate ? dx : nullptr;
+            const int rc = launch_igemm(f, st, multi || accumulate != 0, split);
             if (rc != AG2V_OK) return rc;
             at += (size_t)K * C * Rc * Sc;
         }

@@ -1,6 +1,8 @@
 """SPADE residual block (reference: networks/architecture.py:21-68)."""
 import torch.nn as nn
 
+from .... import ops
+
 from .normalization import SPADE, SpectralConv2d
 
 
@@ -21,6 +23,13 @@ class SPADEResnetBlock(nn.Module):
             self.norm_s = SPADE(cfg, fin, opt.semantic_nc)
 
     def forward(self, x, seg):
-        x_s = self.conv_s(self.norm_s(x, seg)) if self.learned_shortcut else x
-        dx = self.conv_0(self.norm_0(x, seg, slope=0.2))
-        return self.conv_1(self.norm_1(dx, seg, slope=0.2), residual=x_s)   # out = x_s + dx fused in the conv epilogue
+        # norm_0, norm_1 (and norm_s) see the segmentation map at the same resolution (conv_0 keeps the size): their mlp_shared
+        # convolutions run as one shared-input group, whose input gradient is accumulated in place (ops.conv2d_shared_input)
+        norms = [self.norm_0, self.norm_1] + ([self.norm_s] if self.learned_shortcut else [])
+        sh = [m.mlp_shared[0] for m in norms]
+        seg_r = self.norm_0.resized_segmap(x, seg)
+        actv = ops.conv2d_shared_input(seg_r, [c.weight for c in sh], [c.bias for c in sh], sh[0].stride[0], sh[0].padding[0],
+                                       relu=True, grad_premasked=True)
+        x_s = self.conv_s(self.norm_s(x, seg, actv=actv[2])) if self.learned_shortcut else x
+        dx = self.conv_0(self.norm_0(x, seg, slope=0.2, actv=actv[0]))
+        return self.conv_1(self.norm_1(dx, seg, slope=0.2, actv=actv[1]), residual=x_s)   # out = x_s + dx fused in the conv epilogue

@@ -114,18 +114,23 @@ class SPADE(nn.Module):
         self.mlp_gamma = Conv2d(nhidden, norm_nc, kernel_size=ks, padding=pw)
         self.mlp_beta = Conv2d(nhidden, norm_nc, kernel_size=ks, padding=pw)
 
-    def forward(self, x, segmap, slope=1.0):
+    def resized_segmap(self, x, segmap):
+        if isinstance(segmap, SegmapPyramid):
+            return segmap.at(x.shape[2], x.shape[3])
+        return ops.nearest_resize(segmap, x.shape[2], x.shape[3])
+
+    def forward(self, x, segmap, slope=1.0, actv=None):
         """slope: LeakyReLU fused behind the modulation (the caller's actvn, architecture.py:53-54); 1.0 = none.
         ``segmap`` may be a SegmapPyramid: every SPADE of a decoder pass resizes the same map to one of six sizes, so
-        the nearest-neighbour resize (normalization.py:102) is done once per size instead of once per SPADE."""
-        if isinstance(segmap, SegmapPyramid):
-            seg = segmap.at(x.shape[2], x.shape[3])
-        else:
-            seg = ops.nearest_resize(segmap, x.shape[2], x.shape[3])
-        # mlp_shared = Conv2d + ReLU: the ReLU rides in the convolution's epilogue and its backward in the epilogue of the
-        # gamma|beta convolution's data gradient (actv has no other consumer)
-        sh = self.mlp_shared[0]
-        actv = ops.conv2d(seg, sh.weight, sh.bias, sh.stride[0], sh.padding[0], relu=True, grad_premasked=True)
+        the nearest-neighbour resize (normalization.py:102) is done once per size instead of once per SPADE.
+        ``actv``: relu(mlp_shared(resized segmap)) computed by the caller together with the other SPADEs that read the same map
+        (SPADEResnetBlock: ops.conv2d_shared_input)."""
+        if actv is None:
+            seg = self.resized_segmap(x, segmap)
+            # mlp_shared = Conv2d + ReLU: the ReLU rides in the convolution's epilogue and its backward in the epilogue of the
+            # gamma|beta convolution's data gradient (actv has no other consumer)
+            sh = self.mlp_shared[0]
+            actv = ops.conv2d(seg, sh.weight, sh.bias, sh.stride[0], sh.padding[0], relu=True, grad_premasked=True)
         # mlp_gamma and mlp_beta read the same activation: one convolution with 2C output rows (a GEMM with twice the rows
         # for the same operand traffic, one data gradient instead of two plus their sum), whose output the modulation kernel
         # reads in place as gamma | beta.  The parameters stay separate (state_dict names of the reference).

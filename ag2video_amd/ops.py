@@ -247,6 +247,90 @@ def conv2d(x, w, bias=None, stride=1, pad=0, residual=None, relu=False, grad_pre
     return _Conv2d.apply(x, w, bias, residual, int(stride), int(pad), bool(relu), bool(grad_premasked), bool(relu_input))
 
 
+class _ConvSharedInput(torch.autograd.Function):
+    """y_i = relu?(conv2d(x, w_i) + b_i) for several weight sets on ONE input (the SPADE mlp_shared convolutions of a residual
+    block all read the same resized segmentation map).  Same kernels as conv2d; the point is the backward: the input gradient
+    is accumulated in place by the data-gradient launches (dx = g_1; dx += g_2; ...) instead of autograd allocating one
+    full-size tensor per branch and summing them pairwise."""
+
+    @staticmethod
+    def forward(ctx, x, stride, pad, relu, grad_premasked, *wb):
+        x = _c(x)
+        ws_, bs_ = [_c(t) for t in wb[0::2]], [_c(t) for t in wb[1::2]]
+        _chk(x, *ws_)
+        _chk(*[b for b in bs_ if b is not None])
+        N, C, H, W = x.shape
+        mr = _current_min_rows()
+        outs = []
+        for w, b in zip(ws_, bs_):
+            K, C2, R, S = w.shape
+            if C2 != C:
+                raise RuntimeError("conv2d_shared_input: input has %d channels, weight expects %d" % (C, C2))
+            OH = (H + 2 * pad - R) // stride + 1
+            OW = (W + 2 * pad - S) // stride + 1
+            y = torch.empty((N, K, OH, OW), device=x.device, dtype=torch.float32)
+            ws = torch.empty(_lib.query('ag2v_conv2d_workspace_floats', C, K, R, S), device=x.device, dtype=torch.float32)
+            _conv_launch(mr, 'ag2v_conv2d_fwd_act', 'conv_fwd', 2.0 * N * K * OH * OW * C * R * S,
+                         _ptr(x), _ptr(w), _ptr(b), None, _ptr(y), N, C, H, W, K, R, S, stride, pad, 1 if relu else 0,
+                         _ptr(ws), _stream(), shape=(N, C, H, W, K, R, stride))
+            outs.append(y)
+        keep_y = relu and not grad_premasked
+        ctx.save_for_backward(x, *ws_, *(outs if keep_y else []))
+        ctx.cfg = (stride, pad, mr, relu, grad_premasked, len(ws_), [b is not None for b in bs_])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        stride, pad, mr, relu, grad_premasked, n, has_b = ctx.cfg
+        saved = ctx.saved_tensors
+        x, ws_ = saved[0], saved[1:1 + n]
+        ys = saved[1 + n:] if (relu and not grad_premasked) else [None] * n
+        N, C, H, W = x.shape
+        st = _stream()
+        dx = None
+        grads = []
+        first = True
+        for i in range(n):
+            w, dy = ws_[i], dys[i]
+            if dy is None:
+                grads += [None, None]
+                continue
+            dy = dy.contiguous()
+            K, _, R, S = w.shape
+            if ys[i] is not None:
+                g = torch.empty_like(dy)
+                _lib.call('ag2v_act_bwd', 0, _ptr(dy), _ptr(ys[i]), _ptr(g), dy.numel(), 0.0, st)
+                dy = g
+            flops = 2.0 * N * K * dy.shape[2] * dy.shape[3] * C * R * S
+            if ctx.needs_input_grad[0]:
+                if dx is None:
+                    dx = torch.empty_like(x)
+                ws = torch.empty(_lib.query('ag2v_conv2d_workspace_floats', C, K, R, S), device=dy.device, dtype=torch.float32)
+                _conv_launch(mr, 'ag2v_conv2d_dgrad_acc', 'conv_dgrad', flops, _ptr(dy), _ptr(w), None, _ptr(dx), N, C, H, W, K, R, S,
+                             stride, pad, 0 if first else 1, _ptr(ws), st, shape=(N, C, H, W, K, R, stride))
+                first = False
+            dw = db = None
+            if ctx.needs_input_grad[5 + 2 * i]:
+                dw = torch.empty_like(w)
+                _conv_launch(mr, 'ag2v_conv2d_wgrad', 'conv_wgrad', flops, _ptr(dy), _ptr(x), _ptr(dw), N, C, H, W, K, R, S, stride, pad,
+                             st, shape=(N, C, H, W, K, R, stride))
+            if has_b[i] and ctx.needs_input_grad[6 + 2 * i]:
+                db = torch.empty(K, device=dy.device, dtype=torch.float32)
+                _lib.call('ag2v_channel_sum', _ptr(dy), _ptr(db), N, K, dy.shape[2] * dy.shape[3], st)
+            grads += [dw, db]
+        if dx is not None and first:
+            dx.zero_()
+        return (dx, None, None, None, None) + tuple(grads)
+
+
+def conv2d_shared_input(x, weights, biases, stride=1, pad=0, relu=False, grad_premasked=False):
+    """[conv2d(x, w_i, b_i) for i] with one accumulated input gradient (see _ConvSharedInput).  Returns a tuple."""
+    wb = []
+    for w, b in zip(weights, biases):
+        wb += [w, b]
+    return _ConvSharedInput.apply(x, int(stride), int(pad), bool(relu), bool(grad_premasked), *wb)
+
+
 # ------------------------------------------------------------------------------------------------ spectral norm
 class _SpectralWeight(torch.autograd.Function):
     @staticmethod

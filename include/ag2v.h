@@ -50,6 +50,11 @@ int ag2v_conv2d_fwd_act(const float* x, const float* w, const float* bias, const
                         int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int relu, float* workspace, void* stream);
 int ag2v_conv2d_dgrad_masked(const float* dy, const float* w, const float* mask, float* dx,
                              int N, int C, int H, int W, int K, int R, int S, int stride, int pad, float* workspace, void* stream);
+/* accumulate != 0: dx += instead of dx = (several convolutions reading one tensor -- the SPADE mlp_shared convolutions of a residual
+ * block, normalization.py:92-95 applied three times to the same segmap -- sum their input gradients in place).  mask must be null then. */
+int ag2v_conv2d_dgrad_acc(const float* dy, const float* w, const float* mask, float* dx,
+                          int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int accumulate, float* workspace,
+                          void* stream);
 int ag2v_conv2d_wgrad(const float* dy, const float* x, float* dw,
                       int N, int C, int H, int W, int K, int R, int S, int stride, int pad, void* stream);
 /* out[c] = sum over n,hw of x[n,c,hw]: conv bias gradient */

@@ -22,6 +22,11 @@ def conv2d(x, w, bias=None, stride=1, pad=0, residual=None, relu=False, grad_pre
     return F.relu(y) if relu else y
 
 
+def conv2d_shared_input(x, weights, biases, stride=1, pad=0, relu=False, grad_premasked=False):
+    """Several convolutions of one input (SPADE.mlp_shared of norm_0 / norm_1 / norm_s on the same segmap, normalization.py:92-104)."""
+    return tuple(conv2d(x, w, b, stride, pad, relu=relu) for w, b in zip(weights, biases))
+
+
 def spectral_weight(w_orig, u, v, training=True, eps=1e-12):
     """torch.nn.utils.spectral_norm.SpectralNorm.compute_weight (n_power_iterations=1) as applied at
     architecture.py:35-39, flows_generator.py:79-85, normalization.py:26-27.  u, v are updated in place in training."""

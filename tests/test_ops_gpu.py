@@ -130,6 +130,37 @@ def test_conv2d_relu_pair(case, precision, device):
               t2, device, name='conv_relu')
 
 
+@pytest.mark.parametrize("case", [(2, 24, 16, 16, (136, 136, 130), 3, 1, 1), (1, 130, 8, 8, (160, 40), 3, 1, 1),
+                                  (2, 12, 9, 11, (24, 3, 200), 3, 1, 1), (2, 16, 10, 10, (136, 24), 4, 2, 1)], ids=str)
+def test_conv2d_shared_input(case, precision, device):
+    """Several convolutions of one input with the in-place accumulated input gradient (ops.conv2d_shared_input)."""
+    from ag2video_amd import ops
+    from oracle import kernels as K
+    N, C, H, W, Ks, R, st, pad = case
+    x = _rand(N, C, H, W, seed=1)
+    ws = [_rand(k, C, R, R, seed=10 + i, scale=(C * R * R) ** -0.5) for i, k in enumerate(Ks)]
+    bs = [_rand(k, seed=20 + i) for i, k in enumerate(Ks)]
+
+    def run(mod, dev):
+        xx = x.clone().to(dev).requires_grad_(True)
+        wl = [w.clone().to(dev).requires_grad_(True) for w in ws]
+        bl = [b.clone().to(dev).requires_grad_(True) for b in bs]
+        ys = mod.conv2d_shared_input(xx, wl, bl, st, pad, relu=True)
+        loss = 0.0
+        for i, y in enumerate(ys):
+            loss = loss + (y * _rand(*y.shape, seed=30 + i).to(dev)).sum() * (i + 1)
+        loss.backward()
+        return ys, xx.grad, [w.grad for w in wl], [b.grad for b in bl]
+
+    yg, dxg, dwg, dbg = run(ops, device)
+    yr, dxr, dwr, dbr = run(K, 'cpu')
+    for i in range(len(Ks)):
+        _cmp('shared.fwd%d' % i, yg[i], yr[i], TOL)
+        _cmp('shared.dw%d' % i, dwg[i], dwr[i], TOL)
+        _cmp('shared.db%d' % i, dbg[i], dbr[i], TOL)
+    _cmp('shared.dx', dxg, dxr, TOL)
+
+
 @pytest.mark.parametrize("shape", [(40, 16, 3, 3), (130, 1027, 3, 3), (16, 8, 4, 4), (8, 16, 1, 1)])
 @pytest.mark.parametrize("training", [True, False])
 def test_spectral_weight(shape, training, device):
