@@ -25,6 +25,7 @@ _SIGS = {
     'ag2v_conv2d_dgrad_masked': (c_int, [_P, _P, _P, _P] + [c_int] * 9 + [_P, _P]),
     'ag2v_conv2d_dgrad_acc': (c_int, [_P, _P, _P, _P] + [c_int] * 10 + [_P, _P]),
     'ag2v_conv2d_wgrad': (c_int, [_P, _P, _P] + [c_int] * 9 + [_P]),
+    'ag2v_conv2d_wgrad_acc': (c_int, [_P, _P, _P] + [c_int] * 10 + [_P]),
     'ag2v_channel_sum': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     'ag2v_bn_workspace_floats': (c_size_t, [c_int, c_int, c_int]),
     'ag2v_bn_stats': (c_int, [_P, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P]),

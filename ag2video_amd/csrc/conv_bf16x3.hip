@@ -687,7 +687,7 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_bf16x3_kernel(ConvArgs p) {
                 const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m < p.M) {
                     float* dst = p.out + (size_t)m * p.NG + colj;
-                    if (p.splitk > 1)
+                    if (p.splitk > 1 || p.accumulate)
                         atomicAdd(dst, acc[i][j][r]);
                     else
                         *dst = acc[i][j][r];
@@ -877,7 +877,7 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_ws_k
                 const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m < p.M) {
                     float* dst = p.out + (size_t)m * p.NG + colj;
-                    if (p.splitk > 1)
+                    if (p.splitk > 1 || p.accumulate)
                         atomicAdd(dst, acc[i][j][r]);
                     else
                         *dst = acc[i][j][r];
@@ -1102,7 +1102,7 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_v_ke
                                    : m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m < p.M) {
                     float* dst = p.out + (size_t)m * p.NG + colj;
-                    if (p.splitk > 1)
+                    if (p.splitk > 1 || p.accumulate)
                         atomicAdd(dst, acc[i][j][r]);
                     else
                         *dst = acc[i][j][r];
@@ -1180,7 +1180,7 @@ int launch_wgrad_bf16x3(ConvArgs& a, hipStream_t st) {
     int kchunk = ceil_div(nq, splitk) * 32;
     splitk = (int)((Q + kchunk - 1) / kchunk);
     a.splitk = splitk; a.kchunk = kchunk;
-    if (splitk > 1) {
+    if (splitk > 1 && !a.accumulate) {
         if (hipMemsetAsync(a.out, 0, (size_t)a.M * a.NG * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
     }
     dim3 grid(tiles, splitk);

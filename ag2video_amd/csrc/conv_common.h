@@ -19,6 +19,7 @@ struct ConvArgs {
     int splitk, kchunk;     // igemm: K-range splits (grid.y) in K-tiles; wgrad: pixel-range splits, pixels per split
     const float* mask;      // igemm epilogue: out = (mask > 0) ? out : 0 (same shape as out) -- the ReLU backward of the conv's input
     int relu;               // igemm epilogue: out = max(out, 0)
+    int accumulate;         // wgrad: add onto the existing dW (no zeroing; atomics) -- the weight is used by several forward calls
 #ifdef AG2V_STAMPS
     unsigned long long* stamps;   // diagnostic build only (tools/ubench/igemm_stamps.hip): per-wave phase clocks
 #endif

@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvArgs p) {
                 const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m < p.M) {
                     float* dst = p.out + (size_t)m * p.NG + col;
-                    if (p.splitk > 1)
+                    if (p.splitk > 1 || p.accumulate)
                         atomicAdd(dst, acc[i][j][r]);
                     else
                         *dst = acc[i][j][r];
@@ -672,12 +672,20 @@ extern "C" int ag2v_conv2d_dgrad_acc(const float* dy, const float* w, const floa
     return AG2V_OK;
 }
 
+// accumulate != 0: dw += instead of dw = : a weight used by several forward calls of one step (the 15 frame passes of the
+// generator) collects its gradient in one buffer instead of one tensor per call plus autograd's pairwise sums.
+extern "C" int ag2v_conv2d_wgrad_acc(const float* dy, const float* x, float* dw, int N, int C, int H, int W, int K, int R, int S,
+                                     int stride, int pad, int accumulate, void* stream);
 extern "C" int ag2v_conv2d_wgrad(const float* dy, const float* x, float* dw,
                                  int N, int C, int H, int W, int K, int R, int S, int stride, int pad, void* stream) {
+    return ag2v_conv2d_wgrad_acc(dy, x, dw, N, C, H, W, K, R, S, stride, pad, 0, stream);
+}
+extern "C" int ag2v_conv2d_wgrad_acc(const float* dy, const float* x, float* dw, int N, int C, int H, int W, int K, int R, int S,
+                                     int stride, int pad, int accumulate, void* stream) {
     if (!dy || !x || !dw || N <= 0 || C <= 0 || K <= 0 || stride <= 0) return AG2V_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     ConvArgs a{};
-    a.a_src = dy; a.b_src = x; a.out = dw;
+    a.a_src = dy; a.b_src = x; a.out = dw; a.accumulate = accumulate ? 1 : 0;
     a.N = N; a.C = C; a.H = H; a.W = W; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.pad_w = pad;
     a.OH = conv_out_dim(H, R, stride, pad); a.OW = conv_out_dim(W, S, stride, pad);
     if (a.OH <= 0 || a.OW <= 0) return AG2V_EINVAL;
@@ -704,7 +712,7 @@ extern "C" int ag2v_conv2d_wgrad(const float* dy, const float* x, float* dw,
     kchunk = ((kchunk + 15) / 16) * 16;
     splitk = (int)((Q + kchunk - 1) / kchunk);
     a.splitk = splitk; a.kchunk = kchunk;
-    if (splitk > 1) {
+    if (splitk > 1 && !a.accumulate) {
         if (hipMemsetAsync(dw, 0, (size_t)a.M * a.NG * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
     }
     dim3 grid(tiles, splitk);

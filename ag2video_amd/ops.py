@@ -179,6 +179,45 @@ def kernel_timing_summary(by_shape=False):
     return out
 
 
+# ---- weight-gradient sinks.  A weight tensor used by several convolution calls of one graph (the generator runs once per frame:
+# 15 uses of every weight per step) gets ONE gradient buffer per backward pass: the first weight-gradient launch of the pass
+# writes it and hands it to autograd, the later ones add into it in place (ag2v_conv2d_wgrad_acc) and hand autograd nothing.
+# Autograd delivers the buffer to the weight's producer (cat / spectral norm / AccumulateGrad) only after all of the weight's
+# consumers have run, so it arrives complete; without this it would receive 15 tensors and sum them pairwise (4 700 small add
+# launches and as many zero-fills per step).  The registry is cleared by an engine callback at the end of every backward pass.
+import weakref
+
+_WSINK = {}          # id(weight tensor) -> [weakref to it, sink tensor or None]
+_WSINK_CB = [False]  # end-of-pass callback queued for the current backward pass
+
+
+def _wsink_register(w):
+    e = _WSINK.get(id(w))
+    if e is None or e[0]() is not w:
+        _WSINK[id(w)] = [weakref.ref(w), None]
+    return id(w)
+
+
+def _wsink_clear():
+    _WSINK.clear()
+    _WSINK_CB[0] = False
+
+
+def _wsink_take(key, like):
+    """-> (buffer to pass to the wgrad launch, accumulate flag, tensor to return to autograd or None)."""
+    e = _WSINK.get(key)
+    if e is None:                       # registered before an earlier backward pass cleared the registry: plain path
+        buf = torch.empty_like(like)
+        return buf, 0, buf
+    if not _WSINK_CB[0]:
+        torch.autograd.Variable._execution_engine.queue_callback(_wsink_clear)
+        _WSINK_CB[0] = True
+    if e[1] is None:
+        e[1] = torch.empty_like(like)
+        return e[1], 0, e[1]
+    return e[1], 1, None
+
+
 # ------------------------------------------------------------------------------------------------ convolution
 class _Conv2d(torch.autograd.Function):
     """relu: y = max(conv, 0) in the forward epilogue; its backward masks dy with (y > 0) unless ``grad_premasked`` says the
@@ -188,6 +227,7 @@ class _Conv2d(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, residual, stride, pad, relu, grad_premasked, relu_input):
+        w_in = w
         x, w, bias, residual = _c(x), _c(w), _c(bias), _c(residual)
         _chk(x, w, bias, residual)
         N, C, H, W = x.shape
@@ -204,6 +244,7 @@ class _Conv2d(torch.autograd.Function):
                      _ptr(ws), _stream(), shape=(N, C, H, W, K, R, stride))
         ctx.save_for_backward(x, w, y if (relu and not grad_premasked) else None)
         ctx.cfg = (stride, pad, bias is not None, residual is not None, mr, relu, grad_premasked, relu_input)
+        ctx.wkey = _wsink_register(w_in) if ctx.needs_input_grad[1] else None
         return y
 
     @staticmethod
@@ -227,9 +268,9 @@ class _Conv2d(torch.autograd.Function):
                          _ptr(dy), _ptr(w), _ptr(x) if relu_input else None, _ptr(dx), N, C, H, W, K, R, S, stride, pad, _ptr(ws),
                          st, shape=(N, C, H, W, K, R, stride))
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)
-            _conv_launch(mr, 'ag2v_conv2d_wgrad', _conv_label('wgrad', K, mr), flops,
-                         _ptr(dy), _ptr(x), _ptr(dw), N, C, H, W, K, R, S, stride, pad, st,
+            buf, acc, dw = _wsink_take(ctx.wkey, w)
+            _conv_launch(mr, 'ag2v_conv2d_wgrad_acc', _conv_label('wgrad', K, mr), flops,
+                         _ptr(dy), _ptr(x), _ptr(buf), N, C, H, W, K, R, S, stride, pad, acc, st,
                          shape=(N, C, H, W, K, R, stride))
         if has_bias and ctx.needs_input_grad[2]:
             db = torch.empty(K, device=dy.device, dtype=torch.float32)
@@ -256,6 +297,7 @@ class _ConvSharedInput(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, stride, pad, relu, grad_premasked, *wb):
         x = _c(x)
+        ctx.wkeys = [(_wsink_register(t) if ctx.needs_input_grad[5 + 2 * i] else None) for i, t in enumerate(wb[0::2])]
         ws_, bs_ = [_c(t) for t in wb[0::2]], [_c(t) for t in wb[1::2]]
         _chk(x, *ws_)
         _chk(*[b for b in bs_ if b is not None])
@@ -311,9 +353,9 @@ class _ConvSharedInput(torch.autograd.Function):
                 first = False
             dw = db = None
             if ctx.needs_input_grad[5 + 2 * i]:
-                dw = torch.empty_like(w)
-                _conv_launch(mr, 'ag2v_conv2d_wgrad', 'conv_wgrad', flops, _ptr(dy), _ptr(x), _ptr(dw), N, C, H, W, K, R, S, stride, pad,
-                             st, shape=(N, C, H, W, K, R, stride))
+                buf, acc, dw = _wsink_take(ctx.wkeys[i], w)
+                _conv_launch(mr, 'ag2v_conv2d_wgrad_acc', 'conv_wgrad', flops, _ptr(dy), _ptr(x), _ptr(buf), N, C, H, W, K, R, S, stride,
+                             pad, acc, st, shape=(N, C, H, W, K, R, stride))
             if has_b[i] and ctx.needs_input_grad[6 + 2 * i]:
                 db = torch.empty(K, device=dy.device, dtype=torch.float32)
                 _lib.call('ag2v_channel_sum', _ptr(dy), _ptr(db), N, K, dy.shape[2] * dy.shape[3], st)

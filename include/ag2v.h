@@ -57,6 +57,9 @@ int ag2v_conv2d_dgrad_acc(const float* dy, const float* w, const float* mask, fl
                           void* stream);
 int ag2v_conv2d_wgrad(const float* dy, const float* x, float* dw,
                       int N, int C, int H, int W, int K, int R, int S, int stride, int pad, void* stream);
+/* accumulate != 0: dw += instead of dw = (a weight used by several forward calls of one step collects its gradient in one buffer). */
+int ag2v_conv2d_wgrad_acc(const float* dy, const float* x, float* dw, int N, int C, int H, int W, int K, int R, int S,
+                          int stride, int pad, int accumulate, void* stream);
 /* out[c] = sum over n,hw of x[n,c,hw]: conv bias gradient */
 int ag2v_channel_sum(const float* x, float* out, int N, int C, int HW, void* stream);
 
