@@ -1,226 +1,24 @@
 // Convolution on the bf16 matrix pipe with fp32-level accuracy ("bf16x3"), gfx950.
 //
 // Every fp32 operand is split as x = hi + lo (+O(2^-18|x|)), hi = bf16(x), lo = bf16(x - hi); a product is evaluated as
-// a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16 (exact 16-bit products, fp32 accumulation).  The dropped
+// a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16 / 16x16x32 (exact 16-bit products, fp32 accumulation).  The dropped
 // a_lo*b_lo term and the split residuals are <= ~1e-5 relative -- two orders inside the 1e-3 parity bound of the step and
 // inside the 2e-4 bound of the kernel tests (tests/test_ops_gpu.py runs every conv case in both arithmetic modes) -- while the
 // bf16 pipe runs 16x the fp32 MFMA rate, i.e. 16/3 of it per fp32-equivalent product.
 //
-// Structure (both kernels): 512 threads = 8 waves, each wave a 64x64 sub-tile (2x2 MFMA tiles); block tile 256x128 or
-// 128x256, K-tile 32 (two MFMA k-steps => 24 MFMAs per wave between barriers); LDS holds the hi and lo images of both
-// operands as k-contiguous rows of 32 bf16 (+8 pad = 80 B: ds_read_b128 / ds_write_b128 conflict-free), double-buffered;
-// global loads run two K-tiles ahead through two register sets.  Per iteration (ONE barrier):
-//     load tile t+2 -> regs[t&1]   |   24 MFMAs on LDS[t&1]   |   split+pack regs[(t+1)&1] -> LDS[(t+1)&1]   |   barrier
-// The weight operand of the forward/dgrad kernel arrives pre-split (packed hi:lo words, k-major) from the prep kernels, so
-// its in-kernel cost is two v_perm per pair; activations are split in-kernel (v_cvt_pk_bf16_f32).
+// Structure (all kernels): one workgroup = 16 waves on one CU: 8 PRODUCER waves (global loads two K-tiles ahead, split, LDS
+// stores) and 8 CONSUMER waves (a 64x64 sub-tile each: fragment reads and MFMAs only); block tile 256x128 or 128x256, K-tile 32;
+// LDS holds the hi and lo images of both operands as k-contiguous rows of 32 bf16 (+8 pad = 80 B: ds_read_b128 /
+// ds_write_b128 conflict-free), double-buffered; one workgroup barrier per K-tile.  The weight operand of the forward / data-
+// gradient kernel arrives pre-split (packed hi:lo words, k-major) from the prep kernels, so its in-kernel cost is two v_perm
+// per pair; activations are split in-kernel (v_cvt_pk_bf16_f32).  History and measurements: DESIGN.md 3.4.
 #include "conv_common.h"
 #include <stdlib.h>
 
-#define NT 512
-
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(NT, 2) void conv_igemm_bf16x3_kernel(ConvArgs p) {
-    constexpr int BK = 32, LDK = 40;
-    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int AP = NT / BM, AK = BK / AP;   // A: thread = (m column, k part): AK consecutive k
-    constexpr int BP = NT / BN, BKK = BK / BP;  // B: thread = (pixel column, k part): BKK consecutive k
-    static_assert(WM * WN == 8 && TM == 2 && TN == 2, "8 waves of 64x64");
-    static_assert(AK % 8 == 0 && BKK % 8 == 0, "16-byte LDS stores");
-    __shared__ __attribute__((aligned(16))) unsigned short Ahi[2][BM * LDK];
-    __shared__ __attribute__((aligned(16))) unsigned short Alo[2][BM * LDK];
-    __shared__ __attribute__((aligned(16))) unsigned short Bhi[2][BN * LDK];
-    __shared__ __attribute__((aligned(16))) unsigned short Blo[2][BN * LDK];
-    __shared__ int2 tab[4][BK];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lid = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-    const int tile_m = lid % p.tiles_m, tile_n = lid / p.tiles_m;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int wm0 = (wave / WN) * 64, wn0 = (wave % WN) * 64;
-    const int RS = p.R * p.S;
-    const int SHW = p.H * p.W;
-
-    // ---- B gather state
-    const int bcol = tid % BN, bpart = tid / BN;
-    const int pix = n0 + bcol;
-    const bool pvalid = pix < p.NG;
-    const int n_img = pix / (p.OH * p.OW);
-    const int prem = pix - n_img * (p.OH * p.OW);
-    const int py = prem / p.OW, px = prem - py * p.OW;
-    const int y0 = py * p.stride - p.pad, x0 = px * p.stride - p.pad_w;
-    unsigned vmask = 0;
-    if (pvalid) {
-        for (int r = 0; r < p.R; ++r)
-            for (int s2 = 0; s2 < p.S; ++s2)
-                if ((unsigned)(y0 + r) < (unsigned)p.H && (unsigned)(x0 + s2) < (unsigned)p.W) vmask |= 1u << (r * p.S + s2);
-    }
-    const int bbase = n_img * p.C * SHW + (y0 * p.W + x0);   // element offset of tap (0,0); only used when the tap is valid
-    const __amdgpu_buffer_rsrc_t brs = make_rsrc(p.b_src, p.b_bytes);
-    // ---- A load state (pre-split packed weights, k-major)
-    const int acol = tid % BM, apart = tid / BM;
-    const bool mvalid = (m0 + acol) < p.M;
-    const int abase = m0 + acol;
-    const __amdgpu_buffer_rsrc_t ars = make_rsrc(p.a_src, p.a_bytes);
-
-    auto build_tab = [&](int kt) {
-        if (tid < BK) {
-            const int kg = kt * BK + tid;
-            int c, r, s2;
-            decode_crs(kg, RS, p.S, c, r, s2);
-            const unsigned bit = (kg < p.KG) ? (1u << (r * p.S + s2)) : 0u;
-            tab[kt & 3][tid] = make_int2(c * SHW + r * p.W + s2, (int)bit);
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    auto fetch = [&](int kt, unsigned (&ra)[AK], float (&rb)[BKK]) {
-        const int ka = kt * BK + AK * apart;
-#pragma unroll
-        for (int i = 0; i < AK; ++i)   // rows past KG lie past the descriptor's end (a_bytes = KG*M*4) and read as 0
-            ra[i] = bload_u32(ars, mvalid ? (unsigned)(abase + (ka + i) * p.M) * 4u : 0xFFFFFFFFu);
-#pragma unroll
-        for (int i = 0; i < BKK; ++i) {
-            const int2 e = tab[kt & 3][BKK * bpart + i];
-            rb[i] = bload_f32(brs, (vmask & (unsigned)e.y) ? (unsigned)(bbase + e.x) * 4u : 0xFFFFFFFFu);
-        }
-    };
-    auto stash = [&](int buf, const unsigned (&ra)[AK], const float (&rb)[BKK]) {
-#pragma unroll
-        for (int g = 0; g < AK / 8; ++g) {
-            unsigned h[4], l[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                h[i] = __builtin_amdgcn_perm(ra[8 * g + 2 * i + 1], ra[8 * g + 2 * i], 0x07060302u);   // {hi(k odd), hi(k even)}
-                l[i] = __builtin_amdgcn_perm(ra[8 * g + 2 * i + 1], ra[8 * g + 2 * i], 0x05040100u);   // {lo(k odd), lo(k even)}
-            }
-            const int off = acol * LDK + AK * apart + 8 * g;   // bf16 elements; 16-byte aligned
-            *reinterpret_cast<uint4*>(&Ahi[buf][off]) = make_uint4(h[0], h[1], h[2], h[3]);
-            *reinterpret_cast<uint4*>(&Alo[buf][off]) = make_uint4(l[0], l[1], l[2], l[3]);
-        }
-#pragma unroll
-        for (int g = 0; g < BKK / 8; ++g) {
-            unsigned h[4], l[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) split2(rb[8 * g + 2 * i], rb[8 * g + 2 * i + 1], h[i], l[i]);
-            const int off = bcol * LDK + BKK * bpart + 8 * g;
-            *reinterpret_cast<uint4*>(&Bhi[buf][off]) = make_uint4(h[0], h[1], h[2], h[3]);
-            *reinterpret_cast<uint4*>(&Blo[buf][off]) = make_uint4(l[0], l[1], l[2], l[3]);
-        }
-    };
-    const int fr = lane & 31, fh = lane >> 5;
-    auto compute = [&](int buf) {
-#pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8 ahi[TM], alo[TM], bhi[TN], blo[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int o = (wm0 + i * 32 + fr) * LDK + ks * 16 + 8 * fh;
-                ahi[i] = *reinterpret_cast<const bf16x8*>(&Ahi[buf][o]);
-                alo[i] = *reinterpret_cast<const bf16x8*>(&Alo[buf][o]);
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int o = (wn0 + j * 32 + fr) * LDK + ks * 16 + 8 * fh;
-                bhi[j] = *reinterpret_cast<const bf16x8*>(&Bhi[buf][o]);
-                blo[j] = *reinterpret_cast<const bf16x8*>(&Blo[buf][o]);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[i], bhi[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], blo[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], bhi[j], acc[i][j], 0, 0, 0);
-                }
-        }
-    };
-
-    const int nk_all = (p.KG + BK - 1) / BK;
-    const int kt0 = (p.splitk > 1) ? blockIdx.y * p.kchunk : 0;
-    const int nk = (p.splitk > 1) ? min(nk_all, kt0 + p.kchunk) : nk_all;
-    if (kt0 >= nk) return;  // uniform per workgroup
-    unsigned ra0[AK], ra1[AK];
-    float rb0[BKK], rb1[BKK];
-    build_tab(kt0);
-    build_tab(kt0 + 1);
-    build_tab(kt0 + 2);
-    __syncthreads();
-    fetch(kt0, ra0, rb0);
-    stash(0, ra0, rb0);          // tile kt0 -> LDS buffer 0
-    fetch(kt0 + 1, ra1, rb1);    // tile kt0+1 -> register set 1 (rows past KG read as zero)
-    __syncthreads();
-    // relative iteration it: tile kt0+it sits in LDS buffer it&1, tile kt0+it+1 in register set (it+1)&1
-    for (int kt = kt0; kt < nk; kt += 2) {
-        fetch(kt + 2, ra0, rb0);
-        build_tab(kt + 3);       // slot (kt+3)&3 held tile kt-1's table, last read two iterations ago
-        compute(0);
-        stash(1, ra1, rb1);
-        __syncthreads();
-        if (kt + 1 >= nk) break;
-        fetch(kt + 3, ra1, rb1);
-        build_tab(kt + 4);
-        compute(1);
-        stash(0, ra0, rb0);
-        __syncthreads();
-    }
-
-    // ---- epilogue (C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5))
-    const int gplane = p.OH * p.OW;
-    const int plane = p.o_H * p.o_W;
-    const bool mapped = (p.o_mul != 1 || p.o_add_y != 0 || p.o_add_x != 0 || p.o_W != p.OW);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int opix = n0 + wn0 + j * 32 + (lane & 31);
-        if (opix >= p.NG) continue;
-        const int on = opix / gplane;
-        int orem = opix - on * gplane;
-        if (mapped) {
-            const int qy = orem / p.OW, qx = orem - qy * p.OW;
-            const int yy = qy * p.o_mul + p.o_add_y, xx = qx * p.o_mul + p.o_add_x;
-            if ((unsigned)yy >= (unsigned)p.o_H || (unsigned)xx >= (unsigned)p.o_W) continue;
-            orem = yy * p.o_W + xx;
-        }
-        float* obase = p.out + (size_t)on * p.M * plane + orem;
-        const float* rbase = p.residual ? p.residual + (size_t)on * p.M * plane + orem : nullptr;
-        const float* mbase = (p.mask && p.splitk == 1) ? p.mask + (size_t)on * p.M * plane + orem : nullptr;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m < p.M) {
-                    float v = acc[i][j][r];
-                    if (kt0 == 0) {
-                        if (p.bias) v += p.bias[m];
-                        if (rbase) v += rbase[(size_t)m * plane];
-                    }
-                    if (p.splitk == 1) {   // (a split-K launch applies these in a pass over the finished sums: launch_act_mask)
-                        if (p.relu) v = fmaxf(v, 0.f);
-                        if (mbase) v = (mbase[(size_t)m * plane] > 0.f) ? v : 0.f;
-                    }
-                    if (p.splitk > 1)
-                        atomicAdd(obase + (size_t)m * plane, v);
-                    else
-                        obase[(size_t)m * plane] = v;
-                }
-            }
-        }
-    }
-}
-
-// Wave-specialised form of the kernel above.  PMC on the homogeneous 8-wave kernel: 7 VALU per MFMA, the MFMA pipe 32 % busy,
-// waves 51 % in s_waitcnt / barrier -- all waves of a workgroup march through "MFMA phase" and "split+stage phase" together,
-// so the matrix pipe idles while every wave converts.  Here waves 0-3 (one per SIMD) are PRODUCERS: they issue all global
-// loads (two K-tiles ahead), split/pack and write LDS; waves 4-7 (one per SIMD) are CONSUMERS: they only read fragments and
-// issue MFMAs (128x64 sub-tile each, 48 MFMAs per K-tile).  A SIMD therefore always has one VALU-bound and one MFMA-bound
-// wave, which the hardware runs concurrently (separate pipes); one workgroup barrier per K-tile hands the buffers over.
+// Forward / data-gradient implicit GEMM.  A homogeneous first version (8 waves that all loaded, split and multiplied: 7 VALU
+// per MFMA, the MFMA pipe 32 % busy, waves 51 % in s_waitcnt / barrier because every wave converts at the same time) is in the
+// history; here the two jobs sit on different waves of each SIMD, which the hardware runs concurrently (separate pipes), and
+// one workgroup barrier per K-tile hands the buffers over.
 template <int BM, int BN, int CWM, int CWN, int NPW, bool MF16>
 __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_kernel(ConvArgs p) {
     constexpr int BK = 32, LDK = 40, NP = NPW * 64;       // NP producer threads
@@ -527,178 +325,9 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
 }
 
 // Weight gradient: dW[m,j] = sum_q dY[m,q] * Xg[q,j], q = (n,oy,ox), j = (c,r,s).  Both operands are activations (split
-// in-kernel).  A thread owns one PAIR of consecutive pixels q for BM/32 rows of dY and BN/32 columns of the gather, so each
-// (hi | lo) pair is one packed ds_write_b32 into the k-contiguous LDS rows.
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(NT, 2) void conv_wgrad_bf16x3_kernel(ConvArgs p) {
-    constexpr int BK = 32, LDK = 40;
-    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int RA = BM / 32, RB = BN / 32;   // rows of dY / gather columns per thread
-    static_assert(WM * WN == 8 && TM == 2 && TN == 2, "8 waves of 64x64");
-    __shared__ __attribute__((aligned(16))) unsigned short Ahi[2][BM * LDK];
-    __shared__ __attribute__((aligned(16))) unsigned short Alo[2][BM * LDK];
-    __shared__ __attribute__((aligned(16))) unsigned short Bhi[2][BN * LDK];
-    __shared__ __attribute__((aligned(16))) unsigned short Blo[2][BN * LDK];
-    __shared__ int4 qtab[4][BK];   // per pixel q of a K-tile: {x offset of tap (0,0), dY offset, (yb<<16)|xb, valid}
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lid = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-    const int tile_m = lid % p.tiles_m, tile_n = lid / p.tiles_m;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int wm0 = (wave / WN) * 64, wn0 = (wave % WN) * 64;
-    const int RS = p.R * p.S;
-    const int OHW = p.OH * p.OW, HW = p.H * p.W;
-    const int Q = p.N * OHW;
-    const int qs = blockIdx.y * p.kchunk;
-    const int qe = min(qs + p.kchunk, Q);
-    if (qs >= qe) return;
-    const __amdgpu_buffer_rsrc_t ars = make_rsrc(p.a_src, p.a_bytes), brs = make_rsrc(p.b_src, p.b_bytes);
-
-    const int qp = tid & 15, rg = tid >> 4;   // pixel pair (2qp, 2qp+1) of the K-tile; rows / columns rg + 32 i
-    int aoff[RA], boff[RB], bpk[RB];
-#pragma unroll
-    for (int i = 0; i < RA; ++i) {
-        const int m = m0 + rg + 32 * i;
-        aoff[i] = (m < p.M) ? m * OHW : -1;
-    }
-#pragma unroll
-    for (int i = 0; i < RB; ++i) {
-        const int j = n0 + rg + 32 * i;
-        int c, r, s;
-        decode_crs(j, RS, p.S, c, r, s);
-        bpk[i] = ((r - p.pad + 64) & 255) | (((s - p.pad + 64) & 255) << 8) | ((j < p.NG) ? (1 << 16) : 0);
-        boff[i] = c * HW + (r - p.pad) * p.W + (s - p.pad);
-    }
-    auto build_tab = [&](int t) {   // t = tile index relative to qs
-        if (tid < BK) {
-            const int q = qs + t * BK + tid;
-            const bool v = q < qe;
-            const int qc = v ? q : qs;
-            const int n = qc / OHW;
-            const int pixl = qc - n * OHW;
-            const int oy = pixl / p.OW, ox = pixl - oy * p.OW;
-            const int yb = oy * p.stride, xb = ox * p.stride;
-            qtab[t & 3][tid] = make_int4(n * p.C * HW + yb * p.W + xb, n * p.K * OHW + pixl, (yb << 16) | xb, v ? 1 : 0);
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    auto fetch = [&](int t, float (&ra)[2 * RA], float (&rb)[2 * RB]) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int4 e = qtab[t & 3][2 * qp + h];
-            const int yb = e.z >> 16, xb = e.z & 0xFFFF;
-#pragma unroll
-            for (int i = 0; i < RA; ++i)
-                ra[2 * i + h] = bload_f32(ars, (e.w && aoff[i] >= 0) ? (unsigned)(e.y + aoff[i]) * 4u : 0xFFFFFFFFu);
-#pragma unroll
-            for (int i = 0; i < RB; ++i) {
-                const int iy = yb + (bpk[i] & 255) - 64, ix = xb + ((bpk[i] >> 8) & 255) - 64;
-                const bool ok = e.w && (bpk[i] >> 16) && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                rb[2 * i + h] = bload_f32(brs, ok ? (unsigned)(e.x + boff[i]) * 4u : 0xFFFFFFFFu);
-            }
-        }
-    };
-    auto stash = [&](int buf, const float (&ra)[2 * RA], const float (&rb)[2 * RB]) {
-#pragma unroll
-        for (int i = 0; i < RA; ++i) {
-            unsigned hi, lo;
-            const int off = (rg + 32 * i) * LDK + 2 * qp;
-            split2(ra[2 * i], ra[2 * i + 1], hi, lo);
-            *reinterpret_cast<unsigned*>(&Ahi[buf][off]) = hi;
-            *reinterpret_cast<unsigned*>(&Alo[buf][off]) = lo;
-        }
-#pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            unsigned hi, lo;
-            const int off = (rg + 32 * i) * LDK + 2 * qp;
-            split2(rb[2 * i], rb[2 * i + 1], hi, lo);
-            *reinterpret_cast<unsigned*>(&Bhi[buf][off]) = hi;
-            *reinterpret_cast<unsigned*>(&Blo[buf][off]) = lo;
-        }
-    };
-    const int fr = lane & 31, fh = lane >> 5;
-    auto compute = [&](int buf) {
-#pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8 ahi[TM], alo[TM], bhi[TN], blo[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int o = (wm0 + i * 32 + fr) * LDK + ks * 16 + 8 * fh;
-                ahi[i] = *reinterpret_cast<const bf16x8*>(&Ahi[buf][o]);
-                alo[i] = *reinterpret_cast<const bf16x8*>(&Alo[buf][o]);
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int o = (wn0 + j * 32 + fr) * LDK + ks * 16 + 8 * fh;
-                bhi[j] = *reinterpret_cast<const bf16x8*>(&Bhi[buf][o]);
-                blo[j] = *reinterpret_cast<const bf16x8*>(&Blo[buf][o]);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[i], bhi[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], blo[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], bhi[j], acc[i][j], 0, 0, 0);
-                }
-        }
-    };
-
-    const int nt = (qe - qs + BK - 1) / BK;
-    float ra0[2 * RA], ra1[2 * RA], rb0[2 * RB], rb1[2 * RB];
-    build_tab(0);
-    build_tab(1);
-    build_tab(2);
-    __syncthreads();
-    fetch(0, ra0, rb0);
-    stash(0, ra0, rb0);
-    fetch(1, ra1, rb1);
-    __syncthreads();
-    for (int t = 0; t < nt; t += 2) {
-        fetch(t + 2, ra0, rb0);
-        build_tab(t + 3);
-        compute(0);
-        stash(1, ra1, rb1);
-        __syncthreads();
-        if (t + 1 >= nt) break;
-        fetch(t + 3, ra1, rb1);
-        build_tab(t + 4);
-        compute(1);
-        stash(0, ra0, rb0);
-        __syncthreads();
-    }
-
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int colj = n0 + wn0 + j * 32 + (lane & 31);
-        if (colj >= p.NG) continue;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m < p.M) {
-                    float* dst = p.out + (size_t)m * p.NG + colj;
-                    if (p.splitk > 1 || p.accumulate)
-                        atomicAdd(dst, acc[i][j][r]);
-                    else
-                        *dst = acc[i][j][r];
-                }
-            }
-        }
-    }
-}
-
-// Wave-specialised weight gradient (same producer / consumer split as conv_igemm_bf16x3_ws_kernel): 8 producer waves own
-// the pixel-pair loads, the split and the packed ds_write_b32; 8 consumer waves (64x64 each) only read fragments and issue MFMAs.
+// in-kernel).  General form (any stride / width): a producer thread owns one PAIR of consecutive pixels q for a set of rows of dY
+// and columns of the gather, so each (hi | lo) pair is one packed ds_write_b32 into the k-contiguous LDS rows; 8 consumer
+// waves (64x64 each) only read fragments and issue MFMAs (same producer / consumer split as conv_igemm_bf16x3_ws_kernel).
 template <int BM, int BN, int CWM, int CWN, int NPW>
 __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_ws_kernel(ConvArgs p) {
     constexpr int BK = 32, LDK = 40, NP = NPW * 64;
@@ -1150,17 +779,12 @@ int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed) {
     }
     if (a.splitk > 1 && a.residual == a.out) a.residual = nullptr;   // accumulating launch: the atomics already add onto out
     dim3 grid(tiles, a.splitk);
-    static const bool homogeneous = getenv("AG2V_BF16X3_HOMOGENEOUS") != nullptr;   // A/B switch: all 8 waves do everything
-    if (homogeneous) {
-        if (tall)
-            { set_last_conv_kernel("conv_igemm_bf16x3_kernel<256, 128, 4, 2>"); hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<256, 128, 4, 2>), grid, dim3(NT), 0, st, a); }
-        else
-            { set_last_conv_kernel("conv_igemm_bf16x3_kernel<128, 256, 2, 4>"); hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<128, 256, 2, 4>), grid, dim3(NT), 0, st, a); }
+    if (tall) {
+        set_last_conv_kernel("conv_igemm_bf16x3_ws_kernel<256, 128, 4, 2, 8, true>");
+        hipLaunchKernelGGL((conv_igemm_bf16x3_ws_kernel<256, 128, 4, 2, 8, true>), grid, dim3(1024), 0, st, a);
     } else {
-        if (tall)
-            { set_last_conv_kernel("conv_igemm_bf16x3_ws_kernel<256, 128, 4, 2, 8, true>"); hipLaunchKernelGGL((conv_igemm_bf16x3_ws_kernel<256, 128, 4, 2, 8, true>), grid, dim3(1024), 0, st, a); }
-        else
-            { set_last_conv_kernel("conv_igemm_bf16x3_ws_kernel<128, 256, 2, 4, 8, false>"); hipLaunchKernelGGL((conv_igemm_bf16x3_ws_kernel<128, 256, 2, 4, 8, false>), grid, dim3(1024), 0, st, a); }
+        set_last_conv_kernel("conv_igemm_bf16x3_ws_kernel<128, 256, 2, 4, 8, false>");
+        hipLaunchKernelGGL((conv_igemm_bf16x3_ws_kernel<128, 256, 2, 4, 8, false>), grid, dim3(1024), 0, st, a);
     }
     AG2V_CHECK_LAUNCH();
     if (a.splitk > 1 && (a.relu || a.mask))
@@ -1183,31 +807,24 @@ int launch_wgrad_bf16x3(ConvArgs& a, hipStream_t st) {
     if (splitk > 1 && !a.accumulate) {
         if (hipMemsetAsync(a.out, 0, (size_t)a.M * a.NG * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
     }
-    dim3 grid(tiles, splitk);
-    static const bool homogeneous = getenv("AG2V_BF16X3_HOMOGENEOUS") != nullptr;
-    if (!homogeneous) grid = dim3(tiles * splitk);     // the wave-specialised kernels decode (split, tile) themselves
-    if (homogeneous) {
-        if (tall)
-            { set_last_conv_kernel("conv_wgrad_bf16x3_kernel<256, 128, 4, 2>"); hipLaunchKernelGGL((conv_wgrad_bf16x3_kernel<256, 128, 4, 2>), grid, dim3(NT), 0, st, a); }
-        else
-            { set_last_conv_kernel("conv_wgrad_bf16x3_kernel<128, 256, 2, 4>"); hipLaunchKernelGGL((conv_wgrad_bf16x3_kernel<128, 256, 2, 4>), grid, dim3(NT), 0, st, a); }
-    } else if (a.stride == 1 && a.OW % 8 == 0 && a.W >= 8 && a.pad <= 7 && a.S - 1 - a.pad <= 7 &&
-               getenv("AG2V_WGRAD_SCALAR_LOADS") == nullptr) {
-        // 16-byte loads along the pixel index (runs of 8 pixels never straddle an image row)
-        static const bool w16 = getenv("AG2V_WGRAD_MF32") == nullptr;    // 16x16x32 MFMAs in the consumers (+3..9 % here); A/B switch
-        if (tall && w16)
-            { set_last_conv_kernel("conv_wgrad_bf16x3_v_kernel<256, 128, 4, 2, 8, true>"); hipLaunchKernelGGL((conv_wgrad_bf16x3_v_kernel<256, 128, 4, 2, 8, true>), grid, dim3(1024), 0, st, a); }
-        else if (tall)
-            { set_last_conv_kernel("conv_wgrad_bf16x3_v_kernel<256, 128, 4, 2, 8, false>"); hipLaunchKernelGGL((conv_wgrad_bf16x3_v_kernel<256, 128, 4, 2, 8, false>), grid, dim3(1024), 0, st, a); }
-        else if (w16)
-            { set_last_conv_kernel("conv_wgrad_bf16x3_v_kernel<128, 256, 2, 4, 8, true>"); hipLaunchKernelGGL((conv_wgrad_bf16x3_v_kernel<128, 256, 2, 4, 8, true>), grid, dim3(1024), 0, st, a); }
-        else
-            { set_last_conv_kernel("conv_wgrad_bf16x3_v_kernel<128, 256, 2, 4, 8, false>"); hipLaunchKernelGGL((conv_wgrad_bf16x3_v_kernel<128, 256, 2, 4, 8, false>), grid, dim3(1024), 0, st, a); }
+    const dim3 grid(tiles * splitk);     // 1-D: the kernels decode (split, tile) themselves (XCD-aware)
+    if (a.stride == 1 && a.OW % 8 == 0 && a.W >= 8 && getenv("AG2V_WGRAD_SCALAR_LOADS") == nullptr) {
+        // 16-byte loads along the pixel index (runs of 8 pixels never straddle an image row); 16x16x32 MFMAs in the consumers
+        if (tall) {
+            set_last_conv_kernel("conv_wgrad_bf16x3_v_kernel<256, 128, 4, 2, 8, true>");
+            hipLaunchKernelGGL((conv_wgrad_bf16x3_v_kernel<256, 128, 4, 2, 8, true>), grid, dim3(1024), 0, st, a);
+        } else {
+            set_last_conv_kernel("conv_wgrad_bf16x3_v_kernel<128, 256, 2, 4, 8, true>");
+            hipLaunchKernelGGL((conv_wgrad_bf16x3_v_kernel<128, 256, 2, 4, 8, true>), grid, dim3(1024), 0, st, a);
+        }
     } else {
-        if (tall)
-            { set_last_conv_kernel("conv_wgrad_bf16x3_ws_kernel<256, 128, 4, 2, 8>"); hipLaunchKernelGGL((conv_wgrad_bf16x3_ws_kernel<256, 128, 4, 2, 8>), grid, dim3(1024), 0, st, a); }
-        else
-            { set_last_conv_kernel("conv_wgrad_bf16x3_ws_kernel<128, 256, 2, 4, 8>"); hipLaunchKernelGGL((conv_wgrad_bf16x3_ws_kernel<128, 256, 2, 4, 8>), grid, dim3(1024), 0, st, a); }
+        if (tall) {
+            set_last_conv_kernel("conv_wgrad_bf16x3_ws_kernel<256, 128, 4, 2, 8>");
+            hipLaunchKernelGGL((conv_wgrad_bf16x3_ws_kernel<256, 128, 4, 2, 8>), grid, dim3(1024), 0, st, a);
+        } else {
+            set_last_conv_kernel("conv_wgrad_bf16x3_ws_kernel<128, 256, 2, 4, 8>");
+            hipLaunchKernelGGL((conv_wgrad_bf16x3_ws_kernel<128, 256, 2, 4, 8>), grid, dim3(1024), 0, st, a);
+        }
     }
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
