@@ -103,8 +103,8 @@ def cpu_baseline(timeout_s=240):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)     # warm-up 3 steps, time >= 10 steps (~20 s at c3)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--config', default='c3', choices=sorted(CONFIGS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-only', action='store_true')
