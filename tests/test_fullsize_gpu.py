@@ -1,0 +1,151 @@
+"""Parity at BASELINE.json's full (c3) layer sizes through size-independent properties: the oracle cannot run a 256x256x512
+convolution in seconds, but (a) a convolution is local -- a window of the full-size GPU output must equal the oracle's result on
+the matching crop; (b) forward / data-gradient / weight-gradient are adjoints of one bilinear form (dot-product test);
+(c) normalisation outputs have known per-channel moments; (d) the pyramid adjoint conserves mass; (e) the warp is linear in the image
+and maps constants to themselves;
+(f) the two arithmetic modes of the convolution agree.  Tolerances are stated per check (fp32 with 1e-5-level split products)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(*shape, seed=0, device='cpu', scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(device)
+
+
+# the three GEMM shapes of the SPADE stack at 256x256 (c3): mlp_shared 512 -> 128, gamma|beta 128 -> 2*64, conv_0 of up_3 128 -> 64
+FULL = [(8, 512, 256, 256, 128), (8, 128, 256, 256, 128), (8, 128, 256, 256, 64)]
+
+
+@pytest.mark.parametrize("shape", FULL, ids=str)
+@pytest.mark.parametrize("prec", ['bf16x3', 'fp32'])
+def test_conv_window_matches_oracle_crop(shape, prec, device):
+    from ag2video_amd import ops
+    from oracle import kernels as K
+    N, C, H, W, Ko = shape
+    old = ops.get_conv_precision()
+    ops.set_conv_precision(prec)
+    try:
+        with ops.bf16x3_min_rows(48):
+            x = _rand(N, C, H, W, seed=1, device=device)
+            w = _rand(Ko, C, 3, 3, seed=2, device=device, scale=(C * 9) ** -0.5)
+            b = _rand(Ko, seed=3, device=device)
+            y = ops.conv2d(x, w, b, 1, 1)
+        for (n, y0, x0) in [(0, 0, 0), (N - 1, H - 24, W - 24), (3, 101, 57)]:     # corner windows exercise the padding taps
+            ys, xs = max(0, y0 - 1), max(0, x0 - 1)
+            ye, xe = min(H, y0 + 25), min(W, x0 + 25)
+            crop = x[n:n + 1, :, ys:ye, xs:xe].cpu()
+            # pad the crop where the window touches the image border so that the oracle sees the same zero padding
+            pt, pl = 1 - (y0 - ys), 1 - (x0 - xs)
+            pb, pr = 1 - (ye - (y0 + 24)), 1 - (xe - (x0 + 24))
+            crop = torch.nn.functional.pad(crop, (pl, pr, pt, pb))
+            ref = K.conv2d(crop, w.cpu(), b.cpu(), 1, 0)                      # [1, Ko, 24, 24]
+            got = y[n:n + 1, :, y0:y0 + 24, x0:x0 + 24].cpu()
+            err = (got - ref).abs().max().item() / ref.abs().max().item()
+            assert err <= 2e-4, (shape, prec, (n, y0, x0), err)
+    finally:
+        ops.set_conv_precision(old)
+
+
+@pytest.mark.parametrize("shape", FULL[:2], ids=str)
+def test_conv_adjoint_identities(shape, device):
+    """<conv(x, w), dy> == <x, dgrad(dy)> == <w, wgrad(dy)> at full size (fp64 dot products of the fp32 kernel outputs)."""
+    from ag2video_amd import ops
+    N, C, H, W, Ko = shape
+    x = _rand(N, C, H, W, seed=1, device=device).requires_grad_(True)
+    w = _rand(Ko, C, 3, 3, seed=2, device=device, scale=(C * 9) ** -0.5).requires_grad_(True)
+    dy = _rand(N, Ko, H, W, seed=3, device=device)
+    y = ops.conv2d(x, w, None, 1, 1)
+    y.backward(dy)
+    a = (y.detach().double() * dy.double()).sum().item()
+    bx = (x.detach().double() * x.grad.double()).sum().item()
+    bw = (w.detach().double() * w.grad.double()).sum().item()
+    scale = (y.detach().double().pow(2).sum().sqrt() * dy.double().pow(2).sum().sqrt()).item()
+    assert abs(a - bx) <= 2e-5 * scale, (a, bx, scale)
+    assert abs(a - bw) <= 2e-5 * scale, (a, bw, scale)
+
+
+def test_conv_modes_agree_full_size(device):
+    from ag2video_amd import ops
+    N, C, H, W, Ko = FULL[0]
+    x = _rand(N, C, H, W, seed=1, device=device)
+    w = _rand(Ko, C, 3, 3, seed=2, device=device, scale=(C * 9) ** -0.5)
+    old = ops.get_conv_precision()
+    try:
+        ops.set_conv_precision('fp32')
+        y0 = ops.conv2d(x, w, None, 1, 1)
+        ops.set_conv_precision('bf16x3')
+        y1 = ops.conv2d(x, w, None, 1, 1)
+    finally:
+        ops.set_conv_precision(old)
+    err = ((y0 - y1).abs().max() / y0.abs().max()).item()
+    assert err <= 5e-5, err
+
+
+def test_spade_norm_moments_full_size(device):
+    """gamma = beta = 0, slope 1: the output is the batch-normalised input -> per-channel mean 0, variance 1."""
+    from ag2video_amd import ops
+    N, C, H, W = 8, 64, 256, 256
+    x = _rand(N, C, H, W, seed=4, device=device) * 3.0 + 1.5
+    gb = torch.zeros(N, 2 * C, H, W, device=device)
+    rm, rv = torch.zeros(C, device=device), torch.ones(C, device=device)
+    y = ops.spade_norm_fused(x, gb, rm, rv, True, 0.1, 1e-5, 1.0)
+    m = y.double().mean(dim=(0, 2, 3))
+    v = y.double().var(dim=(0, 2, 3), unbiased=False)
+    assert m.abs().max().item() <= 1e-4 and (v - 1).abs().max().item() <= 1e-4, (m.abs().max().item(), (v - 1).abs().max().item())
+    # running statistics: momentum 0.1 of the batch mean / unbiased variance
+    xm = x.double().mean(dim=(0, 2, 3))
+    assert ((rm.double() - 0.1 * xm).abs().max() <= 1e-5 * xm.abs().max()).item()
+
+
+def test_pyramid_adjoint_conserves_mass_full_size(device):
+    from ag2video_amd import ops
+    N, C, H = 8, 512, 256
+    x = _rand(N, C, H, H, seed=5, device=device).requires_grad_(True)
+    sizes = [(8 << i, 8 << i) for i in range(6)]
+    ys = ops.nearest_pyramid(x, sizes)
+    gs = [_rand(*y.shape, seed=10 + i, device=device) for i, y in enumerate(ys)]
+    torch.autograd.backward(ys, gs)
+    total = sum(g.double().sum().item() for g in gs)
+    got = x.grad.double().sum().item()
+    norm = sum(g.double().abs().sum().item() for g in gs)
+    assert abs(got - total) <= 1e-6 * norm, (got, total)
+    # and level values land on the grid points: dx at (0, 0) carries one term from every level
+    want00 = sum(g[0, 0, 0, 0].item() for g in gs)
+    assert abs(x.grad[0, 0, 0, 0].item() - want00) <= 1e-5 * max(1.0, abs(want00))
+
+
+def test_flow_warp_is_linear_and_preserves_constants_full_size(device):
+    """Bilinear border-clamped sampling is linear in the image and maps a constant image to itself for ANY flow.  (A zero flow
+    is NOT the identity here: the reference builds its grid with linspace(-1, 1) but samples with align_corners=False,
+    models/utils.py:113-140 -- the product reproduces that.)"""
+    from ag2video_amd import ops
+    a, b = _rand(8, 3, 256, 256, seed=6, device=device), _rand(8, 3, 256, 256, seed=7, device=device)
+    flow = _rand(8, 2, 256, 256, seed=8, device=device) * 6.0
+    lhs = ops.flow_warp(0.7 * a - 1.3 * b, flow)
+    rhs = 0.7 * ops.flow_warp(a, flow) - 1.3 * ops.flow_warp(b, flow)
+    assert (lhs - rhs).abs().max().item() <= 1e-5 * max(1.0, rhs.abs().max().item())
+    const = torch.full((8, 3, 256, 256), 0.375, device=device)
+    assert (ops.flow_warp(const, flow) - const).abs().max().item() <= 1e-6
+
+
+def test_full_size_step_runs_and_is_finite(device):
+    """One c3 training step (256x256, 16 frames, batch 8): finite losses of the documented keys, parameters move."""
+    import bench
+    from ag2video_amd.data.synthetic import make_clip_batch
+    from ag2video_amd.engine import TrainStep
+    opt, side, frames, batch = bench.make_opt('c3')
+    opt.gpu_ids = [0]
+    ts = TrainStep(opt, device, weights_seed=0)
+    clip = ts.to_device(make_clip_batch(opt.vocab, batch, frames, (side, side), seed=1234))
+    pg = dict(ts.model.named_parameters())
+    name = next(k for k in pg if 'netG' in k and k.endswith('weight_orig'))     # a generator weight (the graph nets have their own step)
+    p0 = pg[name].detach().clone()
+    out, GL, DL = ts.gd_step(clip)
+    assert set(GL) >= {'GAN_Img', 'GAN_Feat', 'loss_F_Warp', 'total_loss'} and set(DL) >= {'D_img_fake', 'D_img_real', 'total_img_loss'}
+    assert all(bool(torch.isfinite(v).all()) for v in list(GL.values()) + list(DL.values()))
+    assert tuple(out[0].shape) == (batch, frames, 3, side, side)
+    assert (pg[name].detach() - p0).abs().max().item() > 0
