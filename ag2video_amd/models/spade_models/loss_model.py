@@ -61,12 +61,14 @@ class LossModel(torch.nn.Module):
         r_adata = [item[:, nc:] for item in actions_data]
         G = {}
         with _params_frozen(self.netD_img):
-            fake = self.netD_img(r_pred, objs, r_boxes, r_adata)
+            # the layout part of D's first convolutions is the same for the fake and the real pass: computed once
+            terms = self.netD_img.layout_terms(objs, r_boxes, r_adata) if hasattr(self.netD_img, 'layout_terms') else None
+            fake = self.netD_img(r_pred, objs, r_boxes, r_adata, **({'layout_terms': terms} if terms is not None else {}))
         G['GAN_Img'] = self.criterionGAN(fake, True, for_discriminator=False).squeeze(0) * \
             self.opt.discriminator_img_loss_weight
         if not self.opt.no_ganFeat_loss:
             with torch.no_grad():           # the real features are only used detached (loss_model.py:84)
-                real = self.netD_img(r_imgs, objs, r_boxes, r_adata)
+                real = self.netD_img(r_imgs, objs, r_boxes, r_adata, **({'layout_terms': terms} if terms is not None else {}))
             num_D = len(fake)
             feat = torch.zeros(1, device=imgs.device, dtype=torch.float32)
             for i in range(num_D):
@@ -86,8 +88,10 @@ class LossModel(torch.nn.Module):
         imgs_pred, boxes_pred, flows_pred, conf_pred, actions_data = model_out
         nc = self.n_frames_G - 1
         r_adata = [item[:, nc:] for item in actions_data]
-        fake = self.netD_img(imgs_pred[:, nc:].detach(), objs, boxes[:, nc:], r_adata)
-        real = self.netD_img(imgs[:, nc:], objs, boxes[:, nc:], r_adata)
+        terms = self.netD_img.layout_terms(objs, boxes[:, nc:], r_adata) if hasattr(self.netD_img, 'layout_terms') else None
+        kw = {'layout_terms': terms} if terms is not None else {}
+        fake = self.netD_img(imgs_pred[:, nc:].detach(), objs, boxes[:, nc:], r_adata, **kw)
+        real = self.netD_img(imgs[:, nc:], objs, boxes[:, nc:], r_adata, **kw)
         D = {"D_img_fake": self.criterionGAN(fake, False, for_discriminator=True),
              "D_img_real": self.criterionGAN(real, True, for_discriminator=True)}
         D["total_img_loss"] = torch.stack(list(D.values()), dim=0).sum()

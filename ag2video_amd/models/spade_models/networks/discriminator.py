@@ -103,41 +103,72 @@ class MultiscaleActionDiscriminator(nn.Module):
             out.append(ov)
         return torch.stack(out, dim=1)
 
-    def forward(self, img, objs, layout_boxes, actions_data):
-        """img [B,T,3,H,W], layout_boxes [B,T,O,4] -> num_D lists of n_layers_D+1 feature maps over [B*T, ...]."""
+    def forward(self, img, objs, layout_boxes, actions_data, layout_terms=None):
+        """img [B,T,3,H,W], layout_boxes [B,T,O,4] -> num_D lists of n_layers_D+1 feature maps over [B*T, ...].
+        ``layout_terms``: the result of self.layout_terms(objs, layout_boxes, actions_data), when the caller evaluates the
+        discriminator on several images with the same layout (LossModel: fake and real)."""
         with ops.bf16x3_min_rows(48):      # the 64-channel first layers too (no warp downstream: ops.bf16x3_min_rows)
-            return self._forward(img, objs, layout_boxes, actions_data)
+            return self._forward(img, objs, layout_boxes, actions_data, layout_terms)
 
-    def _forward(self, img, objs, layout_boxes, actions_data):
-        H = self.opt.image_size[0]
-        ov = self.get_obj_vecs(objs, layout_boxes, actions_data)
-        att = self.attribute_embedding(objs)
-        B, T = ov.size(0), ov.size(1)
-        v = self.fc_objs_vecs(torch.cat([att.unsqueeze(1).expand(B, T, att.size(1), att.size(2)), ov], dim=-1))
-        low_rank = getattr(self.opt, 'low_rank_layout', True) and self.opt.num_D <= 2
-        result = []
-        if low_rank:
-            # The 256 layout channels of the 259-channel input are a sum over objects of (vector) x (box weight map): both
-            # scales' first convolutions take them in low-rank form (scale 1 with the pooled box profiles), so neither the
-            # [B*T, 259, H, W] input nor its pooled copy is ever built; only the 3 image channels are convolved densely.
+    def _low_rank(self):
+        return getattr(self.opt, 'low_rank_layout', True) and self.opt.num_D <= 2
+
+    def layout_terms(self, objs, layout_boxes, actions_data):
+        """The part of every scale's first convolution that comes from the 256 layout channels (graph net on the actions ->
+        object vectors -> low-rank layout convolution).  It depends on the layout inputs and this module's parameters only, not
+        on the image: the reference recomputes it inside each of its four discriminator passes per step
+        (loss_model.py:73,77,118,120); LossModel computes it once per loss and shares it between the fake and the real pass
+        (identical values; in the discriminator loss autograd sums the two passes' gradients into the shared node).
+        Returns None when the dense route is configured."""
+        if not self._low_rank():
+            return None
+        with ops.bf16x3_min_rows(48):
+            H = self.opt.image_size[0]
+            ov = self.get_obj_vecs(objs, layout_boxes, actions_data)
+            att = self.attribute_embedding(objs)
+            B, T = ov.size(0), ov.size(1)
+            v = self.fc_objs_vecs(torch.cat([att.unsqueeze(1).expand(B, T, att.size(1), att.size(2)), ov], dim=-1))
             keep = remove_dummy_objects(objs, self.opt.vocab)                                   # [B, O]
             keep = keep.unsqueeze(1).expand(B, T, keep.size(1)).reshape(B * T, -1)
             vf = v.reshape(B * T, v.size(2), v.size(3))
             bf = layout_boxes.reshape(B * T, layout_boxes.size(2), 4)
+            terms, scale = [], 0
+            for name, D in self.named_children():
+                if name.startswith('discriminator'):
+                    conv = D.model0[0]
+                    terms.append(layout_conv_lowrank(conv.weight[:, 3:], [vf], [bf], keep, H, H, conv.stride[0], conv.padding[0],
+                                                     residual=None, pool=scale))
+                    scale += 1
+            return terms
+
+    def _forward(self, img, objs, layout_boxes, actions_data, layout_terms=None):
+        H = self.opt.image_size[0]
+        result = []
+        if self._low_rank():
+            # The 256 layout channels of the 259-channel input are a sum over objects of (vector) x (box weight map): both
+            # scales' first convolutions take them in low-rank form (scale 1 with the pooled box profiles), so neither the
+            # [B*T, 259, H, W] input nor its pooled copy is ever built; only the 3 image channels are convolved densely, with
+            # the layout term added in the convolution's epilogue.
+            if layout_terms is None:
+                layout_terms = self.layout_terms(objs, layout_boxes, actions_data)
+            B, T = img.size(0), img.size(1)
             x_img = img.reshape(B * T, img.size(2), H, H)
             scale = 0
             for name, D in self.named_children():
                 if name.startswith('discriminator'):
                     conv = D.model0[0]
                     nimg = x_img.size(1)
-                    y = ops.conv2d(x_img, conv.weight[:, :nimg], conv.bias, conv.stride[0], conv.padding[0])
-                    y = layout_conv_lowrank(conv.weight[:, nimg:], [vf], [bf], keep, H, H, conv.stride[0], conv.padding[0],
-                                            residual=y, pool=scale)
+                    y = ops.conv2d(x_img, conv.weight[:, :nimg], conv.bias, conv.stride[0], conv.padding[0],
+                                   residual=layout_terms[scale])
                     out = D(first_conv=y)
                     result.append(out if not self.opt.no_ganFeat_loss else [out])
                     x_img = self.downsample(x_img)
                     scale += 1
             return result
+        ov = self.get_obj_vecs(objs, layout_boxes, actions_data)
+        att = self.attribute_embedding(objs)
+        B, T = ov.size(0), ov.size(1)
+        v = self.fc_objs_vecs(torch.cat([att.unsqueeze(1).expand(B, T, att.size(1), att.size(2)), ov], dim=-1))
         segs = render_clip_layouts(v, layout_boxes, objs, self.opt.vocab, H, H, frame_major=True)   # T x [B, 256, H, W]
         seg = torch.stack(segs, dim=1)                                                              # [B, T, 256, H, W]
         x = torch.cat([img, seg], dim=2)

@@ -245,7 +245,8 @@ class _Conv2d(torch.autograd.Function):
         ctx.save_for_backward(x, w, y if (relu and not grad_premasked) else None)
         ctx.cfg = (stride, pad, bias is not None, residual is not None, mr, relu, grad_premasked, relu_input)
         ctx.wkey = _wsink_register(w_in) if ctx.needs_input_grad[1] else None
-        return y
+        ctx.w_alive = w_in      # the registry keys on id(w_in): keep the object alive as long as this node, or a temporary (a
+        return y                # weight slice) could be collected and its id handed to another call's weight
 
     @staticmethod
     def backward(ctx, dy):
@@ -298,6 +299,7 @@ class _ConvSharedInput(torch.autograd.Function):
     def forward(ctx, x, stride, pad, relu, grad_premasked, *wb):
         x = _c(x)
         ctx.wkeys = [(_wsink_register(t) if ctx.needs_input_grad[5 + 2 * i] else None) for i, t in enumerate(wb[0::2])]
+        ctx.w_alive = list(wb[0::2])     # see _Conv2d.forward
         ws_, bs_ = [_c(t) for t in wb[0::2]], [_c(t) for t in wb[1::2]]
         _chk(x, *ws_)
         _chk(*[b for b in bs_ if b is not None])
