@@ -18,19 +18,23 @@ orig_call = _lib.call
 seen = {}
 
 def out_info(name, args):
-    # returns (out_ptr index, numel)
-    if name == 'ag2v_conv2d_fwd':
+    # returns (index of the output pointer, output elements, shape key) for the conv entry points ops.py uses
+    if name == 'ag2v_conv2d_fwd_act':
         N, C, H, W, K, R, S, st, pad = args[5:14]
         OH = (H + 2 * pad - R) // st + 1; OW = (W + 2 * pad - S) // st + 1
         return 4, N * K * OH * OW, (N, C, H, W, K, R, st, pad)
-    if name == 'ag2v_conv2d_dgrad':
-        N, C, H, W, K, R, S, st, pad = args[3:12]
-        return 2, N * C * H * W, (N, C, H, W, K, R, st, pad)
-    N, C, H, W, K, R, S, st, pad = args[3:12]
+    if name in ('ag2v_conv2d_dgrad_masked', 'ag2v_conv2d_dgrad_acc'):
+        N, C, H, W, K, R, S, st, pad = args[4:13]
+        return 3, N * C * H * W, (N, C, H, W, K, R, st, pad)
+    N, C, H, W, K, R, S, st, pad = args[3:12]          # ag2v_conv2d_wgrad_acc
     return 2, K * C * R * S, (N, C, H, W, K, R, st, pad)
 
+
+CONV_CALLS = ('ag2v_conv2d_fwd_act', 'ag2v_conv2d_dgrad_masked', 'ag2v_conv2d_dgrad_acc', 'ag2v_conv2d_wgrad_acc')
+
+
 def wrapped(name, *args):
-    if name not in ('ag2v_conv2d_fwd', 'ag2v_conv2d_dgrad', 'ag2v_conv2d_wgrad'):
+    if name not in CONV_CALLS:
         return orig_call(name, *args)
     idx, numel, shape = out_info(name, args)
     orig_call(name, *args)
@@ -38,11 +42,13 @@ def wrapped(name, *args):
     got = torch.empty(numel, device=dev)
     ref = torch.empty(numel, device=dev)
     a2 = list(args); a2[idx] = ctypes.c_void_p(ref.data_ptr())
+    if name in ('ag2v_conv2d_dgrad_acc', 'ag2v_conv2d_wgrad_acc'):
+        a2[-3 if name.endswith('dgrad_acc') else -2] = 0      # the scratch re-runs overwrite instead of accumulating
     ops.set_conv_precision('fp32')
     orig_call(name, *a2)
     ops.set_conv_precision('bf16x3')
     # and once more in bf16x3 into another scratch (so we never need to wrap the raw pointer)
-    a3 = list(args); a3[idx] = ctypes.c_void_p(got.data_ptr())
+    a3 = list(a2); a3[idx] = ctypes.c_void_p(got.data_ptr())
     orig_call(name, *a3)
     torch.cuda.synchronize()
     err = (got - ref).abs().max().item(); sc = ref.abs().max().item() + 1e-30
