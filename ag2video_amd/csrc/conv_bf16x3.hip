@@ -279,46 +279,69 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
 #endif
 #undef STAMP
 
-    // ---- epilogue (consumers)
+    // ---- epilogue (consumers).  The accumulator tiles put a lane's pixel in (lane & 15) or (lane & 31) and spread a row's 64
+    // pixels over 4 (or 2) registers: stored as they are, every store instruction writes 4 x 64-byte (2 x 128-byte) pieces of
+    // different rows, and the in-kernel clocks show 20 000 cycles per tile in this epilogue (every CU's 128 KB tile reaches
+    // HBM in such pieces at the same moment).  A 4x4 (2x2) transpose of 16-lane (32-lane) blocks between those registers --
+    // v_permlane32_swap + v_permlane16_swap (tools/ubench/permlane_probe.hip) -- gives every register one row and 64
+    // consecutive pixels, i.e. one 256-byte run per store instruction.
+    static_assert(EN * ER == 64, "a consumer wave owns 64 pixels");
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     const int gplane = p.OH * p.OW;
     const int plane = p.o_H * p.o_W;
     const bool mapped = (p.o_mul != 1 || p.o_add_y != 0 || p.o_add_x != 0 || p.o_W != p.OW);
-#pragma unroll
-    for (int j = 0; j < EN; ++j) {
-        const int opix = n0 + wn0 + j * ER + (lane & (ER - 1));
-        if (opix >= p.NG) continue;
-        const int on = opix / gplane;
-        int orem = opix - on * gplane;
-        if (mapped) {
-            const int qy = orem / p.OW, qx = orem - qy * p.OW;
-            const int yy = qy * p.o_mul + p.o_add_y, xx = qx * p.o_mul + p.o_add_x;
-            if ((unsigned)yy >= (unsigned)p.o_H || (unsigned)xx >= (unsigned)p.o_W) continue;
-            orem = yy * p.o_W + xx;
+    const int opix = n0 + wn0 + lane;
+    bool pvalid = opix < p.NG;
+    const int on = pvalid ? opix / gplane : 0;
+    int orem = pvalid ? opix - on * gplane : 0;
+    if (mapped) {
+        const int qy = orem / p.OW, qx = orem - qy * p.OW;
+        const int yy = qy * p.o_mul + p.o_add_y, xx = qx * p.o_mul + p.o_add_x;
+        pvalid = pvalid && (unsigned)yy < (unsigned)p.o_H && (unsigned)xx < (unsigned)p.o_W;
+        orem = yy * p.o_W + xx;
+    }
+    float* obase = p.out + (size_t)on * p.M * plane + orem;
+    const float* rbase = p.residual ? p.residual + (size_t)on * p.M * plane + orem : nullptr;
+    const float* mbase = (p.mask && p.splitk == 1) ? p.mask + (size_t)on * p.M * plane + orem : nullptr;
+    auto emit = [&](int m, float v) {
+        if (pvalid && m < p.M) {
+            if (kt0 == 0) {
+                if (p.bias) v += p.bias[m];
+                if (rbase) v += rbase[(size_t)m * plane];
+            }
+            if (p.splitk == 1) {   // (a split-K launch applies these in a pass over the finished sums: launch_act_mask)
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (mbase) v = (mbase[(size_t)m * plane] > 0.f) ? v : 0.f;
+            }
+            if (p.splitk > 1)
+                atomicAdd(obase + (size_t)m * plane, v);
+            else
+                obase[(size_t)m * plane] = v;
         }
-        float* obase = p.out + (size_t)on * p.M * plane + orem;
-        const float* rbase = p.residual ? p.residual + (size_t)on * p.M * plane + orem : nullptr;
-        const float* mbase = (p.mask && p.splitk == 1) ? p.mask + (size_t)on * p.M * plane + orem : nullptr;
+    };
 #pragma unroll
-        for (int i = 0; i < EM; ++i) {
+    for (int i = 0; i < EM; ++i) {
 #pragma unroll
-            for (int r = 0; r < EREGS; ++r) {
-                const int m = MF16 ? m0 + wm0 + i * 16 + 4 * (lane >> 4) + r
-                                   : m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m < p.M) {
-                    float v = acc[i][j][r];
-                    if (kt0 == 0) {
-                        if (p.bias) v += p.bias[m];
-                        if (rbase) v += rbase[(size_t)m * plane];
-                    }
-                    if (p.splitk == 1) {   // (a split-K launch applies these in a pass over the finished sums: launch_act_mask)
-                        if (p.relu) v = fmaxf(v, 0.f);
-                        if (mbase) v = (mbase[(size_t)m * plane] > 0.f) ? v : 0.f;
-                    }
-                    if (p.splitk > 1)
-                        atomicAdd(obase + (size_t)m * plane, v);
-                    else
-                        obase[(size_t)m * plane] = v;
-                }
+        for (int r = 0; r < EREGS; ++r) {
+            if constexpr (MF16) {
+                unsigned a0 = __float_as_uint(acc[i][0][r]), a1 = __float_as_uint(acc[i][1][r]);
+                unsigned a2 = __float_as_uint(acc[i][2][r]), a3 = __float_as_uint(acc[i][3][r]);
+                u32x2 t;
+                t = __builtin_amdgcn_permlane32_swap(a0, a2, false, false); a0 = t[0]; a2 = t[1];
+                t = __builtin_amdgcn_permlane32_swap(a1, a3, false, false); a1 = t[0]; a3 = t[1];
+                t = __builtin_amdgcn_permlane16_swap(a0, a1, false, false); a0 = t[0]; a1 = t[1];
+                t = __builtin_amdgcn_permlane16_swap(a2, a3, false, false); a2 = t[0]; a3 = t[1];
+                const int mrow = m0 + wm0 + i * 16 + r;      // register g now holds row mrow + 4 g, pixel wn0 + lane
+                emit(mrow, __uint_as_float(a0));
+                emit(mrow + 4, __uint_as_float(a1));
+                emit(mrow + 8, __uint_as_float(a2));
+                emit(mrow + 12, __uint_as_float(a3));
+            } else {
+                unsigned a0 = __float_as_uint(acc[i][0][r]), a1 = __float_as_uint(acc[i][1][r]);
+                const u32x2 t = __builtin_amdgcn_permlane32_swap(a0, a1, false, false);
+                const int mrow = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2);   // t[0]: row mrow, t[1]: row mrow + 4
+                emit(mrow, __uint_as_float(t[0]));
+                emit(mrow + 4, __uint_as_float(t[1]));
             }
         }
     }
