@@ -5,6 +5,7 @@ in the hand-written gfx950 kernels of ag2video_amd/csrc.  Every operator require
 otherwise -- there is no CPU path in the product (tests/ check these operators against oracle/ on the GPU).
 """
 import os
+import weakref
 
 import torch
 
@@ -185,7 +186,6 @@ def kernel_timing_summary(by_shape=False):
 # Autograd delivers the buffer to the weight's producer (cat / spectral norm / AccumulateGrad) only after all of the weight's
 # consumers have run, so it arrives complete; without this it would receive 15 tensors and sum them pairwise (4 700 small add
 # launches and as many zero-fills per step).  The registry is cleared by an engine callback at the end of every backward pass.
-import weakref
 
 _WSINK = {}          # id(weight tensor) -> [weakref to it, sink tensor or None]
 _WSINK_CB = [False]  # end-of-pass callback queued for the current backward pass
