@@ -7,7 +7,7 @@ int launch_act_mask(float*, const float*, long long, int, hipStream_t) { return 
 #include <stdio.h>
 #include <vector>
 int main(int argc, char** argv) {
-    const int N = 8, C = 512, H = 256, W = 256, K = argc > 1 ? atoi(argv[1]) : 128, R = 3;
+    const int N = 8, C = argc > 2 ? atoi(argv[2]) : 512, H = 256, W = 256, K = argc > 1 ? atoi(argv[1]) : 128, R = 3;
     const size_t xn = (size_t)N * C * H * W, wn = (size_t)K * C * R * R, yn = (size_t)N * K * H * W;
     float *x, *y; unsigned* at; unsigned long long* st;
     hipMalloc(&x, xn * 4); hipMalloc(&y, yn * 4); hipMalloc(&at, wn * 4);
