@@ -19,7 +19,7 @@
 // per MFMA, the MFMA pipe 32 % busy, waves 51 % in s_waitcnt / barrier because every wave converts at the same time) is in the
 // history; here the two jobs sit on different waves of each SIMD, which the hardware runs concurrently (separate pipes), and
 // one workgroup barrier per K-tile hands the buffers over.
-template <int BM, int BN, int CWM, int CWN, int NPW, bool MF16>
+template <int BM, int BN, int CWM, int CWN, int NPW, bool MF16, bool TAPK>
 __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_kernel(ConvArgs p) {
     constexpr int BK = 32, LDK = 40, NP = NPW * 64;       // NP producer threads
     constexpr int TM = BM / CWM / 32, TN = BN / CWN / 32;  // consumer wave tile in 32x32 MFMA tiles
@@ -32,7 +32,7 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
     __shared__ __attribute__((aligned(16))) unsigned short Alo[2][BM * LDK];
     __shared__ __attribute__((aligned(16))) unsigned short Bhi[2][BN * LDK];
     __shared__ __attribute__((aligned(16))) unsigned short Blo[2][BN * LDK];
-    __shared__ int2 tab[4][BK];
+    __shared__ int2 tab[TAPK ? 1 : 4][BK];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -110,6 +110,50 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
                 }
             }
         };
+        // TAPK: the reduction index is ordered by tap_major_row() (the launcher lays the weights out to match) and C % BK == 0,
+        // so the BK k's of a K-tile share one filter tap and differ in the channel only.  Per K-tile a thread then needs ONE
+        // voffset per operand (A: its row; B: its pixel moved by the tap, or out of range when the tap falls into the padding)
+        // and every load adds a wave-uniform SGPR offset (k * M resp. channel * H * W) in the instruction's soffset field: no
+        // table and no per-load address arithmetic on the vector ALU, whose issue port the consumers' MFMAs share (16x16x32:
+        // 8 of every 16 cycles); ~40 VALU instructions per K-tile and thread instead of ~110.  The hardware range-checks
+        // voffset + soffset (tools/ubench/soffset_probe.hip), so K-tiles past the end of the reduction (the pipeline runs up to
+        // three ahead) read zeros like every masked element; `live` only keeps their offsets from wrapping.
+        constexpr unsigned kOut = 0xFFFFFFF0u;
+        int f_kt = kt0, f_c = 0, f_r = 0, f_s = 0;       // scalar state: the next K-tile to fetch, its first channel and its tap
+        if constexpr (TAPK) {       // K-tile index = (r * C/BK + channel chunk) * S + s
+            const int q = kt0 / p.S, cpr = p.C / BK;
+            f_s = kt0 - q * p.S;
+            f_r = q / cpr;
+            f_c = (q - f_r * cpr) * BK;
+        }
+        const int apart_s = (wave * 64 / (BM / ACOLS)) % AP, bpart_s = (wave * 64 / (BN / BCOLS)) % BP;   // = apart, bpart (wave-uniform)
+        auto fetch_tap = [&](unsigned (&ra)[ACOLS][AK], float (&rb)[BCOLS][BKK]) {
+            const bool live = f_kt < nk_all;
+            const unsigned m4 = (unsigned)p.M * 4u, c4 = (unsigned)SHW * 4u;
+            const unsigned sa = (unsigned)(f_kt * BK + AK * apart_s) * m4;
+#pragma unroll
+            for (int c = 0; c < ACOLS; ++c) {
+                const int m = m0 + acol0 + c * (BM / ACOLS);
+                const unsigned vo = (live & (m < p.M)) ? (unsigned)m * 4u : kOut;
+#pragma unroll
+                for (int i = 0; i < AK; ++i) ra[c][i] = __builtin_amdgcn_raw_buffer_load_b32(ars, vo, sa + i * m4, 0);
+            }
+            const unsigned sb = (unsigned)(f_c + BKK * bpart_s) * c4;
+            const int toff = f_r * p.W + f_s, tbit = f_r * p.S + f_s;
+#pragma unroll
+            for (int c = 0; c < BCOLS; ++c) {
+                const unsigned vo = (live & (((vmask[c] >> tbit) & 1u) != 0u)) ? (unsigned)(bbase[c] + toff) * 4u : kOut;
+#pragma unroll
+                for (int i = 0; i < BKK; ++i)
+                    rb[c][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, vo, sb + i * c4, 0));
+            }
+            ++f_kt;
+            if (++f_s == p.S) {
+                f_s = 0;
+                f_c += BK;
+                if (f_c >= p.C) { f_c = 0; ++f_r; }
+            }
+        };
         auto stash = [&](int buf, const unsigned (&ra)[ACOLS][AK], const float (&rb)[BCOLS][BKK]) {
 #pragma unroll
             for (int c = 0; c < ACOLS; ++c)
@@ -131,7 +175,14 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
                 for (int g = 0; g < BKK / 8; ++g) {
                     unsigned h[4], l[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) split2(rb[c][8 * g + 2 * i], rb[c][8 * g + 2 * i + 1], h[i], l[i]);
+                    for (int i = 0; i < 4; ++i) {
+#ifdef AG2V_DIAG_PRESPLIT               // timing experiment only (tools/ubench/igemm_stamps.hip): input taken as packed hi:lo
+                        h[i] = __builtin_amdgcn_perm(__float_as_uint(rb[c][8 * g + 2 * i + 1]), __float_as_uint(rb[c][8 * g + 2 * i]), 0x07060302u);
+                        l[i] = __builtin_amdgcn_perm(__float_as_uint(rb[c][8 * g + 2 * i + 1]), __float_as_uint(rb[c][8 * g + 2 * i]), 0x05040100u);
+#else
+                        split2(rb[c][8 * g + 2 * i], rb[c][8 * g + 2 * i + 1], h[i], l[i]);
+#endif
+                    }
                     const int off = (bcol0 + c * (BN / BCOLS)) * LDK + BKK * bpart + 8 * g;
                     *reinterpret_cast<uint4*>(&Bhi[buf][off]) = make_uint4(h[0], h[1], h[2], h[3]);
                     *reinterpret_cast<uint4*>(&Blo[buf][off]) = make_uint4(l[0], l[1], l[2], l[3]);
@@ -145,14 +196,16 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
         // barrier; the consumers multiply tile t after that barrier.  Every load has two full iterations to land and a
         // register set is never written while its loads are in flight.  (The loop starts on the older set and the two
         // prologue fetches are pinned in order, so that the compiler's vmcnt waits at the loop head stay partial.)
-        build_tab(kt0);
-        build_tab(kt0 + 1);
-        build_tab(kt0 + 2);
-        build_tab(kt0 + 3);
+        if constexpr (!TAPK) {
+            build_tab(kt0);
+            build_tab(kt0 + 1);
+            build_tab(kt0 + 2);
+            build_tab(kt0 + 3);
+        }
         __syncthreads();
-        fetch(kt0, ra0, rb0);
+        if constexpr (TAPK) fetch_tap(ra0, rb0); else fetch(kt0, ra0, rb0);
         __builtin_amdgcn_sched_barrier(0);
-        fetch(kt0 + 1, ra1, rb1);
+        if constexpr (TAPK) fetch_tap(ra1, rb1); else fetch(kt0 + 1, ra1, rb1);
         __builtin_amdgcn_sched_barrier(0);
 #ifdef AG2V_STAMPS
         unsigned long long sa[3] = {0, 0, 0};
@@ -170,8 +223,8 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
 #endif
             STAMP(c1)
 #ifndef AG2V_DIAG_NO_PRODUCER_WORK
-            build_tab(kt + 4);
-            fetch(kt + 2, ra0, rb0);
+            if constexpr (TAPK) fetch_tap(ra0, rb0);
+            else { build_tab(kt + 4); fetch(kt + 2, ra0, rb0); }
 #endif
             STAMP(c2)
             __syncthreads();
@@ -185,8 +238,8 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
 #endif
             STAMP(d1)
 #ifndef AG2V_DIAG_NO_PRODUCER_WORK
-            build_tab(kt + 5);
-            fetch(kt + 3, ra1, rb1);
+            if constexpr (TAPK) fetch_tap(ra1, rb1);
+            else { build_tab(kt + 5); fetch(kt + 3, ra1, rb1); }
 #endif
             STAMP(d2)
             __syncthreads();
@@ -802,13 +855,19 @@ int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed) {
     }
     if (a.splitk > 1 && a.residual == a.out) a.residual = nullptr;   // accumulating launch: the atomics already add onto out
     dim3 grid(tiles, a.splitk);
+#define AG2V_LAUNCH_IGEMM(...)                                                                          \
+    do {                                                                                               \
+        set_last_conv_kernel("conv_igemm_bf16x3_ws_kernel<" #__VA_ARGS__ ">");                         \
+        hipLaunchKernelGGL((conv_igemm_bf16x3_ws_kernel<__VA_ARGS__>), grid, dim3(1024), 0, st, a);    \
+    } while (0)
     if (tall) {
-        set_last_conv_kernel("conv_igemm_bf16x3_ws_kernel<256, 128, 4, 2, 8, true>");
-        hipLaunchKernelGGL((conv_igemm_bf16x3_ws_kernel<256, 128, 4, 2, 8, true>), grid, dim3(1024), 0, st, a);
+        if (a.tap_major) AG2V_LAUNCH_IGEMM(256, 128, 4, 2, 8, true, true);
+        else AG2V_LAUNCH_IGEMM(256, 128, 4, 2, 8, true, false);
     } else {
-        set_last_conv_kernel("conv_igemm_bf16x3_ws_kernel<128, 256, 2, 4, 8, false>");
-        hipLaunchKernelGGL((conv_igemm_bf16x3_ws_kernel<128, 256, 2, 4, 8, false>), grid, dim3(1024), 0, st, a);
+        if (a.tap_major) AG2V_LAUNCH_IGEMM(128, 256, 2, 4, 8, false, true);
+        else AG2V_LAUNCH_IGEMM(128, 256, 2, 4, 8, false, false);
     }
+#undef AG2V_LAUNCH_IGEMM
     AG2V_CHECK_LAUNCH();
     if (a.splitk > 1 && (a.relu || a.mask))
         return launch_act_mask(a.out, a.mask, (long long)a.N * a.M * a.o_H * a.o_W, a.relu, st);

@@ -19,6 +19,8 @@ struct ConvArgs {
     int splitk, kchunk;     // igemm: K-range splits (grid.y) in K-tiles; wgrad: pixel-range splits, pixels per split
     const float* mask;      // igemm epilogue: out = (mask > 0) ? out : 0 (same shape as out) -- the ReLU backward of the conv's input
     int relu;               // igemm epilogue: out = max(out, 0)
+    int tap_major;          // igemm bf16x3: a_src rows are ordered by tap_major_row() instead of kg = c * R*S + r*S + s; set by
+                            // igemm_tap_major() for C % 32 == 0 (every 32-wide K-tile then has one filter tap)
     int accumulate;         // wgrad: add onto the existing dW (no zeroing; atomics) -- the weight is used by several forward calls
 #ifdef AG2V_STAMPS
     unsigned long long* stamps;   // diagnostic build only (tools/ubench/igemm_stamps.hip): per-wave phase clocks
@@ -94,6 +96,18 @@ int launch_act_mask(float* out, const float* mask, long long n, int relu, hipStr
 // name of the main kernel of the most recent convolution entry point (as rocprofv3 prints it), for bench.py's per-kernel
 // timing table: ag2v_last_conv_kernel()
 void set_last_conv_kernel(const char* name);
+
+// K ordering of the packed bf16x3 weight operand of an implicit-GEMM launch over C gathered channels (ConvArgs::tap_major):
+// K-tile (r * C/32 + c/32) * S + s holds the 32 channels of chunk c/32 at tap (r, s).  One tap per K-tile lets the producers
+// address with wave-uniform SGPR offsets; the s taps of a chunk in consecutive K-tiles re-read the same cache lines while they
+// are still in L1 (plain tap-major order, c fastest over all of C, was 6 % slower at C = 512 than the c-major table path).
+static inline bool igemm_tap_major(int C, bool split) {
+    static const bool off = getenv("AG2V_NO_TAP_MAJOR") != nullptr;   // A/B aid: the c-major table path for every shape
+    return split && C % 32 == 0 && !off;
+}
+__host__ __device__ __forceinline__ int tap_major_row(int c, int r, int s, int C, int S) {
+    return (((r * (C >> 5) + (c >> 5)) * S + s) << 5) + (c & 31);
+}
 
 // launchers implemented in conv_bf16x3.hip
 int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed);

@@ -306,8 +306,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvArgs p) {
 
 // ---------------------------------------------------------------- weight preparation (k-major A operands)
 // at[col][row] = w[row][col]  (w: [rows][cols] row-major): 32x32 LDS tiles, coalesced on both sides.
+// S > 0: the columns are (c, r, s) triples, col = (c * R + r) * S + s, and row tap_major_row(c, r, s) of at is written
+// (ConvArgs::tap_major).
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ w, float* __restrict__ at, int rows, int cols,
-                                                        int split) {
+                                                        int split, int R, int S) {
     __shared__ float t[32][33];
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
@@ -320,15 +322,24 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = c0 + ty + 8 * i, r = r0 + tx;
-        if (c < cols && r < rows) at[(size_t)c * rows + r] = split ? pack_split(t[tx][ty + 8 * i]) : t[tx][ty + 8 * i];
+        if (c < cols && r < rows) {
+            int dst = c;
+            if (S > 0) {
+                const int ch = c / (R * S), tap = c - ch * (R * S), r = tap / S;
+                dst = tap_major_row(ch, r, tap - r * S, cols / (R * S), S);
+            }
+            at[(size_t)dst * rows + r] = split ? pack_split(t[tx][ty + 8 * i]) : t[tx][ty + 8 * i];
+        }
     }
 }
 
 // Data-gradient sub-filter of pixel class (py,px), flipped, k-major:
 //   at[((k*Rc + r2)*Sc + s2)*C + c] = w[k][c][py + st*(Rc-1-r2)][px + st*(Sc-1-s2)]
+// (tapmaj: row tap_major_row(k, r2, s2) instead of (k*Rc + r2)*Sc + s2, ConvArgs::tap_major)
 // grid (ceil(C/64), K): the 64*R*S contiguous source floats of (k, c-chunk) go through LDS, rows are written coalesced.
 __global__ __launch_bounds__(256) void dgrad_weight_prep_kernel(const float* __restrict__ w, float* __restrict__ at, int K, int C,
-                                                                int R, int S, int py, int px, int st, int Rc, int Sc, int split) {
+                                                                int R, int S, int py, int px, int st, int Rc, int Sc, int split,
+                                                                int tapmaj) {
     __shared__ float t[64 * 16];
     const int RS = R * S;
     const int c0 = blockIdx.x * 64, k = blockIdx.y;
@@ -342,7 +353,8 @@ __global__ __launch_bounds__(256) void dgrad_weight_prep_kernel(const float* __r
         const int r = py + st * (Rc - 1 - r2), s = px + st * (Sc - 1 - s2);
         if (lane < nc) {
             const float v = t[lane * RS + r * S + s];
-            at[((size_t)(k * Rc + r2) * Sc + s2) * C + c0 + lane] = split ? pack_split(v) : v;
+            const size_t row = tapmaj ? (size_t)tap_major_row(k, r2, s2, K, Sc) : (size_t)(k * Rc + r2) * Sc + s2;
+            at[row * C + c0 + lane] = split ? pack_split(v) : v;
         }
     }
 }
@@ -595,8 +607,9 @@ extern "C" int ag2v_conv2d_fwd_act(const float* x, const float* w, const float* 
     const long long abytes = (long long)a.KG * K * 4, bbytes = (long long)N * C * H * W * 4;
     const bool split = use_bf16x3(K) && abytes < kBufMax && bbytes < kBufMax;
     a.a_bytes = (unsigned)abytes; a.b_bytes = (unsigned)bbytes;
+    a.tap_major = igemm_tap_major(C, split) ? 1 : 0;
     hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(a.KG, 32), ceil_div(K, 32)), dim3(256), 0, st, w, workspace, K, a.KG,
-                       split ? 1 : 0);
+                       split ? 1 : 0, R, a.tap_major ? S : 0);
     a.a_src = workspace;
     return launch_igemm(a, st, false, split);
 }
@@ -649,9 +662,11 @@ extern "C" int ag2v_conv2d_dgrad_acc(const float* dy, const float* w, const floa
             if (ay >= H || ax >= W) continue;
             const long long abytes = (long long)K * C * Rc * Sc * 4, bbytes = (long long)N * K * OH * OW * 4;
             const bool split = use_bf16x3(C) && abytes < kBufMax && bbytes < kBufMax;
+            const bool tapmaj = igemm_tap_major(K, split);
             hipLaunchKernelGGL(dgrad_weight_prep_kernel, dim3(ceil_div(C, 64), K), dim3(256), 0, st, w, at, K, C, R, S, py, px,
-                               stride, Rc, Sc, split ? 1 : 0);
+                               stride, Rc, Sc, split ? 1 : 0, tapmaj ? 1 : 0);
             ConvArgs f{};
+            f.tap_major = tapmaj ? 1 : 0;
             f.a_src = at; f.b_src = dy; f.out = dx;
             f.N = N; f.C = K; f.H = OH; f.W = OW; f.K = C; f.R = Rc; f.S = Sc; f.stride = 1;
             f.pad = Rc - 1 - q0y; f.pad_w = Sc - 1 - q0x;

@@ -25,7 +25,7 @@ int main(int argc, char** argv) {
     const bool tall = a.M >= 192;
     const int tiles = ((a.M + (tall ? 255 : 127)) / (tall ? 256 : 128)) * (a.NG / (tall ? 128 : 256));
     hipMalloc(&st, (size_t)tiles * 16 * 4 * 8); hipMemset(st, 0, (size_t)tiles * 16 * 4 * 8);
-    a.stamps = st;
+    a.stamps = st; a.tap_major = getenv("TAPK") ? 1 : 0;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float ms = 0;
     for (int rep = 0; rep < 3; ++rep) {
