@@ -38,6 +38,39 @@ class LossModel(torch.nn.Module):
             raise NotImplementedError("VGG perceptual loss needs pretrained VGG19 weights (no network here); "
                                       "run with --no_vgg_loss (SURVEY.md 2.1 row 6)")
 
+    # ---- discriminator layout terms, once per step.  The terms depend on the discriminator's parameters and on the layout inputs
+    # (objects, ground-truth boxes, action data) only.  The generator step and the discriminator step of one training iteration
+    # see the same inputs and -- optimizer_d_img steps after the discriminator loss -- the same discriminator parameters, so the
+    # reference evaluates the same function twice (four times counting fake/real, loss_model.py:73,77,118,120).  Here the
+    # generator loss computes it with its autograd graph (outside _params_frozen), uses it detached (nothing in it depends on
+    # the generator), and leaves it for the discriminator loss of the same batch, which back-propagates through it.  The key
+    # holds the input tensors themselves (storage + version) and every discriminator parameter's version counter: any in-place
+    # change in between, another batch, or a graph net with batch statistics falls back to a fresh evaluation.
+    def _terms_key(self, inputs):
+        # FusedAdam writes the parameters through raw pointers (no version bump): its step counter is part of the key
+        opt_d = getattr(self.discriminator, 'optimizer_d_img', None)
+        return (tuple((t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride())) for t in inputs),
+                tuple(p._version for p in self.netD_img.parameters()), id(opt_d), getattr(opt_d, '_step', None))
+
+    def _layout_terms(self, objs, r_boxes, r_adata, producer):
+        """producer=True (generator loss): evaluate and remember; producer=False (discriminator loss): reuse when valid."""
+        if not hasattr(self.netD_img, 'layout_terms'):
+            return None
+        inputs = [objs, r_boxes] + list(r_adata)
+        shareable = (torch.is_grad_enabled() and getattr(self.opt, 'mlp_normalization', 'none') == 'none'
+                     and not any(t.requires_grad for t in inputs if t.is_floating_point())
+                     and not getattr(self.opt, 'no_shared_layout_terms', False))
+        cached, self._terms_cache = getattr(self, '_terms_cache', None), None
+        if not shareable:
+            return self.netD_img.layout_terms(objs, r_boxes, r_adata)
+        key = self._terms_key(inputs)
+        if not producer and cached is not None and cached[0] == key:
+            return cached[2]
+        terms = self.netD_img.layout_terms(objs, r_boxes, r_adata)
+        if producer and terms is not None:
+            self._terms_cache = (key, inputs, terms)
+        return terms
+
     def compute_graph_loss(self, batch, boxes_pred):
         """Masked smooth-L1 on predicted boxes (loss_model.py:41-60); a few thousand elements: host-side torch ops."""
         imgs, objs, boxes, triplets, actions, video_id = batch
@@ -60,9 +93,12 @@ class LossModel(torch.nn.Module):
         r_imgs, r_boxes, r_pred = imgs[:, nc:], boxes[:, nc:], imgs_pred[:, nc:]
         r_adata = [item[:, nc:] for item in actions_data]
         G = {}
+        # the layout part of D's first convolutions is the same for the fake and the real pass (and for the discriminator
+        # loss of this batch: _layout_terms)
+        terms = self._layout_terms(objs, r_boxes, r_adata, producer=True)
+        if terms is not None:
+            terms = [t.detach() for t in terms]
         with _params_frozen(self.netD_img):
-            # the layout part of D's first convolutions is the same for the fake and the real pass: computed once
-            terms = self.netD_img.layout_terms(objs, r_boxes, r_adata) if hasattr(self.netD_img, 'layout_terms') else None
             fake = self.netD_img(r_pred, objs, r_boxes, r_adata, **({'layout_terms': terms} if terms is not None else {}))
         G['GAN_Img'] = self.criterionGAN(fake, True, for_discriminator=False).squeeze(0) * \
             self.opt.discriminator_img_loss_weight
@@ -88,7 +124,7 @@ class LossModel(torch.nn.Module):
         imgs_pred, boxes_pred, flows_pred, conf_pred, actions_data = model_out
         nc = self.n_frames_G - 1
         r_adata = [item[:, nc:] for item in actions_data]
-        terms = self.netD_img.layout_terms(objs, boxes[:, nc:], r_adata) if hasattr(self.netD_img, 'layout_terms') else None
+        terms = self._layout_terms(objs, boxes[:, nc:], r_adata, producer=False)
         kw = {'layout_terms': terms} if terms is not None else {}
         fake = self.netD_img(imgs_pred[:, nc:].detach(), objs, boxes[:, nc:], r_adata, **kw)
         real = self.netD_img(imgs[:, nc:], objs, boxes[:, nc:], r_adata, **kw)

@@ -184,3 +184,58 @@ def test_single_attribute_vocab_step(device):
     for got, ref in ((GL, GL_r), (DL, DL_r)):
         for k in ref:
             assert abs(got[k].item() - ref[k].item()) <= 1e-3 * max(1.0, abs(ref[k].item())), (k, got[k].item(), ref[k].item())
+
+
+def test_shared_layout_terms_match_separate_evaluation(device):
+    """LossModel evaluates the discriminator's layout terms once per step (in the generator loss) and reuses them, with their
+    graph, in the discriminator loss of the same batch.  Against separate evaluations (opt.no_shared_layout_terms) on the SAME
+    generator output and module state: same losses, same discriminator gradients.  (Whole steps are not compared: the
+    generator's split-K atomics perturb its output in the last bit from run to run, and at random init that flips LeakyReLU /
+    hinge kinks inside D -- percent-level jumps in single gradients in BOTH modes, tools/debug_shared_terms3.py.)  Then two
+    updating steps count the evaluations: one per step, i.e. the terms are dropped once consumed."""
+    from ag2video_amd.data.args import make_opt
+    from ag2video_amd.data.synthetic import make_clip_batch
+    from ag2video_amd.data.vocab import cater_vocab
+    from ag2video_amd.engine import TrainStep
+    flags = ['--no_vgg_loss', '--image_size', '64,64', '--batch_size', '2', '--ngf', '8', '--ndf', '8', '--nff', '8',
+             '--gconv_hidden_dim', '64', '--gpu_ids', '0']
+    opt = make_opt(cater_vocab(), flags)
+    ts = TrainStep(opt, device, weights_seed=5)
+    D = ts.discriminator.img_discriminator
+    calls = [0]
+    inner = D.layout_terms
+    def counted(*a, **k):
+        calls[0] += 1
+        return inner(*a, **k)
+    D.layout_terms = counted
+    b0 = ts.to_device(make_clip_batch(opt.vocab, 2, 3, (64, 64), seed=11))
+    imgs, objs, boxes, triplets, actions, _ = b0
+    with torch.no_grad():
+        mo = ts.model(imgs, objs, triplets, actions, boxes_gt=boxes, test_mode=False, use_gt=True)
+    bufs = {n: b.detach().clone() for n, b in D.named_buffers()}        # spectral-norm vectors advance in every D pass
+    res = []
+    for separate in (False, True):
+        opt.no_shared_layout_terms = separate
+        with torch.no_grad():
+            for n, b in D.named_buffers():
+                b.copy_(bufs[n])
+        calls[0] = 0
+        GL = ts.gans_model(b0, mo, mode="compute_generator_loss")
+        DL = ts.gans_model(b0, mo, mode="compute_discriminator_loss")
+        ts.discriminator.optimizer_d_img.zero_grad()
+        DL["total_img_loss"].backward()
+        res.append((calls[0], {**{k: v.item() for k, v in GL.items()}, **{k: v.item() for k, v in DL.items()}},
+                    {n: p.grad.detach().clone() for n, p in D.named_parameters() if p.grad is not None}))
+    (c_sh, l_sh, g_sh), (c_se, l_se, g_se) = res
+    assert c_sh == 1 and c_se == 2, (c_sh, c_se)
+    for k in l_se:
+        assert abs(l_sh[k] - l_se[k]) <= 1e-6 * max(1.0, abs(l_se[k])), (k, l_sh[k], l_se[k])
+    assert set(g_sh) == set(g_se) and len(g_se) > 20
+    for k in g_se:
+        err = (g_sh[k] - g_se[k]).abs().max().item()
+        assert err <= 1e-4 * g_se[k].abs().max().item() + 1e-9, (k, err, g_se[k].abs().max().item())
+    opt.no_shared_layout_terms = False
+    calls[0] = 0
+    for step in range(2):
+        ts.gd_step(ts.to_device(make_clip_batch(opt.vocab, 2, 3, (64, 64), seed=12 + step)))
+    assert calls[0] == 2 and ts.gans_model.module._terms_cache is None, calls[0]
