@@ -3,7 +3,7 @@
 #include "common.h"
 
 struct ConvArgs {
-    const float* a_src;     // igemm: At [KG][M] (k-major weights) | wgrad: dy
+    const float* a_src;     // igemm: At [KG][M] (k-major weights; tap_major: [KG/4][M][4]) | wgrad: dy
     const float* b_src;     // gathered tensor [N, C, H, W]
     float* out;
     const float* bias;      // [M] or null (igemm)
@@ -19,8 +19,9 @@ struct ConvArgs {
     int splitk, kchunk;     // igemm: K-range splits (grid.y) in K-tiles; wgrad: pixel-range splits, pixels per split
     const float* mask;      // igemm epilogue: out = (mask > 0) ? out : 0 (same shape as out) -- the ReLU backward of the conv's input
     int relu;               // igemm epilogue: out = max(out, 0)
-    int tap_major;          // igemm bf16x3: a_src rows are ordered by tap_major_row() instead of kg = c * R*S + r*S + s; set by
-                            // igemm_tap_major() for C % 32 == 0 (every 32-wide K-tile then has one filter tap)
+    int tap_major;          // igemm bf16x3: a_src rows are ordered by tap_major_row() instead of kg = c * R*S + r*S + s and four
+                            // consecutive rows are interleaved per output row ([KG/4][M][4]); set by igemm_tap_major() for
+                            // C % 32 == 0 (every 32-wide K-tile then has one filter tap)
     int accumulate;         // wgrad: add onto the existing dW (no zeroing; atomics) -- the weight is used by several forward calls
 #ifdef AG2V_STAMPS
     unsigned long long* stamps;   // diagnostic build only (tools/ubench/igemm_stamps.hip): per-wave phase clocks
@@ -57,7 +58,13 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigne
     const f32x2 v = {x0, x1};
     const bf16x2 h = __builtin_convertvector(v, bf16x2);
     const f32x2 hf = __builtin_convertvector(h, f32x2);
-    const bf16x2 l = __builtin_convertvector(v - hf, bf16x2);
+    // two v_sub_f32, not one v_pk_add_f32: packed f32 VALU beside MFMAs costs ~13 extra cycles per instruction
+    // (MI355X_MICROARCH.md constants table) and the compiler SLP-packs a plain v - hf
+    float d0, d1;
+    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(d0) : "v"(x0), "v"(hf[0]));
+    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(d1) : "v"(x1), "v"(hf[1]));
+    const f32x2 dv = {d0, d1};
+    const bf16x2 l = __builtin_convertvector(dv, bf16x2);
     hi = __builtin_bit_cast(unsigned, h);
     lo = __builtin_bit_cast(unsigned, l);
 }

@@ -306,10 +306,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvArgs p) {
 
 // ---------------------------------------------------------------- weight preparation (k-major A operands)
 // at[col][row] = w[row][col]  (w: [rows][cols] row-major): 32x32 LDS tiles, coalesced on both sides.
-// S > 0: the columns are (c, r, s) triples, col = (c * R + r) * S + s, and row tap_major_row(c, r, s) of at is written
-// (ConvArgs::tap_major).
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ w, float* __restrict__ at, int rows, int cols,
-                                                        int split, int R, int S) {
+                                                        int split) {
     __shared__ float t[32][33];
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
@@ -322,24 +320,42 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = c0 + ty + 8 * i, r = r0 + tx;
-        if (c < cols && r < rows) {
-            int dst = c;
-            if (S > 0) {
-                const int ch = c / (R * S), tap = c - ch * (R * S), r = tap / S;
-                dst = tap_major_row(ch, r, tap - r * S, cols / (R * S), S);
-            }
-            at[(size_t)dst * rows + r] = split ? pack_split(t[tx][ty + 8 * i]) : t[tx][ty + 8 * i];
-        }
+        if (c < cols && r < rows) at[(size_t)c * rows + r] = split ? pack_split(t[tx][ty + 8 * i]) : t[tx][ty + 8 * i];
+    }
+}
+
+// Forward weights in the tap-major packed layout of the bf16x3 implicit GEMM (ConvArgs::tap_major):
+//   at[((tap_major_row(c, r, s) >> 2) * M + m) * 4 + (c & 3)] = pack_split(w[m][c][r][s]),   C % 32 == 0
+// grid (C/32, ceil(M/8)): the 32*R*S contiguous source floats of each of 8 output rows go through LDS; every thread then writes
+// the four channels c..c+3 of one (tap, m) as 16 bytes, 8 lanes along m (one 128-byte line).  Small blocks: the weights of a
+// 128 x 512 x 3 x 3 layer make 256 of them, and the kernel runs in front of every forward convolution.
+__global__ __launch_bounds__(256) void pack_fwd_tap_kernel(const float* __restrict__ w, float* __restrict__ at, int M, int C, int R,
+                                                           int S) {
+    constexpr int MR = 8;
+    __shared__ float t[MR * (32 * 16 + 1)];
+    const int RS = R * S, row = 32 * RS + 1;
+    const int c0 = blockIdx.x * 32, m0 = blockIdx.y * MR;
+    for (int i = threadIdx.x; i < MR * 32 * RS; i += 256) {
+        const int m = i / (32 * RS), j = i - m * (32 * RS);
+        t[m * row + j] = (m0 + m < M) ? w[((size_t)(m0 + m) * C + c0) * RS + j] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < RS * 8 * MR; i += 256) {
+        const int m = i & (MR - 1), c4 = (i >> 3) & 7, tap = i >> 6;
+        if (m0 + m >= M) continue;
+        const int r = tap / S, s2 = tap - r * S;
+        const float* src = &t[m * row + (c4 * 4) * RS + tap];
+        const float4 v = make_float4(pack_split(src[0]), pack_split(src[RS]), pack_split(src[2 * RS]), pack_split(src[3 * RS]));
+        const int drow = tap_major_row(c0 + c4 * 4, r, s2, C, S);
+        *reinterpret_cast<float4*>(&at[((size_t)(drow >> 2) * M + (m0 + m)) * 4]) = v;
     }
 }
 
 // Data-gradient sub-filter of pixel class (py,px), flipped, k-major:
 //   at[((k*Rc + r2)*Sc + s2)*C + c] = w[k][c][py + st*(Rc-1-r2)][px + st*(Sc-1-s2)]
-// (tapmaj: row tap_major_row(k, r2, s2) instead of (k*Rc + r2)*Sc + s2, ConvArgs::tap_major)
 // grid (ceil(C/64), K): the 64*R*S contiguous source floats of (k, c-chunk) go through LDS, rows are written coalesced.
 __global__ __launch_bounds__(256) void dgrad_weight_prep_kernel(const float* __restrict__ w, float* __restrict__ at, int K, int C,
-                                                                int R, int S, int py, int px, int st, int Rc, int Sc, int split,
-                                                                int tapmaj) {
+                                                                int R, int S, int py, int px, int st, int Rc, int Sc, int split) {
     __shared__ float t[64 * 16];
     const int RS = R * S;
     const int c0 = blockIdx.x * 64, k = blockIdx.y;
@@ -353,8 +369,37 @@ __global__ __launch_bounds__(256) void dgrad_weight_prep_kernel(const float* __r
         const int r = py + st * (Rc - 1 - r2), s = px + st * (Sc - 1 - s2);
         if (lane < nc) {
             const float v = t[lane * RS + r * S + s];
-            const size_t row = tapmaj ? (size_t)tap_major_row(k, r2, s2, K, Sc) : (size_t)(k * Rc + r2) * Sc + s2;
-            at[row * C + c0 + lane] = split ? pack_split(v) : v;
+            at[((size_t)(k * Rc + r2) * Sc + s2) * C + c0 + lane] = split ? pack_split(v) : v;
+        }
+    }
+}
+
+// The same sub-filter in the tap-major packed layout (ConvArgs::tap_major; the gathered channels of the data-gradient GEMM are
+// the K forward outputs, its rows the C forward inputs), K % 32 == 0:
+//   at[((tap_major_row(k, r2, s2) >> 2) * C + c) * 4 + (k & 3)] = pack_split(w[k][c][py + st*(Rc-1-r2)][px + st*(Sc-1-s2)])
+// grid (ceil(C/64), K/4): four k per block, so that every thread writes 16 bytes, lanes along c.
+__global__ __launch_bounds__(256) void pack_dgrad_tap_kernel(const float* __restrict__ w, float* __restrict__ at, int K, int C, int R,
+                                                             int S, int py, int px, int st, int Rc, int Sc) {
+    __shared__ float t[4][64 * 17];
+    const int RS = R * S, RSP = RS | 1;      // odd row length: lanes (stride RSP) on distinct banks
+    const int c0 = blockIdx.x * 64, k0 = blockIdx.y * 4;
+    const int nc = min(64, C - c0);
+    for (int j = 0; j < 4; ++j) {
+        const float* src = w + ((size_t)(k0 + j) * C + c0) * RS;
+        for (int i = threadIdx.x; i < nc * RS; i += 256) {
+            const int c = i / RS;
+            t[j][c * RSP + (i - c * RS)] = src[i];
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    for (int tap = grp; tap < Rc * Sc; tap += 4) {
+        const int r2 = tap / Sc, s2 = tap - r2 * Sc;
+        const int q = lane * RSP + (py + st * (Rc - 1 - r2)) * S + (px + st * (Sc - 1 - s2));
+        if (lane < nc) {
+            const float4 v = make_float4(pack_split(t[0][q]), pack_split(t[1][q]), pack_split(t[2][q]), pack_split(t[3][q]));
+            const int drow = tap_major_row(k0, r2, s2, K, Sc);
+            *reinterpret_cast<float4*>(&at[((size_t)(drow >> 2) * C + (c0 + lane)) * 4]) = v;
         }
     }
 }
@@ -608,8 +653,11 @@ extern "C" int ag2v_conv2d_fwd_act(const float* x, const float* w, const float* 
     const bool split = use_bf16x3(K) && abytes < kBufMax && bbytes < kBufMax;
     a.a_bytes = (unsigned)abytes; a.b_bytes = (unsigned)bbytes;
     a.tap_major = igemm_tap_major(C, split) ? 1 : 0;
-    hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(a.KG, 32), ceil_div(K, 32)), dim3(256), 0, st, w, workspace, K, a.KG,
-                       split ? 1 : 0, R, a.tap_major ? S : 0);
+    if (a.tap_major)
+        hipLaunchKernelGGL(pack_fwd_tap_kernel, dim3(C / 32, ceil_div(K, 8)), dim3(256), 0, st, w, workspace, K, C, R, S);
+    else
+        hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(a.KG, 32), ceil_div(K, 32)), dim3(256), 0, st, w, workspace, K, a.KG,
+                           split ? 1 : 0);
     a.a_src = workspace;
     return launch_igemm(a, st, false, split);
 }
@@ -663,8 +711,12 @@ extern "C" int ag2v_conv2d_dgrad_acc(const float* dy, const float* w, const floa
             const long long abytes = (long long)K * C * Rc * Sc * 4, bbytes = (long long)N * K * OH * OW * 4;
             const bool split = use_bf16x3(C) && abytes < kBufMax && bbytes < kBufMax;
             const bool tapmaj = igemm_tap_major(K, split);
-            hipLaunchKernelGGL(dgrad_weight_prep_kernel, dim3(ceil_div(C, 64), K), dim3(256), 0, st, w, at, K, C, R, S, py, px,
-                               stride, Rc, Sc, split ? 1 : 0, tapmaj ? 1 : 0);
+            if (tapmaj)
+                hipLaunchKernelGGL(pack_dgrad_tap_kernel, dim3(ceil_div(C, 64), K / 4), dim3(256), 0, st, w, at, K, C, R, S, py, px,
+                                   stride, Rc, Sc);
+            else
+                hipLaunchKernelGGL(dgrad_weight_prep_kernel, dim3(ceil_div(C, 64), K), dim3(256), 0, st, w, at, K, C, R, S, py, px,
+                                   stride, Rc, Sc, split ? 1 : 0);
             ConvArgs f{};
             f.tap_major = tapmaj ? 1 : 0;
             f.a_src = at; f.b_src = dy; f.out = dx;

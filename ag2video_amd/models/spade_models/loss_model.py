@@ -1,5 +1,6 @@
 """Loss facade (reference: models/spade_models/loss_model.py:14-149)."""
 import contextlib
+import os
 
 import torch
 import torch.nn.functional as F
@@ -59,7 +60,8 @@ class LossModel(torch.nn.Module):
         inputs = [objs, r_boxes] + list(r_adata)
         shareable = (torch.is_grad_enabled() and getattr(self.opt, 'mlp_normalization', 'none') == 'none'
                      and not any(t.requires_grad for t in inputs if t.is_floating_point())
-                     and not getattr(self.opt, 'no_shared_layout_terms', False))
+                     and not getattr(self.opt, 'no_shared_layout_terms', False)
+                     and os.environ.get('AG2V_NO_SHARED_TERMS') is None)
         cached, self._terms_cache = getattr(self, '_terms_cache', None), None
         if not shareable:
             return self.netD_img.layout_terms(objs, r_boxes, r_adata)

@@ -1,6 +1,8 @@
 // Diagnostic: in-kernel phase clocks (s_memtime) of conv_igemm_bf16x3_ws_kernel on the SPADE mlp_shared shape
 // (8 x 512 x 256 x 256 -> 128, 3x3).  Built with -DAG2V_STAMPS; not part of libag2v.so.  GPU box only.
+#ifndef NO_STAMPS
 #define AG2V_STAMPS 1
+#endif
 #include "../../ag2video_amd/csrc/conv_bf16x3.hip"
 void set_last_conv_kernel(const char*) {}
 int launch_act_mask(float*, const float*, long long, int, hipStream_t) { return 0; }
@@ -25,10 +27,14 @@ int main(int argc, char** argv) {
     const bool tall = a.M >= 192;
     const int tiles = ((a.M + (tall ? 255 : 127)) / (tall ? 256 : 128)) * (a.NG / (tall ? 128 : 256));
     hipMalloc(&st, (size_t)tiles * 16 * 4 * 8); hipMemset(st, 0, (size_t)tiles * 16 * 4 * 8);
-    a.stamps = st; a.tap_major = getenv("TAPK") ? 1 : 0;
+#ifdef AG2V_STAMPS
+    a.stamps = st;
+#endif
+    a.tap_major = getenv("TAPK") ? 1 : 0;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float ms = 0;
-    for (int rep = 0; rep < 3; ++rep) {
+    const int reps = getenv("REPS") ? atoi(getenv("REPS")) : 3;     // REPS=300: sustained clocks instead of a cold burst
+    for (int rep = 0; rep < reps; ++rep) {
         hipEventRecord(e0);
         launch_igemm_bf16x3(a, 0, false);
         hipEventRecord(e1); hipEventSynchronize(e1);
@@ -44,6 +50,14 @@ int main(int argc, char** argv) {
             else { c[0] += o[0]; c[1] += o[1]; ++nc; }
         }
     const double it = iters / np;
+    if (getenv("PER_WAVE")) {
+        for (int w = 0; w < 16; ++w) {
+            double a0 = 0, a1 = 0, a2 = 0;
+            for (int b = 0; b < tiles; ++b) { const unsigned long long* o = &hs[((size_t)b * 16 + w) * 4]; a0 += o[0]; a1 += o[1]; a2 += o[2]; }
+            if (w < 8) printf("  wave %2d (producer, SIMD %d): fetch %.0f stash %.0f barrier %.0f\n", w, w & 3, a0 / tiles / it, a1 / tiles / it, a2 / tiles / it);
+            else printf("  wave %2d (consumer, SIMD %d): compute %.0f barrier %.0f\n", w, w & 3, a0 / tiles / it, a1 / tiles / it);
+        }
+    }
     printf("M=%d %s tile: %.3f ms, %.1f TF-equivalent, %d tiles, %.0f K-tiles per workgroup\n", K, tall ? "256x128" : "128x256", ms,
            2.0 * a.M * a.NG * a.KG / ms / 1e9, tiles, it);
     printf("s_memtime ticks (100 MHz? see below) per K-tile, mean over waves:\n");
