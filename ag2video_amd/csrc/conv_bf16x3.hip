@@ -25,6 +25,9 @@
 #ifndef AG2V_TALL_MF16
 #define AG2V_TALL_MF16 true
 #endif
+#ifndef AG2V_WIDE_MF16
+#define AG2V_WIDE_MF16 false
+#endif
 template <int BM, int BN, int CWM, int CWN, int NPW, bool MF16, bool TAPK>
 __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_kernel(ConvArgs p) {
     constexpr int BK = 32, LDK = AG2V_LDK, NP = NPW * 64;       // NP producer threads
@@ -883,10 +886,16 @@ int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed) {
         hipLaunchKernelGGL((conv_igemm_bf16x3_ws_kernel<__VA_ARGS__>), grid, dim3(1024), 0, st, a);    \
     } while (0)
     if (tall) {
-        if (a.tap_major) AG2V_LAUNCH_IGEMM(256, 128, 4, 2, 8, AG2V_TALL_MF16, true);
+        // 16x16x32 MFMAs (+3..6 % with the table-path producers) read their LDS operands with 36 % bank-conflict cycles
+        // (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, tools/ubench/pmc_variants.sh; 32x32x16: 0 %) and leave the prioritised
+        // MFMA waves' partners 8 instead of 24 free issue cycles per MFMA: with the TAPK producers the 32x32x16 shape is
+        // 0.6 % of a c3 step faster (AG2V_TALL16 selects the other one for A/B runs).
+        static const bool tall16 = getenv("AG2V_TALL16") != nullptr;
+        if (a.tap_major && !tall16) AG2V_LAUNCH_IGEMM(256, 128, 4, 2, 8, false, true);
+        else if (a.tap_major) AG2V_LAUNCH_IGEMM(256, 128, 4, 2, 8, AG2V_TALL_MF16, true);
         else AG2V_LAUNCH_IGEMM(256, 128, 4, 2, 8, AG2V_TALL_MF16, false);
     } else {
-        if (a.tap_major) AG2V_LAUNCH_IGEMM(128, 256, 2, 4, 8, false, true);
+        if (a.tap_major) AG2V_LAUNCH_IGEMM(128, 256, 2, 4, 8, AG2V_WIDE_MF16, true);
         else AG2V_LAUNCH_IGEMM(128, 256, 2, 4, 8, false, false);
     }
 #undef AG2V_LAUNCH_IGEMM
@@ -912,14 +921,27 @@ int launch_wgrad_bf16x3(ConvArgs& a, hipStream_t st) {
         if (hipMemsetAsync(a.out, 0, (size_t)a.M * a.NG * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
     }
     const dim3 grid(tiles * splitk);     // 1-D: the kernels decode (split, tile) themselves (XCD-aware)
+    // 32x32x16 MFMAs: the 16x16x32 operand reads cost 49 % LDS bank-conflict cycles in these kernels (pmc_variants.sh) and the
+    // step is 0.35 % faster without them (AG2V_WGRAD16 selects the 16x16x32 form for A/B runs)
+    static const bool wgrad32 = getenv("AG2V_WGRAD16") == nullptr;
     if (a.stride == 1 && a.OW % 8 == 0 && a.W >= 8 && getenv("AG2V_WGRAD_SCALAR_LOADS") == nullptr) {
-        // 16-byte loads along the pixel index (runs of 8 pixels never straddle an image row); 16x16x32 MFMAs in the consumers
+        // 16-byte loads along the pixel index (runs of 8 pixels never straddle an image row)
         if (tall) {
+            if (wgrad32) {
+                set_last_conv_kernel("conv_wgrad_bf16x3_v_kernel<256, 128, 4, 2, 8, false>");
+                hipLaunchKernelGGL((conv_wgrad_bf16x3_v_kernel<256, 128, 4, 2, 8, false>), grid, dim3(1024), 0, st, a);
+            } else {
             set_last_conv_kernel("conv_wgrad_bf16x3_v_kernel<256, 128, 4, 2, 8, true>");
             hipLaunchKernelGGL((conv_wgrad_bf16x3_v_kernel<256, 128, 4, 2, 8, true>), grid, dim3(1024), 0, st, a);
+            }
         } else {
+            if (wgrad32) {
+                set_last_conv_kernel("conv_wgrad_bf16x3_v_kernel<128, 256, 2, 4, 8, false>");
+                hipLaunchKernelGGL((conv_wgrad_bf16x3_v_kernel<128, 256, 2, 4, 8, false>), grid, dim3(1024), 0, st, a);
+            } else {
             set_last_conv_kernel("conv_wgrad_bf16x3_v_kernel<128, 256, 2, 4, 8, true>");
             hipLaunchKernelGGL((conv_wgrad_bf16x3_v_kernel<128, 256, 2, 4, 8, true>), grid, dim3(1024), 0, st, a);
+            }
         }
     } else {
         if (tall) {
