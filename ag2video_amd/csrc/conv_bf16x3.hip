@@ -769,6 +769,7 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_v_ke
     }
 
     const int cw = wave - NPW;
+    if (!p.diag_noprio) __builtin_amdgcn_s_setprio(2);  // MFMA waves first on the SIMD's vector-issue port (see the igemm kernel): -0.45 % step
     const int wm0 = (cw / CWN) * (TM * 32), wn0 = (cw % CWN) * (TN * 32);
     // MFMA shape: see conv_igemm_bf16x3_ws_kernel
     constexpr int EM = MF16 ? TM * 2 : TM, EN = MF16 ? TN * 2 : TN;
@@ -924,6 +925,8 @@ int launch_wgrad_bf16x3(ConvArgs& a, hipStream_t st) {
     // 32x32x16 MFMAs: the 16x16x32 operand reads cost 49 % LDS bank-conflict cycles in these kernels (pmc_variants.sh) and the
     // step is 0.35 % faster without them (AG2V_WGRAD16 selects the 16x16x32 form for A/B runs)
     static const bool wgrad32 = getenv("AG2V_WGRAD16") == nullptr;
+    static const int wnoprio = getenv("AG2V_WGRAD_NOPRIO") ? 1 : 0;     // A/B aid
+    a.diag_noprio = wnoprio;
     if (a.stride == 1 && a.OW % 8 == 0 && a.W >= 8 && getenv("AG2V_WGRAD_SCALAR_LOADS") == nullptr) {
         // 16-byte loads along the pixel index (runs of 8 pixels never straddle an image row)
         if (tall) {

@@ -22,6 +22,7 @@ struct ConvArgs {
     int tap_major;          // igemm bf16x3: a_src rows are ordered by tap_major_row() instead of kg = c * R*S + r*S + s and four
                             // consecutive rows are interleaved per output row ([KG/4][M][4]); set by igemm_tap_major() for
                             // C % 32 == 0 (every 32-wide K-tile then has one filter tap)
+    int diag_noprio;        // tuning aid: the MFMA waves of the wgrad v kernels keep the default issue priority
     int accumulate;         // wgrad: add onto the existing dW (no zeroing; atomics) -- the weight is used by several forward calls
 #ifdef AG2V_STAMPS
     unsigned long long* stamps;   // diagnostic build only (tools/ubench/igemm_stamps.hip): per-wave phase clocks
