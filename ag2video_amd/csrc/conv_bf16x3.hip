@@ -129,11 +129,11 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
         // three ahead) read zeros like every masked element; `live` only keeps their offsets from wrapping.
         constexpr unsigned kOut = 0xFFFFFFF0u;
         int f_kt = kt0, f_c = 0, f_r = 0, f_s = 0;       // scalar state: the next K-tile to fetch, its first channel and its tap
-        if constexpr (TAPK) {       // K-tile index = (r * C/BK + channel chunk) * S + s
-            const int q = kt0 / p.S, cpr = p.C / BK;
+        if constexpr (TAPK) {       // K-tile index = (channel chunk * R + r) * S + s  (tap_major_row)
+            const int q = kt0 / p.S, ch = q / p.R;
             f_s = kt0 - q * p.S;
-            f_r = q / cpr;
-            f_c = (q - f_r * cpr) * BK;
+            f_r = q - ch * p.R;
+            f_c = ch * BK;
         }
         const int apart_s = (wave * 64 / (BM / ACOLS)) % AP, bpart_s = (wave * 64 / (BN / BCOLS)) % BP;   // = apart, bpart (wave-uniform)
         auto fetch_tap = [&](unsigned (&ra)[ACOLS][AK], float (&rb)[BCOLS][BKK]) {
@@ -168,8 +168,7 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
             ++f_kt;
             if (++f_s == p.S) {
                 f_s = 0;
-                f_c += BK;
-                if (f_c >= p.C) { f_c = 0; ++f_r; }
+                if (++f_r == p.R) { f_r = 0; f_c += BK; }
             }
         };
         auto stash = [&](int buf, const unsigned (&ra)[ACOLS][AK], const float (&rb)[BCOLS][BKK]) {

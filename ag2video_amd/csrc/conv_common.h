@@ -106,15 +106,18 @@ int launch_act_mask(float* out, const float* mask, long long n, int relu, hipStr
 void set_last_conv_kernel(const char* name);
 
 // K ordering of the packed bf16x3 weight operand of an implicit-GEMM launch over C gathered channels (ConvArgs::tap_major):
-// K-tile (r * C/32 + c/32) * S + s holds the 32 channels of chunk c/32 at tap (r, s).  One tap per K-tile lets the producers
-// address with wave-uniform SGPR offsets; the s taps of a chunk in consecutive K-tiles re-read the same cache lines while they
-// are still in L1 (plain tap-major order, c fastest over all of C, was 6 % slower at C = 512 than the c-major table path).
+// K-tile ((c/32) * R + r) * S + s holds the 32 channels of chunk c/32 at tap (r, s).  One tap per K-tile lets the producers
+// address with wave-uniform SGPR offsets.  The taps of a chunk follow each other: the s taps re-read the same cache lines while
+// they are still in L1 and the r taps find the neighbouring rows in L2.  Measured alternatives: c fastest over all of C (every
+// tap walks all channels) was 6 % slower at C = 512 than the c-major table path; r outermost (r, chunk, s) fetched the
+// 8 x 512 x 256 x 256 input 3.3 GB instead of 1.3 GB per launch (FETCH_SIZE: one pass over all channels per filter row, 48 MB per
+// XCD between reuses).
 static inline bool igemm_tap_major(int C, bool split) {
     static const bool off = getenv("AG2V_NO_TAP_MAJOR") != nullptr;   // A/B aid: the c-major table path for every shape
     return split && C % 32 == 0 && !off;
 }
-__host__ __device__ __forceinline__ int tap_major_row(int c, int r, int s, int C, int S) {
-    return (((r * (C >> 5) + (c >> 5)) * S + s) << 5) + (c & 31);
+__host__ __device__ __forceinline__ int tap_major_row(int c, int r, int s, int R, int S) {
+    return (((((c >> 5) * R + r) * S + s)) << 5) + (c & 31);
 }
 
 // launchers implemented in conv_bf16x3.hip

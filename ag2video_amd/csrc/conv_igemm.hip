@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void pack_fwd_tap_kernel(const float* __restri
         const int r = tap / S, s2 = tap - r * S;
         const float* src = &t[m * row + (c4 * 4) * RS + tap];
         const float4 v = make_float4(pack_split(src[0]), pack_split(src[RS]), pack_split(src[2 * RS]), pack_split(src[3 * RS]));
-        const int drow = tap_major_row(c0 + c4 * 4, r, s2, C, S);
+        const int drow = tap_major_row(c0 + c4 * 4, r, s2, R, S);
         *reinterpret_cast<float4*>(&at[((size_t)(drow >> 2) * M + (m0 + m)) * 4]) = v;
     }
 }
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256) void pack_dgrad_tap_kernel(const float* __rest
         const int q = lane * RSP + (py + st * (Rc - 1 - r2)) * S + (px + st * (Sc - 1 - s2));
         if (lane < nc) {
             const float4 v = make_float4(pack_split(t[0][q]), pack_split(t[1][q]), pack_split(t[2][q]), pack_split(t[3][q]));
-            const int drow = tap_major_row(k0, r2, s2, K, Sc);
+            const int drow = tap_major_row(k0, r2, s2, Rc, Sc);
             *reinterpret_cast<float4*>(&at[((size_t)(drow >> 2) * C + (c0 + lane)) * 4]) = v;
         }
     }
