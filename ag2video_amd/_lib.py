@@ -27,6 +27,7 @@ _SIGS = {
     'ag2v_conv2d_wgrad': (c_int, [_P, _P, _P] + [c_int] * 9 + [_P]),
     'ag2v_conv2d_wgrad_acc': (c_int, [_P, _P, _P] + [c_int] * 10 + [_P]),
     'ag2v_channel_sum': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    'ag2v_channel_sum_acc': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     'ag2v_bn_workspace_floats': (c_size_t, [c_int, c_int, c_int]),
     'ag2v_bn_stats': (c_int, [_P, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P]),
     'ag2v_norm_apply': (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
@@ -63,6 +64,7 @@ _SIGS = {
     'ag2v_spectral_workspace_floats': (c_size_t, [c_int]),
     'ag2v_spectral_norm_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_float, c_int, _P, _P, _P, _P]),
     'ag2v_spectral_norm_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P]),
+    'ag2v_spectral_norm_bwd_acc': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, c_int, _P, _P]),
 }
 EXPORTS = tuple(sorted(_SIGS))
 

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void instnorm_lrelu_bwd_kernel(const float* __
 // ---------------------------------------------------------------- per-channel sum over (N, H*W): conv bias gradient
 // grid (C, nsplit): split s sums images n = s, s+nsplit, ...; nsplit > 1 accumulates with one atomic per workgroup
 __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int C,
-                                                          int HW, int nsplit) {
+                                                          int HW, int nsplit, int acc) {
     __shared__ float sh[4];
     const int c = blockIdx.x;
     float s = 0.f;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
     }
     s = block_sum_256(s, sh);
     if (threadIdx.x == 0) {
-        if (nsplit > 1) atomicAdd(out + c, s); else out[c] = s;
+        if (nsplit > 1 || acc) atomicAdd(out + c, s); else out[c] = s;
     }
 }
 
@@ -418,7 +418,8 @@ extern "C" int ag2v_instnorm_lrelu_bwd(const float* dy, const float* y, const fl
     return AG2V_OK;
 }
 
-extern "C" int ag2v_channel_sum(const float* x, float* out, int N, int C, int HW, void* stream) {
+// accumulate != 0: out[c] += sum (a bias used by several forward calls of one step collects its gradient in one buffer)
+extern "C" int ag2v_channel_sum_acc(const float* x, float* out, int N, int C, int HW, int accumulate, void* stream) {
     if (!x || !out || N <= 0 || C <= 0 || HW <= 0) return AG2V_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     int nsplit = 1;
@@ -426,8 +427,11 @@ extern "C" int ag2v_channel_sum(const float* x, float* out, int N, int C, int HW
         nsplit = ceil_div(1024, C);
         if (nsplit > N) nsplit = N;
     }
-    if (nsplit > 1 && hipMemsetAsync(out, 0, (size_t)C * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
-    hipLaunchKernelGGL(channel_sum_kernel, dim3(C, nsplit), dim3(256), 0, st, x, out, N, C, HW, nsplit);
+    if (nsplit > 1 && !accumulate && hipMemsetAsync(out, 0, (size_t)C * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(C, nsplit), dim3(256), 0, st, x, out, N, C, HW, nsplit, accumulate ? 1 : 0);
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
+}
+extern "C" int ag2v_channel_sum(const float* x, float* out, int N, int C, int HW, void* stream) {
+    return ag2v_channel_sum_acc(x, out, N, C, HW, 0, stream);
 }

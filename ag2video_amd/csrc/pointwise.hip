@@ -137,11 +137,12 @@ __global__ __launch_bounds__(256) void sn_scale_kernel(const float* __restrict__
 }
 __global__ __launch_bounds__(256) void sn_bwd_kernel(const float* __restrict__ dwbar, const float* __restrict__ u, const float* __restrict__ v,
                                                      const float* __restrict__ sigma, const float* __restrict__ dot, float* __restrict__ dw,
-                                                     int M, int R) {
+                                                     int M, int R, int acc) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long long)M * R) return;
     const int m = (int)(i / R), r = (int)(i - (long long)m * R);
-    dw[i] = (dwbar[i] - dot[0] * u[m] * v[r]) / sigma[0];
+    const float g = (dwbar[i] - dot[0] * u[m] * v[r]) / sigma[0];
+    dw[i] = acc ? dw[i] + g : g;
 }
 __global__ __launch_bounds__(256) void dot_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n,
                                                           float* __restrict__ partial) {
@@ -218,8 +219,9 @@ extern "C" int ag2v_spectral_norm_fwd(const float* w, float* u, float* v, int M,
     return AG2V_OK;
 }
 // dW = (dW_bar - <dW_bar, W_bar> u v^T) / sigma     (u, v: the vectors the forward used)
-extern "C" int ag2v_spectral_norm_bwd(const float* dwbar, const float* wbar, const float* u, const float* v, const float* sigma,
-                                      int M, int R, float* dw, float* workspace, void* stream) {
+// accumulate != 0: dw += (weight_orig is used by every frame pass of a step: one gradient buffer per backward pass)
+extern "C" int ag2v_spectral_norm_bwd_acc(const float* dwbar, const float* wbar, const float* u, const float* v, const float* sigma,
+                                          int M, int R, float* dw, int accumulate, float* workspace, void* stream) {
     if (!dwbar || !wbar || !u || !v || !sigma || !dw || !workspace || M <= 0 || R <= 0) return AG2V_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const long long n = (long long)M * R;
@@ -229,9 +231,13 @@ extern "C" int ag2v_spectral_norm_bwd(const float* dwbar, const float* wbar, con
     float* dot = workspace;  // reuse first float
     hipLaunchKernelGGL(dot_partial_kernel, dim3(nb), dim3(256), 0, st, dwbar, wbar, n, partial);
     hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, st, partial, nb, 1.0f, dot);
-    hipLaunchKernelGGL(sn_bwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, dwbar, u, v, sigma, dot, dw, M, R);
+    hipLaunchKernelGGL(sn_bwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, dwbar, u, v, sigma, dot, dw, M, R, accumulate ? 1 : 0);
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
+}
+extern "C" int ag2v_spectral_norm_bwd(const float* dwbar, const float* wbar, const float* u, const float* v, const float* sigma,
+                                      int M, int R, float* dw, float* workspace, void* stream) {
+    return ag2v_spectral_norm_bwd_acc(dwbar, wbar, u, v, sigma, M, R, dw, 0, workspace, stream);
 }
 
 // ---------------------------------------------------------------- fused Adam over a flat parameter buffer (K15)

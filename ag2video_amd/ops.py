@@ -187,7 +187,10 @@ def kernel_timing_summary(by_shape=False):
 # consumers have run, so it arrives complete; without this it would receive 15 tensors and sum them pairwise (4 700 small add
 # launches and as many zero-fills per step).  The registry is cleared by an engine callback at the end of every backward pass.
 
+# The same holds for spectral norm's weight_orig (one _SpectralWeight node per frame pass: 560 full-size adds per step without it)
+# and for convolution biases (AG2V_NO_EXTRA_SINKS switches these two off for A/B runs).
 _WSINK = {}          # id(weight tensor) -> [weakref to it, sink tensor or None]
+_EXTRA_SINKS = os.environ.get('AG2V_NO_EXTRA_SINKS') is None
 _WSINK_CB = [False]  # end-of-pass callback queued for the current backward pass
 
 
@@ -227,7 +230,7 @@ class _Conv2d(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, residual, stride, pad, relu, grad_premasked, relu_input):
-        w_in = w
+        w_in, bias_in = w, bias
         x, w, bias, residual = _c(x), _c(w), _c(bias), _c(residual)
         _chk(x, w, bias, residual)
         N, C, H, W = x.shape
@@ -245,8 +248,9 @@ class _Conv2d(torch.autograd.Function):
         ctx.save_for_backward(x, w, y if (relu and not grad_premasked) else None)
         ctx.cfg = (stride, pad, bias is not None, residual is not None, mr, relu, grad_premasked, relu_input)
         ctx.wkey = _wsink_register(w_in) if ctx.needs_input_grad[1] else None
-        ctx.w_alive = w_in      # the registry keys on id(w_in): keep the object alive as long as this node, or a temporary (a
-        return y                # weight slice) could be collected and its id handed to another call's weight
+        ctx.bkey = _wsink_register(bias_in) if (bias_in is not None and ctx.needs_input_grad[2] and _EXTRA_SINKS) else None
+        ctx.w_alive = (w_in, bias_in)   # the registry keys on id(): keep the objects alive as long as this node, or a temporary
+        return y                        # (a weight slice) could be collected and its id handed to another call's weight
 
     @staticmethod
     def backward(ctx, dy):
@@ -274,8 +278,8 @@ class _Conv2d(torch.autograd.Function):
                          _ptr(dy), _ptr(x), _ptr(buf), N, C, H, W, K, R, S, stride, pad, acc, st,
                          shape=(N, C, H, W, K, R, stride))
         if has_bias and ctx.needs_input_grad[2]:
-            db = torch.empty(K, device=dy.device, dtype=torch.float32)
-            _lib.call('ag2v_channel_sum', _ptr(dy), _ptr(db), N, K, dy.shape[2] * dy.shape[3], st)
+            bbuf, bacc, db = _wsink_take(ctx.bkey, ctx.w_alive[1])
+            _lib.call('ag2v_channel_sum_acc', _ptr(dy), _ptr(bbuf), N, K, dy.shape[2] * dy.shape[3], bacc, st)
         if has_res and ctx.needs_input_grad[3]:
             dres = dy
         return dx, dw, db, dres, None, None, None, None, None
@@ -299,7 +303,9 @@ class _ConvSharedInput(torch.autograd.Function):
     def forward(ctx, x, stride, pad, relu, grad_premasked, *wb):
         x = _c(x)
         ctx.wkeys = [(_wsink_register(t) if ctx.needs_input_grad[5 + 2 * i] else None) for i, t in enumerate(wb[0::2])]
-        ctx.w_alive = list(wb[0::2])     # see _Conv2d.forward
+        ctx.bkeys = [(_wsink_register(t) if (t is not None and ctx.needs_input_grad[6 + 2 * i] and _EXTRA_SINKS) else None)
+                     for i, t in enumerate(wb[1::2])]
+        ctx.w_alive = list(wb)           # see _Conv2d.forward
         ws_, bs_ = [_c(t) for t in wb[0::2]], [_c(t) for t in wb[1::2]]
         _chk(x, *ws_)
         _chk(*[b for b in bs_ if b is not None])
@@ -359,8 +365,8 @@ class _ConvSharedInput(torch.autograd.Function):
                 _conv_launch(mr, 'ag2v_conv2d_wgrad_acc', 'conv_wgrad', flops, _ptr(dy), _ptr(x), _ptr(buf), N, C, H, W, K, R, S, stride,
                              pad, acc, st, shape=(N, C, H, W, K, R, stride))
             if has_b[i] and ctx.needs_input_grad[6 + 2 * i]:
-                db = torch.empty(K, device=dy.device, dtype=torch.float32)
-                _lib.call('ag2v_channel_sum', _ptr(dy), _ptr(db), N, K, dy.shape[2] * dy.shape[3], st)
+                bbuf, bacc, db = _wsink_take(ctx.bkeys[i], ctx.w_alive[2 * i + 1])
+                _lib.call('ag2v_channel_sum_acc', _ptr(dy), _ptr(bbuf), N, K, dy.shape[2] * dy.shape[3], bacc, st)
             grads += [dw, db]
         if dx is not None and first:
             dx.zero_()
@@ -390,6 +396,9 @@ class _SpectralWeight(torch.autograd.Function):
                   _ptr(wbar), _ptr(sigma), _ptr(ws), _stream())
         # the buffers keep advancing in later calls; the tape needs the vectors this call used
         ctx.save_for_backward(wbar, u.clone(), v.clone(), sigma)
+        # weight_orig is used by every frame pass of a step: one gradient buffer per backward pass (see _wsink_*)
+        ctx.okey = _wsink_register(w_orig) if (ctx.needs_input_grad[0] and _EXTRA_SINKS) else None
+        ctx.o_alive = w_orig
         return wbar
 
     @staticmethod
@@ -398,10 +407,10 @@ class _SpectralWeight(torch.autograd.Function):
         dwbar = dwbar.contiguous()
         M = wbar.shape[0]
         R = wbar.numel() // M
-        dw = torch.empty_like(wbar)
+        buf, acc, dw = _wsink_take(ctx.okey, wbar)
         ws = torch.empty(_lib.query('ag2v_spectral_workspace_floats', M), device=wbar.device, dtype=torch.float32)
-        _lib.call('ag2v_spectral_norm_bwd', _ptr(dwbar), _ptr(wbar), _ptr(u), _ptr(v), _ptr(sigma), M, R, _ptr(dw), _ptr(ws),
-                  _stream())
+        _lib.call('ag2v_spectral_norm_bwd_acc', _ptr(dwbar), _ptr(wbar), _ptr(u), _ptr(v), _ptr(sigma), M, R, _ptr(buf), acc,
+                  _ptr(ws), _stream())
         return dw, None, None, None, None
 
 

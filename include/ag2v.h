@@ -62,6 +62,8 @@ int ag2v_conv2d_wgrad_acc(const float* dy, const float* x, float* dw, int N, int
                           int stride, int pad, int accumulate, void* stream);
 /* out[c] = sum over n,hw of x[n,c,hw]: conv bias gradient */
 int ag2v_channel_sum(const float* x, float* out, int N, int C, int HW, void* stream);
+/* accumulate != 0: out[c] += ... (one gradient buffer per bias and backward pass; the generator runs once per frame) */
+int ag2v_channel_sum_acc(const float* x, float* out, int N, int C, int HW, int accumulate, void* stream);
 
 /* ---- batch norm / SPADE / instance norm -------------------------------------------------------------------------
  * F.batch_norm(training) in sync_batchnorm/batchnorm.py:63-68; SPADE.forward normalization.py:96-110;
@@ -155,6 +157,9 @@ int ag2v_spectral_norm_fwd(const float* w, float* u, float* v, int M, int R, flo
                            float* sigma, float* workspace, void* stream);
 int ag2v_spectral_norm_bwd(const float* dwbar, const float* wbar, const float* u, const float* v, const float* sigma, int M,
                            int R, float* dw, float* workspace, void* stream);
+/* accumulate != 0: dw += ... (weight_orig collects the gradients of all forward calls of a step in one buffer) */
+int ag2v_spectral_norm_bwd_acc(const float* dwbar, const float* wbar, const float* u, const float* v, const float* sigma, int M,
+                               int R, float* dw, int accumulate, float* workspace, void* stream);
 
 /* ---- fused Adam over a flat fp32 buffer: torch.optim.Adam as configured at scripts/train.py:365-368 and
  * meta_models.py:70-72 (weight_decay 0, amsgrad off); step_index >= 1 --------------------------------------------- */
