@@ -191,32 +191,39 @@ def kernel_timing_summary(by_shape=False):
 # and for convolution biases (AG2V_NO_EXTRA_SINKS switches these two off for A/B runs).
 _WSINK = {}          # id(weight tensor) -> [weakref to it, sink tensor or None]
 _EXTRA_SINKS = os.environ.get('AG2V_NO_EXTRA_SINKS') is None
-_WSINK_CB = [False]  # end-of-pass callback queued for the current backward pass
+_WSINK_CB = [None]   # graph-task id of the backward pass whose end-of-pass callback is queued (None: none; ids start at 0)
 
 
 def _wsink_register(w):
     e = _WSINK.get(id(w))
     if e is None or e[0]() is not w:
-        _WSINK[id(w)] = [weakref.ref(w), None]
+        _WSINK[id(w)] = [weakref.ref(w), None, -1]
     return id(w)
 
 
 def _wsink_clear():
     _WSINK.clear()
-    _WSINK_CB[0] = False
+    _WSINK_CB[0] = None
 
 
 def _wsink_take(key, like):
-    """-> (buffer to pass to the wgrad launch, accumulate flag, tensor to return to autograd or None)."""
+    """-> (buffer to pass to the wgrad launch, accumulate flag, tensor to return to autograd or None).
+    A sink buffer belongs to ONE backward pass: it carries the autograd graph-task id it was created under, so a buffer left
+    behind by a pass that ended without its end-of-pass callback (an exception inside backward) is never accumulated into."""
     e = _WSINK.get(key)
-    if e is None:                       # registered before an earlier backward pass cleared the registry: plain path
+    task = torch._C._current_graph_task_id()
+    if e is None or task < 0:           # registered before an earlier backward pass cleared the registry: plain path
         buf = torch.empty_like(like)
         return buf, 0, buf
-    if not _WSINK_CB[0]:
+    if _WSINK_CB[0] != task:            # first sink use of this backward pass
+        if _WSINK_CB[0] is not None:    # an earlier pass never reached its callback: release its buffers
+            for ent in _WSINK.values():
+                if ent[2] != task:
+                    ent[1] = None
         torch.autograd.Variable._execution_engine.queue_callback(_wsink_clear)
-        _WSINK_CB[0] = True
-    if e[1] is None:
-        e[1] = torch.empty_like(like)
+        _WSINK_CB[0] = task
+    if e[1] is None or e[2] != task:
+        e[1], e[2] = torch.empty_like(like), task
         return e[1], 0, e[1]
     return e[1], 1, None
 
