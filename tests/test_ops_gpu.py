@@ -469,3 +469,48 @@ def test_fused_adam_matches_torch_adam(device):
     for a, b in zip(ref_p, gpu_p):
         _cmp('adam.param', b, a, 1e-5)
     assert gpu_p[1].data_ptr() >= opt.flat_param.data_ptr()
+
+
+def test_gradient_sinks_multi_use_and_aborted_backward(device):
+    """A weight / bias / spectral-norm weight_orig used by several calls of one graph collects its gradient in one buffer per
+    backward pass (ops._wsink_*).  (i) the sums match the oracle's plain autograd; (ii) a backward pass that dies after its
+    first weight-gradient launch leaves nothing behind that a later pass would accumulate into."""
+    from ag2video_amd import ops
+    from oracle import kernels as K
+    x1, x2, x3 = _rand(2, 16, 12, 12, seed=1), _rand(2, 16, 12, 12, seed=2), _rand(2, 16, 12, 12, seed=3)
+    w0, b0 = _rand(136, 16, 3, 3, seed=4, scale=0.1), _rand(136, seed=5)
+    u0 = torch.nn.functional.normalize(_rand(136, seed=6), dim=0)
+    v0 = torch.nn.functional.normalize(_rand(16 * 9, seed=7), dim=0)
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError("boom")
+
+    def run(mod, dev, boom=False):
+        w = w0.clone().to(dev).requires_grad_(True)
+        b = b0.clone().to(dev).requires_grad_(True)
+        u, v = u0.clone().to(dev), v0.clone().to(dev)
+        loss = 0.0
+        for i, x in enumerate((x1, x2, x3)):
+            xx = x.clone().to(dev).requires_grad_(True)
+            if boom and i == 0:
+                xx = Boom.apply(xx)
+            weff = mod.spectral_weight(w, u, v, True, 1e-12)          # one node per use, like the 15 frame passes
+            y = mod.conv2d(xx, weff, b, 1, 1)
+            loss = loss + (y * _rand(*y.shape, seed=40 + i).to(dev)).sum()
+        return loss, w, b
+
+    loss, w, b = run(ops, device, boom=True)
+    with pytest.raises(RuntimeError, match="boom"):
+        loss.backward()
+    loss, w, b = run(ops, device)
+    loss.backward()
+    lr, wr, br = run(K, 'cpu')
+    lr.backward()
+    _cmp('sink.dw_orig', w.grad, wr.grad, TOL)
+    _cmp('sink.db', b.grad, br.grad, TOL)
