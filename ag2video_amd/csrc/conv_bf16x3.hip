@@ -860,7 +860,9 @@ static int pick_splits(int tiles, int nk, int max_splits) {
 }
 
 int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed) {
-    const bool tall = a.M >= 192;                 // 256 x 128 tile when there are enough output channels, else 128 x 256
+    // 256 x 128 tile when there are enough rows and it pads no more rows than the 128 x 256 tile does (384 rows: three 128-row
+    // tiles, not two 256-row ones)
+    const bool tall = a.M >= 192 && ceil_div(a.M, 256) * 256 <= ceil_div(a.M, 128) * 128;
     const int bm = tall ? 256 : 128, bn = tall ? 128 : 256;
     a.tiles_m = ceil_div(a.M, bm);
     a.tiles_n = ceil_div(a.NG, bn);
@@ -906,7 +908,7 @@ int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed) {
 }
 
 int launch_wgrad_bf16x3(ConvArgs& a, hipStream_t st) {
-    const bool tall = a.M >= 192;
+    const bool tall = a.M >= 192 && ceil_div(a.M, 256) * 256 <= ceil_div(a.M, 128) * 128;     // see launch_igemm_bf16x3
     const int bm = tall ? 256 : 128, bn = tall ? 128 : 256;
     a.tiles_m = ceil_div(a.M, bm);
     a.tiles_n = ceil_div(a.NG, bn);

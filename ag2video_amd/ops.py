@@ -192,6 +192,7 @@ def kernel_timing_summary(by_shape=False):
 _WSINK = {}          # id(weight tensor) -> [weakref to it, sink tensor or None]
 _EXTRA_SINKS = os.environ.get('AG2V_NO_EXTRA_SINKS') is None
 _MERGE_SHARED_DGRAD = os.environ.get('AG2V_NO_MERGED_DGRAD') is None      # conv2d_shared_input: one data-gradient launch (A/B)
+_MERGE_SHARED_WGRAD = os.environ.get('AG2V_NO_MERGED_WGRAD') is None      # ... and one weight-gradient launch
 _WSINK_CB = [None]   # graph-task id of the backward pass whose end-of-pass callback is queued (None: none; ids start at 0)
 
 
@@ -207,6 +208,17 @@ def _wsink_clear():
     _WSINK_CB[0] = None
 
 
+def _wsink_begin(task):
+    if _WSINK_CB[0] != task:            # first sink use of this backward pass
+        if _WSINK_CB[0] is not None:    # an earlier pass never reached its callback: release its buffers
+            for ent in _WSINK.values():
+                if ent[2] != task:
+                    ent[1] = None
+                    del ent[3:]
+        torch.autograd.Variable._execution_engine.queue_callback(_wsink_clear)
+        _WSINK_CB[0] = task
+
+
 def _wsink_take(key, like):
     """-> (buffer to pass to the wgrad launch, accumulate flag, tensor to return to autograd or None).
     A sink buffer belongs to ONE backward pass: it carries the autograd graph-task id it was created under, so a buffer left
@@ -216,17 +228,35 @@ def _wsink_take(key, like):
     if e is None or task < 0:           # registered before an earlier backward pass cleared the registry: plain path
         buf = torch.empty_like(like)
         return buf, 0, buf
-    if _WSINK_CB[0] != task:            # first sink use of this backward pass
-        if _WSINK_CB[0] is not None:    # an earlier pass never reached its callback: release its buffers
-            for ent in _WSINK.values():
-                if ent[2] != task:
-                    ent[1] = None
-        torch.autograd.Variable._execution_engine.queue_callback(_wsink_clear)
-        _WSINK_CB[0] = task
+    _wsink_begin(task)
     if e[1] is None or e[2] != task:
         e[1], e[2] = torch.empty_like(like), task
         return e[1], 0, e[1]
     return e[1], 1, None
+
+
+def _wsink_take_group(keys, likes):
+    """Sinks of several weights as consecutive slices of one buffer -> (buffer, accumulate flag, tensors for autograd).
+    Falls back to a fresh buffer (plain path) when any of the weights has no live registry entry."""
+    task = torch._C._current_graph_task_id()
+    ents = [_WSINK.get(k) for k in keys]
+    rows = [t.shape[0] for t in likes]
+    shape = (sum(rows),) + tuple(likes[0].shape[1:])
+    if task < 0 or any(e is None for e in ents):
+        cat = torch.empty(shape, device=likes[0].device, dtype=torch.float32)
+        return cat, 0, list(torch.split(cat, rows, dim=0))
+    _wsink_begin(task)
+    e0 = ents[0]
+    cat = e0[3] if (len(e0) > 3 and e0[2] == task) else None
+    if cat is not None and tuple(cat.shape) == shape and all(e[2] == task for e in ents):
+        return cat, 1, [None] * len(keys)
+    cat = torch.empty(shape, device=likes[0].device, dtype=torch.float32)
+    views = list(torch.split(cat, rows, dim=0))
+    for e, v in zip(ents, views):
+        e[1], e[2] = v, task
+    del e0[3:]
+    e0.append(cat)
+    return cat, 0, views
 
 
 # ------------------------------------------------------------------------------------------------ convolution
@@ -347,7 +377,11 @@ class _ConvSharedInput(torch.autograd.Function):
         st = _stream()
         dx = None
         grads = []
-        live = []                       # (weight, masked dy) of the branches that received a gradient
+        live = []                       # (weight, masked dy, index) of the branches that received a gradient
+        # all branches live and all weights want gradients: one weight-gradient launch over the concatenated rows, writing
+        # slices of ONE buffer (the per-weight sinks are views of it), so the gathered input is read once per pass
+        merged_w = (_MERGE_SHARED_WGRAD and n > 1 and all(d is not None for d in dys)
+                    and all(ctx.needs_input_grad[5 + 2 * i] for i in range(n)))
         for i in range(n):
             w, dy = ws_[i], dys[i]
             if dy is None:
@@ -359,10 +393,10 @@ class _ConvSharedInput(torch.autograd.Function):
                 g = torch.empty_like(dy)
                 _lib.call('ag2v_act_bwd', 0, _ptr(dy), _ptr(ys[i]), _ptr(g), dy.numel(), 0.0, st)
                 dy = g
-            live.append((w, dy))
+            live.append((w, dy, i))
             flops = 2.0 * N * K * dy.shape[2] * dy.shape[3] * C * R * S
             dw = db = None
-            if ctx.needs_input_grad[5 + 2 * i]:
+            if ctx.needs_input_grad[5 + 2 * i] and not merged_w:
                 buf, acc, dw = _wsink_take(ctx.wkeys[i], w)
                 _conv_launch(mr, 'ag2v_conv2d_wgrad_acc', 'conv_wgrad', flops, _ptr(dy), _ptr(x), _ptr(buf), N, C, H, W, K, R, S, stride,
                              pad, acc, st, shape=(N, C, H, W, K, R, stride))
@@ -370,6 +404,16 @@ class _ConvSharedInput(torch.autograd.Function):
                 bbuf, bacc, db = _wsink_take(ctx.bkeys[i], ctx.w_alive[2 * i + 1])
                 _lib.call('ag2v_channel_sum_acc', _ptr(dy), _ptr(bbuf), N, K, dy.shape[2] * dy.shape[3], bacc, st)
             grads += [dw, db]
+        dyc = None
+        if merged_w:
+            dyc = torch.cat([d for _, d, _ in live], dim=1)
+            Kt = dyc.shape[1]
+            R, S = ws_[0].shape[2], ws_[0].shape[3]
+            cat, acc, outs = _wsink_take_group(ctx.wkeys, [w for w, _, _ in live])
+            _conv_launch(mr, 'ag2v_conv2d_wgrad_acc', 'conv_wgrad', 2.0 * N * Kt * dyc.shape[2] * dyc.shape[3] * C * R * S,
+                         _ptr(dyc), _ptr(x), _ptr(cat), N, C, H, W, Kt, R, S, stride, pad, acc, st, shape=(N, C, H, W, Kt, R, stride))
+            for j, (_, _, i) in enumerate(live):
+                grads[2 * i] = outs[j]
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             if not live:
@@ -378,15 +422,16 @@ class _ConvSharedInput(torch.autograd.Function):
                 # sum_i dgrad(dy_i, w_i) = dgrad(cat_i dy_i, cat_i w_i): one launch over the concatenated output channels writes
                 # dx once (three launches write it three times and read it back twice: 4.3 GB per block at 8 x 512 x 256 x 256,
                 # against 1.6 GB for the concatenation) and runs a three times longer reduction per tile
-                wc = live[0][0] if len(live) == 1 else torch.cat([w for w, _ in live], dim=0)
-                dyc = live[0][1] if len(live) == 1 else torch.cat([d for _, d in live], dim=1)
+                wc = live[0][0] if len(live) == 1 else torch.cat([w for w, _, _ in live], dim=0)
+                if dyc is None:
+                    dyc = live[0][1] if len(live) == 1 else torch.cat([d for _, d, _ in live], dim=1)
                 K, _, R, S = wc.shape
                 ws = torch.empty(_lib.query('ag2v_conv2d_workspace_floats', C, K, R, S), device=dyc.device, dtype=torch.float32)
                 _conv_launch(mr, 'ag2v_conv2d_dgrad_acc', 'conv_dgrad', 2.0 * N * K * dyc.shape[2] * dyc.shape[3] * C * R * S,
                              _ptr(dyc), _ptr(wc), None, _ptr(dx), N, C, H, W, K, R, S, stride, pad, 0, _ptr(ws), st,
                              shape=(N, C, H, W, K, R, stride))
             else:
-                for j, (w, dy) in enumerate(live):
+                for j, (w, dy, _) in enumerate(live):
                     K, _, R, S = w.shape
                     ws = torch.empty(_lib.query('ag2v_conv2d_workspace_floats', C, K, R, S), device=dy.device, dtype=torch.float32)
                     _conv_launch(mr, 'ag2v_conv2d_dgrad_acc', 'conv_dgrad', 2.0 * N * K * dy.shape[2] * dy.shape[3] * C * R * S,
