@@ -93,15 +93,6 @@ __global__ __launch_bounds__(256) void sn_wtu_kernel(const float* __restrict__ w
     for (int m = m0; m < m1; ++m) s += w[(size_t)m * R + r] * u[m];
     if (gridDim.y > 1) atomicAdd(v + r, s); else v[r] = s;
 }
-// x <- x / max(||x||, eps) (single workgroup)
-__global__ __launch_bounds__(256) void sn_normalize_kernel(float* __restrict__ x, int n, float eps) {
-    __shared__ float sh[4];
-    float s = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) s += x[i] * x[i];
-    s = block_sum_256(s, sh);
-    const float inv = 1.0f / fmaxf(sqrtf(s), eps);
-    for (int i = threadIdx.x; i < n; i += 256) x[i] *= inv;
-}
 // out[m] = sum_r W[m,r] v[r] : one wave per row
 __global__ __launch_bounds__(256) void sn_wv_kernel(const float* __restrict__ w, const float* __restrict__ v, float* __restrict__ out,
                                                     int M, int R) {
@@ -113,11 +104,19 @@ __global__ __launch_bounds__(256) void sn_wv_kernel(const float* __restrict__ w,
     s = wave_sum(s);
     if (lane == 0) out[m] = s;
 }
-// u <- normalize(wv) when update_u; sigma = u . wv   (single workgroup)
-__global__ __launch_bounds__(256) void sn_sigma_kernel(float* __restrict__ u, const float* __restrict__ wv, int M, float eps,
-                                                       int update_u, float* __restrict__ sigma) {
+// update_u: v[R] holds the un-normalised W^T u and wv[M] = W v of it: v <- v / max(|v|, eps), wv <- wv / max(|v|, eps) (W v is
+// linear in v), u <- normalize(wv).  Then sigma = u . wv.   (single workgroup)
+__global__ __launch_bounds__(256) void sn_sigma_kernel(float* __restrict__ u, float* __restrict__ wv, float* __restrict__ v, int M,
+                                                       int R, float eps, int update_u, float* __restrict__ sigma) {
     __shared__ float sh[4];
     if (update_u) {
+        float q = 0.f;
+        for (int i = threadIdx.x; i < R; i += 256) q += v[i] * v[i];
+        q = block_sum_256(q, sh);
+        const float vinv = 1.0f / fmaxf(sqrtf(q), eps);
+        for (int i = threadIdx.x; i < R; i += 256) v[i] *= vinv;
+        for (int i = threadIdx.x; i < M; i += 256) wv[i] *= vinv;
+        __syncthreads();
         float s = 0.f;
         for (int i = threadIdx.x; i < M; i += 256) s += wv[i] * wv[i];
         s = block_sum_256(s, sh);
@@ -135,13 +134,22 @@ __global__ __launch_bounds__(256) void sn_scale_kernel(const float* __restrict__
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) wbar[i] = w[i] / sigma[0];
 }
+// partial[np]: block sums of <dW_bar, W_bar> (dot_partial_kernel); every workgroup adds them up itself (<= 1024 floats from L2,
+// in double like reduce_final_kernel) instead of a one-block launch in between
 __global__ __launch_bounds__(256) void sn_bwd_kernel(const float* __restrict__ dwbar, const float* __restrict__ u, const float* __restrict__ v,
-                                                     const float* __restrict__ sigma, const float* __restrict__ dot, float* __restrict__ dw,
-                                                     int M, int R, int acc) {
+                                                     const float* __restrict__ sigma, const float* __restrict__ partial, int np,
+                                                     float* __restrict__ dw, int M, int R, int acc) {
+    __shared__ double shd[4];
+    double s = 0.0;
+    for (int k = threadIdx.x; k < np; k += 256) s += partial[k];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) shd[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float dot = (float)(shd[0] + shd[1] + shd[2] + shd[3]);
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long long)M * R) return;
     const int m = (int)(i / R), r = (int)(i - (long long)m * R);
-    const float g = (dwbar[i] - dot[0] * u[m] * v[r]) / sigma[0];
+    const float g = (dwbar[i] - dot * u[m] * v[r]) / sigma[0];
     dw[i] = acc ? dw[i] + g : g;
 }
 __global__ __launch_bounds__(256) void dot_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n,
@@ -209,10 +217,9 @@ extern "C" int ag2v_spectral_norm_fwd(const float* w, float* u, float* v, int M,
         msplit = ceil_div(M, mchunk);
         if (msplit > 1 && hipMemsetAsync(v, 0, (size_t)R * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
         hipLaunchKernelGGL(sn_wtu_kernel, dim3(rb, msplit), dim3(256), 0, st, w, u, v, M, R, mchunk);
-        hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(256), 0, st, v, R, eps);
     }
     hipLaunchKernelGGL(sn_wv_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, w, v, wv, M, R);
-    hipLaunchKernelGGL(sn_sigma_kernel, dim3(1), dim3(256), 0, st, u, wv, M, eps, power_iter, sigma);
+    hipLaunchKernelGGL(sn_sigma_kernel, dim3(1), dim3(256), 0, st, u, wv, v, M, R, eps, power_iter, sigma);
     const long long n = (long long)M * R;
     hipLaunchKernelGGL(sn_scale_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, w, sigma, wbar, n);
     AG2V_CHECK_LAUNCH();
@@ -228,10 +235,9 @@ extern "C" int ag2v_spectral_norm_bwd_acc(const float* dwbar, const float* wbar,
     int nb = ceil_div(n, 256 * 8);
     if (nb > RED_BLOCKS) nb = RED_BLOCKS;
     float* partial = workspace + M;
-    float* dot = workspace;  // reuse first float
     hipLaunchKernelGGL(dot_partial_kernel, dim3(nb), dim3(256), 0, st, dwbar, wbar, n, partial);
-    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, st, partial, nb, 1.0f, dot);
-    hipLaunchKernelGGL(sn_bwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, dwbar, u, v, sigma, dot, dw, M, R, accumulate ? 1 : 0);
+    hipLaunchKernelGGL(sn_bwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, dwbar, u, v, sigma, partial, nb, dw, M, R,
+                       accumulate ? 1 : 0);
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
 }
