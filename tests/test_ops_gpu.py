@@ -63,7 +63,8 @@ CONV_CASES = [
     (4, 64, 64, 64, 64, 3, 3, 1, 1, True, False),
     (3, 259, 33, 33, 64, 4, 4, 2, 2, True, False),
     (2, 130, 12, 12, 3, 3, 3, 1, 1, True, False),
-    (2, 3, 16, 16, 200, 3, 3, 1, 1, True, False),
+    (2, 3, 16, 16, 200, 3, 3, 1, 1, True, False),     # <= 4 input channels: data gradient as 1x1 GEMM + shifted-plane sum
+    (2, 2, 10, 12, 72, 4, 4, 1, 2, False, False),     # same path, 4x4 filter with pad 2 (output one larger than the input)
     (2, 64, 8, 8, 48, 3, 3, 1, 1, True, True),        # few pixels, long K loop: split-K (atomic epilogue) path
     (4, 128, 16, 16, 200, 3, 3, 1, 1, True, False),
     (2, 40, 9, 9, 150, 1, 1, 2, 0, False, False),     # 1x1 stride 2: three of the four parity classes are empty
