@@ -62,7 +62,8 @@ CONV_CASES = [
     (2, 8, 16, 16, 16, 3, 3, 2, 1, False, False),
     (4, 64, 64, 64, 64, 3, 3, 1, 1, True, False),
     (3, 259, 33, 33, 64, 4, 4, 2, 2, True, False),
-    (2, 130, 12, 12, 3, 3, 3, 1, 1, True, False),
+    (2, 130, 12, 12, 3, 3, 3, 1, 1, True, False),     # <= 4 output channels: few-row forward and weight-gradient kernels
+    (2, 20, 11, 13, 1, 4, 4, 1, 2, True, False),      # one output channel, 4x4 pad 2 (the discriminator's last layer)
     (2, 3, 16, 16, 200, 3, 3, 1, 1, True, False),     # <= 4 input channels: data gradient as 1x1 GEMM + shifted-plane sum
     (2, 2, 10, 12, 72, 4, 4, 1, 2, False, False),     # same path, 4x4 filter with pad 2 (output one larger than the input)
     (2, 64, 8, 8, 48, 3, 3, 1, 1, True, True),        # few pixels, long K loop: split-K (atomic epilogue) path
