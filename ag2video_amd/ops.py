@@ -193,6 +193,7 @@ _WSINK = {}          # id(weight tensor) -> [weakref to it, sink tensor or None]
 _EXTRA_SINKS = os.environ.get('AG2V_NO_EXTRA_SINKS') is None
 _MERGE_SHARED_DGRAD = os.environ.get('AG2V_NO_MERGED_DGRAD') is None      # conv2d_shared_input: one data-gradient launch (A/B)
 _MERGE_SHARED_WGRAD = os.environ.get('AG2V_NO_MERGED_WGRAD') is None      # ... and one weight-gradient launch
+_SWAP_FEW_WGRAD = os.environ.get('AG2V_NO_SWAPPED_WGRAD') is None         # <= 4-row weight gradients with swapped operands
 _WSINK_CB = [None]   # graph-task id of the backward pass whose end-of-pass callback is queued (None: none; ids start at 0)
 
 
@@ -312,9 +313,24 @@ class _Conv2d(torch.autograd.Function):
                          st, shape=(N, C, H, W, K, R, stride))
         if ctx.needs_input_grad[1]:
             buf, acc, dw = _wsink_take(ctx.wkey, w)
-            _conv_launch(mr, 'ag2v_conv2d_wgrad_acc', _conv_label('wgrad', K, mr), flops,
-                         _ptr(dy), _ptr(x), _ptr(buf), N, C, H, W, K, R, S, stride, pad, acc, st,
-                         shape=(N, C, H, W, K, R, stride))
+            if (_SWAP_FEW_WGRAD and K <= 4 and stride == 1 and dy.shape[2] == H and dy.shape[3] == W and C >= 16 and R == S
+                    and 2 * pad == R - 1):
+                # <= 4 output channels (conv_img, the flow / mask heads), same-size convolution: as a GEMM this has 3 rows on a
+                # 32-row tile and gathers x once per tap column (0.38 ms at 8 x 64 x 256 x 256).  With the operands swapped --
+                # x takes dy's role (C dense rows, read once with 16-byte loads), dy is the gathered 3-channel tensor --
+                # the same launch computes dW'[c][m][r'][s'] = dW[m][c][R-1-r'][S-1-s'].
+                t = torch.empty((C, K, R, S), device=dy.device, dtype=torch.float32)
+                _conv_launch(mr, 'ag2v_conv2d_wgrad_acc', _conv_label('wgrad', C, mr), flops,
+                             _ptr(x), _ptr(dy), _ptr(t), N, K, H, W, C, R, S, 1, pad, 0, st, shape=(N, K, H, W, C, R, 1))
+                t = t.flip(2, 3).transpose(0, 1)
+                if acc:
+                    buf.add_(t)
+                else:
+                    buf.copy_(t)
+            else:
+                _conv_launch(mr, 'ag2v_conv2d_wgrad_acc', _conv_label('wgrad', K, mr), flops,
+                             _ptr(dy), _ptr(x), _ptr(buf), N, C, H, W, K, R, S, stride, pad, acc, st,
+                             shape=(N, C, H, W, K, R, stride))
         if has_bias and ctx.needs_input_grad[2]:
             bbuf, bacc, db = _wsink_take(ctx.bkey, ctx.w_alive[1])
             _lib.call('ag2v_channel_sum_acc', _ptr(dy), _ptr(bbuf), N, K, dy.shape[2] * dy.shape[3], bacc, st)
