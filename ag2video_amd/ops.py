@@ -836,6 +836,7 @@ def upsample2x(x):
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, relu):
+        w_in = w
         x, w, b = _c(x), _c(w), _c(b)
         _chk(x, w, b)
         M, K = x.shape
@@ -844,6 +845,9 @@ class _Linear(torch.autograd.Function):
         _lib.call('ag2v_gemm_f32', _ptr(x), _ptr(w), _ptr(b), _ptr(y), M, N, K, K, 1, 1, K, N, 1 if relu else 0, 0, _stream())
         ctx.save_for_backward(x, w, y if relu else None)
         ctx.cfg = (relu, b is not None)
+        # the graph nets run once per frame / time step: one weight-gradient buffer per backward pass (see _wsink_*)
+        ctx.lkey = _wsink_register(w_in) if (ctx.needs_input_grad[1] and _EXTRA_SINKS) else None
+        ctx.l_alive = w_in
         return y
 
     @staticmethod
@@ -863,8 +867,8 @@ class _Linear(torch.autograd.Function):
             dx = torch.empty_like(x)
             _lib.call('ag2v_gemm_f32', _ptr(g), _ptr(w), None, _ptr(dx), M, K, N, N, 1, K, 1, K, 0, 0, st)
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)
-            _lib.call('ag2v_gemm_f32', _ptr(g), _ptr(x), None, _ptr(dw), N, K, M, 1, N, K, 1, K, 0, 0, st)
+            buf, acc, dw = _wsink_take(ctx.lkey, w)
+            _lib.call('ag2v_gemm_f32', _ptr(g), _ptr(x), None, _ptr(buf), N, K, M, 1, N, K, 1, K, 0, acc, st)
         if has_b and ctx.needs_input_grad[2]:
             db = torch.empty(N, device=g.device, dtype=torch.float32)
             _lib.call('ag2v_col_sum', _ptr(g), _ptr(db), M, N, st)
