@@ -1,5 +1,8 @@
 #!/bin/bash
-# LDS bank-conflict counters + time of the igemm tile variants built by hand under tools/ubench (igemm_ns_<LDK>_<MF16>)
+# LDS bank-conflict counters + time of igemm tile variants.  Build them first (no-stamps builds of igemm_stamps.hip):
+#   for v in "40 true" "48 true" "40 false" "48 false"; do set -- $v; hipcc --offload-arch=gfx950 -O3 -std=c++17 -DNO_STAMPS \
+#       -DAG2V_LDK=$1 -DAG2V_TALL_MF16=$2 -o tools/ubench/igemm_ns_$1_$2 tools/ubench/igemm_stamps.hip; done
+# (AG2V_TALL_MF16 selects the MFMA shape of the table-path 256x128 tile; run the binaries without TAPK=1 to see it)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for v in 40_true 48_true 40_false 48_false; do
