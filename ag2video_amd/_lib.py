@@ -63,6 +63,7 @@ _SIGS = {
     'ag2v_adam_step': (c_int, [_P, _P, _P, _P, c_longlong, c_float, c_float, c_float, c_float, c_int, _P]),
     'ag2v_spectral_workspace_floats': (c_size_t, [c_int]),
     'ag2v_spectral_norm_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_float, c_int, _P, _P, _P, _P]),
+    'ag2v_spectral_norm_fwd_save': (c_int, [_P, _P, _P, c_int, c_int, c_float, c_int, _P, _P, _P, _P, _P, _P]),
     'ag2v_spectral_norm_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P]),
     'ag2v_spectral_norm_bwd_acc': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, c_int, _P, _P]),
 }

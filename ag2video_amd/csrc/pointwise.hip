@@ -106,8 +106,10 @@ __global__ __launch_bounds__(256) void sn_wv_kernel(const float* __restrict__ w,
 }
 // update_u: v[R] holds the un-normalised W^T u and wv[M] = W v of it: v <- v / max(|v|, eps), wv <- wv / max(|v|, eps) (W v is
 // linear in v), u <- normalize(wv).  Then sigma = u . wv.   (single workgroup)
+// u_used / v_used (nullable): copies of the vectors this call used, for the backward tape (the buffers keep advancing)
 __global__ __launch_bounds__(256) void sn_sigma_kernel(float* __restrict__ u, float* __restrict__ wv, float* __restrict__ v, int M,
-                                                       int R, float eps, int update_u, float* __restrict__ sigma) {
+                                                       int R, float eps, int update_u, float* __restrict__ sigma,
+                                                       float* __restrict__ u_used, float* __restrict__ v_used) {
     __shared__ float sh[4];
     if (update_u) {
         float q = 0.f;
@@ -128,6 +130,10 @@ __global__ __launch_bounds__(256) void sn_sigma_kernel(float* __restrict__ u, fl
     for (int i = threadIdx.x; i < M; i += 256) d += u[i] * wv[i];
     d = block_sum_256(d, sh);
     if (threadIdx.x == 0) sigma[0] = d;
+    if (u_used)
+        for (int i = threadIdx.x; i < M; i += 256) u_used[i] = u[i];
+    if (v_used)
+        for (int i = threadIdx.x; i < R; i += 256) v_used[i] = v[i];
 }
 __global__ __launch_bounds__(256) void sn_scale_kernel(const float* __restrict__ w, const float* __restrict__ sigma, float* __restrict__ wbar,
                                                        long long n) {
@@ -204,8 +210,15 @@ extern "C" size_t ag2v_spectral_workspace_floats(int M) { return (size_t)M + RED
 
 // W[M,R] (flattened conv weight).  power_iter != 0: one in-place power iteration on u[M], v[R] first (training mode).
 // Writes sigma[0] and W_bar = W / sigma.  workspace: ag2v_spectral_workspace_floats(M).
+extern "C" int ag2v_spectral_norm_fwd_save(const float* w, float* u, float* v, int M, int R, float eps, int power_iter, float* wbar,
+                                           float* sigma, float* u_used, float* v_used, float* workspace, void* stream);
 extern "C" int ag2v_spectral_norm_fwd(const float* w, float* u, float* v, int M, int R, float eps, int power_iter, float* wbar,
                                       float* sigma, float* workspace, void* stream) {
+    return ag2v_spectral_norm_fwd_save(w, u, v, M, R, eps, power_iter, wbar, sigma, nullptr, nullptr, workspace, stream);
+}
+// u_used[M], v_used[R] (nullable): the vectors behind this call's sigma, written by the same launches (for the backward tape)
+extern "C" int ag2v_spectral_norm_fwd_save(const float* w, float* u, float* v, int M, int R, float eps, int power_iter, float* wbar,
+                                           float* sigma, float* u_used, float* v_used, float* workspace, void* stream) {
     if (!w || !u || !v || !wbar || !sigma || !workspace || M <= 0 || R <= 0) return AG2V_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     float* wv = workspace;
@@ -219,7 +232,7 @@ extern "C" int ag2v_spectral_norm_fwd(const float* w, float* u, float* v, int M,
         hipLaunchKernelGGL(sn_wtu_kernel, dim3(rb, msplit), dim3(256), 0, st, w, u, v, M, R, mchunk);
     }
     hipLaunchKernelGGL(sn_wv_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, w, v, wv, M, R);
-    hipLaunchKernelGGL(sn_sigma_kernel, dim3(1), dim3(256), 0, st, u, wv, v, M, R, eps, power_iter, sigma);
+    hipLaunchKernelGGL(sn_sigma_kernel, dim3(1), dim3(256), 0, st, u, wv, v, M, R, eps, power_iter, sigma, u_used, v_used);
     const long long n = (long long)M * R;
     hipLaunchKernelGGL(sn_scale_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, w, sigma, wbar, n);
     AG2V_CHECK_LAUNCH();

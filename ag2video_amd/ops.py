@@ -475,10 +475,13 @@ class _SpectralWeight(torch.autograd.Function):
         wbar = torch.empty_like(w)
         sigma = torch.empty(1, device=w.device, dtype=torch.float32)
         ws = torch.empty(_lib.query('ag2v_spectral_workspace_floats', M), device=w.device, dtype=torch.float32)
-        _lib.call('ag2v_spectral_norm_fwd', _ptr(w), _ptr(u), _ptr(v), M, R, float(eps), 1 if training else 0,
-                  _ptr(wbar), _ptr(sigma), _ptr(ws), _stream())
-        # the buffers keep advancing in later calls; the tape needs the vectors this call used
-        ctx.save_for_backward(wbar, u.clone(), v.clone(), sigma)
+        # the buffers keep advancing in later calls; the tape needs the vectors this call used (written by the same launches)
+        need = ctx.needs_input_grad[0]
+        uv = torch.empty(M + R, device=w.device, dtype=torch.float32) if need else None
+        u_used, v_used = (uv[:M], uv[M:]) if need else (None, None)
+        _lib.call('ag2v_spectral_norm_fwd_save', _ptr(w), _ptr(u), _ptr(v), M, R, float(eps), 1 if training else 0,
+                  _ptr(wbar), _ptr(sigma), _ptr(u_used), _ptr(v_used), _ptr(ws), _stream())
+        ctx.save_for_backward(wbar, u_used, v_used, sigma)
         # weight_orig is used by every frame pass of a step: one gradient buffer per backward pass (see _wsink_*)
         ctx.okey = _wsink_register(w_orig) if (ctx.needs_input_grad[0] and _EXTRA_SINKS) else None
         ctx.o_alive = w_orig

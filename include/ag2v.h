@@ -155,6 +155,9 @@ int ag2v_reduce_bwd(int op, const float* a, const float* b, long long n, const f
 size_t ag2v_spectral_workspace_floats(int M);
 int ag2v_spectral_norm_fwd(const float* w, float* u, float* v, int M, int R, float eps, int power_iter, float* wbar,
                            float* sigma, float* workspace, void* stream);
+/* as above, also writing copies of the u[M] / v[R] this call used (nullable) for the backward tape */
+int ag2v_spectral_norm_fwd_save(const float* w, float* u, float* v, int M, int R, float eps, int power_iter, float* wbar,
+                                float* sigma, float* u_used, float* v_used, float* workspace, void* stream);
 int ag2v_spectral_norm_bwd(const float* dwbar, const float* wbar, const float* u, const float* v, const float* sigma, int M,
                            int R, float* dw, float* workspace, void* stream);
 /* accumulate != 0: dw += ... (weight_orig collects the gradients of all forward calls of a step in one buffer) */
