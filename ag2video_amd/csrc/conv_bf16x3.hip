@@ -28,7 +28,7 @@
 #ifndef AG2V_WIDE_MF16
 #define AG2V_WIDE_MF16 false
 #endif
-template <int BM, int BN, int CWM, int CWN, int NPW, bool MF16, bool TAPK>
+template <int BM, int BN, int CWM, int CWN, int NPW, bool MF16, bool TAPK, bool B4>
 __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_kernel(ConvArgs p) {
     constexpr int BK = 32, LDK = AG2V_LDK, NP = NPW * 64;       // NP producer threads
     constexpr int TM = BM / CWM / 32, TN = BN / CWN / 32;  // consumer wave tile in 32x32 MFMA tiles
@@ -37,10 +37,18 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
     constexpr int ACOLS = BM / (NP / AP), BCOLS = BN / (NP / BP);   // columns per producer thread (1 or 2 when the tile side is 256)
     static_assert(BM % (CWM * 32) == 0 && BN % (CWN * 32) == 0, "consumer wave tiles");
     static_assert(AK % 8 == 0 && BKK % 8 == 0, "16-byte LDS stores");
+    // B4 (tap-major, stride 1, OW % 4 == 0): a producer thread owns a QUAD of 4 consecutive pixels and KPT channels of the K-tile
+    // and fetches each channel with one 16-byte load (a dwordx4 wave-load costs the texture addresser ~20 cycles, four dword
+    // ones ~40: the gathered operand of the 128 x 256 tile was 16 of a thread's 18 loads).  Pixel p lives in LDS row
+    // (p & 3) * GR + (p >> 2): a wave's stores for quad element j go to consecutive rows, and GR = BN/4 + 4 keeps the consumers'
+    // 16-lane fragment reads on distinct banks (rows 4 g + t, g < 4, t < 4 of an 80-byte pitch).
+    constexpr int QN = BN / 4, KP = NP / QN, KPT = BK / KP, GR = QN + 4;
+    constexpr int BROWS = B4 ? 4 * GR : BN;
+    static_assert(!B4 || (TAPK && BCOLS == 1 && 4 * KPT == BKK && (KPT == 2 || KPT == 4) && !MF16), "quad loads: tap-major 32x32x16 tiles");
     __shared__ __attribute__((aligned(16))) unsigned short Ahi[2][BM * LDK];
     __shared__ __attribute__((aligned(16))) unsigned short Alo[2][BM * LDK];
-    __shared__ __attribute__((aligned(16))) unsigned short Bhi[2][BN * LDK];
-    __shared__ __attribute__((aligned(16))) unsigned short Blo[2][BN * LDK];
+    __shared__ __attribute__((aligned(16))) unsigned short Bhi[2][BROWS * LDK];
+    __shared__ __attribute__((aligned(16))) unsigned short Blo[2][BROWS * LDK];
     __shared__ int2 tab[TAPK ? 1 : 4][BK];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -84,6 +92,23 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
                     for (int s2 = 0; s2 < p.S; ++s2)
                         if ((unsigned)(y0 + r) < (unsigned)p.H && (unsigned)(x0 + s2) < (unsigned)p.W) vmask[c] |= 1u << (r * p.S + s2);
                 bbase[c] = n_img * p.C * SHW + (y0 * p.W + x0);
+            }
+        }
+        // B4: quad state (pixels 4 quad .. 4 quad + 3 of the tile are in one output row; stride 1)
+        const int quad = ptid % QN, kpart = ptid / QN;
+        int qbase = 0, qx0 = 0;
+        unsigned qrmask = 0;
+        if constexpr (B4) {
+            const int pix = n0 + 4 * quad;
+            if (pix < p.NG) {
+                const int n_img = pix / (p.OH * p.OW);
+                const int prem = pix - n_img * (p.OH * p.OW);
+                const int py = prem / p.OW, px = prem - py * p.OW;
+                const int y0 = py - p.pad;
+                qx0 = px - p.pad_w;
+                for (int r = 0; r < p.R; ++r)
+                    if ((unsigned)(y0 + r) < (unsigned)p.H) qrmask |= 1u << r;
+                qbase = (n_img * p.C + kpart * KPT) * SHW + y0 * p.W + qx0;
             }
         }
         auto build_tab = [&](int kt) {
@@ -136,7 +161,7 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
             f_c = ch * BK;
         }
         const int apart_s = (wave * 64 / (BM / ACOLS)) % AP, bpart_s = (wave * 64 / (BN / BCOLS)) % BP;   // = apart, bpart (wave-uniform)
-        auto fetch_tap = [&](unsigned (&ra)[ACOLS][AK], float (&rb)[BCOLS][BKK]) {
+        auto fetch_tap = [&](unsigned (&ra)[ACOLS][AK], float (&rb)[BCOLS][BKK], unsigned& emask) {
             const bool live = f_kt < nk_all;
             const unsigned c4 = (unsigned)SHW * 4u;
             // A: weights packed [KG/4][M][4] (four consecutive k of a row are 16 contiguous bytes; pack_fwd_tap_kernel /
@@ -156,14 +181,44 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
                 }
             }
 
-            const unsigned sb = (unsigned)(f_c + BKK * bpart_s) * c4;
-            const int toff = f_r * p.W + f_s, tbit = f_r * p.S + f_s;
+            if constexpr (B4) {
+                // rb[0][4 i + j] = channel (f_c + kpart KPT + i), pixel j of the quad.  Elements whose tap column falls outside
+                // [0, W) are cleared in stash (emask); a tap row outside [0, H) invalidates the whole quad.
+                const bool rowok = live & (((qrmask >> f_r) & 1u) != 0u);
+                const int o = qbase + f_r * p.W + f_s;            // element offset without the chunk term (soffset)
+                const int ix0 = qx0 + f_s;
+                const unsigned sb = (unsigned)f_c * c4;
+                emask = 0;
 #pragma unroll
-            for (int c = 0; c < BCOLS; ++c) {
-                const unsigned vo = (live & (((vmask[c] >> tbit) & 1u) != 0u)) ? (unsigned)(bbase[c] + toff) * 4u : kOut;
+                for (int j = 0; j < 4; ++j) emask |= ((unsigned)(ix0 + j) >= (unsigned)p.W) ? (1u << j) : 0u;
+                if (__builtin_expect(rowok & (o < 0), 0)) {
+                    // the quad starts before the tensor's first element (image 0, channel part 0, row 0, x < 0): a negative
+                    // voffset is out of range whatever soffset adds, so this one quad of a launch takes element loads
 #pragma unroll
-                for (int i = 0; i < BKK; ++i)
-                    rb[c][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, vo, sb + i * c4, 0));
+                    for (int i = 0; i < KPT; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            rb[0][4 * i + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                brs, (o + j >= 0) ? (unsigned)(o + j) * 4u : kOut, sb + i * c4, 0));
+                } else {
+                    const unsigned vo = rowok ? (unsigned)o * 4u : kOut;
+#pragma unroll
+                    for (int i = 0; i < KPT; ++i) {
+                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(brs, vo, sb + i * c4, 0);
+                        rb[0][4 * i] = __uint_as_float(v[0]); rb[0][4 * i + 1] = __uint_as_float(v[1]);
+                        rb[0][4 * i + 2] = __uint_as_float(v[2]); rb[0][4 * i + 3] = __uint_as_float(v[3]);
+                    }
+                }
+            } else {
+                const unsigned sb = (unsigned)(f_c + BKK * bpart_s) * c4;
+                const int toff = f_r * p.W + f_s, tbit = f_r * p.S + f_s;
+#pragma unroll
+                for (int c = 0; c < BCOLS; ++c) {
+                    const unsigned vo = (live & (((vmask[c] >> tbit) & 1u) != 0u)) ? (unsigned)(bbase[c] + toff) * 4u : kOut;
+#pragma unroll
+                    for (int i = 0; i < BKK; ++i)
+                        rb[c][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, vo, sb + i * c4, 0));
+                }
             }
             ++f_kt;
             if (++f_s == p.S) {
@@ -171,7 +226,7 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
                 if (++f_r == p.R) { f_r = 0; f_c += BK; }
             }
         };
-        auto stash = [&](int buf, const unsigned (&ra)[ACOLS][AK], const float (&rb)[BCOLS][BKK]) {
+        auto stash = [&](int buf, const unsigned (&ra)[ACOLS][AK], float (&rb)[BCOLS][BKK], unsigned emask) {
 #pragma unroll
             for (int c = 0; c < ACOLS; ++c)
 #pragma unroll
@@ -186,6 +241,31 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
                     *reinterpret_cast<uint4*>(&Ahi[buf][off]) = make_uint4(h[0], h[1], h[2], h[3]);
                     *reinterpret_cast<uint4*>(&Alo[buf][off]) = make_uint4(l[0], l[1], l[2], l[3]);
                 }
+            if constexpr (B4) {
+                if (emask) {     // border quads only
+#pragma unroll
+                    for (int i = 0; i < KPT; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if ((emask >> j) & 1u) rb[0][4 * i + j] = 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int off = (j * GR + quad) * LDK + kpart * KPT;
+                    if constexpr (KPT == 4) {
+                        unsigned h0, l0, h1, l1;
+                        split2(rb[0][j], rb[0][4 + j], h0, l0);
+                        split2(rb[0][8 + j], rb[0][12 + j], h1, l1);
+                        *reinterpret_cast<uint2*>(&Bhi[buf][off]) = make_uint2(h0, h1);
+                        *reinterpret_cast<uint2*>(&Blo[buf][off]) = make_uint2(l0, l1);
+                    } else {
+                        unsigned h0, l0;
+                        split2(rb[0][j], rb[0][4 + j], h0, l0);
+                        *reinterpret_cast<unsigned*>(&Bhi[buf][off]) = h0;
+                        *reinterpret_cast<unsigned*>(&Blo[buf][off]) = l0;
+                    }
+                }
+            } else {
 #pragma unroll
             for (int c = 0; c < BCOLS; ++c)
 #pragma unroll
@@ -204,6 +284,7 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
                     *reinterpret_cast<uint4*>(&Bhi[buf][off]) = make_uint4(h[0], h[1], h[2], h[3]);
                     *reinterpret_cast<uint4*>(&Blo[buf][off]) = make_uint4(l[0], l[1], l[2], l[3]);
                 }
+            }
         };
 
         unsigned ra0[ACOLS][AK], ra1[ACOLS][AK];
@@ -220,9 +301,10 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
             build_tab(kt0 + 3);
         }
         __syncthreads();
-        if constexpr (TAPK) fetch_tap(ra0, rb0); else fetch(kt0, ra0, rb0);
+        unsigned em0 = 0, em1 = 0;       // B4: border-element masks of the two register sets
+        if constexpr (TAPK) fetch_tap(ra0, rb0, em0); else fetch(kt0, ra0, rb0);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (TAPK) fetch_tap(ra1, rb1); else fetch(kt0 + 1, ra1, rb1);
+        if constexpr (TAPK) fetch_tap(ra1, rb1, em1); else fetch(kt0 + 1, ra1, rb1);
         __builtin_amdgcn_sched_barrier(0);
 #ifdef AG2V_STAMPS
         unsigned long long sa[3] = {0, 0, 0};
@@ -236,11 +318,11 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
         for (int kt = kt0; kt < nk; kt += 2) {
             STAMP(c0)
 #ifndef AG2V_DIAG_NO_PRODUCER_WORK      // tools/ubench/igemm_stamps.hip: consumers alone / producers alone
-            stash(0, ra0, rb0);
+            stash(0, ra0, rb0, em0);
 #endif
             STAMP(c1)
 #ifndef AG2V_DIAG_NO_PRODUCER_WORK
-            if constexpr (TAPK) fetch_tap(ra0, rb0);
+            if constexpr (TAPK) fetch_tap(ra0, rb0, em0);
             else { build_tab(kt + 4); fetch(kt + 2, ra0, rb0); }
 #endif
             STAMP(c2)
@@ -251,11 +333,11 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
 #endif
             STAMP(d0)
 #ifndef AG2V_DIAG_NO_PRODUCER_WORK
-            stash(1, ra1, rb1);
+            stash(1, ra1, rb1, em1);
 #endif
             STAMP(d1)
 #ifndef AG2V_DIAG_NO_PRODUCER_WORK
-            if constexpr (TAPK) fetch_tap(ra1, rb1);
+            if constexpr (TAPK) fetch_tap(ra1, rb1, em1);
             else { build_tab(kt + 5); fetch(kt + 3, ra1, rb1); }
 #endif
             STAMP(d2)
@@ -304,7 +386,8 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
             bf16x8 bhi[EN], blo[EN];
 #pragma unroll
             for (int j = 0; j < EN; ++j) {
-                const int o = (wn0 + j * ER + fr) * LDK + ks * 16 + 8 * fq;
+                const int pix = wn0 + j * ER + fr;
+                const int o = (B4 ? (pix & 3) * GR + (pix >> 2) : pix) * LDK + ks * 16 + 8 * fq;
                 bhi[j] = *reinterpret_cast<const bf16x8*>(&Bhi[buf][o]);
                 blo[j] = *reinterpret_cast<const bf16x8*>(&Blo[buf][o]);
             }
@@ -887,18 +970,27 @@ int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed) {
         set_last_conv_kernel("conv_igemm_bf16x3_ws_kernel<" AG2V_STR(__VA_ARGS__) ">");                \
         hipLaunchKernelGGL((conv_igemm_bf16x3_ws_kernel<__VA_ARGS__>), grid, dim3(1024), 0, st, a);    \
     } while (0)
+    // quad loads of the gathered operand: stride-1 launches whose pixel rows are whole quads (AG2V_NO_B4: A/B aid).  Isolated,
+    // sustained: 128 x 256 tile 389 -> 407 TF at 144 K-tiles (with the old LDS stores the same loads gave 481: the eight 8-byte
+    // stores per thread cost most of the gain), 256 x 128 tile 381 -> 367 TF (its gathered operand is 8 of 12 loads only), so the
+    // 256-row tile keeps dword loads unless AG2V_B4_TALL is set.
+    static const bool b4_off = getenv("AG2V_NO_B4") != nullptr, b4_tall = getenv("AG2V_B4_TALL") != nullptr;
+    const bool b4 = a.tap_major && !b4_off && a.stride == 1 && a.OW % 4 == 0 && a.W >= 4 && (a.OH * a.OW) % 4 == 0 &&
+                    (!tall || b4_tall);
     if (tall) {
         // 16x16x32 MFMAs (+3..6 % with the table-path producers) read their LDS operands with 36 % bank-conflict cycles
         // (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, tools/ubench/pmc_variants.sh; 32x32x16: 0 %) and leave the prioritised
         // MFMA waves' partners 8 instead of 24 free issue cycles per MFMA: with the TAPK producers the 32x32x16 shape is
         // 0.6 % of a c3 step faster (AG2V_TALL16 selects the other one for A/B runs).
         static const bool tall16 = getenv("AG2V_TALL16") != nullptr;
-        if (a.tap_major && !tall16) AG2V_LAUNCH_IGEMM(256, 128, 4, 2, 8, false, true);
-        else if (a.tap_major) AG2V_LAUNCH_IGEMM(256, 128, 4, 2, 8, AG2V_TALL_MF16, true);
-        else AG2V_LAUNCH_IGEMM(256, 128, 4, 2, 8, AG2V_TALL_MF16, false);
+        if (b4) AG2V_LAUNCH_IGEMM(256, 128, 4, 2, 8, false, true, true);
+        else if (a.tap_major && !tall16) AG2V_LAUNCH_IGEMM(256, 128, 4, 2, 8, false, true, false);
+        else if (a.tap_major) AG2V_LAUNCH_IGEMM(256, 128, 4, 2, 8, AG2V_TALL_MF16, true, false);
+        else AG2V_LAUNCH_IGEMM(256, 128, 4, 2, 8, AG2V_TALL_MF16, false, false);
     } else {
-        if (a.tap_major) AG2V_LAUNCH_IGEMM(128, 256, 2, 4, 8, AG2V_WIDE_MF16, true);
-        else AG2V_LAUNCH_IGEMM(128, 256, 2, 4, 8, false, false);
+        if (b4) AG2V_LAUNCH_IGEMM(128, 256, 2, 4, 8, false, true, true);
+        else if (a.tap_major) AG2V_LAUNCH_IGEMM(128, 256, 2, 4, 8, AG2V_WIDE_MF16, true, false);
+        else AG2V_LAUNCH_IGEMM(128, 256, 2, 4, 8, false, false, false);
     }
 #undef AG2V_LAUNCH_IGEMM
     AG2V_CHECK_LAUNCH();

@@ -75,6 +75,11 @@ CONV_CASES = [
     (2, 12, 7, 15, 130, 4, 4, 1, 2, False, False),    # pad 2: two leading / one trailing element of a border run outside
     (3, 16, 8, 8, 256, 1, 1, 1, 0, False, False),     # 1x1
     (2, 10, 12, 10, 128, 3, 3, 1, 0, True, False),    # pad 0, OW = 8 < W
+    # gathered channels % 32 == 0, stride 1, OW % 4 == 0: tap-major producers with quad (16-byte) loads of the gathered operand
+    (2, 64, 12, 16, 136, 3, 3, 1, 1, True, False),    # forward on the 128 x 256 tile
+    (2, 128, 10, 12, 160, 3, 3, 1, 1, False, True),   # forward and data gradient (160 gathered channels)
+    (2, 32, 9, 11, 128, 4, 4, 1, 2, True, False),     # 4x4, pad 2: two border elements per edge quad
+    (1, 96, 8, 8, 256, 3, 3, 1, 1, False, False),     # 256-row tile, the quad before the tensor's first element (x = -1 at row 0)
     (1, 5, 40, 40, 192, 3, 3, 1, 1, False, True),     # pixel count not a multiple of the K-tile of a split
     # <= 4 output rows, stride 1: the few-row FMA kernel (forward here; data gradient for <= 4 input channels)
     (3, 20, 9, 9, 1, 4, 4, 1, 2, True, False),        # the discriminators' last layer: OW = 10, not a multiple of 4
