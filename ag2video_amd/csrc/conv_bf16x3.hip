@@ -44,7 +44,7 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
     // 16-lane fragment reads on distinct banks (rows 4 g + t, g < 4, t < 4 of an 80-byte pitch).
     constexpr int QN = BN / 4, KP = NP / QN, KPT = BK / KP, GR = QN + 4;
     constexpr int BROWS = B4 ? 4 * GR : BN;
-    static_assert(!B4 || (TAPK && BCOLS == 1 && 4 * KPT == BKK && (KPT == 2 || KPT == 4) && !MF16), "quad loads: tap-major 32x32x16 tiles");
+    static_assert(!B4 || (TAPK && BCOLS == 1 && KPT == 4 && BKK == 16 && QN == 64 && NPW == 8 && !MF16), "quad loads: the tap-major 128 x 256 tile");
     __shared__ __attribute__((aligned(16))) unsigned short Ahi[2][BM * LDK];
     __shared__ __attribute__((aligned(16))) unsigned short Alo[2][BM * LDK];
     __shared__ __attribute__((aligned(16))) unsigned short Bhi[2][BROWS * LDK];
@@ -95,9 +95,9 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
             }
         }
         // B4: quad state (pixels 4 quad .. 4 quad + 3 of the tile are in one output row; stride 1)
-        const int quad = ptid % QN, kpart = ptid / QN;
+        const int quad = ptid % QN, kpart = ptid / QN;      // a wave = the 64 quads of one channel part
         int qbase = 0, qx0 = 0;
-        unsigned qrmask = 0;
+        unsigned qrmask = 0, qemask = 0;       // qemask: nibble s = the quad elements whose column x0 + s + j is outside [0, W)
         if constexpr (B4) {
             const int pix = n0 + 4 * quad;
             if (pix < p.NG) {
@@ -109,6 +109,9 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
                 for (int r = 0; r < p.R; ++r)
                     if ((unsigned)(y0 + r) < (unsigned)p.H) qrmask |= 1u << r;
                 qbase = (n_img * p.C + kpart * KPT) * SHW + y0 * p.W + qx0;
+                for (int t = 0; t < p.S; ++t)
+                    for (int j = 0; j < 4; ++j)
+                        if ((unsigned)(qx0 + t + j) >= (unsigned)p.W) qemask |= 1u << (4 * t + j);
             }
         }
         auto build_tab = [&](int kt) {
@@ -186,11 +189,8 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
                 // [0, W) are cleared in stash (emask); a tap row outside [0, H) invalidates the whole quad.
                 const bool rowok = live & (((qrmask >> f_r) & 1u) != 0u);
                 const int o = qbase + f_r * p.W + f_s;            // element offset without the chunk term (soffset)
-                const int ix0 = qx0 + f_s;
                 const unsigned sb = (unsigned)f_c * c4;
-                emask = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) emask |= ((unsigned)(ix0 + j) >= (unsigned)p.W) ? (1u << j) : 0u;
+                emask = (qemask >> (4 * f_s)) & 15u;
                 if (__builtin_expect(rowok & (o < 0), 0)) {
                     // the quad starts before the tensor's first element (image 0, channel part 0, row 0, x < 0): a negative
                     // voffset is out of range whatever soffset adds, so this one quad of a launch takes element loads
@@ -249,21 +249,17 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
                         for (int j = 0; j < 4; ++j)
                             if ((emask >> j) & 1u) rb[0][4 * i + j] = 0.f;
                 }
+                // 8-byte stores (4 channels of one pixel).  Exchanging pixel halves between lanes l / l + 32 (v_permlane32_swap) to
+                // keep 16-byte stores removes the 2-way bank conflicts of these (22 % of LDS cycles -> 0) but its 8 VALU
+                // instructions cost more (-2 % against dword loads; producer VALU beside prioritised MFMAs ~ 1 % each).
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int off = (j * GR + quad) * LDK + kpart * KPT;
-                    if constexpr (KPT == 4) {
-                        unsigned h0, l0, h1, l1;
-                        split2(rb[0][j], rb[0][4 + j], h0, l0);
-                        split2(rb[0][8 + j], rb[0][12 + j], h1, l1);
-                        *reinterpret_cast<uint2*>(&Bhi[buf][off]) = make_uint2(h0, h1);
-                        *reinterpret_cast<uint2*>(&Blo[buf][off]) = make_uint2(l0, l1);
-                    } else {
-                        unsigned h0, l0;
-                        split2(rb[0][j], rb[0][4 + j], h0, l0);
-                        *reinterpret_cast<unsigned*>(&Bhi[buf][off]) = h0;
-                        *reinterpret_cast<unsigned*>(&Blo[buf][off]) = l0;
-                    }
+                    unsigned h0, l0, h1, l1;
+                    split2(rb[0][j], rb[0][4 + j], h0, l0);
+                    split2(rb[0][8 + j], rb[0][12 + j], h1, l1);
+                    *reinterpret_cast<uint2*>(&Bhi[buf][off]) = make_uint2(h0, h1);
+                    *reinterpret_cast<uint2*>(&Blo[buf][off]) = make_uint2(l0, l1);
                 }
             } else {
 #pragma unroll
@@ -970,21 +966,17 @@ int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed) {
         set_last_conv_kernel("conv_igemm_bf16x3_ws_kernel<" AG2V_STR(__VA_ARGS__) ">");                \
         hipLaunchKernelGGL((conv_igemm_bf16x3_ws_kernel<__VA_ARGS__>), grid, dim3(1024), 0, st, a);    \
     } while (0)
-    // quad loads of the gathered operand: stride-1 launches whose pixel rows are whole quads (AG2V_NO_B4: A/B aid).  Isolated,
-    // sustained: 128 x 256 tile 389 -> 407 TF at 144 K-tiles (with the old LDS stores the same loads gave 481: the eight 8-byte
-    // stores per thread cost most of the gain), 256 x 128 tile 381 -> 367 TF (its gathered operand is 8 of 12 loads only), so the
-    // 256-row tile keeps dword loads unless AG2V_B4_TALL is set.
-    static const bool b4_off = getenv("AG2V_NO_B4") != nullptr, b4_tall = getenv("AG2V_B4_TALL") != nullptr;
-    const bool b4 = a.tap_major && !b4_off && a.stride == 1 && a.OW % 4 == 0 && a.W >= 4 && (a.OH * a.OW) % 4 == 0 &&
-                    (!tall || b4_tall);
+    // quad loads of the gathered operand on the 128 x 256 tile: stride-1 launches whose pixel rows are whole quads
+    // (AG2V_NO_B4: A/B aid).  The 256 x 128 tile (8 of its 12 loads gather) was 4 % slower with them.
+    static const bool b4_off = getenv("AG2V_NO_B4") != nullptr;
+    const bool b4 = a.tap_major && !b4_off && !tall && a.stride == 1 && a.OW % 4 == 0 && a.W >= 4 && (a.OH * a.OW) % 4 == 0;
     if (tall) {
         // 16x16x32 MFMAs (+3..6 % with the table-path producers) read their LDS operands with 36 % bank-conflict cycles
         // (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, tools/ubench/pmc_variants.sh; 32x32x16: 0 %) and leave the prioritised
         // MFMA waves' partners 8 instead of 24 free issue cycles per MFMA: with the TAPK producers the 32x32x16 shape is
         // 0.6 % of a c3 step faster (AG2V_TALL16 selects the other one for A/B runs).
         static const bool tall16 = getenv("AG2V_TALL16") != nullptr;
-        if (b4) AG2V_LAUNCH_IGEMM(256, 128, 4, 2, 8, false, true, true);
-        else if (a.tap_major && !tall16) AG2V_LAUNCH_IGEMM(256, 128, 4, 2, 8, false, true, false);
+        if (a.tap_major && !tall16) AG2V_LAUNCH_IGEMM(256, 128, 4, 2, 8, false, true, false);
         else if (a.tap_major) AG2V_LAUNCH_IGEMM(256, 128, 4, 2, 8, AG2V_TALL_MF16, true, false);
         else AG2V_LAUNCH_IGEMM(256, 128, 4, 2, 8, AG2V_TALL_MF16, false, false);
     } else {
