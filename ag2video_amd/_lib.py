@@ -8,7 +8,7 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libag2v.so')
+LIB_PATH = os.environ.get('AG2V_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libag2v.so')   # AG2V_LIB_PATH: another build, for A/B runs
 
 _P = c_void_p
 _SIGS = {

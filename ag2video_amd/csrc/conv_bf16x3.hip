@@ -167,20 +167,25 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
         auto fetch_tap = [&](unsigned (&ra)[ACOLS][AK], float (&rb)[BCOLS][BKK], unsigned& emask) {
             const bool live = f_kt < nk_all;
             const unsigned c4 = (unsigned)SHW * 4u;
-            // A: weights packed [KG/4][M][4] (four consecutive k of a row are 16 contiguous bytes; pack_fwd_tap_kernel /
-            // pack_dgrad_tap_kernel): one 16-byte load per 4 k.  The CU's texture addresser takes ~10 cycles per dword
-            // wave-load and ~20 per dwordx4 one; with dword loads the second producer wave of each SIMD spent 2 000 of a
-            // K-tile's 3 000 cycles in the load-issue phase (per-wave clocks, tools/ubench/igemm_stamps.hip PER_WAVE=1).
+            // A: weights as two bf16 planes, hi then lo, each [KG/8][M][8] (eight consecutive k of a row are 16 contiguous bytes;
+            // pack_fwd_tap_kernel / pack_dgrad_tap_kernel): one 16-byte load per plane and 8 k, stored to LDS as loaded (no
+            // v_perm: producer VALU beside the prioritised MFMAs costs ~1 % of the 128 x 256 tile's time per instruction).
+            // The CU's texture addresser takes ~10 cycles per dword wave-load and ~20 per dwordx4 one; with dword loads the
+            // second producer wave of each SIMD spent 2 000 of a K-tile's 3 000 cycles in the load-issue phase (per-wave
+            // clocks, tools/ubench/igemm_stamps.hip PER_WAVE=1).
             const unsigned m16 = (unsigned)p.M * 16u;
-            const unsigned sa = (unsigned)((f_kt * BK + AK * apart_s) >> 2) * m16;
+            const unsigned sa = (unsigned)((f_kt * BK + AK * apart_s) >> 3) * m16;
+            const unsigned lo_plane = (unsigned)(p.KG >> 3) * m16;
 #pragma unroll
             for (int c = 0; c < ACOLS; ++c) {
                 const int m = m0 + acol0 + c * (BM / ACOLS);
                 const unsigned vo = (live & (m < p.M)) ? (unsigned)m * 16u : kOut;
 #pragma unroll
-                for (int i = 0; i < AK / 4; ++i) {
-                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ars, vo, sa + i * m16, 0);
-                    ra[c][4 * i] = v[0]; ra[c][4 * i + 1] = v[1]; ra[c][4 * i + 2] = v[2]; ra[c][4 * i + 3] = v[3];
+                for (int i = 0; i < AK / 8; ++i) {
+                    const u32x4 vh = __builtin_amdgcn_raw_buffer_load_b128(ars, vo, sa + i * m16, 0);
+                    const u32x4 vl = __builtin_amdgcn_raw_buffer_load_b128(ars, vo, sa + i * m16 + lo_plane, 0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { ra[c][8 * i + e] = vh[e]; ra[c][8 * i + 4 + e] = vl[e]; }
                 }
             }
 
@@ -234,8 +239,13 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
                     unsigned h[4], l[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        h[i] = __builtin_amdgcn_perm(ra[c][8 * g + 2 * i + 1], ra[c][8 * g + 2 * i], 0x07060302u);
-                        l[i] = __builtin_amdgcn_perm(ra[c][8 * g + 2 * i + 1], ra[c][8 * g + 2 * i], 0x05040100u);
+                        if constexpr (TAPK) {       // hi / lo planes: the words are LDS images already
+                            h[i] = ra[c][8 * g + i];
+                            l[i] = ra[c][8 * g + 4 + i];
+                        } else {
+                            h[i] = __builtin_amdgcn_perm(ra[c][8 * g + 2 * i + 1], ra[c][8 * g + 2 * i], 0x07060302u);
+                            l[i] = __builtin_amdgcn_perm(ra[c][8 * g + 2 * i + 1], ra[c][8 * g + 2 * i], 0x05040100u);
+                        }
                     }
                     const int off = (acol0 + c * (BM / ACOLS)) * LDK + AK * apart + 8 * g;
                     *reinterpret_cast<uint4*>(&Ahi[buf][off]) = make_uint4(h[0], h[1], h[2], h[3]);

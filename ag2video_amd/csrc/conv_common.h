@@ -3,7 +3,7 @@
 #include "common.h"
 
 struct ConvArgs {
-    const float* a_src;     // igemm: At [KG][M] (k-major weights; tap_major: [KG/4][M][4]) | wgrad: dy
+    const float* a_src;     // igemm: At [KG][M] (k-major weights; tap_major: bf16 hi / lo planes [KG/8][M][8]) | wgrad: dy
     const float* b_src;     // gathered tensor [N, C, H, W]
     float* out;
     const float* bias;      // [M] or null (igemm)
@@ -19,8 +19,8 @@ struct ConvArgs {
     int splitk, kchunk;     // igemm: K-range splits (grid.y) in K-tiles; wgrad: pixel-range splits, pixels per split
     const float* mask;      // igemm epilogue: out = (mask > 0) ? out : 0 (same shape as out) -- the ReLU backward of the conv's input
     int relu;               // igemm epilogue: out = max(out, 0)
-    int tap_major;          // igemm bf16x3: a_src rows are ordered by tap_major_row() instead of kg = c * R*S + r*S + s and four
-                            // consecutive rows are interleaved per output row ([KG/4][M][4]); set by igemm_tap_major() for
+    int tap_major;          // igemm bf16x3: a_src rows are ordered by tap_major_row() instead of kg = c * R*S + r*S + s and stored
+                            // as two bf16 planes, eight consecutive rows per output row ([KG/8][M][8]); set by igemm_tap_major() for
                             // C % 32 == 0 (every 32-wide K-tile then has one filter tap)
     int diag_noprio;        // tuning aid: the MFMA waves of the wgrad v kernels keep the default issue priority
     int accumulate;         // wgrad: add onto the existing dW (no zeroing; atomics) -- the weight is used by several forward calls

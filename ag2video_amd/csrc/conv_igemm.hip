@@ -324,11 +324,23 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     }
 }
 
-// Forward weights in the tap-major packed layout of the bf16x3 implicit GEMM (ConvArgs::tap_major):
-//   at[((tap_major_row(c, r, s) >> 2) * M + m) * 4 + (c & 3)] = pack_split(w[m][c][r][s]),   C % 32 == 0
+// Forward weights in the tap-major layout of the bf16x3 implicit GEMM (ConvArgs::tap_major), C % 32 == 0: two bf16 planes
+// (hi = bf16(w), lo = bf16(w - hi)), the lo plane KG * M bf16 behind the hi plane, each [KG/8][M][8]:
+//   plane[((tap_major_row(c, r, s) >> 3) * M + m) * 8 + (c & 7)] = hi | lo of w[m][c][r][s]
 // grid (C/32, ceil(M/8)): the 32*R*S contiguous source floats of each of 8 output rows go through LDS; every thread then writes
-// the four channels c..c+3 of one (tap, m) as 16 bytes, 8 lanes along m (one 128-byte line).  Small blocks: the weights of a
-// 128 x 512 x 3 x 3 layer make 256 of them, and the kernel runs in front of every forward convolution.
+// the eight channels c..c+7 of one (tap, m) as 16 bytes per plane, 8 lanes along m (one 128-byte line).  Small blocks: the
+// weights of a 128 x 512 x 3 x 3 layer make 256 of them, and the kernel runs in front of every forward convolution.
+__device__ __forceinline__ void split_planes8(const float (&x)[8], uint4& hi, uint4& lo) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned a = __float_as_uint(pack_split(x[2 * i])), b = __float_as_uint(pack_split(x[2 * i + 1]));
+        h[i] = (a >> 16) | (b & 0xFFFF0000u);
+        l[i] = (a & 0xFFFFu) | (b << 16);
+    }
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
 __global__ __launch_bounds__(256) void pack_fwd_tap_kernel(const float* __restrict__ w, float* __restrict__ at, int M, int C, int R,
                                                            int S) {
     constexpr int MR = 8;
@@ -340,14 +352,21 @@ __global__ __launch_bounds__(256) void pack_fwd_tap_kernel(const float* __restri
         t[m * row + j] = (m0 + m < M) ? w[((size_t)(m0 + m) * C + c0) * RS + j] : 0.f;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < RS * 8 * MR; i += 256) {
-        const int m = i & (MR - 1), c4 = (i >> 3) & 7, tap = i >> 6;
+    uint4* hi_plane = reinterpret_cast<uint4*>(at);
+    uint4* lo_plane = hi_plane + (size_t)(C * RS / 8) * M;
+    for (int i = threadIdx.x; i < RS * 4 * MR; i += 256) {
+        const int m = i & (MR - 1), c8 = (i >> 3) & 3, tap = i >> 5;
         if (m0 + m >= M) continue;
         const int r = tap / S, s2 = tap - r * S;
-        const float* src = &t[m * row + (c4 * 4) * RS + tap];
-        const float4 v = make_float4(pack_split(src[0]), pack_split(src[RS]), pack_split(src[2 * RS]), pack_split(src[3 * RS]));
-        const int drow = tap_major_row(c0 + c4 * 4, r, s2, R, S);
-        *reinterpret_cast<float4*>(&at[((size_t)(drow >> 2) * M + (m0 + m)) * 4]) = v;
+        const float* src = &t[m * row + (c8 * 8) * RS + tap];
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = src[e * RS];
+        uint4 hi, lo;
+        split_planes8(x, hi, lo);
+        const size_t idx = (size_t)(tap_major_row(c0 + c8 * 8, r, s2, R, S) >> 3) * M + (m0 + m);
+        hi_plane[idx] = hi;
+        lo_plane[idx] = lo;
     }
 }
 
@@ -374,17 +393,17 @@ __global__ __launch_bounds__(256) void dgrad_weight_prep_kernel(const float* __r
     }
 }
 
-// The same sub-filter in the tap-major packed layout (ConvArgs::tap_major; the gathered channels of the data-gradient GEMM are
-// the K forward outputs, its rows the C forward inputs), K % 32 == 0:
-//   at[((tap_major_row(k, r2, s2) >> 2) * C + c) * 4 + (k & 3)] = pack_split(w[k][c][py + st*(Rc-1-r2)][px + st*(Sc-1-s2)])
-// grid (ceil(C/64), K/4): four k per block, so that every thread writes 16 bytes, lanes along c.
+// The same sub-filter in the tap-major plane layout (ConvArgs::tap_major, see pack_fwd_tap_kernel; the gathered channels of the
+// data-gradient GEMM are the K forward outputs, its rows the C forward inputs), K % 32 == 0:
+//   plane[((tap_major_row(k, r2, s2) >> 3) * C + c) * 8 + (k & 7)] = hi | lo of w[k][c][py + st*(Rc-1-r2)][px + st*(Sc-1-s2)]
+// grid (ceil(C/64), K/8): eight k per block, so that every thread writes 16 bytes per plane, lanes along c.
 __global__ __launch_bounds__(256) void pack_dgrad_tap_kernel(const float* __restrict__ w, float* __restrict__ at, int K, int C, int R,
                                                              int S, int py, int px, int st, int Rc, int Sc) {
-    __shared__ float t[4][64 * 17];
+    __shared__ float t[8][64 * 17];
     const int RS = R * S, RSP = RS | 1;      // odd row length: lanes (stride RSP) on distinct banks
-    const int c0 = blockIdx.x * 64, k0 = blockIdx.y * 4;
+    const int c0 = blockIdx.x * 64, k0 = blockIdx.y * 8;
     const int nc = min(64, C - c0);
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 8; ++j) {
         const float* src = w + ((size_t)(k0 + j) * C + c0) * RS;
         for (int i = threadIdx.x; i < nc * RS; i += 256) {
             const int c = i / RS;
@@ -392,14 +411,21 @@ __global__ __launch_bounds__(256) void pack_dgrad_tap_kernel(const float* __rest
         }
     }
     __syncthreads();
+    uint4* hi_plane = reinterpret_cast<uint4*>(at);
+    uint4* lo_plane = hi_plane + (size_t)(K * Rc * Sc / 8) * C;
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     for (int tap = grp; tap < Rc * Sc; tap += 4) {
         const int r2 = tap / Sc, s2 = tap - r2 * Sc;
         const int q = lane * RSP + (py + st * (Rc - 1 - r2)) * S + (px + st * (Sc - 1 - s2));
         if (lane < nc) {
-            const float4 v = make_float4(pack_split(t[0][q]), pack_split(t[1][q]), pack_split(t[2][q]), pack_split(t[3][q]));
-            const int drow = tap_major_row(k0, r2, s2, Rc, Sc);
-            *reinterpret_cast<float4*>(&at[((size_t)(drow >> 2) * C + (c0 + lane)) * 4]) = v;
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = t[e][q];
+            uint4 hi, lo;
+            split_planes8(x, hi, lo);
+            const size_t idx = (size_t)(tap_major_row(k0, r2, s2, Rc, Sc) >> 3) * C + (c0 + lane);
+            hi_plane[idx] = hi;
+            lo_plane[idx] = lo;
         }
     }
 }
@@ -763,7 +789,7 @@ extern "C" int ag2v_conv2d_dgrad_acc(const float* dy, const float* w, const floa
             const bool split = use_bf16x3(C) && abytes < kBufMax && bbytes < kBufMax;
             const bool tapmaj = igemm_tap_major(K, split);
             if (tapmaj)
-                hipLaunchKernelGGL(pack_dgrad_tap_kernel, dim3(ceil_div(C, 64), K / 4), dim3(256), 0, st, w, at, K, C, R, S, py, px,
+                hipLaunchKernelGGL(pack_dgrad_tap_kernel, dim3(ceil_div(C, 64), K / 8), dim3(256), 0, st, w, at, K, C, R, S, py, px,
                                    stride, Rc, Sc);
             else
                 hipLaunchKernelGGL(dgrad_weight_prep_kernel, dim3(ceil_div(C, 64), K), dim3(256), 0, st, w, at, K, C, R, S, py, px,
