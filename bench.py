@@ -32,19 +32,19 @@ CONFIGS = {
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # same guide: dense bf16 MFMA peak; the bf16x3 path issues 3 MFMAs per product => /3
 # HBM-side traffic of the conv kernels from rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of tools/pmc_traffic.py
-# via tools/pmc_quick.sh, FETCH_SIZE doubled per the gfx950 correction; CSVs under profiles/r01/pmc/*_v21_*): bytes per launch ON
+# via tools/pmc_quick.sh, FETCH_SIZE doubled per the gfx950 correction; CSVs under profiles/r01/pmc/*_v25_*): bytes per launch ON
 # THE SHAPE NAMED, not an average over the shapes of a training step.
 PMC_TRAFFIC = {
-    "conv_igemm_bf16x3_ws_kernel<128, 256, 2, 4, 8, false, true>": {
-        "bytes_per_launch": 1284e6 + 268e6,
-        "note": "SPADE mlp_shared forward 8x512x256x256 -> 128: FETCH 1284 MB + WRITE 268 MB vs 1076 MB + 268 MB algorithmic"},
-    "conv_igemm_bf16x3_ws_kernel<256, 128, 4, 2, 8, false, true>": {
-        "bytes_per_launch": 924e6 + 1074e6,
-        "note": "SPADE mlp_shared data gradient (dy 8x128x256x256 -> dx 512 ch): FETCH 924 MB + WRITE 1074 MB vs 271 MB + 1074 MB "
+    "conv_igemm_bf16x3_ws_kernel<128, 256, 2, 4, 8, false, true, true>": {
+        "bytes_per_launch": 1292e6 + 268e6,
+        "note": "SPADE mlp_shared forward 8x512x256x256 -> 128: FETCH 1292 MB + WRITE 268 MB vs 1076 MB + 268 MB algorithmic"},
+    "conv_igemm_bf16x3_ws_kernel<256, 128, 4, 2, 8, false, true, false>": {
+        "bytes_per_launch": 935e6 + 1074e6,
+        "note": "SPADE mlp_shared data gradient (dy 8x128x256x256 -> dx 512 ch): FETCH 935 MB + WRITE 1074 MB vs 271 MB + 1074 MB "
                 "algorithmic (dy re-read by the 2 row tiles and the 3x3 halo through a 4 MB L2)"},
     "conv_wgrad_bf16x3_v_kernel<128, 256, 2, 4, 8, false>": {
-        "bytes_per_launch": 1620e6 + 33e6,
-        "note": "SPADE mlp_shared weight gradient: FETCH 1620 MB + WRITE 33 MB (split-K atomics) vs 1342 MB + 2.4 MB algorithmic"},
+        "bytes_per_launch": 1608e6 + 33e6,
+        "note": "SPADE mlp_shared weight gradient: FETCH 1608 MB + WRITE 33 MB (split-K atomics) vs 1342 MB + 2.4 MB algorithmic"},
     "conv_wgrad_bf16x3_v_kernel<256, 128, 4, 2, 8, false>": {
         "bytes_per_launch": 341e6 + 33e6,
         "note": "256 -> 256 layer at 8x128x128 weight gradient: FETCH 341 MB + WRITE 33 MB (split-K atomics) vs 268 MB + 2.4 MB algorithmic"},
