@@ -744,18 +744,24 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_v_ke
     if (producer) {
         const __amdgpu_buffer_rsrc_t ars = make_rsrc(p.a_src, p.a_bytes), brs = make_rsrc(p.b_src, p.b_bytes);
         const int run = tid & 3, row = tid >> 2;      // run of 8 pixels inside the K-tile; rows / columns row + RPT i
-        int aoff[NA], boff[NB], bdy[NB], bdx[NB];
+        // Validity without per-load selects where the GEMM allows it (producer VALU beside the prioritised MFMA waves costs ~1 %
+        // of the kernel per instruction; a build without any validity logic ran 8-14 % faster): rows m >= M and columns j >= NG
+        // only feed accumulators that are never stored, so they read row 0 / column 0; a run past the end of the split's pixel
+        // range has byte offset 2^31 in the table for dY (the launcher takes this kernel for a_bytes <= 2^31 only), i.e. zeros,
+        // which annihilates whatever x is read beside it.  What remains per x row is the image-row test of its tap.
+        unsigned aoff4[NA];
+        int boff[NB], bdy[NB], bdx[NB];
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int m = m0 + row + RPT * i;
-            aoff[i] = (m < p.M) ? m * OHW : -1;
+            aoff4[i] = (unsigned)((m < p.M) ? m : 0) * (unsigned)OHW * 4u;
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int j = n0 + row + RPT * i;
             int c, r, s;
-            decode_crs(j, RS, p.S, c, r, s);
-            bdy[i] = (j < p.NG) ? r - p.pad : -(1 << 20);     // an invalid column never passes the row test
+            decode_crs((j < p.NG) ? j : 0, RS, p.S, c, r, s);
+            bdy[i] = r - p.pad;
             bdx[i] = s - p.pad;
             boff[i] = c * HW + (r - p.pad) * p.W + (s - p.pad);
         }
@@ -769,42 +775,49 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_v_ke
                 const int oy = pixl / p.OW, ox = pixl - oy * p.OW;
                 // border run: some tap column reaches outside [0, W) for its first or last pixels
                 const bool border = (ox - p.pad < 0) | (ox + 7 + (p.S - 1 - p.pad) >= p.W);
-                qtab[t & 3][tid] = make_int4(n * p.C * HW + oy * p.W + ox, n * p.K * OHW + pixl, (oy << 16) | ox,
-                                             (v ? 1 : 0) | (border ? 2 : 0));
+                // .x: element offset of the run in x (0 for a run past the range), .y: BYTE offset of the run in dY (2^31 past the
+                // range), .w: bit 1 border run, bit 2 the run's first taps may lie before the tensor's first element
+                const int xo = n * p.C * HW + oy * p.W + ox;
+                qtab[t & 3][tid] = make_int4(v ? xo : 0, v ? (n * p.K * OHW + pixl) * 4 : (int)0x80000000u, (oy << 16) | ox,
+                                             (v ? 1 : 0) | (border ? 2 : 0) | ((v && xo < p.pad * (p.W + 1)) ? 4 : 0));
             }
         };
         // fix word: bit (2 i) / (2 i + 1) set when B row i needs its leading / trailing elements patched (see stash)
-        auto fetch = [&](int t, u32x4 (&ra)[NA][2], u32x4 (&rb)[NB][2], int& fixw, int& fixx) {
+        auto fetch = [&](int t, u32x4 (&ra)[NA][2], u32x4 (&rb)[NB][2], int& fixw, int& fixx, int& shw) {
             const int4 e = qtab[t & 3][run];
             asm volatile("" ::: "memory");
             const int yb = e.z >> 16, xb = e.z & 0xFFFF;
-            const bool valid = (e.w & 1) != 0;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                const bool ok = valid & (aoff[i] >= 0);
-                const unsigned off = ok ? (unsigned)(e.y + aoff[i]) * 4u : 0xFFFFFFE0u;
+                const unsigned off = (unsigned)e.y + aoff4[i];
                 ra[i][0] = bload_u32x4(ars, off);
                 ra[i][1] = bload_u32x4(ars, off + 16u);
             }
             fixw = (e.w & 2) ? 1 : 0;
             fixx = xb;
+            // Every row takes the same two 16-byte loads: a branch around loads inside this pipelined loop makes the compiler's
+            // vmcnt bookkeeping pessimistic (it waited down to vmcnt(3), i.e. for the loads issued half an iteration ago; a build
+            // without the branch ran 8-14 % faster).  The one case that needs other addresses -- first rows of image 0, where a
+            // run starts up to `pad` elements before the tensor's first element and a wrapped offset would read 0 in all four
+            // dwords -- loads from element 0 instead and shifts the registers in stash (shw: 2 bits per row).
+            int o[NB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) o[i] = e.x + boff[i];
+            shw = 0;
+            if (__builtin_expect((e.w & 4) != 0, 0)) {
+#pragma unroll
+                for (int i = 0; i < NB; ++i)
+                    if (o[i] < 0) {      // (a row whose tap row is outside the image is not loaded at all: no shift recorded)
+                        if ((unsigned)(yb + bdy[i]) < (unsigned)p.H) shw |= ((-o[i]) & 3) << (2 * i);
+                        o[i] = 0;
+                    }
+            }
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 const int iy = yb + bdy[i];
-                const bool ok = valid & ((unsigned)iy < (unsigned)p.H);
-                const int o = e.x + boff[i];
-                if (__builtin_expect(ok & (o < 0), 0)) {
-                    // the run starts before the first element of the tensor (image 0, channel 0, row 0, x = -1..): element loads
-                    unsigned v[8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = bload_u32(brs, (o + k >= 0) ? (unsigned)(o + k) * 4u : 0xFFFFFFFFu);
-                    rb[i][0] = u32x4{v[0], v[1], v[2], v[3]};
-                    rb[i][1] = u32x4{v[4], v[5], v[6], v[7]};
-                } else {
-                    const unsigned off = ok ? (unsigned)o * 4u : 0xFFFFFFE0u;
-                    rb[i][0] = bload_u32x4(brs, off);
-                    rb[i][1] = bload_u32x4(brs, off + 16u);
-                }
+                const unsigned off = ((unsigned)iy < (unsigned)p.H) ? (unsigned)o[i] * 4u : 0xFFFFFFE0u;
+                rb[i][0] = bload_u32x4(brs, off);
+                rb[i][1] = bload_u32x4(brs, off + 16u);
             }
         };
         auto store_row = [&](unsigned short* hi_img, unsigned short* lo_img, int r, const u32x4 (&v)[2]) {
@@ -817,9 +830,21 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_v_ke
             *reinterpret_cast<uint4*>(&hi_img[off]) = make_uint4(h[0], h[1], h[2], h[3]);
             *reinterpret_cast<uint4*>(&lo_img[off]) = make_uint4(l[0], l[1], l[2], l[3]);
         };
-        auto stash = [&](int buf, const u32x4 (&ra)[NA][2], u32x4 (&rb)[NB][2], int fixw, int fixx) {
+        auto stash = [&](int buf, const u32x4 (&ra)[NA][2], u32x4 (&rb)[NB][2], int fixw, int fixx, int shw) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) store_row(Ahi[buf], Alo[buf], row + RPT * i, ra[i]);
+            if (__builtin_expect(shw != 0, 0)) {   // rows loaded from element 0 instead of element -sh: move them up by sh places
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    const int sh = (shw >> (2 * i)) & 3;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        if (sh > q) {
+                            rb[i][1] = u32x4{rb[i][0][3], rb[i][1][0], rb[i][1][1], rb[i][1][2]};
+                            rb[i][0] = u32x4{0u, rb[i][0][0], rb[i][0][1], rb[i][0][2]};
+                        }
+                }
+            }
             if (fixw) {   // (almost) wave-uniform: the 4 runs of a K-tile are 32 consecutive pixels
 #pragma unroll
                 for (int i = 0; i < NB; ++i) {
@@ -833,24 +858,24 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_v_ke
             for (int i = 0; i < NB; ++i) store_row(Bhi[buf], Blo[buf], row + RPT * i, rb[i]);
         };
         u32x4 ra0[NA][2], ra1[NA][2], rb0[NB][2], rb1[NB][2];
-        int fw0, fx0, fw1, fx1;
+        int fw0, fx0, fw1, fx1, sh0, sh1;
         build_tab(0);
         build_tab(1);
         build_tab(2);
         build_tab(3);
         __syncthreads();
-        fetch(0, ra0, rb0, fw0, fx0);
+        fetch(0, ra0, rb0, fw0, fx0, sh0);
         __builtin_amdgcn_sched_barrier(0);
-        fetch(1, ra1, rb1, fw1, fx1);
+        fetch(1, ra1, rb1, fw1, fx1, sh1);
         __builtin_amdgcn_sched_barrier(0);
         for (int t = 0; t < nt; t += 2) {       // pipeline of conv_igemm_bf16x3_ws_kernel
-            stash(0, ra0, rb0, fw0, fx0);
+            stash(0, ra0, rb0, fw0, fx0, sh0);
             build_tab(t + 4);
-            fetch(t + 2, ra0, rb0, fw0, fx0);
+            fetch(t + 2, ra0, rb0, fw0, fx0, sh0);
             __syncthreads();
-            stash(1, ra1, rb1, fw1, fx1);
+            stash(1, ra1, rb1, fw1, fx1, sh1);
             build_tab(t + 5);
-            fetch(t + 3, ra1, rb1, fw1, fx1);
+            fetch(t + 3, ra1, rb1, fw1, fx1, sh1);
             __syncthreads();
         }
         return;
@@ -1022,7 +1047,8 @@ int launch_wgrad_bf16x3(ConvArgs& a, hipStream_t st) {
     static const bool wgrad32 = getenv("AG2V_WGRAD16") == nullptr;
     static const int wnoprio = getenv("AG2V_WGRAD_NOPRIO") ? 1 : 0;     // A/B aid
     a.diag_noprio = wnoprio;
-    if (a.stride == 1 && a.OW % 8 == 0 && a.W >= 8 && getenv("AG2V_WGRAD_SCALAR_LOADS") == nullptr) {
+    if (a.stride == 1 && a.OW % 8 == 0 && a.W >= 8 && a.a_bytes <= 0x80000000u && a.pad <= 3 &&
+        getenv("AG2V_WGRAD_SCALAR_LOADS") == nullptr) {
         // 16-byte loads along the pixel index (runs of 8 pixels never straddle an image row)
         if (tall) {
             if (wgrad32) {
