@@ -196,23 +196,18 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
                 const int o = qbase + f_r * p.W + f_s;            // element offset without the chunk term (soffset)
                 const unsigned sb = (unsigned)f_c * c4;
                 emask = (qemask >> (4 * f_s)) & 15u;
-                if (__builtin_expect(rowok & (o < 0), 0)) {
-                    // the quad starts before the tensor's first element (image 0, channel part 0, row 0, x < 0): a negative
-                    // voffset is out of range whatever soffset adds, so this one quad of a launch takes element loads
+                // The quad of a launch that starts before the tensor's first element (image 0, channel part 0, row 0, x < 0) cannot
+                // use its negative voffset (out of range whatever soffset adds): it loads from element 0 and stash moves the
+                // registers up by -o places (emask bits 4-5).  No branch around the loads: that made the compiler wait for
+                // vmcnt(0..3) in this loop, i.e. for the loads issued half an iteration earlier.
+                int oc = o;
+                if (__builtin_expect(rowok & (o < 0), 0)) { emask |= (unsigned)((-o) & 3) << 4; oc = 0; }
+                const unsigned vo = rowok ? (unsigned)oc * 4u : kOut;
 #pragma unroll
-                    for (int i = 0; i < KPT; ++i)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            rb[0][4 * i + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                brs, (o + j >= 0) ? (unsigned)(o + j) * 4u : kOut, sb + i * c4, 0));
-                } else {
-                    const unsigned vo = rowok ? (unsigned)o * 4u : kOut;
-#pragma unroll
-                    for (int i = 0; i < KPT; ++i) {
-                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(brs, vo, sb + i * c4, 0);
-                        rb[0][4 * i] = __uint_as_float(v[0]); rb[0][4 * i + 1] = __uint_as_float(v[1]);
-                        rb[0][4 * i + 2] = __uint_as_float(v[2]); rb[0][4 * i + 3] = __uint_as_float(v[3]);
-                    }
+                for (int i = 0; i < KPT; ++i) {
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(brs, vo, sb + i * c4, 0);
+                    rb[0][4 * i] = __uint_as_float(v[0]); rb[0][4 * i + 1] = __uint_as_float(v[1]);
+                    rb[0][4 * i + 2] = __uint_as_float(v[2]); rb[0][4 * i + 3] = __uint_as_float(v[3]);
                 }
             } else {
                 const unsigned sb = (unsigned)(f_c + BKK * bpart_s) * c4;
@@ -253,6 +248,17 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
                 }
             if constexpr (B4) {
                 if (emask) {     // border quads only
+                    const unsigned sh = emask >> 4;
+                    if (sh) {
+#pragma unroll
+                        for (int i = 0; i < KPT; ++i)
+#pragma unroll
+                            for (int q = 0; q < 3; ++q)
+                                if (sh > (unsigned)q) {
+                                    rb[0][4 * i + 3] = rb[0][4 * i + 2]; rb[0][4 * i + 2] = rb[0][4 * i + 1];
+                                    rb[0][4 * i + 1] = rb[0][4 * i]; rb[0][4 * i] = 0.f;
+                                }
+                    }
 #pragma unroll
                     for (int i = 0; i < KPT; ++i)
 #pragma unroll
@@ -1004,7 +1010,8 @@ int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed) {
     // quad loads of the gathered operand on the 128 x 256 tile: stride-1 launches whose pixel rows are whole quads
     // (AG2V_NO_B4: A/B aid).  The 256 x 128 tile (8 of its 12 loads gather) was 4 % slower with them.
     static const bool b4_off = getenv("AG2V_NO_B4") != nullptr;
-    const bool b4 = a.tap_major && !b4_off && !tall && a.stride == 1 && a.OW % 4 == 0 && a.W >= 4 && (a.OH * a.OW) % 4 == 0;
+    const bool b4 = a.tap_major && !b4_off && !tall && a.stride == 1 && a.OW % 4 == 0 && a.W >= 4 && (a.OH * a.OW) % 4 == 0 &&
+                    a.pad_w <= 3;
     if (tall) {
         // 16x16x32 MFMAs (+3..6 % with the table-path producers) read their LDS operands with 36 % bank-conflict cycles
         // (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, tools/ubench/pmc_variants.sh; 32x32x16: 0 %) and leave the prioritised
