@@ -492,7 +492,7 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
 #pragma unroll
     for (int i = 0; i < EM; ++i) {
 #pragma unroll
-        for (int r = 0; r < EREGS; ++r) {
+        for (int r = 0; r < (MF16 ? EREGS : 0); ++r) {
             if constexpr (MF16) {
                 unsigned a0 = __float_as_uint(acc[i][0][r]), a1 = __float_as_uint(acc[i][1][r]);
                 unsigned a2 = __float_as_uint(acc[i][2][r]), a3 = __float_as_uint(acc[i][3][r]);
@@ -506,12 +506,64 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
                 emit(mrow + 4, __uint_as_float(a1));
                 emit(mrow + 8, __uint_as_float(a2));
                 emit(mrow + 12, __uint_as_float(a3));
-            } else {
-                unsigned a0 = __float_as_uint(acc[i][0][r]), a1 = __float_as_uint(acc[i][1][r]);
-                const u32x2 t = __builtin_amdgcn_permlane32_swap(a0, a1, false, false);
-                const int mrow = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2);   // t[0]: row mrow, t[1]: row mrow + 4
-                emit(mrow, __uint_as_float(t[0]));
-                emit(mrow + 4, __uint_as_float(t[1]));
+            }
+        }
+        if constexpr (!MF16) {
+            // 32x32x16 tiles: registers r = 4 g .. 4 g + 3 hold rows 8 g .. 8 g + 7 of this 32-row block after the swap.  The
+            // epilogue's reads are batched: one vector load brings the block's 32 bias values (a row's value is then a
+            // v_readlane), and the residual / mask words of 8 rows are requested together before the first of them is used.
+            // (Row by row, each of the up to three conditional loads was followed by s_waitcnt vmcnt(0): 64-190 serialised
+            // memory round trips per wave and tile.)
+            const int mblk = m0 + wm0 + i * 32;
+            float bvec = 0.f;
+            if (kt0 == 0 && p.bias) {
+                const int mb = mblk + (lane & 31);
+                bvec = (mb < p.M) ? p.bias[mb] : 0.f;
+            }
+            const float* aux = rbase ? rbase : mbase;       // at most one of them (ag2v_conv2d_dgrad_acc rejects both)
+            const float ninf = -__builtin_huge_valf();
+            const float rmul = (rbase && kt0 == 0) ? 1.f : 0.f;                         // residual added by the first K chunk only
+            const float relu_floor = (p.relu && p.splitk == 1) ? 0.f : ninf;
+            const float mask_thr = mbase ? 0.f : ninf;                                  // no mask: every word passes
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v[8], ax[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    unsigned a0 = __float_as_uint(acc[i][0][4 * g + q]), a1 = __float_as_uint(acc[i][1][4 * g + q]);
+                    const u32x2 t = __builtin_amdgcn_permlane32_swap(a0, a1, false, false);
+                    v[q] = __uint_as_float(t[0]);            // row mblk + 8 g + q
+                    v[q + 4] = __uint_as_float(t[1]);        // row mblk + 8 g + q + 4
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) ax[k] = 0.f;
+                if (aux) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int m = mblk + 8 * g + k;
+                        if (pvalid && m < p.M) ax[k] = aux[(size_t)m * plane];
+                    }
+                    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0) once for the batch (the stores below must not be waited for)
+                }
+                // straight-line arithmetic on the loaded words (uniform multipliers / thresholds instead of branches: a use of a
+                // loaded register inside a conditional block makes the compiler wait for vmcnt(0) there, stores included)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float x = v[k] + __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(bvec), 8 * g + k));
+                    x = fmaf(ax[k], rmul, x);
+                    x = fmaxf(x, relu_floor);
+                    v[k] = (ax[k] > mask_thr) ? x : 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int m = mblk + 8 * g + k;
+                    if (pvalid && m < p.M) {
+                        if (p.splitk > 1)
+                            atomicAdd(obase + (size_t)m * plane, v[k]);
+                        else
+                            obase[(size_t)m * plane] = v[k];
+                    }
+                }
             }
         }
     }
