@@ -145,40 +145,66 @@ __global__ __launch_bounds__(256, 4) void conv_igemm_kernel(ConvArgs p) {
     const int gplane = p.OH * p.OW;   // pixels of the GEMM's pixel space per image
     const int plane = p.o_H * p.o_W;  // elements of one output channel plane
     const bool mapped = (p.o_mul != 1 || p.o_add_y != 0 || p.o_add_x != 0 || p.o_W != p.OW);
+    // Reads of the epilogue (bias, residual or mask word) are requested for 8 registers at a time and waited for once; the
+    // arithmetic on them is branch-free (uniform multipliers / thresholds).  Row by row, every conditional load was followed by
+    // s_waitcnt vmcnt(0) -- stores included -- i.e. up to three serialised memory round trips per accumulator register.
+    const float ninf = -__builtin_huge_valf();
+    const float rmul = (p.residual && kt0 == 0) ? 1.f : 0.f;
+    const float relu_floor = (p.relu && p.splitk == 1) ? 0.f : ninf;
+    const float mask_thr = (p.mask && p.splitk == 1) ? 0.f : ninf;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int opix = n0 + wn0 + j * 32 + (lane & 31);
-        if (opix >= p.NG) continue;
-        const int on = opix / gplane;
-        int orem = opix - on * gplane;
+        bool pvalid = opix < p.NG;
+        const int on = pvalid ? opix / gplane : 0;
+        int orem = pvalid ? opix - on * gplane : 0;
         if (mapped) {
             const int qy = orem / p.OW, qx = orem - qy * p.OW;
             const int yy = qy * p.o_mul + p.o_add_y, xx = qx * p.o_mul + p.o_add_x;
-            if ((unsigned)yy >= (unsigned)p.o_H || (unsigned)xx >= (unsigned)p.o_W) continue;
-            orem = yy * p.o_W + xx;
+            pvalid = pvalid && (unsigned)yy < (unsigned)p.o_H && (unsigned)xx < (unsigned)p.o_W;
+            orem = pvalid ? yy * p.o_W + xx : 0;
         }
         float* obase = p.out + (size_t)on * p.M * plane + orem;
         const float* rbase = p.residual ? p.residual + (size_t)on * p.M * plane + orem : nullptr;
         const float* mbase = (p.mask && p.splitk == 1) ? p.mask + (size_t)on * p.M * plane + orem : nullptr;
+        const float* aux = rbase ? rbase : mbase;           // at most one of them (ag2v_conv2d_dgrad_acc rejects both)
+        const bool want_bias = p.bias && kt0 == 0;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m < p.M) {
-                    float v = acc[i][j][r];
-                    if (kt0 == 0) {
-                        if (p.bias) v += p.bias[m];
-                        if (rbase) v += rbase[(size_t)m * plane];
+            for (int h = 0; h < 2; ++h) {
+                float b[8], ax[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { b[k] = 0.f; ax[k] = 0.f; }
+                if (want_bias || aux) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int r = 8 * h + k;
+                        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        if (m < p.M) {
+                            if (want_bias) b[k] = p.bias[m];
+                            if (aux && pvalid) ax[k] = aux[(size_t)m * plane];
+                        }
                     }
-                    if (p.splitk == 1) {   // (a split-K launch applies these in a pass over the finished sums: launch_act_mask)
-                        if (p.relu) v = fmaxf(v, 0.f);
-                        if (mbase) v = (mbase[(size_t)m * plane] > 0.f) ? v : 0.f;
+                    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), once per 8 registers
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float x = acc[i][j][8 * h + k] + b[k];
+                    x = fmaf(ax[k], rmul, x);
+                    x = fmaxf(x, relu_floor);
+                    b[k] = (ax[k] > mask_thr) ? x : 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int r = 8 * h + k;
+                    const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (pvalid && m < p.M) {
+                        if (p.splitk > 1)
+                            atomicAdd(obase + (size_t)m * plane, b[k]);
+                        else
+                            obase[(size_t)m * plane] = b[k];
                     }
-                    if (p.splitk > 1)
-                        atomicAdd(obase + (size_t)m * plane, v);
-                    else
-                        obase[(size_t)m * plane] = v;
                 }
             }
         }
