@@ -525,25 +525,33 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
             const float rmul = (rbase && kt0 == 0) ? 1.f : 0.f;                         // residual added by the first K chunk only
             const float relu_floor = (p.relu && p.splitk == 1) ? 0.f : ninf;
             const float mask_thr = mbase ? 0.f : ninf;                                  // no mask: every word passes
+            // the residual / mask words of all 32 rows are requested before the first store of the block goes out (a wait for
+            // loads issued after stores would wait for those stores as well: vmcnt counts in issue order)
+            float axa[4][8];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) axa[g][k] = 0.f;
+            if (aux) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int m = mblk + 8 * g + k;
+                        if (pvalid && m < p.M) axa[g][k] = aux[(size_t)m * plane];
+                    }
+                __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0) once per 32-row block
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                float v[8], ax[8];
+                float v[8];
+                const float (&ax)[8] = axa[g];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     unsigned a0 = __float_as_uint(acc[i][0][4 * g + q]), a1 = __float_as_uint(acc[i][1][4 * g + q]);
                     const u32x2 t = __builtin_amdgcn_permlane32_swap(a0, a1, false, false);
                     v[q] = __uint_as_float(t[0]);            // row mblk + 8 g + q
                     v[q + 4] = __uint_as_float(t[1]);        // row mblk + 8 g + q + 4
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) ax[k] = 0.f;
-                if (aux) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const int m = mblk + 8 * g + k;
-                        if (pvalid && m < p.M) ax[k] = aux[(size_t)m * plane];
-                    }
-                    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0) once for the batch (the stores below must not be waited for)
                 }
                 // straight-line arithmetic on the loaded words (uniform multipliers / thresholds instead of branches: a use of a
                 // loaded register inside a conditional block makes the compiler wait for vmcnt(0) there, stores included)
