@@ -189,16 +189,24 @@ __global__ __launch_bounds__(256 * KS) void gemm_f32_kernel(const float* __restr
     const int n = n0 + wn0 + (lane & 31);
     if (n < N) {
         const float bv = bias ? bias[n] : 0.f;
+        // the 16 read-backs of an accumulating launch are requested together (one conditional load per register, each followed
+        // by s_waitcnt vmcnt(0), serialised 16 memory round trips behind the stores of the previous registers)
+        float old[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) old[r] = 0.f;
+        if (accumulate) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < M) old[r] = c[(size_t)m * ldc + n];
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+        }
+        const float floor_ = relu ? 0.f : -__builtin_huge_valf();
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (m < M) {
-                float v = acc[r] + bv;
-                float* dst = c + (size_t)m * ldc + n;
-                if (accumulate) v += *dst;
-                if (relu) v = fmaxf(v, 0.f);
-                *dst = v;
-            }
+            if (m < M) c[(size_t)m * ldc + n] = fmaxf(acc[r] + bv + old[r], floor_);
         }
     }
 }
