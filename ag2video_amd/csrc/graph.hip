@@ -204,9 +204,14 @@ __global__ __launch_bounds__(256 * KS) void gemm_f32_kernel(const float* __restr
         }
         const float floor_ = relu ? 0.f : -__builtin_huge_valf();
 #pragma unroll
+        for (int r = 0; r < 16; ++r) {                                                 // straight-line: no use of a loaded word
+            old[r] = fmaxf(acc[r] + bv + old[r], floor_);
+            asm volatile("" : "+v"(old[r]));      // (keeps the compiler from sinking the arithmetic into the store blocks)
+        }
+#pragma unroll                                                                         // inside a conditional block
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (m < M) c[(size_t)m * ldc + n] = fmaxf(acc[r] + bv + old[r], floor_);
+            if (m < M) c[(size_t)m * ldc + n] = old[r];
         }
     }
 }
