@@ -95,3 +95,52 @@ def test_frozen_discriminator_params_restored():
     assert all(p.requires_grad for p in ts.discriminator.img_discriminator.parameters())
     assert all(p.grad is not None for p in ts.discriminator.img_discriminator.parameters()
                if p is not ts.discriminator.img_discriminator.pred_embeddings.weight)
+
+
+def test_layout_terms_shared_once_per_step_and_invalidated():
+    """LossModel evaluates D's layout terms once per step (generator loss) and reuses them in the discriminator loss of the same
+    batch; an in-place change of a discriminator parameter or another batch in between forces a fresh evaluation."""
+    from ag2video_amd.data.synthetic import make_clip_batch
+    from ag2video_amd.engine import TrainStep
+    gold, opt, toy = _setup()
+    with oracle_ops():
+        ts = TrainStep(opt, torch.device('cpu'), weights_seed=toy['wseed'])
+        D = ts.discriminator.img_discriminator
+        calls = [0]
+        inner = D.layout_terms
+
+        def counted(*a, **k):
+            calls[0] += 1
+            return inner(*a, **k)
+        D.layout_terms = counted
+        loss_model = ts.gans_model.module
+        batch = make_clip_batch(opt.vocab, toy['batch'], toy['frames'], tuple(toy['size']), seed=toy['seed'])
+        imgs, objs, boxes, triplets, actions, _ = batch
+        with torch.no_grad():
+            mo = ts.model(imgs, objs, triplets, actions, boxes_gt=boxes, test_mode=False, use_gt=True)
+        # same batch, untouched parameters: one evaluation serves both losses
+        ts.gans_model(batch, mo, mode="compute_generator_loss")
+        dl = ts.gans_model(batch, mo, mode="compute_discriminator_loss")
+        assert calls[0] == 1 and loss_model._terms_cache is None
+        dl["total_img_loss"].backward()          # the reused terms carry their graph: D's graph-net parameters get gradients
+        assert D.gconvs[0].net1[0].weight.grad is not None and float(D.gconvs[0].net1[0].weight.grad.abs().sum()) > 0
+        # a parameter changed in place between the two losses: fresh evaluation
+        calls[0] = 0
+        ts.gans_model(batch, mo, mode="compute_generator_loss")
+        with torch.no_grad():
+            D.fc_objs_vecs.weight.mul_(1.0)
+        ts.gans_model(batch, mo, mode="compute_discriminator_loss")
+        assert calls[0] == 2
+        # another batch in between: fresh evaluation
+        calls[0] = 0
+        other = make_clip_batch(opt.vocab, toy['batch'], toy['frames'], tuple(toy['size']), seed=toy['seed'] + 7)
+        ts.gans_model(batch, mo, mode="compute_generator_loss")
+        with torch.no_grad():
+            mo2 = ts.model(other[0], other[1], other[3], other[4], boxes_gt=other[2], test_mode=False, use_gt=True)
+        ts.gans_model(other, mo2, mode="compute_discriminator_loss")
+        assert calls[0] == 2
+        # without autograd nothing is kept
+        calls[0] = 0
+        with torch.no_grad():
+            ts.gans_model(batch, mo, mode="compute_generator_loss")
+        assert loss_model._terms_cache is None and calls[0] == 1
