@@ -23,7 +23,7 @@
 #define AG2V_LDK 40      // LDS row stride in bf16 elements (tools/ubench builds override it for layout experiments)
 #endif
 #ifndef AG2V_TALL_MF16
-#define AG2V_TALL_MF16 true
+#define AG2V_TALL_MF16 false     // (true: 16x16x32 MFMAs on the table-path 256 x 128 tile; its epilogue is the unbatched one)
 #endif
 #ifndef AG2V_WIDE_MF16
 #define AG2V_WIDE_MF16 false
