@@ -44,7 +44,7 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
     // 16-lane fragment reads on distinct banks (rows 4 g + t, g < 4, t < 4 of an 80-byte pitch).
     constexpr int QN = BN / 4, KP = NP / QN, KPT = BK / KP, GR = QN + 4;
     constexpr int BROWS = B4 ? 4 * GR : BN;
-    static_assert(!B4 || (TAPK && BCOLS == 1 && KPT == 4 && BKK == 16 && QN == 64 && NPW == 8 && !MF16), "quad loads: the tap-major 128 x 256 tile");
+    static_assert(!B4 || (TAPK && BCOLS == 1 && 4 * KPT == BKK && (KPT == 2 || KPT == 4) && !MF16), "quad loads: tap-major 32x32x16 tiles");
     __shared__ __attribute__((aligned(16))) unsigned short Ahi[2][BM * LDK];
     __shared__ __attribute__((aligned(16))) unsigned short Alo[2][BM * LDK];
     __shared__ __attribute__((aligned(16))) unsigned short Bhi[2][BROWS * LDK];
@@ -271,11 +271,18 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int off = (j * GR + quad) * LDK + kpart * KPT;
-                    unsigned h0, l0, h1, l1;
-                    split2(rb[0][j], rb[0][4 + j], h0, l0);
-                    split2(rb[0][8 + j], rb[0][12 + j], h1, l1);
-                    *reinterpret_cast<uint2*>(&Bhi[buf][off]) = make_uint2(h0, h1);
-                    *reinterpret_cast<uint2*>(&Blo[buf][off]) = make_uint2(l0, l1);
+                    if constexpr (KPT == 4) {
+                        unsigned h0, l0, h1, l1;
+                        split2(rb[0][j], rb[0][4 + j], h0, l0);
+                        split2(rb[0][8 + j], rb[0][12 + j], h1, l1);
+                        *reinterpret_cast<uint2*>(&Bhi[buf][off]) = make_uint2(h0, h1);
+                        *reinterpret_cast<uint2*>(&Blo[buf][off]) = make_uint2(l0, l1);
+                    } else {      // 256 x 128 tile: 2 channels per thread
+                        unsigned h0, l0;
+                        split2(rb[0][j], rb[0][4 + j], h0, l0);
+                        *reinterpret_cast<unsigned*>(&Bhi[buf][off]) = h0;
+                        *reinterpret_cast<unsigned*>(&Blo[buf][off]) = l0;
+                    }
                 }
             } else {
 #pragma unroll
@@ -1070,15 +1077,17 @@ int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed) {
     // quad loads of the gathered operand on the 128 x 256 tile: stride-1 launches whose pixel rows are whole quads
     // (AG2V_NO_B4: A/B aid).  The 256 x 128 tile (8 of its 12 loads gather) was 4 % slower with them.
     static const bool b4_off = getenv("AG2V_NO_B4") != nullptr;
-    const bool b4 = a.tap_major && !b4_off && !tall && a.stride == 1 && a.OW % 4 == 0 && a.W >= 4 && (a.OH * a.OW) % 4 == 0 &&
-                    a.pad_w <= 3;
+    static const bool b4_tall = getenv("AG2V_B4_TALL") != nullptr;
+    const bool b4 = a.tap_major && !b4_off && (!tall || b4_tall) && a.stride == 1 && a.OW % 4 == 0 && a.W >= 4 &&
+                    (a.OH * a.OW) % 4 == 0 && a.pad_w <= 3;
     if (tall) {
         // 16x16x32 MFMAs (+3..6 % with the table-path producers) read their LDS operands with 36 % bank-conflict cycles
         // (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, tools/ubench/pmc_variants.sh; 32x32x16: 0 %) and leave the prioritised
         // MFMA waves' partners 8 instead of 24 free issue cycles per MFMA: with the TAPK producers the 32x32x16 shape is
         // 0.6 % of a c3 step faster (AG2V_TALL16 selects the other one for A/B runs).
         static const bool tall16 = getenv("AG2V_TALL16") != nullptr;
-        if (a.tap_major && !tall16) AG2V_LAUNCH_IGEMM(256, 128, 4, 2, 8, false, true, false);
+        if (b4) AG2V_LAUNCH_IGEMM(256, 128, 4, 2, 8, false, true, true);
+        else if (a.tap_major && !tall16) AG2V_LAUNCH_IGEMM(256, 128, 4, 2, 8, false, true, false);
         else if (a.tap_major) AG2V_LAUNCH_IGEMM(256, 128, 4, 2, 8, AG2V_TALL_MF16, true, false);
         else AG2V_LAUNCH_IGEMM(256, 128, 4, 2, 8, AG2V_TALL_MF16, false, false);
     } else {
