@@ -26,12 +26,19 @@ _SIGS = {
     'ag2v_conv2d_dgrad_acc': (c_int, [_P, _P, _P, _P] + [c_int] * 10 + [_P, _P]),
     'ag2v_conv2d_wgrad': (c_int, [_P, _P, _P] + [c_int] * 9 + [_P]),
     'ag2v_conv2d_wgrad_acc': (c_int, [_P, _P, _P] + [c_int] * 10 + [_P]),
+    'ag2v_conv2d_fwd_ex': (c_int, [_P, _P, _P, _P, _P] + [c_int] * 10 + [_P, _P, _P]),
+    'ag2v_conv2d_dgrad_workspace_floats': (c_size_t, [c_int] * 9),
+    'ag2v_conv2d_dgrad_ex': (c_int, [_P, _P, _P, _P] + [c_int] * 10 + [_P, c_size_t, _P, _P]),
+    'ag2v_conv2d_wgrad_ex': (c_int, [_P, _P, _P] + [c_int] * 11 + [_P, _P]),
     'ag2v_channel_sum': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     'ag2v_channel_sum_acc': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     'ag2v_bn_workspace_floats': (c_size_t, [c_int, c_int, c_int]),
     'ag2v_bn_stats': (c_int, [_P, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P]),
     'ag2v_norm_apply': (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
     'ag2v_norm_bwd': (c_int, [c_int] + [_P] * 11 + [c_int, c_int, c_int, c_float, _P, _P]),
+    'ag2v_bn_stats_g': (c_int, [_P, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P]),
+    'ag2v_norm_apply_g': (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
+    'ag2v_norm_bwd_g': (c_int, [c_int] + [_P] * 11 + [c_int, c_int, c_int, c_int, c_float, _P, _P]),
     'ag2v_instnorm_lrelu_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P]),
     'ag2v_instnorm_lrelu_bwd': (c_int, [_P] * 6 + [c_int, c_int, c_float, _P]),
     'ag2v_layout_render_fwd': (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [_P]),
@@ -66,8 +73,16 @@ _SIGS = {
     'ag2v_spectral_norm_fwd_save': (c_int, [_P, _P, _P, c_int, c_int, c_float, c_int, _P, _P, _P, _P, _P, _P]),
     'ag2v_spectral_norm_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P]),
     'ag2v_spectral_norm_bwd_acc': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, c_int, _P, _P]),
+    'ag2v_spectral_sigmas': (c_int, [_P, _P, _P, c_int, c_int, c_float, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    'ag2v_sn_group_combine': (c_int, [_P, _P, _P, c_int, c_longlong, _P, c_int, _P, _P]),
+    'ag2v_spectral_sigmas_bwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),
 }
 EXPORTS = tuple(sorted(_SIGS))
+
+
+class ConvOpts(ctypes.Structure):
+    """ag2v_conv_opts (include/ag2v.h): per-call options of the *_ex convolution entry points."""
+    _fields_ = [('precision', c_int), ('min_rows', c_int), ('gscale', c_void_p), ('group_n', c_int), ('kernel', c_char_p)]
 
 _lib = None
 

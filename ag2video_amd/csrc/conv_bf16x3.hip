@@ -480,8 +480,10 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
     float* obase = p.out + (size_t)on * p.M * plane + orem;
     const float* rbase = p.residual ? p.residual + (size_t)on * p.M * plane + orem : nullptr;
     const float* mbase = (p.mask && p.splitk == 1) ? p.mask + (size_t)on * p.M * plane + orem : nullptr;
+    const float gs = p.gscale ? p.gscale[on / p.group_n] : 1.f;     // per-sample-group scale of the product (1/sigma_t)
     auto emit = [&](int m, float v) {
         if (pvalid && m < p.M) {
+            v *= gs;
             if (kt0 == 0) {
                 if (p.bias) v += p.bias[m];
                 if (rbase) v += rbase[(size_t)m * plane];
@@ -564,7 +566,7 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
                 // loaded register inside a conditional block makes the compiler wait for vmcnt(0) there, stores included)
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    float x = v[k] + __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(bvec), 8 * g + k));
+                    float x = fmaf(v[k], gs, __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(bvec), 8 * g + k)));
                     x = fmaf(ax[k], rmul, x);
                     x = fmaxf(x, relu_floor);
                     v[k] = (ax[k] > mask_thr) ? x : 0.f;
@@ -614,11 +616,14 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_ws_k
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int RS = p.R * p.S;
     const int OHW = p.OH * p.OW, HW = p.H * p.W;
-    const int Q = p.N * OHW;
-    const int qs = split * p.kchunk;
-    const int qe = min(qs + p.kchunk, Q);
+    // pixel range of this workgroup: split sl of sample group grp (groups == 1: the whole batch is one group)
+    const int grp = split / p.spg, sl = split - grp * p.spg;
+    const int qs = grp * p.gq + sl * p.kchunk;
+    const int qe = min(qs + p.kchunk, (grp + 1) * p.gq);
     if (qs >= qe) return;
     const int nt = (qe - qs + BK - 1) / BK;
+    float* const outg = p.out + (size_t)grp * p.out_gstride;
+    const bool atomic_out = p.spg > 1 || p.accumulate;
 
     if (producer) {
         const __amdgpu_buffer_rsrc_t ars = make_rsrc(p.a_src, p.a_bytes), brs = make_rsrc(p.b_src, p.b_bytes);
@@ -765,8 +770,8 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_ws_k
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m < p.M) {
-                    float* dst = p.out + (size_t)m * p.NG + colj;
-                    if (p.splitk > 1 || p.accumulate)
+                    float* dst = outg + (size_t)m * p.NG + colj;
+                    if (atomic_out)
                         atomicAdd(dst, acc[i][j][r]);
                     else
                         *dst = acc[i][j][r];
@@ -808,11 +813,14 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_v_ke
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int RS = p.R * p.S;
     const int OHW = p.OH * p.OW, HW = p.H * p.W;
-    const int Q = p.N * OHW;
-    const int qs = split * p.kchunk;
-    const int qe = min(qs + p.kchunk, Q);
+    // pixel range of this workgroup: split sl of sample group grp (groups == 1: the whole batch is one group)
+    const int grp = split / p.spg, sl = split - grp * p.spg;
+    const int qs = grp * p.gq + sl * p.kchunk;
+    const int qe = min(qs + p.kchunk, (grp + 1) * p.gq);
     if (qs >= qe) return;
     const int nt = (qe - qs + BK - 1) / BK;
+    float* const outg = p.out + (size_t)grp * p.out_gstride;
+    const bool atomic_out = p.spg > 1 || p.accumulate;
 
     if (producer) {
         const __amdgpu_buffer_rsrc_t ars = make_rsrc(p.a_src, p.a_bytes), brs = make_rsrc(p.b_src, p.b_bytes);
@@ -1016,8 +1024,8 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_v_ke
                 const int m = MF16 ? m0 + wm0 + i * 16 + 4 * (lane >> 4) + r
                                    : m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m < p.M) {
-                    float* dst = p.out + (size_t)m * p.NG + colj;
-                    if (p.splitk > 1 || p.accumulate)
+                    float* dst = outg + (size_t)m * p.NG + colj;
+                    if (atomic_out)
                         atomicAdd(dst, acc[i][j][r]);
                     else
                         *dst = acc[i][j][r];
@@ -1108,14 +1116,17 @@ int launch_wgrad_bf16x3(ConvArgs& a, hipStream_t st) {
     a.tiles_m = ceil_div(a.M, bm);
     a.tiles_n = ceil_div(a.NG, bn);
     const int tiles = a.tiles_m * a.tiles_n;
-    const long long Q = a.KG;
-    const int nq = (int)((Q + 31) / 32);          // K-tiles (32 pixels each)
-    int splitk = pick_splits(tiles, nq, nq / 8 < 256 ? (nq / 8 > 0 ? nq / 8 : 1) : 256);
-    int kchunk = ceil_div(nq, splitk) * 32;
-    splitk = (int)((Q + kchunk - 1) / kchunk);
-    a.splitk = splitk; a.kchunk = kchunk;
-    if (splitk > 1 && !a.accumulate) {
-        if (hipMemsetAsync(a.out, 0, (size_t)a.M * a.NG * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
+    // per sample group (a.groups == 1: the whole batch): K-tiles of 32 pixels, spg pixel-range splits
+    if (a.groups < 1) { a.groups = 1; a.gq = a.KG; a.out_gstride = (long long)a.M * a.NG; }
+    const long long Qg = a.gq;
+    const int nq = (int)((Qg + 31) / 32);
+    int spg = pick_splits(tiles * a.groups, nq, nq / 8 < 256 ? (nq / 8 > 0 ? nq / 8 : 1) : 256);
+    int kchunk = ceil_div(nq, spg) * 32;
+    spg = (int)((Qg + kchunk - 1) / kchunk);
+    const int splitk = spg * a.groups;
+    a.spg = spg; a.splitk = splitk; a.kchunk = kchunk;
+    if (spg > 1 && !a.accumulate) {
+        if (hipMemsetAsync(a.out, 0, (size_t)a.M * a.NG * a.groups * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
     }
     const dim3 grid(tiles * splitk);     // 1-D: the kernels decode (split, tile) themselves (XCD-aware)
     // 32x32x16 MFMAs: the 16x16x32 operand reads cost 49 % LDS bank-conflict cycles in these kernels (pmc_variants.sh) and the

@@ -22,7 +22,7 @@
 #include <string.h>
 
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256, 4) void conv_igemm_kernel(ConvArgs p) {
+__global__ __launch_bounds__(256, (BM == 64 ? 3 : 4)) void conv_igemm_kernel(ConvArgs p) {   // <64,256>: 3 resident (VGPRs)
     constexpr int BK = 16;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int LDA = BM + 4, LDB = BN + 4;
@@ -169,6 +169,7 @@ __global__ __launch_bounds__(256, 4) void conv_igemm_kernel(ConvArgs p) {
         const float* mbase = (p.mask && p.splitk == 1) ? p.mask + (size_t)on * p.M * plane + orem : nullptr;
         const float* aux = rbase ? rbase : mbase;           // at most one of them (ag2v_conv2d_dgrad_acc rejects both)
         const bool want_bias = p.bias && kt0 == 0;
+        const float gs = p.gscale ? p.gscale[on / p.group_n] : 1.f;   // per-sample-group scale of the product (1/sigma_t)
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(256, 4) void conv_igemm_kernel(ConvArgs p) {
                 }
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    float x = acc[i][j][8 * h + k] + b[k];
+                    float x = fmaf(acc[i][j][8 * h + k], gs, b[k]);
                     x = fmaf(ax[k], rmul, x);
                     x = fmaxf(x, relu_floor);
                     b[k] = (ax[k] > mask_thr) ? x : 0.f;
@@ -228,10 +229,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvArgs p) {
     const int wm0 = (wave / WN) * (TM * 32), wn0 = (wave % WN) * (TN * 32);
     const int RS = p.R * p.S;
     const int OHW = p.OH * p.OW, HW = p.H * p.W;
-    const int Q = p.N * OHW;
-    const int qs = blockIdx.y * p.kchunk;
-    const int qe = min(qs + p.kchunk, Q);
+    // pixel range of this workgroup: split sl of sample group grp (groups == 1: the whole batch is one group)
+    const int grp = blockIdx.y / p.spg, sl = blockIdx.y - grp * p.spg;
+    const int qs = grp * p.gq + sl * p.kchunk;
+    const int qe = min(qs + p.kchunk, (grp + 1) * p.gq);
     if (qs >= qe) return;  // uniform per block
+    float* const outg = p.out + (size_t)grp * p.out_gstride;
+    const bool atomic_out = p.spg > 1 || p.accumulate;
 
     const int qq = tid & 15, rg = tid >> 4;
     // hoisted column decode: j -> (c, r-pad, s-pad)
@@ -319,8 +323,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvArgs p) {
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m < p.M) {
-                    float* dst = p.out + (size_t)m * p.NG + col;
-                    if (p.splitk > 1 || p.accumulate)
+                    float* dst = outg + (size_t)m * p.NG + col;
+                    if (atomic_out)
                         atomicAdd(dst, acc[i][j][r]);
                     else
                         *dst = acc[i][j][r];
@@ -456,15 +460,17 @@ __global__ __launch_bounds__(256) void pack_dgrad_tap_kernel(const float* __rest
     }
 }
 
-static const char* g_last_conv_kernel = "";
+static thread_local const char* g_last_conv_kernel = "";
 void set_last_conv_kernel(const char* name) { g_last_conv_kernel = name; }
 extern "C" const char* ag2v_last_conv_kernel(void) { return g_last_conv_kernel; }
 
 static int conv_out_dim(int in, int k, int stride, int pad) { return (in + 2 * pad - k) / stride + 1; }
 
-// Precision of the 128/256-row igemm / wgrad tiles (GEMMs with M >= bf16x3_min_rows()): 1 = bf16x3 split (default: fp32-level accuracy, ~1e-5
-// relative per product, at up to 16/3 of the fp32 MFMA rate), 0 = exact fp32 MFMA (bit-for-bit fmaf chains).
-// Process-wide setting: ag2v_set_conv_precision(), or the environment variable AG2V_CONV_PRECISION=fp32|bf16x3 read once.
+// Arithmetic of the 128/256-row igemm / wgrad tiles: 1 = bf16x3 split (fp32-level accuracy, ~1e-5 relative per product, at up to
+// 16/3 of the fp32 MFMA rate), 0 = exact fp32 MFMA (bit-for-bit fmaf chains); GEMMs with fewer rows than min_rows stay exact.
+// Both are PER-CALL arguments (ag2v_conv_opts of the *_ex entry points).  The process-wide values below are only the defaults a
+// call without options (or with precision < 0 / min_rows <= 0) falls back to: AG2V_CONV_PRECISION=fp32|bf16x3 and
+// AG2V_BF16X3_MIN_M read once, or ag2v_set_conv_precision() / ag2v_set_bf16x3_min_rows().
 static int g_conv_precision = -1;
 static int conv_precision() {
     if (g_conv_precision < 0) {
@@ -479,10 +485,6 @@ extern "C" int ag2v_set_conv_precision(int mode) {
     return AG2V_OK;
 }
 extern "C" int ag2v_get_conv_precision(void) { return conv_precision(); }
-// GEMMs with fewer rows stay on the exact-fp32 32/64-row tiles (AG2V_BF16X3_MIN_M overrides, for A/B runs).  The 64-row layers
-// are the full-resolution tails of the flow and image decoders: on the random-init toy their 1e-5 split error is amplified
-// ~100x by the flow warp (imgs_pred 1.3e-3 vs 2.4e-4 against the reference golden, tolerance 1e-3), for a 1 % step-time gain,
-// so they keep exact fp32.
 static int g_bf16x3_min_rows = -1;
 static int bf16x3_min_rows() {
     if (g_bf16x3_min_rows < 0) {
@@ -497,7 +499,29 @@ extern "C" int ag2v_set_bf16x3_min_rows(int rows) {
     return AG2V_OK;
 }
 extern "C" int ag2v_get_bf16x3_min_rows(void) { return bf16x3_min_rows(); }
-static bool use_bf16x3(int M) { return conv_precision() == 1 && M >= bf16x3_min_rows(); }
+
+// mirror of ag2v_conv_opts (include/ag2v.h)
+struct ag2v_conv_opts {
+    int precision;
+    int min_rows;
+    const float* gscale;
+    int group_n;
+    const char* kernel;
+};
+struct ConvCfg {
+    int precision, min_rows;
+    const float* gscale;
+    int group_n;
+};
+static ConvCfg conv_cfg(const ag2v_conv_opts* o) {
+    ConvCfg c;
+    c.precision = (o && o->precision >= 0) ? (o->precision ? 1 : 0) : conv_precision();
+    c.min_rows = (o && o->min_rows > 0) ? o->min_rows : bf16x3_min_rows();
+    c.gscale = o ? o->gscale : nullptr;
+    c.group_n = (o && o->group_n > 0) ? o->group_n : 1;
+    return c;
+}
+static bool use_bf16x3(const ConvCfg& c, int M) { return c.precision == 1 && M >= c.min_rows; }
 static const long long kBufMax = (1LL << 32) - 64;   // raw buffer descriptors cover < 4 GiB
 
 
@@ -598,6 +622,7 @@ __global__ __launch_bounds__(256) void conv_fewrow_kernel(ConvArgs p) {
     __syncthreads();
     if (wave > 0 || !live) return;
     const int plane = p.OH * p.OW;
+    const float gs = p.gscale ? p.gscale[n / p.group_n] : 1.f;
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
         const float bv = p.bias ? p.bias[m] : 0.f;
@@ -606,7 +631,7 @@ __global__ __launch_bounds__(256) void conv_fewrow_kernel(ConvArgs p) {
         for (int j = 0; j < 4; ++j) {
             const float sum = acc[m][j] + (red[0][m * 4 + j][lane] + red[1][m * 4 + j][lane] + red[2][m * 4 + j][lane]);
             if (ox0 + j < p.OW) {
-                float v = sum + bv + (p.residual ? p.residual[o + j] : 0.f);
+                float v = fmaf(sum, gs, bv) + (p.residual ? p.residual[o + j] : 0.f);
                 if (p.relu) v = fmaxf(v, 0.f);
                 if (p.mask) v = (p.mask[o + j] > 0.f) ? v : 0.f;
                 p.out[o + j] = v;
@@ -704,88 +729,127 @@ __global__ __launch_bounds__(256) void col2im_few_kernel(const float* __restrict
 
 extern "C" size_t ag2v_conv2d_workspace_floats(int C, int K, int R, int S) { return (size_t)C * K * R * S; }
 
-// y = conv(x, w) (+bias) (+residual).  workspace: ag2v_conv2d_workspace_floats() floats (k-major copy of the weights).
-// relu != 0: y = max(conv + bias + residual, 0) (the ReLU behind SPADE's mlp_shared convolution, normalization.py:92-95)
-extern "C" int ag2v_conv2d_fwd_act(const float* x, const float* w, const float* bias, const float* residual, float* y,
-                                   int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int relu, float* workspace,
-                                   void* stream);
-extern "C" int ag2v_conv2d_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y,
-                               int N, int C, int H, int W, int K, int R, int S, int stride, int pad, float* workspace,
-                               void* stream) {
-    return ag2v_conv2d_fwd_act(x, w, bias, residual, y, N, C, H, W, K, R, S, stride, pad, 0, workspace, stream);
+// Samples per launch so that the gathered operand of a bf16x3 launch stays below the 4 GiB a raw buffer descriptor covers (the
+// frame-batched generator convolves [T*B, C, H, W] tensors of up to 16 GB); a multiple of group_n.  0: one sample is too large.
+// (AG2V_CHUNK_BYTES lowers the limit so that tests can exercise the chunk loop at small sizes.)
+static long long chunk_limit() {
+    const char* e = getenv("AG2V_CHUNK_BYTES");
+    const long long v = e ? atoll(e) : 0;
+    return (v > 0 && v < kBufMax) ? v : kBufMax;
+}
+static int chunk_samples(long long bytes_per_sample, long long bytes_per_sample2, int group_n) {
+    const long long per = bytes_per_sample > bytes_per_sample2 ? bytes_per_sample : bytes_per_sample2;
+    long long n = chunk_limit() / (per > 0 ? per : 1);
+    if (n > (1 << 30)) n = 1 << 30;
+    n -= n % group_n;
+    return (int)n;
+}
+
+// y = conv(x, w) * gscale[n / group_n] (+bias) (+residual).  workspace: ag2v_conv2d_workspace_floats() floats (k-major copy of the
+// weights).  relu != 0: y = max(., 0) (the ReLU behind SPADE's mlp_shared convolution, normalization.py:92-95)
+extern "C" int ag2v_conv2d_fwd_ex(const float* x, const float* w, const float* bias, const float* residual, float* y,
+                                  int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int relu, float* workspace,
+                                  void* stream, ag2v_conv_opts* o) {
+    if (!x || !w || !y || !workspace || N <= 0 || C <= 0 || K <= 0 || stride <= 0 || R * S > 16) return AG2V_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const ConvCfg cfg = conv_cfg(o);
+    const int OH = conv_out_dim(H, R, stride, pad), OW = conv_out_dim(W, S, stride, pad);
+    if (OH <= 0 || OW <= 0) return AG2V_EINVAL;
+    if ((long long)C * R * S >= (1LL << 31) || (long long)C * H * W >= (1LL << 31) || (long long)K * OH * OW >= (1LL << 31))
+        return AG2V_EINVAL;
+    const int KG = C * R * S;
+    const long long abytes = (long long)KG * K * 4, xs = (long long)C * H * W, ys = (long long)K * OH * OW;
+    // (a reduction shorter than two K-tiles is all epilogue: the exact kernels' smaller tiles keep every wave busy there --
+    // D's first convolution, 3 image channels x 4x4 -> 64 rows with the layout term as residual)
+    static const bool short_exact = getenv("AG2V_NO_SHORT_K_EXACT") == nullptr;
+    int nmax = N;
+    bool split = use_bf16x3(cfg, K) && abytes < kBufMax && !(short_exact && KG < 64 && K < 128);
+    if (split && xs * 4 * N >= chunk_limit()) {
+        nmax = chunk_samples(xs * 4, 0, cfg.gscale ? cfg.group_n : 1);
+        if (nmax <= 0) { split = false; nmax = N; }
+    }
+    if ((long long)nmax * OH * OW >= (1LL << 31)) {         // the GEMM's pixel index is a 32-bit int
+        nmax = (int)(((1LL << 31) - 1) / ((long long)OH * OW));
+        if (cfg.gscale) nmax -= nmax % cfg.group_n;
+        if (nmax <= 0) return AG2V_EINVAL;
+    }
+    const bool tapmaj = igemm_tap_major(C, split);
+    if (tapmaj)
+        hipLaunchKernelGGL(pack_fwd_tap_kernel, dim3(C / 32, ceil_div(K, 8)), dim3(256), 0, st, w, workspace, K, C, R, S);
+    else
+        hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(KG, 32), ceil_div(K, 32)), dim3(256), 0, st, w, workspace, K, KG,
+                           split ? 1 : 0);
+    for (int n0 = 0; n0 < N; n0 += nmax) {
+        const int nc = (N - n0 < nmax) ? N - n0 : nmax;
+        ConvArgs a{};
+        a.b_src = x + (size_t)n0 * xs; a.out = y + (size_t)n0 * ys; a.bias = bias;
+        a.residual = residual ? residual + (size_t)n0 * ys : nullptr; a.relu = relu ? 1 : 0;
+        a.gscale = cfg.gscale ? cfg.gscale + n0 / cfg.group_n : nullptr; a.group_n = cfg.group_n;
+        a.N = nc; a.C = C; a.H = H; a.W = W; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.pad_w = pad;
+        a.OH = OH; a.OW = OW;
+        a.M = K; a.NG = nc * OH * OW; a.KG = KG;
+        a.a_bytes = (unsigned)abytes; a.b_bytes = split ? (unsigned)(xs * 4 * nc) : 0u;
+        a.tap_major = tapmaj ? 1 : 0;
+        a.a_src = workspace;
+        const int rc = launch_igemm(a, st, false, split);
+        if (rc != AG2V_OK) return rc;
+    }
+    if (o) o->kernel = g_last_conv_kernel;
+    return AG2V_OK;
 }
 extern "C" int ag2v_conv2d_fwd_act(const float* x, const float* w, const float* bias, const float* residual, float* y,
                                    int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int relu, float* workspace,
                                    void* stream) {
-    if (!x || !w || !y || !workspace || N <= 0 || C <= 0 || K <= 0 || stride <= 0 || R * S > 16) return AG2V_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
-    ConvArgs a{};
-    a.b_src = x; a.out = y; a.bias = bias; a.residual = residual; a.relu = relu ? 1 : 0;
-    a.N = N; a.C = C; a.H = H; a.W = W; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.pad_w = pad;
-    a.OH = conv_out_dim(H, R, stride, pad); a.OW = conv_out_dim(W, S, stride, pad);
-    if (a.OH <= 0 || a.OW <= 0) return AG2V_EINVAL;
-    if ((long long)N * a.OH * a.OW >= (1LL << 31) || (long long)C * R * S >= (1LL << 31) ||
-        (long long)C * H * W >= (1LL << 31)) return AG2V_EINVAL;
-    a.M = K; a.NG = N * a.OH * a.OW; a.KG = C * R * S;
-    const long long abytes = (long long)a.KG * K * 4, bbytes = (long long)N * C * H * W * 4;
-    // (a reduction shorter than two K-tiles is all epilogue: the exact kernels' smaller tiles keep every wave busy there --
-    // D's first convolution, 3 image channels x 4x4 -> 64 rows with the layout term as residual)
-    static const bool short_exact = getenv("AG2V_NO_SHORT_K_EXACT") == nullptr;
-    const bool split = use_bf16x3(K) && abytes < kBufMax && bbytes < kBufMax && !(short_exact && a.KG < 64 && K < 128);
-    a.a_bytes = (unsigned)abytes; a.b_bytes = (unsigned)bbytes;
-    a.tap_major = igemm_tap_major(C, split) ? 1 : 0;
-    if (a.tap_major)
-        hipLaunchKernelGGL(pack_fwd_tap_kernel, dim3(C / 32, ceil_div(K, 8)), dim3(256), 0, st, w, workspace, K, C, R, S);
-    else
-        hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(a.KG, 32), ceil_div(K, 32)), dim3(256), 0, st, w, workspace, K, a.KG,
-                           split ? 1 : 0);
-    a.a_src = workspace;
-    return launch_igemm(a, st, false, split);
+    return ag2v_conv2d_fwd_ex(x, w, bias, residual, y, N, C, H, W, K, R, S, stride, pad, relu, workspace, stream, nullptr);
+}
+extern "C" int ag2v_conv2d_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y,
+                               int N, int C, int H, int W, int K, int R, int S, int stride, int pad, float* workspace,
+                               void* stream) {
+    return ag2v_conv2d_fwd_ex(x, w, bias, residual, y, N, C, H, W, K, R, S, stride, pad, 0, workspace, stream, nullptr);
 }
 
-// dx = d conv / d x.  For each pixel class (py,px) of the stride one forward-kernel launch over dy with the class's
-// flipped sub-filter.  workspace: ag2v_conv2d_workspace_floats() floats.
+// dx = d conv / d x (* gscale[n / group_n]).  For each pixel class (py,px) of the stride one forward-kernel launch over dy with the
+// class's flipped sub-filter.  workspace: ag2v_conv2d_dgrad_workspace_floats() floats.
 // mask (nullable, same shape as dx): dx = (mask > 0) ? dx : 0 -- the backward of a ReLU that produced this convolution's input
 // (SPADE: mlp_gamma / mlp_beta read relu(mlp_shared(seg)); mask = that activation), fused into the epilogue.
-extern "C" int ag2v_conv2d_dgrad_masked(const float* dy, const float* w, const float* mask, float* dx,
-                                        int N, int C, int H, int W, int K, int R, int S, int stride, int pad, float* workspace,
-                                        void* stream);
-extern "C" int ag2v_conv2d_dgrad_acc(const float* dy, const float* w, const float* mask, float* dx,
-                                     int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int accumulate,
-                                     float* workspace, void* stream);
-extern "C" int ag2v_conv2d_dgrad(const float* dy, const float* w, float* dx,
-                                 int N, int C, int H, int W, int K, int R, int S, int stride, int pad, float* workspace,
-                                 void* stream) {
-    return ag2v_conv2d_dgrad_masked(dy, w, nullptr, dx, N, C, H, W, K, R, S, stride, pad, workspace, stream);
-}
-extern "C" int ag2v_conv2d_dgrad_masked(const float* dy, const float* w, const float* mask, float* dx,
-                                        int N, int C, int H, int W, int K, int R, int S, int stride, int pad, float* workspace,
-                                        void* stream) {
-    return ag2v_conv2d_dgrad_acc(dy, w, mask, dx, N, C, H, W, K, R, S, stride, pad, 0, workspace, stream);
-}
 // accumulate != 0: dx += (data gradient) instead of dx = : several convolutions that read the same tensor (the three SPADE
 // mlp_shared convolutions of a residual block) sum their input gradients without a separate pass per pair.  Not with a mask.
-extern "C" int ag2v_conv2d_dgrad_acc(const float* dy, const float* w, const float* mask, float* dx,
-                                     int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int accumulate,
-                                     float* workspace, void* stream) {
+static bool few_channel_dgrad(int N, int C, int K, int R, int S, int OH, int OW, int stride, bool mask) {
+    return C <= 4 && stride == 1 && !mask && K >= 64 && C * R * S <= 64 && getenv("AG2V_NO_FEW_DGRAD_GEMM") == nullptr;
+}
+extern "C" size_t ag2v_conv2d_dgrad_workspace_floats(int N, int C, int H, int W, int K, int R, int S, int stride, int pad) {
+    const int OH = conv_out_dim(H, R, stride, pad), OW = conv_out_dim(W, S, stride, pad);
+    size_t n = (size_t)C * K * R * S;
+    // few input channels: the [N, C R S, OH, OW] intermediate of the 1x1-GEMM + shifted-plane-sum form lives in the workspace too
+    if (OH > 0 && OW > 0 && few_channel_dgrad(N, C, K, R, S, OH, OW, stride, false)) n += (size_t)N * C * R * S * OH * OW;
+    return n;
+}
+extern "C" int ag2v_conv2d_dgrad_ex(const float* dy, const float* w, const float* mask, float* dx,
+                                    int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int accumulate,
+                                    float* workspace, size_t workspace_floats, void* stream, ag2v_conv_opts* o) {
     if (!dy || !w || !dx || !workspace || N <= 0 || C <= 0 || K <= 0 || stride <= 0 || R * S > 16) return AG2V_EINVAL;
     if (accumulate && mask) return AG2V_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    const ConvCfg cfg = conv_cfg(o);
     const int OH = conv_out_dim(H, R, stride, pad), OW = conv_out_dim(W, S, stride, pad);
     if (OH <= 0 || OW <= 0) return AG2V_EINVAL;
-    if ((long long)K * OH * OW >= (1LL << 31)) return AG2V_EINVAL;
-    if (C <= 4 && stride == 1 && !mask && K >= 64 && C * R * S <= 64 && (long long)N * K * OH * OW < (1LL << 31) &&
-        getenv("AG2V_NO_FEW_DGRAD_GEMM") == nullptr) {
-        // few input channels: 1x1-convolution GEMM + shifted-plane sum (col2im_few_kernel); t lives in a stream-ordered allocation
+    if ((long long)K * OH * OW >= (1LL << 31) || (long long)C * H * W >= (1LL << 31)) return AG2V_EINVAL;
+    if (workspace_floats < (size_t)C * K * R * S) return AG2V_EINVAL;
+    const long long dys = (long long)K * OH * OW, dxs = (long long)C * H * W;
+    const size_t t_floats = (size_t)N * C * R * S * OH * OW;
+    if (few_channel_dgrad(N, C, K, R, S, OH, OW, stride, mask != nullptr) && (long long)N * OH * OW < (1LL << 31) &&
+        workspace_floats >= (size_t)C * K * R * S + t_floats) {
+        // few input channels: dx[n,c,y,x] = sum_{r,s} t[n, (c R + r) S + s, y + pad - r, x + pad - s], t = W'^T dy as a 1x1
+        // convolution over contiguous pixels + a sum of C R S shifted planes (col2im_few_kernel); t is caller workspace
         const int J = C * R * S;
-        float* t = nullptr;
-        if (hipMallocAsync((void**)&t, (size_t)N * J * OH * OW * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
+        float* t = workspace + (size_t)C * K * R * S;
         ConvArgs f{};
         f.a_src = w;                      // w[K][C R S] is the k-major operand of the 1x1 convolution as it stands
         f.b_src = dy; f.out = t;
         f.N = N; f.C = K; f.H = OH; f.W = OW; f.K = J; f.R = 1; f.S = 1; f.stride = 1; f.pad = 0; f.pad_w = 0; f.OH = OH; f.OW = OW;
         f.M = J; f.NG = N * OH * OW; f.KG = K;
         f.a_bytes = (unsigned)((long long)K * J * 4); f.b_bytes = 0;
+        f.gscale = cfg.gscale; f.group_n = cfg.group_n;
         int rc = launch_igemm(f, st, false, false);
         if (rc == AG2V_OK) {
             const long long total = (long long)N * C * H * W;
@@ -793,7 +857,7 @@ extern "C" int ag2v_conv2d_dgrad_acc(const float* dy, const float* w, const floa
                                pad, accumulate ? 1 : 0);
             if (hipGetLastError() != hipSuccess) rc = AG2V_EHIP;
         }
-        if (hipFreeAsync(t, st) != hipSuccess && rc == AG2V_OK) rc = AG2V_EHIP;
+        if (o) o->kernel = g_last_conv_kernel;
         return rc;
     }
     // With stride > 1 several classes write disjoint pixels of dx (one of them may be empty when R < stride) and a class
@@ -811,8 +875,19 @@ extern "C" int ag2v_conv2d_dgrad_acc(const float* dy, const float* w, const floa
             const int q0x = (pad > px) ? (pad - px + stride - 1) / stride : 0;
             const int ay = q0y * stride + py - pad, ax = q0x * stride + px - pad;
             if (ay >= H || ax >= W) continue;
-            const long long abytes = (long long)K * C * Rc * Sc * 4, bbytes = (long long)N * K * OH * OW * 4;
-            const bool split = use_bf16x3(C) && abytes < kBufMax && bbytes < kBufMax;
+            const long long abytes = (long long)K * C * Rc * Sc * 4;
+            bool split = use_bf16x3(cfg, C) && abytes < kBufMax;
+            int nmax = N;
+            if (split && dys * 4 * N >= chunk_limit()) {
+                nmax = chunk_samples(dys * 4, 0, cfg.gscale ? cfg.group_n : 1);
+                if (nmax <= 0) { split = false; nmax = N; }
+            }
+            const int cOH = (H - ay + stride - 1) / stride, cOW = (W - ax + stride - 1) / stride;
+            if ((long long)nmax * cOH * cOW >= (1LL << 31)) {
+                nmax = (int)(((1LL << 31) - 1) / ((long long)cOH * cOW));
+                if (cfg.gscale) nmax -= nmax % cfg.group_n;
+                if (nmax <= 0) return AG2V_EINVAL;
+            }
             const bool tapmaj = igemm_tap_major(K, split);
             if (tapmaj)
                 hipLaunchKernelGGL(pack_dgrad_tap_kernel, dim3(ceil_div(C, 64), K / 8), dim3(256), 0, st, w, at, K, C, R, S, py, px,
@@ -820,72 +895,86 @@ extern "C" int ag2v_conv2d_dgrad_acc(const float* dy, const float* w, const floa
             else
                 hipLaunchKernelGGL(dgrad_weight_prep_kernel, dim3(ceil_div(C, 64), K), dim3(256), 0, st, w, at, K, C, R, S, py, px,
                                    stride, Rc, Sc, split ? 1 : 0);
-            ConvArgs f{};
-            f.tap_major = tapmaj ? 1 : 0;
-            f.a_src = at; f.b_src = dy; f.out = dx;
-            f.N = N; f.C = K; f.H = OH; f.W = OW; f.K = C; f.R = Rc; f.S = Sc; f.stride = 1;
-            f.pad = Rc - 1 - q0y; f.pad_w = Sc - 1 - q0x;
-            f.OH = (H - ay + stride - 1) / stride; f.OW = (W - ax + stride - 1) / stride;
-            f.o_mul = stride; f.o_add_y = ay; f.o_add_x = ax; f.o_H = H; f.o_W = W;
-            if ((long long)N * f.OH * f.OW >= (1LL << 31)) return AG2V_EINVAL;
-            f.M = C; f.NG = N * f.OH * f.OW; f.KG = K * Rc * Sc;
-            f.a_bytes = (unsigned)abytes; f.b_bytes = (unsigned)bbytes;
-            f.mask = multi ? nullptr : mask;     // one class (stride 1): in the epilogue; several classes: one pass at the end
-            // accumulate: a split-K launch adds onto the existing dx with its atomics (no zeroing); any other launch reads dx
-            // back as the epilogue's residual term (each element is read and written by the same thread)
-            f.residual = accumulate ? dx : nullptr;
-            const int rc = launch_igemm(f, st, multi || accumulate != 0, split);
-            if (rc != AG2V_OK) return rc;
+            for (int n0 = 0; n0 < N; n0 += nmax) {
+                const int nc = (N - n0 < nmax) ? N - n0 : nmax;
+                float* dxc = dx + (size_t)n0 * dxs;
+                ConvArgs f{};
+                f.tap_major = tapmaj ? 1 : 0;
+                f.a_src = at; f.b_src = dy + (size_t)n0 * dys; f.out = dxc;
+                f.N = nc; f.C = K; f.H = OH; f.W = OW; f.K = C; f.R = Rc; f.S = Sc; f.stride = 1;
+                f.pad = Rc - 1 - q0y; f.pad_w = Sc - 1 - q0x;
+                f.OH = cOH; f.OW = cOW;
+                f.o_mul = stride; f.o_add_y = ay; f.o_add_x = ax; f.o_H = H; f.o_W = W;
+                f.M = C; f.NG = nc * f.OH * f.OW; f.KG = K * Rc * Sc;
+                f.a_bytes = (unsigned)abytes; f.b_bytes = split ? (unsigned)(dys * 4 * nc) : 0u;
+                f.gscale = cfg.gscale ? cfg.gscale + n0 / cfg.group_n : nullptr; f.group_n = cfg.group_n;
+                // one class (stride 1): the mask in the epilogue; several classes: one pass at the end
+                f.mask = (multi || !mask) ? nullptr : mask + (size_t)n0 * dxs;
+                // accumulate: a split-K launch adds onto the existing dx with its atomics (no zeroing); any other launch reads dx
+                // back as the epilogue's residual term (each element is read and written by the same thread)
+                f.residual = accumulate ? dxc : nullptr;
+                const int rc = launch_igemm(f, st, multi || accumulate != 0, split);
+                if (rc != AG2V_OK) return rc;
+            }
             at += (size_t)K * C * Rc * Sc;
         }
+    if (o) o->kernel = g_last_conv_kernel;
     if (multi && mask) return launch_act_mask(dx, mask, (long long)N * C * H * W, 0, st);
     return AG2V_OK;
 }
-
-// accumulate != 0: dw += instead of dw = : a weight used by several forward calls of one step (the 15 frame passes of the
-// generator) collects its gradient in one buffer instead of one tensor per call plus autograd's pairwise sums.
-extern "C" int ag2v_conv2d_wgrad_acc(const float* dy, const float* x, float* dw, int N, int C, int H, int W, int K, int R, int S,
-                                     int stride, int pad, int accumulate, void* stream);
-extern "C" int ag2v_conv2d_wgrad(const float* dy, const float* x, float* dw,
-                                 int N, int C, int H, int W, int K, int R, int S, int stride, int pad, void* stream) {
-    return ag2v_conv2d_wgrad_acc(dy, x, dw, N, C, H, W, K, R, S, stride, pad, 0, stream);
+// The forms without options: process-default arithmetic, no group scale; the <= 4-channel intermediate does not fit the
+// C*K*R*S-float workspace these take, so that case runs on the general kernels here (the product passes the full workspace).
+extern "C" int ag2v_conv2d_dgrad_acc(const float* dy, const float* w, const float* mask, float* dx,
+                                     int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int accumulate,
+                                     float* workspace, void* stream) {
+    return ag2v_conv2d_dgrad_ex(dy, w, mask, dx, N, C, H, W, K, R, S, stride, pad, accumulate, workspace, (size_t)C * K * R * S,
+                                stream, nullptr);
 }
-extern "C" int ag2v_conv2d_wgrad_acc(const float* dy, const float* x, float* dw, int N, int C, int H, int W, int K, int R, int S,
-                                     int stride, int pad, int accumulate, void* stream) {
-    if (!dy || !x || !dw || N <= 0 || C <= 0 || K <= 0 || stride <= 0) return AG2V_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
+extern "C" int ag2v_conv2d_dgrad_masked(const float* dy, const float* w, const float* mask, float* dx,
+                                        int N, int C, int H, int W, int K, int R, int S, int stride, int pad, float* workspace,
+                                        void* stream) {
+    return ag2v_conv2d_dgrad_acc(dy, w, mask, dx, N, C, H, W, K, R, S, stride, pad, 0, workspace, stream);
+}
+extern "C" int ag2v_conv2d_dgrad(const float* dy, const float* w, float* dx,
+                                 int N, int C, int H, int W, int K, int R, int S, int stride, int pad, float* workspace,
+                                 void* stream) {
+    return ag2v_conv2d_dgrad_acc(dy, w, nullptr, dx, N, C, H, W, K, R, S, stride, pad, 0, workspace, stream);
+}
+
+// Weight gradient.  accumulate != 0: dw += instead of dw = : a weight used by several forward calls of one step collects its
+// gradient in one buffer.  groups > 1 (N % groups == 0): the batch is `groups` consecutive sample groups and dw is
+// [groups][K, C, R, S] -- one gradient per group (the frame-batched generator needs dL/dWbar_t per frame t for spectral norm).
+static int wgrad_launch(const float* dy, const float* x, float* dw, int N, int C, int H, int W, int K, int R, int S, int OH, int OW,
+                        int stride, int pad, int accumulate, int groups, bool split, hipStream_t st) {
     ConvArgs a{};
     a.a_src = dy; a.b_src = x; a.out = dw; a.accumulate = accumulate ? 1 : 0;
     a.N = N; a.C = C; a.H = H; a.W = W; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.pad_w = pad;
-    a.OH = conv_out_dim(H, R, stride, pad); a.OW = conv_out_dim(W, S, stride, pad);
-    if (a.OH <= 0 || a.OW <= 0) return AG2V_EINVAL;
-    const long long Q = (long long)N * a.OH * a.OW;
-    if (Q >= (1LL << 31) || (long long)C * H * W >= (1LL << 31)) return AG2V_EINVAL;
+    a.OH = OH; a.OW = OW;
+    const long long Q = (long long)N * OH * OW;
     a.M = K; a.NG = C * R * S; a.KG = (int)Q;
-    {
-        const long long abytes = (long long)N * K * a.OH * a.OW * 4, bbytes = (long long)N * C * H * W * 4;
-        if (use_bf16x3(a.M) && abytes < kBufMax && bbytes < kBufMax) {
-            a.a_bytes = (unsigned)abytes; a.b_bytes = (unsigned)bbytes;
-            return launch_wgrad_bf16x3(a, st);
-        }
+    a.groups = groups; a.gq = (int)(Q / groups); a.out_gstride = (long long)a.M * a.NG;
+    if (split) {
+        a.a_bytes = (unsigned)((long long)N * K * OH * OW * 4); a.b_bytes = (unsigned)((long long)N * C * H * W * 4);
+        return launch_wgrad_bf16x3(a, st);
     }
     int bm = (a.M <= 32) ? 32 : (a.M <= 64 ? 64 : 128);
     a.tiles_m = ceil_div(a.M, bm);
     a.tiles_n = ceil_div(a.NG, 128);
     const int tiles = a.tiles_m * a.tiles_n;
-    // split the pixel reduction so that ~1536 workgroups are in flight (256 CUs x up to 4 resident + slack)
-    int splitk = ceil_div(1536, tiles);
-    const int max_split = (int)((Q + 511) / 512);
-    if (splitk > max_split) splitk = max_split;
-    if (splitk < 1) splitk = 1;
-    int kchunk = (int)((Q + splitk - 1) / splitk);
+    // split each group's pixel reduction so that ~1536 workgroups are in flight (256 CUs x up to 4 resident + slack)
+    const long long Qg = a.gq;
+    int spg = ceil_div(1536, (long long)tiles * groups);
+    const int max_split = (int)((Qg + 511) / 512);
+    if (spg > max_split) spg = max_split;
+    if (spg < 1) spg = 1;
+    int kchunk = (int)((Qg + spg - 1) / spg);
     kchunk = ((kchunk + 15) / 16) * 16;
-    splitk = (int)((Q + kchunk - 1) / kchunk);
-    a.splitk = splitk; a.kchunk = kchunk;
-    if (splitk > 1 && !a.accumulate) {
-        if (hipMemsetAsync(dw, 0, (size_t)a.M * a.NG * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
+    spg = (int)((Qg + kchunk - 1) / kchunk);
+    a.spg = spg; a.splitk = spg * groups; a.kchunk = kchunk;
+    if (spg > 1 && !a.accumulate) {
+        if (hipMemsetAsync(dw, 0, (size_t)a.M * a.NG * groups * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
     }
-    dim3 grid(tiles, splitk);
+    dim3 grid(tiles, a.splitk);
     if (bm == 32)
         { set_last_conv_kernel("conv_wgrad_kernel<32, 128, 1, 4>"); hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4>), grid, dim3(256), 0, st, a); }
     else if (bm == 64)
@@ -894,4 +983,47 @@ extern "C" int ag2v_conv2d_wgrad_acc(const float* dy, const float* x, float* dw,
         { set_last_conv_kernel("conv_wgrad_kernel<128, 128, 2, 2>"); hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, a); }
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
+}
+extern "C" int ag2v_conv2d_wgrad_ex(const float* dy, const float* x, float* dw, int N, int C, int H, int W, int K, int R, int S,
+                                    int stride, int pad, int accumulate, int groups, void* stream, ag2v_conv_opts* o) {
+    if (!dy || !x || !dw || N <= 0 || C <= 0 || K <= 0 || stride <= 0 || groups <= 0 || N % groups != 0) return AG2V_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const ConvCfg cfg = conv_cfg(o);
+    const int OH = conv_out_dim(H, R, stride, pad), OW = conv_out_dim(W, S, stride, pad);
+    if (OH <= 0 || OW <= 0) return AG2V_EINVAL;
+    const long long dys = (long long)K * OH * OW, xs = (long long)C * H * W;
+    if (xs >= (1LL << 31) || dys >= (1LL << 31)) return AG2V_EINVAL;
+    const int Ng = N / groups;
+    bool split = use_bf16x3(cfg, K);
+    // samples per launch: whole groups, both operands below 4 GiB for the bf16x3 kernels, pixel index below 2^31
+    int nmax = N;
+    if (split && (dys * 4 * N >= chunk_limit() || xs * 4 * N >= chunk_limit())) {
+        nmax = chunk_samples(dys * 4, xs * 4, Ng);
+        if (nmax <= 0) { split = false; nmax = N; }
+    }
+    if ((long long)nmax * OH * OW >= (1LL << 31)) {
+        nmax = (int)(((1LL << 31) - 1) / ((long long)OH * OW));
+        nmax -= nmax % Ng;
+        if (nmax <= 0) return AG2V_EINVAL;
+    }
+    const size_t wsz = (size_t)K * C * R * S;
+    for (int n0 = 0; n0 < N; n0 += nmax) {
+        const int nc = (N - n0 < nmax) ? N - n0 : nmax;
+        const int g0 = n0 / Ng, gc = (groups > 1) ? nc / Ng : 1;
+        float* out = (groups > 1) ? dw + (size_t)g0 * wsz : dw;
+        const int acc = (groups > 1) ? accumulate : (accumulate || n0 > 0);
+        const int rc = wgrad_launch(dy + (size_t)n0 * dys, x + (size_t)n0 * xs, out, nc, C, H, W, K, R, S, OH, OW, stride, pad, acc, gc,
+                                    split, st);
+        if (rc != AG2V_OK) return rc;
+    }
+    if (o) o->kernel = g_last_conv_kernel;
+    return AG2V_OK;
+}
+extern "C" int ag2v_conv2d_wgrad_acc(const float* dy, const float* x, float* dw, int N, int C, int H, int W, int K, int R, int S,
+                                     int stride, int pad, int accumulate, void* stream) {
+    return ag2v_conv2d_wgrad_ex(dy, x, dw, N, C, H, W, K, R, S, stride, pad, accumulate, 1, stream, nullptr);
+}
+extern "C" int ag2v_conv2d_wgrad(const float* dy, const float* x, float* dw,
+                                 int N, int C, int H, int W, int K, int R, int S, int stride, int pad, void* stream) {
+    return ag2v_conv2d_wgrad_ex(dy, x, dw, N, C, H, W, K, R, S, stride, pad, 0, 1, stream, nullptr);
 }

@@ -56,9 +56,11 @@ __device__ __forceinline__ void store16(float* __restrict__ p, int cnt, const fl
 
 // ---------------------------------------------------------------- batch statistics
 // partial[(c*nparts + part)*3 + {0,1,2}] = {count, mean, M2}
+// Sample groups (frame-batched generator: statistics per frame group of Ng samples, as the T separate F.batch_norm calls of the
+// reference's frame loop compute them): "channel" gc = (n / Ng) * C + c has nparts = Ng * nchunk parts.  Ng == N: plain batch norm.
 template <bool VEC>
 __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
-                                                               int N, int C, int HW, int nchunk) {
+                                                               int Ng, int C, int HW, int nchunk) {
     __shared__ float sh[4];
     const int bid = blockIdx.x;
     const int chunk = bid % nchunk, nc = bid / nchunk;
@@ -81,37 +83,44 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
     }
     m2 = block_sum_256(m2, sh);
     if (threadIdx.x == 0) {
-        const int nparts = N * nchunk;
-        float* o = partial + ((size_t)c * nparts + (size_t)n * nchunk + chunk) * 3;
+        const int nparts = Ng * nchunk;
+        const int g = n / Ng, nl = n - g * Ng;
+        float* o = partial + ((size_t)(g * C + c) * nparts + (size_t)nl * nchunk + chunk) * 3;
         o[0] = (float)cnt; o[1] = mean; o[2] = m2;
     }
 }
 
-// One thread per channel: Chan's parallel combine in double; writes mean / invstd (biased var, +eps) and updates the
-// running statistics exactly as F.batch_norm(training=True, momentum) does (unbiased var in the running buffer).
-__global__ void bn_stats_finalize_kernel(const float* __restrict__ partial, int C, int nparts, float eps, float momentum,
+// One thread per channel: Chan's parallel combine in double per group; writes mean / invstd (biased var, +eps) of every group and
+// applies the G momentum updates of the running statistics IN GROUP ORDER, exactly as G consecutive
+// F.batch_norm(training=True, momentum) calls do (unbiased var in the running buffer).
+__global__ void bn_stats_finalize_kernel(const float* __restrict__ partial, int G, int C, int nparts, float eps, float momentum,
                                          float* __restrict__ mean_out, float* __restrict__ invstd_out,
                                          float* __restrict__ running_mean, float* __restrict__ running_var) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const float* p = partial + (size_t)c * nparts * 3;
-    double n = 0.0, mean = 0.0, m2 = 0.0;
-    for (int i = 0; i < nparts; ++i) {
-        const double nb = p[3 * i], mb = p[3 * i + 1], m2b = p[3 * i + 2];
-        const double nt = n + nb;
-        const double d = mb - mean;
-        mean += d * (nb / nt);
-        m2 += m2b + d * d * (n * nb / nt);
-        n = nt;
+    double rm = running_mean ? (double)running_mean[c] : 0.0, rv = running_mean ? (double)running_var[c] : 0.0;
+    for (int g = 0; g < G; ++g) {
+        const float* p = partial + (size_t)(g * C + c) * nparts * 3;
+        double n = 0.0, mean = 0.0, m2 = 0.0;
+        for (int i = 0; i < nparts; ++i) {
+            const double nb = p[3 * i], mb = p[3 * i + 1], m2b = p[3 * i + 2];
+            const double nt = n + nb;
+            const double d = mb - mean;
+            mean += d * (nb / nt);
+            m2 += m2b + d * d * (n * nb / nt);
+            n = nt;
+        }
+        const double var = m2 / n;
+        mean_out[g * C + c] = (float)mean;
+        invstd_out[g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (running_mean) {
+            const double unb = (n > 1.0) ? m2 / (n - 1.0) : var;
+            // each update rounds to fp32 as the separate calls would
+            rm = (double)(float)((1.0 - momentum) * rm + momentum * mean);
+            rv = (double)(float)((1.0 - momentum) * rv + momentum * unb);
+        }
     }
-    const double var = m2 / n;
-    mean_out[c] = (float)mean;
-    invstd_out[c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (running_mean) {
-        const double unb = (n > 1.0) ? m2 / (n - 1.0) : var;
-        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
-        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
-    }
+    if (running_mean) { running_mean[c] = (float)rm; running_var[c] = (float)rv; }
 }
 
 // ---------------------------------------------------------------- fused normalise (+affine | +SPADE) (+LeakyReLU)
@@ -121,14 +130,15 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
                                                          const float* __restrict__ invstd, const float* __restrict__ w,
                                                          const float* __restrict__ b, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* __restrict__ y, int C,
-                                                         int HW, int nchunk, float slope, long long gbx) {
+                                                         int HW, int nchunk, float slope, long long gbx, int Ng) {
     const int bid = blockIdx.x;
     const int chunk = bid % nchunk, nc = bid / nchunk;
     const int c = nc % C;
+    const int gc = ((nc / C) / Ng) * C + c;          // statistics of this sample's group
     const int start = chunk * CHUNK;
     const int cnt = min(CHUNK, HW - start);
     const size_t off = (size_t)nc * HW + start;
-    const float mu = mean[c], is = invstd[c];
+    const float mu = mean[gc], is = invstd[gc];
     float v[16], g[16], be[16];
     unsigned mask;
     load16<VEC>(x + off, cnt, v, mask);
@@ -152,16 +162,17 @@ template <int MODE, bool VEC>
 __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                               const float* __restrict__ x, const float* __restrict__ gamma,
                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                              float* __restrict__ partial, int N, int C, int HW, int nchunk,
+                                                              float* __restrict__ partial, int Ng, int C, int HW, int nchunk,
                                                               float slope, long long gbx) {
     __shared__ float sh[4];
     const int bid = blockIdx.x;
     const int chunk = bid % nchunk, nc = bid / nchunk;
     const int n = nc / C, c = nc - n * C;
+    const int grp = n / Ng, nl = n - grp * Ng, gc = grp * C + c;
     const int start = chunk * CHUNK;
     const int cnt = min(CHUNK, HW - start);
     const size_t off = (size_t)nc * HW + start;
-    const float mu = mean[c], is = invstd[c];
+    const float mu = mean[gc], is = invstd[gc];
     float g[16], xv[16], t[16];
     unsigned mask;
     load16<VEC>(dy + off, cnt, g, mask);
@@ -185,8 +196,8 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __res
     s1 = block_sum_256(s1, sh);
     s2 = block_sum_256(s2, sh);
     if (threadIdx.x == 0) {
-        const int nparts = N * nchunk;
-        float* o = partial + ((size_t)c * nparts + (size_t)n * nchunk + chunk) * 2;
+        const int nparts = Ng * nchunk;
+        float* o = partial + ((size_t)gc * nparts + (size_t)nl * nchunk + chunk) * 2;
         o[0] = s1; o[1] = s2;
     }
 }
@@ -212,15 +223,16 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
                                                              const float* __restrict__ invstd, const float* __restrict__ sums,
                                                              float* __restrict__ dx, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta, int C, int HW, int nchunk,
-                                                             float inv_count, float slope, long long gbx) {
+                                                             float inv_count, float slope, long long gbx, int Ng) {
     const int bid = blockIdx.x;
     const int chunk = bid % nchunk, nc = bid / nchunk;
     const int c = nc % C;
+    const int gc = ((nc / C) / Ng) * C + c;
     const int start = chunk * CHUNK;
     const int cnt = min(CHUNK, HW - start);
     const size_t off = (size_t)nc * HW + start;
-    const float mu = mean[c], is = invstd[c];
-    const float m1 = sums[2 * c] * inv_count, m2 = sums[2 * c + 1] * inv_count;
+    const float mu = mean[gc], is = invstd[gc];
+    const float m1 = sums[2 * gc] * inv_count, m2 = sums[2 * gc + 1] * inv_count;
     float g[16], xv[16], t[16];
     unsigned mask;
     load16<VEC>(dy + off, cnt, g, mask);
@@ -327,29 +339,36 @@ extern "C" size_t ag2v_bn_workspace_floats(int N, int C, int HW) {
     return (size_t)C * N * nchunk * 3 + 2 * (size_t)C;
 }
 
-// Batch statistics of x[N,C,H*W]: mean/invstd (biased variance + eps) and, when running_* are non-null,
-// the momentum update of the running buffers.  workspace: ag2v_bn_workspace_floats() floats.
-extern "C" int ag2v_bn_stats(const float* x, int N, int C, int HW, float eps, float momentum, float* mean, float* invstd,
-                             float* running_mean, float* running_var, float* workspace, void* stream) {
-    if (!x || !mean || !invstd || !workspace || N <= 0 || C <= 0 || HW <= 0) return AG2V_EINVAL;
+// Batch statistics of x[N,C,H*W] per sample group of Ng consecutive samples (N % Ng == 0, G = N / Ng): mean / invstd [G, C]
+// (biased variance + eps) and, when running_* are non-null, the G momentum updates of the running buffers in group order.
+// workspace: ag2v_bn_workspace_floats() floats.
+extern "C" int ag2v_bn_stats_g(const float* x, int N, int C, int HW, int Ng, float eps, float momentum, float* mean, float* invstd,
+                               float* running_mean, float* running_var, float* workspace, void* stream) {
+    if (!x || !mean || !invstd || !workspace || N <= 0 || C <= 0 || HW <= 0 || Ng <= 0 || N % Ng != 0) return AG2V_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int nchunk = ceil_div(HW, CHUNK);
     const long long nblk = (long long)N * C * nchunk;
     if (nblk >= (1LL << 31)) return AG2V_EINVAL;
     if (vec_ok(HW, x))
-        hipLaunchKernelGGL(bn_stats_partial_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, st, x, workspace, N, C, HW, nchunk);
+        hipLaunchKernelGGL(bn_stats_partial_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, st, x, workspace, Ng, C, HW, nchunk);
     else
-        hipLaunchKernelGGL(bn_stats_partial_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, st, x, workspace, N, C, HW, nchunk);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, workspace, C, N * nchunk, eps, momentum,
-                       mean, invstd, running_mean, running_var);
+        hipLaunchKernelGGL(bn_stats_partial_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, st, x, workspace, Ng, C, HW, nchunk);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, workspace, N / Ng, C, Ng * nchunk, eps,
+                       momentum, mean, invstd, running_mean, running_var);
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
 }
+extern "C" int ag2v_bn_stats(const float* x, int N, int C, int HW, float eps, float momentum, float* mean, float* invstd,
+                             float* running_mean, float* running_var, float* workspace, void* stream) {
+    return ag2v_bn_stats_g(x, N, C, HW, N, eps, momentum, mean, invstd, running_mean, running_var, workspace, stream);
+}
 
 // mode 0: y = lrelu((x-mean)*invstd*w + b) (w/b may be null); mode 1: y = lrelu(xhat*(1+gamma)+beta). slope 1 => no activation.
-extern "C" int ag2v_norm_apply(int mode, const float* x, const float* mean, const float* invstd, const float* w, const float* b,
-                               const float* gamma, const float* beta, float* y, int N, int C, int HW, float slope, void* stream) {
-    if (!x || !mean || !invstd || !y || N <= 0 || C <= 0 || HW <= 0) return AG2V_EINVAL;
+// mean / invstd are [N / Ng, C]: sample n uses row n / Ng.
+extern "C" int ag2v_norm_apply_g(int mode, const float* x, const float* mean, const float* invstd, const float* w, const float* b,
+                                 const float* gamma, const float* beta, float* y, int N, int C, int HW, int Ng, float slope,
+                                 void* stream) {
+    if (!x || !mean || !invstd || !y || N <= 0 || C <= 0 || HW <= 0 || Ng <= 0 || N % Ng != 0) return AG2V_EINVAL;
     if (mode < 0 || mode > 2 || (mode >= 1 && (!gamma || !beta))) return AG2V_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int nchunk = ceil_div(HW, CHUNK);
@@ -359,23 +378,28 @@ extern "C" int ag2v_norm_apply(int mode, const float* x, const float* mean, cons
     const long long gbx = (mode == 2) ? (long long)C * HW : 0;   // mode 2: gamma / beta are the halves of one [N,2C,HW] tensor
     dim3 g((unsigned)nblk), t(256);
     if (mode == 0) {
-        if (v) hipLaunchKernelGGL((norm_apply_kernel<0, true>), g, t, 0, st, x, mean, invstd, w, b, gamma, beta, y, C, HW, nchunk, slope, gbx);
-        else hipLaunchKernelGGL((norm_apply_kernel<0, false>), g, t, 0, st, x, mean, invstd, w, b, gamma, beta, y, C, HW, nchunk, slope, gbx);
+        if (v) hipLaunchKernelGGL((norm_apply_kernel<0, true>), g, t, 0, st, x, mean, invstd, w, b, gamma, beta, y, C, HW, nchunk, slope, gbx, Ng);
+        else hipLaunchKernelGGL((norm_apply_kernel<0, false>), g, t, 0, st, x, mean, invstd, w, b, gamma, beta, y, C, HW, nchunk, slope, gbx, Ng);
     } else {
-        if (v) hipLaunchKernelGGL((norm_apply_kernel<1, true>), g, t, 0, st, x, mean, invstd, w, b, gamma, beta, y, C, HW, nchunk, slope, gbx);
-        else hipLaunchKernelGGL((norm_apply_kernel<1, false>), g, t, 0, st, x, mean, invstd, w, b, gamma, beta, y, C, HW, nchunk, slope, gbx);
+        if (v) hipLaunchKernelGGL((norm_apply_kernel<1, true>), g, t, 0, st, x, mean, invstd, w, b, gamma, beta, y, C, HW, nchunk, slope, gbx, Ng);
+        else hipLaunchKernelGGL((norm_apply_kernel<1, false>), g, t, 0, st, x, mean, invstd, w, b, gamma, beta, y, C, HW, nchunk, slope, gbx, Ng);
     }
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
 }
+extern "C" int ag2v_norm_apply(int mode, const float* x, const float* mean, const float* invstd, const float* w, const float* b,
+                               const float* gamma, const float* beta, float* y, int N, int C, int HW, float slope, void* stream) {
+    return ag2v_norm_apply_g(mode, x, mean, invstd, w, b, gamma, beta, y, N, C, HW, N, slope, stream);
+}
 
-// Backward of ag2v_norm_apply with batch statistics (training mode).
-//   sums[2C] receives (sum dxhat, sum dxhat*xhat) per channel: for mode 0 these are (dbias, dweight).
+// Backward of ag2v_norm_apply_g with batch statistics (training mode).
+//   sums[G*2C] receives (sum dxhat, sum dxhat*xhat) per (group, channel): for mode 0 these are the groups' (dbias, dweight).
 //   mode 1 additionally writes dgamma/dbeta (same shape as x).  y is the forward output (activation sign); may be null if slope==1.
-extern "C" int ag2v_norm_bwd(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* w,
-                             const float* mean, const float* invstd, float* dx, float* dgamma, float* dbeta, float* sums,
-                             int N, int C, int HW, float slope, float* workspace, void* stream) {
-    if (!dy || !x || !mean || !invstd || !dx || !sums || !workspace || N <= 0 || C <= 0 || HW <= 0) return AG2V_EINVAL;
+extern "C" int ag2v_norm_bwd_g(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* w,
+                               const float* mean, const float* invstd, float* dx, float* dgamma, float* dbeta, float* sums,
+                               int N, int C, int HW, int Ng, float slope, float* workspace, void* stream) {
+    if (!dy || !x || !mean || !invstd || !dx || !sums || !workspace || N <= 0 || C <= 0 || HW <= 0 || Ng <= 0 || N % Ng != 0)
+        return AG2V_EINVAL;
     if (slope != 1.f && !y) return AG2V_EINVAL;
     if (mode < 0 || mode > 2 || (mode >= 1 && (!gamma || !dgamma || !dbeta))) return AG2V_EINVAL;
     hipStream_t st = (hipStream_t)stream;
@@ -385,13 +409,14 @@ extern "C" int ag2v_norm_bwd(int mode, const float* dy, const float* y, const fl
     const bool v = vec_ok(HW, dy, y, x, gamma, dx, dgamma, dbeta);
     const long long gbx = (mode == 2) ? (long long)C * HW : 0;   // mode 2: gamma, dgamma / dbeta are halves of [N,2C,HW] tensors
     dim3 g((unsigned)nblk), t(256);
-    const float inv_count = 1.0f / ((float)N * (float)HW);
+    const int GC = (N / Ng) * C;
+    const float inv_count = 1.0f / ((float)Ng * (float)HW);
 #define LAUNCH_BWD(M, V)                                                                                                         \
-    hipLaunchKernelGGL((norm_bwd_reduce_kernel<M, V>), g, t, 0, st, dy, y, x, gamma, mean, invstd, workspace, N, C, HW, nchunk, \
+    hipLaunchKernelGGL((norm_bwd_reduce_kernel<M, V>), g, t, 0, st, dy, y, x, gamma, mean, invstd, workspace, Ng, C, HW, nchunk, \
                        slope, gbx);                                                                                              \
-    hipLaunchKernelGGL(pair_sum_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, workspace, C, N* nchunk, sums);         \
+    hipLaunchKernelGGL(pair_sum_finalize_kernel, dim3(ceil_div(GC, 64)), dim3(64), 0, st, workspace, GC, Ng* nchunk, sums);      \
     hipLaunchKernelGGL((norm_bwd_apply_kernel<M, V>), g, t, 0, st, dy, y, x, gamma, w, mean, invstd, sums, dx, dgamma, dbeta, C, \
-                       HW, nchunk, inv_count, slope, gbx);
+                       HW, nchunk, inv_count, slope, gbx, Ng);
     if (mode == 0) {
         if (v) { LAUNCH_BWD(0, true) } else { LAUNCH_BWD(0, false) }
     } else {
@@ -400,6 +425,11 @@ extern "C" int ag2v_norm_bwd(int mode, const float* dy, const float* y, const fl
 #undef LAUNCH_BWD
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
+}
+extern "C" int ag2v_norm_bwd(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* w,
+                             const float* mean, const float* invstd, float* dx, float* dgamma, float* dbeta, float* sums,
+                             int N, int C, int HW, float slope, float* workspace, void* stream) {
+    return ag2v_norm_bwd_g(mode, dy, y, x, gamma, w, mean, invstd, dx, dgamma, dbeta, sums, N, C, HW, N, slope, workspace, stream);
 }
 
 extern "C" int ag2v_instnorm_lrelu_fwd(const float* x, float* y, float* mean, float* invstd, int NC, int HW, float eps,

@@ -109,7 +109,8 @@ __global__ __launch_bounds__(256) void sn_wv_kernel(const float* __restrict__ w,
 // u_used / v_used (nullable): copies of the vectors this call used, for the backward tape (the buffers keep advancing)
 __global__ __launch_bounds__(256) void sn_sigma_kernel(float* __restrict__ u, float* __restrict__ wv, float* __restrict__ v, int M,
                                                        int R, float eps, int update_u, float* __restrict__ sigma,
-                                                       float* __restrict__ u_used, float* __restrict__ v_used) {
+                                                       float* __restrict__ u_used, float* __restrict__ v_used,
+                                                       float* __restrict__ inv_sigma = nullptr) {
     __shared__ float sh[4];
     if (update_u) {
         float q = 0.f;
@@ -129,7 +130,10 @@ __global__ __launch_bounds__(256) void sn_sigma_kernel(float* __restrict__ u, fl
     float d = 0.f;
     for (int i = threadIdx.x; i < M; i += 256) d += u[i] * wv[i];
     d = block_sum_256(d, sh);
-    if (threadIdx.x == 0) sigma[0] = d;
+    if (threadIdx.x == 0) {
+        sigma[0] = d;
+        if (inv_sigma) inv_sigma[0] = 1.0f / d;
+    }
     if (u_used)
         for (int i = threadIdx.x; i < M; i += 256) u_used[i] = u[i];
     if (v_used)
@@ -257,6 +261,117 @@ extern "C" int ag2v_spectral_norm_bwd_acc(const float* dwbar, const float* wbar,
 extern "C" int ag2v_spectral_norm_bwd(const float* dwbar, const float* wbar, const float* u, const float* v, const float* sigma,
                                       int M, int R, float* dw, float* workspace, void* stream) {
     return ag2v_spectral_norm_bwd_acc(dwbar, wbar, u, v, sigma, M, R, dw, 0, workspace, stream);
+}
+
+// ---------------------------------------------------------------- spectral norm of a frame-batched forward
+// The generator runs once per generated frame (generator.py:62-87), i.e. T train-mode forward calls of every spectral-norm
+// convolution per step, each advancing (u, v) by one power iteration.  sigma_t depends on W, u, v only -- not on the data -- so
+// all T of them are produced up front and the convolution runs ONCE over the [T*B, ...] batch with the raw weight and the
+// per-frame-group output scale 1/sigma_t (ConvArgs::gscale).  Same arithmetic per iteration as ag2v_spectral_norm_fwd.
+//   sigma[T], inv_sigma[T]; u_used[T*M], v_used[T*R]: the vectors behind sigma_t (backward tape).  power_iter == 0 (eval):
+//   T must be 1 (u, v do not move: one sigma).  workspace: ag2v_spectral_workspace_floats(M).
+extern "C" int ag2v_spectral_sigmas(const float* w, float* u, float* v, int M, int R, float eps, int power_iter, int T, float* sigma,
+                                    float* inv_sigma, float* u_used, float* v_used, float* workspace, void* stream) {
+    if (!w || !u || !v || !sigma || !inv_sigma || !workspace || M <= 0 || R <= 0 || T <= 0) return AG2V_EINVAL;
+    if (!power_iter && T != 1) return AG2V_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    float* wv = workspace;
+    int msplit = 1;
+    const int rb = ceil_div(R, 256);
+    if (rb < 256 && M >= 64) { msplit = ceil_div(512, rb); if (msplit > M / 16) msplit = M / 16; if (msplit < 1) msplit = 1; }
+    const int mchunk = ceil_div(M, msplit);
+    msplit = ceil_div(M, mchunk);
+    for (int t = 0; t < T; ++t) {
+        if (power_iter) {
+            if (msplit > 1 && hipMemsetAsync(v, 0, (size_t)R * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
+            hipLaunchKernelGGL(sn_wtu_kernel, dim3(rb, msplit), dim3(256), 0, st, w, u, v, M, R, mchunk);
+        }
+        hipLaunchKernelGGL(sn_wv_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, w, v, wv, M, R);
+        hipLaunchKernelGGL(sn_sigma_kernel, dim3(1), dim3(256), 0, st, u, wv, v, M, R, eps, power_iter, sigma + t,
+                           u_used ? u_used + (size_t)t * M : nullptr, v_used ? v_used + (size_t)t * R : nullptr, inv_sigma + t);
+    }
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+
+// Backward of y_n = scale[g(n)] * conv(x_n, W) with respect to W and scale, from the per-group weight gradients
+// G[T][n] = sum_{n in group t} wgrad(dy_n, x_n) (ag2v_conv2d_wgrad_ex, groups = T):
+//   dw[i] (+)= sum_t scale[t] * G[t][i];   dscale[t] = <G[t], W>.
+// grid = blocks over i; every block accumulates its T partial dots with one atomic each into the zeroed dscale.
+__global__ __launch_bounds__(256) void sn_group_combine_kernel(const float* __restrict__ G, const float* __restrict__ w,
+                                                               const float* __restrict__ scale, int T, long long n,
+                                                               float* __restrict__ dw, float* __restrict__ dscale, int acc,
+                                                               int vecok) {
+    __shared__ float sh[4];
+    const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    const bool vec = vecok && i0 + 3 < n;
+    float wv[4] = {0.f, 0.f, 0.f, 0.f}, o[4] = {0.f, 0.f, 0.f, 0.f};
+    if (vec) {
+        const float4 t4 = *reinterpret_cast<const float4*>(w + i0);
+        wv[0] = t4.x; wv[1] = t4.y; wv[2] = t4.z; wv[3] = t4.w;
+    } else {
+        for (int k = 0; k < 4; ++k) if (i0 + k < n) wv[k] = w[i0 + k];
+    }
+    for (int t = 0; t < T; ++t) {
+        const float* g = G + (size_t)t * n;
+        float gv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (vec) {
+            const float4 t4 = *reinterpret_cast<const float4*>(g + i0);
+            gv[0] = t4.x; gv[1] = t4.y; gv[2] = t4.z; gv[3] = t4.w;
+        } else {
+            for (int k = 0; k < 4; ++k) if (i0 + k < n) gv[k] = g[i0 + k];
+        }
+        const float sc = scale[t];
+        float d = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o[k] = fmaf(sc, gv[k], o[k]); d = fmaf(gv[k], wv[k], d); }
+        d = block_sum_256(d, sh);
+        if (threadIdx.x == 0) atomicAdd(dscale + t, d);
+    }
+    if (vec) {
+        float4* dst = reinterpret_cast<float4*>(dw + i0);
+        if (acc) { const float4 p = *dst; o[0] += p.x; o[1] += p.y; o[2] += p.z; o[3] += p.w; }
+        *dst = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+        for (int k = 0; k < 4; ++k) if (i0 + k < n) dw[i0 + k] = acc ? dw[i0 + k] + o[k] : o[k];
+    }
+}
+extern "C" int ag2v_sn_group_combine(const float* G, const float* w, const float* scale, int T, long long n, float* dw, int accumulate,
+                                     float* dscale, void* stream) {
+    if (!G || !w || !scale || !dw || !dscale || T <= 0 || n <= 0) return AG2V_EINVAL;
+    // 16-byte accesses need every G[t] row aligned: n % 4 == 0 and aligned bases (else element accesses)
+    const int vecok = ((((uintptr_t)G) | ((uintptr_t)w) | ((uintptr_t)dw)) & 15) == 0 && (n & 3) == 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(dscale, 0, (size_t)T * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
+    hipLaunchKernelGGL(sn_group_combine_kernel, dim3((unsigned)ceil_div(ceil_div(n, 4LL), 256LL)), dim3(256), 0, st, G, w, scale, T, n,
+                       dw, dscale, accumulate ? 1 : 0, vecok);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+
+// Backward of scale[t] = 1 / sigma_t, sigma_t = u_t^T W v_t (u_t, v_t constants):
+//   dw[m, r] (+)= sum_t coef_t * u_t[m] * v_t[r],   coef_t = -dscale[t] * scale[t]^2.
+__global__ __launch_bounds__(256) void sn_rank_update_kernel(const float* __restrict__ u_used, const float* __restrict__ v_used,
+                                                             const float* __restrict__ dscale, const float* __restrict__ scale, int T,
+                                                             int M, int R, float* __restrict__ dw, int acc) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)M * R) return;
+    const int m = (int)(i / R), r = (int)(i - (long long)m * R);
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) {
+        const float sc = scale[t];
+        s = fmaf(-dscale[t] * sc * sc, u_used[(size_t)t * M + m] * v_used[(size_t)t * R + r], s);
+    }
+    dw[i] = acc ? dw[i] + s : s;
+}
+extern "C" int ag2v_spectral_sigmas_bwd(const float* dscale, const float* scale, const float* u_used, const float* v_used, int T,
+                                        int M, int R, float* dw, int accumulate, void* stream) {
+    if (!dscale || !scale || !u_used || !v_used || !dw || T <= 0 || M <= 0 || R <= 0) return AG2V_EINVAL;
+    const long long n = (long long)M * R;
+    hipLaunchKernelGGL(sn_rank_update_kernel, dim3((unsigned)ceil_div(n, 256LL)), dim3(256), 0, (hipStream_t)stream, u_used, v_used,
+                       dscale, scale, T, M, R, dw, accumulate ? 1 : 0);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
 }
 
 // ---------------------------------------------------------------- fused Adam over a flat parameter buffer (K15)

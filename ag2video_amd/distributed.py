@@ -95,6 +95,18 @@ def broadcast_parameters(tensors, src=0):
             dist.broadcast(t, src=src)
 
 
+def any_rank(flag, device):
+    """True on every rank iff ``flag`` is true on at least one rank (one MAX all-reduce of a single int).  The training loop uses
+    it to make skip decisions collective: the reference is ONE process, so its NaN guard (scripts/train.py:450-453) and its
+    per-step try/except (:466-468) may skip locally; with one process per GPU a rank that skipped alone would leave the other
+    ranks inside a gradient all-reduce it never enters."""
+    if not is_dist():
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(t.item() > 0)
+
+
 def shutdown():
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()

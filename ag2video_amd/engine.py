@@ -53,12 +53,22 @@ class TrainStep(object):
     def to_device(self, batch):
         return batch_to(batch, self.device)
 
-    def gd_step(self, batch, apply_updates=True):
-        """Generator step then discriminator step on one clip batch (train.py:446-464, 522-525)."""
+    def gd_step(self, batch, apply_updates=True, nan_guard=True):
+        """Generator step then discriminator step on one clip batch (train.py:446-464, 522-525).
+        nan_guard: the reference's NaN guard (train.py:450-453) -- a NaN in GAN_Img / GAN_Feat skips both updates of this
+        iteration.  The decision is COLLECTIVE (distributed.any_rank): every rank skips or none does, so the gradient
+        all-reduces below always pair up across ranks.  Returns (model_out, G_losses, D_losses); D_losses is None when skipped."""
         imgs, objs, boxes, triplets, actions, video_id = batch
         model_out = self.model(imgs, objs, triplets, actions, boxes_gt=boxes, test_mode=False, use_gt=True)
         G_losses = self.gans_model(batch, model_out, mode="compute_generator_loss")
         G_losses = {k: v.mean() for k, v in G_losses.items()}
+        if nan_guard:
+            watched = [G_losses[k] for k in ('GAN_Img', 'GAN_Feat') if k in G_losses]
+            bad = bool(torch.isnan(torch.stack([w.reshape(()) for w in watched])).any().item())   # the one host read of the step
+            if dist_utils.any_rank(bad, self.device):
+                if bad:
+                    print("Error: video_id {} is NAN!".format(video_id))
+                return model_out, G_losses, None
         self.optimizer_generator.zero_grad()
         G_losses["total_loss"].backward()
         dist_utils.average_gradients(self._gen_params, flat=getattr(self.optimizer_generator, 'flat_grad', None))

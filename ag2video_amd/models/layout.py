@@ -30,14 +30,16 @@ def render_clip_layouts(vecs, boxes, objs, vocab, H, W, frame_major=True):
     return list(out.view(Fr, B, D, H, W).unbind(0))
 
 
-def layout_conv_lowrank(weight, vecs_list, boxes_list, keep, H, W, stride=1, pad=1, residual=None, pool=0):
+def layout_conv_lowrank(weight, vecs_list, boxes_list, keep, H, W, stride=1, pad=1, residual=None, pool=0, sample_scale=None):
     """conv2d(concat_f layout_f, weight) WITHOUT materialising the layouts.
 
     A layout is a sum over objects of (vector) x (separable box weight map) (boxes_to_layout, models/layout.py:28-63), so a
     convolution of it is  sum_objects sum_taps U[obj,k,tap] * weight_map_obj(shifted)  with  U = weight . vector.
     weight [K, n_frames*D, R, R] (the layout channels of the filter, frame-major as in ``seg[:, t-nc:t+1].view(B,-1,H,W)``,
     generator.py:66); vecs_list: n_frames tensors [B, O, D]; boxes_list: n_frames tensors [B, O, 4]; keep [B, O].
-    Gradients reach ``weight`` and the vectors through the small GEMM; boxes get none (ground truth / detached)."""
+    Gradients reach ``weight`` and the vectors through the small GEMM; boxes get none (ground truth / detached).
+    sample_scale [B] (optional): the layout term of sample b is multiplied by sample_scale[b] (spectral norm's 1/sigma of that
+    sample's frame group when ``weight`` is the raw weight_orig: the term is linear in the filter)."""
     K, R = weight.shape[0], weight.shape[2]
     B, O, D = vecs_list[0].shape
     Us = []
@@ -45,6 +47,8 @@ def layout_conv_lowrank(weight, vecs_list, boxes_list, keep, H, W, stride=1, pad
         taps = weight[:, fi * D:(fi + 1) * D].permute(0, 2, 3, 1).reshape(K * R * R, D)      # [(k,r,s), d]
         Us.append(ops.linear(v, taps).view(B, O, K, R * R))
     U = torch.cat(Us, dim=1)
+    if sample_scale is not None:
+        U = U * sample_scale.view(B, 1, 1, 1)
     boxes = torch.cat(list(boxes_list), dim=1)
     keep_all = keep.to(torch.int32).repeat(1, len(vecs_list))
     return ops.layout_conv(U, boxes, keep_all, H, W, R, stride, pad, residual, pool)

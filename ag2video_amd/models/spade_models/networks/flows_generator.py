@@ -70,10 +70,16 @@ class FlowsGenerator(nn.Module):
                 if first and layout is not None:
                     vecs_list, boxes_list, keep, H = layout
                     conv, bn = m[0], m[1]
-                    w = conv.effective_weight()
+                    T = ops.current_frame_groups()
+                    if T > 1:       # frame-batched: raw weight, 1/sigma_t per frame group (SpectralConv2d.weight_and_scales)
+                        w, scales = conv.weight_and_scales()
+                        per_sample = scales.repeat_interleave(prev.shape[0] // scales.numel())
+                    else:
+                        w, scales, per_sample = conv.effective_weight(), None, None
                     nseg = w.shape[1] - prev.shape[1]
-                    y = ops.conv2d(prev, w[:, nseg:], None, conv.stride, conv.padding)
-                    y = layout_conv_lowrank(w[:, :nseg], vecs_list, boxes_list, keep, H, H, conv.stride, conv.padding, residual=y)
+                    y = ops.conv2d(prev, w[:, nseg:], None, conv.stride, conv.padding, gscale=scales)
+                    y = layout_conv_lowrank(w[:, :nseg], vecs_list, boxes_list, keep, H, H, conv.stride, conv.padding, residual=y,
+                                            sample_scale=per_sample)
                     x = bn(y, slope=0.2)
                 else:
                     x = self._conv_bn_act(m, x)

@@ -1,4 +1,6 @@
 """Layout -> video generator (reference: networks/generator.py:11-92)."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -30,7 +32,6 @@ class Layout2VidGenerator(nn.Module):
         """imgs_gt [B,F,3,H,W], objs [B,O,A], obj_vecs [B,F,O,128], layout (boxes) [B,F,O,4] ->
         (imgs [B,F,3,H,W] with frame 0 = GT, flows [B,F,2,H,W], conf [B,F,1,H,W])"""
         opt = self.opt
-        H = opt.image_size[0]
         B, Fr = layout.size(0), layout.size(1)
         att = self.attribute_embedding(objs)                                     # [B, O, 384]
         vecs = torch.cat([att.unsqueeze(1).expand(B, Fr, att.size(1), att.size(2)), obj_vecs], dim=-1)
@@ -39,8 +40,67 @@ class Layout2VidGenerator(nn.Module):
         # (layout_conv_lowrank) and the layouts are never materialised.  low_rank=False keeps the dense route.
         low_rank = getattr(opt, 'low_rank_layout', True)
         keep = remove_dummy_objects(objs, opt.vocab)
-        segs = None if low_rank else render_clip_layouts(vecs, layout, objs, opt.vocab, H, H)
         nc = self.n_frames_G - 1
+        # Teacher forcing (training: every frame pass reads GROUND-TRUTH previous frames, generator.py:71): the F - nc passes do
+        # not depend on each other and run as one frame-major batch.  test_mode / bp_prev feed generated frames back: sequential.
+        batched = (low_rank and not test_mode and not opt.bp_prev and Fr - nc > 1 and getattr(opt, 'batch_frames', True)
+                   and os.environ.get('AG2V_NO_FRAME_BATCH') is None)
+        if batched:
+            gen, flows, confs = self._frames_batched(imgs_gt, vecs, layout, keep, nc)
+        else:
+            gen, flows, confs = self._frames_sequential(imgs_gt, vecs, layout, keep, nc, objs, low_rank, test_mode)
+        imgs = torch.stack(gen, dim=1)
+        # the reference writes slot t-1 for t in [nc, Fr) into zero tensors (generator.py:57-58,78-79): nc-1 leading zero slots,
+        # the flows, one trailing zero slot
+        zf, zc = torch.zeros_like(flows[0]), torch.zeros_like(confs[0])
+        flow_prev = torch.stack([zf] * (nc - 1) + flows + [zf], dim=1)
+        conf_prev = torch.stack([zc] * (nc - 1) + confs + [zc], dim=1)
+        return imgs, flow_prev, conf_prev
+
+    def _frames_batched(self, imgs_gt, vecs, layout, keep, nc):
+        """All T = F - nc teacher-forced frame passes as ONE pass over the frame-major batch [T*B, ...] (sample t*B + b = pass
+        t + nc of clip b).  Per-pass quantities of the reference stay per frame group (ops.frame_groups): batch-norm statistics
+        and running-stat updates, spectral norm's power iterations / sigma_t.  Same arithmetic per sample as the sequential loop;
+        what changes is the launch count (1/T) and the GEMM shapes (T times the pixel columns: no split-K on the 8x8 ... 32x32
+        layers, one weight pack / power-iteration chain / weight-gradient launch per layer and step instead of T)."""
+        opt = self.opt
+        H = opt.image_size[0]
+        B, Fr = layout.size(0), layout.size(1)
+        T = Fr - nc
+
+        def fm(x, f):       # frames f .. f+T-1 of x [B, F, ...] -> frame-major [T*B, ...]
+            return x[:, f:f + T].transpose(0, 1).reshape((T * B,) + tuple(x.shape[2:]))
+        vecs_list = [fm(vecs, f) for f in range(nc + 1)]         # layouts of frames t-nc .. t
+        boxes_list = [fm(layout, f) for f in range(nc + 1)]
+        keep_t = keep.unsqueeze(0).expand(T, B, keep.size(1)).reshape(T * B, keep.size(1))
+        prev = [fm(imgs_gt, f) for f in range(nc)]               # ground-truth frames t-nc .. t-1
+        conv, bn = self.conv_dim_in[0][0], self.conv_dim_in[0][1]
+        with ops.frame_groups(T):
+            spec = (vecs_list, boxes_list, keep_t, H)
+            with ops.bf16x3_min_rows(ops.EXACT, 128):            # flow network forward exact: see _frames_sequential
+                _, flow = self.flows_network(layout=spec, prev=prev[0] if nc == 1 else torch.cat(prev, dim=1))
+            warp = resample(prev[-1], flow)
+            d = prev[-1] - warp
+            conf = (torch.sum(d * d, dim=1, keepdim=True) < 0.02).float()
+            with ops.bf16x3_min_rows(48):
+                w, scales = conv.weight_and_scales()
+                nseg = w.shape[1] - 3
+                y = ops.conv2d(warp, w[:, nseg:], None, conv.stride, conv.padding, gscale=scales)
+                y = layout_conv_lowrank(w[:, :nseg], vecs_list, boxes_list, keep_t, H, H, conv.stride, conv.padding, residual=y,
+                                        sample_scale=scales.repeat_interleave((T * B) // scales.numel()))
+                x = bn(y, slope=0.2)
+                out = self.netG(x) + warp
+        out = out.view(T, B, out.size(1), H, H)
+        flow = flow.view(T, B, 2, H, H)
+        conf = conf.view(T, B, 1, H, H)
+        gen = [imgs_gt[:, i] for i in range(nc)] + list(out.unbind(0))
+        return gen, list(flow.unbind(0)), list(conf.unbind(0))
+
+    def _frames_sequential(self, imgs_gt, vecs, layout, keep, nc, objs, low_rank, test_mode):
+        opt = self.opt
+        H = opt.image_size[0]
+        Fr = layout.size(1)
+        segs = None if low_rank else render_clip_layouts(vecs, layout, objs, opt.vocab, H, H)
         gen = [imgs_gt[:, i] for i in range(nc)]
         confs, flows = [], []
         conv, bn = self.conv_dim_in[0][0], self.conv_dim_in[0][1]
@@ -49,19 +109,23 @@ class Layout2VidGenerator(nn.Module):
                 prev = gen[-nc:]
             else:
                 prev = [imgs_gt[:, i] for i in range(t - nc, t)]
-            if low_rank:
-                frames = list(range(t - nc, t + 1))
-                spec = ([vecs[:, f] for f in frames], [layout[:, f] for f in frames], keep, H)
-                _, flow = self.flows_network(layout=spec, prev=prev[0] if nc == 1 else torch.cat(prev, dim=1))
-            else:
-                seg_t = segs[t - nc:t + 1]
-                _, flow = self.flows_network(torch.cat(seg_t + prev, dim=1))
+            # Flow network: FORWARD on the exact fp32 tiles at every width.  Its output feeds the warp, which turns a flow error
+            # into an image error of |grad image| x error: on the seeded clips the 1e-5 of the split products became 1.3e-3 of
+            # max|imgs_pred| against the oracle at the default widths (c1; limit 1e-3), with the forward exact it is 2.3e-4 -- the
+            # same as an all-fp32 run (tools/debug_c1_precision.py).  Its gradients are not amplified: backward as everywhere.
+            with ops.bf16x3_min_rows(ops.EXACT, 128):
+                if low_rank:
+                    frames = list(range(t - nc, t + 1))
+                    spec = ([vecs[:, f] for f in frames], [layout[:, f] for f in frames], keep, H)
+                    _, flow = self.flows_network(layout=spec, prev=prev[0] if nc == 1 else torch.cat(prev, dim=1))
+                else:
+                    seg_t = segs[t - nc:t + 1]
+                    _, flow = self.flows_network(torch.cat(seg_t + prev, dim=1))
             warp = resample(prev[-1], flow)
             d = prev[-1] - warp
             confs.append((torch.sum(d * d, dim=1, keepdim=True) < 0.02).float())
             flows.append(flow)
-            # Image decoder: 64-channel layers on the bf16x3 tiles too.  The flow network above keeps the library default
-            # (128 rows): its 64-channel tail feeds the warp, which amplifies the 1e-5 split error (ops.bf16x3_min_rows).
+            # Image decoder: 64-channel layers on the bf16x3 tiles too (the flow network above stays exact in its forward).
             with ops.bf16x3_min_rows(48):
                 if low_rank:
                     w = conv.effective_weight()
@@ -72,8 +136,4 @@ class Layout2VidGenerator(nn.Module):
                     y = conv(torch.cat(seg_t + [warp], dim=1))
                 x = bn(y, slope=0.2)
                 gen.append(self.netG(x) + warp)
-        imgs = torch.stack(gen, dim=1)
-        pad = Fr - len(flows)      # slots t-1 are filled; the trailing slot(s) stay zero (generator.py:57-58,78-79)
-        flow_prev = torch.stack(flows + [torch.zeros_like(flows[0])] * pad, dim=1)
-        conf_prev = torch.stack(confs + [torch.zeros_like(confs[0])] * pad, dim=1)
-        return imgs, flow_prev, conf_prev
+        return gen, flows, confs

@@ -37,7 +37,16 @@ class SpectralConv2d(nn.Module):
     def effective_weight(self):
         return ops.spectral_weight(self.weight_orig, self.weight_u, self.weight_v, self.training, self.eps)
 
+    def weight_and_scales(self):
+        """Frame-batched form: (weight_orig, [1 / sigma_t for the T frame groups of ops.frame_groups]) -- T power iterations
+        in a row, as the T forward calls of the reference's frame loop make them; conv2d(..., gscale=scales) applies them."""
+        return self.weight_orig, ops.spectral_scales(self.weight_orig, self.weight_u, self.weight_v, ops.current_frame_groups(),
+                                                     self.training, self.eps)
+
     def forward(self, x, residual=None):
+        if ops.current_frame_groups() > 1:
+            w, scales = self.weight_and_scales()
+            return ops.conv2d(x, w, self.bias, self.stride, self.padding, residual, gscale=scales)
         return ops.conv2d(x, self.effective_weight(), self.bias, self.stride, self.padding, residual)
 
 

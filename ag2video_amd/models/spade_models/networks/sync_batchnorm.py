@@ -41,14 +41,16 @@ class SynchronizedBatchNorm2d(nn.Module):
         self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
 
     def forward(self, x, slope=1.0):
+        # inside ops.frame_groups(T): statistics per frame group, T running-stat updates in order (see ops.frame_groups)
         return ops.batchnorm_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
-                                 self.momentum, self.eps, slope)
+                                 self.momentum, self.eps, slope, groups=ops.current_frame_groups())
 
     def modulate(self, x, gamma, beta, slope=1.0):
         """SPADE use: normalise without affine and apply (1+gamma), beta in the same pass."""
         return ops.spade_norm(x, gamma, beta, self.running_mean, self.running_var, self.training, self.momentum, self.eps,
-                              slope)
+                              slope, groups=ops.current_frame_groups())
 
     def modulate_fused(self, x, gb, slope=1.0):
         """modulate() with gamma | beta as the channel halves of one [N, 2C, H, W] tensor."""
-        return ops.spade_norm_fused(x, gb, self.running_mean, self.running_var, self.training, self.momentum, self.eps, slope)
+        return ops.spade_norm_fused(x, gb, self.running_mean, self.running_var, self.training, self.momentum, self.eps, slope,
+                                    groups=ops.current_frame_groups())

@@ -4,6 +4,7 @@ PyTorch supplies device memory, the current HIP stream and the autograd tape; al
 in the hand-written gfx950 kernels of ag2video_amd/csrc.  Every operator requires CUDA(HIP) fp32 tensors and raises
 otherwise -- there is no CPU path in the product (tests/ check these operators against oracle/ on the GPU).
 """
+import ctypes
 import os
 import weakref
 
@@ -37,16 +38,18 @@ def _c(t):
 
 
 _PRECISIONS = {'fp32': 0, 'bf16x3': 1}
+_PRECISION = [_PRECISIONS.get(os.environ.get('AG2V_CONV_PRECISION', 'bf16x3'), 1)]
 
 
 def set_conv_precision(name):
-    """'bf16x3' (default): conv GEMMs with >64 output channels multiply 3-term bf16 splits on the bf16 MFMA pipe with fp32
-    accumulation (fp32-level accuracy, ~1.6-2x the exact path); 'fp32': exact fp32 MFMA everywhere."""
-    _lib.call('ag2v_set_conv_precision', _PRECISIONS[name])
+    """'bf16x3' (default): conv GEMMs with enough rows multiply 3-term bf16 splits on the bf16 MFMA pipe with fp32 accumulation
+    (fp32-level accuracy, ~1.6-2x the exact path); 'fp32': exact fp32 MFMA everywhere.  The value is handed to the library with
+    every call (ag2v_conv_opts.precision); nothing process-wide changes in the library."""
+    _PRECISION[0] = _PRECISIONS[name]
 
 
 def get_conv_precision():
-    return {v: k for k, v in _PRECISIONS.items()}[_lib.query('ag2v_get_conv_precision')]
+    return {v: k for k, v in _PRECISIONS.items()}[_PRECISION[0]]
 
 
 # ---- optional per-launch timing of the convolution kernels (bench.py's roofline leg): HIP events on the launch stream
@@ -83,11 +86,11 @@ _MIN_ROWS_STACK = []
 
 
 class bf16x3_min_rows(object):
-    """Context manager: convolutions *created* inside (forward and, later, their backward) send GEMMs with at least ``rows``
-    rows to the bf16x3 tiles."""
+    """Context manager: convolutions *created* inside send GEMMs with at least ``rows`` rows to the bf16x3 tiles in their forward
+    pass and with at least ``bwd_rows`` (default: the same) in their backward pass (data / weight gradient)."""
 
-    def __init__(self, rows):
-        self.rows = int(rows)
+    def __init__(self, rows, bwd_rows=None):
+        self.rows = (int(rows), int(rows if bwd_rows is None else bwd_rows))
 
     def __enter__(self):
         _MIN_ROWS_STACK.append(self.rows)
@@ -98,8 +101,36 @@ class bf16x3_min_rows(object):
         return False
 
 
+EXACT = 1 << 30      # a row threshold no GEMM reaches: exact fp32 MFMA
+
+# ---- frame groups.  In training the generator's frame loop is teacher-forced (generator.py:71): its T = F - n_frames_G + 1 passes
+# are data-independent and run here as ONE pass over a frame-major [T*B, ...] batch.  What the reference computes per PASS stays
+# per frame group: batch-norm statistics (+ one running-stat update per pass, in order) and spectral norm's sigma_t (+ one power
+# iteration per pass).  Modules read the group count from this context (SynchronizedBatchNorm2d, SpectralConv2d).
+_FRAME_GROUPS = [1]
+
+
+class frame_groups(object):
+    def __init__(self, T):
+        self.T = int(T)
+
+    def __enter__(self):
+        _FRAME_GROUPS.append(self.T)
+        return self
+
+    def __exit__(self, *exc):
+        _FRAME_GROUPS.pop()
+        return False
+
+
+def current_frame_groups():
+    return _FRAME_GROUPS[-1]
+
+
+
 def _current_min_rows():
-    return _MIN_ROWS_STACK[-1] if _MIN_ROWS_STACK else None
+    """(forward threshold, backward threshold), or (None, None) = library default."""
+    return _MIN_ROWS_STACK[-1] if _MIN_ROWS_STACK else (None, None)
 
 
 def _conv_label(mode, M, min_rows=None):
@@ -107,16 +138,23 @@ def _conv_label(mode, M, min_rows=None):
     return "conv_%s" % mode
 
 
-def _conv_launch(min_rows, name, label, flops, *args, shape=None):
-    """_launch with the library's bf16x3 row threshold set to ``min_rows`` for this call (None: library default)."""
-    if min_rows is None:
-        return _launch(name, label, flops, *args, shape=shape)
-    old = _lib.query('ag2v_get_bf16x3_min_rows')
-    _lib.call('ag2v_set_bf16x3_min_rows', min_rows)
-    try:
-        _launch(name, label, flops, *args, shape=shape)
-    finally:
-        _lib.call('ag2v_set_bf16x3_min_rows', old)
+def _conv_launch(min_rows, name, label, flops, *args, shape=None, gscale=None, group_n=1):
+    """One ag2v_conv2d_*_ex call.  Arithmetic (precision, bf16x3 row threshold: ``min_rows``, None = library default) and the
+    per-sample-group output scale travel as per-call options (ag2v_conv_opts): no process-wide switch is touched."""
+    opts = _lib.ConvOpts(_PRECISION[0], int(min_rows) if min_rows else 0, None if gscale is None else gscale.data_ptr(),
+                         int(group_n), None)
+    args = args + (ctypes.byref(opts),)
+    if _TIMING is None or _PAUSED:
+        _lib.call(name, *args)
+        return
+    e0 = _EVENT_POOL.pop() if _EVENT_POOL else torch.cuda.Event(enable_timing=True)
+    e1 = _EVENT_POOL.pop() if _EVENT_POOL else torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _lib.call(name, *args)
+    e1.record()
+    # key the record on the HIP kernel the library chose (tile shape / arithmetic / load path), as rocprofv3 names it; the
+    # pass (fwd / dgrad / wgrad) stays in front because forward and data gradient share the implicit-GEMM kernels
+    _TIMING.append(("%s:%s" % (label, (opts.kernel or b'?').decode()), flops, e0, e1, shape))
 
 
 _PAUSED = False
@@ -137,10 +175,6 @@ def _launch(name, label, flops, *args, shape=None):
     e0.record()
     _lib.call(name, *args)
     e1.record()
-    if name.startswith('ag2v_conv2d_'):
-        # key the record on the HIP kernel the library chose (tile shape / arithmetic / load path), as rocprofv3 names it; the
-        # pass (fwd / dgrad / wgrad) stays in front because forward and data gradient share the implicit-GEMM kernels
-        label = "%s:%s" % (label, _lib.query('ag2v_last_conv_kernel').decode())
     _TIMING.append((label, flops, e0, e1, shape))
 
 
@@ -261,31 +295,64 @@ def _wsink_take_group(keys, likes):
 
 
 # ------------------------------------------------------------------------------------------------ convolution
+def _conv_fwd_launch(mr, x, w, bias, residual, y, stride, pad, relu, gscale=None, group_n=1):
+    N, C, H, W = x.shape
+    K, _, R, S = w.shape
+    ws = torch.empty(_lib.query('ag2v_conv2d_workspace_floats', C, K, R, S), device=x.device, dtype=torch.float32)
+    _conv_launch(mr, 'ag2v_conv2d_fwd_ex', 'conv_fwd', 2.0 * N * K * y.shape[2] * y.shape[3] * C * R * S,
+                 _ptr(x), _ptr(w), _ptr(bias), _ptr(residual), _ptr(y), N, C, H, W, K, R, S, stride, pad, 1 if relu else 0,
+                 _ptr(ws), _stream(), shape=(N, C, H, W, K, R, stride), gscale=gscale, group_n=group_n)
+
+
+def _conv_dgrad_launch(mr, dy, w, mask, dx, stride, pad, acc, gscale=None, group_n=1):
+    """dx (+)= data gradient.  The workspace holds the re-ordered filters and, for <= 4 input channels, the intermediate of the
+    1x1-GEMM form (caller memory: the library allocates nothing)."""
+    N, C, H, W = dx.shape
+    K, _, R, S = w.shape
+    nws = _lib.query('ag2v_conv2d_dgrad_workspace_floats', N, C, H, W, K, R, S, stride, pad)
+    ws = torch.empty(nws, device=dy.device, dtype=torch.float32)
+    _conv_launch(mr, 'ag2v_conv2d_dgrad_ex', 'conv_dgrad', 2.0 * N * K * dy.shape[2] * dy.shape[3] * C * R * S,
+                 _ptr(dy), _ptr(w), _ptr(mask), _ptr(dx), N, C, H, W, K, R, S, stride, pad, 1 if acc else 0, _ptr(ws), nws, _stream(),
+                 shape=(N, C, H, W, K, R, stride), gscale=gscale, group_n=group_n)
+
+
+def _conv_wgrad_launch(mr, dy, x, dw, K, R, S, stride, pad, acc, groups=1):
+    """dw (+)= weight gradient; groups > 1: dw is [groups, K, C, R, S], one gradient per group of N / groups samples."""
+    N, C, H, W = x.shape
+    _conv_launch(mr, 'ag2v_conv2d_wgrad_ex', 'conv_wgrad', 2.0 * N * K * dy.shape[2] * dy.shape[3] * C * R * S,
+                 _ptr(dy), _ptr(x), _ptr(dw), N, C, H, W, K, R, S, stride, pad, 1 if acc else 0, int(groups), _stream(),
+                 shape=(N, C, H, W, K, R, stride))
+
+
 class _Conv2d(torch.autograd.Function):
     """relu: y = max(conv, 0) in the forward epilogue; its backward masks dy with (y > 0) unless ``grad_premasked`` says the
     consumer of y already did (see relu_input).  relu_input: x is itself a ReLU output whose only consumer is this convolution
     and whose producer was called with grad_premasked=True: the data gradient is returned as (x > 0) ? dx : 0, i.e. the ReLU's
-    backward rides in this convolution's dgrad epilogue instead of a separate pass over dx."""
+    backward rides in this convolution's dgrad epilogue instead of a separate pass over dx.
+    gscale [G] (optional): y_n = gscale[n // (N / G)] * conv(x_n, w) + bias + residual -- a spectral-norm convolution of the
+    frame-batched generator (w = weight_orig, gscale = 1 / sigma_t of frame group t: spectral_scales)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, residual, stride, pad, relu, grad_premasked, relu_input):
+    def forward(ctx, x, w, bias, residual, gscale, stride, pad, relu, grad_premasked, relu_input):
         w_in, bias_in = w, bias
-        x, w, bias, residual = _c(x), _c(w), _c(bias), _c(residual)
-        _chk(x, w, bias, residual)
+        x, w, bias, residual, gscale = _c(x), _c(w), _c(bias), _c(residual), _c(gscale)
+        _chk(x, w, bias, residual, gscale)
         N, C, H, W = x.shape
         K, C2, R, S = w.shape
         if C2 != C:
             raise RuntimeError("conv2d: input has %d channels, weight expects %d" % (C, C2))
+        group_n = 1
+        if gscale is not None:
+            if gscale.dim() != 1 or N % gscale.numel() != 0:
+                raise RuntimeError("conv2d: gscale must be 1-D with a length dividing the batch (%d), got %s" % (N, tuple(gscale.shape)))
+            group_n = N // gscale.numel()
         OH = (H + 2 * pad - R) // stride + 1
         OW = (W + 2 * pad - S) // stride + 1
         y = torch.empty((N, K, OH, OW), device=x.device, dtype=torch.float32)
-        ws = torch.empty(_lib.query('ag2v_conv2d_workspace_floats', C, K, R, S), device=x.device, dtype=torch.float32)
-        mr = _current_min_rows()
-        _conv_launch(mr, 'ag2v_conv2d_fwd_act', _conv_label('fwd', K, mr), 2.0 * N * K * OH * OW * C * R * S,
-                     _ptr(x), _ptr(w), _ptr(bias), _ptr(residual), _ptr(y), N, C, H, W, K, R, S, stride, pad, 1 if relu else 0,
-                     _ptr(ws), _stream(), shape=(N, C, H, W, K, R, stride))
-        ctx.save_for_backward(x, w, y if (relu and not grad_premasked) else None)
-        ctx.cfg = (stride, pad, bias is not None, residual is not None, mr, relu, grad_premasked, relu_input)
+        mr_f, mr = _current_min_rows()
+        _conv_fwd_launch(mr_f, x, w, bias, residual, y, stride, pad, relu, gscale, group_n)
+        ctx.save_for_backward(x, w, y if (relu and not grad_premasked) else None, gscale)
+        ctx.cfg = (stride, pad, bias is not None, residual is not None, mr, relu, grad_premasked, relu_input, group_n)
         ctx.wkey = _wsink_register(w_in) if ctx.needs_input_grad[1] else None
         ctx.bkey = _wsink_register(bias_in) if (bias_in is not None and ctx.needs_input_grad[2] and _EXTRA_SINKS) else None
         ctx.w_alive = (w_in, bias_in)   # the registry keys on id(): keep the objects alive as long as this node, or a temporary
@@ -293,25 +360,31 @@ class _Conv2d(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, y = ctx.saved_tensors
-        stride, pad, has_bias, has_res, mr, relu, grad_premasked, relu_input = ctx.cfg
+        x, w, y, gscale = ctx.saved_tensors
+        stride, pad, has_bias, has_res, mr, relu, grad_premasked, relu_input, group_n = ctx.cfg
         dy = dy.contiguous()
         N, C, H, W = x.shape
         K, _, R, S = w.shape
-        dx = dw = db = dres = None
+        dx = dw = db = dres = dgs = None
         st = _stream()
         if relu and not grad_premasked:
             g = torch.empty_like(dy)
             _lib.call('ag2v_act_bwd', 0, _ptr(dy), _ptr(y), _ptr(g), dy.numel(), 0.0, st)   # op 0 = LeakyReLU(slope 0)
             dy = g
-        flops = 2.0 * N * K * dy.shape[2] * dy.shape[3] * C * R * S      # algorithmic (dense-conv) FLOPs of each pass
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            ws = torch.empty(_lib.query('ag2v_conv2d_workspace_floats', C, K, R, S), device=dy.device, dtype=torch.float32)
-            _conv_launch(mr, 'ag2v_conv2d_dgrad_masked', _conv_label('dgrad', C, mr), flops,
-                         _ptr(dy), _ptr(w), _ptr(x) if relu_input else None, _ptr(dx), N, C, H, W, K, R, S, stride, pad, _ptr(ws),
-                         st, shape=(N, C, H, W, K, R, stride))
-        if ctx.needs_input_grad[1]:
+            _conv_dgrad_launch(mr, dy, w, x if relu_input else None, dx, stride, pad, 0, gscale, group_n)
+        if gscale is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[4]):
+            # per-group weight gradients G_t = dL/d(scale_t W), then dw = sum_t scale_t G_t and dscale_t = <G_t, W> in one pass
+            T = gscale.numel()
+            G = torch.empty((T,) + tuple(w.shape), device=dy.device, dtype=torch.float32)
+            _conv_wgrad_launch(mr, dy, x, G, K, R, S, stride, pad, 0, groups=T)
+            buf, acc, dw = _wsink_take(ctx.wkey, w) if ctx.needs_input_grad[1] else (torch.empty_like(w), 0, None)
+            dgs = torch.empty(T, device=dy.device, dtype=torch.float32)
+            _lib.call('ag2v_sn_group_combine', _ptr(G), _ptr(w), _ptr(gscale), T, w.numel(), _ptr(buf), acc, _ptr(dgs), st)
+            if not ctx.needs_input_grad[4]:
+                dgs = None
+        elif ctx.needs_input_grad[1]:
             buf, acc, dw = _wsink_take(ctx.wkey, w)
             if (_SWAP_FEW_WGRAD and K <= 4 and stride == 1 and dy.shape[2] == H and dy.shape[3] == W and C >= 16 and R == S
                     and 2 * pad == R - 1):
@@ -320,31 +393,28 @@ class _Conv2d(torch.autograd.Function):
                 # x takes dy's role (C dense rows, read once with 16-byte loads), dy is the gathered 3-channel tensor --
                 # the same launch computes dW'[c][m][r'][s'] = dW[m][c][R-1-r'][S-1-s'].
                 t = torch.empty((C, K, R, S), device=dy.device, dtype=torch.float32)
-                _conv_launch(mr, 'ag2v_conv2d_wgrad_acc', _conv_label('wgrad', C, mr), flops,
-                             _ptr(x), _ptr(dy), _ptr(t), N, K, H, W, C, R, S, 1, pad, 0, st, shape=(N, K, H, W, C, R, 1))
+                _conv_wgrad_launch(mr, x, dy, t, C, R, S, 1, pad, 0)
                 t = t.flip(2, 3).transpose(0, 1)
                 if acc:
                     buf.add_(t)
                 else:
                     buf.copy_(t)
             else:
-                _conv_launch(mr, 'ag2v_conv2d_wgrad_acc', _conv_label('wgrad', K, mr), flops,
-                             _ptr(dy), _ptr(x), _ptr(buf), N, C, H, W, K, R, S, stride, pad, acc, st,
-                             shape=(N, C, H, W, K, R, stride))
+                _conv_wgrad_launch(mr, dy, x, buf, K, R, S, stride, pad, acc)
         if has_bias and ctx.needs_input_grad[2]:
             bbuf, bacc, db = _wsink_take(ctx.bkey, ctx.w_alive[1])
             _lib.call('ag2v_channel_sum_acc', _ptr(dy), _ptr(bbuf), N, K, dy.shape[2] * dy.shape[3], bacc, st)
         if has_res and ctx.needs_input_grad[3]:
             dres = dy
-        return dx, dw, db, dres, None, None, None, None, None
+        return dx, dw, db, dres, dgs, None, None, None, None, None
 
 
-def conv2d(x, w, bias=None, stride=1, pad=0, residual=None, relu=False, grad_premasked=False, relu_input=False):
-    """y = conv2d(x, w) + bias + residual   (NCHW, square stride/pad); relu=True: y = max(y, 0).
+def conv2d(x, w, bias=None, stride=1, pad=0, residual=None, relu=False, grad_premasked=False, relu_input=False, gscale=None):
+    """y = conv2d(x, w) [* gscale per sample group] + bias + residual   (NCHW, square stride/pad); relu=True: y = max(y, 0).
     grad_premasked / relu_input: see _Conv2d (the pair fuses the ReLU's backward into the consumer's data gradient)."""
     if relu and residual is not None and grad_premasked:
         raise RuntimeError("conv2d: grad_premasked with a residual input is not supported (the residual's gradient would be masked)")
-    return _Conv2d.apply(x, w, bias, residual, int(stride), int(pad), bool(relu), bool(grad_premasked), bool(relu_input))
+    return _Conv2d.apply(x, w, bias, residual, gscale, int(stride), int(pad), bool(relu), bool(grad_premasked), bool(relu_input))
 
 
 class _ConvSharedInput(torch.autograd.Function):
@@ -364,7 +434,7 @@ class _ConvSharedInput(torch.autograd.Function):
         _chk(x, *ws_)
         _chk(*[b for b in bs_ if b is not None])
         N, C, H, W = x.shape
-        mr = _current_min_rows()
+        mr_f, mr = _current_min_rows()
         outs = []
         for w, b in zip(ws_, bs_):
             K, C2, R, S = w.shape
@@ -373,10 +443,7 @@ class _ConvSharedInput(torch.autograd.Function):
             OH = (H + 2 * pad - R) // stride + 1
             OW = (W + 2 * pad - S) // stride + 1
             y = torch.empty((N, K, OH, OW), device=x.device, dtype=torch.float32)
-            ws = torch.empty(_lib.query('ag2v_conv2d_workspace_floats', C, K, R, S), device=x.device, dtype=torch.float32)
-            _conv_launch(mr, 'ag2v_conv2d_fwd_act', 'conv_fwd', 2.0 * N * K * OH * OW * C * R * S,
-                         _ptr(x), _ptr(w), _ptr(b), None, _ptr(y), N, C, H, W, K, R, S, stride, pad, 1 if relu else 0,
-                         _ptr(ws), _stream(), shape=(N, C, H, W, K, R, stride))
+            _conv_fwd_launch(mr_f, x, w, b, None, y, stride, pad, relu)
             outs.append(y)
         keep_y = relu and not grad_premasked
         ctx.save_for_backward(x, *ws_, *(outs if keep_y else []))
@@ -410,12 +477,10 @@ class _ConvSharedInput(torch.autograd.Function):
                 _lib.call('ag2v_act_bwd', 0, _ptr(dy), _ptr(ys[i]), _ptr(g), dy.numel(), 0.0, st)
                 dy = g
             live.append((w, dy, i))
-            flops = 2.0 * N * K * dy.shape[2] * dy.shape[3] * C * R * S
             dw = db = None
             if ctx.needs_input_grad[5 + 2 * i] and not merged_w:
                 buf, acc, dw = _wsink_take(ctx.wkeys[i], w)
-                _conv_launch(mr, 'ag2v_conv2d_wgrad_acc', 'conv_wgrad', flops, _ptr(dy), _ptr(x), _ptr(buf), N, C, H, W, K, R, S, stride,
-                             pad, acc, st, shape=(N, C, H, W, K, R, stride))
+                _conv_wgrad_launch(mr, dy, x, buf, K, R, S, stride, pad, acc)
             if has_b[i] and ctx.needs_input_grad[6 + 2 * i]:
                 bbuf, bacc, db = _wsink_take(ctx.bkeys[i], ctx.w_alive[2 * i + 1])
                 _lib.call('ag2v_channel_sum_acc', _ptr(dy), _ptr(bbuf), N, K, dy.shape[2] * dy.shape[3], bacc, st)
@@ -426,8 +491,7 @@ class _ConvSharedInput(torch.autograd.Function):
             Kt = dyc.shape[1]
             R, S = ws_[0].shape[2], ws_[0].shape[3]
             cat, acc, outs = _wsink_take_group(ctx.wkeys, [w for w, _, _ in live])
-            _conv_launch(mr, 'ag2v_conv2d_wgrad_acc', 'conv_wgrad', 2.0 * N * Kt * dyc.shape[2] * dyc.shape[3] * C * R * S,
-                         _ptr(dyc), _ptr(x), _ptr(cat), N, C, H, W, Kt, R, S, stride, pad, acc, st, shape=(N, C, H, W, Kt, R, stride))
+            _conv_wgrad_launch(mr, dyc, x, cat, Kt, R, S, stride, pad, acc)
             for j, (_, _, i) in enumerate(live):
                 grads[2 * i] = outs[j]
         if ctx.needs_input_grad[0]:
@@ -441,18 +505,10 @@ class _ConvSharedInput(torch.autograd.Function):
                 wc = live[0][0] if len(live) == 1 else torch.cat([w for w, _, _ in live], dim=0)
                 if dyc is None:
                     dyc = live[0][1] if len(live) == 1 else torch.cat([d for _, d, _ in live], dim=1)
-                K, _, R, S = wc.shape
-                ws = torch.empty(_lib.query('ag2v_conv2d_workspace_floats', C, K, R, S), device=dyc.device, dtype=torch.float32)
-                _conv_launch(mr, 'ag2v_conv2d_dgrad_acc', 'conv_dgrad', 2.0 * N * K * dyc.shape[2] * dyc.shape[3] * C * R * S,
-                             _ptr(dyc), _ptr(wc), None, _ptr(dx), N, C, H, W, K, R, S, stride, pad, 0, _ptr(ws), st,
-                             shape=(N, C, H, W, K, R, stride))
+                _conv_dgrad_launch(mr, dyc, wc, None, dx, stride, pad, 0)
             else:
                 for j, (w, dy, _) in enumerate(live):
-                    K, _, R, S = w.shape
-                    ws = torch.empty(_lib.query('ag2v_conv2d_workspace_floats', C, K, R, S), device=dy.device, dtype=torch.float32)
-                    _conv_launch(mr, 'ag2v_conv2d_dgrad_acc', 'conv_dgrad', 2.0 * N * K * dy.shape[2] * dy.shape[3] * C * R * S,
-                                 _ptr(dy), _ptr(w), None, _ptr(dx), N, C, H, W, K, R, S, stride, pad, 0 if j == 0 else 1, _ptr(ws),
-                                 st, shape=(N, C, H, W, K, R, stride))
+                    _conv_dgrad_launch(mr, dy, w, None, dx, stride, pad, 0 if j == 0 else 1)
         return (dx, None, None, None, None) + tuple(grads)
 
 
@@ -505,20 +561,67 @@ def spectral_weight(w_orig, u, v, training=True, eps=1e-12):
     return _SpectralWeight.apply(w_orig, u, v, bool(training), float(eps))
 
 
+class _SpectralScales(torch.autograd.Function):
+    """scale[t] = 1 / sigma_t for the T train-mode forward calls one spectral-norm convolution makes per step (one per generated
+    frame): T consecutive in-place power iterations on (u, v).  conv2d(x, w_orig, gscale=scale) then evaluates all T frame groups
+    in one launch.  Eval mode: T = 1 (u, v do not move)."""
+
+    @staticmethod
+    def forward(ctx, w_orig, u, v, T, training, eps):
+        w = _c(w_orig)
+        _chk(w, u, v)
+        M = w.shape[0]
+        R = w.numel() // M
+        if not training:
+            T = 1
+        sig = torch.empty(2 * T, device=w.device, dtype=torch.float32)
+        sigma, scale = sig[:T], sig[T:]
+        need = ctx.needs_input_grad[0]
+        uv = torch.empty(T * (M + R), device=w.device, dtype=torch.float32) if need else None
+        u_used, v_used = (uv[:T * M], uv[T * M:]) if need else (None, None)
+        ws = torch.empty(_lib.query('ag2v_spectral_workspace_floats', M), device=w.device, dtype=torch.float32)
+        _lib.call('ag2v_spectral_sigmas', _ptr(w), _ptr(u), _ptr(v), M, R, float(eps), 1 if training else 0, T, _ptr(sigma),
+                  _ptr(scale), _ptr(u_used), _ptr(v_used), _ptr(ws), _stream())
+        ctx.save_for_backward(u_used, v_used, scale)
+        ctx.cfg = (T, M, R)
+        ctx.okey = _wsink_register(w_orig) if (need and _EXTRA_SINKS) else None
+        ctx.o_alive = w_orig
+        return scale
+
+    @staticmethod
+    def backward(ctx, dscale):
+        u_used, v_used, scale = ctx.saved_tensors
+        T, M, R = ctx.cfg
+        dscale = dscale.contiguous()
+        buf, acc, dw = _wsink_take(ctx.okey, ctx.o_alive)
+        _lib.call('ag2v_spectral_sigmas_bwd', _ptr(dscale), _ptr(scale), _ptr(u_used), _ptr(v_used), T, M, R, _ptr(buf), acc, _stream())
+        return dw, None, None, None, None, None
+
+
+def spectral_scales(w_orig, u, v, T, training=True, eps=1e-12):
+    """[1 / sigma_t for t < T] with T in-place power iterations on (u, v) (training) -- or [1 / sigma] in eval mode."""
+    return _SpectralScales.apply(w_orig, u, v, int(T), bool(training), float(eps))
+
+
 # ------------------------------------------------------------------------------------------------ batch norm family
-def _bn_stats(x, running_mean, running_var, training, momentum, eps):
+def _bn_stats(x, running_mean, running_var, training, momentum, eps, groups=1):
+    """-> mean, invstd ([groups * C]: sample n uses row n // (N / groups)), N, C, HW, samples per group."""
     N, C = x.shape[0], x.shape[1]
     HW = x.numel() // (N * C)
+    if N % groups != 0:
+        raise RuntimeError("batch norm: %d sample groups do not divide the batch of %d" % (groups, N))
+    Ng = N // groups
     if training:
-        mean = torch.empty(C, device=x.device, dtype=torch.float32)
-        invstd = torch.empty(C, device=x.device, dtype=torch.float32)
+        mean = torch.empty(groups * C, device=x.device, dtype=torch.float32)
+        invstd = torch.empty(groups * C, device=x.device, dtype=torch.float32)
         ws = torch.empty(_lib.query('ag2v_bn_workspace_floats', N, C, HW), device=x.device, dtype=torch.float32)
-        _lib.call('ag2v_bn_stats', _ptr(x), N, C, HW, float(eps), float(momentum), _ptr(mean), _ptr(invstd),
+        _lib.call('ag2v_bn_stats_g', _ptr(x), N, C, HW, Ng, float(eps), float(momentum), _ptr(mean), _ptr(invstd),
                   _ptr(running_mean), _ptr(running_var), _ptr(ws), _stream())
     else:
         mean = running_mean
         invstd = torch.rsqrt(running_var + eps)
-    return mean, invstd, N, C, HW
+        Ng = N                                      # running statistics: one row for every sample
+    return mean, invstd, N, C, HW, Ng
 
 
 def _ptr_off(t, elems):
@@ -527,74 +630,81 @@ def _ptr_off(t, elems):
 
 class _NormAct(torch.autograd.Function):
     """mode 0: BN(affine w,b) -> LeakyReLU(slope); mode 1: SPADE BN*(1+gamma)+beta -> LeakyReLU(slope); mode 2: as 1 with
-    gamma | beta delivered as the two channel halves of ONE tensor p0 = [N, 2C, H, W] (the output of the fused gamma/beta conv)."""
+    gamma | beta delivered as the two channel halves of ONE tensor p0 = [N, 2C, H, W] (the output of the fused gamma/beta conv).
+    groups > 1: batch statistics per group of N / groups consecutive samples (the frame groups of the frame-batched generator:
+    the reference normalises every frame pass by itself), running statistics updated once per group, in order."""
 
     @staticmethod
-    def forward(ctx, mode, x, p0, p1, running_mean, running_var, training, momentum, eps, slope):
+    def forward(ctx, mode, x, p0, p1, running_mean, running_var, training, momentum, eps, slope, groups):
         x, p0, p1 = _c(x), _c(p0), _c(p1)
         _chk(x, p0, p1)
-        mean, invstd, N, C, HW = _bn_stats(x, running_mean, running_var, training, momentum, eps)
+        mean, invstd, N, C, HW, Ng = _bn_stats(x, running_mean, running_var, training, momentum, eps, groups)
         y = torch.empty_like(x)
         if mode == 0:
-            _lib.call('ag2v_norm_apply', 0, _ptr(x), _ptr(mean), _ptr(invstd), _ptr(p0), _ptr(p1), None, None, _ptr(y),
-                      N, C, HW, float(slope), _stream())
+            _lib.call('ag2v_norm_apply_g', 0, _ptr(x), _ptr(mean), _ptr(invstd), _ptr(p0), _ptr(p1), None, None, _ptr(y),
+                      N, C, HW, Ng, float(slope), _stream())
         else:
             if mode == 2 and tuple(p0.shape) != (N, 2 * C) + tuple(x.shape[2:]):
                 raise RuntimeError("spade_norm_fused: gamma|beta tensor must be [N, 2C, H, W]")
             g_ptr, b_ptr = (_ptr(p0), _ptr(p1)) if mode == 1 else (_ptr(p0), _ptr_off(p0, C * HW))
             # timed as an HBM-bound kernel: algorithmic bytes = x, gamma, beta read + y written (4 tensors), recorded in
             # the "flops" slot of the timing record
-            _launch('ag2v_norm_apply', 'spade_norm_apply', 4.0 * x.numel() * 4, mode, _ptr(x), _ptr(mean), _ptr(invstd), None, None,
-                    g_ptr, b_ptr, _ptr(y), N, C, HW, float(slope), _stream(), shape=(N, C, HW))
+            _launch('ag2v_norm_apply_g', 'spade_norm_apply', 4.0 * x.numel() * 4, mode, _ptr(x), _ptr(mean), _ptr(invstd), None, None,
+                    g_ptr, b_ptr, _ptr(y), N, C, HW, Ng, float(slope), _stream(), shape=(N, C, HW))
         ctx.save_for_backward(x, y if slope != 1.0 else None, p0, mean, invstd)
-        ctx.cfg = (mode, training, slope, N, C, HW)
+        ctx.cfg = (mode, training, slope, N, C, HW, Ng)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, y, p0, mean, invstd = ctx.saved_tensors
-        mode, training, slope, N, C, HW = ctx.cfg
+        mode, training, slope, N, C, HW, Ng = ctx.cfg
         if not training:
             raise RuntimeError("norm backward is only implemented for batch statistics (training mode)")
         dy = dy.contiguous()
         dx = torch.empty_like(x)
-        sums = torch.empty((C, 2), device=x.device, dtype=torch.float32)
+        G = N // Ng
+        sums = torch.empty((G, C, 2), device=x.device, dtype=torch.float32)
         ws = torch.empty(_lib.query('ag2v_bn_workspace_floats', N, C, HW), device=x.device, dtype=torch.float32)
+        none = (None,) * 9
         if mode == 0:
-            _lib.call('ag2v_norm_bwd', 0, _ptr(dy), _ptr(y), _ptr(x), None, _ptr(p0), _ptr(mean), _ptr(invstd), _ptr(dx),
-                      None, None, _ptr(sums), N, C, HW, float(slope), _ptr(ws), _stream())
-            dw = sums[:, 1].contiguous() if p0 is not None else None
-            db = sums[:, 0].contiguous() if p0 is not None else None
-            return None, dx, dw, db, None, None, None, None, None, None
+            _lib.call('ag2v_norm_bwd_g', 0, _ptr(dy), _ptr(y), _ptr(x), None, _ptr(p0), _ptr(mean), _ptr(invstd), _ptr(dx),
+                      None, None, _ptr(sums), N, C, HW, Ng, float(slope), _ptr(ws), _stream())
+            dw = db = None
+            if p0 is not None:
+                tot = sums.sum(dim=0) if G > 1 else sums[0]
+                dw, db = tot[:, 1].contiguous(), tot[:, 0].contiguous()
+            return (None, dx, dw, db) + none[:7]
         if mode == 2:
             dgb = torch.empty_like(p0)
-            _lib.call('ag2v_norm_bwd', 2, _ptr(dy), _ptr(y), _ptr(x), _ptr(p0), None, _ptr(mean), _ptr(invstd), _ptr(dx),
-                      _ptr(dgb), _ptr_off(dgb, C * HW), _ptr(sums), N, C, HW, float(slope), _ptr(ws), _stream())
-            return None, dx, dgb, None, None, None, None, None, None, None
+            _launch('ag2v_norm_bwd_g', 'spade_norm_bwd', 8.0 * x.numel() * 4, 2, _ptr(dy), _ptr(y), _ptr(x), _ptr(p0), None, _ptr(mean),
+                    _ptr(invstd), _ptr(dx), _ptr(dgb), _ptr_off(dgb, C * HW), _ptr(sums), N, C, HW, Ng, float(slope), _ptr(ws), _stream(),
+                    shape=(N, C, HW))
+            return (None, dx, dgb, None) + none[:7]
         dgamma = torch.empty_like(x)
         dbeta = torch.empty_like(x)
-        _lib.call('ag2v_norm_bwd', 1, _ptr(dy), _ptr(y), _ptr(x), _ptr(p0), None, _ptr(mean), _ptr(invstd), _ptr(dx),
-                  _ptr(dgamma), _ptr(dbeta), _ptr(sums), N, C, HW, float(slope), _ptr(ws), _stream())
-        return None, dx, dgamma, dbeta, None, None, None, None, None, None
+        _lib.call('ag2v_norm_bwd_g', 1, _ptr(dy), _ptr(y), _ptr(x), _ptr(p0), None, _ptr(mean), _ptr(invstd), _ptr(dx),
+                  _ptr(dgamma), _ptr(dbeta), _ptr(sums), N, C, HW, Ng, float(slope), _ptr(ws), _stream())
+        return (None, dx, dgamma, dbeta) + none[:7]
 
 
-def batchnorm_act(x, weight, bias, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0):
-    """F.batch_norm (batch statistics + running-stat update when training) followed by LeakyReLU(slope)."""
+def batchnorm_act(x, weight, bias, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0, groups=1):
+    """F.batch_norm (batch statistics + running-stat update when training) followed by LeakyReLU(slope); groups: see _NormAct."""
     return _NormAct.apply(0, x, weight, bias, running_mean, running_var, bool(training), float(momentum), float(eps),
-                          float(slope))
+                          float(slope), int(groups))
 
 
-def spade_norm(x, gamma, beta, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0):
+def spade_norm(x, gamma, beta, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0, groups=1):
     """SPADE modulation: BN_noaffine(x) * (1 + gamma) + beta, then LeakyReLU(slope)."""
     return _NormAct.apply(1, x, gamma, beta, running_mean, running_var, bool(training), float(momentum), float(eps),
-                          float(slope))
+                          float(slope), int(groups))
 
 
-def spade_norm_fused(x, gb, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0):
+def spade_norm_fused(x, gb, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0, groups=1):
     """spade_norm with gamma = gb[:, :C] and beta = gb[:, C:] read in place from the [N, 2C, H, W] output of one convolution
     (and their gradients written in place into one [N, 2C, H, W] tensor)."""
     return _NormAct.apply(2, x, gb, None, running_mean, running_var, bool(training), float(momentum), float(eps),
-                          float(slope))
+                          float(slope), int(groups))
 
 
 class _InstNormLReLU(torch.autograd.Function):

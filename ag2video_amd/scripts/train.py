@@ -4,8 +4,8 @@ seeded synthetic CATER-shaped clips (the real datasets need files/network that a
     python -m ag2video_amd.scripts.train --batch_size 2 --image_size 64,64 --num_iterations 10 --no_vgg_loss
     torchrun --nproc-per-node 8 --master-addr 127.0.0.1 -m ag2video_amd.scripts.train ...     # one rank per GPU
 
-Same flags, step order (G step -> D step -> graph step on a 4x longer clip), NaN guard, per-step try/except, loss-dict
-keys and checkpoint dictionary keys as the reference.
+Same flags, step order (G step -> D step -> graph step on a 4x longer clip), NaN guard (collective across ranks), per-step
+try/except (single process only), loss-dict keys and checkpoint dictionary keys as the reference.
 """
 import json
 import logging
@@ -73,31 +73,26 @@ def main(args):
         if t % args.checkpoint_every == 0 and rank == 0:
             save_checkpoint(args, os.path.join(args.output_dir, 'itr_%s.pt' % t), ts, epoch, t)
         seed = args.seed + 1000003 * t + rank
+        # One code path with bench.py and the tests: TrainStep.gd_step / graph_step (the in-place all-reduce over the optimizers'
+        # flat gradient buffers, the collective NaN guard).  Exceptions: the reference is one process and logs + continues
+        # (train.py:466-468,495-497); with one process per GPU a rank that swallowed an exception would leave the others inside a
+        # collective, so at world > 1 the error is logged, the process group torn down and the exception re-raised (torchrun then
+        # stops the job with a non-zero exit code).
         if not args.graph_only:
             try:
                 batch = ts.to_device(make_clip_batch(args.vocab, args.batch_size, F_short, args.image_size, seed=seed,
                                                      min_objs=lo, max_objs=hi))
-                ts.model.zero_grad(set_to_none=True)
-                model_out = ts.model(batch[0], batch[1], batch[3], batch[4], boxes_gt=batch[2], test_mode=False, use_gt=True)
-                G_losses = ts.gans_model(batch, model_out, mode="compute_generator_loss")
-                G_losses = {k: v.mean() for k, v in G_losses.items()}
-                if torch.isnan(G_losses['GAN_Img']) or ('GAN_Feat' in G_losses and torch.isnan(G_losses['GAN_Feat'])):
-                    print("Error: video_id {} is NAN!".format(batch[5]))          # train.py:450-453
+                _, G_losses, D_new = ts.gd_step(batch)
+                if D_new is None:                       # NaN guard tripped on some rank: train.py:450-453 (t += 1; continue)
                     t += 1
                     continue
-                ts.optimizer_generator.zero_grad()
-                G_losses["total_loss"].backward()
-                D.average_gradients(ts._gen_params)
-                ts.optimizer_generator.step()
-                D_losses = ts.gans_model(batch, model_out, mode="compute_discriminator_loss")
-                D_losses = {k: v.mean() for k, v in D_losses.items()}
-                ts.discriminator.optimizer_d_img.zero_grad()
-                D_losses["total_img_loss"].backward()
-                D.average_gradients(ts._d_params)
-                ts.discriminator.optimizer_d_img.step()
+                D_losses = D_new
             except Exception as e:                                                     # train.py:466-468
                 print("Error in video_id: {}".format(seed))
                 logger.exception(e)
+                if D.is_dist():
+                    D.shutdown()
+                    raise
         G_graph_losses = {}
         try:
             gbatch = ts.to_device(make_clip_batch(args.vocab, args.batch_size, F_long, args.image_size, seed=seed + 7,
@@ -106,6 +101,9 @@ def main(args):
         except Exception as e:
             print("Error in video_id: {}".format(seed + 7))
             logger.exception(e)
+            if D.is_dist():
+                D.shutdown()
+                raise
         if t % args.print_every == 0 and rank == 0:
             print('t = %d / %d' % (t, args.num_iterations))
             for name, val in G_graph_losses.items():

@@ -27,6 +27,9 @@ CONFIGS = {
     'c1': (64, 4, 1, []),
     'c2': (128, 8, 4, []),
     'c3': (256, 16, 8, []),
+    # c5: Something-Something-V2 / Something-Else shaped (data/smth.py:85-104): ONE attribute => 128 layout channels, 2-3
+    # objects per clip incl. the hand, 9 predicates, 9 action classes, 224 x 224 (= 7 * 32), 16 frames
+    'c5': (224, 16, 8, ['--dataset', 'smth_else']),
     'toy': (64, 3, 2, ['--ngf', '8', '--ndf', '8', '--nff', '8', '--gconv_hidden_dim', '64']),
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
@@ -54,10 +57,20 @@ PEAK_HBM_GBS = 8000.0              # same guide: HBM3E 8.0 TB/s spec (6.29 TB/s 
 
 def make_opt(cfg):
     from ag2video_amd.data.args import make_opt as _mk
-    from ag2video_amd.data.vocab import cater_vocab
+    from ag2video_amd.data.vocab import cater_vocab, smth_vocab
     side, frames, batch, extra = CONFIGS[cfg]
     flags = ['--no_vgg_loss', '--image_size', '%d,%d' % (side, side), '--batch_size', str(batch), '--gpu_ids', '0'] + extra
-    return _mk(cater_vocab(), flags), side, frames, batch
+    vocab = smth_vocab() if 'smth_else' in extra else cater_vocab()
+    return _mk(vocab, flags), side, frames, batch
+
+
+def make_clip(opt, cfg, batch, frames, side, seed):
+    """Seeded synthetic clip batch of the configuration's dataset shape (SURVEY.md 8d): CATER 5-10 objects / <= 6 actions;
+    Something-Else 2-3 objects (the hand last) / <= 2 actions."""
+    from ag2video_amd.data.synthetic import make_clip_batch
+    if getattr(opt, 'dataset', 'cater') == 'smth_else':
+        return make_clip_batch(opt.vocab, batch, frames, (side, side), seed=seed, min_objs=2, max_objs=3, max_actions=2)
+    return make_clip_batch(opt.vocab, batch, frames, (side, side), seed=seed)
 
 
 def cpu_baseline_child():
@@ -140,7 +153,7 @@ def main():
     opt.gpu_ids = [local]
     ops.set_conv_precision(args.precision)
     ts = TrainStep(opt, device, weights_seed=0)
-    clip = ts.to_device(make_clip_batch(opt.vocab, batch, frames, (side, side), seed=1234 + rank))
+    clip = ts.to_device(make_clip(opt, args.config, batch, frames, side, seed=1234 + rank))
     torch.cuda.synchronize()
 
     for i in range(args.warmup):
@@ -175,7 +188,7 @@ def main():
     finite = all(bool(torch.isfinite(v).all()) for v in list(GL.values()) + list(DL.values()))
 
     # graph-only step (train.py:471-493), reported separately
-    gclip = ts.to_device(make_clip_batch(opt.vocab, batch, frames, (side, side), seed=4321 + rank))
+    gclip = ts.to_device(make_clip(opt, args.config, batch, frames, side, seed=4321 + rank))
     ts.graph_step(gclip)
     torch.cuda.synchronize()
     tg = time.time()
@@ -258,13 +271,13 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
     line = {
-        "metric": "frames/sec/node (gen+disc fwd+bwd), CATER %dx%dx%df" % (side, side, frames),
+        "metric": "frames/sec/node (gen+disc fwd+bwd), %s %dx%dx%df" % ("SSv2-shaped" if args.config == 'c5' else "CATER", side, side, frames),
         "value": round(value, 3), "unit": "frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": ("f32 (conv products as 3-term bf16 splits on the bf16 MFMA pipe, fp32 accumulate; everything else fp32)"
                   if args.precision == 'bf16x3' else "f32"), "data": "synthetic CATER-shaped clips (seeded), closed-form random-init weights",
-        "config": {"workload": "%s: CATER %dx%d, %d frames, batch %d per GPU, full G+D train step, VGG loss off"
-                   % (args.config, side, side, frames, batch), "global_batch": world * batch, "parallelism": "dp%d" % world},
+        "config": {"workload": "%s: %s %dx%d, %d frames, batch %d per GPU, full G+D train step, VGG loss off"
+                   % (args.config, "SSv2-shaped" if args.config == 'c5' else "CATER", side, side, frames, batch), "global_batch": world * batch, "parallelism": "dp%d" % world},
         "roofline": roof, "roofline_exact_fp32": roof_fp32, "roofline_hbm": roof_hbm, "cpu_baseline": cpu,
         "extra": {"graph_step_ms": round(graph_ms, 2), "losses_finite": finite,
                   "generated_frames_per_sec": round(world * batch * (frames - 1) * args.steps / dt, 3),

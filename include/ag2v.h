@@ -6,6 +6,8 @@
  *   - every tensor is a raw device pointer to contiguous fp32 (NCHW for images) unless stated (int64 indices, uint8/int32 masks);
  *   - the caller owns all memory; no entry point allocates, frees or synchronises; kernels are enqueued on `stream`
  *     (a hipStream_t passed as void*) and are safe to capture in a hipGraph;
+ *   - no entry point reads mutable process state when it is given its options explicitly (ag2v_conv_opts): the library is
+ *     re-entrant per stream / thread.  The ag2v_set_* functions only set the DEFAULTS of calls that pass no options;
  *   - scratch memory is passed in as `workspace` and sized by the matching ag2v_*_workspace_floats();
  *   - return value: 0 on success, AG2V_EINVAL (-1) for a rejected argument, AG2V_EHIP (-2) for a HIP launch error
  *     (the Python host turns non-zero into RuntimeError, matching the reference's "raise, never abort" convention,
@@ -26,18 +28,34 @@ extern "C" {
  * call sites: generator.py:30; flows_generator.py:32-54,82-85; spade_generator.py:16-34; architecture.py:29-32;
  * normalization.py:90-94; discriminator.py:368-379.   x[N,C,H,W], w[K,C,R,S], y[N,K,OH,OW], OH=(H+2p-R)/s+1.
  * fwd: y = conv(x,w) (+bias[K]) (+residual, same shape as y).  dgrad: dx from dy.  wgrad: dw from dy,x. */
-/* Arithmetic of the 128/256-row MFMA tiles (GEMM M >= 48): 1 (default) = bf16x3 split products, fp32 accumulation (each fp32
- * operand = bf16 hi + bf16 lo, a*b = hi*hi + hi*lo + lo*hi: ~1e-5 relative per product); 0 = exact fp32 MFMA.  Process-wide. */
+/* Per-call options of the *_ex convolution entry points (plain C struct, passed by pointer; NULL = all defaults).
+ *   precision: arithmetic of the 128/256-row MFMA tiles: 1 = bf16x3 split products with fp32 accumulation (each fp32 operand
+ *              = bf16 hi + bf16 lo, a*b = hi*hi + hi*lo + lo*hi: ~1e-5 relative per product), 0 = exact fp32 MFMA,
+ *              < 0 = the process default (ag2v_set_conv_precision / AG2V_CONV_PRECISION; initially 1);
+ *   min_rows:  in bf16x3 mode, GEMMs with fewer rows (output channels; input channels for the data gradient) stay on the exact
+ *              fp32 tiles; <= 0 = the process default (ag2v_set_bf16x3_min_rows / AG2V_BF16X3_MIN_M; initially 128);
+ *   gscale:    nullable device pointer: the convolution product of sample n is multiplied by gscale[n / group_n] before bias
+ *              and residual are added (forward and data gradient).  This is how a spectral-norm convolution of the
+ *              frame-batched generator runs: torch.nn.utils.spectral_norm divides W by sigma_t in the t-th forward call of a
+ *              step (call sites architecture.py:35-39, flows_generator.py:79-85, normalization.py:26-27 inside the frame loop
+ *              generator.py:62-87); with all T frames in one [T*B, ...] batch the kernel convolves the raw weight and scales
+ *              group t by 1/sigma_t;
+ *   kernel:    OUT: name (as rocprofv3 prints it) of the main kernel the call launched (static string). */
+typedef struct ag2v_conv_opts {
+    int precision;
+    int min_rows;
+    const float* gscale;
+    int group_n;
+    const char* kernel;
+} ag2v_conv_opts;
+/* Defaults of calls without options (process-wide; the product passes options on every call). */
 int ag2v_set_conv_precision(int mode);
 int ag2v_get_conv_precision(void);
-/* In bf16x3 mode, GEMMs with fewer rows (output channels; input channels for the data gradient) than this stay on the exact
- * fp32 tiles.  Default 128 (AG2V_BF16X3_MIN_M overrides at start-up); the host side lowers it outside the flow network, whose
- * full-resolution 64-channel tail feeds the warp (ag2video_amd/ops.py: bf16x3_min_rows). */
-/* Name (as rocprofv3 prints it) of the main kernel launched by the most recent ag2v_conv2d_* call of this process; bench.py keys
- * its per-kernel HIP-event timing table on it so that it can be laid beside the rocprofv3 kernel statistics. */
-const char* ag2v_last_conv_kernel(void);
 int ag2v_set_bf16x3_min_rows(int rows);
 int ag2v_get_bf16x3_min_rows(void);
+/* Name of the main kernel launched by the most recent ag2v_conv2d_* call of the calling thread (ag2v_conv_opts::kernel is the
+ * per-call form). */
+const char* ag2v_last_conv_kernel(void);
 size_t ag2v_conv2d_workspace_floats(int C, int K, int R, int S);  /* k-major copy of the (sub-)filters; fwd and dgrad */
 int ag2v_conv2d_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y,
                     int N, int C, int H, int W, int K, int R, int S, int stride, int pad, float* workspace, void* stream);
@@ -57,6 +75,24 @@ int ag2v_conv2d_dgrad_acc(const float* dy, const float* w, const float* mask, fl
                           void* stream);
 int ag2v_conv2d_wgrad(const float* dy, const float* x, float* dw,
                       int N, int C, int H, int W, int K, int R, int S, int stride, int pad, void* stream);
+/* The full forms (what ag2video_amd/ops.py calls).  Batches whose gathered operand exceeds 4 GiB are processed in sample chunks
+ * inside the call.
+ *   fwd_ex:   y = conv(x, w) * gscale[n / group_n] + bias + residual, relu != 0: y = max(y, 0).
+ *   dgrad_ex: dx (+)= dgrad(dy, w) * gscale[n / group_n], masked as ag2v_conv2d_dgrad_masked; workspace_floats =
+ *             ag2v_conv2d_dgrad_workspace_floats(...) (the weight copy plus, for <= 4 input channels, the [N, C R S, OH, OW]
+ *             intermediate of the 1x1-GEMM + shifted-plane-sum form); with less workspace the general kernels run.
+ *   wgrad_ex: groups == 1: dw (+)= wgrad(dy, x).  groups > 1 (N % groups == 0): dw is [groups][K, C, R, S] and receives one
+ *             weight gradient per group of N / groups consecutive samples -- dL/dWbar_t of every frame t, which the backward of
+ *             spectral norm needs separately (ag2v_sn_group_combine). */
+int ag2v_conv2d_fwd_ex(const float* x, const float* w, const float* bias, const float* residual, float* y,
+                       int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int relu, float* workspace,
+                       void* stream, ag2v_conv_opts* opts);
+size_t ag2v_conv2d_dgrad_workspace_floats(int N, int C, int H, int W, int K, int R, int S, int stride, int pad);
+int ag2v_conv2d_dgrad_ex(const float* dy, const float* w, const float* mask, float* dx,
+                         int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int accumulate,
+                         float* workspace, size_t workspace_floats, void* stream, ag2v_conv_opts* opts);
+int ag2v_conv2d_wgrad_ex(const float* dy, const float* x, float* dw, int N, int C, int H, int W, int K, int R, int S,
+                         int stride, int pad, int accumulate, int groups, void* stream, ag2v_conv_opts* opts);
 /* accumulate != 0: dw += instead of dw = (a weight used by several forward calls of one step collects its gradient in one buffer). */
 int ag2v_conv2d_wgrad_acc(const float* dy, const float* x, float* dw, int N, int C, int H, int W, int K, int R, int S,
                           int stride, int pad, int accumulate, void* stream);
@@ -79,6 +115,17 @@ int ag2v_norm_apply(int mode, const float* x, const float* mean, const float* in
 int ag2v_norm_bwd(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* w,
                   const float* mean, const float* invstd, float* dx, float* dgamma, float* dbeta, float* sums,
                   int N, int C, int HW, float slope, float* workspace, void* stream);
+/* Sample groups: the T frame passes of the reference's generator loop (generator.py:62-87) are T separate F.batch_norm calls
+ * over B samples each; the frame-batched form holds them as one [T*B, C, HW] tensor, Ng = B samples per group.  mean / invstd
+ * are [N / Ng, C] (sample n uses row n / Ng); the running statistics receive the N / Ng momentum updates in group order; sums is
+ * [N / Ng, C, 2].  Ng == N is the plain form above. */
+int ag2v_bn_stats_g(const float* x, int N, int C, int HW, int Ng, float eps, float momentum, float* mean, float* invstd,
+                    float* running_mean, float* running_var, float* workspace, void* stream);
+int ag2v_norm_apply_g(int mode, const float* x, const float* mean, const float* invstd, const float* w, const float* b,
+                      const float* gamma, const float* beta, float* y, int N, int C, int HW, int Ng, float slope, void* stream);
+int ag2v_norm_bwd_g(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* w,
+                    const float* mean, const float* invstd, float* dx, float* dgamma, float* dbeta, float* sums,
+                    int N, int C, int HW, int Ng, float slope, float* workspace, void* stream);
 int ag2v_instnorm_lrelu_fwd(const float* x, float* y, float* mean, float* invstd, int NC, int HW, float eps, float slope,
                             void* stream);
 int ag2v_instnorm_lrelu_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
@@ -163,6 +210,20 @@ int ag2v_spectral_norm_bwd(const float* dwbar, const float* wbar, const float* u
 /* accumulate != 0: dw += ... (weight_orig collects the gradients of all forward calls of a step in one buffer) */
 int ag2v_spectral_norm_bwd_acc(const float* dwbar, const float* wbar, const float* u, const float* v, const float* sigma, int M,
                                int R, float* dw, int accumulate, float* workspace, void* stream);
+
+/* Frame-batched form: the T train-mode forward calls of one spectral-norm convolution per step (one per generated frame) are T
+ * consecutive power iterations on (u, v); sigma_t depends on W, u, v only, so all T are produced up front:
+ *   sigma[T], inv_sigma[T] (= ag2v_conv_opts::gscale), u_used[T*M] / v_used[T*R] = the vectors behind sigma_t (nullable).
+ *   power_iter == 0 (eval mode): T must be 1.  workspace: ag2v_spectral_workspace_floats(M). */
+int ag2v_spectral_sigmas(const float* w, float* u, float* v, int M, int R, float eps, int power_iter, int T, float* sigma,
+                         float* inv_sigma, float* u_used, float* v_used, float* workspace, void* stream);
+/* Backward of y_n = scale[g(n)] * conv(x_n, W) from the per-group weight gradients G[T][n] (ag2v_conv2d_wgrad_ex, groups = T):
+ * dw[i] (+)= sum_t scale[t] G[t][i];  dscale[t] = <G[t], W>. */
+int ag2v_sn_group_combine(const float* G, const float* w, const float* scale, int T, long long n, float* dw, int accumulate,
+                          float* dscale, void* stream);
+/* Backward of scale[t] = 1 / (u_t^T W v_t):  dw[m, r] (+)= sum_t (-dscale[t] scale[t]^2) u_t[m] v_t[r]. */
+int ag2v_spectral_sigmas_bwd(const float* dscale, const float* scale, const float* u_used, const float* v_used, int T, int M, int R,
+                             float* dw, int accumulate, void* stream);
 
 /* ---- fused Adam over a flat fp32 buffer: torch.optim.Adam as configured at scripts/train.py:365-368 and
  * meta_models.py:70-72 (weight_decay 0, amsgrad off); step_index >= 1 --------------------------------------------- */

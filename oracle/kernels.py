@@ -13,10 +13,19 @@ import torch
 import torch.nn.functional as F
 
 
-def conv2d(x, w, bias=None, stride=1, pad=0, residual=None, relu=False, grad_premasked=False, relu_input=False):
+def conv2d(x, w, bias=None, stride=1, pad=0, residual=None, relu=False, grad_premasked=False, relu_input=False, gscale=None):
     """nn.Conv2d.forward (aten.convolution), e.g. generator.py:30, architecture.py:29-32, discriminator.py:368-379.
     relu: the nn.ReLU that follows SPADE's mlp_shared convolution (normalization.py:92-95).  grad_premasked / relu_input only tell
-    the product where to apply that ReLU's backward; autograd does it here."""
+    the product where to apply that ReLU's backward; autograd does it here.
+    gscale [G]: the frame-batched form of a spectral-norm convolution -- sample group g (N / G consecutive samples = one frame pass
+    of generator.py:62-87) is convolved with w * gscale[g], i.e. with that pass's weight_orig / sigma_g, one F.conv2d per pass."""
+    if gscale is not None:
+        G = gscale.numel()
+        xs = x.reshape((G, x.shape[0] // G) + tuple(x.shape[1:]))
+        y = torch.cat([F.conv2d(xs[g], w * gscale[g], None, stride=stride, padding=pad) for g in range(G)], dim=0)
+        y = y if bias is None else y + bias.view(1, -1, 1, 1)
+        y = y if residual is None else y + residual
+        return F.relu(y) if relu else y
     y = F.conv2d(x, w, bias, stride=stride, padding=pad)
     y = y if residual is None else y + residual
     return F.relu(y) if relu else y
@@ -40,28 +49,53 @@ def spectral_weight(w_orig, u, v, training=True, eps=1e-12):
     return w_orig / sigma
 
 
+def spectral_scales(w_orig, u, v, T, training=True, eps=1e-12):
+    """[1 / sigma_t] of T consecutive train-mode forward calls of one spectral-norm layer (the T frame passes of
+    generator.py:62-87): T times the power iteration + sigma of spectral_weight above, u / v advancing in place.  Eval: one value."""
+    wm = w_orig.reshape(w_orig.shape[0], -1)
+    out = []
+    for _ in range(T if training else 1):
+        if training:
+            with torch.no_grad():
+                v.copy_(F.normalize(torch.mv(wm.t(), u), dim=0, eps=eps))
+                u.copy_(F.normalize(torch.mv(wm, v), dim=0, eps=eps))
+        uc, vc = u.clone(), v.clone()
+        out.append(1.0 / torch.dot(uc, torch.mv(wm, vc)))
+    return torch.stack(out)
+
+
 def _lrelu(y, slope):
     return y if slope == 1.0 else F.leaky_relu(y, slope)
 
 
-def batchnorm_act(x, weight, bias, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0):
+def _batch_norm_groups(x, running_mean, running_var, weight, bias, training, momentum, eps, groups):
+    """One F.batch_norm call per group of N / groups consecutive samples, in order (each call updates the running statistics):
+    the frame passes of the reference's generator loop, held as one frame-major batch by the product."""
+    if groups == 1 or not training:
+        return F.batch_norm(x, running_mean, running_var, weight, bias, training, momentum, eps)
+    n = x.shape[0] // groups
+    return torch.cat([F.batch_norm(x[g * n:(g + 1) * n], running_mean, running_var, weight, bias, training, momentum, eps)
+                      for g in range(groups)], dim=0)
+
+
+def batchnorm_act(x, weight, bias, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0, groups=1):
     """_SynchronizedBatchNorm single-device path = F.batch_norm (sync_batchnorm/batchnorm.py:63-68) + LeakyReLU
     (generator.py:26-33, flows_generator.py:30-54)."""
-    return _lrelu(F.batch_norm(x, running_mean, running_var, weight, bias, training, momentum, eps), slope)
+    return _lrelu(_batch_norm_groups(x, running_mean, running_var, weight, bias, training, momentum, eps, groups), slope)
 
 
-def spade_norm(x, gamma, beta, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0):
+def spade_norm(x, gamma, beta, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0, groups=1):
     """SPADE.forward normalization.py:99,108 (+ actvn architecture.py:53-54,68)."""
-    n = F.batch_norm(x, running_mean, running_var, None, None, training, momentum, eps)
+    n = _batch_norm_groups(x, running_mean, running_var, None, None, training, momentum, eps, groups)
     return _lrelu(n * (1 + gamma) + beta, slope)
 
 
-
-def spade_norm_fused(x, gb, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0):
+def spade_norm_fused(x, gb, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0, groups=1):
     """spade_norm with gamma | beta stacked along channels (the product runs mlp_gamma and mlp_beta, normalization.py:105-106,
     as one convolution)."""
     C = x.shape[1]
-    return spade_norm(x, gb[:, :C], gb[:, C:], running_mean, running_var, training, momentum, eps, slope)
+    return spade_norm(x, gb[:, :C], gb[:, C:], running_mean, running_var, training, momentum, eps, slope, groups)
+
 
 def instnorm_lrelu(x, eps=1e-5, slope=0.2):
     """nn.InstanceNorm2d(affine=False) + LeakyReLU(0.2) (normalization.py:43-44, discriminator.py:374-377)."""

@@ -1,0 +1,73 @@
+"""Child process of tests/test_distributed_gpu.py: one rank of a torchrun job on a real GPU, RCCL ("nccl") backend.
+
+Launched as ``python -m torch.distributed.run --nproc-per-node N ... tests/dist_gpu_child.py OUT.json`` with
+AG2V_FORCE_DIST=1, so that even a world of ONE rank takes every collective code path of the product: process-group init on
+the device, parameter/buffer broadcast at TrainStep construction, the in-place bucketed all-reduce over FusedAdam's flat
+gradient buffers after each backward, the collective skip flag of the training loop, barrier, max-over-ranks.
+"""
+import json
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+
+
+def main(out_path):
+    from ag2video_amd import distributed as D
+    from ag2video_amd.data.args import make_opt
+    from ag2video_amd.data.synthetic import make_clip_batch
+    from ag2video_amd.data.vocab import cater_vocab
+    from ag2video_amd.engine import TrainStep
+    rank, world, local = D.init_from_env()
+    assert torch.distributed.is_initialized() and torch.distributed.get_backend() == 'nccl' and D.is_dist()
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    flags = ['--no_vgg_loss', '--image_size', '64,64', '--batch_size', '2', '--ngf', '8', '--ndf', '8', '--nff', '8',
+             '--gconv_hidden_dim', '64', '--gpu_ids', str(local)]
+    opt = make_opt(cater_vocab(), flags)
+    torch.manual_seed(100 + rank)                     # rank-dependent default init: the broadcast must make ranks agree
+    ts = TrainStep(opt, dev, weights_seed=None if os.environ.get('AG2V_TEST_RANDOM_INIT') else 5)
+    calls = {'n': 0, 'elems': 0}
+    inner = torch.distributed.all_reduce
+
+    def counted(t, *a, **k):
+        calls['n'] += 1
+        calls['elems'] += t.numel()
+        return inner(t, *a, **k)
+    torch.distributed.all_reduce = counted
+    clip = ts.to_device(make_clip_batch(opt.vocab, 2, 3, (64, 64), seed=11 + rank))
+    # gradients before / after the all-reduce on rank-local data: with world == 1 the mean over ranks is the identity, bit for bit
+    _, GL0, DL0 = ts.gd_step(clip, apply_updates=False)
+    g_local = ts.optimizer_generator.flat_grad.clone()
+    D.average_gradients(ts._gen_params, flat=ts.optimizer_generator.flat_grad)
+    same = bool(torch.equal(g_local, ts.optimizer_generator.flat_grad)) if world == 1 else None
+    n_before = calls['n']
+    _, GL, DL = ts.gd_step(clip)
+    n_after = calls['n']
+    gclip = ts.to_device(make_clip_batch(opt.vocab, 2, 5, (64, 64), seed=12 + rank))
+    _, GG = ts.graph_step(gclip)
+    skip = D.any_rank(False, dev), D.any_rank(rank == 0, dev)
+    torch.distributed.barrier()
+    mx = D.max_over_ranks(float(rank + 1), dev)
+    # checksum of all parameters: identical on every rank after identical (averaged) updates
+    csum = float(sum(p.detach().double().sum() for p in ts.model.parameters()))
+    allsum = torch.tensor([csum], dtype=torch.float64, device=dev)
+    gathered = [torch.zeros_like(allsum) for _ in range(world)]
+    torch.distributed.all_gather(gathered, allsum)
+    res = {'rank': rank, 'world': world, 'backend': torch.distributed.get_backend(), 'identity_allreduce': same,
+           'allreduce_calls_per_gd_step': n_after - n_before, 'allreduce_elems': calls['elems'],
+           'flat_grad_elems': [ts.optimizer_generator.flat_grad.numel(), ts.discriminator.optimizer_d_img.flat_grad.numel(),
+                               ts.optimizer_graph.flat_grad.numel()],
+           'G': {k: float(v) for k, v in GL.items()}, 'D': {k: float(v) for k, v in DL.items()},
+           'G0': {k: float(v) for k, v in GL0.items()}, 'graph': {k: float(v) for k, v in GG.items()},
+           'skip_flags': list(skip), 'max_over_ranks': mx, 'param_checksums': [float(t) for t in gathered]}
+    if rank == 0:
+        json.dump(res, open(out_path, 'w'))
+    D.shutdown()
+
+
+if __name__ == '__main__':
+    main(sys.argv[1])

@@ -1,0 +1,64 @@
+"""RCCL on a real GPU ("multi-GPU is code, not evidence").
+
+A fresh child process is started with the torchrun launcher (never a re-exec of this process, which has initialised the GPU)
+with AG2V_FORCE_DIST=1 and one rank per visible GPU (one on the test box): process-group init with the "nccl" (= RCCL) backend
+on the device, broadcast, the in-place bucketed all-reduce over FusedAdam's flat gradient buffers, the collective skip flag,
+barrier.  The losses must equal those of the same step run in THIS process without torch.distributed -- to the noise of the
+split-K atomics (two runs of the same binary differ in the last bits: DESIGN.md 3.4), i.e. 1e-4 relative, and the all-reduce of
+a one-rank world must leave the gradients bit-identical.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_rccl_path_on_gpu_matches_single_process(device, tmp_path):
+    from ag2video_amd.data.args import make_opt
+    from ag2video_amd.data.synthetic import make_clip_batch
+    from ag2video_amd.data.vocab import cater_vocab
+    from ag2video_amd.engine import TrainStep
+    n = 1                                  # the test box has one GPU; the launcher line is the driver's multi-GPU line with N = 1
+    out = os.path.join(str(tmp_path), 'dist.json')
+    env = dict(os.environ, AG2V_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(HERE, 'dist_gpu_child.py'), out]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    res = json.load(open(out))
+    assert res['backend'] == 'nccl' and res['world'] == n
+    assert res['identity_allreduce'] is True
+    # per gd_step: the collective NaN-guard flag (one int) + one all-reduce per 128 MB bucket of each flat gradient buffer (the
+    # toy's buffers are one bucket each: G, D)
+    assert res['allreduce_calls_per_gd_step'] == 3, res['allreduce_calls_per_gd_step']
+    assert res['skip_flags'] == [False, True] and res['max_over_ranks'] == float(n)
+    assert len(set(res['param_checksums'])) == 1
+    # the same step without torch.distributed, in this process
+    flags = ['--no_vgg_loss', '--image_size', '64,64', '--batch_size', '2', '--ngf', '8', '--ndf', '8', '--nff', '8',
+             '--gconv_hidden_dim', '64', '--gpu_ids', '0']
+    opt = make_opt(cater_vocab(), flags)
+    ts = TrainStep(opt, device, weights_seed=5)
+    clip = ts.to_device(make_clip_batch(opt.vocab, 2, 3, (64, 64), seed=11))
+    _, GL0, _ = ts.gd_step(clip, apply_updates=False)
+    _, GL, DL = ts.gd_step(clip)
+    _, GG = ts.graph_step(ts.to_device(make_clip_batch(opt.vocab, 2, 5, (64, 64), seed=12)))
+    for got, ref in ((res['G0'], GL0), (res['G'], GL), (res['D'], DL), (res['graph'], GG)):
+        for k, v in ref.items():
+            assert abs(got[k] - float(v)) <= 1e-4 * max(1.0, abs(float(v))), (k, got[k], float(v))

@@ -313,14 +313,104 @@ def test_layout_conv(cfg, device):
     _run_pair(ops.layout_conv, K.layout_conv, t, device, nondiff=('boxes',), name='layout_conv')
 
 
+def _sample_coords(flow, H, W):
+    """Sampling coordinates of resample()/get_grid (models/utils.py:113-140) in fp64: grid = linspace(-1, 1) + flow / ((W-1)/2),
+    unnormalised with align_corners=False: ix = ((g + 1) * W - 1) / 2 = (x + flow_x) * W / (W - 1) - 1/2."""
+    f = flow.double()
+    xs = torch.arange(W, dtype=torch.float64).view(1, 1, W)
+    ys = torch.arange(H, dtype=torch.float64).view(1, H, 1)
+    return (xs + f[:, 0]) * W / (W - 1) - 0.5, (ys + f[:, 1]) * H / (H - 1) - 0.5
+
+
+def _flow_for_targets(tx, ty, H, W):
+    """Inverse of _sample_coords: the flow that makes pixel (y, x) sample the image at (ty, tx)."""
+    xs = torch.arange(W, dtype=torch.float64).view(1, 1, W)
+    ys = torch.arange(H, dtype=torch.float64).view(1, H, 1)
+    return torch.stack([(tx + 0.5) * (W - 1) / W - xs, (ty + 0.5) * (H - 1) / H - ys], dim=1).float()
+
+
 @pytest.mark.parametrize("shape", [(2, 3, 16, 16), (3, 3, 33, 20), (2, 3, 64, 64)], ids=str)
-@pytest.mark.parametrize("mag", [0.5, 6.0, 40.0])
-def test_flow_warp(shape, mag, device):
+@pytest.mark.parametrize("reach", [1.5, 9.0])
+def test_flow_warp_off_cell_borders(shape, reach, device):
+    """Sampling points constructed to stay >= 0.15 of a cell away from every cell border and from the clamp at the image border
+    (inside: fraction in [0.15, 0.85]; outside: >= 0.65 beyond the edge, where border padding makes the derivative exactly zero).
+    There d(warp)/d(flow) is continuous, so forward, image gradient AND flow gradient are held to the common 2e-4."""
     from ag2video_amd import ops
     from oracle import kernels as K
     N, C, H, W = shape
-    t = {'img': _rand(N, C, H, W, seed=1), 'flow': _rand(N, 2, H, W, seed=2) * mag}
-    _run_pair(ops.flow_warp, K.flow_warp, t, device, name='warp', tol=1e-3)
+    g = torch.Generator().manual_seed(7)
+    xs = torch.arange(W, dtype=torch.float64).view(1, 1, W).expand(N, H, W)
+    ys = torch.arange(H, dtype=torch.float64).view(1, H, 1).expand(N, H, W)
+    def targets(base, size):
+        cell = torch.floor(base + (torch.rand(base.shape, generator=g, dtype=torch.float64) * 2 - 1) * reach)
+        frac = 0.15 + 0.7 * torch.rand(base.shape, generator=g, dtype=torch.float64)
+        t = cell + frac
+        # cells straddling the clamp (ix in (-1, 0) or (size-1, size-0.5...)) are moved fully outside
+        t = torch.where((t < 0), torch.minimum(t, torch.full_like(t, -0.65)), t)
+        t = torch.where((t > size - 1), torch.maximum(t, torch.full_like(t, size - 1 + 0.65)), t)
+        return t
+    flow = _flow_for_targets(targets(xs, W), targets(ys, H), H, W)
+    ix, iy = _sample_coords(flow, H, W)          # what the fp32 flow actually encodes: check the construction survived rounding
+    for c, size in ((ix, W), (iy, H)):
+        inside = (c > 0) & (c < size - 1)
+        fr = c - torch.floor(c)
+        assert bool(((fr[inside] > 0.1) & (fr[inside] < 0.9)).all()) and bool(((c[~inside] < -0.5) | (c[~inside] > size - 0.5)).all())
+    t = {'img': _rand(N, C, H, W, seed=1), 'flow': flow}
+    _run_pair(ops.flow_warp, K.flow_warp, t, device, name='warp')
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 16, 16), (3, 3, 33, 20), (2, 3, 64, 64)], ids=str)
+@pytest.mark.parametrize("mag", [0.5, 6.0, 40.0])
+def test_flow_warp(shape, mag, device):
+    """Random flows (cell borders are crossed freely).  Forward and the image gradient are continuous in the flow: 2e-4.  The flow
+    gradient is piecewise constant per sampling cell: it is compared at 2e-4 on every pixel whose sampling point is farther than
+    1e-3 of a cell from a border (> 99 % of them) -- on the others the oracle's fp32 coordinate and the kernel's may fall into
+    different cells, an O(1) difference that says nothing about either."""
+    from ag2video_amd import ops
+    from oracle import kernels as K
+    N, C, H, W = shape
+    img, flow = _rand(N, C, H, W, seed=1), _rand(N, 2, H, W, seed=2) * mag
+    ic, fc = img.clone().requires_grad_(True), flow.clone().requires_grad_(True)
+    ig, fg = img.clone().to(device).requires_grad_(True), flow.clone().to(device).requires_grad_(True)
+    ref, got = K.flow_warp(ic, fc), ops.flow_warp(ig, fg)
+    _cmp('warp.fwd', got, ref)
+    wgt = _rand(*ref.shape, seed=3)
+    (ref * wgt).sum().backward()
+    (got * wgt.to(device)).sum().backward()
+    _cmp('warp.grad_img', ig.grad, ic.grad)
+    ix, iy = _sample_coords(flow, H, W)
+    safe = torch.ones(N, H, W, dtype=torch.bool)
+    for c, size in ((ix, W), (iy, H)):
+        fr = c - torch.floor(c)
+        safe &= ((fr > 1e-3) & (fr < 1 - 1e-3)) | (c < -1e-3) | (c > size - 1 + 1e-3)
+        safe &= (c.abs() > 1e-3) & ((c - (size - 1)).abs() > 1e-3)
+    assert safe.double().mean().item() > 0.99
+    m = safe.unsqueeze(1).expand(N, 2, H, W)
+    _cmp('warp.grad_flow[safe]', fg.grad.cpu() * m, fc.grad * m)
+
+
+def test_flow_warp_on_cell_borders(device):
+    """Border-crossing case: every sampling point sits EXACTLY on a grid node (integer coordinates, some outside the image).
+    The forward value is then the image value at the clamped node whichever cell an implementation assigns the point to, and the
+    image gradient is a pure scatter: both exact to rounding.  (The flow gradient is one-sided there and not compared.)"""
+    from ag2video_amd import ops
+    from oracle import kernels as K
+    N, C, H, W = 2, 3, 17, 32          # W, H - 1 powers of two: (t + 0.5) * (W - 1) / W - x is exact enough to land on the node
+    g = torch.Generator().manual_seed(11)
+    tx = torch.randint(-3, W + 3, (N, H, W), generator=g).double()
+    ty = torch.randint(-3, H + 3, (N, H, W), generator=g).double()
+    flow = _flow_for_targets(tx, ty, H, W)
+    img = _rand(N, C, H, W, seed=1)
+    ic, ig = img.clone().requires_grad_(True), img.clone().to(device).requires_grad_(True)
+    ref, got = K.flow_warp(ic, flow), ops.flow_warp(ig, flow.to(device))
+    want = img[torch.arange(N).view(N, 1, 1, 1), torch.arange(C).view(1, C, 1, 1), ty.clamp(0, H - 1).long().unsqueeze(1),
+               tx.clamp(0, W - 1).long().unsqueeze(1)]
+    _cmp('warp_nodes.fwd_vs_gather', got, want, 1e-4)
+    _cmp('warp_nodes.fwd', got, ref, 1e-4)
+    wgt = _rand(*ref.shape, seed=3)
+    (ref * wgt).sum().backward()
+    (got * wgt.to(device)).sum().backward()
+    _cmp('warp_nodes.grad_img', ig.grad, ic.grad, 1e-4)
 
 
 @pytest.mark.parametrize("shape", [(2, 5, 16, 16), (3, 4, 17, 9), (1, 2, 64, 64)], ids=str)
@@ -521,3 +611,120 @@ def test_gradient_sinks_multi_use_and_aborted_backward(device):
     lr.backward()
     _cmp('sink.dw_orig', w.grad, wr.grad, TOL)
     _cmp('sink.db', b.grad, br.grad, TOL)
+
+
+# ------------------------------------------------------------------------------------------------ frame-group forms
+# (frame-batched generator: ops.frame_groups).  The oracle restates each of them as the reference's per-pass op applied group by group.
+GS_CASES = [
+    # N, groups, C, H, W, K, R, stride, pad, bias, residual
+    (6, 3, 16, 12, 12, 40, 3, 1, 1, True, True),       # exact tiles, residual
+    (8, 4, 64, 8, 8, 136, 3, 1, 1, True, False),       # bf16x3 128 x 256 tile (tap-major, quad loads)
+    (6, 2, 96, 8, 8, 256, 3, 1, 1, False, False),      # bf16x3 256 x 128 tile, 3 samples per group
+    (4, 4, 1027, 8, 8, 32, 3, 1, 1, False, False),     # table path, one sample per group, split-K epilogue (atomics x scale)
+    (6, 3, 3, 16, 16, 200, 3, 1, 1, False, False),     # <= 4 input channels: data gradient as 1x1 GEMM + shifted-plane sum
+    (4, 2, 24, 10, 10, 3, 3, 1, 1, True, False),       # <= 4 output rows: few-row kernel
+    (6, 3, 20, 9, 9, 48, 4, 2, 2, True, False),        # 4x4 stride 2: four parity classes in the data gradient
+    (4, 2, 128, 6, 6, 130, 1, 1, 0, False, False),     # 1x1 (conv_s of a SPADE block)
+]
+
+
+@pytest.mark.parametrize("case", GS_CASES, ids=str)
+def test_conv2d_group_scale(case, precision, device):
+    """y_n = gscale[group(n)] * conv(x_n, w) + bias + residual: forward, dx, dw (through the per-group weight gradients and
+    ag2v_sn_group_combine), dbias, dresidual and dgscale."""
+    from ag2video_amd import ops
+    from oracle import kernels as K
+    N, G, C, H, W, Ko, R, st, pad, has_b, has_r = case
+    OH, OW = (H + 2 * pad - R) // st + 1, (W + 2 * pad - R) // st + 1
+    t = {'x': _rand(N, C, H, W, seed=1), 'w': _rand(Ko, C, R, R, seed=2, scale=(C * R * R) ** -0.5),
+         'bias': _rand(Ko, seed=3) if has_b else None, 'stride': st, 'pad': pad,
+         'residual': _rand(N, Ko, OH, OW, seed=4) if has_r else None,
+         'gscale': torch.linspace(0.6, 1.7, G) * torch.tensor([1.0, -1.0] * G)[:G]}
+    with ops.bf16x3_min_rows(48):
+        _run_pair(ops.conv2d, K.conv2d, t, device, name='conv_gscale')
+
+
+def test_conv2d_sample_chunks(precision, device, monkeypatch):
+    """Batches whose gathered operand exceeds the 4 GiB of a buffer descriptor are convolved in sample chunks inside the call
+    (AG2V_CHUNK_BYTES lowers the limit): forward, data gradient, weight gradient (accumulated over chunks) and the per-group
+    weight gradients must not depend on the chunking."""
+    from ag2video_amd import ops
+    N, G, C, H, W, Ko = 12, 6, 64, 8, 8, 136
+    x0, w0 = _rand(N, C, H, W, seed=1), _rand(Ko, C, 3, 3, seed=2, scale=(C * 9) ** -0.5)
+    gs = torch.linspace(0.7, 1.4, G).to(device)
+    dy = _rand(N, Ko, H, W, seed=5).to(device)
+    res = []
+    for limit in (None, str(5 * C * H * W * 4)):       # 5 samples per chunk -> rounded down to whole groups of 2: chunks of 4
+        if limit is None:
+            monkeypatch.delenv('AG2V_CHUNK_BYTES', raising=False)
+        else:
+            monkeypatch.setenv('AG2V_CHUNK_BYTES', limit)
+        out = []
+        for g in (None, gs):
+            x, w = x0.clone().to(device).requires_grad_(True), w0.clone().to(device).requires_grad_(True)
+            gg = None if g is None else g.clone().requires_grad_(True)
+            with ops.bf16x3_min_rows(48):
+                y = ops.conv2d(x, w, None, 1, 1, gscale=gg)
+                y.backward(dy)
+            out += [y.detach(), x.grad, w.grad] + ([] if gg is None else [gg.grad])
+        res.append(out)
+    monkeypatch.delenv('AG2V_CHUNK_BYTES', raising=False)
+    for a, b in zip(*res):
+        _cmp('chunked', b, a.cpu(), 2e-5)
+
+
+@pytest.mark.parametrize("cfg", [((6, 5, 9, 9), 3, 0.2), ((8, 16, 64, 64), 4, 1.0), ((4, 3, 70, 70), 2, 0.2), ((15, 8, 4, 4), 15, 0.2)], ids=str)
+def test_norm_frame_groups(cfg, device):
+    """Batch norm (affine) and the SPADE modulation with statistics per group of consecutive samples, and the running statistics
+    after the per-group updates (in order)."""
+    from ag2video_amd import ops
+    from oracle import kernels as K
+    shape, G, slope = cfg
+    N, C = shape[0], shape[1]
+    for kind in ('bn', 'spade'):
+        bufs = {}
+        def mk():
+            return torch.linspace(-0.5, 0.5, C), torch.linspace(0.5, 1.5, C)
+        def f(mod, dev):
+            rm, rv = mk()
+            rm, rv = rm.to(dev), rv.to(dev)
+            bufs[dev] = (rm, rv)
+            if kind == 'bn':
+                return lambda x, weight, bias: mod.batchnorm_act(x, weight, bias, rm, rv, True, 0.1, 1e-5, slope, groups=G)
+            return lambda x, gb: mod.spade_norm_fused(x, gb, rm, rv, True, 0.1, 1e-5, slope, groups=G)
+        x = _rand(*shape, seed=1) * torch.linspace(0.5, 2.0, N).view(N, 1, 1, 1) + torch.linspace(-1, 1, N).view(N, 1, 1, 1)
+        if kind == 'bn':
+            t = {'x': x, 'weight': _rand(C, seed=2) + 1.0, 'bias': _rand(C, seed=3)}
+        else:
+            t = {'x': x, 'gb': _rand(N, 2 * C, *shape[2:], seed=2) * 0.3}
+        _run_pair(f(ops, device), f(K, 'cpu'), t, device, name='norm_groups_' + kind)
+        for got, ref, nm in zip(bufs[device], bufs['cpu'], ('running_mean', 'running_var')):
+            _cmp('norm_groups_%s.%s' % (kind, nm), got, ref, 1e-5)
+
+
+@pytest.mark.parametrize("shape", [(8, 5, 3, 3), (64, 16, 3, 3), (256, 130, 1, 1), (1024, 128, 3, 3)], ids=str)
+@pytest.mark.parametrize("T", [1, 3, 15])
+def test_spectral_scales(shape, T, device):
+    """T consecutive power iterations: 1 / sigma_t, the advanced u / v, and the gradient of sum_t c_t / sigma_t w.r.t. weight_orig."""
+    from ag2video_amd import ops
+    from oracle import kernels as K
+    M, R = shape[0], shape[1] * shape[2] * shape[3]
+    w = _rand(*shape, seed=1)
+    u0 = torch.nn.functional.normalize(_rand(M, seed=2), dim=0)
+    v0 = torch.nn.functional.normalize(_rand(R, seed=3), dim=0)
+    coef = _rand(T, seed=4)
+    outs = []
+    for mod, dev in ((K, 'cpu'), (ops, device)):
+        wd = w.clone().to(dev).requires_grad_(True)
+        u, v = u0.clone().to(dev), v0.clone().to(dev)
+        sc = mod.spectral_scales(wd, u, v, T, True, 1e-12)
+        (sc * coef.to(dev)).sum().backward()
+        outs.append((sc.detach(), u, v, wd.grad))
+    for a, b, nm in zip(outs[1], outs[0], ('scales', 'u', 'v', 'grad_w')):
+        _cmp('spectral_scales.' + nm, a, b, TOL)
+    # eval mode: one value, buffers untouched
+    u, v = u0.clone().to(device), v0.clone().to(device)
+    sc = ops.spectral_scales(w.to(device), u, v, T, False, 1e-12)
+    ref = K.spectral_scales(w, u0.clone(), v0.clone(), T, False, 1e-12)
+    assert sc.numel() == 1 and torch.equal(u.cpu(), u0) and torch.equal(v.cpu(), v0)
+    _cmp('spectral_scales.eval', sc, ref, TOL)
