@@ -996,14 +996,16 @@ extern "C" int ag2v_conv2d_wgrad_ex(const float* dy, const float* x, float* dw, 
     const int Ng = N / groups;
     bool split = use_bf16x3(cfg, K);
     // samples per launch: whole groups, both operands below 4 GiB for the bf16x3 kernels, pixel index below 2^31
+    // (dy at most 2 GiB per launch: the 16-byte-load weight-gradient kernels encode "past the range" as byte offset 2^31)
     int nmax = N;
-    if (split && (dys * 4 * N >= chunk_limit() || xs * 4 * N >= chunk_limit())) {
-        nmax = chunk_samples(dys * 4, xs * 4, Ng);
+    if (split && (dys * 8 * N >= chunk_limit() || xs * 4 * N >= chunk_limit())) {
+        nmax = chunk_samples(dys * 8, xs * 4, groups > 1 ? Ng : 1);
+        if (nmax <= 0) nmax = chunk_samples(dys * 4, xs * 4, groups > 1 ? Ng : 1);
         if (nmax <= 0) { split = false; nmax = N; }
     }
     if ((long long)nmax * OH * OW >= (1LL << 31)) {
         nmax = (int)(((1LL << 31) - 1) / ((long long)OH * OW));
-        nmax -= nmax % Ng;
+        if (groups > 1) nmax -= nmax % Ng;
         if (nmax <= 0) return AG2V_EINVAL;
     }
     const size_t wsz = (size_t)K * C * R * S;
