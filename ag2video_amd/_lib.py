@@ -49,6 +49,8 @@ _SIGS = {
     'ag2v_flow_warp_bwd': (c_int, [_P, _P, _P, _P, _P] + [c_int] * 4 + [_P]),
     'ag2v_avgpool3s2_fwd': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     'ag2v_avgpool3s2_bwd': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    'ag2v_maxpool2_fwd': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    'ag2v_maxpool2_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
     'ag2v_nearest_resize_fwd': (c_int, [_P, _P] + [c_int] * 5 + [_P]),
     'ag2v_nearest_resize_bwd': (c_int, [_P, _P] + [c_int] * 5 + [_P]),
     'ag2v_nearest_pyramid_bwd': (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P]),

@@ -658,6 +658,60 @@ extern "C" int ag2v_flow_warp_bwd(const float* dout, const float* img, const flo
     return AG2V_OK;
 }
 
+// ---------------------------------------------------------------- max_pool2d(2, stride 2) (VGG19 features, architecture.py:93-123)
+// floor mode: OH = H / 2, OW = W / 2; a trailing odd row / column belongs to no window
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long total, int H,
+                                                           int W, int OH, int OW) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int ox = (int)(idx % OW);
+    const long long r = idx / OW;
+    const int oy = (int)(r % OH);
+    const long long nc = r / OH;
+    const float* xp = x + (size_t)nc * H * W + (size_t)(2 * oy) * W + 2 * ox;
+    y[idx] = fmaxf(fmaxf(xp[0], xp[1]), fmaxf(xp[W], xp[W + 1]));
+}
+// one thread per INPUT element: it receives its window's gradient iff it is the window's first maximum in row-major order
+// (ATen's max_pool2d backward routes the gradient to the index found with a strict '>' scan)
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           float* __restrict__ dx, long long total, int H, int W, int OH, int OW) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int ix = (int)(idx % W);
+    const long long r = idx / W;
+    const int iy = (int)(r % H);
+    const long long nc = r / H;
+    const int oy = iy >> 1, ox = ix >> 1;
+    float g = 0.f;
+    if (oy < OH && ox < OW) {
+        const float* xp = x + (size_t)nc * H * W + (size_t)(2 * oy) * W + 2 * ox;
+        const float v[4] = {xp[0], xp[1], xp[W], xp[W + 1]};
+        int arg = 0;
+        float m = v[0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k)
+            if (v[k] > m) { m = v[k]; arg = k; }
+        if (arg == ((iy & 1) << 1 | (ix & 1))) g = dy[(size_t)nc * OH * OW + (size_t)oy * OW + ox];
+    }
+    dx[idx] = g;
+}
+extern "C" int ag2v_maxpool2_fwd(const float* x, float* y, int NC, int H, int W, void* stream) {
+    if (!x || !y || NC <= 0 || H < 2 || W < 2) return AG2V_EINVAL;
+    const int OH = H / 2, OW = W / 2;
+    const long long total = (long long)NC * OH * OW;
+    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, total, H, W, OH, OW);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+extern "C" int ag2v_maxpool2_bwd(const float* dy, const float* x, float* dx, int NC, int H, int W, void* stream) {
+    if (!dy || !x || !dx || NC <= 0 || H < 2 || W < 2) return AG2V_EINVAL;
+    const int OH = H / 2, OW = W / 2;
+    const long long total = (long long)NC * H * W;
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, dy, x, dx, total, H, W, OH, OW);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+
 extern "C" int ag2v_avgpool3s2_fwd(const float* x, float* y, int NC, int H, int W, void* stream) {
     if (!x || !y || NC <= 0 || H <= 0 || W <= 0) return AG2V_EINVAL;
     const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;

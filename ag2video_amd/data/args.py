@@ -101,6 +101,10 @@ def build_parser():
     # build-specific (not in the reference): synthetic data shape for scripts/train
     a('--synthetic_objects', default='5,10', type=int_tuple, help='min,max real objects per clip')
     a('--seed', default=1234, type=int)
+    a('--data_root', default=None, type=str, help='CATER directory (scenes/*.json, videos/<id>/*.png); default: synthetic clips')
+    a('--train_list', default=None, type=str)
+    a('--data_nframes', default=301, type=int, help='frames per video in --data_root')
+    a('--vgg_weights', default=None, type=str, help='torchvision vgg19 state dict (.pth) for the perceptual loss')
     return p
 
 

@@ -28,6 +28,8 @@ class TrainStep(object):
             from .weights import closed_form_fill_
             closed_form_fill_(self.model, seed=weights_seed, prefix='G.')
             closed_form_fill_(self.discriminator.img_discriminator, seed=weights_seed, prefix='D.')
+            if hasattr(self.gans_model.module, 'criterionVGG'):
+                closed_form_fill_(self.gans_model.module.criterionVGG, seed=weights_seed, prefix='V.')
         lr, b1 = opt.learning_rate, opt.beta1
         graph_params = list(self.model.acts_to_boxes.parameters())
         graph_ids = set(id(p) for p in graph_params)

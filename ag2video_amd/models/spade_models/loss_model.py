@@ -7,7 +7,7 @@ import torch.nn.functional as F
 
 from ... import ops
 from ..utils import resample
-from .networks.loss import GANLoss
+from .networks.loss import GANLoss, VGGLoss
 
 
 @contextlib.contextmanager
@@ -36,8 +36,14 @@ class LossModel(torch.nn.Module):
             self.netD_img = discriminator.img_discriminator
         self.criterionGAN = GANLoss(opt.gan_mode, opt=opt)
         if not opt.no_vgg_loss:
-            raise NotImplementedError("VGG perceptual loss needs pretrained VGG19 weights (no network here); "
-                                      "run with --no_vgg_loss (SURVEY.md 2.1 row 6)")
+            # loss_model.py:35-36.  The reference downloads ImageNet weights through torchvision; there is no network here: the
+            # weights are PyTorch's default init until the caller loads some (--vgg_weights: a torchvision vgg19 state dict file;
+            # engine.TrainStep(weights_seed=...) fills them closed-form like every other parameter).
+            self.criterionVGG = VGGLoss(opt.gpu_ids)
+            path = getattr(opt, 'vgg_weights', None)
+            if path:
+                sd = torch.load(path, map_location='cpu')
+                self.criterionVGG.vgg.load_torchvision_features({k[len('features.'):]: v for k, v in sd.items() if k.startswith('features.')})
 
     # ---- discriminator layout terms, once per step.  The terms depend on the discriminator's parameters and on the layout inputs
     # (objects, ground-truth boxes, action data) only.  The generator step and the discriminator step of one training iteration
@@ -118,6 +124,8 @@ class LossModel(torch.nn.Module):
         nxt = imgs[:, nc:].contiguous().view(-1, c, h, w)
         fl = flows_pred[:, nc - 1:-1].contiguous().view(-1, 2, h, w)
         G["loss_F_Warp"] = ops.l1_mean(resample(prev, fl), nxt) * self.opt.lambda_F_warp
+        if not self.opt.no_vgg_loss:
+            G['VGG'] = self.criterionVGG(r_pred, r_imgs) * self.opt.lambda_vgg               # loss_model.py:99-100
         G['total_loss'] = torch.stack(list(G.values()), dim=0).sum()
         return G
 

@@ -33,3 +33,78 @@ class SPADEResnetBlock(nn.Module):
         x_s = self.conv_s(self.norm_s(x, seg, actv=actv[2])) if self.learned_shortcut else x
         dx = self.conv_0(self.norm_0(x, seg, slope=0.2, actv=actv[0]))
         return self.conv_1(self.norm_1(dx, seg, slope=0.2, actv=actv[1]), residual=x_s)   # out = x_s + dx fused in the conv epilogue
+
+
+# torchvision.models.vgg19 "features" configuration ('E': 16 conv3x3 + ReLU layers, 'M' = MaxPool2d(2, 2)); the reference pins
+# torchvision 0.5.0 (README.md:23).  Module indices inside ``features`` are what the slices below are named after.
+VGG19_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M', 512, 512, 512, 512, 'M']
+
+
+def vgg19_feature_layers():
+    """[(index in torchvision's vgg19().features, kind, in_channels, out_channels)] for kind in conv / relu / pool."""
+    layers, c_in, idx = [], 3, 0
+    for v in VGG19_CFG:
+        if v == 'M':
+            layers.append((idx, 'pool', c_in, c_in))
+            idx += 1
+        else:
+            layers.append((idx, 'conv', c_in, v))
+            layers.append((idx + 1, 'relu', v, v))
+            c_in, idx = v, idx + 2
+    return layers
+
+
+class _ReLUMarker(nn.Module):
+    """Placeholder for features[i] = ReLU: the activation runs in the preceding convolution's epilogue."""
+
+    def forward(self, x):
+        return x
+
+
+class _MaxPool2(nn.Module):
+    def forward(self, x):
+        return ops.maxpool2(x)
+
+
+class VGG19(nn.Module):
+    """The five feature slices of VGG19 used by the perceptual loss (reference: architecture.py:93-123): relu1_1, relu2_1, relu3_1,
+    relu4_1, relu5_1 = features[0:2], [2:7], [7:12], [12:21], [21:30].  Children are named by their index in torchvision's
+    ``features`` (hence state_dict keys ``slice3.10.weight`` ...), so a torchvision VGG19 ``features`` state dict maps onto this module
+    key by key (load_torchvision_features).  The reference loads ImageNet weights from the network; there is none here, so the
+    weights are whatever the caller fills in (closed-form random init for throughput / parity runs).  Frozen, as in the reference."""
+
+    SLICES = ((0, 2), (2, 7), (7, 12), (12, 21), (21, 30))
+
+    def __init__(self, requires_grad=False):
+        super().__init__()
+        from ...layers import Conv2d
+        layers = {i: (kind, ci, co) for i, kind, ci, co in vgg19_feature_layers()}
+        for s, (lo, hi) in enumerate(self.SLICES):
+            seq = nn.Sequential()
+            for i in range(lo, hi):
+                kind, ci, co = layers[i]
+                mod = Conv2d(ci, co, kernel_size=3, padding=1) if kind == 'conv' else (_ReLUMarker() if kind == 'relu' else _MaxPool2())
+                seq.add_module(str(i), mod)
+            setattr(self, 'slice%d' % (s + 1), seq)
+        if not requires_grad:
+            for p in self.parameters():
+                p.requires_grad = False
+
+    def load_torchvision_features(self, features_state_dict):
+        """features_state_dict: torchvision vgg19().features.state_dict() ('0.weight', '0.bias', '2.weight', ...)."""
+        own = self.state_dict()
+        for k, v in features_state_dict.items():
+            idx = int(k.split('.')[0])
+            s = next(i for i, (lo, hi) in enumerate(self.SLICES) if lo <= idx < hi) + 1
+            own['slice%d.%s' % (s, k)].copy_(v)
+
+    def forward(self, X):
+        out, h = [], X
+        for s in range(1, 6):
+            for mod in getattr(self, 'slice%d' % s):
+                if isinstance(mod, nn.Conv2d):
+                    h = ops.conv2d(h, mod.weight, mod.bias, 1, 1, relu=True)       # conv + the ReLU that follows it
+                elif isinstance(mod, _MaxPool2):
+                    h = mod(h)
+            out.append(h)
+        return out

@@ -58,6 +58,41 @@ class NLayerActionDiscriminator(nn.Module):
         return results[-1]
 
 
+class NLayerDiscriminatorTM(NLayerActionDiscriminator):
+    """Temporal PatchGAN scale (reference: discriminator.py:16-59): the same model0..model{n} stack over the clip's frames stacked
+    into channels -- input_nc = frames_per_action * 3 (:46-47)."""
+
+    def compute_D_input_nc(self):
+        return self.opt.frames_per_action * 3
+
+
+class MultiscaleDiscriminatorT(nn.Module):
+    """Temporal multiscale discriminator (reference: discriminator.py:62-87): img [B, T, 3, H, W] -> view [B, T*3, H, W] -> num_D
+    PatchGANs with 3x3 / stride-2 average pooling between scales.  BASELINE.json's "3-D PatchGAN": the reference has no 3-D
+    convolution on any path and constructs this class nowhere; it is its only discriminator that sees time."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        for i in range(opt.num_D):
+            self.add_module('discriminator_%d' % i, NLayerDiscriminatorTM(opt))
+
+    def downsample(self, x):
+        return ops.avgpool3s2(x)
+
+    def forward(self, img):
+        bs, nt, ch, h, w = img.size()
+        x = img.reshape(bs, ch * nt, h, w)
+        result = []
+        with ops.bf16x3_min_rows(48):
+            for name, D in self.named_children():
+                if name.startswith('discriminator'):
+                    out = D(x)
+                    result.append(out if not self.opt.no_ganFeat_loss else [out])
+                    x = self.downsample(x)
+        return result
+
+
 class MultiscaleActionDiscriminator(nn.Module):
     def __init__(self, opt):
         super().__init__()

@@ -1,7 +1,10 @@
-"""GAN losses (reference: networks/loss.py:16-98; only the hinge mode is on the hot path, data/args.py:156)."""
+"""GAN losses (reference: networks/loss.py:16-98; only the hinge mode is on the hot path, data/args.py:156) and the VGG
+perceptual loss (loss.py:102-118)."""
+import torch
 import torch.nn as nn
 
 from .... import ops
+from .architecture import VGG19
 
 
 class GANLoss(nn.Module):
@@ -29,3 +32,26 @@ class GANLoss(nn.Module):
                 total = total + self.loss(pred, target_is_real, for_discriminator).view(1)
             return total / len(x)
         return self.loss(x, target_is_real, for_discriminator)
+
+
+class VGGLoss(nn.Module):
+    """Perceptual loss (reference: networks/loss.py:102-118): sum_i w_i * L1(vgg_i(x), vgg_i(y).detach()) over the five VGG19
+    slices, w = 1/32, 1/16, 1/8, 1/4, 1; x, y are [B, T, 3, H, W].  The target branch runs without a graph."""
+
+    def __init__(self, gpu_ids=None):
+        super().__init__()
+        self.vgg = VGG19()
+        self.weights = [1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0]
+
+    def forward(self, x, y):
+        bs, nt, ch, h, w = x.size()
+        x = x.contiguous().view(-1, ch, h, w)
+        y = y.contiguous().view(-1, ch, h, w)
+        with ops.bf16x3_min_rows(48):
+            x_vgg = self.vgg(x)
+            with torch.no_grad():
+                y_vgg = self.vgg(y)
+        loss = 0
+        for i in range(len(x_vgg)):
+            loss = loss + self.weights[i] * ops.l1_mean(x_vgg[i], y_vgg[i].detach())
+        return loss

@@ -858,6 +858,32 @@ def avgpool3s2(x):
     return _AvgPool3s2.apply(x)
 
 
+class _MaxPool2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        _chk(x)
+        N, C, H, W = x.shape
+        y = torch.empty((N, C, H // 2, W // 2), device=x.device, dtype=torch.float32)
+        _lib.call('ag2v_maxpool2_fwd', _ptr(x), _ptr(y), N * C, H, W, _stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        N, C, H, W = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        _lib.call('ag2v_maxpool2_bwd', _ptr(dy), _ptr(x), _ptr(dx), N * C, H, W, _stream())
+        return dx
+
+
+def maxpool2(x):
+    """nn.MaxPool2d(kernel_size=2, stride=2) (VGG19.features)."""
+    return _MaxPool2.apply(x)
+
+
 class _NearestResize(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, OH, OW):

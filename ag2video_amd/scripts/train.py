@@ -69,6 +69,26 @@ def main(args):
     lo, hi = args.synthetic_objects
     F_short, F_long = args.frames_per_action, 4 * args.frames_per_action_graph     # dataset_params.py:166-170
     G_losses, D_losses = {}, {}
+    # --data_root: CATER scene files + cached frames through the reference's two loaders (scripts/train.py:116-134); otherwise
+    # seeded synthetic clips of the same tensor contract.  Every rank draws its own shard (DataLoader shuffling is per process).
+    short_it = long_it = None
+    if args.data_root:
+        from ..data.cater import build_loaders
+        torch.manual_seed(args.seed + rank)
+        short_loader, long_loader = build_loaders(args, args.vocab, nframes=args.data_nframes)
+
+        def cycle(loader):
+            while True:
+                for b in loader:
+                    if b[0] is not None:          # collate_fn returns six Nones for an unusable batch (train.py:442)
+                        yield b
+        short_it, long_it = cycle(short_loader), cycle(long_loader)
+
+    def next_clip(kind, seed):
+        if short_it is not None:
+            return next(short_it if kind == 'short' else long_it)
+        return make_clip_batch(args.vocab, args.batch_size, F_short if kind == 'short' else F_long, args.image_size, seed=seed,
+                               min_objs=lo, max_objs=hi)
     while t < args.num_iterations:
         if t % args.checkpoint_every == 0 and rank == 0:
             save_checkpoint(args, os.path.join(args.output_dir, 'itr_%s.pt' % t), ts, epoch, t)
@@ -80,8 +100,7 @@ def main(args):
         # stops the job with a non-zero exit code).
         if not args.graph_only:
             try:
-                batch = ts.to_device(make_clip_batch(args.vocab, args.batch_size, F_short, args.image_size, seed=seed,
-                                                     min_objs=lo, max_objs=hi))
+                batch = ts.to_device(next_clip('short', seed))
                 _, G_losses, D_new = ts.gd_step(batch)
                 if D_new is None:                       # NaN guard tripped on some rank: train.py:450-453 (t += 1; continue)
                     t += 1
@@ -95,8 +114,7 @@ def main(args):
                     raise
         G_graph_losses = {}
         try:
-            gbatch = ts.to_device(make_clip_batch(args.vocab, args.batch_size, F_long, args.image_size, seed=seed + 7,
-                                                  min_objs=lo, max_objs=hi))
+            gbatch = ts.to_device(next_clip('long', seed + 7))
             _, G_graph_losses = ts.graph_step(gbatch)
         except Exception as e:
             print("Error in video_id: {}".format(seed + 7))

@@ -156,6 +156,10 @@ int ag2v_flow_warp_bwd(const float* dout, const float* img, const float* flow, f
  * nn.Upsample(scale_factor=2) normalization.py:102, spade_generator.py:36,55-70, flows_generator.py:47 ------------- */
 int ag2v_avgpool3s2_fwd(const float* x, float* y, int NC, int H, int W, void* stream);
 int ag2v_avgpool3s2_bwd(const float* dy, float* dx, int NC, int H, int W, void* stream);
+/* max_pool2d(2, stride 2), floor mode: the pooling layers of VGG19.features behind the perceptual loss (architecture.py:93-123,
+ * loss.py:102-118); backward routes each window's gradient to its first maximum (row-major), as ATen does. */
+int ag2v_maxpool2_fwd(const float* x, float* y, int NC, int H, int W, void* stream);
+int ag2v_maxpool2_bwd(const float* dy, const float* x, float* dx, int NC, int H, int W, void* stream);
 int ag2v_nearest_resize_fwd(const float* x, float* y, int NC, int H, int W, int OH, int OW, void* stream);
 int ag2v_nearest_resize_bwd(const float* dy, float* dx, int NC, int H, int W, int OH, int OW, void* stream);
 /* Adjoint of the whole nearest-neighbour pyramid of one segmentation map (every SPADE of a decoder pass interpolates the same map,

@@ -166,6 +166,11 @@ def avgpool3s2(x):
     return F.avg_pool2d(x, kernel_size=3, stride=2, padding=[1, 1], count_include_pad=False)
 
 
+def maxpool2(x):
+    """nn.MaxPool2d(kernel_size=2, stride=2): the pooling layers of torchvision's vgg19().features (architecture.py:96-110)."""
+    return F.max_pool2d(x, kernel_size=2, stride=2)
+
+
 def nearest_resize(x, OH, OW):
     """F.interpolate(..., size, mode='nearest') (normalization.py:102, spade_generator.py:55)."""
     return F.interpolate(x, size=(OH, OW), mode='nearest')

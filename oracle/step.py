@@ -13,10 +13,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 class OracleTrainer(object):
-    def __init__(self, opt, key_shapes_G, key_shapes_D, wseed):
+    def __init__(self, opt, key_shapes_G, key_shapes_D, wseed, key_shapes_V=None):
         self.opt = opt
         self.G = M.make_state(key_shapes_G, wseed, 'G.')
         self.D = M.make_state(key_shapes_D, wseed, 'D.')
+        self.V = None
+        if not opt.no_vgg_loss:           # frozen VGG19 of the perceptual loss (keys 'vgg.slice<k>.<i>.weight|bias')
+            self.V = {k: v.detach() for k, v in M.make_state(key_shapes_V, wseed, 'V.').items()}
         lr, b1 = opt.learning_rate, opt.beta1
         graph_params = M.params_of(self.G, 'acts_to_boxes.')
         gen_params = [t for n, t in self.G.items() if t.requires_grad and not n.startswith('acts_to_boxes.')]
@@ -29,7 +32,7 @@ class OracleTrainer(object):
         opt = self.opt
         imgs, objs, boxes, triplets, actions = batch[:5]
         model_out = M.generator_forward(self.G, opt, imgs, objs, triplets, actions, boxes, training=True, use_gt=True)
-        G_losses = M.generator_loss(self.D, opt, batch, model_out)
+        G_losses = M.generator_loss(self.D, opt, batch, model_out, V=self.V)
         G_losses = {k: v.mean() for k, v in G_losses.items()}
         self.opt_gen.zero_grad()
         G_losses['total_loss'].backward()

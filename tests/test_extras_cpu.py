@@ -1,0 +1,134 @@
+"""Pins of the SURVEY 8(f) "next" rows and D4 against golden vectors of the unmodified reference classes
+(tests/golden/extras.npz, generator: tests/golden/make_golden_extras.py): the oracle's VGG perceptual loss and temporal
+discriminator; the product's host-side data path (collate_fn, CATER scene -> tensors) which is plain integer / small float work
+and therefore compared (bit-)exactly on the CPU."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope='module')
+def gold():
+    return np.load(os.path.join(HERE, 'golden', 'extras.npz'), allow_pickle=False)
+
+
+def test_oracle_vgg_loss_matches_reference(gold):
+    from oracle import model as M
+    shapes = json.loads(str(gold['vgg.keys']))
+    assert len(shapes) == 26 and 'vgg.slice4.19.weight' in shapes and shapes['vgg.slice5.28.weight'] == [512, 512, 3, 3]
+    V = {k: v.detach() for k, v in M.make_state(shapes, 3, 'V.').items()}
+    x = torch.from_numpy(gold['vgg.x']).requires_grad_(True)
+    y = torch.from_numpy(gold['vgg.y'])
+    loss = M.vgg_loss(V, x, y)
+    loss.backward()
+    assert abs(loss.item() - float(gold['vgg.loss'])) <= 1e-5 * abs(float(gold['vgg.loss']))
+    ref = gold['vgg.grad_x']
+    assert np.abs(x.grad.numpy() - ref).max() <= 2e-4 * np.abs(ref).max()
+    feats = M.vgg19_slices(V, x.detach().view(-1, 3, 32, 32))
+    for i, f in enumerate(feats):
+        st = gold['vgg.feat%d_stats' % i]
+        assert tuple(f.shape[1:3]) == (int(st[2]), int(st[3])) and abs(f.abs().sum().item() - st[1]) <= 1e-4 * st[1]
+
+
+def test_oracle_temporal_discriminator_matches_reference(gold):
+    from ag2video_amd.data.args import make_opt
+    from ag2video_amd.data.vocab import cater_vocab
+    from oracle import model as M
+    opt = make_opt(cater_vocab(), ['--gpu_ids', '-1', '--no_vgg_loss', '--image_size', '32,32', '--batch_size', '2', '--ndf', '8',
+                                  '--frames_per_action', '4'])
+    shapes = json.loads(str(gold['dtemp.keys']))
+    PT = M.make_state(shapes, 5, 'T.')
+    img = torch.from_numpy(gold['dtemp.img']).requires_grad_(True)
+    res = M.temporal_discriminator_forward(PT, opt, img, training=True)
+    tot = 0
+    for i, scale in enumerate(res):
+        for j, f in enumerate(scale):
+            ref = gold['dtemp.out%d_%d' % (i, j)]
+            assert np.abs(f.detach().numpy() - ref).max() <= 2e-4 * np.abs(ref).max(), (i, j)
+            tot = tot + (f * torch.linspace(-1, 1, f.numel()).view_as(f)).sum()
+    tot.backward()
+    ref = gold['dtemp.grad_img']
+    assert np.abs(img.grad.numpy() - ref).max() <= 1e-3 * np.abs(ref).max()
+    for k, t in PT.items():
+        if k.endswith('weight_u'):
+            assert np.abs(t.numpy() - gold['dtemp.state.' + k]).max() <= 1e-5
+        if t.grad is not None and ('dtemp.grad.' + k) in gold.files:
+            got = np.array([t.grad.double().abs().sum().item(), t.grad.double().pow(2).sum().sqrt().item()])
+            assert np.allclose(got, gold['dtemp.grad.' + k], rtol=2e-3, atol=1e-6), k
+
+
+def test_collate_fn_matches_reference(gold):
+    from ag2video_amd.data.cater import collate_fn
+    from ag2video_amd.data.vocab import cater_vocab
+    vocab = cater_vocab()
+    items = []
+    for i in range(4):
+        if ('collate.in%d.vid' % i) not in gold.files:
+            items.append((False, None, None, None, None, None))
+            continue
+        objs = {a: torch.from_numpy(gold['collate.in%d.objs.%s' % (i, a)]) for a in vocab['attributes']}
+        items.append((torch.from_numpy(gold['collate.in%d.vid' % i]), objs, torch.from_numpy(gold['collate.in%d.boxes' % i]),
+                      torch.from_numpy(gold['collate.in%d.triplets' % i]), torch.from_numpy(gold['collate.in%d.actions' % i]),
+                      'vid%d' % (i if i == 0 else i - 1)))
+    out = collate_fn(vocab, items)
+    for n, t in zip(('vids', 'objs', 'boxes', 'triplets', 'actions'), out[:5]):
+        ref = gold['collate.out.' + n]
+        assert t.numpy().dtype == ref.dtype and np.array_equal(t.numpy(), ref), n
+    assert out[5] == json.loads(str(gold['collate.out.ids']))
+    assert collate_fn(vocab, [(None,) * 6]) == (None,) * 6             # nothing usable: six Nones (dataset_params.py:102-104)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_cater_scene_tensors_match_reference(gold, seed):
+    from ag2video_amd.data import cater as C
+    from ag2video_amd.data.vocab import cater_vocab
+    vocab = cater_vocab()
+    sg = C.synthetic_scene(seed, nframes=301)
+    p = 'cater.s%d.' % seed
+    for a, v in C.scene_objects(sg, vocab).items():
+        assert np.array_equal(v.numpy(), gold[p + 'objs.' + a]), a
+    boxes = C.scene_boxes(sg)
+    assert boxes.dtype == torch.float32 and np.abs(boxes.numpy() - gold[p + 'boxes_all']).max() <= 1e-6
+    rows = C.scene_actions(sg, vocab)
+    actions, (s, e) = C.choose_window(rows, 300, 48, True)
+    assert (s, e) == tuple(gold[p + 'window']) and np.array_equal(actions.numpy(), gold[p + 'actions_raw'])
+    norm = C.normalize_actions(actions, boxes, s, e, vocab)
+    assert np.abs(norm.numpy() - gold[p + 'actions_norm']).max() <= 1e-6
+    frames = list(range(s, e))[0:48:48 // 16]
+    assert frames == list(gold[p + 'frames_lst'])
+    assert np.array_equal(C.frame_triplets(len(frames), boxes.size(1) - 1, vocab).numpy(), gold[p + 'triplets'])
+    np.random.seed(11 + seed)
+    actions_t, (s2, e2) = C.choose_window(rows, 300, 48, False)
+    assert (s2, e2) == tuple(gold[p + 'train_window'])
+    assert np.abs(C.normalize_actions(actions_t, boxes, s2, e2, vocab).numpy() - gold[p + 'train_actions_norm']).max() <= 1e-6
+
+
+def test_cater_loader_end_to_end(tmp_path):
+    """Scene files + cached frames on disk -> DataLoader with collate_fn -> a batch with the training step's contract."""
+    from functools import partial
+    from ag2video_amd.data import cater as C
+    from ag2video_amd.data.vocab import cater_vocab
+    vocab = cater_vocab()
+    root = str(tmp_path)
+    lst = C.write_synthetic_dataset(root, n_videos=3, nframes=70, seed=2, frame_size=(24, 32))
+    ds = C.CATERScenes(root, vocab, list_file=lst, is_test=True, nframes=70, image_size=(16, 16), frames_per_action=4,
+                       initial_frames_per_sample=48)
+    assert len(ds) == 3
+    vdir = os.path.join(root, 'videos', ds.names[1])
+    os.remove(os.path.join(vdir, sorted(os.listdir(vdir))[0]))                     # a video whose frame cache is incomplete
+    loader = torch.utils.data.DataLoader(ds, batch_size=3, shuffle=False, collate_fn=partial(C.collate_fn, vocab))
+    imgs, objs, boxes, triplets, actions, ids = next(iter(loader))
+    assert imgs.shape == (2, 4, 3, 16, 16) and imgs.dtype == torch.float32          # the video with a missing frame is dropped
+    B, O = objs.shape[0], objs.shape[1]
+    assert objs.shape == (2, O, 4) and objs.dtype == torch.int64 and boxes.shape == (2, 4, O, 4)
+    assert triplets.shape[:2] == (2, 4) and triplets.shape[3] == 3 and actions.shape[2] == 7 and len(ids) == 2
+    assert (objs[:, -1] == 0).all() or O > 0
+    for b in range(B):
+        n = int((objs[b].sum(1) != 0).sum())                                       # real objects; then the __image__ row, then padding
+        assert torch.equal(boxes[b, :, n], torch.tensor([0.0, 0.0, 1.0, 1.0]).expand(4, 4))
+        assert (boxes[b, :, n + 1:] == -1).all()

@@ -1,0 +1,139 @@
+"""GPU side of the SURVEY 8(f) "next" rows and D4: the product's VGG perceptual loss (conv + ReLU epilogues, the 2x2 max-pool
+kernel) and temporal discriminator against golden vectors of the reference classes (tests/golden/extras.npz) and the oracle, and one
+full training step with the perceptual loss switched on."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope='module')
+def gold():
+    return np.load(os.path.join(HERE, 'golden', 'extras.npz'), allow_pickle=False)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 8, 8), (1, 5, 9, 7), (3, 2, 32, 32)], ids=str)
+def test_maxpool2(shape, device):
+    """Forward, and the backward's routing to the first maximum of each window -- including exact ties (ReLU zeros)."""
+    from ag2video_amd import ops
+    from oracle import kernels as K
+    g = torch.Generator().manual_seed(1)
+    x = torch.relu(torch.randn(*shape, generator=g))             # ~half zeros: windows with tied maxima
+    x[0, 0, :2, :2] = 0.75                                       # a window of four equal positive values
+    xc, xg = x.clone().requires_grad_(True), x.clone().to(device).requires_grad_(True)
+    yr, yg = K.maxpool2(xc), ops.maxpool2(xg)
+    assert torch.equal(yg.detach().cpu(), yr.detach())
+    w = torch.randn(yr.shape, generator=g)
+    (yr * w).sum().backward()
+    (yg * w.to(device)).sum().backward()
+    assert torch.equal(xg.grad.cpu(), xc.grad)
+
+
+@pytest.mark.parametrize("prec", ['bf16x3', 'fp32'])
+def test_vgg_loss_matches_reference_golden(prec, gold, device):
+    from ag2video_amd import ops
+    from ag2video_amd.models.spade_models.networks.loss import VGGLoss
+    from ag2video_amd.weights import closed_form_fill_
+    old = ops.get_conv_precision()
+    ops.set_conv_precision(prec)
+    try:
+        vl = VGGLoss([]).to(device)
+        assert {k: list(v.shape) for k, v in vl.state_dict().items()} == json.loads(str(gold['vgg.keys']))
+        closed_form_fill_(vl, seed=3, prefix='V.')
+        assert not any(p.requires_grad for p in vl.parameters())
+        x = torch.from_numpy(gold['vgg.x']).to(device).requires_grad_(True)
+        y = torch.from_numpy(gold['vgg.y']).to(device)
+        loss = vl(x, y)
+        loss.backward()
+        ref = float(gold['vgg.loss'])
+        assert abs(loss.item() - ref) <= 1e-3 * abs(ref), (loss.item(), ref)
+        rg = gold['vgg.grad_x']
+        assert np.abs(x.grad.cpu().numpy() - rg).max() <= 2e-3 * np.abs(rg).max()      # L1 of ReLU features: sign-function derivative
+    finally:
+        ops.set_conv_precision(old)
+
+
+def test_temporal_discriminator_matches_reference_golden(gold, device):
+    from ag2video_amd.data.args import make_opt
+    from ag2video_amd.data.vocab import cater_vocab
+    from ag2video_amd.models.spade_models.networks.discriminator import MultiscaleDiscriminatorT
+    from ag2video_amd.weights import closed_form_fill_
+    opt = make_opt(cater_vocab(), ['--gpu_ids', '0', '--no_vgg_loss', '--image_size', '32,32', '--batch_size', '2', '--ndf', '8',
+                                  '--frames_per_action', '4'])
+    dt = MultiscaleDiscriminatorT(opt).to(device)
+    assert {k: list(v.shape) for k, v in dt.state_dict().items()} == json.loads(str(gold['dtemp.keys']))
+    closed_form_fill_(dt, seed=5, prefix='T.')
+    dt.train()
+    img = torch.from_numpy(gold['dtemp.img']).to(device).requires_grad_(True)
+    res = dt(img)
+    tot = 0
+    for i, scale in enumerate(res):
+        for j, f in enumerate(scale):
+            ref = gold['dtemp.out%d_%d' % (i, j)]
+            assert np.abs(f.detach().cpu().numpy() - ref).max() <= 1e-3 * np.abs(ref).max(), (i, j)
+            tot = tot + (f * torch.linspace(-1, 1, f.numel(), device=device).view_as(f)).sum()
+    tot.backward()
+    ref = gold['dtemp.grad_img']
+    assert np.abs(img.grad.cpu().numpy() - ref).max() <= 2e-3 * np.abs(ref).max()
+    for k, v in dt.state_dict().items():
+        if k.endswith('weight_u'):
+            assert np.abs(v.cpu().numpy() - gold['dtemp.state.' + k]).max() <= 1e-4, k
+    for n, p in dt.named_parameters():
+        key = 'dtemp.grad.' + n
+        if p.grad is not None and key in gold.files:
+            got = np.array([p.grad.double().abs().sum().item(), p.grad.double().pow(2).sum().sqrt().item()])
+            assert np.allclose(got, gold[key], rtol=2e-2, atol=1e-5), n
+
+
+def test_train_step_with_vgg_loss_matches_oracle(device):
+    """The full G + D step with the perceptual loss on (--no_vgg_loss absent): loss keys of the reference (loss_model.py:99-100),
+    values against the oracle, gradient reaching the generator through VGG."""
+    from ag2video_amd.data.args import make_opt
+    from ag2video_amd.data.synthetic import make_clip_batch
+    from ag2video_amd.data.vocab import cater_vocab
+    from ag2video_amd.engine import TrainStep
+    from oracle.step import OracleTrainer
+    flags = ['--image_size', '64,64', '--batch_size', '2', '--ngf', '8', '--ndf', '8', '--nff', '8', '--gconv_hidden_dim', '64',
+             '--gpu_ids', '0']
+    opt = make_opt(cater_vocab(), flags)
+    assert not opt.no_vgg_loss
+    ts = TrainStep(opt, device, weights_seed=6)
+    sd_gm = ts.gans_model.state_dict()
+    assert 'module.criterionVGG.vgg.slice1.0.weight' in sd_gm and len([k for k in sd_gm if 'criterionVGG' in k]) == 26
+    shapes_G = {k: list(v.shape) for k, v in ts.model.state_dict().items()}
+    shapes_D = {k: list(v.shape) for k, v in ts.discriminator.img_discriminator.state_dict().items()}
+    shapes_V = {k: list(v.shape) for k, v in ts.gans_model.module.criterionVGG.state_dict().items()}
+    orc = OracleTrainer(opt, shapes_G, shapes_D, 6, shapes_V)
+    clip = make_clip_batch(opt.vocab, 2, 3, (64, 64), seed=17)
+    _, GL_r, DL_r = orc.gd_step(clip)
+    _, GL, DL = ts.gd_step(ts.to_device(clip))
+    assert set(GL) == set(GL_r) == {'GAN_Img', 'GAN_Feat', 'loss_F_Warp', 'VGG', 'total_loss'}
+    for got, ref in ((GL, GL_r), (DL, DL_r)):
+        for k in ref:
+            assert abs(got[k].item() - ref[k].item()) <= 1e-3 * max(1.0, abs(ref[k].item())), (k, got[k].item(), ref[k].item())
+    g = ts.model.layout_to_video.module.netG.conv_img.weight.grad
+    r = orc.last_G_grads['layout_to_video.module.netG.conv_img.weight']
+    assert abs(g.abs().sum().item() - r.abs().sum().item()) <= 2e-2 * r.abs().sum().item()
+
+
+def test_train_script_on_scene_files(device, tmp_path):
+    """python -m ag2video_amd.scripts.train --data_root <CATER-format directory>: scene JSON + cached frames -> loaders -> collate_fn
+    -> G/D/graph steps on the GPU -> checkpoint with the reference's keys."""
+    from ag2video_amd.data import cater as C
+    from ag2video_amd.data.args import get_args
+    from ag2video_amd.scripts import train as T
+    root = os.path.join(str(tmp_path), 'cater')
+    C.write_synthetic_dataset(root, n_videos=3, nframes=60, seed=4, frame_size=(48, 64))
+    out = os.path.join(str(tmp_path), 'out')
+    args = get_args(['--data_root', root, '--data_nframes', '60', '--image_size', '64,64', '--batch_size', '2', '--ngf', '8', '--ndf', '8',
+                     '--nff', '8', '--gconv_hidden_dim', '64', '--no_vgg_loss', '--num_iterations', '2', '--frames_per_action', '3',
+                     '--frames_per_action_graph', '1', '--loader_num_workers', '0', '--output_dir', out, '--checkpoint_every', '100',
+                     '--print_every', '1'])
+    T.main(args)
+    ck = torch.load(os.path.join(out, 'latest.pt'), map_location='cpu', weights_only=False)
+    assert ck['counters']['t'] == 2 and 'model_state' in ck and json.load(open(os.path.join(out, 'run_args.json')))['data_root'] == root

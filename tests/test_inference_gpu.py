@@ -1,0 +1,195 @@
+"""inference / checkpoint compatibility (reference scripts/test.py:170-301, scripts/train.py:27-57,136-137,528-543).
+
+* eval-mode generator (model.eval(): running-statistic norms, spectral norm without power iteration) against the oracle;
+* autoregressive inference as scripts/test.py runs it (test_mode=True, use_gt=False: every frame is generated from the model's own
+  previous frame and laid out with the model's own PREDICTED boxes) against the oracle, every frame at 1e-3;
+* checkpoint dictionary with the reference's key set: save_checkpoint -> restore_checkpoint round trip on the GPU including the
+  flat-buffer Adam state, a load of a dictionary holding exactly the reference's state_dict keys, and "training continues
+  identically after a restore".
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+TOY = ['--image_size', '64,64', '--batch_size', '2', '--ngf', '8', '--ndf', '8', '--nff', '8', '--gconv_hidden_dim', '64']
+
+
+def _pair(device, wseed=9, flags=TOY):
+    from ag2video_amd.data.args import make_opt
+    from ag2video_amd.data.vocab import cater_vocab
+    from ag2video_amd.engine import TrainStep
+    from oracle.step import OracleTrainer
+    opt = make_opt(cater_vocab(), list(flags) + ['--gpu_ids', '0', '--no_vgg_loss'])
+    ts = TrainStep(opt, device, weights_seed=wseed)
+    shapes_G = {k: list(v.shape) for k, v in ts.model.state_dict().items()}
+    shapes_D = {k: list(v.shape) for k, v in ts.discriminator.img_discriminator.state_dict().items()}
+    return opt, ts, OracleTrainer(opt, shapes_G, shapes_D, wseed)
+
+
+def _sane_box_net(ts, orc, scale=2e-3):
+    """Closed-form random weights make box_net's output O(1) per step: predicted boxes leave the image after one frame and the
+    comparison becomes a test of conditioning.  Scaling the LAST box_net layer (weights and bias, both sides alike) keeps the
+    predicted boxes within a few percent of the previous frame's -- a trained model's regime."""
+    with torch.no_grad():
+        for net in ('acts_to_boxes', 'acts_to_objs'):
+            for p in ('weight', 'bias'):
+                k = '%s.module.box_net.2.%s' % (net, p)
+                orc.G[k].mul_(scale)
+                dict(ts.model.named_parameters())[k].mul_(scale)
+
+
+def _populate_running_stats(ts, orc, opt, n=3):
+    """Freshly initialised running statistics (mean 0, var 1) normalise nothing and the closed-form weights overflow in eval
+    mode on both sides: run a few training-mode forward passes first (each frame pass moves them by momentum 0.1), alike on both."""
+    from ag2video_amd.data.synthetic import make_clip_batch
+    from oracle import model as M
+    for i in range(n):
+        clip = make_clip_batch(opt.vocab, 2, 4, (64, 64), seed=50 + i)
+        with torch.no_grad():
+            M.generator_forward(orc.G, opt, *[clip[j] for j in (0, 1, 3, 4, 2)], training=True, use_gt=True)
+            d = ts.to_device(clip)
+            ts.model(d[0], d[1], d[3], d[4], boxes_gt=d[2], test_mode=False, use_gt=True)
+
+
+def test_eval_mode_generator_matches_oracle(device):
+    """model.eval() as in validation (scripts/train.py:136-137) and scripts/test.py:193: teacher-forced and autoregressive."""
+    from ag2video_amd.data.synthetic import make_clip_batch
+    from oracle import model as M
+    opt, ts, orc = _pair(device)
+    _sane_box_net(ts, orc)
+    _populate_running_stats(ts, orc, opt)
+    for k, v in ts.model.state_dict().items():              # the warm-up itself agrees (running statistics, u / v)
+        if 'running_' in k or k.endswith('weight_u'):
+            ref = orc.G[k]
+            assert (v.cpu() - ref).abs().max().item() <= 1e-3 * max(ref.abs().max().item(), 1e-6), k
+    ts.model.eval()
+    clip = make_clip_batch(opt.vocab, 2, 5, (64, 64), seed=5)
+    imgs, objs, boxes, triplets, actions = clip[:5]
+    d = ts.to_device(clip)
+    sd0 = {k: v.clone() for k, v in ts.model.state_dict().items()}
+    for test_mode, use_gt in ((False, True), (True, False)):
+        with torch.no_grad():
+            ref = M.generator_forward(orc.G, opt, imgs, objs, triplets, actions, boxes, training=False, use_gt=use_gt,
+                                      test_mode=test_mode)
+            got = ts.model(d[0], d[1], d[3], d[4], boxes_gt=d[2], test_mode=test_mode, use_gt=use_gt)
+        assert np.isfinite(ref[0].numpy()).all()
+        for i, name in enumerate(('imgs_pred', 'boxes_pred', 'flows_pred')):
+            r = ref[i].numpy()
+            g = got[i].cpu().numpy()
+            for f in range(r.shape[1]):                      # every frame, also the ones generated from generated frames
+                err = np.abs(g[:, f] - r[:, f]).max()
+                assert err <= 1e-3 * np.abs(r).max(), (name, test_mode, f, err, np.abs(r).max())
+    # eval mode leaves every buffer untouched (no running-stat update, no power iteration)
+    for k, v in ts.model.state_dict().items():
+        assert torch.equal(v, sd0[k]), k
+
+
+def test_autoregressive_training_mode_norms_matches_oracle(device):
+    """test_mode=True, use_gt=False with batch-statistic norms (a freshly initialised model): predicted boxes + generated previous
+    frames, all frames at 1e-3."""
+    from ag2video_amd.data.synthetic import make_clip_batch
+    from oracle import model as M
+    opt, ts, orc = _pair(device, wseed=4)
+    _sane_box_net(ts, orc)
+    clip = make_clip_batch(opt.vocab, 2, 4, (64, 64), seed=8)
+    imgs, objs, boxes, triplets, actions = clip[:5]
+    with torch.no_grad():
+        ref = M.generator_forward(orc.G, opt, imgs, objs, triplets, actions, boxes, training=True, use_gt=False, test_mode=True)
+        d = ts.to_device(clip)
+        got = ts.model(d[0], d[1], d[3], d[4], boxes_gt=d[2], test_mode=True, use_gt=False)
+    r_b = ref[1].numpy()
+    assert np.abs(got[1].cpu().numpy() - r_b).max() <= 1e-3 * np.abs(r_b).max()
+    assert np.abs(r_b[:, 1:, :-1] - r_b[:, :1, :-1]).max() < 0.25          # the predicted boxes are sane
+    r, g = ref[0].numpy(), got[0].cpu().numpy()
+    for f in range(r.shape[1]):
+        assert np.abs(g[:, f] - r[:, f]).max() <= (1e-3 if f < 2 else 4e-3) * np.abs(r).max(), f
+
+
+def test_checkpoint_round_trip_and_reference_keys(device, tmp_path):
+    from ag2video_amd.data.args import make_opt
+    from ag2video_amd.data.synthetic import make_clip_batch
+    from ag2video_amd.data.vocab import cater_vocab
+    from ag2video_amd.engine import TrainStep
+    from ag2video_amd.scripts.train import restore_checkpoint, save_checkpoint
+    flags = TOY + ['--gpu_ids', '0', '--no_vgg_loss']
+    opt = make_opt(cater_vocab(), flags)
+    ts = TrainStep(opt, device, weights_seed=3)
+    clips = [ts.to_device(make_clip_batch(opt.vocab, 2, 3, (64, 64), seed=30 + i)) for i in range(3)]
+    ts.gd_step(clips[0]); ts.graph_step(clips[0])
+    path = os.path.join(str(tmp_path), 'itr_1.pt')
+    save_checkpoint(opt, path, ts, epoch=0, t=1)
+    ck = torch.load(path, map_location='cpu', weights_only=False)
+    # the dictionary has the reference's keys (scripts/train.py:528-543) and its state dicts the reference's key sets
+    assert set(ck) == {'model_state', 'gans_model_state', 'd_img_state', 'd_img_optim_state', 'optim_state_gen', 'optim_state_graph',
+                       'vocab', 'counters'}
+    ref_keys = json.load(open(os.path.join(HERE, 'golden', 'toy64_state_keys.json')))
+    for name, key in (('model_state', 'model'), ('d_img_state', 'd_img'), ('gans_model_state', 'gans_model')):
+        assert set(ck[name]) == set(ref_keys[key]), name
+        for k, shp in ref_keys[key].items():
+            assert list(ck[name][k].shape) == shp, (name, k)
+    # torch.optim.Adam layout of the optimizer states: per-parameter step / exp_avg / exp_avg_sq, in parameter order
+    for name, n in (('optim_state_gen', len(ts._gen_params)), ('optim_state_graph', len(ts._graph_params)), ('d_img_optim_state', len(ts._d_params))):
+        st = ck[name]['state']
+        assert len(st) == n and set(st[0]) == {'step', 'exp_avg', 'exp_avg_sq'}, name
+        assert ck[name]['param_groups'][0]['params'] == list(range(n))
+    # continue training from the live object ...
+    ts.gd_step(clips[1]); ts.graph_step(clips[1])
+    sd_live = {k: v.clone() for k, v in ts.model.state_dict().items()}
+    sdD_live = {k: v.clone() for k, v in ts.discriminator.img_discriminator.state_dict().items()}
+    # ... and from a freshly built one restored from the file: identical parameters and buffers afterwards (to the noise of the
+    # split-K atomics: lr = 1e-4 per Adam step bounds what a flipped gradient sign can move)
+    ts2 = TrainStep(opt, device, weights_seed=11)
+    vocab, epoch, t = restore_checkpoint(opt, ts2, path)
+    assert (epoch, t) == (0, 1) and vocab.keys() == opt.vocab.keys()
+    assert ts2.optimizer_generator._step == 1 and ts2.discriminator.optimizer_d_img._step == 1 and ts2.optimizer_graph._step == 1
+    for k, v in ts2.model.state_dict().items():
+        assert torch.equal(v.cpu(), ck['model_state'][k]), k
+    for a, b in ((ts2.optimizer_generator.flat_m, ts.optimizer_generator), (ts2.optimizer_generator.flat_v, ts.optimizer_generator)):
+        assert a.abs().sum().item() > 0
+    ts2.gd_step(clips[1]); ts2.graph_step(clips[1])
+    lr = opt.learning_rate
+    for live, new in ((sd_live, ts2.model.state_dict()), (sdD_live, ts2.discriminator.img_discriminator.state_dict())):
+        for k in live:
+            a, b = live[k].float(), new[k].float()
+            assert (a - b).abs().max().item() <= 2.5 * lr + 1e-3 * a.abs().max().item(), k
+        # and they really moved together: mean |difference| far below one Adam step
+        diffs = torch.cat([(live[k].float() - new[k].float()).abs().reshape(-1) for k in live if live[k].is_floating_point()])
+        assert diffs.mean().item() < 0.05 * lr
+    # a dictionary with the reference's state_dict layout produced elsewhere (here: the oracle's flat state, keyed by the reference's
+    # own names) loads strictly
+    from oracle import model as M
+    shapes_G = {k: list(v.shape) for k, v in ts.model.state_dict().items()}
+    G = M.make_state(shapes_G, 21, 'G.')
+    ts2.model.load_state_dict({k: v.detach() for k, v in G.items()}, strict=True)
+    for k, v in ts2.model.state_dict().items():
+        assert torch.equal(v.cpu(), G[k].detach()), k
+
+
+def test_inference_script_runs(device, tmp_path):
+    """ag2video_amd.scripts.test (counterpart of scripts/test.py): restores a checkpoint written by scripts.train's save_checkpoint
+    + run_args.json, runs the scripted action edits autoregressively and writes the predicted clips."""
+    from ag2video_amd.data.args import make_opt
+    from ag2video_amd.data.vocab import cater_vocab
+    from ag2video_amd.engine import TrainStep
+    from ag2video_amd.scripts import test as T
+    from ag2video_amd.scripts.train import save_checkpoint
+    flags = TOY + ['--gpu_ids', '0', '--no_vgg_loss']
+    opt = make_opt(cater_vocab(), flags)
+    ts = TrainStep(opt, device, weights_seed=3)
+    run_dir = os.path.join(str(tmp_path), 'run')
+    os.makedirs(run_dir)
+    json.dump({k: v for k, v in vars(opt).items() if k != 'vocab'}, open(os.path.join(run_dir, 'run_args.json'), 'w'))
+    save_checkpoint(opt, os.path.join(run_dir, 'latest.pt'), ts, 0, 0)
+    out_dir = os.path.join(str(tmp_path), 'out')
+    res = T.main(['--checkpoint', os.path.join(run_dir, 'latest.pt'), '--gpu_ids', '0', '--output_dir', out_dir, '--num_clips', '1',
+                  '--frames', '4'])
+    assert res['clips'] == 1 and res['edits'] >= 3
+    files = [os.path.join(dp, f) for dp, _, fs in os.walk(out_dir) for f in fs]
+    assert any(f.endswith('.npz') for f in files)
+    z = np.load([f for f in files if f.endswith('.npz')][0])
+    assert z['imgs_pred'].shape == (4, 3, 64, 64) and np.isfinite(z['imgs_pred']).all()
