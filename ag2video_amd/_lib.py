@@ -39,6 +39,8 @@ _SIGS = {
     'ag2v_bn_stats_g': (c_int, [_P, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P]),
     'ag2v_norm_apply_g': (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     'ag2v_norm_bwd_g': (c_int, [c_int] + [_P] * 11 + [c_int, c_int, c_int, c_int, c_float, _P, _P]),
+    'ag2v_norm_bwd_reduce_g': (c_int, [c_int] + [_P] * 7 + [c_int, c_int, c_int, c_int, c_float, _P, _P]),
+    'ag2v_norm_bwd_apply_g': (c_int, [c_int] + [_P] * 8 + [c_float, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     'ag2v_instnorm_lrelu_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P]),
     'ag2v_instnorm_lrelu_bwd': (c_int, [_P] * 6 + [c_int, c_int, c_float, _P]),
     'ag2v_layout_render_fwd': (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [_P]),

@@ -392,17 +392,19 @@ extern "C" int ag2v_norm_apply(int mode, const float* x, const float* mean, cons
     return ag2v_norm_apply_g(mode, x, mean, invstd, w, b, gamma, beta, y, N, C, HW, N, slope, stream);
 }
 
-// Backward of ag2v_norm_apply_g with batch statistics (training mode).
-//   sums[G*2C] receives (sum dxhat, sum dxhat*xhat) per (group, channel): for mode 0 these are the groups' (dbias, dweight).
-//   mode 1 additionally writes dgamma/dbeta (same shape as x).  y is the forward output (activation sign); may be null if slope==1.
-extern "C" int ag2v_norm_bwd_g(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* w,
-                               const float* mean, const float* invstd, float* dx, float* dgamma, float* dbeta, float* sums,
-                               int N, int C, int HW, int Ng, float slope, float* workspace, void* stream) {
-    if (!dy || !x || !mean || !invstd || !dx || !sums || !workspace || N <= 0 || C <= 0 || HW <= 0 || Ng <= 0 || N % Ng != 0)
-        return AG2V_EINVAL;
+// Backward of ag2v_norm_apply_g with batch statistics (training mode), in two steps so that a data-parallel caller can all-reduce
+// the per-(group, channel) sums between them (synchronised batch norm, sync_batchnorm/batchnorm.py:105-126):
+//   reduce: sums[G*C*2] = (sum dxhat, sum dxhat*xhat) over this process's samples;   mode 0: these are the groups' (dbias, dweight)
+//   apply:  dx (and, modes 1 / 2, dgamma / dbeta) from sums and inv_count = 1 / (#elements per (group, channel) the sums cover).
+// y is the forward output (activation sign); may be null if slope == 1.
+static int norm_bwd_launch(int mode, bool do_reduce, bool do_apply, const float* dy, const float* y, const float* x, const float* gamma,
+                           const float* w, const float* mean, const float* invstd, float* dx, float* dgamma, float* dbeta, float* sums,
+                           int N, int C, int HW, int Ng, float slope, float inv_count, float* workspace, hipStream_t st) {
+    if (!dy || !x || !mean || !invstd || !sums || N <= 0 || C <= 0 || HW <= 0 || Ng <= 0 || N % Ng != 0) return AG2V_EINVAL;
+    if (do_reduce && !workspace) return AG2V_EINVAL;
+    if (do_apply && !dx) return AG2V_EINVAL;
     if (slope != 1.f && !y) return AG2V_EINVAL;
-    if (mode < 0 || mode > 2 || (mode >= 1 && (!gamma || !dgamma || !dbeta))) return AG2V_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
+    if (mode < 0 || mode > 2 || (mode >= 1 && !gamma) || (mode >= 1 && do_apply && (!dgamma || !dbeta))) return AG2V_EINVAL;
     const int nchunk = ceil_div(HW, CHUNK);
     const long long nblk = (long long)N * C * nchunk;
     if (nblk >= (1LL << 31)) return AG2V_EINVAL;
@@ -410,13 +412,15 @@ extern "C" int ag2v_norm_bwd_g(int mode, const float* dy, const float* y, const 
     const long long gbx = (mode == 2) ? (long long)C * HW : 0;   // mode 2: gamma, dgamma / dbeta are halves of [N,2C,HW] tensors
     dim3 g((unsigned)nblk), t(256);
     const int GC = (N / Ng) * C;
-    const float inv_count = 1.0f / ((float)Ng * (float)HW);
-#define LAUNCH_BWD(M, V)                                                                                                         \
-    hipLaunchKernelGGL((norm_bwd_reduce_kernel<M, V>), g, t, 0, st, dy, y, x, gamma, mean, invstd, workspace, Ng, C, HW, nchunk, \
-                       slope, gbx);                                                                                              \
-    hipLaunchKernelGGL(pair_sum_finalize_kernel, dim3(ceil_div(GC, 64)), dim3(64), 0, st, workspace, GC, Ng* nchunk, sums);      \
-    hipLaunchKernelGGL((norm_bwd_apply_kernel<M, V>), g, t, 0, st, dy, y, x, gamma, w, mean, invstd, sums, dx, dgamma, dbeta, C, \
-                       HW, nchunk, inv_count, slope, gbx, Ng);
+#define LAUNCH_BWD(M, V)                                                                                                             \
+    if (do_reduce) {                                                                                                                 \
+        hipLaunchKernelGGL((norm_bwd_reduce_kernel<M, V>), g, t, 0, st, dy, y, x, gamma, mean, invstd, workspace, Ng, C, HW, nchunk, \
+                           slope, gbx);                                                                                              \
+        hipLaunchKernelGGL(pair_sum_finalize_kernel, dim3(ceil_div(GC, 64)), dim3(64), 0, st, workspace, GC, Ng* nchunk, sums);      \
+    }                                                                                                                                \
+    if (do_apply)                                                                                                                    \
+        hipLaunchKernelGGL((norm_bwd_apply_kernel<M, V>), g, t, 0, st, dy, y, x, gamma, w, mean, invstd, sums, dx, dgamma, dbeta, C, \
+                           HW, nchunk, inv_count, slope, gbx, Ng);
     if (mode == 0) {
         if (v) { LAUNCH_BWD(0, true) } else { LAUNCH_BWD(0, false) }
     } else {
@@ -425,6 +429,25 @@ extern "C" int ag2v_norm_bwd_g(int mode, const float* dy, const float* y, const 
 #undef LAUNCH_BWD
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
+}
+extern "C" int ag2v_norm_bwd_g(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* w,
+                               const float* mean, const float* invstd, float* dx, float* dgamma, float* dbeta, float* sums,
+                               int N, int C, int HW, int Ng, float slope, float* workspace, void* stream) {
+    if (Ng <= 0 || HW <= 0) return AG2V_EINVAL;
+    return norm_bwd_launch(mode, true, true, dy, y, x, gamma, w, mean, invstd, dx, dgamma, dbeta, sums, N, C, HW, Ng, slope,
+                           1.0f / ((float)Ng * (float)HW), workspace, (hipStream_t)stream);
+}
+extern "C" int ag2v_norm_bwd_reduce_g(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* mean,
+                                      const float* invstd, float* sums, int N, int C, int HW, int Ng, float slope, float* workspace,
+                                      void* stream) {
+    return norm_bwd_launch(mode, true, false, dy, y, x, gamma, nullptr, mean, invstd, nullptr, nullptr, nullptr, sums, N, C, HW, Ng, slope,
+                           0.f, workspace, (hipStream_t)stream);
+}
+extern "C" int ag2v_norm_bwd_apply_g(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* w,
+                                     const float* mean, const float* invstd, const float* sums, float inv_count, float* dx, float* dgamma,
+                                     float* dbeta, int N, int C, int HW, int Ng, float slope, void* stream) {
+    return norm_bwd_launch(mode, false, true, dy, y, x, gamma, w, mean, invstd, dx, dgamma, dbeta, const_cast<float*>(sums), N, C, HW, Ng,
+                           slope, inv_count, nullptr, (hipStream_t)stream);
 }
 extern "C" int ag2v_norm_bwd(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* w,
                              const float* mean, const float* invstd, float* dx, float* dgamma, float* dbeta, float* sums,

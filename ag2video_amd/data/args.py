@@ -101,6 +101,7 @@ def build_parser():
     # build-specific (not in the reference): synthetic data shape for scripts/train
     a('--synthetic_objects', default='5,10', type=int_tuple, help='min,max real objects per clip')
     a('--seed', default=1234, type=int)
+    a('--sync_bn', default=0, type=int, help='1: batch-norm statistics over the global batch (all ranks) with the reference\'s multi-device formula')
     a('--data_root', default=None, type=str, help='CATER directory (scenes/*.json, videos/<id>/*.png); default: synthetic clips')
     a('--train_list', default=None, type=str)
     a('--data_nframes', default=301, type=int, help='frames per video in --data_root')

@@ -107,6 +107,44 @@ def any_rank(flag, device):
     return bool(t.item() > 0)
 
 
+# ---- synchronised batch norm (reference: sync_batchnorm/batchnorm.py:80-93,105-126,128-145).  The reference's DataParallel splits
+# the batch over the devices and reduces [sum, sum of squares] per channel onto a master; here every rank all-reduces them.
+_SYNC_BN = [False]
+
+
+def set_sync_bn(flag):
+    """Batch statistics over the GLOBAL batch (all ranks) with the reference's multi-device formula -- inv_std =
+    clamp(biased var, eps)^-1/2, running_var fed with the unbiased variance -- instead of per-rank statistics with
+    F.batch_norm's (var + eps)^-1/2.  Takes effect when the collectives are live (is_dist())."""
+    _SYNC_BN[0] = bool(flag)
+
+
+def sync_bn():
+    return _SYNC_BN[0] and is_dist()
+
+
+@torch.no_grad()
+def combine_bn_stats(mean_l, var_l, count_l, eps):
+    """Per-rank (mean, biased variance) [G, C] over count_l elements each -> global (mean, inv_std, unbiased var, count) after ONE
+    all-reduce of [sum, sum of squares] (batchnorm.py:105-126 reduces the same pair; _compute_mean_std :128-145).  fp64 on the
+    wire: E[x^2] - mean^2 cancels badly in fp32."""
+    m, v = mean_l.double(), var_l.double()
+    pack = torch.stack([m * count_l, (v + m * m) * count_l])
+    dist.all_reduce(pack, op=dist.ReduceOp.SUM)
+    n = float(count_l) * dist.get_world_size()
+    mean = pack[0] / n
+    sumvar = pack[1] - pack[0] * mean
+    bias_var, unbias_var = sumvar / n, sumvar / (n - 1)
+    inv_std = bias_var.clamp(min=eps).pow(-0.5)
+    return mean.float(), inv_std.float(), unbias_var.float(), n
+
+
+@torch.no_grad()
+def sum_over_ranks_(t):
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
 def shutdown():
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()

@@ -18,6 +18,7 @@ class TrainStep(object):
     def __init__(self, opt, device, weights_seed=None):
         self.opt = opt
         self.device = device
+        dist_utils.set_sync_bn(getattr(opt, 'sync_bn', 0))
         self.model = AG2VideoModel(opt, device)
         self.model.float()
         self.discriminator = MetaDiscriminatorModel(opt)

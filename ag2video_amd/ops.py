@@ -636,9 +636,27 @@ class _NormAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, mode, x, p0, p1, running_mean, running_var, training, momentum, eps, slope, groups):
+        from . import distributed as D
         x, p0, p1 = _c(x), _c(p0), _c(p1)
         _chk(x, p0, p1)
-        mean, invstd, N, C, HW, Ng = _bn_stats(x, running_mean, running_var, training, momentum, eps, groups)
+        sync = training and D.sync_bn()
+        world = 1
+        if sync:
+            # synchronised statistics (sync_batchnorm/batchnorm.py:80-93): local (mean, var) per (group, channel), one all-reduce,
+            # the reference's multi-device formula, the running buffers updated once per group in order
+            mean, invstd, N, C, HW, Ng = _bn_stats(x, None, None, True, momentum, eps, groups)
+            var_l = invstd.pow(-2) - eps
+            mean, invstd, unb, cnt = D.combine_bn_stats(mean.view(groups, C), var_l.view(groups, C), Ng * HW, eps)
+            world = int(round(cnt / (Ng * HW)))
+            if running_mean is not None:
+                k = torch.arange(groups - 1, -1, -1, device=x.device, dtype=torch.float32)
+                coef = momentum * (1.0 - momentum) ** k                                   # weight of group g in the final value
+                keep = (1.0 - momentum) ** groups
+                running_mean.mul_(keep).add_((coef.view(-1, 1) * mean).sum(0))
+                running_var.mul_(keep).add_((coef.view(-1, 1) * unb).sum(0))
+            mean, invstd = mean.reshape(-1).contiguous(), invstd.reshape(-1).contiguous()
+        else:
+            mean, invstd, N, C, HW, Ng = _bn_stats(x, running_mean, running_var, training, momentum, eps, groups)
         y = torch.empty_like(x)
         if mode == 0:
             _lib.call('ag2v_norm_apply_g', 0, _ptr(x), _ptr(mean), _ptr(invstd), _ptr(p0), _ptr(p1), None, None, _ptr(y),
@@ -652,13 +670,13 @@ class _NormAct(torch.autograd.Function):
             _launch('ag2v_norm_apply_g', 'spade_norm_apply', 4.0 * x.numel() * 4, mode, _ptr(x), _ptr(mean), _ptr(invstd), None, None,
                     g_ptr, b_ptr, _ptr(y), N, C, HW, Ng, float(slope), _stream(), shape=(N, C, HW))
         ctx.save_for_backward(x, y if slope != 1.0 else None, p0, mean, invstd)
-        ctx.cfg = (mode, training, slope, N, C, HW, Ng)
+        ctx.cfg = (mode, training, slope, N, C, HW, Ng, world if sync else 0)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, y, p0, mean, invstd = ctx.saved_tensors
-        mode, training, slope, N, C, HW, Ng = ctx.cfg
+        mode, training, slope, N, C, HW, Ng, sync_world = ctx.cfg
         if not training:
             raise RuntimeError("norm backward is only implemented for batch statistics (training mode)")
         dy = dy.contiguous()
@@ -667,24 +685,42 @@ class _NormAct(torch.autograd.Function):
         sums = torch.empty((G, C, 2), device=x.device, dtype=torch.float32)
         ws = torch.empty(_lib.query('ag2v_bn_workspace_floats', N, C, HW), device=x.device, dtype=torch.float32)
         none = (None,) * 9
+        gam = p0 if mode >= 1 else None
+        wgt = p0 if mode == 0 else None
+        dgamma = dbeta = dgb = None
+        if mode == 2:
+            dgb = torch.empty_like(p0)
+            dg_ptr, db_ptr = _ptr(dgb), _ptr_off(dgb, C * HW)
+        elif mode == 1:
+            dgamma, dbeta = torch.empty_like(x), torch.empty_like(x)
+            dg_ptr, db_ptr = _ptr(dgamma), _ptr(dbeta)
+        else:
+            dg_ptr = db_ptr = None
+        kmode = 2 if mode == 2 else mode
+        if sync_world:
+            # (sum dxhat, sum dxhat * xhat) per (group, channel) over ALL ranks between the two passes (batchnorm.py backward of the
+            # reduce / broadcast pair)
+            from . import distributed as D
+            _lib.call('ag2v_norm_bwd_reduce_g', kmode, _ptr(dy), _ptr(y), _ptr(x), _ptr(gam), _ptr(mean), _ptr(invstd), _ptr(sums),
+                      N, C, HW, Ng, float(slope), _ptr(ws), _stream())
+            local = sums.clone() if mode == 0 else None          # affine gradients stay per rank (averaged with all the others)
+            D.sum_over_ranks_(sums)
+            _lib.call('ag2v_norm_bwd_apply_g', kmode, _ptr(dy), _ptr(y), _ptr(x), _ptr(gam), _ptr(wgt), _ptr(mean), _ptr(invstd),
+                      _ptr(sums), 1.0 / (float(sync_world) * Ng * HW), _ptr(dx), dg_ptr, db_ptr, N, C, HW, Ng, float(slope), _stream())
+            if local is not None:
+                sums = local
+        else:
+            _launch('ag2v_norm_bwd_g', 'spade_norm_bwd' if mode == 2 else 'norm_bwd', 11.0 * x.numel() * 4, kmode, _ptr(dy), _ptr(y), _ptr(x),
+                    _ptr(gam), _ptr(wgt), _ptr(mean), _ptr(invstd), _ptr(dx), dg_ptr, db_ptr, _ptr(sums), N, C, HW, Ng, float(slope),
+                    _ptr(ws), _stream(), shape=(N, C, HW))
         if mode == 0:
-            _lib.call('ag2v_norm_bwd_g', 0, _ptr(dy), _ptr(y), _ptr(x), None, _ptr(p0), _ptr(mean), _ptr(invstd), _ptr(dx),
-                      None, None, _ptr(sums), N, C, HW, Ng, float(slope), _ptr(ws), _stream())
             dw = db = None
             if p0 is not None:
                 tot = sums.sum(dim=0) if G > 1 else sums[0]
                 dw, db = tot[:, 1].contiguous(), tot[:, 0].contiguous()
             return (None, dx, dw, db) + none[:7]
         if mode == 2:
-            dgb = torch.empty_like(p0)
-            _launch('ag2v_norm_bwd_g', 'spade_norm_bwd', 8.0 * x.numel() * 4, 2, _ptr(dy), _ptr(y), _ptr(x), _ptr(p0), None, _ptr(mean),
-                    _ptr(invstd), _ptr(dx), _ptr(dgb), _ptr_off(dgb, C * HW), _ptr(sums), N, C, HW, Ng, float(slope), _ptr(ws), _stream(),
-                    shape=(N, C, HW))
             return (None, dx, dgb, None) + none[:7]
-        dgamma = torch.empty_like(x)
-        dbeta = torch.empty_like(x)
-        _lib.call('ag2v_norm_bwd_g', 1, _ptr(dy), _ptr(y), _ptr(x), _ptr(p0), None, _ptr(mean), _ptr(invstd), _ptr(dx),
-                  _ptr(dgamma), _ptr(dbeta), _ptr(sums), N, C, HW, Ng, float(slope), _ptr(ws), _stream())
         return (None, dx, dgamma, dbeta) + none[:7]
 
 

@@ -126,6 +126,13 @@ int ag2v_norm_apply_g(int mode, const float* x, const float* mean, const float* 
 int ag2v_norm_bwd_g(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* w,
                     const float* mean, const float* invstd, float* dx, float* dgamma, float* dbeta, float* sums,
                     int N, int C, int HW, int Ng, float slope, float* workspace, void* stream);
+/* ag2v_norm_bwd_g in two steps, for data-parallel SYNCHRONISED batch norm (sync_batchnorm/batchnorm.py:105-126): the caller
+ * all-reduces sums[N / Ng, C, 2] over the ranks between them and passes inv_count = 1 / (elements per (group, channel) over ALL ranks). */
+int ag2v_norm_bwd_reduce_g(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* mean,
+                           const float* invstd, float* sums, int N, int C, int HW, int Ng, float slope, float* workspace, void* stream);
+int ag2v_norm_bwd_apply_g(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* w,
+                          const float* mean, const float* invstd, const float* sums, float inv_count, float* dx, float* dgamma,
+                          float* dbeta, int N, int C, int HW, int Ng, float slope, void* stream);
 int ag2v_instnorm_lrelu_fwd(const float* x, float* y, float* mean, float* invstd, int NC, int HW, float eps, float slope,
                             void* stream);
 int ag2v_instnorm_lrelu_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,

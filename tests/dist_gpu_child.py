@@ -49,6 +49,32 @@ def main(out_path):
     n_after = calls['n']
     gclip = ts.to_device(make_clip_batch(opt.vocab, 2, 5, (64, 64), seed=12 + rank))
     _, GG = ts.graph_step(gclip)
+    # synchronised batch norm (--sync_bn 1) through the kernels: local statistics -> all-reduce -> the reference's multi-device
+    # formula (sync_batchnorm/batchnorm.py:128-145) -> apply; backward with the all-reduced (sum dxhat, sum dxhat xhat)
+    from ag2video_amd import ops
+    D.set_sync_bn(True)
+    gx = torch.Generator().manual_seed(3)
+    xb = (torch.randn(6, 5, 9, 9, generator=gx) * 2.0 + 0.5)
+    xb[:, 4] *= 1e-4
+    xb = xb.to(dev).requires_grad_(True)
+    wb, bb = torch.linspace(0.5, 1.5, 5, device=dev).requires_grad_(True), torch.linspace(-1, 1, 5, device=dev).requires_grad_(True)
+    rm, rv = torch.zeros(5, device=dev), torch.ones(5, device=dev)
+    yb = ops.batchnorm_act(xb, wb, bb, rm, rv, True, 0.1, 1e-5, 0.2, groups=2)
+    wgt = torch.randn(yb.shape, generator=gx).to(dev)
+    (yb * wgt).sum().backward()
+    xd = xb.detach().double().view(2, 3, 5, 81).requires_grad_(True)
+    mu = xd.mean(dim=(1, 3), keepdim=True)
+    var = ((xd - mu) ** 2).mean(dim=(1, 3), keepdim=True)
+    yr = (xd - mu) * var.clamp(min=1e-5).pow(-0.5) * wb.detach().double().view(1, 1, 5, 1) + bb.detach().double().view(1, 1, 5, 1)
+    yr = torch.nn.functional.leaky_relu(yr, 0.2)
+    (yr * wgt.double().view(2, 3, 5, 81)).sum().backward()
+    unb = var.squeeze() * (3 * 81) / (3 * 81 - 1)
+    rm_ref = 0.1 * (0.9 * mu.squeeze()[0] + mu.squeeze()[1])
+    rv_ref = 0.9 * (0.9 * 1.0 + 0.1 * unb[0]) + 0.1 * unb[1]
+    sync_bn_err = [float((yb.double().view(2, 3, 5, 81) - yr).abs().max() / yr.abs().max()),
+                   float((xb.grad.double().view(2, 3, 5, 81) - xd.grad).abs().max() / xd.grad.abs().max()),
+                   float((rm.double() - rm_ref).abs().max()), float(((rv.double() - rv_ref).abs() / rv_ref).max())]
+    D.set_sync_bn(False)
     skip = D.any_rank(False, dev), D.any_rank(rank == 0, dev)
     torch.distributed.barrier()
     mx = D.max_over_ranks(float(rank + 1), dev)
@@ -63,7 +89,7 @@ def main(out_path):
                                ts.optimizer_graph.flat_grad.numel()],
            'G': {k: float(v) for k, v in GL.items()}, 'D': {k: float(v) for k, v in DL.items()},
            'G0': {k: float(v) for k, v in GL0.items()}, 'graph': {k: float(v) for k, v in GG.items()},
-           'skip_flags': list(skip), 'max_over_ranks': mx, 'param_checksums': [float(t) for t in gathered]}
+           'skip_flags': list(skip), 'sync_bn_err': sync_bn_err, 'max_over_ranks': mx, 'param_checksums': [float(t) for t in gathered]}
     if rank == 0:
         json.dump(res, open(out_path, 'w'))
     D.shutdown()

@@ -47,6 +47,22 @@ def _worker(rank, world, port, out_dir):
     D.broadcast_parameters([t])
     assert float(t.sum()) == 0.0
     assert D.max_over_ranks(float(rank + 1), torch.device('cpu')) == float(world)
+    # --- synchronised batch-norm statistics: one all-reduce of [sum, sum of squares]; every rank ends with the statistics of the
+    # concatenated batch, the reference's multi-device formula (clamp(biased var, eps)^-1/2, unbiased var for the running buffer)
+    gx = torch.Generator().manual_seed(7)
+    full = torch.randn(2 * 3, 5, 4, 4, generator=gx) * 2.0 + 0.5                 # [ranks * 3 samples, C, H, W], same on both ranks
+    full[:, 4] = 1e-4 * full[:, 4]                                                # a channel whose variance is below eps: the clamp acts
+    mine_x = full[rank * 3:(rank + 1) * 3]
+    G = 3                                                                         # one sample per group: stats over (rank, h, w)
+    xs = mine_x.reshape(G, 1, 5, 16)
+    mean_l, var_l = xs.mean(dim=(1, 3)), xs.var(dim=(1, 3), unbiased=False)
+    mean, inv_std, unb, n = D.combine_bn_stats(mean_l, var_l, 16, 1e-5)
+    ref = torch.stack([full[g::3] for g in range(G)])                             # group g = sample g of every rank
+    ref = ref.permute(0, 2, 1, 3, 4).reshape(G, 5, -1).double()
+    assert n == 32 and torch.allclose(mean.double(), ref.mean(-1), atol=1e-6)
+    assert torch.allclose(unb.double(), ref.var(-1, unbiased=True), rtol=1e-5, atol=1e-9)
+    want = ref.var(-1, unbiased=False).clamp(min=1e-5).pow(-0.5)
+    assert torch.allclose(inv_std.double(), want, rtol=1e-5) and float(inv_std[:, 4].max()) <= 1e-5 ** -0.5 * (1 + 1e-6)
     # --- end-to-end graph step: different clips per rank, identical parameters afterwards
     from _cpu_ops_shim import oracle_ops
     from ag2video_amd.data.args import make_opt
