@@ -50,7 +50,8 @@ def test_rccl_path_on_gpu_matches_single_process(device, tmp_path):
     assert res['allreduce_calls_per_gd_step'] == 3, res['allreduce_calls_per_gd_step']
     assert res['skip_flags'] == [False, True] and res['max_over_ranks'] == float(n)
     assert len(set(res['param_checksums'])) == 1
-    assert max(res['sync_bn_err']) <= 1e-4, res['sync_bn_err']      # synchronised batch norm: y, dx, running_mean, running_var
+    e = res['sync_bn_err']                                           # synchronised batch norm vs an fp64 evaluation of the formula:
+    assert e[0] <= 1e-5 and e[1] <= 5e-4 and e[2] <= 1e-6 and e[3] <= 1e-5, e          # y, dx, running_mean, running_var
     # the same step without torch.distributed, in this process
     flags = ['--no_vgg_loss', '--image_size', '64,64', '--batch_size', '2', '--ngf', '8', '--ndf', '8', '--nff', '8',
              '--gconv_hidden_dim', '64', '--gpu_ids', '0']
