@@ -93,34 +93,46 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
 // One thread per channel: Chan's parallel combine in double per group; writes mean / invstd (biased var, +eps) of every group and
 // applies the G momentum updates of the running statistics IN GROUP ORDER, exactly as G consecutive
 // F.batch_norm(training=True, momentum) calls do (unbiased var in the running buffer).
-__global__ void bn_stats_finalize_kernel(const float* __restrict__ partial, int G, int C, int nparts, float eps, float momentum,
-                                         float* __restrict__ mean_out, float* __restrict__ invstd_out,
-                                         float* __restrict__ running_mean, float* __restrict__ running_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double rm = running_mean ? (double)running_mean[c] : 0.0, rv = running_mean ? (double)running_var[c] : 0.0;
-    for (int g = 0; g < G; ++g) {
-        const float* p = partial + (size_t)(g * C + c) * nparts * 3;
-        double n = 0.0, mean = 0.0, m2 = 0.0;
-        for (int i = 0; i < nparts; ++i) {
-            const double nb = p[3 * i], mb = p[3 * i + 1], m2b = p[3 * i + 2];
-            const double nt = n + nb;
-            const double d = mb - mean;
-            mean += d * (nb / nt);
-            m2 += m2b + d * d * (n * nb / nt);
-            n = nt;
-        }
-        const double var = m2 / n;
-        mean_out[g * C + c] = (float)mean;
-        invstd_out[g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
-        if (running_mean) {
-            const double unb = (n > 1.0) ? m2 / (n - 1.0) : var;
-            // each update rounds to fp32 as the separate calls would
-            rm = (double)(float)((1.0 - momentum) * rm + momentum * mean);
-            rv = (double)(float)((1.0 - momentum) * rv + momentum * unb);
+// grid: ceil(C / 16) blocks of 256 threads = 16 channels x 16 group lanes (lane gl handles groups gl, gl + 16, ...).
+#define FIN_MAXG 64
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ partial, int G, int C, int nparts, float eps,
+                                                                float momentum, float* __restrict__ mean_out,
+                                                                float* __restrict__ invstd_out, float* __restrict__ running_mean,
+                                                                float* __restrict__ running_var) {
+    __shared__ float s_mean[16][FIN_MAXG], s_unb[16][FIN_MAXG];
+    const int cl = threadIdx.x >> 4, gl = threadIdx.x & 15;
+    const int c = blockIdx.x * 16 + cl;
+    if (c < C) {
+        for (int g = gl; g < G; g += 16) {
+            const float* p = partial + (size_t)(g * C + c) * nparts * 3;
+            double n = 0.0, mean = 0.0, m2 = 0.0;
+            for (int i = 0; i < nparts; ++i) {
+                const double nb = p[3 * i], mb = p[3 * i + 1], m2b = p[3 * i + 2];
+                const double nt = n + nb;
+                const double d = mb - mean;
+                mean += d * (nb / nt);
+                m2 += m2b + d * d * (n * nb / nt);
+                n = nt;
+            }
+            const double var = m2 / n;
+            mean_out[g * C + c] = (float)mean;
+            invstd_out[g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+            if (g < FIN_MAXG) {
+                s_mean[cl][g] = (float)mean;
+                s_unb[cl][g] = (float)((n > 1.0) ? m2 / (n - 1.0) : var);
+            }
         }
     }
-    if (running_mean) { running_mean[c] = (float)rm; running_var[c] = (float)rv; }
+    __syncthreads();
+    if (c < C && gl == 0 && running_mean) {
+        double rm = (double)running_mean[c], rv = (double)running_var[c];
+        for (int g = 0; g < G; ++g) {       // each update rounds to fp32 as the separate calls would
+            rm = (double)(float)((1.0 - momentum) * rm + momentum * (double)s_mean[cl][g]);
+            rv = (double)(float)((1.0 - momentum) * rv + momentum * (double)s_unb[cl][g]);
+        }
+        running_mean[c] = (float)rm;
+        running_var[c] = (float)rv;
+    }
 }
 
 // ---------------------------------------------------------------- fused normalise (+affine | +SPADE) (+LeakyReLU)
@@ -353,7 +365,8 @@ extern "C" int ag2v_bn_stats_g(const float* x, int N, int C, int HW, int Ng, flo
         hipLaunchKernelGGL(bn_stats_partial_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, st, x, workspace, Ng, C, HW, nchunk);
     else
         hipLaunchKernelGGL(bn_stats_partial_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, st, x, workspace, Ng, C, HW, nchunk);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, workspace, N / Ng, C, Ng * nchunk, eps,
+    if (N / Ng > FIN_MAXG && running_mean) return AG2V_EINVAL;     // running-stat chain of more groups than the kernel stages
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, st, workspace, N / Ng, C, Ng * nchunk, eps,
                        momentum, mean, invstd, running_mean, running_var);
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;

@@ -374,6 +374,104 @@ extern "C" int ag2v_spectral_sigmas_bwd(const float* dscale, const float* scale,
     return AG2V_OK;
 }
 
+// ---------------------------------------------------------------- multi-tensor spectral norm (all layers of a network per launch)
+// One descriptor per spectral-norm layer; a launch covers every layer of the table, so the T power iterations of a frame-batched
+// step cost 4 launches each instead of 4 per layer (38 layers in the generator: 2 280 -> 60 launches per step).
+struct SnDesc {
+    const float* w;      // [M, R]
+    float* u;            // [M]   module buffer weight_u (advanced in place)
+    float* v;            // [R]   module buffer weight_v
+    float* vtmp;         // [R]   scratch: un-normalised W^T u (zeroed by the caller's memset of the whole scratch block)
+    float* wv;           // [M]   scratch: W v
+    float* sigma;        // [T]   outputs of this layer
+    float* inv_sigma;    // [T]
+    float* u_used;       // [T*M] (nullable)
+    float* v_used;       // [T*R] (nullable)
+    int M, R;
+    int blk0;            // first block of this layer in the W^T u launch (blocks = ceil(R/256) * ceil(M/64))
+    int row0;            // first row of this layer in the W v launch
+};
+__device__ __forceinline__ int sn_find(const SnDesc* d, int n, int key, bool by_row) {
+    int lo = 0, hi = n - 1;                 // last layer whose first block / row is <= key
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((by_row ? d[mid].row0 : d[mid].blk0) <= key) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+__global__ __launch_bounds__(256) void sn_multi_wtu_kernel(const SnDesc* __restrict__ descs, int n) {
+    const int li = sn_find(descs, n, blockIdx.x, false);
+    const SnDesc d = descs[li];
+    const int local = blockIdx.x - d.blk0;
+    const int rb = (d.R + 255) >> 8;
+    const int cb = local % rb, mc = local / rb;
+    const int r = cb * 256 + threadIdx.x;
+    if (r >= d.R) return;
+    const int m0 = mc * 64, m1 = min(d.M, m0 + 64);
+    float s = 0.f;
+    for (int m = m0; m < m1; ++m) s += d.w[(size_t)m * d.R + r] * d.u[m];
+    atomicAdd(d.vtmp + r, s);
+}
+__global__ __launch_bounds__(256) void sn_multi_wv_kernel(const SnDesc* __restrict__ descs, int n, int total_rows) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= total_rows) return;
+    const int li = sn_find(descs, n, row, true);
+    const SnDesc d = descs[li];
+    const int m = row - d.row0;
+    const int lane = threadIdx.x & 63;
+    const float* wr = d.w + (size_t)m * d.R;
+    float s = 0.f;
+    for (int r = lane; r < d.R; r += 64) s += wr[r] * d.vtmp[r];
+    s = wave_sum(s);
+    if (lane == 0) d.wv[m] = s;
+}
+// one workgroup per layer: the normalisations, sigma_t, the buffers' update and the tape copies (as sn_sigma_kernel)
+__global__ __launch_bounds__(256) void sn_multi_sigma_kernel(const SnDesc* __restrict__ descs, int t, float eps) {
+    __shared__ float sh[4];
+    const SnDesc d = descs[blockIdx.x];
+    float q = 0.f;
+    for (int i = threadIdx.x; i < d.R; i += 256) q += d.vtmp[i] * d.vtmp[i];
+    q = block_sum_256(q, sh);
+    const float vinv = 1.0f / fmaxf(sqrtf(q), eps);
+    for (int i = threadIdx.x; i < d.R; i += 256) {
+        const float vn = d.vtmp[i] * vinv;
+        d.v[i] = vn;
+        if (d.v_used) d.v_used[(size_t)t * d.R + i] = vn;
+        d.vtmp[i] = 0.f;                                    // ready for the next iteration's atomics
+    }
+    float s = 0.f;
+    for (int i = threadIdx.x; i < d.M; i += 256) { const float x = d.wv[i] * vinv; s += x * x; }
+    s = block_sum_256(s, sh);
+    const float inv = 1.0f / fmaxf(sqrtf(s), eps);
+    float dot = 0.f;
+    for (int i = threadIdx.x; i < d.M; i += 256) {
+        const float x = d.wv[i] * vinv;
+        const float un = x * inv;
+        d.u[i] = un;
+        if (d.u_used) d.u_used[(size_t)t * d.M + i] = un;
+        dot += un * x;
+    }
+    dot = block_sum_256(dot, sh);
+    if (threadIdx.x == 0) { d.sigma[t] = dot; d.inv_sigma[t] = 1.0f / dot; }
+}
+extern "C" size_t ag2v_sn_desc_bytes(void) { return sizeof(SnDesc); }
+// descs: device array of n_layers SnDesc records (layout above; filled by the caller: blk0 / row0 are the running sums of
+// ceil(R/256) * ceil(M/64) and of M), total_blocks / total_rows their totals; the vtmp scratch of every layer must be zero on entry
+// (it is left zero on exit).  Runs T training-mode power iterations of every layer.
+extern "C" int ag2v_spectral_sigmas_multi(const void* descs, int n_layers, int total_blocks, int total_rows, int T, float eps,
+                                          void* stream) {
+    if (!descs || n_layers <= 0 || total_blocks <= 0 || total_rows <= 0 || T <= 0) return AG2V_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const SnDesc* d = (const SnDesc*)descs;
+    for (int t = 0; t < T; ++t) {
+        hipLaunchKernelGGL(sn_multi_wtu_kernel, dim3(total_blocks), dim3(256), 0, st, d, n_layers);
+        hipLaunchKernelGGL(sn_multi_wv_kernel, dim3(ceil_div(total_rows, 4)), dim3(256), 0, st, d, n_layers, total_rows);
+        hipLaunchKernelGGL(sn_multi_sigma_kernel, dim3(n_layers), dim3(256), 0, st, d, t, eps);
+    }
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+
 // ---------------------------------------------------------------- fused Adam over a flat parameter buffer (K15)
 // torch.optim.Adam (scripts/train.py:365-368, meta_models.py:70-72; weight_decay 0, amsgrad off):
 //   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= (lr / (1-b1^t)) * m / (sqrt(v) / sqrt(1-b2^t) + eps)

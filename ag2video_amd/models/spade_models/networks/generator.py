@@ -75,6 +75,14 @@ class Layout2VidGenerator(nn.Module):
         keep_t = keep.unsqueeze(0).expand(T, B, keep.size(1)).reshape(T * B, keep.size(1))
         prev = [fm(imgs_gt, f) for f in range(nc)]               # ground-truth frames t-nc .. t-1
         conv, bn = self.conv_dim_in[0][0], self.conv_dim_in[0][1]
+        if self.training and os.environ.get('AG2V_NO_SN_BANK') is None:
+            # the T power iterations of ALL spectral-norm layers up front, three launches per iteration (every layer below is called
+            # exactly once per frame pass in the reference, so each consumes its T scales in this pass)
+            if getattr(self, '_sn_bank', None) is None:
+                from .normalization import SpectralConv2d
+                self._sn_bank = ops.SpectralBank([m for m in self.modules() if isinstance(m, SpectralConv2d)])
+            for m, sc in zip(self._sn_bank.layers, self._sn_bank.scales(T)):
+                m._bank_scales = sc
         with ops.frame_groups(T):
             spec = (vecs_list, boxes_list, keep_t, H)
             with ops.bf16x3_min_rows(ops.EXACT, 128):            # flow network forward exact: see _frames_sequential

@@ -40,6 +40,10 @@ class SpectralConv2d(nn.Module):
     def weight_and_scales(self):
         """Frame-batched form: (weight_orig, [1 / sigma_t for the T frame groups of ops.frame_groups]) -- T power iterations
         in a row, as the T forward calls of the reference's frame loop make them; conv2d(..., gscale=scales) applies them."""
+        pending = getattr(self, '_bank_scales', None)
+        if pending is not None:              # produced for every layer of the network at once (ops.SpectralBank, generator.py)
+            self._bank_scales = None
+            return self.weight_orig, pending
         return self.weight_orig, ops.spectral_scales(self.weight_orig, self.weight_u, self.weight_v, ops.current_frame_groups(),
                                                      self.training, self.eps)
 

@@ -37,6 +37,10 @@ def _c(t):
     return None if t is None else t.contiguous()
 
 
+def _ptr_off(t, elems):
+    return _P(t.data_ptr() + 4 * elems)
+
+
 _PRECISIONS = {'fp32': 0, 'bf16x3': 1}
 _PRECISION = [_PRECISIONS.get(os.environ.get('AG2V_CONV_PRECISION', 'bf16x3'), 1)]
 
@@ -254,15 +258,26 @@ def _wsink_begin(task):
         _WSINK_CB[0] = task
 
 
+_DIRECT_GRAD = os.environ.get('AG2V_NO_DIRECT_GRAD') is None
+
+
 def _wsink_take(key, like):
     """-> (buffer to pass to the wgrad launch, accumulate flag, tensor to return to autograd or None).
     A sink buffer belongs to ONE backward pass: it carries the autograd graph-task id it was created under, so a buffer left
-    behind by a pass that ended without its end-of-pass callback (an exception inside backward) is never accumulated into."""
+    behind by a pass that ended without its end-of-pass callback (an exception inside backward) is never accumulated into.
+    Leaf parameters whose .grad is already allocated (the flat-buffer optimizers keep every .grad as a zeroed view of one
+    gradient buffer) take the short way: the launch accumulates straight into .grad and autograd is handed nothing -- what
+    AccumulateGrad would have done with one more buffer and one more add per parameter and backward pass."""
     e = _WSINK.get(key)
     task = torch._C._current_graph_task_id()
     if e is None or task < 0:           # registered before an earlier backward pass cleared the registry: plain path
         buf = torch.empty_like(like)
         return buf, 0, buf
+    if _DIRECT_GRAD:
+        p = e[0]()
+        if (p is not None and p.is_leaf and p.grad is not None and p.grad.shape == like.shape and p.grad.is_contiguous()
+                and p.grad.dtype == torch.float32 and p.grad.device == like.device and not p._backward_hooks):
+            return p.grad, 1, None
     _wsink_begin(task)
     if e[1] is None or e[2] != task:
         e[1], e[2] = torch.empty_like(like), task
@@ -601,6 +616,92 @@ class _SpectralScales(torch.autograd.Function):
 def spectral_scales(w_orig, u, v, T, training=True, eps=1e-12):
     """[1 / sigma_t for t < T] with T in-place power iterations on (u, v) (training) -- or [1 / sigma] in eval mode."""
     return _SpectralScales.apply(w_orig, u, v, int(T), bool(training), float(eps))
+
+
+class SpectralBank(object):
+    """All spectral-norm layers of one network as ONE power-iteration launch chain (ag2v_spectral_sigmas_multi): the generator has 38
+    such layers, each making T forward calls per frame-batched step -- 3 launches per power iteration for all of them instead of 4 per
+    layer.  ``scales(T)`` runs the T iterations of every layer (advancing weight_u / weight_v in place, as the T forward calls of the
+    reference's frame loop do) and returns one [T] tensor of 1/sigma_t per layer, in module order, connected to weight_orig through
+    autograd.  Outputs and tape live in buffers owned by the bank and are overwritten by the next call: a backward that arrives after
+    a newer forward raises instead of using the wrong vectors."""
+
+    def __init__(self, layers):
+        self.layers = list(layers)                # objects with weight_orig, weight_u, weight_v, eps
+        self._key = None
+        self.version = 0
+
+    def _build(self, T):
+        import numpy as np
+        ws = [l.weight_orig for l in self.layers]
+        key = (T,) + tuple((l.weight_orig.data_ptr(), l.weight_u.data_ptr(), l.weight_v.data_ptr()) for l in self.layers)
+        if key == self._key:
+            return
+        dev = ws[0].device
+        Ms = [w.shape[0] for w in ws]
+        Rs = [w.numel() // w.shape[0] for w in ws]
+        n = len(ws)
+        self.sig = torch.empty((n, 2, T), device=dev, dtype=torch.float32)
+        self.tape_u = torch.empty(T * sum(Ms), device=dev, dtype=torch.float32)
+        self.tape_v = torch.empty(T * sum(Rs), device=dev, dtype=torch.float32)
+        self.vtmp = torch.zeros(sum(Rs), device=dev, dtype=torch.float32)
+        self.wv = torch.empty(sum(Ms), device=dev, dtype=torch.float32)
+        dt = np.dtype([('w', '<u8'), ('u', '<u8'), ('v', '<u8'), ('vtmp', '<u8'), ('wv', '<u8'), ('sigma', '<u8'), ('inv', '<u8'),
+                       ('uu', '<u8'), ('vu', '<u8'), ('M', '<i4'), ('R', '<i4'), ('blk0', '<i4'), ('row0', '<i4')])
+        assert dt.itemsize == _lib.query('ag2v_sn_desc_bytes')
+        rec = np.zeros(n, dt)
+        blk = row = mo = ro = 0
+        self.slices = []
+        for i, (l, M, R) in enumerate(zip(self.layers, Ms, Rs)):
+            rec[i] = (ws[i].data_ptr(), l.weight_u.data_ptr(), l.weight_v.data_ptr(), self.vtmp.data_ptr() + 4 * ro,
+                      self.wv.data_ptr() + 4 * mo, self.sig[i, 0].data_ptr(), self.sig[i, 1].data_ptr(),
+                      self.tape_u.data_ptr() + 4 * T * mo, self.tape_v.data_ptr() + 4 * T * ro, M, R, blk, row)
+            self.slices.append((T * mo, T * M, T * ro, T * R, M, R))
+            blk += ((R + 255) // 256) * ((M + 63) // 64)
+            row += M
+            mo += M
+            ro += R
+        self.total_blocks, self.total_rows = blk, row
+        self.desc = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
+        self._key = key
+
+    def scales(self, T, eps=1e-12):
+        for l in self.layers:
+            if not l.weight_orig.is_contiguous():
+                raise RuntimeError("SpectralBank: weight_orig must be contiguous")
+        self._build(int(T))
+        return _SpectralScalesMulti.apply(self, int(T), float(eps), *[l.weight_orig for l in self.layers])
+
+
+class _SpectralScalesMulti(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, bank, T, eps, *w_origs):
+        _chk(*w_origs)
+        _lib.call('ag2v_spectral_sigmas_multi', _ptr(bank.desc), len(w_origs), bank.total_blocks, bank.total_rows, T, eps, _stream())
+        bank.version += 1
+        ctx.bank, ctx.version, ctx.T = bank, bank.version, T
+        ctx.okeys = [(_wsink_register(w) if (ctx.needs_input_grad[3 + i] and _EXTRA_SINKS) else None) for i, w in enumerate(w_origs)]
+        ctx.o_alive = w_origs
+        return tuple(bank.sig[i, 1] for i in range(len(w_origs)))
+
+    @staticmethod
+    def backward(ctx, *dscales):
+        bank, T = ctx.bank, ctx.T
+        if bank.version != ctx.version:
+            raise RuntimeError("SpectralBank: the tape of this forward pass was overwritten by a later one (one frame-batched "
+                               "forward at a time may be awaiting its backward)")
+        grads = []
+        st = _stream()
+        for i, (w, ds) in enumerate(zip(ctx.o_alive, dscales)):
+            if ds is None or not ctx.needs_input_grad[3 + i]:
+                grads.append(None)
+                continue
+            uo, un, vo, vn, M, R = bank.slices[i]
+            buf, acc, dw = _wsink_take(ctx.okeys[i], w)
+            _lib.call('ag2v_spectral_sigmas_bwd', _ptr(ds.contiguous()), _ptr(bank.sig[i, 1]), _ptr_off(bank.tape_u, uo),
+                      _ptr_off(bank.tape_v, vo), T, M, R, _ptr(buf), acc, st)
+            grads.append(dw)
+        return (None, None, None) + tuple(grads)
 
 
 # ------------------------------------------------------------------------------------------------ batch norm family

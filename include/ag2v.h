@@ -236,6 +236,15 @@ int ag2v_sn_group_combine(const float* G, const float* w, const float* scale, in
 int ag2v_spectral_sigmas_bwd(const float* dscale, const float* scale, const float* u_used, const float* v_used, int T, int M, int R,
                              float* dw, int accumulate, void* stream);
 
+/* Multi-tensor form of ag2v_spectral_sigmas: every spectral-norm layer of a network per launch (3 launches per power iteration
+ * for ALL layers).  descs: device array of n_layers records
+ *   { const float* w; float* u; float* v; float* vtmp; float* wv; float* sigma; float* inv_sigma; float* u_used; float* v_used;
+ *     int M; int R; int blk0; int row0; }          (ag2v_sn_desc_bytes() bytes each)
+ * vtmp[R] / wv[M] are per-layer scratch (vtmp zero on entry, left zero on exit); blk0 / row0 = running sums over the layers of
+ * ceil(R/256) * ceil(M/64) and of M; total_blocks / total_rows their totals.  Training mode only (T power iterations). */
+size_t ag2v_sn_desc_bytes(void);
+int ag2v_spectral_sigmas_multi(const void* descs, int n_layers, int total_blocks, int total_rows, int T, float eps, void* stream);
+
 /* ---- fused Adam over a flat fp32 buffer: torch.optim.Adam as configured at scripts/train.py:365-368 and
  * meta_models.py:70-72 (weight_decay 0, amsgrad off); step_index >= 1 --------------------------------------------- */
 int ag2v_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,

@@ -64,6 +64,16 @@ def spectral_scales(w_orig, u, v, T, training=True, eps=1e-12):
     return torch.stack(out)
 
 
+class SpectralBank(object):
+    """Checker for ops.SpectralBank: the T power iterations of every layer, layer by layer (spectral_scales above)."""
+
+    def __init__(self, layers):
+        self.layers = list(layers)
+
+    def scales(self, T, eps=1e-12):
+        return tuple(spectral_scales(l.weight_orig, l.weight_u, l.weight_v, T, True, eps) for l in self.layers)
+
+
 def _lrelu(y, slope):
     return y if slope == 1.0 else F.leaky_relu(y, slope)
 

@@ -728,3 +728,38 @@ def test_spectral_scales(shape, T, device):
     ref = K.spectral_scales(w, u0.clone(), v0.clone(), T, False, 1e-12)
     assert sc.numel() == 1 and torch.equal(u.cpu(), u0) and torch.equal(v.cpu(), v0)
     _cmp('spectral_scales.eval', sc, ref, TOL)
+
+
+def test_spectral_bank_matches_per_layer_scales(device):
+    """ops.SpectralBank (every layer of a network per launch) against the per-layer oracle: scales, advanced u / v, weight gradients."""
+    from ag2video_amd import ops
+    from oracle import kernels as K
+
+    class L(object):
+        eps = 1e-12
+    shapes = [(8, 5, 3, 3), (64, 16, 3, 3), (300, 7, 1, 1), (1024, 64, 3, 3), (32, 1027, 3, 3)]
+    T = 5
+    res = []
+    for mod, dev in ((K, 'cpu'), (ops, device)):
+        layers = []
+        for i, shp in enumerate(shapes):
+            l = L()
+            M, R = shp[0], shp[1] * shp[2] * shp[3]
+            l.weight_orig = _rand(*shp, seed=10 + i).to(dev).requires_grad_(True)
+            l.weight_u = torch.nn.functional.normalize(_rand(M, seed=20 + i), dim=0).to(dev)
+            l.weight_v = torch.nn.functional.normalize(_rand(R, seed=30 + i), dim=0).to(dev)
+            layers.append(l)
+        bank = mod.SpectralBank(layers)
+        for rep in range(2):                      # second call: the cached descriptor table, buffers advanced further
+            sc = bank.scales(T)
+            tot = sum((s * _rand(T, seed=40 + i).to(dev)).sum() for i, s in enumerate(sc))
+            for l in layers:
+                l.weight_orig.grad = None
+            tot.backward()
+        res.append((layers, [s.detach().clone() for s in sc]))
+    (lc, sc_c), (lg, sc_g) = res
+    for i in range(len(shapes)):
+        _cmp('bank.scales%d' % i, sc_g[i], sc_c[i])
+        _cmp('bank.u%d' % i, lg[i].weight_u, lc[i].weight_u)
+        _cmp('bank.v%d' % i, lg[i].weight_v, lc[i].weight_v)
+        _cmp('bank.grad%d' % i, lg[i].weight_orig.grad, lc[i].weight_orig.grad)
