@@ -297,44 +297,60 @@ extern "C" int ag2v_spectral_sigmas(const float* w, float* u, float* v, int M, i
 // Backward of y_n = scale[g(n)] * conv(x_n, W) with respect to W and scale, from the per-group weight gradients
 // G[T][n] = sum_{n in group t} wgrad(dy_n, x_n) (ag2v_conv2d_wgrad_ex, groups = T):
 //   dw[i] (+)= sum_t scale[t] * G[t][i];   dscale[t] = <G[t], W>.
-// grid = blocks over i; every block accumulates its T partial dots with one atomic each into the zeroed dscale.
+// Persistent blocks stride over the weight in chunks of 1024 elements; every thread keeps its share of the (<= 16 per launch) group
+// dots in registers and the block reduces them ONCE at the end (one atomic per group and block into the zeroed dscale): a reduction
+// per group and chunk made this kernel latency-bound (0.3 TB/s; it reads T x |W| floats).
 __global__ __launch_bounds__(256) void sn_group_combine_kernel(const float* __restrict__ G, const float* __restrict__ w,
-                                                               const float* __restrict__ scale, int T, long long n,
+                                                               const float* __restrict__ scale, int t0, int Tn, long long n,
                                                                float* __restrict__ dw, float* __restrict__ dscale, int acc,
                                                                int vecok) {
-    __shared__ float sh[4];
-    const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
-    const bool vec = vecok && i0 + 3 < n;
-    float wv[4] = {0.f, 0.f, 0.f, 0.f}, o[4] = {0.f, 0.f, 0.f, 0.f};
-    if (vec) {
-        const float4 t4 = *reinterpret_cast<const float4*>(w + i0);
-        wv[0] = t4.x; wv[1] = t4.y; wv[2] = t4.z; wv[3] = t4.w;
-    } else {
-        for (int k = 0; k < 4; ++k) if (i0 + k < n) wv[k] = w[i0 + k];
-    }
-    for (int t = 0; t < T; ++t) {
-        const float* g = G + (size_t)t * n;
-        float gv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (vec) {
-            const float4 t4 = *reinterpret_cast<const float4*>(g + i0);
-            gv[0] = t4.x; gv[1] = t4.y; gv[2] = t4.z; gv[3] = t4.w;
-        } else {
-            for (int k = 0; k < 4; ++k) if (i0 + k < n) gv[k] = g[i0 + k];
-        }
-        const float sc = scale[t];
-        float d = 0.f;
+    __shared__ float sh[4][16];
+    float d[16];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { o[k] = fmaf(sc, gv[k], o[k]); d = fmaf(gv[k], wv[k], d); }
-        d = block_sum_256(d, sh);
-        if (threadIdx.x == 0) atomicAdd(dscale + t, d);
+    for (int t = 0; t < 16; ++t) d[t] = 0.f;
+    float sc[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) sc[t] = (t < Tn) ? scale[t0 + t] : 0.f;
+    for (long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i0 < n; i0 += (long long)gridDim.x * 1024) {
+        const bool vec = vecok && i0 + 3 < n;
+        float wv[4] = {0.f, 0.f, 0.f, 0.f}, o[4] = {0.f, 0.f, 0.f, 0.f};
+        if (vec) {
+            const float4 t4 = *reinterpret_cast<const float4*>(w + i0);
+            wv[0] = t4.x; wv[1] = t4.y; wv[2] = t4.z; wv[3] = t4.w;
+        } else {
+            for (int k = 0; k < 4; ++k) if (i0 + k < n) wv[k] = w[i0 + k];
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            if (t < Tn) {
+                const float* g = G + (size_t)(t0 + t) * n;
+                float gv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (vec) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(g + i0);
+                    gv[0] = t4.x; gv[1] = t4.y; gv[2] = t4.z; gv[3] = t4.w;
+                } else {
+                    for (int k = 0; k < 4; ++k) if (i0 + k < n) gv[k] = g[i0 + k];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { o[k] = fmaf(sc[t], gv[k], o[k]); d[t] = fmaf(gv[k], wv[k], d[t]); }
+            }
+        }
+        if (vec) {
+            float4* dst = reinterpret_cast<float4*>(dw + i0);
+            if (acc) { const float4 p = *dst; o[0] += p.x; o[1] += p.y; o[2] += p.z; o[3] += p.w; }
+            *dst = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+            for (int k = 0; k < 4; ++k) if (i0 + k < n) dw[i0 + k] = acc ? dw[i0 + k] + o[k] : o[k];
+        }
     }
-    if (vec) {
-        float4* dst = reinterpret_cast<float4*>(dw + i0);
-        if (acc) { const float4 p = *dst; o[0] += p.x; o[1] += p.y; o[2] += p.z; o[3] += p.w; }
-        *dst = make_float4(o[0], o[1], o[2], o[3]);
-    } else {
-        for (int k = 0; k < 4; ++k) if (i0 + k < n) dw[i0 + k] = acc ? dw[i0 + k] + o[k] : o[k];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const float v = wave_sum(d[t]);
+        if (lane == 0) sh[wave][t] = v;
     }
+    __syncthreads();
+    if (threadIdx.x < Tn) atomicAdd(dscale + t0 + threadIdx.x, sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
 extern "C" int ag2v_sn_group_combine(const float* G, const float* w, const float* scale, int T, long long n, float* dw, int accumulate,
                                      float* dscale, void* stream) {
@@ -343,8 +359,13 @@ extern "C" int ag2v_sn_group_combine(const float* G, const float* w, const float
     const int vecok = ((((uintptr_t)G) | ((uintptr_t)w) | ((uintptr_t)dw)) & 15) == 0 && (n & 3) == 0;
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(dscale, 0, (size_t)T * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
-    hipLaunchKernelGGL(sn_group_combine_kernel, dim3((unsigned)ceil_div(ceil_div(n, 4LL), 256LL)), dim3(256), 0, st, G, w, scale, T, n,
-                       dw, dscale, accumulate ? 1 : 0, vecok);
+    long long nb = ceil_div(n, 1024LL);
+    if (nb > 2048) nb = 2048;
+    for (int t0 = 0; t0 < T; t0 += 16) {
+        const int Tn = (T - t0 < 16) ? T - t0 : 16;
+        hipLaunchKernelGGL(sn_group_combine_kernel, dim3((unsigned)nb), dim3(256), 0, st, G, w, scale, t0, Tn, n, dw, dscale,
+                           (accumulate || t0 > 0) ? 1 : 0, vecok);
+    }
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
 }

@@ -85,7 +85,7 @@ class Layout2VidGenerator(nn.Module):
                 m._bank_scales = sc
         with ops.frame_groups(T):
             spec = (vecs_list, boxes_list, keep_t, H)
-            with ops.bf16x3_min_rows(ops.EXACT, 128):            # flow network forward exact: see _frames_sequential
+            with ops.bf16x3_min_rows(ops.EXACT, int(os.environ.get('AG2V_FLOW_BWD_ROWS', '128'))):   # forward exact: see _frames_sequential
                 _, flow = self.flows_network(layout=spec, prev=prev[0] if nc == 1 else torch.cat(prev, dim=1))
             warp = resample(prev[-1], flow)
             d = prev[-1] - warp
