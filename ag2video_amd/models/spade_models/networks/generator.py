@@ -85,7 +85,7 @@ class Layout2VidGenerator(nn.Module):
                 m._bank_scales = sc
         with ops.frame_groups(T):
             spec = (vecs_list, boxes_list, keep_t, H)
-            with ops.bf16x3_min_rows(ops.EXACT, int(os.environ.get('AG2V_FLOW_BWD_ROWS', '128'))):   # forward exact: see _frames_sequential
+            with ops.bf16x3_min_rows(ops.EXACT, 32):             # forward exact, backward split from 32 rows: see _frames_sequential
                 _, flow = self.flows_network(layout=spec, prev=prev[0] if nc == 1 else torch.cat(prev, dim=1))
             warp = resample(prev[-1], flow)
             d = prev[-1] - warp
@@ -120,8 +120,9 @@ class Layout2VidGenerator(nn.Module):
             # Flow network: FORWARD on the exact fp32 tiles at every width.  Its output feeds the warp, which turns a flow error
             # into an image error of |grad image| x error: on the seeded clips the 1e-5 of the split products became 1.3e-3 of
             # max|imgs_pred| against the oracle at the default widths (c1; limit 1e-3), with the forward exact it is 2.3e-4 -- the
-            # same as an all-fp32 run (tools/debug_c1_precision.py).  Its gradients are not amplified: backward as everywhere.
-            with ops.bf16x3_min_rows(ops.EXACT, 128):
+            # same as an all-fp32 run (tools/debug_c1_precision.py).  Its gradients are not amplified: the backward takes the split
+            # tiles from 32 rows on (its 32- / 64-channel full-resolution layers ran at 30-65 TF on the exact tiles: -9 ms per c3 step).
+            with ops.bf16x3_min_rows(ops.EXACT, 32):
                 if low_rank:
                     frames = list(range(t - nc, t + 1))
                     spec = ([vecs[:, f] for f in frames], [layout[:, f] for f in frames], keep, H)

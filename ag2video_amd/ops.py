@@ -811,7 +811,7 @@ class _NormAct(torch.autograd.Function):
             if local is not None:
                 sums = local
         else:
-            _launch('ag2v_norm_bwd_g', 'spade_norm_bwd' if mode == 2 else 'norm_bwd', 11.0 * x.numel() * 4, kmode, _ptr(dy), _ptr(y), _ptr(x),
+            _launch('ag2v_norm_bwd_g', 'spade_norm_bwd' if mode == 2 else 'norm_bwd', (7.0 if mode == 0 else 11.0) * x.numel() * 4, kmode, _ptr(dy), _ptr(y), _ptr(x),
                     _ptr(gam), _ptr(wgt), _ptr(mean), _ptr(invstd), _ptr(dx), dg_ptr, db_ptr, _ptr(sums), N, C, HW, Ng, float(slope),
                     _ptr(ws), _stream(), shape=(N, C, HW))
         if mode == 0:

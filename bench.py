@@ -34,24 +34,21 @@ CONFIGS = {
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # same guide: dense bf16 MFMA peak; the bf16x3 path issues 3 MFMAs per product => /3
-# HBM-side traffic of the conv kernels from rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of tools/pmc_traffic.py
-# via tools/pmc_quick.sh, FETCH_SIZE doubled per the gfx950 correction; CSVs under profiles/r01/pmc/*_v25_*): bytes per launch ON
-# THE SHAPE NAMED, not an average over the shapes of a training step.
-PMC_TRAFFIC = {
-    "conv_igemm_bf16x3_ws_kernel<128, 256, 2, 4, 8, false, true, true>": {
-        "bytes_per_launch": 1292e6 + 268e6,
-        "note": "SPADE mlp_shared forward 8x512x256x256 -> 128: FETCH 1292 MB + WRITE 268 MB vs 1076 MB + 268 MB algorithmic"},
-    "conv_igemm_bf16x3_ws_kernel<256, 128, 4, 2, 8, false, true, false>": {
-        "bytes_per_launch": 935e6 + 1074e6,
-        "note": "SPADE mlp_shared data gradient (dy 8x128x256x256 -> dx 512 ch): FETCH 935 MB + WRITE 1074 MB vs 271 MB + 1074 MB "
-                "algorithmic (dy re-read by the 2 row tiles and the 3x3 halo through a 4 MB L2)"},
-    "conv_wgrad_bf16x3_v_kernel<128, 256, 2, 4, 8, false>": {
-        "bytes_per_launch": 1608e6 + 33e6,
-        "note": "SPADE mlp_shared weight gradient: FETCH 1608 MB + WRITE 33 MB (split-K atomics) vs 1342 MB + 2.4 MB algorithmic"},
-    "conv_wgrad_bf16x3_v_kernel<256, 128, 4, 2, 8, false>": {
-        "bytes_per_launch": 341e6 + 33e6,
-        "note": "256 -> 256 layer at 8x128x128 weight gradient: FETCH 341 MB + WRITE 33 MB (split-K atomics) vs 268 MB + 2.4 MB algorithmic"},
-}
+# HBM-side traffic of the conv / norm kernels: rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of
+# tools/pmc_traffic.py through tools/pmc_quick.sh; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md), summarised
+# by tools/pmc_summary.py into profiles/<round>/pmc/traffic.json next to the counter CSVs it was computed from.  bench.py READS that
+# file (newest round first): {kernel name: {"shape": ..., "fetch_bytes", "write_bytes", "algorithmic_bytes", "launches"}} -- bytes
+# per launch ON THE SHAPE NAMED there, not an average over the shapes of a training step.
+def load_pmc_traffic():
+    import glob
+    for path in sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*', 'pmc', 'traffic.json')), reverse=True):
+        try:
+            return json.load(open(path)), os.path.relpath(path, REPO)
+        except Exception:
+            continue
+    return {}, None
+
+
 PEAK_HBM_GBS = 8000.0              # same guide: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
@@ -74,37 +71,54 @@ def make_clip(opt, cfg, batch, frames, side, seed):
 
 
 def cpu_baseline_child():
-    """Runs in a child process without a GPU: the oracle (CPU restatement of the reference step) timed on this host's
-    cores on a bounded sample -- one full step of config c1 (64x64, 4 frames, batch 1, default widths)."""
+    """Runs in a child process without a GPU: the oracle (CPU restatement of the reference step) timed on this host's cores on two
+    bounded samples (SURVEY.md 8d "CPU baseline"): c1 (64x64, 4 frames, batch 1: the reference's own CPU-runnable configuration) and
+    c3' = the GPU workload's resolution at the smallest clip that still has its structure (256x256, 4 frames, batch 1; full c3 is
+    ~1 h per step on a CPU).  Default widths, full G + D step each."""
     from ag2video_amd.data.synthetic import make_clip_batch
     from ag2video_amd.models.meta_models import AG2VideoModel, MetaDiscriminatorModel
     from oracle.step import OracleTrainer
-    opt, side, frames, batch = make_opt('c1')
-    opt.gpu_ids = []
     threads = max(1, min(16, os.cpu_count() or 1))   # the step is thousands of small ops: more threads only add barriers
     torch.set_num_threads(threads)
     cpu = torch.device('cpu')
-    shapes_G = {k: list(v.shape) for k, v in AG2VideoModel(opt, cpu).state_dict().items()}
-    shapes_D = {k: list(v.shape) for k, v in MetaDiscriminatorModel(opt).img_discriminator.state_dict().items()}
-    tr = OracleTrainer(opt, shapes_G, shapes_D, 0)
-    b = make_clip_batch(opt.vocab, batch, frames, (side, side), seed=1234)
-    # one untimed step (first-touch allocations, primitive caches: it took 2.8 s on one box and 22 s on another), then full steps
-    # until ~10 s of timed work, at most 3
-    t0 = time.time()
-    tr.gd_step(b)
-    warm = time.time() - t0
-    n, t0 = 0, time.time()
-    while n < 3 and (n == 0 or time.time() - t0 < 10.0):
-        tr.gd_step(b)
-        n += 1
-    dt = (time.time() - t0) / n
-    print(json.dumps({"value": round(batch * frames / dt, 4), "unit": "frames/sec", "cores": threads, "kind": "port",
-                      "sample": "%d full steps (G fwd+loss+bwd+Adam, D loss+bwd+Adam) of config c1: 64x64, 4 frames, batch 1, "
-                                "default widths, on the oracle (PyTorch-CPU restatement of the reference); %.1f s per step after one "
-                                "untimed step of %.1f s" % (n, dt, warm)}), flush=True)
+    t_start = time.time()
+
+    def leg(side, frames, batch, warm, max_steps, budget_s):
+        opt, _, _, _ = make_opt('c1')
+        opt.image_size = (side, side)
+        opt.batch_size = batch
+        opt.gpu_ids = []
+        shapes_G = {k: list(v.shape) for k, v in AG2VideoModel(opt, cpu).state_dict().items()}
+        shapes_D = {k: list(v.shape) for k, v in MetaDiscriminatorModel(opt).img_discriminator.state_dict().items()}
+        tr = OracleTrainer(opt, shapes_G, shapes_D, 0)
+        b = make_clip_batch(opt.vocab, batch, frames, (side, side), seed=1234)
+        w = 0.0
+        if warm:        # one untimed step (first-touch allocations, primitive caches: 2.8 s on one box and 22 s on another at c1)
+            t0 = time.time()
+            tr.gd_step(b)
+            w = time.time() - t0
+        n, t0 = 0, time.time()
+        while n < max_steps and (n == 0 or time.time() - t0 < budget_s):
+            tr.gd_step(b)
+            n += 1
+        dt = (time.time() - t0) / n
+        return {'frames_per_sec': round(batch * frames / dt, 4), 's_per_step': round(dt, 2), 'steps': n, 'warm_s': round(w, 1)}
+    c1 = leg(64, 4, 1, True, 3, 10.0)
+    res = {"value": c1['frames_per_sec'], "unit": "frames/sec", "cores": threads, "kind": "port", "c1": c1, "c3prime": None,
+           "sample": "oracle (PyTorch-CPU restatement of the reference), full steps (G fwd+loss+bwd+Adam, D loss+bwd+Adam), default "
+                     "widths: c1 (64x64, 4 frames, batch 1) %d steps of %.1f s after one untimed step of %.1f s"
+                     % (c1['steps'], c1['s_per_step'], c1['warm_s'])}
+    print(json.dumps(res), flush=True)                       # a complete line already: the c3' leg may hit the parent's time limit
+    if os.environ.get('AG2V_CPU_BASELINE_C3P', '1') != '0' and time.time() - t_start < 60:
+        c3p = leg(256, 4, 1, False, 1, 0.0)                  # one step, no warm-up: ~1 min of CPU work
+        res['c3prime'] = c3p
+        res['value'] = c3p['frames_per_sec']                 # the leg at the GPU workload's resolution is the headline value
+        res['sample'] += "; c3' (256x256, 4 frames, batch 1: the GPU workload's resolution) 1 step of %.1f s = %.4f frames/s -- this is `value`; c1: %.4f frames/s" % (
+            c3p['s_per_step'], c3p['frames_per_sec'], c1['frames_per_sec'])
+        print(json.dumps(res), flush=True)
 
 
-def cpu_baseline(timeout_s=240):
+def cpu_baseline(timeout_s=300):
     """Spawn the CPU baseline as a child process (bounded wall time; the GPU process itself never runs the oracle)."""
     import subprocess
     env = dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='', OMP_NUM_THREADS='16', MKL_NUM_THREADS='16')
@@ -118,7 +132,13 @@ def cpu_baseline(timeout_s=240):
                 return json.loads(line)
         return {"value": None, "unit": "frames/sec", "cores": None, "kind": "port",
                 "sample": "cpu baseline child failed: %s" % (out.stderr.strip()[-200:],)}
-    except subprocess.TimeoutExpired:
+    except subprocess.TimeoutExpired as e:
+        txt = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or '')
+        for line in reversed(txt.strip().splitlines()):
+            if line.startswith('{'):
+                d = json.loads(line)
+                d['sample'] += " (the c3' leg exceeded the %d s limit and was stopped)" % timeout_s
+                return d
         return {"value": None, "unit": "frames/sec", "cores": None, "kind": "port",
                 "sample": "cpu baseline child exceeded %d s and was stopped" % timeout_s}
 
@@ -214,6 +234,8 @@ def main():
         return
     ms_per_step = dt / args.steps * 1e3
     value = world * batch * frames * args.steps / dt
+    PMC, PMC_PATH = load_pmc_traffic()
+
     def conv_roofline(tm, wall_ms):
         """Roofline block of the dominant conv kernel of a timing summary (work slot = dense-conv algorithmic FLOPs).
         Timing records are keyed "conv_<pass>:<HIP kernel name>"; forward and data gradient share the implicit-GEMM kernels, so
@@ -237,10 +259,15 @@ def main():
         achieved = t['flops'] / (t['ms'] * 1e-3) / 1e12
         conv_ms = sum(v['ms'] for v in per.values())
         conv_fl = sum(v['flops'] for v in per.values())
-        pmc = PMC_TRAFFIC.get(dom)
+        pmc = PMC.get(dom)
         return {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": (pmc or {}).get('bytes_per_launch'),
-                "traffic_note": (pmc or {}).get('note', 'no PMC pass for this kernel'),
+                "frac": round(achieved / peak, 4),
+                "traffic": ((pmc['fetch_bytes'] + pmc['write_bytes']) if pmc else None),
+                "traffic_note": (("%s: FETCH %.0f MB + WRITE %.0f MB per launch on shape %s vs %.0f MB algorithmic (x%.2f)"
+                                  % (PMC_PATH, pmc['fetch_bytes'] / 1e6, pmc['write_bytes'] / 1e6, pmc['shape'],
+                                     pmc['algorithmic_bytes'] / 1e6,
+                                     (pmc['fetch_bytes'] + pmc['write_bytes']) / pmc['algorithmic_bytes'])) if pmc
+                                 else 'no PMC pass for this kernel under profiles/'),
                 "peak_basis": ("bf16 dense MFMA 2500 TF (2.4 GHz) / 3 MFMAs per fp32-equivalent product; the kernel's own cycle counter shows "
                                "1.53 GHz under this instruction mix (DESIGN.md 3.4), i.e. 531 TF MFMA-bound at the held clock"
                                if split else "v_mfma_f32_32x32x2_f32 dense peak"),
@@ -252,14 +279,23 @@ def main():
                                      "by_kernel": {k: {"ms": round(v['ms'], 2), "tflops": round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2),
                                                        "launches": v['launches']} for k, v in sorted(per.items())}}}
 
-    roof_hbm = None
-    if 'spade_norm_apply' in timing:
-        t = timing.pop('spade_norm_apply')
-        gbs = t['flops'] / (t['ms'] * 1e-3) / 1e9          # the record's work slot holds algorithmic bytes for this kernel
-        roof_hbm = {"bound": "hbm", "kernel": "norm_apply_kernel<1,true> (SPADE modulation + LeakyReLU)", "achieved": round(gbs, 1),
-                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "launches": t['launches'],
-                    "avg_launch_ms": round(t['ms'] / t['launches'], 4),
-                    "traffic": "rocprofv3 PMC (profiles/r01/pmc): FETCH_SIZE*2 + WRITE_SIZE = 3x + 1x tensor bytes = algorithmic"}
+    def hbm_roofline(key, kernel, passes):
+        if key not in timing:
+            return None
+        t = timing.pop(key)
+        gbs = t['flops'] / (t['ms'] * 1e-3) / 1e9          # the record's work slot holds algorithmic bytes for these kernels
+        names = [k for k in PMC if k.startswith(kernel.split('<')[0])]
+        pm = PMC.get(names[0]) if names else None
+        return {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": round(gbs / PEAK_HBM_GBS, 4), "launches": t['launches'], "avg_launch_ms": round(t['ms'] / t['launches'], 4),
+                "algorithmic_passes": passes,
+                "traffic": ((pm['fetch_bytes'] + pm['write_bytes']) if pm else None),
+                "traffic_note": (("%s: FETCH %.0f MB + WRITE %.0f MB on shape %s vs %.0f MB algorithmic" % (
+                    PMC_PATH, pm['fetch_bytes'] / 1e6, pm['write_bytes'] / 1e6, pm['shape'], pm['algorithmic_bytes'] / 1e6)) if pm else None)}
+    roof_hbm = hbm_roofline('spade_norm_apply', 'norm_apply_kernel<1, true> (SPADE modulation + LeakyReLU, forward)',
+                            'x, gamma, beta read + y written = 4 tensor passes (the statistics pass is a separate kernel)')
+    roof_hbm_bwd = hbm_roofline('spade_norm_bwd', 'norm_bwd_reduce_kernel<1, true> + norm_bwd_apply_kernel<1, true> (SPADE modulation backward)',
+                                'reduce: dy, y, x, gamma read; apply: the same four read + dx, dgamma, dbeta written = 11 tensor passes')
     roof = conv_roofline(timing, dt * 1e3 / args.steps) if timing else None     # the records cover the last timed step
     roof_fp32 = None
     if fp32_leg is not None:
@@ -278,7 +314,8 @@ def main():
                   if args.precision == 'bf16x3' else "f32"), "data": "synthetic CATER-shaped clips (seeded), closed-form random-init weights",
         "config": {"workload": "%s: %s %dx%d, %d frames, batch %d per GPU, full G+D train step, VGG loss off"
                    % (args.config, "SSv2-shaped" if args.config == 'c5' else "CATER", side, side, frames, batch), "global_batch": world * batch, "parallelism": "dp%d" % world},
-        "roofline": roof, "roofline_exact_fp32": roof_fp32, "roofline_hbm": roof_hbm, "cpu_baseline": cpu,
+        "roofline": roof, "roofline_exact_fp32": roof_fp32, "roofline_hbm": roof_hbm, "roofline_hbm_bwd": roof_hbm_bwd,
+        "cpu_baseline": cpu,
         "extra": {"graph_step_ms": round(graph_ms, 2), "losses_finite": finite,
                   "generated_frames_per_sec": round(world * batch * (frames - 1) * args.steps / dt, 3),
                   "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)},

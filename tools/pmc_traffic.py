@@ -1,31 +1,56 @@
-"""Known-traffic launches for calibrating FETCH_SIZE / WRITE_SIZE on this access pattern + the SPADE conv / norm kernels.
-Run under: rocprofv3 --pmc FETCH_SIZE --kernel-trace ...  and again with --pmc WRITE_SIZE."""
-import sys, os
+"""Launches of the dominant kernels on the shapes they see in a frame-batched c3 step, for HBM-traffic counters.
+Run under rocprofv3 --pmc FETCH_SIZE --kernel-trace ... and again with --pmc WRITE_SIZE (tools/pmc_quick.sh); writes the
+algorithmic byte counts of every launch group to gpurun_out/pmc_expect.json for tools/pmc_summary.py."""
+import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ag2video_amd import ops
 dev = torch.device('cuda:0')
-N, C, H = 8, 64, 256
-x = torch.randn(N, C, H, H, device=dev); g = torch.randn_like(x); b = torch.randn_like(x)
+expect = {}
+REPS = 2
+
+
+def conv_case(tag, N, C, H, K, what):
+    """what: 'fwd' | 'dgrad' | 'wgrad' of a 3x3 stride-1 convolution x[N,C,H,H] -> y[N,K,H,H], with the decoder's row threshold."""
+    x = torch.randn(N, C, H, H, device=dev)
+    w = (torch.randn(K, C, 3, 3, device=dev) * 0.01)
+    xb, yb, wb = N * C * H * H * 4, N * K * H * H * 4, K * C * 9 * 4
+    with ops.bf16x3_min_rows(48):
+        if what == 'fwd':
+            for _ in range(REPS):
+                ops.conv2d(x, w, None, 1, 1)
+            alg = xb + yb + wb
+        else:
+            x.requires_grad_(what == 'dgrad')
+            w.requires_grad_(what == 'wgrad')
+            for _ in range(REPS):
+                y = ops.conv2d(x, w, None, 1, 1)
+                y.backward(torch.ones_like(y))
+            alg = (yb + xb + wb) if what == 'dgrad' else (yb + xb + wb)
+    torch.cuda.synchronize()
+    expect[tag] = {'shape': '%s of %dx%dx%dx%d -> %d channels, 3x3' % (what, N, C, H, H, K), 'algorithmic_bytes': alg, 'pass': what}
+
+
+# SPADE mlp_shared at full resolution: forward (128 x 256 tile, quad loads), merged data gradient of a block's three mlp_shared
+# convolutions (256 x 128 tile) and their merged weight gradient (128-row v kernel); sample counts = the chunks ag2v_conv2d_*_ex cuts
+conv_case('mlp_shared_fwd', 31, 512, 256, 128, 'fwd')
+conv_case('mlp_shared_dgrad_merged', 40, 512, 256, 384, 'dgrad')
+conv_case('mlp_shared_wgrad_merged', 21, 512, 256, 384, 'wgrad')
+conv_case('gamma_beta_wgrad_256', 60, 128, 256, 128, 'wgrad')
+# SPADE modulation (HBM-bound): forward and backward at up_3's size, frame groups of 8
+N, C, H = 120, 64, 256
+x = torch.randn(N, C, H, H, device=dev, requires_grad=True)
+gb = torch.randn(N, 2 * C, H, H, device=dev, requires_grad=True)
 rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
-for _ in range(3):
-    y = ops.spade_norm(x, g, b, rm, rv, True, 0.1, 1e-5, 0.2)          # norm_apply<1,true>: reads 3 tensors, writes 1 (16 B/lane)
-    z = ops.leaky_relu(x, 0.2)                                          # act_fwd: read 1, write 1 (16 B/lane)
-xs = torch.randn(8, 512, 256, 256, device=dev); w = torch.randn(128, 512, 3, 3, device=dev) * 0.01
-for _ in range(3):
-    o = ops.conv2d(xs, w, None, 1, 1)                                    # SPADE mlp_shared shape: algorithmic 1.07 GB in + 0.27 GB out
-xr = x.clone().requires_grad_(True)
-for _ in range(3):
-    ops.leaky_relu(xr, 0.2).backward(g)                                  # act_bwd: reads 2 tensors, writes 1, 4 B/lane
-# bf16x3 wave-specialised kernels, forward + data gradient + weight gradient:
-#   SPADE mlp_shared 512 -> 128 (128x256 tile; x 1.07 GB, y / dy 0.27 GB) and a 256 -> 256 layer at 128x128 (256x128 tile; 134 MB each)
-xs.requires_grad_(True); w.requires_grad_(True)
-for _ in range(2):
-    o2 = ops.conv2d(xs, w, None, 1, 1)
-    o2.backward(torch.ones_like(o2))
-xt = torch.randn(8, 256, 128, 128, device=dev, requires_grad=True); wt = (torch.randn(256, 256, 3, 3, device=dev) * 0.01).requires_grad_(True)
-for _ in range(2):
-    o3 = ops.conv2d(xt, wt, None, 1, 1)
-    o3.backward(torch.ones_like(o3))
+for _ in range(REPS):
+    y = ops.spade_norm_fused(x, gb, rm, rv, True, 0.1, 1e-5, 0.2, groups=15)
+    y.backward(torch.ones_like(y))
 torch.cuda.synchronize()
-print('tensor bytes', x.numel() * 4, 'conv in', xs.numel() * 4, 'conv out', o.numel() * 4)
+tb = N * C * H * H * 4
+expect['norm_apply'] = {'shape': 'spade_norm_fused forward %dx%dx%dx%d, 15 groups' % (N, C, H, H), 'algorithmic_bytes': 4 * tb, 'pass': 'fwd'}
+expect['norm_bwd_reduce'] = {'shape': 'same, backward reduce pass', 'algorithmic_bytes': 4 * tb, 'pass': 'bwd'}
+expect['norm_bwd_apply'] = {'shape': 'same, backward apply pass', 'algorithmic_bytes': 7 * tb, 'pass': 'bwd'}
+expect['bn_stats_partial'] = {'shape': 'same, statistics pass', 'algorithmic_bytes': tb, 'pass': 'fwd'}
+os.makedirs('gpurun_out', exist_ok=True)
+json.dump(expect, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', 'pmc_expect.json'), 'w'), indent=1)
+print('done')
