@@ -1,46 +1,48 @@
-"""FETCH_SIZE / WRITE_SIZE counter CSVs of tools/pmc_quick.sh -> <dir>/traffic.json, the file bench.py reads for `roofline.traffic`.
-Units as MI355X_MICROARCH.md's HBM / rocprofv3 section prescribes: both counters are in KiB; on gfx950 FETCH_SIZE counts 64-byte
-requests as 32 bytes, so it is doubled.  Per kernel: the launches whose traffic is largest (the big shapes of tools/pmc_traffic.py;
-warm-up / helper launches of the same kernel on other shapes are ignored) averaged."""
+"""Counter CSVs of tools/pmc_quick.sh -> <dir>/traffic.json, the file bench.py reads for `roofline.traffic`.
+Units as MI355X_MICROARCH.md's HBM / rocprofv3 section prescribes: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts
+64-byte requests as 32 bytes, so it is doubled.  One case per process (tools/pmc_traffic.py <case>): within a case the kernel name
+identifies the launches of interest; FETCH and WRITE of a launch are joined on the dispatch id (the launch sequence is deterministic),
+and the launches with the largest traffic (the case's own shape, not the helper launches around it) are averaged."""
 import collections, csv, json, os, sys
 d = sys.argv[1]
-expect = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', 'pmc_expect.json')))
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def per_dispatch(path, counter):
-    val, name = collections.defaultdict(float), {}
+    val, name = collections.OrderedDict(), {}
     for r in csv.DictReader(open(path)):
         if r['Counter_Name'] == counter:
-            val[r['Dispatch_Id']] += float(r['Counter_Value'])
+            val[r['Dispatch_Id']] = val.get(r['Dispatch_Id'], 0.0) + float(r['Counter_Value'])
             name[r['Dispatch_Id']] = r['Kernel_Name']
-    per = collections.defaultdict(list)
-    for k, v in val.items():
-        per[name[k]].append(v)
-    return per
+    return val, name
 
 
-f = per_dispatch(os.path.join(d, 'fetch_size_counter_collection.csv'), 'FETCH_SIZE')
-w = per_dispatch(os.path.join(d, 'write_size_counter_collection.csv'), 'WRITE_SIZE')
-# which expectation belongs to which kernel (substring of the kernel name, pass)
-MATCH = [('mlp_shared_fwd', 'conv_igemm_bf16x3_ws_kernel<128, 256, 2, 4, 8, false, true, true>'),
-         ('mlp_shared_dgrad_merged', 'conv_igemm_bf16x3_ws_kernel<256, 128, 4, 2, 8, false, true, false>'),
-         ('mlp_shared_wgrad_merged', 'conv_wgrad_bf16x3_v_kernel<256, 128, 4, 2, 8, false>'),
-         ('gamma_beta_wgrad_256', 'conv_wgrad_bf16x3_v_kernel<128, 256, 2, 4, 8, false>'),
-         ('norm_apply', 'norm_apply_kernel<1, true>'), ('norm_bwd_reduce', 'norm_bwd_reduce_kernel<1, true>'),
-         ('norm_bwd_apply', 'norm_bwd_apply_kernel<1, true>'), ('bn_stats_partial', 'bn_stats_partial_kernel<true>')]
+# (case, tag in the case's expectation file, kernel-name substring)
+MATCH = [('mlp_shared_fwd', 'mlp_shared_fwd', 'conv_igemm_bf16x3_ws_kernel<128, 256'),
+         ('mlp_shared_dgrad_merged', 'mlp_shared_dgrad_merged', 'conv_igemm_bf16x3_ws_kernel<256, 128'),
+         ('mlp_shared_wgrad_merged', 'mlp_shared_wgrad_merged', 'conv_wgrad_bf16x3_v_kernel<128, 256'),
+         ('conv_256_wgrad_128px', 'conv_256_wgrad_128px', 'conv_wgrad_bf16x3_v_kernel<256, 128'),
+         ('norm', 'norm_apply', 'norm_apply_kernel<1, true>'), ('norm', 'norm_bwd_reduce', 'norm_bwd_reduce_kernel<1, true>'),
+         ('norm', 'norm_bwd_apply', 'norm_bwd_apply_kernel<1, true>'), ('norm', 'bn_stats_partial', 'bn_stats_partial_kernel<true>')]
 out = {}
-for tag, sub in MATCH:
-    names = [k for k in f if sub in k]
-    if not names:
+for case, tag, sub in MATCH:
+    fp, wp = os.path.join(d, '%s_FETCH_SIZE_counter_collection.csv' % case), os.path.join(d, '%s_WRITE_SIZE_counter_collection.csv' % case)
+    ep = os.path.join(root, 'gpurun_out', 'pmc_expect_%s.json' % case)
+    if not (os.path.exists(fp) and os.path.exists(wp) and os.path.exists(ep)):
         continue
-    k = names[0]
-    fv, wv = sorted(f[k], reverse=True), sorted(w.get(k, [0.0]), reverse=True)
-    top_f = [x for x in fv if x >= 0.8 * fv[0]]
-    top_w = [x for x in wv if x >= 0.8 * wv[0]] or [0.0]
-    key = k.split('(')[0].replace('void ', '')
-    out[key] = {'shape': expect[tag]['shape'], 'fetch_bytes': 2 * 1024 * sum(top_f) / len(top_f), 'write_bytes': 1024 * sum(top_w) / len(top_w),
-                'algorithmic_bytes': expect[tag]['algorithmic_bytes'], 'launches': len(top_f),
-                'ratio': (2 * 1024 * sum(top_f) / len(top_f) + 1024 * sum(top_w) / len(top_w)) / expect[tag]['algorithmic_bytes']}
-    print('%-70s FETCH %8.0f MB  WRITE %8.0f MB  algorithmic %8.0f MB  x%.2f   [%s]' % (
-        key[:70], out[key]['fetch_bytes'] / 1e6, out[key]['write_bytes'] / 1e6, out[key]['algorithmic_bytes'] / 1e6, out[key]['ratio'], expect[tag]['shape']))
+    expect = json.load(open(ep))[tag]
+    f, fn = per_dispatch(fp, 'FETCH_SIZE')
+    w, wn = per_dispatch(wp, 'WRITE_SIZE')
+    ids = [i for i in f if sub in fn[i] and i in w and sub in wn[i]]
+    if not ids:
+        continue
+    tot = {i: 2 * 1024 * f[i] + 1024 * w[i] for i in ids}
+    top = max(tot.values())
+    ids = [i for i in ids if tot[i] >= 0.8 * top]
+    key = fn[ids[0]].split('(')[0].replace('void ', '')
+    fb, wb = 2 * 1024 * sum(f[i] for i in ids) / len(ids), 1024 * sum(w[i] for i in ids) / len(ids)
+    out[key] = {'shape': expect['shape'], 'fetch_bytes': fb, 'write_bytes': wb, 'algorithmic_bytes': expect['algorithmic_bytes'],
+                'launches': len(ids), 'ratio': (fb + wb) / expect['algorithmic_bytes']}
+    print('%-72s FETCH %8.0f MB  WRITE %8.0f MB  algorithmic %8.0f MB  x%.2f   [%s]' % (
+        key[:72], fb / 1e6, wb / 1e6, expect['algorithmic_bytes'] / 1e6, out[key]['ratio'], expect['shape']))
 json.dump(out, open(os.path.join(d, 'traffic.json'), 'w'), indent=1)

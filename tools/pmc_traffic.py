@@ -1,6 +1,7 @@
 """Launches of the dominant kernels on the shapes they see in a frame-batched c3 step, for HBM-traffic counters.
+usage: pmc_traffic.py <case>   (one case per process so that a kernel name identifies the launches of interest)
 Run under rocprofv3 --pmc FETCH_SIZE --kernel-trace ... and again with --pmc WRITE_SIZE (tools/pmc_quick.sh); writes the
-algorithmic byte counts of every launch group to gpurun_out/pmc_expect.json for tools/pmc_summary.py."""
+algorithmic byte counts of the case to gpurun_out/pmc_expect_<case>.json for tools/pmc_summary.py."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,6 +9,7 @@ from ag2video_amd import ops
 dev = torch.device('cuda:0')
 expect = {}
 REPS = 2
+CASE = sys.argv[1]
 
 
 def conv_case(tag, N, C, H, K, what):
@@ -33,24 +35,34 @@ def conv_case(tag, N, C, H, K, what):
 
 # SPADE mlp_shared at full resolution: forward (128 x 256 tile, quad loads), merged data gradient of a block's three mlp_shared
 # convolutions (256 x 128 tile) and their merged weight gradient (128-row v kernel); sample counts = the chunks ag2v_conv2d_*_ex cuts
-conv_case('mlp_shared_fwd', 31, 512, 256, 128, 'fwd')
-conv_case('mlp_shared_dgrad_merged', 40, 512, 256, 384, 'dgrad')
-conv_case('mlp_shared_wgrad_merged', 21, 512, 256, 384, 'wgrad')
-conv_case('gamma_beta_wgrad_256', 60, 128, 256, 128, 'wgrad')
-# SPADE modulation (HBM-bound): forward and backward at up_3's size, frame groups of 8
-N, C, H = 120, 64, 256
-x = torch.randn(N, C, H, H, device=dev, requires_grad=True)
-gb = torch.randn(N, 2 * C, H, H, device=dev, requires_grad=True)
-rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
-for _ in range(REPS):
-    y = ops.spade_norm_fused(x, gb, rm, rv, True, 0.1, 1e-5, 0.2, groups=15)
-    y.backward(torch.ones_like(y))
-torch.cuda.synchronize()
-tb = N * C * H * H * 4
-expect['norm_apply'] = {'shape': 'spade_norm_fused forward %dx%dx%dx%d, 15 groups' % (N, C, H, H), 'algorithmic_bytes': 4 * tb, 'pass': 'fwd'}
-expect['norm_bwd_reduce'] = {'shape': 'same, backward reduce pass', 'algorithmic_bytes': 4 * tb, 'pass': 'bwd'}
-expect['norm_bwd_apply'] = {'shape': 'same, backward apply pass', 'algorithmic_bytes': 7 * tb, 'pass': 'bwd'}
-expect['bn_stats_partial'] = {'shape': 'same, statistics pass', 'algorithmic_bytes': tb, 'pass': 'fwd'}
-os.makedirs('gpurun_out', exist_ok=True)
-json.dump(expect, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', 'pmc_expect.json'), 'w'), indent=1)
+CASES = {
+    'mlp_shared_fwd': lambda: conv_case('mlp_shared_fwd', 31, 512, 256, 128, 'fwd'),
+    'mlp_shared_dgrad_merged': lambda: conv_case('mlp_shared_dgrad_merged', 40, 512, 256, 384, 'dgrad'),
+    'mlp_shared_wgrad_merged': lambda: conv_case('mlp_shared_wgrad_merged', 21, 512, 256, 384, 'wgrad'),
+    'conv_256_wgrad_128px': lambda: conv_case('conv_256_wgrad_128px', 120, 256, 128, 256, 'wgrad'),
+}
+
+
+def norm_case():
+    # SPADE modulation (HBM-bound): forward and backward at up_3's size, frame groups of 8
+    N, C, H = 120, 64, 256
+    x = torch.randn(N, C, H, H, device=dev, requires_grad=True)
+    gb = torch.randn(N, 2 * C, H, H, device=dev, requires_grad=True)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    for _ in range(REPS):
+        y = ops.spade_norm_fused(x, gb, rm, rv, True, 0.1, 1e-5, 0.2, groups=15)
+        y.backward(torch.ones_like(y))
+    torch.cuda.synchronize()
+    tb = N * C * H * H * 4
+    expect['norm_apply'] = {'shape': 'spade_norm_fused forward %dx%dx%dx%d, 15 groups' % (N, C, H, H), 'algorithmic_bytes': 4 * tb, 'pass': 'fwd'}
+    expect['norm_bwd_reduce'] = {'shape': 'same, backward reduce pass', 'algorithmic_bytes': 4 * tb, 'pass': 'bwd'}
+    expect['norm_bwd_apply'] = {'shape': 'same, backward apply pass', 'algorithmic_bytes': 7 * tb, 'pass': 'bwd'}
+    expect['bn_stats_partial'] = {'shape': 'same, statistics pass', 'algorithmic_bytes': tb, 'pass': 'fwd'}
+
+
+CASES['norm'] = norm_case
+CASES[CASE]()
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.makedirs(os.path.join(root, 'gpurun_out'), exist_ok=True)
+json.dump(expect, open(os.path.join(root, 'gpurun_out', 'pmc_expect_%s.json' % CASE), 'w'), indent=1)
 print('done')
