@@ -119,10 +119,14 @@ __global__ __launch_bounds__(256 * KS) void gemm_f32_kernel(const float* __restr
                                                             const float* __restrict__ bias, float* __restrict__ c, int M, int N,
                                                             int K, long long sam, long long sak, long long sbk, long long sbn,
                                                             int ldc, int relu, int accumulate) {
-    constexpr int BK = 16, LD = 64 + 4;
+    // BK = 32 with four K groups: the loop is a chain of (global-load latency, barrier) steps -- ~0.8 us each against 0.25 us of MFMAs
+    // -- so halving its trip count is worth more than the LDS it costs (139 KB: these launches have <= 24 workgroups anyway); the
+    // cross-group reduction buffer aliases the A image, which is dead by then.
+    constexpr int BK = (KS > 1) ? 32 : 16, LD = 64 + 4, EL = BK / 4;    // EL elements of each operand per thread and K-tile
     __shared__ float As[KS][2][BK][LD];
     __shared__ float Bs[KS][2][BK][LD];
-    __shared__ float red[KS > 1 ? KS - 1 : 1][4][16][64];
+    float (*red)[4][16][64] = reinterpret_cast<float (*)[4][16][64]>(&As[0][0][0][0]);
+    static_assert(KS == 1 || sizeof(float) * (KS - 1) * 4 * 16 * 64 <= sizeof(float) * KS * 2 * BK * LD, "reduction buffer fits the A image");
     const int kg = threadIdx.x >> 8;            // K group
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
@@ -137,12 +141,14 @@ __global__ __launch_bounds__(256 * KS) void gemm_f32_kernel(const float* __restr
     // Each thread stages 4 A and 4 B elements per K-tile.  Lanes run along whichever index is contiguous in memory:
     // k-contiguous operand -> (kk = tid & 15, row = (tid >> 4) + 16 i); otherwise (row = tid & 63, kk = (tid >> 6) + 4 i).
     const bool a_kc = (sak == 1), b_kc = (sbk == 1);
-    float ra[4], rb[4];
+    // thread -> (k, row) of element i: k-contiguous operand: kk = (tid & 15) + 16 (i / 4), row = (tid >> 4) + 16 (i % 4);
+    // row-contiguous operand: row = tid & 63, kk = (tid >> 6) + 4 i
+    float ra[EL], rb[EL];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int akk = a_kc ? (tid & 15) : ((tid >> 6) + 4 * i), arow = a_kc ? ((tid >> 4) + 16 * i) : (tid & 63);
-            const int bkk = b_kc ? (tid & 15) : ((tid >> 6) + 4 * i), brow = b_kc ? ((tid >> 4) + 16 * i) : (tid & 63);
+        for (int i = 0; i < EL; ++i) {
+            const int akk = a_kc ? ((tid & 15) + 16 * (i >> 2)) : ((tid >> 6) + 4 * i), arow = a_kc ? ((tid >> 4) + 16 * (i & 3)) : (tid & 63);
+            const int bkk = b_kc ? ((tid & 15) + 16 * (i >> 2)) : ((tid >> 6) + 4 * i), brow = b_kc ? ((tid >> 4) + 16 * (i & 3)) : (tid & 63);
             const int m = m0 + arow, n = n0 + brow;
             ra[i] = (m < M && k0 + akk < kend) ? a[(long long)m * sam + (long long)(k0 + akk) * sak] : 0.f;
             rb[i] = (n < N && k0 + bkk < kend) ? b[(long long)(k0 + bkk) * sbk + (long long)n * sbn] : 0.f;
@@ -150,9 +156,9 @@ __global__ __launch_bounds__(256 * KS) void gemm_f32_kernel(const float* __restr
     };
     auto stash = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int akk = a_kc ? (tid & 15) : ((tid >> 6) + 4 * i), arow = a_kc ? ((tid >> 4) + 16 * i) : (tid & 63);
-            const int bkk = b_kc ? (tid & 15) : ((tid >> 6) + 4 * i), brow = b_kc ? ((tid >> 4) + 16 * i) : (tid & 63);
+        for (int i = 0; i < EL; ++i) {
+            const int akk = a_kc ? ((tid & 15) + 16 * (i >> 2)) : ((tid >> 6) + 4 * i), arow = a_kc ? ((tid >> 4) + 16 * (i & 3)) : (tid & 63);
+            const int bkk = b_kc ? ((tid & 15) + 16 * (i >> 2)) : ((tid >> 6) + 4 * i), brow = b_kc ? ((tid >> 4) + 16 * (i & 3)) : (tid & 63);
             As[kg][buf][akk][arow] = ra[i];
             Bs[kg][buf][bkk][brow] = rb[i];
         }
@@ -175,6 +181,7 @@ __global__ __launch_bounds__(256 * KS) void gemm_f32_kernel(const float* __restr
         cur ^= 1;
     }
     if (KS > 1) {
+        // (the loop's last barrier is behind every group's last read of the A image that `red` aliases)
         if (kg > 0) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) red[kg - 1][wave][r][lane] = acc[r];

@@ -194,7 +194,15 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __res
         for (int i = 0; i < 16; ++i) g[i] = t[i] > 0.f ? g[i] : g[i] * slope;
     }
     load16<VEC>(x + off, cnt, xv, mask);
+    // (s3, s4) = (sum g, sum g * xhat) BEFORE the (1 + gamma) factor: the channel sums of dbeta and dgamma, i.e. the bias gradient of the
+    // convolution that produced gamma | beta -- it would otherwise cost a pass over the two [N, C, HW] gradient tensors (channel_sum)
+    float s3 = 0.f, s4 = 0.f;
     if (MODE == 1) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            s3 += g[i];
+            s4 += g[i] * ((xv[i] - mu) * is);
+        }
         load16<VEC>(gamma + off + (size_t)n * gbx, cnt, t, mask);
 #pragma unroll
         for (int i = 0; i < 16; ++i) g[i] *= (1.f + t[i]);
@@ -207,22 +215,28 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __res
     }
     s1 = block_sum_256(s1, sh);
     s2 = block_sum_256(s2, sh);
+    if (MODE == 1) {
+        s3 = block_sum_256(s3, sh);
+        s4 = block_sum_256(s4, sh);
+    }
     if (threadIdx.x == 0) {
         const int nparts = Ng * nchunk;
-        float* o = partial + ((size_t)gc * nparts + (size_t)nl * nchunk + chunk) * 2;
-        o[0] = s1; o[1] = s2;
+        float* o = partial + ((size_t)gc * nparts + (size_t)nl * nchunk + chunk) * 4;
+        o[0] = s1; o[1] = s2; o[2] = s3; o[3] = s4;
     }
 }
 
-// sums[c*2+{0,1}] = sum over parts (double accumulate)
+// sums[c*4+{0..3}] = sum over parts (double accumulate)
 __global__ void pair_sum_finalize_kernel(const float* __restrict__ partial, int C, int nparts, float* __restrict__ sums) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const float* p = partial + (size_t)c * nparts * 2;
-    double a = 0.0, b = 0.0;
-    for (int i = 0; i < nparts; ++i) { a += p[2 * i]; b += p[2 * i + 1]; }
-    sums[2 * c] = (float)a;
-    sums[2 * c + 1] = (float)b;
+    const float* p = partial + (size_t)c * nparts * 4;
+    double a = 0.0, b = 0.0, d = 0.0, e = 0.0;
+    for (int i = 0; i < nparts; ++i) { a += p[4 * i]; b += p[4 * i + 1]; d += p[4 * i + 2]; e += p[4 * i + 3]; }
+    sums[4 * c] = (float)a;
+    sums[4 * c + 1] = (float)b;
+    sums[4 * c + 2] = (float)d;
+    sums[4 * c + 3] = (float)e;
 }
 
 // backward pass 2.
@@ -244,7 +258,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
     const int cnt = min(CHUNK, HW - start);
     const size_t off = (size_t)nc * HW + start;
     const float mu = mean[gc], is = invstd[gc];
-    const float m1 = sums[2 * gc] * inv_count, m2 = sums[2 * gc + 1] * inv_count;
+    const float m1 = sums[4 * gc] * inv_count, m2 = sums[4 * gc + 1] * inv_count;
     float g[16], xv[16], t[16];
     unsigned mask;
     load16<VEC>(dy + off, cnt, g, mask);
@@ -348,7 +362,7 @@ static inline bool vec_ok(int HW, const void* a, const void* b = nullptr, const 
 
 extern "C" size_t ag2v_bn_workspace_floats(int N, int C, int HW) {
     const int nchunk = ceil_div(HW, CHUNK);
-    return (size_t)C * N * nchunk * 3 + 2 * (size_t)C;
+    return (size_t)C * N * nchunk * 4 + 2 * (size_t)C;      // 3 floats per part for the statistics, 4 for the backward sums
 }
 
 // Batch statistics of x[N,C,H*W] per sample group of Ng consecutive samples (N % Ng == 0, G = N / Ng): mean / invstd [G, C]
@@ -407,7 +421,8 @@ extern "C" int ag2v_norm_apply(int mode, const float* x, const float* mean, cons
 
 // Backward of ag2v_norm_apply_g with batch statistics (training mode), in two steps so that a data-parallel caller can all-reduce
 // the per-(group, channel) sums between them (synchronised batch norm, sync_batchnorm/batchnorm.py:105-126):
-//   reduce: sums[G*C*2] = (sum dxhat, sum dxhat*xhat) over this process's samples;   mode 0: these are the groups' (dbias, dweight)
+//   reduce: sums[G*C*4] = (sum dxhat, sum dxhat*xhat, sum g, sum g*xhat) over this process's samples; mode 0: the first two are the
+//           groups' (dbias, dweight); modes 1 / 2: the last two are the channel sums of (dbeta, dgamma)
 //   apply:  dx (and, modes 1 / 2, dgamma / dbeta) from sums and inv_count = 1 / (#elements per (group, channel) the sums cover).
 // y is the forward output (activation sign); may be null if slope == 1.
 static int norm_bwd_launch(int mode, bool do_reduce, bool do_apply, const float* dy, const float* y, const float* x, const float* gamma,

@@ -118,7 +118,9 @@ int ag2v_norm_bwd(int mode, const float* dy, const float* y, const float* x, con
 /* Sample groups: the T frame passes of the reference's generator loop (generator.py:62-87) are T separate F.batch_norm calls
  * over B samples each; the frame-batched form holds them as one [T*B, C, HW] tensor, Ng = B samples per group.  mean / invstd
  * are [N / Ng, C] (sample n uses row n / Ng); the running statistics receive the N / Ng momentum updates in group order; sums is
- * [N / Ng, C, 2].  Ng == N is the plain form above. */
+ * [N / Ng, C, 4] = (sum dxhat, sum dxhat xhat, sum dbeta, sum dgamma): mode 0 -> the first two are (dbias, dweight) of the affine
+ * parameters; modes 1 / 2 -> the last two are the channel sums of the gamma / beta gradients (the bias gradient of the convolution
+ * that produced them).  Ng == N is the plain form above. */
 int ag2v_bn_stats_g(const float* x, int N, int C, int HW, int Ng, float eps, float momentum, float* mean, float* invstd,
                     float* running_mean, float* running_var, float* workspace, void* stream);
 int ag2v_norm_apply_g(int mode, const float* x, const float* mean, const float* invstd, const float* w, const float* b,
@@ -127,7 +129,7 @@ int ag2v_norm_bwd_g(int mode, const float* dy, const float* y, const float* x, c
                     const float* mean, const float* invstd, float* dx, float* dgamma, float* dbeta, float* sums,
                     int N, int C, int HW, int Ng, float slope, float* workspace, void* stream);
 /* ag2v_norm_bwd_g in two steps, for data-parallel SYNCHRONISED batch norm (sync_batchnorm/batchnorm.py:105-126): the caller
- * all-reduces sums[N / Ng, C, 2] over the ranks between them and passes inv_count = 1 / (elements per (group, channel) over ALL ranks). */
+ * all-reduces sums[N / Ng, C, 4] over the ranks between them and passes inv_count = 1 / (elements per (group, channel) over ALL ranks). */
 int ag2v_norm_bwd_reduce_g(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* mean,
                            const float* invstd, float* sums, int N, int C, int HW, int Ng, float slope, float* workspace, void* stream);
 int ag2v_norm_bwd_apply_g(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* w,

@@ -30,7 +30,7 @@ def test_library_exports_every_symbol():
     lib = _lib.load()          # dlopen + signature binding (no kernel is launched without a GPU)
     assert lib is not None
     assert _lib.query('ag2v_reduce_workspace_floats') == 1024
-    assert _lib.query('ag2v_bn_workspace_floats', 2, 3, 5000) == 3 * 2 * 2 * 3 + 6
+    assert _lib.query('ag2v_bn_workspace_floats', 2, 3, 5000) == 3 * 2 * 2 * 4 + 6
 
 
 def test_ops_refuse_cpu_tensors():

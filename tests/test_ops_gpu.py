@@ -763,3 +763,25 @@ def test_spectral_bank_matches_per_layer_scales(device):
         _cmp('bank.u%d' % i, lg[i].weight_u, lc[i].weight_u)
         _cmp('bank.v%d' % i, lg[i].weight_v, lc[i].weight_v)
         _cmp('bank.grad%d' % i, lg[i].weight_orig.grad, lc[i].weight_orig.grad)
+
+
+def test_spade_bias_gradient_from_norm_backward(device):
+    """gamma | beta convolution -> SPADE modulation: the convolution's bias gradient is taken from the channel sums the norm's
+    backward reduce pass produces (no pass over the [N, 2C, H, W] gradient).  Against the oracle, with frame groups."""
+    from ag2video_amd import ops
+    from oracle import kernels as K
+    N, Cin, C, H, G = 6, 16, 24, 12, 3
+    a = _rand(N, Cin, H, H, seed=1)
+    w, b = _rand(2 * C, Cin, 3, 3, seed=2, scale=0.1), _rand(2 * C, seed=3)
+    x = _rand(N, C, H, H, seed=4) * 2 + 0.3
+    wgt = _rand(N, C, H, H, seed=5)
+    res = []
+    for mod, dev in ((K, 'cpu'), (ops, device)):
+        ad, wd, bd, xd = [t.clone().to(dev).requires_grad_(True) for t in (a, w, b, x)]
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        gb = mod.conv2d(ad, wd, bd, 1, 1)
+        y = mod.spade_norm_fused(xd, gb, rm, rv, True, 0.1, 1e-5, 0.2, groups=G)
+        (y * wgt.to(dev)).sum().backward()
+        res.append((bd.grad, wd.grad, ad.grad, xd.grad))
+    for got, ref, nm in zip(res[1], res[0], ('dbias', 'dw', 'da', 'dx')):
+        _cmp('spade_chain.' + nm, got, ref)
