@@ -273,8 +273,15 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
                     const int off = (j * GR + quad) * LDK + kpart * KPT;
                     if constexpr (KPT == 4) {
                         unsigned h0, l0, h1, l1;
+#ifdef AG2V_DIAG_PRESPLIT               // timing experiment only: input taken as packed hi:lo words
+                        h0 = __builtin_amdgcn_perm(__float_as_uint(rb[0][4 + j]), __float_as_uint(rb[0][j]), 0x07060302u);
+                        l0 = __builtin_amdgcn_perm(__float_as_uint(rb[0][4 + j]), __float_as_uint(rb[0][j]), 0x05040100u);
+                        h1 = __builtin_amdgcn_perm(__float_as_uint(rb[0][12 + j]), __float_as_uint(rb[0][8 + j]), 0x07060302u);
+                        l1 = __builtin_amdgcn_perm(__float_as_uint(rb[0][12 + j]), __float_as_uint(rb[0][8 + j]), 0x05040100u);
+#else
                         split2(rb[0][j], rb[0][4 + j], h0, l0);
                         split2(rb[0][8 + j], rb[0][12 + j], h1, l1);
+#endif
                         *reinterpret_cast<uint2*>(&Bhi[buf][off]) = make_uint2(h0, h1);
                         *reinterpret_cast<uint2*>(&Blo[buf][off]) = make_uint2(l0, l1);
                     } else {      // 256 x 128 tile: 2 channels per thread

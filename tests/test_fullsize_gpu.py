@@ -149,3 +149,36 @@ def test_full_size_step_runs_and_is_finite(device):
     assert all(bool(torch.isfinite(v).all()) for v in list(GL.values()) + list(DL.values()))
     assert tuple(out[0].shape) == (batch, frames, 3, side, side)
     assert (pg[name].detach() - p0).abs().max().item() > 0
+
+
+def test_full_size_frame_batched_equals_sequential(device):
+    """c3 (256x256, 16 frames, batch 8, default widths): the frame-batched generator pass (one [120, ...] batch, per-group statistics
+    and sigma_t, 16 GB tensors convolved in sample chunks) against the sequential 15-pass loop the golden vectors pin -- same weights,
+    same clip.  Outputs within 2e-4 of max (two summation orders of the same arithmetic), the running statistics and the spectral-norm
+    vectors after the 15 per-pass updates within 1e-4."""
+    import os
+    import bench
+    from ag2video_amd.data.synthetic import make_clip_batch
+    from ag2video_amd.engine import TrainStep
+    opt, side, frames, batch = bench.make_opt('c3')
+    opt.gpu_ids = [0]
+    ts = TrainStep(opt, device, weights_seed=0)
+    clip = ts.to_device(make_clip_batch(opt.vocab, batch, frames, (side, side), seed=1234))
+    sd0 = {k: v.clone() for k, v in ts.model.state_dict().items()}
+    outs, states = [], []
+    for seq in (False, True):
+        ts.model.load_state_dict(sd0)
+        opt.batch_frames = not seq
+        with torch.no_grad():
+            o = ts.model(clip[0], clip[1], clip[3], clip[4], boxes_gt=clip[2], test_mode=False, use_gt=True)
+        outs.append([t.clone() for t in o[:4]])
+        states.append({k: v.clone() for k, v in ts.model.state_dict().items() if 'running_' in k or k.endswith('weight_u') or k.endswith('weight_v')})
+        del o
+    opt.batch_frames = True
+    for name, a, b in zip(('imgs_pred', 'boxes_pred', 'flows_pred'), outs[0], outs[1]):
+        err = (a - b).abs().max().item() / b.abs().max().item()
+        assert err <= 2e-4, (name, err)
+    assert (outs[0][3] != outs[1][3]).float().mean().item() < 1e-3          # confidence masks
+    for k in states[1]:
+        a, b = states[0][k], states[1][k]
+        assert (a - b).abs().max().item() <= 1e-4 * max(b.abs().max().item(), 1e-6), k

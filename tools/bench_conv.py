@@ -19,6 +19,12 @@ SHAPES = [  # name, N, C, H, W, K, R, stride, pad
     ('flow_res_32', 8, 256, 32, 32, 256, 3, 1, 1),
     ('spade_shared_64', 8, 512, 64, 64, 128, 3, 1, 1),
     ('g_mid_16_1024_128', 8, 128, 16, 16, 1024, 3, 1, 1),
+    # frame-batched chunk shapes (round 2)
+    ('b_shared_fwd', 31, 512, 256, 256, 128, 3, 1, 1),
+    ('b_merged_384', 24, 512, 256, 256, 384, 3, 1, 1),
+    ('b_gamma_beta', 40, 128, 256, 256, 128, 3, 1, 1),
+    ('b_mid_16', 120, 1024, 16, 16, 1024, 3, 1, 1),
+    ('b_up2', 120, 256, 128, 128, 128, 3, 1, 1),
 ]
 if len(sys.argv) > 1:
     SHAPES = [s for s in SHAPES if s[0] in sys.argv[1:]]
@@ -45,7 +51,7 @@ for name, N, C, H, W, K, R, st, pad in SHAPES:
     for which in ('fwd', 'dgrad', 'wgrad'):
         run(which); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 10
+        reps = int(os.environ.get('REPS', '10'))
         e0.record()
         for _ in range(reps): run(which)
         e1.record(); torch.cuda.synchronize()
