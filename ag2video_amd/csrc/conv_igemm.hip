@@ -657,11 +657,32 @@ static int launch_igemm(ConvArgs& a, hipStream_t st, bool out_zeroed, bool split
     if (a.o_mul == 0) { a.o_mul = 1; a.o_add_y = 0; a.o_add_x = 0; a.o_H = a.OH; a.o_W = a.OW; }
     if (split) return launch_igemm_bf16x3(a, st, out_zeroed);
     if (a.M <= 4 && a.stride == 1 && a.o_mul == 1 && a.o_add_y == 0 && a.o_add_x == 0 && a.o_W == a.OW && a.o_H == a.OH &&
-        (long long)a.N * a.C * a.H * a.W * 4 < 0xE0000000LL && getenv("AG2V_NO_FEWROW") == nullptr) {
-        a.b_bytes = (unsigned)((long long)a.N * a.C * a.H * a.W * 4);
-        const bool ok = a.M == 1 ? launch_fewrow<1>(a, st) : a.M == 2 ? launch_fewrow<2>(a, st)
-                      : a.M == 3 ? launch_fewrow<3>(a, st) : launch_fewrow<4>(a, st);
-        if (ok) { set_last_conv_kernel("conv_fewrow_kernel"); AG2V_CHECK_LAUNCH(); return AG2V_OK; }
+        (long long)a.C * a.H * a.W * 4 < 0x10000000LL && getenv("AG2V_NO_FEWROW") == nullptr) {
+        // The kernel flags an out-of-image tap by adding 0xF0000000 to its byte offset, which only stays out of range while the
+        // valid part of the offset is below 0x10000000: at most 256 MB of input per launch (a frame-batched [120, 64, 256, 256]
+        // input is 2 GB: beyond 256 MB the padding taps of the few-row kernel read real data) -> sample chunks.
+        const long long per = (long long)a.C * a.H * a.W * 4;
+        int nmax = (int)(0x0FFFFFFFLL / per);
+        if (a.gscale) nmax -= nmax % a.group_n;
+        if (nmax >= 1) {
+            const size_t os = (size_t)a.M * a.OH * a.OW;
+            bool ok = true;
+            for (int n0 = 0; n0 < a.N && ok; n0 += nmax) {
+                ConvArgs c = a;
+                c.N = (a.N - n0 < nmax) ? a.N - n0 : nmax;
+                c.b_src = a.b_src + (size_t)n0 * a.C * a.H * a.W;
+                c.out = a.out + (size_t)n0 * os;
+                c.residual = a.residual ? a.residual + (size_t)n0 * os : nullptr;
+                c.mask = a.mask ? a.mask + (size_t)n0 * os : nullptr;
+                c.gscale = a.gscale ? a.gscale + n0 / a.group_n : nullptr;
+                c.NG = c.N * a.OH * a.OW;
+                c.b_bytes = (unsigned)(per * c.N);
+                ok = a.M == 1 ? launch_fewrow<1>(c, st) : a.M == 2 ? launch_fewrow<2>(c, st)
+                   : a.M == 3 ? launch_fewrow<3>(c, st) : launch_fewrow<4>(c, st);
+                if (!ok && n0 > 0) return AG2V_EINVAL;      // (cannot happen: the filter shape decides and is the same for all chunks)
+            }
+            if (ok) { set_last_conv_kernel("conv_fewrow_kernel"); AG2V_CHECK_LAUNCH(); return AG2V_OK; }
+        }
     }
     const int bm = (a.M <= 32) ? 32 : (a.M <= 64 ? 64 : 128);
     const int bk = 16;

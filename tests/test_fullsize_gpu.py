@@ -154,8 +154,11 @@ def test_full_size_step_runs_and_is_finite(device):
 def test_full_size_frame_batched_equals_sequential(device):
     """c3 (256x256, 16 frames, batch 8, default widths): the frame-batched generator pass (one [120, ...] batch, per-group statistics
     and sigma_t, 16 GB tensors convolved in sample chunks) against the sequential 15-pass loop the golden vectors pin -- same weights,
-    same clip.  Outputs within 2e-4 of max (two summation orders of the same arithmetic), the running statistics and the spectral-norm
-    vectors after the 15 per-pass updates within 1e-4."""
+    same clip.  This test found a real bug (the few-row kernel's padding taps read live data beyond 256 MB of input: O(1) errors from
+    frame 3 on).  Tolerances: the flows (exact-fp32 flow network) 1e-4; the images 1e-2 -- at these widths and 256x256 the randomly
+    initialised decoder amplifies last-bit differences (the order of split-K atomics) to 1.5-2e-3 of max between two runs of the SAME
+    path (tools/debug_batched_vs_seq.py PAIR=ss / bb), so 1e-2 separates "same arithmetic" from a plumbing error (O(0.1 - 1));
+    the running statistics and spectral-norm vectors after the 15 per-pass updates 1e-4."""
     import os
     import bench
     from ag2video_amd.data.synthetic import make_clip_batch
@@ -175,10 +178,32 @@ def test_full_size_frame_batched_equals_sequential(device):
         states.append({k: v.clone() for k, v in ts.model.state_dict().items() if 'running_' in k or k.endswith('weight_u') or k.endswith('weight_v')})
         del o
     opt.batch_frames = True
-    for name, a, b in zip(('imgs_pred', 'boxes_pred', 'flows_pred'), outs[0], outs[1]):
+    for name, tol, a, b in zip(('imgs_pred', 'boxes_pred', 'flows_pred'), (1e-2, 1e-6, 1e-4), outs[0], outs[1]):
         err = (a - b).abs().max().item() / b.abs().max().item()
-        assert err <= 2e-4, (name, err)
+        assert err <= tol, (name, err)
+        for f in range(a.shape[1]):                     # every frame group on its own (a chunk-boundary bug hits late groups only)
+            ef = (a[:, f] - b[:, f]).abs().max().item() / b.abs().max().item()
+            assert ef <= tol, (name, f, ef)
     assert (outs[0][3] != outs[1][3]).float().mean().item() < 1e-3          # confidence masks
     for k in states[1]:
         a, b = states[0][k], states[1][k]
         assert (a - b).abs().max().item() <= 1e-4 * max(b.abs().max().item(), 1e-6), k
+
+
+def test_fewrow_conv_beyond_256mb(device):
+    """<= 4 output rows (conv_img, conv_flow, the discriminators' last layer) on an input larger than the 256 MB one launch of the
+    few-row kernel can address: the full batch must equal the same convolution run on sample slices, and a corner window the oracle."""
+    from ag2video_amd import ops
+    from oracle import kernels as K
+    N, C, H = 20, 64, 256                                    # 335 MB
+    x = _rand(N, C, H, H, seed=1, device=device)
+    w = _rand(3, C, 3, 3, seed=2, device=device, scale=(C * 9) ** -0.5)
+    b = _rand(3, seed=3, device=device)
+    y = ops.conv2d(x, w, b, 1, 1)
+    parts = torch.cat([ops.conv2d(x[i:i + 4], w, b, 1, 1) for i in range(0, N, 4)], dim=0)
+    assert torch.equal(y, parts)
+    for n in (0, N - 1):
+        crop = torch.nn.functional.pad(x[n:n + 1, :, :25, :25].cpu(), (1, 0, 1, 0))
+        ref = K.conv2d(crop, w.cpu(), b.cpu(), 1, 0)
+        got = y[n:n + 1, :, :24, :24].cpu()
+        assert (got - ref).abs().max().item() <= 2e-5 * ref.abs().max().item(), n
