@@ -56,7 +56,7 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
     const bool producer = wave < NPW;
     const int lid = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
     const int tile_m = lid % p.tiles_m, tile_n = lid / p.tiles_m;
-    const int m0 = tile_m * BM;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int RS = p.R * p.S;
     const int SHW = p.H * p.W;
 
@@ -80,10 +80,13 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
         unsigned vmask[BCOLS];
 #pragma unroll
         for (int c = 0; c < BCOLS; ++c) {
+            const int pix = n0 + bcol0 + c * (BN / BCOLS);
             vmask[c] = 0;
             bbase[c] = 0;
-            int n_img, py, px;
-            if (igemm_pixel(p, tile_n, bcol0 + c * (BN / BCOLS), BN, n_img, py, px)) {
+            if (pix < p.NG) {
+                const int n_img = pix / (p.OH * p.OW);
+                const int prem = pix - n_img * (p.OH * p.OW);
+                const int py = prem / p.OW, px = prem - py * p.OW;
                 const int y0 = py * p.stride - p.pad, x0 = px * p.stride - p.pad_w;
                 for (int r = 0; r < p.R; ++r)
                     for (int s2 = 0; s2 < p.S; ++s2)
@@ -96,8 +99,11 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
         int qbase = 0, qx0 = 0;
         unsigned qrmask = 0, qemask = 0;       // qemask: nibble s = the quad elements whose column x0 + s + j is outside [0, W)
         if constexpr (B4) {
-            int n_img, py, px;
-            if (igemm_pixel(p, tile_n, 4 * quad, BN, n_img, py, px)) {
+            const int pix = n0 + 4 * quad;
+            if (pix < p.NG) {
+                const int n_img = pix / (p.OH * p.OW);
+                const int prem = pix - n_img * (p.OH * p.OW);
+                const int py = prem / p.OW, px = prem - py * p.OW;
                 const int y0 = py - p.pad;
                 qx0 = px - p.pad_w;
                 for (int r = 0; r < p.R; ++r)
@@ -465,17 +471,19 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
     // consecutive pixels, i.e. one 256-byte run per store instruction.
     static_assert(EN * ER == 64, "a consumer wave owns 64 pixels");
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const int gplane = p.OH * p.OW;
     const int plane = p.o_H * p.o_W;
     const bool mapped = (p.o_mul != 1 || p.o_add_y != 0 || p.o_add_x != 0 || p.o_W != p.OW);
-    int on, qy, qx;
-    bool pvalid = igemm_pixel(p, tile_n, wn0 + lane, BN, on, qy, qx);
-    int orem = qy * p.OW + qx;
+    const int opix = n0 + wn0 + lane;
+    bool pvalid = opix < p.NG;
+    const int on = pvalid ? opix / gplane : 0;
+    int orem = pvalid ? opix - on * gplane : 0;
     if (mapped) {
+        const int qy = orem / p.OW, qx = orem - qy * p.OW;
         const int yy = qy * p.o_mul + p.o_add_y, xx = qx * p.o_mul + p.o_add_x;
         pvalid = pvalid && (unsigned)yy < (unsigned)p.o_H && (unsigned)xx < (unsigned)p.o_W;
         orem = yy * p.o_W + xx;
     }
-    if (!pvalid) { on = 0; orem = 0; }
     float* obase = p.out + (size_t)on * p.M * plane + orem;
     const float* rbase = p.residual ? p.residual + (size_t)on * p.M * plane + orem : nullptr;
     const float* mbase = (p.mask && p.splitk == 1) ? p.mask + (size_t)on * p.M * plane + orem : nullptr;
@@ -1060,13 +1068,6 @@ int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed) {
     const int bm = tall ? 256 : 128, bn = tall ? 128 : 256;
     a.tiles_m = ceil_div(a.M, bm);
     a.tiles_n = ceil_div(a.NG, bn);
-    // 2-D pixel tiles (4 x 32) on the 256 x 128 tile when the image divides into them: halo rows shared inside the tile.  (The
-    // 128 x 256 tile's 256 pixels are whole rows of the large layers, whose neighbours run back to back on one XCD: FETCH 1.16x.)
-    static const bool tiles2d = getenv("AG2V_NO_2D_TILES") == nullptr;
-    a.tw = 0;
-    if (tiles2d && tall && a.R > 1 && a.OW % 32 == 0 && a.OH % 4 == 0) {
-        a.tw = 32; a.th = 4; a.tiles_x = a.OW / 32; a.tiles_img = a.tiles_x * (a.OH / 4);
-    }
     const int tiles = a.tiles_m * a.tiles_n, nk = ceil_div(a.KG, 32);
     a.splitk = 1; a.kchunk = nk;
     if (tiles < 1024 && nk >= 8) {

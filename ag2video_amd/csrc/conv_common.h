@@ -24,8 +24,6 @@ struct ConvArgs {
                             // C % 32 == 0 (every 32-wide K-tile then has one filter tap)
     int diag_noprio;        // tuning aid: the MFMA waves of the wgrad v kernels keep the default issue priority
     int accumulate;         // wgrad: add onto the existing dW (no zeroing; atomics) -- the weight is used by several forward calls
-    int tw, th, tiles_x, tiles_img;   // bf16x3 igemm: 2-D pixel tiles (tw > 0): tile_n covers th x tw output pixels of ONE image instead of
-                            //   BN consecutive pixels of a row -- see igemm_pixel(); tiles_x = OW / tw, tiles_img = tiles_x * (OH / th)
     const float* gscale;    // igemm epilogue (nullable): the accumulated product of sample n is multiplied by gscale[n / group_n]
     int group_n;            //   before bias / residual -- spectral norm's 1/sigma_t of frame group t (frame-batched generator)
     int groups, gq, spg;    // wgrad: `groups` consecutive sample groups of gq pixels each, spg pixel-range splits per group (grid =
@@ -83,29 +81,6 @@ __device__ __forceinline__ float pack_split(float x) {
     return __uint_as_float(w);
 }
 
-
-// Pixel `col` of pixel tile `tile_n` (BN pixels per tile) -> (image, y, x) of the GEMM's pixel space [N, OH, OW].  Linear tiles take BN
-// consecutive pixels of the flattened space; 2-D tiles (p.tw > 0) take th x tw pixels of one image, so that the (R - 1) halo rows a
-// tile gathers beside its own are shared inside the tile: a 1 x 128 tile of a 3x3 convolution reads 3 x 130 input pixels per channel
-// for 128 outputs, a 4 x 32 tile 6 x 34 for the same 128 (FETCH_SIZE of the merged mlp_shared data gradient: 3.5x -> see profiles/).
-__device__ __forceinline__ bool igemm_pixel(const ConvArgs& p, int tile_n, int col, int BN, int& n_img, int& py, int& px) {
-    if (p.tw > 0) {
-        n_img = tile_n / p.tiles_img;
-        const int t = tile_n - n_img * p.tiles_img;
-        const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
-        const int ly = col / p.tw, lx = col - ly * p.tw;
-        py = ty * p.th + ly;
-        px = tx * p.tw + lx;
-        return n_img < p.N;
-    }
-    const int pix = tile_n * BN + col;
-    if (pix >= p.NG) { n_img = 0; py = 0; px = 0; return false; }
-    n_img = pix / (p.OH * p.OW);
-    const int prem = pix - n_img * (p.OH * p.OW);
-    py = prem / p.OW;
-    px = prem - py * p.OW;
-    return true;
-}
 
 // Raw buffer loads: a wave-uniform descriptor in SGPRs + a 32-bit byte offset per lane (no 64-bit address VGPRs); an offset
 // >= the descriptor's byte count reads as 0, which is how masked taps / padded rows are fetched (offset 0xFFFFFFFF).

@@ -85,11 +85,6 @@ CONV_CASES = [
     (3, 20, 9, 9, 1, 4, 4, 1, 2, True, False),        # the discriminators' last layer: OW = 10, not a multiple of 4
     (2, 16, 8, 12, 2, 1, 1, 1, 0, True, True),
     (2, 4, 11, 13, 4, 3, 3, 1, 1, False, False),
-    # 256 x 128 tile with 2-D pixel tiles (4 x 32): OW % 32 == 0, OH % 4 == 0 (forward: >= 192 rows; data gradient: >= 192 input channels)
-    (2, 64, 8, 32, 256, 3, 3, 1, 1, True, True),      # forward 2-D; residual
-    (3, 256, 4, 64, 40, 3, 3, 1, 1, False, False),    # data gradient 2-D (256 gathered rows), 3 images
-    (2, 224, 16, 64, 48, 4, 4, 2, 2, True, False),    # stride-2 data gradient: parity classes of 8 x 32 pixels, mapped placement
-    (2, 96, 12, 32, 200, 3, 3, 1, 1, False, False),   # OH % 4 == 0 with 12 rows: three tile rows
 ]
 
 
