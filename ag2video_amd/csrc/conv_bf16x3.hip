@@ -54,19 +54,8 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool producer = wave < NPW;
-    int tile_m, tile_n;
-    if (p.mtile_by_xcd) {
-        // two row tiles, pixel-tile count a multiple of 4: XCDs 0,2,4,6 take row tile 0, XCDs 1,3,5,7 row tile 1 (workgroups are dealt
-        // to the XCDs round-robin), each its contiguous quarter of the pixel tiles -> an XCD's L2 (4 MB) holds ONE row tile's weight
-        // planes (3.5 MB at 384 x 9 x 256 rows) instead of thrashing on both (7 MB)
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        tile_m = xcd & 1;
-        tile_n = (xcd >> 1) * (p.tiles_n >> 2) + idx;
-    } else {
-        const int lid = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-        tile_m = lid % p.tiles_m;
-        tile_n = lid / p.tiles_m;       // m-tiles of one pixel tile are neighbours
-    }
+    const int lid = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int tile_m = lid % p.tiles_m, tile_n = lid / p.tiles_m;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int RS = p.R * p.S;
     const int SHW = p.H * p.W;
@@ -1080,8 +1069,6 @@ int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed) {
     a.tiles_m = ceil_div(a.M, bm);
     a.tiles_n = ceil_div(a.NG, bn);
     const int tiles = a.tiles_m * a.tiles_n, nk = ceil_div(a.KG, 32);
-    static const bool mx = getenv("AG2V_MTILE_XCD") != nullptr;
-    a.mtile_by_xcd = (mx && a.tiles_m == 2 && a.tiles_n % 4 == 0 && tiles >= 2048) ? 1 : 0;
     a.splitk = 1; a.kchunk = nk;
     if (tiles < 1024 && nk >= 8) {
         const int sk = pick_splits(tiles, nk, nk / 4 < 64 ? nk / 4 : 64);

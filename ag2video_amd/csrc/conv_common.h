@@ -24,7 +24,6 @@ struct ConvArgs {
                             // C % 32 == 0 (every 32-wide K-tile then has one filter tap)
     int diag_noprio;        // tuning aid: the MFMA waves of the wgrad v kernels keep the default issue priority
     int accumulate;         // wgrad: add onto the existing dW (no zeroing; atomics) -- the weight is used by several forward calls
-    int mtile_by_xcd;       // bf16x3 igemm, two row tiles: row tile chosen by the XCD a workgroup lands on (see the kernel)
     const float* gscale;    // igemm epilogue (nullable): the accumulated product of sample n is multiplied by gscale[n / group_n]
     int group_n;            //   before bias / residual -- spectral norm's 1/sigma_t of frame group t (frame-batched generator)
     int groups, gq, spg;    // wgrad: `groups` consecutive sample groups of gq pixels each, spg pixel-range splits per group (grid =
