@@ -41,6 +41,11 @@ _SIGS = {
     'ag2v_norm_bwd_g': (c_int, [c_int] + [_P] * 11 + [c_int, c_int, c_int, c_int, c_float, _P, _P]),
     'ag2v_norm_bwd_reduce_g': (c_int, [c_int] + [_P] * 7 + [c_int, c_int, c_int, c_int, c_float, _P, _P]),
     'ag2v_norm_bwd_apply_g': (c_int, [c_int] + [_P] * 8 + [c_float, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
+    'ag2v_spade_pair_supported': (c_int, [c_int, c_int, c_int]),
+    'ag2v_spade_pair_workspace_floats': (c_size_t, [c_int, c_int, c_int]),
+    'ag2v_spade_pair_stats': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'ag2v_spade_pair_apply': (c_int, [_P] * 7 + [c_int] * 6 + [c_float, c_float, _P]),
+    'ag2v_spade_pair_bwd': (c_int, [_P] * 13 + [c_int] * 6 + [c_float, c_float, _P, _P]),
     'ag2v_instnorm_lrelu_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P]),
     'ag2v_instnorm_lrelu_bwd': (c_int, [_P] * 6 + [c_int, c_int, c_float, _P]),
     'ag2v_layout_render_fwd': (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [_P]),

@@ -95,10 +95,14 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
 // F.batch_norm(training=True, momentum) calls do (unbiased var in the running buffer).
 // grid: ceil(C / 16) blocks of 256 threads = 16 channels x 16 group lanes (lane gl handles groups gl, gl + 16, ...).
 #define FIN_MAXG 64
+// rep: every element stands for `rep` equal elements (statistics of a nearest-upsampled tensor taken on its source: counts and M2 x rep);
+// running_mean2 / running_var2 (nullable): a second pair of running buffers receiving the same updates (two norm layers on one input).
 __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ partial, int G, int C, int nparts, float eps,
                                                                 float momentum, float* __restrict__ mean_out,
                                                                 float* __restrict__ invstd_out, float* __restrict__ running_mean,
-                                                                float* __restrict__ running_var) {
+                                                                float* __restrict__ running_var, int rep = 1,
+                                                                float* __restrict__ running_mean2 = nullptr,
+                                                                float* __restrict__ running_var2 = nullptr) {
     __shared__ float s_mean[16][FIN_MAXG], s_unb[16][FIN_MAXG];
     const int cl = threadIdx.x >> 4, gl = threadIdx.x & 15;
     const int c = blockIdx.x * 16 + cl;
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __r
             const float* p = partial + (size_t)(g * C + c) * nparts * 3;
             double n = 0.0, mean = 0.0, m2 = 0.0;
             for (int i = 0; i < nparts; ++i) {
-                const double nb = p[3 * i], mb = p[3 * i + 1], m2b = p[3 * i + 2];
+                const double nb = (double)p[3 * i] * rep, mb = p[3 * i + 1], m2b = (double)p[3 * i + 2] * rep;
                 const double nt = n + nb;
                 const double d = mb - mean;
                 mean += d * (nb / nt);
@@ -132,6 +136,15 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __r
         }
         running_mean[c] = (float)rm;
         running_var[c] = (float)rv;
+    }
+    if (c < C && gl == 0 && running_mean2) {
+        double rm = (double)running_mean2[c], rv = (double)running_var2[c];
+        for (int g = 0; g < G; ++g) {
+            rm = (double)(float)((1.0 - momentum) * rm + momentum * (double)s_mean[cl][g]);
+            rv = (double)(float)((1.0 - momentum) * rv + momentum * (double)s_unb[cl][g]);
+        }
+        running_mean2[c] = (float)rm;
+        running_var2[c] = (float)rv;
     }
 }
 
@@ -286,6 +299,217 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
         for (int i = 0; i < 16; ++i) g[i] = sc * (g[i] - m1 - xv[i] * m2);
     }
     store16<VEC>(dx + off, cnt, g);
+}
+
+// ---------------------------------------------------------------- SPADE pair on one (optionally 2x nearest-upsampled) input
+// A SPADEResnetBlock with a learned shortcut normalises the SAME tensor twice (norm_0 and norm_s, architecture.py:52-53,60-61): same
+// batch statistics, different gamma | beta.  Its input is the previous block's output after nn.Upsample(scale_factor=2)
+// (spade_generator.py:62-76).  This family evaluates both modulations in one pass over x and reads x at its ORIGINAL resolution
+// (UP = 2: element (y, x) of the plane is xs[y / 2][x / 2]), so the upsampled tensor is never written or read, the statistics pass
+// runs on a quarter of the elements (replicating every element four times changes neither mean nor biased variance; the element
+// count of the unbiased variance is scaled by `rep`), and the backward writes ONE input gradient -- the sum of both branches, already
+// reduced over each 2 x 2 replica block -- instead of two full-resolution tensors, their sum and the upsample's adjoint.
+template <int UP, bool VEC>
+__device__ __forceinline__ void load16_x(const float* __restrict__ xs_plane, int start, int cnt, int W, float (&v)[16]) {
+    if (UP == 1) {
+        unsigned mask;
+        load16<VEC>(xs_plane + start, cnt, v, mask);
+        return;
+    }
+    const int Ws = W >> 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = (i * 256 + threadIdx.x) * 4;
+        if (e < cnt) {
+            const int o = start + e;
+            const int oy = o / W, ox = o - oy * W;          // W % 4 == 0: the four elements share a row
+            const float2 t = *reinterpret_cast<const float2*>(xs_plane + (size_t)(oy >> 1) * Ws + (ox >> 1));
+            v[4 * i] = t.x; v[4 * i + 1] = t.x; v[4 * i + 2] = t.y; v[4 * i + 3] = t.y;
+        } else {
+            v[4 * i] = v[4 * i + 1] = v[4 * i + 2] = v[4 * i + 3] = 0.f;
+        }
+    }
+}
+
+// y0 = lrelu(xhat (1 + g0) + b0, slope0), y1 = lrelu(xhat (1 + g1) + b1, slope1); gb_k = [N, 2C, HW] (gamma half, then beta half)
+template <int UP>
+__global__ __launch_bounds__(256) void spade_pair_apply_kernel(const float* __restrict__ xs, const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd, const float* __restrict__ gb0,
+                                                               const float* __restrict__ gb1, float* __restrict__ y0,
+                                                               float* __restrict__ y1, int C, int HW, int W, int nchunk, float slope0,
+                                                               float slope1, int Ng) {
+    const int bid = blockIdx.x;
+    const int chunk = bid % nchunk, nc = bid / nchunk;
+    const int n = nc / C, c = nc - n * C;
+    const int gc = (n / Ng) * C + c;
+    const int start = chunk * CHUNK;
+    const int cnt = min(CHUNK, HW - start);
+    const size_t off = (size_t)nc * HW + start;
+    const size_t goff = ((size_t)n * 2 * C + c) * HW + start;
+    const float mu = mean[gc], is = invstd[gc];
+    float v[16], g[16], be[16], o[16];
+    unsigned mask;
+    load16_x<UP, true>(xs + (size_t)nc * (HW / (UP * UP)), start, cnt, W, v);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = (v[i] - mu) * is;
+    load16<true>(gb0 + goff, cnt, g, mask);
+    load16<true>(gb0 + goff + (size_t)C * HW, cnt, be, mask);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[i] = lrelu_f(v[i] * (1.f + g[i]) + be[i], slope0);
+    store16<true>(y0 + off, cnt, o);
+    load16<true>(gb1 + goff, cnt, g, mask);
+    load16<true>(gb1 + goff + (size_t)C * HW, cnt, be, mask);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[i] = lrelu_f(v[i] * (1.f + g[i]) + be[i], slope1);
+    store16<true>(y1 + off, cnt, o);
+}
+
+// per (group, channel, part): 8 sums = for k in {0, 1}: (sum dxhat_k, sum dxhat_k xhat, sum g_k, sum g_k xhat)   (cf. norm_bwd_reduce_kernel)
+template <int UP>
+__global__ __launch_bounds__(256) void spade_pair_bwd_reduce_kernel(const float* __restrict__ dy0, const float* __restrict__ y0,
+                                                                    const float* __restrict__ dy1, const float* __restrict__ y1,
+                                                                    const float* __restrict__ xs, const float* __restrict__ gb0,
+                                                                    const float* __restrict__ gb1, const float* __restrict__ mean,
+                                                                    const float* __restrict__ invstd, float* __restrict__ partial, int Ng,
+                                                                    int C, int HW, int W, int nchunk, float slope0, float slope1) {
+    __shared__ float sh[4];
+    const int bid = blockIdx.x;
+    const int chunk = bid % nchunk, nc = bid / nchunk;
+    const int n = nc / C, c = nc - n * C;
+    const int grp = n / Ng, nl = n - grp * Ng, gc = grp * C + c;
+    const int start = chunk * CHUNK;
+    const int cnt = min(CHUNK, HW - start);
+    const size_t off = (size_t)nc * HW + start;
+    const size_t goff = ((size_t)n * 2 * C + c) * HW + start;
+    const float mu = mean[gc], is = invstd[gc];
+    float xh[16], g[16], t[16];
+    unsigned mask;
+    load16_x<UP, true>(xs + (size_t)nc * (HW / (UP * UP)), start, cnt, W, xh);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) xh[i] = (xh[i] - mu) * is;
+    float out[8];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float* dy = k ? dy1 : dy0;
+        const float* y = k ? y1 : y0;
+        const float* gb = k ? gb1 : gb0;
+        const float slope = k ? slope1 : slope0;
+        load16<true>(dy + off, cnt, g, mask);
+        if (slope != 1.f) {
+            load16<true>(y + off, cnt, t, mask);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) g[i] = t[i] > 0.f ? g[i] : g[i] * slope;
+        }
+        load16<true>(gb + goff, cnt, t, mask);
+        float s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const bool live = (mask >> i) & 1u;             // (xhat of a lane beyond the plane is -mu * is, not 0)
+            const float gi = live ? g[i] : 0.f, xi = live ? xh[i] : 0.f;
+            s3 += gi;
+            s4 += gi * xi;
+            const float d = gi * (1.f + t[i]);
+            s1 += d;
+            s2 += d * xi;
+        }
+        out[4 * k] = block_sum_256(s1, sh);
+        out[4 * k + 1] = block_sum_256(s2, sh);
+        out[4 * k + 2] = block_sum_256(s3, sh);
+        out[4 * k + 3] = block_sum_256(s4, sh);
+    }
+    if (threadIdx.x == 0) {
+        const int nparts = Ng * nchunk;
+        float* o = partial + ((size_t)gc * nparts + (size_t)nl * nchunk + chunk) * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = out[k];
+    }
+}
+// sums[c * width + k] = sum over parts (double accumulate)
+__global__ void multi_sum_finalize_kernel(const float* __restrict__ partial, int C, int nparts, int width, float* __restrict__ sums) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * width) return;
+    const int c = i / width, k = i - c * width;
+    const float* p = partial + (size_t)c * nparts * width + k;
+    double a = 0.0;
+    for (int j = 0; j < nparts; ++j) a += p[(size_t)j * width];
+    sums[i] = (float)a;
+}
+// dgb_k = (g_k xhat | g_k);  dx = invstd * sum_k (g_k (1 + gamma_k) - m1_k - xhat m2_k), for UP = 2 summed over each 2 x 2 replica block
+// and written at the input's own resolution.  UP = 2 needs whole row pairs per chunk: CHUNK % (2 W) == 0 (checked by the launcher).
+template <int UP>
+__global__ __launch_bounds__(256) void spade_pair_bwd_apply_kernel(const float* __restrict__ dy0, const float* __restrict__ y0,
+                                                                   const float* __restrict__ dy1, const float* __restrict__ y1,
+                                                                   const float* __restrict__ xs, const float* __restrict__ gb0,
+                                                                   const float* __restrict__ gb1, const float* __restrict__ mean,
+                                                                   const float* __restrict__ invstd, const float* __restrict__ sums,
+                                                                   float* __restrict__ dxs, float* __restrict__ dgb0,
+                                                                   float* __restrict__ dgb1, int C, int HW, int W, int nchunk,
+                                                                   float inv_count, float slope0, float slope1, int Ng) {
+    __shared__ float2 hsum[UP == 2 ? 1024 : 1];
+    const int bid = blockIdx.x;
+    const int chunk = bid % nchunk, nc = bid / nchunk;
+    const int n = nc / C, c = nc - n * C;
+    const int gc = (n / Ng) * C + c;
+    const int start = chunk * CHUNK;
+    const int cnt = min(CHUNK, HW - start);
+    const size_t off = (size_t)nc * HW + start;
+    const size_t goff = ((size_t)n * 2 * C + c) * HW + start;
+    const float mu = mean[gc], is = invstd[gc];
+    float xh[16], g[16], t[16], acc[16];
+    unsigned mask;
+    load16_x<UP, true>(xs + (size_t)nc * (HW / (UP * UP)), start, cnt, W, xh);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { xh[i] = (xh[i] - mu) * is; acc[i] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float* dy = k ? dy1 : dy0;
+        const float* y = k ? y1 : y0;
+        const float* gb = k ? gb1 : gb0;
+        float* dgb = k ? dgb1 : dgb0;
+        const float slope = k ? slope1 : slope0;
+        const float m1 = sums[8 * gc + 4 * k] * inv_count, m2 = sums[8 * gc + 4 * k + 1] * inv_count;
+        load16<true>(dy + off, cnt, g, mask);
+        if (slope != 1.f) {
+            load16<true>(y + off, cnt, t, mask);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) g[i] = t[i] > 0.f ? g[i] : g[i] * slope;
+        }
+        load16<true>(gb + goff, cnt, t, mask);
+        float dg[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            dg[i] = g[i] * xh[i];
+            acc[i] += g[i] * (1.f + t[i]) - m1 - xh[i] * m2;
+        }
+        store16<true>(dgb + goff, cnt, dg);
+        store16<true>(dgb + goff + (size_t)C * HW, cnt, g);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] *= is;
+    if (UP == 1) {
+        store16<true>(dxs + off, cnt, acc);
+        return;
+    }
+    // 2 x 2 reduction: each float4 holds two horizontal pairs; the vertical partner row is W / 4 float4 slots away (same chunk)
+    const int wq = W >> 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = i * 256 + threadIdx.x;
+        if (UP == 2) hsum[f] = make_float2(acc[4 * i] + acc[4 * i + 1], acc[4 * i + 2] + acc[4 * i + 3]);
+    }
+    __syncthreads();
+    const int Ws = W >> 1;
+    float* dplane = dxs + (size_t)nc * (HW >> 2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = i * 256 + threadIdx.x, e = 4 * f;
+        if (e >= cnt) continue;
+        const int o = start + e;
+        const int oy = o / W, ox = o - oy * W;
+        if (oy & 1) continue;
+        const float2 a = hsum[f], b = hsum[f + wq];
+        *reinterpret_cast<float2*>(dplane + (size_t)(oy >> 1) * Ws + (ox >> 1)) = make_float2(a.x + b.x, a.y + b.y);
+    }
 }
 
 // ---------------------------------------------------------------- instance norm (+LeakyReLU): one workgroup per (n,c) plane
@@ -481,6 +705,77 @@ extern "C" int ag2v_norm_bwd(int mode, const float* dy, const float* y, const fl
                              const float* mean, const float* invstd, float* dx, float* dgamma, float* dbeta, float* sums,
                              int N, int C, int HW, float slope, float* workspace, void* stream) {
     return ag2v_norm_bwd_g(mode, dy, y, x, gamma, w, mean, invstd, dx, dgamma, dbeta, sums, N, C, HW, N, slope, workspace, stream);
+}
+
+// ---- SPADE pair (see the kernels): xs [N, C, H/up, W/up] (up = 1 or 2), gb0 / gb1 [N, 2C, H, W] -> y0 / y1 [N, C, H, W].
+// Supported when W % 4 == 0, 16-byte aligned tensors and, for up = 2, 4096 % (2 W) == 0 and H, W even (ag2v_spade_pair_supported).
+extern "C" int ag2v_spade_pair_supported(int H, int W, int up) {
+    if (up != 1 && up != 2) return 0;
+    if (W % 4 != 0 || ((long long)H * W) % 4 != 0) return 0;
+    if (up == 2 && ((H & 1) || (W & 1) || CHUNK % (2 * W) != 0)) return 0;
+    return 1;
+}
+extern "C" size_t ag2v_spade_pair_workspace_floats(int N, int C, int HW) {
+    const int nchunk = ceil_div(HW, CHUNK);
+    return (size_t)C * N * nchunk * 8;
+}
+// statistics of the (virtually upsampled) input: mean / invstd [N / Ng, C]; both running-stat pairs (nullable) updated per group
+extern "C" int ag2v_spade_pair_stats(const float* xs, int N, int C, int HWs, int Ng, int rep, float eps, float momentum, float* mean,
+                                     float* invstd, float* rm0, float* rv0, float* rm1, float* rv1, float* workspace, void* stream) {
+    if (!xs || !mean || !invstd || !workspace || N <= 0 || C <= 0 || HWs <= 0 || Ng <= 0 || N % Ng != 0 || rep < 1) return AG2V_EINVAL;
+    if ((rm0 == nullptr) != (rv0 == nullptr) || (rm1 == nullptr) != (rv1 == nullptr) || (rm1 && !rm0)) return AG2V_EINVAL;
+    if (N / Ng > FIN_MAXG && rm0) return AG2V_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int nchunk = ceil_div(HWs, CHUNK);
+    const long long nblk = (long long)N * C * nchunk;
+    if (nblk >= (1LL << 31)) return AG2V_EINVAL;
+    if (vec_ok(HWs, xs))
+        hipLaunchKernelGGL(bn_stats_partial_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, st, xs, workspace, Ng, C, HWs, nchunk);
+    else
+        hipLaunchKernelGGL(bn_stats_partial_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, st, xs, workspace, Ng, C, HWs, nchunk);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, st, workspace, N / Ng, C, Ng * nchunk, eps, momentum,
+                       mean, invstd, rm0, rv0, rep, rm1, rv1);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+extern "C" int ag2v_spade_pair_apply(const float* xs, const float* mean, const float* invstd, const float* gb0, const float* gb1, float* y0,
+                                     float* y1, int N, int C, int H, int W, int up, int Ng, float slope0, float slope1, void* stream) {
+    if (!xs || !mean || !invstd || !gb0 || !gb1 || !y0 || !y1 || N <= 0 || C <= 0 || Ng <= 0 || N % Ng != 0) return AG2V_EINVAL;
+    if (!ag2v_spade_pair_supported(H, W, up) || !vec_ok(H * W, xs, gb0, gb1, y0, y1)) return AG2V_EINVAL;
+    const int HW = H * W, nchunk = ceil_div(HW, CHUNK);
+    const long long nblk = (long long)N * C * nchunk;
+    if (nblk >= (1LL << 31)) return AG2V_EINVAL;
+    dim3 g((unsigned)nblk), t(256);
+    if (up == 1) hipLaunchKernelGGL(spade_pair_apply_kernel<1>, g, t, 0, (hipStream_t)stream, xs, mean, invstd, gb0, gb1, y0, y1, C, HW, W, nchunk, slope0, slope1, Ng);
+    else hipLaunchKernelGGL(spade_pair_apply_kernel<2>, g, t, 0, (hipStream_t)stream, xs, mean, invstd, gb0, gb1, y0, y1, C, HW, W, nchunk, slope0, slope1, Ng);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+// sums [N / Ng, C, 8] = per norm k: (sum dxhat_k, sum dxhat_k xhat, sum dbeta_k, sum dgamma_k); dxs [N, C, H/up, W/up]; dgb0 / dgb1 like gb.
+extern "C" int ag2v_spade_pair_bwd(const float* dy0, const float* y0, const float* dy1, const float* y1, const float* xs, const float* gb0,
+                                   const float* gb1, const float* mean, const float* invstd, float* dxs, float* dgb0, float* dgb1,
+                                   float* sums, int N, int C, int H, int W, int up, int Ng, float slope0, float slope1, float* workspace,
+                                   void* stream) {
+    if (!dy0 || !dy1 || !xs || !gb0 || !gb1 || !mean || !invstd || !dxs || !dgb0 || !dgb1 || !sums || !workspace) return AG2V_EINVAL;
+    if (N <= 0 || C <= 0 || Ng <= 0 || N % Ng != 0 || (slope0 != 1.f && !y0) || (slope1 != 1.f && !y1)) return AG2V_EINVAL;
+    if (!ag2v_spade_pair_supported(H, W, up) || !vec_ok(H * W, dy0, dy1, y0, y1, gb0, gb1) || !vec_ok(H * W, dgb0, dgb1, xs, dxs)) return AG2V_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int HW = H * W, nchunk = ceil_div(HW, CHUNK);
+    const long long nblk = (long long)N * C * nchunk;
+    if (nblk >= (1LL << 31)) return AG2V_EINVAL;
+    dim3 g((unsigned)nblk), t(256);
+    const int GC = (N / Ng) * C;
+    const float inv_count = 1.0f / ((float)Ng * (float)HW);
+#define PAIR_BWD(U)                                                                                                                  \
+    hipLaunchKernelGGL(spade_pair_bwd_reduce_kernel<U>, g, t, 0, st, dy0, y0, dy1, y1, xs, gb0, gb1, mean, invstd, workspace, Ng, C, HW, \
+                       W, nchunk, slope0, slope1);                                                                                   \
+    hipLaunchKernelGGL(multi_sum_finalize_kernel, dim3(ceil_div(GC * 8, 64)), dim3(64), 0, st, workspace, GC, Ng* nchunk, 8, sums);  \
+    hipLaunchKernelGGL(spade_pair_bwd_apply_kernel<U>, g, t, 0, st, dy0, y0, dy1, y1, xs, gb0, gb1, mean, invstd, sums, dxs, dgb0, dgb1, \
+                       C, HW, W, nchunk, inv_count, slope0, slope1, Ng);
+    if (up == 1) { PAIR_BWD(1) } else { PAIR_BWD(2) }
+#undef PAIR_BWD
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
 }
 
 extern "C" int ag2v_instnorm_lrelu_fwd(const float* x, float* y, float* mean, float* invstd, int NC, int HW, float eps,

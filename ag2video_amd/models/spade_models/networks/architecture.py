@@ -1,4 +1,6 @@
 """SPADE residual block (reference: networks/architecture.py:21-68)."""
+import os
+
 import torch.nn as nn
 
 from .... import ops
@@ -22,18 +24,34 @@ class SPADEResnetBlock(nn.Module):
         if self.learned_shortcut:
             self.norm_s = SPADE(cfg, fin, opt.semantic_nc)
 
-    def forward(self, x, seg):
+    def forward(self, x, seg, up=1):
+        """up = 2: ``x`` is the block input BEFORE the nn.Upsample(scale_factor=2) that precedes this block in SPADEGenerator
+        (spade_generator.py:62-76); the block then works at twice x's resolution."""
         # norm_0, norm_1 (and norm_s) see the segmentation map at the same resolution (conv_0 keeps the size): their mlp_shared
         # convolutions run as one shared-input group, whose input gradient is accumulated in place (ops.conv2d_shared_input)
         norms = [self.norm_0, self.norm_1] + ([self.norm_s] if self.learned_shortcut else [])
         sh = [m.mlp_shared[0] for m in norms]
-        seg_r = self.norm_0.resized_segmap(x, seg)
+        H, W = x.shape[2] * up, x.shape[3] * up
+        seg_r = seg.at(H, W) if hasattr(seg, 'at') else ops.nearest_resize(seg, H, W)
         actv = ops.conv2d_shared_input(seg_r, [c.weight for c in sh], [c.bias for c in sh], sh[0].stride[0], sh[0].padding[0],
                                        relu=True, grad_premasked=True)
-        x_s = self.conv_s(self.norm_s(x, seg, actv=actv[2])) if self.learned_shortcut else x
-        dx = self.conv_0(self.norm_0(x, seg, slope=0.2, actv=actv[0]))
+        bn0, bns = self.norm_0.param_free_norm, (self.norm_s.param_free_norm if self.learned_shortcut else None)
+        from .... import distributed as D
+        if (self.learned_shortcut and self.training and not D.sync_bn() and ops.spade_pair_supported(H, W, up)
+                and os.environ.get('AG2V_NO_SPADE_PAIR') is None):
+            # norm_0 and norm_s modulate the SAME tensor: one statistics pass, one read of x for both outputs, one summed input
+            # gradient -- and with up = 2 the upsampled tensor never exists (ops.spade_pair)
+            y0, ys = ops.spade_pair(x, self.norm_0.gamma_beta(actv[0]), self.norm_s.gamma_beta(actv[2]), bn0.running_mean,
+                                    bn0.running_var, bns.running_mean, bns.running_var, up, bn0.momentum, bn0.eps, 0.2, 1.0,
+                                    ops.current_frame_groups())
+            x_s = self.conv_s(ys)
+            dx = self.conv_0(y0)
+        else:
+            if up == 2:
+                x = ops.upsample2x(x)
+            x_s = self.conv_s(self.norm_s(x, seg, actv=actv[2])) if self.learned_shortcut else x
+            dx = self.conv_0(self.norm_0(x, seg, slope=0.2, actv=actv[0]))
         return self.conv_1(self.norm_1(dx, seg, slope=0.2, actv=actv[1]), residual=x_s)   # out = x_s + dx fused in the conv epilogue
-
 
 # torchvision.models.vgg19 "features" configuration ('E': 16 conv3x3 + ReLU layers, 'M' = MaxPool2d(2, 2)); the reference pins
 # torchvision 0.5.0 (README.md:23).  Module indices inside ``features`` are what the slices below are named after.

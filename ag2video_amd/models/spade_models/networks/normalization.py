@@ -144,12 +144,14 @@ class SPADE(nn.Module):
             # gamma|beta convolution's data gradient (actv has no other consumer)
             sh = self.mlp_shared[0]
             actv = ops.conv2d(seg, sh.weight, sh.bias, sh.stride[0], sh.padding[0], relu=True, grad_premasked=True)
-        # mlp_gamma and mlp_beta read the same activation: one convolution with 2C output rows (a GEMM with twice the rows
-        # for the same operand traffic, one data gradient instead of two plus their sum), whose output the modulation kernel
-        # reads in place as gamma | beta.  The parameters stay separate (state_dict names of the reference).
+        return self.param_free_norm.modulate_fused(x, self.gamma_beta(actv), slope)
+
+    def gamma_beta(self, actv):
+        """gamma | beta as ONE [N, 2C, H, W] tensor: mlp_gamma and mlp_beta read the same activation, so they run as one convolution
+        with 2C output rows (a GEMM with twice the rows for the same operand traffic, one data gradient instead of two plus their
+        sum) whose output the modulation kernels read in place.  The parameters stay separate (state_dict names of the reference)."""
         w, b = self._fused_gamma_beta()
-        gb = ops.conv2d(actv, w, b, self.mlp_gamma.stride[0], self.mlp_gamma.padding[0], relu_input=True)
-        return self.param_free_norm.modulate_fused(x, gb, slope)
+        return ops.conv2d(actv, w, b, self.mlp_gamma.stride[0], self.mlp_gamma.padding[0], relu_input=True)
 
     def _fused_gamma_beta(self):
         """cat(mlp_gamma, mlp_beta) weights / biases, rebuilt when a parameter changed (optimizer step, load_state_dict) or the

@@ -859,6 +859,70 @@ def spade_norm_fused(x, gb, running_mean, running_var, training=True, momentum=0
                           float(slope), int(groups))
 
 
+def spade_pair_supported(H, W, up):
+    return bool(_lib.query('ag2v_spade_pair_supported', int(H), int(W), int(up)))
+
+
+class _SpadePair(torch.autograd.Function):
+    """(y0, y1) = the two SPADE modulations of ONE input x (batch statistics shared), x read at its resolution before the 2x nearest
+    upsampling when up == 2 (see csrc/norm.hip).  gb0 / gb1: [N, 2C, H, W] gamma | beta tensors; training mode only."""
+
+    @staticmethod
+    def forward(ctx, xs, gb0, gb1, rm0, rv0, rm1, rv1, up, momentum, eps, slope0, slope1, groups):
+        xs, gb0, gb1 = _c(xs), _c(gb0), _c(gb1)
+        _chk(xs, gb0, gb1)
+        N, C, Hs, Ws = xs.shape
+        H, W = Hs * up, Ws * up
+        if tuple(gb0.shape) != (N, 2 * C, H, W) or tuple(gb1.shape) != (N, 2 * C, H, W):
+            raise RuntimeError("spade_pair: gamma|beta tensors must be [N, 2C, H, W] = %s" % ((N, 2 * C, H, W),))
+        if N % groups != 0:
+            raise RuntimeError("spade_pair: %d sample groups do not divide the batch of %d" % (groups, N))
+        Ng = N // groups
+        st = _stream()
+        mean = torch.empty(groups * C, device=xs.device, dtype=torch.float32)
+        invstd = torch.empty(groups * C, device=xs.device, dtype=torch.float32)
+        ws = torch.empty(_lib.query('ag2v_bn_workspace_floats', N, C, Hs * Ws), device=xs.device, dtype=torch.float32)
+        _lib.call('ag2v_spade_pair_stats', _ptr(xs), N, C, Hs * Ws, Ng, up * up, float(eps), float(momentum), _ptr(mean), _ptr(invstd),
+                  _ptr(rm0), _ptr(rv0), _ptr(rm1), _ptr(rv1), _ptr(ws), st)
+        y0 = torch.empty((N, C, H, W), device=xs.device, dtype=torch.float32)
+        y1 = torch.empty_like(y0)
+        # algorithmic bytes: x (at its own resolution) + 4 gamma / beta planes read, 2 outputs written
+        _launch('ag2v_spade_pair_apply', 'spade_pair_apply', (xs.numel() + 6.0 * y0.numel()) * 4, _ptr(xs), _ptr(mean), _ptr(invstd), _ptr(gb0),
+                _ptr(gb1), _ptr(y0), _ptr(y1), N, C, H, W, up, Ng, float(slope0), float(slope1), st, shape=(N, C, H * W, up))
+        ctx.save_for_backward(xs, gb0, gb1, y0 if slope0 != 1.0 else None, y1 if slope1 != 1.0 else None, mean, invstd)
+        ctx.cfg = (up, slope0, slope1, N, C, H, W, Ng)
+        return y0, y1
+
+    @staticmethod
+    def backward(ctx, dy0, dy1):
+        xs, gb0, gb1, y0, y1, mean, invstd = ctx.saved_tensors
+        up, slope0, slope1, N, C, H, W, Ng = ctx.cfg
+        z = None
+        if dy0 is None or dy1 is None:
+            z = torch.zeros((N, C, H, W), device=xs.device, dtype=torch.float32)
+        dy0 = z if dy0 is None else dy0.contiguous()
+        dy1 = z if dy1 is None else dy1.contiguous()
+        G = N // Ng
+        dxs = torch.empty_like(xs)
+        dgb0, dgb1 = torch.empty_like(gb0), torch.empty_like(gb1)
+        sums = torch.empty((G, C, 8), device=xs.device, dtype=torch.float32)
+        ws = torch.empty(_lib.query('ag2v_spade_pair_workspace_floats', N, C, H * W), device=xs.device, dtype=torch.float32)
+        _launch('ag2v_spade_pair_bwd', 'spade_pair_bwd', (2.0 * xs.numel() + xs.numel() + 16.0 * dy0.numel()) * 4, _ptr(dy0), _ptr(y0), _ptr(dy1),
+                _ptr(y1), _ptr(xs), _ptr(gb0), _ptr(gb1), _ptr(mean), _ptr(invstd), _ptr(dxs), _ptr(dgb0), _ptr(dgb1), _ptr(sums), N, C, H, W,
+                up, Ng, float(slope0), float(slope1), _ptr(ws), _stream(), shape=(N, C, H * W, up))
+        tot = sums.sum(dim=0) if G > 1 else sums[0]
+        dgb0._ag2v_channel_sums = torch.cat([tot[:, 3], tot[:, 2]])      # bias gradients of the two gamma | beta convolutions
+        dgb1._ag2v_channel_sums = torch.cat([tot[:, 7], tot[:, 6]])
+        return (dxs, dgb0, dgb1) + (None,) * 10
+
+
+def spade_pair(xs, gb0, gb1, rm0, rv0, rm1, rv1, up=1, momentum=0.1, eps=1e-5, slope0=1.0, slope1=1.0, groups=1):
+    """Two SPADE modulations of one input (shared batch statistics; both running-stat pairs updated), the input optionally taken
+    before its 2x nearest upsampling (up = 2).  Training mode, batch statistics; requires spade_pair_supported(H, W, up)."""
+    return _SpadePair.apply(xs, gb0, gb1, rm0, rv0, rm1, rv1, int(up), float(momentum), float(eps), float(slope0), float(slope1),
+                            int(groups))
+
+
 class _InstNormLReLU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, eps, slope):

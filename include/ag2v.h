@@ -135,6 +135,21 @@ int ag2v_norm_bwd_reduce_g(int mode, const float* dy, const float* y, const floa
 int ag2v_norm_bwd_apply_g(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* w,
                           const float* mean, const float* invstd, const float* sums, float inv_count, float* dx, float* dgamma,
                           float* dbeta, int N, int C, int HW, int Ng, float slope, void* stream);
+/* SPADE pair: the two modulations a SPADEResnetBlock with a learned shortcut applies to ONE input (norm_0 and norm_s,
+ * architecture.py:52-53,60-61) in one pass, the input read at its resolution BEFORE nn.Upsample(scale_factor=2)
+ * (spade_generator.py:62-76; up = 2: element (y, x) is xs[y/2][x/2]; up = 1: no upsampling).  xs [N, C, H/up, W/up]; gb0 / gb1
+ * [N, 2C, H, W] (gamma half, beta half); y0 / y1 [N, C, H, W]; mean / invstd [N / Ng, C]; sums [N / Ng, C, 8]; dxs like xs (both
+ * branches' input gradients summed and reduced over the 2 x 2 replica blocks).  _stats: rep = up * up; both running pairs (nullable)
+ * receive the per-group updates.  ag2v_spade_pair_supported(H, W, up) != 0 is required (W % 4 == 0; up = 2: 4096 % (2 W) == 0). */
+int ag2v_spade_pair_supported(int H, int W, int up);
+size_t ag2v_spade_pair_workspace_floats(int N, int C, int HW);
+int ag2v_spade_pair_stats(const float* xs, int N, int C, int HWs, int Ng, int rep, float eps, float momentum, float* mean, float* invstd,
+                          float* rm0, float* rv0, float* rm1, float* rv1, float* workspace, void* stream);
+int ag2v_spade_pair_apply(const float* xs, const float* mean, const float* invstd, const float* gb0, const float* gb1, float* y0, float* y1,
+                          int N, int C, int H, int W, int up, int Ng, float slope0, float slope1, void* stream);
+int ag2v_spade_pair_bwd(const float* dy0, const float* y0, const float* dy1, const float* y1, const float* xs, const float* gb0,
+                        const float* gb1, const float* mean, const float* invstd, float* dxs, float* dgb0, float* dgb1, float* sums,
+                        int N, int C, int H, int W, int up, int Ng, float slope0, float slope1, float* workspace, void* stream);
 int ag2v_instnorm_lrelu_fwd(const float* x, float* y, float* mean, float* invstd, int NC, int HW, float eps, float slope,
                             void* stream);
 int ag2v_instnorm_lrelu_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,

@@ -107,6 +107,18 @@ def spade_norm_fused(x, gb, running_mean, running_var, training=True, momentum=0
     return spade_norm(x, gb[:, :C], gb[:, C:], running_mean, running_var, training, momentum, eps, slope, groups)
 
 
+def spade_pair(xs, gb0, gb1, rm0, rv0, rm1, rv1, up=1, momentum=0.1, eps=1e-5, slope0=1.0, slope1=1.0, groups=1):
+    """Checker for ops.spade_pair: nn.Upsample(scale_factor=2) (spade_generator.py:62-76) followed by the block's two SPADE layers on
+    the same input (norm_0 / norm_s, architecture.py:52-53,60-61), each with its own running buffers."""
+    x = upsample2x(xs) if up == 2 else xs
+    return (spade_norm_fused(x, gb0, rm0, rv0, True, momentum, eps, slope0, groups),
+            spade_norm_fused(x, gb1, rm1, rv1, True, momentum, eps, slope1, groups))
+
+
+def spade_pair_supported(H, W, up):
+    return True
+
+
 def instnorm_lrelu(x, eps=1e-5, slope=0.2):
     """nn.InstanceNorm2d(affine=False) + LeakyReLU(0.2) (normalization.py:43-44, discriminator.py:374-377)."""
     return F.leaky_relu(F.instance_norm(x, eps=eps), slope)

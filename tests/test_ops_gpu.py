@@ -785,3 +785,29 @@ def test_spade_bias_gradient_from_norm_backward(device):
         res.append((bd.grad, wd.grad, ad.grad, xd.grad))
     for got, ref, nm in zip(res[1], res[0], ('dbias', 'dw', 'da', 'dx')):
         _cmp('spade_chain.' + nm, got, ref)
+
+
+@pytest.mark.parametrize("cfg", [((6, 5, 8, 32), 1, 3), ((4, 3, 8, 16), 2, 2), ((6, 16, 32, 32), 2, 3), ((2, 4, 64, 128), 2, 1),
+                                 ((15, 8, 4, 8), 2, 15), ((3, 2, 80, 64), 2, 1)], ids=str)
+def test_spade_pair(cfg, device):
+    """Two SPADE modulations of one input with shared statistics, the input read before its 2x nearest upsampling (up = 2): outputs,
+    both running-stat pairs, and the gradients (dx summed over both branches and over the 2 x 2 replicas; d gamma|beta per branch)."""
+    from ag2video_amd import ops
+    from oracle import kernels as K
+    (N, C, Hs, Ws), up, G = cfg
+    H, W = Hs * up, Ws * up
+    assert ops.spade_pair_supported(H, W, up)
+    xs = _rand(N, C, Hs, Ws, seed=1) * torch.linspace(0.5, 2.0, N).view(N, 1, 1, 1) + torch.linspace(-1, 1, N).view(N, 1, 1, 1)
+    gb0, gb1 = _rand(N, 2 * C, H, W, seed=2) * 0.3, _rand(N, 2 * C, H, W, seed=3) * 0.3
+    w0, w1 = _rand(N, C, H, W, seed=4), _rand(N, C, H, W, seed=5)
+    res = []
+    for mod, dev in ((K, 'cpu'), (ops, device)):
+        xd, g0, g1 = [t.clone().to(dev).requires_grad_(True) for t in (xs, gb0, gb1)]
+        bufs = [torch.linspace(-0.5, 0.5, C).to(dev), torch.linspace(0.5, 1.5, C).to(dev), torch.zeros(C).to(dev), torch.ones(C).to(dev)]
+        y0, y1 = mod.spade_pair(xd, g0, g1, bufs[0], bufs[1], bufs[2], bufs[3], up, 0.1, 1e-5, 0.2, 1.0, G)
+        ((y0 * w0.to(dev)).sum() + (y1 * w1.to(dev)).sum() * 0.7).backward()
+        res.append([y0, y1, xd.grad, g0.grad, g1.grad] + bufs)
+    names = ('y0', 'y1', 'dx', 'dgb0', 'dgb1', 'rm0', 'rv0', 'rm1', 'rv1')
+    for nm, got, ref in zip(names, res[1], res[0]):
+        _cmp('spade_pair.' + nm, got, ref, 1e-5 if nm.startswith('r') else TOL)
+    assert not ops.spade_pair_supported(224, 224, 2) and ops.spade_pair_supported(224, 224, 1)
