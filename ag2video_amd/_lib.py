@@ -51,6 +51,7 @@ _SIGS = {
     'ag2v_layout_render_fwd': (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [_P]),
     'ag2v_layout_render_bwd': (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [_P]),
     'ag2v_layout_conv_fwd': (c_int, [_P, _P, _P, _P, _P] + [c_int] * 9 + [_P]),
+    'ag2v_layout_conv_img_fwd': (c_int, [_P, _P, _P, _P, _P] + [c_int] * 9 + [_P, _P, _P, c_int, _P]),
     'ag2v_layout_conv_bwd': (c_int, [_P, _P, _P, _P] + [c_int] * 9 + [_P]),
     'ag2v_flow_warp_fwd': (c_int, [_P, _P, _P] + [c_int] * 4 + [_P]),
     'ag2v_flow_warp_bwd': (c_int, [_P, _P, _P, _P, _P] + [c_int] * 4 + [_P]),

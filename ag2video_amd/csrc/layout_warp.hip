@@ -137,11 +137,17 @@ __device__ __forceinline__ void lc_taps_y(float (&tyr)[R], int oy, int stride, i
     }
 }
 
+// img / wimg / iscale (nullable; stride 1, pool 0): the IMAGE channels of the same convolution -- conv_dim_in and down_flow[0] see
+// cat[layouts, frame(s)] (generator.py:66,74,82) -- are added here: out += iscale[n] * conv(img[n, :IC], wimg[K, IC, R, R]).  Their
+// IC * R * R = 27 multiply-adds per output are nothing beside the 16 GB this kernel writes at c3, and the dense launch, its 16 GB
+// output and the read-back of it as `residual` disappear (5.9 + ~3 ms per step).
 template <int R, int KPER>
 __global__ __launch_bounds__(256) void layout_conv_fwd_kernel(const float* __restrict__ U, const float* __restrict__ boxes,
                                                               const int* __restrict__ keep, const float* __restrict__ residual,
                                                               float* __restrict__ out, int J, int K, int H, int W, int Hm, int Wm,
-                                                              int pool, int OH, int OW, int stride, int pad) {
+                                                              int pool, int OH, int OW, int stride, int pad,
+                                                              const float* __restrict__ img, const float* __restrict__ wimg,
+                                                              const float* __restrict__ iscale, int IC) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int oy = blockIdx.x * 4 + wave;
     const int n = blockIdx.y;
@@ -187,6 +193,38 @@ __global__ __launch_bounds__(256) void layout_conv_fwd_kernel(const float* __res
                 acc[kk][q] = (residual && (k0 + kk) < K && ox < OW)
                                  ? residual[(((size_t)n * K + k0 + kk) * OH + oy) * OW + ox] : 0.f;
             }
+        if (img) {      // dense image channels (stride 1, no pooling; vec layout: 4 consecutive pixels per thread)
+            const float sc = iscale ? iscale[n] : 1.f;
+            const int x0i = xq * 4 - pad;
+            for (int c = 0; c < IC; ++c) {
+                const float* ip = img + ((size_t)n * IC + c) * H * W;
+                float iv[R][R + 3];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int yy = oy + r - pad;
+                    const bool rowok = (unsigned)yy < (unsigned)H;
+#pragma unroll
+                    for (int i = 0; i < R + 3; ++i) {
+                        const int xx = x0i + i;
+                        iv[r][i] = (rowok && (unsigned)xx < (unsigned)W) ? ip[yy * W + xx] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int kk = 0; kk < KPER; ++kk) {
+                    if (k0 + kk < K) {
+                        const float* wk = wimg + (((size_t)(k0 + kk) * IC + c) * R) * R;      // wave-uniform: scalar loads
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+#pragma unroll
+                            for (int s2 = 0; s2 < R; ++s2) {
+                                const float wv = wk[r * R + s2] * sc;
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) acc[kk][q] = fmaf(wv, iv[r][s2 + q], acc[kk][q]);
+                            }
+                    }
+                }
+            }
+        }
         for (int j = 0; j < J; ++j) {
             const float* b = boxes + ((size_t)n * J + j) * 4;
             const float x0 = b[0], y0 = b[1], ww = b[2], hh = b[3];
@@ -602,23 +640,32 @@ extern "C" int ag2v_layout_render_bwd(const float* dout, const float* boxes, con
     return AG2V_OK;
 }
 
-extern "C" int ag2v_layout_conv_fwd(const float* U, const float* boxes, const int* keep, const float* residual, float* out,
-                                    int NB, int J, int K, int H, int W, int R, int stride, int pad, int pool, void* stream) {
+extern "C" int ag2v_layout_conv_img_fwd(const float* U, const float* boxes, const int* keep, const float* residual, float* out,
+                                        int NB, int J, int K, int H, int W, int R, int stride, int pad, int pool, const float* img,
+                                        const float* wimg, const float* iscale, int IC, void* stream) {
     if (!U || !boxes || !keep || !out || NB <= 0 || J <= 0 || K <= 0 || H <= 0 || W <= 0 || stride <= 0 || NB > 65535) return AG2V_EINVAL;
     if ((R != 3 && R != 4) || pool < 0 || pool > 1) return AG2V_EINVAL;
     const int Hm = pool ? (H - 1) / 2 + 1 : H, Wm = pool ? (W - 1) / 2 + 1 : W;   // size of the map the convolution sees
     const int OH = (Hm + 2 * pad - R) / stride + 1, OW = (Wm + 2 * pad - R) / stride + 1;
     if (OH <= 0 || OW <= 0) return AG2V_EINVAL;
+    if (img) {      // the fused image channels: same-size stride-1 convolution, 16-byte rows (the kernel's 4-pixel layout)
+        if (!wimg || IC <= 0 || IC > 8 || stride != 1 || pool != 0 || (OW & 3) || OH != H || OW != W) return AG2V_EINVAL;
+    }
     constexpr int KPER = 16;
     dim3 grid(ceil_div(OH, 4), NB, ceil_div(K, KPER));
     if (R == 3)
         hipLaunchKernelGGL((layout_conv_fwd_kernel<3, KPER>), grid, dim3(256), 0, (hipStream_t)stream, U, boxes, keep, residual, out,
-                           J, K, H, W, Hm, Wm, pool, OH, OW, stride, pad);
+                           J, K, H, W, Hm, Wm, pool, OH, OW, stride, pad, img, wimg, iscale, IC);
     else
         hipLaunchKernelGGL((layout_conv_fwd_kernel<4, KPER>), grid, dim3(256), 0, (hipStream_t)stream, U, boxes, keep, residual, out,
-                           J, K, H, W, Hm, Wm, pool, OH, OW, stride, pad);
+                           J, K, H, W, Hm, Wm, pool, OH, OW, stride, pad, img, wimg, iscale, IC);
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
+}
+extern "C" int ag2v_layout_conv_fwd(const float* U, const float* boxes, const int* keep, const float* residual, float* out,
+                                    int NB, int J, int K, int H, int W, int R, int stride, int pad, int pool, void* stream) {
+    return ag2v_layout_conv_img_fwd(U, boxes, keep, residual, out, NB, J, K, H, W, R, stride, pad, pool, nullptr, nullptr, nullptr, 0,
+                                    stream);
 }
 
 extern "C" int ag2v_layout_conv_bwd(const float* dout, const float* boxes, const int* keep, float* dU, int NB, int J, int K, int H,

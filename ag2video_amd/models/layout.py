@@ -30,7 +30,8 @@ def render_clip_layouts(vecs, boxes, objs, vocab, H, W, frame_major=True):
     return list(out.view(Fr, B, D, H, W).unbind(0))
 
 
-def layout_conv_lowrank(weight, vecs_list, boxes_list, keep, H, W, stride=1, pad=1, residual=None, pool=0, sample_scale=None):
+def layout_conv_lowrank(weight, vecs_list, boxes_list, keep, H, W, stride=1, pad=1, residual=None, pool=0, sample_scale=None,
+                        img=None, w_img=None, gscale=None):
     """conv2d(concat_f layout_f, weight) WITHOUT materialising the layouts.
 
     A layout is a sum over objects of (vector) x (separable box weight map) (boxes_to_layout, models/layout.py:28-63), so a
@@ -39,7 +40,9 @@ def layout_conv_lowrank(weight, vecs_list, boxes_list, keep, H, W, stride=1, pad
     generator.py:66); vecs_list: n_frames tensors [B, O, D]; boxes_list: n_frames tensors [B, O, 4]; keep [B, O].
     Gradients reach ``weight`` and the vectors through the small GEMM; boxes get none (ground truth / detached).
     sample_scale [B] (optional): the layout term of sample b is multiplied by sample_scale[b] (spectral norm's 1/sigma of that
-    sample's frame group when ``weight`` is the raw weight_orig: the term is linear in the filter)."""
+    sample's frame group when ``weight`` is the raw weight_orig: the term is linear in the filter).
+    img [B, IC, H, W] + w_img [K, IC, R, R] (+ gscale [G]): the IMAGE channels of the same convolution, evaluated in the same launch
+    (ops.layout_conv_img; stride 1) instead of a dense launch whose output is then read back as ``residual``."""
     K, R = weight.shape[0], weight.shape[2]
     B, O, D = vecs_list[0].shape
     Us = []
@@ -51,4 +54,9 @@ def layout_conv_lowrank(weight, vecs_list, boxes_list, keep, H, W, stride=1, pad
         U = U * sample_scale.view(B, 1, 1, 1)
     boxes = torch.cat(list(boxes_list), dim=1)
     keep_all = keep.to(torch.int32).repeat(1, len(vecs_list))
+    if img is not None:
+        if residual is None and ops.layout_conv_img_supported(H, W, R, stride, pool, img.shape[1]):
+            return ops.layout_conv_img(U, boxes, keep_all, H, W, R, pad, img, w_img, gscale)
+        y = ops.conv2d(img, w_img, None, stride, pad, gscale=gscale)
+        residual = y if residual is None else residual + y
     return ops.layout_conv(U, boxes, keep_all, H, W, R, stride, pad, residual, pool)

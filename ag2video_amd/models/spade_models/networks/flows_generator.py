@@ -77,9 +77,8 @@ class FlowsGenerator(nn.Module):
                     else:
                         w, scales, per_sample = conv.effective_weight(), None, None
                     nseg = w.shape[1] - prev.shape[1]
-                    y = ops.conv2d(prev, w[:, nseg:], None, conv.stride, conv.padding, gscale=scales)
-                    y = layout_conv_lowrank(w[:, :nseg], vecs_list, boxes_list, keep, H, H, conv.stride, conv.padding, residual=y,
-                                            sample_scale=per_sample)
+                    y = layout_conv_lowrank(w[:, :nseg], vecs_list, boxes_list, keep, H, H, conv.stride, conv.padding,
+                                            sample_scale=per_sample, img=prev, w_img=w[:, nseg:], gscale=scales)
                     x = bn(y, slope=0.2)
                 else:
                     x = self._conv_bn_act(m, x)

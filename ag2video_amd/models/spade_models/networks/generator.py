@@ -93,9 +93,9 @@ class Layout2VidGenerator(nn.Module):
             with ops.bf16x3_min_rows(48):
                 w, scales = conv.weight_and_scales()
                 nseg = w.shape[1] - 3
-                y = ops.conv2d(warp, w[:, nseg:], None, conv.stride, conv.padding, gscale=scales)
-                y = layout_conv_lowrank(w[:, :nseg], vecs_list, boxes_list, keep_t, H, H, conv.stride, conv.padding, residual=y,
-                                        sample_scale=scales.repeat_interleave((T * B) // scales.numel()))
+                y = layout_conv_lowrank(w[:, :nseg], vecs_list, boxes_list, keep_t, H, H, conv.stride, conv.padding,
+                                        sample_scale=scales.repeat_interleave((T * B) // scales.numel()),
+                                        img=warp, w_img=w[:, nseg:], gscale=scales)
                 x = bn(y, slope=0.2)
                 out = self.netG(x) + warp
         out = out.view(T, B, out.size(1), H, H)
@@ -139,8 +139,8 @@ class Layout2VidGenerator(nn.Module):
                 if low_rank:
                     w = conv.effective_weight()
                     nseg = w.shape[1] - 3
-                    y = ops.conv2d(warp, w[:, nseg:], None, conv.stride, conv.padding)
-                    y = layout_conv_lowrank(w[:, :nseg], spec[0], spec[1], keep, H, H, conv.stride, conv.padding, residual=y)
+                    y = layout_conv_lowrank(w[:, :nseg], spec[0], spec[1], keep, H, H, conv.stride, conv.padding,
+                                            img=warp, w_img=w[:, nseg:])
                 else:
                     y = conv(torch.cat(seg_t + [warp], dim=1))
                 x = bn(y, slope=0.2)

@@ -1024,6 +1024,74 @@ def layout_conv(U, boxes, keep, H, W, R=3, stride=1, pad=1, residual=None, pool=
     return _LayoutConv.apply(U, boxes, keep, residual, int(H), int(W), int(R), int(stride), int(pad), int(pool))
 
 
+class _LayoutConvImg(torch.autograd.Function):
+    """layout_conv plus the image channels of the same convolution in ONE forward launch:
+    out = layout_conv(U) + gscale[group(n)] * conv(img, w_img)   (stride 1, same size).  The backward of the image part is a plain
+    convolution's (few-channel data gradient, per-group weight gradients + ag2v_sn_group_combine when gscale is given)."""
+
+    @staticmethod
+    def forward(ctx, U, boxes, keep, img, w_img, gscale, H, W, R, pad):
+        w_in = w_img
+        U, boxes, img, w_img, gscale = _c(U), _c(boxes), _c(img), _c(w_img), _c(gscale)
+        _chk(U, boxes, img, w_img, gscale)
+        keep = keep.to(torch.int32).contiguous()
+        NB, J, K, RS = U.shape
+        IC = img.shape[1]
+        if RS != R * R or tuple(w_img.shape) != (K, IC, R, R) or tuple(img.shape) != (NB, IC, H, W):
+            raise RuntimeError("layout_conv_img: inconsistent shapes")
+        group_n, iscale = 1, None
+        if gscale is not None:
+            group_n = NB // gscale.numel()
+            iscale = gscale.repeat_interleave(group_n) if group_n > 1 else gscale
+        out = torch.empty((NB, K, H, W), device=U.device, dtype=torch.float32)
+        _lib.call('ag2v_layout_conv_img_fwd', _ptr(U), _ptr(boxes), _ptr(keep), None, _ptr(out), NB, J, K, H, W, R, 1, pad, 0,
+                  _ptr(img), _ptr(w_img), _ptr(iscale), IC, _stream())
+        ctx.save_for_backward(boxes, keep, img, w_img, gscale)
+        ctx.cfg = (NB, J, K, H, W, R, pad, group_n, _current_min_rows()[1])
+        ctx.wkey = _wsink_register(w_in) if ctx.needs_input_grad[4] else None
+        ctx.w_alive = w_in
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        boxes, keep, img, w_img, gscale = ctx.saved_tensors
+        NB, J, K, H, W, R, pad, group_n, mr = ctx.cfg
+        dout = dout.contiguous()
+        st = _stream()
+        dU = dimg = dw = dgs = None
+        if ctx.needs_input_grad[0]:
+            dU = torch.empty((NB, J, K, R * R), device=dout.device, dtype=torch.float32)
+            _lib.call('ag2v_layout_conv_bwd', _ptr(dout), _ptr(boxes), _ptr(keep), _ptr(dU), NB, J, K, H, W, R, 1, pad, 0, st)
+        if ctx.needs_input_grad[3]:
+            dimg = torch.empty_like(img)
+            _conv_dgrad_launch(mr, dout, w_img, None, dimg, 1, pad, 0, gscale, group_n)
+        if gscale is not None and (ctx.needs_input_grad[4] or ctx.needs_input_grad[5]):
+            T = gscale.numel()
+            G = torch.empty((T,) + tuple(w_img.shape), device=dout.device, dtype=torch.float32)
+            _conv_wgrad_launch(mr, dout, img, G, K, R, R, 1, pad, 0, groups=T)
+            buf, acc, dw = _wsink_take(ctx.wkey, w_img) if ctx.needs_input_grad[4] else (torch.empty_like(w_img), 0, None)
+            dgs = torch.empty(T, device=dout.device, dtype=torch.float32)
+            _lib.call('ag2v_sn_group_combine', _ptr(G), _ptr(w_img), _ptr(gscale), T, w_img.numel(), _ptr(buf), acc, _ptr(dgs), st)
+            if not ctx.needs_input_grad[5]:
+                dgs = None
+        elif ctx.needs_input_grad[4]:
+            buf, acc, dw = _wsink_take(ctx.wkey, w_img)
+            _conv_wgrad_launch(mr, dout, img, buf, K, R, R, 1, pad, acc)
+        return dU, None, None, dimg, dw, dgs, None, None, None, None
+
+
+def layout_conv_img_supported(H, W, R, stride, pool, IC):
+    return stride == 1 and pool == 0 and W % 4 == 0 and 0 < IC <= 8 and R in (3, 4) and os.environ.get('AG2V_NO_LAYOUT_IMG') is None
+
+
+def layout_conv_img(U, boxes, keep, H, W, R, pad, img, w_img, gscale=None):
+    """layout_conv(U, ...) + gscale-scaled conv2d(img, w_img) (stride 1, same-size) in one launch: the layout channels and the image
+    channels of conv_dim_in / down_flow[0] (generator.py:66,74,82-83).  2 * pad must equal R - 1."""
+    if 2 * pad != R - 1:
+        raise RuntimeError("layout_conv_img: same-size convolutions only (2 * pad == R - 1)")
+    return _LayoutConvImg.apply(U, boxes, keep, img, w_img, gscale, int(H), int(W), int(R), int(pad))
+
+
 class _FlowWarp(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img, flow):

@@ -173,6 +173,16 @@ def layout_conv(U, boxes, keep, H, W, R=3, stride=1, pad=1, residual=None, pool=
     return y if residual is None else y + residual
 
 
+def layout_conv_img(U, boxes, keep, H, W, R, pad, img, w_img, gscale=None):
+    """Checker for ops.layout_conv_img: the layout channels (layout_conv above) and the image channels (a plain convolution, scaled per
+    sample group) of the convolution the reference applies to cat[layouts, frame(s)] (generator.py:66,74,82-83)."""
+    return layout_conv(U, boxes, keep, H, W, R, 1, pad, conv2d(img, w_img, None, 1, pad, gscale=gscale), 0)
+
+
+def layout_conv_img_supported(H, W, R, stride, pool, IC):
+    return stride == 1 and pool == 0
+
+
 def flow_warp(img, flow):
     """resample + get_grid (models/utils.py:113-140), ALIGN_CORNERS=False (data/args.py:228)."""
     b, c, h, w = img.shape

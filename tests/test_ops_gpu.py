@@ -811,3 +811,21 @@ def test_spade_pair(cfg, device):
     for nm, got, ref in zip(names, res[1], res[0]):
         _cmp('spade_pair.' + nm, got, ref, 1e-5 if nm.startswith('r') else TOL)
     assert not ops.spade_pair_supported(224, 224, 2) and ops.spade_pair_supported(224, 224, 1)
+
+
+@pytest.mark.parametrize("cfg", [(4, 5, 24, 16, 16, 3, 2), (6, 4, 40, 12, 20, 3, 3), (2, 3, 16, 8, 8, 3, None)], ids=str)
+def test_layout_conv_img(cfg, device):
+    """Layout channels (low rank) + image channels (dense, scaled per sample group) of one convolution in one launch; gradients to the
+    taps U, the image, the image filter and the group scales."""
+    from ag2video_amd import ops
+    from oracle import kernels as K
+    NB, J, Kc, H, W, R, G = cfg
+    boxes = _boxes(NB, J, 21)
+    boxes[0, 1] = 0.0
+    keep = torch.ones(NB, J, dtype=torch.int32)
+    keep[:, J - 1] = 0
+    t = {'U': _rand(NB, J, Kc, R * R, seed=22), 'boxes': boxes, 'keep': keep, 'H': H, 'W': W, 'R': R, 'pad': 1,
+         'img': _rand(NB, 3, H, W, seed=23), 'w_img': _rand(Kc, 3, R, R, seed=24, scale=0.2),
+         'gscale': None if G is None else torch.linspace(0.6, 1.5, G)}
+    assert ops.layout_conv_img_supported(H, W, R, 1, 0, 3)
+    _run_pair(ops.layout_conv_img, K.layout_conv_img, t, device, nondiff=('boxes',), name='layout_conv_img')
