@@ -137,7 +137,7 @@ __device__ __forceinline__ void lc_taps_y(float (&tyr)[R], int oy, int stride, i
     }
 }
 
-// img / wimg / iscale (nullable; stride 1, pool 0): the IMAGE channels of the same convolution -- conv_dim_in and down_flow[0] see
+// img / wimg (tap-major [IC*R*R][K]) / iscale (nullable; stride 1, pool 0): the IMAGE channels of the same convolution -- conv_dim_in and down_flow[0] see
 // cat[layouts, frame(s)] (generator.py:66,74,82) -- are added here: out += iscale[n] * conv(img[n, :IC], wimg[K, IC, R, R]).  Their
 // IC * R * R = 27 multiply-adds per output are nothing beside the 16 GB this kernel writes at c3, and the dense launch, its 16 GB
 // output and the read-back of it as `residual` disappear (5.9 + ~3 ms per step).
@@ -194,8 +194,11 @@ __global__ __launch_bounds__(256) void layout_conv_fwd_kernel(const float* __res
                                  ? residual[(((size_t)n * K + k0 + kk) * OH + oy) * OW + ox] : 0.f;
             }
         if (img) {      // dense image channels (stride 1, no pooling; vec layout: 4 consecutive pixels per thread)
+            // wimg is TAP-MAJOR here, [IC * R * R][K]: the KPER filters of a tap are KPER consecutive floats at a wave-uniform address
+            // (four scalar 16-byte loads per tap instead of one dependent scalar load per multiply-add)
             const float sc = iscale ? iscale[n] : 1.f;
             const int x0i = xq * 4 - pad;
+            const bool kfull = (k0 + KPER <= K) && ((K & 3) == 0);
             for (int c = 0; c < IC; ++c) {
                 const float* ip = img + ((size_t)n * IC + c) * H * W;
                 float iv[R][R + 3];
@@ -206,23 +209,30 @@ __global__ __launch_bounds__(256) void layout_conv_fwd_kernel(const float* __res
 #pragma unroll
                     for (int i = 0; i < R + 3; ++i) {
                         const int xx = x0i + i;
-                        iv[r][i] = (rowok && (unsigned)xx < (unsigned)W) ? ip[yy * W + xx] : 0.f;
+                        iv[r][i] = (rowok && (unsigned)xx < (unsigned)W) ? ip[yy * W + xx] * sc : 0.f;
                     }
                 }
 #pragma unroll
-                for (int kk = 0; kk < KPER; ++kk) {
-                    if (k0 + kk < K) {
-                        const float* wk = wimg + (((size_t)(k0 + kk) * IC + c) * R) * R;      // wave-uniform: scalar loads
+                for (int r = 0; r < R; ++r)
 #pragma unroll
-                        for (int r = 0; r < R; ++r)
+                    for (int s2 = 0; s2 < R; ++s2) {
+                        const float* wt = wimg + ((size_t)(c * R + r) * R + s2) * K + k0;
+                        float wv[KPER];
+                        if (kfull) {
 #pragma unroll
-                            for (int s2 = 0; s2 < R; ++s2) {
-                                const float wv = wk[r * R + s2] * sc;
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) acc[kk][q] = fmaf(wv, iv[r][s2 + q], acc[kk][q]);
+                            for (int kk = 0; kk < KPER; kk += 4) {
+                                const float4 t4 = *reinterpret_cast<const float4*>(wt + kk);
+                                wv[kk] = t4.x; wv[kk + 1] = t4.y; wv[kk + 2] = t4.z; wv[kk + 3] = t4.w;
                             }
+                        } else {
+#pragma unroll
+                            for (int kk = 0; kk < KPER; ++kk) wv[kk] = (k0 + kk < K) ? wt[kk] : 0.f;
+                        }
+#pragma unroll
+                        for (int kk = 0; kk < KPER; ++kk)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) acc[kk][q] = fmaf(wv[kk], iv[r][s2 + q], acc[kk][q]);
                     }
-                }
             }
         }
         for (int j = 0; j < J; ++j) {
