@@ -137,14 +137,12 @@ __device__ __forceinline__ void lc_taps_y(float (&tyr)[R], int oy, int stride, i
     }
 }
 
-// img / wimg (tap-major [IC*R*R][K]) / iscale (nullable; stride 1, pool 0): the IMAGE channels of the same convolution -- conv_dim_in and down_flow[0] see
+// img / wimg / iscale (nullable; stride 1, pool 0): the IMAGE channels of the same convolution -- conv_dim_in and down_flow[0] see
 // cat[layouts, frame(s)] (generator.py:66,74,82) -- are added here: out += iscale[n] * conv(img[n, :IC], wimg[K, IC, R, R]).  Their
 // IC * R * R = 27 multiply-adds per output are nothing beside the 16 GB this kernel writes at c3, and the dense launch, its 16 GB
 // output and the read-back of it as `residual` disappear (5.9 + ~3 ms per step).
-// FAST: J <= TJ objects, map width <= TW and J * R <= 128 (every configuration of the path): the profile table, the LDS taps and the
-// lane-held row taps are unconditional and the general fallbacks (kept for other sizes) are compiled out of the hot instantiation.
-template <int R, int KPER, bool FAST>
-__global__ __launch_bounds__(256, 3) void layout_conv_fwd_kernel(const float* __restrict__ U, const float* __restrict__ boxes,
+template <int R, int KPER>
+__global__ __launch_bounds__(256) void layout_conv_fwd_kernel(const float* __restrict__ U, const float* __restrict__ boxes,
                                                               const int* __restrict__ keep, const float* __restrict__ residual,
                                                               float* __restrict__ out, int J, int K, int H, int W, int Hm, int Wm,
                                                               int pool, int OH, int OW, int stride, int pad,
@@ -156,28 +154,11 @@ __global__ __launch_bounds__(256, 3) void layout_conv_fwd_kernel(const float* __
     const int k0 = blockIdx.z * KPER;
     // column profiles tx_j(x) of every object of this image, evaluated once per workgroup (the pooled profile costs three
     // tau8 evaluations per value and every output pixel needs R of them per object)
-    // TJ: two frames of up to 11 CATER objects + the image row = 22 (with 16 the c3 clips fell off the table path and evaluated
-    // every profile value per output pixel and object: 16 ms for a launch whose HBM traffic takes 6)
+    // TJ: two frames of up to 11 CATER objects + the image row = 22 objects (with TJ = 16 the c3 clips fell off the table path and
+    // evaluated every profile value per output pixel and object)
     constexpr int TJ = 24, TW = 264;
     __shared__ float txp[TJ][TW];
-    // this block's taps U[n, j, k0 .. k0 + KPER, :] as [j][tap][kk]: a tap's KPER values are four broadcast 16-byte LDS reads (read as
-    // wave-uniform global scalars they were 144 live SGPRs per object: spills)
-    __shared__ __attribute__((aligned(16))) float usm[TJ][R * R][KPER];
-    const bool ustaged = FAST || (J <= TJ);
-    if (ustaged) {
-        for (int idx = threadIdx.x; idx < J * R * R * KPER; idx += 256) {
-            const int kk = idx % KPER, t = (idx / KPER) % (R * R), j = idx / (KPER * R * R);
-            usm[j][t][kk] = (k0 + kk < K) ? U[(((size_t)n * J + j) * K + k0 + kk) * (R * R) + t] : 0.f;
-        }
-    }
-    __shared__ __attribute__((aligned(16))) float wsm[8 * R * R][KPER];     // this block's image filters, tap-major (img != null)
-    if (img) {
-        for (int idx = threadIdx.x; idx < IC * R * R * KPER; idx += 256) {
-            const int tap = idx / KPER, kk = idx - tap * KPER;
-            wsm[tap][kk] = (k0 + kk < K) ? wimg[(size_t)tap * K + k0 + kk] : 0.f;
-        }
-    }
-    const bool tabled = FAST || ((J <= TJ) && (Wm <= TW));
+    const bool tabled = (J <= TJ) && (Wm <= TW);
     if (tabled) {
         for (int idx = threadIdx.x; idx < J * Wm; idx += 256) {
             const int j = idx / Wm, xx = idx - j * Wm;
@@ -189,7 +170,7 @@ __global__ __launch_bounds__(256, 3) void layout_conv_fwd_kernel(const float* __
     if (oy >= OH) return;
     // row taps ty_j(oy * stride + r - pad) of every object, one (j, r) per lane, read back with readlane in the object loop:
     // evaluated redundantly by all 64 lanes for all J objects they cost more than the FMAs of the 2-3 objects a row touches
-    const bool lane_taps = FAST || (J * R <= 128);
+    const bool lane_taps = J * R <= 128;
     float my_ty[2] = {0.f, 0.f};          // tap index t = j * R + r lives in lane t & 63, register t >> 6
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -219,8 +200,6 @@ __global__ __launch_bounds__(256, 3) void layout_conv_fwd_kernel(const float* __
                                  ? residual[(((size_t)n * K + k0 + kk) * OH + oy) * OW + ox] : 0.f;
             }
         if (img) {      // dense image channels (stride 1, no pooling; vec layout: 4 consecutive pixels per thread)
-            // wimg is TAP-MAJOR here, [IC * R * R][K]: the KPER filters of a tap are KPER consecutive floats at a wave-uniform address
-            // (four scalar 16-byte loads per tap instead of one dependent scalar load per multiply-add)
             const float sc = iscale ? iscale[n] : 1.f;
             const int x0i = xq * 4 - pad;
             for (int c = 0; c < IC; ++c) {
@@ -233,28 +212,23 @@ __global__ __launch_bounds__(256, 3) void layout_conv_fwd_kernel(const float* __
 #pragma unroll
                     for (int i = 0; i < R + 3; ++i) {
                         const int xx = x0i + i;
-                        iv[r][i] = (rowok && (unsigned)xx < (unsigned)W) ? ip[yy * W + xx] * sc : 0.f;
+                        iv[r][i] = (rowok && (unsigned)xx < (unsigned)W) ? ip[yy * W + xx] : 0.f;
                     }
                 }
 #pragma unroll
-                for (int r = 0; r < R; ++r)
+                for (int kk = 0; kk < KPER; ++kk) {
+                    if (k0 + kk < K) {
+                        const float* wk = wimg + (((size_t)(k0 + kk) * IC + c) * R) * R;      // wave-uniform: scalar loads
 #pragma unroll
-                    for (int s2 = 0; s2 < R; ++s2) {
-                        // the tap's KPER filters from LDS (same address in every lane: broadcast reads), 16 live registers per tap
-                        // (as wave-uniform global loads they became 144 live SGPRs per channel: 1 300 spills, 2 waves per SIMD)
-                        const float4* w4 = reinterpret_cast<const float4*>(&wsm[(c * R + r) * R + s2][0]);
-                        float wv[KPER];
+                        for (int r = 0; r < R; ++r)
 #pragma unroll
-                        for (int kk = 0; kk < KPER; kk += 4) {
-                            const float4 t4 = w4[kk >> 2];
-                            wv[kk] = t4.x; wv[kk + 1] = t4.y; wv[kk + 2] = t4.z; wv[kk + 3] = t4.w;
-                        }
+                            for (int s2 = 0; s2 < R; ++s2) {
+                                const float wv = wk[r * R + s2] * sc;
 #pragma unroll
-                        for (int kk = 0; kk < KPER; ++kk)
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) acc[kk][q] = fmaf(wv[kk], iv[r][s2 + q], acc[kk][q]);
-                        __builtin_amdgcn_sched_barrier(0);      // one tap's filters live at a time (the scheduler hoisted all 27 x 16)
+                                for (int q = 0; q < 4; ++q) acc[kk][q] = fmaf(wv, iv[r][s2 + q], acc[kk][q]);
+                            }
                     }
+                }
             }
         }
         for (int j = 0; j < J; ++j) {
@@ -287,30 +261,6 @@ __global__ __launch_bounds__(256, 3) void layout_conv_fwd_kernel(const float* __
                     txsum += fabsf(txs[s][q]);
                 }
             if (__ballot(txsum != 0.f) == 0ull) continue;
-            if (ustaged) {
-#pragma unroll
-                for (int s = 0; s < R; ++s) {
-                    float cs[KPER];         // column-tap coefficient of every channel: sum_r ty(r) U[.., r, s]
-#pragma unroll
-                    for (int kk = 0; kk < KPER; ++kk) cs[kk] = 0.f;
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const float4* u4 = reinterpret_cast<const float4*>(&usm[j][r * R + s][0]);
-#pragma unroll
-                        for (int kk = 0; kk < KPER; kk += 4) {
-                            const float4 t4 = u4[kk >> 2];
-                            cs[kk] = fmaf(tyr[r], t4.x, cs[kk]); cs[kk + 1] = fmaf(tyr[r], t4.y, cs[kk + 1]);
-                            cs[kk + 2] = fmaf(tyr[r], t4.z, cs[kk + 2]); cs[kk + 3] = fmaf(tyr[r], t4.w, cs[kk + 3]);
-                        }
-                    }
-#pragma unroll
-                    for (int kk = 0; kk < KPER; ++kk)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) acc[kk][q] = fmaf(cs[kk], txs[s][q], acc[kk][q]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                continue;
-            }
             const float* uj = U + (((size_t)n * J + j) * K + k0) * (R * R);
 #pragma unroll
             for (int kk = 0; kk < KPER; ++kk) {
@@ -711,13 +661,12 @@ extern "C" int ag2v_layout_conv_img_fwd(const float* U, const float* boxes, cons
     }
     constexpr int KPER = 16;
     dim3 grid(ceil_div(OH, 4), NB, ceil_div(K, KPER));
-    const bool fast = J <= 24 && Wm <= 264 && J * R <= 128;
-#define LC_LAUNCH(RR, FF)                                                                                                            \
-    hipLaunchKernelGGL((layout_conv_fwd_kernel<RR, KPER, FF>), grid, dim3(256), 0, (hipStream_t)stream, U, boxes, keep, residual, out, \
-                       J, K, H, W, Hm, Wm, pool, OH, OW, stride, pad, img, wimg, iscale, IC)
-    if (R == 3) { if (fast) LC_LAUNCH(3, true); else LC_LAUNCH(3, false); }
-    else { if (fast) LC_LAUNCH(4, true); else LC_LAUNCH(4, false); }
-#undef LC_LAUNCH
+    if (R == 3)
+        hipLaunchKernelGGL((layout_conv_fwd_kernel<3, KPER>), grid, dim3(256), 0, (hipStream_t)stream, U, boxes, keep, residual, out,
+                           J, K, H, W, Hm, Wm, pool, OH, OW, stride, pad, img, wimg, iscale, IC);
+    else
+        hipLaunchKernelGGL((layout_conv_fwd_kernel<4, KPER>), grid, dim3(256), 0, (hipStream_t)stream, U, boxes, keep, residual, out,
+                           J, K, H, W, Hm, Wm, pool, OH, OW, stride, pad, img, wimg, iscale, IC);
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
 }

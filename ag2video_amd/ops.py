@@ -1044,9 +1044,8 @@ class _LayoutConvImg(torch.autograd.Function):
             group_n = NB // gscale.numel()
             iscale = gscale.repeat_interleave(group_n) if group_n > 1 else gscale
         out = torch.empty((NB, K, H, W), device=U.device, dtype=torch.float32)
-        w_tap = w_img.permute(1, 2, 3, 0).contiguous()          # tap-major [IC, R, R, K]: a tap's filters are consecutive (kernel: scalar 16-byte loads)
         _lib.call('ag2v_layout_conv_img_fwd', _ptr(U), _ptr(boxes), _ptr(keep), None, _ptr(out), NB, J, K, H, W, R, 1, pad, 0,
-                  _ptr(img), _ptr(w_tap), _ptr(iscale), IC, _stream())
+                  _ptr(img), _ptr(w_img), _ptr(iscale), IC, _stream())
         ctx.save_for_backward(boxes, keep, img, w_img, gscale)
         ctx.cfg = (NB, J, K, H, W, R, pad, group_n, _current_min_rows()[1])
         ctx.wkey = _wsink_register(w_in) if ctx.needs_input_grad[4] else None

@@ -169,8 +169,8 @@ int ag2v_layout_render_bwd(const float* dout, const float* boxes, const int* kee
 int ag2v_layout_conv_fwd(const float* U, const float* boxes, const int* keep, const float* residual /*nullable*/, float* out,
                          int NB, int J, int K, int H, int W, int R, int stride, int pad, int pool, void* stream);
 /* ag2v_layout_conv_fwd plus the IMAGE channels of the same convolution (the reference convolves cat[layouts, frame(s)],
- * generator.py:66,74,82-83): out += iscale[n] * conv(img[n, :IC], w), the filter passed TAP-MAJOR: wimg[IC, R, R, K] = w[K, IC, R, R]
- * permuted (iscale nullable; stride 1, pool 0, same-size convolution, OW % 4 == 0, IC <= 8).  Their gradients are those of a plain convolution (ag2v_conv2d_dgrad_ex / _wgrad_ex on img). */
+ * generator.py:66,74,82-83): out += iscale[n] * conv(img[n, :IC], wimg[K, IC, R, R]) (iscale nullable; stride 1, pool 0, same-size
+ * convolution, OW % 4 == 0, IC <= 8).  Their gradients are those of a plain convolution (ag2v_conv2d_dgrad_ex / _wgrad_ex on img). */
 int ag2v_layout_conv_img_fwd(const float* U, const float* boxes, const int* keep, const float* residual /*nullable*/, float* out,
                              int NB, int J, int K, int H, int W, int R, int stride, int pad, int pool, const float* img,
                              const float* wimg, const float* iscale /*nullable*/, int IC, void* stream);
