@@ -154,9 +154,7 @@ __global__ __launch_bounds__(256) void layout_conv_fwd_kernel(const float* __res
     const int k0 = blockIdx.z * KPER;
     // column profiles tx_j(x) of every object of this image, evaluated once per workgroup (the pooled profile costs three
     // tau8 evaluations per value and every output pixel needs R of them per object)
-    // TJ: two frames of up to 11 CATER objects + the image row = 22 objects (with TJ = 16 the c3 clips fell off the table path and
-    // evaluated every profile value per output pixel and object)
-    constexpr int TJ = 24, TW = 264;
+    constexpr int TJ = 16, TW = 264;
     __shared__ float txp[TJ][TW];
     const bool tabled = (J <= TJ) && (Wm <= TW);
     if (tabled) {
@@ -170,19 +168,15 @@ __global__ __launch_bounds__(256) void layout_conv_fwd_kernel(const float* __res
     if (oy >= OH) return;
     // row taps ty_j(oy * stride + r - pad) of every object, one (j, r) per lane, read back with readlane in the object loop:
     // evaluated redundantly by all 64 lanes for all J objects they cost more than the FMAs of the 2-3 objects a row touches
-    const bool lane_taps = J * R <= 128;
-    float my_ty[2] = {0.f, 0.f};          // tap index t = j * R + r lives in lane t & 63, register t >> 6
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int t = lane + 64 * h;
-        if (lane_taps && t < J * R) {
-            const int jj = t / R, rr = t - jj * R;
-            const float* b = boxes + ((size_t)n * J + jj) * 4;
-            const float bx = b[0], by = b[1], bw = b[2], bh = b[3];
-            const bool act = ((bx != 0.f) || (by != 0.f) || (bw != 0.f) || (bh != 0.f)) && keep[(size_t)n * J + jj] != 0;
-            const int yy = oy * stride + rr - pad;
-            my_ty[h] = (act && (unsigned)yy < (unsigned)Hm) ? lc_profile(yy, H, pool, by, bh) : 0.f;
-        }
+    const bool lane_taps = J * R <= 64;
+    float my_ty = 0.f;
+    if (lane_taps && lane < J * R) {
+        const int jj = lane / R, rr = lane - jj * R;
+        const float* b = boxes + ((size_t)n * J + jj) * 4;
+        const float bx = b[0], by = b[1], bw = b[2], bh = b[3];
+        const bool act = ((bx != 0.f) || (by != 0.f) || (bw != 0.f) || (bh != 0.f)) && keep[(size_t)n * J + jj] != 0;
+        const int yy = oy * stride + rr - pad;
+        my_ty = (act && (unsigned)yy < (unsigned)Hm) ? lc_profile(yy, H, pool, by, bh) : 0.f;
     }
     const int nq = (OW + 3) >> 2;
     // pixel q of thread-iteration xq: 4 consecutive pixels (one 16-byte access) when rows are 16-byte aligned, else the
@@ -239,10 +233,8 @@ __global__ __launch_bounds__(256) void layout_conv_fwd_kernel(const float* __res
             float tyr[R];
             if (lane_taps) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int t = j * R + r;          // wave-uniform
-                    tyr[r] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(t < 64 ? my_ty[0] : my_ty[1]), t & 63));
-                }
+                for (int r = 0; r < R; ++r)
+                    tyr[r] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_ty), j * R + r));
             } else {
                 lc_taps_y<R>(tyr, oy, stride, pad, Hm, H, pool, y0, hh, active);
             }
