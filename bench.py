@@ -292,10 +292,23 @@ def main():
                 "traffic": ((pm['fetch_bytes'] + pm['write_bytes']) if pm else None),
                 "traffic_note": (("%s: FETCH %.0f MB + WRITE %.0f MB on shape %s vs %.0f MB algorithmic" % (
                     PMC_PATH, pm['fetch_bytes'] / 1e6, pm['write_bytes'] / 1e6, pm['shape'], pm['algorithmic_bytes'] / 1e6)) if pm else None)}
-    roof_hbm = hbm_roofline('spade_norm_apply', 'norm_apply_kernel<1, true> (SPADE modulation + LeakyReLU, forward)',
-                            'x, gamma, beta read + y written = 4 tensor passes (the statistics pass is a separate kernel)')
-    roof_hbm_bwd = hbm_roofline('spade_norm_bwd', 'norm_bwd_reduce_kernel<1, true> + norm_bwd_apply_kernel<1, true> (SPADE modulation backward)',
-                                'reduce: dy, y, x, gamma read; apply: the same four read + dx, dgamma, dbeta written = 11 tensor passes')
+    # the HBM-bound kernel with the most time: the SPADE pair (norm_0 + norm_s of a block on one input read before its 2x upsampling)
+    # when the blocks use it, else the single SPADE modulation
+    pair = 'spade_pair_apply' in timing
+    roof_hbm_single = hbm_roofline('spade_norm_apply', 'norm_apply_kernel<1, true> (SPADE modulation + LeakyReLU, forward)',
+                                   'x, gamma, beta read + y written = 4 tensor passes (the statistics pass is a separate kernel)')
+    roof_hbm_single_bwd = hbm_roofline('spade_norm_bwd', 'norm_bwd_reduce_kernel<1, true> + norm_bwd_apply_kernel<1, true> (SPADE modulation backward)',
+                                       'reduce: dy, y, x, gamma read; apply: the same four read + dx, dgamma, dbeta written = 11 tensor passes')
+    roof_hbm, roof_hbm_bwd = roof_hbm_single, roof_hbm_single_bwd
+    if pair:
+        roof_hbm = hbm_roofline('spade_pair_apply', 'spade_pair_apply_kernel<2> (two SPADE modulations of one input read before its 2x upsampling)',
+                                'x at a quarter of the output size + 2 x (gamma, beta) read, 2 outputs written = 6.25 output-sized passes')
+        roof_hbm_bwd = hbm_roofline('spade_pair_bwd', 'spade_pair_bwd_reduce_kernel<2> + spade_pair_bwd_apply_kernel<2>',
+                                    'reduce: 2 x (dy, y | gamma) + x; apply: the same + 2 x (dgamma, dbeta) + dx at input size = 16.75 output-sized passes')
+        if roof_hbm is not None:
+            roof_hbm['single_spade'] = roof_hbm_single
+        if roof_hbm_bwd is not None:
+            roof_hbm_bwd['single_spade'] = roof_hbm_single_bwd
     roof = conv_roofline(timing, dt * 1e3 / args.steps) if timing else None     # the records cover the last timed step
     roof_fp32 = None
     if fp32_leg is not None:

@@ -60,7 +60,25 @@ def norm_case():
     expect['bn_stats_partial'] = {'shape': 'same, statistics pass', 'algorithmic_bytes': tb, 'pass': 'fwd'}
 
 
+def pair_case():
+    # SPADE pair at up_3's size: x [120, 128, 128, 128] read before its 2x upsampling, two gamma|beta tensors [120, 256, 256, 256]
+    N, C, Hs = 120, 128, 128
+    xs = torch.randn(N, C, Hs, Hs, device=dev, requires_grad=True)
+    gb0 = torch.randn(N, 2 * C, 2 * Hs, 2 * Hs, device=dev, requires_grad=True)
+    gb1 = torch.randn(N, 2 * C, 2 * Hs, 2 * Hs, device=dev, requires_grad=True)
+    bufs = [torch.zeros(C, device=dev), torch.ones(C, device=dev), torch.zeros(C, device=dev), torch.ones(C, device=dev)]
+    for _ in range(REPS):
+        y0, y1 = ops.spade_pair(xs, gb0, gb1, bufs[0], bufs[1], bufs[2], bufs[3], 2, 0.1, 1e-5, 0.2, 1.0, 15)
+        (y0.sum() + y1.sum()).backward()
+    torch.cuda.synchronize()
+    ob, xb = N * C * 4 * Hs * Hs * 4, N * C * Hs * Hs * 4
+    expect['spade_pair_apply'] = {'shape': 'spade_pair up=2, x %dx%dx%dx%d' % (N, C, Hs, Hs), 'algorithmic_bytes': xb + 6 * ob, 'pass': 'fwd'}
+    expect['spade_pair_bwd_reduce'] = {'shape': 'same, backward reduce pass', 'algorithmic_bytes': xb + 5 * ob, 'pass': 'bwd'}
+    expect['spade_pair_bwd_apply'] = {'shape': 'same, backward apply pass', 'algorithmic_bytes': 2 * xb + 9 * ob, 'pass': 'bwd'}
+
+
 CASES['norm'] = norm_case
+CASES['spade_pair'] = pair_case
 CASES[CASE]()
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.makedirs(os.path.join(root, 'gpurun_out'), exist_ok=True)
