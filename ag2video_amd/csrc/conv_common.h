@@ -62,12 +62,22 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo) {
     const f32x2 v = {x0, x1};
     const bf16x2 h = __builtin_convertvector(v, bf16x2);
+    float d0, d1;
+#ifndef AG2V_SPLIT_DOT2
     const f32x2 hf = __builtin_convertvector(h, f32x2);
     // two v_sub_f32, not one v_pk_add_f32: packed f32 VALU beside MFMAs costs ~13 extra cycles per instruction
     // (MI355X_MICROARCH.md constants table) and the compiler SLP-packs a plain v - hf
-    float d0, d1;
     asm volatile("v_sub_f32 %0, %1, %2" : "=v"(d0) : "v"(x0), "v"(hf[0]));
     asm volatile("v_sub_f32 %0, %1, %2" : "=v"(d1) : "v"(x1), "v"(hf[1]));
+#else
+    // Measured and NOT used: x - hi straight from the packed pair with v_dot2c_f32_bf16 (x += h.lo * -1 + h.hi * 0; 4 VALU per
+    // pair instead of 6).  The c3 step went from 885 to 959 ms: the dot instruction does not issue beside the MFMAs the way
+    // plain VALU does.
+    const bf16x2 m0 = {(__bf16)-1.0f, (__bf16)0.0f};
+    const bf16x2 m1 = {(__bf16)0.0f, (__bf16)-1.0f};
+    d0 = __builtin_amdgcn_fdot2_f32_bf16(h, m0, x0, false);
+    d1 = __builtin_amdgcn_fdot2_f32_bf16(h, m1, x1, false);
+#endif
     const f32x2 dv = {d0, d1};
     const bf16x2 l = __builtin_convertvector(dv, bf16x2);
     hi = __builtin_bit_cast(unsigned, h);
