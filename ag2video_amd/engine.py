@@ -5,6 +5,8 @@ and ``LossModel`` wrapped in ``DataParallelWithCallback`` -- plus the generator 
 parameter partition (train.py:365-368), and exposes the G step, D step and graph step in the reference's order.
 scripts/train.py, bench.py, __graft_entry__.smoke() and the tests all drive this object.
 """
+import os
+
 import torch
 
 from . import distributed as dist_utils
@@ -50,6 +52,13 @@ class TrainStep(object):
         self._d_params = list(self.discriminator.img_discriminator.parameters())
         for m in (self.model, self.discriminator):
             m.train()
+        # Second HIP stream for the launch-latency-bound graph nets whose results nothing on the main stream waits for: the box
+        # net's forward recurrence (AG2VideoModel.forward) and the discriminator's layout terms, forward here and backward at
+        # the tail of the discriminator's backward pass (autograd runs a node on the stream its forward ran on).
+        self.side_stream = None
+        if torch.device(device).type == 'cuda' and os.environ.get('AG2V_NO_SIDE_STREAM') is None:
+            self.side_stream = torch.cuda.Stream(device=device)
+            self.model.side_stream = self.side_stream
         dist_utils.broadcast_parameters(list(self.model.parameters()) + self._d_params +
                                         list(self.model.buffers()) + list(self.discriminator.buffers()))
 
@@ -62,6 +71,9 @@ class TrainStep(object):
         iteration.  The decision is COLLECTIVE (distributed.any_rank): every rank skips or none does, so the gradient
         all-reduces below always pair up across ranks.  Returns (model_out, G_losses, D_losses); D_losses is None when skipped."""
         imgs, objs, boxes, triplets, actions, video_id = batch
+        if self.side_stream is not None:
+            adata = self.model.acts_to_boxes.module.actions_data(triplets, actions)
+            self.gans_model.module.prefetch_layout_terms(batch, adata, self.side_stream)
         model_out = self.model(imgs, objs, triplets, actions, boxes_gt=boxes, test_mode=False, use_gt=True)
         G_losses = self.gans_model(batch, model_out, mode="compute_generator_loss")
         G_losses = {k: v.mean() for k, v in G_losses.items()}
@@ -81,6 +93,8 @@ class TrainStep(object):
         D_losses = {k: v.mean() for k, v in D_losses.items()}
         self.discriminator.optimizer_d_img.zero_grad()
         D_losses["total_img_loss"].backward()
+        if self.side_stream is not None:      # the layout terms' backward ran there; their gradients are written by the ops themselves
+            torch.cuda.current_stream().wait_stream(self.side_stream)
         dist_utils.average_gradients(self._d_params, flat=getattr(self.discriminator.optimizer_d_img, 'flat_grad', None))
         if apply_updates:
             self.discriminator.optimizer_d_img.step()

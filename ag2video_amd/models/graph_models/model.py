@@ -16,8 +16,9 @@ def decode_actions(actions, timesteps, pad_action):
     f1, f2 = f1.float(), f2.float()
     rel = (t / timesteps) * (f2 - f1 + 1e-6) + f1
     included = (rel >= 0) * (rel <= 1)
-    a = a.clone()
-    a[~included] = pad_action
+    # (torch.where, not a[~included] = pad: boolean-mask assignment goes through nonzero(), a host synchronisation at the top of
+    # every graph-net forward -- the GPU queue ran dry there and the ~2 000 launches of the graph nets were issue-bound)
+    a = torch.where(included, a, torch.full_like(a, pad_action))
     temporal_triplets = torch.stack([sa, a, oa], dim=-1).long()
     return temporal_triplets, rel, x_end, y_end
 
@@ -54,6 +55,13 @@ class Acts2LayoutModel(nn.Module):
                                      Linear(obj_input_dim, obj_input_dim, bias=False), nn.ReLU())
         if args.get("mask_size"):
             raise NotImplementedError("mask_size > 0 (mask_net) is not on the training hot path (data/args.py:45)")
+
+    def actions_data(self, triplets, actions):
+        """The fourth return value of forward() alone: [triplets, temporal_triplets, relative_timesteps, locs] depends on the
+        inputs only (no parameter), so a caller can have it before the recurrence has run."""
+        temporal_triplets, rel, x_end, y_end = decode_actions(actions, triplets.size(1),
+                                                              self.vocab["action_name_to_idx"]["__padding__"])
+        return [triplets, temporal_triplets, rel, torch.stack([x_end, y_end], dim=-1)]
 
     def forward(self, objs, triplets, actions, boxes_gt=None, test_mode=False):
         """objs [B,O,A] i64, triplets [B,F,T,3] i64, actions [B,A,7] f32, boxes_gt [B,F,O,4] ->

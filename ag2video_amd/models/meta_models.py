@@ -24,9 +24,25 @@ class AG2VideoModel(nn.Module):
             objs_model = "graph" if self.args["layout_arch"] == 'gt_layout' else self.args["layout_arch"]
             self.acts_to_objs = DataParallelWithCallback(models[objs_model](opt), device_ids=ids).to(device)
         self.layout_to_video = DataParallelWithCallback(Layout2VidGenerator(opt), device_ids=ids).to(device)
+        # engine.TrainStep sets a second HIP stream here: work whose result the rest of the forward pass does not read runs on it
+        self.side_stream = None
 
     def forward(self, imgs, objs, triplets, actions, boxes_gt=None, test_mode=False, use_gt=False, graph_only=False):
         """-> (imgs_pred, boxes_pred, flows_pred, conf_pred, actions_data), or boxes_pred when graph_only."""
+        side = self.side_stream
+        if side is not None and not graph_only and use_gt and not self.args.get("coupled_motion_apperance") and imgs.is_cuda:
+            # Teacher forcing: the generator reads ground-truth boxes and the appearance net's vectors, so the box net's 15-step
+            # recurrence (~700 launches of 5-20 us on a handful of CUs) is only an OUTPUT of this call.  It runs beside the
+            # appearance net and the generator on the side stream; the caller's stream joins before this function returns.
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                _, boxes_pred, _ = self.acts_to_boxes(objs, triplets, actions, boxes_gt, test_mode=test_mode)
+                boxes_pred.record_stream(main)
+            obj_vecs, _, actions_data = self.acts_to_objs(objs, triplets, actions, boxes_gt, test_mode=test_mode)
+            imgs_pred, flows_pred, conf_pred = self.layout_to_video(imgs, objs, obj_vecs, boxes_gt, test_mode=test_mode)
+            main.wait_stream(side)
+            return imgs_pred, boxes_pred, flows_pred, conf_pred, actions_data
         obj_vecs, boxes_pred, actions_data = self.acts_to_boxes(objs, triplets, actions, boxes_gt, test_mode=test_mode)
         if graph_only:
             return boxes_pred

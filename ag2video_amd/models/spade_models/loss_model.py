@@ -59,7 +59,7 @@ class LossModel(torch.nn.Module):
         return (tuple((t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride())) for t in inputs),
                 tuple(p._version for p in self.netD_img.parameters()), id(opt_d), getattr(opt_d, '_step', None))
 
-    def _layout_terms(self, objs, r_boxes, r_adata, producer):
+    def _layout_terms(self, objs, r_boxes, r_adata, producer, batch=None):
         """producer=True (generator loss): evaluate and remember; producer=False (discriminator loss): reuse when valid."""
         if not hasattr(self.netD_img, 'layout_terms'):
             return None
@@ -69,15 +69,52 @@ class LossModel(torch.nn.Module):
                      and not getattr(self.opt, 'no_shared_layout_terms', False)
                      and os.environ.get('AG2V_NO_SHARED_TERMS') is None)
         cached, self._terms_cache = getattr(self, '_terms_cache', None), None
+        pre, self._terms_prefetch = getattr(self, '_terms_prefetch', None), None
         if not shareable:
             return self.netD_img.layout_terms(objs, r_boxes, r_adata)
         key = self._terms_key(inputs)
+        if producer and pre is not None and batch is not None and pre[0] == self._prefetch_key(batch):
+            torch.cuda.current_stream().wait_event(pre[2])
+            self._terms_cache = (key, inputs, pre[1])
+            return pre[1]
         if not producer and cached is not None and cached[0] == key:
             return cached[2]
         terms = self.netD_img.layout_terms(objs, r_boxes, r_adata)
         if producer and terms is not None:
             self._terms_cache = (key, inputs, terms)
         return terms
+
+    def prefetch_layout_terms(self, batch, actions_data, stream):
+        """Evaluate the discriminator's layout terms for `batch` on `stream` (engine.TrainStep: a side stream, before the generator
+        forward).  They depend on D's parameters and the batch only, so they can be computed while the generator runs; the
+        generator loss picks them up (after waiting for `stream`) when it is called with the same batch tensors and unchanged
+        parameters, and installs them under the regular key for the discriminator loss."""
+        self._terms_prefetch = None
+        if not hasattr(self.netD_img, 'layout_terms') or not torch.is_grad_enabled():
+            return
+        imgs, objs, boxes, triplets, actions, _ = batch
+        nc = self.n_frames_G - 1
+        r_boxes = boxes[:, nc:]
+        r_adata = [item[:, nc:] for item in actions_data]
+        inputs = [objs, r_boxes] + list(r_adata)
+        if (getattr(self.opt, 'mlp_normalization', 'none') != 'none' or getattr(self.opt, 'no_shared_layout_terms', False)
+                or os.environ.get('AG2V_NO_SHARED_TERMS') is not None or any(t.requires_grad for t in inputs if t.is_floating_point())):
+            return
+        main = torch.cuda.current_stream()
+        stream.wait_stream(main)
+        with torch.cuda.stream(stream):
+            terms = self.netD_img.layout_terms(objs, r_boxes, r_adata)
+            if terms is None:
+                return
+            for t in terms:
+                t.record_stream(main)
+            done = torch.cuda.Event()
+            done.record(stream)
+        self._terms_prefetch = (self._prefetch_key(batch), terms, done)
+
+    def _prefetch_key(self, batch):
+        imgs, objs, boxes, triplets, actions, _ = batch
+        return self._terms_key([objs, boxes, triplets, actions])
 
     def compute_graph_loss(self, batch, boxes_pred):
         """Masked smooth-L1 on predicted boxes (loss_model.py:41-60); a few thousand elements: host-side torch ops."""
@@ -103,7 +140,7 @@ class LossModel(torch.nn.Module):
         G = {}
         # the layout part of D's first convolutions is the same for the fake and the real pass (and for the discriminator
         # loss of this batch: _layout_terms)
-        terms = self._layout_terms(objs, r_boxes, r_adata, producer=True)
+        terms = self._layout_terms(objs, r_boxes, r_adata, producer=True, batch=batch)
         if terms is not None:
             terms = [t.detach() for t in terms]
         with _params_frozen(self.netD_img):
