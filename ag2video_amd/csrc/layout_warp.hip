@@ -8,6 +8,7 @@
 //  * flow warp: resample/get_grid (models/utils.py:113-140): grid_sample(bilinear, border, align_corners=False).
 //  * avg_pool2d(3, s2, p1, count_include_pad=False) (discriminator.py:270-271), nearest x2 upsample
 //    (spade_generator.py:36,55-70; flows_generator.py:47), nearest resize of the segmap (normalization.py:102).
+#include <algorithm>
 #include "common.h"
 
 #define MAXO 16
@@ -137,12 +138,14 @@ __device__ __forceinline__ void lc_taps_y(float (&tyr)[R], int oy, int stride, i
     }
 }
 
+constexpr int LC_TJ = 24, LC_TW = 264;   // table limits of layout_conv_fwd_kernel
+
 // img / wimg / iscale (nullable; stride 1, pool 0): the IMAGE channels of the same convolution -- conv_dim_in and down_flow[0] see
 // cat[layouts, frame(s)] (generator.py:66,74,82) -- are added here: out += iscale[n] * conv(img[n, :IC], wimg[K, IC, R, R]).  Their
 // IC * R * R = 27 multiply-adds per output are nothing beside the 16 GB this kernel writes at c3, and the dense launch, its 16 GB
 // output and the read-back of it as `residual` disappear (5.9 + ~3 ms per step).
 template <int R, int KPER>
-__global__ __launch_bounds__(256) void layout_conv_fwd_kernel(const float* __restrict__ U, const float* __restrict__ boxes,
+__global__ __launch_bounds__(256) void layout_conv_fwd_generic_kernel(const float* __restrict__ U, const float* __restrict__ boxes,
                                                               const int* __restrict__ keep, const float* __restrict__ residual,
                                                               float* __restrict__ out, int J, int K, int H, int W, int Hm, int Wm,
                                                               int pool, int OH, int OW, int stride, int pad,
@@ -281,6 +284,153 @@ __global__ __launch_bounds__(256) void layout_conv_fwd_kernel(const float* __res
                     if (px(xq, q) < OW) orow[px(xq, q)] = acc[kk][q];
             }
         }
+    }
+}
+
+// The kernel the path uses (J <= 24 objects, map rows <= 264 wide; everything else: layout_conv_fwd_generic_kernel below).
+// Workgroup = 4 waves = 4 output rows x KPER channels of one image; three LDS tables replace per-lane work that is uniform
+// over a wave: (1) the column profiles tx_j(x) of all objects, (2) the R row taps ty_j of each wave's row, (3) per wave and
+// (object j, channel kk) the row-contracted taps cs[s] = sum_r ty_j[r] * U[j, k, r, s].  The inner loop is then R x 4 FMAs per
+// (object, channel) on 4 pixels, fed by one broadcast ds_read_b128; before, every lane recomputed the 9-FMA contraction (and,
+// from 22 objects on, both profiles) itself: 10.8 -> see DESIGN.md ms per launch at c3 (22 objects, 512 channels, 120 x 256 x 256).
+template <int R, int KPER>
+__global__ __launch_bounds__(256) void layout_conv_fwd_kernel(const float* __restrict__ U, const float* __restrict__ boxes,
+                                                              const int* __restrict__ keep, const float* __restrict__ residual,
+                                                              float* __restrict__ out, int J, int K, int H, int W, int Hm, int Wm,
+                                                              int pool, int OH, int OW, int stride, int pad,
+                                                              const float* __restrict__ img, const float* __restrict__ wimg,
+                                                              const float* __restrict__ iscale, int IC) {
+    constexpr int TJ = LC_TJ, TW = LC_TW;
+    __shared__ float txp[TJ][TW];
+    __shared__ float tyl[4][TJ][4];
+    __shared__ float4 csl[4][TJ][KPER];
+    constexpr int RRP = (R * R + 3) & ~3;       // filter taps per (channel, image channel), padded to 16-byte reads
+    __shared__ float wl[KPER][8][RRP];          // image filter of this channel block, scaled (IC <= 8)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int oy = blockIdx.x * 4 + wave;
+    const int n = blockIdx.y;
+    for (int idx = threadIdx.x; idx < J * Wm; idx += 256) {
+        const int j = idx / Wm, xx = idx - j * Wm;
+        const float* b = boxes + ((size_t)n * J + j) * 4;
+        txp[j][xx] = lc_profile(xx, W, pool, b[0], b[2]);
+    }
+    for (int idx = lane; idx < J * 4; idx += 64) {
+        const int j = idx >> 2, r = idx & 3;
+        const float* b = boxes + ((size_t)n * J + j) * 4;
+        const float bx = b[0], by = b[1], bw = b[2], bh = b[3];
+        const bool act = ((bx != 0.f) || (by != 0.f) || (bw != 0.f) || (bh != 0.f)) && keep[(size_t)n * J + j] != 0;
+        const int yy = oy * stride + r - pad;
+        tyl[wave][j][r] = (r < R && oy < OH && act && (unsigned)yy < (unsigned)Hm) ? lc_profile(yy, H, pool, by, bh) : 0.f;
+    }
+    // the profiles above are shared by every channel: the workgroup walks the channel blocks kb = z, z + gridDim.z, ... itself
+    for (int k0 = blockIdx.z * KPER; k0 < K; k0 += gridDim.z * KPER) {
+    __syncthreads();          // (first pass: the profile tables are complete; later passes: the previous block's tables are no longer read)
+    if (img) {
+        const float sc = iscale ? iscale[n] : 1.f;
+        for (int idx = threadIdx.x; idx < KPER * IC * RRP; idx += 256) {
+            const int t = idx % RRP, c = (idx / RRP) % IC, kk = idx / (RRP * IC);
+            wl[kk][c][t] = (t < R * R && k0 + kk < K) ? wimg[(((size_t)(k0 + kk) * IC + c) * R) * R + t] * sc : 0.f;
+        }
+    }
+    for (int idx = lane; idx < J * KPER; idx += 64) {
+        const int j = idx / KPER, kk = idx - j * KPER;
+        float cs[4] = {0.f, 0.f, 0.f, 0.f};
+        const float4 t4 = *reinterpret_cast<const float4*>(&tyl[wave][j][0]);
+        const float tv[4] = {t4.x, t4.y, t4.z, t4.w};
+        if (k0 + kk < K && (t4.x != 0.f || t4.y != 0.f || t4.z != 0.f || t4.w != 0.f)) {      // rows that miss the object read no taps
+            const float* u = U + (((size_t)n * J + j) * K + k0 + kk) * (R * R);
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int s2 = 0; s2 < R; ++s2) cs[s2] = fmaf(tv[r], u[r * R + s2], cs[s2]);
+        }
+        csl[wave][j][kk] = make_float4(cs[0], cs[1], cs[2], cs[3]);
+    }
+    __syncthreads();
+    const int nq = (OW + 3) >> 2;
+    const bool vec = (OW & 3) == 0;
+    auto px = [&](int xq, int q) -> int { return vec ? xq * 4 + q : (xq >> 6) * 256 + (xq & 63) + 64 * q; };
+    if (oy < OH)
+    for (int xq = lane; vec ? (xq < nq) : ((xq >> 6) * 256 < OW); xq += 64) {
+        float acc[KPER][4];
+#pragma unroll
+        for (int kk = 0; kk < KPER; ++kk)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ox = px(xq, q);
+                acc[kk][q] = (residual && (k0 + kk) < K && ox < OW)
+                                 ? residual[(((size_t)n * K + k0 + kk) * OH + oy) * OW + ox] : 0.f;
+            }
+        if (img) {      // dense image channels (stride 1, no pooling; vec layout: 4 consecutive pixels per thread)
+            const int x0i = xq * 4 - pad;
+            for (int c = 0; c < IC; ++c) {
+                const float* ip = img + ((size_t)n * IC + c) * H * W;
+                float iv[R][R + 3];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int yy = oy + r - pad;
+                    const bool rowok = (unsigned)yy < (unsigned)H;
+#pragma unroll
+                    for (int i = 0; i < R + 3; ++i) {
+                        const int xx = x0i + i;
+                        iv[r][i] = (rowok && (unsigned)xx < (unsigned)W) ? ip[yy * W + xx] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int kk = 0; kk < KPER; ++kk) {
+                    float wv[RRP];
+#pragma unroll
+                    for (int t = 0; t < RRP; t += 4) {
+                        const float4 w4 = *reinterpret_cast<const float4*>(&wl[kk][c][t]);      // wave-uniform address: broadcast
+                        wv[t] = w4.x; wv[t + 1] = w4.y; wv[t + 2] = w4.z; wv[t + 3] = w4.w;
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+#pragma unroll
+                        for (int s2 = 0; s2 < R; ++s2)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) acc[kk][q] = fmaf(wv[r * R + s2], iv[r][s2 + q], acc[kk][q]);
+                }
+            }
+        }
+        for (int j = 0; j < J; ++j) {
+            const float4 t4 = *reinterpret_cast<const float4*>(&tyl[wave][j][0]);
+            const float tysum = fabsf(t4.x) + fabsf(t4.y) + fabsf(t4.z) + fabsf(t4.w);
+            if (__builtin_amdgcn_readfirstlane(__float_as_uint(tysum)) == 0u) continue;      // the row misses the object (uniform)
+            float txs[R][4];
+            float txsum = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < R; ++s2)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int xx = px(xq, q) * stride + s2 - pad;
+                    txs[s2][q] = ((unsigned)xx < (unsigned)Wm) ? txp[j][xx] : 0.f;
+                    txsum += fabsf(txs[s2][q]);
+                }
+            if (__ballot(txsum != 0.f) == 0ull) continue;
+#pragma unroll
+            for (int kk = 0; kk < KPER; ++kk) {
+                const float4 c4 = csl[wave][j][kk];
+                const float cs[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+                for (int s2 = 0; s2 < R; ++s2)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[kk][q] = fmaf(cs[s2], txs[s2][q], acc[kk][q]);
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < KPER; ++kk) {
+            if (k0 + kk >= K) continue;
+            float* orow = out + (((size_t)n * K + k0 + kk) * OH + oy) * OW;
+            if (vec) {
+                *reinterpret_cast<float4*>(orow + xq * 4) = make_float4(acc[kk][0], acc[kk][1], acc[kk][2], acc[kk][3]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (px(xq, q) < OW) orow[px(xq, q)] = acc[kk][q];
+            }
+        }
+    }
     }
 }
 
@@ -653,12 +803,17 @@ extern "C" int ag2v_layout_conv_img_fwd(const float* U, const float* boxes, cons
     }
     constexpr int KPER = 16;
     dim3 grid(ceil_div(OH, 4), NB, ceil_div(K, KPER));
-    if (R == 3)
-        hipLaunchKernelGGL((layout_conv_fwd_kernel<3, KPER>), grid, dim3(256), 0, (hipStream_t)stream, U, boxes, keep, residual, out,
-                           J, K, H, W, Hm, Wm, pool, OH, OW, stride, pad, img, wimg, iscale, IC);
-    else
-        hipLaunchKernelGGL((layout_conv_fwd_kernel<4, KPER>), grid, dim3(256), 0, (hipStream_t)stream, U, boxes, keep, residual, out,
-                           J, K, H, W, Hm, Wm, pool, OH, OW, stride, pad, img, wimg, iscale, IC);
+    static const bool no_tables = getenv("AG2V_LC_GENERIC") != nullptr;       // A/B aid
+    const bool tables = J <= LC_TJ && Wm <= LC_TW && !no_tables;
+#define LC_LAUNCH(KERNEL, RR) hipLaunchKernelGGL((KERNEL<RR, KPER>), grid, dim3(256), 0, (hipStream_t)stream, U, boxes, keep, residual, \
+                                                 out, J, K, H, W, Hm, Wm, pool, OH, OW, stride, pad, img, wimg, iscale, IC)
+    if (tables) {       // channel blocks per workgroup: all of them once rows x images alone fill the chip several times over
+        const int nkb = ceil_div(K, KPER), wg = ceil_div(OH, 4) * NB;
+        grid.z = wg >= 2048 ? 1 : std::min(nkb, ceil_div(2048, wg));
+    }
+    if (tables) { if (R == 3) LC_LAUNCH(layout_conv_fwd_kernel, 3); else LC_LAUNCH(layout_conv_fwd_kernel, 4); }
+    else        { if (R == 3) LC_LAUNCH(layout_conv_fwd_generic_kernel, 3); else LC_LAUNCH(layout_conv_fwd_generic_kernel, 4); }
+#undef LC_LAUNCH
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
 }

@@ -294,7 +294,8 @@ def test_layout_render(cfg, device):
 
 
 @pytest.mark.parametrize("cfg", [(2, 6, 20, 32, 32, 3, 1, 1, 0), (3, 22, 40, 64, 64, 3, 1, 1, 0), (2, 5, 9, 32, 32, 4, 2, 2, 0),
-                                 (1, 9, 33, 24, 40, 3, 1, 1, 0), (3, 7, 12, 64, 64, 4, 2, 2, 1), (2, 4, 8, 33, 29, 4, 2, 2, 1)],
+                                 (1, 9, 33, 24, 40, 3, 1, 1, 0), (3, 7, 12, 64, 64, 4, 2, 2, 1), (2, 4, 8, 33, 29, 4, 2, 2, 1),
+                                 (2, 26, 20, 32, 32, 3, 1, 1, 0), (1, 24, 70, 16, 272, 3, 1, 1, 0), (2, 3, 200, 16, 16, 3, 1, 1, 0)],
                          ids=str)
 def test_layout_conv(cfg, device):
     from ag2video_amd import ops
