@@ -6,6 +6,8 @@
 // layer).  Here every sample of the batch is handled in one launch: edges are read with coalesced index loads, and the
 // pooling is a segmented reduce over the (<= a few dozen) edges of each object -- one workgroup per (sample, object),
 // no atomics, deterministic order.
+#include <cstdint>
+#include <cstdlib>
 #include "common.h"
 
 // triples[b,t,:] = [ obj[b, s(b,t), :Din] | pred[b,t,:Dp] | obj[b, o(b,t), :Din] ]     edges: int64 [B,T,2]
@@ -223,6 +225,73 @@ __global__ __launch_bounds__(256 * KS) void gemm_f32_kernel(const float* __restr
     }
 }
 
+// ---------------------------------------------------------------- one-round-trip GEMM for the graph nets' shapes
+// The graph nets run 15 dependent time steps of ~13 GEMMs with 48-128 rows and K = 128-1152: a launch is a latency chain, not
+// work (gemm_f32_kernel<4> above: 18-21 us for 42 MFLOP -- launch, then 4 x (global load -> LDS -> barrier -> MFMA), cross-group
+// sum, epilogue).  Here a workgroup owns a 32 x 32 output tile and its 16 waves split K between them; every wave requests its
+// whole K slice at once, straight into the registers the MFMAs read (the order of the k terms inside a sum is free, so lane
+// (i, g) simply takes k = 8 q + 4 g + e of the slice for BOTH operands: 16-byte loads along k for a k-contiguous operand,
+// coalesced 4-byte loads for a row-contiguous one, no LDS staging).  One memory round trip, <= 36 MFMAs, one LDS reduction
+// over the 16 waves, epilogue.  Requires K % 4 == 0 (16-byte loads; every K on the path).
+template <int CHQ>
+__global__ __launch_bounds__(1024) void gemm_f32_oneshot_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                                const float* __restrict__ bias, float* __restrict__ c, int M, int N,
+                                                                int K, long long sam, long long sak, long long sbk, long long sbn,
+                                                                int ldc, int relu, int accumulate, int slice) {
+    __shared__ float red[16][1024];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, i32 = lane & 31, g = lane >> 5;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int kbeg = wv * slice, kend = min(K, kbeg + slice);
+    const int m = m0 + i32, n = n0 + i32;
+    const bool a_kc = (sak == 1), b_kc = (sbk == 1);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int kc = kbeg; kc < kend; kc += 8 * CHQ) {
+        float ra[4 * CHQ], rb[4 * CHQ];
+#pragma unroll
+        for (int q = 0; q < CHQ; ++q) {
+            const int k = kc + 8 * q + 4 * g;
+            const bool kin = k < kend;          // (k and kend are multiples of 4: a quad is in or out as a whole)
+            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+            if (kin && m < M) {
+                if (a_kc) va = *reinterpret_cast<const float4*>(a + (long long)m * sam + k);
+                else {
+                    const float* ap = a + (long long)m * sam + (long long)k * sak;
+                    va = make_float4(ap[0], ap[sak], ap[2 * sak], ap[3 * sak]);
+                }
+            }
+            if (kin && n < N) {
+                if (b_kc) vb = *reinterpret_cast<const float4*>(b + (long long)n * sbn + k);
+                else {
+                    const float* bp = b + (long long)n * sbn + (long long)k * sbk;
+                    vb = make_float4(bp[0], bp[sbk], bp[2 * sbk], bp[3 * sbk]);
+                }
+            }
+            ra[4 * q] = va.x; ra[4 * q + 1] = va.y; ra[4 * q + 2] = va.z; ra[4 * q + 3] = va.w;
+            rb[4 * q] = vb.x; rb[4 * q + 1] = vb.y; rb[4 * q + 2] = vb.z; rb[4 * q + 3] = vb.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 4 * CHQ; ++j)
+            if (kc + 8 * (j >> 2) < kend)        // wave-uniform: whole 8-k groups beyond the slice hold zeros only
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[j], rb[j], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wv][r * 64 + lane] = acc[r];
+    __syncthreads();
+    const int t = threadIdx.x;
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) sum += red[w][t];
+    const int r = t >> 6, l2 = t & 63;
+    const int mo = m0 + (r & 3) + 8 * (r >> 2) + 4 * (l2 >> 5), no = n0 + (l2 & 31);
+    if (mo < M && no < N) {
+        float v = sum + (bias ? bias[no] : 0.f);
+        if (accumulate) v += c[(size_t)mo * ldc + no];
+        c[(size_t)mo * ldc + no] = relu ? fmaxf(v, 0.f) : v;
+    }
+}
+
 // g = dy * (y > 0)   (ReLU backward), and column sums for bias gradients
 __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ g,
                                                        long long n) {
@@ -292,6 +361,21 @@ extern "C" int ag2v_triple_pool_bwd(const float* dpooled, const float* dp_in, co
 extern "C" int ag2v_gemm_f32(const float* a, const float* b, const float* bias, float* c, int M, int N, int K, long long sam,
                              long long sak, long long sbk, long long sbn, int ldc, int relu, int accumulate, void* stream) {
     if (!a || !b || !c || M <= 0 || N <= 0 || K <= 0 || ldc < N) return AG2V_EINVAL;
+    static const int oneshot_mode = getenv("AG2V_GEMM_ONESHOT") ? atoi(getenv("AG2V_GEMM_ONESHOT")) : 1;   // 0: never (A/B aid)
+    const long long tiles32 = (long long)ceil_div(N, 32) * ceil_div(M, 32);
+    if (oneshot_mode && K % 4 == 0 && K <= 16 * 72 && tiles32 <= 1024 && ((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0 &&
+        (sak != 1 || sam % 4 == 0) && (sbk != 1 || sbn % 4 == 0)) {
+        const int slice = ((ceil_div(K, 16) + 7) / 8) * 8;
+        const dim3 g32(ceil_div(N, 32), ceil_div(M, 32));
+        if (slice <= 32)
+            hipLaunchKernelGGL(gemm_f32_oneshot_kernel<4>, g32, dim3(1024), 0, (hipStream_t)stream, a, b, bias, c, M, N, K, sam, sak, sbk,
+                               sbn, ldc, relu, accumulate, slice);
+        else
+            hipLaunchKernelGGL(gemm_f32_oneshot_kernel<9>, g32, dim3(1024), 0, (hipStream_t)stream, a, b, bias, c, M, N, K, sam, sak, sbk,
+                               sbn, ldc, relu, accumulate, slice);
+        AG2V_CHECK_LAUNCH();
+        return AG2V_OK;
+    }
     const dim3 grid(ceil_div(N, 64), ceil_div(M, 64));
     if (K >= 256 && (long long)grid.x * grid.y < 512)   // few tiles, long K: four K groups per tile
         hipLaunchKernelGGL(gemm_f32_kernel<4>, grid, dim3(1024), 0, (hipStream_t)stream, a, b, bias, c, M, N, K, sam, sak, sbk, sbn, ldc,
