@@ -59,6 +59,8 @@ class TrainStep(object):
         if torch.device(device).type == 'cuda' and os.environ.get('AG2V_NO_SIDE_STREAM') is None:
             self.side_stream = torch.cuda.Stream(device=device)
             self.model.side_stream = self.side_stream
+            # (graph-net parameters of D receive gradients from nodes of both streams)
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         dist_utils.broadcast_parameters(list(self.model.parameters()) + self._d_params +
                                         list(self.model.buffers()) + list(self.discriminator.buffers()))
 
@@ -72,9 +74,13 @@ class TrainStep(object):
         all-reduces below always pair up across ranks.  Returns (model_out, G_losses, D_losses); D_losses is None when skipped."""
         imgs, objs, boxes, triplets, actions, video_id = batch
         if self.side_stream is not None:
-            adata = self.model.acts_to_boxes.module.actions_data(triplets, actions)
-            self.gans_model.module.prefetch_layout_terms(batch, adata, self.side_stream)
+            adata = self.model.acts_to_boxes.module.actions_data(triplets, actions)      # (inputs only; a few small launches)
+            step_start = torch.cuda.current_stream().record_event()
         model_out = self.model(imgs, objs, triplets, actions, boxes_gt=boxes, test_mode=False, use_gt=True)
+        if self.side_stream is not None:
+            # launched AFTER the generator's forward is queued (the graph net is issue-bound: its launches then reach a busy GPU),
+            # ordered only behind the start of this step
+            self.gans_model.module.prefetch_layout_terms(batch, adata, self.side_stream, after=step_start)
         G_losses = self.gans_model(batch, model_out, mode="compute_generator_loss")
         G_losses = {k: v.mean() for k, v in G_losses.items()}
         if nan_guard:

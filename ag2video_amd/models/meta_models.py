@@ -34,13 +34,17 @@ class AG2VideoModel(nn.Module):
             # Teacher forcing: the generator reads ground-truth boxes and the appearance net's vectors, so the box net's 15-step
             # recurrence (~700 launches of 5-20 us on a handful of CUs) is only an OUTPUT of this call.  It runs beside the
             # appearance net and the generator on the side stream; the caller's stream joins before this function returns.
+            # Issue order: the appearance net and the generator first, the box net after them -- the graph nets are issue-bound
+            # (~1 000 launches of 3-8 us), so their launches should reach the GPU while it has the generator's queue to work on.
+            # The side stream only waits for an event recorded at entry (the inputs), not for the generator.
             main = torch.cuda.current_stream()
-            side.wait_stream(main)
+            entry = main.record_event()
+            obj_vecs, _, actions_data = self.acts_to_objs(objs, triplets, actions, boxes_gt, test_mode=test_mode)
+            imgs_pred, flows_pred, conf_pred = self.layout_to_video(imgs, objs, obj_vecs, boxes_gt, test_mode=test_mode)
+            side.wait_event(entry)
             with torch.cuda.stream(side):
                 _, boxes_pred, _ = self.acts_to_boxes(objs, triplets, actions, boxes_gt, test_mode=test_mode)
                 boxes_pred.record_stream(main)
-            obj_vecs, _, actions_data = self.acts_to_objs(objs, triplets, actions, boxes_gt, test_mode=test_mode)
-            imgs_pred, flows_pred, conf_pred = self.layout_to_video(imgs, objs, obj_vecs, boxes_gt, test_mode=test_mode)
             main.wait_stream(side)
             return imgs_pred, boxes_pred, flows_pred, conf_pred, actions_data
         obj_vecs, boxes_pred, actions_data = self.acts_to_boxes(objs, triplets, actions, boxes_gt, test_mode=test_mode)

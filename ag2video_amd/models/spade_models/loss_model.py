@@ -84,9 +84,9 @@ class LossModel(torch.nn.Module):
             self._terms_cache = (key, inputs, terms)
         return terms
 
-    def prefetch_layout_terms(self, batch, actions_data, stream):
+    def prefetch_layout_terms(self, batch, actions_data, stream, after=None):
         """Evaluate the discriminator's layout terms for `batch` on `stream` (engine.TrainStep: a side stream, before the generator
-        forward).  They depend on D's parameters and the batch only, so they can be computed while the generator runs; the
+        forward's launches are queued).  They depend on D's parameters and the batch only, so they can be computed while the generator runs; the
         generator loss picks them up (after waiting for `stream`) when it is called with the same batch tensors and unchanged
         parameters, and installs them under the regular key for the discriminator loss."""
         self._terms_prefetch = None
@@ -101,7 +101,10 @@ class LossModel(torch.nn.Module):
                 or os.environ.get('AG2V_NO_SHARED_TERMS') is not None or any(t.requires_grad for t in inputs if t.is_floating_point())):
             return
         main = torch.cuda.current_stream()
-        stream.wait_stream(main)
+        if after is not None:       # an event on the caller's stream after which batch and parameters are final
+            stream.wait_event(after)
+        else:
+            stream.wait_stream(main)
         with torch.cuda.stream(stream):
             terms = self.netD_img.layout_terms(objs, r_boxes, r_adata)
             if terms is None:
