@@ -237,13 +237,13 @@ template <int CHQ>
 __global__ __launch_bounds__(1024) void gemm_f32_oneshot_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                                 const float* __restrict__ bias, float* __restrict__ c, int M, int N,
                                                                 int K, long long sam, long long sak, long long sbk, long long sbn,
-                                                                int ldc, int relu, int accumulate, int slice) {
+                                                                int ldc, int relu, int accumulate, int slice, int avec, int bvec) {
     __shared__ float red[16][1024];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, i32 = lane & 31, g = lane >> 5;
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
     const int kbeg = wv * slice, kend = min(K, kbeg + slice);
     const int m = m0 + i32, n = n0 + i32;
-    const bool a_kc = (sak == 1), b_kc = (sbk == 1);
+    const bool a_kc = avec != 0, b_kc = bvec != 0;       // k-contiguous AND 16-byte aligned rows: quad loads
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -363,16 +363,17 @@ extern "C" int ag2v_gemm_f32(const float* a, const float* b, const float* bias, 
     if (!a || !b || !c || M <= 0 || N <= 0 || K <= 0 || ldc < N) return AG2V_EINVAL;
     static const int oneshot_mode = getenv("AG2V_GEMM_ONESHOT") ? atoi(getenv("AG2V_GEMM_ONESHOT")) : 1;   // 0: never (A/B aid)
     const long long tiles32 = (long long)ceil_div(N, 32) * ceil_div(M, 32);
-    if (oneshot_mode && K % 4 == 0 && K <= 16 * 72 && tiles32 <= 1024 && ((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0 &&
-        (sak != 1 || sam % 4 == 0) && (sbk != 1 || sbn % 4 == 0)) {
+    if (oneshot_mode && K % 4 == 0 && K <= 16 * 72 && tiles32 <= 1024) {
         const int slice = ((ceil_div(K, 16) + 7) / 8) * 8;
         const dim3 g32(ceil_div(N, 32), ceil_div(M, 32));
+        // quad loads need 16-byte aligned rows (parameters are views into the optimizers' flat buffers: any 4-byte offset occurs)
+        const int avec = sak == 1 && sam % 4 == 0 && ((uintptr_t)a & 15) == 0, bvec = sbk == 1 && sbn % 4 == 0 && ((uintptr_t)b & 15) == 0;
         if (slice <= 32)
             hipLaunchKernelGGL(gemm_f32_oneshot_kernel<4>, g32, dim3(1024), 0, (hipStream_t)stream, a, b, bias, c, M, N, K, sam, sak, sbk,
-                               sbn, ldc, relu, accumulate, slice);
+                               sbn, ldc, relu, accumulate, slice, avec, bvec);
         else
             hipLaunchKernelGGL(gemm_f32_oneshot_kernel<9>, g32, dim3(1024), 0, (hipStream_t)stream, a, b, bias, c, M, N, K, sam, sak, sbk,
-                               sbn, ldc, relu, accumulate, slice);
+                               sbn, ldc, relu, accumulate, slice, avec, bvec);
         AG2V_CHECK_LAUNCH();
         return AG2V_OK;
     }

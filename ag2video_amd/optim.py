@@ -24,16 +24,20 @@ class FusedAdam(torch.optim.Optimizer):
         if dev.type != 'cuda':
             raise RuntimeError("FusedAdam runs on the HIP device only (no CPU fallback); got %s" % dev)
         self._sizes = [p.numel() for p in ps]
-        total = sum(self._sizes)
-        self.flat_param = torch.empty(total, device=dev, dtype=torch.float32)
+        # every parameter starts on a 16-byte boundary (kernels read weights with 16-byte loads: the graph nets' GEMM, the weight
+        # packing); the <= 3 padding elements between parameters stay 0 in all four buffers (Adam maps 0, 0, 0, 0 to 0)
+        offs, total = [], 0
+        for n in self._sizes:
+            offs.append(total)
+            total += (n + 3) & ~3
+        self.flat_param = torch.zeros(total, device=dev, dtype=torch.float32)
         self.flat_grad = torch.zeros(total, device=dev, dtype=torch.float32)
         self.flat_m = torch.zeros(total, device=dev, dtype=torch.float32)
         self.flat_v = torch.zeros(total, device=dev, dtype=torch.float32)
         self._step = 0
-        off = 0
         self._views = []
         with torch.no_grad():
-            for p, n in zip(ps, self._sizes):
+            for p, n, off in zip(ps, self._sizes, offs):
                 if p.dtype != torch.float32:
                     raise RuntimeError("FusedAdam: fp32 parameters only")
                 pv = self.flat_param[off:off + n].view_as(p)
@@ -42,7 +46,6 @@ class FusedAdam(torch.optim.Optimizer):
                 gv = self.flat_grad[off:off + n].view_as(p)
                 p.grad = gv
                 self._views.append((off, n, gv))
-                off += n
 
     def _adopt_grads(self):
         """Make every .grad the flat view again (someone may have set it to None or replaced it)."""

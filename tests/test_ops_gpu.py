@@ -464,7 +464,8 @@ def test_upsample2x(device):
 
 
 @pytest.mark.parametrize("cfg", [(17, 516, 512, True, True), (136, 1152, 64, True, True), (88, 64, 4, False, True),
-                                 (5, 132, 70, True, False), (200, 128, 1152, True, True)], ids=str)
+                                 (5, 132, 70, True, False), (200, 128, 1152, True, True), (80, 512, 512, True, True),
+                                 (33, 1156, 40, False, True), (9, 130, 33, True, True), (128, 2048, 96, False, False)], ids=str)
 def test_linear(cfg, device):
     from ag2video_amd import ops
     from oracle import kernels as K
@@ -472,6 +473,31 @@ def test_linear(cfg, device):
     t = {'x': _rand(M, Kd, seed=1), 'w': _rand(N, Kd, seed=2, scale=Kd ** -0.5), 'b': _rand(N, seed=3) if bias else None,
          'relu': relu}
     _run_pair(ops.linear, K.linear, t, device, name='linear')
+
+
+def test_linear_unaligned_operands(device):
+    """The one-round-trip GEMM reads k-contiguous operands with 16-byte loads when their rows are 16-byte aligned and with 4-byte
+    loads otherwise (views into a flat buffer at any element offset): same results either way, forward and both gradients."""
+    from ag2video_amd import ops
+    from oracle import kernels as K
+    M, Kd, N = 80, 512, 128
+    x, w, b = _rand(M, Kd, seed=1), _rand(N, Kd, seed=2, scale=Kd ** -0.5), _rand(N, seed=3)
+    ref_in = [t.clone().requires_grad_(True) for t in (x, w, b)]
+    ref = K.linear(ref_in[0], ref_in[1], ref_in[2], True)
+    wgt = _rand(M, N, seed=4)
+    (ref * wgt).sum().backward()
+    for xo, wo in ((0, 0), (1, 0), (0, 2), (3, 1)):
+        xb = torch.zeros(M * Kd + 4, device=device); wb = torch.zeros(N * Kd + 4, device=device)
+        xd = xb[xo:xo + M * Kd].view(M, Kd); wd = wb[wo:wo + N * Kd].view(N, Kd)
+        xd.copy_(x); wd.copy_(w)
+        assert xd.data_ptr() % 16 == 4 * xo and wd.data_ptr() % 16 == 4 * wo
+        xd.requires_grad_(True); wd.requires_grad_(True)
+        bd = b.clone().to(device).requires_grad_(True)
+        got = ops.linear(xd, wd, bd, True)
+        _cmp('linear_unaligned.fwd', got, ref, TOL)
+        gx, gw, gb = torch.autograd.grad((got * wgt.to(device)).sum(), (xd, wd, bd))
+        for nm, g, r in (('x', gx, ref_in[0].grad), ('w', gw, ref_in[1].grad), ('b', gb, ref_in[2].grad)):
+            _cmp('linear_unaligned.grad_' + nm, g, r, TOL)
 
 
 def _edges(B, T, O, seed):
@@ -567,6 +593,12 @@ def test_fused_adam_matches_torch_adam(device):
     for a, b in zip(ref_p, gpu_p):
         _cmp('adam.param', b, a, 1e-5)
     assert gpu_p[1].data_ptr() >= opt.flat_param.data_ptr()
+    # every parameter (and gradient) view starts on a 16-byte boundary of the flat buffers; the padding stays zero
+    assert all(p.data_ptr() % 16 == 0 and p.grad.data_ptr() % 16 == 0 for p in gpu_p)
+    used = torch.zeros_like(opt.flat_param, dtype=torch.bool)
+    for off, n, _ in opt._views:
+        used[off:off + n] = True
+    assert float(opt.flat_param[~used].abs().sum()) == 0.0 and float(opt.flat_m[~used].abs().sum()) == 0.0
 
 
 def test_gradient_sinks_multi_use_and_aborted_backward(device):

@@ -13,7 +13,7 @@ for (M, N, K) in shapes:
     for mode in ('fwd', 'dx', 'dw'):
         torch.manual_seed(1)
         if mode == 'fwd':      # y = x w^T + b
-            x = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev); bias = torch.randn(N, device=dev)
+            x = torch.randn(M, K, device=dev); w = torch.randn(N * K + 2, device=dev)[2:].view(N, K); bias = torch.randn(N, device=dev)   # (w 8 bytes off a 16-byte boundary)
             y = torch.empty(M, N, device=dev)
             args = (P(x), P(w), P(bias), P(y), M, N, K, K, 1, 1, K, N, 1, 0)
             ref = torch.relu(x.double() @ w.double().t() + bias.double()).float()
