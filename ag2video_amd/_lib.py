@@ -30,6 +30,7 @@ _SIGS = {
     'ag2v_conv2d_dgrad_workspace_floats': (c_size_t, [c_int] * 9),
     'ag2v_conv2d_dgrad_ex': (c_int, [_P, _P, _P, _P] + [c_int] * 10 + [_P, c_size_t, _P, _P]),
     'ag2v_conv2d_wgrad_ex': (c_int, [_P, _P, _P] + [c_int] * 11 + [_P, _P]),
+    'ag2v_conv2d_split_input_ok': (c_int, [c_int] * 12),
     'ag2v_channel_sum': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     'ag2v_channel_sum_acc': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     'ag2v_bn_workspace_floats': (c_size_t, [c_int, c_int, c_int]),
@@ -38,6 +39,7 @@ _SIGS = {
     'ag2v_norm_bwd': (c_int, [c_int] + [_P] * 11 + [c_int, c_int, c_int, c_float, _P, _P]),
     'ag2v_bn_stats_g': (c_int, [_P, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P]),
     'ag2v_norm_apply_g': (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
+    'ag2v_norm_apply_gs': (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
     'ag2v_norm_bwd_g': (c_int, [c_int] + [_P] * 11 + [c_int, c_int, c_int, c_int, c_float, _P, _P]),
     'ag2v_norm_bwd_reduce_g': (c_int, [c_int] + [_P] * 7 + [c_int, c_int, c_int, c_int, c_float, _P, _P]),
     'ag2v_norm_bwd_apply_g': (c_int, [c_int] + [_P] * 8 + [c_float, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
@@ -94,7 +96,8 @@ EXPORTS = tuple(sorted(_SIGS))
 
 class ConvOpts(ctypes.Structure):
     """ag2v_conv_opts (include/ag2v.h): per-call options of the *_ex convolution entry points."""
-    _fields_ = [('precision', c_int), ('min_rows', c_int), ('gscale', c_void_p), ('group_n', c_int), ('kernel', c_char_p)]
+    _fields_ = [('precision', c_int), ('min_rows', c_int), ('gscale', c_void_p), ('group_n', c_int), ('kernel', c_char_p),
+                ('in_split', c_int)]
 
 _lib = None
 

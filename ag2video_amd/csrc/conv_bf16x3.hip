@@ -12,6 +12,7 @@
 // ds_write_b128 conflict-free), double-buffered; one workgroup barrier per K-tile.  The weight operand of the forward / data-
 // gradient kernel arrives pre-split (packed hi:lo words, k-major) from the prep kernels, so its in-kernel cost is two v_perm
 // per pair; activations are split in-kernel (v_cvt_pk_bf16_f32).  History and measurements: DESIGN.md 3.4.
+#include <type_traits>
 #include "conv_common.h"
 #include <stdlib.h>
 
@@ -19,6 +20,15 @@
 // per MFMA, the MFMA pipe 32 % busy, waves 51 % in s_waitcnt / barrier because every wave converts at the same time) is in the
 // history; here the two jobs sit on different waves of each SIMD, which the hardware runs concurrently (separate pipes), and
 // one workgroup barrier per K-tile hands the buffers over.
+// pair of split words -> (hi pair, lo pair) LDS words
+__device__ __forceinline__ void regroup2(float w0, float w1, unsigned& hi, unsigned& lo) {
+    hi = __builtin_amdgcn_perm(__float_as_uint(w1), __float_as_uint(w0), 0x07060302u);
+    lo = __builtin_amdgcn_perm(__float_as_uint(w1), __float_as_uint(w0), 0x05040100u);
+}
+template <bool PS>
+__device__ __forceinline__ void split_or_regroup(float x0, float x1, unsigned& hi, unsigned& lo) {
+    if constexpr (PS) regroup2(x0, x1, hi, lo); else split2(x0, x1, hi, lo);
+}
 #ifndef AG2V_LDK
 #define AG2V_LDK 40      // LDS row stride in bf16 elements (tools/ubench builds override it for layout experiments)
 #endif
@@ -28,8 +38,11 @@
 #ifndef AG2V_WIDE_MF16
 #define AG2V_WIDE_MF16 false
 #endif
-template <int BM, int BN, int CWM, int CWN, int NPW, bool MF16, bool TAPK, bool B4>
-__global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_kernel(ConvArgs p) {
+// PSB: the gathered tensor holds SPLIT WORDS already -- (bf16 hi << 16) | bf16 lo of each value, written by the kernel that
+// produced it (ag2v_norm_apply_g(out_split), pack_split()); the producers then only regroup halves (2 v_perm per pair instead
+// of the 6-instruction split).  Same products, same sums: results are bit-identical to the fp32-input kernel's.
+template <int BM, int BN, int CWM, int CWN, int NPW, bool MF16, bool TAPK, bool B4, bool PSB>
+__device__ __forceinline__ void igemm_bf16x3_body(const ConvArgs& p) {
     constexpr int BK = 32, LDK = AG2V_LDK, NP = NPW * 64;       // NP producer threads
     constexpr int TM = BM / CWM / 32, TN = BN / CWN / 32;  // consumer wave tile in 32x32 MFMA tiles
     constexpr int AP = NP / BM > 0 ? NP / BM : 1, AK = BK / AP;
@@ -273,20 +286,13 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
                     const int off = (j * GR + quad) * LDK + kpart * KPT;
                     if constexpr (KPT == 4) {
                         unsigned h0, l0, h1, l1;
-#ifdef AG2V_DIAG_PRESPLIT               // timing experiment only: input taken as packed hi:lo words
-                        h0 = __builtin_amdgcn_perm(__float_as_uint(rb[0][4 + j]), __float_as_uint(rb[0][j]), 0x07060302u);
-                        l0 = __builtin_amdgcn_perm(__float_as_uint(rb[0][4 + j]), __float_as_uint(rb[0][j]), 0x05040100u);
-                        h1 = __builtin_amdgcn_perm(__float_as_uint(rb[0][12 + j]), __float_as_uint(rb[0][8 + j]), 0x07060302u);
-                        l1 = __builtin_amdgcn_perm(__float_as_uint(rb[0][12 + j]), __float_as_uint(rb[0][8 + j]), 0x05040100u);
-#else
-                        split2(rb[0][j], rb[0][4 + j], h0, l0);
-                        split2(rb[0][8 + j], rb[0][12 + j], h1, l1);
-#endif
+                        split_or_regroup<PSB>(rb[0][j], rb[0][4 + j], h0, l0);
+                        split_or_regroup<PSB>(rb[0][8 + j], rb[0][12 + j], h1, l1);
                         *reinterpret_cast<uint2*>(&Bhi[buf][off]) = make_uint2(h0, h1);
                         *reinterpret_cast<uint2*>(&Blo[buf][off]) = make_uint2(l0, l1);
                     } else {      // 256 x 128 tile: 2 channels per thread
                         unsigned h0, l0;
-                        split2(rb[0][j], rb[0][4 + j], h0, l0);
+                        split_or_regroup<PSB>(rb[0][j], rb[0][4 + j], h0, l0);
                         *reinterpret_cast<unsigned*>(&Bhi[buf][off]) = h0;
                         *reinterpret_cast<unsigned*>(&Blo[buf][off]) = l0;
                     }
@@ -299,12 +305,7 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
                     unsigned h[4], l[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-#ifdef AG2V_DIAG_PRESPLIT               // timing experiment only (tools/ubench/igemm_stamps.hip): input taken as packed hi:lo
-                        h[i] = __builtin_amdgcn_perm(__float_as_uint(rb[c][8 * g + 2 * i + 1]), __float_as_uint(rb[c][8 * g + 2 * i]), 0x07060302u);
-                        l[i] = __builtin_amdgcn_perm(__float_as_uint(rb[c][8 * g + 2 * i + 1]), __float_as_uint(rb[c][8 * g + 2 * i]), 0x05040100u);
-#else
-                        split2(rb[c][8 * g + 2 * i], rb[c][8 * g + 2 * i + 1], h[i], l[i]);
-#endif
+                        split_or_regroup<PSB>(rb[c][8 * g + 2 * i], rb[c][8 * g + 2 * i + 1], h[i], l[i]);
                     }
                     const int off = (bcol0 + c * (BN / BCOLS)) * LDK + BKK * bpart + 8 * g;
                     *reinterpret_cast<uint4*>(&Bhi[buf][off]) = make_uint4(h[0], h[1], h[2], h[3]);
@@ -592,6 +593,15 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
         }
     }
 }
+template <int BM, int BN, int CWM, int CWN, int NPW, bool MF16, bool TAPK, bool B4>
+__global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_kernel(ConvArgs p) {
+    igemm_bf16x3_body<BM, BN, CWM, CWN, NPW, MF16, TAPK, B4, false>(p);
+}
+// the same tiles reading a split-word gathered tensor (ConvArgs::b_split)
+template <int BM, int BN, int CWM, int CWN, int NPW, bool MF16, bool TAPK, bool B4>
+__global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ps_kernel(ConvArgs p) {
+    igemm_bf16x3_body<BM, BN, CWM, CWN, NPW, MF16, TAPK, B4, true>(p);
+}
 
 // Weight gradient: dW[m,j] = sum_q dY[m,q] * Xg[q,j], q = (n,oy,ox), j = (c,r,s).  Both operands are activations (split
 // in-kernel).  General form (any stride / width): a producer thread owns one PAIR of consecutive pixels q for a set of rows of dY
@@ -794,8 +804,8 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_ws_k
 // for the hi and the lo image each -- against 8 dword loads and 8 ds_write_b32 in conv_wgrad_bf16x3_ws_kernel.  Only the first /
 // last element of a run can fall outside the image (pad <= 8 - ... checked by the launcher: pad <= S - 1 <= 7); such runs are
 // flagged per K-tile by the table builder and patched after the load.
-template <int BM, int BN, int CWM, int CWN, int NPW, bool MF16>
-__global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_v_kernel(ConvArgs p) {
+template <int BM, int BN, int CWM, int CWN, int NPW, bool MF16, bool PSX>
+__device__ __forceinline__ void wgrad_bf16x3_v_body(const ConvArgs& p) {
     constexpr int BK = 32, LDK = 40, NP = NPW * 64;
     constexpr int TM = BM / CWM / 32, TN = BN / CWN / 32;
     constexpr int RPT = NP / 4;                       // rows covered by one pass of the producer threads (4 runs of 8 q per row)
@@ -908,19 +918,20 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_v_ke
                 rb[i][1] = bload_u32x4(brs, off + 16u);
             }
         };
-        auto store_row = [&](unsigned short* hi_img, unsigned short* lo_img, int r, const u32x4 (&v)[2]) {
+        auto store_row = [&](auto ps, unsigned short* hi_img, unsigned short* lo_img, int r, const u32x4 (&v)[2]) {
+            constexpr bool PS = decltype(ps)::value;
             unsigned h[4], l[4];
-            split2(__uint_as_float(v[0][0]), __uint_as_float(v[0][1]), h[0], l[0]);
-            split2(__uint_as_float(v[0][2]), __uint_as_float(v[0][3]), h[1], l[1]);
-            split2(__uint_as_float(v[1][0]), __uint_as_float(v[1][1]), h[2], l[2]);
-            split2(__uint_as_float(v[1][2]), __uint_as_float(v[1][3]), h[3], l[3]);
+            split_or_regroup<PS>(__uint_as_float(v[0][0]), __uint_as_float(v[0][1]), h[0], l[0]);
+            split_or_regroup<PS>(__uint_as_float(v[0][2]), __uint_as_float(v[0][3]), h[1], l[1]);
+            split_or_regroup<PS>(__uint_as_float(v[1][0]), __uint_as_float(v[1][1]), h[2], l[2]);
+            split_or_regroup<PS>(__uint_as_float(v[1][2]), __uint_as_float(v[1][3]), h[3], l[3]);
             const int off = r * LDK + 8 * run;
             *reinterpret_cast<uint4*>(&hi_img[off]) = make_uint4(h[0], h[1], h[2], h[3]);
             *reinterpret_cast<uint4*>(&lo_img[off]) = make_uint4(l[0], l[1], l[2], l[3]);
         };
         auto stash = [&](int buf, const u32x4 (&ra)[NA][2], u32x4 (&rb)[NB][2], int fixw, int fixx, int shw) {
 #pragma unroll
-            for (int i = 0; i < NA; ++i) store_row(Ahi[buf], Alo[buf], row + RPT * i, ra[i]);
+            for (int i = 0; i < NA; ++i) store_row(std::false_type{}, Ahi[buf], Alo[buf], row + RPT * i, ra[i]);
             if (__builtin_expect(shw != 0, 0)) {   // rows loaded from element 0 instead of element -sh: move them up by sh places
 #pragma unroll
                 for (int i = 0; i < NB; ++i) {
@@ -943,7 +954,7 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_v_ke
                 }
             }
 #pragma unroll
-            for (int i = 0; i < NB; ++i) store_row(Bhi[buf], Blo[buf], row + RPT * i, rb[i]);
+            for (int i = 0; i < NB; ++i) store_row(std::integral_constant<bool, PSX>{}, Bhi[buf], Blo[buf], row + RPT * i, rb[i]);
         };
         u32x4 ra0[NA][2], ra1[NA][2], rb0[NB][2], rb1[NB][2];
         int fw0, fx0, fw1, fx1, sh0, sh1;
@@ -1041,6 +1052,15 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_v_ke
         }
     }
 }
+template <int BM, int BN, int CWM, int CWN, int NPW, bool MF16>
+__global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_v_kernel(ConvArgs p) {
+    wgrad_bf16x3_v_body<BM, BN, CWM, CWN, NPW, MF16, false>(p);
+}
+// x (ConvArgs::b_src) holds split words (ConvArgs::b_split)
+template <int BM, int BN, int CWM, int CWN, int NPW, bool MF16>
+__global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_vps_kernel(ConvArgs p) {
+    wgrad_bf16x3_v_body<BM, BN, CWM, CWN, NPW, MF16, true>(p);
+}
 
 // ================================================================ launchers
 // One 16-wave workgroup occupies a CU (124 KB LDS), so a launch runs in rounds of 256 workgroups.  Pick the number of K-range
@@ -1086,8 +1106,13 @@ int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed) {
 #define AG2V_STR(...) AG2V_STR_(__VA_ARGS__)
 #define AG2V_LAUNCH_IGEMM(...)                                                                          \
     do {                                                                                               \
-        set_last_conv_kernel("conv_igemm_bf16x3_ws_kernel<" AG2V_STR(__VA_ARGS__) ">");                \
-        hipLaunchKernelGGL((conv_igemm_bf16x3_ws_kernel<__VA_ARGS__>), grid, dim3(1024), 0, st, a);    \
+        if (a.b_split) {                                                                               \
+            set_last_conv_kernel("conv_igemm_bf16x3_ps_kernel<" AG2V_STR(__VA_ARGS__) ">");            \
+            hipLaunchKernelGGL((conv_igemm_bf16x3_ps_kernel<__VA_ARGS__>), grid, dim3(1024), 0, st, a); \
+        } else {                                                                                       \
+            set_last_conv_kernel("conv_igemm_bf16x3_ws_kernel<" AG2V_STR(__VA_ARGS__) ">");            \
+            hipLaunchKernelGGL((conv_igemm_bf16x3_ws_kernel<__VA_ARGS__>), grid, dim3(1024), 0, st, a); \
+        }                                                                                              \
     } while (0)
     // quad loads of the gathered operand on the 128 x 256 tile: stride-1 launches whose pixel rows are whole quads
     // (AG2V_NO_B4: A/B aid).  The 256 x 128 tile (8 of its 12 loads gather) was 4 % slower with them.
@@ -1144,7 +1169,15 @@ int launch_wgrad_bf16x3(ConvArgs& a, hipStream_t st) {
     if (a.stride == 1 && a.OW % 8 == 0 && a.W >= 8 && a.a_bytes <= 0x80000000u && a.pad <= 3 &&
         getenv("AG2V_WGRAD_SCALAR_LOADS") == nullptr) {
         // 16-byte loads along the pixel index (runs of 8 pixels never straddle an image row)
-        if (tall) {
+        if (a.b_split) {       // x as split words: the 32x32x16 forms
+            if (tall) {
+                set_last_conv_kernel("conv_wgrad_bf16x3_vps_kernel<256, 128, 4, 2, 8, false>");
+                hipLaunchKernelGGL((conv_wgrad_bf16x3_vps_kernel<256, 128, 4, 2, 8, false>), grid, dim3(1024), 0, st, a);
+            } else {
+                set_last_conv_kernel("conv_wgrad_bf16x3_vps_kernel<128, 256, 2, 4, 8, false>");
+                hipLaunchKernelGGL((conv_wgrad_bf16x3_vps_kernel<128, 256, 2, 4, 8, false>), grid, dim3(1024), 0, st, a);
+            }
+        } else if (tall) {
             if (wgrad32) {
                 set_last_conv_kernel("conv_wgrad_bf16x3_v_kernel<256, 128, 4, 2, 8, false>");
                 hipLaunchKernelGGL((conv_wgrad_bf16x3_v_kernel<256, 128, 4, 2, 8, false>), grid, dim3(1024), 0, st, a);
@@ -1162,6 +1195,7 @@ int launch_wgrad_bf16x3(ConvArgs& a, hipStream_t st) {
             }
         }
     } else {
+        if (a.b_split) return AG2V_EINVAL;      // only the 16-byte-load kernels read split words (wgrad_split_input_ok())
         if (tall) {
             set_last_conv_kernel("conv_wgrad_bf16x3_ws_kernel<256, 128, 4, 2, 8>");
             hipLaunchKernelGGL((conv_wgrad_bf16x3_ws_kernel<256, 128, 4, 2, 8>), grid, dim3(1024), 0, st, a);

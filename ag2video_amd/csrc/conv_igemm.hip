@@ -507,11 +507,13 @@ struct ag2v_conv_opts {
     const float* gscale;
     int group_n;
     const char* kernel;
+    int in_split;
 };
 struct ConvCfg {
     int precision, min_rows;
     const float* gscale;
     int group_n;
+    int in_split;
 };
 static ConvCfg conv_cfg(const ag2v_conv_opts* o) {
     ConvCfg c;
@@ -519,6 +521,7 @@ static ConvCfg conv_cfg(const ag2v_conv_opts* o) {
     c.min_rows = (o && o->min_rows > 0) ? o->min_rows : bf16x3_min_rows();
     c.gscale = o ? o->gscale : nullptr;
     c.group_n = (o && o->group_n > 0) ? o->group_n : 1;
+    c.in_split = (o && o->in_split) ? 1 : 0;
     return c;
 }
 static bool use_bf16x3(const ConvCfg& c, int M) { return c.precision == 1 && M >= c.min_rows; }
@@ -789,6 +792,7 @@ extern "C" int ag2v_conv2d_fwd_ex(const float* x, const float* w, const float* b
         nmax = chunk_samples(xs * 4, 0, cfg.gscale ? cfg.group_n : 1);
         if (nmax <= 0) { split = false; nmax = N; }
     }
+    if (cfg.in_split && !split) return AG2V_EINVAL;        // split words are only read by the bf16x3 kernels (ag2v_conv2d_split_input_ok)
     if ((long long)nmax * OH * OW >= (1LL << 31)) {         // the GEMM's pixel index is a 32-bit int
         nmax = (int)(((1LL << 31) - 1) / ((long long)OH * OW));
         if (cfg.gscale) nmax -= nmax % cfg.group_n;
@@ -812,6 +816,7 @@ extern "C" int ag2v_conv2d_fwd_ex(const float* x, const float* w, const float* b
         a.a_bytes = (unsigned)abytes; a.b_bytes = split ? (unsigned)(xs * 4 * nc) : 0u;
         a.tap_major = tapmaj ? 1 : 0;
         a.a_src = workspace;
+        a.b_split = cfg.in_split;
         const int rc = launch_igemm(a, st, false, split);
         if (rc != AG2V_OK) return rc;
     }
@@ -966,9 +971,11 @@ extern "C" int ag2v_conv2d_dgrad(const float* dy, const float* w, float* dx,
 // gradient in one buffer.  groups > 1 (N % groups == 0): the batch is `groups` consecutive sample groups and dw is
 // [groups][K, C, R, S] -- one gradient per group (the frame-batched generator needs dL/dWbar_t per frame t for spectral norm).
 static int wgrad_launch(const float* dy, const float* x, float* dw, int N, int C, int H, int W, int K, int R, int S, int OH, int OW,
-                        int stride, int pad, int accumulate, int groups, bool split, hipStream_t st) {
+                        int stride, int pad, int accumulate, int groups, bool split, hipStream_t st, int x_split = 0) {
     ConvArgs a{};
     a.a_src = dy; a.b_src = x; a.out = dw; a.accumulate = accumulate ? 1 : 0;
+    a.b_split = x_split;
+    if (x_split && !split) return AG2V_EINVAL;
     a.N = N; a.C = C; a.H = H; a.W = W; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.pad_w = pad;
     a.OH = OH; a.OW = OW;
     const long long Q = (long long)N * OH * OW;
@@ -1036,11 +1043,33 @@ extern "C" int ag2v_conv2d_wgrad_ex(const float* dy, const float* x, float* dw, 
         float* out = (groups > 1) ? dw + (size_t)g0 * wsz : dw;
         const int acc = (groups > 1) ? accumulate : (accumulate || n0 > 0);
         const int rc = wgrad_launch(dy + (size_t)n0 * dys, x + (size_t)n0 * xs, out, nc, C, H, W, K, R, S, OH, OW, stride, pad, acc, gc,
-                                    split, st);
+                                    split, st, cfg.in_split);
         if (rc != AG2V_OK) return rc;
     }
     if (o) o->kernel = g_last_conv_kernel;
     return AG2V_OK;
+}
+// 1 when a convolution of this shape can take its INPUT x as split words (ag2v_conv_opts::in_split) in the forward pass and in
+// the weight gradient with these options: both passes on the bf16x3 kernels (rows >= min_rows, precision), the weight gradient on
+// the 16-byte-load kernels (the only ones with a split-word x path).  Callers decide the format of an activation tensor with
+// this before they produce it (ag2v_norm_apply_g(out_split)); a call that cannot honour in_split returns AG2V_EINVAL.
+extern "C" int ag2v_conv2d_split_input_ok(int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int min_rows_fwd,
+                                          int min_rows_bwd, int precision) {
+    if (N <= 0 || C <= 0 || K <= 0 || stride <= 0 || R * S > 16) return 0;
+    ag2v_conv_opts of{}; of.precision = precision; of.min_rows = min_rows_fwd;
+    ag2v_conv_opts ob{}; ob.precision = precision; ob.min_rows = min_rows_bwd;
+    const ConvCfg cf = conv_cfg(&of), cb = conv_cfg(&ob);
+    const int OH = conv_out_dim(H, R, stride, pad), OW = conv_out_dim(W, S, stride, pad);
+    if (OH <= 0 || OW <= 0) return 0;
+    const int KG = C * R * S;
+    const long long abytes = (long long)KG * K * 4, xs = (long long)C * H * W, dys = (long long)K * OH * OW;
+    static const bool short_exact = getenv("AG2V_NO_SHORT_K_EXACT") == nullptr;
+    if (!(use_bf16x3(cf, K) && abytes < kBufMax && !(short_exact && KG < 64 && K < 128))) return 0;        // forward (ag2v_conv2d_fwd_ex)
+    if (xs * 4 > chunk_limit()) return 0;                                                                   // one sample must fit a launch
+    if (!use_bf16x3(cb, K)) return 0;                                                                      // weight gradient
+    if (dys * 8 > chunk_limit() && dys * 4 > chunk_limit()) return 0;
+    if (!(stride == 1 && OW % 8 == 0 && W >= 8 && pad <= 3) || getenv("AG2V_WGRAD_SCALAR_LOADS") != nullptr) return 0;
+    return 1;
 }
 extern "C" int ag2v_conv2d_wgrad_acc(const float* dy, const float* x, float* dw, int N, int C, int H, int W, int K, int R, int S,
                                      int stride, int pad, int accumulate, void* stream) {

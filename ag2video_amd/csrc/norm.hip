@@ -8,6 +8,7 @@
 // All tensors NCHW fp32 contiguous.  One workgroup owns one <=4096-element chunk of one (n,c) plane, so the
 // per-channel parameters are scalars and every access is a coalesced float4 (or dword when H*W % 4 != 0).
 #include "common.h"
+#include "conv_common.h"   // pack_split()
 
 #define CHUNK 4096  // elements per workgroup (16 per thread)
 
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
                                                          const float* __restrict__ invstd, const float* __restrict__ w,
                                                          const float* __restrict__ b, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* __restrict__ y, int C,
-                                                         int HW, int nchunk, float slope, long long gbx, int Ng) {
+                                                         int HW, int nchunk, float slope, long long gbx, int Ng, int out_split) {
     const int bid = blockIdx.x;
     const int chunk = bid % nchunk, nc = bid / nchunk;
     const int c = nc % C;
@@ -177,6 +178,10 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
         const float sc = is * (w ? w[c] : 1.f), sh = b ? b[c] : 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = lrelu_f((v[i] - mu) * sc + sh, slope);
+    }
+    if (out_split) {        // the output is read by bf16x3 convolutions only: store it as split words (conv_common.h pack_split)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = pack_split(v[i]);
     }
     store16<VEC>(y + off, cnt, v);
 }
@@ -616,9 +621,12 @@ extern "C" int ag2v_bn_stats(const float* x, int N, int C, int HW, float eps, fl
 
 // mode 0: y = lrelu((x-mean)*invstd*w + b) (w/b may be null); mode 1: y = lrelu(xhat*(1+gamma)+beta). slope 1 => no activation.
 // mean / invstd are [N / Ng, C]: sample n uses row n / Ng.
-extern "C" int ag2v_norm_apply_g(int mode, const float* x, const float* mean, const float* invstd, const float* w, const float* b,
-                                 const float* gamma, const float* beta, float* y, int N, int C, int HW, int Ng, float slope,
-                                 void* stream) {
+// out_split != 0: y is written as split words, (bf16(v) << 16) | bf16(v - bf16(v)) per value -- the form the bf16x3 convolution
+// kernels otherwise compute from fp32 in their producers (ag2v_conv_opts::in_split).  A sign test on such a word (the backward
+// pass reads y for the LeakyReLU branch) is a sign test on v.
+extern "C" int ag2v_norm_apply_gs(int mode, const float* x, const float* mean, const float* invstd, const float* w, const float* b,
+                                  const float* gamma, const float* beta, float* y, int N, int C, int HW, int Ng, float slope,
+                                  int out_split, void* stream) {
     if (!x || !mean || !invstd || !y || N <= 0 || C <= 0 || HW <= 0 || Ng <= 0 || N % Ng != 0) return AG2V_EINVAL;
     if (mode < 0 || mode > 2 || (mode >= 1 && (!gamma || !beta))) return AG2V_EINVAL;
     hipStream_t st = (hipStream_t)stream;
@@ -629,14 +637,19 @@ extern "C" int ag2v_norm_apply_g(int mode, const float* x, const float* mean, co
     const long long gbx = (mode == 2) ? (long long)C * HW : 0;   // mode 2: gamma / beta are the halves of one [N,2C,HW] tensor
     dim3 g((unsigned)nblk), t(256);
     if (mode == 0) {
-        if (v) hipLaunchKernelGGL((norm_apply_kernel<0, true>), g, t, 0, st, x, mean, invstd, w, b, gamma, beta, y, C, HW, nchunk, slope, gbx, Ng);
-        else hipLaunchKernelGGL((norm_apply_kernel<0, false>), g, t, 0, st, x, mean, invstd, w, b, gamma, beta, y, C, HW, nchunk, slope, gbx, Ng);
+        if (v) hipLaunchKernelGGL((norm_apply_kernel<0, true>), g, t, 0, st, x, mean, invstd, w, b, gamma, beta, y, C, HW, nchunk, slope, gbx, Ng, out_split ? 1 : 0);
+        else hipLaunchKernelGGL((norm_apply_kernel<0, false>), g, t, 0, st, x, mean, invstd, w, b, gamma, beta, y, C, HW, nchunk, slope, gbx, Ng, out_split ? 1 : 0);
     } else {
-        if (v) hipLaunchKernelGGL((norm_apply_kernel<1, true>), g, t, 0, st, x, mean, invstd, w, b, gamma, beta, y, C, HW, nchunk, slope, gbx, Ng);
-        else hipLaunchKernelGGL((norm_apply_kernel<1, false>), g, t, 0, st, x, mean, invstd, w, b, gamma, beta, y, C, HW, nchunk, slope, gbx, Ng);
+        if (v) hipLaunchKernelGGL((norm_apply_kernel<1, true>), g, t, 0, st, x, mean, invstd, w, b, gamma, beta, y, C, HW, nchunk, slope, gbx, Ng, out_split ? 1 : 0);
+        else hipLaunchKernelGGL((norm_apply_kernel<1, false>), g, t, 0, st, x, mean, invstd, w, b, gamma, beta, y, C, HW, nchunk, slope, gbx, Ng, out_split ? 1 : 0);
     }
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
+}
+extern "C" int ag2v_norm_apply_g(int mode, const float* x, const float* mean, const float* invstd, const float* w, const float* b,
+                                 const float* gamma, const float* beta, float* y, int N, int C, int HW, int Ng, float slope,
+                                 void* stream) {
+    return ag2v_norm_apply_gs(mode, x, mean, invstd, w, b, gamma, beta, y, N, C, HW, Ng, slope, 0, stream);
 }
 extern "C" int ag2v_norm_apply(int mode, const float* x, const float* mean, const float* invstd, const float* w, const float* b,
                                const float* gamma, const float* beta, float* y, int N, int C, int HW, float slope, void* stream) {

@@ -96,7 +96,9 @@ class Layout2VidGenerator(nn.Module):
                 y = layout_conv_lowrank(w[:, :nseg], vecs_list, boxes_list, keep_t, H, H, conv.stride, conv.padding,
                                         sample_scale=scales.repeat_interleave((T * B) // scales.numel()),
                                         img=warp, w_img=w[:, nseg:], gscale=scales)
-                x = bn(y, slope=0.2)
+                # the normalised layout features are read by convolutions only (every SPADE's mlp_shared at its resolution, netG.fc):
+                # stored as split words when all of them run on the bf16x3 kernels (their producers then skip the fp32 split)
+                x = bn(y, slope=0.2, out_split=self.netG.layout_split_ok(y.shape[0], y.shape[1], H, H))
                 out = self.netG(x) + warp
         out = out.view(T, B, out.size(1), H, H)
         flow = flow.view(T, B, 2, H, H)

@@ -41,6 +41,25 @@ class SPADEGenerator(nn.Module):
         n_up = {'normal': 5, 'more': 6, 'most': 7}[self.opt.num_upsampling_layers]
         return [(self.sh << i, self.sw << i) for i in range(n_up + 1)]
 
+    def layout_split_ok(self, N, C, H, W):
+        """Whether the layout features [N, C, H, W] may be handed to forward() as split words (ops.is_split): every reader -- the
+        mlp_shared convolution of each SPADE at each resolution and the first convolution self.fc -- must take them in its forward
+        pass and its weight gradient under the arithmetic settings in force (ops.conv_split_input_ok)."""
+        from .normalization import SPADE
+        shared = set()
+        for m in self.modules():
+            if isinstance(m, SPADE):
+                conv = m.mlp_shared[0]
+                shared.add((tuple(conv.weight.shape), int(conv.stride[0] if isinstance(conv.stride, tuple) else conv.stride),
+                            int(conv.padding[0] if isinstance(conv.padding, tuple) else conv.padding)))
+        for (h, w) in self.pyramid_sizes(H, W):
+            for wshape, st, pad in shared:
+                if not ops.conv_split_input_ok((N, C, h, w), wshape, st, pad):
+                    return False
+        fc = self.fc
+        wshape = tuple((fc.weight_orig if hasattr(fc, 'weight_orig') else fc.weight).shape)
+        return ops.conv_split_input_ok((N, C, self.sh, self.sw), wshape, 1, 1)
+
     def forward(self, layout):
         layout = SegmapPyramid(layout, self.pyramid_sizes(layout.shape[2], layout.shape[3]))
         x = layout.at(self.sh, self.sw)

@@ -40,10 +40,11 @@ class SynchronizedBatchNorm2d(nn.Module):
         self.register_buffer('running_var', torch.ones(num_features))
         self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
 
-    def forward(self, x, slope=1.0):
+    def forward(self, x, slope=1.0, out_split=False):
         # inside ops.frame_groups(T): statistics per frame group, T running-stat updates in order (see ops.frame_groups)
+        # out_split: the result as split words for bf16x3 convolutions (ops.batchnorm_act)
         return ops.batchnorm_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
-                                 self.momentum, self.eps, slope, groups=ops.current_frame_groups())
+                                 self.momentum, self.eps, slope, groups=ops.current_frame_groups(), out_split=out_split)
 
     def modulate(self, x, gamma, beta, slope=1.0):
         """SPADE use: normalise without affine and apply (1+gamma), beta in the same pass."""

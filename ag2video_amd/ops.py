@@ -4,6 +4,7 @@ PyTorch supplies device memory, the current HIP stream and the autograd tape; al
 in the hand-written gfx950 kernels of ag2video_amd/csrc.  Every operator requires CUDA(HIP) fp32 tensors and raises
 otherwise -- there is no CPU path in the product (tests/ check these operators against oracle/ on the GPU).
 """
+import contextlib
 import ctypes
 import os
 import weakref
@@ -54,6 +55,17 @@ def set_conv_precision(name):
 
 def get_conv_precision():
     return {v: k for k, v in _PRECISIONS.items()}[_PRECISION[0]]
+
+
+@contextlib.contextmanager
+def conv_precision(name):
+    """set_conv_precision for the duration of a with block."""
+    old = _PRECISION[0]
+    _PRECISION[0] = _PRECISIONS[name]
+    try:
+        yield
+    finally:
+        _PRECISION[0] = old
 
 
 # ---- optional per-launch timing of the convolution kernels (bench.py's roofline leg): HIP events on the launch stream
@@ -142,11 +154,11 @@ def _conv_label(mode, M, min_rows=None):
     return "conv_%s" % mode
 
 
-def _conv_launch(min_rows, name, label, flops, *args, shape=None, gscale=None, group_n=1):
+def _conv_launch(min_rows, name, label, flops, *args, shape=None, gscale=None, group_n=1, in_split=False):
     """One ag2v_conv2d_*_ex call.  Arithmetic (precision, bf16x3 row threshold: ``min_rows``, None = library default) and the
     per-sample-group output scale travel as per-call options (ag2v_conv_opts): no process-wide switch is touched."""
     opts = _lib.ConvOpts(_PRECISION[0], int(min_rows) if min_rows else 0, None if gscale is None else gscale.data_ptr(),
-                         int(group_n), None)
+                         int(group_n), None, 1 if in_split else 0)
     args = args + (ctypes.byref(opts),)
     if _TIMING is None or _PAUSED:
         _lib.call(name, *args)
@@ -311,13 +323,13 @@ def _wsink_take_group(keys, likes):
 
 
 # ------------------------------------------------------------------------------------------------ convolution
-def _conv_fwd_launch(mr, x, w, bias, residual, y, stride, pad, relu, gscale=None, group_n=1):
+def _conv_fwd_launch(mr, x, w, bias, residual, y, stride, pad, relu, gscale=None, group_n=1, in_split=False):
     N, C, H, W = x.shape
     K, _, R, S = w.shape
     ws = torch.empty(_lib.query('ag2v_conv2d_workspace_floats', C, K, R, S), device=x.device, dtype=torch.float32)
     _conv_launch(mr, 'ag2v_conv2d_fwd_ex', 'conv_fwd', 2.0 * N * K * y.shape[2] * y.shape[3] * C * R * S,
                  _ptr(x), _ptr(w), _ptr(bias), _ptr(residual), _ptr(y), N, C, H, W, K, R, S, stride, pad, 1 if relu else 0,
-                 _ptr(ws), _stream(), shape=(N, C, H, W, K, R, stride), gscale=gscale, group_n=group_n)
+                 _ptr(ws), _stream(), shape=(N, C, H, W, K, R, stride), gscale=gscale, group_n=group_n, in_split=in_split)
 
 
 def _conv_dgrad_launch(mr, dy, w, mask, dx, stride, pad, acc, gscale=None, group_n=1):
@@ -332,12 +344,12 @@ def _conv_dgrad_launch(mr, dy, w, mask, dx, stride, pad, acc, gscale=None, group
                  shape=(N, C, H, W, K, R, stride), gscale=gscale, group_n=group_n)
 
 
-def _conv_wgrad_launch(mr, dy, x, dw, K, R, S, stride, pad, acc, groups=1):
+def _conv_wgrad_launch(mr, dy, x, dw, K, R, S, stride, pad, acc, groups=1, in_split=False):
     """dw (+)= weight gradient; groups > 1: dw is [groups, K, C, R, S], one gradient per group of N / groups samples."""
     N, C, H, W = x.shape
     _conv_launch(mr, 'ag2v_conv2d_wgrad_ex', 'conv_wgrad', 2.0 * N * K * dy.shape[2] * dy.shape[3] * C * R * S,
                  _ptr(dy), _ptr(x), _ptr(dw), N, C, H, W, K, R, S, stride, pad, 1 if acc else 0, int(groups), _stream(),
-                 shape=(N, C, H, W, K, R, stride))
+                 shape=(N, C, H, W, K, R, stride), in_split=in_split)
 
 
 class _Conv2d(torch.autograd.Function):
@@ -349,7 +361,7 @@ class _Conv2d(torch.autograd.Function):
     frame-batched generator (w = weight_orig, gscale = 1 / sigma_t of frame group t: spectral_scales)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, residual, gscale, stride, pad, relu, grad_premasked, relu_input):
+    def forward(ctx, x, w, bias, residual, gscale, stride, pad, relu, grad_premasked, relu_input, x_split=False):
         w_in, bias_in = w, bias
         x, w, bias, residual, gscale = _c(x), _c(w), _c(bias), _c(residual), _c(gscale)
         _chk(x, w, bias, residual, gscale)
@@ -366,9 +378,10 @@ class _Conv2d(torch.autograd.Function):
         OW = (W + 2 * pad - S) // stride + 1
         y = torch.empty((N, K, OH, OW), device=x.device, dtype=torch.float32)
         mr_f, mr = _current_min_rows()
-        _conv_fwd_launch(mr_f, x, w, bias, residual, y, stride, pad, relu, gscale, group_n)
+        _conv_fwd_launch(mr_f, x, w, bias, residual, y, stride, pad, relu, gscale, group_n, in_split=x_split)
         ctx.save_for_backward(x, w, y if (relu and not grad_premasked) else None, gscale)
         ctx.cfg = (stride, pad, bias is not None, residual is not None, mr, relu, grad_premasked, relu_input, group_n)
+        ctx.x_split = bool(x_split)
         ctx.wkey = _wsink_register(w_in) if ctx.needs_input_grad[1] else None
         ctx.bkey = _wsink_register(bias_in) if (bias_in is not None and ctx.needs_input_grad[2] and _EXTRA_SINKS) else None
         ctx.w_alive = (w_in, bias_in)   # the registry keys on id(): keep the objects alive as long as this node, or a temporary
@@ -395,7 +408,7 @@ class _Conv2d(torch.autograd.Function):
             # per-group weight gradients G_t = dL/d(scale_t W), then dw = sum_t scale_t G_t and dscale_t = <G_t, W> in one pass
             T = gscale.numel()
             G = torch.empty((T,) + tuple(w.shape), device=dy.device, dtype=torch.float32)
-            _conv_wgrad_launch(mr, dy, x, G, K, R, S, stride, pad, 0, groups=T)
+            _conv_wgrad_launch(mr, dy, x, G, K, R, S, stride, pad, 0, groups=T, in_split=ctx.x_split)
             buf, acc, dw = _wsink_take(ctx.wkey, w) if ctx.needs_input_grad[1] else (torch.empty_like(w), 0, None)
             dgs = torch.empty(T, device=dy.device, dtype=torch.float32)
             _lib.call('ag2v_sn_group_combine', _ptr(G), _ptr(w), _ptr(gscale), T, w.numel(), _ptr(buf), acc, _ptr(dgs), st)
@@ -404,7 +417,7 @@ class _Conv2d(torch.autograd.Function):
         elif ctx.needs_input_grad[1]:
             buf, acc, dw = _wsink_take(ctx.wkey, w)
             if (_SWAP_FEW_WGRAD and K <= 4 and stride == 1 and dy.shape[2] == H and dy.shape[3] == W and C >= 16 and R == S
-                    and 2 * pad == R - 1):
+                    and 2 * pad == R - 1 and not ctx.x_split):
                 # <= 4 output channels (conv_img, the flow / mask heads), same-size convolution: as a GEMM this has 3 rows on a
                 # 32-row tile and gathers x once per tap column (0.38 ms at 8 x 64 x 256 x 256).  With the operands swapped --
                 # x takes dy's role (C dense rows, read once with 16-byte loads), dy is the gathered 3-channel tensor --
@@ -417,7 +430,7 @@ class _Conv2d(torch.autograd.Function):
                 else:
                     buf.copy_(t)
             else:
-                _conv_wgrad_launch(mr, dy, x, buf, K, R, S, stride, pad, acc)
+                _conv_wgrad_launch(mr, dy, x, buf, K, R, S, stride, pad, acc, in_split=ctx.x_split)
         if has_bias and ctx.needs_input_grad[2]:
             bbuf, bacc, db = _wsink_take(ctx.bkey, ctx.w_alive[1])
             pre = getattr(dy_in, '_ag2v_channel_sums', None) if not (relu and not grad_premasked) else None
@@ -430,7 +443,7 @@ class _Conv2d(torch.autograd.Function):
                 _lib.call('ag2v_channel_sum_acc', _ptr(dy), _ptr(bbuf), N, K, dy.shape[2] * dy.shape[3], bacc, st)
         if has_res and ctx.needs_input_grad[3]:
             dres = dy
-        return dx, dw, db, dres, dgs, None, None, None, None, None
+        return dx, dw, db, dres, dgs, None, None, None, None, None, None
 
 
 def conv2d(x, w, bias=None, stride=1, pad=0, residual=None, relu=False, grad_premasked=False, relu_input=False, gscale=None):
@@ -438,7 +451,29 @@ def conv2d(x, w, bias=None, stride=1, pad=0, residual=None, relu=False, grad_pre
     grad_premasked / relu_input: see _Conv2d (the pair fuses the ReLU's backward into the consumer's data gradient)."""
     if relu and residual is not None and grad_premasked:
         raise RuntimeError("conv2d: grad_premasked with a residual input is not supported (the residual's gradient would be masked)")
-    return _Conv2d.apply(x, w, bias, residual, gscale, int(stride), int(pad), bool(relu), bool(grad_premasked), bool(relu_input))
+    return _Conv2d.apply(x, w, bias, residual, gscale, int(stride), int(pad), bool(relu), bool(grad_premasked), bool(relu_input),
+                         is_split(x))
+
+
+def is_split(t):
+    """True when t holds split words (bf16 hi | bf16 lo per value: ag2v_conv_opts::in_split) instead of fp32 -- a tensor written by
+    batchnorm_act(..., out_split=True) or a nearest-neighbour resize of one; only bf16x3 convolutions may read it."""
+    return bool(getattr(t, '_ag2v_split', False))
+
+
+def mark_split(t):
+    t._ag2v_split = True
+    return t
+
+
+def conv_split_input_ok(x_shape, w_shape, stride, pad):
+    """Whether a convolution of this shape, called under the CURRENT arithmetic settings (conv precision, bf16x3_min_rows
+    context), can read its input as split words in the forward pass and the weight gradient."""
+    N, C, H, W = [int(v) for v in x_shape]
+    K, _, R, S = [int(v) for v in w_shape]
+    mr_f, mr_b = _current_min_rows()
+    return bool(_lib.query('ag2v_conv2d_split_input_ok', N, C, H, W, K, R, S, int(stride), int(pad), int(mr_f or 0), int(mr_b or 0),
+                           _PRECISION[0])) and os.environ.get('AG2V_NO_SPLIT_ACT') is None
 
 
 class _ConvSharedInput(torch.autograd.Function):
@@ -448,10 +483,10 @@ class _ConvSharedInput(torch.autograd.Function):
     full-size tensor per branch and summing them pairwise."""
 
     @staticmethod
-    def forward(ctx, x, stride, pad, relu, grad_premasked, *wb):
+    def forward(ctx, x, stride, pad, relu, grad_premasked, x_split, *wb):
         x = _c(x)
-        ctx.wkeys = [(_wsink_register(t) if ctx.needs_input_grad[5 + 2 * i] else None) for i, t in enumerate(wb[0::2])]
-        ctx.bkeys = [(_wsink_register(t) if (t is not None and ctx.needs_input_grad[6 + 2 * i] and _EXTRA_SINKS) else None)
+        ctx.wkeys = [(_wsink_register(t) if ctx.needs_input_grad[6 + 2 * i] else None) for i, t in enumerate(wb[0::2])]
+        ctx.bkeys = [(_wsink_register(t) if (t is not None and ctx.needs_input_grad[7 + 2 * i] and _EXTRA_SINKS) else None)
                      for i, t in enumerate(wb[1::2])]
         ctx.w_alive = list(wb)           # see _Conv2d.forward
         ws_, bs_ = [_c(t) for t in wb[0::2]], [_c(t) for t in wb[1::2]]
@@ -467,11 +502,12 @@ class _ConvSharedInput(torch.autograd.Function):
             OH = (H + 2 * pad - R) // stride + 1
             OW = (W + 2 * pad - S) // stride + 1
             y = torch.empty((N, K, OH, OW), device=x.device, dtype=torch.float32)
-            _conv_fwd_launch(mr_f, x, w, b, None, y, stride, pad, relu)
+            _conv_fwd_launch(mr_f, x, w, b, None, y, stride, pad, relu, in_split=x_split)
             outs.append(y)
         keep_y = relu and not grad_premasked
         ctx.save_for_backward(x, *ws_, *(outs if keep_y else []))
         ctx.cfg = (stride, pad, mr, relu, grad_premasked, len(ws_), [b is not None for b in bs_])
+        ctx.x_split = bool(x_split)
         return tuple(outs)
 
     @staticmethod
@@ -488,7 +524,7 @@ class _ConvSharedInput(torch.autograd.Function):
         # all branches live and all weights want gradients: one weight-gradient launch over the concatenated rows, writing
         # slices of ONE buffer (the per-weight sinks are views of it), so the gathered input is read once per pass
         merged_w = (_MERGE_SHARED_WGRAD and n > 1 and all(d is not None for d in dys)
-                    and all(ctx.needs_input_grad[5 + 2 * i] for i in range(n)))
+                    and all(ctx.needs_input_grad[6 + 2 * i] for i in range(n)))
         for i in range(n):
             w, dy = ws_[i], dys[i]
             if dy is None:
@@ -502,10 +538,10 @@ class _ConvSharedInput(torch.autograd.Function):
                 dy = g
             live.append((w, dy, i))
             dw = db = None
-            if ctx.needs_input_grad[5 + 2 * i] and not merged_w:
+            if ctx.needs_input_grad[6 + 2 * i] and not merged_w:
                 buf, acc, dw = _wsink_take(ctx.wkeys[i], w)
-                _conv_wgrad_launch(mr, dy, x, buf, K, R, S, stride, pad, acc)
-            if has_b[i] and ctx.needs_input_grad[6 + 2 * i]:
+                _conv_wgrad_launch(mr, dy, x, buf, K, R, S, stride, pad, acc, in_split=ctx.x_split)
+            if has_b[i] and ctx.needs_input_grad[7 + 2 * i]:
                 bbuf, bacc, db = _wsink_take(ctx.bkeys[i], ctx.w_alive[2 * i + 1])
                 _lib.call('ag2v_channel_sum_acc', _ptr(dy), _ptr(bbuf), N, K, dy.shape[2] * dy.shape[3], bacc, st)
             grads += [dw, db]
@@ -515,7 +551,7 @@ class _ConvSharedInput(torch.autograd.Function):
             Kt = dyc.shape[1]
             R, S = ws_[0].shape[2], ws_[0].shape[3]
             cat, acc, outs = _wsink_take_group(ctx.wkeys, [w for w, _, _ in live])
-            _conv_wgrad_launch(mr, dyc, x, cat, Kt, R, S, stride, pad, acc)
+            _conv_wgrad_launch(mr, dyc, x, cat, Kt, R, S, stride, pad, acc, in_split=ctx.x_split)
             for j, (_, _, i) in enumerate(live):
                 grads[2 * i] = outs[j]
         if ctx.needs_input_grad[0]:
@@ -533,7 +569,7 @@ class _ConvSharedInput(torch.autograd.Function):
             else:
                 for j, (w, dy, _) in enumerate(live):
                     _conv_dgrad_launch(mr, dy, w, None, dx, stride, pad, 0 if j == 0 else 1)
-        return (dx, None, None, None, None) + tuple(grads)
+        return (dx, None, None, None, None, None) + tuple(grads)
 
 
 def conv2d_shared_input(x, weights, biases, stride=1, pad=0, relu=False, grad_premasked=False):
@@ -541,7 +577,7 @@ def conv2d_shared_input(x, weights, biases, stride=1, pad=0, relu=False, grad_pr
     wb = []
     for w, b in zip(weights, biases):
         wb += [w, b]
-    return _ConvSharedInput.apply(x, int(stride), int(pad), bool(relu), bool(grad_premasked), *wb)
+    return _ConvSharedInput.apply(x, int(stride), int(pad), bool(relu), bool(grad_premasked), is_split(x), *wb)
 
 
 # ------------------------------------------------------------------------------------------------ spectral norm
@@ -745,7 +781,7 @@ class _NormAct(torch.autograd.Function):
     the reference normalises every frame pass by itself), running statistics updated once per group, in order."""
 
     @staticmethod
-    def forward(ctx, mode, x, p0, p1, running_mean, running_var, training, momentum, eps, slope, groups):
+    def forward(ctx, mode, x, p0, p1, running_mean, running_var, training, momentum, eps, slope, groups, out_split=False):
         from . import distributed as D
         x, p0, p1 = _c(x), _c(p0), _c(p1)
         _chk(x, p0, p1)
@@ -769,9 +805,11 @@ class _NormAct(torch.autograd.Function):
             mean, invstd, N, C, HW, Ng = _bn_stats(x, running_mean, running_var, training, momentum, eps, groups)
         y = torch.empty_like(x)
         if mode == 0:
-            _lib.call('ag2v_norm_apply_g', 0, _ptr(x), _ptr(mean), _ptr(invstd), _ptr(p0), _ptr(p1), None, None, _ptr(y),
-                      N, C, HW, Ng, float(slope), _stream())
+            _lib.call('ag2v_norm_apply_gs', 0, _ptr(x), _ptr(mean), _ptr(invstd), _ptr(p0), _ptr(p1), None, None, _ptr(y),
+                      N, C, HW, Ng, float(slope), 1 if out_split else 0, _stream())
         else:
+            if out_split:
+                raise RuntimeError("out_split is implemented for the affine batch norm (mode 0) only")
             if mode == 2 and tuple(p0.shape) != (N, 2 * C) + tuple(x.shape[2:]):
                 raise RuntimeError("spade_norm_fused: gamma|beta tensor must be [N, 2C, H, W]")
             g_ptr, b_ptr = (_ptr(p0), _ptr(p1)) if mode == 1 else (_ptr(p0), _ptr_off(p0, C * HW))
@@ -794,7 +832,7 @@ class _NormAct(torch.autograd.Function):
         G = N // Ng
         sums = torch.empty((G, C, 4), device=x.device, dtype=torch.float32)
         ws = torch.empty(_lib.query('ag2v_bn_workspace_floats', N, C, HW), device=x.device, dtype=torch.float32)
-        none = (None,) * 9
+        none = (None,) * 10
         gam = p0 if mode >= 1 else None
         wgt = p0 if mode == 0 else None
         dgamma = dbeta = dgb = None
@@ -828,7 +866,7 @@ class _NormAct(torch.autograd.Function):
             if p0 is not None:
                 tot = sums.sum(dim=0) if G > 1 else sums[0]
                 dw, db = tot[:, 1].contiguous(), tot[:, 0].contiguous()
-            return (None, dx, dw, db) + none[:7]
+            return (None, dx, dw, db) + none[:8]
         if mode == 2:
             # the channel sums of dgamma | dbeta came out of the reduce pass: they ARE the bias gradient of the convolution that produced
             # gamma | beta (layout [N, 2C, H, W]: gamma channels first).  Handed to its backward on the gradient tensor itself (sync mode:
@@ -836,14 +874,18 @@ class _NormAct(torch.autograd.Function):
             if not sync_world:
                 tot = sums.sum(dim=0) if G > 1 else sums[0]
                 dgb._ag2v_channel_sums = torch.cat([tot[:, 3], tot[:, 2]])
-            return (None, dx, dgb, None) + none[:7]
-        return (None, dx, dgamma, dbeta) + none[:7]
+            return (None, dx, dgb, None) + none[:8]
+        return (None, dx, dgamma, dbeta) + none[:8]
 
 
-def batchnorm_act(x, weight, bias, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0, groups=1):
-    """F.batch_norm (batch statistics + running-stat update when training) followed by LeakyReLU(slope); groups: see _NormAct."""
-    return _NormAct.apply(0, x, weight, bias, running_mean, running_var, bool(training), float(momentum), float(eps),
-                          float(slope), int(groups))
+def batchnorm_act(x, weight, bias, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0, groups=1,
+                  out_split=False):
+    """F.batch_norm (batch statistics + running-stat update when training) followed by LeakyReLU(slope); groups: see _NormAct.
+    out_split: the result is stored as split words (is_split) -- for a tensor that only bf16x3 convolutions read, which then skip
+    their own fp32 -> (hi, lo) split; the caller checks conv_split_input_ok() for every reader first."""
+    y = _NormAct.apply(0, x, weight, bias, running_mean, running_var, bool(training), float(momentum), float(eps),
+                       float(slope), int(groups), bool(out_split))
+    return mark_split(y) if out_split else y
 
 
 def spade_norm(x, gamma, beta, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0, groups=1):
@@ -1191,7 +1233,8 @@ class _NearestResize(torch.autograd.Function):
 def nearest_resize(x, OH, OW):
     if x.shape[2] == OH and x.shape[3] == OW:
         return x
-    return _NearestResize.apply(x, int(OH), int(OW))
+    y = _NearestResize.apply(x, int(OH), int(OW))
+    return mark_split(y) if is_split(x) else y
 
 
 class _NearestPyramid(torch.autograd.Function):
@@ -1253,7 +1296,11 @@ def nearest_pyramid(x, sizes):
     ok = (W % 4 == 0) and len(sizes) <= 8 and all(H % h == 0 and W % w == 0 for (h, w) in sizes)
     if not ok:
         return tuple(nearest_resize(x, h, w) for (h, w) in sizes)
-    return _NearestPyramid.apply(x, sizes)
+    outs = _NearestPyramid.apply(x, sizes)
+    if is_split(x):       # a nearest-neighbour resize copies words: the levels of a split-word map are split-word maps
+        for o in outs:
+            mark_split(o)
+    return outs
 
 
 def upsample2x(x):

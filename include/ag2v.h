@@ -40,13 +40,17 @@ extern "C" {
  *              step (call sites architecture.py:35-39, flows_generator.py:79-85, normalization.py:26-27 inside the frame loop
  *              generator.py:62-87); with all T frames in one [T*B, ...] batch the kernel convolves the raw weight and scales
  *              group t by 1/sigma_t;
- *   kernel:    OUT: name (as rocprofv3 prints it) of the main kernel the call launched (static string). */
+ *   kernel:    OUT: name (as rocprofv3 prints it) of the main kernel the call launched (static string);
+ *   in_split:  (forward: x; weight gradient: x) the tensor holds SPLIT WORDS -- (bf16(v) << 16) | bf16(v - bf16(v)) per value, as
+ *              ag2v_norm_apply_g(out_split = 1) writes them -- instead of fp32: the bf16x3 kernels then skip their own split
+ *              (bit-identical results).  Only where ag2v_conv2d_split_input_ok() says so; otherwise AG2V_EINVAL. */
 typedef struct ag2v_conv_opts {
     int precision;
     int min_rows;
     const float* gscale;
     int group_n;
     const char* kernel;
+    int in_split;
 } ag2v_conv_opts;
 /* Defaults of calls without options (process-wide; the product passes options on every call). */
 int ag2v_set_conv_precision(int mode);
@@ -93,6 +97,8 @@ int ag2v_conv2d_dgrad_ex(const float* dy, const float* w, const float* mask, flo
                          float* workspace, size_t workspace_floats, void* stream, ag2v_conv_opts* opts);
 int ag2v_conv2d_wgrad_ex(const float* dy, const float* x, float* dw, int N, int C, int H, int W, int K, int R, int S,
                          int stride, int pad, int accumulate, int groups, void* stream, ag2v_conv_opts* opts);
+int ag2v_conv2d_split_input_ok(int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int min_rows_fwd,
+                               int min_rows_bwd, int precision);
 /* accumulate != 0: dw += instead of dw = (a weight used by several forward calls of one step collects its gradient in one buffer). */
 int ag2v_conv2d_wgrad_acc(const float* dy, const float* x, float* dw, int N, int C, int H, int W, int K, int R, int S,
                           int stride, int pad, int accumulate, void* stream);
@@ -125,6 +131,11 @@ int ag2v_bn_stats_g(const float* x, int N, int C, int HW, int Ng, float eps, flo
                     float* running_mean, float* running_var, float* workspace, void* stream);
 int ag2v_norm_apply_g(int mode, const float* x, const float* mean, const float* invstd, const float* w, const float* b,
                       const float* gamma, const float* beta, float* y, int N, int C, int HW, int Ng, float slope, void* stream);
+/* ag2v_norm_apply_g whose output is stored as split words when out_split != 0 (see ag2v_conv_opts::in_split): for a tensor that
+ * only bf16x3 convolutions read (generator.py: the normalised layout features every SPADE block convolves). */
+int ag2v_norm_apply_gs(int mode, const float* x, const float* mean, const float* invstd, const float* w, const float* b,
+                       const float* gamma, const float* beta, float* y, int N, int C, int HW, int Ng, float slope, int out_split,
+                       void* stream);
 int ag2v_norm_bwd_g(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* w,
                     const float* mean, const float* invstd, float* dx, float* dgamma, float* dbeta, float* sums,
                     int N, int C, int HW, int Ng, float slope, float* workspace, void* stream);

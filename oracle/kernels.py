@@ -88,9 +88,17 @@ def _batch_norm_groups(x, running_mean, running_var, weight, bias, training, mom
                       for g in range(groups)], dim=0)
 
 
-def batchnorm_act(x, weight, bias, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0, groups=1):
+def conv_split_input_ok(x_shape, w_shape, stride, pad):
+    """The product may store an activation as split bf16 words for its bf16x3 kernels (ops.is_split): a storage format of the GPU
+    path with no counterpart in the reference's arithmetic -- the oracle always answers "keep fp32"."""
+    return False
+
+
+def batchnorm_act(x, weight, bias, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0, groups=1,
+                  out_split=False):
     """_SynchronizedBatchNorm single-device path = F.batch_norm (sync_batchnorm/batchnorm.py:63-68) + LeakyReLU
     (generator.py:26-33, flows_generator.py:30-54)."""
+    assert not out_split
     return _lrelu(_batch_norm_groups(x, running_mean, running_var, weight, bias, training, momentum, eps, groups), slope)
 
 

@@ -475,6 +475,72 @@ def test_linear(cfg, device):
     _run_pair(ops.linear, K.linear, t, device, name='linear')
 
 
+def _to_split_words(x):
+    """(bf16(v) << 16) | bf16(v - bf16(v)) per value, as float32 bit patterns -- the storage format of ops.is_split tensors."""
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    w = (hi.view(torch.int16).to(torch.int32) << 16) | (lo.view(torch.int16).to(torch.int32) & 0xFFFF)
+    return w.view(torch.float32)
+
+
+@pytest.mark.parametrize("cfg", [(2, 64, 32, 32, 128, 3, 1), (3, 96, 16, 24, 384, 3, 1), (2, 40, 16, 16, 160, 3, 1), (1, 512, 8, 8, 1024, 3, 1)],
+                         ids=str)
+def test_conv2d_split_word_input(cfg, device):
+    """A bf16x3 convolution reading its input as split words (written by the producing kernel) multiplies exactly the terms it
+    derives itself from the fp32 tensor -- forward, weight gradient (plain, per frame group, shared-input form); results agree to
+    the atomics-order noise of split-K launches (a dropped lo term would show at 1e-3) -- and the normalisation kernel's out_split
+    output IS that format, bit for bit.  Shapes that cannot take split words are refused, not silently mis-read."""
+    from ag2video_amd import ops
+
+    def same(a, c, nm):
+        tol = 1e-5 * float(a.abs().max())
+        assert float((a - c).abs().max()) <= tol, (nm, float((a - c).abs().max()), tol)
+    N, C, H, W, K, R, pad = cfg
+    torch.manual_seed(5)
+    x = torch.randn(N, C, H, W, device=device)
+    x[0, 0, 0, :5] = torch.tensor([0.0, -0.0, 1e-30, 1.0, 255.5], device=device)
+    w = (torch.randn(K, C, R, R, device=device) * 0.05).requires_grad_(True)
+    b = torch.randn(K, device=device).requires_grad_(True)
+    gs = torch.linspace(0.5, 1.5, N, device=device)
+    with ops.conv_precision('bf16x3'), ops.bf16x3_min_rows(32):
+        assert ops.conv_split_input_ok(x.shape, w.shape, 1, pad)
+        for gscale in (None, gs):
+            res = []
+            for split in (False, True):
+                xin = (ops.mark_split(_to_split_words(x)) if split else x.clone())
+                y = ops.conv2d(xin, w, b, 1, pad, gscale=gscale)
+                dw, db = torch.autograd.grad((y * torch.linspace(-1, 1, y.numel(), device=device).view_as(y)).sum(), (w, b))
+                res.append((y.detach(), dw, db))
+            for a, c, nm in zip(res[0], res[1], ('y', 'dw', 'db')):
+                same(a, c, nm)
+        # shared-input form (SPADE mlp_shared): three weight sets, merged weight gradient
+        ws = [(torch.randn(128, C, R, R, device=device) * 0.05).requires_grad_(True) for _ in range(3)]
+        res = []
+        for split in (False, True):
+            xin = (ops.mark_split(_to_split_words(x)) if split else x.clone())
+            ys = ops.conv2d_shared_input(xin, ws, [None] * 3, 1, pad, relu=True)
+            res.append([t.detach() for t in ys] + list(torch.autograd.grad(sum((t * t).sum() for t in ys), ws)))
+        for a, c in zip(res[0], res[1]):
+            same(a, c, 'shared')
+        # the producer: batch norm + LeakyReLU with out_split
+        rm, rv = torch.zeros(C, device=device), torch.ones(C, device=device)
+        wt, bs = torch.rand(C, device=device) + 0.5, torch.randn(C, device=device)
+        ref = ops.batchnorm_act(x, wt, bs, rm.clone(), rv.clone(), True, 0.1, 1e-5, 0.2)
+        got = ops.batchnorm_act(x, wt, bs, rm.clone(), rv.clone(), True, 0.1, 1e-5, 0.2, out_split=True)
+        assert ops.is_split(got) and not ops.is_split(ref)
+        assert torch.equal(got.view(torch.int32), _to_split_words(ref).view(torch.int32))
+        lv = ops.nearest_pyramid(got, [(H, W), (H // 2, W // 2)])
+        assert all(ops.is_split(t) for t in lv) and torch.equal(lv[1].view(torch.int32), got[:, :, ::2, ::2].contiguous().view(torch.int32))
+        # refused: exact arithmetic, too few rows, a weight-gradient shape without the 16-byte-load kernel
+        assert not ops.conv_split_input_ok((N, C, 12, 12), w.shape, 1, pad)
+        with pytest.raises(RuntimeError):       # (the forward kernels all read split words; the 12-wide weight gradient cannot)
+            ops.conv2d(ops.mark_split(_to_split_words(torch.randn(N, C, 12, 12, device=device))), w, b, 1, pad).sum().backward()
+    with ops.conv_precision('fp32'):
+        assert not ops.conv_split_input_ok(x.shape, w.shape, 1, pad)
+        with pytest.raises(RuntimeError):
+            ops.conv2d(ops.mark_split(_to_split_words(x)), w, b, 1, pad)
+
+
 def test_linear_unaligned_operands(device):
     """The one-round-trip GEMM reads k-contiguous operands with 16-byte loads when their rows are 16-byte aligned and with 4-byte
     loads otherwise (views into a flat buffer at any element offset): same results either way, forward and both gradients."""
