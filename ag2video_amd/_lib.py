@@ -31,6 +31,7 @@ _SIGS = {
     'ag2v_conv2d_dgrad_ex': (c_int, [_P, _P, _P, _P] + [c_int] * 10 + [_P, c_size_t, _P, _P]),
     'ag2v_conv2d_wgrad_ex': (c_int, [_P, _P, _P] + [c_int] * 11 + [_P, _P]),
     'ag2v_conv2d_split_input_ok': (c_int, [c_int] * 12),
+    'ag2v_conv2d_split_dy_ok': (c_int, [c_int] * 11),
     'ag2v_channel_sum': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     'ag2v_channel_sum_acc': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     'ag2v_bn_workspace_floats': (c_size_t, [c_int, c_int, c_int]),
@@ -41,6 +42,7 @@ _SIGS = {
     'ag2v_norm_apply_g': (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     'ag2v_norm_apply_gs': (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
     'ag2v_norm_bwd_g': (c_int, [c_int] + [_P] * 11 + [c_int, c_int, c_int, c_int, c_float, _P, _P]),
+    'ag2v_norm_bwd_gs': (c_int, [c_int] + [_P] * 11 + [c_int, c_int, c_int, c_int, c_float, _P, c_int, _P]),
     'ag2v_norm_bwd_reduce_g': (c_int, [c_int] + [_P] * 7 + [c_int, c_int, c_int, c_int, c_float, _P, _P]),
     'ag2v_norm_bwd_apply_g': (c_int, [c_int] + [_P] * 8 + [c_float, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     'ag2v_spade_pair_supported': (c_int, [c_int, c_int, c_int]),
@@ -48,6 +50,7 @@ _SIGS = {
     'ag2v_spade_pair_stats': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
     'ag2v_spade_pair_apply': (c_int, [_P] * 7 + [c_int] * 6 + [c_float, c_float, _P]),
     'ag2v_spade_pair_bwd': (c_int, [_P] * 13 + [c_int] * 6 + [c_float, c_float, _P, _P]),
+    'ag2v_spade_pair_bwd_s': (c_int, [_P] * 13 + [c_int] * 6 + [c_float, c_float, _P, c_int, _P]),
     'ag2v_instnorm_lrelu_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P]),
     'ag2v_instnorm_lrelu_bwd': (c_int, [_P] * 6 + [c_int, c_int, c_float, _P]),
     'ag2v_layout_render_fwd': (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [_P]),
@@ -97,7 +100,7 @@ EXPORTS = tuple(sorted(_SIGS))
 class ConvOpts(ctypes.Structure):
     """ag2v_conv_opts (include/ag2v.h): per-call options of the *_ex convolution entry points."""
     _fields_ = [('precision', c_int), ('min_rows', c_int), ('gscale', c_void_p), ('group_n', c_int), ('kernel', c_char_p),
-                ('in_split', c_int)]
+                ('in_split', c_int), ('dy_split', c_int)]
 
 _lib = None
 

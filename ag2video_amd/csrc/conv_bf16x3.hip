@@ -804,7 +804,7 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_ws_k
 // for the hi and the lo image each -- against 8 dword loads and 8 ds_write_b32 in conv_wgrad_bf16x3_ws_kernel.  Only the first /
 // last element of a run can fall outside the image (pad <= 8 - ... checked by the launcher: pad <= S - 1 <= 7); such runs are
 // flagged per K-tile by the table builder and patched after the load.
-template <int BM, int BN, int CWM, int CWN, int NPW, bool MF16, bool PSX>
+template <int BM, int BN, int CWM, int CWN, int NPW, bool MF16, bool PSA, bool PSX>
 __device__ __forceinline__ void wgrad_bf16x3_v_body(const ConvArgs& p) {
     constexpr int BK = 32, LDK = 40, NP = NPW * 64;
     constexpr int TM = BM / CWM / 32, TN = BN / CWN / 32;
@@ -931,7 +931,7 @@ __device__ __forceinline__ void wgrad_bf16x3_v_body(const ConvArgs& p) {
         };
         auto stash = [&](int buf, const u32x4 (&ra)[NA][2], u32x4 (&rb)[NB][2], int fixw, int fixx, int shw) {
 #pragma unroll
-            for (int i = 0; i < NA; ++i) store_row(std::false_type{}, Ahi[buf], Alo[buf], row + RPT * i, ra[i]);
+            for (int i = 0; i < NA; ++i) store_row(std::integral_constant<bool, PSA>{}, Ahi[buf], Alo[buf], row + RPT * i, ra[i]);
             if (__builtin_expect(shw != 0, 0)) {   // rows loaded from element 0 instead of element -sh: move them up by sh places
 #pragma unroll
                 for (int i = 0; i < NB; ++i) {
@@ -1054,12 +1054,12 @@ __device__ __forceinline__ void wgrad_bf16x3_v_body(const ConvArgs& p) {
 }
 template <int BM, int BN, int CWM, int CWN, int NPW, bool MF16>
 __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_v_kernel(ConvArgs p) {
-    wgrad_bf16x3_v_body<BM, BN, CWM, CWN, NPW, MF16, false>(p);
+    wgrad_bf16x3_v_body<BM, BN, CWM, CWN, NPW, MF16, false, false>(p);
 }
-// x (ConvArgs::b_src) holds split words (ConvArgs::b_split)
-template <int BM, int BN, int CWM, int CWN, int NPW, bool MF16>
+// dy (PSA: ConvArgs::a_split) and / or x (PSX: ConvArgs::b_split) hold split words
+template <int BM, int BN, int CWM, int CWN, int NPW, bool MF16, bool PSA, bool PSX>
 __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_vps_kernel(ConvArgs p) {
-    wgrad_bf16x3_v_body<BM, BN, CWM, CWN, NPW, MF16, true>(p);
+    wgrad_bf16x3_v_body<BM, BN, CWM, CWN, NPW, MF16, PSA, PSX>(p);
 }
 
 // ================================================================ launchers
@@ -1169,14 +1169,22 @@ int launch_wgrad_bf16x3(ConvArgs& a, hipStream_t st) {
     if (a.stride == 1 && a.OW % 8 == 0 && a.W >= 8 && a.a_bytes <= 0x80000000u && a.pad <= 3 &&
         getenv("AG2V_WGRAD_SCALAR_LOADS") == nullptr) {
         // 16-byte loads along the pixel index (runs of 8 pixels never straddle an image row)
-        if (a.b_split) {       // x as split words: the 32x32x16 forms
+        if (a.b_split || a.a_split) {       // dy and / or x as split words: the 32x32x16 forms
+#define AG2V_VPS(BM_, BN_, WM_, WN_, PA_, PX_)                                                                                   \
+            do {                                                                                                              \
+                set_last_conv_kernel("conv_wgrad_bf16x3_vps_kernel<" #BM_ ", " #BN_ ", " #WM_ ", " #WN_ ", 8, false, " #PA_ ", " #PX_ ">"); \
+                hipLaunchKernelGGL((conv_wgrad_bf16x3_vps_kernel<BM_, BN_, WM_, WN_, 8, false, PA_, PX_>), grid, dim3(1024), 0, st, a); \
+            } while (0)
             if (tall) {
-                set_last_conv_kernel("conv_wgrad_bf16x3_vps_kernel<256, 128, 4, 2, 8, false>");
-                hipLaunchKernelGGL((conv_wgrad_bf16x3_vps_kernel<256, 128, 4, 2, 8, false>), grid, dim3(1024), 0, st, a);
+                if (a.a_split && a.b_split) AG2V_VPS(256, 128, 4, 2, true, true);
+                else if (a.a_split) AG2V_VPS(256, 128, 4, 2, true, false);
+                else AG2V_VPS(256, 128, 4, 2, false, true);
             } else {
-                set_last_conv_kernel("conv_wgrad_bf16x3_vps_kernel<128, 256, 2, 4, 8, false>");
-                hipLaunchKernelGGL((conv_wgrad_bf16x3_vps_kernel<128, 256, 2, 4, 8, false>), grid, dim3(1024), 0, st, a);
+                if (a.a_split && a.b_split) AG2V_VPS(128, 256, 2, 4, true, true);
+                else if (a.a_split) AG2V_VPS(128, 256, 2, 4, true, false);
+                else AG2V_VPS(128, 256, 2, 4, false, true);
             }
+#undef AG2V_VPS
         } else if (tall) {
             if (wgrad32) {
                 set_last_conv_kernel("conv_wgrad_bf16x3_v_kernel<256, 128, 4, 2, 8, false>");
@@ -1195,7 +1203,7 @@ int launch_wgrad_bf16x3(ConvArgs& a, hipStream_t st) {
             }
         }
     } else {
-        if (a.b_split) return AG2V_EINVAL;      // only the 16-byte-load kernels read split words (wgrad_split_input_ok())
+        if (a.b_split || a.a_split) return AG2V_EINVAL;      // only the 16-byte-load kernels read split words
         if (tall) {
             set_last_conv_kernel("conv_wgrad_bf16x3_ws_kernel<256, 128, 4, 2, 8>");
             hipLaunchKernelGGL((conv_wgrad_bf16x3_ws_kernel<256, 128, 4, 2, 8>), grid, dim3(1024), 0, st, a);

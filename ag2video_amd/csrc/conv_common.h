@@ -28,6 +28,7 @@ struct ConvArgs {
     int group_n;            //   before bias / residual -- spectral norm's 1/sigma_t of frame group t (frame-batched generator)
     int groups, gq, spg;    // wgrad: `groups` consecutive sample groups of gq pixels each, spg pixel-range splits per group (grid =
     long long out_gstride;  //   tiles x groups x spg); group g writes dW at out + g * out_gstride.  groups == 1: the plain form.
+    int a_split;            // weight-gradient bf16x3 kernels: dy (a_src) holds split words
     int b_split;            // bf16x3 kernels: b_src holds split words ((bf16 hi << 16) | bf16 lo per value, pack_split()) instead of fp32
 #ifdef AG2V_STAMPS
     unsigned long long* stamps;   // diagnostic build only (tools/ubench/igemm_stamps.hip): per-wave phase clocks

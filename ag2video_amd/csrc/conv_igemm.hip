@@ -508,12 +508,13 @@ struct ag2v_conv_opts {
     int group_n;
     const char* kernel;
     int in_split;
+    int dy_split;
 };
 struct ConvCfg {
     int precision, min_rows;
     const float* gscale;
     int group_n;
-    int in_split;
+    int in_split, dy_split;
 };
 static ConvCfg conv_cfg(const ag2v_conv_opts* o) {
     ConvCfg c;
@@ -522,6 +523,7 @@ static ConvCfg conv_cfg(const ag2v_conv_opts* o) {
     c.gscale = o ? o->gscale : nullptr;
     c.group_n = (o && o->group_n > 0) ? o->group_n : 1;
     c.in_split = (o && o->in_split) ? 1 : 0;
+    c.dy_split = (o && o->dy_split) ? 1 : 0;
     return c;
 }
 static bool use_bf16x3(const ConvCfg& c, int M) { return c.precision == 1 && M >= c.min_rows; }
@@ -863,6 +865,8 @@ extern "C" int ag2v_conv2d_dgrad_ex(const float* dy, const float* w, const float
     if (workspace_floats < (size_t)C * K * R * S) return AG2V_EINVAL;
     const long long dys = (long long)K * OH * OW, dxs = (long long)C * H * W;
     const size_t t_floats = (size_t)N * C * R * S * OH * OW;
+    if (cfg.dy_split && (few_channel_dgrad(N, C, K, R, S, OH, OW, stride, mask != nullptr) || !use_bf16x3(cfg, C)))
+        return AG2V_EINVAL;                      // split words are only read by the bf16x3 kernels (ag2v_conv2d_split_dy_ok)
     if (few_channel_dgrad(N, C, K, R, S, OH, OW, stride, mask != nullptr) && (long long)N * OH * OW < (1LL << 31) &&
         workspace_floats >= (size_t)C * K * R * S + t_floats) {
         // few input channels: dx[n,c,y,x] = sum_{r,s} t[n, (c R + r) S + s, y + pad - r, x + pad - s], t = W'^T dy as a 1x1
@@ -908,6 +912,7 @@ extern "C" int ag2v_conv2d_dgrad_ex(const float* dy, const float* w, const float
                 nmax = chunk_samples(dys * 4, 0, cfg.gscale ? cfg.group_n : 1);
                 if (nmax <= 0) { split = false; nmax = N; }
             }
+            if (cfg.dy_split && !split) return AG2V_EINVAL;
             const int cOH = (H - ay + stride - 1) / stride, cOW = (W - ax + stride - 1) / stride;
             if ((long long)nmax * cOH * cOW >= (1LL << 31)) {
                 nmax = (int)(((1LL << 31) - 1) / ((long long)cOH * cOW));
@@ -934,6 +939,7 @@ extern "C" int ag2v_conv2d_dgrad_ex(const float* dy, const float* w, const float
                 f.M = C; f.NG = nc * f.OH * f.OW; f.KG = K * Rc * Sc;
                 f.a_bytes = (unsigned)abytes; f.b_bytes = split ? (unsigned)(dys * 4 * nc) : 0u;
                 f.gscale = cfg.gscale ? cfg.gscale + n0 / cfg.group_n : nullptr; f.group_n = cfg.group_n;
+                f.b_split = cfg.dy_split;
                 // one class (stride 1): the mask in the epilogue; several classes: one pass at the end
                 f.mask = (multi || !mask) ? nullptr : mask + (size_t)n0 * dxs;
                 // accumulate: a split-K launch adds onto the existing dx with its atomics (no zeroing); any other launch reads dx
@@ -971,11 +977,11 @@ extern "C" int ag2v_conv2d_dgrad(const float* dy, const float* w, float* dx,
 // gradient in one buffer.  groups > 1 (N % groups == 0): the batch is `groups` consecutive sample groups and dw is
 // [groups][K, C, R, S] -- one gradient per group (the frame-batched generator needs dL/dWbar_t per frame t for spectral norm).
 static int wgrad_launch(const float* dy, const float* x, float* dw, int N, int C, int H, int W, int K, int R, int S, int OH, int OW,
-                        int stride, int pad, int accumulate, int groups, bool split, hipStream_t st, int x_split = 0) {
+                        int stride, int pad, int accumulate, int groups, bool split, hipStream_t st, int x_split = 0, int dy_split = 0) {
     ConvArgs a{};
     a.a_src = dy; a.b_src = x; a.out = dw; a.accumulate = accumulate ? 1 : 0;
-    a.b_split = x_split;
-    if (x_split && !split) return AG2V_EINVAL;
+    a.b_split = x_split; a.a_split = dy_split;
+    if ((x_split || dy_split) && !split) return AG2V_EINVAL;
     a.N = N; a.C = C; a.H = H; a.W = W; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.pad_w = pad;
     a.OH = OH; a.OW = OW;
     const long long Q = (long long)N * OH * OW;
@@ -1043,7 +1049,7 @@ extern "C" int ag2v_conv2d_wgrad_ex(const float* dy, const float* x, float* dw, 
         float* out = (groups > 1) ? dw + (size_t)g0 * wsz : dw;
         const int acc = (groups > 1) ? accumulate : (accumulate || n0 > 0);
         const int rc = wgrad_launch(dy + (size_t)n0 * dys, x + (size_t)n0 * xs, out, nc, C, H, W, K, R, S, OH, OW, stride, pad, acc, gc,
-                                    split, st, cfg.in_split);
+                                    split, st, cfg.in_split, cfg.dy_split);
         if (rc != AG2V_OK) return rc;
     }
     if (o) o->kernel = g_last_conv_kernel;
@@ -1069,6 +1075,23 @@ extern "C" int ag2v_conv2d_split_input_ok(int N, int C, int H, int W, int K, int
     if (!use_bf16x3(cb, K)) return 0;                                                                      // weight gradient
     if (dys * 8 > chunk_limit() && dys * 4 > chunk_limit()) return 0;
     if (!(stride == 1 && OW % 8 == 0 && W >= 8 && pad <= 3) || getenv("AG2V_WGRAD_SCALAR_LOADS") != nullptr) return 0;
+    return 1;
+}
+// The same question for the OUTPUT gradient dy of the convolution (ag2v_conv_opts::dy_split): its data gradient (dy is the
+// gathered operand there) and its weight gradient both on the bf16x3 kernels, the latter on the 16-byte-load form.
+extern "C" int ag2v_conv2d_split_dy_ok(int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int min_rows_bwd,
+                                       int precision) {
+    if (N <= 0 || C <= 0 || K <= 0 || stride != 1 || R * S > 16) return 0;
+    ag2v_conv_opts ob{}; ob.precision = precision; ob.min_rows = min_rows_bwd;
+    const ConvCfg cb = conv_cfg(&ob);
+    const int OH = conv_out_dim(H, R, stride, pad), OW = conv_out_dim(W, S, stride, pad);
+    if (OH <= 0 || OW <= 0) return 0;
+    const long long dys = (long long)K * OH * OW;
+    if (few_channel_dgrad(N, C, K, R, S, OH, OW, stride, false)) return 0;
+    if (!use_bf16x3(cb, C) || (long long)K * C * R * S * 4 >= kBufMax) return 0;          // data gradient: rows = input channels
+    if (!use_bf16x3(cb, K)) return 0;                                                       // weight gradient: rows = output channels
+    if (dys * 8 > chunk_limit()) return 0;
+    if (!(OW % 8 == 0 && W >= 8 && pad <= 3) || getenv("AG2V_WGRAD_SCALAR_LOADS") != nullptr) return 0;
     return 1;
 }
 extern "C" int ag2v_conv2d_wgrad_acc(const float* dy, const float* x, float* dw, int N, int C, int H, int W, int K, int R, int S,

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
                                                              const float* __restrict__ invstd, const float* __restrict__ sums,
                                                              float* __restrict__ dx, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta, int C, int HW, int nchunk,
-                                                             float inv_count, float slope, long long gbx, int Ng) {
+                                                             float inv_count, float slope, long long gbx, int Ng, int dgb_split) {
     const int bid = blockIdx.x;
     const int chunk = bid % nchunk, nc = bid / nchunk;
     const int c = nc % C;
@@ -294,8 +294,16 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
         float dg[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) dg[i] = g[i] * xv[i];
-        store16<VEC>(dgamma + goff, cnt, dg);
-        store16<VEC>(dbeta + goff, cnt, g);
+        if (dgb_split) {        // dgamma | dbeta go to a bf16x3 data gradient + weight gradient only: stored as split words
+            float ps[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { dg[i] = pack_split(dg[i]); ps[i] = pack_split(g[i]); }
+            store16<VEC>(dgamma + goff, cnt, dg);
+            store16<VEC>(dbeta + goff, cnt, ps);
+        } else {
+            store16<VEC>(dgamma + goff, cnt, dg);
+            store16<VEC>(dbeta + goff, cnt, g);
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) g[i] = is * (g[i] * (1.f + t[i]) - m1 - xv[i] * m2);
     } else {
@@ -449,7 +457,7 @@ __global__ __launch_bounds__(256) void spade_pair_bwd_apply_kernel(const float* 
                                                                    const float* __restrict__ invstd, const float* __restrict__ sums,
                                                                    float* __restrict__ dxs, float* __restrict__ dgb0,
                                                                    float* __restrict__ dgb1, int C, int HW, int W, int nchunk,
-                                                                   float inv_count, float slope0, float slope1, int Ng) {
+                                                                   float inv_count, float slope0, float slope1, int Ng, int dgb_split) {
     __shared__ float2 hsum[UP == 2 ? 1024 : 1];
     const int bid = blockIdx.x;
     const int chunk = bid % nchunk, nc = bid / nchunk;
@@ -485,6 +493,10 @@ __global__ __launch_bounds__(256) void spade_pair_bwd_apply_kernel(const float* 
         for (int i = 0; i < 16; ++i) {
             dg[i] = g[i] * xh[i];
             acc[i] += g[i] * (1.f + t[i]) - m1 - xh[i] * m2;
+        }
+        if (dgb_split) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { dg[i] = pack_split(dg[i]); g[i] = pack_split(g[i]); }
         }
         store16<true>(dgb + goff, cnt, dg);
         store16<true>(dgb + goff + (size_t)C * HW, cnt, g);
@@ -664,7 +676,7 @@ extern "C" int ag2v_norm_apply(int mode, const float* x, const float* mean, cons
 // y is the forward output (activation sign); may be null if slope == 1.
 static int norm_bwd_launch(int mode, bool do_reduce, bool do_apply, const float* dy, const float* y, const float* x, const float* gamma,
                            const float* w, const float* mean, const float* invstd, float* dx, float* dgamma, float* dbeta, float* sums,
-                           int N, int C, int HW, int Ng, float slope, float inv_count, float* workspace, hipStream_t st) {
+                           int N, int C, int HW, int Ng, float slope, float inv_count, float* workspace, hipStream_t st, int dgb_split = 0) {
     if (!dy || !x || !mean || !invstd || !sums || N <= 0 || C <= 0 || HW <= 0 || Ng <= 0 || N % Ng != 0) return AG2V_EINVAL;
     if (do_reduce && !workspace) return AG2V_EINVAL;
     if (do_apply && !dx) return AG2V_EINVAL;
@@ -685,7 +697,7 @@ static int norm_bwd_launch(int mode, bool do_reduce, bool do_apply, const float*
     }                                                                                                                                \
     if (do_apply)                                                                                                                    \
         hipLaunchKernelGGL((norm_bwd_apply_kernel<M, V>), g, t, 0, st, dy, y, x, gamma, w, mean, invstd, sums, dx, dgamma, dbeta, C, \
-                           HW, nchunk, inv_count, slope, gbx, Ng);
+                           HW, nchunk, inv_count, slope, gbx, Ng, dgb_split ? 1 : 0);
     if (mode == 0) {
         if (v) { LAUNCH_BWD(0, true) } else { LAUNCH_BWD(0, false) }
     } else {
@@ -695,12 +707,20 @@ static int norm_bwd_launch(int mode, bool do_reduce, bool do_apply, const float*
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
 }
+// dgb_split != 0 (modes 1 / 2): dgamma / dbeta are written as split words (ag2v_conv_opts::dy_split) -- they are read by the data
+// gradient and the weight gradient of the convolution that produced gamma | beta and by nothing else (its bias gradient comes
+// from `sums`).
+extern "C" int ag2v_norm_bwd_gs(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* w,
+                                const float* mean, const float* invstd, float* dx, float* dgamma, float* dbeta, float* sums,
+                                int N, int C, int HW, int Ng, float slope, float* workspace, int dgb_split, void* stream) {
+    if (Ng <= 0 || HW <= 0) return AG2V_EINVAL;
+    return norm_bwd_launch(mode, true, true, dy, y, x, gamma, w, mean, invstd, dx, dgamma, dbeta, sums, N, C, HW, Ng, slope,
+                           1.0f / ((float)Ng * (float)HW), workspace, (hipStream_t)stream, dgb_split);
+}
 extern "C" int ag2v_norm_bwd_g(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* w,
                                const float* mean, const float* invstd, float* dx, float* dgamma, float* dbeta, float* sums,
                                int N, int C, int HW, int Ng, float slope, float* workspace, void* stream) {
-    if (Ng <= 0 || HW <= 0) return AG2V_EINVAL;
-    return norm_bwd_launch(mode, true, true, dy, y, x, gamma, w, mean, invstd, dx, dgamma, dbeta, sums, N, C, HW, Ng, slope,
-                           1.0f / ((float)Ng * (float)HW), workspace, (hipStream_t)stream);
+    return ag2v_norm_bwd_gs(mode, dy, y, x, gamma, w, mean, invstd, dx, dgamma, dbeta, sums, N, C, HW, Ng, slope, workspace, 0, stream);
 }
 extern "C" int ag2v_norm_bwd_reduce_g(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* mean,
                                       const float* invstd, float* sums, int N, int C, int HW, int Ng, float slope, float* workspace,
@@ -765,10 +785,10 @@ extern "C" int ag2v_spade_pair_apply(const float* xs, const float* mean, const f
     return AG2V_OK;
 }
 // sums [N / Ng, C, 8] = per norm k: (sum dxhat_k, sum dxhat_k xhat, sum dbeta_k, sum dgamma_k); dxs [N, C, H/up, W/up]; dgb0 / dgb1 like gb.
-extern "C" int ag2v_spade_pair_bwd(const float* dy0, const float* y0, const float* dy1, const float* y1, const float* xs, const float* gb0,
+extern "C" int ag2v_spade_pair_bwd_s(const float* dy0, const float* y0, const float* dy1, const float* y1, const float* xs, const float* gb0,
                                    const float* gb1, const float* mean, const float* invstd, float* dxs, float* dgb0, float* dgb1,
                                    float* sums, int N, int C, int H, int W, int up, int Ng, float slope0, float slope1, float* workspace,
-                                   void* stream) {
+                                   int dgb_split, void* stream) {
     if (!dy0 || !dy1 || !xs || !gb0 || !gb1 || !mean || !invstd || !dxs || !dgb0 || !dgb1 || !sums || !workspace) return AG2V_EINVAL;
     if (N <= 0 || C <= 0 || Ng <= 0 || N % Ng != 0 || (slope0 != 1.f && !y0) || (slope1 != 1.f && !y1)) return AG2V_EINVAL;
     if (!ag2v_spade_pair_supported(H, W, up) || !vec_ok(H * W, dy0, dy1, y0, y1, gb0, gb1) || !vec_ok(H * W, dgb0, dgb1, xs, dxs)) return AG2V_EINVAL;
@@ -784,11 +804,18 @@ extern "C" int ag2v_spade_pair_bwd(const float* dy0, const float* y0, const floa
                        W, nchunk, slope0, slope1);                                                                                   \
     hipLaunchKernelGGL(multi_sum_finalize_kernel, dim3(ceil_div(GC * 8, 64)), dim3(64), 0, st, workspace, GC, Ng* nchunk, 8, sums);  \
     hipLaunchKernelGGL(spade_pair_bwd_apply_kernel<U>, g, t, 0, st, dy0, y0, dy1, y1, xs, gb0, gb1, mean, invstd, sums, dxs, dgb0, dgb1, \
-                       C, HW, W, nchunk, inv_count, slope0, slope1, Ng);
+                       C, HW, W, nchunk, inv_count, slope0, slope1, Ng, dgb_split ? 1 : 0);
     if (up == 1) { PAIR_BWD(1) } else { PAIR_BWD(2) }
 #undef PAIR_BWD
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
+}
+extern "C" int ag2v_spade_pair_bwd(const float* dy0, const float* y0, const float* dy1, const float* y1, const float* xs, const float* gb0,
+                                   const float* gb1, const float* mean, const float* invstd, float* dxs, float* dgb0, float* dgb1,
+                                   float* sums, int N, int C, int H, int W, int up, int Ng, float slope0, float slope1, float* workspace,
+                                   void* stream) {
+    return ag2v_spade_pair_bwd_s(dy0, y0, dy1, y1, xs, gb0, gb1, mean, invstd, dxs, dgb0, dgb1, sums, N, C, H, W, up, Ng, slope0, slope1,
+                                 workspace, 0, stream);
 }
 
 extern "C" int ag2v_instnorm_lrelu_fwd(const float* x, float* y, float* mean, float* invstd, int NC, int HW, float eps,

@@ -154,11 +154,11 @@ def _conv_label(mode, M, min_rows=None):
     return "conv_%s" % mode
 
 
-def _conv_launch(min_rows, name, label, flops, *args, shape=None, gscale=None, group_n=1, in_split=False):
+def _conv_launch(min_rows, name, label, flops, *args, shape=None, gscale=None, group_n=1, in_split=False, dy_split=False):
     """One ag2v_conv2d_*_ex call.  Arithmetic (precision, bf16x3 row threshold: ``min_rows``, None = library default) and the
     per-sample-group output scale travel as per-call options (ag2v_conv_opts): no process-wide switch is touched."""
     opts = _lib.ConvOpts(_PRECISION[0], int(min_rows) if min_rows else 0, None if gscale is None else gscale.data_ptr(),
-                         int(group_n), None, 1 if in_split else 0)
+                         int(group_n), None, 1 if in_split else 0, 1 if dy_split else 0)
     args = args + (ctypes.byref(opts),)
     if _TIMING is None or _PAUSED:
         _lib.call(name, *args)
@@ -332,7 +332,7 @@ def _conv_fwd_launch(mr, x, w, bias, residual, y, stride, pad, relu, gscale=None
                  _ptr(ws), _stream(), shape=(N, C, H, W, K, R, stride), gscale=gscale, group_n=group_n, in_split=in_split)
 
 
-def _conv_dgrad_launch(mr, dy, w, mask, dx, stride, pad, acc, gscale=None, group_n=1):
+def _conv_dgrad_launch(mr, dy, w, mask, dx, stride, pad, acc, gscale=None, group_n=1, dy_split=False):
     """dx (+)= data gradient.  The workspace holds the re-ordered filters and, for <= 4 input channels, the intermediate of the
     1x1-GEMM form (caller memory: the library allocates nothing)."""
     N, C, H, W = dx.shape
@@ -341,15 +341,15 @@ def _conv_dgrad_launch(mr, dy, w, mask, dx, stride, pad, acc, gscale=None, group
     ws = torch.empty(nws, device=dy.device, dtype=torch.float32)
     _conv_launch(mr, 'ag2v_conv2d_dgrad_ex', 'conv_dgrad', 2.0 * N * K * dy.shape[2] * dy.shape[3] * C * R * S,
                  _ptr(dy), _ptr(w), _ptr(mask), _ptr(dx), N, C, H, W, K, R, S, stride, pad, 1 if acc else 0, _ptr(ws), nws, _stream(),
-                 shape=(N, C, H, W, K, R, stride), gscale=gscale, group_n=group_n)
+                 shape=(N, C, H, W, K, R, stride), gscale=gscale, group_n=group_n, dy_split=dy_split)
 
 
-def _conv_wgrad_launch(mr, dy, x, dw, K, R, S, stride, pad, acc, groups=1, in_split=False):
+def _conv_wgrad_launch(mr, dy, x, dw, K, R, S, stride, pad, acc, groups=1, in_split=False, dy_split=False):
     """dw (+)= weight gradient; groups > 1: dw is [groups, K, C, R, S], one gradient per group of N / groups samples."""
     N, C, H, W = x.shape
     _conv_launch(mr, 'ag2v_conv2d_wgrad_ex', 'conv_wgrad', 2.0 * N * K * dy.shape[2] * dy.shape[3] * C * R * S,
                  _ptr(dy), _ptr(x), _ptr(dw), N, C, H, W, K, R, S, stride, pad, 1 if acc else 0, int(groups), _stream(),
-                 shape=(N, C, H, W, K, R, stride), in_split=in_split)
+                 shape=(N, C, H, W, K, R, stride), in_split=in_split, dy_split=dy_split)
 
 
 class _Conv2d(torch.autograd.Function):
@@ -397,18 +397,21 @@ class _Conv2d(torch.autograd.Function):
         K, _, R, S = w.shape
         dx = dw = db = dres = dgs = None
         st = _stream()
+        dys = is_split(dy_in)       # the gradient arrives as split words (written so by the SPADE backward: ops.conv_split_dy_ok)
+        if dys and ((relu and not grad_premasked) or has_res or dy is not dy_in):
+            raise RuntimeError("conv2d backward: a split-word gradient reached a convolution with a ReLU / residual epilogue")
         if relu and not grad_premasked:
             g = torch.empty_like(dy)
             _lib.call('ag2v_act_bwd', 0, _ptr(dy), _ptr(y), _ptr(g), dy.numel(), 0.0, st)   # op 0 = LeakyReLU(slope 0)
             dy = g
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _conv_dgrad_launch(mr, dy, w, x if relu_input else None, dx, stride, pad, 0, gscale, group_n)
+            _conv_dgrad_launch(mr, dy, w, x if relu_input else None, dx, stride, pad, 0, gscale, group_n, dy_split=dys)
         if gscale is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[4]):
             # per-group weight gradients G_t = dL/d(scale_t W), then dw = sum_t scale_t G_t and dscale_t = <G_t, W> in one pass
             T = gscale.numel()
             G = torch.empty((T,) + tuple(w.shape), device=dy.device, dtype=torch.float32)
-            _conv_wgrad_launch(mr, dy, x, G, K, R, S, stride, pad, 0, groups=T, in_split=ctx.x_split)
+            _conv_wgrad_launch(mr, dy, x, G, K, R, S, stride, pad, 0, groups=T, in_split=ctx.x_split, dy_split=dys)
             buf, acc, dw = _wsink_take(ctx.wkey, w) if ctx.needs_input_grad[1] else (torch.empty_like(w), 0, None)
             dgs = torch.empty(T, device=dy.device, dtype=torch.float32)
             _lib.call('ag2v_sn_group_combine', _ptr(G), _ptr(w), _ptr(gscale), T, w.numel(), _ptr(buf), acc, _ptr(dgs), st)
@@ -417,7 +420,7 @@ class _Conv2d(torch.autograd.Function):
         elif ctx.needs_input_grad[1]:
             buf, acc, dw = _wsink_take(ctx.wkey, w)
             if (_SWAP_FEW_WGRAD and K <= 4 and stride == 1 and dy.shape[2] == H and dy.shape[3] == W and C >= 16 and R == S
-                    and 2 * pad == R - 1 and not ctx.x_split):
+                    and 2 * pad == R - 1 and not ctx.x_split and not dys):
                 # <= 4 output channels (conv_img, the flow / mask heads), same-size convolution: as a GEMM this has 3 rows on a
                 # 32-row tile and gathers x once per tap column (0.38 ms at 8 x 64 x 256 x 256).  With the operands swapped --
                 # x takes dy's role (C dense rows, read once with 16-byte loads), dy is the gathered 3-channel tensor --
@@ -430,7 +433,7 @@ class _Conv2d(torch.autograd.Function):
                 else:
                     buf.copy_(t)
             else:
-                _conv_wgrad_launch(mr, dy, x, buf, K, R, S, stride, pad, acc, in_split=ctx.x_split)
+                _conv_wgrad_launch(mr, dy, x, buf, K, R, S, stride, pad, acc, in_split=ctx.x_split, dy_split=dys)
         if has_bias and ctx.needs_input_grad[2]:
             bbuf, bacc, db = _wsink_take(ctx.bkey, ctx.w_alive[1])
             pre = getattr(dy_in, '_ag2v_channel_sums', None) if not (relu and not grad_premasked) else None
@@ -440,6 +443,8 @@ class _Conv2d(torch.autograd.Function):
                 else:
                     bbuf.copy_(pre)
             else:
+                if dys:
+                    raise RuntimeError("conv2d backward: split-word gradient without its channel sums")
                 _lib.call('ag2v_channel_sum_acc', _ptr(dy), _ptr(bbuf), N, K, dy.shape[2] * dy.shape[3], bacc, st)
         if has_res and ctx.needs_input_grad[3]:
             dres = dy
@@ -451,8 +456,12 @@ def conv2d(x, w, bias=None, stride=1, pad=0, residual=None, relu=False, grad_pre
     grad_premasked / relu_input: see _Conv2d (the pair fuses the ReLU's backward into the consumer's data gradient)."""
     if relu and residual is not None and grad_premasked:
         raise RuntimeError("conv2d: grad_premasked with a residual input is not supported (the residual's gradient would be masked)")
-    return _Conv2d.apply(x, w, bias, residual, gscale, int(stride), int(pad), bool(relu), bool(grad_premasked), bool(relu_input),
-                         is_split(x))
+    y = _Conv2d.apply(x, w, bias, residual, gscale, int(stride), int(pad), bool(relu), bool(grad_premasked), bool(relu_input),
+                      is_split(x))
+    if (not relu and residual is None and int(stride) == 1 and torch.is_grad_enabled() and _USE_CHANNEL_SUMS
+            and conv_split_dy_ok(x.shape, w.shape, stride, pad)):
+        y._ag2v_dy_split_ok = True      # a SPADE backward that is y's only consumer may hand back d(y) as split words
+    return y
 
 
 def is_split(t):
@@ -464,6 +473,16 @@ def is_split(t):
 def mark_split(t):
     t._ag2v_split = True
     return t
+
+
+def conv_split_dy_ok(x_shape, w_shape, stride, pad):
+    """Whether the data gradient and the weight gradient of a convolution of this shape, under the current arithmetic settings, can
+    read the OUTPUT gradient as split words (ag2v_conv_opts::dy_split)."""
+    N, C, H, W = [int(v) for v in x_shape]
+    K, _, R, S = [int(v) for v in w_shape]
+    _, mr_b = _current_min_rows()
+    return bool(_lib.query('ag2v_conv2d_split_dy_ok', N, C, H, W, K, R, S, int(stride), int(pad), int(mr_b or 0), _PRECISION[0])) \
+        and os.environ.get('AG2V_NO_SPLIT_ACT') is None and os.environ.get('AG2V_NO_SPLIT_GRAD') is None
 
 
 def conv_split_input_ok(x_shape, w_shape, stride, pad):
@@ -781,7 +800,8 @@ class _NormAct(torch.autograd.Function):
     the reference normalises every frame pass by itself), running statistics updated once per group, in order."""
 
     @staticmethod
-    def forward(ctx, mode, x, p0, p1, running_mean, running_var, training, momentum, eps, slope, groups, out_split=False):
+    def forward(ctx, mode, x, p0, p1, running_mean, running_var, training, momentum, eps, slope, groups, out_split=False,
+                dgb_split=False):
         from . import distributed as D
         x, p0, p1 = _c(x), _c(p0), _c(p1)
         _chk(x, p0, p1)
@@ -808,8 +828,6 @@ class _NormAct(torch.autograd.Function):
             _lib.call('ag2v_norm_apply_gs', 0, _ptr(x), _ptr(mean), _ptr(invstd), _ptr(p0), _ptr(p1), None, None, _ptr(y),
                       N, C, HW, Ng, float(slope), 1 if out_split else 0, _stream())
         else:
-            if out_split:
-                raise RuntimeError("out_split is implemented for the affine batch norm (mode 0) only")
             if mode == 2 and tuple(p0.shape) != (N, 2 * C) + tuple(x.shape[2:]):
                 raise RuntimeError("spade_norm_fused: gamma|beta tensor must be [N, 2C, H, W]")
             g_ptr, b_ptr = (_ptr(p0), _ptr(p1)) if mode == 1 else (_ptr(p0), _ptr_off(p0, C * HW))
@@ -819,6 +837,7 @@ class _NormAct(torch.autograd.Function):
                     g_ptr, b_ptr, _ptr(y), N, C, HW, Ng, float(slope), _stream(), shape=(N, C, HW))
         ctx.save_for_backward(x, y if slope != 1.0 else None, p0, mean, invstd)
         ctx.cfg = (mode, training, slope, N, C, HW, Ng, world if sync else 0)
+        ctx.dgb_split = bool(dgb_split) and mode == 2 and not sync
         return y
 
     @staticmethod
@@ -832,7 +851,7 @@ class _NormAct(torch.autograd.Function):
         G = N // Ng
         sums = torch.empty((G, C, 4), device=x.device, dtype=torch.float32)
         ws = torch.empty(_lib.query('ag2v_bn_workspace_floats', N, C, HW), device=x.device, dtype=torch.float32)
-        none = (None,) * 10
+        none = (None,) * 11
         gam = p0 if mode >= 1 else None
         wgt = p0 if mode == 0 else None
         dgamma = dbeta = dgb = None
@@ -858,15 +877,15 @@ class _NormAct(torch.autograd.Function):
             if local is not None:
                 sums = local
         else:
-            _launch('ag2v_norm_bwd_g', 'spade_norm_bwd' if mode == 2 else 'norm_bwd', (7.0 if mode == 0 else 11.0) * x.numel() * 4, kmode, _ptr(dy), _ptr(y), _ptr(x),
+            _launch('ag2v_norm_bwd_gs', 'spade_norm_bwd' if mode == 2 else 'norm_bwd', (7.0 if mode == 0 else 11.0) * x.numel() * 4, kmode, _ptr(dy), _ptr(y), _ptr(x),
                     _ptr(gam), _ptr(wgt), _ptr(mean), _ptr(invstd), _ptr(dx), dg_ptr, db_ptr, _ptr(sums), N, C, HW, Ng, float(slope),
-                    _ptr(ws), _stream(), shape=(N, C, HW))
+                    _ptr(ws), 1 if ctx.dgb_split else 0, _stream(), shape=(N, C, HW))
         if mode == 0:
             dw = db = None
             if p0 is not None:
                 tot = sums.sum(dim=0) if G > 1 else sums[0]
                 dw, db = tot[:, 1].contiguous(), tot[:, 0].contiguous()
-            return (None, dx, dw, db) + none[:8]
+            return (None, dx, dw, db) + none[:9]
         if mode == 2:
             # the channel sums of dgamma | dbeta came out of the reduce pass: they ARE the bias gradient of the convolution that produced
             # gamma | beta (layout [N, 2C, H, W]: gamma channels first).  Handed to its backward on the gradient tensor itself (sync mode:
@@ -874,8 +893,10 @@ class _NormAct(torch.autograd.Function):
             if not sync_world:
                 tot = sums.sum(dim=0) if G > 1 else sums[0]
                 dgb._ag2v_channel_sums = torch.cat([tot[:, 3], tot[:, 2]])
-            return (None, dx, dgb, None) + none[:8]
-        return (None, dx, dgamma, dbeta) + none[:8]
+                if ctx.dgb_split:
+                    mark_split(dgb)
+            return (None, dx, dgb, None) + none[:9]
+        return (None, dx, dgamma, dbeta) + none[:9]
 
 
 def batchnorm_act(x, weight, bias, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0, groups=1,
@@ -898,7 +919,7 @@ def spade_norm_fused(x, gb, running_mean, running_var, training=True, momentum=0
     """spade_norm with gamma = gb[:, :C] and beta = gb[:, C:] read in place from the [N, 2C, H, W] output of one convolution
     (and their gradients written in place into one [N, 2C, H, W] tensor)."""
     return _NormAct.apply(2, x, gb, None, running_mean, running_var, bool(training), float(momentum), float(eps),
-                          float(slope), int(groups))
+                          float(slope), int(groups), False, bool(getattr(gb, '_ag2v_dy_split_ok', False)))
 
 
 def spade_pair_supported(H, W, up):
@@ -910,7 +931,7 @@ class _SpadePair(torch.autograd.Function):
     upsampling when up == 2 (see csrc/norm.hip).  gb0 / gb1: [N, 2C, H, W] gamma | beta tensors; training mode only."""
 
     @staticmethod
-    def forward(ctx, xs, gb0, gb1, rm0, rv0, rm1, rv1, up, momentum, eps, slope0, slope1, groups):
+    def forward(ctx, xs, gb0, gb1, rm0, rv0, rm1, rv1, up, momentum, eps, slope0, slope1, groups, dgb_split=False):
         xs, gb0, gb1 = _c(xs), _c(gb0), _c(gb1)
         _chk(xs, gb0, gb1)
         N, C, Hs, Ws = xs.shape
@@ -933,6 +954,7 @@ class _SpadePair(torch.autograd.Function):
                 _ptr(gb1), _ptr(y0), _ptr(y1), N, C, H, W, up, Ng, float(slope0), float(slope1), st, shape=(N, C, H * W, up))
         ctx.save_for_backward(xs, gb0, gb1, y0 if slope0 != 1.0 else None, y1 if slope1 != 1.0 else None, mean, invstd)
         ctx.cfg = (up, slope0, slope1, N, C, H, W, Ng)
+        ctx.dgb_split = bool(dgb_split)
         return y0, y1
 
     @staticmethod
@@ -949,20 +971,23 @@ class _SpadePair(torch.autograd.Function):
         dgb0, dgb1 = torch.empty_like(gb0), torch.empty_like(gb1)
         sums = torch.empty((G, C, 8), device=xs.device, dtype=torch.float32)
         ws = torch.empty(_lib.query('ag2v_spade_pair_workspace_floats', N, C, H * W), device=xs.device, dtype=torch.float32)
-        _launch('ag2v_spade_pair_bwd', 'spade_pair_bwd', (2.0 * xs.numel() + xs.numel() + 16.0 * dy0.numel()) * 4, _ptr(dy0), _ptr(y0), _ptr(dy1),
+        _launch('ag2v_spade_pair_bwd_s', 'spade_pair_bwd', (2.0 * xs.numel() + xs.numel() + 16.0 * dy0.numel()) * 4, _ptr(dy0), _ptr(y0), _ptr(dy1),
                 _ptr(y1), _ptr(xs), _ptr(gb0), _ptr(gb1), _ptr(mean), _ptr(invstd), _ptr(dxs), _ptr(dgb0), _ptr(dgb1), _ptr(sums), N, C, H, W,
-                up, Ng, float(slope0), float(slope1), _ptr(ws), _stream(), shape=(N, C, H * W, up))
+                up, Ng, float(slope0), float(slope1), _ptr(ws), 1 if ctx.dgb_split else 0, _stream(), shape=(N, C, H * W, up))
         tot = sums.sum(dim=0) if G > 1 else sums[0]
         dgb0._ag2v_channel_sums = torch.cat([tot[:, 3], tot[:, 2]])      # bias gradients of the two gamma | beta convolutions
         dgb1._ag2v_channel_sums = torch.cat([tot[:, 7], tot[:, 6]])
-        return (dxs, dgb0, dgb1) + (None,) * 10
+        if ctx.dgb_split:
+            mark_split(dgb0); mark_split(dgb1)
+        return (dxs, dgb0, dgb1) + (None,) * 11
 
 
 def spade_pair(xs, gb0, gb1, rm0, rv0, rm1, rv1, up=1, momentum=0.1, eps=1e-5, slope0=1.0, slope1=1.0, groups=1):
     """Two SPADE modulations of one input (shared batch statistics; both running-stat pairs updated), the input optionally taken
     before its 2x nearest upsampling (up = 2).  Training mode, batch statistics; requires spade_pair_supported(H, W, up)."""
+    split = bool(getattr(gb0, '_ag2v_dy_split_ok', False)) and bool(getattr(gb1, '_ag2v_dy_split_ok', False))
     return _SpadePair.apply(xs, gb0, gb1, rm0, rv0, rm1, rv1, int(up), float(momentum), float(eps), float(slope0), float(slope1),
-                            int(groups))
+                            int(groups), split)
 
 
 class _InstNormLReLU(torch.autograd.Function):

@@ -43,7 +43,9 @@ extern "C" {
  *   kernel:    OUT: name (as rocprofv3 prints it) of the main kernel the call launched (static string);
  *   in_split:  (forward: x; weight gradient: x) the tensor holds SPLIT WORDS -- (bf16(v) << 16) | bf16(v - bf16(v)) per value, as
  *              ag2v_norm_apply_g(out_split = 1) writes them -- instead of fp32: the bf16x3 kernels then skip their own split
- *              (bit-identical results).  Only where ag2v_conv2d_split_input_ok() says so; otherwise AG2V_EINVAL. */
+ *              (bit-identical results).  Only where ag2v_conv2d_split_input_ok() says so; otherwise AG2V_EINVAL;
+ *   dy_split:  (data gradient, weight gradient) the same for the output gradient dy (written split by ag2v_norm_bwd_gs /
+ *              ag2v_spade_pair_bwd_s); only where ag2v_conv2d_split_dy_ok() says so. */
 typedef struct ag2v_conv_opts {
     int precision;
     int min_rows;
@@ -51,6 +53,7 @@ typedef struct ag2v_conv_opts {
     int group_n;
     const char* kernel;
     int in_split;
+    int dy_split;
 } ag2v_conv_opts;
 /* Defaults of calls without options (process-wide; the product passes options on every call). */
 int ag2v_set_conv_precision(int mode);
@@ -99,6 +102,7 @@ int ag2v_conv2d_wgrad_ex(const float* dy, const float* x, float* dw, int N, int 
                          int stride, int pad, int accumulate, int groups, void* stream, ag2v_conv_opts* opts);
 int ag2v_conv2d_split_input_ok(int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int min_rows_fwd,
                                int min_rows_bwd, int precision);
+int ag2v_conv2d_split_dy_ok(int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int min_rows_bwd, int precision);
 /* accumulate != 0: dw += instead of dw = (a weight used by several forward calls of one step collects its gradient in one buffer). */
 int ag2v_conv2d_wgrad_acc(const float* dy, const float* x, float* dw, int N, int C, int H, int W, int K, int R, int S,
                           int stride, int pad, int accumulate, void* stream);
@@ -139,6 +143,11 @@ int ag2v_norm_apply_gs(int mode, const float* x, const float* mean, const float*
 int ag2v_norm_bwd_g(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* w,
                     const float* mean, const float* invstd, float* dx, float* dgamma, float* dbeta, float* sums,
                     int N, int C, int HW, int Ng, float slope, float* workspace, void* stream);
+/* ag2v_norm_bwd_g whose dgamma / dbeta (modes 1 / 2) are stored as split words when dgb_split != 0 (ag2v_conv_opts::dy_split): the
+ * gradient of the convolution that produced gamma | beta goes into that convolution's data gradient and weight gradient only. */
+int ag2v_norm_bwd_gs(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* w,
+                     const float* mean, const float* invstd, float* dx, float* dgamma, float* dbeta, float* sums,
+                     int N, int C, int HW, int Ng, float slope, float* workspace, int dgb_split, void* stream);
 /* ag2v_norm_bwd_g in two steps, for data-parallel SYNCHRONISED batch norm (sync_batchnorm/batchnorm.py:105-126): the caller
  * all-reduces sums[N / Ng, C, 4] over the ranks between them and passes inv_count = 1 / (elements per (group, channel) over ALL ranks). */
 int ag2v_norm_bwd_reduce_g(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* mean,
@@ -161,6 +170,11 @@ int ag2v_spade_pair_apply(const float* xs, const float* mean, const float* invst
 int ag2v_spade_pair_bwd(const float* dy0, const float* y0, const float* dy1, const float* y1, const float* xs, const float* gb0,
                         const float* gb1, const float* mean, const float* invstd, float* dxs, float* dgb0, float* dgb1, float* sums,
                         int N, int C, int H, int W, int up, int Ng, float slope0, float slope1, float* workspace, void* stream);
+/* ... with dgb0 / dgb1 stored as split words when dgb_split != 0 (see ag2v_norm_bwd_gs). */
+int ag2v_spade_pair_bwd_s(const float* dy0, const float* y0, const float* dy1, const float* y1, const float* xs, const float* gb0,
+                          const float* gb1, const float* mean, const float* invstd, float* dxs, float* dgb0, float* dgb1,
+                          float* sums, int N, int C, int H, int W, int up, int Ng, float slope0, float slope1, float* workspace,
+                          int dgb_split, void* stream);
 int ag2v_instnorm_lrelu_fwd(const float* x, float* y, float* mean, float* invstd, int NC, int HW, float eps, float slope,
                             void* stream);
 int ag2v_instnorm_lrelu_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,

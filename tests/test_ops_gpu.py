@@ -541,6 +541,51 @@ def test_conv2d_split_word_input(cfg, device):
             ops.conv2d(ops.mark_split(_to_split_words(x)), w, b, 1, pad)
 
 
+@pytest.mark.parametrize("pair", [False, True], ids=['fused', 'pair'])
+def test_spade_gradient_as_split_words(pair, device, monkeypatch):
+    """gamma | beta = conv(actv) -> SPADE modulation: the modulation's backward hands d(gamma | beta) to the convolution as split
+    words (data gradient, weight gradient; the bias gradient comes from the reduce pass' sums).  Same gradients as with fp32
+    hand-over, to atomics noise."""
+    from ag2video_amd import ops
+    torch.manual_seed(11)
+    N, Cn, Ch, H, W = 4, 64, 128, 32, 32
+    up = 2 if pair else 1
+    xs = torch.randn(N, Cn, H // up, W // up, device=device)
+    actv0 = torch.relu(torch.randn(N, Ch, H, W, device=device))
+    ws = [(torch.randn(2 * Cn, Ch, 3, 3, device=device) * 0.03) for _ in range(2)]
+    bs = [torch.randn(2 * Cn, device=device) * 0.1 for _ in range(2)]
+    wout = torch.randn(N, Cn, H, W, device=device)
+
+    def run():
+        seen = []
+        actv = actv0.clone().requires_grad_(True)
+        x = xs.clone().requires_grad_(True)
+        w = [t.clone().requires_grad_(True) for t in ws]
+        b = [t.clone().requires_grad_(True) for t in bs]
+        bufs = [torch.zeros(Cn, device=device), torch.ones(Cn, device=device), torch.zeros(Cn, device=device), torch.ones(Cn, device=device)]
+        with ops.conv_precision('bf16x3'), ops.bf16x3_min_rows(32), ops.frame_groups(2):
+            gb0 = ops.conv2d(actv, w[0], b[0], 1, 1, relu_input=True)
+            if pair:
+                gb1 = ops.conv2d(actv, w[1], b[1], 1, 1, relu_input=True)
+                y0, y1 = ops.spade_pair(x, gb0, gb1, bufs[0], bufs[1], bufs[2], bufs[3], 2, 0.1, 1e-5, 0.2, 1.0, 2)
+                loss = (y0 * wout).sum() + 0.5 * (y1 * wout).sum()
+                leaves = [actv, x, w[0], w[1], b[0], b[1]]
+            else:
+                y = ops.spade_norm_fused(x, gb0, bufs[0], bufs[1], True, 0.1, 1e-5, 0.2, groups=2)
+                loss = (y * wout).sum()
+                leaves = [actv, x, w[0], b[0]]
+            gb0.register_hook(lambda g: seen.append(ops.is_split(g)))
+            grads = torch.autograd.grad(loss, leaves)
+        return grads, seen
+    split, seen = run()
+    assert seen == [True]
+    monkeypatch.setenv('AG2V_NO_SPLIT_GRAD', '1')
+    plain, seen = run()
+    assert seen == [False]
+    for a, c in zip(split, plain):
+        assert float((a - c).abs().max()) <= 1e-5 * float(c.abs().max())
+
+
 def test_linear_unaligned_operands(device):
     """The one-round-trip GEMM reads k-contiguous operands with 16-byte loads when their rows are 16-byte aligned and with 4-byte
     loads otherwise (views into a flat buffer at any element offset): same results either way, forward and both gradients."""
