@@ -49,6 +49,7 @@ _SIGS = {
     'ag2v_spade_pair_workspace_floats': (c_size_t, [c_int, c_int, c_int]),
     'ag2v_spade_pair_stats': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
     'ag2v_spade_pair_apply': (c_int, [_P] * 7 + [c_int] * 6 + [c_float, c_float, _P]),
+    'ag2v_spade_pair_apply_s': (c_int, [_P] * 7 + [c_int] * 6 + [c_float, c_float, c_int, c_int, _P]),
     'ag2v_spade_pair_bwd': (c_int, [_P] * 13 + [c_int] * 6 + [c_float, c_float, _P, _P]),
     'ag2v_spade_pair_bwd_s': (c_int, [_P] * 13 + [c_int] * 6 + [c_float, c_float, _P, c_int, _P]),
     'ag2v_instnorm_lrelu_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P]),

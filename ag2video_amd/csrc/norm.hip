@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void spade_pair_apply_kernel(const float* __re
                                                                const float* __restrict__ invstd, const float* __restrict__ gb0,
                                                                const float* __restrict__ gb1, float* __restrict__ y0,
                                                                float* __restrict__ y1, int C, int HW, int W, int nchunk, float slope0,
-                                                               float slope1, int Ng) {
+                                                               float slope1, int Ng, int split0, int split1) {
     const int bid = blockIdx.x;
     const int chunk = bid % nchunk, nc = bid / nchunk;
     const int n = nc / C, c = nc - n * C;
@@ -369,11 +369,19 @@ __global__ __launch_bounds__(256) void spade_pair_apply_kernel(const float* __re
     load16<true>(gb0 + goff + (size_t)C * HW, cnt, be, mask);
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[i] = lrelu_f(v[i] * (1.f + g[i]) + be[i], slope0);
+    if (split0) {       // read by a bf16x3 convolution only: stored as split words (ag2v_conv_opts::in_split)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[i] = pack_split(o[i]);
+    }
     store16<true>(y0 + off, cnt, o);
     load16<true>(gb1 + goff, cnt, g, mask);
     load16<true>(gb1 + goff + (size_t)C * HW, cnt, be, mask);
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[i] = lrelu_f(v[i] * (1.f + g[i]) + be[i], slope1);
+    if (split1) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[i] = pack_split(o[i]);
+    }
     store16<true>(y1 + off, cnt, o);
 }
 
@@ -771,18 +779,24 @@ extern "C" int ag2v_spade_pair_stats(const float* xs, int N, int C, int HWs, int
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
 }
-extern "C" int ag2v_spade_pair_apply(const float* xs, const float* mean, const float* invstd, const float* gb0, const float* gb1, float* y0,
-                                     float* y1, int N, int C, int H, int W, int up, int Ng, float slope0, float slope1, void* stream) {
+// split0 / split1 != 0: y0 / y1 stored as split words (see ag2v_norm_apply_gs)
+extern "C" int ag2v_spade_pair_apply_s(const float* xs, const float* mean, const float* invstd, const float* gb0, const float* gb1, float* y0,
+                                       float* y1, int N, int C, int H, int W, int up, int Ng, float slope0, float slope1, int split0,
+                                       int split1, void* stream) {
     if (!xs || !mean || !invstd || !gb0 || !gb1 || !y0 || !y1 || N <= 0 || C <= 0 || Ng <= 0 || N % Ng != 0) return AG2V_EINVAL;
     if (!ag2v_spade_pair_supported(H, W, up) || !vec_ok(H * W, xs, gb0, gb1, y0, y1)) return AG2V_EINVAL;
     const int HW = H * W, nchunk = ceil_div(HW, CHUNK);
     const long long nblk = (long long)N * C * nchunk;
     if (nblk >= (1LL << 31)) return AG2V_EINVAL;
     dim3 g((unsigned)nblk), t(256);
-    if (up == 1) hipLaunchKernelGGL(spade_pair_apply_kernel<1>, g, t, 0, (hipStream_t)stream, xs, mean, invstd, gb0, gb1, y0, y1, C, HW, W, nchunk, slope0, slope1, Ng);
-    else hipLaunchKernelGGL(spade_pair_apply_kernel<2>, g, t, 0, (hipStream_t)stream, xs, mean, invstd, gb0, gb1, y0, y1, C, HW, W, nchunk, slope0, slope1, Ng);
+    if (up == 1) hipLaunchKernelGGL(spade_pair_apply_kernel<1>, g, t, 0, (hipStream_t)stream, xs, mean, invstd, gb0, gb1, y0, y1, C, HW, W, nchunk, slope0, slope1, Ng, split0 ? 1 : 0, split1 ? 1 : 0);
+    else hipLaunchKernelGGL(spade_pair_apply_kernel<2>, g, t, 0, (hipStream_t)stream, xs, mean, invstd, gb0, gb1, y0, y1, C, HW, W, nchunk, slope0, slope1, Ng, split0 ? 1 : 0, split1 ? 1 : 0);
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
+}
+extern "C" int ag2v_spade_pair_apply(const float* xs, const float* mean, const float* invstd, const float* gb0, const float* gb1, float* y0,
+                                     float* y1, int N, int C, int H, int W, int up, int Ng, float slope0, float slope1, void* stream) {
+    return ag2v_spade_pair_apply_s(xs, mean, invstd, gb0, gb1, y0, y1, N, C, H, W, up, Ng, slope0, slope1, 0, 0, stream);
 }
 // sums [N / Ng, C, 8] = per norm k: (sum dxhat_k, sum dxhat_k xhat, sum dbeta_k, sum dgamma_k); dxs [N, C, H/up, W/up]; dgb0 / dgb1 like gb.
 extern "C" int ag2v_spade_pair_bwd_s(const float* dy0, const float* y0, const float* dy1, const float* y1, const float* xs, const float* gb0,

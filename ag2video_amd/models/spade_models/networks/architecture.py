@@ -36,6 +36,14 @@ class SPADEResnetBlock(nn.Module):
         actv = ops.conv2d_shared_input(seg_r, [c.weight for c in sh], [c.bias for c in sh], sh[0].stride[0], sh[0].padding[0],
                                        relu=True, grad_premasked=True)
         bn0, bns = self.norm_0.param_free_norm, (self.norm_s.param_free_norm if self.learned_shortcut else None)
+        # the modulated tensors are read by one convolution each and nothing else: stored as split words where that convolution
+        # takes them (forward + weight gradient on the bf16x3 kernels, ops.conv_split_input_ok)
+
+        def takes_split(conv, cin):
+            return self.training and ops.conv_split_input_ok((x.shape[0], cin, H, W), conv.weight_orig.shape, conv.stride, conv.padding)
+        s0 = takes_split(self.conv_0, x.shape[1])
+        ss = self.learned_shortcut and takes_split(self.conv_s, x.shape[1])
+        s1 = takes_split(self.conv_1, self.conv_0.out_channels)
         from .... import distributed as D
         if (self.learned_shortcut and self.training and not D.sync_bn() and ops.spade_pair_supported(H, W, up)
                 and os.environ.get('AG2V_NO_SPADE_PAIR') is None):
@@ -43,15 +51,15 @@ class SPADEResnetBlock(nn.Module):
             # gradient -- and with up = 2 the upsampled tensor never exists (ops.spade_pair)
             y0, ys = ops.spade_pair(x, self.norm_0.gamma_beta(actv[0]), self.norm_s.gamma_beta(actv[2]), bn0.running_mean,
                                     bn0.running_var, bns.running_mean, bns.running_var, up, bn0.momentum, bn0.eps, 0.2, 1.0,
-                                    ops.current_frame_groups())
+                                    ops.current_frame_groups(), out_split=(s0, ss))
             x_s = self.conv_s(ys)
             dx = self.conv_0(y0)
         else:
             if up == 2:
                 x = ops.upsample2x(x)
-            x_s = self.conv_s(self.norm_s(x, seg, actv=actv[2])) if self.learned_shortcut else x
-            dx = self.conv_0(self.norm_0(x, seg, slope=0.2, actv=actv[0]))
-        return self.conv_1(self.norm_1(dx, seg, slope=0.2, actv=actv[1]), residual=x_s)   # out = x_s + dx fused in the conv epilogue
+            x_s = self.conv_s(self.norm_s(x, seg, actv=actv[2], out_split=ss)) if self.learned_shortcut else x
+            dx = self.conv_0(self.norm_0(x, seg, slope=0.2, actv=actv[0], out_split=s0))
+        return self.conv_1(self.norm_1(dx, seg, slope=0.2, actv=actv[1], out_split=s1), residual=x_s)   # out = x_s + dx fused in the conv epilogue
 
 # torchvision.models.vgg19 "features" configuration ('E': 16 conv3x3 + ReLU layers, 'M' = MaxPool2d(2, 2)); the reference pins
 # torchvision 0.5.0 (README.md:23).  Module indices inside ``features`` are what the slices below are named after.

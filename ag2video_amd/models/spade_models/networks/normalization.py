@@ -132,7 +132,7 @@ class SPADE(nn.Module):
             return segmap.at(x.shape[2], x.shape[3])
         return ops.nearest_resize(segmap, x.shape[2], x.shape[3])
 
-    def forward(self, x, segmap, slope=1.0, actv=None):
+    def forward(self, x, segmap, slope=1.0, actv=None, out_split=False):
         """slope: LeakyReLU fused behind the modulation (the caller's actvn, architecture.py:53-54); 1.0 = none.
         ``segmap`` may be a SegmapPyramid: every SPADE of a decoder pass resizes the same map to one of six sizes, so
         the nearest-neighbour resize (normalization.py:102) is done once per size instead of once per SPADE.
@@ -144,7 +144,7 @@ class SPADE(nn.Module):
             # gamma|beta convolution's data gradient (actv has no other consumer)
             sh = self.mlp_shared[0]
             actv = ops.conv2d(seg, sh.weight, sh.bias, sh.stride[0], sh.padding[0], relu=True, grad_premasked=True)
-        return self.param_free_norm.modulate_fused(x, self.gamma_beta(actv), slope)
+        return self.param_free_norm.modulate_fused(x, self.gamma_beta(actv), slope, out_split=out_split)
 
     def gamma_beta(self, actv):
         """gamma | beta as ONE [N, 2C, H, W] tensor: mlp_gamma and mlp_beta read the same activation, so they run as one convolution

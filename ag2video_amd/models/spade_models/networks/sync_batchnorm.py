@@ -51,7 +51,7 @@ class SynchronizedBatchNorm2d(nn.Module):
         return ops.spade_norm(x, gamma, beta, self.running_mean, self.running_var, self.training, self.momentum, self.eps,
                               slope, groups=ops.current_frame_groups())
 
-    def modulate_fused(self, x, gb, slope=1.0):
+    def modulate_fused(self, x, gb, slope=1.0, out_split=False):
         """modulate() with gamma | beta as the channel halves of one [N, 2C, H, W] tensor."""
         return ops.spade_norm_fused(x, gb, self.running_mean, self.running_var, self.training, self.momentum, self.eps, slope,
-                                    groups=ops.current_frame_groups())
+                                    groups=ops.current_frame_groups(), out_split=out_split)

@@ -833,8 +833,8 @@ class _NormAct(torch.autograd.Function):
             g_ptr, b_ptr = (_ptr(p0), _ptr(p1)) if mode == 1 else (_ptr(p0), _ptr_off(p0, C * HW))
             # timed as an HBM-bound kernel: algorithmic bytes = x, gamma, beta read + y written (4 tensors), recorded in
             # the "flops" slot of the timing record
-            _launch('ag2v_norm_apply_g', 'spade_norm_apply', 4.0 * x.numel() * 4, mode, _ptr(x), _ptr(mean), _ptr(invstd), None, None,
-                    g_ptr, b_ptr, _ptr(y), N, C, HW, Ng, float(slope), _stream(), shape=(N, C, HW))
+            _launch('ag2v_norm_apply_gs', 'spade_norm_apply', 4.0 * x.numel() * 4, mode, _ptr(x), _ptr(mean), _ptr(invstd), None, None,
+                    g_ptr, b_ptr, _ptr(y), N, C, HW, Ng, float(slope), 1 if out_split else 0, _stream(), shape=(N, C, HW))
         ctx.save_for_backward(x, y if slope != 1.0 else None, p0, mean, invstd)
         ctx.cfg = (mode, training, slope, N, C, HW, Ng, world if sync else 0)
         ctx.dgb_split = bool(dgb_split) and mode == 2 and not sync
@@ -915,11 +915,12 @@ def spade_norm(x, gamma, beta, running_mean, running_var, training=True, momentu
                           float(slope), int(groups))
 
 
-def spade_norm_fused(x, gb, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0, groups=1):
+def spade_norm_fused(x, gb, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0, groups=1, out_split=False):
     """spade_norm with gamma = gb[:, :C] and beta = gb[:, C:] read in place from the [N, 2C, H, W] output of one convolution
     (and their gradients written in place into one [N, 2C, H, W] tensor)."""
-    return _NormAct.apply(2, x, gb, None, running_mean, running_var, bool(training), float(momentum), float(eps),
-                          float(slope), int(groups), False, bool(getattr(gb, '_ag2v_dy_split_ok', False)))
+    y = _NormAct.apply(2, x, gb, None, running_mean, running_var, bool(training), float(momentum), float(eps),
+                       float(slope), int(groups), bool(out_split), bool(getattr(gb, '_ag2v_dy_split_ok', False)))
+    return mark_split(y) if out_split else y
 
 
 def spade_pair_supported(H, W, up):
@@ -931,7 +932,8 @@ class _SpadePair(torch.autograd.Function):
     upsampling when up == 2 (see csrc/norm.hip).  gb0 / gb1: [N, 2C, H, W] gamma | beta tensors; training mode only."""
 
     @staticmethod
-    def forward(ctx, xs, gb0, gb1, rm0, rv0, rm1, rv1, up, momentum, eps, slope0, slope1, groups, dgb_split=False):
+    def forward(ctx, xs, gb0, gb1, rm0, rv0, rm1, rv1, up, momentum, eps, slope0, slope1, groups, dgb_split=False, split0=False,
+                split1=False):
         xs, gb0, gb1 = _c(xs), _c(gb0), _c(gb1)
         _chk(xs, gb0, gb1)
         N, C, Hs, Ws = xs.shape
@@ -950,8 +952,9 @@ class _SpadePair(torch.autograd.Function):
         y0 = torch.empty((N, C, H, W), device=xs.device, dtype=torch.float32)
         y1 = torch.empty_like(y0)
         # algorithmic bytes: x (at its own resolution) + 4 gamma / beta planes read, 2 outputs written
-        _launch('ag2v_spade_pair_apply', 'spade_pair_apply', (xs.numel() + 6.0 * y0.numel()) * 4, _ptr(xs), _ptr(mean), _ptr(invstd), _ptr(gb0),
-                _ptr(gb1), _ptr(y0), _ptr(y1), N, C, H, W, up, Ng, float(slope0), float(slope1), st, shape=(N, C, H * W, up))
+        _launch('ag2v_spade_pair_apply_s', 'spade_pair_apply', (xs.numel() + 6.0 * y0.numel()) * 4, _ptr(xs), _ptr(mean), _ptr(invstd), _ptr(gb0),
+                _ptr(gb1), _ptr(y0), _ptr(y1), N, C, H, W, up, Ng, float(slope0), float(slope1), 1 if split0 else 0, 1 if split1 else 0, st,
+                shape=(N, C, H * W, up))
         ctx.save_for_backward(xs, gb0, gb1, y0 if slope0 != 1.0 else None, y1 if slope1 != 1.0 else None, mean, invstd)
         ctx.cfg = (up, slope0, slope1, N, C, H, W, Ng)
         ctx.dgb_split = bool(dgb_split)
@@ -979,15 +982,20 @@ class _SpadePair(torch.autograd.Function):
         dgb1._ag2v_channel_sums = torch.cat([tot[:, 7], tot[:, 6]])
         if ctx.dgb_split:
             mark_split(dgb0); mark_split(dgb1)
-        return (dxs, dgb0, dgb1) + (None,) * 11
+        return (dxs, dgb0, dgb1) + (None,) * 13
 
 
-def spade_pair(xs, gb0, gb1, rm0, rv0, rm1, rv1, up=1, momentum=0.1, eps=1e-5, slope0=1.0, slope1=1.0, groups=1):
+def spade_pair(xs, gb0, gb1, rm0, rv0, rm1, rv1, up=1, momentum=0.1, eps=1e-5, slope0=1.0, slope1=1.0, groups=1, out_split=(False, False)):
     """Two SPADE modulations of one input (shared batch statistics; both running-stat pairs updated), the input optionally taken
     before its 2x nearest upsampling (up = 2).  Training mode, batch statistics; requires spade_pair_supported(H, W, up)."""
     split = bool(getattr(gb0, '_ag2v_dy_split_ok', False)) and bool(getattr(gb1, '_ag2v_dy_split_ok', False))
-    return _SpadePair.apply(xs, gb0, gb1, rm0, rv0, rm1, rv1, int(up), float(momentum), float(eps), float(slope0), float(slope1),
-                            int(groups), split)
+    y0, y1 = _SpadePair.apply(xs, gb0, gb1, rm0, rv0, rm1, rv1, int(up), float(momentum), float(eps), float(slope0), float(slope1),
+                              int(groups), split, bool(out_split[0]), bool(out_split[1]))
+    if out_split[0]:
+        mark_split(y0)
+    if out_split[1]:
+        mark_split(y1)
+    return y0, y1
 
 
 class _InstNormLReLU(torch.autograd.Function):

@@ -167,6 +167,10 @@ int ag2v_spade_pair_stats(const float* xs, int N, int C, int HWs, int Ng, int re
                           float* rm0, float* rv0, float* rm1, float* rv1, float* workspace, void* stream);
 int ag2v_spade_pair_apply(const float* xs, const float* mean, const float* invstd, const float* gb0, const float* gb1, float* y0, float* y1,
                           int N, int C, int H, int W, int up, int Ng, float slope0, float slope1, void* stream);
+/* ... with y0 / y1 stored as split words when split0 / split1 != 0 (ag2v_conv_opts::in_split of the convolutions that read them). */
+int ag2v_spade_pair_apply_s(const float* xs, const float* mean, const float* invstd, const float* gb0, const float* gb1, float* y0,
+                            float* y1, int N, int C, int H, int W, int up, int Ng, float slope0, float slope1, int split0, int split1,
+                            void* stream);
 int ag2v_spade_pair_bwd(const float* dy0, const float* y0, const float* dy1, const float* y1, const float* xs, const float* gb0,
                         const float* gb1, const float* mean, const float* invstd, float* dxs, float* dgb0, float* dgb1, float* sums,
                         int N, int C, int H, int W, int up, int Ng, float slope0, float slope1, float* workspace, void* stream);

@@ -108,14 +108,14 @@ def spade_norm(x, gamma, beta, running_mean, running_var, training=True, momentu
     return _lrelu(n * (1 + gamma) + beta, slope)
 
 
-def spade_norm_fused(x, gb, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0, groups=1):
+def spade_norm_fused(x, gb, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0, groups=1, out_split=False):
     """spade_norm with gamma | beta stacked along channels (the product runs mlp_gamma and mlp_beta, normalization.py:105-106,
     as one convolution)."""
     C = x.shape[1]
     return spade_norm(x, gb[:, :C], gb[:, C:], running_mean, running_var, training, momentum, eps, slope, groups)
 
 
-def spade_pair(xs, gb0, gb1, rm0, rv0, rm1, rv1, up=1, momentum=0.1, eps=1e-5, slope0=1.0, slope1=1.0, groups=1):
+def spade_pair(xs, gb0, gb1, rm0, rv0, rm1, rv1, up=1, momentum=0.1, eps=1e-5, slope0=1.0, slope1=1.0, groups=1, out_split=(False, False)):
     """Checker for ops.spade_pair: nn.Upsample(scale_factor=2) (spade_generator.py:62-76) followed by the block's two SPADE layers on
     the same input (norm_0 / norm_s, architecture.py:52-53,60-61), each with its own running buffers."""
     x = upsample2x(xs) if up == 2 else xs
