@@ -101,7 +101,7 @@ EXPORTS = tuple(sorted(_SIGS))
 class ConvOpts(ctypes.Structure):
     """ag2v_conv_opts (include/ag2v.h): per-call options of the *_ex convolution entry points."""
     _fields_ = [('precision', c_int), ('min_rows', c_int), ('gscale', c_void_p), ('group_n', c_int), ('kernel', c_char_p),
-                ('in_split', c_int), ('dy_split', c_int)]
+                ('in_split', c_int), ('dy_split', c_int), ('out_split', c_int)]
 
 _lib = None
 

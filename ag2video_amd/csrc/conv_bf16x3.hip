@@ -499,6 +499,7 @@ __device__ __forceinline__ void igemm_bf16x3_body(const ConvArgs& p) {
             if (p.splitk == 1) {   // (a split-K launch applies these in a pass over the finished sums: launch_act_mask)
                 if (p.relu) v = fmaxf(v, 0.f);
                 if (mbase) v = (mbase[(size_t)m * plane] > 0.f) ? v : 0.f;
+                if (p.out_split) v = pack_split(v);
             }
             if (p.splitk > 1)
                 atomicAdd(obase + (size_t)m * plane, v);
@@ -542,6 +543,7 @@ __device__ __forceinline__ void igemm_bf16x3_body(const ConvArgs& p) {
             const float rmul = (rbase && kt0 == 0) ? 1.f : 0.f;                         // residual added by the first K chunk only
             const float relu_floor = (p.relu && p.splitk == 1) ? 0.f : ninf;
             const float mask_thr = mbase ? 0.f : ninf;                                  // no mask: every word passes
+            const bool osplit = p.out_split && p.splitk == 1;                           // (split-K: launch_act_mask packs)
             // the residual / mask words of all 32 rows are requested before the first store of the block goes out (a wait for
             // loads issued after stores would wait for those stores as well: vmcnt counts in issue order)
             float axa[4][8];
@@ -578,6 +580,10 @@ __device__ __forceinline__ void igemm_bf16x3_body(const ConvArgs& p) {
                     x = fmaf(ax[k], rmul, x);
                     x = fmaxf(x, relu_floor);
                     v[k] = (ax[k] > mask_thr) ? x : 0.f;
+                }
+                if (osplit) {       // (wave-uniform) the activation goes to bf16x3 convolutions only: stored as split words
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = pack_split(v[k]);
                 }
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -1137,8 +1143,8 @@ int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed) {
     }
 #undef AG2V_LAUNCH_IGEMM
     AG2V_CHECK_LAUNCH();
-    if (a.splitk > 1 && (a.relu || a.mask))
-        return launch_act_mask(a.out, a.mask, (long long)a.N * a.M * a.o_H * a.o_W, a.relu, st);
+    if (a.splitk > 1 && (a.relu || a.mask || a.out_split))
+        return launch_act_mask(a.out, a.mask, (long long)a.N * a.M * a.o_H * a.o_W, a.relu, st, a.out_split);
     return AG2V_OK;
 }
 

@@ -28,6 +28,8 @@ struct ConvArgs {
     int group_n;            //   before bias / residual -- spectral norm's 1/sigma_t of frame group t (frame-batched generator)
     int groups, gq, spg;    // wgrad: `groups` consecutive sample groups of gq pixels each, spg pixel-range splits per group (grid =
     long long out_gstride;  //   tiles x groups x spg); group g writes dW at out + g * out_gstride.  groups == 1: the plain form.
+    int out_split;          // igemm bf16x3 epilogue: store the finished values as split words (forward with relu: the activation is
+                            //   read by bf16x3 convolutions only)
     int a_split;            // weight-gradient bf16x3 kernels: dy (a_src) holds split words
     int b_split;            // bf16x3 kernels: b_src holds split words ((bf16 hi << 16) | bf16 lo per value, pack_split()) instead of fp32
 #ifdef AG2V_STAMPS
@@ -115,7 +117,7 @@ __device__ __forceinline__ u32x4 bload_u32x4(__amdgpu_buffer_rsrc_t r, unsigned 
 
 // out = relu ? max(out, 0) : out;  out = mask ? (mask > 0 ? out : 0) : out -- the epilogue of a split-K launch, whose workgroups
 // only hold partial sums (implemented in conv_igemm.hip)
-int launch_act_mask(float* out, const float* mask, long long n, int relu, hipStream_t st);
+int launch_act_mask(float* out, const float* mask, long long n, int relu, hipStream_t st, int pack = 0);
 
 // name of the main kernel of the most recent convolution entry point (as rocprofv3 prints it), for bench.py's per-kernel
 // timing table: ag2v_last_conv_kernel()

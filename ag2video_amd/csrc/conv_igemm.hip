@@ -509,12 +509,13 @@ struct ag2v_conv_opts {
     const char* kernel;
     int in_split;
     int dy_split;
+    int out_split;
 };
 struct ConvCfg {
     int precision, min_rows;
     const float* gscale;
     int group_n;
-    int in_split, dy_split;
+    int in_split, dy_split, out_split;
 };
 static ConvCfg conv_cfg(const ag2v_conv_opts* o) {
     ConvCfg c;
@@ -524,6 +525,7 @@ static ConvCfg conv_cfg(const ag2v_conv_opts* o) {
     c.group_n = (o && o->group_n > 0) ? o->group_n : 1;
     c.in_split = (o && o->in_split) ? 1 : 0;
     c.dy_split = (o && o->dy_split) ? 1 : 0;
+    c.out_split = (o && o->out_split) ? 1 : 0;
     return c;
 }
 static bool use_bf16x3(const ConvCfg& c, int M) { return c.precision == 1 && M >= c.min_rows; }
@@ -531,7 +533,8 @@ static const long long kBufMax = (1LL << 32) - 64;   // raw buffer descriptors c
 
 
 // ---------------------------------------------------------------- epilogue pass of split-K launches
-__global__ __launch_bounds__(256) void act_mask_kernel(float* __restrict__ out, const float* __restrict__ mask, long long n, int relu) {
+__global__ __launch_bounds__(256) void act_mask_kernel(float* __restrict__ out, const float* __restrict__ mask, long long n, int relu,
+                                                       int pack) {
     const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i + 3 < n) {
         float4 v = *reinterpret_cast<float4*>(out + i);
@@ -540,20 +543,22 @@ __global__ __launch_bounds__(256) void act_mask_kernel(float* __restrict__ out, 
             const float4 m = *reinterpret_cast<const float4*>(mask + i);
             v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
         }
+        if (pack) { v.x = pack_split(v.x); v.y = pack_split(v.y); v.z = pack_split(v.z); v.w = pack_split(v.w); }
         *reinterpret_cast<float4*>(out + i) = v;
     } else {
         for (long long k = i; k < n; ++k) {
             float v = out[k];
             if (relu) v = fmaxf(v, 0.f);
             if (mask) v = mask[k] > 0.f ? v : 0.f;
-            out[k] = v;
+            out[k] = pack ? pack_split(v) : v;
         }
     }
 }
-int launch_act_mask(float* out, const float* mask, long long n, int relu, hipStream_t st) {
-    if (n <= 0 || (!relu && !mask)) return AG2V_OK;
+// pack != 0: the finished values are rewritten as split words (ConvArgs::out_split of a split-K launch)
+int launch_act_mask(float* out, const float* mask, long long n, int relu, hipStream_t st, int pack) {
+    if (n <= 0 || (!relu && !mask && !pack)) return AG2V_OK;
     if ((((uintptr_t)out) & 15) || (mask && (((uintptr_t)mask) & 15))) return AG2V_EINVAL;
-    hipLaunchKernelGGL(act_mask_kernel, dim3((unsigned)ceil_div(ceil_div(n, 4LL), 256LL)), dim3(256), 0, st, out, mask, n, relu);
+    hipLaunchKernelGGL(act_mask_kernel, dim3((unsigned)ceil_div(ceil_div(n, 4LL), 256LL)), dim3(256), 0, st, out, mask, n, relu, pack);
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
 }
@@ -794,7 +799,8 @@ extern "C" int ag2v_conv2d_fwd_ex(const float* x, const float* w, const float* b
         nmax = chunk_samples(xs * 4, 0, cfg.gscale ? cfg.group_n : 1);
         if (nmax <= 0) { split = false; nmax = N; }
     }
-    if (cfg.in_split && !split) return AG2V_EINVAL;        // split words are only read by the bf16x3 kernels (ag2v_conv2d_split_input_ok)
+    if ((cfg.in_split || cfg.out_split) && !split) return AG2V_EINVAL;   // split words: bf16x3 kernels only (ag2v_conv2d_split_input_ok)
+    if (cfg.out_split && residual) return AG2V_EINVAL;
     if ((long long)nmax * OH * OW >= (1LL << 31)) {         // the GEMM's pixel index is a 32-bit int
         nmax = (int)(((1LL << 31) - 1) / ((long long)OH * OW));
         if (cfg.gscale) nmax -= nmax % cfg.group_n;
@@ -818,7 +824,7 @@ extern "C" int ag2v_conv2d_fwd_ex(const float* x, const float* w, const float* b
         a.a_bytes = (unsigned)abytes; a.b_bytes = split ? (unsigned)(xs * 4 * nc) : 0u;
         a.tap_major = tapmaj ? 1 : 0;
         a.a_src = workspace;
-        a.b_split = cfg.in_split;
+        a.b_split = cfg.in_split; a.out_split = cfg.out_split;
         const int rc = launch_igemm(a, st, false, split);
         if (rc != AG2V_OK) return rc;
     }

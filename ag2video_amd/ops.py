@@ -154,11 +154,12 @@ def _conv_label(mode, M, min_rows=None):
     return "conv_%s" % mode
 
 
-def _conv_launch(min_rows, name, label, flops, *args, shape=None, gscale=None, group_n=1, in_split=False, dy_split=False):
+def _conv_launch(min_rows, name, label, flops, *args, shape=None, gscale=None, group_n=1, in_split=False, dy_split=False,
+                 out_split=False):
     """One ag2v_conv2d_*_ex call.  Arithmetic (precision, bf16x3 row threshold: ``min_rows``, None = library default) and the
     per-sample-group output scale travel as per-call options (ag2v_conv_opts): no process-wide switch is touched."""
     opts = _lib.ConvOpts(_PRECISION[0], int(min_rows) if min_rows else 0, None if gscale is None else gscale.data_ptr(),
-                         int(group_n), None, 1 if in_split else 0, 1 if dy_split else 0)
+                         int(group_n), None, 1 if in_split else 0, 1 if dy_split else 0, 1 if out_split else 0)
     args = args + (ctypes.byref(opts),)
     if _TIMING is None or _PAUSED:
         _lib.call(name, *args)
@@ -323,13 +324,14 @@ def _wsink_take_group(keys, likes):
 
 
 # ------------------------------------------------------------------------------------------------ convolution
-def _conv_fwd_launch(mr, x, w, bias, residual, y, stride, pad, relu, gscale=None, group_n=1, in_split=False):
+def _conv_fwd_launch(mr, x, w, bias, residual, y, stride, pad, relu, gscale=None, group_n=1, in_split=False, out_split=False):
     N, C, H, W = x.shape
     K, _, R, S = w.shape
     ws = torch.empty(_lib.query('ag2v_conv2d_workspace_floats', C, K, R, S), device=x.device, dtype=torch.float32)
     _conv_launch(mr, 'ag2v_conv2d_fwd_ex', 'conv_fwd', 2.0 * N * K * y.shape[2] * y.shape[3] * C * R * S,
                  _ptr(x), _ptr(w), _ptr(bias), _ptr(residual), _ptr(y), N, C, H, W, K, R, S, stride, pad, 1 if relu else 0,
-                 _ptr(ws), _stream(), shape=(N, C, H, W, K, R, stride), gscale=gscale, group_n=group_n, in_split=in_split)
+                 _ptr(ws), _stream(), shape=(N, C, H, W, K, R, stride), gscale=gscale, group_n=group_n, in_split=in_split,
+                 out_split=out_split)
 
 
 def _conv_dgrad_launch(mr, dy, w, mask, dx, stride, pad, acc, gscale=None, group_n=1, dy_split=False):
@@ -502,10 +504,10 @@ class _ConvSharedInput(torch.autograd.Function):
     full-size tensor per branch and summing them pairwise."""
 
     @staticmethod
-    def forward(ctx, x, stride, pad, relu, grad_premasked, x_split, *wb):
+    def forward(ctx, x, stride, pad, relu, grad_premasked, x_split, out_splits, *wb):
         x = _c(x)
-        ctx.wkeys = [(_wsink_register(t) if ctx.needs_input_grad[6 + 2 * i] else None) for i, t in enumerate(wb[0::2])]
-        ctx.bkeys = [(_wsink_register(t) if (t is not None and ctx.needs_input_grad[7 + 2 * i] and _EXTRA_SINKS) else None)
+        ctx.wkeys = [(_wsink_register(t) if ctx.needs_input_grad[7 + 2 * i] else None) for i, t in enumerate(wb[0::2])]
+        ctx.bkeys = [(_wsink_register(t) if (t is not None and ctx.needs_input_grad[8 + 2 * i] and _EXTRA_SINKS) else None)
                      for i, t in enumerate(wb[1::2])]
         ctx.w_alive = list(wb)           # see _Conv2d.forward
         ws_, bs_ = [_c(t) for t in wb[0::2]], [_c(t) for t in wb[1::2]]
@@ -514,14 +516,16 @@ class _ConvSharedInput(torch.autograd.Function):
         N, C, H, W = x.shape
         mr_f, mr = _current_min_rows()
         outs = []
-        for w, b in zip(ws_, bs_):
+        if out_splits and not (relu and grad_premasked):
+            raise RuntimeError("conv2d_shared_input: split-word outputs need relu=True, grad_premasked=True (the backward never reads them)")
+        for j, (w, b) in enumerate(zip(ws_, bs_)):
             K, C2, R, S = w.shape
             if C2 != C:
                 raise RuntimeError("conv2d_shared_input: input has %d channels, weight expects %d" % (C, C2))
             OH = (H + 2 * pad - R) // stride + 1
             OW = (W + 2 * pad - S) // stride + 1
             y = torch.empty((N, K, OH, OW), device=x.device, dtype=torch.float32)
-            _conv_fwd_launch(mr_f, x, w, b, None, y, stride, pad, relu, in_split=x_split)
+            _conv_fwd_launch(mr_f, x, w, b, None, y, stride, pad, relu, in_split=x_split, out_split=bool(out_splits and out_splits[j]))
             outs.append(y)
         keep_y = relu and not grad_premasked
         ctx.save_for_backward(x, *ws_, *(outs if keep_y else []))
@@ -543,7 +547,7 @@ class _ConvSharedInput(torch.autograd.Function):
         # all branches live and all weights want gradients: one weight-gradient launch over the concatenated rows, writing
         # slices of ONE buffer (the per-weight sinks are views of it), so the gathered input is read once per pass
         merged_w = (_MERGE_SHARED_WGRAD and n > 1 and all(d is not None for d in dys)
-                    and all(ctx.needs_input_grad[6 + 2 * i] for i in range(n)))
+                    and all(ctx.needs_input_grad[7 + 2 * i] for i in range(n)))
         for i in range(n):
             w, dy = ws_[i], dys[i]
             if dy is None:
@@ -557,10 +561,10 @@ class _ConvSharedInput(torch.autograd.Function):
                 dy = g
             live.append((w, dy, i))
             dw = db = None
-            if ctx.needs_input_grad[6 + 2 * i] and not merged_w:
+            if ctx.needs_input_grad[7 + 2 * i] and not merged_w:
                 buf, acc, dw = _wsink_take(ctx.wkeys[i], w)
                 _conv_wgrad_launch(mr, dy, x, buf, K, R, S, stride, pad, acc, in_split=ctx.x_split)
-            if has_b[i] and ctx.needs_input_grad[7 + 2 * i]:
+            if has_b[i] and ctx.needs_input_grad[8 + 2 * i]:
                 bbuf, bacc, db = _wsink_take(ctx.bkeys[i], ctx.w_alive[2 * i + 1])
                 _lib.call('ag2v_channel_sum_acc', _ptr(dy), _ptr(bbuf), N, K, dy.shape[2] * dy.shape[3], bacc, st)
             grads += [dw, db]
@@ -588,15 +592,24 @@ class _ConvSharedInput(torch.autograd.Function):
             else:
                 for j, (w, dy, _) in enumerate(live):
                     _conv_dgrad_launch(mr, dy, w, None, dx, stride, pad, 0 if j == 0 else 1)
-        return (dx, None, None, None, None, None) + tuple(grads)
+        return (dx, None, None, None, None, None, None) + tuple(grads)
 
 
-def conv2d_shared_input(x, weights, biases, stride=1, pad=0, relu=False, grad_premasked=False):
-    """[conv2d(x, w_i, b_i) for i] with one accumulated input gradient (see _ConvSharedInput).  Returns a tuple."""
+def conv2d_shared_input(x, weights, biases, stride=1, pad=0, relu=False, grad_premasked=False, out_split=None):
+    """[conv2d(x, w_i, b_i) for i] with one accumulated input gradient (see _ConvSharedInput).  Returns a tuple.
+    out_split: per output, store it as split words (relu + grad_premasked outputs whose reader takes them: conv_split_input_ok)."""
     wb = []
     for w, b in zip(weights, biases):
         wb += [w, b]
-    return _ConvSharedInput.apply(x, int(stride), int(pad), bool(relu), bool(grad_premasked), is_split(x), *wb)
+    flags = tuple(bool(f) for f in out_split) if out_split else None
+    if flags is not None and not any(flags):
+        flags = None
+    outs = _ConvSharedInput.apply(x, int(stride), int(pad), bool(relu), bool(grad_premasked), is_split(x), flags, *wb)
+    if flags:
+        for o, f in zip(outs, flags):
+            if f:
+                mark_split(o)
+    return outs
 
 
 # ------------------------------------------------------------------------------------------------ spectral norm

@@ -45,7 +45,9 @@ extern "C" {
  *              ag2v_norm_apply_g(out_split = 1) writes them -- instead of fp32: the bf16x3 kernels then skip their own split
  *              (bit-identical results).  Only where ag2v_conv2d_split_input_ok() says so; otherwise AG2V_EINVAL;
  *   dy_split:  (data gradient, weight gradient) the same for the output gradient dy (written split by ag2v_norm_bwd_gs /
- *              ag2v_spade_pair_bwd_s); only where ag2v_conv2d_split_dy_ok() says so. */
+ *              ag2v_spade_pair_bwd_s); only where ag2v_conv2d_split_dy_ok() says so;
+ *   out_split: (forward, bf16x3 path, no residual) the result is stored as split words by the epilogue -- for an activation that
+ *              only convolutions taking in_split read (SPADE: relu(mlp_shared(seg)) feeds the gamma | beta convolution). */
 typedef struct ag2v_conv_opts {
     int precision;
     int min_rows;
@@ -54,6 +56,7 @@ typedef struct ag2v_conv_opts {
     const char* kernel;
     int in_split;
     int dy_split;
+    int out_split;
 } ag2v_conv_opts;
 /* Defaults of calls without options (process-wide; the product passes options on every call). */
 int ag2v_set_conv_precision(int mode);

@@ -522,6 +522,18 @@ def test_conv2d_split_word_input(cfg, device):
             res.append([t.detach() for t in ys] + list(torch.autograd.grad(sum((t * t).sum() for t in ys), ws)))
         for a, c in zip(res[0], res[1]):
             same(a, c, 'shared')
+        # the convolution epilogue as producer (relu(mlp_shared) of a SPADE block): split words out, zeros stay zero words
+        ys = ops.conv2d_shared_input(x.clone(), ws, [None] * 3, 1, pad, relu=True, grad_premasked=True, out_split=[True, False, True])
+        ref = ops.conv2d_shared_input(x.clone(), ws, [None] * 3, 1, pad, relu=True, grad_premasked=True)
+        assert [ops.is_split(t) for t in ys] == [True, False, True]
+        for t, r, sp in zip(ys, ref, (True, False, True)):
+            if sp:
+                wd = t.detach().view(torch.int32)
+                val = (wd & -65536).view(torch.float32) + (wd << 16).view(torch.float32)
+                assert float((val - r.detach()).abs().max()) <= 3e-5 * float(r.detach().abs().max())
+                assert bool(((wd == 0) == (val == 0)).all()) and bool((val >= 0).all())
+            else:
+                same(t.detach(), r.detach(), 'plain output')
         # the producer: batch norm + LeakyReLU with out_split
         rm, rv = torch.zeros(C, device=device), torch.ones(C, device=device)
         wt, bs = torch.rand(C, device=device) + 0.5, torch.randn(C, device=device)
