@@ -34,6 +34,7 @@ _SIGS = {
     'ag2v_conv2d_split_dy_ok': (c_int, [c_int] * 11),
     'ag2v_channel_sum': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     'ag2v_channel_sum_acc': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    'ag2v_channel_sum_acc_s': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'ag2v_bn_workspace_floats': (c_size_t, [c_int, c_int, c_int]),
     'ag2v_bn_stats': (c_int, [_P, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P]),
     'ag2v_norm_apply': (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),

@@ -871,8 +871,9 @@ extern "C" int ag2v_conv2d_dgrad_ex(const float* dy, const float* w, const float
     if (workspace_floats < (size_t)C * K * R * S) return AG2V_EINVAL;
     const long long dys = (long long)K * OH * OW, dxs = (long long)C * H * W;
     const size_t t_floats = (size_t)N * C * R * S * OH * OW;
-    if (cfg.dy_split && (few_channel_dgrad(N, C, K, R, S, OH, OW, stride, mask != nullptr) || !use_bf16x3(cfg, C)))
-        return AG2V_EINVAL;                      // split words are only read by the bf16x3 kernels (ag2v_conv2d_split_dy_ok)
+    if ((cfg.dy_split || cfg.out_split) && (few_channel_dgrad(N, C, K, R, S, OH, OW, stride, mask != nullptr) || !use_bf16x3(cfg, C)))
+        return AG2V_EINVAL;                      // split words are only read / written by the bf16x3 kernels (ag2v_conv2d_split_dy_ok)
+    if (cfg.out_split && (accumulate || stride != 1)) return AG2V_EINVAL;   // dx as split words: one class, written once
     if (few_channel_dgrad(N, C, K, R, S, OH, OW, stride, mask != nullptr) && (long long)N * OH * OW < (1LL << 31) &&
         workspace_floats >= (size_t)C * K * R * S + t_floats) {
         // few input channels: dx[n,c,y,x] = sum_{r,s} t[n, (c R + r) S + s, y + pad - r, x + pad - s], t = W'^T dy as a 1x1
@@ -918,7 +919,7 @@ extern "C" int ag2v_conv2d_dgrad_ex(const float* dy, const float* w, const float
                 nmax = chunk_samples(dys * 4, 0, cfg.gscale ? cfg.group_n : 1);
                 if (nmax <= 0) { split = false; nmax = N; }
             }
-            if (cfg.dy_split && !split) return AG2V_EINVAL;
+            if ((cfg.dy_split || cfg.out_split) && !split) return AG2V_EINVAL;
             const int cOH = (H - ay + stride - 1) / stride, cOW = (W - ax + stride - 1) / stride;
             if ((long long)nmax * cOH * cOW >= (1LL << 31)) {
                 nmax = (int)(((1LL << 31) - 1) / ((long long)cOH * cOW));
@@ -945,7 +946,7 @@ extern "C" int ag2v_conv2d_dgrad_ex(const float* dy, const float* w, const float
                 f.M = C; f.NG = nc * f.OH * f.OW; f.KG = K * Rc * Sc;
                 f.a_bytes = (unsigned)abytes; f.b_bytes = split ? (unsigned)(dys * 4 * nc) : 0u;
                 f.gscale = cfg.gscale ? cfg.gscale + n0 / cfg.group_n : nullptr; f.group_n = cfg.group_n;
-                f.b_split = cfg.dy_split;
+                f.b_split = cfg.dy_split; f.out_split = cfg.out_split;
                 // one class (stride 1): the mask in the epilogue; several classes: one pass at the end
                 f.mask = (multi || !mask) ? nullptr : mask + (size_t)n0 * dxs;
                 // accumulate: a split-K launch adds onto the existing dx with its atomics (no zeroing); any other launch reads dx

@@ -582,6 +582,12 @@ __global__ __launch_bounds__(256) void instnorm_lrelu_bwd_kernel(const float* __
 
 // ---------------------------------------------------------------- per-channel sum over (N, H*W): conv bias gradient
 // grid (C, nsplit): split s sums images n = s, s+nsplit, ...; nsplit > 1 accumulates with one atomic per workgroup
+// SPLIT: x holds split words; a value is hi + lo (exactly what the bf16x3 kernels multiply)
+__device__ __forceinline__ float unsplit(float w) {
+    const unsigned u = __float_as_uint(w);
+    return __uint_as_float(u & 0xFFFF0000u) + __uint_as_float(u << 16);
+}
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int C,
                                                           int HW, int nsplit, int acc) {
     __shared__ float sh[4];
@@ -591,9 +597,13 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
         const float* p = x + ((size_t)n * C + c) * HW;
         if ((HW & 3) == 0 && ((((uintptr_t)p) & 15) == 0)) {
             const float4* p4 = reinterpret_cast<const float4*>(p);
-            for (int i = threadIdx.x; i < (HW >> 2); i += 256) { const float4 v = p4[i]; s += (v.x + v.y) + (v.z + v.w); }
+            for (int i = threadIdx.x; i < (HW >> 2); i += 256) {
+                float4 v = p4[i];
+                if (SPLIT) { v.x = unsplit(v.x); v.y = unsplit(v.y); v.z = unsplit(v.z); v.w = unsplit(v.w); }
+                s += (v.x + v.y) + (v.z + v.w);
+            }
         } else {
-            for (int i = threadIdx.x; i < HW; i += 256) s += p[i];
+            for (int i = threadIdx.x; i < HW; i += 256) s += SPLIT ? unsplit(p[i]) : p[i];
         }
     }
     s = block_sum_256(s, sh);
@@ -849,7 +859,8 @@ extern "C" int ag2v_instnorm_lrelu_bwd(const float* dy, const float* y, const fl
 }
 
 // accumulate != 0: out[c] += sum (a bias used by several forward calls of one step collects its gradient in one buffer)
-extern "C" int ag2v_channel_sum_acc(const float* x, float* out, int N, int C, int HW, int accumulate, void* stream) {
+// x_split != 0: x holds split words (a gradient written by a convolution epilogue with ag2v_conv_opts::out_split); the sum is over hi + lo
+extern "C" int ag2v_channel_sum_acc_s(const float* x, float* out, int N, int C, int HW, int accumulate, int x_split, void* stream) {
     if (!x || !out || N <= 0 || C <= 0 || HW <= 0) return AG2V_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     int nsplit = 1;
@@ -858,9 +869,13 @@ extern "C" int ag2v_channel_sum_acc(const float* x, float* out, int N, int C, in
         if (nsplit > N) nsplit = N;
     }
     if (nsplit > 1 && !accumulate && hipMemsetAsync(out, 0, (size_t)C * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
-    hipLaunchKernelGGL(channel_sum_kernel, dim3(C, nsplit), dim3(256), 0, st, x, out, N, C, HW, nsplit, accumulate ? 1 : 0);
+    if (x_split) hipLaunchKernelGGL(channel_sum_kernel<true>, dim3(C, nsplit), dim3(256), 0, st, x, out, N, C, HW, nsplit, accumulate ? 1 : 0);
+    else hipLaunchKernelGGL(channel_sum_kernel<false>, dim3(C, nsplit), dim3(256), 0, st, x, out, N, C, HW, nsplit, accumulate ? 1 : 0);
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
+}
+extern "C" int ag2v_channel_sum_acc(const float* x, float* out, int N, int C, int HW, int accumulate, void* stream) {
+    return ag2v_channel_sum_acc_s(x, out, N, C, HW, accumulate, 0, stream);
 }
 extern "C" int ag2v_channel_sum(const float* x, float* out, int N, int C, int HW, void* stream) {
     return ag2v_channel_sum_acc(x, out, N, C, HW, 0, stream);

@@ -39,8 +39,12 @@ class SPADEResnetBlock(nn.Module):
         aspl = [self.training and ops.conv_split_input_ok((N_, c.out_channels, H, W), (2 * m.mlp_gamma.out_channels, c.out_channels) +
                                                           tuple(m.mlp_gamma.kernel_size), m.mlp_gamma.stride[0], m.mlp_gamma.padding[0])
                 for m, c in zip(norms, sh)]
+        # ... and, when all of those convolutions can, their data gradients (which apply this ReLU's mask) hand d(actv) back split
+        gspl = self.training and all(
+            ops.conv_split_dy_ok((N_, c.out_channels, H, W), (2 * m.mlp_gamma.out_channels, c.out_channels) + tuple(m.mlp_gamma.kernel_size),
+                                 m.mlp_gamma.stride[0], m.mlp_gamma.padding[0]) for m, c in zip(norms, sh))
         actv = ops.conv2d_shared_input(seg_r, [c.weight for c in sh], [c.bias for c in sh], sh[0].stride[0], sh[0].padding[0],
-                                       relu=True, grad_premasked=True, out_split=aspl)
+                                       relu=True, grad_premasked=True, out_split=aspl, grad_split=gspl)
         bn0, bns = self.norm_0.param_free_norm, (self.norm_s.param_free_norm if self.learned_shortcut else None)
         # the modulated tensors are read by one convolution each and nothing else: stored as split words where that convolution
         # takes them (forward + weight gradient on the bf16x3 kernels, ops.conv_split_input_ok)

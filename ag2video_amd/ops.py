@@ -334,7 +334,7 @@ def _conv_fwd_launch(mr, x, w, bias, residual, y, stride, pad, relu, gscale=None
                  out_split=out_split)
 
 
-def _conv_dgrad_launch(mr, dy, w, mask, dx, stride, pad, acc, gscale=None, group_n=1, dy_split=False):
+def _conv_dgrad_launch(mr, dy, w, mask, dx, stride, pad, acc, gscale=None, group_n=1, dy_split=False, out_split=False):
     """dx (+)= data gradient.  The workspace holds the re-ordered filters and, for <= 4 input channels, the intermediate of the
     1x1-GEMM form (caller memory: the library allocates nothing)."""
     N, C, H, W = dx.shape
@@ -343,7 +343,7 @@ def _conv_dgrad_launch(mr, dy, w, mask, dx, stride, pad, acc, gscale=None, group
     ws = torch.empty(nws, device=dy.device, dtype=torch.float32)
     _conv_launch(mr, 'ag2v_conv2d_dgrad_ex', 'conv_dgrad', 2.0 * N * K * dy.shape[2] * dy.shape[3] * C * R * S,
                  _ptr(dy), _ptr(w), _ptr(mask), _ptr(dx), N, C, H, W, K, R, S, stride, pad, 1 if acc else 0, _ptr(ws), nws, _stream(),
-                 shape=(N, C, H, W, K, R, stride), gscale=gscale, group_n=group_n, dy_split=dy_split)
+                 shape=(N, C, H, W, K, R, stride), gscale=gscale, group_n=group_n, dy_split=dy_split, out_split=out_split)
 
 
 def _conv_wgrad_launch(mr, dy, x, dw, K, R, S, stride, pad, acc, groups=1, in_split=False, dy_split=False):
@@ -363,7 +363,7 @@ class _Conv2d(torch.autograd.Function):
     frame-batched generator (w = weight_orig, gscale = 1 / sigma_t of frame group t: spectral_scales)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, residual, gscale, stride, pad, relu, grad_premasked, relu_input, x_split=False):
+    def forward(ctx, x, w, bias, residual, gscale, stride, pad, relu, grad_premasked, relu_input, x_split=False, dx_split=False):
         w_in, bias_in = w, bias
         x, w, bias, residual, gscale = _c(x), _c(w), _c(bias), _c(residual), _c(gscale)
         _chk(x, w, bias, residual, gscale)
@@ -384,6 +384,7 @@ class _Conv2d(torch.autograd.Function):
         ctx.save_for_backward(x, w, y if (relu and not grad_premasked) else None, gscale)
         ctx.cfg = (stride, pad, bias is not None, residual is not None, mr, relu, grad_premasked, relu_input, group_n)
         ctx.x_split = bool(x_split)
+        ctx.dx_split = bool(dx_split)
         ctx.wkey = _wsink_register(w_in) if ctx.needs_input_grad[1] else None
         ctx.bkey = _wsink_register(bias_in) if (bias_in is not None and ctx.needs_input_grad[2] and _EXTRA_SINKS) else None
         ctx.w_alive = (w_in, bias_in)   # the registry keys on id(): keep the objects alive as long as this node, or a temporary
@@ -408,7 +409,10 @@ class _Conv2d(torch.autograd.Function):
             dy = g
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _conv_dgrad_launch(mr, dy, w, x if relu_input else None, dx, stride, pad, 0, gscale, group_n, dy_split=dys)
+            _conv_dgrad_launch(mr, dy, w, x if relu_input else None, dx, stride, pad, 0, gscale, group_n, dy_split=dys,
+                               out_split=ctx.dx_split)
+            if ctx.dx_split:
+                mark_split(dx)
         if gscale is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[4]):
             # per-group weight gradients G_t = dL/d(scale_t W), then dw = sum_t scale_t G_t and dscale_t = <G_t, W> in one pass
             T = gscale.numel()
@@ -450,7 +454,7 @@ class _Conv2d(torch.autograd.Function):
                 _lib.call('ag2v_channel_sum_acc', _ptr(dy), _ptr(bbuf), N, K, dy.shape[2] * dy.shape[3], bacc, st)
         if has_res and ctx.needs_input_grad[3]:
             dres = dy
-        return dx, dw, db, dres, dgs, None, None, None, None, None, None
+        return dx, dw, db, dres, dgs, None, None, None, None, None, None, None
 
 
 def conv2d(x, w, bias=None, stride=1, pad=0, residual=None, relu=False, grad_premasked=False, relu_input=False, gscale=None):
@@ -458,10 +462,14 @@ def conv2d(x, w, bias=None, stride=1, pad=0, residual=None, relu=False, grad_pre
     grad_premasked / relu_input: see _Conv2d (the pair fuses the ReLU's backward into the consumer's data gradient)."""
     if relu and residual is not None and grad_premasked:
         raise RuntimeError("conv2d: grad_premasked with a residual input is not supported (the residual's gradient would be masked)")
+    dy_ok = (not relu and residual is None and int(stride) == 1 and torch.is_grad_enabled() and _USE_CHANNEL_SUMS
+             and conv_split_dy_ok(x.shape, w.shape, stride, pad))
+    # x = relu(...) whose producer takes its gradient as split words (conv2d_shared_input): this convolution's data gradient, which
+    # applies that ReLU's mask in its epilogue, writes them
+    dx_split = bool(relu_input and dy_ok and getattr(x, '_ag2v_dy_split_ok', False))
     y = _Conv2d.apply(x, w, bias, residual, gscale, int(stride), int(pad), bool(relu), bool(grad_premasked), bool(relu_input),
-                      is_split(x))
-    if (not relu and residual is None and int(stride) == 1 and torch.is_grad_enabled() and _USE_CHANNEL_SUMS
-            and conv_split_dy_ok(x.shape, w.shape, stride, pad)):
+                      is_split(x), dx_split)
+    if dy_ok:
         y._ag2v_dy_split_ok = True      # a SPADE backward that is y's only consumer may hand back d(y) as split words
     return y
 
@@ -544,6 +552,11 @@ class _ConvSharedInput(torch.autograd.Function):
         dx = None
         grads = []
         live = []                       # (weight, masked dy, index) of the branches that received a gradient
+        # gradients written as split words by the consumers' data-gradient epilogues (ops.conv2d: dx_split): all branches or none
+        dsp = [is_split(d) for d in dys if d is not None]
+        dys_split = bool(dsp) and all(dsp)
+        if any(dsp) and (not dys_split or (relu and not grad_premasked)):
+            raise RuntimeError("conv2d_shared_input backward: mixed fp32 / split-word gradients")
         # all branches live and all weights want gradients: one weight-gradient launch over the concatenated rows, writing
         # slices of ONE buffer (the per-weight sinks are views of it), so the gathered input is read once per pass
         merged_w = (_MERGE_SHARED_WGRAD and n > 1 and all(d is not None for d in dys)
@@ -563,10 +576,10 @@ class _ConvSharedInput(torch.autograd.Function):
             dw = db = None
             if ctx.needs_input_grad[7 + 2 * i] and not merged_w:
                 buf, acc, dw = _wsink_take(ctx.wkeys[i], w)
-                _conv_wgrad_launch(mr, dy, x, buf, K, R, S, stride, pad, acc, in_split=ctx.x_split)
+                _conv_wgrad_launch(mr, dy, x, buf, K, R, S, stride, pad, acc, in_split=ctx.x_split, dy_split=dys_split)
             if has_b[i] and ctx.needs_input_grad[8 + 2 * i]:
                 bbuf, bacc, db = _wsink_take(ctx.bkeys[i], ctx.w_alive[2 * i + 1])
-                _lib.call('ag2v_channel_sum_acc', _ptr(dy), _ptr(bbuf), N, K, dy.shape[2] * dy.shape[3], bacc, st)
+                _lib.call('ag2v_channel_sum_acc_s', _ptr(dy), _ptr(bbuf), N, K, dy.shape[2] * dy.shape[3], bacc, 1 if dys_split else 0, st)
             grads += [dw, db]
         dyc = None
         if merged_w:
@@ -574,7 +587,7 @@ class _ConvSharedInput(torch.autograd.Function):
             Kt = dyc.shape[1]
             R, S = ws_[0].shape[2], ws_[0].shape[3]
             cat, acc, outs = _wsink_take_group(ctx.wkeys, [w for w, _, _ in live])
-            _conv_wgrad_launch(mr, dyc, x, cat, Kt, R, S, stride, pad, acc, in_split=ctx.x_split)
+            _conv_wgrad_launch(mr, dyc, x, cat, Kt, R, S, stride, pad, acc, in_split=ctx.x_split, dy_split=dys_split)
             for j, (_, _, i) in enumerate(live):
                 grads[2 * i] = outs[j]
         if ctx.needs_input_grad[0]:
@@ -588,16 +601,18 @@ class _ConvSharedInput(torch.autograd.Function):
                 wc = live[0][0] if len(live) == 1 else torch.cat([w for w, _, _ in live], dim=0)
                 if dyc is None:
                     dyc = live[0][1] if len(live) == 1 else torch.cat([d for _, d, _ in live], dim=1)
-                _conv_dgrad_launch(mr, dyc, wc, None, dx, stride, pad, 0)
+                _conv_dgrad_launch(mr, dyc, wc, None, dx, stride, pad, 0, dy_split=dys_split)
             else:
                 for j, (w, dy, _) in enumerate(live):
-                    _conv_dgrad_launch(mr, dy, w, None, dx, stride, pad, 0 if j == 0 else 1)
+                    _conv_dgrad_launch(mr, dy, w, None, dx, stride, pad, 0 if j == 0 else 1, dy_split=dys_split)
         return (dx, None, None, None, None, None, None) + tuple(grads)
 
 
-def conv2d_shared_input(x, weights, biases, stride=1, pad=0, relu=False, grad_premasked=False, out_split=None):
+def conv2d_shared_input(x, weights, biases, stride=1, pad=0, relu=False, grad_premasked=False, out_split=None, grad_split=False):
     """[conv2d(x, w_i, b_i) for i] with one accumulated input gradient (see _ConvSharedInput).  Returns a tuple.
-    out_split: per output, store it as split words (relu + grad_premasked outputs whose reader takes them: conv_split_input_ok)."""
+    out_split: per output, store it as split words (relu + grad_premasked outputs whose reader takes them: conv_split_input_ok).
+    grad_split: the caller has checked that EVERY consumer (a conv2d(relu_input=True) per output) can write its data gradient as split
+    words (conv_split_dy_ok on each of them); the gradients then arrive split when this group's own backward takes them as well."""
     wb = []
     for w, b in zip(weights, biases):
         wb += [w, b]
@@ -609,6 +624,10 @@ def conv2d_shared_input(x, weights, biases, stride=1, pad=0, relu=False, grad_pr
         for o, f in zip(outs, flags):
             if f:
                 mark_split(o)
+    if (grad_split and relu and grad_premasked and torch.is_grad_enabled() and os.environ.get('AG2V_NO_SPLIT_DACTV') is None
+            and conv_split_dy_ok(x.shape, (sum(int(w.shape[0]) for w in weights),) + tuple(weights[0].shape[1:]), stride, pad)):
+        for o in outs:
+            o._ag2v_dy_split_ok = True      # the consumers' data gradients may hand d(out) back as split words (all of them or none)
     return outs
 
 

@@ -113,6 +113,8 @@ int ag2v_conv2d_wgrad_acc(const float* dy, const float* x, float* dw, int N, int
 int ag2v_channel_sum(const float* x, float* out, int N, int C, int HW, void* stream);
 /* accumulate != 0: out[c] += ... (one gradient buffer per bias and backward pass; the generator runs once per frame) */
 int ag2v_channel_sum_acc(const float* x, float* out, int N, int C, int HW, int accumulate, void* stream);
+/* ... over a tensor of split words when x_split != 0 (each value is hi + lo). */
+int ag2v_channel_sum_acc_s(const float* x, float* out, int N, int C, int HW, int accumulate, int x_split, void* stream);
 
 /* ---- batch norm / SPADE / instance norm -------------------------------------------------------------------------
  * F.batch_norm(training) in sync_batchnorm/batchnorm.py:63-68; SPADE.forward normalization.py:96-110;

@@ -31,7 +31,7 @@ def conv2d(x, w, bias=None, stride=1, pad=0, residual=None, relu=False, grad_pre
     return F.relu(y) if relu else y
 
 
-def conv2d_shared_input(x, weights, biases, stride=1, pad=0, relu=False, grad_premasked=False, out_split=None):
+def conv2d_shared_input(x, weights, biases, stride=1, pad=0, relu=False, grad_premasked=False, out_split=None, grad_split=False):
     """Several convolutions of one input (SPADE.mlp_shared of norm_0 / norm_1 / norm_s on the same segmap, normalization.py:92-104)."""
     return tuple(conv2d(x, w, b, stride, pad, relu=relu) for w, b in zip(weights, biases))
 
