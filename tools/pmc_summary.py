@@ -22,6 +22,10 @@ MATCH = [('mlp_shared_fwd', 'mlp_shared_fwd', 'conv_igemm_bf16x3_ws_kernel<128, 
          ('mlp_shared_dgrad_merged', 'mlp_shared_dgrad_merged', 'conv_igemm_bf16x3_ws_kernel<256, 128'),
          ('mlp_shared_wgrad_merged', 'mlp_shared_wgrad_merged', 'conv_wgrad_bf16x3_v_kernel<128, 256'),
          ('conv_256_wgrad_128px', 'conv_256_wgrad_128px', 'conv_wgrad_bf16x3_v_kernel<256, 128'),
+         ('mlp_shared_fwd_ps', 'mlp_shared_fwd_ps', 'conv_igemm_bf16x3_ps_kernel<128, 256'),
+         ('mlp_shared_dgrad_merged_ps', 'mlp_shared_dgrad_merged_ps', 'conv_igemm_bf16x3_ps_kernel<256, 128'),
+         ('mlp_shared_wgrad_merged_ps', 'mlp_shared_wgrad_merged_ps', 'conv_wgrad_bf16x3_vps_kernel<128, 256'),
+         ('conv_256_wgrad_128px_ps', 'conv_256_wgrad_128px_ps', 'conv_wgrad_bf16x3_vps_kernel<256, 128'),
          ('norm', 'norm_apply', 'norm_apply_kernel<1, true>'), ('norm', 'norm_bwd_reduce', 'norm_bwd_reduce_kernel<1, true>'),
          ('norm', 'norm_bwd_apply', 'norm_bwd_apply_kernel<1, true>'), ('norm', 'bn_stats_partial', 'bn_stats_partial_kernel<true>'),
          ('spade_pair', 'spade_pair_apply', 'spade_pair_apply_kernel<2>'), ('spade_pair', 'spade_pair_bwd_reduce', 'spade_pair_bwd_reduce_kernel<2>'),

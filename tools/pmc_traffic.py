@@ -12,9 +12,21 @@ REPS = 2
 CASE = sys.argv[1]
 
 
-def conv_case(tag, N, C, H, K, what):
-    """what: 'fwd' | 'dgrad' | 'wgrad' of a 3x3 stride-1 convolution x[N,C,H,H] -> y[N,K,H,H], with the decoder's row threshold."""
+def split_words(t):
+    """(bf16(v) << 16) | bf16(v - bf16(v)) per value (ops.is_split format), built with torch ops."""
+    hi = t.to(torch.bfloat16)
+    lo = (t - hi.float()).to(torch.bfloat16)
+    w = (hi.view(torch.int16).to(torch.int32) << 16) | (lo.view(torch.int16).to(torch.int32) & 0xFFFF)
+    return ops.mark_split(w.view(torch.float32))
+
+
+def conv_case(tag, N, C, H, K, what, split=False):
+    """what: 'fwd' | 'dgrad' | 'wgrad' of a 3x3 stride-1 convolution x[N,C,H,H] -> y[N,K,H,H], with the decoder's row threshold.
+    split: the operands the step hands over as split words are split words here too (x in fwd / wgrad, dy in dgrad / wgrad): the
+    *_ps / *_vps kernels."""
     x = torch.randn(N, C, H, H, device=dev)
+    if split and what != 'dgrad':
+        x = split_words(x)
     w = (torch.randn(K, C, 3, 3, device=dev) * 0.01)
     xb, yb, wb = N * C * H * H * 4, N * K * H * H * 4, K * C * 9 * 4
     with ops.bf16x3_min_rows(48):
@@ -27,10 +39,14 @@ def conv_case(tag, N, C, H, K, what):
             w.requires_grad_(what == 'wgrad')
             for _ in range(REPS):
                 y = ops.conv2d(x, w, None, 1, 1)
-                y.backward(torch.ones_like(y))
+                g = torch.ones_like(y)
+                if split:
+                    g = split_words(g)
+                y.backward(g)
             alg = (yb + xb + wb) if what == 'dgrad' else (yb + xb + wb)
     torch.cuda.synchronize()
-    expect[tag] = {'shape': '%s of %dx%dx%dx%d -> %d channels, 3x3' % (what, N, C, H, H, K), 'algorithmic_bytes': alg, 'pass': what}
+    expect[tag] = {'shape': '%s of %dx%dx%dx%d -> %d channels, 3x3%s' % (what, N, C, H, H, K, ', split-word operands' if split else ''),
+                   'algorithmic_bytes': alg, 'pass': what}
 
 
 # SPADE mlp_shared at full resolution: forward (128 x 256 tile, quad loads), merged data gradient of a block's three mlp_shared
@@ -40,6 +56,11 @@ CASES = {
     'mlp_shared_dgrad_merged': lambda: conv_case('mlp_shared_dgrad_merged', 40, 512, 256, 384, 'dgrad'),
     'mlp_shared_wgrad_merged': lambda: conv_case('mlp_shared_wgrad_merged', 21, 512, 256, 384, 'wgrad'),
     'conv_256_wgrad_128px': lambda: conv_case('conv_256_wgrad_128px', 120, 256, 128, 256, 'wgrad'),
+    # the same launches as the step issues them since the split-word hand-over
+    'mlp_shared_fwd_ps': lambda: conv_case('mlp_shared_fwd_ps', 31, 512, 256, 128, 'fwd', True),
+    'mlp_shared_dgrad_merged_ps': lambda: conv_case('mlp_shared_dgrad_merged_ps', 40, 512, 256, 384, 'dgrad', True),
+    'mlp_shared_wgrad_merged_ps': lambda: conv_case('mlp_shared_wgrad_merged_ps', 21, 512, 256, 384, 'wgrad', True),
+    'conv_256_wgrad_128px_ps': lambda: conv_case('conv_256_wgrad_128px_ps', 120, 256, 128, 256, 'wgrad', True),
 }
 
 
