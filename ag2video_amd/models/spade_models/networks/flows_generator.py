@@ -83,12 +83,17 @@ class FlowsGenerator(nn.Module):
                 else:
                     x = self._conv_bn_act(m, x)
                 first = False
-        for blk in self.res_flow:
-            x = blk(x)
-        for m in self.up_flow:
-            if isinstance(m, nn.Upsample):
-                x = ops.upsample2x(x)
-            elif isinstance(m, nn.Sequential):
-                x = self._conv_bn_act(m, x)
+        import contextlib, os
+        part = os.environ.get('AG2V_FLOW_SPLIT_PARTS', '')          # diagnostic (tools/debug_c1_precision.py): forward of these parts on bf16x3
+        ctx = lambda name: ops.bf16x3_min_rows(48, 32) if name in part else contextlib.nullcontext()
+        with ctx('res'):
+            for blk in self.res_flow:
+                x = blk(x)
+        with ctx('up'):
+            for m in self.up_flow:
+                if isinstance(m, nn.Upsample):
+                    x = ops.upsample2x(x)
+                elif isinstance(m, nn.Sequential):
+                    x = self._conv_bn_act(m, x)
         flow = self.conv_flow[0](x) * self.flow_multiplier
         return None, flow

@@ -33,11 +33,8 @@ def run(tag):
         r = ref[i].detach().numpy()
         out[name] = float(np.abs(got[i].cpu().numpy() - r).max() / np.abs(r).max())
     print(tag, out, flush=True)
-for prec in ('fp32', 'bf16x3'):
-    ops.set_conv_precision(prec)
-    for fm in ([None] if prec == 'fp32' else [128, 300, 1 << 20]):
-        if fm is not None:
-            os.environ['AG2V_FLOW_MIN_ROWS'] = str(fm)
-        for dm in ([48] if prec == 'fp32' else [48, 128, 1 << 20]):
-            os.environ['AG2V_DEC_MIN_ROWS'] = str(dm)
-            run('%s flow_min_rows=%s dec_min_rows=%s' % (prec, fm, dm))
+ops.set_conv_precision('bf16x3')
+for parts in ('', 'res', 'up', 'res,up'):
+    os.environ['AG2V_FLOW_SPLIT_PARTS'] = parts
+    for rep in range(2):
+        run('bf16x3 flow parts on split tiles: [%s]' % parts)
