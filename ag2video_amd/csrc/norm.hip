@@ -193,7 +193,8 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __res
                                                               const float* __restrict__ x, const float* __restrict__ gamma,
                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
                                                               float* __restrict__ partial, int Ng, int C, int HW, int nchunk,
-                                                              float slope, long long gbx) {
+                                                              float slope, long long gbx, const float* __restrict__ aw,
+                                                              const float* __restrict__ ab) {
     __shared__ float sh[4];
     const int bid = blockIdx.x;
     const int chunk = bid % nchunk, nc = bid / nchunk;
@@ -206,12 +207,20 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __res
     float g[16], xv[16], t[16];
     unsigned mask;
     load16<VEC>(dy + off, cnt, g, mask);
-    if (slope != 1.f) {
-        load16<VEC>(y + off, cnt, t, mask);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) g[i] = t[i] > 0.f ? g[i] : g[i] * slope;
-    }
     load16<VEC>(x + off, cnt, xv, mask);
+    if (slope != 1.f) {
+        if (MODE == 0 && y == nullptr) {
+            // affine batch norm: the activation's sign is the sign of (x - mu) * (invstd w) + b, the expression norm_apply_kernel<0>
+            // evaluated -- no read of the forward output (2 of this backward's 7 tensor passes)
+            const float sc = is * (aw ? aw[c] : 1.f), shf = ab ? ab[c] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) g[i] = ((xv[i] - mu) * sc + shf) > 0.f ? g[i] : g[i] * slope;
+        } else {
+            load16<VEC>(y + off, cnt, t, mask);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) g[i] = t[i] > 0.f ? g[i] : g[i] * slope;
+        }
+    }
     // (s3, s4) = (sum g, sum g * xhat) BEFORE the (1 + gamma) factor: the channel sums of dbeta and dgamma, i.e. the bias gradient of the
     // convolution that produced gamma | beta -- it would otherwise cost a pass over the two [N, C, HW] gradient tensors (channel_sum)
     float s3 = 0.f, s4 = 0.f;
@@ -267,7 +276,8 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
                                                              const float* __restrict__ invstd, const float* __restrict__ sums,
                                                              float* __restrict__ dx, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta, int C, int HW, int nchunk,
-                                                             float inv_count, float slope, long long gbx, int Ng, int dgb_split) {
+                                                             float inv_count, float slope, long long gbx, int Ng, int dgb_split,
+                                                             const float* __restrict__ ab) {
     const int bid = blockIdx.x;
     const int chunk = bid % nchunk, nc = bid / nchunk;
     const int c = nc % C;
@@ -280,12 +290,18 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
     float g[16], xv[16], t[16];
     unsigned mask;
     load16<VEC>(dy + off, cnt, g, mask);
-    if (slope != 1.f) {
-        load16<VEC>(y + off, cnt, t, mask);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) g[i] = t[i] > 0.f ? g[i] : g[i] * slope;
-    }
     load16<VEC>(x + off, cnt, xv, mask);
+    if (slope != 1.f) {
+        if (MODE == 0 && y == nullptr) {       // see norm_bwd_reduce_kernel
+            const float sc = is * (w ? w[c] : 1.f), shf = ab ? ab[c] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) g[i] = ((xv[i] - mu) * sc + shf) > 0.f ? g[i] : g[i] * slope;
+        } else {
+            load16<VEC>(y + off, cnt, t, mask);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) g[i] = t[i] > 0.f ? g[i] : g[i] * slope;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) xv[i] = (xv[i] - mu) * is;  // xhat
     if (MODE == 1) {
@@ -694,11 +710,13 @@ extern "C" int ag2v_norm_apply(int mode, const float* x, const float* mean, cons
 // y is the forward output (activation sign); may be null if slope == 1.
 static int norm_bwd_launch(int mode, bool do_reduce, bool do_apply, const float* dy, const float* y, const float* x, const float* gamma,
                            const float* w, const float* mean, const float* invstd, float* dx, float* dgamma, float* dbeta, float* sums,
-                           int N, int C, int HW, int Ng, float slope, float inv_count, float* workspace, hipStream_t st, int dgb_split = 0) {
+                           int N, int C, int HW, int Ng, float slope, float inv_count, float* workspace, hipStream_t st, int dgb_split = 0,
+                           const float* bias = nullptr, bool sign_from_x = false) {
     if (!dy || !x || !mean || !invstd || !sums || N <= 0 || C <= 0 || HW <= 0 || Ng <= 0 || N % Ng != 0) return AG2V_EINVAL;
     if (do_reduce && !workspace) return AG2V_EINVAL;
     if (do_apply && !dx) return AG2V_EINVAL;
-    if (slope != 1.f && !y) return AG2V_EINVAL;
+    if (slope != 1.f && !y && !(sign_from_x && mode == 0)) return AG2V_EINVAL;
+    if (sign_from_x && mode == 0) y = nullptr;
     if (mode < 0 || mode > 2 || (mode >= 1 && !gamma) || (mode >= 1 && do_apply && (!dgamma || !dbeta))) return AG2V_EINVAL;
     const int nchunk = ceil_div(HW, CHUNK);
     const long long nblk = (long long)N * C * nchunk;
@@ -710,12 +728,12 @@ static int norm_bwd_launch(int mode, bool do_reduce, bool do_apply, const float*
 #define LAUNCH_BWD(M, V)                                                                                                             \
     if (do_reduce) {                                                                                                                 \
         hipLaunchKernelGGL((norm_bwd_reduce_kernel<M, V>), g, t, 0, st, dy, y, x, gamma, mean, invstd, workspace, Ng, C, HW, nchunk, \
-                           slope, gbx);                                                                                              \
+                           slope, gbx, w, bias);                                                                                              \
         hipLaunchKernelGGL(pair_sum_finalize_kernel, dim3(ceil_div(GC, 64)), dim3(64), 0, st, workspace, GC, Ng* nchunk, sums);      \
     }                                                                                                                                \
     if (do_apply)                                                                                                                    \
         hipLaunchKernelGGL((norm_bwd_apply_kernel<M, V>), g, t, 0, st, dy, y, x, gamma, w, mean, invstd, sums, dx, dgamma, dbeta, C, \
-                           HW, nchunk, inv_count, slope, gbx, Ng, dgb_split ? 1 : 0);
+                           HW, nchunk, inv_count, slope, gbx, Ng, dgb_split ? 1 : 0, bias);
     if (mode == 0) {
         if (v) { LAUNCH_BWD(0, true) } else { LAUNCH_BWD(0, false) }
     } else {
@@ -728,17 +746,19 @@ static int norm_bwd_launch(int mode, bool do_reduce, bool do_apply, const float*
 // dgb_split != 0 (modes 1 / 2): dgamma / dbeta are written as split words (ag2v_conv_opts::dy_split) -- they are read by the data
 // gradient and the weight gradient of the convolution that produced gamma | beta and by nothing else (its bias gradient comes
 // from `sums`).
+// mode 0 with y == NULL: the LeakyReLU branch of every element is recomputed from x, w and `bias` (the affine pair the forward
+// pass applied: y = lrelu(xhat w + bias)) instead of being read from the forward output.
 extern "C" int ag2v_norm_bwd_gs(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* w,
-                                const float* mean, const float* invstd, float* dx, float* dgamma, float* dbeta, float* sums,
-                                int N, int C, int HW, int Ng, float slope, float* workspace, int dgb_split, void* stream) {
+                                const float* bias, const float* mean, const float* invstd, float* dx, float* dgamma, float* dbeta,
+                                float* sums, int N, int C, int HW, int Ng, float slope, float* workspace, int dgb_split, void* stream) {
     if (Ng <= 0 || HW <= 0) return AG2V_EINVAL;
     return norm_bwd_launch(mode, true, true, dy, y, x, gamma, w, mean, invstd, dx, dgamma, dbeta, sums, N, C, HW, Ng, slope,
-                           1.0f / ((float)Ng * (float)HW), workspace, (hipStream_t)stream, dgb_split);
+                           1.0f / ((float)Ng * (float)HW), workspace, (hipStream_t)stream, dgb_split, bias, mode == 0 && y == nullptr);
 }
 extern "C" int ag2v_norm_bwd_g(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* w,
                                const float* mean, const float* invstd, float* dx, float* dgamma, float* dbeta, float* sums,
                                int N, int C, int HW, int Ng, float slope, float* workspace, void* stream) {
-    return ag2v_norm_bwd_gs(mode, dy, y, x, gamma, w, mean, invstd, dx, dgamma, dbeta, sums, N, C, HW, Ng, slope, workspace, 0, stream);
+    return ag2v_norm_bwd_gs(mode, dy, y, x, gamma, w, nullptr, mean, invstd, dx, dgamma, dbeta, sums, N, C, HW, Ng, slope, workspace, 0, stream);
 }
 extern "C" int ag2v_norm_bwd_reduce_g(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* mean,
                                       const float* invstd, float* sums, int N, int C, int HW, int Ng, float slope, float* workspace,

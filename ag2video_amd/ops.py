@@ -867,14 +867,16 @@ class _NormAct(torch.autograd.Function):
             # the "flops" slot of the timing record
             _launch('ag2v_norm_apply_gs', 'spade_norm_apply', 4.0 * x.numel() * 4, mode, _ptr(x), _ptr(mean), _ptr(invstd), None, None,
                     g_ptr, b_ptr, _ptr(y), N, C, HW, Ng, float(slope), 1 if out_split else 0, _stream(), shape=(N, C, HW))
-        ctx.save_for_backward(x, y if slope != 1.0 else None, p0, mean, invstd)
+        # mode 0 (affine batch norm): the backward recomputes the activation's sign from x, w, b -- y is not kept for it
+        sign_from_x = (mode == 0 and not sync and os.environ.get('AG2V_NORM_BWD_READ_Y') is None)
+        ctx.save_for_backward(x, y if (slope != 1.0 and not sign_from_x) else None, p0, mean, invstd, p1 if mode == 0 else None)
         ctx.cfg = (mode, training, slope, N, C, HW, Ng, world if sync else 0)
         ctx.dgb_split = bool(dgb_split) and mode == 2 and not sync
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, p0, mean, invstd = ctx.saved_tensors
+        x, y, p0, mean, invstd, bias0 = ctx.saved_tensors
         mode, training, slope, N, C, HW, Ng, sync_world = ctx.cfg
         if not training:
             raise RuntimeError("norm backward is only implemented for batch statistics (training mode)")
@@ -909,8 +911,8 @@ class _NormAct(torch.autograd.Function):
             if local is not None:
                 sums = local
         else:
-            _launch('ag2v_norm_bwd_gs', 'spade_norm_bwd' if mode == 2 else 'norm_bwd', (7.0 if mode == 0 else 11.0) * x.numel() * 4, kmode, _ptr(dy), _ptr(y), _ptr(x),
-                    _ptr(gam), _ptr(wgt), _ptr(mean), _ptr(invstd), _ptr(dx), dg_ptr, db_ptr, _ptr(sums), N, C, HW, Ng, float(slope),
+            _launch('ag2v_norm_bwd_gs', 'spade_norm_bwd' if mode == 2 else 'norm_bwd', ((7.0 if y is not None or slope == 1.0 else 5.0) if mode == 0 else 11.0) * x.numel() * 4, kmode, _ptr(dy), _ptr(y), _ptr(x),
+                    _ptr(gam), _ptr(wgt), _ptr(bias0), _ptr(mean), _ptr(invstd), _ptr(dx), dg_ptr, db_ptr, _ptr(sums), N, C, HW, Ng, float(slope),
                     _ptr(ws), 1 if ctx.dgb_split else 0, _stream(), shape=(N, C, HW))
         if mode == 0:
             dw = db = None

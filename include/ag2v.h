@@ -151,8 +151,10 @@ int ag2v_norm_bwd_g(int mode, const float* dy, const float* y, const float* x, c
 /* ag2v_norm_bwd_g whose dgamma / dbeta (modes 1 / 2) are stored as split words when dgb_split != 0 (ag2v_conv_opts::dy_split): the
  * gradient of the convolution that produced gamma | beta goes into that convolution's data gradient and weight gradient only. */
 int ag2v_norm_bwd_gs(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* w,
-                     const float* mean, const float* invstd, float* dx, float* dgamma, float* dbeta, float* sums,
+                     const float* bias, const float* mean, const float* invstd, float* dx, float* dgamma, float* dbeta, float* sums,
                      int N, int C, int HW, int Ng, float slope, float* workspace, int dgb_split, void* stream);
+/* (mode 0, y == NULL: the LeakyReLU branch is recomputed from x, w and `bias` -- the affine pair of the forward pass -- instead of
+ *  being read from the forward output: 5 instead of 7 tensor passes.) */
 /* ag2v_norm_bwd_g in two steps, for data-parallel SYNCHRONISED batch norm (sync_batchnorm/batchnorm.py:105-126): the caller
  * all-reduces sums[N / Ng, C, 4] over the ranks between them and passes inv_count = 1 / (elements per (group, channel) over ALL ranks). */
 int ag2v_norm_bwd_reduce_g(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* mean,
