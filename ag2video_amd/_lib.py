@@ -43,6 +43,7 @@ _SIGS = {
     'ag2v_norm_apply_g': (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     'ag2v_norm_apply_gs': (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
     'ag2v_norm_bwd_g': (c_int, [c_int] + [_P] * 11 + [c_int, c_int, c_int, c_int, c_float, _P, _P]),
+    'ag2v_norm_bwd_pyr': (c_int, [_P, _P, _P, _P, c_int] + [_P] * 7 + [c_int] * 5 + [c_float, _P, _P]),
     'ag2v_norm_bwd_gs': (c_int, [c_int] + [_P] * 12 + [c_int, c_int, c_int, c_int, c_float, _P, c_int, _P]),
     'ag2v_norm_bwd_reduce_g': (c_int, [c_int] + [_P] * 7 + [c_int, c_int, c_int, c_int, c_float, _P, _P]),
     'ag2v_norm_bwd_apply_g': (c_int, [c_int] + [_P] * 8 + [c_float, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),

@@ -186,15 +186,54 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
     store16<VEC>(y + off, cnt, v);
 }
 
+// Gradient of a tensor that was also read through nearest-neighbour down-samplings (the segmentation-map pyramid of the decoder):
+// dy = g_full + sum_l scatter(g_l).  The affine batch-norm backward can form it while loading (PYR) instead of reading a
+// materialised sum that a separate pass wrote: level l with factors (fy, fx) contributes g_l[y / fy, x / fx] at on-grid (y, x).
+struct NormPyramid {
+    const float* g[8];
+    int h[8], w[8], fy[8], fx[8];
+    int n;
+    int W;      // row length of the full-resolution map
+    int pow2;   // every factor is a power of two
+};
+// adds the level terms to the 16 elements load16<true> fetched for (image plane nc, elements start ...) of a [., H, W] tensor
+__device__ __forceinline__ void pyramid_add16(float (&g)[16], const NormPyramid& lv, size_t nc, int start, int cnt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = (i * 256 + threadIdx.x) * 4;
+        if (e >= cnt) continue;
+        const int L = start + e;
+        const int y = L / lv.W, x0 = L - y * lv.W;       // (W % 4 == 0: the four elements share the row)
+        for (int l = 0; l < lv.n; ++l) {
+            const int fy = lv.fy[l], fx = lv.fx[l];
+            if (lv.pow2) {          // power-of-two factors (the decoder's pyramid): masks and shifts, no integer divisions
+                if (y & (fy - 1)) continue;
+                const int sy = 31 - __clz(fy), sx = 31 - __clz(fx);
+                const float* gp = lv.g[l] + (nc * lv.h[l] + (y >> sy)) * lv.w[l] + (x0 >> sx);
+                if (fx == 2) { g[4 * i] += gp[0]; g[4 * i + 2] += gp[1]; }
+                else if (fx == 1) { g[4 * i] += gp[0]; g[4 * i + 1] += gp[1]; g[4 * i + 2] += gp[2]; g[4 * i + 3] += gp[3]; }
+                else if ((x0 & (fx - 1)) == 0) g[4 * i] += gp[0];
+                continue;
+            }
+            if (y % fy) continue;
+            const float* gp = lv.g[l] + (nc * lv.h[l] + y / fy) * lv.w[l];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int x = x0 + q;
+                if (x % fx == 0) g[4 * i + q] += gp[x / fx];
+            }
+        }
+    }
+}
 // backward pass 1: per (c, part) partial sums  s1 = sum dxhat, s2 = sum dxhat * xhat
 //   MODE 0: dxhat = g (weight applied in pass 2);  MODE 1: dxhat = g * (1 + gamma);   g = dy * lrelu'(y)
-template <int MODE, bool VEC>
+template <int MODE, bool VEC, bool PYR = false>
 __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                               const float* __restrict__ x, const float* __restrict__ gamma,
                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
                                                               float* __restrict__ partial, int Ng, int C, int HW, int nchunk,
                                                               float slope, long long gbx, const float* __restrict__ aw,
-                                                              const float* __restrict__ ab) {
+                                                              const float* __restrict__ ab, NormPyramid pyr = NormPyramid{}) {
     __shared__ float sh[4];
     const int bid = blockIdx.x;
     const int chunk = bid % nchunk, nc = bid / nchunk;
@@ -206,7 +245,13 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __res
     const float mu = mean[gc], is = invstd[gc];
     float g[16], xv[16], t[16];
     unsigned mask;
+    if (PYR && dy == nullptr) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) g[i] = 0.f;
+        mask = 0;
+    } else
     load16<VEC>(dy + off, cnt, g, mask);
+    if (PYR) pyramid_add16(g, pyr, (size_t)nc, start, cnt);
     load16<VEC>(x + off, cnt, xv, mask);
     if (slope != 1.f) {
         if (MODE == 0 && y == nullptr) {
@@ -269,7 +314,7 @@ __global__ void pair_sum_finalize_kernel(const float* __restrict__ partial, int 
 // backward pass 2.
 //   MODE 0: dx = w*invstd*(g - s1/n - xhat*s2/n)                    (dw = s2, db = s1 are read from sums by the host)
 //   MODE 1: dgamma = g*xhat, dbeta = g, dx = invstd*(g(1+gamma) - s1/n - xhat*s2/n)
-template <int MODE, bool VEC>
+template <int MODE, bool VEC, bool PYR = false>
 __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                              const float* __restrict__ x, const float* __restrict__ gamma,
                                                              const float* __restrict__ w, const float* __restrict__ mean,
@@ -277,7 +322,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
                                                              float* __restrict__ dx, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta, int C, int HW, int nchunk,
                                                              float inv_count, float slope, long long gbx, int Ng, int dgb_split,
-                                                             const float* __restrict__ ab) {
+                                                             const float* __restrict__ ab, NormPyramid pyr = NormPyramid{}) {
     const int bid = blockIdx.x;
     const int chunk = bid % nchunk, nc = bid / nchunk;
     const int c = nc % C;
@@ -289,7 +334,13 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
     const float m1 = sums[4 * gc] * inv_count, m2 = sums[4 * gc + 1] * inv_count;
     float g[16], xv[16], t[16];
     unsigned mask;
+    if (PYR && dy == nullptr) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) g[i] = 0.f;
+        mask = 0;
+    } else
     load16<VEC>(dy + off, cnt, g, mask);
+    if (PYR) pyramid_add16(g, pyr, (size_t)nc, start, cnt);
     load16<VEC>(x + off, cnt, xv, mask);
     if (slope != 1.f) {
         if (MODE == 0 && y == nullptr) {       // see norm_bwd_reduce_kernel
@@ -754,6 +805,45 @@ extern "C" int ag2v_norm_bwd_gs(int mode, const float* dy, const float* y, const
     if (Ng <= 0 || HW <= 0) return AG2V_EINVAL;
     return norm_bwd_launch(mode, true, true, dy, y, x, gamma, w, mean, invstd, dx, dgamma, dbeta, sums, N, C, HW, Ng, slope,
                            1.0f / ((float)Ng * (float)HW), workspace, (hipStream_t)stream, dgb_split, bias, mode == 0 && y == nullptr);
+}
+// Backward of y = lrelu(batch_norm_affine(x)) (mode 0 of ag2v_norm_bwd_gs, the activation branch recomputed from x) whose output was
+// read directly AND through nearest-neighbour down-samplings (ag2v_nearest_resize_fwd to hs[l] x ws[l]): the gradient
+// g_full (nullable) + sum_l scatter(g_levels[l]) is formed while loading -- no materialised sum (ag2v_nearest_pyramid_bwd) in between.
+// W % 4 == 0, 16-byte aligned tensors, H % hs[l] == 0, W % ws[l] == 0, at most 8 levels.
+extern "C" int ag2v_norm_bwd_pyr(const float* g_full, const float* const* g_levels, const int* hs, const int* ws, int n_levels,
+                                 const float* x, const float* w, const float* bias, const float* mean, const float* invstd, float* dx,
+                                 float* sums, int N, int C, int H, int W, int Ng, float slope, float* workspace, void* stream) {
+    if (!x || !mean || !invstd || !dx || !sums || !workspace || N <= 0 || C <= 0 || H <= 0 || W <= 0 || (W & 3) || Ng <= 0 || N % Ng)
+        return AG2V_EINVAL;
+    if (n_levels < 0 || n_levels > 8 || (n_levels && (!g_levels || !hs || !ws))) return AG2V_EINVAL;
+    const int HW = H * W;
+    if (!vec_ok(HW, g_full, x, dx)) return AG2V_EINVAL;
+    NormPyramid lv{};
+    lv.W = W;
+    for (int l = 0; l < n_levels; ++l) {
+        if (!g_levels[l]) continue;
+        if (hs[l] <= 0 || ws[l] <= 0 || H % hs[l] || W % ws[l]) return AG2V_EINVAL;
+        lv.g[lv.n] = g_levels[l]; lv.h[lv.n] = hs[l]; lv.w[lv.n] = ws[l]; lv.fy[lv.n] = H / hs[l]; lv.fx[lv.n] = W / ws[l];
+        ++lv.n;
+    }
+    lv.pow2 = 1;
+    for (int l = 0; l < lv.n; ++l)
+        if ((lv.fy[l] & (lv.fy[l] - 1)) || (lv.fx[l] & (lv.fx[l] - 1))) lv.pow2 = 0;
+    if (!g_full && lv.n == 0) return AG2V_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int nchunk = ceil_div(HW, CHUNK);
+    const long long nblk = (long long)N * C * nchunk;
+    if (nblk >= (1LL << 31)) return AG2V_EINVAL;
+    dim3 g((unsigned)nblk), t(256);
+    const int GC = (N / Ng) * C;
+    const float inv_count = 1.0f / ((float)Ng * (float)HW);
+    hipLaunchKernelGGL((norm_bwd_reduce_kernel<0, true, true>), g, t, 0, st, g_full, (const float*)nullptr, x, (const float*)nullptr, mean,
+                       invstd, workspace, Ng, C, HW, nchunk, slope, 0LL, w, bias, lv);
+    hipLaunchKernelGGL(pair_sum_finalize_kernel, dim3(ceil_div(GC, 64)), dim3(64), 0, st, workspace, GC, Ng * nchunk, sums);
+    hipLaunchKernelGGL((norm_bwd_apply_kernel<0, true, true>), g, t, 0, st, g_full, (const float*)nullptr, x, (const float*)nullptr, w, mean,
+                       invstd, sums, dx, (float*)nullptr, (float*)nullptr, C, HW, nchunk, inv_count, slope, 0LL, Ng, 0, bias, lv);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
 }
 extern "C" int ag2v_norm_bwd_g(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* w,
                                const float* mean, const float* invstd, float* dx, float* dgamma, float* dbeta, float* sums,

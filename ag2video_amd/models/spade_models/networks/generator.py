@@ -98,7 +98,16 @@ class Layout2VidGenerator(nn.Module):
                                         img=warp, w_img=w[:, nseg:], gscale=scales)
                 # the normalised layout features are read by convolutions only (every SPADE's mlp_shared at its resolution, netG.fc):
                 # stored as split words when all of them run on the bf16x3 kernels (their producers then skip the fp32 split)
-                x = bn(y, slope=0.2, out_split=self.netG.layout_split_ok(y.shape[0], y.shape[1], H, H))
+                spl = self.netG.layout_split_ok(y.shape[0], y.shape[1], H, H)
+                sizes = sorted(set(self.netG.pyramid_sizes(H, H)) | {(H, H)})
+                if ops.batchnorm_act_pyramid_supported(y.shape, sizes):
+                    # batch norm + the decoder's segmentation-map pyramid as one node: its backward forms the sum of the level
+                    # gradients while the norm backward loads it
+                    from .normalization import SegmapPyramid
+                    lv = bn.forward_pyramid(y, sizes, slope=0.2, out_split=spl)
+                    x = SegmapPyramid.from_levels(lv[(H, H)], lv)
+                else:
+                    x = bn(y, slope=0.2, out_split=spl)
                 out = self.netG(x) + warp
         out = out.view(T, B, out.size(1), H, H)
         flow = flow.view(T, B, 2, H, H)

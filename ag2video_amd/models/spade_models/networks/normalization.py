@@ -103,6 +103,13 @@ class SegmapPyramid(object):
             for key, t in zip(sizes, ops.nearest_pyramid(segmap, sizes)):
                 self._cache[key] = t
 
+    @classmethod
+    def from_levels(cls, segmap, levels):
+        """A pyramid whose levels were built elsewhere ({(h, w): tensor}; SynchronizedBatchNorm2d.forward_pyramid)."""
+        p = cls(segmap)
+        p._cache.update(levels)
+        return p
+
     def at(self, h, w):
         key = (int(h), int(w))
         if key not in self._cache:

@@ -61,7 +61,8 @@ class SPADEGenerator(nn.Module):
         return ops.conv_split_input_ok((N, C, self.sh, self.sw), wshape, 1, 1)
 
     def forward(self, layout):
-        layout = SegmapPyramid(layout, self.pyramid_sizes(layout.shape[2], layout.shape[3]))
+        if not isinstance(layout, SegmapPyramid):      # (the frame-batched generator hands over the pyramid it built with the batch norm)
+            layout = SegmapPyramid(layout, self.pyramid_sizes(layout.shape[2], layout.shape[3]))
         x = layout.at(self.sh, self.sw)
         x = self.fc(x)
         x = self.head_0(x, layout)

@@ -46,6 +46,13 @@ class SynchronizedBatchNorm2d(nn.Module):
         return ops.batchnorm_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
                                  self.momentum, self.eps, slope, groups=ops.current_frame_groups(), out_split=out_split)
 
+    def forward_pyramid(self, x, sizes, slope=1.0, out_split=False):
+        """forward() followed by the nearest-neighbour pyramid of the result (every SPADE's resized segmentation map) as one autograd
+        node (ops.batchnorm_act_pyramid); returns {size: tensor}."""
+        outs = ops.batchnorm_act_pyramid(x, self.weight, self.bias, self.running_mean, self.running_var, sizes, self.training,
+                                         self.momentum, self.eps, slope, groups=ops.current_frame_groups(), out_split=out_split)
+        return {tuple(int(v) for v in k): t for k, t in zip(sizes, outs)}
+
     def modulate(self, x, gamma, beta, slope=1.0):
         """SPADE use: normalise without affine and apply (1+gamma), beta in the same pass."""
         return ops.spade_norm(x, gamma, beta, self.running_mean, self.running_var, self.training, self.momentum, self.eps,

@@ -943,6 +943,87 @@ def batchnorm_act(x, weight, bias, running_mean, running_var, training=True, mom
     return mark_split(y) if out_split else y
 
 
+class _BNActPyramid(torch.autograd.Function):
+    """batchnorm_act (affine batch norm + LeakyReLU, optionally split-word output) followed by the nearest-neighbour pyramid of its
+    output (nearest_pyramid) as ONE node: the backward forms  g_full + sum of the scattered level gradients  while the batch-norm
+    backward loads it (ag2v_norm_bwd_pyr) instead of materialising that sum first (one write + two reads of the full-size tensor).
+    Returns one tensor per entry of ``sizes`` (the full size is the normalised tensor itself)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, slope, groups, sizes, out_split):
+        x, weight, bias = _c(x), _c(weight), _c(bias)
+        _chk(x, weight, bias)
+        mean, invstd, N, C, HW, Ng = _bn_stats(x, running_mean, running_var, training, momentum, eps, groups)
+        H, W = x.shape[2], x.shape[3]
+        y = torch.empty_like(x)
+        _lib.call('ag2v_norm_apply_gs', 0, _ptr(x), _ptr(mean), _ptr(invstd), _ptr(weight), _ptr(bias), None, None, _ptr(y),
+                  N, C, HW, Ng, float(slope), 1 if out_split else 0, _stream())
+        built = {(H, W): y}
+        for (h, w) in sorted(set(sizes), key=lambda s_: -s_[0] * s_[1]):       # as _NearestPyramid.forward: level from level
+            if (h, w) in built:
+                continue
+            src = min((s_ for s_ in built if s_[0] % h == 0 and s_[1] % w == 0), key=lambda s_: s_[0] * s_[1])
+            t = torch.empty((N, C, h, w), device=x.device, dtype=torch.float32)
+            _lib.call('ag2v_nearest_resize_fwd', _ptr(built[src]), _ptr(t), N * C, src[0], src[1], h, w, _stream())
+            built[(h, w)] = t
+        ctx.save_for_backward(x, weight, bias, mean, invstd)
+        ctx.cfg = (training, slope, N, C, H, W, Ng, tuple(sizes))
+        return tuple(y.view_as(y) if (h, w) == (H, W) else built[(h, w)] for (h, w) in sizes)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        x, weight, bias, mean, invstd = ctx.saved_tensors
+        training, slope, N, C, H, W, Ng, sizes = ctx.cfg
+        if not training:
+            raise RuntimeError("norm backward is only implemented for batch statistics (training mode)")
+        g_full, lv, hs, ws_, keep = None, [], [], [], []
+        for (h, w), g in zip(sizes, grads):
+            if g is None:
+                continue
+            g = g.contiguous()
+            keep.append(g)
+            if (h, w) == (H, W):
+                g_full = g if g_full is None else g_full + g
+            else:
+                lv.append(g.data_ptr()); hs.append(h); ws_.append(w)
+        G = N // Ng
+        dx = torch.empty_like(x)
+        sums = torch.empty((G, C, 4), device=x.device, dtype=torch.float32)
+        ws = torch.empty(_lib.query('ag2v_bn_workspace_floats', N, C, H * W), device=x.device, dtype=torch.float32)
+        n = len(lv)
+        arr_p = (ctypes.c_void_p * max(n, 1))(*lv)
+        arr_h = (ctypes.c_int * max(n, 1))(*hs)
+        arr_w = (ctypes.c_int * max(n, 1))(*ws_)
+        _launch('ag2v_norm_bwd_pyr', 'norm_bwd', 5.0 * x.numel() * 4, _ptr(g_full), ctypes.cast(arr_p, ctypes.c_void_p),
+                ctypes.cast(arr_h, ctypes.c_void_p), ctypes.cast(arr_w, ctypes.c_void_p), n, _ptr(x), _ptr(weight), _ptr(bias), _ptr(mean),
+                _ptr(invstd), _ptr(dx), _ptr(sums), N, C, H, W, Ng, float(slope), _ptr(ws), _stream(), shape=(N, C, H * W))
+        dw = db = None
+        if weight is not None:
+            tot = sums.sum(dim=0) if G > 1 else sums[0]
+            dw, db = tot[:, 1].contiguous(), tot[:, 0].contiguous()
+        return (dx, dw, db) + (None,) * 9
+
+
+def batchnorm_act_pyramid_supported(x_shape, sizes):
+    from . import distributed as D
+    H, W = int(x_shape[2]), int(x_shape[3])
+    return ((W % 4 == 0) and len(sizes) <= 8 and all(H % int(h) == 0 and W % int(w) == 0 for (h, w) in sizes) and not D.sync_bn()
+            and os.environ.get('AG2V_NO_BN_PYRAMID') is None)
+
+
+def batchnorm_act_pyramid(x, weight, bias, running_mean, running_var, sizes, training=True, momentum=0.1, eps=1e-5, slope=1.0, groups=1,
+                          out_split=False):
+    """nearest_pyramid(batchnorm_act(x, ...), sizes) with a fused backward (see _BNActPyramid); requires
+    batchnorm_act_pyramid_supported(x.shape, sizes).  Returns a tuple of tensors (split words when out_split)."""
+    sizes = tuple((int(h), int(w)) for (h, w) in sizes)
+    outs = _BNActPyramid.apply(x, weight, bias, running_mean, running_var, bool(training), float(momentum), float(eps), float(slope),
+                               int(groups), sizes, bool(out_split))
+    if out_split:
+        for o in outs:
+            mark_split(o)
+    return outs
+
+
 def spade_norm(x, gamma, beta, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0, groups=1):
     """SPADE modulation: BN_noaffine(x) * (1 + gamma) + beta, then LeakyReLU(slope)."""
     return _NormAct.apply(1, x, gamma, beta, running_mean, running_var, bool(training), float(momentum), float(eps),

@@ -155,6 +155,12 @@ int ag2v_norm_bwd_gs(int mode, const float* dy, const float* y, const float* x, 
                      int N, int C, int HW, int Ng, float slope, float* workspace, int dgb_split, void* stream);
 /* (mode 0, y == NULL: the LeakyReLU branch is recomputed from x, w and `bias` -- the affine pair of the forward pass -- instead of
  *  being read from the forward output: 5 instead of 7 tensor passes.) */
+/* ag2v_norm_bwd_gs(mode 0, y == NULL) for an output that was read directly and through nearest-neighbour down-samplings (the
+ * decoder's segmentation-map pyramid, normalization.py:102): dy = g_full (nullable) + sum_l scatter(g_levels[l]) is formed while
+ * loading.  g_levels / hs / ws: host arrays of n_levels <= 8 entries (null level pointers are skipped). */
+int ag2v_norm_bwd_pyr(const float* g_full, const float* const* g_levels, const int* hs, const int* ws, int n_levels,
+                      const float* x, const float* w, const float* bias, const float* mean, const float* invstd, float* dx,
+                      float* sums, int N, int C, int H, int W, int Ng, float slope, float* workspace, void* stream);
 /* ag2v_norm_bwd_g in two steps, for data-parallel SYNCHRONISED batch norm (sync_batchnorm/batchnorm.py:105-126): the caller
  * all-reduces sums[N / Ng, C, 4] over the ranks between them and passes inv_count = 1 / (elements per (group, channel) over ALL ranks). */
 int ag2v_norm_bwd_reduce_g(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* mean,

@@ -102,6 +102,19 @@ def batchnorm_act(x, weight, bias, running_mean, running_var, training=True, mom
     return _lrelu(_batch_norm_groups(x, running_mean, running_var, weight, bias, training, momentum, eps, groups), slope)
 
 
+def batchnorm_act_pyramid(x, weight, bias, running_mean, running_var, sizes, training=True, momentum=0.1, eps=1e-5, slope=1.0, groups=1,
+                          out_split=False):
+    """The product's fused node = the reference's two steps: the normalised tensor (generator.py:26-33), then every SPADE's
+    F.interpolate(segmap, size, 'nearest') of it (normalization.py:102)."""
+    assert not out_split
+    y = batchnorm_act(x, weight, bias, running_mean, running_var, training, momentum, eps, slope, groups)
+    return nearest_pyramid(y, sizes)
+
+
+def batchnorm_act_pyramid_supported(x_shape, sizes):
+    return True
+
+
 def spade_norm(x, gamma, beta, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0, groups=1):
     """SPADE.forward normalization.py:99,108 (+ actvn architecture.py:53-54,68)."""
     n = _batch_norm_groups(x, running_mean, running_var, None, None, training, momentum, eps, groups)

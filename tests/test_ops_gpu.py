@@ -598,6 +598,32 @@ def test_spade_gradient_as_split_words(pair, device, monkeypatch):
         assert float((a - c).abs().max()) <= 1e-5 * float(c.abs().max())
 
 
+@pytest.mark.parametrize("cfg", [(4, 6, 32, 32, 2, [(32, 32), (16, 16), (8, 8), (2, 2)]), (3, 5, 16, 24, 1, [(8, 12), (4, 6)]),
+                                 (2, 4, 8, 8, 2, [(8, 8)])], ids=str)
+def test_batchnorm_act_pyramid(cfg, device):
+    """Affine batch norm + LeakyReLU + the nearest-neighbour pyramid of the result as one node (fused backward: the level gradients are
+    gathered while the norm backward loads its dy) against the oracle's two steps; frame groups; levels without a gradient."""
+    from ag2video_amd import ops
+    from oracle import kernels as K
+    N, C, H, W, G, sizes = cfg
+    assert ops.batchnorm_act_pyramid_supported((N, C, H, W), sizes)
+    x, wt, bs = _rand(N, C, H, W, seed=1), torch.rand(C) + 0.5, _rand(C, seed=3)
+    res = []
+    for mod, dev in ((K, 'cpu'), (ops, device)):
+        xd, wd, bd = [t.clone().to(dev).requires_grad_(True) for t in (x, wt, bs)]
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        outs = mod.batchnorm_act_pyramid(xd, wd, bd, rm, rv, sizes, True, 0.1, 1e-5, 0.2, groups=G)
+        loss = 0
+        for i, o in enumerate(outs):
+            if i == 1 and len(outs) > 2:
+                continue                      # a level nobody back-propagates through
+            loss = loss + (o * _rand(*o.shape, seed=10 + i).to(dev)).sum() * (0.5 + i)
+        loss.backward()
+        res.append(list(outs) + [xd.grad, wd.grad, bd.grad, rm, rv])
+    for i, (got, ref) in enumerate(zip(res[1], res[0])):
+        _cmp('bn_pyramid[%d]' % i, got, ref, TOL)
+
+
 def test_linear_unaligned_operands(device):
     """The one-round-trip GEMM reads k-contiguous operands with 16-byte loads when their rows are 16-byte aligned and with 4-byte
     loads otherwise (views into a flat buffer at any element offset): same results either way, forward and both gradients."""
