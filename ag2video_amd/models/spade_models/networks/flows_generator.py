@@ -1,4 +1,7 @@
 """Optical-flow generator (reference: networks/flows_generator.py:14-109)."""
+import contextlib
+import os
+
 import torch.nn as nn
 
 from .... import ops
@@ -83,7 +86,6 @@ class FlowsGenerator(nn.Module):
                 else:
                     x = self._conv_bn_act(m, x)
                 first = False
-        import contextlib, os
         part = os.environ.get('AG2V_FLOW_SPLIT_PARTS', '')          # diagnostic (tools/debug_c1_precision.py): forward of these parts on bf16x3
         ctx = lambda name: ops.bf16x3_min_rows(48, 32) if name in part else contextlib.nullcontext()
         with ctx('res'):

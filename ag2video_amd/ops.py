@@ -3,6 +3,13 @@
 PyTorch supplies device memory, the current HIP stream and the autograd tape; all arithmetic of these operators runs
 in the hand-written gfx950 kernels of ag2video_amd/csrc.  Every operator requires CUDA(HIP) fp32 tensors and raises
 otherwise -- there is no CPU path in the product (tests/ check these operators against oracle/ on the GPU).
+
+Side channels between operators travel as attributes on the tensor objects autograd hands from one Function to the next (the
+same Python object arrives; a tensor that lost its attribute simply takes the plain path):
+  _ag2v_split          the tensor holds split words (bf16 hi | bf16 lo per value) instead of fp32: is_split / mark_split;
+  _ag2v_dy_split_ok    on an operator's OUTPUT: its backward accepts the gradient of this tensor as split words;
+  _ag2v_channel_sums   on a GRADIENT tensor: its per-channel sums, already computed by the kernel that produced it (the bias
+                       gradient of the convolution it goes to).
 """
 import contextlib
 import ctypes
