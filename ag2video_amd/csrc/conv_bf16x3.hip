@@ -41,7 +41,10 @@ __device__ __forceinline__ void split_or_regroup(float x0, float x1, unsigned& h
 // PSB: the gathered tensor holds SPLIT WORDS already -- (bf16 hi << 16) | bf16 lo of each value, written by the kernel that
 // produced it (ag2v_norm_apply_g(out_split), pack_split()); the producers then only regroup halves (2 v_perm per pair instead
 // of the 6-instruction split).  Same products, same sums: results are bit-identical to the fp32-input kernel's.
-template <int BM, int BN, int CWM, int CWN, int NPW, bool MF16, bool TAPK, bool B4, bool PSB>
+// F32: the same wave-specialised pipeline on EXACT fp32 operands (v_mfma_f32_32x32x2_f32): the producers store the fp32 words as
+// loaded, [row][k] with 36-word rows; consumer lane (row, half) multiplies k = 16 half + j, j < 16 (the order of the k terms of a
+// K-tile is free as long as both operands use the same), i.e. four 16-byte LDS reads per 32-row fragment.  Table path only.
+template <int BM, int BN, int CWM, int CWN, int NPW, bool MF16, bool TAPK, bool B4, bool PSB, bool F32 = false>
 __device__ __forceinline__ void igemm_bf16x3_body(const ConvArgs& p) {
     constexpr int BK = 32, LDK = AG2V_LDK, NP = NPW * 64;       // NP producer threads
     constexpr int TM = BM / CWM / 32, TN = BN / CWN / 32;  // consumer wave tile in 32x32 MFMA tiles
@@ -58,10 +61,14 @@ __device__ __forceinline__ void igemm_bf16x3_body(const ConvArgs& p) {
     constexpr int QN = BN / 4, KP = NP / QN, KPT = BK / KP, GR = QN + 4;
     constexpr int BROWS = B4 ? 4 * GR : BN;
     static_assert(!B4 || (TAPK && BCOLS == 1 && 4 * KPT == BKK && (KPT == 2 || KPT == 4) && !MF16), "quad loads: tap-major 32x32x16 tiles");
-    __shared__ __attribute__((aligned(16))) unsigned short Ahi[2][BM * LDK];
-    __shared__ __attribute__((aligned(16))) unsigned short Alo[2][BM * LDK];
-    __shared__ __attribute__((aligned(16))) unsigned short Bhi[2][BROWS * LDK];
-    __shared__ __attribute__((aligned(16))) unsigned short Blo[2][BROWS * LDK];
+    static_assert(!F32 || (!MF16 && !TAPK && !B4 && !PSB), "fp32 operands: table path, 32x32 tiles");
+    constexpr int LDKF = BK + 4;     // fp32 rows: 144 bytes (16-byte aligned; 32 lanes x 16 bytes cover every bank 4 times)
+    __shared__ __attribute__((aligned(16))) unsigned short Ahi[2][F32 ? 8 : BM * LDK];
+    __shared__ __attribute__((aligned(16))) unsigned short Alo[2][F32 ? 8 : BM * LDK];
+    __shared__ __attribute__((aligned(16))) unsigned short Bhi[2][F32 ? 8 : BROWS * LDK];
+    __shared__ __attribute__((aligned(16))) unsigned short Blo[2][F32 ? 8 : BROWS * LDK];
+    __shared__ __attribute__((aligned(16))) float Af[2][F32 ? BM * LDKF : 4];
+    __shared__ __attribute__((aligned(16))) float Bf[2][F32 ? BN * LDKF : 4];
     __shared__ int2 tab[TAPK ? 1 : 4][BK];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -240,6 +247,21 @@ __device__ __forceinline__ void igemm_bf16x3_body(const ConvArgs& p) {
             }
         };
         auto stash = [&](int buf, const unsigned (&ra)[ACOLS][AK], float (&rb)[BCOLS][BKK], unsigned emask) {
+            if constexpr (F32) {        // fp32 words as loaded
+#pragma unroll
+                for (int c = 0; c < ACOLS; ++c)
+#pragma unroll
+                    for (int g = 0; g < AK / 4; ++g)
+                        *reinterpret_cast<uint4*>(&Af[buf][(acol0 + c * (BM / ACOLS)) * LDKF + AK * apart + 4 * g]) =
+                            make_uint4(ra[c][4 * g], ra[c][4 * g + 1], ra[c][4 * g + 2], ra[c][4 * g + 3]);
+#pragma unroll
+                for (int c = 0; c < BCOLS; ++c)
+#pragma unroll
+                    for (int g = 0; g < BKK / 4; ++g)
+                        *reinterpret_cast<float4*>(&Bf[buf][(bcol0 + c * (BN / BCOLS)) * LDKF + BKK * bpart + 4 * g]) =
+                            make_float4(rb[c][4 * g], rb[c][4 * g + 1], rb[c][4 * g + 2], rb[c][4 * g + 3]);
+                return;
+            }
 #pragma unroll
             for (int c = 0; c < ACOLS; ++c)
 #pragma unroll
@@ -408,6 +430,32 @@ __device__ __forceinline__ void igemm_bf16x3_body(const ConvArgs& p) {
             for (int r = 0; r < EREGS; ++r) acc[i][j][r] = 0.f;
     const int fr = lane & (ER - 1), fq = lane / ER;
     auto compute = [&](int buf) {
+        if constexpr (F32) {
+            const int half = lane >> 5, r32 = lane & 31;
+            float4 bfr[EN][4];
+#pragma unroll
+            for (int j = 0; j < EN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    bfr[j][q] = *reinterpret_cast<const float4*>(&Bf[buf][(wn0 + j * 32 + r32) * LDKF + 16 * half + 4 * q]);
+#pragma unroll
+            for (int i = 0; i < EM; ++i) {
+                float4 afr[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    afr[q] = *reinterpret_cast<const float4*>(&Af[buf][(wm0 + i * 32 + r32) * LDKF + 16 * half + 4 * q]);
+#pragma unroll
+                for (int j = 0; j < EN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[q].x, bfr[j][q].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[q].y, bfr[j][q].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[q].z, bfr[j][q].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[q].w, bfr[j][q].w, acc[i][j], 0, 0, 0);
+                    }
+            }
+            return;
+        }
 #pragma unroll
         for (int ks = 0; ks < (MF16 ? 1 : BK / 16); ++ks) {
             bf16x8 bhi[EN], blo[EN];
@@ -602,6 +650,11 @@ __device__ __forceinline__ void igemm_bf16x3_body(const ConvArgs& p) {
 template <int BM, int BN, int CWM, int CWN, int NPW, bool MF16, bool TAPK, bool B4>
 __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_kernel(ConvArgs p) {
     igemm_bf16x3_body<BM, BN, CWM, CWN, NPW, MF16, TAPK, B4, false>(p);
+}
+// exact fp32 on the same pipeline (ConvArgs::f32): conv_igemm_kernel's arithmetic at a higher MFMA occupancy
+template <int BM, int BN, int CWM, int CWN, int NPW>
+__global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_f32_ws_kernel(ConvArgs p) {
+    igemm_bf16x3_body<BM, BN, CWM, CWN, NPW, false, false, false, false, true>(p);
 }
 // the same tiles reading a split-word gathered tensor (ConvArgs::b_split)
 template <int BM, int BN, int CWM, int CWN, int NPW, bool MF16, bool TAPK, bool B4>
@@ -1126,7 +1179,16 @@ int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed) {
     static const bool b4_tall = getenv("AG2V_B4_TALL") != nullptr;
     const bool b4 = a.tap_major && !b4_off && (!tall || b4_tall) && a.stride == 1 && a.OW % 4 == 0 && a.W >= 4 &&
                     (a.OH * a.OW) % 4 == 0 && a.pad_w <= 3;
-    if (tall) {
+    if (a.f32) {        // exact fp32 operands (k-major fp32 weights, table path)
+        if (a.tap_major || a.b_split || a.out_split) return AG2V_EINVAL;
+        if (tall) {
+            set_last_conv_kernel("conv_igemm_f32_ws_kernel<256, 128, 4, 2, 8>");
+            hipLaunchKernelGGL((conv_igemm_f32_ws_kernel<256, 128, 4, 2, 8>), grid, dim3(1024), 0, st, a);
+        } else {
+            set_last_conv_kernel("conv_igemm_f32_ws_kernel<128, 256, 2, 4, 8>");
+            hipLaunchKernelGGL((conv_igemm_f32_ws_kernel<128, 256, 2, 4, 8>), grid, dim3(1024), 0, st, a);
+        }
+    } else if (tall) {
         // 16x16x32 MFMAs (+3..6 % with the table-path producers) read their LDS operands with 36 % bank-conflict cycles
         // (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, tools/ubench/pmc_variants.sh; 32x32x16: 0 %) and leave the prioritised
         // MFMA waves' partners 8 instead of 24 free issue cycles per MFMA: with the TAPK producers the 32x32x16 shape is

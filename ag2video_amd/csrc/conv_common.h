@@ -30,6 +30,7 @@ struct ConvArgs {
     long long out_gstride;  //   tiles x groups x spg); group g writes dW at out + g * out_gstride.  groups == 1: the plain form.
     int out_split;          // igemm bf16x3 epilogue: store the finished values as split words (forward with relu: the activation is
                             //   read by bf16x3 convolutions only)
+    int f32;                // wave-specialised implicit-GEMM kernels on exact fp32 operands (conv_igemm_f32_ws_kernel)
     int a_split;            // weight-gradient bf16x3 kernels: dy (a_src) holds split words
     int b_split;            // bf16x3 kernels: b_src holds split words ((bf16 hi << 16) | bf16 lo per value, pack_split()) instead of fp32
 #ifdef AG2V_STAMPS

@@ -800,6 +800,13 @@ extern "C" int ag2v_conv2d_fwd_ex(const float* x, const float* w, const float* b
         if (nmax <= 0) { split = false; nmax = N; }
     }
     if ((cfg.in_split || cfg.out_split) && !split) return AG2V_EINVAL;   // split words: bf16x3 kernels only (ag2v_conv2d_split_input_ok)
+    // exact arithmetic with >= 128 rows: the wave-specialised pipeline on fp32 operands (same chunking / descriptors as `split`)
+    static const bool f32ws_on = getenv("AG2V_NO_F32_WS") == nullptr;
+    bool f32ws = !split && f32ws_on && K >= 128 && KG >= 64 && abytes < kBufMax;
+    if (f32ws && xs * 4 * N >= chunk_limit()) {
+        nmax = chunk_samples(xs * 4, 0, cfg.gscale ? cfg.group_n : 1);
+        if (nmax <= 0) { f32ws = false; nmax = N; }
+    }
     if (cfg.out_split && residual) return AG2V_EINVAL;
     if ((long long)nmax * OH * OW >= (1LL << 31)) {         // the GEMM's pixel index is a 32-bit int
         nmax = (int)(((1LL << 31) - 1) / ((long long)OH * OW));
@@ -821,11 +828,12 @@ extern "C" int ag2v_conv2d_fwd_ex(const float* x, const float* w, const float* b
         a.N = nc; a.C = C; a.H = H; a.W = W; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.pad_w = pad;
         a.OH = OH; a.OW = OW;
         a.M = K; a.NG = nc * OH * OW; a.KG = KG;
-        a.a_bytes = (unsigned)abytes; a.b_bytes = split ? (unsigned)(xs * 4 * nc) : 0u;
+        a.a_bytes = (unsigned)abytes; a.b_bytes = (split || f32ws) ? (unsigned)(xs * 4 * nc) : 0u;
         a.tap_major = tapmaj ? 1 : 0;
         a.a_src = workspace;
         a.b_split = cfg.in_split; a.out_split = cfg.out_split;
-        const int rc = launch_igemm(a, st, false, split);
+        a.f32 = f32ws ? 1 : 0;
+        const int rc = launch_igemm(a, st, false, split || f32ws);
         if (rc != AG2V_OK) return rc;
     }
     if (o) o->kernel = g_last_conv_kernel;
@@ -920,6 +928,13 @@ extern "C" int ag2v_conv2d_dgrad_ex(const float* dy, const float* w, const float
                 if (nmax <= 0) { split = false; nmax = N; }
             }
             if ((cfg.dy_split || cfg.out_split) && !split) return AG2V_EINVAL;
+            // exact arithmetic with >= 128 rows: conv_igemm_f32_ws_kernel (see ag2v_conv2d_fwd_ex)
+            static const bool f32ws_on = getenv("AG2V_NO_F32_WS") == nullptr;
+            bool f32ws = !split && f32ws_on && C >= 128 && K * Rc * Sc >= 64 && abytes < kBufMax;
+            if (f32ws && dys * 4 * N >= chunk_limit()) {
+                nmax = chunk_samples(dys * 4, 0, cfg.gscale ? cfg.group_n : 1);
+                if (nmax <= 0) { f32ws = false; nmax = N; }
+            }
             const int cOH = (H - ay + stride - 1) / stride, cOW = (W - ax + stride - 1) / stride;
             if ((long long)nmax * cOH * cOW >= (1LL << 31)) {
                 nmax = (int)(((1LL << 31) - 1) / ((long long)cOH * cOW));
@@ -944,7 +959,8 @@ extern "C" int ag2v_conv2d_dgrad_ex(const float* dy, const float* w, const float
                 f.OH = cOH; f.OW = cOW;
                 f.o_mul = stride; f.o_add_y = ay; f.o_add_x = ax; f.o_H = H; f.o_W = W;
                 f.M = C; f.NG = nc * f.OH * f.OW; f.KG = K * Rc * Sc;
-                f.a_bytes = (unsigned)abytes; f.b_bytes = split ? (unsigned)(dys * 4 * nc) : 0u;
+                f.a_bytes = (unsigned)abytes; f.b_bytes = (split || f32ws) ? (unsigned)(dys * 4 * nc) : 0u;
+                f.f32 = f32ws ? 1 : 0;
                 f.gscale = cfg.gscale ? cfg.gscale + n0 / cfg.group_n : nullptr; f.group_n = cfg.group_n;
                 f.b_split = cfg.dy_split; f.out_split = cfg.out_split;
                 // one class (stride 1): the mask in the epilogue; several classes: one pass at the end
@@ -952,7 +968,7 @@ extern "C" int ag2v_conv2d_dgrad_ex(const float* dy, const float* w, const float
                 // accumulate: a split-K launch adds onto the existing dx with its atomics (no zeroing); any other launch reads dx
                 // back as the epilogue's residual term (each element is read and written by the same thread)
                 f.residual = accumulate ? dxc : nullptr;
-                const int rc = launch_igemm(f, st, multi || accumulate != 0, split);
+                const int rc = launch_igemm(f, st, multi || accumulate != 0, split || f32ws);
                 if (rc != AG2V_OK) return rc;
             }
             at += (size_t)K * C * Rc * Sc;
