@@ -50,7 +50,9 @@ def test_library_reports_the_launched_kernel(device):
     try:
         _lib.call('ag2v_set_bf16x3_min_rows', 512)
         ops.conv2d(x, w, None, 1, 1)
-        assert _lib.query('ag2v_last_conv_kernel').startswith(b'conv_igemm_kernel<128')
+        assert _lib.query('ag2v_last_conv_kernel').startswith(b'conv_igemm_f32_ws_kernel<128')      # exact arithmetic, >= 128 rows
+        ops.conv2d(x, w[:96], None, 1, 1)
+        assert _lib.query('ag2v_last_conv_kernel').startswith(b'conv_igemm_kernel<128')             # ... fewer rows
         with pytest.raises(RuntimeError):
             _lib.call('ag2v_set_bf16x3_min_rows', 0)
     finally:
