@@ -86,7 +86,7 @@ class FlowsGenerator(nn.Module):
                 else:
                     x = self._conv_bn_act(m, x)
                 first = False
-        part = os.environ.get('AG2V_FLOW_SPLIT_PARTS', '')          # diagnostic (tools/debug_c1_precision.py): forward of these parts on bf16x3
+        part = os.environ.get('AG2V_FLOW_SPLIT_PARTS', '')          # diagnostic (tests/debug/debug_c1_precision.py): forward of these parts on bf16x3
         ctx = lambda name: ops.bf16x3_min_rows(48, 32) if name in part else contextlib.nullcontext()
         with ctx('res'):
             for blk in self.res_flow:

@@ -1,7 +1,7 @@
 """Diagnostic: c1 (default widths) GPU-vs-oracle output errors for different arithmetic policies.
-usage: python tools/debug_c1_precision.py [flow_min_rows ...]"""
+usage: python tests/debug/debug_c1_precision.py [flow_min_rows ...]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 import bench

@@ -1,6 +1,6 @@
 """GPU-vs-oracle drift after one optimizer step (debug)."""
 import sys, os, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from ag2video_amd.data.args import make_opt
 from ag2video_amd.data.vocab import cater_vocab
