@@ -85,6 +85,36 @@ def average_gradients(params, bucket_bytes=BUCKET_BYTES, flat=None):
             off += n
 
 
+class _Pending(object):
+    """Handle of average_gradients_begin: finish() makes the current stream wait for the reductions and turns sums into means."""
+
+    def __init__(self, works, flat, world):
+        self.works, self.flat, self.world = works, flat, world
+
+    def finish(self):
+        for w in self.works:
+            w.wait()            # (NCCL / RCCL: the current stream waits, the host does not)
+        if self.flat is not None:
+            self.flat.div_(self.world)
+        self.works, self.flat = [], None
+
+
+def average_gradients_begin(params, bucket_bytes=BUCKET_BYTES, flat=None):
+    """average_gradients in two halves: the all-reduces of the flat gradient buffer are LAUNCHED here (asynchronously, in the same
+    bucket order on every rank) and the caller runs independent work -- the discriminator's loss and backward pass, which read none
+    of these gradients -- before it calls .finish() on the returned handle.  Without a flat buffer (torch.optim.Adam on the CPU) or
+    with AG2V_SYNC_ALLREDUCE set the reduction happens here and finish() is a no-op."""
+    if not is_dist():
+        return _Pending([], None, 1)
+    if flat is None or os.environ.get('AG2V_SYNC_ALLREDUCE') is not None:
+        average_gradients(params, bucket_bytes, flat)
+        return _Pending([], None, 1)
+    world = dist.get_world_size()
+    step = max(1, bucket_bytes // flat.element_size())
+    works = [dist.all_reduce(flat[off:off + step], op=dist.ReduceOp.SUM, async_op=True) for off in range(0, flat.numel(), step)]
+    return _Pending(works, flat, world)
+
+
 @torch.no_grad()
 def broadcast_parameters(tensors, src=0):
     """Make every rank start from rank 0's parameters and buffers (the reference re-broadcasts every forward)."""

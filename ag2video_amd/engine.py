@@ -92,8 +92,13 @@ class TrainStep(object):
                 return model_out, G_losses, None
         self.optimizer_generator.zero_grad()
         G_losses["total_loss"].backward()
-        dist_utils.average_gradients(self._gen_params, flat=getattr(self.optimizer_generator, 'flat_grad', None))
-        if apply_updates:
+        # One process per GPU: the generator's 500 MB gradient all-reduce is launched here and joined after the discriminator's
+        # loss + backward (which read neither these gradients nor the generator's parameters: imgs_pred is detached), then
+        # Adam(G) runs -- the same updates as the reference order (G step, then D loss), with the ring traffic behind ~150 ms of
+        # convolutions.  Single process: nothing is pending and Adam(G) runs here, in the reference's order.
+        pending = dist_utils.average_gradients_begin(self._gen_params, flat=getattr(self.optimizer_generator, 'flat_grad', None))
+        deferred = bool(pending.works)
+        if apply_updates and not deferred:
             self.optimizer_generator.step()
         D_losses = self.gans_model(batch, model_out, mode="compute_discriminator_loss")
         D_losses = {k: v.mean() for k, v in D_losses.items()}
@@ -101,6 +106,10 @@ class TrainStep(object):
         D_losses["total_img_loss"].backward()
         if self.side_stream is not None:      # the layout terms' backward ran there; their gradients are written by the ops themselves
             torch.cuda.current_stream().wait_stream(self.side_stream)
+        if deferred:
+            pending.finish()
+            if apply_updates:
+                self.optimizer_generator.step()
         dist_utils.average_gradients(self._d_params, flat=getattr(self.discriminator.optimizer_d_img, 'flat_grad', None))
         if apply_updates:
             self.discriminator.optimizer_d_img.step()

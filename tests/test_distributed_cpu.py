@@ -42,6 +42,21 @@ def _worker(rank, world, port, out_dir):
         dist.all_gather(lst, m)
     for p, lst in zip(params, gathered):
         assert torch.allclose(p.grad, sum(lst) / world, atol=1e-6)
+    # --- the two-phase form on a flat buffer (FusedAdam's layout): reductions launched, unrelated work, then joined
+    flat = torch.randn(3000, generator=g)
+    mine_flat = flat.clone()
+    pending = D.average_gradients_begin([], bucket_bytes=4096, flat=flat)
+    assert len(pending.works) == 3                      # 3000 floats in 1024-float buckets
+    other = torch.ones(10).sum()                        # (the discriminator phase stands here)
+    pending.finish()
+    lst = [torch.zeros_like(mine_flat) for _ in range(world)]
+    dist.all_gather(lst, mine_flat)
+    assert torch.allclose(flat, sum(lst) / world, atol=1e-6) and float(other) == 10.0 and not pending.works
+    os.environ['AG2V_SYNC_ALLREDUCE'] = '1'             # the synchronous fallback: nothing pending
+    flat2 = mine_flat.clone()
+    p2 = D.average_gradients_begin([], bucket_bytes=4096, flat=flat2)
+    assert not p2.works and torch.allclose(flat2, flat, atol=1e-6)
+    del os.environ['AG2V_SYNC_ALLREDUCE']
     # --- broadcast
     t = torch.full((4,), float(rank))
     D.broadcast_parameters([t])
