@@ -98,6 +98,39 @@ def pair_case():
     expect['spade_pair_bwd_apply'] = {'shape': 'same, backward apply pass', 'algorithmic_bytes': 2 * xb + 9 * ob, 'pass': 'bwd'}
 
 
+def layout_case():
+    # conv_dim_in's low-rank layout convolution + image channels at c3 (22 object slots, 6 occupied): one 16 GB write
+    NB, J, K, H, R = 120, 22, 512, 256, 3
+    U = torch.randn(NB, J, K, R * R, device=dev) * 0.1
+    boxes = torch.rand(NB, J, 4, device=dev) * 0.5
+    boxes[:, :, 2:] = boxes[:, :, 2:] * 0.6 + 0.1
+    m = torch.zeros(J, device=dev); m[[0, 1, 2, 11, 12, 13]] = 1
+    boxes = boxes * m.view(1, J, 1)
+    keep = torch.ones(NB, J, dtype=torch.int32, device=dev)
+    img = torch.randn(NB, 3, H, H, device=dev); wimg = torch.randn(K, 3, R, R, device=dev) * 0.1
+    gs = torch.ones(15, device=dev)
+    with torch.no_grad():
+        for _ in range(REPS):
+            ops.layout_conv_img(U, boxes, keep, H, H, R, 1, img, wimg, gs)
+    torch.cuda.synchronize()
+    expect['layout_conv_fwd'] = {'shape': 'layout_conv_img %dx%dx%dx%d, %d object slots (6 occupied), 3 image channels' % (NB, K, H, H, J),
+                                 'algorithmic_bytes': (NB * K * H * H + NB * 3 * H * H + NB * J * K * R * R) * 4, 'pass': 'fwd'}
+
+
+def f32_case():
+    # a residual-block convolution of the flow network (exact fp32 forward): 120 x 256 x 32 x 32 -> 256
+    N, C, H, K = 120, 256, 32, 256
+    x = torch.randn(N, C, H, H, device=dev); w = torch.randn(K, C, 3, 3, device=dev) * 0.02
+    with ops.conv_precision('fp32'), torch.no_grad():
+        for _ in range(REPS):
+            ops.conv2d(x, w, None, 1, 1)
+    torch.cuda.synchronize()
+    expect['flow_res_fp32'] = {'shape': 'exact fp32 fwd of %dx%dx%dx%d -> %d channels, 3x3' % (N, C, H, H, K),
+                               'algorithmic_bytes': (N * C * H * H + N * K * H * H + K * C * 9) * 4, 'pass': 'fwd'}
+
+
+CASES['layout_conv'] = layout_case
+CASES['flow_res_fp32'] = f32_case
 CASES['norm'] = norm_case
 CASES['spade_pair'] = pair_case
 CASES[CASE]()
