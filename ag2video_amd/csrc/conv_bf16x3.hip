@@ -38,6 +38,9 @@ __device__ __forceinline__ void split_or_regroup(float x0, float x1, unsigned& h
 #ifndef AG2V_WIDE_MF16
 #define AG2V_WIDE_MF16 false
 #endif
+#ifndef AG2V_CONSUMER_SKEW
+#define AG2V_CONSUMER_SKEW 1      // 0: the unskewed consumer loop (A/B builds)
+#endif
 // PSB: the gathered tensor holds SPLIT WORDS already -- (bf16 hi << 16) | bf16 lo of each value, written by the kernel that
 // produced it (ag2v_norm_apply_g(out_split), pack_split()); the producers then only regroup halves (2 v_perm per pair instead
 // of the 6-instruction split).  Same products, same sums: results are bit-identical to the fp32-input kernel's.
@@ -492,6 +495,59 @@ __device__ __forceinline__ void igemm_bf16x3_body(const ConvArgs& p) {
     unsigned long long sc[2] = {0, 0};
 #endif
     const int nk2 = kt0 + ((nk - kt0 + 1) & ~1);   // the producers run an even number of iterations
+    // SKEW (32x32x16 tiles): the last MFMAs of a K-tile -- row block 1 of its second k-step -- are issued AFTER the next barrier,
+    // from fragments read before it, right behind the first LDS reads of the next tile: all eight consumer waves leave the
+    // barrier together and used to wait ~450 of a K-tile's ~2 700 cycles for those reads with an idle MFMA pipe.  Every
+    // accumulator still receives its products in the same order (bit-identical results).  c3 step: 822.7 -> 816.6 ms (two builds,
+    // same box).  Requesting the second row block's fragments before the deferred MFMAs as well (128 VGPRs) was slower again.
+    constexpr bool SKEW = !MF16 && !F32 && (BK / 16 == 2) && EM == 2 && (AG2V_CONSUMER_SKEW != 0);
+    if constexpr (SKEW) {
+        auto ldB = [&](int buf, int ks, bf16x8 (&bh)[EN], bf16x8 (&bl)[EN]) {
+#pragma unroll
+            for (int j = 0; j < EN; ++j) {
+                const int pix = wn0 + j * ER + fr;
+                const int o = (B4 ? (pix & 3) * GR + (pix >> 2) : pix) * LDK + ks * 16 + 8 * fq;
+                bh[j] = *reinterpret_cast<const bf16x8*>(&Bhi[buf][o]);
+                bl[j] = *reinterpret_cast<const bf16x8*>(&Blo[buf][o]);
+            }
+        };
+        auto ldA = [&](int buf, int ks, int i, bf16x8& ah, bf16x8& al) {
+            const int o = (wm0 + i * ER + fr) * LDK + ks * 16 + 8 * fq;
+            ah = *reinterpret_cast<const bf16x8*>(&Ahi[buf][o]);
+            al = *reinterpret_cast<const bf16x8*>(&Alo[buf][o]);
+        };
+        auto mm = [&](int i, const bf16x8& ah, const bf16x8& al, const bf16x8 (&bh)[EN], const bf16x8 (&bl)[EN]) {
+#pragma unroll
+            for (int j = 0; j < EN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+            }
+        };
+        bf16x8 hbh[EN], hbl[EN], hah, hal;      // deferred: (row block 1, k-step 1) of the previous tile
+        bool have = false;
+        for (int kt = kt0; kt < nk2; ++kt) {
+            __syncthreads();   // tile kt is in LDS buffer (kt - kt0) & 1
+            if (kt < nk) {
+                const int buf = (kt - kt0) & 1;
+                bf16x8 bh0[EN], bl0[EN], a0h, a0l, a1h, a1l;
+                ldB(buf, 0, bh0, bl0);
+                ldA(buf, 0, 0, a0h, a0l);
+                __builtin_amdgcn_sched_barrier(0);
+                if (have) mm(1, hah, hal, hbh, hbl);          // previous tile's tail, while the reads above are in flight
+                __builtin_amdgcn_sched_barrier(0);
+                ldA(buf, 0, 1, a1h, a1l);
+                mm(0, a0h, a0l, bh0, bl0);
+                ldB(buf, 1, hbh, hbl);
+                ldA(buf, 1, 0, a0h, a0l);
+                mm(1, a1h, a1l, bh0, bl0);
+                ldA(buf, 1, 1, hah, hal);
+                mm(0, a0h, a0l, hbh, hbl);
+                have = true;
+            }
+        }
+        if (have) mm(1, hah, hal, hbh, hbl);
+    } else
     for (int kt = kt0; kt < nk2; ++kt) {
         STAMP(e0)
         __syncthreads();   // tile kt is in LDS buffer (kt - kt0) & 1

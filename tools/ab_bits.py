@@ -1,7 +1,12 @@
 """Checksum of bf16x3 convolution results (forward, data gradient, weight gradient) on seeded inputs: run under two builds
 (AG2V_LIB_PATH=...) to see whether a kernel change is bit-neutral.  Inputs include denormals and huge values."""
 import hashlib
+import os
+import sys
+
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ag2video_amd import ops
 
 torch.manual_seed(0)
