@@ -499,7 +499,8 @@ __device__ __forceinline__ void igemm_bf16x3_body(const ConvArgs& p) {
     // from fragments read before it, right behind the first LDS reads of the next tile: all eight consumer waves leave the
     // barrier together and used to wait ~450 of a K-tile's ~2 700 cycles for those reads with an idle MFMA pipe.  Every
     // accumulator still receives its products in the same order (bit-identical results).  c3 step: 822.7 -> 816.6 ms (two builds,
-    // same box).  Requesting the second row block's fragments before the deferred MFMAs as well (128 VGPRs) was slower again.
+    // same box).  Requesting the second row block's fragments before the deferred MFMAs as well (128 VGPRs) was slower again, and
+    // the fp32 form (64 MFMAs per K-tile) gains nothing from a deferred quarter.
     constexpr bool SKEW = !MF16 && !F32 && (BK / 16 == 2) && EM == 2 && (AG2V_CONSUMER_SKEW != 0);
     if constexpr (SKEW) {
         auto ldB = [&](int buf, int ks, bf16x8 (&bh)[EN], bf16x8 (&bl)[EN]) {
@@ -887,6 +888,54 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_ws_k
         }
     };
     __syncthreads();
+    // the consumer skew of igemm_bf16x3_body: (row block 1, k-step 1) of a K-tile runs behind the next barrier
+    constexpr bool SKEW = (BK / 16 == 2) && TM == 2 && (AG2V_CONSUMER_SKEW != 0);
+    if constexpr (SKEW) {
+        auto ldB = [&](int buf, int ks, bf16x8 (&bh)[TN], bf16x8 (&bl)[TN]) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int o = (wn0 + j * 32 + fr) * LDK + ks * 16 + 8 * fh;
+                bh[j] = *reinterpret_cast<const bf16x8*>(&Bhi[buf][o]);
+                bl[j] = *reinterpret_cast<const bf16x8*>(&Blo[buf][o]);
+            }
+        };
+        auto ldA = [&](int buf, int ks, int i, bf16x8& ah, bf16x8& al) {
+            const int o = (wm0 + i * 32 + fr) * LDK + ks * 16 + 8 * fh;
+            ah = *reinterpret_cast<const bf16x8*>(&Ahi[buf][o]);
+            al = *reinterpret_cast<const bf16x8*>(&Alo[buf][o]);
+        };
+        auto mm = [&](int i, const bf16x8& ah, const bf16x8& al, const bf16x8 (&bh)[TN], const bf16x8 (&bl)[TN]) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+            }
+        };
+        bf16x8 hbh[TN], hbl[TN], hah, hal;
+        bool have = false;
+        for (int t = 0; t < ((nt + 1) & ~1); ++t) {
+            __syncthreads();   // tile t is in LDS buffer t & 1
+            if (t < nt) {
+                const int buf = t & 1;
+                bf16x8 bh0[TN], bl0[TN], a0h, a0l, a1h, a1l;
+                ldB(buf, 0, bh0, bl0);
+                ldA(buf, 0, 0, a0h, a0l);
+                __builtin_amdgcn_sched_barrier(0);
+                if (have) mm(1, hah, hal, hbh, hbl);
+                __builtin_amdgcn_sched_barrier(0);
+                ldA(buf, 0, 1, a1h, a1l);
+                mm(0, a0h, a0l, bh0, bl0);
+                ldB(buf, 1, hbh, hbl);
+                ldA(buf, 1, 0, a0h, a0l);
+                mm(1, a1h, a1l, bh0, bl0);
+                ldA(buf, 1, 1, hah, hal);
+                mm(0, a0h, a0l, hbh, hbl);
+                have = true;
+            }
+        }
+        if (have) mm(1, hah, hal, hbh, hbl);
+    } else
     for (int t = 0; t < ((nt + 1) & ~1); ++t) {   // the producers run an even number of iterations
         __syncthreads();   // tile t is in LDS buffer t & 1
         if (t < nt) compute(t & 1);
