@@ -25,9 +25,10 @@ def decode_actions(actions, timesteps, pad_action):
 
 def action_edge_vectors(acts_embeddings, a, x_end_t, y_end_t, r_t):
     """Action embeddings whose last three columns are overwritten by (x_end, y_end, relative time) (model.py:143-146);
-    written as a concatenation so the three columns of the table receive no gradient, as with the in-place write."""
+    written as a concatenation so the three columns of the table receive no gradient, as with the in-place write.
+    Any leading dimensions ([B, A] for one time step, [B, F, A] for all of them)."""
     av = acts_embeddings(a.long())
-    return torch.cat([av[:, :, :-3], x_end_t.unsqueeze(-1), y_end_t.unsqueeze(-1), r_t.unsqueeze(-1)], dim=-1)
+    return torch.cat([av[..., :-3], x_end_t.unsqueeze(-1), y_end_t.unsqueeze(-1), r_t.unsqueeze(-1)], dim=-1)
 
 
 class Acts2LayoutModel(nn.Module):
@@ -73,22 +74,27 @@ class Acts2LayoutModel(nn.Module):
         emb = self.attribute_embedding(objs)
         tvecs = [torch.zeros(objs.size(0), objs.size(1), self.args["embedding_dim"], device=emb.device, dtype=emb.dtype)]
         only_temporal = self.args.get("only_temporal", False)
+        # Everything of a time step that does not depend on the recurrence (the boxes) -- edge lists, validity masks, predicate /
+        # action embeddings with their (x_end, y_end, t) columns -- is built for ALL steps at once, frame-major, so that the loop
+        # below only slices: ~10 small launches per step, net and pass become ~10 per net and pass.
+        s, a, o = temporal_triplets[..., 0], temporal_triplets[..., 1], temporal_triplets[..., 2]          # [B, F, A]
+        a_edges = torch.stack([s, o], dim=-1)
+        a_ind = a != vocab["action_name_to_idx"]["__padding__"]
+        av = action_edge_vectors(self.acts_embeddings, a, x_end, y_end, rel)                                 # [B, F, A, D]
+        if not only_temporal:
+            ss, p, so = triplets[..., 0], triplets[..., 1], triplets[..., 2]                                 # [B, F, T]
+            ind_all = torch.cat([p != vocab["pred_name_to_idx"]["__padding__"], a_ind], dim=2)
+            edges_all = torch.cat([torch.stack([ss, so], dim=-1), a_edges.long()], dim=2)
+            pv_all = torch.cat([self.pred_embeddings(p), av], dim=2)
+        else:
+            ind_all, edges_all, pv_all = a_ind, a_edges, av
+        ind_all = ind_all.transpose(0, 1).contiguous()            # [F, B, ...]: a step is a contiguous slice
+        edges_all = edges_all.transpose(0, 1).contiguous()
+        pv_steps = pv_all.transpose(0, 1).contiguous().unbind(0)        # (unbind: ONE stacked gradient in the backward pass)
         for t in range(1, timesteps):
-            at = temporal_triplets[:, t]
             boxes_c = boxes_pred[-1]
             ov = self.obj_vecs_net(torch.cat([emb, boxes_c], dim=-1))
-            s, a, o = at[..., 0], at[..., 1], at[..., 2]
-            a_edges = torch.stack([s, o], dim=-1)
-            a_ind = a != vocab["action_name_to_idx"]["__padding__"]
-            av = action_edge_vectors(self.acts_embeddings, a, x_end[:, t], y_end[:, t], rel[:, t])
-            if not only_temporal:
-                sp = triplets[:, t]
-                ss, p, so = sp[..., 0], sp[..., 1], sp[..., 2]
-                ind = torch.cat([p != vocab["pred_name_to_idx"]["__padding__"], a_ind], dim=1)
-                edges = torch.cat([torch.stack([ss, so], dim=-1), a_edges.long()], dim=1)
-                pred_vecs = torch.cat([self.pred_embeddings(p), av], dim=1)
-            else:
-                ind, edges, pred_vecs = a_ind, a_edges, av
+            ind, edges, pred_vecs = ind_all[t], edges_all[t], pv_steps[t]
             for gconv in self.gconvs:
                 ov, pred_vecs = gconv(ov, pred_vecs, edges, ind)
             tvecs.append(ov)

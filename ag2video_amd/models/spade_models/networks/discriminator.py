@@ -126,13 +126,15 @@ class MultiscaleActionDiscriminator(nn.Module):
         pad = self.opt.vocab["action_name_to_idx"]["__padding__"]
         ov = self.pre_obj_vecs_net(self.attribute_embedding(objs))
         out = []
+        # edge lists, masks and action-edge vectors of ALL time steps at once, frame-major (the recurrence only carries ov)
+        s, a, o = temporal_triplets[..., 0], temporal_triplets[..., 1], temporal_triplets[..., 2]           # [B, T, A]
+        edges_all = torch.stack([s, o], dim=-1).long().transpose(0, 1).contiguous()
+        ind_all = (a != pad).transpose(0, 1).contiguous()
+        pv_steps = action_edge_vectors(self.acts_embeddings, a, x_end, y_end, rel).transpose(0, 1).contiguous().unbind(0)
+        boxes_steps = layout_boxes.transpose(0, 1).contiguous()
         for t in range(layout_boxes.size(1)):
-            at = temporal_triplets[:, t]
-            ov = self.obj_vecs_net(torch.cat([ov, layout_boxes[:, t]], dim=-1))
-            s, a, o = at[..., 0], at[..., 1], at[..., 2]
-            edges = torch.stack([s, o], dim=-1).long()
-            ind = a != pad
-            pv = action_edge_vectors(self.acts_embeddings, a, x_end[:, t], y_end[:, t], rel[:, t])
+            ov = self.obj_vecs_net(torch.cat([ov, boxes_steps[t]], dim=-1))
+            edges, ind, pv = edges_all[t], ind_all[t], pv_steps[t]
             for gconv in self.gconvs:
                 ov, pv = gconv(ov, pv, edges, ind)
             out.append(ov)
