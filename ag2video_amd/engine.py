@@ -17,7 +17,9 @@ from .models.utils import batch_to
 
 
 class TrainStep(object):
-    def __init__(self, opt, device, weights_seed=None):
+    def __init__(self, opt, device, weights_seed=None, adam_cls=None):
+        """adam_cls: optimizer class override (tests only: a flat-buffer Adam whose step runs on the CPU, so that the gloo test drives
+        the same two-phase gradient all-reduce as the GPU path); default FusedAdam on the HIP device."""
         self.opt = opt
         self.device = device
         dist_utils.set_sync_bn(getattr(opt, 'sync_bn', 0))
@@ -39,7 +41,9 @@ class TrainStep(object):
         gen_params = [p for p in self.model.parameters() if id(p) not in graph_ids]   # train.py:367
         # Adam as in train.py:365-368 / meta_models.py:70-72; on the GPU the fused flat-buffer implementation (one kernel
         # per step).  (torch.optim.Adam is only used when the modules live on the CPU, i.e. in the host-logic tests.)
-        if torch.device(device).type == 'cuda':
+        if adam_cls is not None:
+            Adam = adam_cls
+        elif torch.device(device).type == 'cuda':
             from .optim import FusedAdam as Adam
         else:
             Adam = torch.optim.Adam
@@ -49,6 +53,9 @@ class TrainStep(object):
         self.discriminator.optimizer_d_img = Adam(list(self.discriminator.img_discriminator.parameters()),
                                                   lr=lr, betas=(b1, 0.999))
         self._gen_params, self._graph_params = gen_params, graph_params
+        # bench.py (N > 1): HIP event pairs around the join of the generator's asynchronous all-reduce (= the time the compute stream
+        # stalls for it: the EXPOSED part) and around the discriminator's synchronous one; None = not recorded
+        self.comm_events = None
         self._d_params = list(self.discriminator.img_discriminator.parameters())
         for m in (self.model, self.discriminator):
             m.train()
@@ -106,11 +113,20 @@ class TrainStep(object):
         D_losses["total_img_loss"].backward()
         if self.side_stream is not None:      # the layout terms' backward ran there; their gradients are written by the ops themselves
             torch.cuda.current_stream().wait_stream(self.side_stream)
+        rec = self.comm_events is not None and dist_utils.is_dist() and torch.device(self.device).type == 'cuda'
         if deferred:
+            if rec:
+                e0 = torch.cuda.current_stream().record_event(torch.cuda.Event(enable_timing=True))
             pending.finish()
+            if rec:
+                self.comm_events.append(('g_join', e0, torch.cuda.current_stream().record_event(torch.cuda.Event(enable_timing=True))))
             if apply_updates:
                 self.optimizer_generator.step()
+        if rec:
+            e0 = torch.cuda.current_stream().record_event(torch.cuda.Event(enable_timing=True))
         dist_utils.average_gradients(self._d_params, flat=getattr(self.discriminator.optimizer_d_img, 'flat_grad', None))
+        if rec:
+            self.comm_events.append(('d_sync', e0, torch.cuda.current_stream().record_event(torch.cuda.Event(enable_timing=True))))
         if apply_updates:
             self.discriminator.optimizer_d_img.step()
         return model_out, G_losses, D_losses

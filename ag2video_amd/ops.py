@@ -1096,7 +1096,11 @@ class _SpadePair(torch.autograd.Function):
         dgb0, dgb1 = torch.empty_like(gb0), torch.empty_like(gb1)
         sums = torch.empty((G, C, 8), device=xs.device, dtype=torch.float32)
         ws = torch.empty(_lib.query('ag2v_spade_pair_workspace_floats', N, C, H * W), device=xs.device, dtype=torch.float32)
-        _launch('ag2v_spade_pair_bwd_s', 'spade_pair_bwd', (2.0 * xs.numel() + xs.numel() + 16.0 * dy0.numel()) * 4, _ptr(dy0), _ptr(y0), _ptr(dy1),
+        # algorithmic bytes: reduce pass reads dy0, dy1, gamma0, gamma1 and x (input size) plus y_i only where slope_i != 1 (the
+        # kernels skip the LeakyReLU sign otherwise: norm.hip `if (slope != 1.f)`); the apply pass reads the same and writes
+        # dgamma / dbeta of both norms and dx at input size: (12 + 2 ny) output-sized passes + 3 input-sized ones (PMC: profiles/r02/pmc)
+        ny = (1 if slope0 != 1.0 else 0) + (1 if slope1 != 1.0 else 0)
+        _launch('ag2v_spade_pair_bwd_s', 'spade_pair_bwd', (3.0 * xs.numel() + (12.0 + 2.0 * ny) * dy0.numel()) * 4, _ptr(dy0), _ptr(y0), _ptr(dy1),
                 _ptr(y1), _ptr(xs), _ptr(gb0), _ptr(gb1), _ptr(mean), _ptr(invstd), _ptr(dxs), _ptr(dgb0), _ptr(dgb1), _ptr(sums), N, C, H, W,
                 up, Ng, float(slope0), float(slope1), _ptr(ws), 1 if ctx.dgb_split else 0, _stream(), shape=(N, C, H * W, up))
         tot = sums.sum(dim=0) if G > 1 else sums[0]

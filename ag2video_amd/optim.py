@@ -21,8 +21,8 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         ps = self.param_groups[0]['params']
         dev = ps[0].device
-        if dev.type != 'cuda':
-            raise RuntimeError("FusedAdam runs on the HIP device only (no CPU fallback); got %s" % dev)
+        # (the flat layout itself is device-agnostic -- tests/test_distributed_cpu.py drives engine.gd_step's two-phase all-reduce over
+        # it under gloo with a test-only subclass that overrides step(); the update below exists as a HIP kernel only)
         self._sizes = [p.numel() for p in ps]
         # every parameter starts on a 16-byte boundary (kernels read weights with 16-byte loads: the graph nets' GEMM, the weight
         # packing); the <= 3 padding elements between parameters stay 0 in all four buffers (Adam maps 0, 0, 0, 0 to 0)
@@ -63,6 +63,8 @@ class FusedAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
+        if self.flat_param.device.type != 'cuda':
+            raise RuntimeError("FusedAdam.step runs on the HIP device only (no CPU fallback); got %s" % self.flat_param.device)
         loss = closure() if closure is not None else None
         self._adopt_grads()
         g = self.param_groups[0]

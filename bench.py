@@ -304,7 +304,8 @@ def main():
         roof_hbm = hbm_roofline('spade_pair_apply', 'spade_pair_apply_kernel<2> (two SPADE modulations of one input read before its 2x upsampling)',
                                 'x at a quarter of the output size + 2 x (gamma, beta) read, 2 outputs written = 6.25 output-sized passes')
         roof_hbm_bwd = hbm_roofline('spade_pair_bwd', 'spade_pair_bwd_reduce_kernel<2> + spade_pair_bwd_apply_kernel<2>',
-                                    'reduce: 2 x (dy, y | gamma) + x; apply: the same + 2 x (dgamma, dbeta) + dx at input size = 16.75 output-sized passes')
+                                    'reduce: dy0, dy1, gamma0, gamma1, x (input size) + y_i where slope_i != 1; apply: the same + 2 x (dgamma, dbeta) + dx at '
+                                    'input size = 12 + 2 * (#norms with a LeakyReLU) output-sized passes + 0.75 (decoder blocks: 14.75)')
         if roof_hbm is not None:
             roof_hbm['single_spade'] = roof_hbm_single
         if roof_hbm_bwd is not None:

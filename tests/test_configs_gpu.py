@@ -27,91 +27,187 @@ def _rand(*shape, seed=0, device='cpu', scale=1.0):
     return (torch.randn(*shape, generator=g) * scale).to(device)
 
 
-@pytest.mark.parametrize("prec", ['bf16x3', 'fp32'])
-def test_step_c1_default_widths_matches_oracle(prec, device):
+# ---- GPU step against the CPU oracle at default widths.  name: (image side, frames, batch).  c1 is BASELINE.json's configs[0];
+# c2p / c3p are the resolutions of c2 / c3 at the smallest clip that keeps their structure (batch 1; 3 / 4 frames: two / three
+# generated frames, i.e. T > 1 frame groups): the 128^2 / 256^2 layer stack -- up_2 / up_3, the full-resolution flow network and
+# warp, the discriminators at 129^2 / 65^2, the 6-level segmentation pyramid -- compared with the oracle AS A STACK (VERDICT r02
+# weak #1).  The oracle side of c3p is bench.py's c3' cpu_baseline leg (~16 s on the GPU box's host cores).
+STEP_CASES = {'c1': (64, 4, 1), 'c2p': (128, 3, 1), 'c3p': (256, 4, 1)}
+_ORACLE_CACHE = {}
+
+
+def _case_opt(case):
     import bench
+    side, frames, batch = STEP_CASES[case]
+    opt, _, _, _ = bench.make_opt('c1')
+    opt.image_size = (side, side)
+    opt.batch_size = batch
+    opt.gpu_ids = [0]
+    return opt, side, frames, batch
+
+
+def _oracle_step(case, shapes_G, shapes_D):
+    """One oracle iteration (G step, D step, graph step) of a case, computed once per session and kept as what the checks need:
+    outputs, losses, per-parameter gradient statistics, post-step state statistics + buffers."""
+    if case in _ORACLE_CACHE:
+        return _ORACLE_CACHE[case]
+    from ag2video_amd.data.synthetic import make_clip_batch
+    from oracle.step import OracleTrainer
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    opt, side, frames, batch = _case_opt(case)
+    orc = OracleTrainer(opt, shapes_G, shapes_D, 1)
+    clip = make_clip_batch(opt.vocab, batch, frames, (side, side), seed=1234)
+    mo_r, GL_r, DL_r = orc.gd_step(clip)
+    res = {'out': [mo_r[i].detach().clone() for i in range(4)],
+           'GL': {k: float(v) for k, v in GL_r.items()}, 'DL': {k: float(v) for k, v in DL_r.items()},
+           'G_grads': {n: (None if g is None else _stats(g)) for n, g in orc.last_G_grads.items()},
+           'D_grads': {n: (None if g is None else _stats(g)) for n, g in orc.last_D_grads.items()}}
+    gclip = make_clip_batch(opt.vocab, batch, 4 * frames, (side, side), seed=4321)
+    bp_r, GG_r = orc.graph_step(gclip)
+    res['bp'] = bp_r.detach().clone()
+    res['GG'] = {k: float(v) for k, v in GG_r.items()}
+    state = {}
+    for tag, sd in (('G', orc.G), ('D', orc.D)):
+        for k, v in sd.items():
+            r = v.detach()
+            buf = (not v.requires_grad) and r.is_floating_point()
+            state[(tag, k)] = (_stats(r.float()), r.numel(), r.clone() if buf else None)
+    res['state'] = state
+    del orc
+    _ORACLE_CACHE[case] = res
+    return res
+
+
+def _step_vs_oracle(case, prec, device):
     from ag2video_amd import ops
     from ag2video_amd.data.synthetic import make_clip_batch
     from ag2video_amd.engine import TrainStep
-    from oracle.step import OracleTrainer
-    torch.set_num_threads(min(16, torch.get_num_threads()))
     old = ops.get_conv_precision()
     ops.set_conv_precision(prec)
     try:
-        opt, side, frames, batch = bench.make_opt('c1')
+        opt, side, frames, batch = _case_opt(case)
         assert (opt.ngf, opt.ndf, opt.nff, opt.gconv_hidden_dim) == (64, 64, 32, 512)
-        opt.gpu_ids = [0]
         ts = TrainStep(opt, device, weights_seed=1)
         shapes_G = {k: list(v.shape) for k, v in ts.model.state_dict().items()}
         shapes_D = {k: list(v.shape) for k, v in ts.discriminator.img_discriminator.state_dict().items()}
-        orc = OracleTrainer(opt, shapes_G, shapes_D, 1)
+        ref = _oracle_step(case, shapes_G, shapes_D)
         clip = make_clip_batch(opt.vocab, batch, frames, (side, side), seed=1234)
-        mo_r, GL_r, DL_r = orc.gd_step(clip)
         mo, GL, DL = ts.gd_step(ts.to_device(clip))
-        for got, ref in ((GL, GL_r), (DL, DL_r)):
-            assert set(got) == set(ref)
-            for k in ref:
-                assert abs(got[k].item() - ref[k].item()) <= 1e-3 * max(1.0, abs(ref[k].item())), (k, got[k].item(), ref[k].item())
+        for got, rf in ((GL, ref['GL']), (DL, ref['DL'])):
+            assert set(got) == set(rf)
+            for k in rf:
+                assert abs(got[k].item() - rf[k]) <= 1e-3 * max(1.0, abs(rf[k])), (k, got[k].item(), rf[k])
         worst = {}
         for i, name in enumerate(('imgs_pred', 'boxes_pred', 'flows_pred')):
-            ref = mo_r[i].detach().numpy()
-            err = np.abs(mo[i].detach().cpu().numpy() - ref).max()
-            worst[name] = err / np.abs(ref).max()
-            assert err <= 1e-3 * np.abs(ref).max(), (name, err, np.abs(ref).max())
-        assert np.mean(mo[3].cpu().numpy() != mo_r[3].numpy()) < 2e-3
+            r = ref['out'][i].numpy()
+            err = np.abs(mo[i].detach().cpu().numpy() - r).max()
+            worst[name] = err / np.abs(r).max()
+            assert err <= 1e-3 * np.abs(r).max(), (name, err, np.abs(r).max())
+        assert np.mean(mo[3].cpu().numpy() != ref['out'][3].numpy()) < 2e-3
         # gradients: abs-sum of every parameter's gradient (bounds: module docstring of tests/test_step_gpu.py)
         bad = []
         for n, prm in ts.model.named_parameters():
-            g_ref = orc.last_G_grads.get(n)
+            g_ref = ref['G_grads'].get(n)
             if g_ref is None:
                 assert prm.grad is None or float(prm.grad.abs().sum()) == 0.0 or n.startswith('acts_to_boxes'), n
                 continue
             assert prm.grad is not None, n
-            got, ref = _stats(prm.grad), _stats(g_ref)
+            got = _stats(prm.grad)
             rel = 5e-2 if ('flows_network' in n or n.startswith('acts_to_objs')) else 2e-2
-            if abs(got[1] - ref[1]) > rel * abs(ref[1]) + 2e-6 * prm.numel():
-                bad.append((n, got[1], ref[1]))
+            if abs(got[1] - g_ref[1]) > rel * abs(g_ref[1]) + 2e-6 * prm.numel():
+                bad.append((n, got[1], g_ref[1]))
         assert not bad, (len(bad), bad[:10])
         badd = []
         for n, prm in ts.discriminator.img_discriminator.named_parameters():
-            g_ref = orc.last_D_grads.get(n)
+            g_ref = ref['D_grads'].get(n)
             if g_ref is None or prm.grad is None:
                 continue
-            got, ref = _stats(prm.grad), _stats(g_ref)
-            if abs(got[1] - ref[1]) > 2e-2 * abs(ref[1]) + 2e-6 * prm.numel():
-                badd.append((n, got[1], ref[1]))
+            got = _stats(prm.grad)
+            if abs(got[1] - g_ref[1]) > 2e-2 * abs(g_ref[1]) + 2e-6 * prm.numel():
+                badd.append((n, got[1], g_ref[1]))
         assert not badd, (len(badd), badd[:10])
         # graph step on a 4x longer clip (train.py:471-493)
         gclip = make_clip_batch(opt.vocab, batch, 4 * frames, (side, side), seed=4321)
-        bp_r, GG_r = orc.graph_step(gclip)
         bp, GG = ts.graph_step(ts.to_device(gclip))
-        for k in GG_r:
-            assert abs(GG[k].item() - GG_r[k].item()) <= 1e-3 * max(1.0, abs(GG_r[k].item())), (k, GG[k].item(), GG_r[k].item())
-        assert np.abs(bp.detach().cpu().numpy() - bp_r.detach().numpy()).max() <= 1e-3 * np.abs(bp_r.detach().numpy()).max()
+        for k, v in ref['GG'].items():
+            assert abs(GG[k].item() - v) <= 1e-3 * max(1.0, abs(v)), (k, GG[k].item(), v)
+        bp_r = ref['bp'].numpy()
+        assert np.abs(bp.detach().cpu().numpy() - bp_r).max() <= 1e-3 * np.abs(bp_r).max()
         # every state tensor after the three optimizer steps: buffers (spectral-norm u / v, running statistics) element-wise at
         # 1e-3 of their max; parameters through (abs-sum, L2) at 1e-3 + Adam's first-step floor lr per element (a parameter whose
         # true gradient is zero moves by +-lr in a rounding-determined direction)
         floor = 1.2 * opt.learning_rate
         bad_state, n_keys = [], 0
-        for sd, ref_sd in ((ts.model.state_dict(), orc.G), (ts.discriminator.img_discriminator.state_dict(), orc.D)):
-            assert set(sd) == set(ref_sd)
+        for tag, sd in (('G', ts.model.state_dict()), ('D', ts.discriminator.img_discriminator.state_dict())):
+            assert set(sd) == set(k for (t, k) in ref['state'] if t == tag)
             for k, v in sd.items():
-                r = ref_sd[k].detach()
+                rstat, n, rbuf = ref['state'][(tag, k)]
                 n_keys += 1
-                if not ref_sd[k].requires_grad and r.is_floating_point():
-                    err = (v.detach().cpu() - r).abs().max().item()
-                    if err > 1e-3 * max(r.abs().max().item(), 1e-6):
-                        bad_state.append((k, 'buffer', err, r.abs().max().item()))
-                got, ref = _stats(v.float()), _stats(r.float())
-                n = v.numel()
+                if rbuf is not None:
+                    err = (v.detach().cpu() - rbuf).abs().max().item()
+                    if err > 1e-3 * max(rbuf.abs().max().item(), 1e-6):
+                        bad_state.append((k, 'buffer', err, rbuf.abs().max().item()))
+                got = _stats(v.float())
                 for i, fl in ((1, floor * n), (2, floor * n ** 0.5)):
-                    if abs(got[i] - ref[i]) > 1e-3 * abs(ref[i]) + fl:
-                        bad_state.append((k, i, got[i], ref[i]))
+                    if abs(got[i] - rstat[i]) > 1e-3 * abs(rstat[i]) + fl:
+                        bad_state.append((k, i, got[i], rstat[i]))
         assert n_keys == 492 + 56
         assert not bad_state, (len(bad_state), bad_state[:10])
-        print('c1 default widths [%s]: worst output errors relative to max:' % prec, worst)
+        print('%s default widths [%s]: worst output errors relative to max:' % (case, prec), worst)
+        return worst
     finally:
         ops.set_conv_precision(old)
+
+
+@pytest.mark.parametrize("prec", ['bf16x3', 'fp32'])
+def test_step_c1_default_widths_matches_oracle(prec, device):
+    _step_vs_oracle('c1', prec, device)
+
+
+@pytest.mark.parametrize("prec", ['bf16x3', 'fp32'])
+def test_step_c2prime_default_widths_matches_oracle(prec, device):
+    """128 x 128 (c2's resolution), 3 frames, batch 1, default widths: full iteration against the oracle."""
+    _step_vs_oracle('c2p', prec, device)
+
+
+@pytest.mark.parametrize("prec", ['bf16x3', 'fp32'])
+def test_step_c3prime_default_widths_matches_oracle(prec, device):
+    """256 x 256 (the benchmarked resolution), 4 frames, batch 1, default widths: full iteration against the oracle -- losses and
+    outputs <= 1e-3, gradient statistics, all 548 post-step state keys."""
+    _step_vs_oracle('c3p', prec, device)
+
+
+def test_c3prime_flow_forward_margin(device):
+    """How much of the 1e-3 output bound the exact-fp32 flow-network forward buys at 256 x 256 (DESIGN 9.2 measured it at 64 x 64):
+    imgs_pred against the oracle with the flow network's forward (a) exact -- the product's policy, must hold 1e-3 -- and (b) on the
+    bf16x3 tiles (AG2V_FLOW_SPLIT_PARTS diagnostic switch).  (b) is reported, and asserted only to stay a small error (< 1e-2):
+    it documents the margin, it is not a product path."""
+    import os
+    from ag2video_amd import ops
+    from ag2video_amd.data.synthetic import make_clip_batch
+    from ag2video_amd.engine import TrainStep
+    opt, side, frames, batch = _case_opt('c3p')
+    errs = {}
+    for label, parts in (('exact', ''), ('split', 'res,up')):
+        os.environ['AG2V_FLOW_SPLIT_PARTS'] = parts
+        try:
+            with ops.conv_precision('bf16x3'):
+                ts = TrainStep(opt, device, weights_seed=1)
+                shapes_G = {k: list(v.shape) for k, v in ts.model.state_dict().items()}
+                shapes_D = {k: list(v.shape) for k, v in ts.discriminator.img_discriminator.state_dict().items()}
+                ref = _oracle_step('c3p', shapes_G, shapes_D)
+                clip = ts.to_device(make_clip_batch(opt.vocab, batch, frames, (side, side), seed=1234))
+                with torch.no_grad():
+                    mo = ts.model(clip[0], clip[1], clip[3], clip[4], boxes_gt=clip[2], test_mode=False, use_gt=True)
+            for i, name in ((0, 'imgs_pred'), (2, 'flows_pred')):
+                r = ref['out'][i].numpy()
+                errs[(label, name)] = float(np.abs(mo[i].detach().cpu().numpy() - r).max() / np.abs(r).max())
+            del ts
+        finally:
+            os.environ.pop('AG2V_FLOW_SPLIT_PARTS', None)
+    print('c3p flow-forward margin (error / max|ref|):', errs)
+    assert errs[('exact', 'imgs_pred')] <= 1e-3, errs
+    assert errs[('split', 'imgs_pred')] <= 1e-2, errs
 
 
 # ---------------------------------------------------------------------------------------------------- c2 / c5 layer sizes
