@@ -106,6 +106,7 @@ def build_parser():
     a('--train_list', default=None, type=str)
     a('--data_nframes', default=301, type=int, help='frames per video in --data_root')
     a('--vgg_weights', default=None, type=str, help='torchvision vgg19 state dict (.pth) for the perceptual loss')
+    a('--vgg_random_init', action='store_true', help='explicit opt-in: run the perceptual loss on a RANDOMLY initialised VGG19 (throughput / parity runs; not a training objective)')
     return p
 
 

@@ -10,6 +10,7 @@ import os
 import torch
 
 from . import distributed as dist_utils
+from . import ops
 from .models.meta_models import AG2VideoModel, MetaDiscriminatorModel
 from .models.spade_models.loss_model import LossModel
 from .models.spade_models.networks.sync_batchnorm import DataParallelWithCallback
@@ -33,7 +34,8 @@ class TrainStep(object):
             from .weights import closed_form_fill_
             closed_form_fill_(self.model, seed=weights_seed, prefix='G.')
             closed_form_fill_(self.discriminator.img_discriminator, seed=weights_seed, prefix='D.')
-            if hasattr(self.gans_model.module, 'criterionVGG'):
+            # (weights loaded through --vgg_weights are the objective: the closed-form filler only replaces a random init)
+            if hasattr(self.gans_model.module, 'criterionVGG') and not getattr(self.gans_model.module, 'vgg_weights_loaded', False):
                 closed_form_fill_(self.gans_model.module.criterionVGG, seed=weights_seed, prefix='V.')
         lr, b1 = opt.learning_rate, opt.beta1
         graph_params = list(self.model.acts_to_boxes.parameters())
@@ -98,7 +100,8 @@ class TrainStep(object):
                     print("Error: video_id {} is NAN!".format(video_id))
                 return model_out, G_losses, None
         self.optimizer_generator.zero_grad()
-        G_losses["total_loss"].backward()
+        with ops.accumulate_into_param_grads():
+            G_losses["total_loss"].backward()
         # One process per GPU: the generator's 500 MB gradient all-reduce is launched here and joined after the discriminator's
         # loss + backward (which read neither these gradients nor the generator's parameters: imgs_pred is detached), then
         # Adam(G) runs -- the same updates as the reference order (G step, then D loss), with the ring traffic behind ~150 ms of
@@ -110,7 +113,8 @@ class TrainStep(object):
         D_losses = self.gans_model(batch, model_out, mode="compute_discriminator_loss")
         D_losses = {k: v.mean() for k, v in D_losses.items()}
         self.discriminator.optimizer_d_img.zero_grad()
-        D_losses["total_img_loss"].backward()
+        with ops.accumulate_into_param_grads():
+            D_losses["total_img_loss"].backward()
         if self.side_stream is not None:      # the layout terms' backward ran there; their gradients are written by the ops themselves
             torch.cuda.current_stream().wait_stream(self.side_stream)
         rec = self.comm_events is not None and dist_utils.is_dist() and torch.device(self.device).type == 'cuda'
@@ -138,7 +142,8 @@ class TrainStep(object):
         L = self.gans_model(batch, boxes_pred, mode="compute_graph_loss")
         L = {k: v.mean() for k, v in L.items()}
         self.optimizer_graph.zero_grad()
-        L["total_loss"].backward()
+        with ops.accumulate_into_param_grads():
+            L["total_loss"].backward()
         dist_utils.average_gradients(self._graph_params, flat=getattr(self.optimizer_graph, 'flat_grad', None))
         if apply_updates:
             self.optimizer_graph.step()

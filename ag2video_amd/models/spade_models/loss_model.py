@@ -39,8 +39,15 @@ class LossModel(torch.nn.Module):
             # loss_model.py:35-36.  The reference downloads ImageNet weights through torchvision; there is no network here: the
             # weights are PyTorch's default init until the caller loads some (--vgg_weights: a torchvision vgg19 state dict file;
             # engine.TrainStep(weights_seed=...) fills them closed-form like every other parameter).
-            self.criterionVGG = VGGLoss(opt.gpu_ids)
             path = getattr(opt, 'vgg_weights', None)
+            if not path and not getattr(opt, 'vgg_random_init', False):
+                # the reference's default objective includes lambda_vgg * VGG on ImageNet features; without those weights the term is
+                # noise with weight 10 in total_loss -- never silently
+                raise RuntimeError("perceptual loss: no ImageNet VGG19 weights (the reference downloads them; no network here). Pass "
+                                   "--vgg_weights <torchvision vgg19 state dict>, or --no_vgg_loss, or opt in to a randomly "
+                                   "initialised VGG19 with --vgg_random_init (throughput / parity runs only)")
+            self.criterionVGG = VGGLoss(opt.gpu_ids)
+            self.vgg_weights_loaded = bool(path)
             if path:
                 sd = torch.load(path, map_location='cpu')
                 self.criterionVGG.vgg.load_torchvision_features({k[len('features.'):]: v for k, v in sd.items() if k.startswith('features.')})

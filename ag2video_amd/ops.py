@@ -262,9 +262,22 @@ def _wsink_register(w):
     return id(w)
 
 
+_DIRECT_STREAMS = []  # HIP streams on which launches of the current backward pass wrote straight into a leaf's .grad
+
+
 def _wsink_clear():
+    """End-of-pass callback (runs on the thread that called backward, after the last node).  Direct .grad writes are invisible to
+    autograd's own leaf-stream synchronisation, so the caller's stream is made to wait here for every other stream that performed
+    one (nodes run on the stream of their forward: the side-stream graph nets) -- an optimizer step or all-reduce issued after
+    backward() then sees complete gradients without the caller having to know which streams were involved."""
     _WSINK.clear()
     _WSINK_CB[0] = None
+    if _DIRECT_STREAMS:
+        cur = torch.cuda.current_stream()
+        for s_ in _DIRECT_STREAMS:
+            if s_ != cur:
+                cur.wait_stream(s_)
+        del _DIRECT_STREAMS[:]
 
 
 def _wsink_begin(task):
@@ -280,6 +293,23 @@ def _wsink_begin(task):
 
 _DIRECT_GRAD = os.environ.get('AG2V_NO_DIRECT_GRAD') is None
 _USE_CHANNEL_SUMS = os.environ.get('AG2V_NO_CHANNEL_SUMS') is None
+_DIRECT_DEPTH = [0]
+
+
+class accumulate_into_param_grads(object):
+    """Context manager around a ``loss.backward()`` that ACCUMULATES into the parameters' .grad (the training step): inside it the
+    weight / bias gradient launches of leaf parameters whose .grad is preallocated (the flat-buffer optimizers) add straight into
+    .grad and hand autograd nothing.  Outside it -- torch.autograd.grad(...), backward(inputs=...), any caller that has not said so --
+    every gradient is returned to autograd, which delivers it the usual way (the direct path returned None to
+    autograd.grad and still wrote .grad)."""
+
+    def __enter__(self):
+        _DIRECT_DEPTH[0] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _DIRECT_DEPTH[0] -= 1
+        return False
 
 
 def _wsink_take(key, like):
@@ -294,10 +324,15 @@ def _wsink_take(key, like):
     if e is None or task < 0:           # registered before an earlier backward pass cleared the registry: plain path
         buf = torch.empty_like(like)
         return buf, 0, buf
-    if _DIRECT_GRAD:
+    if _DIRECT_GRAD and _DIRECT_DEPTH[0] > 0:
         p = e[0]()
         if (p is not None and p.is_leaf and p.grad is not None and p.grad.shape == like.shape and p.grad.is_contiguous()
-                and p.grad.dtype == torch.float32 and p.grad.device == like.device and not p._backward_hooks):
+                and p.grad.dtype == torch.float32 and p.grad.device == like.device and not p._backward_hooks
+                and not getattr(p, '_post_accumulate_grad_hooks', None)):
+            _wsink_begin(task)              # (queues the end-of-pass callback, which joins the streams recorded here)
+            st = torch.cuda.current_stream()
+            if st not in _DIRECT_STREAMS:
+                _DIRECT_STREAMS.append(st)
             return p.grad, 1, None
     _wsink_begin(task)
     if e[1] is None or e[2] != task:

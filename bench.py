@@ -189,6 +189,8 @@ def main():
         else:
             ops.enable_kernel_timing(True)
     torch.cuda.synchronize()
+    if D.is_dist():
+        ts.comm_events = []                     # event pairs around the gradient all-reduce joins (engine.gd_step)
     t0 = time.time()
     for i in range(args.steps):
         # HIP event pairs around every convolution call cost ~3 % of a step (20k stream markers): they are recorded during the
@@ -200,6 +202,38 @@ def main():
         torch.distributed.barrier()
     dt = D.max_over_ranks(time.time() - t0, device)
     timing = ops.kernel_timing_summary() if not args.no_kernel_timing else {}
+    by_shape = ops.kernel_timing_summary(by_shape=True) if not args.no_kernel_timing else {}
+    # ---- communication record (N > 1): proves how many ranks RCCL saw and how much of the all-reduce time the step waits for
+    comm = {"rccl_world": (torch.distributed.get_world_size() if D.is_dist() else 1),
+            "backend": (torch.distributed.get_backend() if D.is_dist() else None)}
+    if D.is_dist():
+        ev, ts.comm_events = ts.comm_events, None
+        per = {}
+        for name, e0, e1 in ev:
+            per.setdefault(name, []).append(e0.elapsed_time(e1))
+        gflat, dflat = ts.optimizer_generator.flat_grad, ts.discriminator.optimizer_d_img.flat_grad
+
+        def sync_ms(flat):          # the same buckets, NOT overlapped with anything: one untimed call between two events
+            torch.cuda.synchronize()
+            torch.distributed.barrier()
+            a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+            a.record()
+            D.average_gradients([], flat=flat)
+            b.record()
+            torch.cuda.synchronize()
+            return a.elapsed_time(b)
+        g_alone, d_alone = sync_ms(gflat), sync_ms(dflat)
+        g_exposed = sum(per.get('g_join', [0.0])) / max(1, len(per.get('g_join', [])))
+        comm.update({
+            "g_allreduce_bytes": gflat.numel() * 4, "d_allreduce_bytes": dflat.numel() * 4,
+            "g_allreduce_ms_alone": round(g_alone, 3), "d_allreduce_ms_alone": round(d_alone, 3),
+            "g_allreduce_exposed_ms_per_step": round(g_exposed, 3),
+            "g_allreduce_hidden_ms_per_step": round(max(0.0, g_alone - g_exposed), 3),
+            "d_allreduce_exposed_ms_per_step": round(sum(per.get('d_sync', [0.0])) / max(1, len(per.get('d_sync', []))), 3),
+            "g_bus_gbps_alone": round(2.0 * (world - 1) / world * gflat.numel() * 4 / (g_alone * 1e-3) / 1e9, 1) if world > 1 else None,
+            "note": "exposed = time the compute stream waits at the join of the generator's asynchronous all-reduce (launched after G's "
+                    "backward, joined behind the discriminator phase); alone = the same buckets reduced with nothing else running; the "
+                    "discriminator's all-reduce is synchronous (fully exposed)"})
     if os.environ.get('AG2V_TIMING_DETAIL') and rank == 0:
         det = ops.kernel_timing_summary(by_shape=True)
         for k, v in sorted(det.items(), key=lambda kv: -kv[1]['ms'])[:45]:
@@ -235,6 +269,25 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = world * batch * frames * args.steps / dt
     PMC, PMC_PATH = load_pmc_traffic()
+
+    def top_shapes(kernel, n=3):
+        """The dominant kernel's n shapes with the most time: (N, C, H, W, K, R, stride) of the call, its passes, TFLOP/s."""
+        rows = {}
+        for k, v in by_shape.items():
+            if not k.startswith('conv_') or ':' not in k:
+                continue
+            lab, rest = k.split(':', 1)
+            name, _, shp = rest.partition(' (')
+            if name != kernel:
+                continue
+            d = rows.setdefault('(' + shp, {'ms': 0.0, 'flops': 0.0, 'launches': 0, 'passes': set()})
+            d['ms'] += v['ms']; d['flops'] += v['flops']; d['launches'] += v['launches']; d['passes'].add(lab[5:])
+        out = []
+        for shp, d in sorted(rows.items(), key=lambda kv: -kv[1]['ms'])[:n]:
+            tf = d['flops'] / (d['ms'] * 1e-3) / 1e12
+            out.append({"shape_N_C_H_W_K_R_stride": shp, "passes": sorted(d['passes']), "launches": d['launches'], "ms": round(d['ms'], 2),
+                        "tflops": round(tf, 1), "frac": round(tf / ((PEAK_BF16_MFMA_TFLOPS / 3.0) if 'bf16x3' in kernel else PEAK_FP32_MFMA_TFLOPS), 4)})
+        return out
 
     def conv_roofline(tm, wall_ms):
         """Roofline block of the dominant conv kernel of a timing summary (work slot = dense-conv algorithmic FLOPs).
@@ -274,6 +327,7 @@ def main():
                 "launches": t['launches'], "avg_launch_ms": round(t['ms'] / t['launches'], 4),
                 "launches_cover": "one step (the last timed one)",
                 "flops_per_launch": t['flops'] / t['launches'], "passes": t['passes'],
+                "by_shape": (top_shapes(dom) if tm is timing else None),
                 "all_conv_kernels": {"achieved": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
                                      "share_of_step_time": round(conv_ms / wall_ms, 4),
                                      "by_kernel": {k: {"ms": round(v['ms'], 2), "tflops": round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2),
@@ -329,7 +383,7 @@ def main():
         "config": {"workload": "%s: %s %dx%d, %d frames, batch %d per GPU, full G+D train step, VGG loss off"
                    % (args.config, "SSv2-shaped" if args.config == 'c5' else "CATER", side, side, frames, batch), "global_batch": world * batch, "parallelism": "dp%d" % world},
         "roofline": roof, "roofline_exact_fp32": roof_fp32, "roofline_hbm": roof_hbm, "roofline_hbm_bwd": roof_hbm_bwd,
-        "cpu_baseline": cpu,
+        "cpu_baseline": cpu, "comm": comm,
         "extra": {"graph_step_ms": round(graph_ms, 2), "losses_finite": finite,
                   "generated_frames_per_sec": round(world * batch * (frames - 1) * args.steps / dt, 3),
                   "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)},

@@ -78,9 +78,64 @@ def _lrelu(y, slope):
     return y if slope == 1.0 else F.leaky_relu(y, slope)
 
 
+# ---- the reference's MULTI-DEVICE batch norm (sync_batchnorm/batchnorm.py:80-93,105-126,128-145): every replica sums x and x^2 over
+# its shard, the master adds them up (ReduceAddCoalesced), computes mean and inv_std = clamp(biased var, eps)^-1/2, feeds the
+# running buffers with the UNBIASED variance and broadcasts (mean, inv_std); y = x * (inv_std w) + (b - mean inv_std w).  Gradients
+# flow through the reduce / broadcast pair, which for one process per device is an all-reduce in both directions.
+# SYNC_BN = True selects it (tests of --sync_bn 1); in a single process the all-reduce is the identity, i.e. the same formula over
+# the whole local batch -- the single-process checker of a two-rank run on the two half batches.
+SYNC_BN = False
+
+
+class _AllReduceSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t):
+        import torch.distributed as dist
+        t = t.clone()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t
+
+    @staticmethod
+    def backward(ctx, g):
+        import torch.distributed as dist
+        g = g.clone()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        return g
+
+
+def _sync_batch_norm(x, running_mean, running_var, weight, bias, momentum, eps):
+    """_SynchronizedBatchNorm.forward, data-parallel branch (batchnorm.py:72-93) + _compute_mean_std (:128-145)."""
+    import torch.distributed as dist
+    world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    N, C = x.shape[0], x.shape[1]
+    xr = x.reshape(N, C, -1)
+    size = float(N * xr.shape[2] * world)
+    packed = _AllReduceSum.apply(torch.stack([xr.sum(dim=(0, 2)), (xr * xr).sum(dim=(0, 2))]))
+    ssum, sqsum = packed[0], packed[1]
+    mean = ssum / size
+    sumvar = sqsum - ssum * mean
+    unbias_var, bias_var = sumvar / (size - 1), sumvar / size
+    with torch.no_grad():
+        running_mean.mul_(1 - momentum).add_(momentum * mean.detach())
+        running_var.mul_(1 - momentum).add_(momentum * unbias_var.detach())
+    inv_std = bias_var.clamp(min=eps) ** -0.5
+    if weight is not None:
+        scale = (inv_std * weight).view(1, C, 1)
+        shift = (bias - mean * inv_std * weight).view(1, C, 1)
+    else:
+        scale, shift = inv_std.view(1, C, 1), (-mean * inv_std).view(1, C, 1)
+    return (xr * scale + shift).reshape(x.shape)
+
+
 def _batch_norm_groups(x, running_mean, running_var, weight, bias, training, momentum, eps, groups):
     """One F.batch_norm call per group of N / groups consecutive samples, in order (each call updates the running statistics):
     the frame passes of the reference's generator loop, held as one frame-major batch by the product."""
+    if SYNC_BN and training:
+        n = x.shape[0] // groups
+        return torch.cat([_sync_batch_norm(x[g * n:(g + 1) * n], running_mean, running_var, weight, bias, momentum, eps)
+                          for g in range(groups)], dim=0)
     if groups == 1 or not training:
         return F.batch_norm(x, running_mean, running_var, weight, bias, training, momentum, eps)
     n = x.shape[0] // groups

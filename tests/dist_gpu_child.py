@@ -68,7 +68,8 @@ def main(out_path):
     yr = (xd - mu) * var.clamp(min=1e-5).pow(-0.5) * wb.detach().double().view(1, 1, 5, 1) + bb.detach().double().view(1, 1, 5, 1)
     yr = torch.nn.functional.leaky_relu(yr, 0.2)
     (yr * wgt.double().view(2, 3, 5, 81)).sum().backward()
-    unb = var.squeeze() * (3 * 81) / (3 * 81 - 1)
+    cnt = world * 3 * 81                      # every rank holds the same xb: global statistics = local ones, over world x the count
+    unb = var.squeeze() * cnt / (cnt - 1)
     rm_ref = 0.1 * (0.9 * mu.squeeze()[0] + mu.squeeze()[1])
     rv_ref = 0.9 * (0.9 * 1.0 + 0.1 * unb[0]) + 0.1 * unb[1]
     sync_bn_err = [float((yb.double().view(2, 3, 5, 81) - yr).abs().max() / yr.abs().max()),

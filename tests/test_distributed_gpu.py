@@ -33,7 +33,7 @@ def test_rccl_path_on_gpu_matches_single_process(device, tmp_path):
     from ag2video_amd.data.synthetic import make_clip_batch
     from ag2video_amd.data.vocab import cater_vocab
     from ag2video_amd.engine import TrainStep
-    n = 1                                  # the test box has one GPU; the launcher line is the driver's multi-GPU line with N = 1
+    n = max(1, torch.cuda.device_count())  # one rank per visible GPU (the test box has one); the launcher line is the driver's multi-GPU line
     out = os.path.join(str(tmp_path), 'dist.json')
     env = dict(os.environ, AG2V_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
@@ -44,7 +44,7 @@ def test_rccl_path_on_gpu_matches_single_process(device, tmp_path):
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     res = json.load(open(out))
     assert res['backend'] == 'nccl' and res['world'] == n
-    assert res['identity_allreduce'] is True
+    assert res['identity_allreduce'] is (True if n == 1 else None)       # a one-rank mean is the identity, bit for bit
     # per gd_step: the collective NaN-guard flag (one int) + one all-reduce per 128 MB bucket of each flat gradient buffer (the
     # toy's buffers are one bucket each: G, D)
     assert res['allreduce_calls_per_gd_step'] == 3, res['allreduce_calls_per_gd_step']
@@ -61,6 +61,9 @@ def test_rccl_path_on_gpu_matches_single_process(device, tmp_path):
     _, GL0, _ = ts.gd_step(clip, apply_updates=False)
     _, GL, DL = ts.gd_step(clip)
     _, GG = ts.graph_step(ts.to_device(make_clip_batch(opt.vocab, 2, 5, (64, 64), seed=12)))
-    for got, ref in ((res['G0'], GL0), (res['G'], GL), (res['D'], DL), (res['graph'], GG)):
+    # rank 0's clip is this process's clip; its losses before any update are rank-local at every world size (per-rank batch
+    # statistics), the graph step follows an update averaged over the ranks' different clips
+    cmp = ((res['G0'], GL0), (res['G'], GL), (res['D'], DL)) + (((res['graph'], GG),) if n == 1 else ())
+    for got, ref in cmp:
         for k, v in ref.items():
             assert abs(got[k] - float(v)) <= 1e-4 * max(1.0, abs(float(v))), (k, got[k], float(v))

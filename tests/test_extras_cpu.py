@@ -132,3 +132,17 @@ def test_cater_loader_end_to_end(tmp_path):
         n = int((objs[b].sum(1) != 0).sum())                                       # real objects; then the __image__ row, then padding
         assert torch.equal(boxes[b, :, n], torch.tensor([0.0, 0.0, 1.0, 1.0]).expand(4, 4))
         assert (boxes[b, :, n + 1:] == -1).all()
+
+
+def test_perceptual_loss_needs_weights_or_an_explicit_opt_in():
+    """the default flags (no --no_vgg_loss, lambda_vgg 10) must not silently optimise a randomly initialised VGG19."""
+    import pytest
+    from ag2video_amd.data.args import make_opt
+    from ag2video_amd.data.vocab import cater_vocab
+    from ag2video_amd.models.spade_models.loss_model import LossModel
+    flags = ['--image_size', '32,32', '--gpu_ids', '-1']
+    with pytest.raises(RuntimeError, match='vgg_weights'):
+        LossModel(make_opt(cater_vocab(), flags), discriminator=None)
+    lm = LossModel(make_opt(cater_vocab(), flags + ['--vgg_random_init']), discriminator=None)
+    assert hasattr(lm, 'criterionVGG') and lm.vgg_weights_loaded is False
+    assert not hasattr(LossModel(make_opt(cater_vocab(), flags + ['--no_vgg_loss']), discriminator=None), 'criterionVGG')

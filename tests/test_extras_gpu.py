@@ -104,7 +104,10 @@ def test_train_step_with_vgg_loss_matches_oracle(device):
     from oracle.step import OracleTrainer
     flags = ['--image_size', '64,64', '--batch_size', '2', '--ngf', '8', '--ndf', '8', '--nff', '8', '--gconv_hidden_dim', '64',
              '--gpu_ids', '0']
-    opt = make_opt(cater_vocab(), flags)
+    from ag2video_amd.models.spade_models.loss_model import LossModel
+    with pytest.raises(RuntimeError, match='vgg_weights'):       # the default flags must not silently train on a random VGG19
+        LossModel(make_opt(cater_vocab(), flags), discriminator=None)
+    opt = make_opt(cater_vocab(), flags + ['--vgg_random_init'])
     assert not opt.no_vgg_loss
     ts = TrainStep(opt, device, weights_seed=6)
     sd_gm = ts.gans_model.state_dict()

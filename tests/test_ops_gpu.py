@@ -795,6 +795,49 @@ def test_gradient_sinks_multi_use_and_aborted_backward(device):
     _cmp('sink.db', b.grad, br.grad, TOL)
 
 
+def test_direct_param_grads_only_inside_the_accumulating_context(device):
+    """a leaf with a preallocated .grad (every FusedAdam parameter) takes the direct-to-.grad path ONLY inside
+    ops.accumulate_into_param_grads() (the training step's backward).  torch.autograd.grad and a plain backward() go through
+    autograd: autograd.grad returns the gradient and leaves .grad alone; both routes produce the same numbers; gradients written
+    from a side stream are joined to the caller's stream by the end-of-pass callback."""
+    from ag2video_amd import ops
+    from ag2video_amd.optim import FusedAdam
+    x = _rand(2, 16, 12, 12, seed=1).to(device)
+    w = torch.nn.Parameter(_rand(136, 16, 3, 3, seed=4, scale=0.1).to(device))
+    b = torch.nn.Parameter(_rand(136, seed=5).to(device))
+    opt = FusedAdam([w, b], lr=1e-3)
+    tgt = _rand(2, 136, 12, 12, seed=9).to(device)
+
+    def loss():
+        return (ops.conv2d(x, w, b, 1, 1) * tgt).sum()
+    opt.zero_grad()
+    gw, gb = torch.autograd.grad(loss(), [w, b])
+    assert gw is not None and gb is not None and float(gw.abs().sum()) > 0
+    assert float(w.grad.abs().sum()) == 0.0 and float(b.grad.abs().sum()) == 0.0           # .grad untouched by autograd.grad
+    loss().backward()                                                                        # plain backward: AccumulateGrad
+    torch.cuda.synchronize()
+    plain_w, plain_b = w.grad.clone(), b.grad.clone()
+    _cmp('direct.autograd_grad_w', gw, plain_w.cpu(), 1e-5)
+    opt.zero_grad()
+    side = torch.cuda.Stream(device=device)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        l2 = loss()                                                                          # forward on the side stream => its backward too
+    with ops.accumulate_into_param_grads():
+        l2.backward()
+    assert w.grad.data_ptr() == opt.flat_grad.data_ptr() or w.grad.data_ptr() > 0          # still the flat view
+    got_w, got_b = w.grad.clone(), b.grad.clone()                                            # current stream: must see the side stream's writes
+    torch.cuda.synchronize()
+    _cmp('direct.context_w', got_w, plain_w.cpu(), 1e-5)
+    _cmp('direct.context_b', got_b, plain_b.cpu(), 1e-5)
+    hooked = []
+    w.register_post_accumulate_grad_hook(lambda p: hooked.append(1))
+    opt.zero_grad()
+    with ops.accumulate_into_param_grads():
+        loss().backward()
+    assert hooked, "a post-accumulate-grad hook must still fire (the direct path steps aside for hooked parameters)"
+
+
 # ------------------------------------------------------------------------------------------------ frame-group forms
 # (frame-batched generator: ops.frame_groups).  The oracle restates each of them as the reference's per-pass op applied group by group.
 GS_CASES = [
