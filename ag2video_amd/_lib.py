@@ -30,6 +30,7 @@ _SIGS = {
     'ag2v_conv2d_dgrad_workspace_floats': (c_size_t, [c_int] * 9),
     'ag2v_conv2d_dgrad_ex': (c_int, [_P, _P, _P, _P] + [c_int] * 10 + [_P, c_size_t, _P, _P]),
     'ag2v_conv2d_wgrad_ex': (c_int, [_P, _P, _P] + [c_int] * 11 + [_P, _P]),
+    'ag2v_conv2d_wgrad_det_workspace_floats': (c_size_t, [c_int] * 10 + [_P]),
     'ag2v_conv2d_split_input_ok': (c_int, [c_int] * 12),
     'ag2v_conv2d_split_dy_ok': (c_int, [c_int] * 11),
     'ag2v_channel_sum': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
@@ -93,7 +94,7 @@ _SIGS = {
     'ag2v_spectral_norm_bwd_acc': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, c_int, _P, _P]),
     'ag2v_spectral_sigmas': (c_int, [_P, _P, _P, c_int, c_int, c_float, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     'ag2v_sn_desc_bytes': (c_size_t, []),
-    'ag2v_spectral_sigmas_multi': (c_int, [_P, c_int, c_int, c_int, c_int, c_float, _P]),
+    'ag2v_spectral_sigmas_multi': (c_int, [_P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
     'ag2v_sn_group_combine': (c_int, [_P, _P, _P, c_int, c_longlong, _P, c_int, _P, _P]),
     'ag2v_spectral_sigmas_bwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),
 }
@@ -103,7 +104,8 @@ EXPORTS = tuple(sorted(_SIGS))
 class ConvOpts(ctypes.Structure):
     """ag2v_conv_opts (include/ag2v.h): per-call options of the *_ex convolution entry points."""
     _fields_ = [('precision', c_int), ('min_rows', c_int), ('gscale', c_void_p), ('group_n', c_int), ('kernel', c_char_p),
-                ('in_split', c_int), ('dy_split', c_int), ('out_split', c_int)]
+                ('in_split', c_int), ('dy_split', c_int), ('out_split', c_int), ('deterministic', c_int), ('det_workspace', c_void_p),
+                ('det_workspace_floats', ctypes.c_size_t)]
 
 _lib = None
 

@@ -755,8 +755,8 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_ws_k
     const int qe = min(qs + p.kchunk, (grp + 1) * p.gq);
     if (qs >= qe) return;
     const int nt = (qe - qs + BK - 1) / BK;
-    float* const outg = p.out + (size_t)grp * p.out_gstride;
-    const bool atomic_out = p.spg > 1 || p.accumulate;
+    float* const outg = p.det ? p.out + (size_t)split * ((size_t)p.M * p.NG) : p.out + (size_t)grp * p.out_gstride;
+    const bool atomic_out = !p.det && (p.spg > 1 || p.accumulate);
 
     if (producer) {
         const __amdgpu_buffer_rsrc_t ars = make_rsrc(p.a_src, p.a_bytes), brs = make_rsrc(p.b_src, p.b_bytes);
@@ -1000,8 +1000,8 @@ __device__ __forceinline__ void wgrad_bf16x3_v_body(const ConvArgs& p) {
     const int qe = min(qs + p.kchunk, (grp + 1) * p.gq);
     if (qs >= qe) return;
     const int nt = (qe - qs + BK - 1) / BK;
-    float* const outg = p.out + (size_t)grp * p.out_gstride;
-    const bool atomic_out = p.spg > 1 || p.accumulate;
+    float* const outg = p.det ? p.out + (size_t)split * ((size_t)p.M * p.NG) : p.out + (size_t)grp * p.out_gstride;
+    const bool atomic_out = !p.det && (p.spg > 1 || p.accumulate);
 
     if (producer) {
         const __amdgpu_buffer_rsrc_t ars = make_rsrc(p.a_src, p.a_bytes), brs = make_rsrc(p.b_src, p.b_bytes);
@@ -1302,7 +1302,7 @@ int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed) {
     a.tiles_n = ceil_div(a.NG, bn);
     const int tiles = a.tiles_m * a.tiles_n, nk = ceil_div(a.KG, 32);
     a.splitk = 1; a.kchunk = nk;
-    if (tiles < 1024 && nk >= 8) {
+    if (tiles < 1024 && nk >= 8 && !a.det) {      // (deterministic: one workgroup owns an output tile's whole reduction)
         const int sk = pick_splits(tiles, nk, nk / 4 < 64 ? nk / 4 : 64);
         if (sk > 1) {
             a.kchunk = ceil_div(nk, sk);
@@ -1363,7 +1363,7 @@ int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed) {
     return AG2V_OK;
 }
 
-int launch_wgrad_bf16x3(ConvArgs& a, hipStream_t st) {
+void plan_wgrad_bf16x3(ConvArgs& a) {
     const bool tall = a.M >= 192 && ceil_div(a.M, 256) * 256 <= ceil_div(a.M, 128) * 128;     // see launch_igemm_bf16x3
     const int bm = tall ? 256 : 128, bn = tall ? 128 : 256;
     a.tiles_m = ceil_div(a.M, bm);
@@ -1376,9 +1376,15 @@ int launch_wgrad_bf16x3(ConvArgs& a, hipStream_t st) {
     int spg = pick_splits(tiles * a.groups, nq, nq / 8 < 256 ? (nq / 8 > 0 ? nq / 8 : 1) : 256);
     int kchunk = ceil_div(nq, spg) * 32;
     spg = (int)((Qg + kchunk - 1) / kchunk);
-    const int splitk = spg * a.groups;
-    a.spg = spg; a.splitk = splitk; a.kchunk = kchunk;
-    if (spg > 1 && !a.accumulate) {
+    a.spg = spg; a.splitk = spg * a.groups; a.kchunk = kchunk;
+}
+
+int launch_wgrad_bf16x3(ConvArgs& a, hipStream_t st) {
+    plan_wgrad_bf16x3(a);
+    const bool tall = a.M >= 192 && ceil_div(a.M, 256) * 256 <= ceil_div(a.M, 128) * 128;
+    const int tiles = a.tiles_m * a.tiles_n;
+    const int spg = a.spg, splitk = a.splitk;
+    if (spg > 1 && !a.accumulate && !a.det) {
         if (hipMemsetAsync(a.out, 0, (size_t)a.M * a.NG * a.groups * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
     }
     const dim3 grid(tiles * splitk);     // 1-D: the kernels decode (split, tile) themselves (XCD-aware)

@@ -33,6 +33,9 @@ struct ConvArgs {
     int f32;                // wave-specialised implicit-GEMM kernels on exact fp32 operands (conv_igemm_f32_ws_kernel)
     int a_split;            // weight-gradient bf16x3 kernels: dy (a_src) holds split words
     int b_split;            // bf16x3 kernels: b_src holds split words ((bf16 hi << 16) | bf16 lo per value, pack_split()) instead of fp32
+    int det;                // deterministic reduction (ag2v_conv_opts::deterministic): igemm: no split-K (launchers); wgrad: pixel-range
+                            //   split number `split` stores its partial tile to out + split * M * NG (a caller workspace slab, plain
+                            //   stores) and launch_wgrad_det_reduce() adds the slabs in split order -- no floating-point atomics
 #ifdef AG2V_STAMPS
     unsigned long long* stamps;   // diagnostic build only (tools/ubench/igemm_stamps.hip): per-wave phase clocks
 #endif
@@ -141,4 +144,7 @@ __host__ __device__ __forceinline__ int tap_major_row(int c, int r, int s, int R
 
 // launchers implemented in conv_bf16x3.hip
 int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed);
+void plan_wgrad_bf16x3(ConvArgs& a);      // tiles, pixel-range splits per group (a.spg), a.splitk, a.kchunk -- what the launch will use
 int launch_wgrad_bf16x3(ConvArgs& a, hipStream_t st);
+// dw[g][i] = (accumulate ? dw[g][i] : 0) + sum_{sl < spg, in order} slabs[(g * spg + sl) * mn + i]   (conv_igemm.hip)
+int launch_wgrad_det_reduce(const float* slabs, float* dw, long long mn, int groups, int spg, int accumulate, hipStream_t st);

@@ -234,8 +234,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvArgs p) {
     const int qs = grp * p.gq + sl * p.kchunk;
     const int qe = min(qs + p.kchunk, (grp + 1) * p.gq);
     if (qs >= qe) return;  // uniform per block
-    float* const outg = p.out + (size_t)grp * p.out_gstride;
-    const bool atomic_out = p.spg > 1 || p.accumulate;
+    float* const outg = p.det ? p.out + (size_t)blockIdx.y * ((size_t)p.M * p.NG) : p.out + (size_t)grp * p.out_gstride;
+    const bool atomic_out = !p.det && (p.spg > 1 || p.accumulate);
 
     const int qq = tid & 15, rg = tid >> 4;
     // hoisted column decode: j -> (c, r-pad, s-pad)
@@ -510,12 +510,18 @@ struct ag2v_conv_opts {
     int in_split;
     int dy_split;
     int out_split;
+    int deterministic;
+    float* det_workspace;
+    size_t det_workspace_floats;
 };
 struct ConvCfg {
     int precision, min_rows;
     const float* gscale;
     int group_n;
     int in_split, dy_split, out_split;
+    int det;
+    float* det_ws;
+    size_t det_ws_floats;
 };
 static ConvCfg conv_cfg(const ag2v_conv_opts* o) {
     ConvCfg c;
@@ -526,11 +532,51 @@ static ConvCfg conv_cfg(const ag2v_conv_opts* o) {
     c.in_split = (o && o->in_split) ? 1 : 0;
     c.dy_split = (o && o->dy_split) ? 1 : 0;
     c.out_split = (o && o->out_split) ? 1 : 0;
+    c.det = (o && o->deterministic) ? 1 : 0;
+    c.det_ws = o ? o->det_workspace : nullptr;
+    c.det_ws_floats = o ? o->det_workspace_floats : 0;
     return c;
 }
 static bool use_bf16x3(const ConvCfg& c, int M) { return c.precision == 1 && M >= c.min_rows; }
 static const long long kBufMax = (1LL << 32) - 64;   // raw buffer descriptors cover < 4 GiB
 
+
+// ---------------------------------------------------------------- ordered reduction of a deterministic weight-gradient launch
+// (ConvArgs::det): dw[g][e] = (acc ? dw[g][e] : 0) + slab[g * spg + 0][e] + slab[g * spg + 1][e] + ...  -- the pixel-range splits of a
+// sample group added in split order, one thread per element (float4 where the row length allows it)
+__global__ __launch_bounds__(256) void wgrad_det_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, long long mn,
+                                                               int groups, int spg, int acc, int vec) {
+    const long long total = (long long)groups * mn;
+    if (vec) {
+        const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+        if (i >= total) return;
+        const long long g = i / mn, e = i - g * mn;
+        float4 s = acc ? *reinterpret_cast<const float4*>(dw + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* sp = slabs + (size_t)g * spg * mn + e;
+        for (int sl = 0; sl < spg; ++sl) {
+            const float4 v = *reinterpret_cast<const float4*>(sp + (size_t)sl * mn);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *reinterpret_cast<float4*>(dw + i) = s;
+    } else {
+        const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+        if (i >= total) return;
+        const long long g = i / mn, e = i - g * mn;
+        float s = acc ? dw[i] : 0.f;
+        const float* sp = slabs + (size_t)g * spg * mn + e;
+        for (int sl = 0; sl < spg; ++sl) s += sp[(size_t)sl * mn];
+        dw[i] = s;
+    }
+}
+int launch_wgrad_det_reduce(const float* slabs, float* dw, long long mn, int groups, int spg, int accumulate, hipStream_t st) {
+    const int vec = ((mn & 3) == 0 && ((((uintptr_t)slabs) | ((uintptr_t)dw)) & 15) == 0) ? 1 : 0;
+    const long long total = (long long)groups * mn;
+    const long long threads = vec ? total / 4 : total;
+    hipLaunchKernelGGL(wgrad_det_reduce_kernel, dim3((unsigned)ceil_div(threads, 256LL)), dim3(256), 0, st, slabs, dw, mn, groups, spg,
+                       accumulate ? 1 : 0, vec);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
 
 // ---------------------------------------------------------------- epilogue pass of split-K launches
 __global__ __launch_bounds__(256) void act_mask_kernel(float* __restrict__ out, const float* __restrict__ mask, long long n, int relu,
@@ -703,7 +749,7 @@ static int launch_igemm(ConvArgs& a, hipStream_t st, bool out_zeroed, bool split
     // thousands of steps long: split K over grid.y and accumulate with fp32 atomics into the zeroed output.
     const int tiles = a.tiles_m * a.tiles_n, nk = ceil_div(a.KG, bk);
     a.splitk = 1; a.kchunk = nk;
-    if (tiles < 384 && nk >= 16) {
+    if (tiles < 384 && nk >= 16 && !a.det) {      // (deterministic: no split-K, no atomics)
         int sk = ceil_div(768, tiles);
         if (sk > nk / 8) sk = nk / 8;
         if (sk > 1) {
@@ -833,6 +879,7 @@ extern "C" int ag2v_conv2d_fwd_ex(const float* x, const float* w, const float* b
         a.a_src = workspace;
         a.b_split = cfg.in_split; a.out_split = cfg.out_split;
         a.f32 = f32ws ? 1 : 0;
+        a.det = cfg.det;
         const int rc = launch_igemm(a, st, false, split || f32ws);
         if (rc != AG2V_OK) return rc;
     }
@@ -895,6 +942,7 @@ extern "C" int ag2v_conv2d_dgrad_ex(const float* dy, const float* w, const float
         f.M = J; f.NG = N * OH * OW; f.KG = K;
         f.a_bytes = (unsigned)((long long)K * J * 4); f.b_bytes = 0;
         f.gscale = cfg.gscale; f.group_n = cfg.group_n;
+        f.det = cfg.det;
         int rc = launch_igemm(f, st, false, false);
         if (rc == AG2V_OK) {
             const long long total = (long long)N * C * H * W;
@@ -968,6 +1016,7 @@ extern "C" int ag2v_conv2d_dgrad_ex(const float* dy, const float* w, const float
                 // accumulate: a split-K launch adds onto the existing dx with its atomics (no zeroing); any other launch reads dx
                 // back as the epilogue's residual term (each element is read and written by the same thread)
                 f.residual = accumulate ? dxc : nullptr;
+                f.det = cfg.det;
                 const int rc = launch_igemm(f, st, multi || accumulate != 0, split || f32ws);
                 if (rc != AG2V_OK) return rc;
             }
@@ -999,8 +1048,12 @@ extern "C" int ag2v_conv2d_dgrad(const float* dy, const float* w, float* dx,
 // Weight gradient.  accumulate != 0: dw += instead of dw = : a weight used by several forward calls of one step collects its
 // gradient in one buffer.  groups > 1 (N % groups == 0): the batch is `groups` consecutive sample groups and dw is
 // [groups][K, C, R, S] -- one gradient per group (the frame-batched generator needs dL/dWbar_t per frame t for spectral norm).
+// det: deterministic reduction -- a launch whose pixel range is split (spg > 1) stores one partial weight gradient per split into
+// det_ws (groups * spg * K*C*R*S floats) and launch_wgrad_det_reduce adds them in order; need (nullable): only plan the launch and
+// report that float count (0 when the launch does not split).
 static int wgrad_launch(const float* dy, const float* x, float* dw, int N, int C, int H, int W, int K, int R, int S, int OH, int OW,
-                        int stride, int pad, int accumulate, int groups, bool split, hipStream_t st, int x_split = 0, int dy_split = 0) {
+                        int stride, int pad, int accumulate, int groups, bool split, hipStream_t st, int x_split = 0, int dy_split = 0,
+                        int det = 0, float* det_ws = nullptr, size_t det_ws_floats = 0, size_t* need = nullptr) {
     ConvArgs a{};
     a.a_src = dy; a.b_src = x; a.out = dw; a.accumulate = accumulate ? 1 : 0;
     a.b_split = x_split; a.a_split = dy_split;
@@ -1010,42 +1063,57 @@ static int wgrad_launch(const float* dy, const float* x, float* dw, int N, int C
     const long long Q = (long long)N * OH * OW;
     a.M = K; a.NG = C * R * S; a.KG = (int)Q;
     a.groups = groups; a.gq = (int)(Q / groups); a.out_gstride = (long long)a.M * a.NG;
+    const long long mn = (long long)a.M * a.NG;
+    int bm = 0;
     if (split) {
         a.a_bytes = (unsigned)((long long)N * K * OH * OW * 4); a.b_bytes = (unsigned)((long long)N * C * H * W * 4);
-        return launch_wgrad_bf16x3(a, st);
+        plan_wgrad_bf16x3(a);
+    } else {
+        bm = (a.M <= 32) ? 32 : (a.M <= 64 ? 64 : 128);
+        a.tiles_m = ceil_div(a.M, bm);
+        a.tiles_n = ceil_div(a.NG, 128);
+        const int tiles = a.tiles_m * a.tiles_n;
+        // split each group's pixel reduction so that ~1536 workgroups are in flight (256 CUs x up to 4 resident + slack)
+        const long long Qg = a.gq;
+        int spg = ceil_div(1536, (long long)tiles * groups);
+        const int max_split = (int)((Qg + 511) / 512);
+        if (spg > max_split) spg = max_split;
+        if (spg < 1) spg = 1;
+        int kchunk = (int)((Qg + spg - 1) / spg);
+        kchunk = ((kchunk + 15) / 16) * 16;
+        spg = (int)((Qg + kchunk - 1) / kchunk);
+        a.spg = spg; a.splitk = spg * groups; a.kchunk = kchunk;
     }
-    int bm = (a.M <= 32) ? 32 : (a.M <= 64 ? 64 : 128);
-    a.tiles_m = ceil_div(a.M, bm);
-    a.tiles_n = ceil_div(a.NG, 128);
-    const int tiles = a.tiles_m * a.tiles_n;
-    // split each group's pixel reduction so that ~1536 workgroups are in flight (256 CUs x up to 4 resident + slack)
-    const long long Qg = a.gq;
-    int spg = ceil_div(1536, (long long)tiles * groups);
-    const int max_split = (int)((Qg + 511) / 512);
-    if (spg > max_split) spg = max_split;
-    if (spg < 1) spg = 1;
-    int kchunk = (int)((Qg + spg - 1) / spg);
-    kchunk = ((kchunk + 15) / 16) * 16;
-    spg = (int)((Qg + kchunk - 1) / kchunk);
-    a.spg = spg; a.splitk = spg * groups; a.kchunk = kchunk;
-    if (spg > 1 && !a.accumulate) {
-        if (hipMemsetAsync(dw, 0, (size_t)a.M * a.NG * groups * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
+    const bool slabs = det && a.spg > 1;
+    const size_t slab_floats = slabs ? (size_t)groups * a.spg * (size_t)mn : 0;
+    if (need) { *need = slab_floats; return AG2V_OK; }
+    if (slabs) {
+        if (!det_ws || det_ws_floats < slab_floats) return AG2V_EINVAL;      // ag2v_conv2d_wgrad_det_workspace_floats()
+        a.det = 1;
+        a.out = det_ws;
     }
-    dim3 grid(tiles, a.splitk);
-    if (bm == 32)
-        { set_last_conv_kernel("conv_wgrad_kernel<32, 128, 1, 4>"); hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4>), grid, dim3(256), 0, st, a); }
-    else if (bm == 64)
-        { set_last_conv_kernel("conv_wgrad_kernel<64, 128, 2, 2>"); hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 2, 2>), grid, dim3(256), 0, st, a); }
-    else
-        { set_last_conv_kernel("conv_wgrad_kernel<128, 128, 2, 2>"); hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, a); }
-    AG2V_CHECK_LAUNCH();
+    if (split) {
+        const int rc = launch_wgrad_bf16x3(a, st);
+        if (rc != AG2V_OK) return rc;
+    } else {
+        if (a.spg > 1 && !a.accumulate && !a.det) {
+            if (hipMemsetAsync(dw, 0, (size_t)a.M * a.NG * groups * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
+        }
+        dim3 grid(a.tiles_m * a.tiles_n, a.splitk);
+        if (bm == 32)
+            { set_last_conv_kernel("conv_wgrad_kernel<32, 128, 1, 4>"); hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4>), grid, dim3(256), 0, st, a); }
+        else if (bm == 64)
+            { set_last_conv_kernel("conv_wgrad_kernel<64, 128, 2, 2>"); hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 2, 2>), grid, dim3(256), 0, st, a); }
+        else
+            { set_last_conv_kernel("conv_wgrad_kernel<128, 128, 2, 2>"); hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, a); }
+        AG2V_CHECK_LAUNCH();
+    }
+    if (slabs) return launch_wgrad_det_reduce(det_ws, dw, mn, groups, a.spg, accumulate, st);
     return AG2V_OK;
 }
-extern "C" int ag2v_conv2d_wgrad_ex(const float* dy, const float* x, float* dw, int N, int C, int H, int W, int K, int R, int S,
-                                    int stride, int pad, int accumulate, int groups, void* stream, ag2v_conv_opts* o) {
-    if (!dy || !x || !dw || N <= 0 || C <= 0 || K <= 0 || stride <= 0 || groups <= 0 || N % groups != 0) return AG2V_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
-    const ConvCfg cfg = conv_cfg(o);
+// the sample-chunk loop of ag2v_conv2d_wgrad_ex; need != null: plan only, *need = the largest per-launch slab workspace (floats)
+static int wgrad_ex_impl(const float* dy, const float* x, float* dw, int N, int C, int H, int W, int K, int R, int S,
+                         int stride, int pad, int accumulate, int groups, hipStream_t st, const ConvCfg& cfg, size_t* need) {
     const int OH = conv_out_dim(H, R, stride, pad), OW = conv_out_dim(W, S, stride, pad);
     if (OH <= 0 || OW <= 0) return AG2V_EINVAL;
     const long long dys = (long long)K * OH * OW, xs = (long long)C * H * W;
@@ -1066,17 +1134,40 @@ extern "C" int ag2v_conv2d_wgrad_ex(const float* dy, const float* x, float* dw, 
         if (nmax <= 0) return AG2V_EINVAL;
     }
     const size_t wsz = (size_t)K * C * R * S;
+    size_t most = 0;
     for (int n0 = 0; n0 < N; n0 += nmax) {
         const int nc = (N - n0 < nmax) ? N - n0 : nmax;
         const int g0 = n0 / Ng, gc = (groups > 1) ? nc / Ng : 1;
-        float* out = (groups > 1) ? dw + (size_t)g0 * wsz : dw;
+        float* out = (groups > 1 && dw) ? dw + (size_t)g0 * wsz : dw;
         const int acc = (groups > 1) ? accumulate : (accumulate || n0 > 0);
-        const int rc = wgrad_launch(dy + (size_t)n0 * dys, x + (size_t)n0 * xs, out, nc, C, H, W, K, R, S, OH, OW, stride, pad, acc, gc,
-                                    split, st, cfg.in_split, cfg.dy_split);
+        size_t one = 0;
+        const int rc = wgrad_launch(need ? nullptr : dy + (size_t)n0 * dys, need ? nullptr : x + (size_t)n0 * xs, out, nc, C, H, W, K, R, S,
+                                    OH, OW, stride, pad, acc, gc, split, st, cfg.in_split, cfg.dy_split, cfg.det, cfg.det_ws,
+                                    cfg.det_ws_floats, need ? &one : nullptr);
         if (rc != AG2V_OK) return rc;
+        if (one > most) most = one;
     }
-    if (o) o->kernel = g_last_conv_kernel;
+    if (need) *need = most;
     return AG2V_OK;
+}
+extern "C" int ag2v_conv2d_wgrad_ex(const float* dy, const float* x, float* dw, int N, int C, int H, int W, int K, int R, int S,
+                                    int stride, int pad, int accumulate, int groups, void* stream, ag2v_conv_opts* o) {
+    if (!dy || !x || !dw || N <= 0 || C <= 0 || K <= 0 || stride <= 0 || groups <= 0 || N % groups != 0) return AG2V_EINVAL;
+    const ConvCfg cfg = conv_cfg(o);
+    const int rc = wgrad_ex_impl(dy, x, dw, N, C, H, W, K, R, S, stride, pad, accumulate, groups, (hipStream_t)stream, cfg, nullptr);
+    if (rc == AG2V_OK && o) o->kernel = g_last_conv_kernel;
+    return rc;
+}
+// Floats of ag2v_conv_opts::det_workspace a deterministic ag2v_conv2d_wgrad_ex call with these arguments and options needs
+// (0: the launch does not split its pixel range, or the arguments are invalid).  Same planning code as the call itself.
+extern "C" size_t ag2v_conv2d_wgrad_det_workspace_floats(int N, int C, int H, int W, int K, int R, int S, int stride, int pad,
+                                                         int groups, const ag2v_conv_opts* o) {
+    if (N <= 0 || C <= 0 || K <= 0 || stride <= 0 || groups <= 0 || N % groups != 0) return 0;
+    ConvCfg cfg = conv_cfg(o);
+    cfg.det = 1;
+    size_t need = 0;
+    if (wgrad_ex_impl(nullptr, nullptr, nullptr, N, C, H, W, K, R, S, stride, pad, 0, groups, nullptr, cfg, &need) != AG2V_OK) return 0;
+    return need;
 }
 // 1 when a convolution of this shape can take its INPUT x as split words (ag2v_conv_opts::in_split) in the forward pass and in
 // the weight gradient with these options: both passes on the bf16x3 kernels (rows >= min_rows, precision), the weight gradient on

@@ -970,11 +970,15 @@ extern "C" int ag2v_instnorm_lrelu_bwd(const float* dy, const float* y, const fl
 
 // accumulate != 0: out[c] += sum (a bias used by several forward calls of one step collects its gradient in one buffer)
 // x_split != 0: x holds split words (a gradient written by a convolution epilogue with ag2v_conv_opts::out_split); the sum is over hi + lo
+// accumulate is a flag word: AG2V_ACCUMULATE (1) | AG2V_DETERMINISTIC (2: one workgroup per channel sums every image in order -- no
+// floating-point atomics between image splits; an accumulating launch then adds its one sum per channel, which is order-free)
 extern "C" int ag2v_channel_sum_acc_s(const float* x, float* out, int N, int C, int HW, int accumulate, int x_split, void* stream) {
     if (!x || !out || N <= 0 || C <= 0 || HW <= 0) return AG2V_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    const bool det = (accumulate & 2) != 0;
+    accumulate &= 1;
     int nsplit = 1;
-    if ((long long)C < 1024 && (long long)HW * N >= (1 << 16)) {
+    if ((long long)C < 1024 && (long long)HW * N >= (1 << 16) && !det) {
         nsplit = ceil_div(1024, C);
         if (nsplit > N) nsplit = N;
     }

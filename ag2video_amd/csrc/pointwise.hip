@@ -226,10 +226,12 @@ extern "C" int ag2v_spectral_norm_fwd_save(const float* w, float* u, float* v, i
     if (!w || !u || !v || !wbar || !sigma || !workspace || M <= 0 || R <= 0) return AG2V_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     float* wv = workspace;
+    const bool det = (power_iter & 2) != 0;      // AG2V_DETERMINISTIC: W^T u without row splits (no atomics)
+    power_iter &= 1;
     if (power_iter) {
         int msplit = 1;
         const int rb = ceil_div(R, 256);
-        if (rb < 256 && M >= 64) { msplit = ceil_div(512, rb); if (msplit > M / 16) msplit = M / 16; if (msplit < 1) msplit = 1; }
+        if (rb < 256 && M >= 64 && !det) { msplit = ceil_div(512, rb); if (msplit > M / 16) msplit = M / 16; if (msplit < 1) msplit = 1; }
         const int mchunk = ceil_div(M, msplit);
         msplit = ceil_div(M, mchunk);
         if (msplit > 1 && hipMemsetAsync(v, 0, (size_t)R * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
@@ -273,12 +275,14 @@ extern "C" int ag2v_spectral_norm_bwd(const float* dwbar, const float* wbar, con
 extern "C" int ag2v_spectral_sigmas(const float* w, float* u, float* v, int M, int R, float eps, int power_iter, int T, float* sigma,
                                     float* inv_sigma, float* u_used, float* v_used, float* workspace, void* stream) {
     if (!w || !u || !v || !sigma || !inv_sigma || !workspace || M <= 0 || R <= 0 || T <= 0) return AG2V_EINVAL;
+    const bool det = (power_iter & 2) != 0;      // AG2V_DETERMINISTIC: W^T u without row splits (no atomics)
+    power_iter &= 1;
     if (!power_iter && T != 1) return AG2V_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     float* wv = workspace;
     int msplit = 1;
     const int rb = ceil_div(R, 256);
-    if (rb < 256 && M >= 64) { msplit = ceil_div(512, rb); if (msplit > M / 16) msplit = M / 16; if (msplit < 1) msplit = 1; }
+    if (rb < 256 && M >= 64 && !det) { msplit = ceil_div(512, rb); if (msplit > M / 16) msplit = M / 16; if (msplit < 1) msplit = 1; }
     const int mchunk = ceil_div(M, msplit);
     msplit = ceil_div(M, mchunk);
     for (int t = 0; t < T; ++t) {
@@ -361,6 +365,10 @@ extern "C" int ag2v_sn_group_combine(const float* G, const float* w, const float
     if (hipMemsetAsync(dscale, 0, (size_t)T * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
     long long nb = ceil_div(n, 1024LL);
     if (nb > 2048) nb = 2048;
+    // accumulate is a flag word: AG2V_ACCUMULATE (1) | AG2V_DETERMINISTIC (2: ONE block walks the whole weight, so each dscale[t] is
+    // one ordered sum and receives a single add -- slow (one CU), meant for verification runs)
+    if (accumulate & 2) nb = 1;
+    accumulate &= 1;
     for (int t0 = 0; t0 < T; t0 += 16) {
         const int Tn = (T - t0 < 16) ? T - t0 : 16;
         hipLaunchKernelGGL(sn_group_combine_kernel, dim3((unsigned)nb), dim3(256), 0, st, G, w, scale, t0, Tn, n, dw, dscale,
@@ -420,7 +428,8 @@ __device__ __forceinline__ int sn_find(const SnDesc* d, int n, int key, bool by_
     }
     return lo;
 }
-__global__ __launch_bounds__(256) void sn_multi_wtu_kernel(const SnDesc* __restrict__ descs, int n) {
+// det: the blocks of row chunk 0 walk ALL rows of their 256 columns and store the sum (the other row chunks exit): no atomics
+__global__ __launch_bounds__(256) void sn_multi_wtu_kernel(const SnDesc* __restrict__ descs, int n, int det) {
     const int li = sn_find(descs, n, blockIdx.x, false);
     const SnDesc d = descs[li];
     const int local = blockIdx.x - d.blk0;
@@ -428,6 +437,13 @@ __global__ __launch_bounds__(256) void sn_multi_wtu_kernel(const SnDesc* __restr
     const int cb = local % rb, mc = local / rb;
     const int r = cb * 256 + threadIdx.x;
     if (r >= d.R) return;
+    if (det) {
+        if (mc != 0) return;
+        float s = 0.f;
+        for (int m = 0; m < d.M; ++m) s += d.w[(size_t)m * d.R + r] * d.u[m];
+        d.vtmp[r] = s;
+        return;
+    }
     const int m0 = mc * 64, m1 = min(d.M, m0 + 64);
     float s = 0.f;
     for (int m = m0; m < m1; ++m) s += d.w[(size_t)m * d.R + r] * d.u[m];
@@ -480,12 +496,12 @@ extern "C" size_t ag2v_sn_desc_bytes(void) { return sizeof(SnDesc); }
 // ceil(R/256) * ceil(M/64) and of M), total_blocks / total_rows their totals; the vtmp scratch of every layer must be zero on entry
 // (it is left zero on exit).  Runs T training-mode power iterations of every layer.
 extern "C" int ag2v_spectral_sigmas_multi(const void* descs, int n_layers, int total_blocks, int total_rows, int T, float eps,
-                                          void* stream) {
+                                          int deterministic, void* stream) {
     if (!descs || n_layers <= 0 || total_blocks <= 0 || total_rows <= 0 || T <= 0) return AG2V_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const SnDesc* d = (const SnDesc*)descs;
     for (int t = 0; t < T; ++t) {
-        hipLaunchKernelGGL(sn_multi_wtu_kernel, dim3(total_blocks), dim3(256), 0, st, d, n_layers);
+        hipLaunchKernelGGL(sn_multi_wtu_kernel, dim3(total_blocks), dim3(256), 0, st, d, n_layers, deterministic ? 1 : 0);
         hipLaunchKernelGGL(sn_multi_wv_kernel, dim3(ceil_div(total_rows, 4)), dim3(256), 0, st, d, n_layers, total_rows);
         hipLaunchKernelGGL(sn_multi_sigma_kernel, dim3(n_layers), dim3(256), 0, st, d, t, eps);
     }

@@ -65,7 +65,8 @@ class TrainStep(object):
         # net's forward recurrence (AG2VideoModel.forward) and the discriminator's layout terms, forward here and backward at
         # the tail of the discriminator's backward pass (autograd runs a node on the stream its forward ran on).
         self.side_stream = None
-        if torch.device(device).type == 'cuda' and os.environ.get('AG2V_NO_SIDE_STREAM') is None:
+        # (deterministic mode keeps everything on one stream: two streams accumulating gradients interleave in a varying order)
+        if torch.device(device).type == 'cuda' and os.environ.get('AG2V_NO_SIDE_STREAM') is None and not ops.is_deterministic():
             self.side_stream = torch.cuda.Stream(device=device)
             self.model.side_stream = self.side_stream
             # (graph-net parameters of D receive gradients from nodes of both streams)

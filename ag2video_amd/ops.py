@@ -75,6 +75,44 @@ def conv_precision(name):
         _PRECISION[0] = old
 
 
+# ---- deterministic reductions (ag2v_conv_opts::deterministic, AG2V_DETERMINISTIC).  Default off: split-K / split-pixel partial sums
+# meet in fp32 atomics, whose order -- and therefore the last bits of every sum -- changes from run to run.  On: forward / data
+# gradient never split a tile's reduction, the weight gradient writes its partials to a workspace and adds them in order, the
+# bias-gradient sums, the spectral-norm power iteration and the per-group scale gradients run without atomics.  Two runs of the same
+# step are then bit-identical (tests/test_fullsize_gpu.py).  One exception: the image gradient of flow_warp (scatter-add; only needed
+# when the previous frame is a generated one: test_mode / bp_prev, not the teacher-forced training step).
+_DETERMINISTIC = [os.environ.get('AG2V_DETERMINISTIC', '0') not in ('', '0')]
+
+
+def set_deterministic(flag):
+    _DETERMINISTIC[0] = bool(flag)
+
+
+def is_deterministic():
+    return _DETERMINISTIC[0]
+
+
+class deterministic(object):
+    """Context manager: operators called inside use the deterministic (atomic-free, ordered) reductions; the flag travels with
+    every call (per-call options of the C ABI), nothing process-wide changes in the library."""
+
+    def __init__(self, flag=True):
+        self.flag = bool(flag)
+
+    def __enter__(self):
+        self.old = _DETERMINISTIC[0]
+        _DETERMINISTIC[0] = self.flag
+        return self
+
+    def __exit__(self, *exc):
+        _DETERMINISTIC[0] = self.old
+        return False
+
+
+def _det_bit():
+    return 2 if _DETERMINISTIC[0] else 0
+
+
 # ---- optional per-launch timing of the convolution kernels (bench.py's roofline leg): HIP events on the launch stream
 _TIMING = None
 
@@ -162,11 +200,19 @@ def _conv_label(mode, M, min_rows=None):
 
 
 def _conv_launch(min_rows, name, label, flops, *args, shape=None, gscale=None, group_n=1, in_split=False, dy_split=False,
-                 out_split=False):
+                 out_split=False, det_ws_query=None):
     """One ag2v_conv2d_*_ex call.  Arithmetic (precision, bf16x3 row threshold: ``min_rows``, None = library default) and the
     per-sample-group output scale travel as per-call options (ag2v_conv_opts): no process-wide switch is touched."""
     opts = _lib.ConvOpts(_PRECISION[0], int(min_rows) if min_rows else 0, None if gscale is None else gscale.data_ptr(),
-                         int(group_n), None, 1 if in_split else 0, 1 if dy_split else 0, 1 if out_split else 0)
+                         int(group_n), None, 1 if in_split else 0, 1 if dy_split else 0, 1 if out_split else 0,
+                         1 if _DETERMINISTIC[0] else 0, None, 0)
+    det_ws = None
+    if _DETERMINISTIC[0] and det_ws_query is not None:      # weight gradient: slabs for the ordered reduction of its pixel-range splits
+        dev, qargs = det_ws_query
+        n = _lib.query('ag2v_conv2d_wgrad_det_workspace_floats', *qargs, ctypes.byref(opts))
+        if n:
+            det_ws = torch.empty(n, device=dev, dtype=torch.float32)
+            opts.det_workspace, opts.det_workspace_floats = det_ws.data_ptr(), n
     args = args + (ctypes.byref(opts),)
     if _TIMING is None or _PAUSED:
         _lib.call(name, *args)
@@ -393,7 +439,8 @@ def _conv_wgrad_launch(mr, dy, x, dw, K, R, S, stride, pad, acc, groups=1, in_sp
     N, C, H, W = x.shape
     _conv_launch(mr, 'ag2v_conv2d_wgrad_ex', 'conv_wgrad', 2.0 * N * K * dy.shape[2] * dy.shape[3] * C * R * S,
                  _ptr(dy), _ptr(x), _ptr(dw), N, C, H, W, K, R, S, stride, pad, 1 if acc else 0, int(groups), _stream(),
-                 shape=(N, C, H, W, K, R, stride), in_split=in_split, dy_split=dy_split)
+                 shape=(N, C, H, W, K, R, stride), in_split=in_split, dy_split=dy_split,
+                 det_ws_query=(x.device, (N, C, H, W, K, R, S, stride, pad, int(groups))))
 
 
 class _Conv2d(torch.autograd.Function):
@@ -462,7 +509,7 @@ class _Conv2d(torch.autograd.Function):
             _conv_wgrad_launch(mr, dy, x, G, K, R, S, stride, pad, 0, groups=T, in_split=ctx.x_split, dy_split=dys)
             buf, acc, dw = _wsink_take(ctx.wkey, w) if ctx.needs_input_grad[1] else (torch.empty_like(w), 0, None)
             dgs = torch.empty(T, device=dy.device, dtype=torch.float32)
-            _lib.call('ag2v_sn_group_combine', _ptr(G), _ptr(w), _ptr(gscale), T, w.numel(), _ptr(buf), acc, _ptr(dgs), st)
+            _lib.call('ag2v_sn_group_combine', _ptr(G), _ptr(w), _ptr(gscale), T, w.numel(), _ptr(buf), acc | _det_bit(), _ptr(dgs), st)
             if not ctx.needs_input_grad[4]:
                 dgs = None
         elif ctx.needs_input_grad[1]:
@@ -493,7 +540,7 @@ class _Conv2d(torch.autograd.Function):
             else:
                 if dys:
                     raise RuntimeError("conv2d backward: split-word gradient without its channel sums")
-                _lib.call('ag2v_channel_sum_acc', _ptr(dy), _ptr(bbuf), N, K, dy.shape[2] * dy.shape[3], bacc, st)
+                _lib.call('ag2v_channel_sum_acc', _ptr(dy), _ptr(bbuf), N, K, dy.shape[2] * dy.shape[3], bacc | _det_bit(), st)
         if has_res and ctx.needs_input_grad[3]:
             dres = dy
         return dx, dw, db, dres, dgs, None, None, None, None, None, None, None
@@ -621,7 +668,7 @@ class _ConvSharedInput(torch.autograd.Function):
                 _conv_wgrad_launch(mr, dy, x, buf, K, R, S, stride, pad, acc, in_split=ctx.x_split, dy_split=dys_split)
             if has_b[i] and ctx.needs_input_grad[8 + 2 * i]:
                 bbuf, bacc, db = _wsink_take(ctx.bkeys[i], ctx.w_alive[2 * i + 1])
-                _lib.call('ag2v_channel_sum_acc_s', _ptr(dy), _ptr(bbuf), N, K, dy.shape[2] * dy.shape[3], bacc, 1 if dys_split else 0, st)
+                _lib.call('ag2v_channel_sum_acc_s', _ptr(dy), _ptr(bbuf), N, K, dy.shape[2] * dy.shape[3], bacc | _det_bit(), 1 if dys_split else 0, st)
             grads += [dw, db]
         dyc = None
         if merged_w:
@@ -688,7 +735,7 @@ class _SpectralWeight(torch.autograd.Function):
         need = ctx.needs_input_grad[0]
         uv = torch.empty(M + R, device=w.device, dtype=torch.float32) if need else None
         u_used, v_used = (uv[:M], uv[M:]) if need else (None, None)
-        _lib.call('ag2v_spectral_norm_fwd_save', _ptr(w), _ptr(u), _ptr(v), M, R, float(eps), 1 if training else 0,
+        _lib.call('ag2v_spectral_norm_fwd_save', _ptr(w), _ptr(u), _ptr(v), M, R, float(eps), (1 if training else 0) | _det_bit(),
                   _ptr(wbar), _ptr(sigma), _ptr(u_used), _ptr(v_used), _ptr(ws), _stream())
         ctx.save_for_backward(wbar, u_used, v_used, sigma)
         # weight_orig is used by every frame pass of a step: one gradient buffer per backward pass (see _wsink_*)
@@ -733,7 +780,7 @@ class _SpectralScales(torch.autograd.Function):
         uv = torch.empty(T * (M + R), device=w.device, dtype=torch.float32) if need else None
         u_used, v_used = (uv[:T * M], uv[T * M:]) if need else (None, None)
         ws = torch.empty(_lib.query('ag2v_spectral_workspace_floats', M), device=w.device, dtype=torch.float32)
-        _lib.call('ag2v_spectral_sigmas', _ptr(w), _ptr(u), _ptr(v), M, R, float(eps), 1 if training else 0, T, _ptr(sigma),
+        _lib.call('ag2v_spectral_sigmas', _ptr(w), _ptr(u), _ptr(v), M, R, float(eps), (1 if training else 0) | _det_bit(), T, _ptr(sigma),
                   _ptr(scale), _ptr(u_used), _ptr(v_used), _ptr(ws), _stream())
         ctx.save_for_backward(u_used, v_used, scale)
         ctx.cfg = (T, M, R)
@@ -815,7 +862,8 @@ class _SpectralScalesMulti(torch.autograd.Function):
     @staticmethod
     def forward(ctx, bank, T, eps, *w_origs):
         _chk(*w_origs)
-        _lib.call('ag2v_spectral_sigmas_multi', _ptr(bank.desc), len(w_origs), bank.total_blocks, bank.total_rows, T, eps, _stream())
+        _lib.call('ag2v_spectral_sigmas_multi', _ptr(bank.desc), len(w_origs), bank.total_blocks, bank.total_rows, T, eps,
+                  1 if _DETERMINISTIC[0] else 0, _stream())
         bank.version += 1
         ctx.bank, ctx.version, ctx.T = bank, bank.version, T
         ctx.okeys = [(_wsink_register(w) if (ctx.needs_input_grad[3 + i] and _EXTRA_SINKS) else None) for i, w in enumerate(w_origs)]
@@ -1307,7 +1355,7 @@ class _LayoutConvImg(torch.autograd.Function):
             _conv_wgrad_launch(mr, dout, img, G, K, R, R, 1, pad, 0, groups=T)
             buf, acc, dw = _wsink_take(ctx.wkey, w_img) if ctx.needs_input_grad[4] else (torch.empty_like(w_img), 0, None)
             dgs = torch.empty(T, device=dout.device, dtype=torch.float32)
-            _lib.call('ag2v_sn_group_combine', _ptr(G), _ptr(w_img), _ptr(gscale), T, w_img.numel(), _ptr(buf), acc, _ptr(dgs), st)
+            _lib.call('ag2v_sn_group_combine', _ptr(G), _ptr(w_img), _ptr(gscale), T, w_img.numel(), _ptr(buf), acc | _det_bit(), _ptr(dgs), st)
             if not ctx.needs_input_grad[5]:
                 dgs = None
         elif ctx.needs_input_grad[4]:

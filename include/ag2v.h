@@ -47,7 +47,14 @@ extern "C" {
  *   dy_split:  (data gradient, weight gradient) the same for the output gradient dy (written split by ag2v_norm_bwd_gs /
  *              ag2v_spade_pair_bwd_s); only where ag2v_conv2d_split_dy_ok() says so;
  *   out_split: (forward, bf16x3 path, no residual) the result is stored as split words by the epilogue -- for an activation that
- *              only convolutions taking in_split read (SPADE: relu(mlp_shared(seg)) feeds the gamma | beta convolution). */
+ *              only convolutions taking in_split read (SPADE: relu(mlp_shared(seg)) feeds the gamma | beta convolution);
+ *   deterministic: != 0: bit-reproducible results -- NO floating-point atomics.  Forward / data gradient: the reduction of an output
+ *              tile is never split over workgroups (small maps run on fewer CUs).  Weight gradient: every pixel-range split of a
+ *              launch stores its partial gradient into det_workspace and an ordered pass adds the partials (and, when accumulating,
+ *              the previous dw) in split order.  The default (0) accumulates split partials with fp32 atomics, whose order varies
+ *              from run to run (~1e-7 relative per sum);
+ *   det_workspace / det_workspace_floats: (weight gradient, deterministic) caller scratch of at least
+ *              ag2v_conv2d_wgrad_det_workspace_floats(...) floats (may be NULL when that returns 0). */
 typedef struct ag2v_conv_opts {
     int precision;
     int min_rows;
@@ -57,6 +64,9 @@ typedef struct ag2v_conv_opts {
     int in_split;
     int dy_split;
     int out_split;
+    int deterministic;
+    float* det_workspace;
+    size_t det_workspace_floats;
 } ag2v_conv_opts;
 /* Defaults of calls without options (process-wide; the product passes options on every call). */
 int ag2v_set_conv_precision(int mode);
@@ -103,15 +113,22 @@ int ag2v_conv2d_dgrad_ex(const float* dy, const float* w, const float* mask, flo
                          float* workspace, size_t workspace_floats, void* stream, ag2v_conv_opts* opts);
 int ag2v_conv2d_wgrad_ex(const float* dy, const float* x, float* dw, int N, int C, int H, int W, int K, int R, int S,
                          int stride, int pad, int accumulate, int groups, void* stream, ag2v_conv_opts* opts);
+size_t ag2v_conv2d_wgrad_det_workspace_floats(int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int groups,
+                                              const ag2v_conv_opts* opts);
 int ag2v_conv2d_split_input_ok(int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int min_rows_fwd,
                                int min_rows_bwd, int precision);
 int ag2v_conv2d_split_dy_ok(int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int min_rows_bwd, int precision);
 /* accumulate != 0: dw += instead of dw = (a weight used by several forward calls of one step collects its gradient in one buffer). */
 int ag2v_conv2d_wgrad_acc(const float* dy, const float* x, float* dw, int N, int C, int H, int W, int K, int R, int S,
                           int stride, int pad, int accumulate, void* stream);
+/* Flag word of the `accumulate` (and, for the spectral-norm entry points, `power_iter`) arguments of the reductions below:
+ * bit 0 = the argument's own meaning (accumulate / run the power iteration), bit 1 = AG2V_DETERMINISTIC: ordered reduction without
+ * floating-point atomics (one workgroup per channel / no row splits / one block) -- slower, bit-reproducible. */
+#define AG2V_ACCUMULATE 1
+#define AG2V_DETERMINISTIC 2
 /* out[c] = sum over n,hw of x[n,c,hw]: conv bias gradient */
 int ag2v_channel_sum(const float* x, float* out, int N, int C, int HW, void* stream);
-/* accumulate != 0: out[c] += ... (one gradient buffer per bias and backward pass; the generator runs once per frame) */
+/* accumulate & 1: out[c] += ... (one gradient buffer per bias and backward pass; the generator runs once per frame); & 2: deterministic */
 int ag2v_channel_sum_acc(const float* x, float* out, int N, int C, int HW, int accumulate, void* stream);
 /* ... over a tensor of split words when x_split != 0 (each value is hi + lo). */
 int ag2v_channel_sum_acc_s(const float* x, float* out, int N, int C, int HW, int accumulate, int x_split, void* stream);
@@ -275,6 +292,7 @@ int ag2v_reduce_bwd(int op, const float* a, const float* b, long long n, const f
 
 /* ---- spectral norm: torch.nn.utils.spectral_norm forward pre-hook (call sites architecture.py:35-39,
  * flows_generator.py:79-85, normalization.py:26-27) ---------------------------------------------------------------- */
+/* power_iter & 1: one in-place power iteration on (u, v) first (training mode); & 2 (AG2V_DETERMINISTIC): W^T u without row splits */
 size_t ag2v_spectral_workspace_floats(int M);
 int ag2v_spectral_norm_fwd(const float* w, float* u, float* v, int M, int R, float eps, int power_iter, float* wbar,
                            float* sigma, float* workspace, void* stream);
@@ -294,7 +312,7 @@ int ag2v_spectral_norm_bwd_acc(const float* dwbar, const float* wbar, const floa
 int ag2v_spectral_sigmas(const float* w, float* u, float* v, int M, int R, float eps, int power_iter, int T, float* sigma,
                          float* inv_sigma, float* u_used, float* v_used, float* workspace, void* stream);
 /* Backward of y_n = scale[g(n)] * conv(x_n, W) from the per-group weight gradients G[T][n] (ag2v_conv2d_wgrad_ex, groups = T):
- * dw[i] (+)= sum_t scale[t] G[t][i];  dscale[t] = <G[t], W>. */
+ * dw[i] (+)= sum_t scale[t] G[t][i];  dscale[t] = <G[t], W>.  accumulate: AG2V_ACCUMULATE | AG2V_DETERMINISTIC (one block, ordered). */
 int ag2v_sn_group_combine(const float* G, const float* w, const float* scale, int T, long long n, float* dw, int accumulate,
                           float* dscale, void* stream);
 /* Backward of scale[t] = 1 / (u_t^T W v_t):  dw[m, r] (+)= sum_t (-dscale[t] scale[t]^2) u_t[m] v_t[r]. */
@@ -306,9 +324,11 @@ int ag2v_spectral_sigmas_bwd(const float* dscale, const float* scale, const floa
  *   { const float* w; float* u; float* v; float* vtmp; float* wv; float* sigma; float* inv_sigma; float* u_used; float* v_used;
  *     int M; int R; int blk0; int row0; }          (ag2v_sn_desc_bytes() bytes each)
  * vtmp[R] / wv[M] are per-layer scratch (vtmp zero on entry, left zero on exit); blk0 / row0 = running sums over the layers of
- * ceil(R/256) * ceil(M/64) and of M; total_blocks / total_rows their totals.  Training mode only (T power iterations). */
+ * ceil(R/256) * ceil(M/64) and of M; total_blocks / total_rows their totals.  Training mode only (T power iterations).
+ * deterministic != 0: W^T u of a column block by ONE workgroup over all rows (stores, no atomics across row chunks). */
 size_t ag2v_sn_desc_bytes(void);
-int ag2v_spectral_sigmas_multi(const void* descs, int n_layers, int total_blocks, int total_rows, int T, float eps, void* stream);
+int ag2v_spectral_sigmas_multi(const void* descs, int n_layers, int total_blocks, int total_rows, int T, float eps, int deterministic,
+                               void* stream);
 
 /* ---- fused Adam over a flat fp32 buffer: torch.optim.Adam as configured at scripts/train.py:365-368 and
  * meta_models.py:70-72 (weight_decay 0, amsgrad off); step_index >= 1 --------------------------------------------- */

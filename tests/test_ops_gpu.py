@@ -4,6 +4,8 @@ forward and backward, on seeded inputs.
 Tolerance (stated once): max|got - ref| <= TOL * max|ref| with TOL = 2e-4 for every tensor compared -- an order tighter
 than BASELINE.json's 1e-3 relative fp32 bound, so that errors cannot pile up across the ~100 layers of the step.
 """
+import contextlib
+
 import pytest
 import torch
 
@@ -836,6 +838,97 @@ def test_direct_param_grads_only_inside_the_accumulating_context(device):
     with ops.accumulate_into_param_grads():
         loss().backward()
     assert hooked, "a post-accumulate-grad hook must still fire (the direct path steps aside for hooked parameters)"
+
+
+# ------------------------------------------------------------------------------------------------ deterministic reductions
+DET_CASES = [
+    # N, C, H, K, R, stride, pad, groups, what exercises it
+    (2, 1024, 8, 1024, 3, 1, 1, 1),      # small map: forward / data gradient normally split K over workgroups (atomics)
+    (6, 64, 64, 128, 3, 1, 1, 3),        # 24k pixels: the weight gradient splits its pixel range; 3 sample groups (spectral-norm form)
+    (4, 128, 33, 256, 4, 2, 2, 1),       # discriminator layer: 4x4 stride 2 (four data-gradient classes), odd size
+    (8, 16, 40, 24, 3, 1, 1, 1),         # 24 rows: the exact-fp32 32-row tiles (forward, data gradient, weight gradient)
+    (3, 259, 24, 64, 4, 2, 2, 1),        # table-path gather (C % 32 != 0), 64-row tiles
+]
+
+
+@pytest.mark.parametrize("case", DET_CASES, ids=lambda c: "x".join(str(v) for v in c))
+@pytest.mark.parametrize("prec", ['bf16x3', 'fp32'])
+def test_conv_deterministic_mode_is_bit_reproducible(case, prec, device):
+    """ops.deterministic(): no floating-point atomics -- forward / data gradient never split a tile's reduction, the weight gradient
+    adds its pixel-range partials from a workspace in order (ag2v_conv_opts::deterministic).  (i) the same call twice gives the same
+    bits, also when accumulating into an existing gradient and with per-group weight gradients; (ii) the results agree with the default
+    (atomic) mode to reduction-order noise and with the oracle at the kernel tolerance."""
+    from ag2video_amd import ops
+    from oracle import kernels as K
+    N, C, H, Ko, R, st, pad, groups = case
+    x0 = _rand(N, C, H, H, seed=1)
+    w0 = _rand(Ko, C, R, R, seed=2, scale=(C * R * R) ** -0.5)
+    b0 = _rand(Ko, seed=3)
+    gs0 = (torch.rand(groups, generator=torch.Generator().manual_seed(4)) + 0.5) if groups > 1 else None
+
+    def run(mod, dev, det):
+        x = x0.clone().to(dev).requires_grad_(True)
+        w = w0.clone().to(dev).requires_grad_(True)
+        b = b0.clone().to(dev).requires_grad_(True)
+        gs = None if gs0 is None else gs0.clone().to(dev).requires_grad_(True)
+        ctx = ops.deterministic(det) if mod is ops else contextlib.nullcontext()
+        with ctx, (ops.bf16x3_min_rows(48) if mod is ops else contextlib.nullcontext()):
+            y = mod.conv2d(x, w, b, st, pad, gscale=gs)
+            dy = _rand(*y.shape, seed=5).to(dev)
+            # two uses of the weight in one graph: the second weight-gradient launch ACCUMULATES into the first one's buffer
+            y2 = mod.conv2d(x * 0.5, w, None, st, pad, gscale=gs)
+            ((y * dy).sum() + (y2 * dy).sum() * 0.25).backward()
+        return [t.detach().clone() for t in (y, x.grad, w.grad, b.grad)] + ([gs.grad.detach().clone()] if gs is not None else [])
+    old = ops.get_conv_precision()
+    ops.set_conv_precision(prec)
+    try:
+        a = run(ops, device, True)
+        b = run(ops, device, True)
+        c = run(ops, device, False)
+    finally:
+        ops.set_conv_precision(old)
+    ref = run(K, 'cpu', False)
+    names = ['y', 'dx', 'dw', 'db', 'dgscale']
+    for n, ta, tb, tc, tr in zip(names, a, b, c, ref):
+        assert torch.equal(ta, tb), "deterministic mode: %s differs between two runs" % n
+        _cmp('det.%s vs default mode' % n, ta, tc.cpu(), 2e-5)
+        _cmp('det.%s vs oracle' % n, ta, tr, TOL)
+
+
+def test_spectral_bank_and_train_step_deterministic(device):
+    """The remaining reductions with atomics in the default mode -- the multi-layer power iteration (W^T u over row chunks), the per-group
+    scale gradients (sn_group_combine), the bias-gradient channel sums -- through one toy training iteration: with ops.deterministic()
+    two runs from the same state give bit-identical outputs, losses, gradients and updated state (the engine then also keeps the graph
+    nets on the main stream)."""
+    from ag2video_amd import ops
+    from ag2video_amd.data.args import make_opt
+    from ag2video_amd.data.synthetic import make_clip_batch
+    from ag2video_amd.data.vocab import cater_vocab
+    from ag2video_amd.engine import TrainStep
+    flags = ['--no_vgg_loss', '--image_size', '64,64', '--batch_size', '2', '--ngf', '16', '--ndf', '16', '--nff', '16',
+             '--gconv_hidden_dim', '64', '--gpu_ids', '0']
+    res = []
+    with ops.deterministic():
+        for rep in range(2):
+            opt = make_opt(cater_vocab(), flags)
+            ts = TrainStep(opt, device, weights_seed=5)
+            assert ts.side_stream is None
+            clip = ts.to_device(make_clip_batch(opt.vocab, 2, 4, (64, 64), seed=11))
+            out, GL, DL = ts.gd_step(clip, apply_updates=False)
+            gG, gD = ts.optimizer_generator.flat_grad.clone(), ts.discriminator.optimizer_d_img.flat_grad.clone()
+            ts.gd_step(clip)
+            _, GG = ts.graph_step(ts.to_device(make_clip_batch(opt.vocab, 2, 8, (64, 64), seed=12)))
+            torch.cuda.synchronize()
+            res.append(([t.clone() for t in out[:3]], {k: float(v) for k, v in list(GL.items()) + list(DL.items()) + list(GG.items())}, gG, gD,
+                        {k: v.clone() for k, v in ts.model.state_dict().items()}))
+            del ts
+    (o0, l0, gG0, gD0, s0), (o1, l1, gG1, gD1, s1) = res
+    assert l0 == l1, (l0, l1)
+    for a, b in zip(o0, o1):
+        assert torch.equal(a, b)
+    assert torch.equal(gG0, gG1) and torch.equal(gD0, gD1)
+    bad = [k for k in s0 if not torch.equal(s0[k], s1[k])]
+    assert not bad, bad[:10]
 
 
 # ------------------------------------------------------------------------------------------------ frame-group forms
