@@ -106,6 +106,9 @@ def build_parser():
     a('--train_list', default=None, type=str)
     a('--data_nframes', default=301, type=int, help='frames per video in --data_root')
     a('--vgg_weights', default=None, type=str, help='torchvision vgg19 state dict (.pth) for the perceptual loss')
+    a('--temporal_D', default=0, type=int, help='1: add the temporal multiscale PatchGAN (reference discriminator.py:16-87: the frames of a '
+      'window stacked into the channels of a 2-D PatchGAN; the reference constructs it nowhere) with hinge + feature-matching terms '
+      'over non-overlapping windows of frames_per_action generated frames (BASELINE "3-D PatchGAN" row D4)')
     a('--vgg_random_init', action='store_true', help='explicit opt-in: run the perceptual loss on a RANDOMLY initialised VGG19 (throughput / parity runs; not a training objective)')
     return p
 

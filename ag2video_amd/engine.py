@@ -34,6 +34,8 @@ class TrainStep(object):
             from .weights import closed_form_fill_
             closed_form_fill_(self.model, seed=weights_seed, prefix='G.')
             closed_form_fill_(self.discriminator.img_discriminator, seed=weights_seed, prefix='D.')
+            if hasattr(self.discriminator, 'temporal_discriminator'):
+                closed_form_fill_(self.discriminator.temporal_discriminator, seed=weights_seed, prefix='T.')
             # (weights loaded through --vgg_weights are the objective: the closed-form filler only replaces a random init)
             if hasattr(self.gans_model.module, 'criterionVGG') and not getattr(self.gans_model.module, 'vgg_weights_loaded', False):
                 closed_form_fill_(self.gans_model.module.criterionVGG, seed=weights_seed, prefix='V.')
@@ -52,13 +54,12 @@ class TrainStep(object):
         self.optimizer_graph = Adam(graph_params, lr=lr, betas=(b1, 0.999))
         self.optimizer_generator = Adam(gen_params, lr=lr, betas=(b1, 0.999))
         # the discriminator's Adam was built before .to(device); rebuild it over the moved parameters
-        self.discriminator.optimizer_d_img = Adam(list(self.discriminator.img_discriminator.parameters()),
-                                                  lr=lr, betas=(b1, 0.999))
+        self.discriminator.optimizer_d_img = Adam(self.discriminator.d_parameters(), lr=lr, betas=(b1, 0.999))
         self._gen_params, self._graph_params = gen_params, graph_params
         # bench.py (N > 1): HIP event pairs around the join of the generator's asynchronous all-reduce (= the time the compute stream
         # stalls for it: the EXPOSED part) and around the discriminator's synchronous one; None = not recorded
         self.comm_events = None
-        self._d_params = list(self.discriminator.img_discriminator.parameters())
+        self._d_params = self.discriminator.d_parameters()
         for m in (self.model, self.discriminator):
             m.train()
         # Second HIP stream for the launch-latency-bound graph nets whose results nothing on the main stream waits for: the box

@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 
 from .graph_models.model import models
-from .spade_models.networks.discriminator import MultiscaleActionDiscriminator
+from .spade_models.networks.discriminator import MultiscaleActionDiscriminator, MultiscaleDiscriminatorT
 from .spade_models.networks.generator import Layout2VidGenerator
 from .spade_models.networks.sync_batchnorm import DataParallelWithCallback
 
@@ -68,5 +68,19 @@ class MetaDiscriminatorModel(nn.Module):
         self.img_discriminator = MultiscaleActionDiscriminator(opt)
         self.img_discriminator.float()
         self.img_discriminator.train()
-        self.optimizer_d_img = torch.optim.Adam(list(self.img_discriminator.parameters()), lr=opt.learning_rate,
-                                                betas=(opt.beta1, 0.999))
+        params = list(self.img_discriminator.parameters())
+        if getattr(opt, 'temporal_D', 0):
+            # --temporal_D 1: the reference's temporal discriminator classes (discriminator.py:16-87), which its own
+            # MetaDiscriminatorModel never constructs (meta_models.py:66-67).  Same Adam as the image discriminator.
+            self.temporal_discriminator = MultiscaleDiscriminatorT(opt)
+            self.temporal_discriminator.float()
+            self.temporal_discriminator.train()
+            params += list(self.temporal_discriminator.parameters())
+        self.optimizer_d_img = torch.optim.Adam(params, lr=opt.learning_rate, betas=(opt.beta1, 0.999))
+
+    def d_parameters(self):
+        """Everything optimizer_d_img owns: the image discriminator (+ the temporal one with --temporal_D 1)."""
+        ps = list(self.img_discriminator.parameters())
+        if hasattr(self, 'temporal_discriminator'):
+            ps += list(self.temporal_discriminator.parameters())
+        return ps

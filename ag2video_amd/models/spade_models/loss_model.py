@@ -34,6 +34,7 @@ class LossModel(torch.nn.Module):
         self.discriminator = discriminator
         if hasattr(discriminator, 'img_discriminator'):
             self.netD_img = discriminator.img_discriminator
+        self.netD_tmp = getattr(discriminator, 'temporal_discriminator', None)       # --temporal_D 1 (meta_models.py)
         self.criterionGAN = GANLoss(opt.gan_mode, opt=opt)
         if not opt.no_vgg_loss:
             # loss_model.py:35-36.  The reference downloads ImageNet weights through torchvision; there is no network here: the
@@ -141,6 +142,16 @@ class LossModel(torch.nn.Module):
         G['total_loss'] = torch.stack(list(G.values()), dim=0).sum()
         return G
 
+    def _temporal_windows(self, x):
+        """[B, T, 3, H, W] -> [B * (T // fpa), fpa, 3, H, W]: non-overlapping windows of frames_per_action consecutive frames (the
+        temporal discriminator's input is frames_per_action * 3 channels, discriminator.py:46-47; a remainder is dropped)."""
+        fpa = self.opt.frames_per_action
+        B, T = x.shape[0], x.shape[1]
+        nw = T // fpa
+        if nw < 1:
+            raise RuntimeError("--temporal_D 1 needs at least frames_per_action = %d frames after the first n_frames_G - 1; got %d" % (fpa, T))
+        return x[:, :nw * fpa].reshape((B * nw, fpa) + tuple(x.shape[2:]))
+
     def compute_generator_loss(self, batch, model_out):
         imgs, objs, boxes, triplets, actions, video_id = batch
         imgs_pred, boxes_pred, flows_pred, conf_pred, actions_data = model_out
@@ -166,6 +177,18 @@ class LossModel(torch.nn.Module):
                 for j in range(len(fake[i]) - 1):
                     feat = feat + ops.l1_mean(fake[i][j], real[i][j].detach()) * self.opt.lambda_feat / num_D
             G['GAN_Feat'] = feat.squeeze(0)
+        if self.netD_tmp is not None:       # temporal PatchGAN over frame windows: the image discriminator's two terms once more
+            with _params_frozen(self.netD_tmp):
+                fake_t = self.netD_tmp(self._temporal_windows(r_pred))
+            G['GAN_Tmp'] = self.criterionGAN(fake_t, True, for_discriminator=False).squeeze(0) * self.opt.discriminator_img_loss_weight
+            if not self.opt.no_ganFeat_loss:
+                with torch.no_grad():
+                    real_t = self.netD_tmp(self._temporal_windows(r_imgs))
+                feat = torch.zeros(1, device=imgs.device, dtype=torch.float32)
+                for i in range(len(fake_t)):
+                    for j in range(len(fake_t[i]) - 1):
+                        feat = feat + ops.l1_mean(fake_t[i][j], real_t[i][j].detach()) * self.opt.lambda_feat / len(fake_t)
+                G['GAN_Tmp_Feat'] = feat.squeeze(0)
         b, t, c, h, w = imgs.size()
         prev = imgs[:, nc - 1:-1].contiguous().view(-1, c, h, w)
         nxt = imgs[:, nc:].contiguous().view(-1, c, h, w)
@@ -187,6 +210,9 @@ class LossModel(torch.nn.Module):
         real = self.netD_img(imgs[:, nc:], objs, boxes[:, nc:], r_adata, **kw)
         D = {"D_img_fake": self.criterionGAN(fake, False, for_discriminator=True),
              "D_img_real": self.criterionGAN(real, True, for_discriminator=True)}
+        if self.netD_tmp is not None:
+            D["D_tmp_fake"] = self.criterionGAN(self.netD_tmp(self._temporal_windows(imgs_pred[:, nc:].detach())), False, for_discriminator=True)
+            D["D_tmp_real"] = self.criterionGAN(self.netD_tmp(self._temporal_windows(imgs[:, nc:])), True, for_discriminator=True)
         D["total_img_loss"] = torch.stack(list(D.values()), dim=0).sum()
         return D
 

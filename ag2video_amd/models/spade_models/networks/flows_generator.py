@@ -74,7 +74,7 @@ class FlowsGenerator(nn.Module):
                     vecs_list, boxes_list, keep, H = layout
                     conv, bn = m[0], m[1]
                     T = ops.current_frame_groups()
-                    if T > 1:       # frame-batched: raw weight, 1/sigma_t per frame group (SpectralConv2d.weight_and_scales)
+                    if T > 1 or conv.training:      # raw weight, 1/sigma_t per frame group (SpectralConv2d.forward: one form in training)
                         w, scales = conv.weight_and_scales()
                         per_sample = scales.repeat_interleave(prev.shape[0] // scales.numel())
                     else:

@@ -147,7 +147,13 @@ class Layout2VidGenerator(nn.Module):
             flows.append(flow)
             # Image decoder: 64-channel layers on the bf16x3 tiles too (the flow network above stays exact in its forward).
             with ops.bf16x3_min_rows(48):
-                if low_rank:
+                if low_rank and conv.training:       # the frame-batched pass's formulation with one group (SpectralConv2d.forward)
+                    w, scales = conv.weight_and_scales()
+                    nseg = w.shape[1] - 3
+                    y = layout_conv_lowrank(w[:, :nseg], spec[0], spec[1], keep, H, H, conv.stride, conv.padding,
+                                            sample_scale=scales.repeat_interleave(warp.shape[0] // scales.numel()),
+                                            img=warp, w_img=w[:, nseg:], gscale=scales)
+                elif low_rank:
                     w = conv.effective_weight()
                     nseg = w.shape[1] - 3
                     y = layout_conv_lowrank(w[:, :nseg], spec[0], spec[1], keep, H, H, conv.stride, conv.padding,

@@ -48,7 +48,11 @@ class SpectralConv2d(nn.Module):
                                                      self.training, self.eps)
 
     def forward(self, x, residual=None):
-        if ops.current_frame_groups() > 1:
+        # Training: ONE formulation for the frame-batched pass (T groups) and a single call (T = 1) -- the raw weight_orig in the
+        # GEMM and 1 / sigma_t applied to the product in the epilogue.  (conv(x, W / sigma) and conv(x, W) / sigma differ in the last
+        # bit; with both paths on the same form the frame-batched and the sequential generator agree bit for bit in deterministic
+        # mode, tests/test_fullsize_gpu.py.)  Eval: W / sigma without a power iteration.
+        if self.training or ops.current_frame_groups() > 1:
             w, scales = self.weight_and_scales()
             return ops.conv2d(x, w, self.bias, self.stride, self.padding, residual, gscale=scales)
         return ops.conv2d(x, self.effective_weight(), self.bias, self.stride, self.padding, residual)

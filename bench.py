@@ -155,6 +155,7 @@ def main():
     ap.add_argument('--precision', default='bf16x3', choices=['bf16x3', 'fp32'],
                     help='arithmetic of the 128-row conv MFMA tiles (both hold the 1e-3 parity bound; tests/test_step_gpu.py)')
     ap.add_argument('--no-fp32-leg', action='store_true', help='skip the extra exact-fp32 step used for roofline_exact_fp32')
+    ap.add_argument('--temporal-D', action='store_true', help='--temporal_D 1: the temporal multiscale PatchGAN on top of the image discriminator (not BASELINE.json\'s metric; reported in config.workload)')
     args = ap.parse_args()
     if args.cpu_baseline_only:
         cpu_baseline_child()
@@ -171,6 +172,7 @@ def main():
     device = torch.device('cuda', local)
     opt, side, frames, batch = make_opt(args.config)
     opt.gpu_ids = [local]
+    opt.temporal_D = 1 if args.temporal_D else 0
     ops.set_conv_precision(args.precision)
     ts = TrainStep(opt, device, weights_seed=0)
     clip = ts.to_device(make_clip(opt, args.config, batch, frames, side, seed=1234 + rank))
@@ -380,8 +382,8 @@ def main():
         "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": ("f32 (conv products as 3-term bf16 splits on the bf16 MFMA pipe, fp32 accumulate; everything else fp32)"
                   if args.precision == 'bf16x3' else "f32"), "data": "synthetic CATER-shaped clips (seeded), closed-form random-init weights",
-        "config": {"workload": "%s: %s %dx%d, %d frames, batch %d per GPU, full G+D train step, VGG loss off"
-                   % (args.config, "SSv2-shaped" if args.config == 'c5' else "CATER", side, side, frames, batch), "global_batch": world * batch, "parallelism": "dp%d" % world},
+        "config": {"workload": "%s: %s %dx%d, %d frames, batch %d per GPU, full G+D train step, VGG loss off%s"
+                   % (args.config, "SSv2-shaped" if args.config == 'c5' else "CATER", side, side, frames, batch, ", + temporal discriminator (--temporal_D 1)" if args.temporal_D else ""), "global_batch": world * batch, "parallelism": "dp%d" % world},
         "roofline": roof, "roofline_exact_fp32": roof_fp32, "roofline_hbm": roof_hbm, "roofline_hbm_bwd": roof_hbm_bwd,
         "cpu_baseline": cpu, "comm": comm,
         "extra": {"graph_step_ms": round(graph_ms, 2), "losses_finite": finite,

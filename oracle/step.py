@@ -13,10 +13,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 class OracleTrainer(object):
-    def __init__(self, opt, key_shapes_G, key_shapes_D, wseed, key_shapes_V=None):
+    def __init__(self, opt, key_shapes_G, key_shapes_D, wseed, key_shapes_V=None, key_shapes_T=None):
         self.opt = opt
         self.G = M.make_state(key_shapes_G, wseed, 'G.')
         self.D = M.make_state(key_shapes_D, wseed, 'D.')
+        self.T = M.make_state(key_shapes_T, wseed, 'T.') if key_shapes_T else None      # --temporal_D 1
         self.V = None
         if not opt.no_vgg_loss:           # frozen VGG19 of the perceptual loss (keys 'vgg.slice<k>.<i>.weight|bias')
             self.V = {k: v.detach() for k, v in M.make_state(key_shapes_V, wseed, 'V.').items()}
@@ -25,25 +26,27 @@ class OracleTrainer(object):
         gen_params = [t for n, t in self.G.items() if t.requires_grad and not n.startswith('acts_to_boxes.')]
         self.opt_graph = torch.optim.Adam(graph_params, lr=lr, betas=(b1, 0.999))
         self.opt_gen = torch.optim.Adam(gen_params, lr=lr, betas=(b1, 0.999))
-        self.opt_d = torch.optim.Adam(M.params_of(self.D), lr=lr, betas=(b1, 0.999))
+        self.opt_d = torch.optim.Adam(M.params_of(self.D) + (M.params_of(self.T) if self.T else []), lr=lr, betas=(b1, 0.999))
 
     def gd_step(self, batch, apply_updates=True):
         """G step then D step on one clip batch; returns (model_out, G_losses, D_losses)."""
         opt = self.opt
         imgs, objs, boxes, triplets, actions = batch[:5]
         model_out = M.generator_forward(self.G, opt, imgs, objs, triplets, actions, boxes, training=True, use_gt=True)
-        G_losses = M.generator_loss(self.D, opt, batch, model_out, V=self.V)
+        G_losses = M.generator_loss(self.D, opt, batch, model_out, V=self.V, PT=self.T)
         G_losses = {k: v.mean() for k, v in G_losses.items()}
         self.opt_gen.zero_grad()
         G_losses['total_loss'].backward()
         self.last_G_grads = {n: (None if t.grad is None else t.grad.clone()) for n, t in self.G.items() if t.requires_grad}
         if apply_updates:
             self.opt_gen.step()
-        D_losses = M.discriminator_loss(self.D, opt, batch, model_out)
+        D_losses = M.discriminator_loss(self.D, opt, batch, model_out, PT=self.T)
         D_losses = {k: v.mean() for k, v in D_losses.items()}
         self.opt_d.zero_grad()
         D_losses['total_img_loss'].backward()
         self.last_D_grads = {n: (None if t.grad is None else t.grad.clone()) for n, t in self.D.items() if t.requires_grad}
+        if self.T:
+            self.last_T_grads = {n: (None if t.grad is None else t.grad.clone()) for n, t in self.T.items() if t.requires_grad}
         if apply_updates:
             self.opt_d.step()
         return model_out, G_losses, D_losses

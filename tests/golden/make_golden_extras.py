@@ -140,6 +140,31 @@ def main():
     for k, v in dt.state_dict().items():
         if k.endswith('weight_u'):
             out['dtemp.state.' + k] = v.numpy()
+    # the same classes at 64 x 64 with ndf 16 (round 3: the size of the --temporal_D training-step test)
+    args64 = parser.parse_args(['--gpu_ids', '-1', '--use_cuda', '0', '--no_vgg_loss', '--image_size', '64,64', '--batch_size', '2',
+                                '--ndf', '16', '--frames_per_action', '4'])
+    args64.vocab = vocab
+    init_args(args64)
+    dt64 = MultiscaleDiscriminatorT(args64)
+    closed_form_fill_(dt64, seed=7, prefix='T.')
+    dt64.train()
+    img64 = torch.randn(2, 4, 3, 64, 64, generator=g).requires_grad_(True)
+    res64 = dt64(img64)
+    out['dtemp64.img'] = img64.detach().numpy()
+    tot = 0
+    for i, scale in enumerate(res64):
+        for j, f in enumerate(scale):
+            out['dtemp64.out%d_%d' % (i, j)] = f.detach().numpy()
+            tot = tot + (f * torch.linspace(-1, 1, f.numel()).view_as(f)).sum()
+    tot.backward()
+    out['dtemp64.grad_img'] = img64.grad.numpy()
+    for n, p_ in dt64.named_parameters():
+        if p_.grad is not None:
+            out['dtemp64.grad.' + n] = np.array([p_.grad.double().abs().sum().item(), p_.grad.double().pow(2).sum().sqrt().item()])
+    out['dtemp64.keys'] = np.array(json.dumps({k: list(v.shape) for k, v in dt64.state_dict().items()}))
+    for k, v in dt64.state_dict().items():
+        if k.endswith('weight_u'):
+            out['dtemp64.state.' + k] = v.numpy()
     np.savez_compressed(os.path.join(HERE, 'extras.npz'), **out)
     print('wrote extras.npz with %d arrays, %.1f KB' % (len(out), os.path.getsize(os.path.join(HERE, 'extras.npz')) / 1024))
 

@@ -222,6 +222,8 @@ LAYERS = {
     'c5_up0_28': (2, 1024, 28, 28, 512, 3, 1, 1),
     'c5_D_model0_img_224': (30, 3, 224, 224, 64, 4, 2, 2),     # image part of D's first convolution -> 113 x 113
     'c5_D_model2_57': (30, 128, 57, 57, 256, 4, 2, 2),
+    'c5_Dtmp_model0_224': (6, 48, 224, 224, 64, 4, 2, 2),      # temporal discriminator (--temporal_D 1): a window of 16 frames x 3 channels
+    'c5_Dtmp_model0_fpa4_224': (6, 12, 224, 224, 64, 4, 2, 2),   # ... of frames_per_action = 4 frames (the default width)
 }
 
 

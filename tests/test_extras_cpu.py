@@ -35,31 +35,32 @@ def test_oracle_vgg_loss_matches_reference(gold):
         assert tuple(f.shape[1:3]) == (int(st[2]), int(st[3])) and abs(f.abs().sum().item() - st[1]) <= 1e-4 * st[1]
 
 
-def test_oracle_temporal_discriminator_matches_reference(gold):
+@pytest.mark.parametrize("tag,side,ndf,seed", [('dtemp', 32, 8, 5), ('dtemp64', 64, 16, 7)])
+def test_oracle_temporal_discriminator_matches_reference(gold, tag, side, ndf, seed):
     from ag2video_amd.data.args import make_opt
     from ag2video_amd.data.vocab import cater_vocab
     from oracle import model as M
-    opt = make_opt(cater_vocab(), ['--gpu_ids', '-1', '--no_vgg_loss', '--image_size', '32,32', '--batch_size', '2', '--ndf', '8',
-                                  '--frames_per_action', '4'])
-    shapes = json.loads(str(gold['dtemp.keys']))
-    PT = M.make_state(shapes, 5, 'T.')
-    img = torch.from_numpy(gold['dtemp.img']).requires_grad_(True)
+    opt = make_opt(cater_vocab(), ['--gpu_ids', '-1', '--no_vgg_loss', '--image_size', '%d,%d' % (side, side), '--batch_size', '2',
+                                  '--ndf', str(ndf), '--frames_per_action', '4'])
+    shapes = json.loads(str(gold[tag + '.keys']))
+    PT = M.make_state(shapes, seed, 'T.')
+    img = torch.from_numpy(gold[tag + '.img']).requires_grad_(True)
     res = M.temporal_discriminator_forward(PT, opt, img, training=True)
     tot = 0
     for i, scale in enumerate(res):
         for j, f in enumerate(scale):
-            ref = gold['dtemp.out%d_%d' % (i, j)]
+            ref = gold[tag + '.out%d_%d' % (i, j)]
             assert np.abs(f.detach().numpy() - ref).max() <= 2e-4 * np.abs(ref).max(), (i, j)
             tot = tot + (f * torch.linspace(-1, 1, f.numel()).view_as(f)).sum()
     tot.backward()
-    ref = gold['dtemp.grad_img']
+    ref = gold[tag + '.grad_img']
     assert np.abs(img.grad.numpy() - ref).max() <= 1e-3 * np.abs(ref).max()
     for k, t in PT.items():
         if k.endswith('weight_u'):
-            assert np.abs(t.numpy() - gold['dtemp.state.' + k]).max() <= 1e-5
-        if t.grad is not None and ('dtemp.grad.' + k) in gold.files:
+            assert np.abs(t.numpy() - gold[tag + '.state.' + k]).max() <= 1e-5
+        if t.grad is not None and (tag + '.grad.' + k) in gold.files:
             got = np.array([t.grad.double().abs().sum().item(), t.grad.double().pow(2).sum().sqrt().item()])
-            assert np.allclose(got, gold['dtemp.grad.' + k], rtol=2e-3, atol=1e-6), k
+            assert np.allclose(got, gold[tag + '.grad.' + k], rtol=2e-3, atol=1e-6), k
 
 
 def test_collate_fn_matches_reference(gold):

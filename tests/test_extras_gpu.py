@@ -62,36 +62,81 @@ def test_vgg_loss_matches_reference_golden(prec, gold, device):
         ops.set_conv_precision(old)
 
 
-def test_temporal_discriminator_matches_reference_golden(gold, device):
+@pytest.mark.parametrize("tag,side,ndf,seed", [('dtemp', 32, 8, 5), ('dtemp64', 64, 16, 7)])
+def test_temporal_discriminator_matches_reference_golden(gold, device, tag, side, ndf, seed):
     from ag2video_amd.data.args import make_opt
     from ag2video_amd.data.vocab import cater_vocab
     from ag2video_amd.models.spade_models.networks.discriminator import MultiscaleDiscriminatorT
     from ag2video_amd.weights import closed_form_fill_
-    opt = make_opt(cater_vocab(), ['--gpu_ids', '0', '--no_vgg_loss', '--image_size', '32,32', '--batch_size', '2', '--ndf', '8',
-                                  '--frames_per_action', '4'])
+    opt = make_opt(cater_vocab(), ['--gpu_ids', '0', '--no_vgg_loss', '--image_size', '%d,%d' % (side, side), '--batch_size', '2',
+                                  '--ndf', str(ndf), '--frames_per_action', '4'])
     dt = MultiscaleDiscriminatorT(opt).to(device)
-    assert {k: list(v.shape) for k, v in dt.state_dict().items()} == json.loads(str(gold['dtemp.keys']))
-    closed_form_fill_(dt, seed=5, prefix='T.')
+    assert {k: list(v.shape) for k, v in dt.state_dict().items()} == json.loads(str(gold[tag + '.keys']))
+    closed_form_fill_(dt, seed=seed, prefix='T.')
     dt.train()
-    img = torch.from_numpy(gold['dtemp.img']).to(device).requires_grad_(True)
+    img = torch.from_numpy(gold[tag + '.img']).to(device).requires_grad_(True)
     res = dt(img)
     tot = 0
     for i, scale in enumerate(res):
         for j, f in enumerate(scale):
-            ref = gold['dtemp.out%d_%d' % (i, j)]
+            ref = gold[tag + '.out%d_%d' % (i, j)]
             assert np.abs(f.detach().cpu().numpy() - ref).max() <= 1e-3 * np.abs(ref).max(), (i, j)
             tot = tot + (f * torch.linspace(-1, 1, f.numel(), device=device).view_as(f)).sum()
     tot.backward()
-    ref = gold['dtemp.grad_img']
+    ref = gold[tag + '.grad_img']
     assert np.abs(img.grad.cpu().numpy() - ref).max() <= 2e-3 * np.abs(ref).max()
     for k, v in dt.state_dict().items():
         if k.endswith('weight_u'):
-            assert np.abs(v.cpu().numpy() - gold['dtemp.state.' + k]).max() <= 1e-4, k
+            assert np.abs(v.cpu().numpy() - gold[tag + '.state.' + k]).max() <= 1e-4, k
     for n, p in dt.named_parameters():
-        key = 'dtemp.grad.' + n
+        key = tag + '.grad.' + n
         if p.grad is not None and key in gold.files:
             got = np.array([p.grad.double().abs().sum().item(), p.grad.double().pow(2).sum().sqrt().item()])
             assert np.allclose(got, gold[key], rtol=2e-2, atol=1e-5), n
+
+
+def test_train_step_with_temporal_discriminator_matches_oracle(device):
+    """--temporal_D 1 (D4 reachable): MetaDiscriminatorModel adds the temporal multiscale PatchGAN, LossModel its hinge
+    and feature-matching terms over windows of frames_per_action generated frames, optimizer_d_img owns its parameters.  One full
+    iteration against the oracle (which restates the same terms over its golden-pinned temporal_discriminator_forward): loss keys and
+    values, gradients reaching the temporal discriminator and -- through it -- the generator, its parameters updated."""
+    from ag2video_amd.data.args import make_opt
+    from ag2video_amd.data.synthetic import make_clip_batch
+    from ag2video_amd.data.vocab import cater_vocab
+    from ag2video_amd.engine import TrainStep
+    from oracle.step import OracleTrainer
+    flags = ['--no_vgg_loss', '--image_size', '64,64', '--batch_size', '2', '--ngf', '8', '--ndf', '16', '--nff', '8', '--gconv_hidden_dim', '64',
+             '--gpu_ids', '0', '--temporal_D', '1', '--frames_per_action', '4']
+    opt = make_opt(cater_vocab(), flags)
+    ts = TrainStep(opt, device, weights_seed=6)
+    dt = ts.discriminator.temporal_discriminator
+    assert ts.gans_model.module.netD_tmp is dt
+    assert any(k.startswith('module.netD_tmp.discriminator_0.model0') for k in ts.gans_model.state_dict())
+    n_d = len(list(ts.discriminator.img_discriminator.parameters()))
+    assert len(ts._d_params) == n_d + len(list(dt.parameters()))
+    assert len(ts.discriminator.img_discriminator.state_dict()) == 56                    # the reference's key set is untouched
+    shapes_G = {k: list(v.shape) for k, v in ts.model.state_dict().items()}
+    shapes_D = {k: list(v.shape) for k, v in ts.discriminator.img_discriminator.state_dict().items()}
+    shapes_T = {k: list(v.shape) for k, v in dt.state_dict().items()}
+    orc = OracleTrainer(opt, shapes_G, shapes_D, 6, key_shapes_T=shapes_T)
+    clip = make_clip_batch(opt.vocab, 2, 10, (64, 64), seed=21, max_objs=6)          # 9 generated frames: two windows of 4, one frame dropped
+    p0 = {n: p.detach().clone() for n, p in dt.named_parameters()}
+    _, GL_r, DL_r = orc.gd_step(clip)
+    _, GL, DL = ts.gd_step(ts.to_device(clip))
+    assert set(GL) == set(GL_r) >= {'GAN_Tmp', 'GAN_Tmp_Feat'} and set(DL) == set(DL_r) >= {'D_tmp_fake', 'D_tmp_real'}
+    for got, ref in ((GL, GL_r), (DL, DL_r)):
+        for k in ref:
+            assert abs(got[k].item() - ref[k].item()) <= 1e-3 * max(1.0, abs(ref[k].item())), (k, got[k].item(), ref[k].item())
+    bad = []
+    for n, p in dt.named_parameters():
+        g_ref = orc.last_T_grads.get(n)
+        if g_ref is None:
+            continue
+        got, ref = p.grad.double().abs().sum().item(), g_ref.double().abs().sum().item()
+        if abs(got - ref) > 2e-2 * ref + 2e-6 * p.numel():
+            bad.append((n, got, ref))
+        assert (p.detach() - p0[n]).abs().max().item() > 0, n          # Adam moved it
+    assert not bad, bad[:6]
 
 
 def test_train_step_with_vgg_loss_matches_oracle(device):
