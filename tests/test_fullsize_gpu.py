@@ -306,6 +306,11 @@ def test_full_size_deterministic_mode(device):
             print('deterministic c3, batched vs sequential step: losses', lerr, 'gradients (relative L2: G, D)', gerr)
         finally:
             opt.batch_frames = True
-    assert errs['flows_pred'] <= 1e-4 and errs['boxes_pred'] <= 1e-6 and serr <= 1e-4, (errs, serr)
-    assert errs['imgs_pred'] <= 1e-3, errs
-    assert lerr <= 1e-3 and gerr[0] <= 1e-2 and gerr[1] <= 1e-2, (lerr, gerr)
+    # Measured (r03): flows and boxes bit-identical, state 1e-6, images 6.2e-4 of max, losses identical, gradients 1.1e-3 (G) / 2e-4 (D)
+    # in relative L2.  At batch 2 the two passes agree BIT FOR BIT in every decoder block (tools/debug_det_paths.py); at batch 8 they
+    # part ways at the 1e-6 level in front of netG.fc: the low-rank layout taps come from a small fp32 GEMM whose kernel (K order)
+    # is chosen by its row count (120 x 22 object slots batched, 8 x 22 per pass), and the decoder amplifies that ~300x.  The bounds
+    # are 5-10x tighter than the non-deterministic tests above (1e-2 / 5e-2).
+    assert errs['flows_pred'] <= 1e-6 and errs['boxes_pred'] <= 1e-6 and serr <= 1e-5, (errs, serr)
+    assert errs['imgs_pred'] <= 2e-3, errs
+    assert lerr <= 1e-5 and gerr[0] <= 5e-3 and gerr[1] <= 1e-3, (lerr, gerr)
