@@ -25,9 +25,27 @@ __device__ __forceinline__ void regroup2(float w0, float w1, unsigned& hi, unsig
     hi = __builtin_amdgcn_perm(__float_as_uint(w1), __float_as_uint(w0), 0x07060302u);
     lo = __builtin_amdgcn_perm(__float_as_uint(w1), __float_as_uint(w0), 0x05040100u);
 }
-template <bool PS>
+template <bool PS, bool H16 = false>
 __device__ __forceinline__ void split_or_regroup(float x0, float x1, unsigned& hi, unsigned& lo) {
-    if constexpr (PS) regroup2(x0, x1, hi, lo); else split2(x0, x1, hi, lo);
+    if constexpr (PS) regroup2(x0, x1, hi, lo);
+    else if constexpr (H16) split2_h(x0, x1, hi, lo);
+    else split2(x0, x1, hi, lo);
+}
+// the three MFMAs of one 32x32x16 product block on bf16 or fp16 operand words (same registers: eight 16-bit values per lane)
+template <bool H16>
+__device__ __forceinline__ f32x16 mfma3(const bf16x8& ah, const bf16x8& al, const bf16x8& bh, const bf16x8& bl, f32x16 acc) {
+    if constexpr (H16) {
+        const f16x8 xah = __builtin_bit_cast(f16x8, ah), xal = __builtin_bit_cast(f16x8, al);
+        const f16x8 xbh = __builtin_bit_cast(f16x8, bh), xbl = __builtin_bit_cast(f16x8, bl);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xal, xbh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xah, xbl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xah, xbh, acc, 0, 0, 0);
+    } else {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+    }
+    return acc;
 }
 #ifndef AG2V_LDK
 #define AG2V_LDK 40      // LDS row stride in bf16 elements (tools/ubench builds override it for layout experiments)
@@ -47,8 +65,11 @@ __device__ __forceinline__ void split_or_regroup(float x0, float x1, unsigned& h
 // F32: the same wave-specialised pipeline on EXACT fp32 operands (v_mfma_f32_32x32x2_f32): the producers store the fp32 words as
 // loaded, [row][k] with 36-word rows; consumer lane (row, half) multiplies k = 16 half + j, j < 16 (the order of the k terms of a
 // K-tile is free as long as both operands use the same), i.e. four 16-byte LDS reads per 32-row fragment.  Table path only.
-template <int BM, int BN, int CWM, int CWN, int NPW, bool MF16, bool TAPK, bool B4, bool PSB, bool F32 = false>
+// H16: fp16 3-term split instead of bf16 (split2_h, v_mfma_f32_32x32x16_f16; weights packed by the *_h pack kernels): 32x32x16 tiles,
+// fp32 gathered operand.
+template <int BM, int BN, int CWM, int CWN, int NPW, bool MF16, bool TAPK, bool B4, bool PSB, bool F32 = false, bool H16 = false>
 __device__ __forceinline__ void igemm_bf16x3_body(const ConvArgs& p) {
+    static_assert(!H16 || (!MF16 && !PSB && !F32), "fp16 split: 32x32x16 tiles on fp32 inputs");
     constexpr int BK = 32, LDK = AG2V_LDK, NP = NPW * 64;       // NP producer threads
     constexpr int TM = BM / CWM / 32, TN = BN / CWN / 32;  // consumer wave tile in 32x32 MFMA tiles
     constexpr int AP = NP / BM > 0 ? NP / BM : 1, AK = BK / AP;
@@ -311,13 +332,13 @@ __device__ __forceinline__ void igemm_bf16x3_body(const ConvArgs& p) {
                     const int off = (j * GR + quad) * LDK + kpart * KPT;
                     if constexpr (KPT == 4) {
                         unsigned h0, l0, h1, l1;
-                        split_or_regroup<PSB>(rb[0][j], rb[0][4 + j], h0, l0);
-                        split_or_regroup<PSB>(rb[0][8 + j], rb[0][12 + j], h1, l1);
+                        split_or_regroup<PSB, H16>(rb[0][j], rb[0][4 + j], h0, l0);
+                        split_or_regroup<PSB, H16>(rb[0][8 + j], rb[0][12 + j], h1, l1);
                         *reinterpret_cast<uint2*>(&Bhi[buf][off]) = make_uint2(h0, h1);
                         *reinterpret_cast<uint2*>(&Blo[buf][off]) = make_uint2(l0, l1);
                     } else {      // 256 x 128 tile: 2 channels per thread
                         unsigned h0, l0;
-                        split_or_regroup<PSB>(rb[0][j], rb[0][4 + j], h0, l0);
+                        split_or_regroup<PSB, H16>(rb[0][j], rb[0][4 + j], h0, l0);
                         *reinterpret_cast<unsigned*>(&Bhi[buf][off]) = h0;
                         *reinterpret_cast<unsigned*>(&Blo[buf][off]) = l0;
                     }
@@ -330,7 +351,7 @@ __device__ __forceinline__ void igemm_bf16x3_body(const ConvArgs& p) {
                     unsigned h[4], l[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        split_or_regroup<PSB>(rb[c][8 * g + 2 * i], rb[c][8 * g + 2 * i + 1], h[i], l[i]);
+                        split_or_regroup<PSB, H16>(rb[c][8 * g + 2 * i], rb[c][8 * g + 2 * i + 1], h[i], l[i]);
                     }
                     const int off = (bcol0 + c * (BN / BCOLS)) * LDK + BKK * bpart + 8 * g;
                     *reinterpret_cast<uint4*>(&Bhi[buf][off]) = make_uint4(h[0], h[1], h[2], h[3]);
@@ -481,9 +502,7 @@ __device__ __forceinline__ void igemm_bf16x3_body(const ConvArgs& p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, blo[j], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, bhi[j], acc[i][j], 0, 0, 0);
                     } else {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma3<H16>(ahi, alo, bhi[j], blo[j], acc[i][j]);
                     }
                 }
             }
@@ -519,11 +538,7 @@ __device__ __forceinline__ void igemm_bf16x3_body(const ConvArgs& p) {
         };
         auto mm = [&](int i, const bf16x8& ah, const bf16x8& al, const bf16x8 (&bh)[EN], const bf16x8 (&bl)[EN]) {
 #pragma unroll
-            for (int j = 0; j < EN; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
-            }
+            for (int j = 0; j < EN; ++j) acc[i][j] = mfma3<H16>(ah, al, bh[j], bl[j], acc[i][j]);
         };
         bf16x8 hbh[EN], hbl[EN], hah, hal;      // deferred: (row block 1, k-step 1) of the previous tile
         bool have = false;
@@ -593,7 +608,7 @@ __device__ __forceinline__ void igemm_bf16x3_body(const ConvArgs& p) {
     float* obase = p.out + (size_t)on * p.M * plane + orem;
     const float* rbase = p.residual ? p.residual + (size_t)on * p.M * plane + orem : nullptr;
     const float* mbase = (p.mask && p.splitk == 1) ? p.mask + (size_t)on * p.M * plane + orem : nullptr;
-    const float gs = p.gscale ? p.gscale[on / p.group_n] : 1.f;     // per-sample-group scale of the product (1/sigma_t)
+    const float gs = (p.gscale ? p.gscale[on / p.group_n] : 1.f) * (p.oscale != 0.f ? p.oscale : 1.f);   // 1/sigma_t (x 1/weight scale of the h16 pack)
     auto emit = [&](int m, float v) {
         if (pvalid && m < p.M) {
             v *= gs;
@@ -712,6 +727,11 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_bf16x3_ws_k
 template <int BM, int BN, int CWM, int CWN, int NPW>
 __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_f32_ws_kernel(ConvArgs p) {
     igemm_bf16x3_body<BM, BN, CWM, CWN, NPW, false, false, false, false, true>(p);
+}
+// fp16 3-term split (ConvArgs::h16): forward passes on normalised operands at fp32-class accuracy
+template <int BM, int BN, int CWM, int CWN, int NPW, bool TAPK, bool B4>
+__global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_igemm_f16x3_ws_kernel(ConvArgs p) {
+    igemm_bf16x3_body<BM, BN, CWM, CWN, NPW, false, TAPK, B4, false, false, true>(p);
 }
 // the same tiles reading a split-word gathered tensor (ConvArgs::b_split)
 template <int BM, int BN, int CWM, int CWN, int NPW, bool MF16, bool TAPK, bool B4>
@@ -1332,7 +1352,24 @@ int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed) {
     static const bool b4_tall = getenv("AG2V_B4_TALL") != nullptr;
     const bool b4 = a.tap_major && !b4_off && (!tall || b4_tall) && a.stride == 1 && a.OW % 4 == 0 && a.W >= 4 &&
                     (a.OH * a.OW) % 4 == 0 && a.pad_w <= 3;
-    if (a.f32) {        // exact fp32 operands (k-major fp32 weights, table path)
+    if (a.h16) {        // fp16 split (weights packed by the *_h kernels)
+        if (a.b_split || a.out_split || a.f32) return AG2V_EINVAL;
+#define AG2V_LAUNCH_H16(...)                                                                           \
+    do {                                                                                               \
+        set_last_conv_kernel("conv_igemm_f16x3_ws_kernel<" AG2V_STR(__VA_ARGS__) ">");                 \
+        hipLaunchKernelGGL((conv_igemm_f16x3_ws_kernel<__VA_ARGS__>), grid, dim3(1024), 0, st, a);      \
+    } while (0)
+        if (tall) {
+            if (b4) AG2V_LAUNCH_H16(256, 128, 4, 2, 8, true, true);
+            else if (a.tap_major) AG2V_LAUNCH_H16(256, 128, 4, 2, 8, true, false);
+            else AG2V_LAUNCH_H16(256, 128, 4, 2, 8, false, false);
+        } else {
+            if (b4) AG2V_LAUNCH_H16(128, 256, 2, 4, 8, true, true);
+            else if (a.tap_major) AG2V_LAUNCH_H16(128, 256, 2, 4, 8, true, false);
+            else AG2V_LAUNCH_H16(128, 256, 2, 4, 8, false, false);
+        }
+#undef AG2V_LAUNCH_H16
+    } else if (a.f32) {        // exact fp32 operands (k-major fp32 weights, table path)
         if (a.tap_major || a.b_split || a.out_split) return AG2V_EINVAL;
         if (tall) {
             set_last_conv_kernel("conv_igemm_f32_ws_kernel<256, 128, 4, 2, 8>");

@@ -33,6 +33,10 @@ struct ConvArgs {
     int f32;                // wave-specialised implicit-GEMM kernels on exact fp32 operands (conv_igemm_f32_ws_kernel)
     int a_split;            // weight-gradient bf16x3 kernels: dy (a_src) holds split words
     int b_split;            // bf16x3 kernels: b_src holds split words ((bf16 hi << 16) | bf16 lo per value, pack_split()) instead of fp32
+    int h16;                // igemm: FP16 3-term split (ag2v_conv_opts::precision == 2): x = hi + lo with fp16 hi / lo (11 + 11 bits) on
+                            //   v_mfma_f32_32x32x16_f16 -- ~5e-6 relative (fp32-class; bf16: ~1.5e-5) for operands of O(1) magnitude;
+                            //   the packed weights are scaled by kH16WScale (a power of two), the epilogue multiplies by oscale
+    float oscale;           // igemm epilogue: factor on the accumulated product (0 = 1)
     int det;                // deterministic reduction (ag2v_conv_opts::deterministic): igemm: no split-K (launchers); wgrad: pixel-range
                             //   split number `split` stores its partial tile to out + split * M * NG (a caller workspace slab, plain
                             //   stores) and launch_wgrad_det_reduce() adds the slabs in split order -- no floating-point atomics
@@ -91,6 +95,36 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigne
     hi = __builtin_bit_cast(unsigned, h);
     lo = __builtin_bit_cast(unsigned, l);
 }
+// ---- fp16 3-term split (forward passes on O(1)-scaled operands: the flow network, whose output feeds the warp).  fp16 carries
+// 11 significand bits against bf16's 8: hi + lo covers 22 bits and hi*hi + hi*lo + lo*hi is accurate to ~2^-21 -- measured 4.5e-6 of
+// rms(out) on K = 4608 dot products, BELOW a sequential fp32 fmaf chain's 6.5e-6, where the bf16 split has 1.6e-5
+// (tools/ubench/f16x3_probe.hip).  The price is range: below ~1e-2 the lo term is an fp16 subnormal and the accuracy decays (8e-5 at
+// 1e-3), so the weights are packed times kH16WScale = 32 (kaiming-scale filters become O(1); exact, undone by ConvArgs::oscale) and
+// the mode is only used where activations are normalised (ag2v_conv_opts::precision == 2).  Same MFMA rate as bf16.
+#define AG2V_H16_WSCALE 32.0f
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2_h(float x0, float x1, unsigned& hi, unsigned& lo) {
+    const f32x2 v = {x0, x1};
+    const f16x2 h = __builtin_convertvector(v, f16x2);
+    const f32x2 hf = __builtin_convertvector(h, f32x2);
+    float d0, d1;
+    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(d0) : "v"(x0), "v"(hf[0]));      // (two v_sub_f32: see split2)
+    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(d1) : "v"(x1), "v"(hf[1]));
+    const f32x2 dv = {d0, d1};
+    const f16x2 l = __builtin_convertvector(dv, f16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+// fp32 -> packed (fp16 hi << 16) | fp16 lo of x * AG2V_H16_WSCALE: the pre-split weight operand of the h16 kernels
+__device__ __forceinline__ float pack_split_h(float x) {
+    x *= AG2V_H16_WSCALE;
+    const _Float16 h = (_Float16)x;
+    const _Float16 l = (_Float16)(x - (float)h);
+    const unsigned w = ((unsigned)__builtin_bit_cast(unsigned short, h) << 16) | (unsigned)__builtin_bit_cast(unsigned short, l);
+    return __uint_as_float(w);
+}
+
 // one fp32 -> packed word (hi bf16 in the upper half, lo bf16 in the lower half); used for the pre-split weight operand
 __device__ __forceinline__ float pack_split(float x) {
     const __bf16 h = (__bf16)x;

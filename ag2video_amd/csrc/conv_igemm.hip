@@ -350,7 +350,10 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = c0 + ty + 8 * i, r = r0 + tx;
-        if (c < cols && r < rows) at[(size_t)c * rows + r] = split ? pack_split(t[tx][ty + 8 * i]) : t[tx][ty + 8 * i];
+        if (c < cols && r < rows) {
+            const float v = t[tx][ty + 8 * i];
+            at[(size_t)c * rows + r] = (split == 2) ? pack_split_h(v) : (split ? pack_split(v) : v);      // 2: fp16 planes (ConvArgs::h16)
+        }
     }
 }
 
@@ -360,11 +363,12 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 // grid (C/32, ceil(M/8)): the 32*R*S contiguous source floats of each of 8 output rows go through LDS; every thread then writes
 // the eight channels c..c+7 of one (tap, m) as 16 bytes per plane, 8 lanes along m (one 128-byte line).  Small blocks: the
 // weights of a 128 x 512 x 3 x 3 layer make 256 of them, and the kernel runs in front of every forward convolution.
-__device__ __forceinline__ void split_planes8(const float (&x)[8], uint4& hi, uint4& lo) {
+__device__ __forceinline__ void split_planes8(const float (&x)[8], uint4& hi, uint4& lo, int h16 = 0) {
     unsigned h[4], l[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const unsigned a = __float_as_uint(pack_split(x[2 * i])), b = __float_as_uint(pack_split(x[2 * i + 1]));
+        const unsigned a = __float_as_uint(h16 ? pack_split_h(x[2 * i]) : pack_split(x[2 * i]));
+        const unsigned b = __float_as_uint(h16 ? pack_split_h(x[2 * i + 1]) : pack_split(x[2 * i + 1]));
         h[i] = (a >> 16) | (b & 0xFFFF0000u);
         l[i] = (a & 0xFFFFu) | (b << 16);
     }
@@ -372,7 +376,7 @@ __device__ __forceinline__ void split_planes8(const float (&x)[8], uint4& hi, ui
     lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
 __global__ __launch_bounds__(256) void pack_fwd_tap_kernel(const float* __restrict__ w, float* __restrict__ at, int M, int C, int R,
-                                                           int S) {
+                                                           int S, int h16) {
     constexpr int MR = 8;
     __shared__ float t[MR * (32 * 16 + 1)];
     const int RS = R * S, row = 32 * RS + 1;
@@ -393,7 +397,7 @@ __global__ __launch_bounds__(256) void pack_fwd_tap_kernel(const float* __restri
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = src[e * RS];
         uint4 hi, lo;
-        split_planes8(x, hi, lo);
+        split_planes8(x, hi, lo, h16);
         const size_t idx = (size_t)(tap_major_row(c0 + c8 * 8, r, s2, R, S) >> 3) * M + (m0 + m);
         hi_plane[idx] = hi;
         lo_plane[idx] = lo;
@@ -525,7 +529,7 @@ struct ConvCfg {
 };
 static ConvCfg conv_cfg(const ag2v_conv_opts* o) {
     ConvCfg c;
-    c.precision = (o && o->precision >= 0) ? (o->precision ? 1 : 0) : conv_precision();
+    c.precision = (o && o->precision >= 0) ? (o->precision == 2 ? 2 : (o->precision ? 1 : 0)) : conv_precision();
     c.min_rows = (o && o->min_rows > 0) ? o->min_rows : bf16x3_min_rows();
     c.gscale = o ? o->gscale : nullptr;
     c.group_n = (o && o->group_n > 0) ? o->group_n : 1;
@@ -537,7 +541,7 @@ static ConvCfg conv_cfg(const ag2v_conv_opts* o) {
     c.det_ws_floats = o ? o->det_workspace_floats : 0;
     return c;
 }
-static bool use_bf16x3(const ConvCfg& c, int M) { return c.precision == 1 && M >= c.min_rows; }
+static bool use_bf16x3(const ConvCfg& c, int M) { return c.precision >= 1 && M >= c.min_rows; }     // (2: fp16 split in the forward pass)
 static const long long kBufMax = (1LL << 32) - 64;   // raw buffer descriptors cover < 4 GiB
 
 
@@ -841,6 +845,9 @@ extern "C" int ag2v_conv2d_fwd_ex(const float* x, const float* w, const float* b
     static const bool short_exact = getenv("AG2V_NO_SHORT_K_EXACT") == nullptr;
     int nmax = N;
     bool split = use_bf16x3(cfg, K) && abytes < kBufMax && !(short_exact && KG < 64 && K < 128);
+    // precision 2: fp16 3-term split for THIS forward (operands of O(1) magnitude: the flow network); same tiles as bf16x3
+    const bool h16 = cfg.precision == 2 && split;
+    if (h16 && (cfg.in_split || cfg.out_split)) return AG2V_EINVAL;
     if (split && xs * 4 * N >= chunk_limit()) {
         nmax = chunk_samples(xs * 4, 0, cfg.gscale ? cfg.group_n : 1);
         if (nmax <= 0) { split = false; nmax = N; }
@@ -861,10 +868,10 @@ extern "C" int ag2v_conv2d_fwd_ex(const float* x, const float* w, const float* b
     }
     const bool tapmaj = igemm_tap_major(C, split);
     if (tapmaj)
-        hipLaunchKernelGGL(pack_fwd_tap_kernel, dim3(C / 32, ceil_div(K, 8)), dim3(256), 0, st, w, workspace, K, C, R, S);
+        hipLaunchKernelGGL(pack_fwd_tap_kernel, dim3(C / 32, ceil_div(K, 8)), dim3(256), 0, st, w, workspace, K, C, R, S, h16 ? 1 : 0);
     else
         hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(KG, 32), ceil_div(K, 32)), dim3(256), 0, st, w, workspace, K, KG,
-                           split ? 1 : 0);
+                           h16 ? 2 : (split ? 1 : 0));
     for (int n0 = 0; n0 < N; n0 += nmax) {
         const int nc = (N - n0 < nmax) ? N - n0 : nmax;
         ConvArgs a{};
@@ -880,6 +887,8 @@ extern "C" int ag2v_conv2d_fwd_ex(const float* x, const float* w, const float* b
         a.b_split = cfg.in_split; a.out_split = cfg.out_split;
         a.f32 = f32ws ? 1 : 0;
         a.det = cfg.det;
+        a.h16 = h16 ? 1 : 0;
+        a.oscale = h16 ? 1.0f / AG2V_H16_WSCALE : 0.f;
         const int rc = launch_igemm(a, st, false, split || f32ws);
         if (rc != AG2V_OK) return rc;
     }

@@ -150,8 +150,10 @@ class bf16x3_min_rows(object):
     """Context manager: convolutions *created* inside send GEMMs with at least ``rows`` rows to the bf16x3 tiles in their forward
     pass and with at least ``bwd_rows`` (default: the same) in their backward pass (data / weight gradient)."""
 
-    def __init__(self, rows, bwd_rows=None):
-        self.rows = (int(rows), int(rows if bwd_rows is None else bwd_rows))
+    def __init__(self, rows, bwd_rows=None, fwd_h16=False):
+        # fwd_h16: the FORWARD launches that take the split tiles use the fp16 3-term split (ag2v_conv_opts::precision = 2: ~5e-6,
+        # fp32-class, for normalised operands -- the flow network, whose output the warp amplifies) instead of the bf16 one
+        self.rows = (int(rows), int(rows if bwd_rows is None else bwd_rows), bool(fwd_h16))
 
     def __enter__(self):
         _MIN_ROWS_STACK.append(self.rows)
@@ -191,7 +193,11 @@ def current_frame_groups():
 
 def _current_min_rows():
     """(forward threshold, backward threshold), or (None, None) = library default."""
-    return _MIN_ROWS_STACK[-1] if _MIN_ROWS_STACK else (None, None)
+    return _MIN_ROWS_STACK[-1][:2] if _MIN_ROWS_STACK else (None, None)
+
+
+def _current_fwd_h16():
+    return bool(_MIN_ROWS_STACK and _MIN_ROWS_STACK[-1][2] and _PRECISION[0] == 1 and os.environ.get('AG2V_NO_H16') is None)
 
 
 def _conv_label(mode, M, min_rows=None):
@@ -200,10 +206,10 @@ def _conv_label(mode, M, min_rows=None):
 
 
 def _conv_launch(min_rows, name, label, flops, *args, shape=None, gscale=None, group_n=1, in_split=False, dy_split=False,
-                 out_split=False, det_ws_query=None):
+                 out_split=False, det_ws_query=None, precision=None):
     """One ag2v_conv2d_*_ex call.  Arithmetic (precision, bf16x3 row threshold: ``min_rows``, None = library default) and the
     per-sample-group output scale travel as per-call options (ag2v_conv_opts): no process-wide switch is touched."""
-    opts = _lib.ConvOpts(_PRECISION[0], int(min_rows) if min_rows else 0, None if gscale is None else gscale.data_ptr(),
+    opts = _lib.ConvOpts(_PRECISION[0] if precision is None else int(precision), int(min_rows) if min_rows else 0, None if gscale is None else gscale.data_ptr(),
                          int(group_n), None, 1 if in_split else 0, 1 if dy_split else 0, 1 if out_split else 0,
                          1 if _DETERMINISTIC[0] else 0, None, 0)
     det_ws = None
@@ -414,12 +420,13 @@ def _wsink_take_group(keys, likes):
 # ------------------------------------------------------------------------------------------------ convolution
 def _conv_fwd_launch(mr, x, w, bias, residual, y, stride, pad, relu, gscale=None, group_n=1, in_split=False, out_split=False):
     N, C, H, W = x.shape
+    h16 = _current_fwd_h16() and not in_split and not out_split
     K, _, R, S = w.shape
     ws = torch.empty(_lib.query('ag2v_conv2d_workspace_floats', C, K, R, S), device=x.device, dtype=torch.float32)
     _conv_launch(mr, 'ag2v_conv2d_fwd_ex', 'conv_fwd', 2.0 * N * K * y.shape[2] * y.shape[3] * C * R * S,
                  _ptr(x), _ptr(w), _ptr(bias), _ptr(residual), _ptr(y), N, C, H, W, K, R, S, stride, pad, 1 if relu else 0,
                  _ptr(ws), _stream(), shape=(N, C, H, W, K, R, stride), gscale=gscale, group_n=group_n, in_split=in_split,
-                 out_split=out_split)
+                 out_split=out_split, precision=(2 if h16 else None))
 
 
 def _conv_dgrad_launch(mr, dy, w, mask, dx, stride, pad, acc, gscale=None, group_n=1, dy_split=False, out_split=False):

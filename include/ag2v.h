@@ -31,6 +31,10 @@ extern "C" {
 /* Per-call options of the *_ex convolution entry points (plain C struct, passed by pointer; NULL = all defaults).
  *   precision: arithmetic of the 128/256-row MFMA tiles: 1 = bf16x3 split products with fp32 accumulation (each fp32 operand
  *              = bf16 hi + bf16 lo, a*b = hi*hi + hi*lo + lo*hi: ~1e-5 relative per product), 0 = exact fp32 MFMA,
+ *              2 = (forward only; backward entry points treat it as 1) the same three products on FP16 hi / lo parts
+ *              (11 + 11 significand bits: ~5e-6 of rms(out), the level of a sequential fp32 fmaf chain) for operands of O(1)
+ *              magnitude -- below ~1e-2 the lo part is an fp16 subnormal and the accuracy decays, so the weights are packed
+ *              times 32 (exact, undone in the epilogue) and the caller uses it on normalised activations only (the flow network),
  *              < 0 = the process default (ag2v_set_conv_precision / AG2V_CONV_PRECISION; initially 1);
  *   min_rows:  in bf16x3 mode, GEMMs with fewer rows (output channels; input channels for the data gradient) stay on the exact
  *              fp32 tiles; <= 0 = the process default (ag2v_set_bf16x3_min_rows / AG2V_BF16X3_MIN_M; initially 128);

@@ -840,6 +840,40 @@ def test_direct_param_grads_only_inside_the_accumulating_context(device):
     assert hooked, "a post-accumulate-grad hook must still fire (the direct path steps aside for hooked parameters)"
 
 
+# ------------------------------------------------------------------------------------------------ fp16 3-term split (forward)
+@pytest.mark.parametrize("case", [(4, 256, 32, 256, 3, 1, 1), (3, 128, 40, 64, 3, 1, 1), (2, 64, 64, 32, 3, 1, 1), (3, 64, 33, 128, 3, 2, 1),
+                                  (2, 48, 24, 128, 3, 1, 1)], ids=lambda c: "x".join(str(v) for v in c))
+def test_conv_forward_fp16_split(case, device):
+    """ag2v_conv_opts::precision = 2 (ops.bf16x3_min_rows(..., fwd_h16=True)): the forward's three products on fp16 hi / lo parts.  On
+    normalised activations and kaiming-scale filters (the flow network's operands) the result must sit at the fp32 level: against an
+    fp64 convolution it may not be worse than 3x the exact-fp32 kernels' own error, and must beat the bf16 split; gradients (bf16
+    split in both cases) are unchanged.  Shapes: 256- / 128-row tiles, quad-load, tap-major and table (C % 32 != 0) paths, stride 2."""
+    from ag2video_amd import ops
+    N, C, H, Ko, R, st, pad = case
+    x0 = torch.nn.functional.leaky_relu(_rand(N, C, H, H, seed=1), 0.2)
+    w0 = _rand(Ko, C, R, R, seed=2, scale=(2.0 / (C * R * R)) ** 0.5)
+    b0 = _rand(Ko, seed=3)
+    gs0 = torch.tensor([0.7], dtype=torch.float32)
+    ref = torch.nn.functional.conv2d(x0.double(), w0.double() * 0.7, b0.double(), stride=st, padding=pad)
+
+    def run(ctx):
+        x = x0.clone().to(device).requires_grad_(True)
+        w = w0.clone().to(device).requires_grad_(True)
+        with ops.conv_precision('bf16x3'), ctx:
+            y = ops.conv2d(x, w, b0.to(device), st, pad, gscale=gs0.to(device))
+            y.backward(_rand(*y.shape, seed=5).to(device))
+        return y.detach().double().cpu(), x.grad.detach().cpu(), w.grad.detach().cpu()
+    yh, dxh, dwh = run(ops.bf16x3_min_rows(32, 32, fwd_h16=True))
+    yb, dxb, dwb = run(ops.bf16x3_min_rows(32, 32))
+    ye, _, _ = run(ops.bf16x3_min_rows(ops.EXACT, 32))
+    scale = ref.abs().max().item()
+    eh, eb, ee = [(t - ref).abs().max().item() / scale for t in (yh, yb, ye)]
+    print('fp16 split forward %s: error / max|ref|  h16 %.2e  bf16 %.2e  exact fp32 %.2e' % (case, eh, eb, ee))
+    assert eh <= 3.0 * ee + 2e-7, (eh, ee)
+    assert eh < 0.6 * eb, (eh, eb)
+    assert torch.equal(dxh, dxb) and (dwh - dwb).abs().max().item() <= 2e-5 * dwb.abs().max().item()
+
+
 # ------------------------------------------------------------------------------------------------ deterministic reductions
 DET_CASES = [
     # N, C, H, K, R, stride, pad, groups, what exercises it
