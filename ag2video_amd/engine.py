@@ -102,14 +102,17 @@ class TrainStep(object):
                     print("Error: video_id {} is NAN!".format(video_id))
                 return model_out, G_losses, None
         self.optimizer_generator.zero_grad()
-        with ops.accumulate_into_param_grads():
+        # single process with a side stream: the appearance net's backward (side stream) keeps running under the discriminator phase;
+        # this stream joins it before Adam(G) below.  With collectives the all-reduce launched next must see complete gradients.
+        overlap_tail = self.side_stream is not None and not dist_utils.is_dist()
+        with ops.accumulate_into_param_grads(join_streams=not overlap_tail):
             G_losses["total_loss"].backward()
         # One process per GPU: the generator's 500 MB gradient all-reduce is launched here and joined after the discriminator's
         # loss + backward (which read neither these gradients nor the generator's parameters: imgs_pred is detached), then
         # Adam(G) runs -- the same updates as the reference order (G step, then D loss), with the ring traffic behind ~150 ms of
         # convolutions.  Single process: nothing is pending and Adam(G) runs here, in the reference's order.
         pending = dist_utils.average_gradients_begin(self._gen_params, flat=getattr(self.optimizer_generator, 'flat_grad', None))
-        deferred = bool(pending.works)
+        deferred = bool(pending.works) or overlap_tail      # Adam(G) after the discriminator phase (which reads neither G's gradients nor its parameters)
         if apply_updates and not deferred:
             self.optimizer_generator.step()
         D_losses = self.gans_model(batch, model_out, mode="compute_discriminator_loss")
@@ -119,6 +122,7 @@ class TrainStep(object):
             D_losses["total_img_loss"].backward()
         if self.side_stream is not None:      # the layout terms' backward ran there; their gradients are written by the ops themselves
             torch.cuda.current_stream().wait_stream(self.side_stream)
+        ops.join_direct_grad_streams()
         rec = self.comm_events is not None and dist_utils.is_dist() and torch.device(self.device).type == 'cuda'
         if deferred:
             if rec:

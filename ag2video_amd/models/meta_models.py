@@ -39,9 +39,18 @@ class AG2VideoModel(nn.Module):
             # The side stream only waits for an event recorded at entry (the inputs), not for the generator.
             main = torch.cuda.current_stream()
             entry = main.record_event()
-            obj_vecs, _, actions_data = self.acts_to_objs(objs, triplets, actions, boxes_gt, test_mode=test_mode)
-            imgs_pred, flows_pred, conf_pred = self.layout_to_video(imgs, objs, obj_vecs, boxes_gt, test_mode=test_mode)
+            # The appearance net's FORWARD is on the critical path (the generator's first convolutions read its vectors), but it is
+            # issued on the side stream as well: autograd runs a node's backward on the stream of its forward, so the net's 15-step
+            # BACKWARD recurrence -- the tail of the generator's backward pass, ~10 ms of 5 us kernels -- runs there, under the
+            # discriminator phase that engine.gd_step queues next on the main stream (Adam(G) is applied after that phase).
             side.wait_event(entry)
+            with torch.cuda.stream(side):
+                obj_vecs, _, actions_data = self.acts_to_objs(objs, triplets, actions, boxes_gt, test_mode=test_mode)
+                ready = side.record_event()
+            main.wait_event(ready)
+            for t_ in [obj_vecs] + [a for a in actions_data if torch.is_tensor(a)]:
+                t_.record_stream(main)
+            imgs_pred, flows_pred, conf_pred = self.layout_to_video(imgs, objs, obj_vecs, boxes_gt, test_mode=test_mode)
             with torch.cuda.stream(side):
                 _, boxes_pred, _ = self.acts_to_boxes(objs, triplets, actions, boxes_gt, test_mode=test_mode)
                 boxes_pred.record_stream(main)

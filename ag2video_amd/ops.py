@@ -324,6 +324,14 @@ def _wsink_clear():
     backward() then sees complete gradients without the caller having to know which streams were involved."""
     _WSINK.clear()
     _WSINK_CB[0] = None
+    if _DIRECT_STREAMS and _JOIN_AT_END[0]:
+        join_direct_grad_streams()
+
+
+def join_direct_grad_streams():
+    """Make the current stream wait for every other stream on which a backward pass wrote parameter gradients directly (see
+    _wsink_clear).  Called from the end-of-pass callback, or -- accumulate_into_param_grads(join_streams=False) -- by the caller
+    itself right before it reads the gradients (engine.gd_step: before Adam(G), after the discriminator phase has been queued)."""
     if _DIRECT_STREAMS:
         cur = torch.cuda.current_stream()
         for s_ in _DIRECT_STREAMS:
@@ -346,6 +354,7 @@ def _wsink_begin(task):
 _DIRECT_GRAD = os.environ.get('AG2V_NO_DIRECT_GRAD') is None
 _USE_CHANNEL_SUMS = os.environ.get('AG2V_NO_CHANNEL_SUMS') is None
 _DIRECT_DEPTH = [0]
+_JOIN_AT_END = [True]
 
 
 class accumulate_into_param_grads(object):
@@ -355,12 +364,20 @@ class accumulate_into_param_grads(object):
     every gradient is returned to autograd, which delivers it the usual way (the direct path returned None to
     autograd.grad and still wrote .grad)."""
 
+    def __init__(self, join_streams=True):
+        # join_streams=False: the caller joins the writing streams itself (ops.join_direct_grad_streams()) before it reads .grad --
+        # lets side-stream backward work (the graph nets) run under whatever the caller queues next on its own stream
+        self.join = bool(join_streams)
+
     def __enter__(self):
         _DIRECT_DEPTH[0] += 1
+        self.old_join = _JOIN_AT_END[0]
+        _JOIN_AT_END[0] = self.join
         return self
 
     def __exit__(self, *exc):
         _DIRECT_DEPTH[0] -= 1
+        _JOIN_AT_END[0] = self.old_join
         return False
 
 

@@ -871,7 +871,8 @@ def test_conv_forward_fp16_split(case, device):
     print('fp16 split forward %s: error / max|ref|  h16 %.2e  bf16 %.2e  exact fp32 %.2e' % (case, eh, eb, ee))
     assert eh <= 3.0 * ee + 2e-7, (eh, ee)
     assert eh < 0.6 * eb, (eh, eb)
-    assert torch.equal(dxh, dxb) and (dwh - dwb).abs().max().item() <= 2e-5 * dwb.abs().max().item()
+    for a, b in ((dxh, dxb), (dwh, dwb)):                     # same backward arithmetic (split-K atomics: reduction-order noise)
+        assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
 
 
 # ------------------------------------------------------------------------------------------------ deterministic reductions
