@@ -1,0 +1,399 @@
+"""Graph-net recurrences as persistent-kernel PROGRAMS (csrc/graph_prog.hip, include/ag2v.h "graph-net programs").
+
+The time-step loops of ``Acts2LayoutModel.forward`` (reference models/graph_models/model.py:126-169) and
+``MultiscaleActionDiscriminator.get_obj_vecs`` (discriminator.py:273-313) -- obj_vecs_net, 2-3 ``GraphTripleConv`` layers
+(graph.py:41-107) and box_net per step, 15 steps -- are written here as ONE operator program per pass (forward; backward = the
+input-gradient chain in reverse) that a single launch of co-resident workgroups interprets.  The weight gradients do not depend on
+each other: after the backward program they are one GEMM per layer over the stacked time steps.
+
+Everything a program touches lives in one arena allocated per pass (no tensor is reused, so the forward values are the backward's
+ReLU masks); operands are row-major views described by (base, offset, rows, cols, leading dimension).
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+
+GEMM, CAT, POOL, POOL_BWD, GATHER_BWD, TRANSPOSE, ADD3 = 1, 2, 3, 4, 5, 6, 7
+
+_OP_DTYPE = np.dtype([('type', '<i4'), ('M', '<i4'), ('N', '<i4'), ('K', '<i4'),
+                      ('a', '<u8'), ('b', '<u8'), ('d', '<u8'), ('bias', '<u8'), ('res', '<u8'), ('mask', '<u8'), ('c', '<u8'),
+                      ('i0', '<u8'), ('i1', '<u8'), ('i2', '<u8'), ('valid', '<u8'),
+                      ('lda', '<i8'), ('ldb', '<i8'), ('ldd', '<i8'), ('ldr', '<i8'), ('ldm', '<i8'), ('ldc', '<i8'),
+                      ('w0', '<i4'), ('w1', '<i4'), ('w2', '<i4'), ('relu', '<i4'), ('acc', '<i4'), ('O', '<i4'), ('T', '<i4'),
+                      ('pad', '<i4', (3,))])
+
+
+def enabled():
+    return os.environ.get('AG2V_NO_GRAPH_PROGRAM') is None
+
+
+class Ref(object):
+    """A row-major matrix view [rows, cols] with leading dimension ld at element offset `off` of `base` (a torch tensor, or None =
+    the program's arena)."""
+    __slots__ = ('base', 'off', 'rows', 'cols', 'ld')
+
+    def __init__(self, base, off, rows, cols, ld):
+        self.base, self.off, self.rows, self.cols, self.ld = base, int(off), int(rows), int(cols), int(ld)
+
+    def cols_from(self, c0, n):
+        return Ref(self.base, self.off + c0, self.rows, n, self.ld)
+
+
+class Stack(object):
+    """[steps, rows, cols] contiguous in the arena: one slot per time step (the weight-gradient GEMMs read the whole stack)."""
+
+    def __init__(self, off, steps, rows, cols):
+        self.off, self.steps, self.rows, self.cols = off, steps, rows, cols
+
+    def at(self, t):
+        return Ref(None, self.off + t * self.rows * self.cols, self.rows, self.cols, self.cols)
+
+
+class Program(object):
+    def __init__(self, device):
+        self.device = device
+        self.recs = []
+        self.size = 0
+        self.keep = []
+        self.arena = None
+
+    # ---- memory
+    def new(self, rows, cols):
+        off = self.size
+        self.size += (rows * cols + 3) & ~3
+        return Ref(None, off, rows, cols, cols)
+
+    def stack(self, steps, rows, cols):
+        off = self.size
+        self.size += (steps * rows * cols + 3) & ~3
+        return Stack(off, steps, rows, cols)
+
+    def ext(self, t, rows=None, cols=None):
+        """An external contiguous fp32 tensor viewed as [rows, cols] (default: all leading dimensions folded into rows)."""
+        if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+            raise RuntimeError("graph program: operands must be contiguous fp32 device tensors")
+        self.keep.append(t)
+        cols = t.shape[-1] if cols is None else cols
+        rows = t.numel() // cols if rows is None else rows
+        return Ref(t, 0, rows, cols, cols)
+
+    def ext_at(self, t, index, rows, cols):
+        """Slot `index` of a [steps, rows, cols] external stack."""
+        self.keep.append(t)
+        return Ref(t, index * rows * cols, rows, cols, cols)
+
+    def _p(self, r):
+        if r is None:
+            return 0
+        if isinstance(r, Ref):
+            base = self._arena_ptr if r.base is None else r.base.data_ptr()
+            return base + 4 * r.off
+        self.keep.append(r)
+        return r.data_ptr()          # raw tensor (index / validity / bias arrays)
+
+    # ---- operators (recorded; pointers are resolved in finalize)
+    def _rec(self, **kw):
+        self.recs.append(kw)
+
+    def gemm(self, a, b, out, bias=None, res=None, mask=None, relu=False, acc=False):
+        assert a.cols == b.cols and out.rows == a.rows and out.cols == b.rows, (a.rows, a.cols, b.rows, b.cols, out.rows, out.cols)
+        self._rec(type=GEMM, M=a.rows, N=b.rows, K=a.cols, a=a, b=b, bias=bias, res=res, mask=mask, c=out, relu=int(relu), acc=int(acc))
+
+    def cat(self, out, segs):
+        """segs: up to three (Ref, row-index int32 tensor or None)."""
+        kw = dict(type=CAT, M=out.rows, c=out)
+        names = (('a', 'i0', 'w0'), ('b', 'i1', 'w1'), ('d', 'i2', 'w2'))
+        assert sum(s[0].cols for s in segs) == out.cols
+        for (ref, idx), (pn, inn, wn) in zip(segs, names):
+            kw[pn], kw[inn], kw[wn] = ref, idx, ref.cols
+        self._rec(**kw)
+
+    def pool(self, newt, out, counts, i0, i1, valid, O, T, Hd, Dp):
+        self._rec(type=POOL, M=out.rows, a=newt, c=out, mask=counts, i0=i0, i1=i1, valid=valid, O=O, T=T, w0=Hd, w1=Dp)
+
+    def pool_bwd(self, dpooled, dp_in, out, counts, i0, i1, valid, O, T, Hd, Dp):
+        self._rec(type=POOL_BWD, M=out.rows, a=dpooled, b=dp_in, c=out, mask=counts, i0=i0, i1=i1, valid=valid, O=O, T=T, w0=Hd, w1=Dp)
+
+    def gather_bwd(self, dtri, out, i0, i1, O, T, Din, Dp, res=None):
+        self._rec(type=GATHER_BWD, M=out.rows, a=dtri, c=out, res=res, i0=i0, i1=i1, O=O, T=T, w0=Din, w1=Dp)
+
+    def transpose(self, w, out):
+        self._rec(type=TRANSPOSE, N=w.rows, K=w.cols, a=w, c=out)
+
+    def add3(self, out, a, b=None, d=None):
+        self._rec(type=ADD3, M=out.rows, N=out.cols, a=a, b=b, d=d, c=out)
+
+    # ---- build + run
+    def finalize(self):
+        self.arena = torch.empty(max(self.size, 4), device=self.device, dtype=torch.float32)
+        self._arena_ptr = self.arena.data_ptr()
+        arr = np.zeros(len(self.recs), _OP_DTYPE)
+        assert _OP_DTYPE.itemsize == _lib.query('ag2v_graph_op_bytes')
+        lds = {'a': 'lda', 'b': 'ldb', 'd': 'ldd', 'res': 'ldr', 'mask': 'ldm', 'c': 'ldc'}
+        for i, r in enumerate(self.recs):
+            for k, v in r.items():
+                if k in ('a', 'b', 'd', 'bias', 'res', 'mask', 'c', 'i0', 'i1', 'i2', 'valid'):
+                    arr[i][k] = self._p(v)
+                    if k in lds and isinstance(v, Ref):
+                        arr[i][lds[k]] = v.ld
+                else:
+                    arr[i][k] = v
+        self.n_ops = len(self.recs)
+        self.ops_dev = torch.from_numpy(arr.view(np.uint8).reshape(-1).copy()).to(self.device, non_blocking=False)
+        self.sync = torch.zeros(4, device=self.device, dtype=torch.int32)
+        self.recs = None
+        return self
+
+    def run(self):
+        _lib.call('ag2v_graph_program_run', ctypes.c_void_p(self.ops_dev.data_ptr()), self.n_ops, ctypes.c_void_p(self.sync.data_ptr()),
+                  _lib.query('ag2v_graph_program_grid'), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+    def timed_out(self):
+        """Host read (synchronises): True when a grid barrier gave up -- the results of that run are invalid."""
+        return bool(self.sync[1].item())
+
+    def tensor(self, ref_or_stack):
+        if isinstance(ref_or_stack, Stack):
+            s = ref_or_stack
+            return self.arena[s.off:s.off + s.steps * s.rows * s.cols].view(s.steps, s.rows, s.cols)
+        r = ref_or_stack
+        assert r.base is None
+        return torch.as_strided(self.arena, (r.rows, r.cols), (r.ld, 1), r.off)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# The recurrent net.  `net` supplies the parameters:
+#   first = (W1, W2): obj_vecs_net (no bias); gconvs = [(n1a_w, n1a_b, n1b_w, n1b_b, n2a_w, n2a_b, n2b_w, n2b_b), ...];
+#   box = (b1_w, b1_b, b2_w, b2_b) or None.
+# mode 'emb': step input = cat(emb, boxes[t-1]) and boxes[t] = boxes[t-1] + box_net(ov_t)  (Acts2LayoutModel)
+# mode 'ov' : step input = cat(ov_{t-1}, boxes_given[t])                                    (the discriminator's get_obj_vecs)
+class _Recurrence(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cfg, x0, pv_all, boxes_in, *params):
+        """x0: emb [BO, E] (mode 'emb') or the initial object vectors [BO, D] (mode 'ov'); pv_all [S, BT, Dp] frame-major predicate /
+        action vectors of the S recurrence steps; boxes_in: [BO, 4] initial boxes (mode 'emb') or [S, BO, 4] given boxes (mode 'ov').
+        Returns (ov_stack [S, BO, Dout], boxes_stack [S, BO, 4] (mode 'emb') or an empty tensor)."""
+        mode, S, BO, BT, O, T, idx_s, idx_o, valid, n_first, n_gconv, has_box = cfg
+        dev = x0.device
+        x0, pv_all, boxes_in = x0.contiguous(), pv_all.contiguous(), boxes_in.contiguous()
+        params = [p.contiguous() for p in params]
+        W1, W2 = params[0], params[1]
+        gcs = [params[2 + 8 * l: 10 + 8 * l] for l in range(n_gconv)]
+        box = params[2 + 8 * n_gconv: 6 + 8 * n_gconv] if has_box else None
+        P = Program(dev)
+        E = x0.shape[1]
+        Hd = gcs[0][2].shape[1]                 # hidden_dim (n1b_w: [2 Hd + Dp, Hd])
+        Dp = gcs[0][2].shape[0] - 2 * Hd
+        Dout = gcs[-1][6].shape[0]
+        f = {'in0': P.stack(S, BO, W1.shape[1]), 'h1': P.stack(S, BO, W1.shape[0]), 'ov0': P.stack(S, BO, W2.shape[0])}
+        Dins = []
+        for l, g in enumerate(gcs):
+            Din = (g[0].shape[1] - (pv_all.shape[2] if l == 0 else Dp)) // 2
+            Dins.append(Din)
+            dpi = pv_all.shape[2] if l == 0 else Dp
+            f['cur%d' % l] = P.stack(S, BT, 2 * Din + dpi)
+            f['a1%d' % l] = P.stack(S, BT, g[0].shape[0])
+            f['nt%d' % l] = P.stack(S, BT, g[2].shape[0])
+            f['pool%d' % l] = P.stack(S, BO, Hd)
+            f['cnt%d' % l] = P.stack(S, BO, 1)
+            f['a2%d' % l] = P.stack(S, BO, g[4].shape[0])
+            f['ov%d' % (l + 1)] = P.stack(S, BO, g[6].shape[0])
+        if has_box:
+            f['bh'] = P.stack(S, BO, box[0].shape[0])
+            f['boxes'] = P.stack(S, BO, 4)
+        x0r = P.ext(x0, BO, E)
+        for s in range(S):
+            i0, i1, vl = idx_s[s], idx_o[s], valid[s]
+            if mode == 'emb':
+                bprev = P.ext(boxes_in, BO, 4) if s == 0 else f['boxes'].at(s - 1)
+                P.cat(f['in0'].at(s), [(x0r, None), (bprev, None)])
+            else:
+                ovprev = x0r if s == 0 else f['ov%d' % n_gconv].at(s - 1)
+                P.cat(f['in0'].at(s), [(ovprev, None), (P.ext_at(boxes_in, s, BO, 4), None)])
+            P.gemm(f['in0'].at(s), P.ext(W1), f['h1'].at(s), relu=True)
+            P.gemm(f['h1'].at(s), P.ext(W2), f['ov0'].at(s), relu=True)
+            ov = f['ov0'].at(s)
+            pv = P.ext_at(pv_all, s, BT, pv_all.shape[2])
+            for l, g in enumerate(gcs):
+                n1a_w, n1a_b, n1b_w, n1b_b, n2a_w, n2a_b, n2b_w, n2b_b = g
+                P.cat(f['cur%d' % l].at(s), [(ov, i0), (pv, None), (ov, i1)])
+                P.gemm(f['cur%d' % l].at(s), P.ext(n1a_w), f['a1%d' % l].at(s), bias=n1a_b, relu=True)
+                P.gemm(f['a1%d' % l].at(s), P.ext(n1b_w), f['nt%d' % l].at(s), bias=n1b_b, relu=True)
+                P.pool(f['nt%d' % l].at(s), f['pool%d' % l].at(s), f['cnt%d' % l].at(s), i0, i1, vl, O, T, Hd, Dp)
+                P.gemm(f['pool%d' % l].at(s), P.ext(n2a_w), f['a2%d' % l].at(s), bias=n2a_b, relu=True)
+                P.gemm(f['a2%d' % l].at(s), P.ext(n2b_w), f['ov%d' % (l + 1)].at(s), bias=n2b_b, relu=True)
+                ov = f['ov%d' % (l + 1)].at(s)
+                pv = f['nt%d' % l].at(s).cols_from(Hd, Dp)
+            if has_box:
+                bprev = P.ext(boxes_in, BO, 4) if s == 0 else f['boxes'].at(s - 1)
+                P.gemm(ov, P.ext(box[0]), f['bh'].at(s), bias=box[1], relu=True)
+                P.gemm(f['bh'].at(s), P.ext(box[2]), f['boxes'].at(s), bias=box[3], res=bprev)
+        P.finalize().run()
+        ctx.P, ctx.f, ctx.cfg, ctx.dims = P, f, cfg, (E, Hd, Dp, Dout, Dins)
+        ctx.save_for_backward(x0, pv_all, boxes_in, *params)
+        ctx.wkeys = [(ops._wsink_register(p) if ctx.needs_input_grad[4 + i] else None) for i, p in enumerate(params)]
+        ctx.p_alive = params
+        ov_stack = P.tensor(f['ov%d' % n_gconv])
+        boxes_stack = P.tensor(f['boxes']) if has_box else torch.empty(0, device=dev)
+        return ov_stack, boxes_stack
+
+    @staticmethod
+    def backward(ctx, d_ov, d_boxes):
+        mode, S, BO, BT, O, T, idx_s, idx_o, valid, n_first, n_gconv, has_box = ctx.cfg
+        F, f = ctx.P, ctx.f
+        E, Hd, Dp, Dout, Dins = ctx.dims
+        saved = ctx.saved_tensors
+        x0, pv_all, boxes_in = saved[0], saved[1], saved[2]
+        params = list(saved[3:])
+        W1, W2 = params[0], params[1]
+        gcs = [params[2 + 8 * l: 10 + 8 * l] for l in range(n_gconv)]
+        box = params[2 + 8 * n_gconv: 6 + 8 * n_gconv] if has_box else None
+        dev = x0.device
+        d_ov = torch.zeros((S, BO, Dout), device=dev) if d_ov is None else d_ov.contiguous()
+        if has_box:
+            d_boxes = torch.zeros((S, BO, 4), device=dev) if d_boxes is None else d_boxes.contiguous()
+
+        def fr(name, s):        # a forward value (lives in the forward program's arena)
+            r = f[name].at(s)
+            return Ref(F.arena, r.off, r.rows, r.cols, r.ld)
+        P = Program(dev)
+        P.keep.append(F.arena)
+        # transposed weights: the input-gradient GEMMs reduce over the output index
+        def tr(w):
+            out = P.new(w.shape[1], w.shape[0])
+            P.transpose(P.ext(w), out)
+            return out
+        W1t, W2t = tr(W1), tr(W2)
+        gct = [(tr(g[0]), tr(g[2]), tr(g[4]), tr(g[6])) for g in gcs]
+        boxt = (tr(box[0]), tr(box[2])) if has_box else None
+        g = {'din0': P.stack(S, BO, W1.shape[1]), 'dh1': P.stack(S, BO, W1.shape[0]), 'dov0': P.stack(S, BO, W2.shape[0])}
+        for l in range(n_gconv):
+            dpi = pv_all.shape[2] if l == 0 else Dp
+            g['dcur%d' % l] = P.stack(S, BT, 2 * Dins[l] + dpi)
+            g['da1%d' % l] = P.stack(S, BT, gcs[l][0].shape[0])
+            g['dnt%d' % l] = P.stack(S, BT, gcs[l][2].shape[0])
+            g['dpool%d' % l] = P.stack(S, BO, Hd)
+            g['da2%d' % l] = P.stack(S, BO, gcs[l][4].shape[0])
+            g['dov%d' % (l + 1)] = P.stack(S, BO, gcs[l][6].shape[0])
+        if has_box:
+            g['dbh'] = P.stack(S, BO, box[0].shape[0])
+            g['gbox'] = P.stack(S, BO, 4)
+        for s in range(S - 1, -1, -1):
+            i0, i1, vl = idx_s[s], idx_o[s], valid[s]
+            top = g['dov%d' % n_gconv].at(s)
+            dov_ext = P.ext_at(d_ov, s, BO, Dout)
+            if has_box:
+                # gradient of boxes[s]: the output's, plus (s < S - 1) the residual path and the next step's input columns
+                if s == S - 1:
+                    P.add3(g['gbox'].at(s), P.ext_at(d_boxes, s, BO, 4))
+                else:
+                    P.add3(g['gbox'].at(s), P.ext_at(d_boxes, s, BO, 4), g['gbox'].at(s + 1), g['din0'].at(s + 1).cols_from(E, 4))
+                P.gemm(g['gbox'].at(s), boxt[1], g['dbh'].at(s))
+                P.gemm(g['dbh'].at(s), boxt[0], top, mask=fr('bh', s), res=dov_ext)
+            elif mode == 'ov' and s < S - 1:
+                P.add3(top, dov_ext, g['din0'].at(s + 1).cols_from(0, Dout))
+            else:
+                P.add3(top, dov_ext)
+            for l in range(n_gconv - 1, -1, -1):
+                n1a_t, n1b_t, n2a_t, n2b_t = gct[l]
+                P.gemm(g['dov%d' % (l + 1)].at(s), n2b_t, g['da2%d' % l].at(s), mask=fr('ov%d' % (l + 1), s))
+                P.gemm(g['da2%d' % l].at(s), n2a_t, g['dpool%d' % l].at(s), mask=fr('a2%d' % l, s))
+                dp_in = None
+                if l < n_gconv - 1:
+                    dp_in = g['dcur%d' % (l + 1)].at(s).cols_from(Dins[l + 1], Dp)
+                cnt = fr('cnt%d' % l, s)
+                P.pool_bwd(g['dpool%d' % l].at(s), dp_in, g['dnt%d' % l].at(s), cnt, i0, i1, vl, O, T, Hd, Dp)
+                P.gemm(g['dnt%d' % l].at(s), n1b_t, g['da1%d' % l].at(s), mask=fr('nt%d' % l, s))
+                P.gemm(g['da1%d' % l].at(s), n1a_t, g['dcur%d' % l].at(s), mask=fr('a1%d' % l, s))
+                dpi = pv_all.shape[2] if l == 0 else Dp
+                P.gather_bwd(g['dcur%d' % l].at(s), g['dov%d' % l].at(s), i0, i1, O, T, Dins[l], dpi)
+            P.gemm(g['dov0'].at(s), W2t, g['dh1'].at(s), mask=fr('ov0', s))
+            P.gemm(g['dh1'].at(s), W1t, g['din0'].at(s), mask=fr('h1', s))
+        P.finalize().run()
+        T_ = lambda name: P.tensor(g[name])
+        FT = lambda name: F.tensor(f[name])
+        st = ops._stream()
+        grads = [None] * len(params)
+
+        def lin_grads(wi, bi, A, dY, Y):
+            """dW (+)= dZ^T A, db (+)= column sums of dZ, dZ = dY masked by the forward output Y (None: no ReLU) -- over all steps."""
+            M = dY.shape[0] * dY.shape[1]
+            N, K = dY.shape[2], A.shape[2]
+            dZ = dY.reshape(M, N)
+            if Y is not None:
+                z = torch.empty_like(dZ)
+                _lib.call('ag2v_relu_bwd', ops._ptr(dZ), ops._ptr(Y.reshape(M, N)), ops._ptr(z), dZ.numel(), st)
+                dZ = z
+            if ctx.needs_input_grad[4 + wi]:
+                buf, acc, dw = ops._wsink_take(ctx.wkeys[wi], ctx.p_alive[wi])
+                _lib.call('ag2v_gemm_f32', ops._ptr(dZ), ops._ptr(A.reshape(M, K)), None, ops._ptr(buf), N, K, M, 1, N, K, 1, K, 0, acc, st)
+                grads[wi] = dw
+            if bi is not None and ctx.needs_input_grad[4 + bi]:
+                bbuf, bacc, db = ops._wsink_take(ctx.wkeys[bi], ctx.p_alive[bi])
+                if bacc:
+                    t = torch.empty(N, device=dev, dtype=torch.float32)
+                    _lib.call('ag2v_col_sum', ops._ptr(dZ), ops._ptr(t), M, N, st)
+                    bbuf.add_(t)
+                else:
+                    _lib.call('ag2v_col_sum', ops._ptr(dZ), ops._ptr(bbuf), M, N, st)
+                grads[bi] = db
+        lin_grads(0, None, FT('in0'), T_('dh1'), FT('h1'))
+        lin_grads(1, None, FT('h1'), T_('dov0'), FT('ov0'))
+        for l in range(n_gconv):
+            b0 = 2 + 8 * l
+            lin_grads(b0, b0 + 1, FT('cur%d' % l), T_('da1%d' % l), FT('a1%d' % l))
+            lin_grads(b0 + 2, b0 + 3, FT('a1%d' % l), T_('dnt%d' % l), FT('nt%d' % l))
+            lin_grads(b0 + 4, b0 + 5, FT('pool%d' % l), T_('da2%d' % l), FT('a2%d' % l))
+            lin_grads(b0 + 6, b0 + 7, FT('a2%d' % l), T_('dov%d' % (l + 1)), FT('ov%d' % (l + 1)))
+        if has_box:
+            b0 = 2 + 8 * n_gconv
+            lin_grads(b0, b0 + 1, FT('ov%d' % n_gconv), T_('dbh'), FT('bh'))
+            lin_grads(b0 + 2, b0 + 3, FT('bh'), T_('gbox'), None)
+        din0 = T_('din0')
+        dx0 = dpv = None
+        if ctx.needs_input_grad[1]:
+            dx0 = din0[:, :, :E].sum(dim=0) if mode == 'emb' else din0[0, :, :Dout].contiguous()
+        if ctx.needs_input_grad[2]:
+            dpv = T_('dcur0')[:, :, Dins[0]:Dins[0] + pv_all.shape[2]].contiguous()
+        ctx.P = ctx.f = None
+        return (None, dx0, dpv, None) + tuple(grads)
+
+
+def _row_indices(edges_all, O):
+    """edges_all int64 [S, B, T, 2] (object index inside the sample) -> int32 row indices b * O + index, [S, B * T] each."""
+    S, B, T, _ = edges_all.shape
+    base = (torch.arange(B, device=edges_all.device, dtype=torch.int64) * O).view(1, B, 1)
+    i0 = (edges_all[..., 0] + base).reshape(S, B * T).to(torch.int32).contiguous()
+    i1 = (edges_all[..., 1] + base).reshape(S, B * T).to(torch.int32).contiguous()
+    return i0, i1
+
+
+def run_recurrence(mode, x0, pv_steps, edges_steps, ind_steps, boxes_in, first, gconvs, box):
+    """x0 [B, O, E | D]; pv_steps [S, B, T, Dp]; edges_steps int64 [S, B, T, 2]; ind_steps bool [S, B, T]; boxes_in [B, O, 4]
+    (mode 'emb': the first frame's boxes) or [S, B, O, 4] (mode 'ov'); first = obj_vecs_net's two Linear modules, gconvs = list of
+    GraphTripleConv, box = box_net's two Linear modules or None.  Returns (ov [S, B, O, Dout], boxes [S, B, O, 4] or None)."""
+    S, B, T = pv_steps.shape[0], pv_steps.shape[1], pv_steps.shape[2]
+    O = x0.shape[1]
+    i0, i1 = _row_indices(edges_steps, O)
+    valid = ind_steps.reshape(S, B * T).to(torch.uint8).contiguous()
+    params = [first[0].weight, first[1].weight]
+    for gc in gconvs:
+        lins = [m for m in gc.net1.children() if hasattr(m, 'weight')] + [m for m in gc.net2.children() if hasattr(m, 'weight')]
+        for m in lins:
+            params += [m.weight, m.bias]
+    if box is not None:
+        params += [box[0].weight, box[0].bias, box[1].weight, box[1].bias]
+    cfg = (mode, S, B * O, B * T, O, T, list(i0.unbind(0)), list(i1.unbind(0)), list(valid.unbind(0)), 2, len(gconvs), box is not None)
+    bi = boxes_in.reshape(B * O, 4) if mode == 'emb' else boxes_in.reshape(S, B * O, 4)
+    ov, boxes = _Recurrence.apply(cfg, x0.reshape(B * O, -1), pv_steps.reshape(S, B * T, -1), bi, *params)
+    ov = ov.view(S, B, O, -1)
+    return ov, (boxes.view(S, B, O, 4) if box is not None else None)
+
+
+def supported(module_or_opt):
+    args = module_or_opt if isinstance(module_or_opt, dict) else vars(module_or_opt)
+    return enabled() and args.get('mlp_normalization', 'none') in ('none', None) and args.get('gconv_pooling', 'avg') == 'avg'

@@ -90,7 +90,19 @@ class Acts2LayoutModel(nn.Module):
             ind_all, edges_all, pv_all = a_ind, a_edges, av
         ind_all = ind_all.transpose(0, 1).contiguous()            # [F, B, ...]: a step is a contiguous slice
         edges_all = edges_all.transpose(0, 1).contiguous()
-        pv_steps = pv_all.transpose(0, 1).contiguous().unbind(0)        # (unbind: ONE stacked gradient in the backward pass)
+        pv_fm = pv_all.transpose(0, 1).contiguous()                     # [F, B, T, D]
+        from ... import graph_program
+        if emb.is_cuda and timesteps > 1 and graph_program.supported(self.args):
+            # the whole recurrence as one persistent-kernel program per pass (ag2video_amd/graph_program.py)
+            lin = [m for m in self.obj_vecs_net.children() if isinstance(m, Linear)]
+            blin = [m for m in self.box_net.children() if isinstance(m, Linear)]
+            ov, boxes = graph_program.run_recurrence('emb', emb, pv_fm[1:], edges_all[1:], ind_all[1:], boxes_gt[:, 0], lin,
+                                                     list(self.gconvs), blin)
+            tvecs = torch.cat([tvecs[0].unsqueeze(1), ov.permute(1, 0, 2, 3)], dim=1)
+            boxes_pred = torch.cat([boxes_gt[:, :1], boxes.permute(1, 0, 2, 3)], dim=1)
+            locs = torch.stack([x_end, y_end], dim=-1)
+            return tvecs, boxes_pred, [triplets, temporal_triplets, rel, locs]
+        pv_steps = pv_fm.unbind(0)        # (unbind: ONE stacked gradient in the backward pass)
         for t in range(1, timesteps):
             boxes_c = boxes_pred[-1]
             ov = self.obj_vecs_net(torch.cat([emb, boxes_c], dim=-1))

@@ -130,8 +130,14 @@ class MultiscaleActionDiscriminator(nn.Module):
         s, a, o = temporal_triplets[..., 0], temporal_triplets[..., 1], temporal_triplets[..., 2]           # [B, T, A]
         edges_all = torch.stack([s, o], dim=-1).long().transpose(0, 1).contiguous()
         ind_all = (a != pad).transpose(0, 1).contiguous()
-        pv_steps = action_edge_vectors(self.acts_embeddings, a, x_end, y_end, rel).transpose(0, 1).contiguous().unbind(0)
+        pv_fm = action_edge_vectors(self.acts_embeddings, a, x_end, y_end, rel).transpose(0, 1).contiguous()         # [T, B, A, D]
         boxes_steps = layout_boxes.transpose(0, 1).contiguous()
+        from .... import graph_program
+        if ov.is_cuda and graph_program.supported(self.opt):
+            lin = [m for m in self.obj_vecs_net.children() if isinstance(m, Linear)]
+            out, _ = graph_program.run_recurrence('ov', ov, pv_fm, edges_all, ind_all, boxes_steps, lin, list(self.gconvs), None)
+            return out.permute(1, 0, 2, 3)
+        pv_steps = pv_fm.unbind(0)
         for t in range(layout_boxes.size(1)):
             ov = self.obj_vecs_net(torch.cat([ov, boxes_steps[t]], dim=-1))
             edges, ind, pv = edges_all[t], ind_all[t], pv_steps[t]

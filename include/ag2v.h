@@ -334,6 +334,25 @@ size_t ag2v_sn_desc_bytes(void);
 int ag2v_spectral_sigmas_multi(const void* descs, int n_layers, int total_blocks, int total_rows, int T, float eps, int deterministic,
                                void* stream);
 
+/* ---- graph-net programs: one persistent launch per recurrent pass of an action-graph net -------------------------------------
+ * Replaces the per-operator launches of Acts2LayoutModel.forward's loop over time steps (models/graph_models/model.py:126-169),
+ * GraphTripleConv (graph.py:41-107) and MultiscaleActionDiscriminator.get_obj_vecs (discriminator.py:273-313): the host writes the
+ * pass as an array of operator records over caller-owned tensors and `grid` co-resident workgroups interpret it, meeting at a grid
+ * barrier (agent-scope release / acquire) after every operator.  Record layout (ag2v_graph_op_bytes() = 192 bytes, little endian):
+ *   int type, M, N, K;  const float *a, *b, *d, *bias, *res, *mask;  float *c;  const int *i0, *i1, *i2;  const unsigned char *valid;
+ *   long long lda, ldb, ldd, ldr, ldm, ldc;  int w0, w1, w2, relu, acc, O, T, pad[3];
+ * type 1 GEMM  c[m,n] = act(sum_k A'[m,k] b[n,k] + bias[n]) + res[m,n], A' = mask ? (mask[m,k] > 0 ? a : 0) : a  (exact fp32 MFMA)
+ *      2 CAT   c[r,:] = [a[i0(r), :w0] | b[i1(r), :w1] | d[i2(r), :w2]]   (null index = r; null b / d = segment absent)
+ *      3 POOL  masked average pooling onto objects (graph.py:79-100): a = new triples [B*T, 2 w0 + w1], i0 / i1 = subject / object
+ *              ROW (b * O + object) per edge, valid per edge; c [B*O, w0]; counts written to `mask` (as floats)
+ *      4 POOL_BWD  adjoint: a = dpooled, b = gradient of the predicate part (nullable), mask = counts; c [B*T, 2 w0 + w1]
+ *      5 GATHER_BWD  c[bo, :w0] = res[bo] + sum over the sample's edges of the subject / object parts of a [B*T, 2 w0 + w1]
+ *      6 TRANSPOSE  c[k, n] = a[n, k]        7 ADD3  c = a + b + d (b, d nullable), M rows of N columns
+ * sync: two device words {arrival counter (zeroed by the call), timeout flag (set when a barrier gave up: results invalid)}. */
+size_t ag2v_graph_op_bytes(void);
+int ag2v_graph_program_grid(void);
+int ag2v_graph_program_run(const void* ops, int n_ops, unsigned* sync, int grid, void* stream);
+
 /* ---- fused Adam over a flat fp32 buffer: torch.optim.Adam as configured at scripts/train.py:365-368 and
  * meta_models.py:70-72 (weight_decay 0, amsgrad off); step_index >= 1 --------------------------------------------- */
 int ag2v_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
