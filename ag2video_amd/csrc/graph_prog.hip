@@ -9,9 +9,15 @@
 // Here the host writes the pass as a PROGRAM -- an array of operator descriptors (GOp) over tensors of one pre-planned arena -- and a
 // single launch of G co-resident workgroups interprets it: every workgroup takes its share of an operator's output tiles / rows, then
 // all meet at a grid barrier.  No tensor is reused inside a program (a forward value is the backward's mask), so the only hazards are
-// producer -> consumer across workgroups, which the barrier orders with an agent-scope release / acquire pair
-// (cdna_hip_programming.md, Guideline 16: a workgroup's stores are drained, one lane releases and adds to the arrival counter with an
-// agent-scope atomic, polls it, acquires, and the workgroup barrier passes the acquire on to the other waves).
+// producer -> consumer across workgroups on different XCDs (private, non-coherent L2s).  Visibility without cache-wide fences -- an
+// agent-scope release / acquire per barrier writes back and invalidates whole L2s: 21 us per operator measured, the weights re-fetched
+// from memory for every operator -- rests on a WRITE-ONCE discipline (cdna_hip_programming.md, Guideline 16, sc1 payload form):
+//   * every store of the program is WRITE-THROUGH (sc1: __hip_atomic_store, relaxed, agent scope) and drained (s_waitcnt vmcnt(0))
+//     by its wave before the workgroup arrives at the barrier, so the bytes are in memory when the arrival counter moves;
+//   * every tensor is written by exactly one operator and read only by later ones, and tensors never share a 128-byte line (the
+//     arena hands out 128-byte-aligned blocks): no cache can hold a line of a tensor from before it was written, so plain loads
+//     after the barrier miss and fetch the written bytes (caches start clean at the launch boundary; nothing prefetches);
+//   * the arrival counter is only touched by agent-scope atomics.
 //
 // Operators (all fp32; matrices row-major with explicit row strides, so slices and stacks are views):
 //   GEMM        C[m,n] = act(sum_k A'[m,k] B[n,k] + bias[n]) + res[m,n],  A' = A, or (mask > 0 ? A : 0) -- the backward of a ReLU
@@ -51,20 +57,22 @@ static_assert(sizeof(GOp) == 192, "GOp layout is part of the host interface");
 #define GP_WAVES 16
 #define GP_SPIN_LIMIT (1u << 24)
 
-// ---------------------------------------------------------------- grid barrier (agent-scope release / acquire)
+// write-through store (sc1): the value is in memory once the storing wave's vmcnt has drained
+__device__ __forceinline__ void st_wt(float* p, float v) {
+    __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------- grid barrier (arrival counter; visibility: see the header)
 __device__ __forceinline__ void grid_barrier(unsigned* ctr, unsigned target, unsigned* timeout) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every wave: its stores have reached L2
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
         while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(1);
             if (++spins > GP_SPIN_LIMIT) { __hip_atomic_store(timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
 }
@@ -73,62 +81,75 @@ __device__ __forceinline__ void grid_barrier(unsigned* ctr, unsigned target, uns
 // one 32 x 32 tile: wave w takes k in [w * Kw, (w + 1) * Kw), Kw a multiple of 8; lane (r = lane & 31, h = lane >> 5) loads
 // A[m0 + r][k8 + 4 h .. + 3] and B[n0 + r][k8 + 4 h .. + 3] for every k8 of its slice at once; MFMA j of a k8 step multiplies the
 // k = k8 + j (h = 0) and k = k8 + 4 + j (h = 1) columns.  Partials meet in LDS [16][1024].
-#define GP_MAXSTEP 8        // k8 steps per wave held in registers at once (K <= 16 * 8 * 8 = 1024 in one batch; longer K loops)
-__device__ __forceinline__ void gemm_tile(const GOp& o, int tm, int tn, float* red) {
+typedef unsigned gp_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t gp_rsrc(const void* p, long long bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes > 0xFFFFFFF0LL ? 0xFFFFFFF0u : (unsigned)bytes, 0x00020000);
+}
+// One 32 x 32 output tile.  Wave w owns the k slice [w Kw, (w + 1) Kw), Kw a multiple of 8, and walks it in chunks of 32 columns:
+//   * the chunk of A (and of the ReLU mask) and of B is loaded COALESCED -- eight lanes cover the 128 contiguous bytes of one row,
+//     a wave instruction eight whole rows (a first version loaded MFMA-fragment-shaped, one 16-byte piece of each of 32 rows per
+//     instruction: 64 partial cache lines per wave-load x 16 waves kept the CU's address unit busy for ~8 us per tile);
+//   * staged through a wave-private LDS block [32][33] per operand (only this wave reads what it wrote: no workgroup barrier),
+//     from which the MFMA operands are conflict-free ds_read_b32; the next chunk's loads are in flight meanwhile;
+//   * the 16 partial tiles meet in LDS (aliasing the staging blocks) and the 1024 threads finish one element each.
+#define GP_CH 32
+#define GP_PITCH 33
+__device__ __forceinline__ void gemm_tile(const GOp& o, int tm, int tn, float* lds) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int m = tm * 32 + r, n = tn * 32 + r;
-    const int K = o.K;
+    const int K = o.K;                                          // K % 4 == 0, every leading dimension % 4 == 0, 16-byte aligned bases
     const int Kw = ((K + GP_WAVES * 8 - 1) / (GP_WAVES * 8)) * 8;
     const int k_lo = wave * Kw, k_hi = min(K, k_lo + Kw);
-    const bool mok = m < o.M, nok = n < o.N;
-    const float* ap = o.a + (size_t)(mok ? m : 0) * o.lda;
-    const float* mp = o.mask ? o.mask + (size_t)(mok ? m : 0) * o.ldm : nullptr;
-    const float* bp = o.b + (size_t)(nok ? n : 0) * o.ldb;
-    const bool vec = ((o.lda | o.ldb | (o.mask ? o.ldm : 0)) & 3) == 0 &&
-                     ((((uintptr_t)o.a) | ((uintptr_t)o.b) | ((uintptr_t)(o.mask ? o.mask : o.a))) & 15) == 0;
+    const __amdgpu_buffer_rsrc_t ars = gp_rsrc(o.a, ((long long)(o.M - 1) * o.lda + K) * 4);
+    const __amdgpu_buffer_rsrc_t brs = gp_rsrc(o.b, ((long long)(o.N - 1) * o.ldb + K) * 4);
+    const bool masked = o.mask != nullptr;
+    const __amdgpu_buffer_rsrc_t mrs = gp_rsrc(masked ? o.mask : o.a, ((long long)(o.M - 1) * (masked ? o.ldm : o.lda) + K) * 4);
+    float* sa = lds + wave * (2 * 32 * GP_PITCH);               // this wave's staging blocks
+    float* sb = sa + 32 * GP_PITCH;
+    // unit u = it * 64 + lane of a chunk: row u >> 3, four columns 4 (u & 7)
+    const int urow = lane >> 3, ucol = 4 * (lane & 7);
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    for (int kb = k_lo; kb < k_hi; kb += 8 * GP_MAXSTEP) {
-        float4 av[GP_MAXSTEP], bv[GP_MAXSTEP];
+    gp_u32x4 ra[4], rb[4], rm[4];
+    auto fetch = [&](int kc) {
 #pragma unroll
-        for (int s = 0; s < GP_MAXSTEP; ++s) {
-            const int k = kb + 8 * s + 4 * h;
-            float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = a4;
-            if (k < k_hi) {
-                if (vec && k + 3 < k_hi) {
-                    if (mok) {
-                        a4 = *reinterpret_cast<const float4*>(ap + k);
-                        if (mp) {
-                            const float4 q = *reinterpret_cast<const float4*>(mp + k);
-                            a4.x = q.x > 0.f ? a4.x : 0.f; a4.y = q.y > 0.f ? a4.y : 0.f;
-                            a4.z = q.z > 0.f ? a4.z : 0.f; a4.w = q.w > 0.f ? a4.w : 0.f;
-                        }
-                    }
-                    if (nok) b4 = *reinterpret_cast<const float4*>(bp + k);
-                } else {
-                    float at[4] = {0.f, 0.f, 0.f, 0.f}, bt[4] = {0.f, 0.f, 0.f, 0.f};
-                    for (int j = 0; j < 4; ++j)
-                        if (k + j < k_hi) {
-                            if (mok) at[j] = (mp && !(mp[k + j] > 0.f)) ? 0.f : ap[k + j];
-                            if (nok) bt[j] = bp[k + j];
-                        }
-                    a4 = make_float4(at[0], at[1], at[2], at[3]);
-                    b4 = make_float4(bt[0], bt[1], bt[2], bt[3]);
-                }
+        for (int it = 0; it < 4; ++it) {
+            const int row = it * 8 + urow, k = kc + ucol;
+            const bool kok = k < k_hi;
+            const int m = tm * 32 + row, n = tn * 32 + row;
+            const unsigned ao = (kok && m < o.M) ? (unsigned)(((long long)m * o.lda + k) * 4) : 0xFFFFFFFFu;
+            const unsigned bo = (kok && n < o.N) ? (unsigned)(((long long)n * o.ldb + k) * 4) : 0xFFFFFFFFu;
+            ra[it] = __builtin_amdgcn_raw_buffer_load_b128(ars, ao, 0, 0);
+            rb[it] = __builtin_amdgcn_raw_buffer_load_b128(brs, bo, 0, 0);
+            if (masked) {
+                const unsigned mo = (kok && m < o.M) ? (unsigned)(((long long)m * o.ldm + k) * 4) : 0xFFFFFFFFu;
+                rm[it] = __builtin_amdgcn_raw_buffer_load_b128(mrs, mo, 0, 0);
             }
-            av[s] = a4; bv[s] = b4;
         }
+    };
+    const int r = lane & 31, h = lane >> 5;
+    if (k_lo < k_hi) fetch(k_lo);
+    for (int kc = k_lo; kc < k_hi; kc += GP_CH) {
 #pragma unroll
-        for (int s = 0; s < GP_MAXSTEP; ++s) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s].x, bv[s].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s].y, bv[s].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s].z, bv[s].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s].w, bv[s].w, acc, 0, 0, 0);
+        for (int it = 0; it < 4; ++it) {
+            const int row = it * 8 + urow;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float a = __uint_as_float(ra[it][j]);
+                if (masked) a = (__uint_as_float(rm[it][j]) > 0.f) ? a : 0.f;
+                sa[row * GP_PITCH + ucol + j] = a;
+                sb[row * GP_PITCH + ucol + j] = __uint_as_float(rb[it][j]);
+            }
         }
+        if (kc + GP_CH < k_hi) fetch(kc + GP_CH);               // next chunk in flight under this chunk's MFMAs
+        __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0): this wave's LDS writes have landed (wave-private block)
+        const int nk = min(GP_CH, k_hi - kc);
+#pragma unroll 4
+        for (int k2 = 0; k2 < nk; k2 += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[r * GP_PITCH + k2 + h], sb[r * GP_PITCH + k2 + h], acc, 0, 0, 0);
     }
-    __syncthreads();                                   // the previous tile's reduction reads are done
+    __syncthreads();                                   // every wave is done with its staging block: the reduction buffer aliases them
+    float* red = lds;
 #pragma unroll
     for (int i = 0; i < 16; ++i) red[wave * 1024 + i * 64 + lane] = acc[i];
     __syncthreads();
@@ -143,94 +164,112 @@ __device__ __forceinline__ void gemm_tile(const GOp& o, int tm, int tn, float* r
         if (o.relu) s = fmaxf(s, 0.f);
         if (o.res) s += o.res[(size_t)row * o.ldr + col];
         float* dst = o.c + (size_t)row * o.ldc + col;
-        *dst = o.acc ? *dst + s : s;
+        st_wt(dst, o.acc ? *dst + s : s);
     }
+    __syncthreads();                                   // the reduction reads are done before the next tile stages into the same LDS
 }
 
-// ---------------------------------------------------------------- row operators: one wave per row, lanes along the columns
-__device__ __forceinline__ void op_cat(const GOp& o, int row) {
-    const int lane = threadIdx.x & 63;
-    float* dst = o.c + (size_t)row * o.ldc;
-    const float* s0 = o.a + (size_t)(o.i0 ? o.i0[row] : row) * o.lda;
-    for (int i = lane; i < o.w0; i += 64) dst[i] = s0[i];
-    if (o.b) {
-        const float* s1 = o.b + (size_t)(o.i1 ? o.i1[row] : row) * o.ldb;
-        for (int i = lane; i < o.w1; i += 64) dst[o.w0 + i] = s1[i];
-    }
-    if (o.d) {
-        const float* s2 = o.d + (size_t)(o.i2 ? o.i2[row] : row) * o.ldd;
-        for (int i = lane; i < o.w2; i += 64) dst[o.w0 + o.w1 + i] = s2[i];
+// ---------------------------------------------------------------- element-parallel operators (gid = one group of 4 columns of one row)
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st_wt4(float* p, float4 v) { st_wt(p, v.x); st_wt(p + 1, v.y); st_wt(p + 2, v.z); st_wt(p + 3, v.w); }
+
+// every segment width and leading dimension is a multiple of 4 (builder)
+__device__ __forceinline__ void op_cat(const GOp& o, long long gid, long long nthreads) {
+    const int W4 = (o.w0 + o.w1 + o.w2) >> 2;
+    for (long long u = gid; u < (long long)o.M * W4; u += nthreads) {
+        const int row = (int)(u / W4), c = 4 * (int)(u - (long long)row * W4);
+        const float* src;
+        if (c < o.w0) src = o.a + (size_t)(o.i0 ? o.i0[row] : row) * o.lda + c;
+        else if (c < o.w0 + o.w1) src = o.b + (size_t)(o.i1 ? o.i1[row] : row) * o.ldb + (c - o.w0);
+        else src = o.d + (size_t)(o.i2 ? o.i2[row] : row) * o.ldd + (c - o.w0 - o.w1);
+        st_wt4(o.c + (size_t)row * o.ldc + c, ld4(src));
     }
 }
 // pooled[bo, :Hd] = (sum over valid edges t of sample b with s(t) == bo of newt[t, :Hd] + ... o(t) == bo of newt[t, Hd + Dp:]) / count
-__device__ __forceinline__ void op_pool(const GOp& o, int bo) {
-    const int lane = threadIdx.x & 63;
-    const int b = bo / o.O, Hd = o.w0, Dp = o.w1;
-    int cnt = 0;
+// T <= 32: the incidence of the sample's edges on this object is gathered into two bit masks first (independent index loads), then the
+// matching rows are summed (independent data loads) -- a loop of "load index, compare, load data" was a 17-deep dependent chain (51 us)
+__device__ __forceinline__ void edge_masks(const GOp& o, int b, int bo, bool use_valid, unsigned& ms, unsigned& mo) {
+    ms = mo = 0;
+#pragma unroll 8
     for (int t = 0; t < o.T; ++t) {
         const int e = b * o.T + t;
-        if (!o.valid[e]) continue;
-        cnt += (o.i0[e] == bo) + (o.i1[e] == bo);
+        const bool v = !use_valid || o.valid[e] != 0;
+        ms |= (v && o.i0[e] == bo) ? (1u << t) : 0u;
+        mo |= (v && o.i1[e] == bo) ? (1u << t) : 0u;
     }
-    for (int i = lane; i < Hd; i += 64) {
-        float acc = 0.f;
+}
+__device__ __forceinline__ void op_pool(const GOp& o, long long gid, long long nthreads) {
+    const int Hd = o.w0, Dp = o.w1, H4 = Hd >> 2;
+    for (long long u = gid; u < (long long)o.M * H4; u += nthreads) {
+        const int bo = (int)(u / H4), c = 4 * (int)(u - (long long)bo * H4);
+        const int b = bo / o.O;
+        unsigned ms, mo;
+        edge_masks(o, b, bo, true, ms, mo);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
         for (int t = 0; t < o.T; ++t) {
-            const int e = b * o.T + t;
-            if (!o.valid[e]) continue;
-            if (o.i0[e] == bo) acc += o.a[(size_t)e * o.lda + i];
-            if (o.i1[e] == bo) acc += o.a[(size_t)e * o.lda + Hd + Dp + i];
+            const float* rowp = o.a + (size_t)(b * o.T + t) * o.lda + c;
+            if ((ms >> t) & 1u) { const float4 v = ld4(rowp); acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+            if ((mo >> t) & 1u) { const float4 v = ld4(rowp + Hd + Dp); acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
         }
-        o.c[(size_t)bo * o.ldc + i] = cnt > 0 ? acc / (float)cnt : acc;
-    }
-    if (lane == 0) const_cast<float*>(o.mask)[bo] = (float)cnt;          // counts (written here, read by POOL_BWD of the backward program)
-}
-__device__ __forceinline__ void op_pool_bwd(const GOp& o, int bt) {
-    const int lane = threadIdx.x & 63;
-    const int Hd = o.w0, Dp = o.w1;
-    const int s = o.i0[bt], ob = o.i1[bt];
-    const bool v = o.valid[bt] != 0;
-    const float cs = o.mask[s], co = o.mask[ob];
-    const float is = (v && cs > 0.f) ? 1.0f / cs : 0.f, io = (v && co > 0.f) ? 1.0f / co : 0.f;
-    const float* ds = o.a + (size_t)s * o.lda;
-    const float* dob = o.a + (size_t)ob * o.lda;
-    float* dst = o.c + (size_t)bt * o.ldc;
-    for (int i = lane; i < 2 * Hd + Dp; i += 64) {
-        float g;
-        if (i < Hd) g = v ? ds[i] * is : 0.f;
-        else if (i < Hd + Dp) g = o.b ? o.b[(size_t)bt * o.ldb + (i - Hd)] : 0.f;
-        else g = v ? dob[i - Hd - Dp] * io : 0.f;
-        dst[i] = g;
+        const int cnt = __builtin_popcount(ms) + __builtin_popcount(mo);
+        if (cnt > 0) { const float q = (float)cnt; acc.x /= q; acc.y /= q; acc.z /= q; acc.w /= q; }
+        st_wt4(o.c + (size_t)bo * o.ldc + c, acc);
+        if (c == 0) st_wt(const_cast<float*>(o.mask) + bo, (float)cnt);      // counts (read by POOL_BWD of the backward program)
     }
 }
-// dobj[bo, :Din] (+)= res[bo] + sum_t (s(t) == bo) dtri[t, :Din] + (o(t) == bo) dtri[t, Din + Dp:]   (every edge: the gather is unmasked)
-__device__ __forceinline__ void op_gather_bwd(const GOp& o, int bo) {
-    const int lane = threadIdx.x & 63;
-    const int b = bo / o.O, Din = o.w0, Dp = o.w1;
-    for (int i = lane; i < Din; i += 64) {
-        float acc = o.res ? o.res[(size_t)bo * o.ldr + i] : 0.f;
+__device__ __forceinline__ void op_pool_bwd(const GOp& o, long long gid, long long nthreads) {
+    const int Hd = o.w0, Dp = o.w1, W4 = (2 * Hd + Dp) >> 2;
+    for (long long u = gid; u < (long long)o.M * W4; u += nthreads) {
+        const int bt = (int)(u / W4), c = 4 * (int)(u - (long long)bt * W4);
+        const bool v = o.valid[bt] != 0;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < Hd || c >= Hd + Dp) {
+            const int ob = (c < Hd) ? o.i0[bt] : o.i1[bt];
+            const float cn = o.mask[ob];
+            const float inv = (v && cn > 0.f) ? 1.0f / cn : 0.f;
+            const float4 d = ld4(o.a + (size_t)ob * o.lda + (c < Hd ? c : c - Hd - Dp));
+            g = make_float4(d.x * inv, d.y * inv, d.z * inv, d.w * inv);
+        } else if (o.b) {
+            g = ld4(o.b + (size_t)bt * o.ldb + (c - Hd));
+        }
+        st_wt4(o.c + (size_t)bt * o.ldc + c, g);
+    }
+}
+// dobj[bo, :Din] = res[bo] + sum_t (s(t) == bo) dtri[t, :Din] + (o(t) == bo) dtri[t, Din + Dp:]   (every edge: the gather is unmasked)
+__device__ __forceinline__ void op_gather_bwd(const GOp& o, long long gid, long long nthreads) {
+    const int Din = o.w0, Dp = o.w1, D4 = Din >> 2;
+    for (long long u = gid; u < (long long)o.M * D4; u += nthreads) {
+        const int bo = (int)(u / D4), c = 4 * (int)(u - (long long)bo * D4);
+        const int b = bo / o.O;
+        unsigned ms, mo;
+        edge_masks(o, b, bo, false, ms, mo);
+        float4 acc = o.res ? ld4(o.res + (size_t)bo * o.ldr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
         for (int t = 0; t < o.T; ++t) {
-            const int e = b * o.T + t;
-            if (o.i0[e] == bo) acc += o.a[(size_t)e * o.lda + i];
-            if (o.i1[e] == bo) acc += o.a[(size_t)e * o.lda + Din + Dp + i];
+            const float* rowp = o.a + (size_t)(b * o.T + t) * o.lda + c;
+            if ((ms >> t) & 1u) { const float4 v = ld4(rowp); acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+            if ((mo >> t) & 1u) { const float4 v = ld4(rowp + Din + Dp); acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
         }
-        o.c[(size_t)bo * o.ldc + i] = acc;
+        st_wt4(o.c + (size_t)bo * o.ldc + c, acc);
     }
 }
-__device__ __forceinline__ void op_add3(const GOp& o, int row) {
-    const int lane = threadIdx.x & 63;
-    for (int i = lane; i < o.N; i += 64) {
-        float v = o.a[(size_t)row * o.lda + i];
-        if (o.b) v += o.b[(size_t)row * o.ldb + i];
-        if (o.d) v += o.d[(size_t)row * o.ldd + i];
-        o.c[(size_t)row * o.ldc + i] = v;
+__device__ __forceinline__ void op_add3(const GOp& o, long long gid, long long nthreads) {
+    const int N4 = o.N >> 2;
+    for (long long u = gid; u < (long long)o.M * N4; u += nthreads) {
+        const int row = (int)(u / N4), c = 4 * (int)(u - (long long)row * N4);
+        float4 v = ld4(o.a + (size_t)row * o.lda + c);
+        if (o.b) { const float4 t = ld4(o.b + (size_t)row * o.ldb + c); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+        if (o.d) { const float4 t = ld4(o.d + (size_t)row * o.ldd + c); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+        st_wt4(o.c + (size_t)row * o.ldc + c, v);
     }
 }
 
 __global__ __launch_bounds__(GP_THREADS) void graph_program_kernel(const GOp* __restrict__ ops, int n_ops, unsigned* __restrict__ sync) {
-    __shared__ float red[GP_WAVES * 1024];
+    __shared__ __attribute__((aligned(16))) float red[GP_WAVES * 2 * 32 * GP_PITCH];      // staging blocks / reduction buffer (>= 16 x 1024)
     __shared__ GOp cur;
     const int G = gridDim.x, wg = blockIdx.x;
-    const int wave = threadIdx.x >> 6;
+    const long long gid = (long long)wg * GP_THREADS + threadIdx.x, nthreads = (long long)G * GP_THREADS;
     for (int k = 0; k < n_ops; ++k) {
         // the descriptor through LDS: one copy per workgroup, then uniform reads (the array is constant for the launch)
         __syncthreads();
@@ -243,19 +282,19 @@ __global__ __launch_bounds__(GP_THREADS) void graph_program_kernel(const GOp* __
                 for (int t = wg; t < tms * tns; t += G) gemm_tile(o, t % tms, t / tms, red);
             } break;
             case GOP_CAT:
-                for (int r = wg * GP_WAVES + wave; r < o.M; r += G * GP_WAVES) op_cat(o, r);
+                op_cat(o, gid, nthreads);
                 break;
             case GOP_POOL:
-                for (int r = wg * GP_WAVES + wave; r < o.M; r += G * GP_WAVES) op_pool(o, r);
+                op_pool(o, gid, nthreads);
                 break;
             case GOP_POOL_BWD:
-                for (int r = wg * GP_WAVES + wave; r < o.M; r += G * GP_WAVES) op_pool_bwd(o, r);
+                op_pool_bwd(o, gid, nthreads);
                 break;
             case GOP_GATHER_BWD:
-                for (int r = wg * GP_WAVES + wave; r < o.M; r += G * GP_WAVES) op_gather_bwd(o, r);
+                op_gather_bwd(o, gid, nthreads);
                 break;
             case GOP_ADD3:
-                for (int r = wg * GP_WAVES + wave; r < o.M; r += G * GP_WAVES) op_add3(o, r);
+                op_add3(o, gid, nthreads);
                 break;
             case GOP_TRANSPOSE: {       // c[k * ldc + n] = a[n * lda + k], n < N, k < K: 32 x 32 tiles through LDS (red as [32][33])
                 const int tns = (o.N + 31) >> 5, tks = (o.K + 31) >> 5;
@@ -265,7 +304,7 @@ __global__ __launch_bounds__(GP_THREADS) void graph_program_kernel(const GOp* __
                     __syncthreads();
                     red[y * 33 + x] = (n0 + y < o.N && k0 + x < o.K) ? o.a[(size_t)(n0 + y) * o.lda + k0 + x] : 0.f;
                     __syncthreads();
-                    if (k0 + y < o.K && n0 + x < o.N) o.c[(size_t)(k0 + y) * o.ldc + n0 + x] = red[x * 33 + y];
+                    if (k0 + y < o.K && n0 + x < o.N) st_wt(o.c + (size_t)(k0 + y) * o.ldc + n0 + x, red[x * 33 + y]);
                 }
             } break;
             default: break;

@@ -44,13 +44,17 @@ class Ref(object):
 
 
 class Stack(object):
-    """[steps, rows, cols] contiguous in the arena: one slot per time step (the weight-gradient GEMMs read the whole stack)."""
+    """[steps, rows, cols] in the arena, one slot per time step (the weight-gradient GEMMs read the whole stack).  Slots start on
+    128-byte boundaries -- a slot is written at its own step while its neighbours are read at others, and tensors must not share a
+    cache line (csrc/graph_prog.hip) --, i.e. the stack is contiguous when rows * cols is a multiple of 32 (every c2 / c3 / c5 shape)."""
 
-    def __init__(self, off, steps, rows, cols):
+    def __init__(self, off, steps, rows, cols, ld=None):
         self.off, self.steps, self.rows, self.cols = off, steps, rows, cols
+        self.ld = cols if ld is None else ld
+        self.slot = (rows * self.ld + 31) & ~31
 
     def at(self, t):
-        return Ref(None, self.off + t * self.rows * self.cols, self.rows, self.cols, self.cols)
+        return Ref(None, self.off + t * self.slot, self.rows, self.cols, self.ld)
 
 
 class Program(object):
@@ -64,13 +68,18 @@ class Program(object):
     # ---- memory
     def new(self, rows, cols):
         off = self.size
-        self.size += (rows * cols + 3) & ~3
+        self.size += (rows * cols + 31) & ~31          # 128-byte blocks: two tensors never share a cache line (csrc/graph_prog.hip)
         return Ref(None, off, rows, cols, cols)
 
-    def stack(self, steps, rows, cols):
+    def stack(self, steps, rows, cols, gemm_out=False):
+        """gemm_out: the slots are written by GEMM tiles (32 columns each, by different workgroups): rows wider than one tile get a
+        leading dimension that is a multiple of 32, so that no 128-byte line is shared by two tiles (csrc/graph_prog.hip: tensors AND
+        tiles of different workgroups must not share a cache line -- a 516-column output once left stale halves in other XCDs' L2)."""
         off = self.size
-        self.size += (steps * rows * cols + 3) & ~3
-        return Stack(off, steps, rows, cols)
+        ld = ((cols + 31) & ~31) if (gemm_out and cols > 32 and cols % 32) else None
+        st = Stack(off, steps, rows, cols, ld)
+        self.size += steps * st.slot
+        return st
 
     def ext(self, t, rows=None, cols=None):
         """An external contiguous fp32 tensor viewed as [rows, cols] (default: all leading dimensions folded into rows)."""
@@ -101,6 +110,7 @@ class Program(object):
 
     def gemm(self, a, b, out, bias=None, res=None, mask=None, relu=False, acc=False):
         assert a.cols == b.cols and out.rows == a.rows and out.cols == b.rows, (a.rows, a.cols, b.rows, b.cols, out.rows, out.cols)
+        assert out.cols <= 32 or out.ld % 32 == 0, "GEMM outputs wider than a tile need a leading dimension that is a multiple of 32"
         self._rec(type=GEMM, M=a.rows, N=b.rows, K=a.cols, a=a, b=b, bias=bias, res=res, mask=mask, c=out, relu=int(relu), acc=int(acc))
 
     def cat(self, out, segs):
@@ -149,8 +159,9 @@ class Program(object):
         return self
 
     def run(self):
+        grid = int(os.environ.get('AG2V_GRAPH_GRID', 0)) or _lib.query('ag2v_graph_program_grid')
         _lib.call('ag2v_graph_program_run', ctypes.c_void_p(self.ops_dev.data_ptr()), self.n_ops, ctypes.c_void_p(self.sync.data_ptr()),
-                  _lib.query('ag2v_graph_program_grid'), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+                  grid, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
 
     def timed_out(self):
         """Host read (synchronises): True when a grid barrier gave up -- the results of that run are invalid."""
@@ -159,42 +170,52 @@ class Program(object):
     def tensor(self, ref_or_stack):
         if isinstance(ref_or_stack, Stack):
             s = ref_or_stack
-            return self.arena[s.off:s.off + s.steps * s.rows * s.cols].view(s.steps, s.rows, s.cols)
+            return torch.as_strided(self.arena, (s.steps, s.rows, s.cols), (s.slot, s.ld, 1), s.off)
         r = ref_or_stack
         assert r.base is None
         return torch.as_strided(self.arena, (r.rows, r.cols), (r.ld, 1), r.off)
 
 
 # ------------------------------------------------------------------------------------------------------------------------------------
-# The recurrent net.  `net` supplies the parameters:
-#   first = (W1, W2): obj_vecs_net (no bias); gconvs = [(n1a_w, n1a_b, n1b_w, n1b_b, n2a_w, n2a_b, n2b_w, n2b_b), ...];
-#   box = (b1_w, b1_b, b2_w, b2_b) or None.
+# The recurrent net.  Parameters: first = (W1, W2): obj_vecs_net (no bias); per GraphTripleConv (n1a_w, n1a_b, n1b_w, n1b_b, n2a_w,
+# n2a_b, n2b_w, n2b_b); box_net (b1_w, b1_b, b2_w, b2_b) or none.
 # mode 'emb': step input = cat(emb, boxes[t-1]) and boxes[t] = boxes[t-1] + box_net(ov_t)  (Acts2LayoutModel)
 # mode 'ov' : step input = cat(ov_{t-1}, boxes_given[t])                                    (the discriminator's get_obj_vecs)
-class _Recurrence(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, cfg, x0, pv_all, boxes_in, *params):
-        """x0: emb [BO, E] (mode 'emb') or the initial object vectors [BO, D] (mode 'ov'); pv_all [S, BT, Dp] frame-major predicate /
-        action vectors of the S recurrence steps; boxes_in: [BO, 4] initial boxes (mode 'emb') or [S, BO, 4] given boxes (mode 'ov').
-        Returns (ov_stack [S, BO, Dout], boxes_stack [S, BO, 4] (mode 'emb') or an empty tensor)."""
-        mode, S, BO, BT, O, T, idx_s, idx_o, valid, n_first, n_gconv, has_box = cfg
+#
+# A PLAN holds the two programs of one (shape, parameter storage) configuration with every operand at a fixed address -- the inputs
+# are copied into slots of the plan -- so the operator arrays are written and uploaded ONCE and a training step only copies a few
+# small inputs and launches.  A plan is busy from its forward until its backward (or until the forward's output is dropped); a
+# second forward in between takes another plan of the pool.
+class _Plan(object):
+    def __init__(self, mode, S, BO, BT, O, T, n_gconv, has_box, x0, pv_all, params):
         dev = x0.device
-        x0, pv_all, boxes_in = x0.contiguous(), pv_all.contiguous(), boxes_in.contiguous()
-        params = [p.contiguous() for p in params]
+        self.dev, self.mode, self.S, self.BO, self.BT, self.O, self.T = dev, mode, S, BO, BT, O, T
+        self.n_gconv, self.has_box = n_gconv, has_box
+        self.busy, self.out_ref = False, None
         W1, W2 = params[0], params[1]
         gcs = [params[2 + 8 * l: 10 + 8 * l] for l in range(n_gconv)]
         box = params[2 + 8 * n_gconv: 6 + 8 * n_gconv] if has_box else None
-        P = Program(dev)
-        E = x0.shape[1]
+        E, dp0 = x0.shape[1], pv_all.shape[2]
         Hd = gcs[0][2].shape[1]                 # hidden_dim (n1b_w: [2 Hd + Dp, Hd])
         Dp = gcs[0][2].shape[0] - 2 * Hd
         Dout = gcs[-1][6].shape[0]
+        # input slots (fixed addresses)
+        self.x0 = torch.empty((BO, E), device=dev)
+        self.pv = torch.empty((S, BT, dp0), device=dev)
+        self.boxes_in = torch.empty((BO, 4) if mode == 'emb' else (S, BO, 4), device=dev)
+        self.i0 = torch.empty((S, BT), device=dev, dtype=torch.int32)
+        self.i1 = torch.empty((S, BT), device=dev, dtype=torch.int32)
+        self.valid = torch.empty((S, BT), device=dev, dtype=torch.uint8)
+        self.d_ov = torch.zeros((S, BO, Dout), device=dev)
+        self.d_boxes = torch.zeros((S, BO, 4), device=dev) if has_box else None
+        i0s, i1s, vls = list(self.i0.unbind(0)), list(self.i1.unbind(0)), list(self.valid.unbind(0))
+        P = Program(dev)
         f = {'in0': P.stack(S, BO, W1.shape[1]), 'h1': P.stack(S, BO, W1.shape[0]), 'ov0': P.stack(S, BO, W2.shape[0])}
         Dins = []
         for l, g in enumerate(gcs):
-            Din = (g[0].shape[1] - (pv_all.shape[2] if l == 0 else Dp)) // 2
+            dpi = dp0 if l == 0 else Dp
+            Din = (g[0].shape[1] - dpi) // 2
             Dins.append(Din)
-            dpi = pv_all.shape[2] if l == 0 else Dp
             f['cur%d' % l] = P.stack(S, BT, 2 * Din + dpi)
             f['a1%d' % l] = P.stack(S, BT, g[0].shape[0])
             f['nt%d' % l] = P.stack(S, BT, g[2].shape[0])
@@ -205,19 +226,19 @@ class _Recurrence(torch.autograd.Function):
         if has_box:
             f['bh'] = P.stack(S, BO, box[0].shape[0])
             f['boxes'] = P.stack(S, BO, 4)
-        x0r = P.ext(x0, BO, E)
+        x0r = P.ext(self.x0, BO, E)
         for s in range(S):
-            i0, i1, vl = idx_s[s], idx_o[s], valid[s]
+            i0, i1, vl = i0s[s], i1s[s], vls[s]
             if mode == 'emb':
-                bprev = P.ext(boxes_in, BO, 4) if s == 0 else f['boxes'].at(s - 1)
+                bprev = P.ext(self.boxes_in, BO, 4) if s == 0 else f['boxes'].at(s - 1)
                 P.cat(f['in0'].at(s), [(x0r, None), (bprev, None)])
             else:
                 ovprev = x0r if s == 0 else f['ov%d' % n_gconv].at(s - 1)
-                P.cat(f['in0'].at(s), [(ovprev, None), (P.ext_at(boxes_in, s, BO, 4), None)])
+                P.cat(f['in0'].at(s), [(ovprev, None), (P.ext_at(self.boxes_in, s, BO, 4), None)])
             P.gemm(f['in0'].at(s), P.ext(W1), f['h1'].at(s), relu=True)
             P.gemm(f['h1'].at(s), P.ext(W2), f['ov0'].at(s), relu=True)
             ov = f['ov0'].at(s)
-            pv = P.ext_at(pv_all, s, BT, pv_all.shape[2])
+            pv = P.ext_at(self.pv, s, BT, dp0)
             for l, g in enumerate(gcs):
                 n1a_w, n1a_b, n1b_w, n1b_b, n2a_w, n2a_b, n2b_w, n2b_b = g
                 P.cat(f['cur%d' % l].at(s), [(ov, i0), (pv, None), (ov, i1)])
@@ -229,50 +250,40 @@ class _Recurrence(torch.autograd.Function):
                 ov = f['ov%d' % (l + 1)].at(s)
                 pv = f['nt%d' % l].at(s).cols_from(Hd, Dp)
             if has_box:
-                bprev = P.ext(boxes_in, BO, 4) if s == 0 else f['boxes'].at(s - 1)
+                bprev = P.ext(self.boxes_in, BO, 4) if s == 0 else f['boxes'].at(s - 1)
                 P.gemm(ov, P.ext(box[0]), f['bh'].at(s), bias=box[1], relu=True)
                 P.gemm(f['bh'].at(s), P.ext(box[2]), f['boxes'].at(s), bias=box[3], res=bprev)
-        P.finalize().run()
-        ctx.P, ctx.f, ctx.cfg, ctx.dims = P, f, cfg, (E, Hd, Dp, Dout, Dins)
-        ctx.save_for_backward(x0, pv_all, boxes_in, *params)
-        ctx.wkeys = [(ops._wsink_register(p) if ctx.needs_input_grad[4 + i] else None) for i, p in enumerate(params)]
-        ctx.p_alive = params
-        ov_stack = P.tensor(f['ov%d' % n_gconv])
-        boxes_stack = P.tensor(f['boxes']) if has_box else torch.empty(0, device=dev)
-        return ov_stack, boxes_stack
+        self.fwd, self.f = P.finalize(), f
+        self.dims = (E, Hd, Dp, Dout, Dins, dp0)
+        self.bwd = self.g = None
+        self._params = params
 
-    @staticmethod
-    def backward(ctx, d_ov, d_boxes):
-        mode, S, BO, BT, O, T, idx_s, idx_o, valid, n_first, n_gconv, has_box = ctx.cfg
-        F, f = ctx.P, ctx.f
-        E, Hd, Dp, Dout, Dins = ctx.dims
-        saved = ctx.saved_tensors
-        x0, pv_all, boxes_in = saved[0], saved[1], saved[2]
-        params = list(saved[3:])
+    def build_backward(self):
+        mode, S, BO, BT, O, T, n_gconv, has_box = self.mode, self.S, self.BO, self.BT, self.O, self.T, self.n_gconv, self.has_box
+        params = self._params
         W1, W2 = params[0], params[1]
         gcs = [params[2 + 8 * l: 10 + 8 * l] for l in range(n_gconv)]
         box = params[2 + 8 * n_gconv: 6 + 8 * n_gconv] if has_box else None
-        dev = x0.device
-        d_ov = torch.zeros((S, BO, Dout), device=dev) if d_ov is None else d_ov.contiguous()
-        if has_box:
-            d_boxes = torch.zeros((S, BO, 4), device=dev) if d_boxes is None else d_boxes.contiguous()
+        E, Hd, Dp, Dout, Dins, dp0 = self.dims
+        F, f = self.fwd, self.f
+        i0s, i1s, vls = list(self.i0.unbind(0)), list(self.i1.unbind(0)), list(self.valid.unbind(0))
 
         def fr(name, s):        # a forward value (lives in the forward program's arena)
             r = f[name].at(s)
             return Ref(F.arena, r.off, r.rows, r.cols, r.ld)
-        P = Program(dev)
+        P = Program(self.dev)
         P.keep.append(F.arena)
-        # transposed weights: the input-gradient GEMMs reduce over the output index
-        def tr(w):
+
+        def tr(w):              # transposed weights: the input-gradient GEMMs reduce over the output index
             out = P.new(w.shape[1], w.shape[0])
             P.transpose(P.ext(w), out)
             return out
         W1t, W2t = tr(W1), tr(W2)
         gct = [(tr(g[0]), tr(g[2]), tr(g[4]), tr(g[6])) for g in gcs]
         boxt = (tr(box[0]), tr(box[2])) if has_box else None
-        g = {'din0': P.stack(S, BO, W1.shape[1]), 'dh1': P.stack(S, BO, W1.shape[0]), 'dov0': P.stack(S, BO, W2.shape[0])}
+        g = {'din0': P.stack(S, BO, W1.shape[1], gemm_out=True), 'dh1': P.stack(S, BO, W1.shape[0]), 'dov0': P.stack(S, BO, W2.shape[0])}
         for l in range(n_gconv):
-            dpi = pv_all.shape[2] if l == 0 else Dp
+            dpi = dp0 if l == 0 else Dp
             g['dcur%d' % l] = P.stack(S, BT, 2 * Dins[l] + dpi)
             g['da1%d' % l] = P.stack(S, BT, gcs[l][0].shape[0])
             g['dnt%d' % l] = P.stack(S, BT, gcs[l][2].shape[0])
@@ -283,15 +294,15 @@ class _Recurrence(torch.autograd.Function):
             g['dbh'] = P.stack(S, BO, box[0].shape[0])
             g['gbox'] = P.stack(S, BO, 4)
         for s in range(S - 1, -1, -1):
-            i0, i1, vl = idx_s[s], idx_o[s], valid[s]
+            i0, i1, vl = i0s[s], i1s[s], vls[s]
             top = g['dov%d' % n_gconv].at(s)
-            dov_ext = P.ext_at(d_ov, s, BO, Dout)
+            dov_ext = P.ext_at(self.d_ov, s, BO, Dout)
             if has_box:
                 # gradient of boxes[s]: the output's, plus (s < S - 1) the residual path and the next step's input columns
                 if s == S - 1:
-                    P.add3(g['gbox'].at(s), P.ext_at(d_boxes, s, BO, 4))
+                    P.add3(g['gbox'].at(s), P.ext_at(self.d_boxes, s, BO, 4))
                 else:
-                    P.add3(g['gbox'].at(s), P.ext_at(d_boxes, s, BO, 4), g['gbox'].at(s + 1), g['din0'].at(s + 1).cols_from(E, 4))
+                    P.add3(g['gbox'].at(s), P.ext_at(self.d_boxes, s, BO, 4), g['gbox'].at(s + 1), g['din0'].at(s + 1).cols_from(E, 4))
                 P.gemm(g['gbox'].at(s), boxt[1], g['dbh'].at(s))
                 P.gemm(g['dbh'].at(s), boxt[0], top, mask=fr('bh', s), res=dov_ext)
             elif mode == 'ov' and s < S - 1:
@@ -305,18 +316,85 @@ class _Recurrence(torch.autograd.Function):
                 dp_in = None
                 if l < n_gconv - 1:
                     dp_in = g['dcur%d' % (l + 1)].at(s).cols_from(Dins[l + 1], Dp)
-                cnt = fr('cnt%d' % l, s)
-                P.pool_bwd(g['dpool%d' % l].at(s), dp_in, g['dnt%d' % l].at(s), cnt, i0, i1, vl, O, T, Hd, Dp)
+                P.pool_bwd(g['dpool%d' % l].at(s), dp_in, g['dnt%d' % l].at(s), fr('cnt%d' % l, s), i0, i1, vl, O, T, Hd, Dp)
                 P.gemm(g['dnt%d' % l].at(s), n1b_t, g['da1%d' % l].at(s), mask=fr('nt%d' % l, s))
                 P.gemm(g['da1%d' % l].at(s), n1a_t, g['dcur%d' % l].at(s), mask=fr('a1%d' % l, s))
-                dpi = pv_all.shape[2] if l == 0 else Dp
-                P.gather_bwd(g['dcur%d' % l].at(s), g['dov%d' % l].at(s), i0, i1, O, T, Dins[l], dpi)
+                P.gather_bwd(g['dcur%d' % l].at(s), g['dov%d' % l].at(s), i0, i1, O, T, Dins[l], dp0 if l == 0 else Dp)
             P.gemm(g['dov0'].at(s), W2t, g['dh1'].at(s), mask=fr('ov0', s))
             P.gemm(g['dh1'].at(s), W1t, g['din0'].at(s), mask=fr('h1', s))
-        P.finalize().run()
+        self.bwd, self.g = P.finalize(), g
+
+
+_PLANS = {}
+
+
+def _get_plan(key, make):
+    pool = _PLANS.setdefault(key, [])
+    for pl in pool:
+        if pl.busy and pl.out_ref is not None and pl.out_ref() is None:
+            pl.busy = False                  # the forward's autograd node is gone: nobody can back-propagate into this plan any more
+        if not pl.busy:
+            return pl
+    pl = make()
+    if len(pool) < 4:
+        pool.append(pl)
+    return pl
+
+
+class _Recurrence(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cfg, x0, pv_all, boxes_in, *params):
+        """x0: emb [BO, E] (mode 'emb') or the initial object vectors [BO, D] (mode 'ov'); pv_all [S, BT, Dp] frame-major predicate /
+        action vectors of the S recurrence steps; boxes_in: [BO, 4] initial boxes (mode 'emb') or [S, BO, 4] given boxes (mode 'ov').
+        Returns (ov_stack [S, BO, Dout], boxes_stack [S, BO, 4] (mode 'emb') or an empty tensor)."""
+        mode, S, BO, BT, O, T, i0, i1, valid, n_gconv, has_box = cfg
+        params = [p.contiguous() for p in params]
+        key = (mode, S, BO, BT, O, T, n_gconv, has_box, tuple(x0.shape), tuple(pv_all.shape), str(x0.device),
+               tuple(p.data_ptr() for p in params))
+        pl = _get_plan(key, lambda: _Plan(mode, S, BO, BT, O, T, n_gconv, has_box, x0, pv_all, params))
+        pl.x0.copy_(x0)
+        pl.pv.copy_(pv_all)
+        pl.boxes_in.copy_(boxes_in)
+        pl.i0.copy_(i0)
+        pl.i1.copy_(i1)
+        pl.valid.copy_(valid)
+        pl.fwd.run()
+        needs = any(ctx.needs_input_grad)
+        pl.busy = bool(needs)
+        ctx.pl = pl
+        ctx.wkeys = [(ops._wsink_register(p) if ctx.needs_input_grad[4 + i] else None) for i, p in enumerate(params)]
+        ctx.p_alive = params
+        ov_stack = pl.fwd.tensor(pl.f['ov%d' % n_gconv])
+        boxes_stack = pl.fwd.tensor(pl.f['boxes']) if has_box else torch.empty(0, device=x0.device)
+        if not needs:                        # nothing will come back: hand out copies so that the plan is free for the next call
+            return ov_stack.clone(), boxes_stack.clone()
+        import weakref
+        pl.out_ref = weakref.ref(ctx)        # the autograd node lives exactly as long as something can still back-propagate into it
+        return ov_stack, boxes_stack
+
+    @staticmethod
+    def backward(ctx, d_ov, d_boxes):
+        pl = ctx.pl
+        mode, S, BO, BT, n_gconv, has_box = pl.mode, pl.S, pl.BO, pl.BT, pl.n_gconv, pl.has_box
+        E, Hd, Dp, Dout, Dins, dp0 = pl.dims
+        dev = pl.dev
+        if pl.bwd is None:
+            pl.build_backward()
+        if d_ov is None:
+            pl.d_ov.zero_()
+        else:
+            pl.d_ov.copy_(d_ov)
+        if has_box:
+            if d_boxes is None:
+                pl.d_boxes.zero_()
+            else:
+                pl.d_boxes.copy_(d_boxes)
+        pl.bwd.run()
+        P, F, f, g = pl.bwd, pl.fwd, pl.f, pl.g
         T_ = lambda name: P.tensor(g[name])
         FT = lambda name: F.tensor(f[name])
         st = ops._stream()
+        params = ctx.p_alive
         grads = [None] * len(params)
 
         def lin_grads(wi, bi, A, dY, Y):
@@ -329,11 +407,11 @@ class _Recurrence(torch.autograd.Function):
                 _lib.call('ag2v_relu_bwd', ops._ptr(dZ), ops._ptr(Y.reshape(M, N)), ops._ptr(z), dZ.numel(), st)
                 dZ = z
             if ctx.needs_input_grad[4 + wi]:
-                buf, acc, dw = ops._wsink_take(ctx.wkeys[wi], ctx.p_alive[wi])
+                buf, acc, dw = ops._wsink_take(ctx.wkeys[wi], params[wi])
                 _lib.call('ag2v_gemm_f32', ops._ptr(dZ), ops._ptr(A.reshape(M, K)), None, ops._ptr(buf), N, K, M, 1, N, K, 1, K, 0, acc, st)
                 grads[wi] = dw
             if bi is not None and ctx.needs_input_grad[4 + bi]:
-                bbuf, bacc, db = ops._wsink_take(ctx.wkeys[bi], ctx.p_alive[bi])
+                bbuf, bacc, db = ops._wsink_take(ctx.wkeys[bi], params[bi])
                 if bacc:
                     t = torch.empty(N, device=dev, dtype=torch.float32)
                     _lib.call('ag2v_col_sum', ops._ptr(dZ), ops._ptr(t), M, N, st)
@@ -356,10 +434,11 @@ class _Recurrence(torch.autograd.Function):
         din0 = T_('din0')
         dx0 = dpv = None
         if ctx.needs_input_grad[1]:
-            dx0 = din0[:, :, :E].sum(dim=0) if mode == 'emb' else din0[0, :, :Dout].contiguous()
+            dx0 = din0[:, :, :E].sum(dim=0) if mode == 'emb' else din0[0, :, :Dout].clone()
         if ctx.needs_input_grad[2]:
-            dpv = T_('dcur0')[:, :, Dins[0]:Dins[0] + pv_all.shape[2]].contiguous()
-        ctx.P = ctx.f = None
+            dpv = T_('dcur0')[:, :, Dins[0]:Dins[0] + dp0].contiguous()
+        pl.busy = False
+        ctx.pl = None
         return (None, dx0, dpv, None) + tuple(grads)
 
 
@@ -387,11 +466,11 @@ def run_recurrence(mode, x0, pv_steps, edges_steps, ind_steps, boxes_in, first, 
             params += [m.weight, m.bias]
     if box is not None:
         params += [box[0].weight, box[0].bias, box[1].weight, box[1].bias]
-    cfg = (mode, S, B * O, B * T, O, T, list(i0.unbind(0)), list(i1.unbind(0)), list(valid.unbind(0)), 2, len(gconvs), box is not None)
+    cfg = (mode, S, B * O, B * T, O, T, i0, i1, valid, len(gconvs), box is not None)
     bi = boxes_in.reshape(B * O, 4) if mode == 'emb' else boxes_in.reshape(S, B * O, 4)
     ov, boxes = _Recurrence.apply(cfg, x0.reshape(B * O, -1), pv_steps.reshape(S, B * T, -1), bi, *params)
-    ov = ov.view(S, B, O, -1)
-    return ov, (boxes.view(S, B, O, 4) if box is not None else None)
+    ov = ov.reshape(S, B, O, -1)
+    return ov, (boxes.reshape(S, B, O, 4) if box is not None else None)
 
 
 def supported(module_or_opt):
