@@ -55,7 +55,7 @@ static_assert(sizeof(GOp) == 192, "GOp layout is part of the host interface");
 
 #define GP_THREADS 1024
 #define GP_WAVES 16
-#define GP_SPIN_LIMIT (1u << 24)
+#define GP_SPIN_LIMIT (1u << 18)     // ~0.3 s per barrier: a grid that is not co-resident ends with the timeout flag set instead of hanging
 
 // write-through store (sc1): the value is in memory once the storing wave's vmcnt has drained
 __device__ __forceinline__ void st_wt(float* p, float v) {

@@ -8,7 +8,7 @@ fam = {}
 def family(n):
     if 'conv_' in n and 'layout' not in n: return 'conv'
     if 'norm' in n or 'bn_stats' in n or 'pair_sum' in n or 'channel_sum' in n: return 'norm'
-    if any(k in n for k in ('gemm_f32', 'triple', 'embedding', 'col_sum', 'relu_bwd')): return 'graph'
+    if any(k in n for k in ('gemm_f32', 'triple', 'embedding', 'col_sum', 'relu_bwd', 'graph_program')): return 'graph'
     if 'sn_' in n or 'dot_partial' in n: return 'spectral'
     if 'at::' in n or 'rocclr' in n: return 'aten'
     if any(k in n for k in ('pack_', 'transpose', 'prep')): return 'pack'
