@@ -67,7 +67,12 @@ class TrainStep(object):
         # the tail of the discriminator's backward pass (autograd runs a node on the stream its forward ran on).
         self.side_stream = None
         # (deterministic mode keeps everything on one stream: two streams accumulating gradients interleave in a varying order)
-        if torch.device(device).type == 'cuda' and os.environ.get('AG2V_NO_SIDE_STREAM') is None and not ops.is_deterministic():
+        # Round 3: OFF by default (AG2V_SIDE_STREAM=1 enables it).  The convolution tiles fill every SIMD's register file, so side-stream
+        # kernels only ever ran in the gaps between convolution launches (same-box A/B: 790.0 vs 790.0 ms per step), and the graph
+        # nets are now persistent programs whose 128 workgroups meet at grid barriers: beside a convolution they would wait for CUs
+        # while holding others.
+        if (torch.device(device).type == 'cuda' and os.environ.get('AG2V_SIDE_STREAM') is not None
+                and os.environ.get('AG2V_NO_SIDE_STREAM') is None and not ops.is_deterministic()):
             self.side_stream = torch.cuda.Stream(device=device)
             self.model.side_stream = self.side_stream
             # (graph-net parameters of D receive gradients from nodes of both streams)

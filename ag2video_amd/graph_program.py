@@ -412,12 +412,12 @@ class _Recurrence(torch.autograd.Function):
                 grads[wi] = dw
             if bi is not None and ctx.needs_input_grad[4 + bi]:
                 bbuf, bacc, db = ops._wsink_take(ctx.wkeys[bi], params[bi])
+                # (column sums over ~1 300 stacked rows: a tree reduction -- the graph kernels' one-thread-per-column col_sum walks the
+                # rows serially, 165 us per layer here)
                 if bacc:
-                    t = torch.empty(N, device=dev, dtype=torch.float32)
-                    _lib.call('ag2v_col_sum', ops._ptr(dZ), ops._ptr(t), M, N, st)
-                    bbuf.add_(t)
+                    bbuf.add_(dZ.sum(dim=0))
                 else:
-                    _lib.call('ag2v_col_sum', ops._ptr(dZ), ops._ptr(bbuf), M, N, st)
+                    torch.sum(dZ, dim=0, out=bbuf)
                 grads[bi] = db
         lin_grads(0, None, FT('in0'), T_('dh1'), FT('h1'))
         lin_grads(1, None, FT('h1'), T_('dov0'), FT('ov0'))

@@ -26,6 +26,9 @@ MATCH = [('mlp_shared_fwd', 'mlp_shared_fwd', 'conv_igemm_bf16x3_ws_kernel<128, 
          ('mlp_shared_dgrad_merged_ps', 'mlp_shared_dgrad_merged_ps', 'conv_igemm_bf16x3_ps_kernel<256, 128'),
          ('mlp_shared_wgrad_merged_ps', 'mlp_shared_wgrad_merged_ps', 'conv_wgrad_bf16x3_vps_kernel<128, 256'),
          ('conv_256_wgrad_128px_ps', 'conv_256_wgrad_128px_ps', 'conv_wgrad_bf16x3_vps_kernel<256, 128'),
+         ('flow_res_h16', 'flow_res_h16', 'conv_igemm_f16x3_ws_kernel<256, 128'),
+         ('bn_pyramid', 'bn_pyr_bwd_reduce', 'norm_bwd_reduce_kernel<0, true, true>'), ('bn_pyramid', 'bn_pyr_bwd_apply', 'norm_bwd_apply_kernel<0, true, true>'),
+         ('layout_conv_bwd', 'layout_conv_bwd', 'layout_conv_bwd_kernel<3>'),
          ('layout_conv', 'layout_conv_fwd', 'layout_conv_fwd_kernel<3, 16>'), ('flow_res_fp32', 'flow_res_fp32', 'conv_igemm_f32_ws_kernel<256, 128'),
          ('norm', 'norm_apply', 'norm_apply_kernel<1, true>'), ('norm', 'norm_bwd_reduce', 'norm_bwd_reduce_kernel<1, true>'),
          ('norm', 'norm_bwd_apply', 'norm_bwd_apply_kernel<1, true>'), ('norm', 'bn_stats_partial', 'bn_stats_partial_kernel<true>'),

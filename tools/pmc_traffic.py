@@ -129,6 +129,61 @@ def f32_case():
                                'algorithmic_bytes': (N * C * H * H + N * K * H * H + K * C * 9) * 4, 'pass': 'fwd'}
 
 
+def bn_pyramid_case():
+    # conv_dim_in's batch norm + segmentation-map pyramid (one autograd node): the backward gathers the five coarser levels' gradients
+    # while it loads the full-resolution one -- norm_bwd_reduce_kernel<0, true, true> / norm_bwd_apply_kernel<0, true, true>
+    N, C, H = 120, 512, 256
+    x = torch.randn(N, C, H, H, device=dev, requires_grad=True)
+    w = torch.ones(C, device=dev, requires_grad=True); b = torch.zeros(C, device=dev, requires_grad=True)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    sizes = [(H >> i, H >> i) for i in range(6)]
+    for _ in range(REPS):
+        outs = ops.batchnorm_act_pyramid(x, w, b, rm, rv, sizes, True, 0.1, 1e-5, 0.2, groups=15)
+        torch.autograd.backward(outs, [torch.ones_like(o) for o in outs])
+        x.grad = None
+    torch.cuda.synchronize()
+    tb = N * C * H * H * 4
+    lv = tb / 3.0 * (1 - 4.0 ** -5)          # the five coarser levels: 1/4 + 1/16 + ... of the full tensor
+    expect['bn_pyr_bwd_reduce'] = {'shape': 'batch norm + 6-level pyramid backward, reduce pass, %dx%dx%dx%d, 15 groups' % (N, C, H, H),
+                                   'algorithmic_bytes': 2 * tb + lv, 'pass': 'bwd'}
+    expect['bn_pyr_bwd_apply'] = {'shape': 'same, apply pass', 'algorithmic_bytes': 3 * tb + lv, 'pass': 'bwd'}
+
+
+def layout_bwd_case():
+    # backward of conv_dim_in's low-rank layout convolution: reads each object's support rectangle of the 16 GB output gradient
+    NB, J, K, H, R = 120, 22, 512, 256, 3
+    U = (torch.randn(NB, J, K, R * R, device=dev) * 0.1).requires_grad_(True)
+    boxes = torch.rand(NB, J, 4, device=dev) * 0.5
+    boxes[:, :, 2:] = boxes[:, :, 2:] * 0.6 + 0.1
+    m = torch.zeros(J, device=dev); m[[0, 1, 2, 11, 12, 13]] = 1
+    boxes = boxes * m.view(1, J, 1)
+    area = float((boxes[:, :, 2] * boxes[:, :, 3]).sum() / NB)        # mean covered fraction of the image, summed over the objects
+    keep = torch.ones(NB, J, dtype=torch.int32, device=dev)
+    g = torch.randn(NB, K, H, H, device=dev)
+    for _ in range(REPS):
+        y = ops.layout_conv(U, boxes, keep, H, H, R, 1, 1)
+        y.backward(g)
+        U.grad = None
+    torch.cuda.synchronize()
+    expect['layout_conv_bwd'] = {'shape': 'layout_conv backward %dx%dx%dx%d, %d object slots (6 occupied, mean covered area %.2f of the image)' % (NB, K, H, H, J, area),
+                                 'algorithmic_bytes': (area * NB * K * H * H + NB * J * K * R * R) * 4, 'pass': 'bwd'}
+
+
+def h16_case():
+    # the same flow-network layer on the fp16 3-term split (the product's forward arithmetic there since round 3)
+    N, C, H, K = 120, 256, 32, 256
+    x = torch.randn(N, C, H, H, device=dev); w = torch.randn(K, C, 3, 3, device=dev) * 0.02
+    with ops.bf16x3_min_rows(32, 32, fwd_h16=True), torch.no_grad():
+        for _ in range(REPS):
+            ops.conv2d(x, w, None, 1, 1)
+    torch.cuda.synchronize()
+    expect['flow_res_h16'] = {'shape': 'fp16-split fwd of %dx%dx%dx%d -> %d channels, 3x3' % (N, C, H, H, K),
+                              'algorithmic_bytes': (N * C * H * H + N * K * H * H + K * C * 9) * 4, 'pass': 'fwd'}
+
+
+CASES['flow_res_h16'] = h16_case
+CASES['bn_pyramid'] = bn_pyramid_case
+CASES['layout_conv_bwd'] = layout_bwd_case
 CASES['layout_conv'] = layout_case
 CASES['flow_res_fp32'] = f32_case
 CASES['norm'] = norm_case
