@@ -267,15 +267,17 @@ __device__ __forceinline__ void op_add3(const GOp& o, long long gid, long long n
 
 __global__ __launch_bounds__(GP_THREADS) void graph_program_kernel(const GOp* __restrict__ ops, int n_ops, unsigned* __restrict__ sync) {
     __shared__ __attribute__((aligned(16))) float red[GP_WAVES * 2 * 32 * GP_PITCH];      // staging blocks / reduction buffer (>= 16 x 1024)
-    __shared__ GOp cur;
+    __shared__ GOp desc[2];
     const int G = gridDim.x, wg = blockIdx.x;
     const long long gid = (long long)wg * GP_THREADS + threadIdx.x, nthreads = (long long)G * GP_THREADS;
+    // descriptors through LDS, one copy per workgroup, then uniform reads; the array is constant for the launch, so operator k + 1's
+    // record is fetched while operator k runs (it used to cost a memory round trip behind every barrier)
+    if (threadIdx.x < (int)(sizeof(GOp) / 4)) reinterpret_cast<unsigned*>(&desc[0])[threadIdx.x] = reinterpret_cast<const unsigned*>(ops)[threadIdx.x];
+    __syncthreads();
     for (int k = 0; k < n_ops; ++k) {
-        // the descriptor through LDS: one copy per workgroup, then uniform reads (the array is constant for the launch)
-        __syncthreads();
-        if (threadIdx.x < (int)(sizeof(GOp) / 4)) reinterpret_cast<unsigned*>(&cur)[threadIdx.x] = reinterpret_cast<const unsigned*>(ops + k)[threadIdx.x];
-        __syncthreads();
-        const GOp& o = cur;
+        if (k + 1 < n_ops && threadIdx.x < (int)(sizeof(GOp) / 4))
+            reinterpret_cast<unsigned*>(&desc[(k + 1) & 1])[threadIdx.x] = reinterpret_cast<const unsigned*>(ops + k + 1)[threadIdx.x];
+        const GOp& o = desc[k & 1];
         switch (o.type) {
             case GOP_GEMM: {
                 const int tms = (o.M + 31) >> 5, tns = (o.N + 31) >> 5;
