@@ -340,7 +340,7 @@ def main():
             return None
         t = timing.pop(key)
         gbs = t['flops'] / (t['ms'] * 1e-3) / 1e9          # the record's work slot holds algorithmic bytes for these kernels
-        names = [k for k in PMC if k.startswith(kernel.split('<')[0])]
+        names = [k for k in PMC if k.startswith(kernel.split('>')[0] + '>')]       # the instantiation named in `kernel`, not a sibling
         pm = PMC.get(names[0]) if names else None
         return {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": round(gbs / PEAK_HBM_GBS, 4), "launches": t['launches'], "avg_launch_ms": round(t['ms'] / t['launches'], 4),
