@@ -39,6 +39,22 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh4) {
     return sh4[0] + sh4[1] + sh4[2] + sh4[3];
 }
 
+// NV block-wide sums of a 256-thread block at once: the wave sums go to LDS together and ONE barrier hands them over (block_sum_256
+// costs two barriers per value; a reduce kernel with 4-8 sums per 4096-element chunk spent its time in them).  sh: 4 * NV floats, not
+// reused before the next barrier of the caller.  Same summation order as block_sum_256: bit-identical results.
+template <int NV>
+__device__ __forceinline__ void block_sums_256(float (&v)[NV], float* sh) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = wave_sum(v[k]);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) sh[(threadIdx.x >> 6) * NV + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = sh[k] + sh[NV + k] + sh[2 * NV + k] + sh[3 * NV + k];
+}
+
 // Bijective XCD-aware remap (8 XCDs, blocks are dealt round-robin): gives every XCD a
 // contiguous range of logical tile ids so that neighbouring tiles share that XCD's L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __res
                                                               float* __restrict__ partial, int Ng, int C, int HW, int nchunk,
                                                               float slope, long long gbx, const float* __restrict__ aw,
                                                               const float* __restrict__ ab, NormPyramid pyr = NormPyramid{}) {
-    __shared__ float sh[4];
+    __shared__ float sh[16];
     const int bid = blockIdx.x;
     const int chunk = bid % nchunk, nc = bid / nchunk;
     const int n = nc / C, c = nc - n * C;
@@ -285,11 +285,14 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __res
         s1 += g[i];  // invalid lanes hold g == 0
         s2 += g[i] * ((xv[i] - mu) * is);
     }
-    s1 = block_sum_256(s1, sh);
-    s2 = block_sum_256(s2, sh);
     if (MODE == 1) {
-        s3 = block_sum_256(s3, sh);
-        s4 = block_sum_256(s4, sh);
+        float v4[4] = {s1, s2, s3, s4};
+        block_sums_256<4>(v4, sh);
+        s1 = v4[0]; s2 = v4[1]; s3 = v4[2]; s4 = v4[3];
+    } else {
+        float v2[2] = {s1, s2};
+        block_sums_256<2>(v2, sh);
+        s1 = v2[0]; s2 = v2[1];
     }
     if (threadIdx.x == 0) {
         const int nparts = Ng * nchunk;
@@ -460,7 +463,7 @@ __global__ __launch_bounds__(256) void spade_pair_bwd_reduce_kernel(const float*
                                                                     const float* __restrict__ gb1, const float* __restrict__ mean,
                                                                     const float* __restrict__ invstd, float* __restrict__ partial, int Ng,
                                                                     int C, int HW, int W, int nchunk, float slope0, float slope1) {
-    __shared__ float sh[4];
+    __shared__ float sh[32];
     const int bid = blockIdx.x;
     const int chunk = bid % nchunk, nc = bid / nchunk;
     const int n = nc / C, c = nc - n * C;
@@ -500,11 +503,9 @@ __global__ __launch_bounds__(256) void spade_pair_bwd_reduce_kernel(const float*
             s1 += d;
             s2 += d * xi;
         }
-        out[4 * k] = block_sum_256(s1, sh);
-        out[4 * k + 1] = block_sum_256(s2, sh);
-        out[4 * k + 2] = block_sum_256(s3, sh);
-        out[4 * k + 3] = block_sum_256(s4, sh);
+        out[4 * k] = s1; out[4 * k + 1] = s2; out[4 * k + 2] = s3; out[4 * k + 3] = s4;
     }
+    block_sums_256<8>(out, sh);
     if (threadIdx.x == 0) {
         const int nparts = Ng * nchunk;
         float* o = partial + ((size_t)gc * nparts + (size_t)nl * nchunk + chunk) * 8;

@@ -115,7 +115,8 @@ class TrainStep(object):
         # One process per GPU: the generator's 500 MB gradient all-reduce is launched here and joined after the discriminator's
         # loss + backward (which read neither these gradients nor the generator's parameters: imgs_pred is detached), then
         # Adam(G) runs -- the same updates as the reference order (G step, then D loss), with the ring traffic behind ~150 ms of
-        # convolutions.  Single process: nothing is pending and Adam(G) runs here, in the reference's order.
+        # convolutions.  Single process: nothing is pending and Adam(G) runs here, in the reference's order (unless the optional side
+        # stream is on: then Adam(G) waits for the appearance net's backward behind the discriminator phase, `overlap_tail`).
         pending = dist_utils.average_gradients_begin(self._gen_params, flat=getattr(self.optimizer_generator, 'flat_grad', None))
         deferred = bool(pending.works) or overlap_tail      # Adam(G) after the discriminator phase (which reads neither G's gradients nor its parameters)
         if apply_updates and not deferred:

@@ -77,12 +77,20 @@ def main(args):
         torch.manual_seed(args.seed + rank)
         short_loader, long_loader = build_loaders(args, args.vocab, nframes=args.data_nframes)
 
-        def cycle(loader):
+        def cycle(loader, name):
             while True:
+                usable = 0
                 for b in loader:
                     if b[0] is not None:          # collate_fn returns six Nones for an unusable batch (train.py:442)
+                        usable += 1
                         yield b
-        short_it, long_it = cycle(short_loader), cycle(long_loader)
+                if usable == 0:
+                    # every item unusable (e.g. the frame count of the scenes differs from --data_nframes, or fewer scenes than
+                    # --batch_size with drop_last): the reference would spin forever; at world > 1 the other ranks would wait in a
+                    # collective until the RCCL timeout
+                    raise RuntimeError("%s loader over --data_root %s yielded no usable batch in a full pass (data_nframes=%s, batch_size=%s)"
+                                       % (name, args.data_root, args.data_nframes, args.batch_size))
+        short_it, long_it = cycle(short_loader, 'train'), cycle(long_loader, 'train_graph')
 
     def next_clip(kind, seed):
         if short_it is not None:
