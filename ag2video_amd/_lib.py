@@ -123,6 +123,10 @@ def load():
             "ag2video_amd: %s not found -- build the HIP kernels first "
             "(python -c 'import __graft_entry__ as g; g.build()' or make -C ag2video_amd/csrc). "
             "There is no CPU fallback." % LIB_PATH)
+    # torch first: its bundled libamdhip64.so.7 must be the HIP runtime of the process. Loaded in the other order the
+    # /opt/rocm runtime this library's RUNPATH names wins the soname, torch runs on a runtime it was not built
+    # against, and the first kernel launch fails with a HIP launch error.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)  # AttributeError if the .so is stale

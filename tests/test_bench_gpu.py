@@ -57,3 +57,12 @@ def test_library_reports_the_launched_kernel(device):
             _lib.call('ag2v_set_bf16x3_min_rows', 0)
     finally:
         _lib.call('ag2v_set_bf16x3_min_rows', old)
+
+
+def test_build_then_smoke_in_one_process():
+    """The driver's two entry points in one interpreter: build() loads the library before anything imported torch,
+    which must not leave the process on a HIP runtime torch was not built against."""
+    out = subprocess.run([sys.executable, '-c', 'import __graft_entry__ as g; g.build(); g.smoke()'],
+                         cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert 'smoke ok' in out.stdout
