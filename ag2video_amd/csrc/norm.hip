@@ -325,7 +325,8 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
                                                              float* __restrict__ dx, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta, int C, int HW, int nchunk,
                                                              float inv_count, float slope, long long gbx, int Ng, int dgb_split,
-                                                             const float* __restrict__ ab, NormPyramid pyr = NormPyramid{}) {
+                                                             const float* __restrict__ ab, long long ggx = -1,
+                                                             NormPyramid pyr = NormPyramid{}) {
     const int bid = blockIdx.x;
     const int chunk = bid % nchunk, nc = bid / nchunk;
     const int c = nc % C;
@@ -360,7 +361,8 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
     for (int i = 0; i < 16; ++i) xv[i] = (xv[i] - mu) * is;  // xhat
     if (MODE == 1) {
         const size_t goff = off + (size_t)(nc / C) * gbx;
-        load16<VEC>(gamma + goff, cnt, t, mask);
+        // (ggx >= 0: gamma kept as a compact [N, C, HW] copy -- the lean tape -- while dgamma | dbeta stay halves of [N, 2C, HW])
+        load16<VEC>(gamma + (ggx >= 0 ? off + (size_t)(nc / C) * ggx : goff), cnt, t, mask);
         float dg[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) dg[i] = g[i] * xv[i];
@@ -462,7 +464,8 @@ __global__ __launch_bounds__(256) void spade_pair_bwd_reduce_kernel(const float*
                                                                     const float* __restrict__ xs, const float* __restrict__ gb0,
                                                                     const float* __restrict__ gb1, const float* __restrict__ mean,
                                                                     const float* __restrict__ invstd, float* __restrict__ partial, int Ng,
-                                                                    int C, int HW, int W, int nchunk, float slope0, float slope1) {
+                                                                    int C, int HW, int W, int nchunk, float slope0, float slope1,
+                                                                    int gcompact) {
     __shared__ float sh[32];
     const int bid = blockIdx.x;
     const int chunk = bid % nchunk, nc = bid / nchunk;
@@ -491,7 +494,7 @@ __global__ __launch_bounds__(256) void spade_pair_bwd_reduce_kernel(const float*
 #pragma unroll
             for (int i = 0; i < 16; ++i) g[i] = t[i] > 0.f ? g[i] : g[i] * slope;
         }
-        load16<true>(gb + goff, cnt, t, mask);
+        load16<true>(gb + (gcompact ? off : goff), cnt, t, mask);     // gcompact: gamma as a compact [N, C, HW] copy (lean tape)
         float s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -533,7 +536,8 @@ __global__ __launch_bounds__(256) void spade_pair_bwd_apply_kernel(const float* 
                                                                    const float* __restrict__ invstd, const float* __restrict__ sums,
                                                                    float* __restrict__ dxs, float* __restrict__ dgb0,
                                                                    float* __restrict__ dgb1, int C, int HW, int W, int nchunk,
-                                                                   float inv_count, float slope0, float slope1, int Ng, int dgb_split) {
+                                                                   float inv_count, float slope0, float slope1, int Ng, int dgb_split,
+                                                                   int gcompact) {
     __shared__ float2 hsum[UP == 2 ? 1024 : 1];
     const int bid = blockIdx.x;
     const int chunk = bid % nchunk, nc = bid / nchunk;
@@ -563,7 +567,7 @@ __global__ __launch_bounds__(256) void spade_pair_bwd_apply_kernel(const float* 
 #pragma unroll
             for (int i = 0; i < 16; ++i) g[i] = t[i] > 0.f ? g[i] : g[i] * slope;
         }
-        load16<true>(gb + goff, cnt, t, mask);
+        load16<true>(gb + (gcompact ? off : goff), cnt, t, mask);
         float dg[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -769,23 +773,25 @@ static int norm_bwd_launch(int mode, bool do_reduce, bool do_apply, const float*
     if (do_apply && !dx) return AG2V_EINVAL;
     if (slope != 1.f && !y && !(sign_from_x && mode == 0)) return AG2V_EINVAL;
     if (sign_from_x && mode == 0) y = nullptr;
-    if (mode < 0 || mode > 2 || (mode >= 1 && !gamma) || (mode >= 1 && do_apply && (!dgamma || !dbeta))) return AG2V_EINVAL;
+    if (mode < 0 || mode > 3 || (mode >= 1 && !gamma) || (mode >= 1 && do_apply && (!dgamma || !dbeta))) return AG2V_EINVAL;
     const int nchunk = ceil_div(HW, CHUNK);
     const long long nblk = (long long)N * C * nchunk;
     if (nblk >= (1LL << 31)) return AG2V_EINVAL;
     const bool v = vec_ok(HW, dy, y, x, gamma, dx, dgamma, dbeta);
-    const long long gbx = (mode == 2) ? (long long)C * HW : 0;   // mode 2: gamma, dgamma / dbeta are halves of [N,2C,HW] tensors
+    // mode 2: gamma, dgamma / dbeta are halves of [N,2C,HW] tensors; mode 3: the same gradients, gamma as a compact [N,C,HW] tensor
+    const long long gbx = (mode >= 2) ? (long long)C * HW : 0;
+    const long long ggx = (mode == 3) ? 0 : gbx;
     dim3 g((unsigned)nblk), t(256);
     const int GC = (N / Ng) * C;
 #define LAUNCH_BWD(M, V)                                                                                                             \
     if (do_reduce) {                                                                                                                 \
         hipLaunchKernelGGL((norm_bwd_reduce_kernel<M, V>), g, t, 0, st, dy, y, x, gamma, mean, invstd, workspace, Ng, C, HW, nchunk, \
-                           slope, gbx, w, bias);                                                                                              \
+                           slope, ggx, w, bias);                                                                                              \
         hipLaunchKernelGGL(pair_sum_finalize_kernel, dim3(ceil_div(GC, 64)), dim3(64), 0, st, workspace, GC, Ng* nchunk, sums);      \
     }                                                                                                                                \
     if (do_apply)                                                                                                                    \
         hipLaunchKernelGGL((norm_bwd_apply_kernel<M, V>), g, t, 0, st, dy, y, x, gamma, w, mean, invstd, sums, dx, dgamma, dbeta, C, \
-                           HW, nchunk, inv_count, slope, gbx, Ng, dgb_split ? 1 : 0, bias);
+                           HW, nchunk, inv_count, slope, gbx, Ng, dgb_split ? 1 : 0, bias, ggx);
     if (mode == 0) {
         if (v) { LAUNCH_BWD(0, true) } else { LAUNCH_BWD(0, false) }
     } else {
@@ -842,7 +848,7 @@ extern "C" int ag2v_norm_bwd_pyr(const float* g_full, const float* const* g_leve
                        invstd, workspace, Ng, C, HW, nchunk, slope, 0LL, w, bias, lv);
     hipLaunchKernelGGL(pair_sum_finalize_kernel, dim3(ceil_div(GC, 64)), dim3(64), 0, st, workspace, GC, Ng * nchunk, sums);
     hipLaunchKernelGGL((norm_bwd_apply_kernel<0, true, true>), g, t, 0, st, g_full, (const float*)nullptr, x, (const float*)nullptr, w, mean,
-                       invstd, sums, dx, (float*)nullptr, (float*)nullptr, C, HW, nchunk, inv_count, slope, 0LL, Ng, 0, bias, lv);
+                       invstd, sums, dx, (float*)nullptr, (float*)nullptr, C, HW, nchunk, inv_count, slope, 0LL, Ng, 0, bias, -1LL, lv);
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
 }
@@ -928,6 +934,10 @@ extern "C" int ag2v_spade_pair_bwd_s(const float* dy0, const float* y0, const fl
     if (N <= 0 || C <= 0 || Ng <= 0 || N % Ng != 0 || (slope0 != 1.f && !y0) || (slope1 != 1.f && !y1)) return AG2V_EINVAL;
     if (!ag2v_spade_pair_supported(H, W, up) || !vec_ok(H * W, dy0, dy1, y0, y1, gb0, gb1) || !vec_ok(H * W, dgb0, dgb1, xs, dxs)) return AG2V_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    // dgb_split is a flag word: 1 = dgb0 / dgb1 written as split words; 2 = gb0 / gb1 point at compact gamma copies [N, C, H, W]
+    // (the backward never reads beta: a caller that keeps only gamma frees half of every gamma | beta tensor of the tape)
+    const int gcompact = (dgb_split >> 1) & 1;
+    dgb_split &= 1;
     const int HW = H * W, nchunk = ceil_div(HW, CHUNK);
     const long long nblk = (long long)N * C * nchunk;
     if (nblk >= (1LL << 31)) return AG2V_EINVAL;
@@ -936,10 +946,10 @@ extern "C" int ag2v_spade_pair_bwd_s(const float* dy0, const float* y0, const fl
     const float inv_count = 1.0f / ((float)Ng * (float)HW);
 #define PAIR_BWD(U)                                                                                                                  \
     hipLaunchKernelGGL(spade_pair_bwd_reduce_kernel<U>, g, t, 0, st, dy0, y0, dy1, y1, xs, gb0, gb1, mean, invstd, workspace, Ng, C, HW, \
-                       W, nchunk, slope0, slope1);                                                                                   \
+                       W, nchunk, slope0, slope1, gcompact);                                                                         \
     hipLaunchKernelGGL(multi_sum_finalize_kernel, dim3(ceil_div(GC * 8, 64)), dim3(64), 0, st, workspace, GC, Ng* nchunk, 8, sums);  \
     hipLaunchKernelGGL(spade_pair_bwd_apply_kernel<U>, g, t, 0, st, dy0, y0, dy1, y1, xs, gb0, gb1, mean, invstd, sums, dxs, dgb0, dgb1, \
-                       C, HW, W, nchunk, inv_count, slope0, slope1, Ng, dgb_split ? 1 : 0);
+                       C, HW, W, nchunk, inv_count, slope0, slope1, Ng, dgb_split ? 1 : 0, gcompact);
     if (up == 1) { PAIR_BWD(1) } else { PAIR_BWD(2) }
 #undef PAIR_BWD
     AG2V_CHECK_LAUNCH();

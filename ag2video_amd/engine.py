@@ -24,6 +24,8 @@ class TrainStep(object):
         self.opt = opt
         self.device = device
         dist_utils.set_sync_bn(getattr(opt, 'sync_bn', 0))
+        if getattr(opt, 'lean_tape', 0):
+            ops.set_lean_tape(True)
         self.model = AG2VideoModel(opt, device)
         self.model.float()
         self.discriminator = MetaDiscriminatorModel(opt)

@@ -119,6 +119,7 @@ class Layout2VidGenerator(nn.Module):
                     x = SegmapPyramid.from_levels(lv[(H, H)], lv)
                 else:
                     x = bn(y, slope=0.2, out_split=spl)
+                y = None        # (lean tape: the batch norm did not keep its input -- this name must not either)
                 out = self.netG(x) + warp
         out = out.view(T, B, out.size(1), H, H)
         flow = flow.view(T, B, 2, H, H)

@@ -92,6 +92,23 @@ def is_deterministic():
     return _DETERMINISTIC[0]
 
 
+# Lean tape (AG2V_LEAN_TAPE=1 / set_lean_tape / --lean_tape 1): trade a few passes over memory for tape size.
+#  * SPADE modulations keep a compact copy of gamma for their backward instead of the whole gamma | beta tensor (the backward never
+#    reads beta: half of every [N, 2C, H, W] tensor of the tape is dead weight);
+#  * the batch norm behind the low-rank layout convolution does not keep its input: the backward runs that convolution's last kernel
+#    again (deterministic, so the recomputed tensor is bit-identical) when everything else of the tape has been freed.
+# c3: 138.6 -> ~105 GB peak for ~ +1.5 % step time.  Results are bit-identical to the default mode's in deterministic mode.
+_LEAN_TAPE = [os.environ.get('AG2V_LEAN_TAPE', '0') not in ('', '0')]
+
+
+def set_lean_tape(flag):
+    _LEAN_TAPE[0] = bool(flag)
+
+
+def lean_tape():
+    return _LEAN_TAPE[0]
+
+
 class deterministic(object):
     """Context manager: operators called inside use the deterministic (atomic-free, ordered) reductions; the flag travels with
     every call (per-call options of the C ABI), nothing process-wide changes in the library."""
@@ -983,7 +1000,11 @@ class _NormAct(torch.autograd.Function):
                     g_ptr, b_ptr, _ptr(y), N, C, HW, Ng, float(slope), 1 if out_split else 0, _stream(), shape=(N, C, HW))
         # mode 0 (affine batch norm): the backward recomputes the activation's sign from x, w, b -- y is not kept for it
         sign_from_x = (mode == 0 and not sync and os.environ.get('AG2V_NORM_BWD_READ_Y') is None)
-        ctx.save_for_backward(x, y if (slope != 1.0 and not sign_from_x) else None, p0, mean, invstd, p1 if mode == 0 else None)
+        # lean tape, mode 2: only gamma is read by the backward -- keep a compact copy, let the [N, 2C, H, W] tensor go
+        ctx.gcompact = bool(mode == 2 and _LEAN_TAPE[0])
+        ctx.gb_shape = tuple(p0.shape) if mode == 2 else None
+        keep0 = p0[:, :C].contiguous() if ctx.gcompact else p0
+        ctx.save_for_backward(x, y if (slope != 1.0 and not sign_from_x) else None, keep0, mean, invstd, p1 if mode == 0 else None)
         ctx.cfg = (mode, training, slope, N, C, HW, Ng, world if sync else 0)
         ctx.dgb_split = bool(dgb_split) and mode == 2 and not sync
         return y
@@ -1004,14 +1025,14 @@ class _NormAct(torch.autograd.Function):
         wgt = p0 if mode == 0 else None
         dgamma = dbeta = dgb = None
         if mode == 2:
-            dgb = torch.empty_like(p0)
+            dgb = torch.empty(ctx.gb_shape, device=x.device, dtype=torch.float32)
             dg_ptr, db_ptr = _ptr(dgb), _ptr_off(dgb, C * HW)
         elif mode == 1:
             dgamma, dbeta = torch.empty_like(x), torch.empty_like(x)
             dg_ptr, db_ptr = _ptr(dgamma), _ptr(dbeta)
         else:
             dg_ptr = db_ptr = None
-        kmode = 2 if mode == 2 else mode
+        kmode = (3 if ctx.gcompact else 2) if mode == 2 else mode     # 3: gamma is a compact [N, C, H, W] copy (lean tape)
         if sync_world:
             # (sum dxhat, sum dxhat * xhat) per (group, channel) over ALL ranks between the two passes (batchnorm.py backward of the
             # reduce / broadcast pair)
@@ -1064,7 +1085,7 @@ class _BNActPyramid(torch.autograd.Function):
     Returns one tensor per entry of ``sizes`` (the full size is the normalised tensor itself)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, slope, groups, sizes, out_split):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, slope, groups, sizes, out_split, recompute=None):
         x, weight, bias = _c(x), _c(weight), _c(bias)
         _chk(x, weight, bias)
         mean, invstd, N, C, HW, Ng = _bn_stats(x, running_mean, running_var, training, momentum, eps, groups)
@@ -1080,16 +1101,31 @@ class _BNActPyramid(torch.autograd.Function):
             t = torch.empty((N, C, h, w), device=x.device, dtype=torch.float32)
             _lib.call('ag2v_nearest_resize_fwd', _ptr(built[src]), _ptr(t), N * C, src[0], src[1], h, w, _stream())
             built[(h, w)] = t
-        ctx.save_for_backward(x, weight, bias, mean, invstd)
+        # lean tape: x is the output of a launch that can be repeated bit for bit (recompute = its operands, layout_conv_img): the
+        # backward -- the LAST node of the generator's backward pass, when the rest of the tape is gone -- runs it again instead of
+        # keeping [N, C, H, W] floats alive through the whole step
+        ctx.n_rc = 0
+        if recompute is not None:
+            rc_t = [t_ for t_ in recompute if torch.is_tensor(t_) or t_ is None]
+            ctx.rc_meta = tuple(v for v in recompute if not (torch.is_tensor(v) or v is None))
+            ctx.n_rc = len(rc_t)
+            ctx.save_for_backward(None, weight, bias, mean, invstd, *rc_t)
+        else:
+            ctx.save_for_backward(x, weight, bias, mean, invstd)
         ctx.cfg = (training, slope, N, C, H, W, Ng, tuple(sizes))
         return tuple(y.view_as(y) if (h, w) == (H, W) else built[(h, w)] for (h, w) in sizes)
 
     @staticmethod
     def backward(ctx, *grads):
-        x, weight, bias, mean, invstd = ctx.saved_tensors
+        x, weight, bias, mean, invstd = ctx.saved_tensors[:5]
         training, slope, N, C, H, W, Ng, sizes = ctx.cfg
         if not training:
             raise RuntimeError("norm backward is only implemented for batch statistics (training mode)")
+        if ctx.n_rc:
+            with torch.no_grad():
+                x = _layout_conv_img_run(*(tuple(ctx.saved_tensors[5:5 + ctx.n_rc]) + ctx.rc_meta))
+            if tuple(x.shape) != (N, C, H, W):
+                raise RuntimeError("batchnorm_act_pyramid: the recomputed input has shape %s, expected %s" % (tuple(x.shape), (N, C, H, W)))
         g_full, lv, hs, ws_, keep = None, [], [], [], []
         for (h, w), g in zip(sizes, grads):
             if g is None:
@@ -1115,7 +1151,7 @@ class _BNActPyramid(torch.autograd.Function):
         if weight is not None:
             tot = sums.sum(dim=0) if G > 1 else sums[0]
             dw, db = tot[:, 1].contiguous(), tot[:, 0].contiguous()
-        return (dx, dw, db) + (None,) * 9
+        return (dx, dw, db) + (None,) * 10
 
 
 def batchnorm_act_pyramid_supported(x_shape, sizes):
@@ -1130,8 +1166,9 @@ def batchnorm_act_pyramid(x, weight, bias, running_mean, running_var, sizes, tra
     """nearest_pyramid(batchnorm_act(x, ...), sizes) with a fused backward (see _BNActPyramid); requires
     batchnorm_act_pyramid_supported(x.shape, sizes).  Returns a tuple of tensors (split words when out_split)."""
     sizes = tuple((int(h), int(w)) for (h, w) in sizes)
+    rc = getattr(x, '_ag2v_recompute', None) if (_LEAN_TAPE[0] and training) else None
     outs = _BNActPyramid.apply(x, weight, bias, running_mean, running_var, bool(training), float(momentum), float(eps), float(slope),
-                               int(groups), sizes, bool(out_split))
+                               int(groups), sizes, bool(out_split), rc)
     if out_split:
         for o in outs:
             mark_split(o)
@@ -1184,7 +1221,10 @@ class _SpadePair(torch.autograd.Function):
         _launch('ag2v_spade_pair_apply_s', 'spade_pair_apply', (xs.numel() + 6.0 * y0.numel()) * 4, _ptr(xs), _ptr(mean), _ptr(invstd), _ptr(gb0),
                 _ptr(gb1), _ptr(y0), _ptr(y1), N, C, H, W, up, Ng, float(slope0), float(slope1), 1 if split0 else 0, 1 if split1 else 0, st,
                 shape=(N, C, H * W, up))
-        ctx.save_for_backward(xs, gb0, gb1, y0 if slope0 != 1.0 else None, y1 if slope1 != 1.0 else None, mean, invstd)
+        # lean tape: the backward reads gamma_0 / gamma_1 only -- compact copies instead of the two [N, 2C, H, W] tensors
+        ctx.gcompact = _LEAN_TAPE[0]
+        k0, k1 = (gb0[:, :C].contiguous(), gb1[:, :C].contiguous()) if ctx.gcompact else (gb0, gb1)
+        ctx.save_for_backward(xs, k0, k1, y0 if slope0 != 1.0 else None, y1 if slope1 != 1.0 else None, mean, invstd)
         ctx.cfg = (up, slope0, slope1, N, C, H, W, Ng)
         ctx.dgb_split = bool(dgb_split)
         return y0, y1
@@ -1200,7 +1240,8 @@ class _SpadePair(torch.autograd.Function):
         dy1 = z if dy1 is None else dy1.contiguous()
         G = N // Ng
         dxs = torch.empty_like(xs)
-        dgb0, dgb1 = torch.empty_like(gb0), torch.empty_like(gb1)
+        dgb0 = torch.empty((N, 2 * C, H, W), device=xs.device, dtype=torch.float32)
+        dgb1 = torch.empty_like(dgb0)
         sums = torch.empty((G, C, 8), device=xs.device, dtype=torch.float32)
         ws = torch.empty(_lib.query('ag2v_spade_pair_workspace_floats', N, C, H * W), device=xs.device, dtype=torch.float32)
         # algorithmic bytes: reduce pass reads dy0, dy1, gamma0, gamma1 and x (input size) plus y_i only where slope_i != 1 (the
@@ -1209,7 +1250,8 @@ class _SpadePair(torch.autograd.Function):
         ny = (1 if slope0 != 1.0 else 0) + (1 if slope1 != 1.0 else 0)
         _launch('ag2v_spade_pair_bwd_s', 'spade_pair_bwd', (3.0 * xs.numel() + (12.0 + 2.0 * ny) * dy0.numel()) * 4, _ptr(dy0), _ptr(y0), _ptr(dy1),
                 _ptr(y1), _ptr(xs), _ptr(gb0), _ptr(gb1), _ptr(mean), _ptr(invstd), _ptr(dxs), _ptr(dgb0), _ptr(dgb1), _ptr(sums), N, C, H, W,
-                up, Ng, float(slope0), float(slope1), _ptr(ws), 1 if ctx.dgb_split else 0, _stream(), shape=(N, C, H * W, up))
+                up, Ng, float(slope0), float(slope1), _ptr(ws), (1 if ctx.dgb_split else 0) | (2 if ctx.gcompact else 0), _stream(),
+                shape=(N, C, H * W, up))
         tot = sums.sum(dim=0) if G > 1 else sums[0]
         dgb0._ag2v_channel_sums = torch.cat([tot[:, 3], tot[:, 2]])      # bias gradients of the two gamma | beta convolutions
         dgb1._ag2v_channel_sums = torch.cat([tot[:, 7], tot[:, 6]])
@@ -1332,6 +1374,21 @@ def layout_conv(U, boxes, keep, H, W, R=3, stride=1, pad=1, residual=None, pool=
     return _LayoutConv.apply(U, boxes, keep, residual, int(H), int(W), int(R), int(stride), int(pad), int(pool))
 
 
+def _layout_conv_img_run(U, boxes, keep, img, w_img, gscale, H, W, R, pad):
+    """The forward launch of _LayoutConvImg on contiguous operands (keep: int32).  No atomics: a second call with the same operands
+    returns the same bits -- which is what the lean tape's recomputation relies on (_BNActPyramid)."""
+    NB, J, K, RS = U.shape
+    IC = img.shape[1]
+    iscale = None
+    if gscale is not None:
+        group_n = NB // gscale.numel()
+        iscale = gscale.repeat_interleave(group_n) if group_n > 1 else gscale
+    out = torch.empty((NB, K, H, W), device=U.device, dtype=torch.float32)
+    _lib.call('ag2v_layout_conv_img_fwd', _ptr(U), _ptr(boxes), _ptr(keep), None, _ptr(out), NB, J, K, H, W, R, 1, pad, 0,
+              _ptr(img), _ptr(w_img), _ptr(iscale), IC, _stream())
+    return out
+
+
 class _LayoutConvImg(torch.autograd.Function):
     """layout_conv plus the image channels of the same convolution in ONE forward launch:
     out = layout_conv(U) + gscale[group(n)] * conv(img, w_img)   (stride 1, same size).  The backward of the image part is a plain
@@ -1347,13 +1404,8 @@ class _LayoutConvImg(torch.autograd.Function):
         IC = img.shape[1]
         if RS != R * R or tuple(w_img.shape) != (K, IC, R, R) or tuple(img.shape) != (NB, IC, H, W):
             raise RuntimeError("layout_conv_img: inconsistent shapes")
-        group_n, iscale = 1, None
-        if gscale is not None:
-            group_n = NB // gscale.numel()
-            iscale = gscale.repeat_interleave(group_n) if group_n > 1 else gscale
-        out = torch.empty((NB, K, H, W), device=U.device, dtype=torch.float32)
-        _lib.call('ag2v_layout_conv_img_fwd', _ptr(U), _ptr(boxes), _ptr(keep), None, _ptr(out), NB, J, K, H, W, R, 1, pad, 0,
-                  _ptr(img), _ptr(w_img), _ptr(iscale), IC, _stream())
+        group_n = 1 if gscale is None else NB // gscale.numel()
+        out = _layout_conv_img_run(U, boxes, keep, img, w_img, gscale, H, W, R, pad)
         ctx.save_for_backward(boxes, keep, img, w_img, gscale)
         ctx.cfg = (NB, J, K, H, W, R, pad, group_n, _current_min_rows()[1])
         ctx.wkey = _wsink_register(w_in) if ctx.needs_input_grad[4] else None
@@ -1397,7 +1449,14 @@ def layout_conv_img(U, boxes, keep, H, W, R, pad, img, w_img, gscale=None):
     channels of conv_dim_in / down_flow[0] (generator.py:66,74,82-83).  2 * pad must equal R - 1."""
     if 2 * pad != R - 1:
         raise RuntimeError("layout_conv_img: same-size convolutions only (2 * pad == R - 1)")
-    return _LayoutConvImg.apply(U, boxes, keep, img, w_img, gscale, int(H), int(W), int(R), int(pad))
+    out = _LayoutConvImg.apply(U, boxes, keep, img, w_img, gscale, int(H), int(W), int(R), int(pad))
+    if _LEAN_TAPE[0]:
+        # how to produce this tensor again (detached operands, a few MB): a consumer that would otherwise keep the [N, K, H, W] result for
+        # its backward may drop it and re-run the launch instead (batchnorm_act_pyramid)
+        with torch.no_grad():
+            out._ag2v_recompute = (_c(U.detach()), _c(boxes.detach()), keep.to(torch.int32).contiguous(), _c(img.detach()),
+                                   _c(w_img.detach()), None if gscale is None else _c(gscale.detach()), int(H), int(W), int(R), int(pad))
+    return out
 
 
 class _FlowWarp(torch.autograd.Function):

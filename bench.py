@@ -156,6 +156,7 @@ def main():
                     help='arithmetic of the 128-row conv MFMA tiles (both hold the 1e-3 parity bound; tests/test_step_gpu.py)')
     ap.add_argument('--no-fp32-leg', action='store_true', help='skip the extra exact-fp32 step used for roofline_exact_fp32')
     ap.add_argument('--temporal-D', action='store_true', help='--temporal_D 1: the temporal multiscale PatchGAN on top of the image discriminator (not BASELINE.json\'s metric; reported in config.workload)')
+    ap.add_argument('--lean-tape', action='store_true', help='--lean_tape 1: smaller autograd tape for a few extra passes over memory (reported in config.workload)')
     args = ap.parse_args()
     if args.cpu_baseline_only:
         cpu_baseline_child()
@@ -173,6 +174,7 @@ def main():
     opt, side, frames, batch = make_opt(args.config)
     opt.gpu_ids = [local]
     opt.temporal_D = 1 if args.temporal_D else 0
+    opt.lean_tape = 1 if args.lean_tape else 0
     ops.set_conv_precision(args.precision)
     ts = TrainStep(opt, device, weights_seed=0)
     clip = ts.to_device(make_clip(opt, args.config, batch, frames, side, seed=1234 + rank))
@@ -238,7 +240,8 @@ def main():
                     "discriminator's all-reduce is synchronous (fully exposed)"})
     if os.environ.get('AG2V_TIMING_DETAIL') and rank == 0:
         det = ops.kernel_timing_summary(by_shape=True)
-        for k, v in sorted(det.items(), key=lambda kv: -kv[1]['ms'])[:45]:
+        top = int(os.environ['AG2V_TIMING_DETAIL']) if os.environ['AG2V_TIMING_DETAIL'].isdigit() and int(os.environ['AG2V_TIMING_DETAIL']) > 1 else 45
+        for k, v in sorted(det.items(), key=lambda kv: -kv[1]['ms'])[:top]:
             print('DETAIL %8.1f ms %5d launches %6.1f TF  %s' % (v['ms'], v['launches'], v['flops'] / (v['ms'] * 1e-3) / 1e12, k), file=sys.stderr)
     ops.enable_kernel_timing(False)
     finite = all(bool(torch.isfinite(v).all()) for v in list(GL.values()) + list(DL.values()))
@@ -383,7 +386,7 @@ def main():
         "dtype": ("f32 (conv products as 3-term bf16 splits on the bf16 MFMA pipe, fp32 accumulate; everything else fp32)"
                   if args.precision == 'bf16x3' else "f32"), "data": "synthetic CATER-shaped clips (seeded), closed-form random-init weights",
         "config": {"workload": "%s: %s %dx%d, %d frames, batch %d per GPU, full G+D train step, VGG loss off%s"
-                   % (args.config, "SSv2-shaped" if args.config == 'c5' else "CATER", side, side, frames, batch, ", + temporal discriminator (--temporal_D 1)" if args.temporal_D else ""), "global_batch": world * batch, "parallelism": "dp%d" % world},
+                   % (args.config, "SSv2-shaped" if args.config == 'c5' else "CATER", side, side, frames, batch, (", + temporal discriminator (--temporal_D 1)" if args.temporal_D else "") + (", lean tape (--lean_tape 1)" if args.lean_tape else "")), "global_batch": world * batch, "parallelism": "dp%d" % world},
         "roofline": roof, "roofline_exact_fp32": roof_fp32, "roofline_hbm": roof_hbm, "roofline_hbm_bwd": roof_hbm_bwd,
         "cpu_baseline": cpu, "comm": comm,
         "extra": {"graph_step_ms": round(graph_ms, 2), "losses_finite": finite,

@@ -175,7 +175,10 @@ int ag2v_norm_bwd_gs(int mode, const float* dy, const float* y, const float* x, 
                      const float* bias, const float* mean, const float* invstd, float* dx, float* dgamma, float* dbeta, float* sums,
                      int N, int C, int HW, int Ng, float slope, float* workspace, int dgb_split, void* stream);
 /* (mode 0, y == NULL: the LeakyReLU branch is recomputed from x, w and `bias` -- the affine pair of the forward pass -- instead of
- *  being read from the forward output: 5 instead of 7 tensor passes.) */
+ *  being read from the forward output: 5 instead of 7 tensor passes.)
+ * (mode 3 = mode 2 whose `gamma` points at a COMPACT copy [N, C, HW] of the gamma half; dgamma / dbeta are still the halves of one
+ *  [N, 2C, HW] tensor.  The backward never reads beta, so a caller that keeps this copy instead of the gamma | beta tensor halves
+ *  that part of its tape: ops.set_lean_tape.) */
 /* ag2v_norm_bwd_gs(mode 0, y == NULL) for an output that was read directly and through nearest-neighbour down-samplings (the
  * decoder's segmentation-map pyramid, normalization.py:102): dy = g_full (nullable) + sum_l scatter(g_levels[l]) is formed while
  * loading.  g_levels / hs / ws: host arrays of n_levels <= 8 entries (null level pointers are skipped). */
@@ -208,7 +211,8 @@ int ag2v_spade_pair_apply_s(const float* xs, const float* mean, const float* inv
 int ag2v_spade_pair_bwd(const float* dy0, const float* y0, const float* dy1, const float* y1, const float* xs, const float* gb0,
                         const float* gb1, const float* mean, const float* invstd, float* dxs, float* dgb0, float* dgb1, float* sums,
                         int N, int C, int H, int W, int up, int Ng, float slope0, float slope1, float* workspace, void* stream);
-/* ... with dgb0 / dgb1 stored as split words when dgb_split != 0 (see ag2v_norm_bwd_gs). */
+/* ... dgb_split is a flag word: 1 = dgb0 / dgb1 stored as split words (see ag2v_norm_bwd_gs); 2 = gb0 / gb1 point at compact
+ * copies [N, C, H, W] of the gamma halves (the backward reads no beta; see ag2v_norm_bwd_gs mode 3). */
 int ag2v_spade_pair_bwd_s(const float* dy0, const float* y0, const float* dy1, const float* y1, const float* xs, const float* gb0,
                           const float* gb1, const float* mean, const float* invstd, float* dxs, float* dgb0, float* dgb1,
                           float* sums, int N, int C, int H, int W, int up, int Ng, float slope0, float slope1, float* workspace,

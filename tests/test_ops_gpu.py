@@ -1182,3 +1182,122 @@ def test_layout_conv_img(cfg, device):
          'gscale': None if G is None else torch.linspace(0.6, 1.5, G)}
     assert ops.layout_conv_img_supported(H, W, R, 1, 0, 3)
     _run_pair(ops.layout_conv_img, K.layout_conv_img, t, device, nondiff=('boxes',), name='layout_conv_img')
+
+
+# ------------------------------------------------------------------------------------------------ lean tape (ops.set_lean_tape)
+def _tape_bytes(fn):
+    """Runs fn() under saved-tensor hooks; returns (result, bytes of unique device storages autograd kept for the backward)."""
+    seen = {}
+
+    def pack(t):
+        if t.is_cuda:
+            st = t.untyped_storage()
+            seen[st.data_ptr()] = st.nbytes()
+        return t
+    with torch.autograd.graph.saved_tensors_hooks(pack, lambda t: t):
+        out = fn()
+    return out, sum(seen.values())
+
+
+def test_lean_tape_spade_backward_reads_compact_gamma(device):
+    """ops.set_lean_tape: the SPADE modulations (pair and fused forms) keep a compact copy of gamma instead of the [N, 2C, H, W]
+    gamma | beta tensor.  Same kernels, same order of operations: outputs and every gradient are bit-identical to the default
+    mode's, and the tape is smaller by the beta halves."""
+    from ag2video_amd import ops
+    N, C, Hs, Ws, up, G = 6, 16, 8, 16, 2, 3
+    H, W = Hs * up, Ws * up
+    xs = _rand(N, C, Hs, Ws, seed=1)
+    gb0, gb1 = _rand(N, 2 * C, H, W, seed=2) * 0.3, _rand(N, 2 * C, H, W, seed=3) * 0.3
+    xf = _rand(N, C, H, W, seed=6)
+    w0, w1, w2 = _rand(N, C, H, W, seed=4).to(device), _rand(N, C, H, W, seed=5).to(device), _rand(N, C, H, W, seed=7).to(device)
+    res, tape = [], []
+    try:
+        for lean in (False, True):
+            ops.set_lean_tape(lean)
+            xd, g0, g1, xg, g2 = [t.clone().to(device).requires_grad_(True) for t in (xs, gb0, gb1, xf, gb0)]
+            bufs = [torch.zeros(C, device=device), torch.ones(C, device=device), torch.zeros(C, device=device), torch.ones(C, device=device),
+                    torch.zeros(C, device=device), torch.ones(C, device=device)]
+
+            def fwd():
+                # (g * 1.0: the modulations must not be handed leaves -- a leaf is alive whoever saves it)
+                y0, y1 = ops.spade_pair(xd, g0 * 1.0, g1 * 1.0, bufs[0], bufs[1], bufs[2], bufs[3], up, 0.1, 1e-5, 0.2, 1.0, G)
+                y2 = ops.spade_norm_fused(xg, g2 * 1.0, bufs[4], bufs[5], True, 0.1, 1e-5, 0.2, G)
+                return y0, y1, y2
+            (y0, y1, y2), nbytes = _tape_bytes(fwd)
+            ((y0 * w0).sum() + (y1 * w1).sum() * 0.7 + (y2 * w2).sum()).backward()
+            res.append([y0, y1, y2, xd.grad, g0.grad, g1.grad, xg.grad, g2.grad] + bufs)
+            tape.append(nbytes)
+    finally:
+        ops.set_lean_tape(False)
+    for i, (a, b) in enumerate(zip(*res)):
+        assert torch.equal(a, b), i
+    beta_bytes = 3 * N * C * H * W * 4
+    assert tape[0] - tape[1] == beta_bytes, (tape, beta_bytes)
+
+
+def test_lean_tape_batchnorm_recomputes_the_layout_convolution(device):
+    """ops.set_lean_tape: batchnorm_act_pyramid behind layout_conv_img does not keep its [N, K, H, W] input; its backward runs the
+    layout convolution's forward launch again.  Bit-identical gradients, smaller tape."""
+    from ag2video_amd import ops
+    NB, J, Kc, H, W, R, G = 6, 4, 40, 16, 32, 3, 3
+    boxes = _boxes(NB, J, 21).to(device)
+    keep = torch.ones(NB, J, dtype=torch.int32, device=device)
+    keep[:, J - 1] = 0
+    U0, img0, wimg0 = _rand(NB, J, Kc, R * R, seed=22), _rand(NB, 3, H, W, seed=23), _rand(Kc, 3, R, R, seed=24, scale=0.2)
+    gs0 = torch.linspace(0.6, 1.5, G)
+    sizes = ((H, W), (H // 2, W // 2), (H // 4, W // 4))
+    wl = [_rand(NB, Kc, h, w, seed=30 + i).to(device) for i, (h, w) in enumerate(sizes)]
+    res, tape = [], []
+    try:
+        for lean in (False, True):
+            ops.set_lean_tape(lean)
+            U, img, wimg, gs = [t.clone().to(device).requires_grad_(True) for t in (U0, img0, wimg0, gs0)]
+            bw, bb = torch.linspace(0.5, 1.5, Kc, device=device).requires_grad_(True), torch.linspace(-0.2, 0.2, Kc, device=device).requires_grad_(True)
+            rm, rv = torch.zeros(Kc, device=device), torch.ones(Kc, device=device)
+
+            def fwd():
+                y = ops.layout_conv_img(U, boxes, keep, H, W, R, 1, img, wimg, gs)
+                assert ops.batchnorm_act_pyramid_supported(y.shape, sizes)
+                return ops.batchnorm_act_pyramid(y, bw, bb, rm, rv, sizes, True, 0.1, 1e-5, 0.2, G)
+            lv, nbytes = _tape_bytes(fwd)
+            sum((l * w_).sum() for l, w_ in zip(lv, wl)).backward()
+            res.append(list(lv) + [U.grad, img.grad, wimg.grad, gs.grad, bw.grad, bb.grad, rm, rv])
+            tape.append(nbytes)
+    finally:
+        ops.set_lean_tape(False)
+    for i, (a, b) in enumerate(zip(*res)):
+        assert torch.equal(a, b), i
+    assert tape[0] - tape[1] >= NB * Kc * H * W * 4 - (1 << 20), tape
+
+
+def test_lean_tape_train_step_is_bit_identical(device):
+    """One toy training iteration with --lean_tape 1 against the default tape, both with deterministic reductions: outputs, losses and
+    both flat gradients are bit-identical (the lean tape recomputes or copies, it does not re-associate)."""
+    from ag2video_amd import ops
+    from ag2video_amd.data.args import make_opt
+    from ag2video_amd.data.synthetic import make_clip_batch
+    from ag2video_amd.data.vocab import cater_vocab
+    from ag2video_amd.engine import TrainStep
+    flags = ['--no_vgg_loss', '--image_size', '64,64', '--batch_size', '2', '--ngf', '16', '--ndf', '16', '--nff', '16',
+             '--gconv_hidden_dim', '64', '--gpu_ids', '0']
+    res = []
+    try:
+        with ops.deterministic():
+            for lean in (0, 1):
+                ops.set_lean_tape(False)
+                opt = make_opt(cater_vocab(), flags + ['--lean_tape', str(lean)])
+                ts = TrainStep(opt, device, weights_seed=5)
+                assert ops.lean_tape() == bool(lean)
+                clip = ts.to_device(make_clip_batch(opt.vocab, 2, 4, (64, 64), seed=11))
+                out, GL, DL = ts.gd_step(clip, apply_updates=False)
+                torch.cuda.synchronize()
+                res.append(([t.clone() for t in out[:3]], {k: float(v) for k, v in list(GL.items()) + list(DL.items())},
+                            ts.optimizer_generator.flat_grad.clone(), ts.discriminator.optimizer_d_img.flat_grad.clone()))
+                del ts
+    finally:
+        ops.set_lean_tape(False)
+    (o0, l0, gG0, gD0), (o1, l1, gG1, gD1) = res
+    assert l0 == l1, (l0, l1)
+    for a, b in zip(o0, o1):
+        assert torch.equal(a, b)
+    assert torch.equal(gG0, gG1) and torch.equal(gD0, gD1)
