@@ -70,6 +70,7 @@ _SIGS = {
     'ag2v_maxpool2_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
     'ag2v_nearest_resize_fwd': (c_int, [_P, _P] + [c_int] * 5 + [_P]),
     'ag2v_nearest_resize_bwd': (c_int, [_P, _P] + [c_int] * 5 + [_P]),
+    'ag2v_norm_apply_half': (c_int, [_P] * 7 + [c_int] * 5 + [c_float, c_int, _P]),
     'ag2v_nearest_pyramid_bwd': (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P]),
     'ag2v_triple_gather_fwd': (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [_P]),
     'ag2v_triple_gather_bwd': (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [_P]),

@@ -156,7 +156,8 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
                                                          const float* __restrict__ invstd, const float* __restrict__ w,
                                                          const float* __restrict__ b, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* __restrict__ y, int C,
-                                                         int HW, int nchunk, float slope, long long gbx, int Ng, int out_split) {
+                                                         int HW, int nchunk, float slope, long long gbx, int Ng, int out_split,
+                                                         float* __restrict__ yhalf = nullptr, int W = 0) {
     const int bid = blockIdx.x;
     const int chunk = bid % nchunk, nc = bid / nchunk;
     const int c = nc % C;
@@ -184,6 +185,21 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
         for (int i = 0; i < 16; ++i) v[i] = pack_split(v[i]);
     }
     store16<VEC>(y + off, cnt, v);
+    if (VEC && yhalf) {
+        // the 2x nearest-neighbour down-sampling of y (the first level of the decoder's segmentation-map pyramid: y[2i][2j]) from the
+        // registers: W % 8 == 0, so a thread's four consecutive elements share a row and start at a multiple of 4
+        const int Wh = W >> 1;
+        float* yh = yhalf + (size_t)nc * (HW >> 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = (i * 256 + threadIdx.x) * 4;
+            if (e >= cnt) continue;
+            const int L = start + e;
+            const int row = L / W, x0 = L - row * W;
+            if (row & 1) continue;
+            *reinterpret_cast<float2*>(yh + (size_t)(row >> 1) * Wh + (x0 >> 1)) = make_float2(v[4 * i], v[4 * i + 2]);
+        }
+    }
 }
 
 // Gradient of a tensor that was also read through nearest-neighbour down-samplings (the segmentation-map pyramid of the decoder):
@@ -753,6 +769,23 @@ extern "C" int ag2v_bn_stats_g(const float* x, int N, int C, int HW, int Ng, flo
     if (N / Ng > FIN_MAXG && running_mean) return AG2V_EINVAL;     // running-stat chain of more groups than the kernel stages
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, st, workspace, N / Ng, C, Ng * nchunk, eps,
                        momentum, mean, invstd, running_mean, running_var);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+// ag2v_norm_apply_gs(mode 0) that also writes the 2x nearest-neighbour down-sampling of y (y_half [N, C, H/2, W/2] = y[:, :, ::2, ::2],
+// same word format) from the registers: the first level of the decoder's segmentation-map pyramid without a second pass over y.
+// H % 2 == 0, W % 8 == 0, 16-byte aligned tensors.
+extern "C" int ag2v_norm_apply_half(const float* x, const float* mean, const float* invstd, const float* w, const float* b, float* y,
+                                    float* y_half, int N, int C, int H, int W, int Ng, float slope, int out_split, void* stream) {
+    if (!x || !mean || !invstd || !y || !y_half || N <= 0 || C <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 7) || Ng <= 0 || N % Ng != 0)
+        return AG2V_EINVAL;
+    const int HW = H * W;
+    if (!vec_ok(HW, x, y) || (reinterpret_cast<uintptr_t>(y_half) & 15)) return AG2V_EINVAL;
+    const int nchunk = ceil_div(HW, CHUNK);
+    const long long nblk = (long long)N * C * nchunk;
+    if (nblk >= (1LL << 31)) return AG2V_EINVAL;
+    hipLaunchKernelGGL((norm_apply_kernel<0, true>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, w, b,
+                       (const float*)nullptr, (const float*)nullptr, y, C, HW, nchunk, slope, 0LL, Ng, out_split ? 1 : 0, y_half, W);
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
 }

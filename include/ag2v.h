@@ -166,6 +166,11 @@ int ag2v_norm_apply_g(int mode, const float* x, const float* mean, const float* 
 int ag2v_norm_apply_gs(int mode, const float* x, const float* mean, const float* invstd, const float* w, const float* b,
                        const float* gamma, const float* beta, float* y, int N, int C, int HW, int Ng, float slope, int out_split,
                        void* stream);
+/* ag2v_norm_apply_gs(mode 0, ...) that also writes y_half [N, C, H/2, W/2] = y[:, :, ::2, ::2] (same word format) from the registers:
+ * the first level of the decoder's segmentation-map pyramid (normalization.py:102, F.interpolate(segmap, mode='nearest')) without a
+ * second pass over y.  H % 2 == 0, W % 8 == 0, 16-byte aligned tensors. */
+int ag2v_norm_apply_half(const float* x, const float* mean, const float* invstd, const float* w, const float* b, float* y,
+                         float* y_half, int N, int C, int H, int W, int Ng, float slope, int out_split, void* stream);
 int ag2v_norm_bwd_g(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* w,
                     const float* mean, const float* invstd, float* dx, float* dgamma, float* dbeta, float* sums,
                     int N, int C, int HW, int Ng, float slope, float* workspace, void* stream);

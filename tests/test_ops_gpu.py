@@ -601,7 +601,9 @@ def test_spade_gradient_as_split_words(pair, device, monkeypatch):
 
 
 @pytest.mark.parametrize("cfg", [(4, 6, 32, 32, 2, [(32, 32), (16, 16), (8, 8), (2, 2)]), (3, 5, 16, 24, 1, [(8, 12), (4, 6)]),
-                                 (2, 4, 8, 8, 2, [(8, 8)])], ids=str)
+                                 (2, 4, 8, 8, 2, [(8, 8)]),
+                                 # half-size level written by the normalisation pass; three small levels folded into one before the backward
+                                 (2, 4, 64, 64, 1, [(64, 64), (8, 8), (32, 32), (16, 16), (4, 4)])], ids=str)
 def test_batchnorm_act_pyramid(cfg, device):
     """Affine batch norm + LeakyReLU + the nearest-neighbour pyramid of the result as one node (fused backward: the level gradients are
     gathered while the norm backward loads its dy) against the oracle's two steps; frame groups; levels without a gradient."""

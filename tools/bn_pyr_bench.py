@@ -29,3 +29,21 @@ for sizes in (sizes_all, ((256, 256),), sizes_all[:2]):
         if 'norm_bwd' in k:
             print(len(sizes), 'levels:', k, '%.2f ms per call' % (v['ms'] / v['launches']), '%.2f TB/s algorithmic' % (v['flops'] / v['launches'] / (v['ms'] / v['launches'] * 1e-3) / 1e12))
     del outs, grads, xr
+
+# forward: normalisation pass + pyramid construction, with and without the half-size level written by the normalisation pass
+for env in (None, '1'):
+    if env:
+        os.environ['AG2V_NO_APPLY_HALF'] = env
+    else:
+        os.environ.pop('AG2V_NO_APPLY_HALF', None)
+    with torch.no_grad():
+        for rep in range(2):
+            outs = ops.batchnorm_act_pyramid(x, w, b, rm, rv, sizes_all, True, 0.1, 1e-5, 0.2, G)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for rep in range(5):
+            outs = ops.batchnorm_act_pyramid(x, w, b, rm, rv, sizes_all, True, 0.1, 1e-5, 0.2, G)
+        e1.record()
+        torch.cuda.synchronize()
+        print('forward (stats + apply + 5 levels), half level %s: %.2f ms' % ('by resize' if env else 'in the apply pass', e0.elapsed_time(e1) / 5))
