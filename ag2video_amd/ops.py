@@ -7,9 +7,13 @@ otherwise -- there is no CPU path in the product (tests/ check these operators a
 Side channels between operators travel as attributes on the tensor objects autograd hands from one Function to the next (the
 same Python object arrives; a tensor that lost its attribute simply takes the plain path):
   _ag2v_split          the tensor holds split words (bf16 hi | bf16 lo per value) instead of fp32: is_split / mark_split;
-  _ag2v_dy_split_ok    on an operator's OUTPUT: its backward accepts the gradient of this tensor as split words;
+  _ag2v_dy_split_ok    on an operator's OUTPUT: its backward accepts the gradient of this tensor as split words (a _DySplitOffer);
   _ag2v_channel_sums   on a GRADIENT tensor: its per-channel sums, already computed by the kernel that produced it (the bias
                        gradient of the convolution it goes to).
+These only make sense for a tensor with ONE consumer (autograd would add a second gradient contribution to split words as if they
+were floats).  That is enforced, not assumed: the attributes carry the tensor's version counter (an in-place accumulation into the
+tensor makes is_split raise and voids the channel sums), an offer can be taken once (a second taker raises in the forward pass),
+and the producer's backward raises when a taken offer's gradient arrives as anything but the taker's split-word tensor.
 """
 import contextlib
 import ctypes
@@ -531,6 +535,7 @@ class _Conv2d(torch.autograd.Function):
         dx = dw = db = dres = dgs = None
         st = _stream()
         dys = is_split(dy_in)       # the gradient arrives as split words (written so by the SPADE backward: ops.conv_split_dy_ok)
+        _check_taken_offer(ctx, 0, dy_in, "conv2d")
         if dys and ((relu and not grad_premasked) or has_res or dy is not dy_in):
             raise RuntimeError("conv2d backward: a split-word gradient reached a convolution with a ReLU / residual epilogue")
         if relu and not grad_premasked:
@@ -572,7 +577,7 @@ class _Conv2d(torch.autograd.Function):
                 _conv_wgrad_launch(mr, dy, x, buf, K, R, S, stride, pad, acc, in_split=ctx.x_split, dy_split=dys)
         if has_bias and ctx.needs_input_grad[2]:
             bbuf, bacc, db = _wsink_take(ctx.bkey, ctx.w_alive[1])
-            pre = getattr(dy_in, '_ag2v_channel_sums', None) if not (relu and not grad_premasked) else None
+            pre = _channel_sums_of(dy_in) if not (relu and not grad_premasked) else None
             if pre is not None and pre.numel() == K and _USE_CHANNEL_SUMS:     # produced with dy by the SPADE backward (_NormAct)
                 if bacc:
                     bbuf.add_(pre)
@@ -596,23 +601,90 @@ def conv2d(x, w, bias=None, stride=1, pad=0, residual=None, relu=False, grad_pre
              and conv_split_dy_ok(x.shape, w.shape, stride, pad))
     # x = relu(...) whose producer takes its gradient as split words (conv2d_shared_input): this convolution's data gradient, which
     # applies that ReLU's mask in its epilogue, writes them
-    dx_split = bool(relu_input and dy_ok and getattr(x, '_ag2v_dy_split_ok', False))
+    dx_split = bool(relu_input and dy_ok and x.requires_grad and _take_dy_split(x))
     y = _Conv2d.apply(x, w, bias, residual, gscale, int(stride), int(pad), bool(relu), bool(grad_premasked), bool(relu_input),
                       is_split(x), dx_split)
-    if dy_ok:
-        y._ag2v_dy_split_ok = True      # a SPADE backward that is y's only consumer may hand back d(y) as split words
+    if dy_ok and y.grad_fn is not None:
+        _offer_dy_split(y)              # a SPADE backward that is y's only consumer may hand back d(y) as split words
     return y
 
 
 def is_split(t):
     """True when t holds split words (bf16 hi | bf16 lo per value: ag2v_conv_opts::in_split) instead of fp32 -- a tensor written by
-    batchnorm_act(..., out_split=True) or a nearest-neighbour resize of one; only bf16x3 convolutions may read it."""
-    return bool(getattr(t, '_ag2v_split', False))
+    batchnorm_act(..., out_split=True) or a nearest-neighbour resize of one; only bf16x3 convolutions may read it.
+    Raises when the tensor was modified in place after it was marked (autograd accumulating a second gradient contribution into it:
+    split words added as floats are garbage)."""
+    v = getattr(t, '_ag2v_split', None)
+    if v is None:
+        return False
+    if v != t._version:
+        raise RuntimeError("ag2video_amd.ops: a split-word tensor was modified in place after it was written (shape %s): it has a second "
+                           "consumer or an in-place update, and split words cannot be summed as floats" % (tuple(t.shape),))
+    return True
 
 
 def mark_split(t):
-    t._ag2v_split = True
+    t._ag2v_split = t._version
     return t
+
+
+class _DySplitOffer(object):
+    """`t._ag2v_dy_split_ok` on an operator output t: the producer's backward accepts d(t) as split words.  The producing autograd
+    node keeps the same object (`_ag2v_offers[output_nr]`), so its backward knows whether a consumer took the offer -- and then
+    insists on receiving that consumer's split-word tensor (anything else means t had a second consumer)."""
+    __slots__ = ('taken',)
+
+    def __init__(self):
+        self.taken = False
+
+
+def _offer_dy_split(t):
+    offer = _DySplitOffer()
+    t._ag2v_dy_split_ok = offer
+    node = t.grad_fn
+    if node is not None:
+        offers = getattr(node, '_ag2v_offers', None)
+        if offers is None:
+            offers = node._ag2v_offers = {}
+        offers[t.output_nr] = offer
+    return t
+
+
+def _take_dy_split(*ts):
+    """Consumer side, all or nothing: True when every tensor of ts offers split-word gradients; the offers are then TAKEN (the
+    consumer's backward must return split words for each).  A tensor whose offer was taken before has two consumers: raises."""
+    offers = [getattr(t, '_ag2v_dy_split_ok', None) for t in ts]
+    if not offers or not all(isinstance(o, _DySplitOffer) for o in offers):
+        return False
+    for o, t in zip(offers, ts):
+        if o.taken:
+            raise RuntimeError("ag2video_amd.ops: the gradient of a tensor (shape %s) was promised to one consumer as split words and a "
+                               "second consumer reads the same tensor" % (tuple(t.shape),))
+    for o in offers:
+        o.taken = True
+    return True
+
+
+def _check_taken_offer(ctx, output_nr, dy, what):
+    """Producer side (backward): a taken offer's gradient must be the taker's split-word tensor."""
+    offers = getattr(ctx, '_ag2v_offers', None)
+    o = offers.get(output_nr) if offers else None
+    if o is not None and o.taken and (dy is None or not is_split(dy)):
+        raise RuntimeError("%s backward: the gradient of output %d was promised as split words and arrived as %s: the output has a "
+                           "second consumer (autograd summed split words with floats)" % (what, output_nr, 'None' if dy is None else 'fp32'))
+
+
+def _attach_channel_sums(g, sums):
+    g._ag2v_channel_sums = (sums, g._version)
+    return g
+
+
+def _channel_sums_of(g):
+    """The per-channel sums a kernel attached to the gradient tensor g, or None (never attached, or g was modified since)."""
+    rec = getattr(g, '_ag2v_channel_sums', None)
+    if rec is None or rec[1] != g._version:
+        return None
+    return rec[0]
 
 
 def conv_split_dy_ok(x_shape, w_shape, stride, pad):
@@ -683,6 +755,9 @@ class _ConvSharedInput(torch.autograd.Function):
         grads = []
         live = []                       # (weight, masked dy, index) of the branches that received a gradient
         # gradients written as split words by the consumers' data-gradient epilogues (ops.conv2d: dx_split): all branches or none
+        for i_, d_ in enumerate(dys):
+            if d_ is not None:
+                _check_taken_offer(ctx, i_, d_, "conv2d_shared_input")
         dsp = [is_split(d) for d in dys if d is not None]
         dys_split = bool(dsp) and all(dsp)
         if any(dsp) and (not dys_split or (relu and not grad_premasked)):
@@ -757,7 +832,8 @@ def conv2d_shared_input(x, weights, biases, stride=1, pad=0, relu=False, grad_pr
     if (grad_split and relu and grad_premasked and torch.is_grad_enabled() and os.environ.get('AG2V_NO_SPLIT_DACTV') is None
             and conv_split_dy_ok(x.shape, (sum(int(w.shape[0]) for w in weights),) + tuple(weights[0].shape[1:]), stride, pad)):
         for o in outs:
-            o._ag2v_dy_split_ok = True      # the consumers' data gradients may hand d(out) back as split words (all of them or none)
+            if o.grad_fn is not None:
+                _offer_dy_split(o)          # the consumers' data gradients may hand d(out) back as split words (all of them or none)
     return outs
 
 
@@ -1061,7 +1137,7 @@ class _NormAct(torch.autograd.Function):
             # the sums were all-reduced for the statistics' sake; the bias gradient must stay per rank -> not offered)
             if not sync_world:
                 tot = sums.sum(dim=0) if G > 1 else sums[0]
-                dgb._ag2v_channel_sums = torch.cat([tot[:, 3], tot[:, 2]])
+                _attach_channel_sums(dgb, torch.cat([tot[:, 3], tot[:, 2]]))
                 if ctx.dgb_split:
                     mark_split(dgb)
             return (None, dx, dgb, None) + none[:9]
@@ -1207,8 +1283,11 @@ def spade_norm(x, gamma, beta, running_mean, running_var, training=True, momentu
 def spade_norm_fused(x, gb, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0, groups=1, out_split=False):
     """spade_norm with gamma = gb[:, :C] and beta = gb[:, C:] read in place from the [N, 2C, H, W] output of one convolution
     (and their gradients written in place into one [N, 2C, H, W] tensor)."""
+    from . import distributed as D
+    # (synchronised statistics: the backward writes fp32 gradients -- the offer is left alone)
+    take = bool(training) and not D.sync_bn() and gb.requires_grad and _take_dy_split(gb)
     y = _NormAct.apply(2, x, gb, None, running_mean, running_var, bool(training), float(momentum), float(eps),
-                       float(slope), int(groups), bool(out_split), bool(getattr(gb, '_ag2v_dy_split_ok', False)))
+                       float(slope), int(groups), bool(out_split), take)
     return mark_split(y) if out_split else y
 
 
@@ -1276,8 +1355,8 @@ class _SpadePair(torch.autograd.Function):
                 up, Ng, float(slope0), float(slope1), _ptr(ws), (1 if ctx.dgb_split else 0) | (2 if ctx.gcompact else 0), _stream(),
                 shape=(N, C, H * W, up))
         tot = sums.sum(dim=0) if G > 1 else sums[0]
-        dgb0._ag2v_channel_sums = torch.cat([tot[:, 3], tot[:, 2]])      # bias gradients of the two gamma | beta convolutions
-        dgb1._ag2v_channel_sums = torch.cat([tot[:, 7], tot[:, 6]])
+        _attach_channel_sums(dgb0, torch.cat([tot[:, 3], tot[:, 2]]))      # bias gradients of the two gamma | beta convolutions
+        _attach_channel_sums(dgb1, torch.cat([tot[:, 7], tot[:, 6]]))
         if ctx.dgb_split:
             mark_split(dgb0); mark_split(dgb1)
         return (dxs, dgb0, dgb1) + (None,) * 13
@@ -1286,7 +1365,7 @@ class _SpadePair(torch.autograd.Function):
 def spade_pair(xs, gb0, gb1, rm0, rv0, rm1, rv1, up=1, momentum=0.1, eps=1e-5, slope0=1.0, slope1=1.0, groups=1, out_split=(False, False)):
     """Two SPADE modulations of one input (shared batch statistics; both running-stat pairs updated), the input optionally taken
     before its 2x nearest upsampling (up = 2).  Training mode, batch statistics; requires spade_pair_supported(H, W, up)."""
-    split = bool(getattr(gb0, '_ag2v_dy_split_ok', False)) and bool(getattr(gb1, '_ag2v_dy_split_ok', False))
+    split = gb0.requires_grad and gb1.requires_grad and _take_dy_split(gb0, gb1)
     y0, y1 = _SpadePair.apply(xs, gb0, gb1, rm0, rv0, rm1, rv1, int(up), float(momentum), float(eps), float(slope0), float(slope1),
                               int(groups), split, bool(out_split[0]), bool(out_split[1]))
     if out_split[0]:

@@ -1303,3 +1303,46 @@ def test_lean_tape_train_step_is_bit_identical(device):
     for a, b in zip(o0, o1):
         assert torch.equal(a, b)
     assert torch.equal(gG0, gG1) and torch.equal(gD0, gD1)
+
+
+# ------------------------------------------------------------------------------------------------ single-consumer enforcement
+def test_split_word_side_channels_refuse_a_second_consumer(device):
+    """The split-word hand-overs assume ONE consumer per tensor (autograd would add a second gradient contribution to split words as
+    if they were floats).  The assumption is enforced: a second ops consumer of a tensor whose gradient was promised as
+    split words raises in the forward pass; a second torch consumer makes the producer's backward raise; a split-word tensor
+    modified in place raises at its next reader; channel sums attached to a gradient are void once it was modified."""
+    from ag2video_amd import ops
+    torch.manual_seed(3)
+    N, Cn, Ch, H, W = 4, 64, 128, 32, 32
+    actv = torch.relu(torch.randn(N, Ch, H, W, device=device)).requires_grad_(True)
+    x = torch.randn(N, Cn, H, W, device=device, requires_grad=True)
+    w = (torch.randn(2 * Cn, Ch, 3, 3, device=device) * 0.03).requires_grad_(True)
+    b = (torch.randn(2 * Cn, device=device) * 0.1).requires_grad_(True)
+
+    def bufs():
+        return torch.zeros(Cn, device=device), torch.ones(Cn, device=device)
+    with ops.conv_precision('bf16x3'), ops.bf16x3_min_rows(32), ops.frame_groups(2):
+        # (1) two modulations read the same gamma | beta tensor
+        gb = ops.conv2d(actv, w, b, 1, 1, relu_input=True)
+        assert isinstance(getattr(gb, '_ag2v_dy_split_ok', None), ops._DySplitOffer)
+        y = ops.spade_norm_fused(x, gb, *bufs(), True, 0.1, 1e-5, 0.2, groups=2)
+        with pytest.raises(RuntimeError, match='second consumer'):
+            ops.spade_norm_fused(x, gb, *bufs(), True, 0.1, 1e-5, 0.2, groups=2)
+        y.sum().backward()          # the first consumer alone is fine
+        # (2) a modulation (takes the offer) and a plain torch consumer: autograd sums split words with floats
+        gb = ops.conv2d(actv, w, b, 1, 1, relu_input=True)
+        y = ops.spade_norm_fused(x, gb, *bufs(), True, 0.1, 1e-5, 0.2, groups=2)
+        with pytest.raises(RuntimeError, match='second consumer|modified in place'):
+            (y.sum() + gb.sum()).backward()
+    # (3) in-place update of a split-word tensor
+    t = ops.mark_split(torch.zeros(8, device=device))
+    assert ops.is_split(t)
+    t.add_(1.0)
+    with pytest.raises(RuntimeError, match='modified in place'):
+        ops.is_split(t)
+    # (4) channel sums follow the tensor's version
+    g = torch.ones(2, 3, 4, 4, device=device)
+    ops._attach_channel_sums(g, torch.full((3,), 32.0, device=device))
+    assert ops._channel_sums_of(g) is not None
+    g.mul_(2.0)
+    assert ops._channel_sums_of(g) is None
