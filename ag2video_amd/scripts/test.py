@@ -47,25 +47,45 @@ def _swap(boxes, rng):
     return [[i, 5, i, -0.3, 1.3, float(ti[0]), float(ti[1])], [j, 2, j, -0.3, 1.3, float(tj[0]), float(tj[1])]]
 
 
-def scripted_edits(dataset, objs, boxes, rng):
+def scripted_edits(dataset, objs, boxes, rng, actions=None, vocab=None):
     """-> {edit name: {'now' | 'before' | 'after': actions tensor [1, A, 7]}}: the edit itself and its two re-timed variants
-    (scripts/test.py:228-262: t1/t2 = (0, 3) "before", (-2, 1) "after"; converge has its own variants)."""
+    (scripts/test.py:228-262: t1/t2 = (0, 3) "before", (-2, 1) "after"; converge has its own variants).
+    * Something-Else: ``down_left`` / ``right_up`` are skipped when the first object of the first frame sits where the move would
+      leave the image (x < 0.35 or y > 0.65, resp. x > 0.65 or y < 0.35: scripts/test.py:216-221).
+    * ``actions`` (the clip's own collated action rows) adds the reference's per-clip "initial action" edit (scripts/test.py:198-214):
+      one randomly chosen action of the clip, named by the vocabulary, re-timed to (0, 1.1) -- CATER keeps only that row,
+      Something-Else re-times all rows."""
     def T(rows):
         return torch.tensor(rows, dtype=torch.float32).unsqueeze(0)
 
     def retimed(rows, t1, t2):
         return [[r[0], r[1], r[2], t1, t2, r[5], r[6]] for r in rows]
+
+    def triple(rows):
+        return {'now': T(rows), 'before': T(retimed(rows, 0.0, 3.0)), 'after': T(retimed(rows, -2.0, 1.0))}
     out = {}
     if dataset == 'smth_else':
+        first = boxes[0, 0, 0].detach().cpu().numpy()
         for name, rows in _SMTH_EDITS.items():
-            out[name] = {'now': T(rows), 'before': T(retimed(rows, 0.0, 3.0)), 'after': T(retimed(rows, -2.0, 1.0))}
-        return out
-    n = objs.shape[1] - 1
-    if n >= 2:
-        out['converge'] = {'now': T(_converge(n, lambda s: s, 1.05)), 'before': T(_converge(n, lambda s: -s, 2.0)),
-                           'after': T(_converge(n, lambda s: -s - 1.0, 1.05))}
-        rows = _swap(boxes.cpu().numpy(), rng)
-        out['swap'] = {'now': T(rows), 'before': T(retimed(rows, 0.0, 3.0)), 'after': T(retimed(rows, -2.0, 1.0))}
+            if name == 'down_left' and (first[0] < 0.35 or first[1] > 0.65):
+                continue
+            if name == 'right_up' and (first[0] > 0.65 or first[1] < 0.35):
+                continue
+            out[name] = triple(rows)
+    else:
+        n = objs.shape[1] - 1
+        if n >= 2:
+            out['converge'] = {'now': T(_converge(n, lambda s: s, 1.05)), 'before': T(_converge(n, lambda s: -s, 2.0)),
+                               'after': T(_converge(n, lambda s: -s - 1.0, 1.05))}
+            out['swap'] = triple(_swap(boxes.cpu().numpy(), rng))
+    if actions is not None and actions.numel() and vocab is not None:
+        rows = actions[0].detach().cpu().numpy().tolist()
+        pick = int(rng.permutation(len(rows))[0])
+        aid = int(rows[pick][1])
+        names = vocab['action_idx_to_name']
+        name = names[aid] if aid in names else names[str(aid)]          # (a vocabulary read from JSON has string keys: test.py:203-205)
+        chosen = retimed(rows[pick:pick + 1] if dataset != 'smth_else' else rows, 0.0, 1.1)
+        out.setdefault(str(name), triple(chosen))
     return out
 
 
@@ -81,6 +101,9 @@ def build_parser():
     p.add_argument('--num_clips', type=int, default=4)
     p.add_argument('--frames', type=int, default=None)
     p.add_argument('--seed', type=int, default=4321)
+    p.add_argument('--trust_checkpoint', type=int, default=0,
+                   help='1: unpickle arbitrary objects from the checkpoint (torch.load(weights_only=False), as the reference does). '
+                        'Checkpoints written by scripts.train hold tensors and plain containers only and load without it.')
     return p
 
 
@@ -91,13 +114,15 @@ def main(argv=None):
     train_args.update(gpu_ids=[args.gpu_ids], batch_size=1, loader_num_workers=0, frames_per_action_graph=1)   # test.py:174-178
     opt = Namespace(**train_args)
     opt.image_size = tuple(opt.image_size)
-    opt.vocab = smth_vocab() if opt.dataset == 'smth_else' else cater_vocab()
-    init_args(opt)
     if not torch.cuda.is_available():
         raise RuntimeError("ag2video_amd.scripts.test needs an MI355X: there is no CPU fallback")
     device = torch.device('cuda', args.gpu_ids)
     torch.cuda.set_device(device)
-    ckpt = torch.load(args.checkpoint, map_location=device, weights_only=False)
+    ckpt = torch.load(args.checkpoint, map_location=device, weights_only=not args.trust_checkpoint)
+    # the vocabulary the model was trained with travels in the checkpoint (scripts/train.py:528-543); the defaults only stand in for
+    # a checkpoint without one
+    opt.vocab = ckpt.get('vocab') or (smth_vocab() if opt.dataset == 'smth_else' else cater_vocab())
+    init_args(opt)
     model = AG2VideoModel(opt, device)
     model.load_state_dict(ckpt['model_state'], strict=True)
     model.eval()
@@ -119,11 +144,15 @@ def main(argv=None):
         clip = make_clip_batch(opt.vocab, 1, frames, opt.image_size, seed=args.seed + c, min_objs=lo, max_objs=hi)
         vids, objs, boxes, triplets, actions, vid_id = batch_to(clip, device)
         if args.save_actions:
-            for name, variants in scripted_edits(opt.dataset, objs, boxes, rng).items():
+            for name, variants in scripted_edits(opt.dataset, objs, boxes, rng, actions, opt.vocab).items():
                 for when, acts in variants.items():
                     sub = 'action_accuracy/%s' % name if when == 'now' else 'action_timing/%s/%s' % (name, when)
                     dump(os.path.join(out_root, sub, vid_id[0] + '.npz'), run(vids, objs, triplets, acts, boxes, False), vids)
                     n_edits += 1
+                # the ground-truth clip beside every edit (scripts/test.py:259-261)
+                gt = os.path.join(out_root, 'gt_action', name, vid_id[0] + '.npz')
+                os.makedirs(os.path.dirname(gt), exist_ok=True)
+                np.savez(gt, imgs_gt=vids[0].cpu().numpy())
         if args.save_test:
             dump(os.path.join(out_root, 'test', vid_id[0] + '.npz'), run(vids, objs, triplets, actions, boxes, bool(args.use_test)), vids)
     return {'clips': args.num_clips, 'edits': n_edits, 'output': out_root}

@@ -37,7 +37,7 @@ def save_checkpoint(args, path, ts, epoch, t):
 
 def restore_checkpoint(args, ts, path):
     """scripts/train.py:27-57 (optimizer state is mapped to the device by load_state_dict)."""
-    ckpt = torch.load(path, map_location=ts.device, weights_only=False)
+    ckpt = torch.load(path, map_location=ts.device, weights_only=True)     # tensors and plain containers only (save_checkpoint)
     ts.model.load_state_dict(ckpt['model_state'])
     ts.gans_model.load_state_dict(ckpt['gans_model_state'])
     ts.discriminator.img_discriminator.load_state_dict(ckpt['d_img_state'])

@@ -144,3 +144,39 @@ def test_layout_terms_shared_once_per_step_and_invalidated():
         with torch.no_grad():
             ts.gans_model(batch, mo, mode="compute_generator_loss")
         assert loss_model._terms_cache is None and calls[0] == 1
+
+
+def test_inference_driver_scripted_edits():
+    """ag2video_amd.scripts.test.scripted_edits against the reference's loop (scripts/test.py:198-262): the per-clip "initial action"
+    (one action of the clip, named by the vocabulary, re-timed to (0, 1.1); CATER keeps that row only, Something-Else all rows),
+    the position-based skips of down_left / right_up, and the (0, 3) / (-2, 1) re-timings."""
+    import numpy as np
+    from ag2video_amd.data.vocab import cater_vocab, smth_vocab
+    from ag2video_amd.scripts.test import scripted_edits
+    rng = np.random.RandomState(0)
+    objs = torch.zeros(1, 5, 3, dtype=torch.long)
+    boxes = torch.rand(1, 4, 5, 4)
+    acts = torch.tensor([[[0, 2, 0, 0.1, 0.6, 0.3, 0.4], [1, 3, 1, 0.2, 0.9, 0.5, 0.5]]])
+    v = cater_vocab()
+    ed = scripted_edits('cater', objs, boxes, rng, acts, v)
+    assert {'converge', 'swap'} <= set(ed) and len(ed) == 3
+    name = [k for k in ed if k not in ('converge', 'swap')][0]
+    assert name in (v['action_idx_to_name'][2], v['action_idx_to_name'][3])
+    row = ed[name]['now']
+    assert tuple(row.shape) == (1, 1, 7) and row[0, 0, 3] == 0.0 and abs(float(row[0, 0, 4]) - 1.1) < 1e-6
+    assert int(row[0, 0, 1]) == v['action_name_to_idx'][name]
+    assert ed[name]['before'][0, 0, 3:5].tolist() == [0.0, 3.0] and ed[name]['after'][0, 0, 3:5].tolist() == [-2.0, 1.0]
+    assert ed['swap']['before'][0, :, 3:5].tolist() == [[0.0, 3.0]] * 2
+    # Something-Else: the first object's first-frame position decides which diagonal moves are offered
+    sv = smth_vocab()
+    b = torch.full((1, 4, 3, 4), 0.5)
+    assert {'down_left', 'right_up', 'up', 'down', 'left', 'right'} <= set(scripted_edits('smth_else', objs[:, :3], b, rng, acts, sv))
+    b[0, 0, 0, 0] = 0.2                                     # too far left for down_left
+    e2 = scripted_edits('smth_else', objs[:, :3], b, rng, acts, sv)
+    assert 'down_left' not in e2 and 'right_up' in e2
+    b[0, 0, 0, 0], b[0, 0, 0, 1] = 0.8, 0.5                 # too far right for right_up
+    e3 = scripted_edits('smth_else', objs[:, :3], b, rng, acts, sv)
+    assert 'right_up' not in e3 and 'down_left' in e3
+    init = [k for k in e3 if k not in ('up', 'down', 'left', 'right', 'down_left', 'right_up')]
+    assert len(init) == 1 and tuple(e3[init[0]]['now'].shape) == (1, 2, 7)      # every row of the clip, re-timed
+    assert e3[init[0]]['now'][0, :, 4].tolist() == pytest.approx([1.1, 1.1])

@@ -200,8 +200,12 @@ def test_inference_script_runs(device, tmp_path):
     out_dir = os.path.join(str(tmp_path), 'out')
     res = T.main(['--checkpoint', os.path.join(run_dir, 'latest.pt'), '--gpu_ids', '0', '--output_dir', out_dir, '--num_clips', '1',
                   '--frames', '4'])
-    assert res['clips'] == 1 and res['edits'] >= 3
+    assert res['clips'] == 1 and res['edits'] == 9          # converge, swap and the clip's own "initial action", three timings each
     files = [os.path.join(dp, f) for dp, _, fs in os.walk(out_dir) for f in fs]
-    assert any(f.endswith('.npz') for f in files)
-    z = np.load([f for f in files if f.endswith('.npz')][0])
+    acc = [f for f in files if '/action_accuracy/' in f and f.endswith('.npz')]
+    assert len(acc) == 3 and len([f for f in files if '/action_timing/' in f]) == 6
+    gts = [f for f in files if '/gt_action/' in f]
+    assert sorted(os.path.basename(os.path.dirname(f)) for f in gts) == sorted(os.path.basename(os.path.dirname(f)) for f in acc)
+    assert np.load(gts[0])['imgs_gt'].shape == (4, 3, 64, 64)
+    z = np.load(acc[0])
     assert z['imgs_pred'].shape == (4, 3, 64, 64) and np.isfinite(z['imgs_pred']).all()
