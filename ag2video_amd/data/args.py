@@ -102,8 +102,9 @@ def build_parser():
     a('--synthetic_objects', default='5,10', type=int_tuple, help='min,max real objects per clip')
     a('--seed', default=1234, type=int)
     a('--sync_bn', default=0, type=int, help='1: batch-norm statistics over the global batch (all ranks) with the reference\'s multi-device formula')
-    a('--data_root', default=None, type=str, help='CATER directory (scenes/*.json, videos/<id>/*.png); default: synthetic clips')
-    a('--train_list', default=None, type=str)
+    a('--data_root', default=None, type=str, help='CATER directory (scenes/*.json, videos/<id>/*.png) or, with --dataset smth_else, a Something-Else '
+      'directory (offical_release_boxes/{objs_mapping.json, boxes_by_video_id/<id>/boxes.pkl}, frames/...); default: synthetic clips')
+    a('--train_list', default=None, type=str, help='CATER: split list (default <data_root>/lists/train.txt); smth_else: label table (default <data_root>/train.csv)')
     a('--data_nframes', default=301, type=int, help='frames per video in --data_root')
     a('--vgg_weights', default=None, type=str, help='torchvision vgg19 state dict (.pth) for the perceptual loss')
     a('--temporal_D', default=0, type=int, help='1: add the temporal multiscale PatchGAN (reference discriminator.py:16-87: the frames of a '

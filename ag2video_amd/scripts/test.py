@@ -83,7 +83,8 @@ def scripted_edits(dataset, objs, boxes, rng, actions=None, vocab=None):
         pick = int(rng.permutation(len(rows))[0])
         aid = int(rows[pick][1])
         names = vocab['action_idx_to_name']
-        name = names[aid] if aid in names else names[str(aid)]          # (a vocabulary read from JSON has string keys: test.py:203-205)
+        # (Something-Else: a list indexed by the action id; a CATER vocabulary read from JSON has string keys: test.py:203-205)
+        name = names[aid] if isinstance(names, (list, tuple)) or aid in names else names[str(aid)]
         chosen = retimed(rows[pick:pick + 1] if dataset != 'smth_else' else rows, 0.0, 1.1)
         out.setdefault(str(name), triple(chosen))
     return out

@@ -11,6 +11,7 @@ import json
 import logging
 import os
 
+import numpy as np
 import torch
 
 from .. import distributed as D
@@ -51,7 +52,11 @@ def restore_checkpoint(args, ts, path):
 def main(args):
     logger = logging.getLogger(__name__)
     rank, world, local = D.init_from_env()
-    args.vocab = smth_vocab() if args.dataset == 'smth_else' else cater_vocab()
+    if args.dataset == 'smth_else' and args.data_root:
+        from ..data.smth import dataset_vocab            # object names come from the dataset's own mapping file (data/smth.py:85-104)
+        args.vocab = dataset_vocab(args.data_root)
+    else:
+        args.vocab = smth_vocab() if args.dataset == 'smth_else' else cater_vocab()
     init_args(args)
     if not torch.cuda.is_available():
         raise RuntimeError("ag2video_amd.scripts.train needs an MI355X: there is no CPU fallback")
@@ -73,9 +78,18 @@ def main(args):
     # seeded synthetic clips of the same tensor contract.  Every rank draws its own shard (DataLoader shuffling is per process).
     short_it = long_it = None
     if args.data_root:
-        from ..data.cater import build_loaders
         torch.manual_seed(args.seed + rank)
-        short_loader, long_loader = build_loaders(args, args.vocab, nframes=args.data_nframes)
+        if args.dataset == 'smth_else':
+            # Something-Else: label table + box tracks + frames (data/smth.py); the spatial relations and the training window are drawn
+            # with Python's / numpy's global generators, as in the reference
+            import random
+            from ..data.smth import build_loaders as build_smth_loaders
+            random.seed(args.seed + rank)
+            np.random.seed((args.seed + rank) % (2 ** 32))
+            short_loader, long_loader = build_smth_loaders(args, args.vocab)
+        else:
+            from ..data.cater import build_loaders
+            short_loader, long_loader = build_loaders(args, args.vocab, nframes=args.data_nframes)
 
         def cycle(loader, name):
             while True:

@@ -147,3 +147,68 @@ def test_perceptual_loss_needs_weights_or_an_explicit_opt_in():
     lm = LossModel(make_opt(cater_vocab(), flags + ['--vgg_random_init']), discriminator=None)
     assert hasattr(lm, 'criterionVGG') and lm.vgg_weights_loaded is False
     assert not hasattr(LossModel(make_opt(cater_vocab(), flags + ['--no_vgg_loss']), discriminator=None), 'criterionVGG')
+
+
+def test_something_else_reader_matches_reference(tmp_path):
+    """ag2video_amd.data.smth against the reference's SmthElseDataset on the same miniature dataset (tests/golden/smth.npz, generator
+    tests/golden/make_golden_smth.py): vocabulary, label filters, unique frames, test / train windows, box tracks, hand-chain
+    actions, spatial triplets (Python ``random``) and whole items, bit for bit; frames by the CATER reader's loader; a batch through
+    collate_fn."""
+    import pickle
+    import random
+    import sys
+    sys.path.insert(0, os.path.join(HERE, 'golden'))
+    from make_golden_smth import SPAN, build_fixture
+    from ag2video_amd.data import smth as S
+    from ag2video_amd.data.cater import collate_fn, load_frames
+    gold = np.load(os.path.join(HERE, 'golden', 'smth.npz'), allow_pickle=False)
+    root, labels = build_fixture(str(tmp_path))
+    ds = S.SmthElseScenes(root, labels, image_size=(32, 32), frames_per_action=SPAN, initial_frames_per_sample=SPAN)
+    ref_vocab = json.loads(str(gold['vocab']))
+    mine = json.loads(json.dumps({k: ds.vocab[k] for k in ref_vocab}, sort_keys=True))
+    assert mine == ref_vocab
+    assert [r['id'] for r in ds.rows] == gold['kept_ids'].tolist() and len(ds) == 6
+    for k, row in enumerate(ds.rows):
+        p = 'v%d.' % k
+        with open(os.path.join(root, 'offical_release_boxes', 'boxes_by_video_id', str(row['id']), 'boxes.pkl'), 'rb') as f:
+            track = S.unique_frames(pickle.load(f))
+        assert [e['name'] for e in track] == json.loads(str(gold[p + 'unique_names']))
+        n_inst = S.INSTANCES_PER_TEMPLATE[row['template']]
+        assert np.array_equal(np.array(S.action_window(track, n_inst, SPAN, True), np.float64), gold[p + 'window_test'])
+        np.random.seed(100 + k)
+        f1, f2, s, e = S.action_window(track, n_inst, SPAN, False)
+        assert np.array_equal(np.array([f1, f2, s, e], np.float64), gold[p + 'window_train'])
+        boxes, objs = S.track_boxes(track[f1:f2], (120, 90), n_inst, ds.objs_mapping, ds.vocab)
+        assert np.array_equal(boxes.numpy(), gold[p + 'boxes']) and np.array_equal(objs['object'].numpy(), gold[p + 'objs'])
+        acts = S.hand_chain_actions(objs['object'], ds.vocab, ds.vocab['action_name_to_idx'][row['template']], s, e)
+        assert np.array_equal(acts.numpy(), gold[p + 'actions'])
+        random.seed(200 + k)
+        assert np.array_equal(S.spatial_triplets(boxes, ds.vocab).numpy(), gold[p + 'triplets'])
+        for mode, is_test in (('train', False), ('test', True)):
+            ds.is_test = ds.is_val = is_test
+            np.random.seed(300 + k)
+            random.seed(400 + k)
+            vids, o, b, t, a, vid_id = ds[k]
+            assert vid_id == str(gold[p + mode + '.id'])
+            assert np.array_equal(o['object'].numpy(), gold[p + mode + '.objs']) and np.array_equal(b.numpy(), gold[p + mode + '.boxes'])
+            assert np.array_equal(t.numpy(), gold[p + mode + '.triplets']) and np.array_equal(a.numpy(), gold[p + mode + '.actions'])
+            assert tuple(vids.shape) == (int(gold[p + mode + '.n_frames']), 3, 32, 32) and vids.dtype == torch.float32
+        ds.is_test = ds.is_val = False
+    # the frames of an item are the window's frames through the CATER reader's loader (PIL bilinear resize, ImageNet mean / std)
+    np.random.seed(300)
+    random.seed(400)
+    vids, _, _, _, _, vid_id = ds[0]
+    f1 = int(vid_id.split('_')[1].split('-')[0])
+    paths = sorted(os.path.join(root, 'frames', e['name']) for e in ds.track(ds.rows[0]['id']))
+    assert torch.equal(vids, load_frames(paths[f1:f1 + SPAN], (32, 32)))
+    # a video whose hand never appears is skipped, and the batch still collates (dataset_params.py:8-104)
+    bad = ds.track(ds.rows[1]['id'])
+    for e in bad:
+        e['labels'] = [lab for lab in e['labels'] if lab['category'] != 'hand']
+        e['nr_instances'] = len(e['labels'])
+    with open(os.path.join(root, 'offical_release_boxes', 'boxes_by_video_id', str(ds.rows[1]['id']), 'boxes.pkl'), 'wb') as f:
+        pickle.dump(bad, f)
+    assert ds[1][0] is None
+    batch = collate_fn(ds.vocab, [ds[i] for i in range(len(ds))])
+    assert tuple(batch[0].shape) == (5, SPAN, 3, 32, 32) and batch[1].shape[0] == 5 and batch[1].shape[2] == 1
+    assert batch[2].shape[2] == 3 and (batch[2][:, :, -1] == -1).any()        # two-instance videos padded to the covering video's three

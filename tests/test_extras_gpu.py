@@ -189,3 +189,26 @@ def test_train_script_on_scene_files(device, tmp_path):
     T.main(args)
     ck = torch.load(os.path.join(out, 'latest.pt'), map_location='cpu', weights_only=False)
     assert ck['counters']['t'] == 2 and 'model_state' in ck and json.load(open(os.path.join(out, 'run_args.json')))['data_root'] == root
+
+
+def test_train_script_on_something_else_files(device, tmp_path):
+    """python -m ag2video_amd.scripts.train --dataset smth_else --data_root <Something-Else-format directory>: label table + box tracks +
+    frames -> ag2video_amd.data.smth loaders (vocabulary from the dataset's object mapping) -> collate_fn -> G/D/graph steps on the
+    GPU -> checkpoint carrying that vocabulary; the inference driver then runs its Something-Else edits from the checkpoint."""
+    from ag2video_amd.data import smth as S
+    from ag2video_amd.data.args import get_args
+    from ag2video_amd.scripts import test as TS
+    from ag2video_amd.scripts import train as T
+    root, labels = S.write_synthetic_dataset(os.path.join(str(tmp_path), 'smth'), n_videos=6, n_frames=20, frame_size=(64, 48), seed=2)
+    out = os.path.join(str(tmp_path), 'out')
+    args = get_args(['--dataset', 'smth_else', '--data_root', root, '--train_list', labels, '--image_size', '64,64', '--batch_size', '2',
+                     '--ngf', '8', '--ndf', '8', '--nff', '8', '--gconv_hidden_dim', '64', '--no_vgg_loss', '--num_iterations', '2',
+                     '--frames_per_action', '4', '--frames_per_action_graph', '2', '--loader_num_workers', '0', '--output_dir', out,
+                     '--checkpoint_every', '100', '--print_every', '1'])
+    T.main(args)
+    ck = torch.load(os.path.join(out, 'latest.pt'), map_location='cpu', weights_only=True)
+    assert ck['counters']['t'] == 2 and ck['vocab']['object_idx_to_name'][0] == '__image__' and 'hand' in ck['vocab']['object_name_to_idx']
+    assert ck['vocab']['action_idx_to_name'][5].startswith('Covering')
+    res = TS.main(['--checkpoint', os.path.join(out, 'latest.pt'), '--gpu_ids', '0', '--output_dir', os.path.join(str(tmp_path), 'res'),
+                   '--num_clips', '1', '--frames', '4'])
+    assert res['clips'] == 1 and res['edits'] >= 3 * 5
