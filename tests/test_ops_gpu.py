@@ -1272,9 +1272,11 @@ def test_lean_tape_batchnorm_recomputes_the_layout_convolution(device):
     assert tape[0] - tape[1] >= NB * Kc * H * W * 4 - (1 << 20), tape
 
 
-def test_lean_tape_train_step_is_bit_identical(device):
+@pytest.mark.parametrize("extra", [[], ['--sync_bn', '1']], ids=['default', 'sync_bn'])
+def test_lean_tape_train_step_is_bit_identical(extra, precision, device):
     """One toy training iteration with --lean_tape 1 against the default tape, both with deterministic reductions: outputs, losses and
-    both flat gradients are bit-identical (the lean tape recomputes or copies, it does not re-associate)."""
+    both flat gradients are bit-identical (the lean tape recomputes or copies, it does not re-associate).  Both arithmetic modes; with
+    --sync_bn 1 the modulations take the two-pass backward (ag2v_norm_bwd_reduce_g / _apply_g, mode 3)."""
     from ag2video_amd import ops
     from ag2video_amd.data.args import make_opt
     from ag2video_amd.data.synthetic import make_clip_batch
@@ -1287,7 +1289,7 @@ def test_lean_tape_train_step_is_bit_identical(device):
         with ops.deterministic():
             for lean in (0, 1):
                 ops.set_lean_tape(False)
-                opt = make_opt(cater_vocab(), flags + ['--lean_tape', str(lean)])
+                opt = make_opt(cater_vocab(), flags + extra + ['--lean_tape', str(lean)])
                 ts = TrainStep(opt, device, weights_seed=5)
                 assert ops.lean_tape() == bool(lean)
                 clip = ts.to_device(make_clip_batch(opt.vocab, 2, 4, (64, 64), seed=11))
@@ -1298,6 +1300,8 @@ def test_lean_tape_train_step_is_bit_identical(device):
                 del ts
     finally:
         ops.set_lean_tape(False)
+        from ag2video_amd import distributed as D
+        D.set_sync_bn(0)
     (o0, l0, gG0, gD0), (o1, l1, gG1, gD1) = res
     assert l0 == l1, (l0, l1)
     for a, b in zip(o0, o1):
