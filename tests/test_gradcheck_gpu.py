@@ -11,8 +11,9 @@ layer whose gradient is off by 1 % (a dropped term, a wrong scale, a mask applie
 graph nets, embeddings) are held to 2e-2 (measured 1.3e-2 ... 1.5e-2), limited by the roughness of an fp32 forward pass as a function
 of parameters that every activation depends on.  The functional is a fixed random linear form of the step's outputs accumulated in
 fp64 -- the step's own L1 / hinge losses put a kink wherever two features cross, which a finite difference smears over (with them the
-same check reads 2e-2 ... 4e-1); the loss kernels have their own tests (tests/test_ops_gpu.py::test_losses).  The run is
-deterministic: it reproduces bit for bit.
+same check reads 2e-2 ... 4e-1); the loss kernels have their own tests (tests/test_ops_gpu.py::test_losses).  Two widths: the toy
+networks (16-channel base) and the default ones (c1: 64-channel base, 512-wide graph nets -- the 256 x 128 / 128 x 256 tiles,
+the graph-net programs at their real shapes).  The run is deterministic: it reproduces bit for bit.
 
 What makes the two sides the same function:
 * deterministic reductions and the exact-fp32 convolution kernels (no split-K order noise in L);
@@ -64,8 +65,12 @@ def _resolve(named, want):
     return hits[0] if hits else (None, None)
 
 
+FLAGS_DEFAULT_WIDTH = ['--no_vgg_loss', '--image_size', '64,64', '--batch_size', '1', '--gpu_ids', '0']      # c1: ngf = ndf = 64, 512-wide graph nets
+
+
+@pytest.mark.parametrize("width", ['toy', 'default'])
 @pytest.mark.parametrize("prec", ['fp32', 'bf16x3'])
-def test_loss_gradients_match_finite_differences_layer_by_layer(prec, device, monkeypatch):
+def test_loss_gradients_match_finite_differences_layer_by_layer(prec, width, device, monkeypatch):
     from ag2video_amd import ops
     from ag2video_amd.data.args import make_opt
     from ag2video_amd.data.synthetic import make_clip_batch
@@ -77,9 +82,9 @@ def test_loss_gradients_match_finite_differences_layer_by_layer(prec, device, mo
     ops.set_conv_precision(prec)
     try:
         with ops.deterministic():
-            opt = make_opt(cater_vocab(), FLAGS)
+            opt = make_opt(cater_vocab(), FLAGS if width == 'toy' else FLAGS_DEFAULT_WIDTH)
             ts = TrainStep(opt, device, weights_seed=5)
-            clip = ts.to_device(make_clip_batch(opt.vocab, 2, 4, (64, 64), seed=11, max_objs=6))
+            clip = ts.to_device(make_clip_batch(opt.vocab, opt.batch_size, 4, (64, 64), seed=11, max_objs=6))
             for _ in range(int(os.environ.get('AG2V_GRADCHECK_WARM', '60'))):      # power iterations to their fixed points (no updates)
                 ts.gd_step(clip, apply_updates=False)
             bufs = [(b, b.detach().clone()) for m in (ts.model, ts.discriminator) for b in m.buffers()]
