@@ -331,8 +331,11 @@ def test_c2_step_runs_and_is_finite(device):
     _finite_step('c2', device)
 
 
-def test_c5_shaped_step_runs_and_is_finite(device):
-    """c5-shaped: Something-Else vocabulary (one attribute => semantic_nc 128, 2-3 objects incl. the hand), 224x224, 16 frames;
-    per-GPU batch 2 keeps the test short (bench.py --config c5 runs batch 8)."""
-    opt = _finite_step('c5', device, batch=2)
+@pytest.mark.parametrize("batch", [2, 8], ids=['batch2', 'batch8_as_benched'])
+def test_c5_shaped_step_runs_and_is_finite(batch, device):
+    """c5-shaped: Something-Else vocabulary (one attribute => semantic_nc 128, 2-3 objects incl. the hand), 224x224, 16 frames, at a
+    short per-GPU batch and at the batch bench.py --config c5 runs (8: 120 frame passes per step, ~90 GB)."""
+    torch.cuda.empty_cache()
+    opt = _finite_step('c5', device, batch=batch)
     assert opt.semantic_nc == 128 and tuple(opt.image_size) == (224, 224)
+    torch.cuda.empty_cache()
