@@ -98,6 +98,7 @@ _SIGS = {
     'ag2v_spectral_sigmas_multi': (c_int, [_P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
     'ag2v_graph_op_bytes': (c_size_t, []),
     'ag2v_graph_program_grid': (c_int, []),
+    'ag2v_graph_program_max_edges': (c_int, []),
     'ag2v_graph_program_run': (c_int, [_P, c_int, _P, c_int, _P]),
     'ag2v_sn_group_combine': (c_int, [_P, _P, _P, c_int, c_longlong, _P, c_int, _P, _P]),
     'ag2v_spectral_sigmas_bwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),

@@ -53,6 +53,7 @@ struct GOp {                // 192 bytes (ag2v_graph_op_bytes()); filled by the 
 };
 static_assert(sizeof(GOp) == 192, "GOp layout is part of the host interface");
 
+#define GP_MAX_EDGES 64              // edges per sample a POOL / GATHER_BWD operator can take (one 64-bit incidence mask per endpoint)
 #define GP_THREADS 1024
 #define GP_WAVES 16
 #define GP_SPIN_LIMIT (1u << 18)     // ~0.3 s per barrier: a grid that is not co-resident ends with the timeout flag set instead of hanging
@@ -186,16 +187,17 @@ __device__ __forceinline__ void op_cat(const GOp& o, long long gid, long long nt
     }
 }
 // pooled[bo, :Hd] = (sum over valid edges t of sample b with s(t) == bo of newt[t, :Hd] + ... o(t) == bo of newt[t, Hd + Dp:]) / count
-// T <= 32: the incidence of the sample's edges on this object is gathered into two bit masks first (independent index loads), then the
+// T <= GP_MAX_EDGES (64; the host checks ag2v_graph_program_max_edges() before it builds a program, a larger T takes the
+// per-operator path): the incidence of the sample's edges on this object is gathered into two bit masks first (independent index loads), then the
 // matching rows are summed (independent data loads) -- a loop of "load index, compare, load data" was a 17-deep dependent chain (51 us)
-__device__ __forceinline__ void edge_masks(const GOp& o, int b, int bo, bool use_valid, unsigned& ms, unsigned& mo) {
+__device__ __forceinline__ void edge_masks(const GOp& o, int b, int bo, bool use_valid, unsigned long long& ms, unsigned long long& mo) {
     ms = mo = 0;
 #pragma unroll 8
     for (int t = 0; t < o.T; ++t) {
         const int e = b * o.T + t;
         const bool v = !use_valid || o.valid[e] != 0;
-        ms |= (v && o.i0[e] == bo) ? (1u << t) : 0u;
-        mo |= (v && o.i1[e] == bo) ? (1u << t) : 0u;
+        ms |= (v && o.i0[e] == bo) ? (1ull << t) : 0ull;
+        mo |= (v && o.i1[e] == bo) ? (1ull << t) : 0ull;
     }
 }
 __device__ __forceinline__ void op_pool(const GOp& o, long long gid, long long nthreads) {
@@ -203,16 +205,16 @@ __device__ __forceinline__ void op_pool(const GOp& o, long long gid, long long n
     for (long long u = gid; u < (long long)o.M * H4; u += nthreads) {
         const int bo = (int)(u / H4), c = 4 * (int)(u - (long long)bo * H4);
         const int b = bo / o.O;
-        unsigned ms, mo;
+        unsigned long long ms, mo;
         edge_masks(o, b, bo, true, ms, mo);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 8
         for (int t = 0; t < o.T; ++t) {
             const float* rowp = o.a + (size_t)(b * o.T + t) * o.lda + c;
-            if ((ms >> t) & 1u) { const float4 v = ld4(rowp); acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
-            if ((mo >> t) & 1u) { const float4 v = ld4(rowp + Hd + Dp); acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+            if ((ms >> t) & 1ull) { const float4 v = ld4(rowp); acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+            if ((mo >> t) & 1ull) { const float4 v = ld4(rowp + Hd + Dp); acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
         }
-        const int cnt = __builtin_popcount(ms) + __builtin_popcount(mo);
+        const int cnt = __builtin_popcountll(ms) + __builtin_popcountll(mo);
         if (cnt > 0) { const float q = (float)cnt; acc.x /= q; acc.y /= q; acc.z /= q; acc.w /= q; }
         st_wt4(o.c + (size_t)bo * o.ldc + c, acc);
         if (c == 0) st_wt(const_cast<float*>(o.mask) + bo, (float)cnt);      // counts (read by POOL_BWD of the backward program)
@@ -242,14 +244,14 @@ __device__ __forceinline__ void op_gather_bwd(const GOp& o, long long gid, long 
     for (long long u = gid; u < (long long)o.M * D4; u += nthreads) {
         const int bo = (int)(u / D4), c = 4 * (int)(u - (long long)bo * D4);
         const int b = bo / o.O;
-        unsigned ms, mo;
+        unsigned long long ms, mo;
         edge_masks(o, b, bo, false, ms, mo);
         float4 acc = o.res ? ld4(o.res + (size_t)bo * o.ldr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 8
         for (int t = 0; t < o.T; ++t) {
             const float* rowp = o.a + (size_t)(b * o.T + t) * o.lda + c;
-            if ((ms >> t) & 1u) { const float4 v = ld4(rowp); acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
-            if ((mo >> t) & 1u) { const float4 v = ld4(rowp + Din + Dp); acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+            if ((ms >> t) & 1ull) { const float4 v = ld4(rowp); acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+            if ((mo >> t) & 1ull) { const float4 v = ld4(rowp + Din + Dp); acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
         }
         st_wt4(o.c + (size_t)bo * o.ldc + c, acc);
     }
@@ -319,13 +321,15 @@ extern "C" size_t ag2v_graph_op_bytes(void) { return sizeof(GOp); }
 // Largest grid whose workgroups are all resident on an otherwise idle device (one 1024-thread workgroup per CU, half the CUs:
 // leaves the barrier's polling traffic light and is plenty for <= 180 tiles per operator).
 extern "C" int ag2v_graph_program_grid(void) { return 128; }
+// Most edges per sample (GOp::T) the POOL / GATHER_BWD operators handle; the program builder refuses larger graphs (they run per operator).
+extern "C" int ag2v_graph_program_max_edges(void) { return GP_MAX_EDGES; }
 // Runs the program `ops` (device array of n_ops GOp records) with `grid` workgroups (<= ag2v_graph_program_grid()).  sync: two device
-// words {arrival counter, timeout flag}; the counter is zeroed here, the flag is left for the caller to read (non-zero: a grid barrier
-// gave up -- the workgroups were not co-resident -- and the results are invalid).
+// words {arrival counter, timeout flag}; BOTH are zeroed here, so that after the launch a non-zero flag belongs to THIS run (a grid
+// barrier gave up -- the workgroups were not co-resident -- and the results are invalid; the caller must read it before trusting them).
 extern "C" int ag2v_graph_program_run(const void* ops, int n_ops, unsigned* sync, int grid, void* stream) {
     if (!ops || !sync || n_ops <= 0 || grid <= 0 || grid > 256) return AG2V_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(sync, 0, sizeof(unsigned), st) != hipSuccess) return AG2V_EHIP;
+    if (hipMemsetAsync(sync, 0, 2 * sizeof(unsigned), st) != hipSuccess) return AG2V_EHIP;
     hipLaunchKernelGGL(graph_program_kernel, dim3(grid), dim3(GP_THREADS), 0, st, (const GOp*)ops, n_ops, sync);
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;

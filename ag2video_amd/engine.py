@@ -85,6 +85,14 @@ class TrainStep(object):
     def to_device(self, batch):
         return batch_to(batch, self.device)
 
+    def check_health(self):
+        """Raises RuntimeError when a graph-net program launched since the last call gave up at a grid barrier (results invalid).
+        Costs a wait for 4-byte copies that are complete by any host read of the step; scripts/train.py and bench.py also call it
+        once after their last step."""
+        if torch.device(self.device).type == 'cuda':
+            from . import graph_program
+            graph_program.check_timeouts()
+
     def gd_step(self, batch, apply_updates=True, nan_guard=True):
         """Generator step then discriminator step on one clip batch (train.py:446-464, 522-525).
         nan_guard: the reference's NaN guard (train.py:450-453) -- a NaN in GAN_Img / GAN_Feat skips both updates of this
@@ -104,6 +112,9 @@ class TrainStep(object):
         if nan_guard:
             watched = [G_losses[k] for k in ('GAN_Img', 'GAN_Feat') if k in G_losses]
             bad = bool(torch.isnan(torch.stack([w.reshape(()) for w in watched])).any().item())   # the one host read of the step
+            # ... next to it: the timeout flags of every graph-net program run since the last check (this step's forward programs, the
+            # previous step's backward programs) -- a run whose workgroups were not co-resident produced garbage and must not train on
+            self.check_health()
             if dist_utils.any_rank(bad, self.device):
                 if bad:
                     print("Error: video_id {} is NAN!".format(video_id))

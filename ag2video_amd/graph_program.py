@@ -31,6 +31,49 @@ def enabled():
     return os.environ.get('AG2V_NO_GRAPH_PROGRAM') is None
 
 
+_MAX_EDGES = []
+
+
+def max_edges():
+    """Edges per sample the POOL / GATHER_BWD operators take (one 64-bit incidence mask per endpoint): the library's limit."""
+    if not _MAX_EDGES:
+        _MAX_EDGES.append(int(_lib.query('ag2v_graph_program_max_edges')))
+    return _MAX_EDGES[0]
+
+
+# ---- the timeout flag of every run is read back (ADVICE r03): a launch whose workgroups were not all co-resident gives up at a grid
+# barrier after ~0.3 s, sets sync[1] and carries on with incomplete operands.  Each run copies its flag asynchronously into one slot of
+# a pinned ring; check_timeouts() -- called by the training step next to its one host read (engine.TrainStep.gd_step: the NaN guard) and
+# by anything else that is about to trust results -- waits for the copies made so far (long complete at that point) and raises.
+_RING_SLOTS = 64
+_ring = {'host': None, 'pending': [], 'next': 0}
+
+
+def _watch_flag(prog):
+    if _ring['host'] is None:
+        _ring['host'] = torch.zeros(_RING_SLOTS, dtype=torch.int32).pin_memory()
+    if len(_ring['pending']) >= _RING_SLOTS:
+        check_timeouts()                          # the ring is full (nobody checked for 64 runs): drain it now, with a host wait
+    slot = _ring['next'] % _RING_SLOTS
+    _ring['next'] += 1
+    _ring['host'][slot:slot + 1].copy_(prog.sync[1:2], non_blocking=True)
+    _ring['pending'].append((slot, torch.cuda.current_stream().record_event(), prog.n_ops))
+
+
+def check_timeouts():
+    """Raises RuntimeError if a grid barrier of any graph-net program run since the last check gave up (that run's object vectors,
+    boxes and gradients are invalid).  Waits only for the 4-byte flag copies of those runs."""
+    pend, _ring['pending'] = _ring['pending'], []
+    bad = []
+    for slot, ev, n_ops in pend:
+        ev.synchronize()
+        if int(_ring['host'][slot]) != 0:
+            bad.append(n_ops)
+    if bad:
+        raise RuntimeError("graph-net program: a grid barrier timed out in %d run(s) (programs of %s operators): the launch's workgroups "
+                           "were not co-resident (another process or stream held the CUs); the results of those runs are invalid" % (len(bad), bad))
+
+
 class Ref(object):
     """A row-major matrix view [rows, cols] with leading dimension ld at element offset `off` of `base` (a torch tensor, or None =
     the program's arena)."""
@@ -108,27 +151,52 @@ class Program(object):
     def _rec(self, **kw):
         self.recs.append(kw)
 
+    @staticmethod
+    def _need(cond, msg):
+        # (explicit raises, not asserts: under python -O a violated constraint would come back as stale cache lines or misaligned
+        # 16-byte accesses inside the kernel)
+        if not cond:
+            raise RuntimeError("graph program: " + msg)
+
+    def _aligned(self, *refs):
+        for r in refs:
+            if isinstance(r, Ref):
+                self._need(r.cols % 4 == 0 and r.ld % 4 == 0 and r.off % 4 == 0,
+                           "widths, leading dimensions and offsets must be multiples of 4 floats (got cols %d, ld %d, off %d)" % (r.cols, r.ld, r.off))
+
     def gemm(self, a, b, out, bias=None, res=None, mask=None, relu=False, acc=False):
-        assert a.cols == b.cols and out.rows == a.rows and out.cols == b.rows, (a.rows, a.cols, b.rows, b.cols, out.rows, out.cols)
-        assert out.cols <= 32 or out.ld % 32 == 0, "GEMM outputs wider than a tile need a leading dimension that is a multiple of 32"
+        self._need(a.cols == b.cols and out.rows == a.rows and out.cols == b.rows,
+                   "GEMM shapes %r" % ((a.rows, a.cols, b.rows, b.cols, out.rows, out.cols),))
+        self._need(out.cols <= 32 or out.ld % 32 == 0, "GEMM outputs wider than a tile need a leading dimension that is a multiple of 32")
+        self._aligned(a, b, out, res, mask)
         self._rec(type=GEMM, M=a.rows, N=b.rows, K=a.cols, a=a, b=b, bias=bias, res=res, mask=mask, c=out, relu=int(relu), acc=int(acc))
 
     def cat(self, out, segs):
         """segs: up to three (Ref, row-index int32 tensor or None)."""
         kw = dict(type=CAT, M=out.rows, c=out)
         names = (('a', 'i0', 'w0'), ('b', 'i1', 'w1'), ('d', 'i2', 'w2'))
-        assert sum(s[0].cols for s in segs) == out.cols
+        self._need(sum(s[0].cols for s in segs) == out.cols, "CAT segment widths do not add up to the output width")
+        self._aligned(out, *[s[0] for s in segs])
         for (ref, idx), (pn, inn, wn) in zip(segs, names):
             kw[pn], kw[inn], kw[wn] = ref, idx, ref.cols
         self._rec(**kw)
 
+    def _edges_ok(self, T, *refs):
+        self._need(T <= max_edges(), "%d edges per sample; POOL / GATHER_BWD take at most %d (csrc/graph_prog.hip)" % (T, max_edges()))
+        self._aligned(*refs)
+
     def pool(self, newt, out, counts, i0, i1, valid, O, T, Hd, Dp):
+        self._edges_ok(T, newt, out)
+        self._need(Hd % 4 == 0 and Dp % 4 == 0, "POOL widths must be multiples of 4")
         self._rec(type=POOL, M=out.rows, a=newt, c=out, mask=counts, i0=i0, i1=i1, valid=valid, O=O, T=T, w0=Hd, w1=Dp)
 
     def pool_bwd(self, dpooled, dp_in, out, counts, i0, i1, valid, O, T, Hd, Dp):
+        self._edges_ok(T, dpooled, dp_in, out)
         self._rec(type=POOL_BWD, M=out.rows, a=dpooled, b=dp_in, c=out, mask=counts, i0=i0, i1=i1, valid=valid, O=O, T=T, w0=Hd, w1=Dp)
 
     def gather_bwd(self, dtri, out, i0, i1, O, T, Din, Dp, res=None):
+        self._edges_ok(T, dtri, out, res)
+        self._need(Din % 4 == 0 and Dp % 4 == 0, "GATHER_BWD widths must be multiples of 4")
         self._rec(type=GATHER_BWD, M=out.rows, a=dtri, c=out, res=res, i0=i0, i1=i1, O=O, T=T, w0=Din, w1=Dp)
 
     def transpose(self, w, out):
@@ -142,7 +210,7 @@ class Program(object):
         self.arena = torch.empty(max(self.size, 4), device=self.device, dtype=torch.float32)
         self._arena_ptr = self.arena.data_ptr()
         arr = np.zeros(len(self.recs), _OP_DTYPE)
-        assert _OP_DTYPE.itemsize == _lib.query('ag2v_graph_op_bytes')
+        self._need(_OP_DTYPE.itemsize == _lib.query('ag2v_graph_op_bytes'), "operator record layout differs from the library's")
         lds = {'a': 'lda', 'b': 'ldb', 'd': 'ldd', 'res': 'ldr', 'mask': 'ldm', 'c': 'ldc'}
         for i, r in enumerate(self.recs):
             for k, v in r.items():
@@ -162,9 +230,10 @@ class Program(object):
         grid = int(os.environ.get('AG2V_GRAPH_GRID', 0)) or _lib.query('ag2v_graph_program_grid')
         _lib.call('ag2v_graph_program_run', ctypes.c_void_p(self.ops_dev.data_ptr()), self.n_ops, ctypes.c_void_p(self.sync.data_ptr()),
                   grid, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _watch_flag(self)
 
     def timed_out(self):
-        """Host read (synchronises): True when a grid barrier gave up -- the results of that run are invalid."""
+        """Host read (synchronises): True when a grid barrier of the LAST run gave up -- the results of that run are invalid."""
         return bool(self.sync[1].item())
 
     def tensor(self, ref_or_stack):
@@ -210,21 +279,23 @@ class _Plan(object):
         self.d_boxes = torch.zeros((S, BO, 4), device=dev) if has_box else None
         i0s, i1s, vls = list(self.i0.unbind(0)), list(self.i1.unbind(0)), list(self.valid.unbind(0))
         P = Program(dev)
-        f = {'in0': P.stack(S, BO, W1.shape[1]), 'h1': P.stack(S, BO, W1.shape[0]), 'ov0': P.stack(S, BO, W2.shape[0])}
+        # (every GEMM-written stack is allocated gemm_out: a width that is not a multiple of 32 gets a padded leading dimension instead
+        # of tripping the tile / cache-line rule; the weight-gradient GEMMs read the stacks through their strides)
+        f = {'in0': P.stack(S, BO, W1.shape[1]), 'h1': P.stack(S, BO, W1.shape[0], gemm_out=True), 'ov0': P.stack(S, BO, W2.shape[0], gemm_out=True)}
         Dins = []
         for l, g in enumerate(gcs):
             dpi = dp0 if l == 0 else Dp
             Din = (g[0].shape[1] - dpi) // 2
             Dins.append(Din)
             f['cur%d' % l] = P.stack(S, BT, 2 * Din + dpi)
-            f['a1%d' % l] = P.stack(S, BT, g[0].shape[0])
-            f['nt%d' % l] = P.stack(S, BT, g[2].shape[0])
+            f['a1%d' % l] = P.stack(S, BT, g[0].shape[0], gemm_out=True)
+            f['nt%d' % l] = P.stack(S, BT, g[2].shape[0], gemm_out=True)
             f['pool%d' % l] = P.stack(S, BO, Hd)
             f['cnt%d' % l] = P.stack(S, BO, 1)
-            f['a2%d' % l] = P.stack(S, BO, g[4].shape[0])
-            f['ov%d' % (l + 1)] = P.stack(S, BO, g[6].shape[0])
+            f['a2%d' % l] = P.stack(S, BO, g[4].shape[0], gemm_out=True)
+            f['ov%d' % (l + 1)] = P.stack(S, BO, g[6].shape[0], gemm_out=True)
         if has_box:
-            f['bh'] = P.stack(S, BO, box[0].shape[0])
+            f['bh'] = P.stack(S, BO, box[0].shape[0], gemm_out=True)
             f['boxes'] = P.stack(S, BO, 4)
         x0r = P.ext(self.x0, BO, E)
         for s in range(S):
@@ -281,17 +352,18 @@ class _Plan(object):
         W1t, W2t = tr(W1), tr(W2)
         gct = [(tr(g[0]), tr(g[2]), tr(g[4]), tr(g[6])) for g in gcs]
         boxt = (tr(box[0]), tr(box[2])) if has_box else None
-        g = {'din0': P.stack(S, BO, W1.shape[1], gemm_out=True), 'dh1': P.stack(S, BO, W1.shape[0]), 'dov0': P.stack(S, BO, W2.shape[0])}
+        g = {'din0': P.stack(S, BO, W1.shape[1], gemm_out=True), 'dh1': P.stack(S, BO, W1.shape[0], gemm_out=True),
+             'dov0': P.stack(S, BO, W2.shape[0])}
         for l in range(n_gconv):
             dpi = dp0 if l == 0 else Dp
-            g['dcur%d' % l] = P.stack(S, BT, 2 * Dins[l] + dpi)
-            g['da1%d' % l] = P.stack(S, BT, gcs[l][0].shape[0])
+            g['dcur%d' % l] = P.stack(S, BT, 2 * Dins[l] + dpi, gemm_out=True)
+            g['da1%d' % l] = P.stack(S, BT, gcs[l][0].shape[0], gemm_out=True)
             g['dnt%d' % l] = P.stack(S, BT, gcs[l][2].shape[0])
-            g['dpool%d' % l] = P.stack(S, BO, Hd)
-            g['da2%d' % l] = P.stack(S, BO, gcs[l][4].shape[0])
-            g['dov%d' % (l + 1)] = P.stack(S, BO, gcs[l][6].shape[0])
+            g['dpool%d' % l] = P.stack(S, BO, Hd, gemm_out=True)
+            g['da2%d' % l] = P.stack(S, BO, gcs[l][4].shape[0], gemm_out=True)
+            g['dov%d' % (l + 1)] = P.stack(S, BO, gcs[l][6].shape[0], gemm_out=True)
         if has_box:
-            g['dbh'] = P.stack(S, BO, box[0].shape[0])
+            g['dbh'] = P.stack(S, BO, box[0].shape[0], gemm_out=True)
             g['gbox'] = P.stack(S, BO, 4)
         for s in range(S - 1, -1, -1):
             i0, i1, vl = i0s[s], i1s[s], vls[s]
@@ -325,11 +397,23 @@ class _Plan(object):
         self.bwd, self.g = P.finalize(), g
 
 
-_PLANS = {}
+import collections
+
+_PLANS = collections.OrderedDict()       # key -> pool of plans; least recently used keys are dropped beyond _MAX_PLAN_KEYS
+_MAX_PLAN_KEYS = 12                      # a training run has 3 nets x (clip step, graph step) = 6 keys once T is bucketed (run_recurrence)
 
 
 def _get_plan(key, make):
-    pool = _PLANS.setdefault(key, [])
+    pool = _PLANS.get(key)
+    if pool is None:
+        pool = _PLANS[key] = []
+        while len(_PLANS) > _MAX_PLAN_KEYS:
+            old_key = next(iter(_PLANS))
+            if any(pl.busy and pl.out_ref is not None and pl.out_ref() is not None for pl in _PLANS[old_key]):
+                break                        # its backward is still to come: keep it (checked again at the next insertion)
+            del _PLANS[old_key]              # arenas, operator arrays and parameter references of that shape are released
+    else:
+        _PLANS.move_to_end(key)
     for pl in pool:
         if pl.busy and pl.out_ref is not None and pl.out_ref() is None:
             pl.busy = False                  # the forward's autograd node is gone: nobody can back-propagate into this plan any more
@@ -364,17 +448,21 @@ class _Recurrence(torch.autograd.Function):
         ctx.pl = pl
         ctx.wkeys = [(ops._wsink_register(p) if ctx.needs_input_grad[4 + i] else None) for i, p in enumerate(params)]
         ctx.p_alive = params
-        ov_stack = pl.fwd.tensor(pl.f['ov%d' % n_gconv])
-        boxes_stack = pl.fwd.tensor(pl.f['boxes']) if has_box else torch.empty(0, device=x0.device)
-        if not needs:                        # nothing will come back: hand out copies so that the plan is free for the next call
-            return ov_stack.clone(), boxes_stack.clone()
-        import weakref
-        pl.out_ref = weakref.ref(ctx)        # the autograd node lives exactly as long as something can still back-propagate into it
+        # the outputs are COPIES (S * BO * Dout floats): the arena belongs to the plan, whose next forward overwrites it -- a caller that
+        # keeps an output (logging, metrics, retain_graph) must not see it change; the arena itself stays the source of the backward's masks
+        ov_stack = pl.fwd.tensor(pl.f['ov%d' % n_gconv]).clone()
+        boxes_stack = pl.fwd.tensor(pl.f['boxes']).clone() if has_box else torch.empty(0, device=x0.device)
+        if needs:
+            import weakref
+            pl.out_ref = weakref.ref(ctx)    # the autograd node lives exactly as long as something can still back-propagate into it
         return ov_stack, boxes_stack
 
     @staticmethod
     def backward(ctx, d_ov, d_boxes):
         pl = ctx.pl
+        if pl is None:
+            raise RuntimeError("graph program: this recurrence has already been back-propagated (its plan -- the forward values the "
+                               "backward masks with -- was released); run the forward again instead of a second backward / retain_graph")
         mode, S, BO, BT, n_gconv, has_box = pl.mode, pl.S, pl.BO, pl.BT, pl.n_gconv, pl.has_box
         E, Hd, Dp, Dout, Dins, dp0 = pl.dims
         dev = pl.dev
@@ -457,6 +545,18 @@ def run_recurrence(mode, x0, pv_steps, edges_steps, ind_steps, boxes_in, first, 
     GraphTripleConv, box = box_net's two Linear modules or None.  Returns (ov [S, B, O, Dout], boxes [S, B, O, 4] or None)."""
     S, B, T = pv_steps.shape[0], pv_steps.shape[1], pv_steps.shape[2]
     O = x0.shape[1]
+    if T > max_edges():
+        raise RuntimeError("graph program: %d edges per sample exceed the kernel's %d; callers check supported(args, T) first" % (T, max_edges()))
+    Tb = min(max_edges(), (T + 7) & ~7)
+    if Tb != T:
+        # T is the per-batch padded maximum of triplets + actions (collate_fn): bucketed to multiples of 8 with edges that are padding in
+        # the kernel's sense too -- index 0, invalid (POOL skips them; their rows receive zero gradient, so GATHER_BWD adds zeros) -- one
+        # plan per net serves every batch of a bucket instead of one plan (programs, arenas) per distinct T
+        pad = Tb - T
+        pv_steps = torch.nn.functional.pad(pv_steps, (0, 0, 0, pad))
+        edges_steps = torch.nn.functional.pad(edges_steps, (0, 0, 0, pad))
+        ind_steps = torch.nn.functional.pad(ind_steps, (0, pad))
+        T = Tb
     i0, i1 = _row_indices(edges_steps, O)
     valid = ind_steps.reshape(S, B * T).to(torch.uint8).contiguous()
     params = [first[0].weight, first[1].weight]
@@ -473,6 +573,14 @@ def run_recurrence(mode, x0, pv_steps, edges_steps, ind_steps, boxes_in, first, 
     return ov, (boxes.reshape(S, B, O, 4) if box is not None else None)
 
 
-def supported(module_or_opt):
+def supported(module_or_opt, T=None):
+    """True when the recurrence can run as a program: no MLP normalisation, average pooling, every width a multiple of 4 floats (the
+    kernels' 16-byte accesses; GEMM outputs get padded leading dimensions where 32-column tiles need them) and at most max_edges() edges
+    per sample (T = the padded triplets + actions of this batch, when the caller knows it).  Otherwise callers take the per-operator path."""
     args = module_or_opt if isinstance(module_or_opt, dict) else vars(module_or_opt)
-    return enabled() and args.get('mlp_normalization', 'none') in ('none', None) and args.get('gconv_pooling', 'avg') == 'avg'
+    if not (enabled() and args.get('mlp_normalization', 'none') in ('none', None) and args.get('gconv_pooling', 'avg') == 'avg'):
+        return False
+    for k in ('embedding_dim', 'gconv_dim', 'gconv_hidden_dim'):
+        if int(args.get(k, 128)) % 4:
+            return False
+    return T is None or int(T) <= max_edges()

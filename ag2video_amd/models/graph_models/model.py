@@ -92,7 +92,7 @@ class Acts2LayoutModel(nn.Module):
         edges_all = edges_all.transpose(0, 1).contiguous()
         pv_fm = pv_all.transpose(0, 1).contiguous()                     # [F, B, T, D]
         from ... import graph_program
-        if emb.is_cuda and timesteps > 1 and graph_program.supported(self.args):
+        if emb.is_cuda and timesteps > 1 and graph_program.supported(self.args, T=pv_fm.shape[2]):
             # the whole recurrence as one persistent-kernel program per pass (ag2video_amd/graph_program.py)
             lin = [m for m in self.obj_vecs_net.children() if isinstance(m, Linear)]
             blin = [m for m in self.box_net.children() if isinstance(m, Linear)]

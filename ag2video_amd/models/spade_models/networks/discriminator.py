@@ -133,7 +133,7 @@ class MultiscaleActionDiscriminator(nn.Module):
         pv_fm = action_edge_vectors(self.acts_embeddings, a, x_end, y_end, rel).transpose(0, 1).contiguous()         # [T, B, A, D]
         boxes_steps = layout_boxes.transpose(0, 1).contiguous()
         from .... import graph_program
-        if ov.is_cuda and graph_program.supported(self.opt):
+        if ov.is_cuda and graph_program.supported(self.opt, T=pv_fm.shape[2]):
             lin = [m for m in self.obj_vecs_net.children() if isinstance(m, Linear)]
             out, _ = graph_program.run_recurrence('ov', ov, pv_fm, edges_all, ind_all, boxes_steps, lin, list(self.gconvs), None)
             return out.permute(1, 0, 2, 3)

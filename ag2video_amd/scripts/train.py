@@ -153,6 +153,7 @@ def main(args):
             for name, val in D_losses.items():
                 print(' D [%s]: %.4f' % (name, val))
         t += 1
+    ts.check_health()
     if rank == 0:
         save_checkpoint(args, ckpt_path, ts, epoch, t)
 

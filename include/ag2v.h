@@ -357,9 +357,13 @@ int ag2v_spectral_sigmas_multi(const void* descs, int n_layers, int total_blocks
  *      4 POOL_BWD  adjoint: a = dpooled, b = gradient of the predicate part (nullable), mask = counts; c [B*T, 2 w0 + w1]
  *      5 GATHER_BWD  c[bo, :w0] = res[bo] + sum over the sample's edges of the subject / object parts of a [B*T, 2 w0 + w1]
  *      6 TRANSPOSE  c[k, n] = a[n, k]        7 ADD3  c = a + b + d (b, d nullable), M rows of N columns
- * sync: two device words {arrival counter (zeroed by the call), timeout flag (set when a barrier gave up: results invalid)}. */
+ *      POOL / GATHER_BWD take at most ag2v_graph_program_max_edges() edges per sample (T); every width, K and leading dimension is
+ *      a multiple of 4 floats (16-byte accesses).  The record builder (ag2video_amd/graph_program.py) refuses anything else.
+ * sync: two device words {arrival counter, timeout flag}, BOTH zeroed by the call; the flag is set when a grid barrier gave up (the
+ * workgroups were not co-resident): the results of THAT run are invalid and the caller must read the flag before it trusts them. */
 size_t ag2v_graph_op_bytes(void);
 int ag2v_graph_program_grid(void);
+int ag2v_graph_program_max_edges(void);
 int ag2v_graph_program_run(const void* ops, int n_ops, unsigned* sync, int grid, void* stream);
 
 /* ---- fused Adam over a flat fp32 buffer: torch.optim.Adam as configured at scripts/train.py:365-368 and

@@ -66,3 +66,19 @@ def test_build_then_smoke_in_one_process():
                          cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     assert 'smoke ok' in out.stdout
+
+
+def test_bench_launches_its_own_ranks_over_rccl():
+    """`bench.py --gpus N` without a torchrun environment starts the N ranks itself (a child `torch.distributed.run`) and relays
+    rank 0's line; with AG2V_FORCE_DIST=1 the same launcher path runs at N = 1, so the RCCL process group is real on the test box."""
+    env = dict(os.environ, AG2V_FORCE_DIST='1')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--config', 'toy', '--gpus', '1', '--steps', '2', '--warmup', '1',
+                          '--no-fp32-leg', '--no-cpu-baseline'], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 1 and d['comm']['rccl_world'] == 1 and d['comm']['backend'] == 'nccl', d['comm']
+    assert 'g_allreduce_ms_alone' in d['comm']

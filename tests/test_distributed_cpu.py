@@ -224,3 +224,25 @@ def test_two_rank_gloo_gd_step_sync_bn(tmp_path):
     rel = ((a['gG'] - s['gG']).norm() / s['gG'].norm()).item()
     assert rel <= 1e-2, ('gG', rel)
     assert float(a['gG'].abs().sum()) > 0 and float(a['gD'].abs().sum()) > 0
+
+
+def test_bench_gpus_2_without_two_gpus_fails_loudly():
+    """`python bench.py --gpus N` starts N ranks itself.  Where fewer than N GPUs are visible (none here) it must
+    refuse with a non-zero exit code and a message -- never run fewer ranks and print a line for them."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    if __import__('torch').cuda.device_count() >= 2:
+        pytest.skip('two GPUs visible: the launcher would start them')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--config', 'toy', '--steps', '1', '--warmup', '0'],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert 'refusing to run fewer ranks' in r.stderr, r.stderr[-500:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith('{')]
+    # a rank started by a launcher whose world disagrees with --gpus refuses as well
+    env2 = dict(env, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--config', 'toy', '--steps', '1', '--warmup', '0'],
+                       env=env2, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and 'WORLD_SIZE=1' in r.stderr, r.stderr[-500:]

@@ -222,3 +222,99 @@ def test_recurrence_program_matches_fp64_autograd(mode, device):
         _close(n, gr, P[n].grad, 2e-5)
         checked += 1
     assert checked >= (30 if mode == 'emb' else 18), checked
+
+
+def test_program_takes_more_than_32_edges_and_refuses_beyond_the_limit(device):
+    """the incidence masks of POOL / GATHER_BWD were 32 bits wide and nothing stopped a longer edge list (T = padded
+    triplets + actions of the batch).  Now 64 bits, the limit is the library's (ag2v_graph_program_max_edges) and callers ask
+    supported(args, T) -- a longer list runs per operator.  A clip with up to 40 actions (T in 33..64 here) must agree with the
+    per-operator path as the CATER-sized clips do."""
+    from ag2video_amd import graph_program as gp
+    from ag2video_amd.data.synthetic import make_clip_batch
+    from ag2video_amd.models.graph_models.model import Acts2LayoutModel
+    from ag2video_amd.weights import closed_form_fill_
+    opt = _opt(64)
+    assert gp.max_edges() == 64
+    assert gp.supported(opt, T=64) and not gp.supported(opt, T=65)
+    net = Acts2LayoutModel(opt).to(device)
+    closed_form_fill_(net, seed=3, prefix='G.acts_to_objs.module.')
+    clip = make_clip_batch(opt.vocab, 3, 4, (64, 64), seed=9, max_actions=40)
+    objs, boxes, triplets, actions = [t.to(device) for t in (clip[1], clip[2], clip[3], clip[4])]
+    T = triplets.shape[2] + actions.shape[1]
+    assert 32 < T <= 64, T
+    wt = torch.randn(3, 4, objs.shape[1], 128, generator=torch.Generator().manual_seed(1)).to(device)
+    wb = torch.randn(3, 4, objs.shape[1], 4, generator=torch.Generator().manual_seed(2)).to(device)
+
+    def run():
+        net.zero_grad(set_to_none=True)
+        tv, bp, adata = net(objs, triplets, actions, boxes)
+        ((tv * wt).sum() + (bp * wb).sum()).backward()
+        torch.cuda.synchronize()
+        return tv.detach().clone(), bp.detach().clone(), {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    runs = gp._ring['next']
+    (tv, bp, g), (tv_r, bp_r, g_r) = _both(run)
+    assert gp._ring['next'] == runs + 2                # the program path did run: one forward and one backward program
+    gp.check_timeouts()
+    _close('tvecs', tv, tv_r)
+    _close('boxes_pred', bp, bp_r)
+    for n in g_r:
+        assert ((g[n] - g_r[n]).norm() / g_r[n].norm().clamp(min=1e-12)).item() <= 2e-2, n
+    # beyond the limit: the builder refuses (no silent truncation) ...
+    P = gp.Program(device)
+    with pytest.raises(RuntimeError):
+        P.pool(P.new(2 * 65, 64 * 2 + 64), P.new(2 * 3, 64), P.new(2 * 3, 1), None, None, None, 3, 65, 64, 64)
+    # ... and so does an operand that is not 16-byte granular
+    with pytest.raises(RuntimeError):
+        P.gemm(P.new(8, 30), P.new(8, 30), P.new(8, 8))
+
+
+def test_outputs_are_copies_and_a_second_backward_is_refused(device):
+    """the recurrence handed out views of its plan's arena, which the next forward of the same shape overwrites."""
+    from ag2video_amd import graph_program as gp
+    from ag2video_amd.models.graph_models.model import Acts2LayoutModel
+    from ag2video_amd.data.synthetic import make_clip_batch
+    from ag2video_amd.weights import closed_form_fill_
+    opt = _opt(64)
+    net = Acts2LayoutModel(opt).to(device)
+    closed_form_fill_(net, seed=3, prefix='G.acts_to_objs.module.')
+    c1 = make_clip_batch(opt.vocab, 2, 4, (64, 64), seed=5)
+    c2 = make_clip_batch(opt.vocab, 2, 4, (64, 64), seed=6)
+    a = [t.to(device) for t in (c1[1], c1[3], c1[4], c1[2])]
+    b = [t.to(device) for t in (c2[1], c2[3], c2[4], c2[2])]
+    tv1, bp1, _ = net(*a)
+    keep_tv, keep_bp = tv1.detach(), bp1.detach()
+    snap_tv, snap_bp = keep_tv.clone(), keep_bp.clone()
+    (tv1.sum() + bp1.sum()).backward()
+    tv2, bp2, _ = net(*b)                                # same shapes: the same plan, its arena rewritten
+    torch.cuda.synchronize()
+    assert torch.equal(keep_tv, snap_tv) and torch.equal(keep_bp, snap_bp)
+    assert not torch.equal(tv2.detach(), snap_tv)
+    (tv2.sum() + bp2.sum()).backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match='already been back-propagated'):
+        (tv2.sum() + bp2.sum()).backward()
+
+
+def test_timeout_flags_are_read_back(device):
+    """every run's timeout flag reaches the host (a pinned ring, drained by check_timeouts(), which the training step calls
+    next to its NaN guard); a set flag raises.  The flag itself cannot be provoked on an idle GPU, so the ring slot is poked."""
+    from ag2video_amd import graph_program as gp
+    gp.check_timeouts()
+    P = gp.Program(device)
+    a = torch.randn(32, 32, device=device)
+    out = P.new(32, 32)
+    P.gemm(P.ext(a), P.ext(a), out)
+    P.finalize()
+    P.sync[1] = 7                                        # a stale flag from "an earlier run": the call zeroes it
+    P.run()
+    assert len(gp._ring['pending']) == 1
+    slot = gp._ring['pending'][0][0]
+    gp.check_timeouts()                                  # clean run: passes, ring drained
+    assert not gp._ring['pending'] and int(gp._ring['host'][slot]) == 0 and not P.timed_out()
+    P.run()
+    slot = gp._ring['pending'][0][0]
+    torch.cuda.synchronize()
+    gp._ring['host'][slot] = 1
+    with pytest.raises(RuntimeError, match='timed out'):
+        gp.check_timeouts()
+    assert not gp._ring['pending']
+    gp._ring['host'][slot] = 0
