@@ -6,7 +6,9 @@ data-path collective is one gradient all-reduce per optimizer step, issued over 
 point-to-point xGMI fabric (7 links x ~153 GB/s per GPU: large buckets amortise the per-collective latency, and
 RCCL stripes a large all-reduce over all links).  The step's compute is seconds while 500 MB of gradients take
 ~1-6 ms, so buckets are reduced right after backward on the compute stream (DESIGN.md "Multi-GPU").
-Batch-norm statistics stay per process (per-GPU batch of 8 clips): see sync_batchnorm.py.
+Batch-norm statistics: per process by default (per-GPU batch of 8 clips, the single-device formula); ``--sync_bn 1`` switches to
+global-batch statistics with the reference's multi-device formula (set_sync_bn / combine_bn_stats below, sync_batchnorm.py).
+``bench.py --gpus N`` starts the N ranks itself (a child ``torch.distributed.run``); under an external torchrun it checks WORLD_SIZE.
 """
 import os
 

@@ -84,7 +84,7 @@ class MultiscaleDiscriminatorT(nn.Module):
         bs, nt, ch, h, w = img.size()
         x = img.reshape(bs, ch * nt, h, w)
         result = []
-        with ops.bf16x3_min_rows(48):
+        with ops.bf16x3_min_rows(48), ops.timing_scope('D_tmp'):
             for name, D in self.named_children():
                 if name.startswith('discriminator'):
                     out = D(x)
@@ -147,6 +147,10 @@ class MultiscaleActionDiscriminator(nn.Module):
         return torch.stack(out, dim=1)
 
     def forward(self, img, objs, layout_boxes, actions_data, layout_terms=None):
+        with ops.timing_scope('D'):          # bench.py's per-stack roofline (ops.kernel_timing_summary(by_scope=True))
+            return self._forward_impl(img, objs, layout_boxes, actions_data, layout_terms=layout_terms)
+
+    def _forward_impl(self, img, objs, layout_boxes, actions_data, layout_terms=None):
         """img [B,T,3,H,W], layout_boxes [B,T,O,4] -> num_D lists of n_layers_D+1 feature maps over [B*T, ...].
         ``layout_terms``: the result of self.layout_terms(objs, layout_boxes, actions_data), when the caller evaluates the
         discriminator on several images with the same layout (LossModel: fake and real)."""
@@ -165,7 +169,7 @@ class MultiscaleActionDiscriminator(nn.Module):
         Returns None when the dense route is configured."""
         if not self._low_rank():
             return None
-        with ops.bf16x3_min_rows(48):
+        with ops.bf16x3_min_rows(48), ops.timing_scope('D'):
             H = self.opt.image_size[0]
             ov = self.get_obj_vecs(objs, layout_boxes, actions_data)
             att = self.attribute_embedding(objs)

@@ -63,6 +63,10 @@ class FlowsGenerator(nn.Module):
         return seq[1](seq[0](x), slope=0.2)
 
     def forward(self, label=None, layout=None, prev=None):
+        with ops.timing_scope('flow'):          # bench.py's per-stack roofline (ops.kernel_timing_summary(by_scope=True))
+            return self._forward_impl(label=label, layout=layout, prev=prev)
+
+    def _forward_impl(self, label=None, layout=None, prev=None):
         """Either ``label`` = cat[layouts, previous frames] (dense first conv, as flows_generator.py:62-68), or
         ``layout`` = (vecs_list, boxes_list, keep, H) + ``prev`` [B, 3*nc, H, W]: the first conv then treats its layout
         channels in low-rank form (models/layout.py:layout_conv_lowrank) and only the image channels densely."""

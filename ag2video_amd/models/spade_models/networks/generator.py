@@ -101,7 +101,7 @@ class Layout2VidGenerator(nn.Module):
             warp = resample(prev[-1], flow)
             d = prev[-1] - warp
             conf = (torch.sum(d * d, dim=1, keepdim=True) < 0.02).float()
-            with ops.bf16x3_min_rows(48):
+            with ops.bf16x3_min_rows(48), ops.timing_scope('conv_dim_in'):      # (netG opens its own scope inside)
                 w, scales = conv.weight_and_scales()
                 nseg = w.shape[1] - 3
                 y = layout_conv_lowrank(w[:, :nseg], vecs_list, boxes_list, keep_t, H, H, conv.stride, conv.padding,
@@ -160,7 +160,7 @@ class Layout2VidGenerator(nn.Module):
             confs.append((torch.sum(d * d, dim=1, keepdim=True) < 0.02).float())
             flows.append(flow)
             # Image decoder: 64-channel layers on the bf16x3 tiles too (the flow network above stays exact in its forward).
-            with ops.bf16x3_min_rows(48):
+            with ops.bf16x3_min_rows(48), ops.timing_scope('conv_dim_in'):      # (netG opens its own scope inside)
                 if low_rank and conv.training:       # the frame-batched pass's formulation with one group (SpectralConv2d.forward)
                     w, scales = conv.weight_and_scales()
                     nseg = w.shape[1] - 3

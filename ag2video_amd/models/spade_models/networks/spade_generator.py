@@ -61,6 +61,10 @@ class SPADEGenerator(nn.Module):
         return ops.conv_split_input_ok((N, C, self.sh, self.sw), wshape, 1, 1)
 
     def forward(self, layout):
+        with ops.timing_scope('netG'):          # bench.py's per-stack roofline (ops.kernel_timing_summary(by_scope=True))
+            return self._forward_impl(layout)
+
+    def _forward_impl(self, layout):
         if not isinstance(layout, SegmapPyramid):      # (the frame-batched generator hands over the pyramid it built with the batch norm)
             layout = SegmapPyramid(layout, self.pyramid_sizes(layout.shape[2], layout.shape[3]))
         x = layout.at(self.sh, self.sw)

@@ -3,8 +3,11 @@
 The reference is single-process torch.nn.DataParallel (threads + NCCL broadcast of every parameter every forward,
 replicate.py:50-67).  This build runs one process per GPU: the wrapper below only reproduces the ``.module`` attribute
 (hence the ``.module.`` infix of every state_dict key); gradient averaging is done once per step by
-ag2video_amd.distributed over RCCL.  Batch-norm statistics are per process, i.e. the single-device formula
-F.batch_norm ((var+eps)^-1/2, batchnorm.py:63-68) at every world size (DESIGN.md "Multi-GPU").
+ag2video_amd.distributed over RCCL.  Batch-norm statistics: by default per process -- the single-device formula F.batch_norm
+((var+eps)^-1/2, batchnorm.py:63-68), which the golden vectors pin; with ``--sync_bn 1`` (distributed.set_sync_bn) and live
+collectives they are taken over the GLOBAL batch with the reference's multi-device formula (one all-reduce of [sum, sum of squares]
+per call, inv_std = clamp(biased var, eps)^-1/2, unbiased variance into running_var: batchnorm.py:80-93,105-145;
+distributed.combine_bn_stats), and the backward all-reduces its per-channel sums between the reduce and the apply pass.
 """
 import torch
 import torch.nn as nn

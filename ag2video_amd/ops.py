@@ -251,10 +251,35 @@ def _conv_launch(min_rows, name, label, flops, *args, shape=None, gscale=None, g
     e1.record()
     # key the record on the HIP kernel the library chose (tile shape / arithmetic / load path), as rocprofv3 names it; the
     # pass (fwd / dgrad / wgrad) stays in front because forward and data gradient share the implicit-GEMM kernels
-    _TIMING.append(("%s:%s" % (label, (opts.kernel or b'?').decode()), flops, e0, e1, shape))
+    _TIMING.append(("%s:%s" % (label, (opts.kernel or b'?').decode()), flops, e0, e1, shape, _SCOPE[-1]))
 
 
 _PAUSED = False
+
+# ---- timing scopes: which part of the model a convolution call belongs to ('netG' = the SPADE decoder stack north_star's MFMA target
+# is stated on, 'flow', 'conv_dim_in', 'D', ...).  Modules open a scope around their forward; the convolution nodes remember it for their
+# backward launches.  Only the timing records read it.
+_SCOPE = ['other']
+
+
+class timing_scope(object):
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        _SCOPE.append(self.name if self.name is not None else _SCOPE[-1])
+        return self
+
+    def __exit__(self, *exc):
+        _SCOPE.pop()
+        return False
+
+
+def _scoped_backward(fn):
+    def backward(ctx, *grads):
+        with timing_scope(getattr(ctx, 'scope', None)):
+            return fn(ctx, *grads)
+    return backward
 
 
 def pause_kernel_timing(flag):
@@ -272,11 +297,11 @@ def _launch(name, label, flops, *args, shape=None):
     e0.record()
     _lib.call(name, *args)
     e1.record()
-    _TIMING.append((label, flops, e0, e1, shape))
+    _TIMING.append((label, flops, e0, e1, shape, _SCOPE[-1]))
 
 
 _EVENT_POOL = []      # HIP events are recycled across steps: creating ~20k of them inside a timed step costs ~2 %
-_FOLDED = {}          # records already converted to milliseconds: (label, shape) -> [launches, flops, ms]
+_FOLDED = {}          # records already converted to milliseconds: (label, shape, scope) -> [launches, flops, ms]
 
 
 def fold_kernel_timing(keep=True):
@@ -286,9 +311,9 @@ def fold_kernel_timing(keep=True):
     torch.cuda.synchronize()
     if not _TIMING:
         return
-    for label, flops, e0, e1, shape in _TIMING:
+    for label, flops, e0, e1, shape, scope in _TIMING:
         if keep:
-            d = _FOLDED.setdefault((label, shape), [0, 0.0, 0.0])
+            d = _FOLDED.setdefault((label, shape, scope), [0, 0.0, 0.0])
             d[0] += 1
             d[1] += flops
             d[2] += e0.elapsed_time(e1)
@@ -297,11 +322,14 @@ def fold_kernel_timing(keep=True):
     del _TIMING[:]
 
 
-def kernel_timing_summary(by_shape=False):
-    """{label: {launches, flops, ms}} for everything recorded since enable_kernel_timing(True); synchronises."""
+def kernel_timing_summary(by_shape=False, by_scope=False):
+    """{label: {launches, flops, ms}} for everything recorded since enable_kernel_timing(True); synchronises.  by_scope: keys are
+    "<scope>|<label>" (timing_scope: 'netG', 'flow', 'conv_dim_in', 'D', 'other')."""
     fold_kernel_timing(True)
     out = {}
-    for (label, shape), (n, flops, ms) in _FOLDED.items():
+    for (label, shape, scope), (n, flops, ms) in _FOLDED.items():
+        if by_scope:
+            label = "%s|%s" % (scope, label)
         if by_shape:
             label = "%s %s" % (label, shape)
         d = out.setdefault(label, {'launches': 0, 'flops': 0.0, 'ms': 0.0})
@@ -519,12 +547,14 @@ class _Conv2d(torch.autograd.Function):
         ctx.cfg = (stride, pad, bias is not None, residual is not None, mr, relu, grad_premasked, relu_input, group_n)
         ctx.x_split = bool(x_split)
         ctx.dx_split = bool(dx_split)
+        ctx.scope = _SCOPE[-1]
         ctx.wkey = _wsink_register(w_in) if ctx.needs_input_grad[1] else None
         ctx.bkey = _wsink_register(bias_in) if (bias_in is not None and ctx.needs_input_grad[2] and _EXTRA_SINKS) else None
         ctx.w_alive = (w_in, bias_in)   # the registry keys on id(): keep the objects alive as long as this node, or a temporary
         return y                        # (a weight slice) could be collected and its id handed to another call's weight
 
     @staticmethod
+    @_scoped_backward
     def backward(ctx, dy):
         x, w, y, gscale = ctx.saved_tensors
         stride, pad, has_bias, has_res, mr, relu, grad_premasked, relu_input, group_n = ctx.cfg
@@ -741,9 +771,11 @@ class _ConvSharedInput(torch.autograd.Function):
         ctx.save_for_backward(x, *ws_, *(outs if keep_y else []))
         ctx.cfg = (stride, pad, mr, relu, grad_premasked, len(ws_), [b is not None for b in bs_])
         ctx.x_split = bool(x_split)
+        ctx.scope = _SCOPE[-1]
         return tuple(outs)
 
     @staticmethod
+    @_scoped_backward
     def backward(ctx, *dys):
         stride, pad, mr, relu, grad_premasked, n, has_b = ctx.cfg
         saved = ctx.saved_tensors
@@ -1510,11 +1542,13 @@ class _LayoutConvImg(torch.autograd.Function):
         out = _layout_conv_img_run(U, boxes, keep, img, w_img, gscale, H, W, R, pad)
         ctx.save_for_backward(boxes, keep, img, w_img, gscale)
         ctx.cfg = (NB, J, K, H, W, R, pad, group_n, _current_min_rows()[1])
+        ctx.scope = _SCOPE[-1]
         ctx.wkey = _wsink_register(w_in) if ctx.needs_input_grad[4] else None
         ctx.w_alive = w_in
         return out
 
     @staticmethod
+    @_scoped_backward
     def backward(ctx, dout):
         boxes, keep, img, w_img, gscale = ctx.saved_tensors
         NB, J, K, H, W, R, pad, group_n, mr = ctx.cfg

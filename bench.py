@@ -259,6 +259,7 @@ def main():
     ts.check_health()                               # (after the clock stopped) the last step's graph-net programs completed their barriers
     timing = ops.kernel_timing_summary() if not args.no_kernel_timing else {}
     by_shape = ops.kernel_timing_summary(by_shape=True) if not args.no_kernel_timing else {}
+    by_scope = ops.kernel_timing_summary(by_scope=True) if not args.no_kernel_timing else {}
     # ---- communication record (N > 1): proves how many ranks RCCL saw and how much of the all-reduce time the step waits for
     comm = {"rccl_world": (torch.distributed.get_world_size() if D.is_dist() else 1),
             "backend": (torch.distributed.get_backend() if D.is_dist() else None)}
@@ -316,7 +317,7 @@ def main():
         t1 = time.time()
         ts.gd_step(clip)
         torch.cuda.synchronize()
-        fp32_leg = {'ms': (time.time() - t1) * 1e3, 'timing': ops.kernel_timing_summary()}
+        fp32_leg = {'ms': (time.time() - t1) * 1e3, 'timing': ops.kernel_timing_summary(), 'by_scope': ops.kernel_timing_summary(by_scope=True)}
         ops.enable_kernel_timing(False)
         ops.set_conv_precision(args.precision)
 
@@ -390,6 +391,35 @@ def main():
                                      "by_kernel": {k: {"ms": round(v['ms'], 2), "tflops": round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2),
                                                        "launches": v['launches']} for k, v in sorted(per.items())}}}
 
+    def stack_roofline(scoped, peak, peak_basis):
+        """north_star's own figure: MFMA-roofline fraction of the SPADE decoder conv stack = the convolution launches made
+        inside SPADEGenerator.forward and their backward launches (netG: fc, every SPADEResnetBlock's conv_0 / conv_1 / conv_s and its
+        SPADEs' mlp_shared / gamma / beta, conv_img; reference spade_generator.py:16-34, architecture.py:29-32, normalization.py:90-94).
+        `algorithmic` = dense-conv 2 * MAC FLOPs of those launches (what the timing records carry; SURVEY 8d's 0.581 TF per generated
+        frame x 3 passes x B x (F - 1) = 209 TF at c3 is quoted beside it); frac = algorithmic / time in those launches / peak.
+        The other stacks of the step are listed the same way."""
+        per = {}
+        for k, v in scoped.items():
+            scope, lab = k.split('|', 1)
+            if not lab.startswith('conv_'):
+                continue
+            d = per.setdefault(scope, {'ms': 0.0, 'flops': 0.0, 'launches': 0})
+            d['ms'] += v['ms']; d['flops'] += v['flops']; d['launches'] += v['launches']
+        if 'netG' not in per:
+            return None
+        g = per['netG']
+        tf = g['flops'] / (g['ms'] * 1e-3) / 1e12
+        survey = 0.581e12 * 3 * world_batch_frames * (side / 256.0) ** 2 if args.config in ('c1', 'c2', 'c3') else None
+        return {"stack": "SPADE decoder conv stack (netG): forward + data gradient + weight gradient launches of one step",
+                "algorithmic_tflop_per_step": round(g['flops'] / 1e12, 2),
+                "survey_8d_tflop_per_step": (round(survey / 1e12, 2) if survey else None),
+                "ms": round(g['ms'], 2), "launches": g['launches'], "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                "frac": round(tf / peak, 4), "peak_basis": peak_basis,
+                "other_stacks": {k: {"ms": round(v['ms'], 2), "tflops": round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2), "launches": v['launches'],
+                                     "algorithmic_tflop_per_step": round(v['flops'] / 1e12, 2)}
+                                 for k, v in sorted(per.items()) if k != 'netG'}}
+    world_batch_frames = batch * (frames - 1)          # per rank (the records are rank 0's launches)
+
     def hbm_roofline(key, kernel, passes):
         if key not in timing:
             return None
@@ -422,10 +452,16 @@ def main():
         if roof_hbm_bwd is not None:
             roof_hbm_bwd['single_spade'] = roof_hbm_single_bwd
     roof = conv_roofline(timing, dt * 1e3 / args.steps) if timing else None     # the records cover the last timed step
+    if roof is not None and by_scope:
+        roof['spade_stack'] = stack_roofline(by_scope, (PEAK_BF16_MFMA_TFLOPS / 3.0) if args.precision == 'bf16x3' else PEAK_FP32_MFMA_TFLOPS,
+                                             ("bf16 dense MFMA 2500 TF / 3 MFMAs per fp32-equivalent product (the stack's <= 4-row and 32-row layers run "
+                                              "on exact-fp32 kernels and are priced against the same basis)") if args.precision == 'bf16x3'
+                                             else "v_mfma_f32_32x32x2_f32 dense peak")
     roof_fp32 = None
     if fp32_leg is not None:
         roof_fp32 = conv_roofline(fp32_leg['timing'], fp32_leg['ms'])
         if roof_fp32 is not None:
+            roof_fp32['spade_stack'] = stack_roofline(fp32_leg['by_scope'], PEAK_FP32_MFMA_TFLOPS, "v_mfma_f32_32x32x2_f32 dense peak")
             roof_fp32["ms_per_step"] = round(fp32_leg['ms'], 2)
             roof_fp32["note"] = "one extra step with --precision fp32 (exact fp32 MFMA everywhere); not part of `value`"
     cpu = None

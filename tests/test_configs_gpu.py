@@ -32,13 +32,25 @@ def _rand(*shape, seed=0, device='cpu', scale=1.0):
 # generated frames, i.e. T > 1 frame groups): the 128^2 / 256^2 layer stack -- up_2 / up_3, the full-resolution flow network and
 # warp, the discriminators at 129^2 / 65^2, the 6-level segmentation pyramid -- compared with the oracle AS A STACK (VERDICT r02
 # weak #1).  The oracle side of c3p is bench.py's c3' cpu_baseline leg (~16 s on the GPU box's host cores).
-STEP_CASES = {'c1': (64, 4, 1), 'c2p': (128, 3, 1), 'c3p': (256, 4, 1)}
+# c5p / c5pT: c5's geometry -- Something-Else vocabulary (ONE attribute => 128 layout channels, 2-3 objects with the
+# hand last, 9 predicates / 9 action classes: reference data/smth.py:85-104), 224 x 224 = 7 * 32 (the non-power-of-two pyramid 7, 14,
+# ..., 224 of spade_generator.py:53-81; discriminator maps 113^2 / 57^2) -- as a full default-width iteration against the oracle;
+# c5pT adds --temporal_D 1 --frames_per_action 4 (the reference's MultiscaleDiscriminatorT, discriminator.py:16-59, over one window of
+# 4 generated frames: 5 frames).
+STEP_CASES = {'c1': (64, 4, 1), 'c2p': (128, 3, 1), 'c3p': (256, 4, 1), 'c5p': (224, 3, 1), 'c5pT': (224, 5, 1)}
 _ORACLE_CACHE = {}
 
 
 def _case_opt(case):
     import bench
     side, frames, batch = STEP_CASES[case]
+    if case.startswith('c5'):
+        from ag2video_amd.data.args import make_opt
+        from ag2video_amd.data.vocab import smth_vocab
+        flags = ['--no_vgg_loss', '--image_size', '%d,%d' % (side, side), '--batch_size', str(batch), '--gpu_ids', '0', '--dataset', 'smth_else']
+        if case.endswith('T'):
+            flags += ['--temporal_D', '1', '--frames_per_action', '4']
+        return make_opt(smth_vocab(), flags), side, frames, batch
     opt, _, _, _ = bench.make_opt('c1')
     opt.image_size = (side, side)
     opt.batch_size = batch
@@ -46,7 +58,14 @@ def _case_opt(case):
     return opt, side, frames, batch
 
 
-def _oracle_step(case, shapes_G, shapes_D):
+def _case_clip(case, opt, batch, frames, side, seed):
+    from ag2video_amd.data.synthetic import make_clip_batch
+    if case.startswith('c5'):        # bench.make_clip's Something-Else shape: 2-3 objects (the hand last), <= 2 actions
+        return make_clip_batch(opt.vocab, batch, frames, (side, side), seed=seed, min_objs=2, max_objs=3, max_actions=2)
+    return make_clip_batch(opt.vocab, batch, frames, (side, side), seed=seed)
+
+
+def _oracle_step(case, shapes_G, shapes_D, shapes_T=None):
     """One oracle iteration (G step, D step, graph step) of a case, computed once per session and kept as what the checks need:
     outputs, losses, per-parameter gradient statistics, post-step state statistics + buffers."""
     if case in _ORACLE_CACHE:
@@ -55,14 +74,16 @@ def _oracle_step(case, shapes_G, shapes_D):
     from oracle.step import OracleTrainer
     torch.set_num_threads(min(16, torch.get_num_threads()))
     opt, side, frames, batch = _case_opt(case)
-    orc = OracleTrainer(opt, shapes_G, shapes_D, 1)
-    clip = make_clip_batch(opt.vocab, batch, frames, (side, side), seed=1234)
+    orc = OracleTrainer(opt, shapes_G, shapes_D, 1, key_shapes_T=shapes_T)
+    clip = _case_clip(case, opt, batch, frames, side, 1234)
     mo_r, GL_r, DL_r = orc.gd_step(clip)
     res = {'out': [mo_r[i].detach().clone() for i in range(4)],
            'GL': {k: float(v) for k, v in GL_r.items()}, 'DL': {k: float(v) for k, v in DL_r.items()},
            'G_grads': {n: (None if g is None else _stats(g)) for n, g in orc.last_G_grads.items()},
            'D_grads': {n: (None if g is None else _stats(g)) for n, g in orc.last_D_grads.items()}}
-    gclip = make_clip_batch(opt.vocab, batch, 4 * frames, (side, side), seed=4321)
+    if shapes_T:
+        res['T_grads'] = {n: (None if g is None else _stats(g)) for n, g in orc.last_T_grads.items()}
+    gclip = _case_clip(case, opt, batch, 4 * frames, side, 4321)
     bp_r, GG_r = orc.graph_step(gclip)
     res['bp'] = bp_r.detach().clone()
     res['GG'] = {k: float(v) for k, v in GG_r.items()}
@@ -90,9 +111,16 @@ def _step_vs_oracle(case, prec, device):
         ts = TrainStep(opt, device, weights_seed=1)
         shapes_G = {k: list(v.shape) for k, v in ts.model.state_dict().items()}
         shapes_D = {k: list(v.shape) for k, v in ts.discriminator.img_discriminator.state_dict().items()}
-        ref = _oracle_step(case, shapes_G, shapes_D)
-        clip = make_clip_batch(opt.vocab, batch, frames, (side, side), seed=1234)
+        dtmp = getattr(ts.discriminator, 'temporal_discriminator', None)
+        shapes_T = {k: list(v.shape) for k, v in dtmp.state_dict().items()} if dtmp is not None else None
+        assert (dtmp is not None) == case.endswith('T')
+        if case.startswith('c5'):
+            assert opt.semantic_nc == 128 and len(opt.vocab['attributes']) == 1        # one attribute => 128 layout channels
+        ref = _oracle_step(case, shapes_G, shapes_D, shapes_T)
+        clip = _case_clip(case, opt, batch, frames, side, 1234)
         mo, GL, DL = ts.gd_step(ts.to_device(clip))
+        if dtmp is not None:
+            assert set(GL) >= {'GAN_Tmp', 'GAN_Tmp_Feat'} and set(DL) >= {'D_tmp_fake', 'D_tmp_real'}
         for got, rf in ((GL, ref['GL']), (DL, ref['DL'])):
             assert set(got) == set(rf)
             for k in rf:
@@ -126,8 +154,18 @@ def _step_vs_oracle(case, prec, device):
             if abs(got[1] - g_ref[1]) > 2e-2 * abs(g_ref[1]) + 2e-6 * prm.numel():
                 badd.append((n, got[1], g_ref[1]))
         assert not badd, (len(badd), badd[:10])
+        if dtmp is not None:
+            badt = []
+            for n, prm in dtmp.named_parameters():
+                g_ref = ref['T_grads'].get(n)
+                if g_ref is None or prm.grad is None:
+                    continue
+                got = _stats(prm.grad)
+                if abs(got[1] - g_ref[1]) > 2e-2 * abs(g_ref[1]) + 2e-6 * prm.numel():
+                    badt.append((n, got[1], g_ref[1]))
+            assert not badt, (len(badt), badt[:10])
         # graph step on a 4x longer clip (train.py:471-493)
-        gclip = make_clip_batch(opt.vocab, batch, 4 * frames, (side, side), seed=4321)
+        gclip = _case_clip(case, opt, batch, 4 * frames, side, 4321)
         bp, GG = ts.graph_step(ts.to_device(gclip))
         for k, v in ref['GG'].items():
             assert abs(GG[k].item() - v) <= 1e-3 * max(1.0, abs(v)), (k, GG[k].item(), v)
@@ -151,7 +189,9 @@ def _step_vs_oracle(case, prec, device):
                 for i, fl in ((1, floor * n), (2, floor * n ** 0.5)):
                     if abs(got[i] - rstat[i]) > 1e-3 * abs(rstat[i]) + fl:
                         bad_state.append((k, i, got[i], rstat[i]))
-        assert n_keys == 492 + 56
+        # (CATER: 4 attributes => the reference's 492 + 56 keys; one attribute: AttributeEmbeddings has no mixing Linear,
+        # attribute_embed.py:29-46 -- the key sets were compared with the oracle's above either way)
+        assert n_keys == (492 + 56 if not case.startswith('c5') else len(ref['state'])) and n_keys >= 500
         assert not bad_state, (len(bad_state), bad_state[:10])
         print('%s default widths [%s]: worst output errors relative to max:' % (case, prec), worst)
         return worst
@@ -339,3 +379,17 @@ def test_c5_shaped_step_runs_and_is_finite(batch, device):
     opt = _finite_step('c5', device, batch=batch)
     assert opt.semantic_nc == 128 and tuple(opt.image_size) == (224, 224)
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("prec", ['bf16x3', 'fp32'])
+def test_step_c5prime_default_widths_matches_oracle(prec, device):
+    """c5's geometry as a STEP against the oracle: Something-Else vocabulary, 224 x 224, 3 frames, batch 1, default
+    widths, both arithmetics -- losses and outputs <= 1e-3, gradient statistics, every post-step state key (the same assertions as c3')."""
+    _step_vs_oracle('c5p', prec, device)
+
+
+def test_step_c5prime_temporal_discriminator_matches_oracle(device):
+    """The same geometry with --temporal_D 1 --frames_per_action 4 (5 frames: one window of 4 generated frames through the
+    reference's MultiscaleDiscriminatorT, discriminator.py:16-59): the temporal loss keys, and the temporal discriminator's gradients
+    beside everything the c5' step checks."""
+    _step_vs_oracle('c5pT', 'bf16x3', device)
