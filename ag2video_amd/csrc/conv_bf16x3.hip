@@ -1314,6 +1314,7 @@ static int pick_splits(int tiles, int nk, int max_splits) {
 }
 
 int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed) {
+    if (igemm_halo_ok(a)) return launch_igemm_halo(a, st);       // 3x3 stride-1 on split words: halo tiles by LDS-DMA (conv_halo.hip)
     // 256 x 128 tile when there are enough rows and it pads no more rows than the 128 x 256 tile does (384 rows: three 128-row
     // tiles, not two 256-row ones)
     const bool tall = a.M >= 192 && ceil_div(a.M, 256) * 256 <= ceil_div(a.M, 128) * 128;

@@ -178,6 +178,9 @@ __host__ __device__ __forceinline__ int tap_major_row(int c, int r, int s, int R
 
 // launchers implemented in conv_bf16x3.hip
 int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed);
+// conv_halo.hip: 3x3 stride-1 launches on split-word inputs as halo tiles staged by LDS-DMA (launch_igemm_bf16x3 asks first)
+bool igemm_halo_ok(const ConvArgs& a);
+int launch_igemm_halo(ConvArgs& a, hipStream_t st);
 void plan_wgrad_bf16x3(ConvArgs& a);      // tiles, pixel-range splits per group (a.spg), a.splitk, a.kchunk -- what the launch will use
 int launch_wgrad_bf16x3(ConvArgs& a, hipStream_t st);
 // dw[g][i] = (accumulate ? dw[g][i] : 0) + sum_{sl < spg, in order} slabs[(g * spg + sl) * mn + i]   (conv_igemm.hip)

@@ -1,0 +1,376 @@
+// 3x3 stride-1 convolution on the bf16 matrix pipe ("bf16x3", see conv_bf16x3.hip) with the gathered operand staged as HALO TILES by
+// LDS-DMA (buffer_load ... lds): no producer waves, no VALU and no ds_write on the way from memory to LDS.  gfx950 only.
+//
+// Replaces, for the shapes it covers, conv_igemm_bf16x3_ps_kernel: forward and stride-1 data gradient of every 3x3 convolution whose
+// gathered tensor holds SPLIT WORDS ((bf16 hi << 16) | bf16 lo per value: the SPADE decoder's activations and gradients, reference
+// models/spade_models/networks/architecture.py:29-32 conv_0 / conv_1, normalization.py:90-94 mlp_shared / mlp_gamma / mlp_beta).
+//
+// Why: in the wave-specialised kernels 8 producer waves spend a K-tile issuing 4..16-byte gathers (every filter tap re-fetches the same
+// pixels shifted by one), regrouping hi / lo halves and storing them to LDS, next to 8 consumer waves -- each side alone needs ~2 000
+// cycles per K-tile, together ~2 700.  Here a workgroup (8 waves, all of them multiply) owns an output patch of TH rows
+// x TW columns and stages, per 16 input channels, ONE image of the (TH + 2) x (TW + 8) input pixels around it: all nine taps read it
+// at different offsets, so memory -> LDS traffic drops ~4x against tap-by-tap gathers and the copy is 1 KiB DMA pieces
+// (lane-linear LDS destination, per-lane source: 64 quads of 4 pixels) whose per-lane offsets are computed once per workgroup -- a
+// stage only moves a wave-uniform SGPR offset.  Padding never reaches LDS: out-of-image quads load from an out-of-range buffer offset
+// (reads 0) and the buffers are cleared once, so either DMA out-of-range semantic (write 0 / write nothing) leaves zeros there.
+// The weights arrive as the bf16 hi / lo planes the tap-major pack kernels already write ([KG/8][M][8], conv_igemm.hip
+// pack_fwd_tap_kernel / pack_dgrad_tap_kernel) and go to a 6-slot LDS ring the same way, one 16-deep k-step (16 channels of one tap)
+// per slot, three steps ahead.
+//
+// A wave owns EM x 32 output channels x 32 pixels.  Per k-step it reads its B fragment as 8 split words (ds_read_b32 at immediate
+// offsets: channel j, tap (r, s)), regroups them into the hi / lo bf16x8 operands (8 v_perm) and issues 3 EM MFMAs; the operands of
+// step t + 1 are requested during step t (B from the staged image, A from the ring slot certified by the barrier at the top of
+// step t), so the matrix pipe starts right behind each barrier.  One s_barrier and one counted s_waitcnt vmcnt per step.
+#include "conv_common.h"
+#include <stdlib.h>
+
+typedef __attribute__((address_space(3))) void* lds_vptr;
+
+#ifndef AG2V_HALO_NA
+#define AG2V_HALO_NA 6          // A ring slots (divides the 18-step unrolled body)
+#endif
+
+template <int WM, int WN, int EM, int TW, int TH>
+struct HaloCfg {
+    static constexpr int BM = WM * EM * 32, BN = WN * 32;
+    static_assert(WM * WN == 8, "8 waves");
+    static_assert(TW * TH == BN && TW % 32 == 0, "pixel patch");
+    static constexpr int CH = 16;                         // channels per stage = one MFMA k-step
+    static constexpr int RP = TW + 8, NR = TH + 2;        // staged row pitch (words) / rows: one quad of halo columns each side
+    static constexpr int CHP = NR * RP;                   // words per channel
+    static constexpr int BQ = CH * CHP / 4;               // quads per stage
+    static constexpr int NPB = (BQ + 63) / 64;            // DMA pieces (64 quads = 1 KiB) per stage
+    static constexpr int PPW = (NPB + 7) / 8;             // ... per wave
+    static constexpr int BBYTES = NPB * 1024;
+    static constexpr int ASZ = BM * 64;                   // bytes per A step: [plane hi | lo][k group 0 | 1][BM rows][8 bf16]
+    static constexpr int APS = ASZ / 1024;                // A pieces per step
+    static constexpr int APW = (APS + 7) / 8;
+    static constexpr int NA = AG2V_HALO_NA;
+    static constexpr int A_OFF = 0, B_OFF = NA * ASZ, DUMMY_OFF = B_OFF + 2 * BBYTES, LDS_BYTES = DUMMY_OFF + 1024;
+    static_assert(PPW <= 6, "a stage's pieces must be certified before the next stage's first prefetch");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    static_assert((7 * CHP + 2 * RP + 2) * 4 < 65536 && (2 * ASZ + 3 * BM * 16 + EM * 512) < 65536, "ds_read immediate offsets");
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)      // (the host pass only needs the kernel stubs; it rejects some of the device-only template code)
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int WM, int WN, int EM, int TW, int TH>
+struct HaloBody {
+    typedef HaloCfg<WM, WN, EM, TW, TH> G;
+    const ConvArgs& p;
+    char* smem;
+    __amdgpu_buffer_rsrc_t ars, brs;
+    int wave, lane;
+    // DMA state (per lane, fixed for the workgroup)
+    unsigned vA[G::APW], vB[G::PPW];
+    unsigned dstB0[G::PPW];              // LDS byte offset of this wave's B pieces inside a stage buffer (or the dummy KiB, absolute)
+    bool dummyB[G::PPW];
+    unsigned dstA[G::APW];               // LDS byte offset inside an A slot (or the dummy KiB, absolute)
+    bool dummyA[G::APW];
+    unsigned hw4;                        // H * W * 4
+    int NS, lastP, P;                    // stages, last stage pair, current pair
+    // fragment state
+    unsigned baseA[2], baseB[2];
+    bf16x8 ah[2][EM], al[2][EM], bh[2], bl[2];
+    unsigned bw[8];
+    f32x16 acc[EM];
+
+    __device__ __forceinline__ HaloBody(const ConvArgs& p_, char* s) : p(p_), smem(s) {}
+
+    template <int U3>
+    __device__ __forceinline__ void dma_a(int Pn) {          // the A step that sits U3 steps into pair Pn (U3 < 18)
+        constexpr int slot = U3 % G::NA;
+        constexpr int c = (U3 % 9) * 4 + 2 * (U3 / 9);       // k-group row of the step inside its 32-channel chunk: (tap, half)
+        const unsigned soff = (unsigned)(Pn * 36 + c) * (unsigned)p.M * 16u;
+#pragma unroll
+        for (int j = 0; j < G::APW; ++j) {
+            const unsigned dst = dummyA[j] ? dstA[j] : (unsigned)(G::A_OFF + slot * G::ASZ) + dstA[j];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (lds_vptr)(smem + dst), 16, vA[j], soff, 0, 0);
+        }
+    }
+    template <int K, int BUF>
+    __device__ __forceinline__ void dma_b(int stage) {       // piece round K of stage `stage` into buffer BUF
+        const unsigned soff = (unsigned)stage * 16u * hw4;
+        const unsigned dst = dummyB[K] ? dstB0[K] : (unsigned)(G::B_OFF + BUF * G::BBYTES) + dstB0[K];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (lds_vptr)(smem + dst), 16, vB[K], soff, 0, 0);
+    }
+    // Operand registers: set (U & 1) holds step U's A fragments (ah / al) and its B operand already regrouped (bh / bl).
+    template <int U1>
+    __device__ __forceinline__ void load_a(int i) {          // A fragments of row block i for the step U1 steps into the pair
+        constexpr int set = U1 & 1, slot = U1 % G::NA;
+        const char* ab = smem + baseA[slot / 3] + (slot % 3) * G::ASZ;
+        ah[set][i] = *reinterpret_cast<const bf16x8*>(ab + i * 512);
+        al[set][i] = *reinterpret_cast<const bf16x8*>(ab + 2 * G::BM * 16 + i * 512);
+    }
+    template <int U1>
+    __device__ __forceinline__ unsigned load_bw(int j) {     // split word of channel j (of this lane's k group) at step U1's tap
+        constexpr int buf = (U1 / 9) & 1, tap = U1 % 9, r = tap / 3, s = tap % 3;
+        return *reinterpret_cast<const unsigned*>(smem + baseB[buf] + (r * G::RP + s) * 4 + j * G::CHP * 4);
+    }
+    template <int U1>
+    __device__ __forceinline__ void regroup() {              // 8 split words -> hi / lo bf16x8 operands of set U1 & 1
+        constexpr int set = U1 & 1;
+        typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+        u32x4v hv, lv;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            hv[q] = __builtin_amdgcn_perm(bw[2 * q + 1], bw[2 * q], 0x07060302u);
+            lv[q] = __builtin_amdgcn_perm(bw[2 * q + 1], bw[2 * q], 0x05040100u);
+        }
+        bh[set] = __builtin_bit_cast(bf16x8, hv);
+        bl[set] = __builtin_bit_cast(bf16x8, lv);
+    }
+    template <int U1>
+    __device__ __forceinline__ void prefetch_all() {         // (prologue) every operand of step U1 at once
+#pragma unroll
+        for (int i = 0; i < EM; ++i) load_a<U1>(i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bw[j] = load_bw<U1>(j);
+        regroup<U1>();
+    }
+    template <int U>
+    __device__ __forceinline__ void step() {
+        constexpr int tap = U % 9, ptap = (U + 8) % 9, set = U & 1;
+        // everything this wave issued before the previous step has landed; the barrier makes that true for every wave's pieces: the A
+        // slots of steps t, t + 1 and (from tap PPW + 1 on) the next stage's image are certified
+        wait_vmcnt<G::APW + (ptap < G::PPW ? 1 : 0)>();
+        __builtin_amdgcn_s_barrier();
+        // EM groups of {3 MFMAs on this step's operands (in registers since the previous step), the LDS reads of 1 / EM of the next
+        // step's operands}.  The order is pinned: left alone the scheduler sinks every read to just in front of its use (fewest live
+        // registers), which puts an LDS round trip in front of every other MFMA.  The step's DMA pieces are issued BEHIND the first
+        // MFMA group: an LDS-DMA instruction takes 60-180 cycles to issue (MI355X_MICROARCH.md constants) and both waves of a SIMD issue
+        // theirs at the same point of the step -- at the top of the step the matrix pipe would idle for that long after every barrier.
+        constexpr int WPG = 8 / EM;
+#pragma unroll
+        for (int g = 0; g < EM; ++g) {
+            __builtin_amdgcn_sched_barrier(0);
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[set][g], bh[set], acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[set][g], bl[set], acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[set][g], bh[set], acc[g], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (g == 0) {
+                if constexpr (tap < G::PPW) {
+                    const int st = 2 * P + U / 9 + 1;
+                    dma_b<tap, ((U / 9) + 1) & 1>(st < NS ? st : NS - 1);
+                }
+                if constexpr (U + 3 < 18) dma_a<U + 3>(P);
+                else dma_a<U + 3 - 18>(P + 1 <= lastP ? P + 1 : lastP);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            load_a<U + 1>(g);
+#pragma unroll
+            for (int j = 0; j < WPG; ++j) bw[g * WPG + j] = load_bw<U + 1>(g * WPG + j);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        regroup<U + 1>();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    __device__ __forceinline__ void run() {
+        const int tid = threadIdx.x;
+        lane = tid & 63;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        ars = make_rsrc(p.a_src, p.a_bytes);
+        brs = make_rsrc(p.b_src, p.b_bytes);
+        constexpr unsigned kOut = 0xFFFFFFF0u;
+        hw4 = (unsigned)(p.H * p.W) * 4u;
+        NS = p.C / 16;
+        lastP = NS / 2 - 1;
+        // ---- tile
+        const int lid = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+        const int tile_m = lid % p.tiles_m, tn = lid / p.tiles_m;
+        const int tcols = p.OW / TW, tpi = (p.OH / TH) * tcols;
+        const int n_img = tn / tpi, trem = tn - n_img * tpi;
+        const int y0 = (trem / tcols) * TH, x0 = (trem % tcols) * TW;
+        const int m0 = tile_m * G::BM;
+        // ---- clear LDS (padding positions are never written afterwards)
+        // (only the image buffers: a row of the A ring beyond M is never DMA-written either, but it only feeds accumulator rows that
+        // are not stored)
+        for (int o = G::B_OFF + tid * 16; o < G::LDS_BYTES; o += 512 * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0u, 0u, 0u, 0u);
+        // ---- DMA descriptors
+        const unsigned lo_plane = (unsigned)(p.KG >> 3) * (unsigned)p.M * 16u;
+#pragma unroll
+        for (int j = 0; j < G::APW; ++j) {
+            const int a = wave + 8 * j;
+            const int e = a * 64 + lane;
+            const int plane = e / (2 * G::BM), kg = (e / G::BM) & 1, m = e % G::BM;
+            dummyA[j] = a >= G::APS;
+            dstA[j] = dummyA[j] ? (unsigned)G::DUMMY_OFF : (unsigned)a * 1024u;
+            vA[j] = (!dummyA[j] && m0 + m < p.M) ? (unsigned)plane * lo_plane + (unsigned)(kg * p.M + m0 + m) * 16u : kOut;
+        }
+#pragma unroll
+        for (int k = 0; k < G::PPW; ++k) {
+            const int pc = wave + 8 * k;
+            const int q = pc * 64 + lane;
+            const int ch = q / (G::CHP / 4), w = q % (G::CHP / 4);
+            const int row = w / (G::RP / 4), cq = w % (G::RP / 4);
+            const int y = y0 - 1 + row, x = x0 - 4 + 4 * cq;
+            dummyB[k] = pc >= G::NPB;
+            dstB0[k] = dummyB[k] ? (unsigned)G::DUMMY_OFF : (unsigned)pc * 1024u;
+            const bool ok = !dummyB[k] && q < G::BQ && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+            vB[k] = ok ? (unsigned)(((n_img * p.C + ch) * p.H + y) * p.W + x) * 4u : kOut;
+        }
+        // ---- fragment addresses
+        const int wm = wave / WN, wn = wave % WN;
+        const int wm0 = wm * EM * 32;
+        const int pb = wn * 32, ty = pb / TW, tx = pb % TW;
+        const int kg = lane >> 5, l31 = lane & 31;
+        baseA[0] = (unsigned)(G::A_OFF + kg * G::BM * 16 + (wm0 + l31) * 16);
+        baseA[1] = baseA[0] + 3u * G::ASZ;
+        baseB[0] = (unsigned)(G::B_OFF + ((kg * 8) * G::CHP + ty * G::RP + tx + l31 + 3) * 4);
+        baseB[1] = baseB[0] + (unsigned)G::BBYTES;
+        // opaque to the optimiser: it would fold the region offsets (up to 150 KB) into the per-read constants, which then no longer fit
+        // the 16-bit ds_read offset field and become one address register per (channel, tap) -- dozens of them, spilled
+        asm volatile("" : "+v"(baseA[0]), "+v"(baseA[1]), "+v"(baseB[0]), "+v"(baseB[1]));
+#pragma unroll
+        for (int i = 0; i < EM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        __syncthreads();
+        // ---- prologue: stage 0, A steps 0..2
+        P = 0;
+        if constexpr (G::PPW > 0) dma_b<0, 0>(0);
+        if constexpr (G::PPW > 1) dma_b<1, 0>(0);
+        if constexpr (G::PPW > 2) dma_b<2, 0>(0);
+        if constexpr (G::PPW > 3) dma_b<3, 0>(0);
+        if constexpr (G::PPW > 4) dma_b<4, 0>(0);
+        if constexpr (G::PPW > 5) dma_b<5, 0>(0);
+        dma_a<0>(0);
+        dma_a<1>(0);
+        dma_a<2>(0);
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        prefetch_all<0>();
+        for (P = 0; P <= lastP; ++P) {
+            step<0>(); step<1>(); step<2>(); step<3>(); step<4>(); step<5>(); step<6>(); step<7>(); step<8>();
+            step<9>(); step<10>(); step<11>(); step<12>(); step<13>(); step<14>(); step<15>(); step<16>(); step<17>();
+        }
+        wait_vmcnt<0>();          // (the clamped tail DMAs still target this workgroup's LDS)
+        // ---- epilogue.  Accumulator register r of block i holds row (r & 3) + 8 (r >> 2) + 4 kg, pixel l31 of the wave's 32.
+        const int plane = p.OH * p.OW;
+        const int oy = y0 + ty, ox = x0 + tx + l31;
+        float* obase = p.out + (size_t)n_img * p.M * plane + (size_t)oy * p.OW + ox;
+        const float* rbase = p.residual ? p.residual + (size_t)n_img * p.M * plane + (size_t)oy * p.OW + ox : nullptr;
+        const float* mbase = p.mask ? p.mask + (size_t)n_img * p.M * plane + (size_t)oy * p.OW + ox : nullptr;
+        const float gs = (p.gscale ? p.gscale[n_img / p.group_n] : 1.f) * (p.oscale != 0.f ? p.oscale : 1.f);
+        const float* aux = rbase ? rbase : mbase;           // at most one of them (the entry points reject both)
+        const float ninf = -__builtin_huge_valf();
+        const float rmul = rbase ? 1.f : 0.f;
+        const float relu_floor = p.relu ? 0.f : ninf;
+        const float mask_thr = mbase ? 0.f : ninf;
+        const bool osplit = p.out_split != 0;
+#pragma unroll
+        for (int i = 0; i < EM; ++i) {
+            const int mblk = m0 + wm0 + i * 32;
+            float bvec = 0.f;
+            if (p.bias) {
+                const int mb = mblk + l31;
+                bvec = (mb < p.M) ? p.bias[mb] : 0.f;
+            }
+            float ax[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ax[r] = 0.f;
+            if (aux) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mblk + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                    if (m < p.M) ax[r] = aux[(size_t)m * plane];
+                }
+                __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0) once per 32-row block
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int rr = (r & 3) + 8 * (r >> 2);
+                const float b0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(bvec), rr));
+                const float b1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(bvec), rr + 4));
+                float x = fmaf(acc[i][r], gs, kg ? b1 : b0);
+                x = fmaf(ax[r], rmul, x);
+                x = fmaxf(x, relu_floor);
+                x = (ax[r] > mask_thr) ? x : 0.f;
+                if (osplit) x = pack_split(x);
+                const int m = mblk + rr + 4 * kg;
+                if (m < p.M) obase[(size_t)m * plane] = x;
+            }
+        }
+    }
+};
+
+#endif
+
+template <int WM, int WN, int EM, int TW, int TH>
+__global__ __launch_bounds__(512) void conv_halo_bf16x3_kernel(ConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(1024))) char smem[HaloCfg<WM, WN, EM, TW, TH>::LDS_BYTES];
+    HaloBody<WM, WN, EM, TW, TH> body(p, smem);
+    body.run();
+#endif
+}
+
+// ---- host side
+// Geometry of the pixel patch for a BN-pixel tile on an OH x OW map: the widest TW in {128, 64, 32} that divides OW with TH = BN / TW
+// dividing OH and leaving at least one row outside the patch (a patch as tall as the image would make pieces that are all padding).
+static bool halo_geometry(int BN, int OH, int OW, int& TW, int& TH) {
+    for (int tw = 128; tw >= 32; tw >>= 1) {
+        if (tw > BN || OW % tw) continue;
+        const int th = BN / tw;
+        if (OH % th || th >= OH) continue;
+        TW = tw; TH = th;
+        return true;
+    }
+    return false;
+}
+
+// Can this launch (as the callers of launch_igemm_bf16x3 describe it) run on the halo kernels?
+bool igemm_halo_ok(const ConvArgs& a) {
+    // (read per call, not cached: tools/halo_bench.py and the tests switch kernels inside one process)
+    if (getenv("AG2V_NO_HALO") != nullptr || !a.tap_major || !a.b_split || a.h16 || a.f32) return false;
+    if (a.R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1 || a.pad_w != 1 || a.OH != a.H || a.OW != a.W) return false;
+    if (a.C % 32 || a.W % 4 || (a.o_mul != 1 && a.o_mul != 0) || a.o_add_y || a.o_add_x) return false;
+    if ((a.o_H && a.o_H != a.OH) || (a.o_W && a.o_W != a.OW)) return false;
+    if (a.residual == a.out && a.residual) return false;          // accumulating launches stay on the split-K capable kernels
+    const bool tall = a.M >= 192 && ceil_div(a.M, 256) * 256 <= ceil_div(a.M, 128) * 128;
+    const int bn = tall ? 128 : 256, bm = tall ? 256 : (a.M <= 64 ? 64 : 128);
+    int tw, th;
+    if (!halo_geometry(bn, a.OH, a.OW, tw, th)) return false;
+    const long long tiles = (long long)ceil_div(a.M, bm) * (a.NG / bn);
+    const char* mt = getenv("AG2V_HALO_MIN_TILES");                 // (tests run small shapes through these kernels)
+    return tiles >= (mt ? atoi(mt) : 512);                          // small maps: the split-K kernels fill the chip better
+}
+
+int launch_igemm_halo(ConvArgs& a, hipStream_t st) {
+    const bool tall = a.M >= 192 && ceil_div(a.M, 256) * 256 <= ceil_div(a.M, 128) * 128;
+    const int bn = tall ? 128 : 256, bm = tall ? 256 : (a.M <= 64 ? 64 : 128);
+    int tw, th;
+    if (!halo_geometry(bn, a.OH, a.OW, tw, th)) return AG2V_EINVAL;
+    a.tiles_m = ceil_div(a.M, bm);
+    a.tiles_n = a.NG / bn;
+    a.splitk = 1;
+    const dim3 grid(a.tiles_m * a.tiles_n);
+#define AG2V_HALO(WM_, WN_, EM_, TW_, TH_)                                                                              \
+    do {                                                                                                                \
+        set_last_conv_kernel("conv_halo_bf16x3_kernel<" #WM_ ", " #WN_ ", " #EM_ ", " #TW_ ", " #TH_ ">");               \
+        hipLaunchKernelGGL((conv_halo_bf16x3_kernel<WM_, WN_, EM_, TW_, TH_>), grid, dim3(512), 0, st, a);                \
+    } while (0)
+    if (tall) {
+        if (tw == 128) AG2V_HALO(2, 4, 4, 128, 1);
+        else if (tw == 64) AG2V_HALO(2, 4, 4, 64, 2);
+        else AG2V_HALO(2, 4, 4, 32, 4);
+    } else if (bm == 128) {
+        if (tw == 128) AG2V_HALO(1, 8, 4, 128, 2);
+        else if (tw == 64) AG2V_HALO(1, 8, 4, 64, 4);
+        else AG2V_HALO(1, 8, 4, 32, 8);
+    } else {
+        if (tw == 128) AG2V_HALO(1, 8, 2, 128, 2);
+        else if (tw == 64) AG2V_HALO(1, 8, 2, 64, 4);
+        else AG2V_HALO(1, 8, 2, 32, 8);
+    }
+#undef AG2V_HALO
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}

@@ -1,0 +1,123 @@
+"""The halo-tile LDS-DMA convolution kernels (csrc/conv_halo.hip: 3x3 stride-1 forward / data gradient on split-word operands) against
+the oracle (oracle/kernels.py::conv2d = nn.Conv2d.forward, reference architecture.py:29-32 / normalization.py:90-94 call sites) on the
+split words' exact values, and against the wave-specialised kernels they replace (AG2V_NO_HALO=1: same products, another summation order):
+every patch geometry (TW x TH = 128x2, 64x4, 32x8 for the 64- / 128-row tiles; 128x1, 64x2, 32x4 for the 256-row tile), row counts
+that do not fill the last row tile, every epilogue (bias, ReLU, residual, per-group scale, ReLU mask, split-word output), the data
+gradient, image borders on all four sides and several images per launch.  AG2V_HALO_MIN_TILES=1 lets these small shapes take the
+kernels (the product only sends launches with >= 512 tiles there)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _to_split_words(x):
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    w = (hi.view(torch.int16).to(torch.int32) << 16) | (lo.view(torch.int16).to(torch.int32) & 0xFFFF)
+    return w.view(torch.float32)
+
+
+def _from_split_words(t):
+    wd = t.view(torch.int32)
+    return (wd & -65536).view(torch.float32) + (wd << 16).view(torch.float32)
+
+
+class _halo(object):
+    def __init__(self, on):
+        self.on = on
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in ('AG2V_NO_HALO', 'AG2V_HALO_MIN_TILES')}
+        os.environ['AG2V_HALO_MIN_TILES'] = '1'
+        if self.on:
+            os.environ.pop('AG2V_NO_HALO', None)
+        else:
+            os.environ['AG2V_NO_HALO'] = '1'
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        return False
+
+
+# (N, C, H, W, K): geometry it selects
+CASES = [(2, 32, 32, 32, 128), (2, 64, 64, 64, 128), (1, 32, 128, 128, 128), (3, 32, 256, 256, 96),        # 128-row tile: 32x8, 64x4, 128x2 (x2 patches per row)
+         (2, 32, 32, 32, 256), (2, 32, 64, 64, 320), (1, 64, 128, 128, 256),                                  # 256-row tile: 32x4, 64x2, 128x1
+         (2, 32, 64, 64, 64), (1, 32, 128, 128, 48), (2, 64, 32, 32, 64),                                     # 64-row tile
+         (1, 32, 224, 224, 128), (2, 96, 64, 64, 384)]                                                        # c5's 224 = 7 * 32; three 128-row tiles
+
+
+@pytest.mark.parametrize("cfg", CASES, ids=str)
+def test_halo_forward_matches_oracle_and_previous_kernels(cfg, device):
+    from ag2video_amd import _lib, ops
+    from oracle import kernels as K
+    N, C, H, W, Kout = cfg
+    torch.manual_seed(3)
+    x = torch.randn(N, C, H, W, device=device)
+    xs = _to_split_words(x)
+    xv = _from_split_words(xs)                      # the values the kernels multiply (exact in fp32)
+    w = torch.randn(Kout, C, 3, 3, device=device) * 0.05
+    b = torch.randn(Kout, device=device)
+    res = torch.randn(N, Kout, H, W, device=device)
+    gs = torch.linspace(0.5, 1.5, N, device=device)
+    variants = [dict(bias=b, relu=True), dict(bias=None, residual=res), dict(bias=b, gscale=gs)]
+    with ops.conv_precision('bf16x3'), ops.bf16x3_min_rows(32), torch.no_grad():
+        for kw in variants:
+            outs = {}
+            for on in (True, False):
+                with _halo(on):
+                    outs[on] = ops.conv2d(ops.mark_split(xs.clone()), w, kw.get('bias'), 1, 1, residual=kw.get('residual'), relu=kw.get('relu', False),
+                                          gscale=kw.get('gscale'))
+                    name = _lib.query('ag2v_last_conv_kernel')
+                    assert name.startswith(b'conv_halo_bf16x3_kernel') == on, name
+            ref = K.conv2d(xv.cpu(), w.cpu(), None if kw.get('bias') is None else b.cpu(), 1, 1,
+                           residual=None if kw.get('residual') is None else res.cpu(), relu=kw.get('relu', False),
+                           gscale=None if kw.get('gscale') is None else gs.cpu())
+            scale = float(ref.abs().max())
+            assert float((outs[True].cpu() - ref).abs().max()) <= 2e-4 * scale, (sorted(kw), 'oracle')
+            assert float((outs[True] - outs[False]).abs().max()) <= 1e-5 * scale, (sorted(kw), 'previous kernels')
+
+
+@pytest.mark.parametrize("cfg", [(2, 64, 64, 64, 128), (1, 32, 128, 128, 256), (2, 32, 64, 64, 64)], ids=str)
+def test_halo_split_word_output_and_data_gradient(cfg, device):
+    """out_split (relu(mlp_shared) written as split words by the epilogue) and the stride-1 data gradient with its gathered operand dy
+    as split words and the ReLU mask of the convolution's input in the epilogue (ops._conv_dgrad_launch as conv2d's backward calls it)."""
+    from ag2video_amd import _lib, ops
+    from oracle import kernels as K
+    N, C, H, W, Kout = cfg
+    torch.manual_seed(4)
+    xs = _to_split_words(torch.randn(N, C, H, W, device=device))
+    w = torch.randn(Kout, C, 3, 3, device=device) * 0.05
+    with ops.conv_precision('bf16x3'), ops.bf16x3_min_rows(32), torch.no_grad():
+        with _halo(True):
+            ys = ops.conv2d_shared_input(ops.mark_split(xs.clone()), [w], [None], 1, 1, relu=True, grad_premasked=True, out_split=[True])[0]
+            assert _lib.query('ag2v_last_conv_kernel').startswith(b'conv_halo_bf16x3_kernel')
+        ref = K.conv2d(_from_split_words(xs).cpu(), w.cpu(), None, 1, 1, relu=True)
+        got = _from_split_words(ys.detach()).cpu()
+        assert float((got - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
+        # where the ReLU clipped, the split word is the zero word (another summation order may leave a sum within rounding of zero on
+        # the other side: those stay tiny)
+        assert float(got[ref == 0].abs().max()) <= 1e-5 * float(ref.abs().max())
+        assert float((ys.detach().view(torch.int32)[got.to(device) == 0] & 0x7FFF7FFF).abs().max()) == 0
+        # data gradient: dx = conv_transpose(dy, w) masked by (x_in > 0); dy arrives as split words
+        dy = torch.randn(N, Kout, H, W, device=device)
+        dys = _to_split_words(dy)
+        xin = torch.randn(N, C, H, W, device=device)              # the (ReLU output) input of the forward convolution: the mask
+        outs = {}
+        for on in (True, False):
+            with _halo(on):
+                dx = torch.empty(N, C, H, W, device=device)
+                ops._conv_dgrad_launch(32, dys, w, xin, dx, 1, 1, 0, dy_split=True)
+                assert _lib.query('ag2v_last_conv_kernel').startswith(b'conv_halo_bf16x3_kernel') == on
+                outs[on] = dx
+        dyv = _from_split_words(dys).cpu().double()
+        refdx = torch.nn.functional.conv_transpose2d(dyv, w.cpu().double(), None, 1, 1).float() * (xin.cpu() > 0).float()
+        sc = float(refdx.abs().max())
+        assert float((outs[True].cpu() - refdx).abs().max()) <= 2e-4 * sc
+        assert float((outs[True] - outs[False]).abs().max()) <= 1e-5 * sc
