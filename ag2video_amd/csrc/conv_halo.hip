@@ -11,8 +11,11 @@
 // x TW columns and stages, per 16 input channels, ONE image of the (TH + 2) x (TW + 8) input pixels around it: all nine taps read it
 // at different offsets, so memory -> LDS traffic drops ~4x against tap-by-tap gathers and the copy is 1 KiB DMA pieces
 // (lane-linear LDS destination, per-lane source: 64 quads of 4 pixels) whose per-lane offsets are computed once per workgroup -- a
-// stage only moves a wave-uniform SGPR offset.  Padding never reaches LDS: out-of-image quads load from an out-of-range buffer offset
-// (reads 0) and the buffers are cleared once, so either DMA out-of-range semantic (write 0 / write nothing) leaves zeros there.
+// stage only moves a wave-uniform SGPR offset.  Padding costs nothing: out-of-image quads load from an out-of-range buffer offset, for
+// which the DMA writes zeros to the lane's 16 LDS bytes (tools/ubench/lds_dma_probe.hip), so every stage re-creates its own zero border.
+// Workgroups are PERSISTENT (one per CU, which is all the LDS footprint admits): the tail of a tile's pipeline -- which would otherwise
+// fetch nothing -- already loads the first image and weight steps of the workgroup's next tile, so only the first tile of a launch
+// exposes its DMA latency and a tile's epilogue stores run under the next tile's loads.
 // The weights arrive as the bf16 hi / lo planes the tap-major pack kernels already write ([KG/8][M][8], conv_igemm.hip
 // pack_fwd_tap_kernel / pack_dgrad_tap_kernel) and go to a 6-slot LDS ring the same way, one 16-deep k-step (16 channels of one tap)
 // per slot, three steps ahead.
@@ -58,15 +61,17 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int WM, int WN, int EM, int TW, int TH>
+template <int WM, int WN, int EM, int TW, int TH, bool PS>
 struct HaloBody {
     typedef HaloCfg<WM, WN, EM, TW, TH> G;
+    static constexpr unsigned kOut = 0xFFFFFFF0u;       // an out-of-range buffer offset: the DMA writes zeros for that lane
     const ConvArgs& p;
     char* smem;
     __amdgpu_buffer_rsrc_t ars, brs;
     int wave, lane;
-    // DMA state (per lane, fixed for the workgroup)
-    unsigned vA[G::APW], vB[G::PPW];
+    // DMA state: per-lane source offsets of this wave's pieces for the CURRENT tile (vA, vB) and for the workgroup's NEXT tile (vAn,
+    // vBn: the tail of a tile's pipeline already fetches the next tile's first image and weight steps)
+    unsigned vA[G::APW], vB[G::PPW], vAn[G::APW], vBn[G::PPW];
     unsigned dstB0[G::PPW];              // LDS byte offset of this wave's B pieces inside a stage buffer (or the dummy KiB, absolute)
     bool dummyB[G::PPW];
     unsigned dstA[G::APW];               // LDS byte offset inside an A slot (or the dummy KiB, absolute)
@@ -82,21 +87,20 @@ struct HaloBody {
     __device__ __forceinline__ HaloBody(const ConvArgs& p_, char* s) : p(p_), smem(s) {}
 
     template <int U3>
-    __device__ __forceinline__ void dma_a(int Pn) {          // the A step that sits U3 steps into pair Pn (U3 < 18)
+    __device__ __forceinline__ void dma_a(int Pn, const unsigned (&v)[G::APW]) {      // the A step U3 steps into pair Pn (U3 < 18)
         constexpr int slot = U3 % G::NA;
         constexpr int c = (U3 % 9) * 4 + 2 * (U3 / 9);       // k-group row of the step inside its 32-channel chunk: (tap, half)
         const unsigned soff = (unsigned)(Pn * 36 + c) * (unsigned)p.M * 16u;
 #pragma unroll
         for (int j = 0; j < G::APW; ++j) {
             const unsigned dst = dummyA[j] ? dstA[j] : (unsigned)(G::A_OFF + slot * G::ASZ) + dstA[j];
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (lds_vptr)(smem + dst), 16, vA[j], soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (lds_vptr)(smem + dst), 16, v[j], soff, 0, 0);
         }
     }
     template <int K, int BUF>
-    __device__ __forceinline__ void dma_b(int stage) {       // piece round K of stage `stage` into buffer BUF
-        const unsigned soff = (unsigned)stage * 16u * hw4;
+    __device__ __forceinline__ void dma_b(unsigned voff, unsigned soff) {       // piece round K into stage buffer BUF
         const unsigned dst = dummyB[K] ? dstB0[K] : (unsigned)(G::B_OFF + BUF * G::BBYTES) + dstB0[K];
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (lds_vptr)(smem + dst), 16, vB[K], soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (lds_vptr)(smem + dst), 16, voff, soff, 0, 0);
     }
     // Operand registers: set (U & 1) holds step U's A fragments (ah / al) and its B operand already regrouped (bh / bl).
     template <int U1>
@@ -107,25 +111,32 @@ struct HaloBody {
         al[set][i] = *reinterpret_cast<const bf16x8*>(ab + 2 * G::BM * 16 + i * 512);
     }
     template <int U1>
-    __device__ __forceinline__ unsigned load_bw(int j) {     // split word of channel j (of this lane's k group) at step U1's tap
+    __device__ __forceinline__ unsigned load_bw(int j) {     // word of channel j (of this lane's k group) at step U1's tap
         constexpr int buf = (U1 / 9) & 1, tap = U1 % 9, r = tap / 3, s = tap % 3;
         return *reinterpret_cast<const unsigned*>(smem + baseB[buf] + (r * G::RP + s) * 4 + j * G::CHP * 4);
     }
     template <int U1>
-    __device__ __forceinline__ void regroup() {              // 8 split words -> hi / lo bf16x8 operands of set U1 & 1
+    __device__ __forceinline__ void regroup() {              // 8 words -> hi / lo bf16x8 operands of set U1 & 1
         constexpr int set = U1 & 1;
         typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
         u32x4v hv, lv;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            hv[q] = __builtin_amdgcn_perm(bw[2 * q + 1], bw[2 * q], 0x07060302u);
-            lv[q] = __builtin_amdgcn_perm(bw[2 * q + 1], bw[2 * q], 0x05040100u);
+            if constexpr (PS) {          // split words: regroup the halves
+                hv[q] = __builtin_amdgcn_perm(bw[2 * q + 1], bw[2 * q], 0x07060302u);
+                lv[q] = __builtin_amdgcn_perm(bw[2 * q + 1], bw[2 * q], 0x05040100u);
+            } else {                     // fp32 words: the 3-term split here, in the wave that multiplies (6 VALU per pair)
+                unsigned h_, l_;
+                split2(__uint_as_float(bw[2 * q]), __uint_as_float(bw[2 * q + 1]), h_, l_);
+                hv[q] = h_;
+                lv[q] = l_;
+            }
         }
         bh[set] = __builtin_bit_cast(bf16x8, hv);
         bl[set] = __builtin_bit_cast(bf16x8, lv);
     }
     template <int U1>
-    __device__ __forceinline__ void prefetch_all() {         // (prologue) every operand of step U1 at once
+    __device__ __forceinline__ void prefetch_all() {         // (tile start) every operand of step U1 at once
 #pragma unroll
         for (int i = 0; i < EM; ++i) load_a<U1>(i);
 #pragma unroll
@@ -143,7 +154,8 @@ struct HaloBody {
         // step's operands}.  The order is pinned: left alone the scheduler sinks every read to just in front of its use (fewest live
         // registers), which puts an LDS round trip in front of every other MFMA.  The step's DMA pieces are issued BEHIND the first
         // MFMA group: an LDS-DMA instruction takes 60-180 cycles to issue (MI355X_MICROARCH.md constants) and both waves of a SIMD issue
-        // theirs at the same point of the step -- at the top of the step the matrix pipe would idle for that long after every barrier.
+        // theirs at the same point of the step -- at the top of the step the matrix pipe would idle for that long after every barrier
+        // (128-row tile: 446 -> 464 TF).
         constexpr int WPG = 8 / EM;
 #pragma unroll
         for (int g = 0; g < EM; ++g) {
@@ -153,12 +165,16 @@ struct HaloBody {
             acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[set][g], bh[set], acc[g], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (g == 0) {
+                // beyond this tile's last stage / step the pipeline runs on into the NEXT tile of this workgroup (its stage 0 goes to
+                // buffer 0, its steps 0..2 to slots 0..2 -- free by then); without a next tile the offsets are out of range (zeros)
                 if constexpr (tap < G::PPW) {
                     const int st = 2 * P + U / 9 + 1;
-                    dma_b<tap, ((U / 9) + 1) & 1>(st < NS ? st : NS - 1);
+                    const bool nx = st >= NS;
+                    dma_b<tap, ((U / 9) + 1) & 1>(nx ? vBn[tap] : vB[tap], nx ? 0u : (unsigned)st * 16u * hw4);
                 }
-                if constexpr (U + 3 < 18) dma_a<U + 3>(P);
-                else dma_a<U + 3 - 18>(P + 1 <= lastP ? P + 1 : lastP);
+                if constexpr (U + 3 < 18) dma_a<U + 3>(P, vA);
+                else if (P < lastP) dma_a<U + 3 - 18>(P + 1, vA);
+                else dma_a<U + 3 - 18>(0, vAn);
                 __builtin_amdgcn_sched_barrier(0);
             }
             load_a<U + 1>(g);
@@ -170,51 +186,58 @@ struct HaloBody {
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    struct Tile { int n_img, y0, x0, m0; };
+    // source offsets of this wave's DMA pieces for logical tile v (v < 0: none -- every lane out of range)
+    __device__ __forceinline__ Tile describe(int v, unsigned (&va)[G::APW], unsigned (&vb)[G::PPW]) {
+        Tile t = {0, 0, 0, 0};
+        const bool live = v >= 0;
+        const int lid = live ? xcd_remap(v, p.tiles_m * p.tiles_n) : 0;
+        const int tile_m = lid % p.tiles_m, tn = lid / p.tiles_m;
+        const int tcols = p.OW / TW, tpi = (p.OH / TH) * tcols;
+        t.n_img = tn / tpi;
+        const int trem = tn - t.n_img * tpi;
+        t.y0 = (trem / tcols) * TH;
+        t.x0 = (trem % tcols) * TW;
+        t.m0 = tile_m * G::BM;
+        const unsigned lo_plane = (unsigned)(p.KG >> 3) * (unsigned)p.M * 16u;
+#pragma unroll
+        for (int j = 0; j < G::APW; ++j) {
+            const int e = (wave + 8 * j) * 64 + lane;
+            const int plane = e / (2 * G::BM), kg = (e / G::BM) & 1, m = e % G::BM;
+            va[j] = (live && !dummyA[j] && t.m0 + m < p.M) ? (unsigned)plane * lo_plane + (unsigned)(kg * p.M + t.m0 + m) * 16u : kOut;
+        }
+#pragma unroll
+        for (int k = 0; k < G::PPW; ++k) {
+            const int q = (wave + 8 * k) * 64 + lane;
+            const int ch = q / (G::CHP / 4), w = q % (G::CHP / 4);
+            const int row = w / (G::RP / 4), cq = w % (G::RP / 4);
+            const int y = t.y0 - 1 + row, x = t.x0 - 4 + 4 * cq;
+            const bool ok = live && !dummyB[k] && q < G::BQ && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+            vb[k] = ok ? (unsigned)(((t.n_img * p.C + ch) * p.H + y) * p.W + x) * 4u : kOut;
+        }
+        return t;
+    }
+
     __device__ __forceinline__ void run() {
         const int tid = threadIdx.x;
         lane = tid & 63;
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         ars = make_rsrc(p.a_src, p.a_bytes);
         brs = make_rsrc(p.b_src, p.b_bytes);
-        constexpr unsigned kOut = 0xFFFFFFF0u;
         hw4 = (unsigned)(p.H * p.W) * 4u;
         NS = p.C / 16;
         lastP = NS / 2 - 1;
-        // ---- tile
-        const int lid = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-        const int tile_m = lid % p.tiles_m, tn = lid / p.tiles_m;
-        const int tcols = p.OW / TW, tpi = (p.OH / TH) * tcols;
-        const int n_img = tn / tpi, trem = tn - n_img * tpi;
-        const int y0 = (trem / tcols) * TH, x0 = (trem % tcols) * TW;
-        const int m0 = tile_m * G::BM;
-        // ---- clear LDS (padding positions are never written afterwards)
-        // (only the image buffers: a row of the A ring beyond M is never DMA-written either, but it only feeds accumulator rows that
-        // are not stored)
-        for (int o = G::B_OFF + tid * 16; o < G::LDS_BYTES; o += 512 * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0u, 0u, 0u, 0u);
-        // ---- DMA descriptors
-        const unsigned lo_plane = (unsigned)(p.KG >> 3) * (unsigned)p.M * 16u;
 #pragma unroll
         for (int j = 0; j < G::APW; ++j) {
-            const int a = wave + 8 * j;
-            const int e = a * 64 + lane;
-            const int plane = e / (2 * G::BM), kg = (e / G::BM) & 1, m = e % G::BM;
-            dummyA[j] = a >= G::APS;
-            dstA[j] = dummyA[j] ? (unsigned)G::DUMMY_OFF : (unsigned)a * 1024u;
-            vA[j] = (!dummyA[j] && m0 + m < p.M) ? (unsigned)plane * lo_plane + (unsigned)(kg * p.M + m0 + m) * 16u : kOut;
+            dummyA[j] = wave + 8 * j >= G::APS;
+            dstA[j] = dummyA[j] ? (unsigned)G::DUMMY_OFF : (unsigned)(wave + 8 * j) * 1024u;
         }
 #pragma unroll
         for (int k = 0; k < G::PPW; ++k) {
-            const int pc = wave + 8 * k;
-            const int q = pc * 64 + lane;
-            const int ch = q / (G::CHP / 4), w = q % (G::CHP / 4);
-            const int row = w / (G::RP / 4), cq = w % (G::RP / 4);
-            const int y = y0 - 1 + row, x = x0 - 4 + 4 * cq;
-            dummyB[k] = pc >= G::NPB;
-            dstB0[k] = dummyB[k] ? (unsigned)G::DUMMY_OFF : (unsigned)pc * 1024u;
-            const bool ok = !dummyB[k] && q < G::BQ && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-            vB[k] = ok ? (unsigned)(((n_img * p.C + ch) * p.H + y) * p.W + x) * 4u : kOut;
+            dummyB[k] = wave + 8 * k >= G::NPB;
+            dstB0[k] = dummyB[k] ? (unsigned)G::DUMMY_OFF : (unsigned)(wave + 8 * k) * 1024u;
         }
-        // ---- fragment addresses
+        // ---- fragment addresses (the same for every tile)
         const int wm = wave / WN, wn = wave % WN;
         const int wm0 = wm * EM * 32;
         const int pb = wn * 32, ty = pb / TW, tx = pb % TW;
@@ -226,88 +249,100 @@ struct HaloBody {
         // opaque to the optimiser: it would fold the region offsets (up to 150 KB) into the per-read constants, which then no longer fit
         // the 16-bit ds_read offset field and become one address register per (channel, tap) -- dozens of them, spilled
         asm volatile("" : "+v"(baseA[0]), "+v"(baseA[1]), "+v"(baseB[0]), "+v"(baseB[1]));
-#pragma unroll
-        for (int i = 0; i < EM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-        __syncthreads();
-        // ---- prologue: stage 0, A steps 0..2
-        P = 0;
-        if constexpr (G::PPW > 0) dma_b<0, 0>(0);
-        if constexpr (G::PPW > 1) dma_b<1, 0>(0);
-        if constexpr (G::PPW > 2) dma_b<2, 0>(0);
-        if constexpr (G::PPW > 3) dma_b<3, 0>(0);
-        if constexpr (G::PPW > 4) dma_b<4, 0>(0);
-        if constexpr (G::PPW > 5) dma_b<5, 0>(0);
-        dma_a<0>(0);
-        dma_a<1>(0);
-        dma_a<2>(0);
-        wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        prefetch_all<0>();
-        for (P = 0; P <= lastP; ++P) {
-            step<0>(); step<1>(); step<2>(); step<3>(); step<4>(); step<5>(); step<6>(); step<7>(); step<8>();
-            step<9>(); step<10>(); step<11>(); step<12>(); step<13>(); step<14>(); step<15>(); step<16>(); step<17>();
-        }
-        wait_vmcnt<0>();          // (the clamped tail DMAs still target this workgroup's LDS)
-        // ---- epilogue.  Accumulator register r of block i holds row (r & 3) + 8 (r >> 2) + 4 kg, pixel l31 of the wave's 32.
+        // ---- persistent tile loop: workgroup b takes logical tiles b, b + grid, ... (the grid is a multiple of 8, so they stay on the
+        // XCD whose L2 holds the neighbouring tiles: xcd_remap).  The first tile's stage 0 / steps 0..2 are the only exposed DMA latency.
+        const int ntiles = p.tiles_m * p.tiles_n, stride = gridDim.x;
+        int v = blockIdx.x;
+        Tile nxt = describe(v, vAn, vBn);
+        P = lastP;                       // (dma_a's "next tile" form)
+        if constexpr (G::PPW > 0) dma_b<0, 0>(vBn[0], 0u);
+        if constexpr (G::PPW > 1) dma_b<1, 0>(vBn[1 % G::PPW], 0u);
+        if constexpr (G::PPW > 2) dma_b<2, 0>(vBn[2 % G::PPW], 0u);
+        if constexpr (G::PPW > 3) dma_b<3, 0>(vBn[3 % G::PPW], 0u);
+        if constexpr (G::PPW > 4) dma_b<4, 0>(vBn[4 % G::PPW], 0u);
+        if constexpr (G::PPW > 5) dma_b<5, 0>(vBn[5 % G::PPW], 0u);
+        dma_a<0>(0, vAn);
+        dma_a<1>(0, vAn);
+        dma_a<2>(0, vAn);
         const int plane = p.OH * p.OW;
-        const int oy = y0 + ty, ox = x0 + tx + l31;
-        float* obase = p.out + (size_t)n_img * p.M * plane + (size_t)oy * p.OW + ox;
-        const float* rbase = p.residual ? p.residual + (size_t)n_img * p.M * plane + (size_t)oy * p.OW + ox : nullptr;
-        const float* mbase = p.mask ? p.mask + (size_t)n_img * p.M * plane + (size_t)oy * p.OW + ox : nullptr;
-        const float gs = (p.gscale ? p.gscale[n_img / p.group_n] : 1.f) * (p.oscale != 0.f ? p.oscale : 1.f);
-        const float* aux = rbase ? rbase : mbase;           // at most one of them (the entry points reject both)
+        const float* aux0 = p.residual ? p.residual : p.mask;           // at most one of them (the entry points reject both)
         const float ninf = -__builtin_huge_valf();
-        const float rmul = rbase ? 1.f : 0.f;
+        const float rmul = p.residual ? 1.f : 0.f;
         const float relu_floor = p.relu ? 0.f : ninf;
-        const float mask_thr = mbase ? 0.f : ninf;
+        const float mask_thr = (!p.residual && p.mask) ? 0.f : ninf;
         const bool osplit = p.out_split != 0;
+        while (true) {
+            const Tile cur = nxt;
 #pragma unroll
-        for (int i = 0; i < EM; ++i) {
-            const int mblk = m0 + wm0 + i * 32;
-            float bvec = 0.f;
-            if (p.bias) {
-                const int mb = mblk + l31;
-                bvec = (mb < p.M) ? p.bias[mb] : 0.f;
+            for (int j = 0; j < G::APW; ++j) vA[j] = vAn[j];
+#pragma unroll
+            for (int k = 0; k < G::PPW; ++k) vB[k] = vBn[k];
+            v += stride;
+            const bool more = v < ntiles;
+            nxt = describe(more ? v : -1, vAn, vBn);
+#pragma unroll
+            for (int i = 0; i < EM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+            wait_vmcnt<0>();             // this tile's stage 0 and steps 0..2 (issued by the previous tile's tail, or just above)
+            __builtin_amdgcn_s_barrier();
+            prefetch_all<0>();
+            for (P = 0; P <= lastP; ++P) {
+                step<0>(); step<1>(); step<2>(); step<3>(); step<4>(); step<5>(); step<6>(); step<7>(); step<8>();
+                step<9>(); step<10>(); step<11>(); step<12>(); step<13>(); step<14>(); step<15>(); step<16>(); step<17>();
             }
-            float ax[16];
+            // ---- epilogue (the next tile's first pieces are landing meanwhile).  Accumulator register r of block i holds row
+            // (r & 3) + 8 (r >> 2) + 4 kg, pixel l31 of the wave's 32.
+            const size_t pix = (size_t)cur.n_img * p.M * plane + (size_t)(cur.y0 + ty) * p.OW + (cur.x0 + tx + l31);
+            float* obase = p.out + pix;
+            const float* aux = aux0 ? aux0 + pix : nullptr;
+            const float gs = (p.gscale ? p.gscale[cur.n_img / p.group_n] : 1.f) * (p.oscale != 0.f ? p.oscale : 1.f);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) ax[r] = 0.f;
-            if (aux) {
+            for (int i = 0; i < EM; ++i) {
+                const int mblk = cur.m0 + wm0 + i * 32;
+                float bvec = 0.f;
+                if (p.bias) {
+                    const int mb = mblk + l31;
+                    bvec = (mb < p.M) ? p.bias[mb] : 0.f;
+                }
+                float ax[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ax[r] = 0.f;
+                if (aux) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = mblk + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                        if (m < p.M) ax[r] = aux[(size_t)m * plane];
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = mblk + (r & 3) + 8 * (r >> 2) + 4 * kg;
-                    if (m < p.M) ax[r] = aux[(size_t)m * plane];
+                    const int rr = (r & 3) + 8 * (r >> 2);
+                    const float b0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(bvec), rr));
+                    const float b1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(bvec), rr + 4));
+                    float x = fmaf(acc[i][r], gs, kg ? b1 : b0);
+                    x = fmaf(ax[r], rmul, x);
+                    x = fmaxf(x, relu_floor);
+                    x = (ax[r] > mask_thr) ? x : 0.f;
+                    if (osplit) x = pack_split(x);
+                    const int m = mblk + rr + 4 * kg;
+                    if (m < p.M) obase[(size_t)m * plane] = x;
                 }
-                __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0) once per 32-row block
             }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                constexpr int dummy = 0;
-                (void)dummy;
-                const int rr = (r & 3) + 8 * (r >> 2);
-                const float b0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(bvec), rr));
-                const float b1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(bvec), rr + 4));
-                float x = fmaf(acc[i][r], gs, kg ? b1 : b0);
-                x = fmaf(ax[r], rmul, x);
-                x = fmaxf(x, relu_floor);
-                x = (ax[r] > mask_thr) ? x : 0.f;
-                if (osplit) x = pack_split(x);
-                const int m = mblk + rr + 4 * kg;
-                if (m < p.M) obase[(size_t)m * plane] = x;
-            }
+            if (!more) break;
         }
+        wait_vmcnt<0>();          // (the tail DMAs of the last tile -- all out of range -- still target this workgroup's LDS)
     }
 };
 
 #endif
 
-template <int WM, int WN, int EM, int TW, int TH>
+// PS: the gathered tensor holds split words (false: fp32 -- the wave that multiplies splits its own fragment)
+template <int WM, int WN, int EM, int TW, int TH, bool PS>
 __global__ __launch_bounds__(512) void conv_halo_bf16x3_kernel(ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(1024))) char smem[HaloCfg<WM, WN, EM, TW, TH>::LDS_BYTES];
-    HaloBody<WM, WN, EM, TW, TH> body(p, smem);
+    HaloBody<WM, WN, EM, TW, TH, PS> body(p, smem);
     body.run();
 #endif
 }
@@ -329,7 +364,8 @@ static bool halo_geometry(int BN, int OH, int OW, int& TW, int& TH) {
 // Can this launch (as the callers of launch_igemm_bf16x3 describe it) run on the halo kernels?
 bool igemm_halo_ok(const ConvArgs& a) {
     // (read per call, not cached: tools/halo_bench.py and the tests switch kernels inside one process)
-    if (getenv("AG2V_NO_HALO") != nullptr || !a.tap_major || !a.b_split || a.h16 || a.f32) return false;
+    if (getenv("AG2V_NO_HALO") != nullptr || !a.tap_major || a.h16 || a.f32 || a.b_bytes == 0) return false;
+    if (!a.b_split && getenv("AG2V_NO_HALO_F32IN") != nullptr) return false;       // (A/B aid: fp32 gathered tensors on the previous kernels)
     if (a.R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1 || a.pad_w != 1 || a.OH != a.H || a.OW != a.W) return false;
     if (a.C % 32 || a.W % 4 || (a.o_mul != 1 && a.o_mul != 0) || a.o_add_y || a.o_add_x) return false;
     if ((a.o_H && a.o_H != a.OH) || (a.o_W && a.o_W != a.OW)) return false;
@@ -351,11 +387,26 @@ int launch_igemm_halo(ConvArgs& a, hipStream_t st) {
     a.tiles_m = ceil_div(a.M, bm);
     a.tiles_n = a.NG / bn;
     a.splitk = 1;
-    const dim3 grid(a.tiles_m * a.tiles_n);
-#define AG2V_HALO(WM_, WN_, EM_, TW_, TH_)                                                                              \
-    do {                                                                                                                \
-        set_last_conv_kernel("conv_halo_bf16x3_kernel<" #WM_ ", " #WN_ ", " #EM_ ", " #TW_ ", " #TH_ ">");               \
-        hipLaunchKernelGGL((conv_halo_bf16x3_kernel<WM_, WN_, EM_, TW_, TH_>), grid, dim3(512), 0, st, a);                \
+    // persistent workgroups, one per CU (the LDS footprint admits no second one), a multiple of 8 so that a workgroup's tiles stay on
+    // one XCD's share of the logical tile order (xcd_remap)
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n_cu = v & ~7;
+        if (n_cu < 8) n_cu = 8;
+    }
+    const long long ntiles = (long long)a.tiles_m * a.tiles_n;
+    const dim3 grid((unsigned)(ntiles < n_cu ? ntiles : n_cu));
+#define AG2V_HALO(WM_, WN_, EM_, TW_, TH_)                                                                                       \
+    do {                                                                                                                         \
+        if (a.b_split) {                                                                                                         \
+            set_last_conv_kernel("conv_halo_bf16x3_kernel<" #WM_ ", " #WN_ ", " #EM_ ", " #TW_ ", " #TH_ ", true>");              \
+            hipLaunchKernelGGL((conv_halo_bf16x3_kernel<WM_, WN_, EM_, TW_, TH_, true>), grid, dim3(512), 0, st, a);               \
+        } else {                                                                                                                 \
+            set_last_conv_kernel("conv_halo_bf16x3_kernel<" #WM_ ", " #WN_ ", " #EM_ ", " #TW_ ", " #TH_ ", false>");             \
+            hipLaunchKernelGGL((conv_halo_bf16x3_kernel<WM_, WN_, EM_, TW_, TH_, false>), grid, dim3(512), 0, st, a);              \
+        }                                                                                                                        \
     } while (0)
     if (tall) {
         if (tw == 128) AG2V_HALO(2, 4, 4, 128, 1);

@@ -39,6 +39,12 @@ def _rand(*shape, seed=0, device='cpu', scale=1.0):
 # 4 generated frames: 5 frames).
 STEP_CASES = {'c1': (64, 4, 1), 'c2p': (128, 3, 1), 'c3p': (256, 4, 1), 'c5p': (224, 3, 1), 'c5pT': (224, 5, 1)}
 _ORACLE_CACHE = {}
+# imgs_pred bound per case (everything else: 1e-3).  The image error is the flow's fp32-rounding-level error (3e-6 of max in every case
+# and BOTH arithmetics) amplified by the warp of white-noise frames and the decoder behind it, and it is a maximum over
+# all pixels of all generated frames.  Measured over repeated runs (atomics order varies): c3p 7.1-7.4e-4; c5p 7.8-9.3e-4 (bf16x3) and
+# 7.2-8.8e-4 (exact fp32); c5pT -- 4 generated frames instead of 2, i.e. the maximum over twice the pixels -- 9.0e-4 ... 1.24e-3.  The
+# exact-fp32 mode sits at the same level, so this is the conditioning of the input, not the arithmetic: c5pT holds 1.5e-3, the others 1e-3.
+IMG_BOUND = {'c5pT': 1.5e-3}
 
 
 def _case_opt(case):
@@ -130,7 +136,9 @@ def _step_vs_oracle(case, prec, device):
             r = ref['out'][i].numpy()
             err = np.abs(mo[i].detach().cpu().numpy() - r).max()
             worst[name] = err / np.abs(r).max()
-            assert err <= 1e-3 * np.abs(r).max(), (name, err, np.abs(r).max())
+        print('%s [%s] output errors relative to max:' % (case, prec), worst)
+        for i, name in enumerate(('imgs_pred', 'boxes_pred', 'flows_pred')):
+            assert worst[name] <= (IMG_BOUND.get(case, 1e-3) if name == 'imgs_pred' else 1e-3), (name, worst)
         assert np.mean(mo[3].cpu().numpy() != ref['out'][3].numpy()) < 2e-3
         # gradients: abs-sum of every parameter's gradient (bounds: module docstring of tests/test_step_gpu.py)
         bad = []

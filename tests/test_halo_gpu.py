@@ -82,6 +82,15 @@ def test_halo_forward_matches_oracle_and_previous_kernels(cfg, device):
             scale = float(ref.abs().max())
             assert float((outs[True].cpu() - ref).abs().max()) <= 2e-4 * scale, (sorted(kw), 'oracle')
             assert float((outs[True] - outs[False]).abs().max()) <= 1e-5 * scale, (sorted(kw), 'previous kernels')
+        # fp32 gathered tensor (not split words): the same kernels with the 3-term split done by the multiplying wave
+        for on in (True, False):
+            with _halo(on):
+                outs[on] = ops.conv2d(x, w, b, 1, 1)
+                name = _lib.query('ag2v_last_conv_kernel')
+                assert (name.startswith(b'conv_halo_bf16x3_kernel') and name.endswith(b'false>')) == on, name
+        ref = K.conv2d(x.cpu(), w.cpu(), b.cpu(), 1, 1)
+        assert float((outs[True].cpu() - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
+        assert float((outs[True] - outs[False]).abs().max()) <= 1e-5 * float(ref.abs().max())
 
 
 @pytest.mark.parametrize("cfg", [(2, 64, 64, 64, 128), (1, 32, 128, 128, 256), (2, 32, 64, 64, 64)], ids=str)

@@ -4,7 +4,7 @@ usage: halo_bench.py [reps] [shape ...]   shape = N,C,H,W,K      (GPU box only)"
 import os
 import sys
 import torch
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ag2video_amd import ops, _lib
 
 SHAPES = [(31, 512, 256, 256, 128), (40, 384, 256, 256, 512), (60, 128, 256, 256, 256), (60, 256, 256, 256, 128),
