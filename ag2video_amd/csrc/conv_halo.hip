@@ -33,7 +33,7 @@ typedef __attribute__((address_space(3))) void* lds_vptr;
 #define AG2V_HALO_NA 6          // A ring slots (divides the 18-step unrolled body)
 #endif
 
-template <int WM, int WN, int EM, int TW, int TH>
+template <int WM, int WN, int EM, int TW, int TH, bool MF16 = false>
 struct HaloCfg {
     static constexpr int BM = WM * EM * 32, BN = WN * 32;
     static_assert(WM * WN == 8, "8 waves");
@@ -41,7 +41,11 @@ struct HaloCfg {
     static constexpr int CH = 16;                         // channels per stage = one MFMA k-step
     static constexpr int RP = TW + 8, NR = TH + 2;        // staged row pitch (words) / rows: one quad of halo columns each side
     static constexpr int CHP = NR * RP;                   // words per channel
-    static constexpr int BQ = CH * CHP / 4;               // quads per stage
+    // MF16 (16x16x32 MFMAs): lanes 0-15 / 16-31 of a B-fragment read belong to the two 8-channel groups of the stage; a 16-word skew
+    // between the groups puts them on disjoint banks (8 * CHP is a multiple of 32 words for every patch geometry)
+    static constexpr int SKEW = MF16 ? 16 : 0;            // words between channel group 0 and channel group 1
+    static constexpr int G8 = 8 * CHP + SKEW;             // words from group 0 to group 1
+    static constexpr int BQ = (CH * CHP + SKEW) / 4;      // quads per stage
     static constexpr int NPB = (BQ + 63) / 64;            // DMA pieces (64 quads = 1 KiB) per stage
     static constexpr int PPW = (NPB + 7) / 8;             // ... per wave
     static constexpr int BBYTES = NPB * 1024;
@@ -50,7 +54,7 @@ struct HaloCfg {
     static constexpr int APW = (APS + 7) / 8;
     static constexpr int NA = AG2V_HALO_NA;
     static constexpr int A_OFF = 0, B_OFF = NA * ASZ, DUMMY_OFF = B_OFF + 2 * BBYTES, LDS_BYTES = DUMMY_OFF + 1024;
-    static_assert(PPW <= 6, "a stage's pieces must be certified before the next stage's first prefetch");
+    static_assert(PPW <= (MF16 ? 5 : 6), "a stage's pieces must be certified before the next stage's first prefetch");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     static_assert((7 * CHP + 2 * RP + 2) * 4 < 65536 && (2 * ASZ + 3 * BM * 16 + EM * 512) < 65536, "ds_read immediate offsets");
 };
@@ -160,9 +164,26 @@ struct HaloBody {
 #pragma unroll
         for (int g = 0; g < EM; ++g) {
             __builtin_amdgcn_sched_barrier(0);
+#ifndef AG2V_HALO_FAKE16
             acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[set][g], bh[set], acc[g], 0, 0, 0);
             acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[set][g], bl[set], acc[g], 0, 0, 0);
             acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[set][g], bh[set], acc[g], 0, 0, 0);
+#else
+            // TIMING EXPERIMENT ONLY (wrong results): the same operands, matrix-pipe cycles and accumulator registers through the 16x16x32
+            // shape -- does the chip hold a higher clock on it in this loop (MI355X_MICROARCH.md, DVFS give-back item 7)?
+            {
+                f32x4 q0 = __builtin_shufflevector(acc[g], acc[g], 0, 1, 2, 3), q1 = __builtin_shufflevector(acc[g], acc[g], 4, 5, 6, 7);
+                f32x4 q2 = __builtin_shufflevector(acc[g], acc[g], 8, 9, 10, 11), q3 = __builtin_shufflevector(acc[g], acc[g], 12, 13, 14, 15);
+                q0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[set][g], bh[set], q0, 0, 0, 0);
+                q1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[set][g], bh[set], q1, 0, 0, 0);
+                q2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[set][g], bl[set], q2, 0, 0, 0);
+                q3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[set][g], bl[set], q3, 0, 0, 0);
+                q0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[set][g], bh[set], q0, 0, 0, 0);
+                q1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[set][g], bh[set], q1, 0, 0, 0);
+                acc[g] = __builtin_shufflevector(__builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7),
+                                                 __builtin_shufflevector(q2, q3, 0, 1, 2, 3, 4, 5, 6, 7), 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+            }
+#endif
             __builtin_amdgcn_sched_barrier(0);
             if (g == 0) {
                 // beyond this tile's last stage / step the pipeline runs on into the NEXT tile of this workgroup (its stage 0 goes to
@@ -335,6 +356,314 @@ struct HaloBody {
     }
 };
 
+
+// ---- the same pipeline on v_mfma_f32_16x16x32_bf16.  The chip holds a higher clock on this shape (MI355X_MICROARCH.md, DVFS give-back
+// item 7; a timing-only build of the 32x32x16 kernel with its MFMAs replaced one-for-two ran +5 % (128-row tile) / +10 % (256-row tile)).
+// One instruction spans K = 32 = TWO k-steps of the 32x32x16 pipeline: lanes 0-31 (k groups 0, 1) take the 16 channels of step 2D, lanes
+// 32-63 (k groups 2, 3) those of step 2D + 1 -- another tap of the same staged image (or tap 8 of one stage with tap 0 of the next: 18
+// steps per stage pair = 9 double-steps), whose ring slot / image offset differs from the first one's by a compile-time constant that sits
+// in the lane's base address.  One barrier, one counted wait per DOUBLE-step (48 MFMAs per wave at EM = 4).
+template <int WM, int WN, int EM, int TW, int TH, bool PS>
+struct HaloBody16 {
+    typedef HaloCfg<WM, WN, EM, TW, TH, true> G;
+    static constexpr unsigned kOut = 0xFFFFFFF0u;
+    static constexpr int RB = 2 * EM;                    // 16-row blocks of a wave's EM * 32 rows
+    const ConvArgs& p;
+    char* smem;
+    __amdgpu_buffer_rsrc_t ars, brs;
+    int wave, lane;
+    unsigned vA[G::APW], vB[G::PPW], vAn[G::APW], vBn[G::PPW];
+    unsigned dstB0[G::PPW], dstA[G::APW];
+    bool dummyB[G::PPW], dummyA[G::APW];
+    unsigned hw4;
+    int NS, lastP, P;
+    unsigned baseA[3];                   // per slot pair (2 q, 2 q + 1): lanes of the second k half point into the odd slot
+    unsigned baseB[5];                   // per (buffer, offset between the two taps of a double-step): see kidx()
+    bf16x8 ah[RB], al[RB], bh[2], bl[2];
+    unsigned bw[16];
+    f32x4 acc[RB][2];
+
+    __device__ __forceinline__ HaloBody16(const ConvArgs& p_, char* s) : p(p_), smem(s) {}
+
+    // image offset (words) of step u of a stage pair: buffer (u / 9) & 1, tap u % 9
+    static constexpr int tapoff(int u) { return ((u % 9) / 3) * G::RP + (u % 9) % 3; }
+    static constexpr int kidx(int D) { return D == 0 ? 0 : D == 1 ? 1 : D == 2 ? 0 : D == 3 ? 0 : D == 4 ? 2 : D == 5 ? 3 : D == 6 ? 3 : D == 7 ? 4 : 3; }
+    static constexpr int nB(int D) {     // image pieces issued per wave in double-step D: rounds {0,1,2} at D = 0 / 5, {3,4} at D = 1 / 6
+        return (D == 0 || D == 5) ? (G::PPW < 3 ? G::PPW : 3) : (D == 1 || D == 6) ? (G::PPW > 3 ? G::PPW - 3 : 0) : 0;
+    }
+
+    template <int U3>
+    __device__ __forceinline__ void dma_a(int Pn, const unsigned (&v)[G::APW]) {
+        constexpr int slot = U3 % G::NA;
+        constexpr int c = (U3 % 9) * 4 + 2 * (U3 / 9);
+        const unsigned soff = (unsigned)(Pn * 36 + c) * (unsigned)p.M * 16u;
+#pragma unroll
+        for (int j = 0; j < G::APW; ++j) {
+            const unsigned dst = dummyA[j] ? dstA[j] : (unsigned)(G::A_OFF + slot * G::ASZ) + dstA[j];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (lds_vptr)(smem + dst), 16, v[j], soff, 0, 0);
+        }
+    }
+    template <int K, int BUF>
+    __device__ __forceinline__ void dma_b(unsigned voff, unsigned soff) {
+        const unsigned dst = dummyB[K] ? dstB0[K] : (unsigned)(G::B_OFF + BUF * G::BBYTES) + dstB0[K];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (lds_vptr)(smem + dst), 16, voff, soff, 0, 0);
+    }
+    template <int K, int BUF>
+    __device__ __forceinline__ void dma_b_round(int st) {       // round K of stage st (>= NS: the next tile's stage 0)
+        if constexpr (K < G::PPW) {
+            const bool nx = st >= NS;
+            dma_b<K, BUF>(nx ? vBn[K] : vB[K], nx ? 0u : (unsigned)st * 16u * hw4);
+        }
+    }
+    template <int U3>
+    __device__ __forceinline__ void dma_a_ahead() {             // A step U3 (>= 18: next pair, or the next tile's first pair)
+        if constexpr (U3 < 18) dma_a<U3>(P, vA);
+        else if (P < lastP) dma_a<U3 - 18>(P + 1, vA);
+        else dma_a<U3 - 18>(0, vAn);
+    }
+    template <int D1>
+    __device__ __forceinline__ void load_a(int i) {              // row block i of double-step D1 (mod 9)
+        constexpr int q = (D1 % 9) % 3;
+        const char* ab = smem + baseA[q];
+        ah[i] = *reinterpret_cast<const bf16x8*>(ab + i * 256);
+        al[i] = *reinterpret_cast<const bf16x8*>(ab + 2 * G::BM * 16 + i * 256);
+    }
+    template <int D1>
+    __device__ __forceinline__ unsigned load_bw(int c, int j) {  // column block c, channel j of the lane's group
+        constexpr int D = D1 % 9, u = 2 * D;
+        return *reinterpret_cast<const unsigned*>(smem + baseB[kidx(D)] + (tapoff(u) + j * G::CHP + 16 * c) * 4);
+    }
+    __device__ __forceinline__ void regroup() {
+        typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            u32x4v hv, lv;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if constexpr (PS) {
+                    hv[q] = __builtin_amdgcn_perm(bw[8 * c + 2 * q + 1], bw[8 * c + 2 * q], 0x07060302u);
+                    lv[q] = __builtin_amdgcn_perm(bw[8 * c + 2 * q + 1], bw[8 * c + 2 * q], 0x05040100u);
+                } else {
+                    unsigned h_, l_;
+                    split2(__uint_as_float(bw[8 * c + 2 * q]), __uint_as_float(bw[8 * c + 2 * q + 1]), h_, l_);
+                    hv[q] = h_;
+                    lv[q] = l_;
+                }
+            }
+            bh[c] = __builtin_bit_cast(bf16x8, hv);
+            bl[c] = __builtin_bit_cast(bf16x8, lv);
+        }
+    }
+    template <int D1>
+    __device__ __forceinline__ void prefetch_all() {
+#pragma unroll
+        for (int i = 0; i < RB; ++i) load_a<D1>(i);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bw[8 * c + j] = load_bw<D1>(c, j);
+        regroup();
+    }
+    template <int D>
+    __device__ __forceinline__ void dstep() {
+        constexpr int U = 2 * D, PD = (D + 8) % 9;
+        wait_vmcnt<2 * G::APW + nB(PD)>();
+        __builtin_amdgcn_s_barrier();
+        constexpr int WPG = 16 / RB;                 // B words of the next double-step fetched per row-block group
+#pragma unroll
+        for (int g = 0; g < RB; ++g) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[g], bh[c], acc[g][c], 0, 0, 0);
+                acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[g], bl[c], acc[g][c], 0, 0, 0);
+                acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[g], bh[c], acc[g][c], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (g == 0) {
+                // image pieces: the pair's second stage (buffer 1) during double-steps 0, 1; the NEXT pair's (or tile's) first stage
+                // (buffer 0, free once step 8 has been fetched: after barrier 4) during double-steps 5, 6
+                if constexpr (D == 0) { dma_b_round<0, 1>(2 * P + 1); dma_b_round<1, 1>(2 * P + 1); dma_b_round<2, 1>(2 * P + 1); }
+                if constexpr (D == 1) { dma_b_round<3, 1>(2 * P + 1); dma_b_round<4, 1>(2 * P + 1); }
+                if constexpr (D == 5) { dma_b_round<0, 0>(2 * P + 2); dma_b_round<1, 0>(2 * P + 2); dma_b_round<2, 0>(2 * P + 2); }
+                if constexpr (D == 6) { dma_b_round<3, 0>(2 * P + 2); dma_b_round<4, 0>(2 * P + 2); }
+                dma_a_ahead<U + 6>();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (g == 1) {
+                dma_a_ahead<U + 7>();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            load_a<D + 1>(g);
+#pragma unroll
+            for (int j = 0; j < WPG; ++j) {
+                const int w = g * WPG + j;
+                bw[w] = load_bw<D + 1>(w >> 3, w & 7);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        regroup();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    struct Tile { int n_img, y0, x0, m0; };
+    __device__ __forceinline__ Tile describe(int v, unsigned (&va)[G::APW], unsigned (&vb)[G::PPW]) {
+        Tile t = {0, 0, 0, 0};
+        const bool live = v >= 0;
+        const int lid = live ? xcd_remap(v, p.tiles_m * p.tiles_n) : 0;
+        const int tile_m = lid % p.tiles_m, tn = lid / p.tiles_m;
+        const int tcols = p.OW / TW, tpi = (p.OH / TH) * tcols;
+        t.n_img = tn / tpi;
+        const int trem = tn - t.n_img * tpi;
+        t.y0 = (trem / tcols) * TH;
+        t.x0 = (trem % tcols) * TW;
+        t.m0 = tile_m * G::BM;
+        const unsigned lo_plane = (unsigned)(p.KG >> 3) * (unsigned)p.M * 16u;
+#pragma unroll
+        for (int j = 0; j < G::APW; ++j) {
+            const int e = (wave + 8 * j) * 64 + lane;
+            const int plane = e / (2 * G::BM), kg = (e / G::BM) & 1, m = e % G::BM;
+            va[j] = (live && !dummyA[j] && t.m0 + m < p.M) ? (unsigned)plane * lo_plane + (unsigned)(kg * p.M + t.m0 + m) * 16u : kOut;
+        }
+#pragma unroll
+        for (int k = 0; k < G::PPW; ++k) {
+            const int ql = (wave + 8 * k) * 64 + lane;                       // quad position in the LDS image (with the skew hole)
+            const bool hole = ql >= 2 * G::CHP && ql < 2 * G::CHP + G::SKEW / 4;
+            const int q = ql < 2 * G::CHP ? ql : ql - G::SKEW / 4;
+            const int ch = q / (G::CHP / 4), w = q % (G::CHP / 4);
+            const int row = w / (G::RP / 4), cq = w % (G::RP / 4);
+            const int y = t.y0 - 1 + row, x = t.x0 - 4 + 4 * cq;
+            const bool ok = live && !dummyB[k] && !hole && ql < G::BQ && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+            vb[k] = ok ? (unsigned)(((t.n_img * p.C + ch) * p.H + y) * p.W + x) * 4u : kOut;
+        }
+        return t;
+    }
+
+    __device__ __forceinline__ void run() {
+        const int tid = threadIdx.x;
+        lane = tid & 63;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        ars = make_rsrc(p.a_src, p.a_bytes);
+        brs = make_rsrc(p.b_src, p.b_bytes);
+        hw4 = (unsigned)(p.H * p.W) * 4u;
+        NS = p.C / 16;
+        lastP = NS / 2 - 1;
+#pragma unroll
+        for (int j = 0; j < G::APW; ++j) {
+            dummyA[j] = wave + 8 * j >= G::APS;
+            dstA[j] = dummyA[j] ? (unsigned)G::DUMMY_OFF : (unsigned)(wave + 8 * j) * 1024u;
+        }
+#pragma unroll
+        for (int k = 0; k < G::PPW; ++k) {
+            dummyB[k] = wave + 8 * k >= G::NPB;
+            dstB0[k] = dummyB[k] ? (unsigned)G::DUMMY_OFF : (unsigned)(wave + 8 * k) * 1024u;
+        }
+        const int wm = wave / WN, wn = wave % WN;
+        const int wm0 = wm * EM * 32;
+        const int pb = wn * 32, ty = pb / TW, tx = pb % TW;
+        const int l15 = lane & 15, kq = lane >> 4, kg = kq & 1, sub = kq >> 1;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) baseA[q] = (unsigned)(G::A_OFF + (2 * q + sub) * G::ASZ + kg * G::BM * 16 + (wm0 + l15) * 16);
+        const int lb = (kg * G::G8 + ty * G::RP + tx + l15 + 3) * 4;
+        const int d_next = 4, d_row = (G::RP - 2) * 4, d_stage = G::BBYTES - (2 * G::RP + 2) * 4;
+        baseB[0] = (unsigned)(G::B_OFF + lb + sub * d_next);
+        baseB[1] = (unsigned)(G::B_OFF + lb + sub * d_row);
+        baseB[2] = (unsigned)(G::B_OFF + lb + sub * d_stage);
+        baseB[3] = (unsigned)(G::B_OFF + G::BBYTES + lb + sub * d_next);
+        baseB[4] = (unsigned)(G::B_OFF + G::BBYTES + lb + sub * d_row);
+        asm volatile("" : "+v"(baseA[0]), "+v"(baseA[1]), "+v"(baseA[2]), "+v"(baseB[0]), "+v"(baseB[1]), "+v"(baseB[2]), "+v"(baseB[3]), "+v"(baseB[4]));
+        const int ntiles = p.tiles_m * p.tiles_n, stride = gridDim.x;
+        int v = blockIdx.x;
+        Tile nxt = describe(v, vAn, vBn);
+        P = lastP;
+        NS = NS;
+        {   // first tile: its stage 0 (as "the next tile's") and A steps 0..5
+            const int keepNS = NS;
+            NS = 0;                       // every stage index counts as "beyond": dma_b_round takes vBn with offset 0
+            dma_b_round<0, 0>(0); dma_b_round<1, 0>(0); dma_b_round<2, 0>(0); dma_b_round<3, 0>(0); dma_b_round<4, 0>(0);
+            NS = keepNS;
+        }
+        dma_a<0>(0, vAn); dma_a<1>(0, vAn); dma_a<2>(0, vAn); dma_a<3>(0, vAn); dma_a<4>(0, vAn); dma_a<5>(0, vAn);
+        const int plane = p.OH * p.OW;
+        const float* aux0 = p.residual ? p.residual : p.mask;
+        const float ninf = -__builtin_huge_valf();
+        const float rmul = p.residual ? 1.f : 0.f;
+        const float relu_floor = p.relu ? 0.f : ninf;
+        const float mask_thr = (!p.residual && p.mask) ? 0.f : ninf;
+        const bool osplit = p.out_split != 0;
+        const int l31 = lane & 31, up = lane >> 5;
+        while (true) {
+            const Tile cur = nxt;
+#pragma unroll
+            for (int j = 0; j < G::APW; ++j) vA[j] = vAn[j];
+#pragma unroll
+            for (int k = 0; k < G::PPW; ++k) vB[k] = vBn[k];
+            v += stride;
+            const bool more = v < ntiles;
+            nxt = describe(more ? v : -1, vAn, vBn);
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][c][r] = 0.f;
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            prefetch_all<0>();
+            for (P = 0; P <= lastP; ++P) {
+                dstep<0>(); dstep<1>(); dstep<2>(); dstep<3>(); dstep<4>(); dstep<5>(); dstep<6>(); dstep<7>(); dstep<8>();
+            }
+            // ---- epilogue.  Tile (i, c) register r: row 16 i + 4 (lane >> 4) + r, pixel 16 c + (lane & 15).  One v_permlane16_swap per
+            // register pair (c = 0, 1) turns them into X: row 16 i + r + 8 (lane >> 5), Y: row 16 i + 4 + r + 8 (lane >> 5), pixel lane & 31:
+            // two 128-byte row runs per store instruction.
+            const size_t pix = (size_t)cur.n_img * p.M * plane + (size_t)(cur.y0 + ty) * p.OW + (cur.x0 + tx + l31);
+            float* obase = p.out + pix;
+            const float* aux = aux0 ? aux0 + pix : nullptr;
+            const float gs = (p.gscale ? p.gscale[cur.n_img / p.group_n] : 1.f) * (p.oscale != 0.f ? p.oscale : 1.f);
+            typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                const int mblk = cur.m0 + wm0 + i * 16;
+                float bvec = 0.f;
+                if (p.bias) {
+                    const int mb = mblk + l15;
+                    bvec = (mb < p.M) ? p.bias[mb] : 0.f;
+                }
+                float val[8], ax[8];
+                int mrow[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const u32x2v t = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[i][0][r]), __float_as_uint(acc[i][1][r]), false, false);
+                    val[r] = __uint_as_float(t[0]);          // X: row r + 8 up
+                    val[4 + r] = __uint_as_float(t[1]);      // Y: row 4 + r + 8 up
+                    mrow[r] = mblk + r + 8 * up;
+                    mrow[4 + r] = mblk + 4 + r + 8 * up;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) ax[k] = 0.f;
+                if (aux) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (mrow[k] < p.M) ax[k] = aux[(size_t)mrow[k] * plane];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int rr = (k & 3) + 4 * (k >> 2);       // row inside the 16-row block for lanes < 32 (lanes >= 32: + 8)
+                    const float b0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(bvec), rr));
+                    const float b1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(bvec), rr + 8));
+                    float x = fmaf(val[k], gs, up ? b1 : b0);
+                    x = fmaf(ax[k], rmul, x);
+                    x = fmaxf(x, relu_floor);
+                    x = (ax[k] > mask_thr) ? x : 0.f;
+                    if (osplit) x = pack_split(x);
+                    if (mrow[k] < p.M) obase[(size_t)mrow[k] * plane] = x;
+                }
+            }
+            if (!more) break;
+        }
+        wait_vmcnt<0>();
+    }
+};
 #endif
 
 // PS: the gathered tensor holds split words (false: fp32 -- the wave that multiplies splits its own fragment)
@@ -343,6 +672,15 @@ __global__ __launch_bounds__(512) void conv_halo_bf16x3_kernel(ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(1024))) char smem[HaloCfg<WM, WN, EM, TW, TH>::LDS_BYTES];
     HaloBody<WM, WN, EM, TW, TH, PS> body(p, smem);
+    body.run();
+#endif
+}
+// the 16x16x32 form (HaloBody16)
+template <int WM, int WN, int EM, int TW, int TH, bool PS>
+__global__ __launch_bounds__(512) void conv_halo16_bf16x3_kernel(ConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(1024))) char smem[HaloCfg<WM, WN, EM, TW, TH, true>::LDS_BYTES];
+    HaloBody16<WM, WN, EM, TW, TH, PS> body(p, smem);
     body.run();
 #endif
 }
@@ -398,9 +736,16 @@ int launch_igemm_halo(ConvArgs& a, hipStream_t st) {
     }
     const long long ntiles = (long long)a.tiles_m * a.tiles_n;
     const dim3 grid((unsigned)(ntiles < n_cu ? ntiles : n_cu));
+    const bool mf16 = getenv("AG2V_HALO_MFMA32") == nullptr;          // (A/B aid: the 32x32x16 form)
 #define AG2V_HALO(WM_, WN_, EM_, TW_, TH_)                                                                                       \
     do {                                                                                                                         \
-        if (a.b_split) {                                                                                                         \
+        if (mf16 && a.b_split) {                                                                                                 \
+            set_last_conv_kernel("conv_halo16_bf16x3_kernel<" #WM_ ", " #WN_ ", " #EM_ ", " #TW_ ", " #TH_ ", true>");            \
+            hipLaunchKernelGGL((conv_halo16_bf16x3_kernel<WM_, WN_, EM_, TW_, TH_, true>), grid, dim3(512), 0, st, a);             \
+        } else if (mf16) {                                                                                                       \
+            set_last_conv_kernel("conv_halo16_bf16x3_kernel<" #WM_ ", " #WN_ ", " #EM_ ", " #TW_ ", " #TH_ ", false>");           \
+            hipLaunchKernelGGL((conv_halo16_bf16x3_kernel<WM_, WN_, EM_, TW_, TH_, false>), grid, dim3(512), 0, st, a);            \
+        } else if (a.b_split) {                                                                                                         \
             set_last_conv_kernel("conv_halo_bf16x3_kernel<" #WM_ ", " #WN_ ", " #EM_ ", " #TW_ ", " #TH_ ", true>");              \
             hipLaunchKernelGGL((conv_halo_bf16x3_kernel<WM_, WN_, EM_, TW_, TH_, true>), grid, dim3(512), 0, st, a);               \
         } else {                                                                                                                 \

@@ -26,14 +26,19 @@ def _from_split_words(t):
 
 
 class _halo(object):
+    """on: False = the previous kernels; True / '16' = the 16x16x32 halo kernels (the default); '32' = the 32x32x16 halo kernels."""
+
     def __init__(self, on):
         self.on = on
 
     def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in ('AG2V_NO_HALO', 'AG2V_HALO_MIN_TILES')}
+        self.old = {k: os.environ.get(k) for k in ('AG2V_NO_HALO', 'AG2V_HALO_MIN_TILES', 'AG2V_HALO_MFMA32')}
         os.environ['AG2V_HALO_MIN_TILES'] = '1'
+        os.environ.pop('AG2V_HALO_MFMA32', None)
         if self.on:
             os.environ.pop('AG2V_NO_HALO', None)
+            if self.on == '32':
+                os.environ['AG2V_HALO_MFMA32'] = '1'
         else:
             os.environ['AG2V_NO_HALO'] = '1'
 
@@ -70,27 +75,29 @@ def test_halo_forward_matches_oracle_and_previous_kernels(cfg, device):
     with ops.conv_precision('bf16x3'), ops.bf16x3_min_rows(32), torch.no_grad():
         for kw in variants:
             outs = {}
-            for on in (True, False):
+            for on in (True, '32', False):
                 with _halo(on):
                     outs[on] = ops.conv2d(ops.mark_split(xs.clone()), w, kw.get('bias'), 1, 1, residual=kw.get('residual'), relu=kw.get('relu', False),
                                           gscale=kw.get('gscale'))
                     name = _lib.query('ag2v_last_conv_kernel')
-                    assert name.startswith(b'conv_halo_bf16x3_kernel') == on, name
+                    assert name.startswith({True: b'conv_halo16_bf16x3_kernel', '32': b'conv_halo_bf16x3_kernel', False: b'conv_igemm'}[on]), name
             ref = K.conv2d(xv.cpu(), w.cpu(), None if kw.get('bias') is None else b.cpu(), 1, 1,
                            residual=None if kw.get('residual') is None else res.cpu(), relu=kw.get('relu', False),
                            gscale=None if kw.get('gscale') is None else gs.cpu())
             scale = float(ref.abs().max())
-            assert float((outs[True].cpu() - ref).abs().max()) <= 2e-4 * scale, (sorted(kw), 'oracle')
-            assert float((outs[True] - outs[False]).abs().max()) <= 1e-5 * scale, (sorted(kw), 'previous kernels')
+            for fam in (True, '32'):
+                assert float((outs[fam].cpu() - ref).abs().max()) <= 2e-4 * scale, (sorted(kw), fam, 'oracle')
+                assert float((outs[fam] - outs[False]).abs().max()) <= 1e-5 * scale, (sorted(kw), fam, 'previous kernels')
         # fp32 gathered tensor (not split words): the same kernels with the 3-term split done by the multiplying wave
-        for on in (True, False):
+        for on in (True, '32', False):
             with _halo(on):
                 outs[on] = ops.conv2d(x, w, b, 1, 1)
                 name = _lib.query('ag2v_last_conv_kernel')
-                assert (name.startswith(b'conv_halo_bf16x3_kernel') and name.endswith(b'false>')) == on, name
+                assert (name.startswith(b'conv_halo') and name.endswith(b'false>')) == bool(on), name
         ref = K.conv2d(x.cpu(), w.cpu(), b.cpu(), 1, 1)
-        assert float((outs[True].cpu() - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
-        assert float((outs[True] - outs[False]).abs().max()) <= 1e-5 * float(ref.abs().max())
+        for fam in (True, '32'):
+            assert float((outs[fam].cpu() - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
+            assert float((outs[fam] - outs[False]).abs().max()) <= 1e-5 * float(ref.abs().max())
 
 
 @pytest.mark.parametrize("cfg", [(2, 64, 64, 64, 128), (1, 32, 128, 128, 256), (2, 32, 64, 64, 64)], ids=str)
@@ -104,29 +111,31 @@ def test_halo_split_word_output_and_data_gradient(cfg, device):
     xs = _to_split_words(torch.randn(N, C, H, W, device=device))
     w = torch.randn(Kout, C, 3, 3, device=device) * 0.05
     with ops.conv_precision('bf16x3'), ops.bf16x3_min_rows(32), torch.no_grad():
-        with _halo(True):
-            ys = ops.conv2d_shared_input(ops.mark_split(xs.clone()), [w], [None], 1, 1, relu=True, grad_premasked=True, out_split=[True])[0]
-            assert _lib.query('ag2v_last_conv_kernel').startswith(b'conv_halo_bf16x3_kernel')
         ref = K.conv2d(_from_split_words(xs).cpu(), w.cpu(), None, 1, 1, relu=True)
-        got = _from_split_words(ys.detach()).cpu()
-        assert float((got - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
-        # where the ReLU clipped, the split word is the zero word (another summation order may leave a sum within rounding of zero on
-        # the other side: those stay tiny)
-        assert float(got[ref == 0].abs().max()) <= 1e-5 * float(ref.abs().max())
-        assert float((ys.detach().view(torch.int32)[got.to(device) == 0] & 0x7FFF7FFF).abs().max()) == 0
+        for fam in (True, '32'):
+            with _halo(fam):
+                ys = ops.conv2d_shared_input(ops.mark_split(xs.clone()), [w], [None], 1, 1, relu=True, grad_premasked=True, out_split=[True])[0]
+                assert _lib.query('ag2v_last_conv_kernel').startswith(b'conv_halo')
+            got = _from_split_words(ys.detach()).cpu()
+            assert float((got - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
+            # where the ReLU clipped, the split word is the zero word (another summation order may leave a sum within rounding of zero
+            # on the other side: those stay tiny)
+            assert float(got[ref == 0].abs().max()) <= 1e-5 * float(ref.abs().max())
+            assert float((ys.detach().view(torch.int32)[got.to(device) == 0] & 0x7FFF7FFF).abs().max()) == 0
         # data gradient: dx = conv_transpose(dy, w) masked by (x_in > 0); dy arrives as split words
         dy = torch.randn(N, Kout, H, W, device=device)
         dys = _to_split_words(dy)
         xin = torch.randn(N, C, H, W, device=device)              # the (ReLU output) input of the forward convolution: the mask
         outs = {}
-        for on in (True, False):
+        for on in (True, '32', False):
             with _halo(on):
                 dx = torch.empty(N, C, H, W, device=device)
                 ops._conv_dgrad_launch(32, dys, w, xin, dx, 1, 1, 0, dy_split=True)
-                assert _lib.query('ag2v_last_conv_kernel').startswith(b'conv_halo_bf16x3_kernel') == on
+                assert _lib.query('ag2v_last_conv_kernel').startswith(b'conv_halo') == bool(on)
                 outs[on] = dx
         dyv = _from_split_words(dys).cpu().double()
         refdx = torch.nn.functional.conv_transpose2d(dyv, w.cpu().double(), None, 1, 1).float() * (xin.cpu() > 0).float()
         sc = float(refdx.abs().max())
-        assert float((outs[True].cpu() - refdx).abs().max()) <= 2e-4 * sc
-        assert float((outs[True] - outs[False]).abs().max()) <= 1e-5 * sc
+        for fam in (True, '32'):
+            assert float((outs[fam].cpu() - refdx).abs().max()) <= 2e-4 * sc
+            assert float((outs[fam] - outs[False]).abs().max()) <= 1e-5 * sc

@@ -1,6 +1,6 @@
 """A/B of the halo-tile LDS-DMA convolution kernels (csrc/conv_halo.hip) against the wave-specialised split-word kernels they replace
 (conv_igemm_bf16x3_ps_kernel), in ONE process, alternating: forward and stride-1 data gradient on split-word operands.
-usage: halo_bench.py [reps] [shape ...]   shape = N,C,H,W,K      (GPU box only)"""
+usage: halo_bench.py [reps] [shape ...]   shape = N,C,H,W,K      (GPU box only; HALO_BASE=32: "old" = the 32x32x16 halo kernels)"""
 import os
 import sys
 import torch
@@ -49,9 +49,10 @@ def main():
             for mode in ('old', 'new'):
                 os.environ.pop('AG2V_NO_HALO', None)
                 if mode == 'old':
-                    os.environ['AG2V_NO_HALO'] = '1'
+                    os.environ['AG2V_NO_HALO' if os.environ.get('HALO_BASE') != '32' else 'AG2V_HALO_MFMA32'] = '1'
                 res[mode] = fwd()
                 names[mode] = _lib.query('ag2v_last_conv_kernel').decode()
+                os.environ.pop('AG2V_HALO_MFMA32', None)
             torch.cuda.synchronize()
             err = float((res['new'] - res['old']).abs().max() / res['old'].abs().max())
             # fp64 reference on a corner crop of image 0 and of the last image (padding taps included)
@@ -64,8 +65,9 @@ def main():
             for rnd in range(3):
                 for mode in ('old', 'new'):
                     os.environ.pop('AG2V_NO_HALO', None)
+                    os.environ.pop('AG2V_HALO_MFMA32', None)
                     if mode == 'old':
-                        os.environ['AG2V_NO_HALO'] = '1'
+                        os.environ['AG2V_NO_HALO' if os.environ.get('HALO_BASE') != '32' else 'AG2V_HALO_MFMA32'] = '1'
                     fwd()
                     t[mode].append(timed(fwd, reps))
             os.environ.pop('AG2V_NO_HALO', None)
