@@ -368,6 +368,12 @@ struct HaloBody16 {
     typedef HaloCfg<WM, WN, EM, TW, TH, true> G;
     static constexpr unsigned kOut = 0xFFFFFFF0u;
     static constexpr int RB = 2 * EM;                    // 16-row blocks of a wave's EM * 32 rows
+    // HALFWIN (EM = 4): the A fragments of a double-step are fetched in two halves -- row blocks 0 .. RB/2 - 1 during the previous
+    // double-step, RB/2 .. RB - 1 during the double-step itself (5 instead of 8 row blocks live: the full window pushed loop invariants
+    // into scratch).  The ring slots of double-step D are then still being read during D, so the DMA pieces that refill them are issued
+    // by row halves: the rows of the early blocks three double-steps ahead (as before), the rows of the late blocks only TWO ahead, i.e.
+    // after the barrier that ends their last readers' double-step.  A wave's pieces all lie in one row half (lateA).
+    static constexpr bool HALFWIN = EM == 4;
     const ConvArgs& p;
     char* smem;
     __amdgpu_buffer_rsrc_t ars, brs;
@@ -377,6 +383,7 @@ struct HaloBody16 {
     bool dummyB[G::PPW], dummyA[G::APW];
     unsigned hw4;
     int NS, lastP, P;
+    bool lateA;                          // this wave's A pieces hold rows of the late row blocks (HALFWIN)
     unsigned baseA[3];                   // per slot pair (2 q, 2 q + 1): lanes of the second k half point into the odd slot
     unsigned baseB[5];                   // per (buffer, offset between the two taps of a double-step): see kidx()
     bf16x8 ah[RB], al[RB], bh[2], bl[2];
@@ -457,7 +464,7 @@ struct HaloBody16 {
     template <int D1>
     __device__ __forceinline__ void prefetch_all() {
 #pragma unroll
-        for (int i = 0; i < RB; ++i) load_a<D1>(i);
+        for (int i = 0; i < (HALFWIN ? RB / 2 : RB); ++i) load_a<D1>(i);       // (HALFWIN: the second half follows inside the double-step)
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -487,14 +494,21 @@ struct HaloBody16 {
                 if constexpr (D == 1) { dma_b_round<3, 1>(2 * P + 1); dma_b_round<4, 1>(2 * P + 1); }
                 if constexpr (D == 5) { dma_b_round<0, 0>(2 * P + 2); dma_b_round<1, 0>(2 * P + 2); dma_b_round<2, 0>(2 * P + 2); }
                 if constexpr (D == 6) { dma_b_round<3, 0>(2 * P + 2); dma_b_round<4, 0>(2 * P + 2); }
-                dma_a_ahead<U + 6>();
+                if (HALFWIN && lateA) dma_a_ahead<U + 4>();
+                else dma_a_ahead<U + 6>();
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (g == 1) {
-                dma_a_ahead<U + 7>();
+                if (HALFWIN && lateA) dma_a_ahead<U + 5>();
+                else dma_a_ahead<U + 7>();
                 __builtin_amdgcn_sched_barrier(0);
             }
-            load_a<D + 1>(g);
+            if constexpr (HALFWIN) {         // row block g + RB/2 of this double-step, then row blocks 0 .. RB/2 - 1 of the next
+                if (g < RB / 2) load_a<D>(g + RB / 2);
+                else load_a<D + 1>(g - RB / 2);
+            } else {
+                load_a<D + 1>(g);
+            }
 #pragma unroll
             for (int j = 0; j < WPG; ++j) {
                 const int w = g * WPG + j;
@@ -562,6 +576,9 @@ struct HaloBody16 {
         const int wm0 = wm * EM * 32;
         const int pb = wn * 32, ty = pb / TW, tx = pb % TW;
         const int l15 = lane & 15, kq = lane >> 4, kg = kq & 1, sub = kq >> 1;
+        // piece a = wave (+ 8): 64 consecutive rows of one (plane, k group); rows [64 h, 64 h + 64) are the early (h even) / late (h odd)
+        // row blocks of the waves that own rows [128 (h / 2), + 128)
+        lateA = HALFWIN && (((wave * 64) % G::BM) / 64) % 2 == 1;
 #pragma unroll
         for (int q = 0; q < 3; ++q) baseA[q] = (unsigned)(G::A_OFF + (2 * q + sub) * G::ASZ + kg * G::BM * 16 + (wm0 + l15) * 16);
         const int lb = (kg * G::G8 + ty * G::RP + tx + l15 + 3) * 4;
@@ -583,7 +600,8 @@ struct HaloBody16 {
             dma_b_round<0, 0>(0); dma_b_round<1, 0>(0); dma_b_round<2, 0>(0); dma_b_round<3, 0>(0); dma_b_round<4, 0>(0);
             NS = keepNS;
         }
-        dma_a<0>(0, vAn); dma_a<1>(0, vAn); dma_a<2>(0, vAn); dma_a<3>(0, vAn); dma_a<4>(0, vAn); dma_a<5>(0, vAn);
+        dma_a<0>(0, vAn); dma_a<1>(0, vAn); dma_a<2>(0, vAn); dma_a<3>(0, vAn);
+        if (!(HALFWIN && lateA)) { dma_a<4>(0, vAn); dma_a<5>(0, vAn); }       // (late-row pieces run two double-steps ahead, not three)
         const int plane = p.OH * p.OW;
         const float* aux0 = p.residual ? p.residual : p.mask;
         const float ninf = -__builtin_huge_valf();
@@ -592,6 +610,7 @@ struct HaloBody16 {
         const float mask_thr = (!p.residual && p.mask) ? 0.f : ninf;
         const bool osplit = p.out_split != 0;
         const int l31 = lane & 31, up = lane >> 5;
+        bool first = true, full_prev = false;
         while (true) {
             const Tile cur = nxt;
 #pragma unroll
@@ -607,58 +626,135 @@ struct HaloBody16 {
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[i][c][r] = 0.f;
-            wait_vmcnt<0>();
+            // this tile's stage 0 and A steps 0..5 (issued by the previous tile's tail, or just above) have landed.  They are OLDER than
+            // the previous tile's 2 RB epilogue stores, which may stay in flight (vmcnt counts in issue order); a tile whose last row block
+            // is partly outside M issues fewer stores, so it waits for everything.
+            if (first || !full_prev) wait_vmcnt<0>();
+            else wait_vmcnt<2 * RB>();
+            first = false;
+            full_prev = cur.m0 + G::BM <= p.M;
             __builtin_amdgcn_s_barrier();
             prefetch_all<0>();
             for (P = 0; P <= lastP; ++P) {
                 dstep<0>(); dstep<1>(); dstep<2>(); dstep<3>(); dstep<4>(); dstep<5>(); dstep<6>(); dstep<7>(); dstep<8>();
             }
             // ---- epilogue.  Tile (i, c) register r: row 16 i + 4 (lane >> 4) + r, pixel 16 c + (lane & 15).  One v_permlane16_swap per
-            // register pair (c = 0, 1) turns them into X: row 16 i + r + 8 (lane >> 5), Y: row 16 i + 4 + r + 8 (lane >> 5), pixel lane & 31:
-            // two 128-byte row runs per store instruction.
-            const size_t pix = (size_t)cur.n_img * p.M * plane + (size_t)(cur.y0 + ty) * p.OW + (cur.x0 + tx + l31);
+            // register pair (c = 0, 1) gives X: row 16 i + r + 8 (lane >> 5), Y: row 16 i + 4 + r + 8 (lane >> 5), pixel lane & 31; a 4 x 4
+            // transpose between the four registers r and the four lanes of a quad (two DPP quad_perm exchange stages) then leaves every
+            // lane FOUR CONSECUTIVE PIXELS of row (lane & 3): 16-byte stores, 8 row runs of 128 bytes per instruction and a quarter of
+            // the store instructions -- the tile's 128 KB used to leave as 512 dword wave-stores, ~10 us of store ISSUE per tile with
+            // the matrix pipe idle (cdna_hip_programming.md T21; 19 k-steps' worth on a 128-row tile).
+            const int qrow = lane & 3, qpx = 4 * (l31 >> 2);
+            const size_t pix = (size_t)cur.n_img * p.M * plane + (size_t)(cur.y0 + ty) * p.OW + (cur.x0 + tx + qpx);
             float* obase = p.out + pix;
             const float* aux = aux0 ? aux0 + pix : nullptr;
             const float gs = (p.gscale ? p.gscale[cur.n_img / p.group_n] : 1.f) * (p.oscale != 0.f ? p.oscale : 1.f);
             typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+            const bool odd1 = (lane & 1) != 0, odd2 = (lane & 2) != 0;
+            // 2 x 2 transposes of (register pair) x (lane pair): the even lane keeps e[r] and takes its partner's e[r] as e[r'], the odd lane
+            // takes its partner's e[r'] as e[r] and keeps e[r']
+            auto transpose4 = [&](float (&e)[4]) {       // e[r] of lane q  ->  e[j] = (old e[q] of lane j), within each quad of lanes
+                // stage 1 (lane bit 0 <-> register bit 0): pairs (0, 1), (2, 3)
 #pragma unroll
-            for (int i = 0; i < RB; ++i) {
-                const int mblk = cur.m0 + wm0 + i * 16;
-                float bvec = 0.f;
-                if (p.bias) {
-                    const int mb = mblk + l15;
-                    bvec = (mb < p.M) ? p.bias[mb] : 0.f;
+                for (int r = 0; r < 4; r += 2) {
+                    const float t0 = __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(e[r + 1]), 0xB1, 0xF, 0xF, true));   // from lane ^ 1
+                    const float t1 = __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(e[r]), 0xB1, 0xF, 0xF, true));
+                    const float a = odd1 ? t0 : e[r], b = odd1 ? e[r + 1] : t1;
+                    e[r] = a; e[r + 1] = b;
                 }
-                float val[8], ax[8];
-                int mrow[8];
+                // stage 2 (lane bit 1 <-> register bit 1): pairs (0, 2), (1, 3)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const u32x2v t = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[i][0][r]), __float_as_uint(acc[i][1][r]), false, false);
-                    val[r] = __uint_as_float(t[0]);          // X: row r + 8 up
-                    val[4 + r] = __uint_as_float(t[1]);      // Y: row 4 + r + 8 up
-                    mrow[r] = mblk + r + 8 * up;
-                    mrow[4 + r] = mblk + 4 + r + 8 * up;
+                for (int r = 0; r < 2; ++r) {
+                    const float t0 = __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(e[r + 2]), 0x4E, 0xF, 0xF, true));   // from lane ^ 2
+                    const float t1 = __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(e[r]), 0x4E, 0xF, 0xF, true));
+                    const float a = odd2 ? t0 : e[r], b = odd2 ? e[r + 2] : t1;
+                    e[r] = a; e[r + 2] = b;
                 }
+            };
+            // Residual / mask words and bias values are fetched by BRANCH-FREE loads (a null pointer is replaced by the output itself and
+            // the value discarded by a select; rows beyond M are clamped), in two batches of RB / 2 row blocks, ordered
+            //   loads 1 | results 1 | loads 2 | stores 1 | results 2 | stores 2
+            // so that no load is ever younger than a store it does not depend on: vmcnt counts in issue order, and a load under a condition
+            // (or behind stores) makes the wait for it cover those stores as well -- the first version of this epilogue had one such
+            // wait in front of each of its 2 RB stores, i.e. 2 RB serialised memory round trips per tile.  Two batches instead of one keep
+            // the epilogue within the register budget of the main loop (one batch: 64 more live registers, spilled loop invariants).
+            constexpr int HB = RB / 2;
+            const int rx = qrow + 8 * up, ry = rx + 4;
+            const bool has_bias = p.bias != nullptr, has_aux = aux0 != nullptr;
+            // (without a residual / mask the placeholder loads all read the first 16 bytes of the output: one cached line, not a pass
+            // over the tile's own output rows -- that version doubled the epilogue's memory traffic)
+            const float* bsrc = has_bias ? p.bias : p.out;
+            const float* asrc = has_aux ? aux : p.out;
+            const size_t astride = has_aux ? (size_t)plane : 0;
+            float bv[HB];
+            float4 axs[HB], ays[HB], ox[HB], oy[HB];
+            auto loads = [&](int h) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) ax[k] = 0.f;
-                if (aux) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k)
-                        if (mrow[k] < p.M) ax[k] = aux[(size_t)mrow[k] * plane];
+                for (int k = 0; k < HB; ++k) {
+                    const int mblk = cur.m0 + wm0 + (h * HB + k) * 16;
+                    const int mb = min(mblk + l15, p.M - 1), mxc = min(mblk + rx, p.M - 1), myc = min(mblk + ry, p.M - 1);
+                    bv[k] = bsrc[has_bias ? mb : 0];
+                    axs[k] = *reinterpret_cast<const float4*>(asrc + (size_t)mxc * astride);
+                    ays[k] = *reinterpret_cast<const float4*>(asrc + (size_t)myc * astride);
                 }
+            };
+            auto results = [&](int h) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int rr = (k & 3) + 4 * (k >> 2);       // row inside the 16-row block for lanes < 32 (lanes >= 32: + 8)
-                    const float b0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(bvec), rr));
-                    const float b1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(bvec), rr + 8));
-                    float x = fmaf(val[k], gs, up ? b1 : b0);
-                    x = fmaf(ax[k], rmul, x);
-                    x = fmaxf(x, relu_floor);
-                    x = (ax[k] > mask_thr) ? x : 0.f;
-                    if (osplit) x = pack_split(x);
-                    if (mrow[k] < p.M) obase[(size_t)mrow[k] * plane] = x;
+                for (int k = 0; k < HB; ++k) {
+                    const int i = h * HB + k;
+                    float X[4], Y[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const u32x2v t = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[i][0][r]), __float_as_uint(acc[i][1][r]), false, false);
+                        X[r] = __uint_as_float(t[0]);
+                        Y[r] = __uint_as_float(t[1]);
+                    }
+                    transpose4(X);
+                    transpose4(Y);
+                    // this lane's rows: X -> 16 i + qrow + 8 up, Y -> + 4; the bias values sit in lanes (row index) of bv[k]
+                    const float b_ = has_bias ? bv[k] : 0.f;
+                    const float bx = __uint_as_float(__builtin_amdgcn_ds_bpermute(rx * 4, __float_as_uint(b_)));
+                    const float by = __uint_as_float(__builtin_amdgcn_ds_bpermute(ry * 4, __float_as_uint(b_)));
+                    const float4 ax4 = has_aux ? axs[k] : make_float4(0.f, 0.f, 0.f, 0.f), ay4 = has_aux ? ays[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float axv[4] = {ax4.x, ax4.y, ax4.z, ax4.w}, ayv[4] = {ay4.x, ay4.y, ay4.z, ay4.w};
+                    float vx[4], vy[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float x = fmaf(X[j], gs, bx);
+                        x = fmaf(axv[j], rmul, x);
+                        x = fmaxf(x, relu_floor);
+                        x = (axv[j] > mask_thr) ? x : 0.f;
+                        vx[j] = osplit ? pack_split(x) : x;
+                        float y = fmaf(Y[j], gs, by);
+                        y = fmaf(ayv[j], rmul, y);
+                        y = fmaxf(y, relu_floor);
+                        y = (ayv[j] > mask_thr) ? y : 0.f;
+                        vy[j] = osplit ? pack_split(y) : y;
+                    }
+                    ox[k] = make_float4(vx[0], vx[1], vx[2], vx[3]);
+                    oy[k] = make_float4(vy[0], vy[1], vy[2], vy[3]);
                 }
-            }
+            };
+            auto stores = [&](int h) {
+#pragma unroll
+                for (int k = 0; k < HB; ++k) {
+                    const int mblk = cur.m0 + wm0 + (h * HB + k) * 16;
+                    const int mx = mblk + rx, my = mblk + ry;
+                    if (mx < p.M) *reinterpret_cast<float4*>(obase + (size_t)mx * plane) = ox[k];
+                    if (my < p.M) *reinterpret_cast<float4*>(obase + (size_t)my * plane) = oy[k];
+                }
+            };
+            loads(0);
+            __builtin_amdgcn_sched_barrier(0);
+            results(0);
+            __builtin_amdgcn_sched_barrier(0);
+            loads(1);
+            __builtin_amdgcn_sched_barrier(0);
+            stores(0);
+            __builtin_amdgcn_sched_barrier(0);
+            results(1);
+            __builtin_amdgcn_sched_barrier(0);
+            stores(1);
             if (!more) break;
         }
         wait_vmcnt<0>();
