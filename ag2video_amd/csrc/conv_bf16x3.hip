@@ -988,9 +988,12 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_ws_k
 // for the hi and the lo image each -- against 8 dword loads and 8 ds_write_b32 in conv_wgrad_bf16x3_ws_kernel.  Only the first /
 // last element of a run can fall outside the image (pad <= 8 - ... checked by the launcher: pad <= S - 1 <= 7); such runs are
 // flagged per K-tile by the table builder and patched after the load.
+#ifndef AG2V_WGRAD_LDK
+#define AG2V_WGRAD_LDK 40      // LDS row stride in bf16 elements of the 16-byte-load weight-gradient kernels (experiments override it)
+#endif
 template <int BM, int BN, int CWM, int CWN, int NPW, bool MF16, bool PSA, bool PSX>
 __device__ __forceinline__ void wgrad_bf16x3_v_body(const ConvArgs& p) {
-    constexpr int BK = 32, LDK = 40, NP = NPW * 64;
+    constexpr int BK = 32, LDK = AG2V_WGRAD_LDK, NP = NPW * 64;
     constexpr int TM = BM / CWM / 32, TN = BN / CWN / 32;
     constexpr int RPT = NP / 4;                       // rows covered by one pass of the producer threads (4 runs of 8 q per row)
     constexpr int NA = BM / RPT, NB = BN / RPT;       // A / B rows per producer thread

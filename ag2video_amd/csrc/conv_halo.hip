@@ -60,6 +60,12 @@ struct HaloCfg {
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)      // (the host pass only needs the kernel stubs; it rejects some of the device-only template code)
+// (measured and NOT used: the two waves of a SIMD issuing their DMA pieces behind different MFMA groups -- -1..-3 % on every shape)
+#ifdef AG2V_HALO_STAGGER
+__device__ __forceinline__ bool getenv_stagger() { return true; }
+#else
+__device__ __forceinline__ bool getenv_stagger() { return false; }
+#endif
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -384,6 +390,7 @@ struct HaloBody16 {
     unsigned hw4;
     int NS, lastP, P;
     bool lateA;                          // this wave's A pieces hold rows of the late row blocks (HALFWIN)
+    int dma_g;                           // MFMA group behind which this wave issues its DMA pieces (0, or RB / 2 for waves 4..7)
     unsigned baseA[3];                   // per slot pair (2 q, 2 q + 1): lanes of the second k half point into the odd slot
     unsigned baseB[5];                   // per (buffer, offset between the two taps of a double-step): see kidx()
     bf16x8 ah[RB], al[RB], bh[2], bl[2];
@@ -474,7 +481,11 @@ struct HaloBody16 {
     template <int D>
     __device__ __forceinline__ void dstep() {
         constexpr int U = 2 * D, PD = (D + 8) % 9;
+#ifdef AG2V_HALO_LOOSE_WAIT      // TIMING EXPERIMENT ONLY (races): is the counted wait -- i.e. DMA latency -- what the waves park on?
+        wait_vmcnt<2 * G::APW + nB(PD) + AG2V_HALO_LOOSE_WAIT>();
+#else
         wait_vmcnt<2 * G::APW + nB(PD)>();
+#endif
         __builtin_amdgcn_s_barrier();
         constexpr int WPG = 16 / RB;                 // B words of the next double-step fetched per row-block group
 #pragma unroll
@@ -487,7 +498,8 @@ struct HaloBody16 {
                 acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[g], bh[c], acc[g][c], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (g == 0) {
+            // The double-step's DMA pieces go out behind the first MFMA group (an LDS-DMA takes 60-180 cycles to issue).
+            if (g == dma_g) {
                 // image pieces: the pair's second stage (buffer 1) during double-steps 0, 1; the NEXT pair's (or tile's) first stage
                 // (buffer 0, free once step 8 has been fetched: after barrier 4) during double-steps 5, 6
                 if constexpr (D == 0) { dma_b_round<0, 1>(2 * P + 1); dma_b_round<1, 1>(2 * P + 1); dma_b_round<2, 1>(2 * P + 1); }
@@ -498,7 +510,7 @@ struct HaloBody16 {
                 else dma_a_ahead<U + 6>();
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (g == 1) {
+            if (g == dma_g + 1) {
                 if (HALFWIN && lateA) dma_a_ahead<U + 5>();
                 else dma_a_ahead<U + 7>();
                 __builtin_amdgcn_sched_barrier(0);
@@ -579,6 +591,7 @@ struct HaloBody16 {
         // piece a = wave (+ 8): 64 consecutive rows of one (plane, k group); rows [64 h, 64 h + 64) are the early (h even) / late (h odd)
         // row blocks of the waves that own rows [128 (h / 2), + 128)
         lateA = HALFWIN && (((wave * 64) % G::BM) / 64) % 2 == 1;
+        dma_g = (wave >= 4 && getenv_stagger()) ? RB / 2 : 0;
 #pragma unroll
         for (int q = 0; q < 3; ++q) baseA[q] = (unsigned)(G::A_OFF + (2 * q + sub) * G::ASZ + kg * G::BM * 16 + (wm0 + l15) * 16);
         const int lb = (kg * G::G8 + ty * G::RP + tx + l15 + 3) * 4;
@@ -795,6 +808,14 @@ static bool halo_geometry(int BN, int OH, int OW, int& TW, int& TH) {
     return false;
 }
 
+// 256-row tile (128 pixels) when there are enough rows and it pads no more rows than the 128-row tile (256 pixels) does
+static bool halo_tall(int M) {
+    // 128-row tiles (256 pixels as 2 x 128: 2x row halo, 8 KB of weights per k-step) beat the 256-row tile (128 x 1 pixels: 3x row halo)
+    // on every shape measured (+1.9 % at C = 384, +4.5 % at C = 128): the 256-row form is kept for A/B runs (AG2V_HALO_TALL)
+    if (getenv("AG2V_HALO_TALL") == nullptr) return false;
+    return M >= 192 && ceil_div(M, 256) * 256 <= ceil_div(M, 128) * 128;
+}
+
 // Can this launch (as the callers of launch_igemm_bf16x3 describe it) run on the halo kernels?
 bool igemm_halo_ok(const ConvArgs& a) {
     // (read per call, not cached: tools/halo_bench.py and the tests switch kernels inside one process)
@@ -804,17 +825,17 @@ bool igemm_halo_ok(const ConvArgs& a) {
     if (a.C % 32 || a.W % 4 || (a.o_mul != 1 && a.o_mul != 0) || a.o_add_y || a.o_add_x) return false;
     if ((a.o_H && a.o_H != a.OH) || (a.o_W && a.o_W != a.OW)) return false;
     if (a.residual == a.out && a.residual) return false;          // accumulating launches stay on the split-K capable kernels
-    const bool tall = a.M >= 192 && ceil_div(a.M, 256) * 256 <= ceil_div(a.M, 128) * 128;
+    const bool tall = halo_tall(a.M);
     const int bn = tall ? 128 : 256, bm = tall ? 256 : (a.M <= 64 ? 64 : 128);
     int tw, th;
     if (!halo_geometry(bn, a.OH, a.OW, tw, th)) return false;
     const long long tiles = (long long)ceil_div(a.M, bm) * (a.NG / bn);
     const char* mt = getenv("AG2V_HALO_MIN_TILES");                 // (tests run small shapes through these kernels)
-    return tiles >= (mt ? atoi(mt) : 512);                          // small maps: the split-K kernels fill the chip better
+    return tiles >= (mt ? atoi(mt) : 384);                          // small maps: the split-K kernels fill the chip better
 }
 
 int launch_igemm_halo(ConvArgs& a, hipStream_t st) {
-    const bool tall = a.M >= 192 && ceil_div(a.M, 256) * 256 <= ceil_div(a.M, 128) * 128;
+    const bool tall = halo_tall(a.M);
     const int bn = tall ? 128 : 256, bm = tall ? 256 : (a.M <= 64 ? 64 : 128);
     int tw, th;
     if (!halo_geometry(bn, a.OH, a.OW, tw, th)) return AG2V_EINVAL;

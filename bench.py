@@ -53,11 +53,13 @@ def load_pmc_traffic():
 PEAK_HBM_GBS = 8000.0              # same guide: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
-def make_opt(cfg):
+def make_opt(cfg, vgg=False):
     from ag2video_amd.data.args import make_opt as _mk
     from ag2video_amd.data.vocab import cater_vocab, smth_vocab
     side, frames, batch, extra = CONFIGS[cfg]
-    flags = ['--no_vgg_loss', '--image_size', '%d,%d' % (side, side), '--batch_size', str(batch), '--gpu_ids', '0'] + extra
+    # vgg: the perceptual loss on a RANDOM-INIT VGG19 (--vgg_random_init: the ImageNet weights are not obtainable here) -- a memory / time
+    # probe of the full loss set, not BASELINE.json's metric (which is quoted with the VGG loss off)
+    flags = (['--vgg_random_init'] if vgg else ['--no_vgg_loss']) + ['--image_size', '%d,%d' % (side, side), '--batch_size', str(batch), '--gpu_ids', '0'] + extra
     vocab = smth_vocab() if 'smth_else' in extra else cater_vocab()
     return _mk(vocab, flags), side, frames, batch
 
@@ -200,6 +202,7 @@ def main():
                     help='arithmetic of the 128-row conv MFMA tiles (both hold the 1e-3 parity bound; tests/test_step_gpu.py)')
     ap.add_argument('--no-fp32-leg', action='store_true', help='skip the extra exact-fp32 step used for roofline_exact_fp32')
     ap.add_argument('--temporal-D', action='store_true', help='--temporal_D 1: the temporal multiscale PatchGAN on top of the image discriminator (not BASELINE.json\'s metric; reported in config.workload)')
+    ap.add_argument('--vgg-random-init', action='store_true', help='perceptual loss on a random-init VGG19 (memory / time probe; reported in config.workload)')
     ap.add_argument('--lean-tape', action='store_true', help='--lean_tape 1: smaller autograd tape for a few extra passes over memory (reported in config.workload)')
     args = ap.parse_args()
     if args.cpu_baseline_only:
@@ -222,7 +225,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
-    opt, side, frames, batch = make_opt(args.config)
+    opt, side, frames, batch = make_opt(args.config, vgg=args.vgg_random_init)
     opt.gpu_ids = [local]
     opt.temporal_D = 1 if args.temporal_D else 0
     opt.lean_tape = 1 if args.lean_tape else 0
@@ -473,8 +476,8 @@ def main():
         "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": ("f32 (conv products as 3-term bf16 splits on the bf16 MFMA pipe, fp32 accumulate; everything else fp32)"
                   if args.precision == 'bf16x3' else "f32"), "data": "synthetic CATER-shaped clips (seeded), closed-form random-init weights",
-        "config": {"workload": "%s: %s %dx%d, %d frames, batch %d per GPU, full G+D train step, VGG loss off%s"
-                   % (args.config, "SSv2-shaped" if args.config == 'c5' else "CATER", side, side, frames, batch, (", + temporal discriminator (--temporal_D 1)" if args.temporal_D else "") + (", lean tape (--lean_tape 1)" if args.lean_tape else "")), "global_batch": world * batch, "parallelism": "dp%d" % world},
+        "config": {"workload": "%s: %s %dx%d, %d frames, batch %d per GPU, full G+D train step, %s%s"
+                   % (args.config, "SSv2-shaped" if args.config == 'c5' else "CATER", side, side, frames, batch, ("VGG loss on (random-init VGG19)" if args.vgg_random_init else "VGG loss off"), (", + temporal discriminator (--temporal_D 1)" if args.temporal_D else "") + (", lean tape (--lean_tape 1)" if args.lean_tape else "")), "global_batch": world * batch, "parallelism": "dp%d" % world},
         "roofline": roof, "roofline_exact_fp32": roof_fp32, "roofline_hbm": roof_hbm, "roofline_hbm_bwd": roof_hbm_bwd,
         "cpu_baseline": cpu, "comm": comm,
         "extra": {"graph_step_ms": round(graph_ms, 2), "losses_finite": finite,

@@ -1,4 +1,5 @@
 """Counter CSVs of tools/pmc_quick.sh -> <dir>/traffic.json, the file bench.py reads for `roofline.traffic`.
+usage: pmc_summary.py <dir> [earlier traffic.json whose entries are kept for kernels this pass did not measure]
 Units as MI355X_MICROARCH.md's HBM / rocprofv3 section prescribes: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts
 64-byte requests as 32 bytes, so it is doubled.  One case per process (tools/pmc_traffic.py <case>): within a case the kernel name
 identifies the launches of interest; FETCH and WRITE of a launch are joined on the dispatch id (the launch sequence is deterministic),
@@ -23,6 +24,9 @@ MATCH = [('mlp_shared_fwd', 'mlp_shared_fwd', 'conv_igemm_bf16x3_ws_kernel<128, 
          ('mlp_shared_wgrad_merged', 'mlp_shared_wgrad_merged', 'conv_wgrad_bf16x3_v_kernel<128, 256'),
          ('conv_256_wgrad_128px', 'conv_256_wgrad_128px', 'conv_wgrad_bf16x3_v_kernel<256, 128'),
          ('mlp_shared_fwd_ps', 'mlp_shared_fwd_ps', 'conv_igemm_bf16x3_ps_kernel<128, 256'),
+         # round 4: the same split-word launches run on the halo-tile LDS-DMA kernels (csrc/conv_halo.hip)
+         ('mlp_shared_fwd_ps', 'mlp_shared_fwd_ps', 'conv_halo16_bf16x3_kernel<1, 8, 4, 128, 2, true>'),
+         ('mlp_shared_dgrad_merged_ps', 'mlp_shared_dgrad_merged_ps', 'conv_halo16_bf16x3_kernel<2, 4, 4, 128, 1, true>'),
          ('mlp_shared_dgrad_merged_ps', 'mlp_shared_dgrad_merged_ps', 'conv_igemm_bf16x3_ps_kernel<256, 128'),
          ('mlp_shared_wgrad_merged_ps', 'mlp_shared_wgrad_merged_ps', 'conv_wgrad_bf16x3_vps_kernel<128, 256'),
          ('conv_256_wgrad_128px_ps', 'conv_256_wgrad_128px_ps', 'conv_wgrad_bf16x3_vps_kernel<256, 128'),
@@ -55,4 +59,13 @@ for case, tag, sub in MATCH:
                 'launches': len(ids), 'ratio': (fb + wb) / expect['algorithmic_bytes']}
     print('%-72s FETCH %8.0f MB  WRITE %8.0f MB  algorithmic %8.0f MB  x%.2f   [%s]' % (
         key[:72], fb / 1e6, wb / 1e6, expect['algorithmic_bytes'] / 1e6, out[key]['ratio'], expect['shape']))
+# kernels that were not re-measured in this pass keep the newest earlier round's entry (marked so): bench.py reads ONE file
+base = None
+if len(sys.argv) > 2:
+    base = json.load(open(sys.argv[2]))
+    for k, v in base.items():
+        if k not in out:
+            v = dict(v)
+            v.setdefault('measured_in', os.path.relpath(sys.argv[2], root))
+            out[k] = v
 json.dump(out, open(os.path.join(d, 'traffic.json'), 'w'), indent=1)
