@@ -991,17 +991,24 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_ws_k
 #ifndef AG2V_WGRAD_LDK
 #define AG2V_WGRAD_LDK 40      // LDS row stride in bf16 elements of the 16-byte-load weight-gradient kernels (experiments override it)
 #endif
-template <int BM, int BN, int CWM, int CWN, int NPW, bool MF16, bool PSA, bool PSX>
+// F32: the same pipeline on EXACT fp32 operands (v_mfma_f32_32x32x2_f32; ConvArgs::f32): the producers store the words as loaded,
+// [row][32 pixels] with 36-word rows; consumer lane (row, half) multiplies pixels 16 half + j (the order of the terms of a K-tile is
+// free as long as both operands use the same): four 16-byte LDS reads per 32-row fragment, as in conv_igemm_f32_ws_kernel.
+template <int BM, int BN, int CWM, int CWN, int NPW, bool MF16, bool PSA, bool PSX, bool F32 = false>
 __device__ __forceinline__ void wgrad_bf16x3_v_body(const ConvArgs& p) {
+    static_assert(!F32 || (!MF16 && !PSA && !PSX), "fp32 operands: 32x32 tiles on fp32 tensors");
     constexpr int BK = 32, LDK = AG2V_WGRAD_LDK, NP = NPW * 64;
+    constexpr int LDKF = BK + 4;
     constexpr int TM = BM / CWM / 32, TN = BN / CWN / 32;
     constexpr int RPT = NP / 4;                       // rows covered by one pass of the producer threads (4 runs of 8 q per row)
     constexpr int NA = BM / RPT, NB = BN / RPT;       // A / B rows per producer thread
     static_assert(BM % RPT == 0 && BN % RPT == 0, "producer mapping");
-    __shared__ __attribute__((aligned(16))) unsigned short Ahi[2][BM * LDK];
-    __shared__ __attribute__((aligned(16))) unsigned short Alo[2][BM * LDK];
-    __shared__ __attribute__((aligned(16))) unsigned short Bhi[2][BN * LDK];
-    __shared__ __attribute__((aligned(16))) unsigned short Blo[2][BN * LDK];
+    __shared__ __attribute__((aligned(16))) unsigned short Ahi[2][F32 ? 8 : BM * LDK];
+    __shared__ __attribute__((aligned(16))) unsigned short Alo[2][F32 ? 8 : BM * LDK];
+    __shared__ __attribute__((aligned(16))) unsigned short Bhi[2][F32 ? 8 : BN * LDK];
+    __shared__ __attribute__((aligned(16))) unsigned short Blo[2][F32 ? 8 : BN * LDK];
+    __shared__ __attribute__((aligned(16))) float Af[2][F32 ? BM * LDKF : 4];
+    __shared__ __attribute__((aligned(16))) float Bf[2][F32 ? BN * LDKF : 4];
     __shared__ int4 qtab[4][4];   // per run of 8 pixels of a K-tile: {x offset of tap (0,0), dY offset, (yb<<16)|xb, flags}
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1116,9 +1123,16 @@ __device__ __forceinline__ void wgrad_bf16x3_v_body(const ConvArgs& p) {
             *reinterpret_cast<uint4*>(&hi_img[off]) = make_uint4(h[0], h[1], h[2], h[3]);
             *reinterpret_cast<uint4*>(&lo_img[off]) = make_uint4(l[0], l[1], l[2], l[3]);
         };
+        auto store_row_f = [&](float* img, int r, const u32x4 (&v)[2]) {      // fp32 words as loaded
+            *reinterpret_cast<u32x4*>(&img[r * LDKF + 8 * run]) = v[0];
+            *reinterpret_cast<u32x4*>(&img[r * LDKF + 8 * run + 4]) = v[1];
+        };
         auto stash = [&](int buf, const u32x4 (&ra)[NA][2], u32x4 (&rb)[NB][2], int fixw, int fixx, int shw) {
 #pragma unroll
-            for (int i = 0; i < NA; ++i) store_row(std::integral_constant<bool, PSA>{}, Ahi[buf], Alo[buf], row + RPT * i, ra[i]);
+            for (int i = 0; i < NA; ++i) {
+                if constexpr (F32) store_row_f(Af[buf], row + RPT * i, ra[i]);
+                else store_row(std::integral_constant<bool, PSA>{}, Ahi[buf], Alo[buf], row + RPT * i, ra[i]);
+            }
             if (__builtin_expect(shw != 0, 0)) {   // rows loaded from element 0 instead of element -sh: move them up by sh places
 #pragma unroll
                 for (int i = 0; i < NB; ++i) {
@@ -1141,7 +1155,10 @@ __device__ __forceinline__ void wgrad_bf16x3_v_body(const ConvArgs& p) {
                 }
             }
 #pragma unroll
-            for (int i = 0; i < NB; ++i) store_row(std::integral_constant<bool, PSX>{}, Bhi[buf], Blo[buf], row + RPT * i, rb[i]);
+            for (int i = 0; i < NB; ++i) {
+                if constexpr (F32) store_row_f(Bf[buf], row + RPT * i, rb[i]);
+                else store_row(std::integral_constant<bool, PSX>{}, Bhi[buf], Blo[buf], row + RPT * i, rb[i]);
+            }
         };
         u32x4 ra0[NA][2], ra1[NA][2], rb0[NB][2], rb1[NB][2];
         int fw0, fx0, fw1, fx1, sh0, sh1;
@@ -1183,6 +1200,32 @@ __device__ __forceinline__ void wgrad_bf16x3_v_body(const ConvArgs& p) {
             for (int r = 0; r < EREGS; ++r) acc[i][j][r] = 0.f;
     const int fr = lane & (ER - 1), fq = lane / ER;
     auto compute = [&](int buf) {
+        if constexpr (F32) {
+            const int half = lane >> 5, r32 = lane & 31;
+            float4 bfr[EN][4];
+#pragma unroll
+            for (int j = 0; j < EN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    bfr[j][q] = *reinterpret_cast<const float4*>(&Bf[buf][(wn0 + j * 32 + r32) * LDKF + 16 * half + 4 * q]);
+#pragma unroll
+            for (int i = 0; i < EM; ++i) {
+                float4 afr[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    afr[q] = *reinterpret_cast<const float4*>(&Af[buf][(wm0 + i * 32 + r32) * LDKF + 16 * half + 4 * q]);
+#pragma unroll
+                for (int j = 0; j < EN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[q].x, bfr[j][q].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[q].y, bfr[j][q].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[q].z, bfr[j][q].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[q].w, bfr[j][q].w, acc[i][j], 0, 0, 0);
+                    }
+            }
+            return;
+        }
 #pragma unroll
         for (int ks = 0; ks < (MF16 ? 1 : BK / 16); ++ks) {
             bf16x8 bhi[EN], blo[EN];
@@ -1214,7 +1257,7 @@ __device__ __forceinline__ void wgrad_bf16x3_v_body(const ConvArgs& p) {
     };
     __syncthreads();
     // the consumer skew of igemm_bf16x3_body: (row block 1, k-step 1) of a K-tile runs behind the next barrier
-    constexpr bool SKEW = !MF16 && (BK / 16 == 2) && EM == 2 && (AG2V_CONSUMER_SKEW != 0);
+    constexpr bool SKEW = !MF16 && !F32 && (BK / 16 == 2) && EM == 2 && (AG2V_CONSUMER_SKEW != 0);
     if constexpr (SKEW) {
         auto ldB = [&](int buf, int ks, bf16x8 (&bh)[EN], bf16x8 (&bl)[EN]) {
 #pragma unroll
@@ -1292,6 +1335,11 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_v_ke
     wgrad_bf16x3_v_body<BM, BN, CWM, CWN, NPW, MF16, false, false>(p);
 }
 // dy (PSA: ConvArgs::a_split) and / or x (PSX: ConvArgs::b_split) hold split words
+// exact fp32 on the same pipeline (ConvArgs::f32): conv_wgrad_kernel's arithmetic with 16-byte loads and 8 + 8 waves
+template <int BM, int BN, int CWM, int CWN, int NPW>
+__global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_f32_v_kernel(ConvArgs p) {
+    wgrad_bf16x3_v_body<BM, BN, CWM, CWN, NPW, false, false, false, true>(p);
+}
 template <int BM, int BN, int CWM, int CWN, int NPW, bool MF16, bool PSA, bool PSX>
 __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_vps_kernel(ConvArgs p) {
     wgrad_bf16x3_v_body<BM, BN, CWM, CWN, NPW, MF16, PSA, PSX>(p);
@@ -1420,6 +1468,14 @@ void plan_wgrad_bf16x3(ConvArgs& a) {
     a.spg = spg; a.splitk = spg * a.groups; a.kchunk = kchunk;
 }
 
+// exact-fp32 weight gradients that the 16-byte-load pipeline takes (the others stay on conv_wgrad_kernel): stride 1, pixel rows of whole
+// 8-pixel runs, at least 128 rows (fewer rows: the 4-wave kernels' 32- / 64-row tiles pad less), dY within the 2^31-byte offset encoding
+bool wgrad_f32_ws_ok(const ConvArgs& a) {
+    static const bool off = getenv("AG2V_NO_F32_WGRAD_WS") != nullptr;
+    return !off && a.M >= 128 && a.stride == 1 && a.OW % 8 == 0 && a.W >= 8 && a.pad <= 3 && a.a_bytes != 0 && a.a_bytes <= 0x80000000u &&
+           ((long long)a.N * a.OH * a.OW) % 8 == 0;
+}
+
 int launch_wgrad_bf16x3(ConvArgs& a, hipStream_t st) {
     plan_wgrad_bf16x3(a);
     const bool tall = a.M >= 192 && ceil_div(a.M, 256) * 256 <= ceil_div(a.M, 128) * 128;
@@ -1434,6 +1490,18 @@ int launch_wgrad_bf16x3(ConvArgs& a, hipStream_t st) {
     static const bool wgrad32 = getenv("AG2V_WGRAD16") == nullptr;
     static const int wnoprio = getenv("AG2V_WGRAD_NOPRIO") ? 1 : 0;     // A/B aid
     a.diag_noprio = wnoprio;
+    if (a.f32) {        // exact fp32 operands: the 16-byte-load kernels only (wgrad_f32_ws_ok)
+        if (!wgrad_f32_ws_ok(a) || a.a_split || a.b_split) return AG2V_EINVAL;
+        if (tall) {
+            set_last_conv_kernel("conv_wgrad_f32_v_kernel<256, 128, 4, 2, 8>");
+            hipLaunchKernelGGL((conv_wgrad_f32_v_kernel<256, 128, 4, 2, 8>), grid, dim3(1024), 0, st, a);
+        } else {
+            set_last_conv_kernel("conv_wgrad_f32_v_kernel<128, 256, 2, 4, 8>");
+            hipLaunchKernelGGL((conv_wgrad_f32_v_kernel<128, 256, 2, 4, 8>), grid, dim3(1024), 0, st, a);
+        }
+        AG2V_CHECK_LAUNCH();
+        return AG2V_OK;
+    }
     if (a.stride == 1 && a.OW % 8 == 0 && a.W >= 8 && a.a_bytes <= 0x80000000u && a.pad <= 3 &&
         getenv("AG2V_WGRAD_SCALAR_LOADS") == nullptr) {
         // 16-byte loads along the pixel index (runs of 8 pixels never straddle an image row)

@@ -1062,7 +1062,7 @@ extern "C" int ag2v_conv2d_dgrad(const float* dy, const float* w, float* dx,
 // report that float count (0 when the launch does not split).
 static int wgrad_launch(const float* dy, const float* x, float* dw, int N, int C, int H, int W, int K, int R, int S, int OH, int OW,
                         int stride, int pad, int accumulate, int groups, bool split, hipStream_t st, int x_split = 0, int dy_split = 0,
-                        int det = 0, float* det_ws = nullptr, size_t det_ws_floats = 0, size_t* need = nullptr) {
+                        int det = 0, float* det_ws = nullptr, size_t det_ws_floats = 0, size_t* need = nullptr, bool f32ws = false) {
     ConvArgs a{};
     a.a_src = dy; a.b_src = x; a.out = dw; a.accumulate = accumulate ? 1 : 0;
     a.b_split = x_split; a.a_split = dy_split;
@@ -1074,10 +1074,16 @@ static int wgrad_launch(const float* dy, const float* x, float* dw, int N, int C
     a.groups = groups; a.gq = (int)(Q / groups); a.out_gstride = (long long)a.M * a.NG;
     const long long mn = (long long)a.M * a.NG;
     int bm = 0;
-    if (split) {
+    if (!split && f32ws) {       // exact fp32, 8 + 8 waves, 16-byte loads: the planning of the split kernels
+        a.a_bytes = (unsigned)((long long)N * K * OH * OW * 4); a.b_bytes = (unsigned)((long long)N * C * H * W * 4);
+        a.f32 = 1;
+        if (wgrad_f32_ws_ok(a)) { split = true; plan_wgrad_bf16x3(a); }
+        else { a.f32 = 0; a.a_bytes = a.b_bytes = 0; }
+    } else if (split) {
         a.a_bytes = (unsigned)((long long)N * K * OH * OW * 4); a.b_bytes = (unsigned)((long long)N * C * H * W * 4);
         plan_wgrad_bf16x3(a);
-    } else {
+    }
+    if (!split) {
         bm = (a.M <= 32) ? 32 : (a.M <= 64 ? 64 : 128);
         a.tiles_m = ceil_div(a.M, bm);
         a.tiles_n = ceil_div(a.NG, 128);
@@ -1132,10 +1138,12 @@ static int wgrad_ex_impl(const float* dy, const float* x, float* dw, int N, int 
     // samples per launch: whole groups, both operands below 4 GiB for the bf16x3 kernels, pixel index below 2^31
     // (dy at most 2 GiB per launch: the 16-byte-load weight-gradient kernels encode "past the range" as byte offset 2^31)
     int nmax = N;
-    if (split && (dys * 8 * N >= chunk_limit() || xs * 4 * N >= chunk_limit())) {
+    // exact fp32 on the 16-byte-load pipeline (conv_wgrad_f32_v_kernel) addresses through 32-bit buffer offsets as well: same chunks
+    bool f32ws = !split && K >= 128 && stride == 1 && OW % 8 == 0 && W >= 8 && pad <= 3 && getenv("AG2V_NO_F32_WGRAD_WS") == nullptr;
+    if ((split || f32ws) && (dys * 8 * N >= chunk_limit() || xs * 4 * N >= chunk_limit())) {
         nmax = chunk_samples(dys * 8, xs * 4, groups > 1 ? Ng : 1);
         if (nmax <= 0) nmax = chunk_samples(dys * 4, xs * 4, groups > 1 ? Ng : 1);
-        if (nmax <= 0) { split = false; nmax = N; }
+        if (nmax <= 0) { split = false; f32ws = false; nmax = N; }
     }
     if ((long long)nmax * OH * OW >= (1LL << 31)) {
         nmax = (int)(((1LL << 31) - 1) / ((long long)OH * OW));
@@ -1152,7 +1160,7 @@ static int wgrad_ex_impl(const float* dy, const float* x, float* dw, int N, int 
         size_t one = 0;
         const int rc = wgrad_launch(need ? nullptr : dy + (size_t)n0 * dys, need ? nullptr : x + (size_t)n0 * xs, out, nc, C, H, W, K, R, S,
                                     OH, OW, stride, pad, acc, gc, split, st, cfg.in_split, cfg.dy_split, cfg.det, cfg.det_ws,
-                                    cfg.det_ws_floats, need ? &one : nullptr);
+                                    cfg.det_ws_floats, need ? &one : nullptr, f32ws);
         if (rc != AG2V_OK) return rc;
         if (one > most) most = one;
     }

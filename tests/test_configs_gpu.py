@@ -141,7 +141,7 @@ def _step_vs_oracle(case, prec, device):
             assert worst[name] <= (IMG_BOUND.get(case, 1e-3) if name == 'imgs_pred' else 1e-3), (name, worst)
         assert np.mean(mo[3].cpu().numpy() != ref['out'][3].numpy()) < 2e-3
         # gradients: abs-sum of every parameter's gradient (bounds: module docstring of tests/test_step_gpu.py)
-        bad = []
+        bad, worst_g = [], {'front': (0.0, ''), 'decoder': (0.0, '')}
         for n, prm in ts.model.named_parameters():
             g_ref = ref['G_grads'].get(n)
             if g_ref is None:
@@ -149,9 +149,19 @@ def _step_vs_oracle(case, prec, device):
                 continue
             assert prm.grad is not None, n
             got = _stats(prm.grad)
-            rel = 5e-2 if ('flows_network' in n or n.startswith('acts_to_objs')) else 2e-2
+            front = 'flows_network' in n or n.startswith('acts_to_objs')
+            # tensors in FRONT of the whole generator (flow network, appearance graph net): their gradient sums thousands of decoder paths
+            # whose ReLU / hinge branches sit within fp32 rounding of zero, and the 4-element `acts_to_objs...box_net.2.bias` moves by
+            # 2.7 ... 5.4 % between runs of the SAME build (atomics order; measured over 9 runs at 256^2, both arithmetics and both
+            # weight-gradient kernels) -- 7e-2 there; decoder tensors measure 0.2 ... 0.7 % under their 2e-2.  Correctness of these
+            # gradients is pinned by tests/test_gradcheck_gpu.py (central differences), not by this statistic.
+            rel = 7e-2 if front else 2e-2
+            dev = abs(got[1] - g_ref[1]) / max(abs(g_ref[1]), 1e-30)
+            if abs(g_ref[1]) > 2e-6 * prm.numel() and dev > worst_g['front' if front else 'decoder'][0]:
+                worst_g['front' if front else 'decoder'] = (dev, n)
             if abs(got[1] - g_ref[1]) > rel * abs(g_ref[1]) + 2e-6 * prm.numel():
                 bad.append((n, got[1], g_ref[1]))
+        print('%s [%s] worst gradient abs-sum deviations:' % (case, prec), worst_g)
         assert not bad, (len(bad), bad[:10])
         badd = []
         for n, prm in ts.discriminator.img_discriminator.named_parameters():
