@@ -139,3 +139,39 @@ def test_halo_split_word_output_and_data_gradient(cfg, device):
         for fam in (True, '32'):
             assert float((outs[fam].cpu() - refdx).abs().max()) <= 2e-4 * sc
             assert float((outs[fam] - outs[False]).abs().max()) <= 1e-5 * sc
+
+
+@pytest.mark.parametrize("cfg", [(2, 64, 32, 32, 128), (3, 40, 24, 48, 256), (4, 32, 16, 16, 160)], ids=str)
+def test_exact_fp32_weight_gradient_on_the_wave_specialised_pipeline(cfg, device):
+    """--precision fp32: weight gradients with >= 128 rows, stride 1 and pixel rows of whole 8-pixel runs run on conv_wgrad_f32_v_kernel
+    (16-byte loads, 8 producer + 8 consumer waves, v_mfma_f32_32x32x2_f32) instead of the 4-wave conv_wgrad_kernel: against an fp64
+    evaluation of the same sums -- plain, accumulating, and one gradient per sample group (spectral norm's frame groups)."""
+    from ag2video_amd import _lib, ops
+    N, C, H, W, K = cfg
+    torch.manual_seed(7)
+    x = torch.randn(N, C, H, W, device=device)
+    dy = torch.randn(N, K, H, W, device=device)
+    w0 = torch.zeros(K, C, 3, 3, device=device, dtype=torch.float64, requires_grad=True)
+
+    def ref(xs, dys):
+        y = torch.nn.functional.conv2d(xs.double(), w0, None, 1, 1)
+        return torch.autograd.grad((y * dys.double()).sum(), w0)[0].float()
+    with ops.conv_precision('fp32'), torch.no_grad():
+        dw = torch.empty(K, C, 3, 3, device=device)
+        ops._conv_wgrad_launch(None, dy, x, dw, K, 3, 3, 1, 1, 0)
+        assert _lib.query('ag2v_last_conv_kernel').startswith(b'conv_wgrad_f32_v_kernel'), _lib.query('ag2v_last_conv_kernel')
+        with torch.enable_grad():
+            r = ref(x, dy)
+        sc = float(r.abs().max())
+        assert float((dw - r).abs().max()) <= 2e-5 * sc
+        ops._conv_wgrad_launch(None, dy, x, dw, K, 3, 3, 1, 1, 1)          # accumulate: dw += the same gradient
+        assert float((dw - 2 * r).abs().max()) <= 4e-5 * sc
+        if N % 2 == 0:
+            G = 2
+            dwg = torch.empty(G, K, C, 3, 3, device=device)
+            ops._conv_wgrad_launch(None, dy, x, dwg, K, 3, 3, 1, 1, 0, groups=G)
+            for g in range(G):
+                sl = slice(g * N // G, (g + 1) * N // G)
+                with torch.enable_grad():
+                    rg = ref(x[sl], dy[sl])
+                assert float((dwg[g] - rg).abs().max()) <= 2e-5 * float(rg.abs().max())
