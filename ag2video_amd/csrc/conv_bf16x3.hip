@@ -605,7 +605,7 @@ __device__ __forceinline__ void igemm_bf16x3_body(const ConvArgs& p) {
         pvalid = pvalid && (unsigned)yy < (unsigned)p.o_H && (unsigned)xx < (unsigned)p.o_W;
         orem = yy * p.o_W + xx;
     }
-    float* obase = p.out + (size_t)on * p.M * plane + orem;
+    float* obase = p.out + (size_t)on * p.out_nstride + orem;
     const float* rbase = p.residual ? p.residual + (size_t)on * p.M * plane + orem : nullptr;
     const float* mbase = (p.mask && p.splitk == 1) ? p.mask + (size_t)on * p.M * plane + orem : nullptr;
     const float gs = (p.gscale ? p.gscale[on / p.group_n] : 1.f) * (p.oscale != 0.f ? p.oscale : 1.f);   // 1/sigma_t (x 1/weight scale of the h16 pack)
@@ -1374,7 +1374,8 @@ int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed) {
     a.tiles_n = ceil_div(a.NG, bn);
     const int tiles = a.tiles_m * a.tiles_n, nk = ceil_div(a.KG, 32);
     a.splitk = 1; a.kchunk = nk;
-    if (tiles < 1024 && nk >= 8 && !a.det) {      // (deterministic: one workgroup owns an output tile's whole reduction)
+    const bool dense_out = a.out_nstride == (long long)a.M * a.o_H * a.o_W;      // (a strided output is written once, by plain stores)
+    if (tiles < 1024 && nk >= 8 && !a.det && dense_out) {      // (deterministic: one workgroup owns an output tile's whole reduction)
         const int sk = pick_splits(tiles, nk, nk / 4 < 64 ? nk / 4 : 64);
         if (sk > 1) {
             a.kchunk = ceil_div(nk, sk);

@@ -40,6 +40,10 @@ struct ConvArgs {
     int det;                // deterministic reduction (ag2v_conv_opts::deterministic): igemm: no split-K (launchers); wgrad: pixel-range
                             //   split number `split` stores its partial tile to out + split * M * NG (a caller workspace slab, plain
                             //   stores) and launch_wgrad_det_reduce() adds the slabs in split order -- no floating-point atomics
+    long long out_nstride;  // igemm epilogue: floats between consecutive samples of `out` (0 = M * o_H * o_W, the dense tensor; set
+                            //   by launch_igemm).  Larger: out is a channel slice of a wider [N, Ktot, H, W] buffer
+                            //   (ag2v_conv_opts::out_nstride: data gradients written straight into the concatenation their consumer
+                            //   reads); residual / mask keep the dense layout.  Such launches never split K.
 #ifdef AG2V_STAMPS
     unsigned long long* stamps;   // diagnostic build only (tools/ubench/igemm_stamps.hip): per-wave phase clocks
 #endif

@@ -320,8 +320,9 @@ struct HaloBody {
             }
             // ---- epilogue (the next tile's first pieces are landing meanwhile).  Accumulator register r of block i holds row
             // (r & 3) + 8 (r >> 2) + 4 kg, pixel l31 of the wave's 32.
-            const size_t pix = (size_t)cur.n_img * p.M * plane + (size_t)(cur.y0 + ty) * p.OW + (cur.x0 + tx + l31);
-            float* obase = p.out + pix;
+            const size_t pxo = (size_t)(cur.y0 + ty) * p.OW + (cur.x0 + tx + l31);
+            const size_t pix = (size_t)cur.n_img * p.M * plane + pxo;
+            float* obase = p.out + (size_t)cur.n_img * p.out_nstride + pxo;
             const float* aux = aux0 ? aux0 + pix : nullptr;
             const float gs = (p.gscale ? p.gscale[cur.n_img / p.group_n] : 1.f) * (p.oscale != 0.f ? p.oscale : 1.f);
 #pragma unroll
@@ -658,8 +659,9 @@ struct HaloBody16 {
             // the store instructions -- the tile's 128 KB used to leave as 512 dword wave-stores, ~10 us of store ISSUE per tile with
             // the matrix pipe idle (cdna_hip_programming.md T21; 19 k-steps' worth on a 128-row tile).
             const int qrow = lane & 3, qpx = 4 * (l31 >> 2);
-            const size_t pix = (size_t)cur.n_img * p.M * plane + (size_t)(cur.y0 + ty) * p.OW + (cur.x0 + tx + qpx);
-            float* obase = p.out + pix;
+            const size_t pxo = (size_t)(cur.y0 + ty) * p.OW + (cur.x0 + tx + qpx);
+            const size_t pix = (size_t)cur.n_img * p.M * plane + pxo;
+            float* obase = p.out + (size_t)cur.n_img * p.out_nstride + pxo;
             const float* aux = aux0 ? aux0 + pix : nullptr;
             const float gs = (p.gscale ? p.gscale[cur.n_img / p.group_n] : 1.f) * (p.oscale != 0.f ? p.oscale : 1.f);
             typedef unsigned u32x2v __attribute__((ext_vector_type(2)));

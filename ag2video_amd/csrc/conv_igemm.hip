@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256, (BM == 64 ? 3 : 4)) void conv_igemm_kernel(Con
             pvalid = pvalid && (unsigned)yy < (unsigned)p.o_H && (unsigned)xx < (unsigned)p.o_W;
             orem = pvalid ? yy * p.o_W + xx : 0;
         }
-        float* obase = p.out + (size_t)on * p.M * plane + orem;
+        float* obase = p.out + (size_t)on * p.out_nstride + orem;
         const float* rbase = p.residual ? p.residual + (size_t)on * p.M * plane + orem : nullptr;
         const float* mbase = (p.mask && p.splitk == 1) ? p.mask + (size_t)on * p.M * plane + orem : nullptr;
         const float* aux = rbase ? rbase : mbase;           // at most one of them (ag2v_conv2d_dgrad_acc rejects both)
@@ -517,6 +517,7 @@ struct ag2v_conv_opts {
     int deterministic;
     float* det_workspace;
     size_t det_workspace_floats;
+    long long out_nstride;
 };
 struct ConvCfg {
     int precision, min_rows;
@@ -526,6 +527,7 @@ struct ConvCfg {
     int det;
     float* det_ws;
     size_t det_ws_floats;
+    long long out_nstride;
 };
 static ConvCfg conv_cfg(const ag2v_conv_opts* o) {
     ConvCfg c;
@@ -539,6 +541,7 @@ static ConvCfg conv_cfg(const ag2v_conv_opts* o) {
     c.det = (o && o->deterministic) ? 1 : 0;
     c.det_ws = o ? o->det_workspace : nullptr;
     c.det_ws_floats = o ? o->det_workspace_floats : 0;
+    c.out_nstride = o ? o->out_nstride : 0;
     return c;
 }
 static bool use_bf16x3(const ConvCfg& c, int M) { return c.precision >= 1 && M >= c.min_rows; }     // (2: fp16 split in the forward pass)
@@ -715,8 +718,11 @@ static bool launch_fewrow(const ConvArgs& a, hipStream_t st) {
 static int launch_igemm(ConvArgs& a, hipStream_t st, bool out_zeroed, bool split) {
     if (a.M <= 0 || a.NG <= 0 || a.KG <= 0 || a.R * a.S > 16) return AG2V_EINVAL;
     if (a.o_mul == 0) { a.o_mul = 1; a.o_add_y = 0; a.o_add_x = 0; a.o_H = a.OH; a.o_W = a.OW; }
+    const long long dense_nstride = (long long)a.M * a.o_H * a.o_W;
+    if (a.out_nstride == 0) a.out_nstride = dense_nstride;
+    const bool dense_out = a.out_nstride == dense_nstride;
     if (split) return launch_igemm_bf16x3(a, st, out_zeroed);
-    if (a.M <= 4 && a.stride == 1 && a.o_mul == 1 && a.o_add_y == 0 && a.o_add_x == 0 && a.o_W == a.OW && a.o_H == a.OH &&
+    if (dense_out && a.M <= 4 && a.stride == 1 && a.o_mul == 1 && a.o_add_y == 0 && a.o_add_x == 0 && a.o_W == a.OW && a.o_H == a.OH &&
         (long long)a.C * a.H * a.W * 4 < 0x10000000LL && getenv("AG2V_NO_FEWROW") == nullptr) {
         // The kernel flags an out-of-image tap by adding 0xF0000000 to its byte offset, which only stays out of range while the
         // valid part of the offset is below 0x10000000: at most 256 MB of input per launch (a frame-batched [120, 64, 256, 256]
@@ -753,7 +759,7 @@ static int launch_igemm(ConvArgs& a, hipStream_t st, bool out_zeroed, bool split
     // thousands of steps long: split K over grid.y and accumulate with fp32 atomics into the zeroed output.
     const int tiles = a.tiles_m * a.tiles_n, nk = ceil_div(a.KG, bk);
     a.splitk = 1; a.kchunk = nk;
-    if (tiles < 384 && nk >= 16 && !a.det) {      // (deterministic: no split-K, no atomics)
+    if (tiles < 384 && nk >= 16 && !a.det && dense_out) {      // (deterministic: no split-K, no atomics)
         int sk = ceil_div(768, tiles);
         if (sk > nk / 8) sk = nk / 8;
         if (sk > 1) {
@@ -938,6 +944,10 @@ extern "C" int ag2v_conv2d_dgrad_ex(const float* dy, const float* w, const float
     if ((cfg.dy_split || cfg.out_split) && (few_channel_dgrad(N, C, K, R, S, OH, OW, stride, mask != nullptr) || !use_bf16x3(cfg, C)))
         return AG2V_EINVAL;                      // split words are only read / written by the bf16x3 kernels (ag2v_conv2d_split_dy_ok)
     if (cfg.out_split && (accumulate || stride != 1)) return AG2V_EINVAL;   // dx as split words: one class, written once
+    // dx as a channel slice of a wider buffer (ag2v_conv_opts::out_nstride): one class, written once, by the general kernels
+    const long long dxo = cfg.out_nstride > 0 ? cfg.out_nstride : dxs;
+    if (dxo != dxs && (dxo < dxs || accumulate || stride != 1 || few_channel_dgrad(N, C, K, R, S, OH, OW, stride, mask != nullptr)))
+        return AG2V_EINVAL;
     if (few_channel_dgrad(N, C, K, R, S, OH, OW, stride, mask != nullptr) && (long long)N * OH * OW < (1LL << 31) &&
         workspace_floats >= (size_t)C * K * R * S + t_floats) {
         // few input channels: dx[n,c,y,x] = sum_{r,s} t[n, (c R + r) S + s, y + pad - r, x + pad - s], t = W'^T dy as a 1x1
@@ -1007,8 +1017,9 @@ extern "C" int ag2v_conv2d_dgrad_ex(const float* dy, const float* w, const float
                                    stride, Rc, Sc, split ? 1 : 0);
             for (int n0 = 0; n0 < N; n0 += nmax) {
                 const int nc = (N - n0 < nmax) ? N - n0 : nmax;
-                float* dxc = dx + (size_t)n0 * dxs;
+                float* dxc = dx + (size_t)n0 * dxo;
                 ConvArgs f{};
+                f.out_nstride = dxo;
                 f.tap_major = tapmaj ? 1 : 0;
                 f.a_src = at; f.b_src = dy + (size_t)n0 * dys; f.out = dxc;
                 f.N = nc; f.C = K; f.H = OH; f.W = OW; f.K = C; f.R = Rc; f.S = Sc; f.stride = 1;

@@ -227,12 +227,12 @@ def _conv_label(mode, M, min_rows=None):
 
 
 def _conv_launch(min_rows, name, label, flops, *args, shape=None, gscale=None, group_n=1, in_split=False, dy_split=False,
-                 out_split=False, det_ws_query=None, precision=None):
+                 out_split=False, det_ws_query=None, precision=None, out_nstride=0):
     """One ag2v_conv2d_*_ex call.  Arithmetic (precision, bf16x3 row threshold: ``min_rows``, None = library default) and the
     per-sample-group output scale travel as per-call options (ag2v_conv_opts): no process-wide switch is touched."""
     opts = _lib.ConvOpts(_PRECISION[0] if precision is None else int(precision), int(min_rows) if min_rows else 0, None if gscale is None else gscale.data_ptr(),
                          int(group_n), None, 1 if in_split else 0, 1 if dy_split else 0, 1 if out_split else 0,
-                         1 if _DETERMINISTIC[0] else 0, None, 0)
+                         1 if _DETERMINISTIC[0] else 0, None, 0, int(out_nstride))
     det_ws = None
     if _DETERMINISTIC[0] and det_ws_query is not None:      # weight gradient: slabs for the ordered reduction of its pixel-range splits
         dev, qargs = det_ws_query
@@ -352,6 +352,7 @@ _WSINK = {}          # id(weight tensor) -> [weakref to it, sink tensor or None]
 _EXTRA_SINKS = os.environ.get('AG2V_NO_EXTRA_SINKS') is None
 _MERGE_SHARED_DGRAD = os.environ.get('AG2V_NO_MERGED_DGRAD') is None      # conv2d_shared_input: one data-gradient launch (A/B)
 _MERGE_SHARED_WGRAD = os.environ.get('AG2V_NO_MERGED_WGRAD') is None      # ... and one weight-gradient launch
+_GRAD_SLOTS = os.environ.get('AG2V_NO_GRAD_SLOTS') is None                # ... whose concatenated dy the consumers write in place (_GradSlots; A/B)
 _SWAP_FEW_WGRAD = os.environ.get('AG2V_NO_SWAPPED_WGRAD') is None         # <= 4-row weight gradients with swapped operands
 _WSINK_CB = [None]   # graph-task id of the backward pass whose end-of-pass callback is queued (None: none; ids start at 0)
 
@@ -497,14 +498,21 @@ def _conv_fwd_launch(mr, x, w, bias, residual, y, stride, pad, relu, gscale=None
 
 def _conv_dgrad_launch(mr, dy, w, mask, dx, stride, pad, acc, gscale=None, group_n=1, dy_split=False, out_split=False):
     """dx (+)= data gradient.  The workspace holds the re-ordered filters and, for <= 4 input channels, the intermediate of the
-    1x1-GEMM form (caller memory: the library allocates nothing)."""
+    1x1-GEMM form (caller memory: the library allocates nothing).  dx may be a channel slice of a wider [N, Ctot, H, W] buffer
+    (_GradSlots): the kernels then step Ctot * H * W floats between samples (ag2v_conv_opts::out_nstride)."""
     N, C, H, W = dx.shape
+    onst = 0
+    if not dx.is_contiguous():
+        if dx.stride()[1:] != (H * W, W, 1) or dx.stride(0) < C * H * W:
+            raise RuntimeError("conv2d data gradient: dx must be dense or a channel slice of a dense buffer, got strides %s" % (dx.stride(),))
+        onst = dx.stride(0)
     K, _, R, S = w.shape
     nws = _lib.query('ag2v_conv2d_dgrad_workspace_floats', N, C, H, W, K, R, S, stride, pad)
     ws = torch.empty(nws, device=dy.device, dtype=torch.float32)
     _conv_launch(mr, 'ag2v_conv2d_dgrad_ex', 'conv_dgrad', 2.0 * N * K * dy.shape[2] * dy.shape[3] * C * R * S,
                  _ptr(dy), _ptr(w), _ptr(mask), _ptr(dx), N, C, H, W, K, R, S, stride, pad, 1 if acc else 0, _ptr(ws), nws, _stream(),
-                 shape=(N, C, H, W, K, R, stride), gscale=gscale, group_n=group_n, dy_split=dy_split, out_split=out_split)
+                 shape=(N, C, H, W, K, R, stride), gscale=gscale, group_n=group_n, dy_split=dy_split, out_split=out_split,
+                 out_nstride=onst)
 
 
 def _conv_wgrad_launch(mr, dy, x, dw, K, R, S, stride, pad, acc, groups=1, in_split=False, dy_split=False):
@@ -525,7 +533,8 @@ class _Conv2d(torch.autograd.Function):
     frame-batched generator (w = weight_orig, gscale = 1 / sigma_t of frame group t: spectral_scales)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, residual, gscale, stride, pad, relu, grad_premasked, relu_input, x_split=False, dx_split=False):
+    def forward(ctx, x, w, bias, residual, gscale, stride, pad, relu, grad_premasked, relu_input, x_split=False, dx_split=False,
+                dx_slot=None):
         w_in, bias_in = w, bias
         x, w, bias, residual, gscale = _c(x), _c(w), _c(bias), _c(residual), _c(gscale)
         _chk(x, w, bias, residual, gscale)
@@ -547,6 +556,7 @@ class _Conv2d(torch.autograd.Function):
         ctx.cfg = (stride, pad, bias is not None, residual is not None, mr, relu, grad_premasked, relu_input, group_n)
         ctx.x_split = bool(x_split)
         ctx.dx_split = bool(dx_split)
+        ctx.dx_slot = dx_slot if (dx_split and stride == 1 and C > 4) else None
         ctx.scope = _SCOPE[-1]
         ctx.wkey = _wsink_register(w_in) if ctx.needs_input_grad[1] else None
         ctx.bkey = _wsink_register(bias_in) if (bias_in is not None and ctx.needs_input_grad[2] and _EXTRA_SINKS) else None
@@ -573,7 +583,10 @@ class _Conv2d(torch.autograd.Function):
             _lib.call('ag2v_act_bwd', 0, _ptr(dy), _ptr(y), _ptr(g), dy.numel(), 0.0, st)   # op 0 = LeakyReLU(slope 0)
             dy = g
         if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
+            # (the producer of x collects its outputs' gradients in one buffer: this one goes straight into its slice)
+            dx = ctx.dx_slot[0].view(ctx.dx_slot[1], N, H, W, x.device) if ctx.dx_slot is not None else torch.empty_like(x)
+            if tuple(dx.shape) != tuple(x.shape):
+                raise RuntimeError("conv2d backward: gradient slot of shape %s for an input of shape %s" % (tuple(dx.shape), tuple(x.shape)))
             _conv_dgrad_launch(mr, dy, w, x if relu_input else None, dx, stride, pad, 0, gscale, group_n, dy_split=dys,
                                out_split=ctx.dx_split)
             if ctx.dx_split:
@@ -619,7 +632,7 @@ class _Conv2d(torch.autograd.Function):
                 _lib.call('ag2v_channel_sum_acc', _ptr(dy), _ptr(bbuf), N, K, dy.shape[2] * dy.shape[3], bacc | _det_bit(), st)
         if has_res and ctx.needs_input_grad[3]:
             dres = dy
-        return dx, dw, db, dres, dgs, None, None, None, None, None, None, None
+        return dx, dw, db, dres, dgs, None, None, None, None, None, None, None, None
 
 
 def conv2d(x, w, bias=None, stride=1, pad=0, residual=None, relu=False, grad_premasked=False, relu_input=False, gscale=None):
@@ -633,7 +646,7 @@ def conv2d(x, w, bias=None, stride=1, pad=0, residual=None, relu=False, grad_pre
     # applies that ReLU's mask in its epilogue, writes them
     dx_split = bool(relu_input and dy_ok and x.requires_grad and _take_dy_split(x))
     y = _Conv2d.apply(x, w, bias, residual, gscale, int(stride), int(pad), bool(relu), bool(grad_premasked), bool(relu_input),
-                      is_split(x), dx_split)
+                      is_split(x), dx_split, x._ag2v_dy_split_ok.slot if dx_split else None)
     if dy_ok and y.grad_fn is not None:
         _offer_dy_split(y)              # a SPADE backward that is y's only consumer may hand back d(y) as split words
     return y
@@ -662,10 +675,39 @@ class _DySplitOffer(object):
     """`t._ag2v_dy_split_ok` on an operator output t: the producer's backward accepts d(t) as split words.  The producing autograd
     node keeps the same object (`_ag2v_offers[output_nr]`), so its backward knows whether a consumer took the offer -- and then
     insists on receiving that consumer's split-word tensor (anything else means t had a second consumer)."""
-    __slots__ = ('taken',)
+    __slots__ = ('taken', 'slot')
 
     def __init__(self):
         self.taken = False
+        self.slot = None        # (_GradSlots, index): where the taker's backward writes d(t) (conv2d_shared_input)
+
+
+class _GradSlots(object):
+    """One [N, sum K_i, H, W] buffer for the gradients of the n outputs of a conv2d_shared_input call.  The call's backward runs ONE
+    weight-gradient and ONE data-gradient launch over the concatenated output channels; the consumers of its outputs (one
+    conv2d(relu_input=True) each: a SPADE's gamma | beta convolution reading relu(mlp_shared)) write their data gradients straight into
+    channel slice i of this buffer instead of n tensors that the backward then copied together (torch.cat: 16 GB read + written per
+    c3 step).  Allocated by the first consumer's backward, dropped by the producer's."""
+    __slots__ = ('ks', 'buf')
+
+    def __init__(self, ks):
+        self.ks = [int(k) for k in ks]
+        self.buf = None
+
+    def view(self, i, N, H, W, device):
+        if self.buf is None or tuple(self.buf.shape) != (N, sum(self.ks), H, W):
+            self.buf = torch.empty((N, sum(self.ks), H, W), device=device, dtype=torch.float32)
+        off = sum(self.ks[:i])
+        return self.buf[:, off:off + self.ks[i]]
+
+    def holds(self, i, t):
+        """t is exactly channel slice i of the buffer."""
+        b = self.buf
+        if b is None or t is None or t.dim() != 4:
+            return False
+        off = sum(self.ks[:i])
+        return (t.data_ptr() == b.data_ptr() + off * b.shape[2] * b.shape[3] * 4 and tuple(t.shape) == (b.shape[0], self.ks[i], b.shape[2], b.shape[3])
+                and t.stride() == b.stride())
 
 
 def _offer_dy_split(t):
@@ -798,12 +840,18 @@ class _ConvSharedInput(torch.autograd.Function):
         # slices of ONE buffer (the per-weight sinks are views of it), so the gathered input is read once per pass
         merged_w = (_MERGE_SHARED_WGRAD and n > 1 and all(d is not None for d in dys)
                     and all(ctx.needs_input_grad[7 + 2 * i] for i in range(n)))
+        # the consumers wrote their data gradients into the slices of one buffer (_GradSlots): that buffer IS the concatenation
+        slots = getattr(ctx, '_ag2v_slots', None)
+        slotted = (slots is not None and merged_w and not (relu and not grad_premasked)
+                   and (_MERGE_SHARED_DGRAD or not ctx.needs_input_grad[0]) and all(slots.holds(i, d) for i, d in enumerate(dys)))
+        slot_sums = None
         for i in range(n):
             w, dy = ws_[i], dys[i]
             if dy is None:
                 grads += [None, None]
                 continue
-            dy = dy.contiguous()
+            if not slotted:
+                dy = dy.contiguous()
             K, _, R, S = w.shape
             if ys[i] is not None:
                 g = torch.empty_like(dy)
@@ -816,11 +864,27 @@ class _ConvSharedInput(torch.autograd.Function):
                 _conv_wgrad_launch(mr, dy, x, buf, K, R, S, stride, pad, acc, in_split=ctx.x_split, dy_split=dys_split)
             if has_b[i] and ctx.needs_input_grad[8 + 2 * i]:
                 bbuf, bacc, db = _wsink_take(ctx.bkeys[i], ctx.w_alive[2 * i + 1])
-                _lib.call('ag2v_channel_sum_acc_s', _ptr(dy), _ptr(bbuf), N, K, dy.shape[2] * dy.shape[3], bacc | _det_bit(), 1 if dys_split else 0, st)
+                if slotted:         # channel sums of the whole buffer, once; each bias takes its slice
+                    if slot_sums is None:
+                        slot_sums = torch.empty(slots.buf.shape[1], device=dy.device, dtype=torch.float32)
+                        _lib.call('ag2v_channel_sum_acc_s', _ptr(slots.buf), _ptr(slot_sums), N, slots.buf.shape[1], dy.shape[2] * dy.shape[3],
+                                  _det_bit(), 1 if dys_split else 0, st)
+                    off = sum(slots.ks[:i])
+                    if bacc:
+                        bbuf.add_(slot_sums[off:off + K])
+                    else:
+                        bbuf.copy_(slot_sums[off:off + K])
+                else:
+                    _lib.call('ag2v_channel_sum_acc_s', _ptr(dy), _ptr(bbuf), N, K, dy.shape[2] * dy.shape[3], bacc | _det_bit(), 1 if dys_split else 0, st)
             grads += [dw, db]
         dyc = None
         if merged_w:
-            dyc = torch.cat([d for _, d, _ in live], dim=1)
+            if slotted:
+                dyc = slots.buf
+                if dys_split:
+                    mark_split(dyc)
+            else:
+                dyc = torch.cat([d for _, d, _ in live], dim=1)
             Kt = dyc.shape[1]
             R, S = ws_[0].shape[2], ws_[0].shape[3]
             cat, acc, outs = _wsink_take_group(ctx.wkeys, [w for w, _, _ in live])
@@ -842,6 +906,8 @@ class _ConvSharedInput(torch.autograd.Function):
             else:
                 for j, (w, dy, _) in enumerate(live):
                     _conv_dgrad_launch(mr, dy, w, None, dx, stride, pad, 0 if j == 0 else 1, dy_split=dys_split)
+        if slots is not None:
+            slots.buf = None
         return (dx, None, None, None, None, None, None) + tuple(grads)
 
 
@@ -866,6 +932,13 @@ def conv2d_shared_input(x, weights, biases, stride=1, pad=0, relu=False, grad_pr
         for o in outs:
             if o.grad_fn is not None:
                 _offer_dy_split(o)          # the consumers' data gradients may hand d(out) back as split words (all of them or none)
+        node = outs[0].grad_fn
+        if (node is not None and len(outs) > 1 and _MERGE_SHARED_WGRAD and _GRAD_SLOTS and int(stride) == 1
+                and all(o.grad_fn is node for o in outs) and len(set(tuple(w.shape[2:]) for w in weights)) == 1):
+            # ... and write them into the slices of one buffer, which this call's backward reads as the concatenation (_GradSlots)
+            node._ag2v_slots = _GradSlots([o.shape[1] for o in outs])
+            for i, o in enumerate(outs):
+                o._ag2v_dy_split_ok.slot = (node._ag2v_slots, i)
     return outs
 
 

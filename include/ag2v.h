@@ -58,7 +58,13 @@ extern "C" {
  *              the previous dw) in split order.  The default (0) accumulates split partials with fp32 atomics, whose order varies
  *              from run to run (~1e-7 relative per sum);
  *   det_workspace / det_workspace_floats: (weight gradient, deterministic) caller scratch of at least
- *              ag2v_conv2d_wgrad_det_workspace_floats(...) floats (may be NULL when that returns 0). */
+ *              ag2v_conv2d_wgrad_det_workspace_floats(...) floats (may be NULL when that returns 0);
+ *   out_nstride: (data gradient, stride 1, not accumulating, more than 4 input channels) floats between consecutive samples of dx;
+ *              0 = C * H * W, the dense tensor.  Larger: dx is the channel slice [:, c0 : c0 + C] of a wider [N, Ctot, H, W] buffer
+ *              (out_nstride = Ctot * H * W, dx = buffer + c0 * H * W) -- the gradients of several convolutions that share a
+ *              consumer are written straight into the concatenation that consumer's merged weight / data gradient reads
+ *              (conv2d_shared_input: every SPADE's mlp_shared, normalization.py:90-94).  The mask keeps the dense layout.
+ *              Anything else with a non-dense stride: AG2V_EINVAL. */
 typedef struct ag2v_conv_opts {
     int precision;
     int min_rows;
@@ -71,6 +77,7 @@ typedef struct ag2v_conv_opts {
     int deterministic;
     float* det_workspace;
     size_t det_workspace_floats;
+    long long out_nstride;
 } ag2v_conv_opts;
 /* Defaults of calls without options (process-wide; the product passes options on every call). */
 int ag2v_set_conv_precision(int mode);

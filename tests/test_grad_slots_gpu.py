@@ -1,0 +1,104 @@
+"""conv2d_shared_input's gradient slots (ops._GradSlots): the consumers of its outputs -- one conv2d(relu_input=True) each, the
+gamma | beta convolution of a SPADE reading relu(mlp_shared(seg)), reference normalization.py:90-94,104-106 -- write their data
+gradients into the channel slices of ONE [N, sum K_i, H, W] buffer (ag2v_conv_opts::out_nstride) that the group's merged weight /
+data gradient then reads in place of torch.cat(dys).  Same kernels, same operands: every gradient must equal the torch.cat path
+(AG2V_NO_GRAD_SLOTS) and an fp64 autograd evaluation of the same graph."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _graph(ops, seg, ws, bs, gws, gbs, heads):
+    """three mlp_shared convolutions on one map, each read by its own gamma|beta convolution, whose outputs meet fp32 heads"""
+    actv = ops.conv2d_shared_input(seg, ws, bs, 1, 1, relu=True, grad_premasked=True, out_split=[True] * len(ws), grad_split=True)
+    loss = 0.
+    for a, gw, gb, h in zip(actv, gws, gbs, heads):
+        loss = loss + (ops.conv2d(a, gw, gb, 1, 1, relu_input=True) * h).sum()
+    return loss
+
+
+def _ref64(seg, ws, bs, gws, gbs, heads, masks):
+    """masks: where the product's forward found the pre-activation positive (a pre-activation within rounding of zero may fall on
+    either side in fp64; the ReLU's subgradient there is the product's choice)"""
+    F = torch.nn.functional
+    loss = 0.
+    for w, b, gw, gb, h, m in zip(ws, bs, gws, gbs, heads, masks):
+        loss = loss + (F.conv2d(F.conv2d(seg, w, b, 1, 1) * m, gw, gb, 1, 1) * h).sum()
+    return loss
+
+
+@pytest.mark.parametrize("cfg", [(4, 64, 64, 64, (128, 128, 128), 96), (2, 32, 128, 128, (128, 128), 256), (3, 64, 32, 32, (128, 64, 128), 128)], ids=str)
+def test_gradient_slots_equal_the_concatenation(cfg, device, monkeypatch):
+    from ag2video_amd import _lib, ops
+    N, C, H, W, Ks, G = cfg
+    torch.manual_seed(11)
+    seg0 = torch.randn(N, C, H, W, device=device)
+    hi = seg0.to(torch.bfloat16)
+    lo = (seg0 - hi.float()).to(torch.bfloat16)
+    words = ((hi.view(torch.int16).to(torch.int32) << 16) | (lo.view(torch.int16).to(torch.int32) & 0xFFFF)).view(torch.float32)
+    segv = hi.float() + lo.float()                     # the values the split words stand for
+    ws = [torch.randn(k, C, 3, 3, device=device) * 0.06 for k in Ks]
+    bs = [torch.randn(k, device=device) * 0.1 for k in Ks]
+    gws = [torch.randn(G, k, 3, 3, device=device) * 0.04 for k in Ks]
+    gbs = [torch.randn(G, device=device) * 0.1 for _ in Ks]
+    heads = [torch.randn(N, G, H, W, device=device) for _ in Ks]
+    cats = []
+    real_cat = torch.cat
+
+    def counting_cat(ts, *a, **k):
+        out = real_cat(ts, *a, **k)
+        cats.append(out.numel())
+        return out
+
+    def run(slots_on):
+        monkeypatch.setattr(ops, '_GRAD_SLOTS', slots_on)
+        leaves = [t.clone().requires_grad_(True) for t in ws + bs + gws + gbs]
+        n = len(Ks)
+        seg = ops.mark_split(words.clone()).requires_grad_(True)
+        ops.mark_split(seg)
+        del cats[:]
+        with ops.conv_precision('bf16x3'), ops.bf16x3_min_rows(32), ops.deterministic(True):
+            loss = _graph(ops, seg, leaves[:n], leaves[n:2 * n], leaves[2 * n:3 * n], leaves[3 * n:], heads)
+            monkeypatch.setattr(torch, 'cat', counting_cat)
+            try:
+                loss.backward()
+            finally:
+                monkeypatch.setattr(torch, 'cat', real_cat)
+        return float(loss), [seg.grad] + [t.grad for t in leaves], max(cats) if cats else 0
+
+    l1, g1, big1 = run(True)
+    l0, g0, big0 = run(False)
+    assert big0 >= N * sum(Ks) * H * W, "the reference path concatenates the gradients"
+    assert big1 < N * min(Ks) * H * W, "with slots no activation-sized torch.cat runs in the backward"
+    assert l1 == l0
+    for a, b in zip(g1, g0):
+        assert torch.equal(a, b)                      # deterministic mode: the same sums in the same order
+    # ... and both are the gradients of the graph (fp64 autograd on the split words' values)
+    leaves = [t.double().requires_grad_(True) for t in ws + bs + gws + gbs]
+    n = len(Ks)
+    seg = segv.double().requires_grad_(True)
+    with torch.no_grad(), ops.conv_precision('bf16x3'), ops.bf16x3_min_rows(32):
+        actv = ops.conv2d_shared_input(ops.mark_split(words.clone()), ws, bs, 1, 1, relu=True, grad_premasked=True, out_split=[True] * n)
+        masks = [((a.view(torch.int32) & 0x7FFF0000) != 0).double() * (a.view(torch.int32) >= 0).double() for a in actv]     # hi part > 0
+    _ref64(seg, leaves[:n], leaves[n:2 * n], leaves[2 * n:3 * n], leaves[3 * n:], [h.double() for h in heads], masks).backward()
+    refs = [seg.grad] + [t.grad for t in leaves]
+    for a, r in zip(g1, refs):
+        assert float((a.double() - r).abs().max()) <= 3e-4 * float(r.abs().max())
+
+
+def test_strided_data_gradient_is_refused_where_no_kernel_writes_it(device):
+    """out_nstride with a strided / accumulating / few-channel data gradient: AG2V_EINVAL, never a silently dense write."""
+    from ag2video_amd import ops
+    dy = torch.randn(2, 64, 16, 16, device=device)
+    w = torch.randn(64, 32, 4, 4, device=device)
+    buf = torch.zeros(2, 96, 32, 32, device=device)
+    with pytest.raises(RuntimeError):
+        ops._conv_dgrad_launch(32, dy, w, None, buf[:, 16:48], 2, 1, 0)          # stride 2
+    w3 = torch.randn(64, 32, 3, 3, device=device)
+    buf = torch.zeros(2, 96, 16, 16, device=device)
+    with pytest.raises(RuntimeError):
+        ops._conv_dgrad_launch(32, dy, w3, None, buf[:, 16:48], 1, 1, 1)         # accumulating
+    with pytest.raises(RuntimeError):
+        ops._conv_dgrad_launch(32, dy, w3, None, buf[:, :, ::2], 1, 1, 0)        # not a channel slice
+    assert float(buf.abs().max()) == 0.0
