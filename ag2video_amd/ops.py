@@ -354,6 +354,7 @@ _MERGE_SHARED_DGRAD = os.environ.get('AG2V_NO_MERGED_DGRAD') is None      # conv
 _MERGE_SHARED_WGRAD = os.environ.get('AG2V_NO_MERGED_WGRAD') is None      # ... and one weight-gradient launch
 _GRAD_SLOTS = os.environ.get('AG2V_NO_GRAD_SLOTS') is None                # ... whose concatenated dy the consumers write in place (_GradSlots; A/B)
 _SWAP_FEW_WGRAD = os.environ.get('AG2V_NO_SWAPPED_WGRAD') is None         # <= 4-row weight gradients with swapped operands
+_SWAP_WIDE_WGRAD = os.environ.get('AG2V_NO_WIDE_SWAPPED_WGRAD') is None   # ... and layers with fewer output than input channels (A/B)
 _WSINK_CB = [None]   # graph-task id of the backward pass whose end-of-pass callback is queued (None: none; ids start at 0)
 
 
@@ -524,6 +525,48 @@ def _conv_wgrad_launch(mr, dy, x, dw, K, R, S, stride, pad, acc, groups=1, in_sp
                  det_ws_query=(x.device, (N, C, H, W, K, R, S, stride, pad, int(groups))))
 
 
+def _wgrad_tile_area(rows, cols):
+    """Padded GEMM area of a bf16x3 weight-gradient launch with `rows` dense rows and `cols` gathered columns (plan_wgrad_bf16x3:
+    256 x 128 tiles from 192 rows on when they pad no more rows, else 128 x 256)."""
+    tall = rows >= 192 and -(-rows // 256) * 256 <= -(-rows // 128) * 128
+    bm, bn = (256, 128) if tall else (128, 256)
+    return (-(-rows // bm) * bm) * (-(-cols // bn) * bn)
+
+
+def _wgrad_swap_pays(mr, x_shape, dy_shape, K, R, S, stride, pad, x_split, dy_split):
+    """A same-size stride-1 weight gradient may run with its operands swapped: x becomes the dense row operand, dy the gathered
+    one, and the launch computes dW'[c][k][r'][s'] = dW[k][c][R-1-r'][S-1-s'].  The kernels are bound by their producer waves
+    (gather + split of the column operand), whose work and the matrix work both follow the PADDED tile area: a layer with fewer output
+    than input channels (up_3's 128 -> 64 and the flow network's 64 -> 32 layers: 64 / 32 rows on a 128-row tile) pads less the
+    other way round -- 6.0 -> 3.6 ms for 120 x 128 x 256 x 256 -> 64."""
+    N, C, H, W = x_shape
+    if not (_SWAP_WIDE_WGRAD and K > 4 and stride == 1 and R == S and 2 * pad == R - 1 and tuple(dy_shape[2:]) == (H, W) and _PRECISION[0] == 1):
+        return False
+    if _wgrad_tile_area(C, K * R * S) > 0.8 * _wgrad_tile_area(K, C * R * S):
+        return False
+    # the swapped launch reads dy in x's place (and the other way round): each must be readable in that role
+    # (mr: the node's backward row threshold, recorded in its forward)
+    if (mr or _lib.query('ag2v_get_bf16x3_min_rows')) > min(C, K):
+        return False
+    if dy_split and not _lib.query('ag2v_conv2d_split_input_ok', N, K, H, W, C, R, S, 1, pad, int(mr or 0), int(mr or 0), 1):
+        return False
+    if x_split and not _lib.query('ag2v_conv2d_split_dy_ok', N, K, H, W, C, R, S, 1, pad, int(mr or 0), 1):
+        return False
+    return True
+
+
+def _conv_wgrad_swapped(mr, dy, x, out, K, R, S, pad, acc, groups, x_split, dy_split):
+    """out (+)= the weight gradient [groups x] [K, C, R, S], computed as the swapped launch's [groups x] [C, K, R, S] (see above)."""
+    C = x.shape[1]
+    t = torch.empty(((groups,) if groups > 1 else ()) + (C, K, R, S), device=dy.device, dtype=torch.float32)
+    _conv_wgrad_launch(mr, x, dy, t, C, R, S, 1, pad, 0, groups=groups, in_split=dy_split, dy_split=x_split)
+    t = t.flip(-2, -1).transpose(-4, -3)
+    if acc:
+        out.add_(t)
+    else:
+        out.copy_(t)
+
+
 class _Conv2d(torch.autograd.Function):
     """relu: y = max(conv, 0) in the forward epilogue; its backward masks dy with (y > 0) unless ``grad_premasked`` says the
     consumer of y already did (see relu_input).  relu_input: x is itself a ReLU output whose only consumer is this convolution
@@ -595,7 +638,10 @@ class _Conv2d(torch.autograd.Function):
             # per-group weight gradients G_t = dL/d(scale_t W), then dw = sum_t scale_t G_t and dscale_t = <G_t, W> in one pass
             T = gscale.numel()
             G = torch.empty((T,) + tuple(w.shape), device=dy.device, dtype=torch.float32)
-            _conv_wgrad_launch(mr, dy, x, G, K, R, S, stride, pad, 0, groups=T, in_split=ctx.x_split, dy_split=dys)
+            if _wgrad_swap_pays(mr, x.shape, dy.shape, K, R, S, stride, pad, ctx.x_split, dys):
+                _conv_wgrad_swapped(mr, dy, x, G, K, R, S, pad, 0, T, ctx.x_split, dys)
+            else:
+                _conv_wgrad_launch(mr, dy, x, G, K, R, S, stride, pad, 0, groups=T, in_split=ctx.x_split, dy_split=dys)
             buf, acc, dw = _wsink_take(ctx.wkey, w) if ctx.needs_input_grad[1] else (torch.empty_like(w), 0, None)
             dgs = torch.empty(T, device=dy.device, dtype=torch.float32)
             _lib.call('ag2v_sn_group_combine', _ptr(G), _ptr(w), _ptr(gscale), T, w.numel(), _ptr(buf), acc | _det_bit(), _ptr(dgs), st)
@@ -616,6 +662,8 @@ class _Conv2d(torch.autograd.Function):
                     buf.add_(t)
                 else:
                     buf.copy_(t)
+            elif _wgrad_swap_pays(mr, x.shape, dy.shape, K, R, S, stride, pad, ctx.x_split, dys):
+                _conv_wgrad_swapped(mr, dy, x, buf, K, R, S, pad, acc, 1, ctx.x_split, dys)
             else:
                 _conv_wgrad_launch(mr, dy, x, buf, K, R, S, stride, pad, acc, in_split=ctx.x_split, dy_split=dys)
         if has_bias and ctx.needs_input_grad[2]:

@@ -102,3 +102,54 @@ def test_strided_data_gradient_is_refused_where_no_kernel_writes_it(device):
     with pytest.raises(RuntimeError):
         ops._conv_dgrad_launch(32, dy, w3, None, buf[:, :, ::2], 1, 1, 0)        # not a channel slice
     assert float(buf.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("cfg", [(4, 128, 64, 64, 64, 3, 1), (6, 64, 32, 64, 32, 3, 2), (2, 128, 32, 32, 48, 1, 1)], ids=str)
+def test_weight_gradient_with_swapped_operands(cfg, device):
+    """Layers with fewer output than input channels (up_3's 128 -> 64 convolutions, spade_generator.py:29-34; the flow network's
+    64 -> 32 layers) run their same-size stride-1 weight gradient with x as the dense row operand and dy as the gathered one
+    (ops._wgrad_swap_pays / _conv_wgrad_swapped: less tile padding, less producer work): against the plain launch and fp64, fp32 and
+    split-word operands, per-frame-group gradients (spectral norm) and accumulation."""
+    from ag2video_amd import ops
+    N, C, H, W, K, R, G = cfg
+    pad = (R - 1) // 2
+    torch.manual_seed(5)
+    x = torch.randn(N, C, H, W, device=device)
+    dy = torch.randn(N, K, H, W, device=device)
+
+    def words(t):
+        hi = t.to(torch.bfloat16)
+        lo = (t - hi.float()).to(torch.bfloat16)
+        return ((hi.view(torch.int16).to(torch.int32) << 16) | (lo.view(torch.int16).to(torch.int32) & 0xFFFF)).view(torch.float32), hi.float() + lo.float()
+    xw, xv = words(x)
+    dw_, dv = words(dy)
+    w0 = torch.zeros(K, C, R, R, device=device, dtype=torch.float64, requires_grad=True)
+
+    def ref(xs, dys):
+        y = torch.nn.functional.conv2d(xs.double(), w0, None, 1, pad)
+        return torch.autograd.grad((y * dys.double()).sum(), w0)[0]
+    with ops.conv_precision('bf16x3'), torch.no_grad():
+        assert ops._wgrad_swap_pays(32, x.shape, dy.shape, K, R, R, 1, pad, False, False) == (R == 3)
+        assert not ops._wgrad_swap_pays(32, x.shape, dy.shape, K, R, R, 2, pad, False, False)
+        assert not ops._wgrad_swap_pays(32, dy.shape, x.shape, C, R, R, 1, pad, False, False)       # more output than input channels
+        for xs, ds in ((False, False), (True, False), (False, True), (True, True)):
+            xa, da = (xw if xs else x), (dw_ if ds else dy)
+            with torch.enable_grad():
+                r = ref(xv if xs else x, dv if ds else dy)
+            sc = float(r.abs().max())
+            plain = torch.empty(K, C, R, R, device=device)
+            ops._conv_wgrad_launch(32, da, xa, plain, K, R, R, 1, pad, 0, in_split=xs, dy_split=ds)
+            sw = torch.empty(K, C, R, R, device=device)
+            ops._conv_wgrad_swapped(32, da, xa, sw, K, R, R, pad, 0, 1, xs, ds)
+            assert float((sw.double() - r).abs().max()) <= 2e-4 * sc, (xs, ds)
+            assert float((sw - plain).abs().max()) <= 2e-5 * sc, (xs, ds)
+            ops._conv_wgrad_swapped(32, da, xa, sw, K, R, R, pad, 1, 1, xs, ds)                       # accumulate
+            assert float((sw.double() - 2 * r).abs().max()) <= 4e-4 * sc
+        if G > 1:
+            g = torch.empty(G, K, C, R, R, device=device)
+            ops._conv_wgrad_swapped(32, dy, x, g, K, R, R, pad, 0, G, False, False)
+            for i in range(G):
+                sl = slice(i * N // G, (i + 1) * N // G)
+                with torch.enable_grad():
+                    rg = ref(x[sl], dy[sl])
+                assert float((g[i].double() - rg).abs().max()) <= 2e-4 * float(rg.abs().max())
