@@ -1065,6 +1065,114 @@ extern "C" int ag2v_conv2d_dgrad(const float* dy, const float* w, float* dx,
     return ag2v_conv2d_dgrad_acc(dy, w, nullptr, dx, N, C, H, W, K, R, S, stride, pad, 0, workspace, stream);
 }
 
+// ---------------------------------------------------------------- weight gradient of a convolution with <= 4 output channels
+// The discriminators' last layer (512 -> 1, 4 x 4, discriminator.py:368-379) and any other few-row layer whose swapped form
+// (ops._SWAP_FEW_WGRAD) does not apply: as a GEMM this has 1-4 rows on a 32-row tile and its 130 k-long pixel reduction was gathered
+// tap by tap (2 TF, 1.15 ms for 284 MB of input).  Here a workgroup owns ONE input channel (and one slice of the images): a thread
+// walks groups of 4 output pixels, keeps the S x (S + 3) input window and the 4 K output gradients in registers and feeds
+// 4 K S S FMAs from them; the K S S sums meet by wave reduction + LDS, one atomic add (or, with one slice per channel -- the
+// deterministic form -- one plain store) per weight.
+template <int KR, int S>
+__global__ __launch_bounds__(256) void conv_wgrad_fewrow_kernel(ConvArgs p) {
+    __shared__ float red[4][KR * S * S];
+    const int c = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int QX = (p.OW + 3) >> 2;
+    const long long total = (long long)p.N * p.OH * QX;
+    const long long per = (total + gridDim.y - 1) / gridDim.y;
+    const long long q0 = (long long)blockIdx.y * per, q1 = min(total, q0 + per);
+    float acc[KR][S][S];
+#pragma unroll
+    for (int k = 0; k < KR; ++k)
+#pragma unroll
+        for (int r = 0; r < S; ++r)
+#pragma unroll
+            for (int s2 = 0; s2 < S; ++s2) acc[k][r][s2] = 0.f;
+    const float* __restrict__ dy = p.a_src;
+    const float* __restrict__ x = p.b_src;
+    const size_t oplane = (size_t)p.OH * p.OW, iplane = (size_t)p.H * p.W;
+    for (long long q = q0 + threadIdx.x; q < q1; q += 256) {
+        const int xq = (int)(q % QX);
+        const long long t = q / QX;
+        const int oy = (int)(t % p.OH), n = (int)(t / p.OH);
+        const int ox0 = xq * 4;
+        float g[KR][4];
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+            const float* gp = dy + ((size_t)n * KR + k) * oplane + (size_t)oy * p.OW + ox0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g[k][j] = (ox0 + j < p.OW) ? gp[j] : 0.f;
+        }
+        const float* xp = x + ((size_t)n * p.C + c) * iplane;
+        const int ix0 = ox0 - p.pad_w;
+        float v[S][S + 3];
+#pragma unroll
+        for (int r = 0; r < S; ++r) {
+            const int iy = oy + r - p.pad;
+            const bool rowok = (unsigned)iy < (unsigned)p.H;
+#pragma unroll
+            for (int i = 0; i < S + 3; ++i)
+                v[r][i] = (rowok && (unsigned)(ix0 + i) < (unsigned)p.W) ? xp[(size_t)iy * p.W + ix0 + i] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < KR; ++k)
+#pragma unroll
+            for (int r = 0; r < S; ++r)
+#pragma unroll
+                for (int s2 = 0; s2 < S; ++s2)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[k][r][s2] = fmaf(g[k][j], v[r][s2 + j], acc[k][r][s2]);
+    }
+#pragma unroll
+    for (int k = 0; k < KR; ++k)
+#pragma unroll
+        for (int r = 0; r < S; ++r)
+#pragma unroll
+            for (int s2 = 0; s2 < S; ++s2) {
+                const float tsum = wave_sum(acc[k][r][s2]);
+                if (lane == 0) red[wave][(k * S + r) * S + s2] = tsum;
+            }
+    __syncthreads();
+    if (threadIdx.x < KR * S * S) {
+        const int i = threadIdx.x, k = i / (S * S), rs = i - k * (S * S);
+        const float tsum = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+        float* o = p.out + ((size_t)k * p.C + c) * (S * S) + rs;
+        if (gridDim.y > 1) atomicAdd(o, tsum);                 // (the launcher zeroed dw unless it accumulates)
+        else *o = p.accumulate ? *o + tsum : tsum;
+    }
+}
+template <int KR>
+static bool launch_wgrad_fewrow_k(const ConvArgs& a, dim3 grid, hipStream_t st) {
+    switch (a.S) {
+        case 1: hipLaunchKernelGGL((conv_wgrad_fewrow_kernel<KR, 1>), grid, dim3(256), 0, st, a); return true;
+        case 3: hipLaunchKernelGGL((conv_wgrad_fewrow_kernel<KR, 3>), grid, dim3(256), 0, st, a); return true;
+        case 4: hipLaunchKernelGGL((conv_wgrad_fewrow_kernel<KR, 4>), grid, dim3(256), 0, st, a); return true;
+        default: return false;
+    }
+}
+static bool wgrad_fewrow_ok(int K, int R, int S, int stride, int groups, int x_split, int dy_split) {
+    static const bool on = getenv("AG2V_NO_FEWROW_WGRAD") == nullptr;
+    return on && K <= 4 && R == S && (S == 1 || S == 3 || S == 4) && stride == 1 && groups == 1 && !x_split && !dy_split;
+}
+// det: one slice per channel (plain stores, a fixed summation order)
+static int launch_wgrad_fewrow(ConvArgs& a, int det, hipStream_t st) {
+    const long long quads = (long long)a.N * a.OH * ((a.OW + 3) >> 2);
+    int slices = det ? 1 : (int)ceil_div(1536, a.C);
+    const int max_slices = (int)((quads + 2047) / 2048);
+    if (slices > max_slices) slices = max_slices;
+    if (slices < 1) slices = 1;
+    if (slices > 1 && !a.accumulate) {
+        if (hipMemsetAsync(a.out, 0, (size_t)a.K * a.C * a.R * a.S * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
+    }
+    const dim3 grid(a.C, slices);
+    const bool ok = a.K == 1 ? launch_wgrad_fewrow_k<1>(a, grid, st) : a.K == 2 ? launch_wgrad_fewrow_k<2>(a, grid, st)
+                  : a.K == 3 ? launch_wgrad_fewrow_k<3>(a, grid, st) : launch_wgrad_fewrow_k<4>(a, grid, st);
+    if (!ok) return AG2V_EINVAL;
+    set_last_conv_kernel("conv_wgrad_fewrow_kernel");
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
+
 // Weight gradient.  accumulate != 0: dw += instead of dw = : a weight used by several forward calls of one step collects its
 // gradient in one buffer.  groups > 1 (N % groups == 0): the batch is `groups` consecutive sample groups and dw is
 // [groups][K, C, R, S] -- one gradient per group (the frame-batched generator needs dL/dWbar_t per frame t for spectral norm).
@@ -1085,6 +1193,10 @@ static int wgrad_launch(const float* dy, const float* x, float* dw, int N, int C
     a.groups = groups; a.gq = (int)(Q / groups); a.out_gstride = (long long)a.M * a.NG;
     const long long mn = (long long)a.M * a.NG;
     int bm = 0;
+    if (!split && wgrad_fewrow_ok(K, R, S, stride, groups, x_split, dy_split)) {      // <= 4 rows: one workgroup per input channel
+        if (need) { *need = 0; return AG2V_OK; }
+        return launch_wgrad_fewrow(a, det, st);
+    }
     if (!split && f32ws) {       // exact fp32, 8 + 8 waves, 16-byte loads: the planning of the split kernels
         a.a_bytes = (unsigned)((long long)N * K * OH * OW * 4); a.b_bytes = (unsigned)((long long)N * C * H * W * 4);
         a.f32 = 1;

@@ -295,7 +295,7 @@ def main():
                     "backward, joined behind the discriminator phase); alone = the same buckets reduced with nothing else running; the "
                     "discriminator's all-reduce is synchronous (fully exposed)"})
     if os.environ.get('AG2V_TIMING_DETAIL') and rank == 0:
-        det = ops.kernel_timing_summary(by_shape=True)
+        det = ops.kernel_timing_summary(by_shape=True, by_scope=os.environ.get('AG2V_TIMING_SCOPES') is not None)
         top = int(os.environ['AG2V_TIMING_DETAIL']) if os.environ['AG2V_TIMING_DETAIL'].isdigit() and int(os.environ['AG2V_TIMING_DETAIL']) > 1 else 45
         for k, v in sorted(det.items(), key=lambda kv: -kv[1]['ms'])[:top]:
             print('DETAIL %8.1f ms %5d launches %6.1f TF  %s' % (v['ms'], v['launches'], v['flops'] / (v['ms'] * 1e-3) / 1e12, k), file=sys.stderr)

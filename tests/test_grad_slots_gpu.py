@@ -153,3 +153,34 @@ def test_weight_gradient_with_swapped_operands(cfg, device):
                 with torch.enable_grad():
                     rg = ref(x[sl], dy[sl])
                 assert float((g[i].double() - rg).abs().max()) <= 2e-4 * float(rg.abs().max())
+
+
+@pytest.mark.parametrize("cfg", [(6, 40, 18, 18, 1, 4, 2), (5, 24, 20, 28, 3, 3, 1), (3, 16, 9, 33, 2, 1, 0), (120, 64, 34, 34, 1, 4, 2), (4, 8, 12, 12, 4, 4, 1)], ids=str)
+def test_few_row_weight_gradient_kernel(cfg, device):
+    """conv_wgrad_fewrow_kernel: <= 4 output channels (the discriminators' last layer, 512 -> 1 4x4 pad 2, discriminator.py:368-379):
+    one workgroup per input channel, register-resident windows -- against fp64, accumulating, and bit-reproducible in deterministic mode."""
+    from ag2video_amd import _lib, ops
+    N, C, H, W, K, R, pad = cfg
+    torch.manual_seed(9)
+    x = torch.randn(N, C, H, W, device=device)
+    OH, OW = H + 2 * pad - R + 1, W + 2 * pad - R + 1
+    dy = torch.randn(N, K, OH, OW, device=device)
+    w0 = torch.zeros(K, C, R, R, device=device, dtype=torch.float64, requires_grad=True)
+    y = torch.nn.functional.conv2d(x.double(), w0, None, 1, pad)
+    ref = torch.autograd.grad((y * dy.double()).sum(), w0)[0]
+    sc = float(ref.abs().max())
+    with torch.no_grad():
+        dw = torch.empty(K, C, R, R, device=device)
+        ops._conv_wgrad_launch(None, dy, x, dw, K, R, R, 1, pad, 0)
+        assert _lib.query('ag2v_last_conv_kernel') == b'conv_wgrad_fewrow_kernel', _lib.query('ag2v_last_conv_kernel')
+        assert float((dw.double() - ref).abs().max()) <= 2e-5 * sc
+        ops._conv_wgrad_launch(None, dy, x, dw, K, R, R, 1, pad, 1)
+        assert float((dw.double() - 2 * ref).abs().max()) <= 4e-5 * sc
+        with ops.deterministic(True):
+            a, b = torch.empty_like(dw), torch.empty_like(dw)
+            ops._conv_wgrad_launch(None, dy, x, a, K, R, R, 1, pad, 0)
+            ops._conv_wgrad_launch(None, dy, x, b, K, R, R, 1, pad, 0)
+            assert torch.equal(a, b)
+            assert float((a.double() - ref).abs().max()) <= 2e-5 * sc
+            ops._conv_wgrad_launch(None, dy, x, a, K, R, R, 1, pad, 1)
+            assert float((a.double() - 2 * ref).abs().max()) <= 4e-5 * sc
