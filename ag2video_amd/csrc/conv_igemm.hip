@@ -702,9 +702,151 @@ __global__ __launch_bounds__(256) void conv_fewrow_kernel(ConvArgs p) {
         }
     }
 }
+// The same convolutions, second form (filter 3 x 3 pad 1, 4 x 4 pad 2, 1 x 1): the kernel above issues S (S + 3) dword loads per
+// input channel for 4 S S MR FMAs and is bound by the CU's address unit (~10 cycles per dword wave-load: conv_img 13 TF, the
+// discriminators' 512 -> 1 layer 4 TF).  Here a lane owns 4 pixels x TWO output rows and fetches ONE aligned 16-byte quad per input
+// row (S + 1 rows); the pad_w columns left and S - 1 - pad_w columns right of it come from the neighbouring lanes' quads
+// (ds_bpermute: the lanes of a wave walk consecutive quads of the (image, row pair, quad) order).  Lanes 0 and 63 of a wave only
+// feed their neighbours (a wave covers 62 quads); the next channel's quads are in flight while the current one is multiplied.
+template <int MR, int S, int PW>
+__global__ __launch_bounds__(256) void conv_fewrow2_kernel(ConvArgs p) {
+    constexpr int NR = S + 1, RW = S - 1 - PW;          // input rows per lane; columns taken from the right neighbour
+    static_assert(PW <= 3 && RW >= 0 && RW <= 3, "window");
+    __shared__ float red[3][MR * 8][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int QG = max((p.OW + 3) >> 2, (p.W + 3) >> 2);
+    const int RPN = (p.OH + 1) >> 1;
+    const long long total = (long long)p.N * RPN * QG;
+    const long long gq = (long long)xcd_remap(blockIdx.x, gridDim.x) * 62 + lane - 1;
+    const bool inrange = gq >= 0 && gq < total;
+    const long long g = inrange ? gq : 0;
+    const int q = (int)(g % QG);
+    const long long t = g / QG;
+    const int rp = (int)(t % RPN), n = (int)(t / RPN);
+    const int oy0 = 2 * rp, ox0 = 4 * q;
+    const __amdgpu_buffer_rsrc_t brs = make_rsrc(p.b_src, p.b_bytes);
+    const int HW = p.H * p.W;
+    unsigned roff[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int iy = oy0 - p.pad + r;
+        roff[r] = (inrange && (unsigned)iy < (unsigned)p.H && ox0 < p.W) ? (unsigned)(n * p.C * HW + iy * p.W + ox0) * 4u : 0xF0000000u;
+    }
+    const bool has_left = q > 0, has_right = q < QG - 1;
+    const bool wtail = (p.W & 3) != 0;                    // (uniform) the last quad of an input row is partial
+    bool own_ok[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) own_ok[e] = ox0 + e < p.W;
+    const int lsrc = ((lane + 63) & 63) * 4, rsrc = ((lane + 1) & 63) * 4;
+    float acc[MR][2][4];
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[m][o][j] = 0.f;
+    const float* __restrict__ wt = p.a_src;
+    const int cper = (p.C + 3) >> 2;
+    const int c_lo = wave * cper, c_hi = min(p.C, c_lo + cper);
+    u32x4 L[NR], Ln[NR];
+    if (c_lo < c_hi) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) Ln[r] = bload_u32x4(brs, roff[r] + (unsigned)(c_lo * HW) * 4u);
+    }
+    for (int c = c_lo; c < c_hi; ++c) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) L[r] = Ln[r];
+        if (c + 1 < c_hi) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) Ln[r] = bload_u32x4(brs, roff[r] + (unsigned)((c + 1) * HW) * 4u);
+        }
+        float v[NR][S + 3];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            unsigned own[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) own[e] = (wtail && !own_ok[e]) ? 0u : L[r][e];
+#pragma unroll
+            for (int i = 0; i < PW; ++i) {
+                const unsigned x = (unsigned)__builtin_amdgcn_ds_bpermute(lsrc, (int)own[4 - PW + i]);
+                v[r][i] = has_left ? __uint_as_float(x) : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[r][PW + e] = __uint_as_float(own[e]);
+#pragma unroll
+            for (int i = 0; i < RW; ++i) {
+                const unsigned x = (unsigned)__builtin_amdgcn_ds_bpermute(rsrc, (int)own[i]);
+                v[r][PW + 4 + i] = has_right ? __uint_as_float(x) : 0.f;
+            }
+        }
+        const float* wc = wt + (size_t)c * (S * S * MR);
+#pragma unroll
+        for (int r = 0; r < S; ++r)
+#pragma unroll
+            for (int s2 = 0; s2 < S; ++s2)
+#pragma unroll
+                for (int m = 0; m < MR; ++m) {
+                    const float wv = wc[(r * S + s2) * MR + m];
+#pragma unroll
+                    for (int o = 0; o < 2; ++o)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[m][o][j] = fmaf(wv, v[o + r][s2 + j], acc[m][o][j]);
+                }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) red[wave - 1][(m * 2 + o) * 4 + j][lane] = acc[m][o][j];
+    }
+    __syncthreads();
+    if (wave > 0 || !inrange || lane == 0 || lane == 63 || ox0 >= p.OW) return;
+    const int plane = p.OH * p.OW;
+    const float gs = p.gscale ? p.gscale[n / p.group_n] : 1.f;
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+        const float bv = p.bias ? p.bias[m] : 0.f;
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            if (oy0 + o >= p.OH) continue;
+            const size_t ob = ((size_t)n * MR + m) * plane + (size_t)(oy0 + o) * p.OW + ox0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ri = (m * 2 + o) * 4 + j;
+                const float sum = acc[m][o][j] + (red[0][ri][lane] + red[1][ri][lane] + red[2][ri][lane]);
+                if (ox0 + j < p.OW) {
+                    float y = fmaf(sum, gs, bv) + (p.residual ? p.residual[ob + j] : 0.f);
+                    if (p.relu) y = fmaxf(y, 0.f);
+                    if (p.mask) y = (p.mask[ob + j] > 0.f) ? y : 0.f;
+                    p.out[ob + j] = y;
+                }
+            }
+        }
+    }
+}
+static bool g_fewrow2_last = false;      // which of the two forms the last few-row launch took (kernel name for the timing tables)
+template <int MR>
+static bool launch_fewrow2(const ConvArgs& a, hipStream_t st) {
+    static const bool on = getenv("AG2V_NO_FEWROW2") == nullptr;
+    g_fewrow2_last = false;
+    if (!on || a.R != a.S || a.pad != a.pad_w) return false;
+    g_fewrow2_last = (a.S == 3 && a.pad_w == 1) || (a.S == 4 && (a.pad_w == 2 || a.pad_w == 1)) || (a.S == 1 && a.pad_w == 0);
+    const int QG = ((a.OW + 3) >> 2) > ((a.W + 3) >> 2) ? ((a.OW + 3) >> 2) : ((a.W + 3) >> 2);
+    const long long total = (long long)a.N * ((a.OH + 1) >> 1) * QG;
+    const dim3 grid((unsigned)ceil_div(total, 62LL));
+    if (a.S == 3 && a.pad_w == 1) { hipLaunchKernelGGL((conv_fewrow2_kernel<MR, 3, 1>), grid, dim3(256), 0, st, a); return true; }
+    if (a.S == 4 && a.pad_w == 2) { hipLaunchKernelGGL((conv_fewrow2_kernel<MR, 4, 2>), grid, dim3(256), 0, st, a); return true; }
+    if (a.S == 4 && a.pad_w == 1) { hipLaunchKernelGGL((conv_fewrow2_kernel<MR, 4, 1>), grid, dim3(256), 0, st, a); return true; }
+    if (a.S == 1 && a.pad_w == 0) { hipLaunchKernelGGL((conv_fewrow2_kernel<MR, 1, 0>), grid, dim3(256), 0, st, a); return true; }
+    return false;
+}
 template <int MR>
 static bool launch_fewrow(const ConvArgs& a, hipStream_t st) {
     if (a.R != a.S) return false;
+    if (launch_fewrow2<MR>(a, st)) return true;
     const long long total = (long long)a.N * a.OH * ((a.OW + 3) >> 2);
     const dim3 grid((unsigned)ceil_div(total, 64LL));
     switch (a.S) {
@@ -747,7 +889,7 @@ static int launch_igemm(ConvArgs& a, hipStream_t st, bool out_zeroed, bool split
                    : a.M == 3 ? launch_fewrow<3>(c, st) : launch_fewrow<4>(c, st);
                 if (!ok && n0 > 0) return AG2V_EINVAL;      // (cannot happen: the filter shape decides and is the same for all chunks)
             }
-            if (ok) { set_last_conv_kernel("conv_fewrow_kernel"); AG2V_CHECK_LAUNCH(); return AG2V_OK; }
+            if (ok) { set_last_conv_kernel(g_fewrow2_last ? "conv_fewrow2_kernel" : "conv_fewrow_kernel"); AG2V_CHECK_LAUNCH(); return AG2V_OK; }
         }
     }
     const int bm = (a.M <= 32) ? 32 : (a.M <= 64 ? 64 : 128);

@@ -184,3 +184,30 @@ def test_few_row_weight_gradient_kernel(cfg, device):
             assert float((a.double() - ref).abs().max()) <= 2e-5 * sc
             ops._conv_wgrad_launch(None, dy, x, a, K, R, R, 1, pad, 1)
             assert float((a.double() - 2 * ref).abs().max()) <= 4e-5 * sc
+
+
+@pytest.mark.parametrize("cfg", [(3, 20, 34, 34, 1, 4, 2), (2, 16, 64, 64, 3, 3, 1), (5, 9, 17, 23, 2, 3, 1), (2, 12, 31, 30, 4, 4, 2), (3, 7, 10, 70, 1, 1, 0),
+                                 (2, 8, 33, 258, 3, 3, 1), (2, 6, 12, 9, 2, 4, 1)], ids=str)
+def test_few_row_forward_second_form(cfg, device):
+    """conv_fewrow2_kernel (<= 4 output channels: conv_img spade_generator.py:28,82, conv_flow flows_generator.py:56, the
+    discriminators' last layer): one 16-byte quad per input row and lane, neighbours' columns by lane exchange, two output rows per lane --
+    against the oracle (oracle/kernels.py::conv2d), with bias, residual, ReLU and per-group scale; map widths that are
+    not multiples of 4, waves that span several rows / images, output wider than the input (4 x 4, pad 2)."""
+    from ag2video_amd import _lib, ops
+    from oracle import kernels as K
+    N, C, H, W, M, R, pad = cfg
+    torch.manual_seed(13)
+    x = torch.randn(N, C, H, W, device=device)
+    w = torch.randn(M, C, R, R, device=device) * 0.1
+    b = torch.randn(M, device=device)
+    OH, OW = H + 2 * pad - R + 1, W + 2 * pad - R + 1
+    res = torch.randn(N, M, OH, OW, device=device)
+    gs = torch.linspace(0.5, 1.5, N, device=device)
+    for kw in (dict(bias=b), dict(bias=None, residual=res, relu=True), dict(bias=b, gscale=gs)):
+        with torch.no_grad():
+            out = ops.conv2d(x, w, kw.get('bias'), 1, pad, residual=kw.get('residual'), relu=kw.get('relu', False), gscale=kw.get('gscale'))
+        assert _lib.query('ag2v_last_conv_kernel') == b'conv_fewrow2_kernel', _lib.query('ag2v_last_conv_kernel')
+        ref = K.conv2d(x.cpu(), w.cpu(), None if kw.get('bias') is None else b.cpu(), 1, pad,
+                       residual=None if kw.get('residual') is None else res.cpu(), relu=kw.get('relu', False),
+                       gscale=None if kw.get('gscale') is None else gs.cpu())
+        assert float((out.cpu() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), sorted(kw)
