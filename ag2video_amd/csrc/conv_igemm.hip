@@ -804,24 +804,28 @@ __global__ __launch_bounds__(256) void conv_fewrow2_kernel(ConvArgs p) {
     }
     __syncthreads();
     if (wave > 0 || !inrange || lane == 0 || lane == 63 || ox0 >= p.OW) return;
-    const int plane = p.OH * p.OW;
+    // output placement (ConvArgs::o_mul ...): pixel (oy, ox) of the GEMM's pixel space is (oy o_mul + o_add_y, ox o_mul + o_add_x) of the
+    // [o_H, o_W] output -- the parity classes of a strided data gradient write every o_mul-th pixel
+    const int plane = p.o_H * p.o_W;
     const float gs = p.gscale ? p.gscale[n / p.group_n] : 1.f;
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
         const float bv = p.bias ? p.bias[m] : 0.f;
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
-            if (oy0 + o >= p.OH) continue;
-            const size_t ob = ((size_t)n * MR + m) * plane + (size_t)(oy0 + o) * p.OW + ox0;
+            const int yy = (oy0 + o) * p.o_mul + p.o_add_y;
+            if (oy0 + o >= p.OH || yy >= p.o_H) continue;
+            const size_t ob = ((size_t)n * MR + m) * plane + (size_t)yy * p.o_W;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int ri = (m * 2 + o) * 4 + j;
                 const float sum = acc[m][o][j] + (red[0][ri][lane] + red[1][ri][lane] + red[2][ri][lane]);
-                if (ox0 + j < p.OW) {
-                    float y = fmaf(sum, gs, bv) + (p.residual ? p.residual[ob + j] : 0.f);
+                const int xx = (ox0 + j) * p.o_mul + p.o_add_x;
+                if (ox0 + j < p.OW && xx < p.o_W) {
+                    float y = fmaf(sum, gs, bv) + (p.residual ? p.residual[ob + xx] : 0.f);
                     if (p.relu) y = fmaxf(y, 0.f);
-                    if (p.mask) y = (p.mask[ob + j] > 0.f) ? y : 0.f;
-                    p.out[ob + j] = y;
+                    if (p.mask) y = (p.mask[ob + xx] > 0.f) ? y : 0.f;
+                    p.out[ob + xx] = y;
                 }
             }
         }
@@ -833,7 +837,8 @@ static bool launch_fewrow2(const ConvArgs& a, hipStream_t st) {
     static const bool on = getenv("AG2V_NO_FEWROW2") == nullptr;
     g_fewrow2_last = false;
     if (!on || a.R != a.S || a.pad != a.pad_w) return false;
-    g_fewrow2_last = (a.S == 3 && a.pad_w == 1) || (a.S == 4 && (a.pad_w == 2 || a.pad_w == 1)) || (a.S == 1 && a.pad_w == 0);
+    g_fewrow2_last = (a.S == 3 && a.pad_w == 1) || (a.S == 4 && (a.pad_w == 2 || a.pad_w == 1)) || (a.S == 1 && a.pad_w == 0) ||
+                     (a.S == 2 && (a.pad_w == 0 || a.pad_w == 1));
     const int QG = ((a.OW + 3) >> 2) > ((a.W + 3) >> 2) ? ((a.OW + 3) >> 2) : ((a.W + 3) >> 2);
     const long long total = (long long)a.N * ((a.OH + 1) >> 1) * QG;
     const dim3 grid((unsigned)ceil_div(total, 62LL));
@@ -841,12 +846,16 @@ static bool launch_fewrow2(const ConvArgs& a, hipStream_t st) {
     if (a.S == 4 && a.pad_w == 2) { hipLaunchKernelGGL((conv_fewrow2_kernel<MR, 4, 2>), grid, dim3(256), 0, st, a); return true; }
     if (a.S == 4 && a.pad_w == 1) { hipLaunchKernelGGL((conv_fewrow2_kernel<MR, 4, 1>), grid, dim3(256), 0, st, a); return true; }
     if (a.S == 1 && a.pad_w == 0) { hipLaunchKernelGGL((conv_fewrow2_kernel<MR, 1, 0>), grid, dim3(256), 0, st, a); return true; }
+    // 2 x 2: the parity classes of a 4 x 4 stride-2 data gradient (the discriminators' first layer, 64 -> 3 channels)
+    if (a.S == 2 && a.pad_w == 0) { hipLaunchKernelGGL((conv_fewrow2_kernel<MR, 2, 0>), grid, dim3(256), 0, st, a); return true; }
+    if (a.S == 2 && a.pad_w == 1) { hipLaunchKernelGGL((conv_fewrow2_kernel<MR, 2, 1>), grid, dim3(256), 0, st, a); return true; }
     return false;
 }
 template <int MR>
-static bool launch_fewrow(const ConvArgs& a, hipStream_t st) {
+static bool launch_fewrow(const ConvArgs& a, hipStream_t st, bool mapped) {
     if (a.R != a.S) return false;
     if (launch_fewrow2<MR>(a, st)) return true;
+    if (mapped) return false;            // only the second form places its output (ConvArgs::o_mul ...)
     const long long total = (long long)a.N * a.OH * ((a.OW + 3) >> 2);
     const dim3 grid((unsigned)ceil_div(total, 64LL));
     switch (a.S) {
@@ -864,7 +873,9 @@ static int launch_igemm(ConvArgs& a, hipStream_t st, bool out_zeroed, bool split
     if (a.out_nstride == 0) a.out_nstride = dense_nstride;
     const bool dense_out = a.out_nstride == dense_nstride;
     if (split) return launch_igemm_bf16x3(a, st, out_zeroed);
-    if (dense_out && a.M <= 4 && a.stride == 1 && a.o_mul == 1 && a.o_add_y == 0 && a.o_add_x == 0 && a.o_W == a.OW && a.o_H == a.OH &&
+    const bool mapped = !(a.o_mul == 1 && a.o_add_y == 0 && a.o_add_x == 0 && a.o_W == a.OW && a.o_H == a.OH);
+    static const bool fewrow_mapped = getenv("AG2V_NO_FEWROW_MAPPED") == nullptr;
+    if (dense_out && a.M <= 4 && a.stride == 1 && (!mapped || (fewrow_mapped && a.S == 2 && a.R == 2 && a.pad == a.pad_w)) &&
         (long long)a.C * a.H * a.W * 4 < 0x10000000LL && getenv("AG2V_NO_FEWROW") == nullptr) {
         // The kernel flags an out-of-image tap by adding 0xF0000000 to its byte offset, which only stays out of range while the
         // valid part of the offset is below 0x10000000: at most 256 MB of input per launch (a frame-batched [120, 64, 256, 256]
@@ -873,7 +884,7 @@ static int launch_igemm(ConvArgs& a, hipStream_t st, bool out_zeroed, bool split
         int nmax = (int)(0x0FFFFFFFLL / per);
         if (a.gscale) nmax -= nmax % a.group_n;
         if (nmax >= 1) {
-            const size_t os = (size_t)a.M * a.OH * a.OW;
+            const size_t os = (size_t)a.M * a.o_H * a.o_W;
             bool ok = true;
             for (int n0 = 0; n0 < a.N && ok; n0 += nmax) {
                 ConvArgs c = a;
@@ -885,8 +896,8 @@ static int launch_igemm(ConvArgs& a, hipStream_t st, bool out_zeroed, bool split
                 c.gscale = a.gscale ? a.gscale + n0 / a.group_n : nullptr;
                 c.NG = c.N * a.OH * a.OW;
                 c.b_bytes = (unsigned)(per * c.N);
-                ok = a.M == 1 ? launch_fewrow<1>(c, st) : a.M == 2 ? launch_fewrow<2>(c, st)
-                   : a.M == 3 ? launch_fewrow<3>(c, st) : launch_fewrow<4>(c, st);
+                ok = a.M == 1 ? launch_fewrow<1>(c, st, mapped) : a.M == 2 ? launch_fewrow<2>(c, st, mapped)
+                   : a.M == 3 ? launch_fewrow<3>(c, st, mapped) : launch_fewrow<4>(c, st, mapped);
                 if (!ok && n0 > 0) return AG2V_EINVAL;      // (cannot happen: the filter shape decides and is the same for all chunks)
             }
             if (ok) { set_last_conv_kernel(g_fewrow2_last ? "conv_fewrow2_kernel" : "conv_fewrow_kernel"); AG2V_CHECK_LAUNCH(); return AG2V_OK; }

@@ -211,3 +211,33 @@ def test_few_row_forward_second_form(cfg, device):
                        residual=None if kw.get('residual') is None else res.cpu(), relu=kw.get('relu', False),
                        gscale=None if kw.get('gscale') is None else gs.cpu())
         assert float((out.cpu() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), sorted(kw)
+
+
+@pytest.mark.parametrize("cfg", [(3, 3, 32, 32, 16, 4, 2, 2), (2, 2, 30, 26, 8, 4, 2, 1), (4, 3, 64, 64, 64, 4, 2, 2), (2, 4, 17, 21, 8, 4, 2, 2), (2, 3, 20, 20, 8, 3, 2, 1)], ids=str)
+def test_strided_data_gradient_to_few_channels(cfg, device):
+    """The data gradient of a 4 x 4 stride-2 convolution with <= 4 input channels (the discriminators' first layer on the generated
+    image, discriminator.py:368-379): its four parity classes are 2 x 2 stride-1 convolutions of dy that write every second pixel of
+    dx -- conv_fewrow2_kernel with output placement (was: a 3-row GEMM per class on 32-row tiles, 5.7 TF).  Against fp64
+    conv_transpose2d, plain, masked and accumulating; odd map sizes; a 3 x 3 filter (non-square classes keep the general kernels)."""
+    from ag2video_amd import _lib, ops
+    N, C, H, W, K, R, stride, pad = cfg
+    torch.manual_seed(17)
+    OH, OW = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+    dy = torch.randn(N, K, OH, OW, device=device)
+    w = torch.randn(K, C, R, R, device=device) * 0.1
+    xin = torch.randn(N, C, H, W, device=device)
+    ref = torch.nn.functional.conv_transpose2d(dy.double(), w.double(), None, stride, pad,
+                                               output_padding=(H + 2 * pad - R - (OH - 1) * stride, W + 2 * pad - R - (OW - 1) * stride)).float()
+    sc = float(ref.abs().max())
+    with torch.no_grad():
+        dx = torch.empty(N, C, H, W, device=device)
+        ops._conv_dgrad_launch(None, dy, w, None, dx, stride, pad, 0)
+        if R == 4:
+            assert _lib.query('ag2v_last_conv_kernel') == b'conv_fewrow2_kernel', _lib.query('ag2v_last_conv_kernel')
+        assert float((dx - ref).abs().max()) <= 2e-5 * sc
+        ops._conv_dgrad_launch(None, dy, w, xin, dx, stride, pad, 0)                     # ReLU mask of the convolution's input
+        assert float((dx - ref * (xin > 0).float()).abs().max()) <= 2e-5 * sc
+        base = torch.randn(N, C, H, W, device=device)
+        dx = base.clone()
+        ops._conv_dgrad_launch(None, dy, w, None, dx, stride, pad, 1)                    # dx += ...
+        assert float((dx - base - ref).abs().max()) <= 2e-5 * sc + 1e-6
