@@ -793,7 +793,10 @@ extern "C" int ag2v_layout_render_bwd(const float* dout, const float* boxes, con
 extern "C" int ag2v_layout_conv_img_fwd(const float* U, const float* boxes, const int* keep, const float* residual, float* out,
                                         int NB, int J, int K, int H, int W, int R, int stride, int pad, int pool, const float* img,
                                         const float* wimg, const float* iscale, int IC, void* stream) {
-    if (!U || !boxes || !keep || !out || NB <= 0 || J <= 0 || K <= 0 || H <= 0 || W <= 0 || stride <= 0 || NB > 65535) return AG2V_EINVAL;
+    // J == 0 (with img): no layout term at all -- a same-size convolution of <= 8 dense channels to K outputs through the kernel's
+    // image path (U / boxes / keep are not read): the data gradients of conv_img / conv_flow, whose gathered tensor has 3 / 2 channels
+    if (!out || NB <= 0 || J < 0 || (J == 0 && !img) || (J > 0 && (!U || !boxes || !keep)) || K <= 0 || H <= 0 || W <= 0 || stride <= 0 ||
+        NB > 65535) return AG2V_EINVAL;
     if ((R != 3 && R != 4) || pool < 0 || pool > 1) return AG2V_EINVAL;
     const int Hm = pool ? (H - 1) / 2 + 1 : H, Wm = pool ? (W - 1) / 2 + 1 : W;   // size of the map the convolution sees
     const int OH = (Hm + 2 * pad - R) / stride + 1, OW = (Wm + 2 * pad - R) / stride + 1;

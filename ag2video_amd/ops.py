@@ -355,6 +355,7 @@ _MERGE_SHARED_WGRAD = os.environ.get('AG2V_NO_MERGED_WGRAD') is None      # ... 
 _GRAD_SLOTS = os.environ.get('AG2V_NO_GRAD_SLOTS') is None                # ... whose concatenated dy the consumers write in place (_GradSlots; A/B)
 _SWAP_FEW_WGRAD = os.environ.get('AG2V_NO_SWAPPED_WGRAD') is None         # <= 4-row weight gradients with swapped operands
 _SWAP_WIDE_WGRAD = os.environ.get('AG2V_NO_WIDE_SWAPPED_WGRAD') is None   # ... and layers with fewer output than input channels (A/B)
+_FEWIN_DGRAD = os.environ.get('AG2V_NO_FEWIN_DGRAD') is None              # data gradients of <= 4-row layers on the layout kernel's image path (A/B)
 _WSINK_CB = [None]   # graph-task id of the backward pass whose end-of-pass callback is queued (None: none; ids start at 0)
 
 
@@ -625,7 +626,17 @@ class _Conv2d(torch.autograd.Function):
             g = torch.empty_like(dy)
             _lib.call('ag2v_act_bwd', 0, _ptr(dy), _ptr(y), _ptr(g), dy.numel(), 0.0, st)   # op 0 = LeakyReLU(slope 0)
             dy = g
-        if ctx.needs_input_grad[0]:
+        if (ctx.needs_input_grad[0] and _FEWIN_DGRAD and K <= 4 and C >= 16 and stride == 1 and R == S == 3 and pad == 1 and W % 4 == 0
+                and tuple(dy.shape[2:]) == (H, W) and not relu_input and gscale is None and not dys and not ctx.dx_split and N <= 65535
+                and ctx.dx_slot is None):
+            # <= 4 output channels (conv_img, conv_flow): the data gradient is a same-size convolution of the 3- / 2-channel dy to C
+            # outputs, 27 / 18 FMAs per written float -- memory-bound on its output.  It runs on the image path of the layout-convolution
+            # kernel (4 pixels x 16 channels per thread, filters broadcast from LDS, 16-byte stores; no layout term: J = 0) with the
+            # flipped, transposed filter; as a GEMM with K = 27 it had one k-step per tile and ran at 19 / 7 TF.
+            dx = torch.empty_like(x)
+            wt = w.flip(2, 3).transpose(0, 1).contiguous()
+            _lib.call('ag2v_layout_conv_img_fwd', None, None, None, None, _ptr(dx), N, 0, C, H, W, R, 1, pad, 0, _ptr(dy), _ptr(wt), None, K, st)
+        elif ctx.needs_input_grad[0]:
             # (the producer of x collects its outputs' gradients in one buffer: this one goes straight into its slice)
             dx = ctx.dx_slot[0].view(ctx.dx_slot[1], N, H, W, x.device) if ctx.dx_slot is not None else torch.empty_like(x)
             if tuple(dx.shape) != tuple(x.shape):

@@ -249,7 +249,10 @@ int ag2v_layout_conv_fwd(const float* U, const float* boxes, const int* keep, co
                          int NB, int J, int K, int H, int W, int R, int stride, int pad, int pool, void* stream);
 /* ag2v_layout_conv_fwd plus the IMAGE channels of the same convolution (the reference convolves cat[layouts, frame(s)],
  * generator.py:66,74,82-83): out += iscale[n] * conv(img[n, :IC], wimg[K, IC, R, R]) (iscale nullable; stride 1, pool 0, same-size
- * convolution, OW % 4 == 0, IC <= 8).  Their gradients are those of a plain convolution (ag2v_conv2d_dgrad_ex / _wgrad_ex on img). */
+ * convolution, OW % 4 == 0, IC <= 8).  Their gradients are those of a plain convolution (ag2v_conv2d_dgrad_ex / _wgrad_ex on img).
+ * J == 0 (U, boxes, keep may be NULL): no layout term -- out = residual + iscale[n] * conv(img, wimg), a dense convolution of <= 8
+ * channels to K outputs on this kernel's 4-pixel x 16-channel FMA path: the data gradients of conv_img / conv_flow
+ * (spade_generator.py:28,82, flows_generator.py:56), whose gathered tensor dy has 3 / 2 channels. */
 int ag2v_layout_conv_img_fwd(const float* U, const float* boxes, const int* keep, const float* residual /*nullable*/, float* out,
                              int NB, int J, int K, int H, int W, int R, int stride, int pad, int pool, const float* img,
                              const float* wimg, const float* iscale /*nullable*/, int IC, void* stream);

@@ -241,3 +241,23 @@ def test_strided_data_gradient_to_few_channels(cfg, device):
         dx = base.clone()
         ops._conv_dgrad_launch(None, dy, w, None, dx, stride, pad, 1)                    # dx += ...
         assert float((dx - base - ref).abs().max()) <= 2e-5 * sc + 1e-6
+
+
+@pytest.mark.parametrize("cfg", [(3, 64, 64, 64, 3), (2, 32, 48, 72, 2), (5, 16, 20, 36, 4)], ids=str)
+def test_data_gradient_of_few_row_layers_on_the_dense_image_path(cfg, device):
+    """conv2d backward of a 3 x 3 layer with <= 4 output channels (conv_img spade_generator.py:28,82; conv_flow flows_generator.py:56):
+    dx = same-size convolution of the 3- / 2-channel dy with the flipped, transposed filter on ag2v_layout_conv_img_fwd's image path (J = 0).
+    All gradients of the node against fp64 autograd."""
+    from ag2video_amd import ops
+    N, C, H, W, K = cfg
+    torch.manual_seed(19)
+    x = torch.randn(N, C, H, W, device=device, requires_grad=True)
+    w = (torch.randn(K, C, 3, 3, device=device) * 0.1).requires_grad_(True)
+    b = torch.randn(K, device=device, requires_grad=True)
+    head = torch.randn(N, K, H, W, device=device)
+    assert ops._FEWIN_DGRAD
+    (ops.conv2d(x, w, b, 1, 1) * head).sum().backward()
+    xd, wd, bd = [t.detach().double().requires_grad_(True) for t in (x, w, b)]
+    (torch.nn.functional.conv2d(xd, wd, bd, 1, 1) * head.double()).sum().backward()
+    for got, ref in ((x.grad, xd.grad), (w.grad, wd.grad), (b.grad, bd.grad)):
+        assert float((got.double() - ref).abs().max()) <= 3e-5 * float(ref.abs().max())
