@@ -1231,7 +1231,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_fewrow_kernel(ConvArgs p) {
     const int c = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int QX = (p.OW + 3) >> 2;
-    const long long total = (long long)p.N * p.OH * QX;
+    // blockIdx.z: sample group (ConvArgs::groups consecutive groups of N / groups samples, one gradient each)
+    const int ng = p.N / p.groups, grp = blockIdx.z;
+    const long long total = (long long)ng * p.OH * QX;
     const long long per = (total + gridDim.y - 1) / gridDim.y;
     const long long q0 = (long long)blockIdx.y * per, q1 = min(total, q0 + per);
     float acc[KR][S][S];
@@ -1247,7 +1249,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_fewrow_kernel(ConvArgs p) {
     for (long long q = q0 + threadIdx.x; q < q1; q += 256) {
         const int xq = (int)(q % QX);
         const long long t = q / QX;
-        const int oy = (int)(t % p.OH), n = (int)(t / p.OH);
+        const int oy = (int)(t % p.OH), n = grp * ng + (int)(t / p.OH);
         const int ox0 = xq * 4;
         float g[KR][4];
 #pragma unroll
@@ -1289,7 +1291,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_fewrow_kernel(ConvArgs p) {
     if (threadIdx.x < KR * S * S) {
         const int i = threadIdx.x, k = i / (S * S), rs = i - k * (S * S);
         const float tsum = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
-        float* o = p.out + ((size_t)k * p.C + c) * (S * S) + rs;
+        float* o = p.out + (size_t)grp * p.out_gstride + ((size_t)k * p.C + c) * (S * S) + rs;
         if (gridDim.y > 1) atomicAdd(o, tsum);                 // (the launcher zeroed dw unless it accumulates)
         else *o = p.accumulate ? *o + tsum : tsum;
     }
@@ -1305,19 +1307,19 @@ static bool launch_wgrad_fewrow_k(const ConvArgs& a, dim3 grid, hipStream_t st) 
 }
 static bool wgrad_fewrow_ok(int K, int R, int S, int stride, int groups, int x_split, int dy_split) {
     static const bool on = getenv("AG2V_NO_FEWROW_WGRAD") == nullptr;
-    return on && K <= 4 && R == S && (S == 1 || S == 3 || S == 4) && stride == 1 && groups == 1 && !x_split && !dy_split;
+    return on && K <= 4 && R == S && (S == 1 || S == 3 || S == 4) && stride == 1 && groups >= 1 && groups <= 65535 && !x_split && !dy_split;
 }
 // det: one slice per channel (plain stores, a fixed summation order)
 static int launch_wgrad_fewrow(ConvArgs& a, int det, hipStream_t st) {
-    const long long quads = (long long)a.N * a.OH * ((a.OW + 3) >> 2);
-    int slices = det ? 1 : (int)ceil_div(1536, a.C);
+    const long long quads = (long long)(a.N / a.groups) * a.OH * ((a.OW + 3) >> 2);
+    int slices = det ? 1 : (int)ceil_div(1536, a.C * a.groups);
     const int max_slices = (int)((quads + 2047) / 2048);
     if (slices > max_slices) slices = max_slices;
     if (slices < 1) slices = 1;
     if (slices > 1 && !a.accumulate) {
-        if (hipMemsetAsync(a.out, 0, (size_t)a.K * a.C * a.R * a.S * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
+        if (hipMemsetAsync(a.out, 0, (size_t)a.groups * a.K * a.C * a.R * a.S * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
     }
-    const dim3 grid(a.C, slices);
+    const dim3 grid(a.C, slices, a.groups);
     const bool ok = a.K == 1 ? launch_wgrad_fewrow_k<1>(a, grid, st) : a.K == 2 ? launch_wgrad_fewrow_k<2>(a, grid, st)
                   : a.K == 3 ? launch_wgrad_fewrow_k<3>(a, grid, st) : launch_wgrad_fewrow_k<4>(a, grid, st);
     if (!ok) return AG2V_EINVAL;

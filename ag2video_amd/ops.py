@@ -355,6 +355,10 @@ _MERGE_SHARED_WGRAD = os.environ.get('AG2V_NO_MERGED_WGRAD') is None      # ... 
 _GRAD_SLOTS = os.environ.get('AG2V_NO_GRAD_SLOTS') is None                # ... whose concatenated dy the consumers write in place (_GradSlots; A/B)
 _SWAP_FEW_WGRAD = os.environ.get('AG2V_NO_SWAPPED_WGRAD') is None         # <= 4-row weight gradients with swapped operands
 _SWAP_WIDE_WGRAD = os.environ.get('AG2V_NO_WIDE_SWAPPED_WGRAD') is None   # ... and layers with fewer output than input channels (A/B)
+# <= 4-row same-size weight gradients on the library's one-workgroup-per-input-channel kernel (conv_wgrad_fewrow_kernel) instead of the
+# swapped GEMM: OFF -- on 256 x 256 maps its dword gathers lose to the GEMM (tools/fewrow_wgrad_bench.py: conv_img 3.17 vs 1.50 ms,
+# conv_flow 1.40 vs 1.26); the kernel serves the layers the swap does not cover (the discriminators' 4 x 4 last layer: 1.15 -> 0.35 ms)
+_FEWROW_WGRAD_DIRECT = os.environ.get('AG2V_DIRECT_FEW_WGRAD') is not None
 _FEWIN_DGRAD = os.environ.get('AG2V_NO_FEWIN_DGRAD') is None              # data gradients of <= 4-row layers on the layout kernel's image path (A/B)
 _WSINK_CB = [None]   # graph-task id of the backward pass whose end-of-pass callback is queued (None: none; ids start at 0)
 
@@ -660,7 +664,7 @@ class _Conv2d(torch.autograd.Function):
                 dgs = None
         elif ctx.needs_input_grad[1]:
             buf, acc, dw = _wsink_take(ctx.wkey, w)
-            if (_SWAP_FEW_WGRAD and K <= 4 and stride == 1 and dy.shape[2] == H and dy.shape[3] == W and C >= 16 and R == S
+            if (_SWAP_FEW_WGRAD and not _FEWROW_WGRAD_DIRECT and K <= 4 and stride == 1 and dy.shape[2] == H and dy.shape[3] == W and C >= 16 and R == S
                     and 2 * pad == R - 1 and not ctx.x_split and not dys):
                 # <= 4 output channels (conv_img, the flow / mask heads), same-size convolution: as a GEMM this has 3 rows on a
                 # 32-row tile and gathers x once per tap column (0.38 ms at 8 x 64 x 256 x 256).  With the operands swapped --
@@ -1696,7 +1700,12 @@ class _LayoutConvImg(torch.autograd.Function):
         if gscale is not None and (ctx.needs_input_grad[4] or ctx.needs_input_grad[5]):
             T = gscale.numel()
             G = torch.empty((T,) + tuple(w_img.shape), device=dout.device, dtype=torch.float32)
-            _conv_wgrad_launch(mr, dout, img, G, K, R, R, 1, pad, 0, groups=T)
+            if _FEWROW_WGRAD_DIRECT and img.shape[1] <= 4 and K <= 128 and R in (3, 4) and 2 * pad == R - 1:
+                # <= 4 image channels and a moderate number of outputs (the flow network's first layer): with the operands swapped the
+                # launch has <= 4 rows and runs on the few-row kernel (one workgroup per dout channel and frame group)
+                _conv_wgrad_swapped(None, dout, img, G, K, R, R, pad, 0, T, False, False)
+            else:
+                _conv_wgrad_launch(mr, dout, img, G, K, R, R, 1, pad, 0, groups=T)
             buf, acc, dw = _wsink_take(ctx.wkey, w_img) if ctx.needs_input_grad[4] else (torch.empty_like(w_img), 0, None)
             dgs = torch.empty(T, device=dout.device, dtype=torch.float32)
             _lib.call('ag2v_sn_group_combine', _ptr(G), _ptr(w_img), _ptr(gscale), T, w_img.numel(), _ptr(buf), acc | _det_bit(), _ptr(dgs), st)

@@ -184,6 +184,16 @@ def test_few_row_weight_gradient_kernel(cfg, device):
             assert float((a.double() - ref).abs().max()) <= 2e-5 * sc
             ops._conv_wgrad_launch(None, dy, x, a, K, R, R, 1, pad, 1)
             assert float((a.double() - 2 * ref).abs().max()) <= 4e-5 * sc
+        if N % 3 == 0:          # one gradient per group of N / 3 samples (spectral norm's frame groups)
+            g = torch.empty(3, K, C, R, R, device=device)
+            ops._conv_wgrad_launch(None, dy, x, g, K, R, R, 1, pad, 0, groups=3)
+            assert _lib.query('ag2v_last_conv_kernel') == b'conv_wgrad_fewrow_kernel'
+            for i in range(3):
+                sl = slice(i * N // 3, (i + 1) * N // 3)
+                with torch.enable_grad():
+                    yg = torch.nn.functional.conv2d(x[sl].double(), w0, None, 1, pad)
+                    rg = torch.autograd.grad((yg * dy[sl].double()).sum(), w0)[0]
+                assert float((g[i].double() - rg).abs().max()) <= 2e-5 * float(rg.abs().max())
 
 
 @pytest.mark.parametrize("cfg", [(3, 20, 34, 34, 1, 4, 2), (2, 16, 64, 64, 3, 3, 1), (5, 9, 17, 23, 2, 3, 1), (2, 12, 31, 30, 4, 4, 2), (3, 7, 10, 70, 1, 1, 0),
