@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256) void layout_conv_bwd_kernel(const float* __res
     const bool active = legal && keep[(size_t)n * J + j] != 0;
     // Support of the object in output coordinates, found once per wave: rows / 64-column blocks where some tap is nonzero.
     int oy_lo = OH, oy_hi = -1;
-    unsigned xblk_mask = 0;   // bit b: column block [64b, 64b+64) has a nonzero tap (OW <= 2048)
+    unsigned long long xblk_mask = 0;   // bit b: column block [32b, 32b+32) has a nonzero tap (OW <= 2048)
     if (active) {
         for (int base = 0; base < OH; base += 64) {
             const int oy = base + lane;
@@ -472,7 +472,9 @@ __global__ __launch_bounds__(256) void layout_conv_bwd_kernel(const float* __res
                 const int xx = ox * stride + s - pad;
                 t += (ox < OW && (unsigned)xx < (unsigned)Wm) ? fabsf(lc_profile(xx, W, pool, x0, ww)) : 0.f;
             }
-            if (__ballot(t != 0.f)) xblk_mask |= 1u << (xb >> 6);
+            const unsigned long long bal = __ballot(t != 0.f);
+            if (bal & 0xFFFFFFFFull) xblk_mask |= 1ull << (xb >> 5);
+            if (bal >> 32) xblk_mask |= 2ull << (xb >> 5);
         }
     }
     // The wave's 8 channels (k = 32 z + wave + 4 i) go through the support together, CH at a time: the row taps are evaluated once
@@ -490,9 +492,11 @@ __global__ __launch_bounds__(256) void layout_conv_bwd_kernel(const float* __res
 #pragma unroll
                 for (int s = 0; s < R; ++s) acc[ci][r][s] = 0.f;
         if (active && oy_hi >= oy_lo) {
-            for (int xb = 0; xb < OW; xb += 64) {
-                if (xb < 2048 && !((xblk_mask >> (xb >> 6)) & 1u)) continue;   // wave-uniform
-                const int ox = xb + lane;
+            // a wave pass covers 32 columns x 2 rows (128-byte row segments): the support is rounded to 32 columns, not 64 -- an object
+            // 77 pixels wide touches 3-4 such blocks instead of 2-3 blocks of 64 (the pass read x2.28 of the support's bytes)
+            for (int xb = 0; xb < OW; xb += 32) {
+                if (xb < 2048 && !((xblk_mask >> (xb >> 5)) & 1ull)) continue;   // wave-uniform
+                const int ox = xb + (lane & 31);
                 float txs[R];
                 float txsum = 0.f;
 #pragma unroll
@@ -501,15 +505,17 @@ __global__ __launch_bounds__(256) void layout_conv_bwd_kernel(const float* __res
                     txs[s] = (ox < OW && (unsigned)xx < (unsigned)Wm) ? lc_profile(xx, W, pool, x0, ww) : 0.f;
                     txsum += fabsf(txs[s]);
                 }
-                const bool col_live = txsum != 0.f;
+                const bool col_live = txsum != 0.f && ox < OW;
                 const float* dp = dout + ((size_t)n * K + kfirst) * plane + ox;
-                for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+                for (int oyb = oy_lo; oyb <= oy_hi; oyb += 2) {
+                    const int oy = oyb + (lane >> 5);
+                    const bool live = col_live && oy <= oy_hi;
                     float g[CH];
 #pragma unroll
                     for (int ci = 0; ci < CH; ++ci)
-                        g[ci] = (col_live && kfirst + 4 * ci < K) ? dp[(size_t)(4 * ci) * plane + (size_t)oy * OW] : 0.f;
+                        g[ci] = (live && kfirst + 4 * ci < K) ? dp[(size_t)(4 * ci) * plane + (size_t)oy * OW] : 0.f;
                     float tyr[R];
-                    lc_taps_y<R>(tyr, oy, stride, pad, Hm, H, pool, y0, hh, true);
+                    lc_taps_y<R>(tyr, oy, stride, pad, Hm, H, pool, y0, hh, live);
                     float w9[R][R];
 #pragma unroll
                     for (int r = 0; r < R; ++r)
