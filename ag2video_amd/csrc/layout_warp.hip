@@ -287,6 +287,12 @@ __global__ __launch_bounds__(256) void layout_conv_fwd_generic_kernel(const floa
     }
 }
 
+#ifdef AG2V_LC_STAMPS      // diagnostic build only (tools/ubench/lc_stamps.hip): phase clocks of one workgroup's first channel blocks
+__device__ unsigned long long g_lc_stamps[4][8][6];
+#define LC_STAMP(slot) do { if (blockIdx.x == 17 && blockIdx.y == 3 && lane == 0 && kbi < 8) g_lc_stamps[wave][kbi][slot] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define LC_STAMP(slot) do { } while (0)
+#endif
 // The kernel the path uses (J <= 24 objects, map rows <= 264 wide; everything else: layout_conv_fwd_generic_kernel below).
 // Workgroup = 4 waves = 4 output rows x KPER channels of one image; three LDS tables replace per-lane work that is uniform
 // over a wave: (1) the column profiles tx_j(x) of all objects, (2) the R row taps ty_j of each wave's row, (3) per wave and
@@ -323,8 +329,12 @@ __global__ __launch_bounds__(256) void layout_conv_fwd_kernel(const float* __res
         tyl[wave][j][r] = (r < R && oy < OH && act && (unsigned)yy < (unsigned)Hm) ? lc_profile(yy, H, pool, by, bh) : 0.f;
     }
     // the profiles above are shared by every channel: the workgroup walks the channel blocks kb = z, z + gridDim.z, ... itself
+    int kbi = -1;
+    (void)kbi;
     for (int k0 = blockIdx.z * KPER; k0 < K; k0 += gridDim.z * KPER) {
+    ++kbi;
     __syncthreads();          // (first pass: the profile tables are complete; later passes: the previous block's tables are no longer read)
+    LC_STAMP(0);
     if (img) {
         const float sc = iscale ? iscale[n] : 1.f;
         for (int idx = threadIdx.x; idx < KPER * IC * RRP; idx += 256) {
@@ -346,7 +356,9 @@ __global__ __launch_bounds__(256) void layout_conv_fwd_kernel(const float* __res
         }
         csl[wave][j][kk] = make_float4(cs[0], cs[1], cs[2], cs[3]);
     }
+    LC_STAMP(1);
     __syncthreads();
+    LC_STAMP(2);
     const int nq = (OW + 3) >> 2;
     const bool vec = (OW & 3) == 0;
     auto px = [&](int xq, int q) -> int { return vec ? xq * 4 + q : (xq >> 6) * 256 + (xq & 63) + 64 * q; };
@@ -393,6 +405,7 @@ __global__ __launch_bounds__(256) void layout_conv_fwd_kernel(const float* __res
                 }
             }
         }
+        LC_STAMP(4);
         for (int j = 0; j < J; ++j) {
             const float4 t4 = *reinterpret_cast<const float4*>(&tyl[wave][j][0]);
             const float tysum = fabsf(t4.x) + fabsf(t4.y) + fabsf(t4.z) + fabsf(t4.w);
@@ -418,6 +431,7 @@ __global__ __launch_bounds__(256) void layout_conv_fwd_kernel(const float* __res
                     for (int q = 0; q < 4; ++q) acc[kk][q] = fmaf(cs[s2], txs[s2][q], acc[kk][q]);
             }
         }
+        LC_STAMP(5);
 #pragma unroll
         for (int kk = 0; kk < KPER; ++kk) {
             if (k0 + kk >= K) continue;
@@ -431,7 +445,204 @@ __global__ __launch_bounds__(256) void layout_conv_fwd_kernel(const float* __res
             }
         }
     }
+    LC_STAMP(3);
     }
+}
+
+// Third form (3 x 3, pad 1, stride 1, no pooling, map rows of <= 256 pixels in whole quads, K % KPER == 0, <= 3 image channels):
+// what conv_dim_in / down_flow[0] and the dense J = 0 calls launch.  The kernel above, measured with in-kernel clocks
+// (tools/ubench/lc_stamps.hip) on the c3 shape: a channel block takes a wave ~24 k cycles (43 k with image channels) -- 3 k building the
+// taps, 5 k + 19 k accumulator set-up and image channels, 10 k walking the 22 object slots, 5-8 k issuing 16 stores -- against the 13 k the
+// 16 KB of stores need at the 5.9 TB/s this store pattern reaches alone (tools/ubench/store_pattern.hip).  Every global load in
+// the block loop (the U entries under a condition, the filter block, the image window -- the SAME 54 values for every block) was
+// followed by s_waitcnt vmcnt(0), which on this ISA also waits for the previous block's stores: compute and stores never overlapped.
+// Here nothing in the loop waits for memory behind a store:
+//   * the image rows the workgroup's four output rows see are staged ONCE, scaled and zero-padded, in LDS (imgl);
+//   * U[n, :, k0 : k0 + KPER] and the filter block of the NEXT channel block are copied global -> LDS by LDS-DMA pieces
+//     (buffer_load ... lds, no registers) issued after the barrier that frees the buffers; the copy is waited for (vmcnt(0)) just
+//     BEFORE the current block's stores are issued, when only loads are outstanding, and published by the barrier at the next top;
+//   * each wave keeps a list of the objects its row touches (built once): the taps are contracted for those only and the object
+//     loop walks the list (no per-slot LDS round trip + branch); an object's six profile values per lane are one 16-byte read + 2.
+// A row that touches more than ACT objects contracts the extra ones on the fly (correct, slower; c3 rows touch 2-5).
+typedef __attribute__((address_space(3))) void* lc_lds_vptr;
+template <int KPER>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void layout_conv_fwd3_kernel(const float* __restrict__ U, const float* __restrict__ boxes, const int* __restrict__ keep,
+                             const float* __restrict__ residual, float* __restrict__ out, int J, int K, int H, int W,
+                             const float* __restrict__ img, const float* __restrict__ wimg, const float* __restrict__ iscale, int IC) {
+#if defined(__HIP_DEVICE_COMPILE__)      // (the host pass only needs the stub; it rejects the LDS-DMA builtin)
+    constexpr int R = 3, RR = 9, RRP = 12, TJ = LC_TJ, TW = LC_TW, ACT = 10, UB = KPER * RR, IR = R + 3, IWP = 272;
+    constexpr int UPIECES = (TJ * UB * 4 + 1023) / 1024, WPIECES = (KPER * 3 * RR * 4 + 1023) / 1024;
+    __shared__ float txp[TJ][TW];                 // column profiles; index x + 4 (x = -4 .. 259 for W <= 256)
+    __shared__ float tyl[4][TJ][4];
+    __shared__ int actl[4][TJ + 1];               // [wave][0] = number of objects the wave's row touches, then their slots
+    __shared__ float4 csl[4][ACT][KPER];
+    __shared__ float wl[KPER][3][RRP];
+    __shared__ __attribute__((aligned(16))) float ul[UPIECES * 256];      // DMA target [j][KPER][RR] (+ the last piece's tail)
+    __shared__ __attribute__((aligned(16))) float wraw[WPIECES * 256];    // DMA target [KPER][IC][RR]
+    __shared__ __attribute__((aligned(16))) float imgl[3][IR][IWP];       // scaled image rows oy0 - 1 .. oy0 + 4; index x + 4
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int oy0 = blockIdx.x * 4, oy = oy0 + wave;
+    const int n = blockIdx.y;
+    const bool has_img = img != nullptr;
+    // ---- once per workgroup: profiles, the rows' taps and object lists, the image rows
+    for (int idx = threadIdx.x; idx < J * TW; idx += 256) {
+        const int j = idx / TW, xi = idx - j * TW, xx = xi - 4;
+        const float* b = boxes + ((size_t)n * J + j) * 4;
+        txp[j][xi] = ((unsigned)xx < (unsigned)W) ? lc_profile(xx, W, 0, b[0], b[2]) : 0.f;
+    }
+    {
+        bool touched = false;
+        if (lane < J) {
+            const float* b = boxes + ((size_t)n * J + lane) * 4;
+            const float bx = b[0], by = b[1], bw = b[2], bh = b[3];
+            const bool act = ((bx != 0.f) || (by != 0.f) || (bw != 0.f) || (bh != 0.f)) && keep[(size_t)n * J + lane] != 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int yy = oy + r - 1;
+                const float v = (r < R && oy < H && act && (unsigned)yy < (unsigned)H) ? lc_profile(yy, H, 0, by, bh) : 0.f;
+                tyl[wave][lane][r] = v;
+                touched = touched || v != 0.f;
+            }
+        }
+        const unsigned long long m = __ballot(touched);
+        if (lane == 0) actl[wave][0] = __popcll(m);
+        if (touched) actl[wave][1 + __popcll(m & ((1ull << lane) - 1ull))] = lane;
+    }
+    if (has_img) {
+        const float sc = iscale ? iscale[n] : 1.f;
+        for (int idx = threadIdx.x; idx < 3 * IR * IWP; idx += 256) {
+            const int xi = idx % IWP, ri = (idx / IWP) % IR, c = idx / (IWP * IR);
+            const int xx = xi - 4, yy = oy0 - 1 + ri;
+            (&imgl[0][0][0])[idx] = (c < IC && (unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H)
+                                        ? img[(((size_t)n * IC + c) * H + yy) * W + xx] * sc : 0.f;
+        }
+    }
+    // ---- LDS-DMA of a channel block's U entries and filter block
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(U ? U + (size_t)n * J * K * RR : out), 0,
+                                                                        U ? (unsigned)((size_t)J * K * RR * 4) : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(has_img ? wimg : out), 0,
+                                                                        has_img ? (unsigned)((size_t)K * IC * RR * 4) : 0u, 0x00020000);
+    unsigned uoff[(UPIECES + 3) / 4];
+#pragma unroll
+    for (int i = 0; i < (UPIECES + 3) / 4; ++i) {
+        const int e = ((wave + 4 * i) * 64 + lane) * 4;            // first float of this lane's 16 bytes in ul
+        const int j = e / UB, rem = e - j * UB;
+        uoff[i] = (wave + 4 * i < UPIECES && j < J) ? (unsigned)((j * K * RR + rem) * 4) : 0xFFFFFFF0u;      // out of range: zeros
+    }
+    const unsigned woff = (wave < WPIECES && (wave * 64 + lane) * 4 < KPER * IC * RR) ? (unsigned)((wave * 64 + lane) * 16) : 0xFFFFFFF0u;
+    auto dma = [&](int kb) {
+#pragma unroll
+        for (int i = 0; i < (UPIECES + 3) / 4; ++i)
+            if (wave + 4 * i < UPIECES)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(urs, (lc_lds_vptr)(&ul[(wave + 4 * i) * 256]), 16, uoff[i], (unsigned)(kb * RR * 4), 0, 0);
+        if (wave < WPIECES)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lc_lds_vptr)(&wraw[wave * 256]), 16, woff, (unsigned)(kb * IC * RR * 4), 0, 0);
+    };
+    dma(blockIdx.z * KPER);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int xq = lane;
+    const bool px_live = oy < H && xq * 4 < W;
+    for (int k0 = blockIdx.z * KPER; k0 < K; k0 += gridDim.z * KPER) {
+        __syncthreads();          // the block's U / filter copies have landed (every wave waited for its pieces); csl / wl of the previous block are free
+        const int na = actl[wave][0];
+        for (int idx = lane; idx < min(na, ACT) * KPER; idx += 64) {
+            const int a = idx / KPER, kk = idx - a * KPER;
+            const int j = actl[wave][1 + a];
+            const float4 t4 = *reinterpret_cast<const float4*>(&tyl[wave][j][0]);
+            const float* u = &ul[j * UB + kk * RR];
+            float cs[3];
+#pragma unroll
+            for (int s2 = 0; s2 < 3; ++s2) cs[s2] = fmaf(t4.z, u[6 + s2], fmaf(t4.y, u[3 + s2], t4.x * u[s2]));
+            csl[wave][a][kk] = make_float4(cs[0], cs[1], cs[2], 0.f);
+        }
+        if (has_img) {
+            for (int idx = threadIdx.x; idx < KPER * 3 * RRP; idx += 256) {
+                const int t = idx % RRP, c = (idx / RRP) % 3, kk = idx / (RRP * 3);
+                (&wl[0][0][0])[idx] = (t < RR && c < IC) ? wraw[(kk * IC + c) * RR + t] : 0.f;
+            }
+        }
+        __syncthreads();          // ul / wraw are read out: the next block's copies may start (unless a row has extra objects, which read ul below)
+        const bool extra = (actl[0][0] > ACT) || (actl[1][0] > ACT) || (actl[2][0] > ACT) || (actl[3][0] > ACT);      // uniform over the workgroup
+        const int kn = k0 + gridDim.z * KPER;
+        if (!extra && kn < K) dma(kn);
+        float acc[KPER][4];
+        if (px_live) {
+#pragma unroll
+            for (int kk = 0; kk < KPER; ++kk)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    acc[kk][q] = residual ? residual[(((size_t)n * K + k0 + kk) * H + oy) * W + xq * 4 + q] : 0.f;
+            if (has_img) {
+                for (int c = 0; c < IC; ++c) {
+                    float iv[R][6];                 // columns 4 xq - 1 .. 4 xq + 4
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const float* row = &imgl[c][wave + r][xq * 4 + 4];
+                        const float4 m4 = *reinterpret_cast<const float4*>(row);
+                        iv[r][0] = row[-1]; iv[r][1] = m4.x; iv[r][2] = m4.y; iv[r][3] = m4.z; iv[r][4] = m4.w; iv[r][5] = row[4];
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < KPER; ++kk) {
+                        float wv[RRP];
+#pragma unroll
+                        for (int t = 0; t < RRP; t += 4) {
+                            const float4 w4 = *reinterpret_cast<const float4*>(&wl[kk][c][t]);      // wave-uniform address: broadcast
+                            wv[t] = w4.x; wv[t + 1] = w4.y; wv[t + 2] = w4.z; wv[t + 3] = w4.w;
+                        }
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+#pragma unroll
+                            for (int s2 = 0; s2 < R; ++s2)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) acc[kk][q] = fmaf(wv[r * R + s2], iv[r][s2 + q], acc[kk][q]);
+                    }
+                }
+            }
+            for (int a = 0; a < na; ++a) {
+                const int j = __builtin_amdgcn_readfirstlane(actl[wave][1 + a]);
+                const float* row = &txp[j][xq * 4 + 4];
+                const float4 m4 = *reinterpret_cast<const float4*>(row);
+                const float tx[6] = {row[-1], m4.x, m4.y, m4.z, m4.w, row[4]};
+                const float txsum = fabsf(tx[0]) + fabsf(tx[1]) + fabsf(tx[2]) + fabsf(tx[3]) + fabsf(tx[4]) + fabsf(tx[5]);
+                if (__ballot(txsum != 0.f) == 0ull) continue;
+                if (a < ACT) {
+#pragma unroll
+                    for (int kk = 0; kk < KPER; ++kk) {
+                        const float4 c4 = csl[wave][a][kk];
+                        const float cs[3] = {c4.x, c4.y, c4.z};
+#pragma unroll
+                        for (int s2 = 0; s2 < R; ++s2)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) acc[kk][q] = fmaf(cs[s2], tx[s2 + q], acc[kk][q]);
+                    }
+                } else {            // more objects on this row than the tap table holds: contract on the fly
+                    const float4 t4 = *reinterpret_cast<const float4*>(&tyl[wave][j][0]);
+                    for (int kk = 0; kk < KPER; ++kk) {
+                        const float* u = &ul[j * UB + kk * RR];
+#pragma unroll
+                        for (int s2 = 0; s2 < R; ++s2) {
+                            const float cs = fmaf(t4.z, u[6 + s2], fmaf(t4.y, u[3 + s2], t4.x * u[s2]));
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) acc[kk][q] = fmaf(cs, tx[s2 + q], acc[kk][q]);
+                        }
+                    }
+                }
+            }
+        }
+        if (extra) {              // (rare) the object loop read ul: copy only now
+            __syncthreads();
+            if (kn < K) dma(kn);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the copies (and nothing younger: this block's stores follow)
+        if (px_live) {
+#pragma unroll
+            for (int kk = 0; kk < KPER; ++kk)
+                *reinterpret_cast<float4*>(out + (((size_t)n * K + k0 + kk) * H + oy) * W + xq * 4) =
+                    make_float4(acc[kk][0], acc[kk][1], acc[kk][2], acc[kk][3]);
+        }
+    }
+#endif
 }
 
 // dU[n,j,k,r,s] = sum_{oy,ox} dout[n,k,oy,ox] * ty_j(oy*st+r-pad) * tx_j(ox*st+s-pad): grid (J, NB, ceil(K/32)),
@@ -820,6 +1031,12 @@ extern "C" int ag2v_layout_conv_img_fwd(const float* U, const float* boxes, cons
         const int nkb = ceil_div(K, KPER), wg = ceil_div(OH, 4) * NB;
         grid.z = wg >= 2048 ? 1 : std::min(nkb, ceil_div(2048, wg));
     }
+    static const bool no_fwd3 = getenv("AG2V_NO_LC_FWD3") != nullptr;       // A/B aid
+    if (tables && !no_fwd3 && R == 3 && pad == 1 && stride == 1 && pool == 0 && W <= 256 && (W & 3) == 0 && K % KPER == 0 && (!img || IC <= 3) &&
+        (size_t)J * K * 9 * 4 < 0xFFFFFFF0ull && (((uintptr_t)U | (uintptr_t)wimg) & 15) == 0) {
+        hipLaunchKernelGGL((layout_conv_fwd3_kernel<KPER>), grid, dim3(256), 0, (hipStream_t)stream, U, boxes, keep, residual, out, J, K, H, W,
+                           img, wimg, iscale, IC);
+    } else
     if (tables) { if (R == 3) LC_LAUNCH(layout_conv_fwd_kernel, 3); else LC_LAUNCH(layout_conv_fwd_kernel, 4); }
     else        { if (R == 3) LC_LAUNCH(layout_conv_fwd_generic_kernel, 3); else LC_LAUNCH(layout_conv_fwd_generic_kernel, 4); }
 #undef LC_LAUNCH

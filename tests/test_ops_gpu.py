@@ -297,7 +297,10 @@ def test_layout_render(cfg, device):
 
 @pytest.mark.parametrize("cfg", [(2, 6, 20, 32, 32, 3, 1, 1, 0), (3, 22, 40, 64, 64, 3, 1, 1, 0), (2, 5, 9, 32, 32, 4, 2, 2, 0),
                                  (1, 9, 33, 24, 40, 3, 1, 1, 0), (3, 7, 12, 64, 64, 4, 2, 2, 1), (2, 4, 8, 33, 29, 4, 2, 2, 1),
-                                 (2, 26, 20, 32, 32, 3, 1, 1, 0), (1, 24, 70, 16, 272, 3, 1, 1, 0), (2, 3, 200, 16, 16, 3, 1, 1, 0)],
+                                 (2, 26, 20, 32, 32, 3, 1, 1, 0), (1, 24, 70, 16, 272, 3, 1, 1, 0), (2, 3, 200, 16, 16, 3, 1, 1, 0),
+                                 # layout_conv_fwd3_kernel (3 x 3, K % 16 == 0, rows of whole quads): rows touching more objects than its tap
+                                 # table holds, map heights that are not multiples of 4, the widest rows it takes, one channel block
+                                 (3, 22, 48, 36, 64, 3, 1, 1, 0), (2, 24, 32, 18, 256, 3, 1, 1, 0), (2, 5, 16, 7, 12, 3, 1, 1, 0)],
                          ids=str)
 def test_layout_conv(cfg, device):
     from ag2video_amd import ops
@@ -307,6 +310,9 @@ def test_layout_conv(cfg, device):
     boxes[0, 1] = 0.0
     boxes[NB - 1, 0] = torch.tensor([0.0, 0.0, 1.0, 1.0])
     boxes[0, J - 1] = -1.0
+    if J >= 22 and Kc % 16 == 0:            # 14 tall objects in the last image: its rows touch more objects than fwd3's tap table holds
+        boxes[NB - 1, 1:15, 1] = 0.02
+        boxes[NB - 1, 1:15, 3] = 0.9
     keep = torch.ones(NB, J, dtype=torch.int32)
     keep[:, J - 1] = 0
     Hm, Wm = ((H - 1) // 2 + 1, (W - 1) // 2 + 1) if pool else (H, W)
@@ -1168,7 +1174,8 @@ def test_spade_pair(cfg, device):
     assert not ops.spade_pair_supported(224, 224, 2) and ops.spade_pair_supported(224, 224, 1)
 
 
-@pytest.mark.parametrize("cfg", [(4, 5, 24, 16, 16, 3, 2), (6, 4, 40, 12, 20, 3, 3), (2, 3, 16, 8, 8, 3, None)], ids=str)
+@pytest.mark.parametrize("cfg", [(4, 5, 24, 16, 16, 3, 2), (6, 4, 40, 12, 20, 3, 3), (2, 3, 16, 8, 8, 3, None),
+                                 (3, 14, 32, 22, 64, 3, 3), (2, 22, 48, 10, 256, 3, None)], ids=str)      # (the last two: layout_conv_fwd3_kernel)
 def test_layout_conv_img(cfg, device):
     """Layout channels (low rank) + image channels (dense, scaled per sample group) of one convolution in one launch; gradients to the
     taps U, the image, the image filter and the group scales."""

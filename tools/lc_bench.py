@@ -1,8 +1,8 @@
 """Micro-benchmark of the low-rank layout convolution at conv_dim_in's c3 shape (22 object slots, 512 channels, 120 x 256 x 256),
 with all slots occupied and with 6 occupied (c3 clips: 2-3 objects per frame, two layouts)."""
-import sys, time
+import os, sys, time
 import torch
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from ag2video_amd import ops
 torch.manual_seed(0)
 dev = 'cuda'
