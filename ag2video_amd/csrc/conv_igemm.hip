@@ -1065,6 +1065,93 @@ extern "C" int ag2v_conv2d_fwd(const float* x, const float* w, const float* bias
     return ag2v_conv2d_fwd_ex(x, w, bias, residual, y, N, C, H, W, K, R, S, stride, pad, 0, workspace, stream, nullptr);
 }
 
+// ---------------------------------------------------------------- stride-2 data gradient as ONE convolution + depth-to-space
+// The four pixel classes (py, px) of a stride-2 data gradient are stride-1 convolutions of dy with <= 2 x 2 sub-filters.  Run one by
+// one each is a GEMM with C rows (64 of a 128-row tile for the discriminators' 128 -> 64 layer) that scatters 4-byte stores to every
+// second pixel of dx: 93-240 TF, 11.5 ms per c3 step.  When all four classes read the SAME 2 x 2 window of dy (4 x 4 pad 2, 3 x 3
+// pad 1: discriminator.py:368-379, flows_generator.py:45-47) they are one stride-1 2 x 2 convolution to 4 C output channels
+// (class-major rows, zero taps where a class's sub-filter is smaller) on the half-resolution grid -- full 256-row tiles, dense
+// 16-byte stores into a workspace -- followed by a depth-to-space pass (mask, accumulate) over dx.
+struct S2Geom { int Q, ay[2], rc[2]; bool ok; };      // per axis: grid size, first dx row of class p, sub-filter length of class p
+static S2Geom s2_geom(int L, int R, int pad) {      // L: dx length along the axis
+    S2Geom g{};
+    g.ok = R <= 4;
+    for (int p = 0; p < 2; ++p) {
+        const int rc = (R - p + 1) / 2;
+        const int q0 = (pad > p) ? (pad - p + 1) / 2 : 0;
+        g.rc[p] = rc;
+        g.ay[p] = q0 * 2 + p - pad;
+        if (rc < 1 || rc > 2 || rc - 1 - q0 != 0 || g.ay[p] < 0 || g.ay[p] > 1 || g.ay[p] >= L) g.ok = false;
+        const int n = g.ok ? (L - g.ay[p] + 1) / 2 : 0;
+        if (n > g.Q) g.Q = n;
+    }
+    if (g.ay[0] == g.ay[1]) g.ok = false;
+    return g;
+}
+// plane[((tap_major_row(k, i, i2; 2, 2) >> 3) * 4C + cls * C + c) * 8 + (k & 7)] = hi | lo of the class's tap at window position
+// (i, i2), or 0 -- grid (ceil(C / 64), K / 8), as pack_dgrad_tap_kernel
+__global__ __launch_bounds__(256) void pack_dgrad_s2_tap_kernel(const float* __restrict__ w, float* __restrict__ at, int K, int C, int R, int S,
+                                                                int rc0, int rc1, int sc0, int sc1) {
+    __shared__ float t[8][64 * 17];
+    const int RS = R * S, RSP = RS | 1;
+    const int c0 = blockIdx.x * 64, k0 = blockIdx.y * 8;
+    const int nc = min(64, C - c0);
+    for (int j = 0; j < 8; ++j) {
+        const float* src = w + ((size_t)(k0 + j) * C + c0) * RS;
+        for (int i = threadIdx.x; i < nc * RS; i += 256) {
+            const int c = i / RS;
+            t[j][c * RSP + (i - c * RS)] = src[i];
+        }
+    }
+    __syncthreads();
+    const int M = 4 * C;
+    uint4* hi_plane = reinterpret_cast<uint4*>(at);
+    uint4* lo_plane = hi_plane + (size_t)(K * 4 / 8) * M;
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    for (int u = grp; u < 16; u += 4) {           // (class, window position)
+        const int cls = u >> 2, i = (u >> 1) & 1, i2 = u & 1;
+        const int py = cls >> 1, px = cls & 1;
+        const int Rc = py ? rc1 : rc0, Sc = px ? sc1 : sc0;
+        if (lane < nc) {
+            float x[8];
+            const bool live = i < Rc && i2 < Sc;
+            const int q = lane * RSP + (py + 2 * (Rc - 1 - i)) * S + (px + 2 * (Sc - 1 - i2));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = live ? t[e][q] : 0.f;
+            uint4 hi, lo;
+            split_planes8(x, hi, lo);
+            const size_t idx = (size_t)(tap_major_row(k0, i, i2, 2, 2) >> 3) * M + (size_t)cls * C + (c0 + lane);
+            hi_plane[idx] = hi;
+            lo_plane[idx] = lo;
+        }
+    }
+}
+// dx[n, c, y, x] (+)= t[n, cls * C + c, (y - ay[py]) / 2, (x - ax[px]) / 2] for the class whose parity (y, x) has; mask as the epilogues
+__global__ __launch_bounds__(256) void depth_to_space_s2_kernel(const float* __restrict__ t, const float* __restrict__ mask, float* __restrict__ dx,
+                                                                long long total, int C, int H, int W, int Qy, int Qx, int ay0, int ax0, int acc) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int x = (int)(i % W);
+    const int y = (int)((i / W) % H);
+    const int c = (int)((i / ((long long)W * H)) % C);
+    const long long n = i / ((long long)W * H * C);
+    const int py = ((y - ay0) & 1), px = ((x - ax0) & 1);          // class 0 owns the rows of ay0's parity
+    const int qy = (y - (py ? 1 - ay0 : ay0)) >> 1, qx = (x - (px ? 1 - ax0 : ax0)) >> 1;
+    float v = t[(((size_t)n * 4 + (py * 2 + px)) * C + c) * ((size_t)Qy * Qx) + (size_t)qy * Qx + qx];
+    if (mask) v = (mask[i] > 0.f) ? v : 0.f;
+    dx[i] = acc ? dx[i] + v : v;
+}
+static bool s2_unified_ok(const ConvCfg& cfg, int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int OH, int OW) {
+    static const bool on = getenv("AG2V_NO_S2_UNIFIED") == nullptr;
+    if (!on || stride != 2 || R != S || cfg.out_nstride > 0 || cfg.out_split) return false;
+    if (!use_bf16x3(cfg, C) || !igemm_tap_major(K, true) || C < 32) return false;
+    const S2Geom gy = s2_geom(H, R, pad), gx = s2_geom(W, S, pad);
+    if (!gy.ok || !gx.ok) return false;
+    if ((long long)K * 4 * 4 * C * 4 >= kBufMax || (long long)4 * C * gy.Q * gx.Q >= (1LL << 31)) return false;
+    (void)N; (void)OH; (void)OW;
+    return true;
+}
+
 // dx = d conv / d x (* gscale[n / group_n]).  For each pixel class (py,px) of the stride one forward-kernel launch over dy with the
 // class's flipped sub-filter.  workspace: ag2v_conv2d_dgrad_workspace_floats() floats.
 // mask (nullable, same shape as dx): dx = (mask > 0) ? dx : 0 -- the backward of a ReLU that produced this convolution's input
@@ -1079,6 +1166,13 @@ extern "C" size_t ag2v_conv2d_dgrad_workspace_floats(int N, int C, int H, int W,
     size_t n = (size_t)C * K * R * S;
     // few input channels: the [N, C R S, OH, OW] intermediate of the 1x1-GEMM + shifted-plane-sum form lives in the workspace too
     if (OH > 0 && OW > 0 && few_channel_dgrad(N, C, K, R, S, OH, OW, stride, false)) n += (size_t)N * C * R * S * OH * OW;
+    if (OH > 0 && OW > 0 && stride == 2 && R == S && R <= 4) {      // the one-convolution form of a stride-2 data gradient (if the call takes it)
+        const S2Geom gy = s2_geom(H, R, pad), gx = s2_geom(W, S, pad);
+        if (gy.ok && gx.ok) {
+            const size_t need = (size_t)16 * K * C + (size_t)N * 4 * C * gy.Q * gx.Q;
+            if (need > n) n = need;
+        }
+    }
     return n;
 }
 extern "C" int ag2v_conv2d_dgrad_ex(const float* dy, const float* w, const float* mask, float* dx,
@@ -1124,6 +1218,43 @@ extern "C" int ag2v_conv2d_dgrad_ex(const float* dy, const float* w, const float
         }
         if (o) o->kernel = g_last_conv_kernel;
         return rc;
+    }
+    if (s2_unified_ok(cfg, N, C, H, W, K, R, S, stride, pad, OH, OW)) {
+        const S2Geom gy = s2_geom(H, R, pad), gx = s2_geom(W, S, pad);
+        const size_t wfl = (size_t)16 * K * C, per_t = (size_t)4 * C * gy.Q * gx.Q;
+        int nmax = N;
+        if (dys * 4 * N >= chunk_limit() || (long long)per_t * 4 * N >= chunk_limit())
+            nmax = chunk_samples(dys * 4, (long long)per_t * 4, cfg.gscale ? cfg.group_n : 1);
+        if ((long long)nmax * gy.Q * gx.Q >= (1LL << 31)) nmax = (int)(((1LL << 31) - 1) / ((long long)gy.Q * gx.Q));
+        if (cfg.gscale) nmax -= nmax % cfg.group_n;
+        if (nmax > 0 && workspace_floats >= wfl + per_t * (size_t)(nmax < N ? nmax : N)) {
+            float* at = workspace;
+            float* tmp = workspace + wfl;
+            hipLaunchKernelGGL(pack_dgrad_s2_tap_kernel, dim3(ceil_div(C, 64), K / 8), dim3(256), 0, st, w, at, K, C, R, S, gy.rc[0], gy.rc[1],
+                               gx.rc[0], gx.rc[1]);
+            for (int n0 = 0; n0 < N; n0 += nmax) {
+                const int nc = (N - n0 < nmax) ? N - n0 : nmax;
+                ConvArgs f{};
+                f.tap_major = 1;
+                f.a_src = at; f.b_src = dy + (size_t)n0 * dys; f.out = tmp;
+                f.N = nc; f.C = K; f.H = OH; f.W = OW; f.K = 4 * C; f.R = 2; f.S = 2; f.stride = 1; f.pad = 0; f.pad_w = 0;
+                f.OH = gy.Q; f.OW = gx.Q;
+                f.M = 4 * C; f.NG = nc * gy.Q * gx.Q; f.KG = K * 4;
+                f.a_bytes = (unsigned)((long long)K * 4 * 4 * C * 4); f.b_bytes = (unsigned)(dys * 4 * nc);
+                f.gscale = cfg.gscale ? cfg.gscale + n0 / cfg.group_n : nullptr; f.group_n = cfg.group_n;
+                f.b_split = cfg.dy_split;
+                f.det = cfg.det;
+                const int rc = launch_igemm(f, st, false, true);
+                if (rc != AG2V_OK) return rc;
+                const long long total = (long long)nc * C * H * W;
+                hipLaunchKernelGGL(depth_to_space_s2_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, tmp,
+                                   mask ? mask + (size_t)n0 * dxs : nullptr, dx + (size_t)n0 * dxs, total, C, H, W, gy.Q, gx.Q, gy.ay[0], gx.ay[0],
+                                   accumulate ? 1 : 0);
+                if (hipGetLastError() != hipSuccess) return AG2V_EHIP;
+            }
+            if (o) o->kernel = g_last_conv_kernel;
+            return AG2V_OK;
+        }
     }
     // With stride > 1 several classes write disjoint pixels of dx (one of them may be empty when R < stride) and a class
     // may take the atomic split-K epilogue: zero dx once up front.  Stride 1 is a single class covering every pixel.

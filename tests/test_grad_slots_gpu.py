@@ -271,3 +271,35 @@ def test_data_gradient_of_few_row_layers_on_the_dense_image_path(cfg, device):
     (torch.nn.functional.conv2d(xd, wd, bd, 1, 1) * head.double()).sum().backward()
     for got, ref in ((x.grad, xd.grad), (w.grad, wd.grad), (b.grad, bd.grad)):
         assert float((got.double() - ref).abs().max()) <= 3e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("cfg", [(3, 64, 33, 33, 128, 4, 2), (2, 32, 64, 64, 64, 3, 1), (2, 96, 31, 45, 96, 4, 2), (4, 128, 16, 16, 256, 4, 2), (2, 64, 18, 18, 64, 4, 1)], ids=str)
+def test_stride_2_data_gradient_as_one_convolution(cfg, device):
+    """Stride-2 data gradients whose four pixel classes read the same 2 x 2 window of dy (4 x 4 pad 2: the discriminators' layers,
+    discriminator.py:368-379; 3 x 3 pad 1: the flow network's down path, flows_generator.py:45-47) run as ONE stride-1 2 x 2 convolution
+    to 4 C class-major channels + a depth-to-space pass (conv_igemm.hip: s2_unified_ok).  Against fp64 conv_transpose2d: plain, with the
+    ReLU mask, accumulating, with per-group scales; odd map sizes (class grids of different sizes); 4 x 4 pad 1 keeps the per-class launches."""
+    from ag2video_amd import _lib, ops
+    N, C, H, W, K, R, pad = cfg
+    torch.manual_seed(23)
+    OH, OW = (H + 2 * pad - R) // 2 + 1, (W + 2 * pad - R) // 2 + 1
+    dy = torch.randn(N, K, OH, OW, device=device)
+    w = torch.randn(K, C, R, R, device=device) * 0.05
+    xin = torch.randn(N, C, H, W, device=device)
+    gs = torch.linspace(0.5, 1.5, N, device=device)
+    ref = torch.nn.functional.conv_transpose2d(dy.double(), w.double(), None, 2, pad,
+                                               output_padding=(H + 2 * pad - R - (OH - 1) * 2, W + 2 * pad - R - (OW - 1) * 2)).float()
+    sc = float(ref.abs().max())
+    with ops.conv_precision('bf16x3'), ops.bf16x3_min_rows(32), torch.no_grad():
+        dx = torch.empty(N, C, H, W, device=device)
+        ops._conv_dgrad_launch(32, dy, w, None, dx, 2, pad, 0)
+        assert float((dx - ref).abs().max()) <= 2e-4 * sc
+        ops._conv_dgrad_launch(32, dy, w, xin, dx, 2, pad, 0)
+        assert float((dx - ref * (xin > 0).float()).abs().max()) <= 2e-4 * sc
+        base = torch.randn(N, C, H, W, device=device)
+        dx = base.clone()
+        ops._conv_dgrad_launch(32, dy, w, None, dx, 2, pad, 1)
+        assert float((dx - base - ref).abs().max()) <= 2e-4 * sc + 1e-6
+        dx = torch.empty(N, C, H, W, device=device)
+        ops._conv_dgrad_launch(32, dy, w, None, dx, 2, pad, 0, gscale=gs, group_n=1)
+        assert float((dx - ref * gs.view(N, 1, 1, 1)).abs().max()) <= 3e-4 * sc
