@@ -370,8 +370,11 @@ struct HaloBody {
 // 32-63 (k groups 2, 3) those of step 2D + 1 -- another tap of the same staged image (or tap 8 of one stage with tap 0 of the next: 18
 // steps per stage pair = 9 double-steps), whose ring slot / image offset differs from the first one's by a compile-time constant that sits
 // in the lane's base address.  One barrier, one counted wait per DOUBLE-step (48 MFMAs per wave at EM = 4).
-template <int WM, int WN, int EM, int TW, int TH, bool PS>
+// H16 (with PS = false): the fp16 3-term split of the forward passes that need fp32-class products (ConvArgs::h16: the flow network,
+// conv_common.h split2_h) -- v_mfma_f32_16x16x32_f16 on planes the *_h pack kernels wrote; the epilogue's oscale undoes their scale
+template <int WM, int WN, int EM, int TW, int TH, bool PS, bool H16 = false>
 struct HaloBody16 {
+    static_assert(!(PS && H16), "split words are bf16 pairs");
     typedef HaloCfg<WM, WN, EM, TW, TH, true> G;
     static constexpr unsigned kOut = 0xFFFFFFF0u;
     static constexpr int RB = 2 * EM;                    // 16-row blocks of a wave's EM * 32 rows
@@ -460,7 +463,8 @@ struct HaloBody16 {
                     lv[q] = __builtin_amdgcn_perm(bw[8 * c + 2 * q + 1], bw[8 * c + 2 * q], 0x05040100u);
                 } else {
                     unsigned h_, l_;
-                    split2(__uint_as_float(bw[8 * c + 2 * q]), __uint_as_float(bw[8 * c + 2 * q + 1]), h_, l_);
+                    if constexpr (H16) split2_h(__uint_as_float(bw[8 * c + 2 * q]), __uint_as_float(bw[8 * c + 2 * q + 1]), h_, l_);
+                    else split2(__uint_as_float(bw[8 * c + 2 * q]), __uint_as_float(bw[8 * c + 2 * q + 1]), h_, l_);
                     hv[q] = h_;
                     lv[q] = l_;
                 }
@@ -494,9 +498,15 @@ struct HaloBody16 {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[g], bh[c], acc[g][c], 0, 0, 0);
-                acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[g], bl[c], acc[g][c], 0, 0, 0);
-                acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[g], bh[c], acc[g][c], 0, 0, 0);
+                if constexpr (H16) {
+                    acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, al[g]), __builtin_bit_cast(f16x8, bh[c]), acc[g][c], 0, 0, 0);
+                    acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah[g]), __builtin_bit_cast(f16x8, bl[c]), acc[g][c], 0, 0, 0);
+                    acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah[g]), __builtin_bit_cast(f16x8, bh[c]), acc[g][c], 0, 0, 0);
+                } else {
+                    acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[g], bh[c], acc[g][c], 0, 0, 0);
+                    acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[g], bl[c], acc[g][c], 0, 0, 0);
+                    acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[g], bh[c], acc[g][c], 0, 0, 0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             // The double-step's DMA pieces go out behind the first MFMA group (an LDS-DMA takes 60-180 cycles to issue).
@@ -796,6 +806,16 @@ __global__ __launch_bounds__(512) void conv_halo16_bf16x3_kernel(ConvArgs p) {
 #endif
 }
 
+// ... on the fp16 3-term split (fp32 gathered tensor, ConvArgs::h16)
+template <int WM, int WN, int EM, int TW, int TH>
+__global__ __launch_bounds__(512) void conv_halo16_f16x3_kernel(ConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(1024))) char smem[HaloCfg<WM, WN, EM, TW, TH, true>::LDS_BYTES];
+    HaloBody16<WM, WN, EM, TW, TH, false, true> body(p, smem);
+    body.run();
+#endif
+}
+
 // ---- host side
 // Geometry of the pixel patch for a BN-pixel tile on an OH x OW map: the widest TW in {128, 64, 32} that divides OW with TH = BN / TW
 // dividing OH and leaving at least one row outside the patch (a patch as tall as the image would make pieces that are all padding).
@@ -821,7 +841,9 @@ static bool halo_tall(int M) {
 // Can this launch (as the callers of launch_igemm_bf16x3 describe it) run on the halo kernels?
 bool igemm_halo_ok(const ConvArgs& a) {
     // (read per call, not cached: tools/halo_bench.py and the tests switch kernels inside one process)
-    if (getenv("AG2V_NO_HALO") != nullptr || !a.tap_major || a.h16 || a.f32 || a.b_bytes == 0) return false;
+    if (getenv("AG2V_NO_HALO") != nullptr || !a.tap_major || a.f32 || a.b_bytes == 0) return false;
+    // fp16 split: fp32 gathered tensor, plain output, the 16x16x32 form only (AG2V_NO_HALO_H16: A/B aid)
+    if (a.h16 && (a.b_split || a.out_split || getenv("AG2V_HALO_MFMA32") != nullptr || getenv("AG2V_NO_HALO_H16") != nullptr)) return false;
     if (!a.b_split && getenv("AG2V_NO_HALO_F32IN") != nullptr) return false;       // (A/B aid: fp32 gathered tensors on the previous kernels)
     if (a.R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1 || a.pad_w != 1 || a.OH != a.H || a.OW != a.W) return false;
     if (a.C % 32 || a.W % 4 || (a.o_mul != 1 && a.o_mul != 0) || a.o_add_y || a.o_add_x) return false;
@@ -858,7 +880,10 @@ int launch_igemm_halo(ConvArgs& a, hipStream_t st) {
     const bool mf16 = getenv("AG2V_HALO_MFMA32") == nullptr;          // (A/B aid: the 32x32x16 form)
 #define AG2V_HALO(WM_, WN_, EM_, TW_, TH_)                                                                                       \
     do {                                                                                                                         \
-        if (mf16 && a.b_split) {                                                                                                 \
+        if (a.h16) {                                                                                                             \
+            set_last_conv_kernel("conv_halo16_f16x3_kernel<" #WM_ ", " #WN_ ", " #EM_ ", " #TW_ ", " #TH_ ">");                    \
+            hipLaunchKernelGGL((conv_halo16_f16x3_kernel<WM_, WN_, EM_, TW_, TH_>), grid, dim3(512), 0, st, a);                    \
+        } else if (mf16 && a.b_split) {                                                                                                 \
             set_last_conv_kernel("conv_halo16_bf16x3_kernel<" #WM_ ", " #WN_ ", " #EM_ ", " #TW_ ", " #TH_ ", true>");            \
             hipLaunchKernelGGL((conv_halo16_bf16x3_kernel<WM_, WN_, EM_, TW_, TH_, true>), grid, dim3(512), 0, st, a);             \
         } else if (mf16) {                                                                                                       \

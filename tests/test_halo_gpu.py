@@ -175,3 +175,28 @@ def test_exact_fp32_weight_gradient_on_the_wave_specialised_pipeline(cfg, device
                 with torch.enable_grad():
                     rg = ref(x[sl], dy[sl])
                 assert float((dwg[g] - rg).abs().max()) <= 2e-5 * float(rg.abs().max())
+
+
+@pytest.mark.parametrize("cfg", [(2, 64, 64, 64, 128), (1, 32, 128, 128, 64), (2, 32, 32, 32, 256), (1, 64, 256, 256, 32)], ids=str)
+def test_halo_forward_on_the_fp16_split(cfg, device):
+    """conv_halo16_f16x3_kernel: the forward passes that run on the fp16 3-term split (the flow network, flows_generator.py:45-54,
+    ops.bf16x3_min_rows(fwd_h16=True): fp32 gathered tensor, weights packed x 32 as fp16 hi / lo planes) on the halo-tile pipeline --
+    against the oracle at the fp16 split's accuracy (~5e-6 of rms: bound 3e-5 of max) and the wave-specialised fp16-split kernel."""
+    from ag2video_amd import _lib, ops
+    from oracle import kernels as K
+    N, C, H, W, Kout = cfg
+    torch.manual_seed(29)
+    x = torch.randn(N, C, H, W, device=device)
+    w = torch.randn(Kout, C, 3, 3, device=device) * 0.03
+    b = torch.randn(Kout, device=device)
+    outs = {}
+    with ops.conv_precision('bf16x3'), ops.bf16x3_min_rows(32, fwd_h16=True), torch.no_grad():
+        for on in (True, False):
+            with _halo(on):
+                outs[on] = ops.conv2d(x, w, b, 1, 1, relu=True)
+                name = _lib.query('ag2v_last_conv_kernel')
+                assert name.startswith(b'conv_halo16_f16x3_kernel' if on else b'conv_igemm_f16x3'), name
+    ref = K.conv2d(x.cpu(), w.cpu(), b.cpu(), 1, 1, relu=True)
+    sc = float(ref.abs().max())
+    assert float((outs[True].cpu() - ref).abs().max()) <= 3e-5 * sc
+    assert float((outs[True] - outs[False]).abs().max()) <= 1e-5 * sc
