@@ -843,7 +843,9 @@ bool igemm_halo_ok(const ConvArgs& a) {
     // (read per call, not cached: tools/halo_bench.py and the tests switch kernels inside one process)
     if (getenv("AG2V_NO_HALO") != nullptr || !a.tap_major || a.f32 || a.b_bytes == 0) return false;
     // fp16 split: fp32 gathered tensor, plain output, the 16x16x32 form only (AG2V_NO_HALO_H16: A/B aid)
-    if (a.h16 && (a.b_split || a.out_split || getenv("AG2V_HALO_MFMA32") != nullptr || getenv("AG2V_NO_HALO_H16") != nullptr)) return false;
+    // (not in deterministic mode: there the flow network keeps ONE kernel family for every batch size, so that the frame-batched and
+    // the sequential passes agree to the last bit in their flows -- tests/test_fullsize_gpu.py::test_full_size_deterministic_mode)
+    if (a.h16 && (a.b_split || a.out_split || a.det || getenv("AG2V_HALO_MFMA32") != nullptr || getenv("AG2V_NO_HALO_H16") != nullptr)) return false;
     if (!a.b_split && getenv("AG2V_NO_HALO_F32IN") != nullptr) return false;       // (A/B aid: fp32 gathered tensors on the previous kernels)
     if (a.R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1 || a.pad_w != 1 || a.OH != a.H || a.OW != a.W) return false;
     if (a.C % 32 || a.W % 4 || (a.o_mul != 1 && a.o_mul != 0) || a.o_add_y || a.o_add_x) return false;

@@ -311,6 +311,9 @@ def test_full_size_deterministic_mode(device):
     # part ways at the 1e-6 level in front of netG.fc: the low-rank layout taps come from a small fp32 GEMM whose kernel (K order)
     # is chosen by its row count (120 x 22 object slots batched, 8 x 22 per pass), and the decoder amplifies that ~300x.  The bounds
     # are 5-10x tighter than the non-deterministic tests above (1e-2 / 5e-2).
+    # (Round 4: the halo-tile fp16-split kernel, which only launches of >= 384 tiles take, stays off in deterministic mode -- with it the
+    # batched pass's flows differ from the sequential passes' by 2.1e-6 of max and the random-init decoder turns that into 1.4e-2 of the
+    # generator gradient: what this test is there to catch.)
     assert errs['flows_pred'] <= 1e-6 and errs['boxes_pred'] <= 1e-6 and serr <= 1e-5, (errs, serr)
     assert errs['imgs_pred'] <= 2e-3, errs
     assert lerr <= 1e-5 and gerr[0] <= 5e-3 and gerr[1] <= 1e-3, (lerr, gerr)
