@@ -59,3 +59,54 @@ torch.cuda.synchronize()
 torch.cat, torch.stack = _cat, _stack
 for key, (n, mb) in sorted(sites.items(), key=lambda kv: -kv[1][1])[:25]:
     print('%9.1f MB %4d x  %-6s %s' % (mb, n, key[0], key[1]))
+
+# small fills / copies by call site (each is a ~7 us rocclr fill / copy kernel on the stream: ~770 per step)
+small = collections.defaultdict(lambda: [0, 0])
+_orig = {}
+
+
+def _site():
+    fr = [s for s in traceback.extract_stack()[:-2] if '/ag2video_amd/' in s.filename]
+    return '%s:%d' % (fr[-1].filename.split('/ag2video_amd/')[-1], fr[-1].lineno) if fr else '?'
+
+
+def _wrap_method(name):
+    orig = getattr(torch.Tensor, name)
+    _orig[name] = orig
+
+    def f(self, *a, **k):
+        if self.is_cuda:
+            rec = small[(name, _site())]
+            rec[0] += 1
+            rec[1] += self.numel()
+        return orig(self, *a, **k)
+    setattr(torch.Tensor, name, f)
+
+
+def _wrap_fn(name):
+    orig = getattr(torch, name)
+    _orig['torch.' + name] = orig
+
+    def f(*a, **k):
+        out = orig(*a, **k)
+        if torch.is_tensor(out) and out.is_cuda:
+            rec = small[(name, _site())]
+            rec[0] += 1
+            rec[1] += out.numel()
+        return out
+    setattr(torch, name, f)
+
+
+for nm in ('copy_', 'zero_', 'fill_'):
+    _wrap_method(nm)
+for nm in ('zeros', 'zeros_like', 'ones', 'full', 'tensor', 'clone'):
+    _wrap_fn(nm)
+ts.gd_step(clip)
+torch.cuda.synchronize()
+for nm in ('copy_', 'zero_', 'fill_'):
+    setattr(torch.Tensor, nm, _orig[nm])
+for nm in ('zeros', 'zeros_like', 'ones', 'full', 'tensor', 'clone'):
+    setattr(torch, nm, _orig['torch.' + nm])
+print('fills / copies per step by call site (calls, elements):')
+for key, (n, el) in sorted(small.items(), key=lambda kv: -kv[1][0])[:40]:
+    print('%5d x %12d el  %-10s %s' % (n, el, key[0], key[1]))
