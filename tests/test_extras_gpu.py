@@ -54,11 +54,13 @@ def test_vgg_loss_matches_reference_golden(prec, gold, device):
         assert abs(loss.item() - ref) <= 1e-3 * abs(ref), (loss.item(), ref)
         # d|a - b| is a sign function: a feature pair closer than the arithmetic's rounding flips its whole term, so single
         # elements are held to 3e-2 of the largest gradient (fp32: 2e-3 measured; bf16x3: 6e-2 -- which pairs flip varies with the
-        # summation order of split-K launches, 1 run in ~10 exceeded 3e-2) and the mean deviation to 2e-3 (bf16x3: 4e-3 -- the same flips:
-        # 1 run in 6 measured 2.4e-3 in round 4)
+        # summation order of split-K launches, 1 run in ~10 exceeded 3e-2) and the mean deviation to 2e-3.  bf16x3, 40 runs in one process
+        # (tools/debug_vgg_grad_spread.py): max deviation 2.13e-2 of the largest gradient in every run; mean deviation 3.05e-4 of the mean
+        # in 39 runs and 2.36e-3 in one (one flipped term); relative L2 2.9e-3 / 5.1e-3 -> bounds 6e-2, 1e-2, 2e-2
         rg, gg = gold['vgg.grad_x'], x.grad.cpu().numpy()
-        tol_max, tol_mean = (3e-2, 2e-3) if prec == 'fp32' else (6e-2, 4e-3)
+        tol_max, tol_mean = (3e-2, 2e-3) if prec == 'fp32' else (6e-2, 1e-2)
         assert np.abs(gg - rg).max() <= tol_max * np.abs(rg).max() and np.abs(gg - rg).mean() <= tol_mean * np.abs(rg).mean()
+        assert np.linalg.norm(gg - rg) <= 2e-2 * np.linalg.norm(rg)
     finally:
         ops.set_conv_precision(old)
 
