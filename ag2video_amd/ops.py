@@ -359,6 +359,7 @@ _SWAP_WIDE_WGRAD = os.environ.get('AG2V_NO_WIDE_SWAPPED_WGRAD') is None   # ... 
 # swapped GEMM: OFF -- on 256 x 256 maps its dword gathers lose to the GEMM (tools/fewrow_wgrad_bench.py: conv_img 3.17 vs 1.50 ms,
 # conv_flow 1.40 vs 1.26); the kernel serves the layers the swap does not cover (the discriminators' 4 x 4 last layer: 1.15 -> 0.35 ms)
 _FEWROW_WGRAD_DIRECT = os.environ.get('AG2V_DIRECT_FEW_WGRAD') is not None
+_PAD_WGRAD = os.environ.get('AG2V_NO_PADDED_WGRAD') is None                # odd-width stride-1 weight gradients on the 16-byte-load kernel via zero columns (A/B)
 _FEWIN_DGRAD = os.environ.get('AG2V_NO_FEWIN_DGRAD') is None              # data gradients of <= 4-row layers on the layout kernel's image path (A/B)
 _WSINK_CB = [None]   # graph-task id of the backward pass whose end-of-pass callback is queued (None: none; ids start at 0)
 
@@ -560,6 +561,18 @@ def _wgrad_swap_pays(mr, x_shape, dy_shape, K, R, S, stride, pad, x_split, dy_sp
     return True
 
 
+def _wgrad_pad_pays(mr, x_shape, dy_shape, K, R, S, stride, pad, x_split, dy_split):
+    """A stride-1 bf16x3 weight gradient on fp32 operands whose output rows are not multiples of 8 pixels, large enough for the two
+    padded copies to pay (see the call site)."""
+    N, C, H, W = x_shape
+    OH, OW = int(dy_shape[2]), int(dy_shape[3])
+    if not (_PAD_WGRAD and stride == 1 and OW % 8 != 0 and OW >= 16 and not x_split and not dy_split and _PRECISION[0] == 1 and pad <= 3):
+        return False
+    if (mr or _lib.query('ag2v_get_bf16x3_min_rows')) > K or K < 128 or C < 64:
+        return False
+    return (-OW % 8) * 5 <= OW and N * OH * OW >= 16384       # at most 20 % more columns
+
+
 def _conv_wgrad_swapped(mr, dy, x, out, K, R, S, pad, acc, groups, x_split, dy_split):
     """out (+)= the weight gradient [groups x] [K, C, R, S], computed as the swapped launch's [groups x] [C, K, R, S] (see above)."""
     C = x.shape[1]
@@ -679,6 +692,13 @@ class _Conv2d(torch.autograd.Function):
                     buf.copy_(t)
             elif _wgrad_swap_pays(mr, x.shape, dy.shape, K, R, S, stride, pad, ctx.x_split, dys):
                 _conv_wgrad_swapped(mr, dy, x, buf, K, R, S, pad, acc, 1, ctx.x_split, dys)
+            elif _wgrad_pad_pays(mr, x.shape, dy.shape, K, R, S, stride, pad, ctx.x_split, dys):
+                # stride-1 layers whose output rows are not whole runs of 8 pixels (the discriminators' 4 x 4 layers on 33 x 33 / 17 x 17
+                # maps) run their weight gradient on the 4-byte-load kernel (230 TF); with dy and x padded on the right by the same number
+                # of zero columns -- the padded dy columns contribute nothing, the padded x columns are the zero padding the real columns
+                # saw anyway -- the same sums run on the 16-byte-load kernel
+                extra = -dy.shape[3] % 8
+                _conv_wgrad_launch(mr, torch.nn.functional.pad(dy, (0, extra)), torch.nn.functional.pad(x, (0, extra)), buf, K, R, S, stride, pad, acc)
             else:
                 _conv_wgrad_launch(mr, dy, x, buf, K, R, S, stride, pad, acc, in_split=ctx.x_split, dy_split=dys)
         if has_bias and ctx.needs_input_grad[2]:

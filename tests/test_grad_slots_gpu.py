@@ -303,3 +303,31 @@ def test_stride_2_data_gradient_as_one_convolution(cfg, device):
         dx = torch.empty(N, C, H, W, device=device)
         ops._conv_dgrad_launch(32, dy, w, None, dx, 2, pad, 0, gscale=gs, group_n=1)
         assert float((dx - ref * gs.view(N, 1, 1, 1)).abs().max()) <= 3e-4 * sc
+
+
+@pytest.mark.parametrize("cfg", [(6, 128, 33, 33, 256, 4, 2), (4, 64, 17, 35, 128, 3, 1), (30, 256, 17, 17, 512, 4, 2)], ids=str)
+def test_odd_width_weight_gradient_through_zero_columns(cfg, device):
+    """conv2d backward of a stride-1 layer whose output rows are not whole runs of 8 pixels (the discriminators' 4 x 4 pad 2 layers on
+    33 x 33 / 17 x 17 maps, discriminator.py:368-379): ops._wgrad_pad_pays pads dy and x by the same zero columns so that the
+    16-byte-load weight-gradient kernel takes the launch.  Against fp64 autograd and the unpadded launch."""
+    from ag2video_amd import _lib, ops
+    N, C, H, W, K, R, pad = cfg
+    torch.manual_seed(31)
+    x = torch.randn(N, C, H, W, device=device)
+    OH, OW = H + 2 * pad - R + 1, W + 2 * pad - R + 1
+    dy = torch.randn(N, K, OH, OW, device=device)
+    w0 = torch.zeros(K, C, R, R, device=device, dtype=torch.float64, requires_grad=True)
+    y = torch.nn.functional.conv2d(x.double(), w0, None, 1, pad)
+    ref = torch.autograd.grad((y * dy.double()).sum(), w0)[0]
+    sc = float(ref.abs().max())
+    with ops.conv_precision('bf16x3'), torch.no_grad():
+        pays = ops._wgrad_pad_pays(48, x.shape, dy.shape, K, R, R, 1, pad, False, False)
+        assert pays == (OW >= 16 and N * OH * OW >= 16384 and (-OW % 8) * 5 <= OW)
+        plain = torch.empty(K, C, R, R, device=device)
+        ops._conv_wgrad_launch(48, dy, x, plain, K, R, R, 1, pad, 0)
+        extra = -OW % 8
+        padded = torch.empty(K, C, R, R, device=device)
+        ops._conv_wgrad_launch(48, torch.nn.functional.pad(dy, (0, extra)), torch.nn.functional.pad(x, (0, extra)), padded, K, R, R, 1, pad, 0)
+        assert b'_v_kernel' in _lib.query('ag2v_last_conv_kernel') or b'_vps_kernel' in _lib.query('ag2v_last_conv_kernel')
+        assert float((padded.double() - ref).abs().max()) <= 2e-4 * sc
+        assert float((padded - plain).abs().max()) <= 2e-5 * sc
