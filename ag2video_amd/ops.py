@@ -668,6 +668,10 @@ class _Conv2d(torch.autograd.Function):
             G = torch.empty((T,) + tuple(w.shape), device=dy.device, dtype=torch.float32)
             if _wgrad_swap_pays(mr, x.shape, dy.shape, K, R, S, stride, pad, ctx.x_split, dys):
                 _conv_wgrad_swapped(mr, dy, x, G, K, R, S, pad, 0, T, ctx.x_split, dys)
+            elif _wgrad_pad_pays(mr, x.shape, dy.shape, K, R, S, stride, pad, ctx.x_split, dys):      # (see the plain branch below)
+                extra = -dy.shape[3] % 8
+                _conv_wgrad_launch(mr, torch.nn.functional.pad(dy, (0, extra)), torch.nn.functional.pad(x, (0, extra)), G, K, R, S, stride, pad, 0,
+                                   groups=T)
             else:
                 _conv_wgrad_launch(mr, dy, x, G, K, R, S, stride, pad, 0, groups=T, in_split=ctx.x_split, dy_split=dys)
             buf, acc, dw = _wsink_take(ctx.wkey, w) if ctx.needs_input_grad[1] else (torch.empty_like(w), 0, None)
