@@ -18,6 +18,9 @@ _SIGS = {
     'ag2v_last_conv_kernel': (c_char_p, []),
     'ag2v_set_bf16x3_min_rows': (c_int, [c_int]),
     'ag2v_get_bf16x3_min_rows': (c_int, []),
+    'ag2v_debug_hold_cus': (c_int, [c_int, c_float, _P]),
+    'ag2v_halo_reload_env': (c_int, []),
+    'ag2v_halo_min_tiles': (c_int, []),
     'ag2v_conv2d_workspace_floats': (c_size_t, [c_int] * 4),
     'ag2v_conv2d_fwd': (c_int, [_P, _P, _P, _P, _P] + [c_int] * 9 + [_P, _P]),
     'ag2v_conv2d_dgrad': (c_int, [_P, _P, _P] + [c_int] * 9 + [_P, _P]),
@@ -45,7 +48,9 @@ _SIGS = {
     'ag2v_norm_apply_gs': (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
     'ag2v_norm_bwd_g': (c_int, [c_int] + [_P] * 11 + [c_int, c_int, c_int, c_int, c_float, _P, _P]),
     'ag2v_norm_bwd_pyr': (c_int, [_P, _P, _P, _P, c_int] + [_P] * 7 + [c_int] * 5 + [c_float, _P, _P]),
+    'ag2v_norm_bwd_pyr_p': (c_int, [_P, _P, _P, _P, c_int] + [_P] * 7 + [c_int] * 5 + [c_float, _P, c_int, c_float, _P]),
     'ag2v_norm_bwd_gs': (c_int, [c_int] + [_P] * 12 + [c_int, c_int, c_int, c_int, c_float, _P, c_int, _P]),
+    'ag2v_norm_bwd_gs_p': (c_int, [c_int] + [_P] * 12 + [c_int, c_int, c_int, c_int, c_float, _P, c_int, c_int, c_float, _P]),
     'ag2v_norm_bwd_reduce_g': (c_int, [c_int] + [_P] * 7 + [c_int, c_int, c_int, c_int, c_float, _P, _P]),
     'ag2v_norm_bwd_apply_g': (c_int, [c_int] + [_P] * 8 + [c_float, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     'ag2v_spade_pair_supported': (c_int, [c_int, c_int, c_int]),
@@ -55,6 +60,7 @@ _SIGS = {
     'ag2v_spade_pair_apply_s': (c_int, [_P] * 7 + [c_int] * 6 + [c_float, c_float, c_int, c_int, _P]),
     'ag2v_spade_pair_bwd': (c_int, [_P] * 13 + [c_int] * 6 + [c_float, c_float, _P, _P]),
     'ag2v_spade_pair_bwd_s': (c_int, [_P] * 13 + [c_int] * 6 + [c_float, c_float, _P, c_int, _P]),
+    'ag2v_spade_pair_bwd_sp': (c_int, [_P] * 13 + [c_int] * 6 + [c_float, c_float, _P, c_int, c_int, c_float, _P]),
     'ag2v_instnorm_lrelu_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P]),
     'ag2v_instnorm_lrelu_bwd': (c_int, [_P] * 6 + [c_int, c_int, c_float, _P]),
     'ag2v_layout_render_fwd': (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [_P]),

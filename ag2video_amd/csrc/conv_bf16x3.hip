@@ -1365,6 +1365,8 @@ static int pick_splits(int tiles, int nk, int max_splits) {
 }
 
 int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed) {
+    if (a.o_mul == 0) { a.o_mul = 1; a.o_add_y = 0; a.o_add_x = 0; a.o_H = a.OH; a.o_W = a.OW; }      // (direct callers: the dense output)
+    if (a.out_nstride == 0) a.out_nstride = (long long)a.M * a.o_H * a.o_W;
     if (igemm_halo_ok(a)) return launch_igemm_halo(a, st);       // 3x3 stride-1 on split words: halo tiles by LDS-DMA (conv_halo.hip)
     // 256 x 128 tile when there are enough rows and it pads no more rows than the 128 x 256 tile does (384 rows: three 128-row
     // tiles, not two 256-row ones)

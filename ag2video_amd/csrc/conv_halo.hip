@@ -830,23 +830,46 @@ static bool halo_geometry(int BN, int OH, int OW, int& TW, int& TH) {
     return false;
 }
 
+
+// ---- diagnostic / A-B switches of the launchers, read from the environment ONCE (not per launch: getenv beside a concurrent putenv is
+// not thread-safe, and the autograd thread launches kernels while the main thread may be editing os.environ -- ADVICE r04) and again
+// only when ag2v_halo_reload_env() is called (tests and tools/halo_bench.py call it after changing the variables, with no launch in
+// flight).  None of them changes results beyond the summation order of the kernel family selected.
+struct HaloSwitches { int no_halo, tall, mfma32, no_h16, no_f32in, min_tiles; };
+static HaloSwitches read_halo_switches() {
+    HaloSwitches h;
+    h.no_halo = getenv("AG2V_NO_HALO") != nullptr;
+    h.tall = getenv("AG2V_HALO_TALL") != nullptr;
+    h.mfma32 = getenv("AG2V_HALO_MFMA32") != nullptr;
+    h.no_h16 = getenv("AG2V_NO_HALO_H16") != nullptr;
+    h.no_f32in = getenv("AG2V_NO_HALO_F32IN") != nullptr;
+    const char* mt = getenv("AG2V_HALO_MIN_TILES");                 // (tests run small shapes through these kernels)
+    h.min_tiles = mt ? atoi(mt) : 384;                              // small maps: the split-K kernels fill the chip better
+    return h;
+}
+static HaloSwitches g_halo_sw = read_halo_switches();
+extern "C" int ag2v_halo_reload_env(void) {
+    g_halo_sw = read_halo_switches();
+    return AG2V_OK;
+}
+extern "C" int ag2v_halo_min_tiles(void) { return g_halo_sw.min_tiles; }
+
 // 256-row tile (128 pixels) when there are enough rows and it pads no more rows than the 128-row tile (256 pixels) does
 static bool halo_tall(int M) {
     // 128-row tiles (256 pixels as 2 x 128: 2x row halo, 8 KB of weights per k-step) beat the 256-row tile (128 x 1 pixels: 3x row halo)
     // on every shape measured (+1.9 % at C = 384, +4.5 % at C = 128): the 256-row form is kept for A/B runs (AG2V_HALO_TALL)
-    if (getenv("AG2V_HALO_TALL") == nullptr) return false;
+    if (!g_halo_sw.tall) return false;
     return M >= 192 && ceil_div(M, 256) * 256 <= ceil_div(M, 128) * 128;
 }
 
 // Can this launch (as the callers of launch_igemm_bf16x3 describe it) run on the halo kernels?
 bool igemm_halo_ok(const ConvArgs& a) {
-    // (read per call, not cached: tools/halo_bench.py and the tests switch kernels inside one process)
-    if (getenv("AG2V_NO_HALO") != nullptr || !a.tap_major || a.f32 || a.b_bytes == 0) return false;
+    if (g_halo_sw.no_halo || !a.tap_major || a.f32 || a.b_bytes == 0) return false;
     // fp16 split: fp32 gathered tensor, plain output, the 16x16x32 form only (AG2V_NO_HALO_H16: A/B aid)
     // (not in deterministic mode: there the flow network keeps ONE kernel family for every batch size, so that the frame-batched and
     // the sequential passes agree to the last bit in their flows -- tests/test_fullsize_gpu.py::test_full_size_deterministic_mode)
-    if (a.h16 && (a.b_split || a.out_split || a.det || getenv("AG2V_HALO_MFMA32") != nullptr || getenv("AG2V_NO_HALO_H16") != nullptr)) return false;
-    if (!a.b_split && getenv("AG2V_NO_HALO_F32IN") != nullptr) return false;       // (A/B aid: fp32 gathered tensors on the previous kernels)
+    if (a.h16 && (a.b_split || a.out_split || a.det || g_halo_sw.mfma32 || g_halo_sw.no_h16)) return false;
+    if (!a.b_split && g_halo_sw.no_f32in) return false;       // (A/B aid: fp32 gathered tensors on the previous kernels)
     if (a.R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1 || a.pad_w != 1 || a.OH != a.H || a.OW != a.W) return false;
     if (a.C % 32 || a.W % 4 || (a.o_mul != 1 && a.o_mul != 0) || a.o_add_y || a.o_add_x) return false;
     if ((a.o_H && a.o_H != a.OH) || (a.o_W && a.o_W != a.OW)) return false;
@@ -856,11 +879,11 @@ bool igemm_halo_ok(const ConvArgs& a) {
     int tw, th;
     if (!halo_geometry(bn, a.OH, a.OW, tw, th)) return false;
     const long long tiles = (long long)ceil_div(a.M, bm) * (a.NG / bn);
-    const char* mt = getenv("AG2V_HALO_MIN_TILES");                 // (tests run small shapes through these kernels)
-    return tiles >= (mt ? atoi(mt) : 384);                          // small maps: the split-K kernels fill the chip better
+    return tiles >= g_halo_sw.min_tiles;
 }
 
 int launch_igemm_halo(ConvArgs& a, hipStream_t st) {
+    if (a.out_nstride == 0) a.out_nstride = (long long)a.M * a.OH * a.OW;       // (direct callers: the dense output)
     const bool tall = halo_tall(a.M);
     const int bn = tall ? 128 : 256, bm = tall ? 256 : (a.M <= 64 ? 64 : 128);
     int tw, th;
@@ -879,7 +902,7 @@ int launch_igemm_halo(ConvArgs& a, hipStream_t st) {
     }
     const long long ntiles = (long long)a.tiles_m * a.tiles_n;
     const dim3 grid((unsigned)(ntiles < n_cu ? ntiles : n_cu));
-    const bool mf16 = getenv("AG2V_HALO_MFMA32") == nullptr;          // (A/B aid: the 32x32x16 form)
+    const bool mf16 = !g_halo_sw.mfma32;          // (A/B aid: the 32x32x16 form)
 #define AG2V_HALO(WM_, WN_, EM_, TW_, TH_)                                                                                       \
     do {                                                                                                                         \
         if (a.h16) {                                                                                                             \

@@ -472,34 +472,51 @@ static int conv_out_dim(int in, int k, int stride, int pad) { return (in + 2 * p
 
 // Arithmetic of the 128/256-row igemm / wgrad tiles: 1 = bf16x3 split (fp32-level accuracy, ~1e-5 relative per product, at up to
 // 16/3 of the fp32 MFMA rate), 0 = exact fp32 MFMA (bit-for-bit fmaf chains); GEMMs with fewer rows than min_rows stay exact.
-// Both are PER-CALL arguments (ag2v_conv_opts of the *_ex entry points).  The process-wide values below are only the defaults a
-// call without options (or with precision < 0 / min_rows <= 0) falls back to: AG2V_CONV_PRECISION=fp32|bf16x3 and
-// AG2V_BF16X3_MIN_M read once, or ag2v_set_conv_precision() / ag2v_set_bf16x3_min_rows().
-static int g_conv_precision = -1;
-static int conv_precision() {
-    if (g_conv_precision < 0) {
-        const char* e = getenv("AG2V_CONV_PRECISION");
-        g_conv_precision = (e && !strcmp(e, "fp32")) ? 0 : 1;
-    }
-    return g_conv_precision;
+// Both are PER-CALL arguments (ag2v_conv_opts of the *_ex entry points): a call that names them reads nothing but its arguments.
+// A call that does NOT name them (no options, precision < 0, min_rows <= 0) takes the defaults of the DEVICE it runs on: a per-device
+// record (no global mutable state beyond a per-device handle), initialised once from AG2V_CONV_PRECISION=fp32|bf16x3 /
+// AG2V_BF16X3_MIN_M and changed only by the deprecated ag2v_set_* shims for the calling thread's current device.  The Python host
+// never relies on them: ops.py passes both fields with every call.
+#include <atomic>
+static constexpr int kMaxDevices = 64;
+struct DeviceDefaults { std::atomic<int> precision{-1}, min_rows{-1}; };
+static DeviceDefaults g_dev_defaults[kMaxDevices];
+static DeviceDefaults& device_defaults() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+    return g_dev_defaults[dev];
 }
+static int conv_precision() {
+    DeviceDefaults& d = device_defaults();
+    int v = d.precision.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("AG2V_CONV_PRECISION");
+        v = (e && !strcmp(e, "fp32")) ? 0 : 1;
+        d.precision.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+/* deprecated: pass ag2v_conv_opts::precision */
 extern "C" int ag2v_set_conv_precision(int mode) {
     if (mode != 0 && mode != 1) return AG2V_EINVAL;
-    g_conv_precision = mode;
+    device_defaults().precision.store(mode, std::memory_order_relaxed);
     return AG2V_OK;
 }
 extern "C" int ag2v_get_conv_precision(void) { return conv_precision(); }
-static int g_bf16x3_min_rows = -1;
 static int bf16x3_min_rows() {
-    if (g_bf16x3_min_rows < 0) {
+    DeviceDefaults& d = device_defaults();
+    int v = d.min_rows.load(std::memory_order_relaxed);
+    if (v < 0) {
         const char* e = getenv("AG2V_BF16X3_MIN_M");
-        g_bf16x3_min_rows = (e && atoi(e) > 0) ? atoi(e) : 128;
+        v = (e && atoi(e) > 0) ? atoi(e) : 128;
+        d.min_rows.store(v, std::memory_order_relaxed);
     }
-    return g_bf16x3_min_rows;
+    return v;
 }
+/* deprecated: pass ag2v_conv_opts::min_rows */
 extern "C" int ag2v_set_bf16x3_min_rows(int rows) {
     if (rows < 1) return AG2V_EINVAL;
-    g_bf16x3_min_rows = rows;
+    device_defaults().min_rows.store(rows, std::memory_order_relaxed);
     return AG2V_OK;
 }
 extern "C" int ag2v_get_bf16x3_min_rows(void) { return bf16x3_min_rows(); }

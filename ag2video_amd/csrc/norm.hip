@@ -882,22 +882,35 @@ static int norm_bwd_launch(int mode, bool do_reduce, bool do_apply, const float*
 // from `sums`).
 // mode 0 with y == NULL: the LeakyReLU branch of every element is recomputed from x, w and `bias` (the affine pair the forward
 // pass applied: y = lrelu(xhat w + bias)) instead of being read from the forward output.
+// _p ("phased"): phase 0 = both passes (ag2v_norm_bwd_gs); 1 = the reduce pass only (sums written); 2 = the apply pass only (sums read).
+// Data-parallel SYNCHRONISED batch norm (sync_batchnorm/batchnorm.py:105-126) runs 1, all-reduces columns 0 / 1 of sums[N / Ng, C, 4]
+// over the ranks, then 2 with inv_count = 1 / (elements per (group, channel) over ALL ranks); inv_count <= 0 = this process's own count.
+extern "C" int ag2v_norm_bwd_gs_p(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* w,
+                                  const float* bias, const float* mean, const float* invstd, float* dx, float* dgamma, float* dbeta,
+                                  float* sums, int N, int C, int HW, int Ng, float slope, float* workspace, int dgb_split, int phase,
+                                  float inv_count, void* stream) {
+    if (Ng <= 0 || HW <= 0 || phase < 0 || phase > 2) return AG2V_EINVAL;
+    if (!(inv_count > 0.f)) inv_count = 1.0f / ((float)Ng * (float)HW);
+    return norm_bwd_launch(mode, phase != 2, phase != 1, dy, y, x, gamma, w, mean, invstd, dx, dgamma, dbeta, sums, N, C, HW, Ng, slope,
+                           inv_count, workspace, (hipStream_t)stream, dgb_split, bias, mode == 0 && y == nullptr);
+}
 extern "C" int ag2v_norm_bwd_gs(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* w,
                                 const float* bias, const float* mean, const float* invstd, float* dx, float* dgamma, float* dbeta,
                                 float* sums, int N, int C, int HW, int Ng, float slope, float* workspace, int dgb_split, void* stream) {
-    if (Ng <= 0 || HW <= 0) return AG2V_EINVAL;
-    return norm_bwd_launch(mode, true, true, dy, y, x, gamma, w, mean, invstd, dx, dgamma, dbeta, sums, N, C, HW, Ng, slope,
-                           1.0f / ((float)Ng * (float)HW), workspace, (hipStream_t)stream, dgb_split, bias, mode == 0 && y == nullptr);
+    return ag2v_norm_bwd_gs_p(mode, dy, y, x, gamma, w, bias, mean, invstd, dx, dgamma, dbeta, sums, N, C, HW, Ng, slope, workspace,
+                              dgb_split, 0, 0.f, stream);
 }
 // Backward of y = lrelu(batch_norm_affine(x)) (mode 0 of ag2v_norm_bwd_gs, the activation branch recomputed from x) whose output was
 // read directly AND through nearest-neighbour down-samplings (ag2v_nearest_resize_fwd to hs[l] x ws[l]): the gradient
 // g_full (nullable) + sum_l scatter(g_levels[l]) is formed while loading -- no materialised sum (ag2v_nearest_pyramid_bwd) in between.
 // W % 4 == 0, 16-byte aligned tensors, H % hs[l] == 0, W % ws[l] == 0, at most 8 levels.
-extern "C" int ag2v_norm_bwd_pyr(const float* g_full, const float* const* g_levels, const int* hs, const int* ws, int n_levels,
-                                 const float* x, const float* w, const float* bias, const float* mean, const float* invstd, float* dx,
-                                 float* sums, int N, int C, int H, int W, int Ng, float slope, float* workspace, void* stream) {
+extern "C" int ag2v_norm_bwd_pyr_p(const float* g_full, const float* const* g_levels, const int* hs, const int* ws, int n_levels,
+                                   const float* x, const float* w, const float* bias, const float* mean, const float* invstd, float* dx,
+                                   float* sums, int N, int C, int H, int W, int Ng, float slope, float* workspace, int phase,
+                                   float inv_count_arg, void* stream) {
     if (!x || !mean || !invstd || !dx || !sums || !workspace || N <= 0 || C <= 0 || H <= 0 || W <= 0 || (W & 3) || Ng <= 0 || N % Ng)
         return AG2V_EINVAL;
+    if (phase < 0 || phase > 2) return AG2V_EINVAL;
     if (n_levels < 0 || n_levels > 8 || (n_levels && (!g_levels || !hs || !ws))) return AG2V_EINVAL;
     const int HW = H * W;
     if (!vec_ok(HW, g_full, x, dx)) return AG2V_EINVAL;
@@ -919,16 +932,25 @@ extern "C" int ag2v_norm_bwd_pyr(const float* g_full, const float* const* g_leve
     if (nblk >= (1LL << 31)) return AG2V_EINVAL;
     dim3 g((unsigned)nblk), t(256);
     const int GC = (N / Ng) * C;
-    const float inv_count = 1.0f / ((float)Ng * (float)HW);
+    const float inv_count = inv_count_arg > 0.f ? inv_count_arg : 1.0f / ((float)Ng * (float)HW);
     const int cpb = reduce_chunks_per_block(N * C, nchunk);
     const int nchunk_r = ceil_div(nchunk, cpb);
-    hipLaunchKernelGGL((norm_bwd_reduce_kernel<0, true, true>), dim3((unsigned)((long long)N * C * nchunk_r)), t, 0, st, g_full,
-                       (const float*)nullptr, x, (const float*)nullptr, mean, invstd, workspace, Ng, C, HW, nchunk_r, slope, 0LL, w, bias, cpb, lv);
-    hipLaunchKernelGGL(pair_sum_finalize_kernel, dim3(ceil_div(GC, 64)), dim3(64), 0, st, workspace, GC, Ng * nchunk_r, sums);
-    hipLaunchKernelGGL((norm_bwd_apply_kernel<0, true, true>), g, t, 0, st, g_full, (const float*)nullptr, x, (const float*)nullptr, w, mean,
-                       invstd, sums, dx, (float*)nullptr, (float*)nullptr, C, HW, nchunk, inv_count, slope, 0LL, Ng, 0, bias, -1LL, lv);
+    if (phase != 2) {
+        hipLaunchKernelGGL((norm_bwd_reduce_kernel<0, true, true>), dim3((unsigned)((long long)N * C * nchunk_r)), t, 0, st, g_full,
+                           (const float*)nullptr, x, (const float*)nullptr, mean, invstd, workspace, Ng, C, HW, nchunk_r, slope, 0LL, w, bias, cpb, lv);
+        hipLaunchKernelGGL(pair_sum_finalize_kernel, dim3(ceil_div(GC, 64)), dim3(64), 0, st, workspace, GC, Ng * nchunk_r, sums);
+    }
+    if (phase != 1)
+        hipLaunchKernelGGL((norm_bwd_apply_kernel<0, true, true>), g, t, 0, st, g_full, (const float*)nullptr, x, (const float*)nullptr, w, mean,
+                           invstd, sums, dx, (float*)nullptr, (float*)nullptr, C, HW, nchunk, inv_count, slope, 0LL, Ng, 0, bias, -1LL, lv);
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
+}
+extern "C" int ag2v_norm_bwd_pyr(const float* g_full, const float* const* g_levels, const int* hs, const int* ws, int n_levels,
+                                 const float* x, const float* w, const float* bias, const float* mean, const float* invstd, float* dx,
+                                 float* sums, int N, int C, int H, int W, int Ng, float slope, float* workspace, void* stream) {
+    return ag2v_norm_bwd_pyr_p(g_full, g_levels, hs, ws, n_levels, x, w, bias, mean, invstd, dx, sums, N, C, H, W, Ng, slope, workspace, 0,
+                               0.f, stream);
 }
 extern "C" int ag2v_norm_bwd_g(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* w,
                                const float* mean, const float* invstd, float* dx, float* dgamma, float* dbeta, float* sums,
@@ -1004,10 +1026,12 @@ extern "C" int ag2v_spade_pair_apply(const float* xs, const float* mean, const f
     return ag2v_spade_pair_apply_s(xs, mean, invstd, gb0, gb1, y0, y1, N, C, H, W, up, Ng, slope0, slope1, 0, 0, stream);
 }
 // sums [N / Ng, C, 8] = per norm k: (sum dxhat_k, sum dxhat_k xhat, sum dbeta_k, sum dgamma_k); dxs [N, C, H/up, W/up]; dgb0 / dgb1 like gb.
-extern "C" int ag2v_spade_pair_bwd_s(const float* dy0, const float* y0, const float* dy1, const float* y1, const float* xs, const float* gb0,
-                                   const float* gb1, const float* mean, const float* invstd, float* dxs, float* dgb0, float* dgb1,
-                                   float* sums, int N, int C, int H, int W, int up, int Ng, float slope0, float slope1, float* workspace,
-                                   int dgb_split, void* stream) {
+// _sp: phases as ag2v_norm_bwd_gs_p (synchronised batch norm all-reduces columns 0, 1, 4, 5 of sums[N / Ng, C, 8] between them)
+extern "C" int ag2v_spade_pair_bwd_sp(const float* dy0, const float* y0, const float* dy1, const float* y1, const float* xs, const float* gb0,
+                                    const float* gb1, const float* mean, const float* invstd, float* dxs, float* dgb0, float* dgb1,
+                                    float* sums, int N, int C, int H, int W, int up, int Ng, float slope0, float slope1, float* workspace,
+                                    int dgb_split, int phase, float inv_count_arg, void* stream) {
+    if (phase < 0 || phase > 2) return AG2V_EINVAL;
     if (!dy0 || !dy1 || !xs || !gb0 || !gb1 || !mean || !invstd || !dxs || !dgb0 || !dgb1 || !sums || !workspace) return AG2V_EINVAL;
     if (N <= 0 || C <= 0 || Ng <= 0 || N % Ng != 0 || (slope0 != 1.f && !y0) || (slope1 != 1.f && !y1)) return AG2V_EINVAL;
     if (!ag2v_spade_pair_supported(H, W, up) || !vec_ok(H * W, dy0, dy1, y0, y1, gb0, gb1) || !vec_ok(H * W, dgb0, dgb1, xs, dxs)) return AG2V_EINVAL;
@@ -1021,20 +1045,30 @@ extern "C" int ag2v_spade_pair_bwd_s(const float* dy0, const float* y0, const fl
     if (nblk >= (1LL << 31)) return AG2V_EINVAL;
     dim3 g((unsigned)nblk), t(256);
     const int GC = (N / Ng) * C;
-    const float inv_count = 1.0f / ((float)Ng * (float)HW);
+    const float inv_count = inv_count_arg > 0.f ? inv_count_arg : 1.0f / ((float)Ng * (float)HW);
     const int cpb = reduce_chunks_per_block(N * C, nchunk);
     const int nchunk_r = ceil_div(nchunk, cpb);
     dim3 gr((unsigned)((long long)N * C * nchunk_r));
 #define PAIR_BWD(U)                                                                                                                  \
-    hipLaunchKernelGGL(spade_pair_bwd_reduce_kernel<U>, gr, t, 0, st, dy0, y0, dy1, y1, xs, gb0, gb1, mean, invstd, workspace, Ng, C, HW, \
-                       W, nchunk_r, slope0, slope1, gcompact, cpb);                                                                  \
-    hipLaunchKernelGGL(multi_sum_finalize_kernel, dim3(ceil_div(GC * 8, 64)), dim3(64), 0, st, workspace, GC, Ng* nchunk_r, 8, sums); \
-    hipLaunchKernelGGL(spade_pair_bwd_apply_kernel<U>, g, t, 0, st, dy0, y0, dy1, y1, xs, gb0, gb1, mean, invstd, sums, dxs, dgb0, dgb1, \
-                       C, HW, W, nchunk, inv_count, slope0, slope1, Ng, dgb_split ? 1 : 0, gcompact);
+    if (phase != 2) {                                                                                                                \
+        hipLaunchKernelGGL(spade_pair_bwd_reduce_kernel<U>, gr, t, 0, st, dy0, y0, dy1, y1, xs, gb0, gb1, mean, invstd, workspace, Ng, C, HW, \
+                           W, nchunk_r, slope0, slope1, gcompact, cpb);                                                              \
+        hipLaunchKernelGGL(multi_sum_finalize_kernel, dim3(ceil_div(GC * 8, 64)), dim3(64), 0, st, workspace, GC, Ng* nchunk_r, 8, sums); \
+    }                                                                                                                                \
+    if (phase != 1)                                                                                                                  \
+        hipLaunchKernelGGL(spade_pair_bwd_apply_kernel<U>, g, t, 0, st, dy0, y0, dy1, y1, xs, gb0, gb1, mean, invstd, sums, dxs, dgb0, dgb1, \
+                           C, HW, W, nchunk, inv_count, slope0, slope1, Ng, dgb_split ? 1 : 0, gcompact);
     if (up == 1) { PAIR_BWD(1) } else { PAIR_BWD(2) }
 #undef PAIR_BWD
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
+}
+extern "C" int ag2v_spade_pair_bwd_s(const float* dy0, const float* y0, const float* dy1, const float* y1, const float* xs, const float* gb0,
+                                   const float* gb1, const float* mean, const float* invstd, float* dxs, float* dgb0, float* dgb1,
+                                   float* sums, int N, int C, int H, int W, int up, int Ng, float slope0, float slope1, float* workspace,
+                                   int dgb_split, void* stream) {
+    return ag2v_spade_pair_bwd_sp(dy0, y0, dy1, y1, xs, gb0, gb1, mean, invstd, dxs, dgb0, dgb1, sums, N, C, H, W, up, Ng, slope0, slope1,
+                                  workspace, dgb_split, 0, 0.f, stream);
 }
 extern "C" int ag2v_spade_pair_bwd(const float* dy0, const float* y0, const float* dy1, const float* y1, const float* xs, const float* gb0,
                                    const float* gb1, const float* mean, const float* invstd, float* dxs, float* dgb0, float* dgb1,

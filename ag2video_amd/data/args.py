@@ -101,7 +101,7 @@ def build_parser():
     # build-specific (not in the reference): synthetic data shape for scripts/train
     a('--synthetic_objects', default='5,10', type=int_tuple, help='min,max real objects per clip')
     a('--seed', default=1234, type=int)
-    a('--sync_bn', default=0, type=int, help='1: batch-norm statistics over the global batch (all ranks) with the reference\'s multi-device formula')
+    a('--sync_bn', default=-1, type=int, help='batch-norm statistics over the global batch (all ranks) with the reference\'s multi-device formula (sync_batchnorm/batchnorm.py:78-93): 1 on, 0 off (per-rank statistics, F.batch_norm formula), -1 (default) = what the reference does at this world size: on when more than one rank runs, off on a single device')
     a('--data_root', default=None, type=str, help='CATER directory (scenes/*.json, videos/<id>/*.png) or, with --dataset smth_else, a Something-Else '
       'directory (offical_release_boxes/{objs_mapping.json, boxes_by_video_id/<id>/boxes.pkl}, frames/...); default: synthetic clips')
     a('--train_list', default=None, type=str, help='CATER: split list (default <data_root>/lists/train.txt); smth_else: label table (default <data_root>/train.csv)')

@@ -26,6 +26,10 @@ def is_dist():
     return dist.get_world_size() > 1 or os.environ.get('AG2V_FORCE_DIST') == '1' 
 
 
+def world_size():
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
 def init_from_env(backend=None):
     """Initialise torch.distributed from torchrun's environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))

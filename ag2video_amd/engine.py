@@ -23,7 +23,10 @@ class TrainStep(object):
         the same two-phase gradient all-reduce as the GPU path); default FusedAdam on the HIP device."""
         self.opt = opt
         self.device = device
-        dist_utils.set_sync_bn(getattr(opt, 'sync_bn', 0))
+        # batch-norm statistics: the reference synchronises them over the devices of a DataParallel run and uses F.batch_norm on a single
+        # device (sync_batchnorm/batchnorm.py:63-93); --sync_bn -1 (the default) follows it per world size
+        sb = int(getattr(opt, 'sync_bn', -1))
+        dist_utils.set_sync_bn(sb > 0 or (sb < 0 and dist_utils.is_dist() and dist_utils.world_size() > 1))
         if getattr(opt, 'lean_tape', 0):
             ops.set_lean_tape(True)
         self.model = AG2VideoModel(opt, device)

@@ -55,7 +55,7 @@ class SPADEResnetBlock(nn.Module):
         ss = self.learned_shortcut and takes_split(self.conv_s, x.shape[1])
         s1 = takes_split(self.conv_1, self.conv_0.out_channels)
         from .... import distributed as D
-        if (self.learned_shortcut and self.training and not D.sync_bn() and ops.spade_pair_supported(H, W, up)
+        if (self.learned_shortcut and self.training and ops.spade_pair_supported(H, W, up)
                 and os.environ.get('AG2V_NO_SPADE_PAIR') is None):
             # norm_0 and norm_s modulate the SAME tensor: one statistics pass, one read of x for both outputs, one summed input
             # gradient -- and with up = 2 the upsampled tensor never exists (ops.spade_pair)

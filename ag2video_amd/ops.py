@@ -53,6 +53,46 @@ def _ptr_off(t, elems):
     return _P(t.data_ptr() + 4 * elems)
 
 
+# ---- synchronised batch norm on every norm path (reference: sync_batchnorm/batchnorm.py:80-93 forward, :105-126 reduce / broadcast,
+# :128-145 _compute_mean_std).  Forward: the local (mean, inv_std) of a statistics kernel -> ONE all-reduce of [sum, sum of squares]
+# -> the reference's multi-device formula (inv_std = clamp(biased var, eps)^-1/2, running_var fed with the unbiased variance).
+# Backward: every fused backward is a reduce pass and an apply pass (the *_p entry points); between them (sum dxhat, sum dxhat xhat)
+# are summed over the ranks, everything else in `sums` (affine / bias gradients) stays per rank.
+def _sync_world():
+    from . import distributed as D
+    return D.sync_bn()
+
+
+@torch.no_grad()
+def _sync_combine(mean_l, invstd_l, groups, C, count, eps, momentum, running_pairs):
+    """Local statistics [groups * C] over `count` elements per (group, channel) -> (global mean, inv_std, world); the running buffers
+    of `running_pairs` get the per-group updates, in order, in closed form."""
+    from . import distributed as D
+    var_l = invstd_l.pow(-2) - eps
+    mean, invstd, unb, cnt = D.combine_bn_stats(mean_l.view(groups, C), var_l.view(groups, C), count, eps)
+    world = int(round(cnt / count))
+    k = torch.arange(groups - 1, -1, -1, device=mean_l.device, dtype=torch.float32)
+    coef = momentum * (1.0 - momentum) ** k                                   # weight of group g in the final value
+    keep = (1.0 - momentum) ** groups
+    for rm, rv in running_pairs:
+        if rm is not None:
+            rm.mul_(keep).add_((coef.view(-1, 1) * mean).sum(0))
+            rv.mul_(keep).add_((coef.view(-1, 1) * unb).sum(0))
+    return mean.reshape(-1).contiguous(), invstd.reshape(-1).contiguous(), world
+
+
+@torch.no_grad()
+def _sync_bwd_sums(sums, n_norms):
+    """sums [G, C, 4 * n_norms] of a reduce pass: columns 4 k + (0, 1) summed over the ranks in place; returns this rank's own copy."""
+    from . import distributed as D
+    local = sums.clone()
+    idx = [4 * k + i for k in range(n_norms) for i in (0, 1)]
+    part = sums[..., idx].contiguous()
+    D.sum_over_ranks_(part)
+    sums[..., idx] = part
+    return local
+
+
 _PRECISIONS = {'fp32': 0, 'bf16x3': 1}
 _PRECISION = [_PRECISIONS.get(os.environ.get('AG2V_CONV_PRECISION', 'bf16x3'), 1)]
 
@@ -165,6 +205,9 @@ def param_epoch():
 # 64-channel full-resolution tail feeds the warp, which amplifies its 1e-5 split error ~100x on the reference golden toy
 # (imgs_pred 1.3e-3 against a 1e-3 tolerance), everywhere else the error stays at 1e-5.
 _MIN_ROWS_STACK = []
+# the row threshold of a convolution created outside any bf16x3_min_rows block.  Host-side: it travels with every call
+# (ag2v_conv_opts::min_rows), the library's per-device default is never consulted
+DEFAULT_MIN_ROWS = max(int(os.environ.get('AG2V_BF16X3_MIN_M', '0') or 0), 0) or 128
 
 
 class bf16x3_min_rows(object):
@@ -228,9 +271,9 @@ def _conv_label(mode, M, min_rows=None):
 
 def _conv_launch(min_rows, name, label, flops, *args, shape=None, gscale=None, group_n=1, in_split=False, dy_split=False,
                  out_split=False, det_ws_query=None, precision=None, out_nstride=0):
-    """One ag2v_conv2d_*_ex call.  Arithmetic (precision, bf16x3 row threshold: ``min_rows``, None = library default) and the
+    """One ag2v_conv2d_*_ex call.  Arithmetic (precision, bf16x3 row threshold: ``min_rows``, None = DEFAULT_MIN_ROWS) and the
     per-sample-group output scale travel as per-call options (ag2v_conv_opts): no process-wide switch is touched."""
-    opts = _lib.ConvOpts(_PRECISION[0] if precision is None else int(precision), int(min_rows) if min_rows else 0, None if gscale is None else gscale.data_ptr(),
+    opts = _lib.ConvOpts(_PRECISION[0] if precision is None else int(precision), int(min_rows) if min_rows else DEFAULT_MIN_ROWS, None if gscale is None else gscale.data_ptr(),
                          int(group_n), None, 1 if in_split else 0, 1 if dy_split else 0, 1 if out_split else 0,
                          1 if _DETERMINISTIC[0] else 0, None, 0, int(out_nstride))
     det_ws = None
@@ -552,7 +595,7 @@ def _wgrad_swap_pays(mr, x_shape, dy_shape, K, R, S, stride, pad, x_split, dy_sp
         return False
     # the swapped launch reads dy in x's place (and the other way round): each must be readable in that role
     # (mr: the node's backward row threshold, recorded in its forward)
-    if (mr or _lib.query('ag2v_get_bf16x3_min_rows')) > min(C, K):
+    if (mr or DEFAULT_MIN_ROWS) > min(C, K):
         return False
     if dy_split and not _lib.query('ag2v_conv2d_split_input_ok', N, K, H, W, C, R, S, 1, pad, int(mr or 0), int(mr or 0), 1):
         return False
@@ -568,7 +611,7 @@ def _wgrad_pad_pays(mr, x_shape, dy_shape, K, R, S, stride, pad, x_split, dy_spl
     OH, OW = int(dy_shape[2]), int(dy_shape[3])
     if not (_PAD_WGRAD and stride == 1 and OW % 8 != 0 and OW >= 16 and not x_split and not dy_split and _PRECISION[0] == 1 and pad <= 3):
         return False
-    if (mr or _lib.query('ag2v_get_bf16x3_min_rows')) > K or K < 128 or C < 64:
+    if (mr or DEFAULT_MIN_ROWS) > K or K < 128 or C < 64:
         return False
     return (-OW % 8) * 5 <= OW and N * OH * OW >= 16384       # at most 20 % more columns
 
@@ -660,6 +703,8 @@ class _Conv2d(torch.autograd.Function):
                 raise RuntimeError("conv2d backward: gradient slot of shape %s for an input of shape %s" % (tuple(dx.shape), tuple(x.shape)))
             _conv_dgrad_launch(mr, dy, w, x if relu_input else None, dx, stride, pad, 0, gscale, group_n, dy_split=dys,
                                out_split=ctx.dx_split)
+            if ctx.dx_slot is not None:
+                ctx.dx_slot[0].mark(ctx.dx_slot[1])
             if ctx.dx_split:
                 mark_split(dx)
         if gscale is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[4]):
@@ -774,23 +819,35 @@ class _GradSlots(object):
     weight-gradient and ONE data-gradient launch over the concatenated output channels; the consumers of its outputs (one
     conv2d(relu_input=True) each: a SPADE's gamma | beta convolution reading relu(mlp_shared)) write their data gradients straight into
     channel slice i of this buffer instead of n tensors that the backward then copied together (torch.cat: 16 GB read + written per
-    c3 step).  Allocated by the first consumer's backward, dropped by the producer's."""
-    __slots__ = ('ks', 'buf')
+    c3 step).  Allocated by the first consumer's backward, dropped by the producer's.  A slice counts as the gradient only when a
+    consumer's backward of THIS pass has launched its data gradient into it (`written`, set by mark() behind the launch and cleared
+    with the buffer): a slice left over from a pass that stopped half way is never read as a gradient."""
+    __slots__ = ('ks', 'buf', 'written')
 
     def __init__(self, ks):
         self.ks = [int(k) for k in ks]
         self.buf = None
+        self.written = set()
 
     def view(self, i, N, H, W, device):
         if self.buf is None or tuple(self.buf.shape) != (N, sum(self.ks), H, W):
             self.buf = torch.empty((N, sum(self.ks), H, W), device=device, dtype=torch.float32)
+            self.written = set()
+        self.written.discard(i)
         off = sum(self.ks[:i])
         return self.buf[:, off:off + self.ks[i]]
 
+    def mark(self, i):
+        self.written.add(i)
+
+    def drop(self):
+        self.buf = None
+        self.written = set()
+
     def holds(self, i, t):
-        """t is exactly channel slice i of the buffer."""
+        """t is exactly channel slice i of the buffer, and this pass wrote it."""
         b = self.buf
-        if b is None or t is None or t.dim() != 4:
+        if b is None or t is None or t.dim() != 4 or i not in self.written:
             return False
         off = sum(self.ks[:i])
         return (t.data_ptr() == b.data_ptr() + off * b.shape[2] * b.shape[3] * 4 and tuple(t.shape) == (b.shape[0], self.ks[i], b.shape[2], b.shape[3])
@@ -994,7 +1051,7 @@ class _ConvSharedInput(torch.autograd.Function):
                 for j, (w, dy, _) in enumerate(live):
                     _conv_dgrad_launch(mr, dy, w, None, dx, stride, pad, 0 if j == 0 else 1, dy_split=dys_split)
         if slots is not None:
-            slots.buf = None
+            slots.drop()
         return (dx, None, None, None, None, None, None) + tuple(grads)
 
 
@@ -1224,6 +1281,46 @@ def _ptr_off(t, elems):
     return _P(t.data_ptr() + 4 * elems)
 
 
+# ---- synchronised batch norm on every norm path (reference: sync_batchnorm/batchnorm.py:80-93 forward, :105-126 reduce / broadcast,
+# :128-145 _compute_mean_std).  Forward: the local (mean, inv_std) of a statistics kernel -> ONE all-reduce of [sum, sum of squares]
+# -> the reference's multi-device formula (inv_std = clamp(biased var, eps)^-1/2, running_var fed with the unbiased variance).
+# Backward: every fused backward is a reduce pass and an apply pass (the *_p entry points); between them (sum dxhat, sum dxhat xhat)
+# are summed over the ranks, everything else in `sums` (affine / bias gradients) stays per rank.
+def _sync_world():
+    from . import distributed as D
+    return D.sync_bn()
+
+
+@torch.no_grad()
+def _sync_combine(mean_l, invstd_l, groups, C, count, eps, momentum, running_pairs):
+    """Local statistics [groups * C] over `count` elements per (group, channel) -> (global mean, inv_std, world); the running buffers
+    of `running_pairs` get the per-group updates, in order, in closed form."""
+    from . import distributed as D
+    var_l = invstd_l.pow(-2) - eps
+    mean, invstd, unb, cnt = D.combine_bn_stats(mean_l.view(groups, C), var_l.view(groups, C), count, eps)
+    world = int(round(cnt / count))
+    k = torch.arange(groups - 1, -1, -1, device=mean_l.device, dtype=torch.float32)
+    coef = momentum * (1.0 - momentum) ** k                                   # weight of group g in the final value
+    keep = (1.0 - momentum) ** groups
+    for rm, rv in running_pairs:
+        if rm is not None:
+            rm.mul_(keep).add_((coef.view(-1, 1) * mean).sum(0))
+            rv.mul_(keep).add_((coef.view(-1, 1) * unb).sum(0))
+    return mean.reshape(-1).contiguous(), invstd.reshape(-1).contiguous(), world
+
+
+@torch.no_grad()
+def _sync_bwd_sums(sums, n_norms):
+    """sums [G, C, 4 * n_norms] of a reduce pass: columns 4 k + (0, 1) summed over the ranks in place; returns this rank's own copy."""
+    from . import distributed as D
+    local = sums.clone()
+    idx = [4 * k + i for k in range(n_norms) for i in (0, 1)]
+    part = sums[..., idx].contiguous()
+    D.sum_over_ranks_(part)
+    sums[..., idx] = part
+    return local
+
+
 class _NormAct(torch.autograd.Function):
     """mode 0: BN(affine w,b) -> LeakyReLU(slope); mode 1: SPADE BN*(1+gamma)+beta -> LeakyReLU(slope); mode 2: as 1 with
     gamma | beta delivered as the two channel halves of ONE tensor p0 = [N, 2C, H, W] (the output of the fused gamma/beta conv).
@@ -1239,19 +1336,8 @@ class _NormAct(torch.autograd.Function):
         sync = training and D.sync_bn()
         world = 1
         if sync:
-            # synchronised statistics (sync_batchnorm/batchnorm.py:80-93): local (mean, var) per (group, channel), one all-reduce,
-            # the reference's multi-device formula, the running buffers updated once per group in order
             mean, invstd, N, C, HW, Ng = _bn_stats(x, None, None, True, momentum, eps, groups)
-            var_l = invstd.pow(-2) - eps
-            mean, invstd, unb, cnt = D.combine_bn_stats(mean.view(groups, C), var_l.view(groups, C), Ng * HW, eps)
-            world = int(round(cnt / (Ng * HW)))
-            if running_mean is not None:
-                k = torch.arange(groups - 1, -1, -1, device=x.device, dtype=torch.float32)
-                coef = momentum * (1.0 - momentum) ** k                                   # weight of group g in the final value
-                keep = (1.0 - momentum) ** groups
-                running_mean.mul_(keep).add_((coef.view(-1, 1) * mean).sum(0))
-                running_var.mul_(keep).add_((coef.view(-1, 1) * unb).sum(0))
-            mean, invstd = mean.reshape(-1).contiguous(), invstd.reshape(-1).contiguous()
+            mean, invstd, world = _sync_combine(mean, invstd, groups, C, Ng * HW, eps, momentum, [(running_mean, running_var)])
         else:
             mean, invstd, N, C, HW, Ng = _bn_stats(x, running_mean, running_var, training, momentum, eps, groups)
         y = torch.empty_like(x)
@@ -1267,14 +1353,14 @@ class _NormAct(torch.autograd.Function):
             _launch('ag2v_norm_apply_gs', 'spade_norm_apply', 4.0 * x.numel() * 4, mode, _ptr(x), _ptr(mean), _ptr(invstd), None, None,
                     g_ptr, b_ptr, _ptr(y), N, C, HW, Ng, float(slope), 1 if out_split else 0, _stream(), shape=(N, C, HW))
         # mode 0 (affine batch norm): the backward recomputes the activation's sign from x, w, b -- y is not kept for it
-        sign_from_x = (mode == 0 and not sync and os.environ.get('AG2V_NORM_BWD_READ_Y') is None)
+        sign_from_x = (mode == 0 and os.environ.get('AG2V_NORM_BWD_READ_Y') is None)
         # lean tape, mode 2: only gamma is read by the backward -- keep a compact copy, let the [N, 2C, H, W] tensor go
         ctx.gcompact = bool(mode == 2 and _LEAN_TAPE[0])
         ctx.gb_shape = tuple(p0.shape) if mode == 2 else None
         keep0 = p0[:, :C].contiguous() if ctx.gcompact else p0
         ctx.save_for_backward(x, y if (slope != 1.0 and not sign_from_x) else None, keep0, mean, invstd, p1 if mode == 0 else None)
         ctx.cfg = (mode, training, slope, N, C, HW, Ng, world if sync else 0)
-        ctx.dgb_split = bool(dgb_split) and mode == 2 and not sync
+        ctx.dgb_split = bool(dgb_split) and mode == 2
         return y
 
     @staticmethod
@@ -1301,22 +1387,19 @@ class _NormAct(torch.autograd.Function):
         else:
             dg_ptr = db_ptr = None
         kmode = (3 if ctx.gcompact else 2) if mode == 2 else mode     # 3: gamma is a compact [N, C, H, W] copy (lean tape)
+        label = 'spade_norm_bwd' if mode == 2 else 'norm_bwd'
+        nbytes = ((7.0 if y is not None or slope == 1.0 else 5.0) if mode == 0 else 11.0) * x.numel() * 4
+        args = (kmode, _ptr(dy), _ptr(y), _ptr(x), _ptr(gam), _ptr(wgt), _ptr(bias0), _ptr(mean), _ptr(invstd), _ptr(dx), dg_ptr, db_ptr,
+                _ptr(sums), N, C, HW, Ng, float(slope), _ptr(ws), 1 if ctx.dgb_split else 0)
         if sync_world:
             # (sum dxhat, sum dxhat * xhat) per (group, channel) over ALL ranks between the two passes (batchnorm.py backward of the
-            # reduce / broadcast pair)
-            from . import distributed as D
-            _lib.call('ag2v_norm_bwd_reduce_g', kmode, _ptr(dy), _ptr(y), _ptr(x), _ptr(gam), _ptr(mean), _ptr(invstd), _ptr(sums),
-                      N, C, HW, Ng, float(slope), _ptr(ws), _stream())
-            local = sums.clone() if mode == 0 else None          # affine gradients stay per rank (averaged with all the others)
-            D.sum_over_ranks_(sums)
-            _lib.call('ag2v_norm_bwd_apply_g', kmode, _ptr(dy), _ptr(y), _ptr(x), _ptr(gam), _ptr(wgt), _ptr(mean), _ptr(invstd),
-                      _ptr(sums), 1.0 / (float(sync_world) * Ng * HW), _ptr(dx), dg_ptr, db_ptr, N, C, HW, Ng, float(slope), _stream())
-            if local is not None:
-                sums = local
+            # reduce / broadcast pair); the affine / bias gradients in `sums` stay per rank (averaged with all the others)
+            _lib.call('ag2v_norm_bwd_gs_p', *(args + (1, 0.0, _stream())))
+            local = _sync_bwd_sums(sums, 1)
+            _launch('ag2v_norm_bwd_gs_p', label, nbytes, *(args + (2, 1.0 / (float(sync_world) * Ng * HW), _stream())), shape=(N, C, HW))
+            sums = local
         else:
-            _launch('ag2v_norm_bwd_gs', 'spade_norm_bwd' if mode == 2 else 'norm_bwd', ((7.0 if y is not None or slope == 1.0 else 5.0) if mode == 0 else 11.0) * x.numel() * 4, kmode, _ptr(dy), _ptr(y), _ptr(x),
-                    _ptr(gam), _ptr(wgt), _ptr(bias0), _ptr(mean), _ptr(invstd), _ptr(dx), dg_ptr, db_ptr, _ptr(sums), N, C, HW, Ng, float(slope),
-                    _ptr(ws), 1 if ctx.dgb_split else 0, _stream(), shape=(N, C, HW))
+            _launch('ag2v_norm_bwd_gs', label, nbytes, *(args + (_stream(),)), shape=(N, C, HW))
         if mode == 0:
             dw = db = None
             if p0 is not None:
@@ -1326,12 +1409,11 @@ class _NormAct(torch.autograd.Function):
         if mode == 2:
             # the channel sums of dgamma | dbeta came out of the reduce pass: they ARE the bias gradient of the convolution that produced
             # gamma | beta (layout [N, 2C, H, W]: gamma channels first).  Handed to its backward on the gradient tensor itself (sync mode:
-            # the sums were all-reduced for the statistics' sake; the bias gradient must stay per rank -> not offered)
-            if not sync_world:
-                tot = sums.sum(dim=0) if G > 1 else sums[0]
-                _attach_channel_sums(dgb, torch.cat([tot[:, 3], tot[:, 2]]))
-                if ctx.dgb_split:
-                    mark_split(dgb)
+            # this rank's own sums -- the bias gradient stays per rank)
+            tot = sums.sum(dim=0) if G > 1 else sums[0]
+            _attach_channel_sums(dgb, torch.cat([tot[:, 3], tot[:, 2]]))
+            if ctx.dgb_split:
+                mark_split(dgb)
             return (None, dx, dgb, None) + none[:9]
         return (None, dx, dgamma, dbeta) + none[:9]
 
@@ -1356,7 +1438,13 @@ class _BNActPyramid(torch.autograd.Function):
     def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, slope, groups, sizes, out_split, recompute=None):
         x, weight, bias = _c(x), _c(weight), _c(bias)
         _chk(x, weight, bias)
-        mean, invstd, N, C, HW, Ng = _bn_stats(x, running_mean, running_var, training, momentum, eps, groups)
+        world = 0
+        if training and _sync_world():
+            mean, invstd, N, C, HW, Ng = _bn_stats(x, None, None, True, momentum, eps, groups)
+            mean, invstd, world = _sync_combine(mean, invstd, groups, C, Ng * HW, eps, momentum, [(running_mean, running_var)])
+        else:
+            mean, invstd, N, C, HW, Ng = _bn_stats(x, running_mean, running_var, training, momentum, eps, groups)
+        ctx.sync_world = world
         H, W = x.shape[2], x.shape[3]
         y = torch.empty_like(x)
         built = {(H, W): y}
@@ -1435,9 +1523,16 @@ class _BNActPyramid(torch.autograd.Function):
         arr_p = (ctypes.c_void_p * max(n, 1))(*lv)
         arr_h = (ctypes.c_int * max(n, 1))(*hs)
         arr_w = (ctypes.c_int * max(n, 1))(*ws_)
-        _launch('ag2v_norm_bwd_pyr', 'norm_bwd', 5.0 * x.numel() * 4, _ptr(g_full), ctypes.cast(arr_p, ctypes.c_void_p),
-                ctypes.cast(arr_h, ctypes.c_void_p), ctypes.cast(arr_w, ctypes.c_void_p), n, _ptr(x), _ptr(weight), _ptr(bias), _ptr(mean),
-                _ptr(invstd), _ptr(dx), _ptr(sums), N, C, H, W, Ng, float(slope), _ptr(ws), _stream(), shape=(N, C, H * W))
+        args = (_ptr(g_full), ctypes.cast(arr_p, ctypes.c_void_p), ctypes.cast(arr_h, ctypes.c_void_p), ctypes.cast(arr_w, ctypes.c_void_p), n,
+                _ptr(x), _ptr(weight), _ptr(bias), _ptr(mean), _ptr(invstd), _ptr(dx), _ptr(sums), N, C, H, W, Ng, float(slope), _ptr(ws))
+        if ctx.sync_world:       # synchronised statistics: the reduce pass, the ranks' sums, the apply pass (see _sync_bwd_sums)
+            _lib.call('ag2v_norm_bwd_pyr_p', *(args + (1, 0.0, _stream())))
+            local = _sync_bwd_sums(sums, 1)
+            _launch('ag2v_norm_bwd_pyr_p', 'norm_bwd', 5.0 * x.numel() * 4, *(args + (2, 1.0 / (float(ctx.sync_world) * Ng * H * W), _stream())),
+                    shape=(N, C, H * W))
+            sums = local
+        else:
+            _launch('ag2v_norm_bwd_pyr', 'norm_bwd', 5.0 * x.numel() * 4, *(args + (_stream(),)), shape=(N, C, H * W))
         dw = db = None
         if weight is not None:
             tot = sums.sum(dim=0) if G > 1 else sums[0]
@@ -1446,9 +1541,8 @@ class _BNActPyramid(torch.autograd.Function):
 
 
 def batchnorm_act_pyramid_supported(x_shape, sizes):
-    from . import distributed as D
     H, W = int(x_shape[2]), int(x_shape[3])
-    return ((W % 4 == 0) and len(sizes) <= 8 and all(H % int(h) == 0 and W % int(w) == 0 for (h, w) in sizes) and not D.sync_bn()
+    return ((W % 4 == 0) and len(sizes) <= 8 and all(H % int(h) == 0 and W % int(w) == 0 for (h, w) in sizes)
             and os.environ.get('AG2V_NO_BN_PYRAMID') is None)
 
 
@@ -1475,9 +1569,7 @@ def spade_norm(x, gamma, beta, running_mean, running_var, training=True, momentu
 def spade_norm_fused(x, gb, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0, groups=1, out_split=False):
     """spade_norm with gamma = gb[:, :C] and beta = gb[:, C:] read in place from the [N, 2C, H, W] output of one convolution
     (and their gradients written in place into one [N, 2C, H, W] tensor)."""
-    from . import distributed as D
-    # (synchronised statistics: the backward writes fp32 gradients -- the offer is left alone)
-    take = bool(training) and not D.sync_bn() and gb.requires_grad and _take_dy_split(gb)
+    take = bool(training) and gb.requires_grad and _take_dy_split(gb)
     y = _NormAct.apply(2, x, gb, None, running_mean, running_var, bool(training), float(momentum), float(eps),
                        float(slope), int(groups), bool(out_split), take)
     return mark_split(y) if out_split else y
@@ -1507,8 +1599,15 @@ class _SpadePair(torch.autograd.Function):
         mean = torch.empty(groups * C, device=xs.device, dtype=torch.float32)
         invstd = torch.empty(groups * C, device=xs.device, dtype=torch.float32)
         ws = torch.empty(_lib.query('ag2v_bn_workspace_floats', N, C, Hs * Ws), device=xs.device, dtype=torch.float32)
-        _lib.call('ag2v_spade_pair_stats', _ptr(xs), N, C, Hs * Ws, Ng, up * up, float(eps), float(momentum), _ptr(mean), _ptr(invstd),
-                  _ptr(rm0), _ptr(rv0), _ptr(rm1), _ptr(rv1), _ptr(ws), st)
+        world = 0
+        if _sync_world():        # synchronised statistics: local moments, one all-reduce, both running pairs updated on the host side
+            _lib.call('ag2v_spade_pair_stats', _ptr(xs), N, C, Hs * Ws, Ng, up * up, float(eps), float(momentum), _ptr(mean), _ptr(invstd),
+                      None, None, None, None, _ptr(ws), st)
+            mean, invstd, world = _sync_combine(mean, invstd, groups, C, Ng * H * W, eps, momentum, [(rm0, rv0), (rm1, rv1)])
+        else:
+            _lib.call('ag2v_spade_pair_stats', _ptr(xs), N, C, Hs * Ws, Ng, up * up, float(eps), float(momentum), _ptr(mean), _ptr(invstd),
+                      _ptr(rm0), _ptr(rv0), _ptr(rm1), _ptr(rv1), _ptr(ws), st)
+        ctx.sync_world = world
         y0 = torch.empty((N, C, H, W), device=xs.device, dtype=torch.float32)
         y1 = torch.empty_like(y0)
         # algorithmic bytes: x (at its own resolution) + 4 gamma / beta planes read, 2 outputs written
@@ -1542,10 +1641,18 @@ class _SpadePair(torch.autograd.Function):
         # kernels skip the LeakyReLU sign otherwise: norm.hip `if (slope != 1.f)`); the apply pass reads the same and writes
         # dgamma / dbeta of both norms and dx at input size: (12 + 2 ny) output-sized passes + 3 input-sized ones (PMC: profiles/r02/pmc)
         ny = (1 if slope0 != 1.0 else 0) + (1 if slope1 != 1.0 else 0)
-        _launch('ag2v_spade_pair_bwd_s', 'spade_pair_bwd', (3.0 * xs.numel() + (12.0 + 2.0 * ny) * dy0.numel()) * 4, _ptr(dy0), _ptr(y0), _ptr(dy1),
-                _ptr(y1), _ptr(xs), _ptr(gb0), _ptr(gb1), _ptr(mean), _ptr(invstd), _ptr(dxs), _ptr(dgb0), _ptr(dgb1), _ptr(sums), N, C, H, W,
-                up, Ng, float(slope0), float(slope1), _ptr(ws), (1 if ctx.dgb_split else 0) | (2 if ctx.gcompact else 0), _stream(),
-                shape=(N, C, H * W, up))
+        nbytes = (3.0 * xs.numel() + (12.0 + 2.0 * ny) * dy0.numel()) * 4
+        args = (_ptr(dy0), _ptr(y0), _ptr(dy1), _ptr(y1), _ptr(xs), _ptr(gb0), _ptr(gb1), _ptr(mean), _ptr(invstd), _ptr(dxs), _ptr(dgb0),
+                _ptr(dgb1), _ptr(sums), N, C, H, W, up, Ng, float(slope0), float(slope1), _ptr(ws),
+                (1 if ctx.dgb_split else 0) | (2 if ctx.gcompact else 0))
+        if ctx.sync_world:       # synchronised statistics: the reduce pass, the ranks' sums, the apply pass (see _sync_bwd_sums)
+            _lib.call('ag2v_spade_pair_bwd_sp', *(args + (1, 0.0, _stream())))
+            local = _sync_bwd_sums(sums, 2)
+            _launch('ag2v_spade_pair_bwd_sp', 'spade_pair_bwd', nbytes, *(args + (2, 1.0 / (float(ctx.sync_world) * Ng * H * W), _stream())),
+                    shape=(N, C, H * W, up))
+            sums = local
+        else:
+            _launch('ag2v_spade_pair_bwd_s', 'spade_pair_bwd', nbytes, *(args + (_stream(),)), shape=(N, C, H * W, up))
         tot = sums.sum(dim=0) if G > 1 else sums[0]
         _attach_channel_sums(dgb0, torch.cat([tot[:, 3], tot[:, 2]]))      # bias gradients of the two gamma | beta convolutions
         _attach_channel_sums(dgb1, torch.cat([tot[:, 7], tot[:, 6]]))

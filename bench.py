@@ -203,6 +203,9 @@ def main():
     ap.add_argument('--no-fp32-leg', action='store_true', help='skip the extra exact-fp32 step used for roofline_exact_fp32')
     ap.add_argument('--temporal-D', action='store_true', help='--temporal_D 1: the temporal multiscale PatchGAN on top of the image discriminator (not BASELINE.json\'s metric; reported in config.workload)')
     ap.add_argument('--vgg-random-init', action='store_true', help='perceptual loss on a random-init VGG19 (memory / time probe; reported in config.workload)')
+    ap.add_argument('--sync-bn', type=int, default=-1, choices=[-1, 0, 1],
+                    help="batch-norm statistics over all ranks with the reference's multi-device formula: -1 (default) = as the reference at this "
+                         "world size (on at N > 1, off at N = 1); the N > 1 line then also carries the per-rank-statistics step time")
     ap.add_argument('--lean-tape', action='store_true', help='--lean_tape 1: smaller autograd tape for a few extra passes over memory (reported in config.workload)')
     args = ap.parse_args()
     if args.cpu_baseline_only:
@@ -229,6 +232,7 @@ def main():
     opt.gpu_ids = [local]
     opt.temporal_D = 1 if args.temporal_D else 0
     opt.lean_tape = 1 if args.lean_tape else 0
+    opt.sync_bn = args.sync_bn
     ops.set_conv_precision(args.precision)
     ts = TrainStep(opt, device, weights_seed=0)
     clip = ts.to_device(make_clip(opt, args.config, batch, frames, side, seed=1234 + rank))
@@ -294,6 +298,23 @@ def main():
             "note": "exposed = time the compute stream waits at the join of the generator's asynchronous all-reduce (launched after G's "
                     "backward, joined behind the discriminator phase); alone = the same buckets reduced with nothing else running; the "
                     "discriminator's all-reduce is synchronous (fully exposed)"})
+    comm["sync_bn"] = bool(D.sync_bn())
+    if D.is_dist() and D.sync_bn() and world > 1:
+        # the same step with PER-RANK batch statistics (F.batch_norm's formula; --sync-bn 0), beside the synchronised default
+        D.set_sync_bn(False)
+        ops.pause_kernel_timing(True)
+        ts.gd_step(clip)
+        torch.cuda.synchronize()
+        torch.distributed.barrier()
+        t1 = time.time()
+        k2 = max(2, args.steps // 2)
+        for i in range(k2):
+            ts.gd_step(clip)
+        torch.cuda.synchronize()
+        torch.distributed.barrier()
+        comm["per_rank_bn_ms_per_step"] = round(D.max_over_ranks(time.time() - t1, device) * 1e3 / k2, 2)
+        comm["per_rank_bn_steps"] = k2
+        D.set_sync_bn(True)
     if os.environ.get('AG2V_TIMING_DETAIL') and rank == 0:
         det = ops.kernel_timing_summary(by_shape=True, by_scope=os.environ.get('AG2V_TIMING_SCOPES') is not None)
         top = int(os.environ['AG2V_TIMING_DETAIL']) if os.environ['AG2V_TIMING_DETAIL'].isdigit() and int(os.environ['AG2V_TIMING_DETAIL']) > 1 else 45
@@ -467,6 +488,19 @@ def main():
             roof_fp32['spade_stack'] = stack_roofline(fp32_leg['by_scope'], PEAK_FP32_MFMA_TFLOPS, "v_mfma_f32_32x32x2_f32 dense peak")
             roof_fp32["ms_per_step"] = round(fp32_leg['ms'], 2)
             roof_fp32["note"] = "one extra step with --precision fp32 (exact fp32 MFMA everywhere); not part of `value`"
+    if roof is not None:
+        # flat copies of the nested figures (the driver's record keeps the scalar keys of `roofline` only -- VERDICT r04 #14)
+        ss = roof.get('spade_stack') or {}
+        roof['spade_stack_frac'] = ss.get('frac')
+        roof['spade_stack_tflops'] = ss.get('achieved')
+        roof['spade_stack_ms'] = ss.get('ms')
+        roof['all_conv_tflops'] = roof['all_conv_kernels']['achieved']
+        roof['all_conv_frac'] = round(roof['all_conv_kernels']['achieved'] / roof['peak'], 4)
+        roof['hbm_kernel_frac'] = roof_hbm['frac'] if roof_hbm else None
+        roof['hbm_kernel_gbs'] = roof_hbm['achieved'] if roof_hbm else None
+        roof['exact_fp32_ms_per_step'] = roof_fp32.get('ms_per_step') if roof_fp32 else None
+        roof['exact_fp32_frac'] = roof_fp32.get('frac') if roof_fp32 else None
+        roof['exact_fp32_spade_stack_frac'] = ((roof_fp32.get('spade_stack') or {}).get('frac')) if roof_fp32 else None
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
@@ -477,7 +511,9 @@ def main():
         "dtype": ("f32 (conv products as 3-term bf16 splits on the bf16 MFMA pipe, fp32 accumulate; everything else fp32)"
                   if args.precision == 'bf16x3' else "f32"), "data": "synthetic CATER-shaped clips (seeded), closed-form random-init weights",
         "config": {"workload": "%s: %s %dx%d, %d frames, batch %d per GPU, full G+D train step, %s%s"
-                   % (args.config, "SSv2-shaped" if args.config == 'c5' else "CATER", side, side, frames, batch, ("VGG loss on (random-init VGG19)" if args.vgg_random_init else "VGG loss off"), (", + temporal discriminator (--temporal_D 1)" if args.temporal_D else "") + (", lean tape (--lean_tape 1)" if args.lean_tape else "")), "global_batch": world * batch, "parallelism": "dp%d" % world},
+                   % (args.config, "SSv2-shaped" if args.config == 'c5' else "CATER", side, side, frames, batch, ("VGG loss on (random-init VGG19)" if args.vgg_random_init else "VGG loss off"), (", + temporal discriminator (--temporal_D 1)" if args.temporal_D else "") + (", lean tape (--lean_tape 1)" if args.lean_tape else "")), "global_batch": world * batch, "parallelism": "dp%d" % world,
+                   "batch_norm": ("statistics synchronised over the %d ranks, the reference's multi-device formula (sync_batchnorm/batchnorm.py:78-93)" % world
+                                  if comm.get("sync_bn") else "per-rank statistics, F.batch_norm's formula (the reference's single-device path)")},
         "roofline": roof, "roofline_exact_fp32": roof_fp32, "roofline_hbm": roof_hbm, "roofline_hbm_bwd": roof_hbm_bwd,
         "cpu_baseline": cpu, "comm": comm,
         "extra": {"graph_step_ms": round(graph_ms, 2), "losses_finite": finite,

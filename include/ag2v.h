@@ -6,8 +6,9 @@
  *   - every tensor is a raw device pointer to contiguous fp32 (NCHW for images) unless stated (int64 indices, uint8/int32 masks);
  *   - the caller owns all memory; no entry point allocates, frees or synchronises; kernels are enqueued on `stream`
  *     (a hipStream_t passed as void*) and are safe to capture in a hipGraph;
- *   - no entry point reads mutable process state when it is given its options explicitly (ag2v_conv_opts): the library is
- *     re-entrant per stream / thread.  The ag2v_set_* functions only set the DEFAULTS of calls that pass no options;
+ *   - the library holds no process-global mutable state: every option travels with the call (ag2v_conv_opts, ag2v_halo_opts); a call
+ *     that leaves precision / min_rows unnamed takes the defaults of the DEVICE it runs on (a per-device record initialised from the
+ *     environment).  The ag2v_set_* functions are deprecated shims that edit that record for the calling thread's current device;
  *   - scratch memory is passed in as `workspace` and sized by the matching ag2v_*_workspace_floats();
  *   - return value: 0 on success, AG2V_EINVAL (-1) for a rejected argument, AG2V_EHIP (-2) for a HIP launch error
  *     (the Python host turns non-zero into RuntimeError, matching the reference's "raise, never abort" convention,
@@ -35,9 +36,9 @@ extern "C" {
  *              (11 + 11 significand bits: ~5e-6 of rms(out), the level of a sequential fp32 fmaf chain) for operands of O(1)
  *              magnitude -- below ~1e-2 the lo part is an fp16 subnormal and the accuracy decays, so the weights are packed
  *              times 32 (exact, undone in the epilogue) and the caller uses it on normalised activations only (the flow network),
- *              < 0 = the process default (ag2v_set_conv_precision / AG2V_CONV_PRECISION; initially 1);
+ *              < 0 = the current device's default (AG2V_CONV_PRECISION, initially 1; deprecated ag2v_set_conv_precision);
  *   min_rows:  in bf16x3 mode, GEMMs with fewer rows (output channels; input channels for the data gradient) stay on the exact
- *              fp32 tiles; <= 0 = the process default (ag2v_set_bf16x3_min_rows / AG2V_BF16X3_MIN_M; initially 128);
+ *              fp32 tiles; <= 0 = the current device's default (AG2V_BF16X3_MIN_M, initially 128; deprecated ag2v_set_bf16x3_min_rows);
  *   gscale:    nullable device pointer: the convolution product of sample n is multiplied by gscale[n / group_n] before bias
  *              and residual are added (forward and data gradient).  This is how a spectral-norm convolution of the
  *              frame-batched generator runs: torch.nn.utils.spectral_norm divides W by sigma_t in the t-th forward call of a
@@ -79,11 +80,19 @@ typedef struct ag2v_conv_opts {
     size_t det_workspace_floats;
     long long out_nstride;
 } ag2v_conv_opts;
-/* Defaults of calls without options (process-wide; the product passes options on every call). */
+/* Defaults of calls that do not name precision / min_rows: a record per DEVICE, initialised from AG2V_CONV_PRECISION /
+ * AG2V_BF16X3_MIN_M.  The setters are deprecated shims editing the calling thread's current device's record (the product passes both
+ * fields with every call and never reads it). */
 int ag2v_set_conv_precision(int mode);
 int ag2v_get_conv_precision(void);
 int ag2v_set_bf16x3_min_rows(int rows);
 int ag2v_get_bf16x3_min_rows(void);
+/* Diagnostic A/B switches of the halo-tile launchers (AG2V_NO_HALO, AG2V_HALO_TALL, AG2V_HALO_MFMA32, AG2V_NO_HALO_H16,
+ * AG2V_NO_HALO_F32IN, AG2V_HALO_MIN_TILES: which kernel FAMILY takes a launch -- same products, another summation order) are read
+ * from the environment once at load time; ag2v_halo_reload_env() reads them again (tests / tools, with no launch in flight).
+ * ag2v_halo_min_tiles(): the tile count from which a 3x3 stride-1 launch takes those kernels (384 unless AG2V_HALO_MIN_TILES). */
+int ag2v_halo_reload_env(void);
+int ag2v_halo_min_tiles(void);
 /* Name of the main kernel launched by the most recent ag2v_conv2d_* call of the calling thread (ag2v_conv_opts::kernel is the
  * per-call form). */
 const char* ag2v_last_conv_kernel(void);
@@ -186,6 +195,15 @@ int ag2v_norm_bwd_g(int mode, const float* dy, const float* y, const float* x, c
 int ag2v_norm_bwd_gs(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* w,
                      const float* bias, const float* mean, const float* invstd, float* dx, float* dgamma, float* dbeta, float* sums,
                      int N, int C, int HW, int Ng, float slope, float* workspace, int dgb_split, void* stream);
+/* ... in phases, for data-parallel SYNCHRONISED batch norm (sync_batchnorm/batchnorm.py:105-126, _compute_mean_std :128-145) on the fused
+ * paths: phase 0 = both passes (the function above), 1 = the reduce pass only (sums written), 2 = the apply pass only (sums read).
+ * The caller runs 1, all-reduces columns 0 / 1 of sums[N / Ng, C, 4] (sum dxhat, sum dxhat xhat) over the ranks -- columns 2 / 3,
+ * the channel sums of dbeta / dgamma, stay per rank -- and runs 2 with inv_count = 1 / (elements per (group, channel) over ALL
+ * ranks); inv_count <= 0 = this process's own count. */
+int ag2v_norm_bwd_gs_p(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* w,
+                       const float* bias, const float* mean, const float* invstd, float* dx, float* dgamma, float* dbeta, float* sums,
+                       int N, int C, int HW, int Ng, float slope, float* workspace, int dgb_split, int phase, float inv_count,
+                       void* stream);
 /* (mode 0, y == NULL: the LeakyReLU branch is recomputed from x, w and `bias` -- the affine pair of the forward pass -- instead of
  *  being read from the forward output: 5 instead of 7 tensor passes.)
  * (mode 3 = mode 2 whose `gamma` points at a COMPACT copy [N, C, HW] of the gamma half; dgamma / dbeta are still the halves of one
@@ -197,6 +215,10 @@ int ag2v_norm_bwd_gs(int mode, const float* dy, const float* y, const float* x, 
 int ag2v_norm_bwd_pyr(const float* g_full, const float* const* g_levels, const int* hs, const int* ws, int n_levels,
                       const float* x, const float* w, const float* bias, const float* mean, const float* invstd, float* dx,
                       float* sums, int N, int C, int H, int W, int Ng, float slope, float* workspace, void* stream);
+int ag2v_norm_bwd_pyr_p(const float* g_full, const float* const* g_levels, const int* hs, const int* ws, int n_levels,
+                        const float* x, const float* w, const float* bias, const float* mean, const float* invstd, float* dx,
+                        float* sums, int N, int C, int H, int W, int Ng, float slope, float* workspace, int phase, float inv_count,
+                        void* stream);      /* phases as ag2v_norm_bwd_gs_p */
 /* ag2v_norm_bwd_g in two steps, for data-parallel SYNCHRONISED batch norm (sync_batchnorm/batchnorm.py:105-126): the caller
  * all-reduces sums[N / Ng, C, 4] over the ranks between them and passes inv_count = 1 / (elements per (group, channel) over ALL ranks). */
 int ag2v_norm_bwd_reduce_g(int mode, const float* dy, const float* y, const float* x, const float* gamma, const float* mean,
@@ -229,6 +251,11 @@ int ag2v_spade_pair_bwd_s(const float* dy0, const float* y0, const float* dy1, c
                           const float* gb1, const float* mean, const float* invstd, float* dxs, float* dgb0, float* dgb1,
                           float* sums, int N, int C, int H, int W, int up, int Ng, float slope0, float slope1, float* workspace,
                           int dgb_split, void* stream);
+/* phases as ag2v_norm_bwd_gs_p; synchronised batch norm all-reduces columns 0, 1, 4, 5 of sums[N / Ng, C, 8] between them */
+int ag2v_spade_pair_bwd_sp(const float* dy0, const float* y0, const float* dy1, const float* y1, const float* xs, const float* gb0,
+                           const float* gb1, const float* mean, const float* invstd, float* dxs, float* dgb0, float* dgb1,
+                           float* sums, int N, int C, int H, int W, int up, int Ng, float slope0, float slope1, float* workspace,
+                           int dgb_split, int phase, float inv_count, void* stream);
 int ag2v_instnorm_lrelu_fwd(const float* x, float* y, float* mean, float* invstd, int NC, int HW, float eps, float slope,
                             void* stream);
 int ag2v_instnorm_lrelu_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
@@ -371,6 +398,9 @@ int ag2v_spectral_sigmas_multi(const void* descs, int n_layers, int total_blocks
  *      a multiple of 4 floats (16-byte accesses).  The record builder (ag2video_amd/graph_program.py) refuses anything else.
  * sync: two device words {arrival counter, timeout flag}, BOTH zeroed by the call; the flag is set when a grid barrier gave up (the
  * workgroups were not co-resident): the results of THAT run are invalid and the caller must read the flag before it trusts them. */
+/* TEST AID: occupy n_wgs CUs (1024 threads + 128 KB of LDS each) for ms <= 500 milliseconds of wall time on `stream`, as another stream's
+ * persistent kernel would; bounded by the clock.  Used to show that the graph-net programs' grid barriers survive late co-residency. */
+int ag2v_debug_hold_cus(int n_wgs, float ms, void* stream);
 size_t ag2v_graph_op_bytes(void);
 int ag2v_graph_program_grid(void);
 int ag2v_graph_program_max_edges(void);

@@ -13,14 +13,19 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 class OracleTrainer(object):
-    def __init__(self, opt, key_shapes_G, key_shapes_D, wseed, key_shapes_V=None, key_shapes_T=None):
+    def __init__(self, opt, key_shapes_G, key_shapes_D, wseed, key_shapes_V=None, key_shapes_T=None, dtype=torch.float32):
+        """`dtype=torch.float64`: the same fp32 weights and the same fp32 clip, widened, with every operation of the iteration in
+        double precision -- the reference point against which the fp32 oracle's OWN rounding is measured (tests/golden/
+        make_noise_floor.py -> noise_floor.json) and against which the HIP result is compared beside the fp32 oracle."""
         self.opt = opt
-        self.G = M.make_state(key_shapes_G, wseed, 'G.')
-        self.D = M.make_state(key_shapes_D, wseed, 'D.')
-        self.T = M.make_state(key_shapes_T, wseed, 'T.') if key_shapes_T else None      # --temporal_D 1
+        self.dtype = dtype
+        dt = None if dtype == torch.float32 else dtype
+        self.G = M.make_state(key_shapes_G, wseed, 'G.', dt)
+        self.D = M.make_state(key_shapes_D, wseed, 'D.', dt)
+        self.T = M.make_state(key_shapes_T, wseed, 'T.', dt) if key_shapes_T else None      # --temporal_D 1
         self.V = None
         if not opt.no_vgg_loss:           # frozen VGG19 of the perceptual loss (keys 'vgg.slice<k>.<i>.weight|bias')
-            self.V = {k: v.detach() for k, v in M.make_state(key_shapes_V, wseed, 'V.').items()}
+            self.V = {k: v.detach() for k, v in M.make_state(key_shapes_V, wseed, 'V.', dt).items()}
         lr, b1 = opt.learning_rate, opt.beta1
         graph_params = M.params_of(self.G, 'acts_to_boxes.')
         gen_params = [t for n, t in self.G.items() if t.requires_grad and not n.startswith('acts_to_boxes.')]
@@ -28,6 +33,23 @@ class OracleTrainer(object):
         self.opt_gen = torch.optim.Adam(gen_params, lr=lr, betas=(b1, 0.999))
         self.opt_d = torch.optim.Adam(M.params_of(self.D) + (M.params_of(self.T) if self.T else []), lr=lr, betas=(b1, 0.999))
 
+    def _widen(self, batch):
+        return [t.to(self.dtype) if torch.is_tensor(t) and t.is_floating_point() else t for t in batch]
+
+    def _in_dtype(fn):
+        """Run a step with torch's default dtype = self.dtype (tensor constructors inside oracle/model.py follow it)."""
+        def run(self, batch, *a, **k):
+            if self.dtype == torch.float32:
+                return fn(self, batch, *a, **k)
+            old = torch.get_default_dtype()
+            torch.set_default_dtype(self.dtype)
+            try:
+                return fn(self, self._widen(batch), *a, **k)
+            finally:
+                torch.set_default_dtype(old)
+        return run
+
+    @_in_dtype
     def gd_step(self, batch, apply_updates=True):
         """G step then D step on one clip batch; returns (model_out, G_losses, D_losses)."""
         opt = self.opt
@@ -51,6 +73,7 @@ class OracleTrainer(object):
             self.opt_d.step()
         return model_out, G_losses, D_losses
 
+    @_in_dtype
     def graph_step(self, batch, apply_updates=True):
         imgs, objs, boxes, triplets, actions = batch[:5]
         boxes_pred = M.generator_forward(self.G, self.opt, imgs, objs, triplets, actions, boxes, training=True, graph_only=True)

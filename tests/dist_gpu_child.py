@@ -49,6 +49,17 @@ def main(out_path):
     n_after = calls['n']
     gclip = ts.to_device(make_clip_batch(opt.vocab, 2, 5, (64, 64), seed=12 + rank))
     _, GG = ts.graph_step(gclip)
+    # the same step while ANOTHER stream holds 64 CUs from start to end (what RCCL's kernels or a persistent kernel on the side stream
+    # do at > 1 rank): the graph-net programs' grid barriers must complete -- check_health() raises on a timeout flag
+    import ctypes
+    from ag2video_amd import _lib
+    hold = torch.cuda.Stream()
+    with torch.cuda.stream(hold):
+        _lib.call('ag2v_debug_hold_cus', 64, 400.0, ctypes.c_void_p(hold.cuda_stream))
+    _, GLh, DLh = ts.gd_step(clip, apply_updates=False)
+    ts.check_health()
+    torch.cuda.synchronize()
+    held_step = {k: float(v) for k, v in list(GLh.items()) + list(DLh.items())}
     # synchronised batch norm (--sync_bn 1) through the kernels: local statistics -> all-reduce -> the reference's multi-device
     # formula (sync_batchnorm/batchnorm.py:128-145) -> apply; backward with the all-reduced (sum dxhat, sum dxhat xhat)
     from ag2video_amd import ops
@@ -76,6 +87,51 @@ def main(out_path):
                    float((xb.grad.double().view(2, 3, 5, 81) - xd.grad).abs().max() / xd.grad.abs().max()),
                    float((rm.double() - rm_ref).abs().max()), float(((rv.double() - rv_ref).abs() / rv_ref).max())]
     D.set_sync_bn(False)
+    # A whole training step with --sync_bn 1 (the reference's behaviour at > 1 device, sync_batchnorm/batchnorm.py:78-93,105-145) on
+    # the product's FAST path -- the batch-norm + pyramid node, the SPADE pair, split-word gradients -- against (a) the oracle with its
+    # multi-device formula switched on and (b) the same step with those fusions off.  Every rank holds the same
+    # clip here, so global statistics = local ones; the oracle leg runs at world 1 only (its CPU all-reduce has no backend otherwise).
+    sync_step = None
+    if world == 1:
+        from oracle import kernels as K
+        from oracle.step import OracleTrainer
+        opt_s = make_opt(cater_vocab(), flags + ['--sync_bn', '1'])
+        sclip = make_clip_batch(opt.vocab, 2, 3, (64, 64), seed=21)
+
+        def run(env):
+            old = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)
+            try:
+                with ops.deterministic():
+                    t = TrainStep(opt_s, dev, weights_seed=5)
+                    assert D.sync_bn()
+                    _, gl, dl = t.gd_step(t.to_device(sclip))
+                sd = {k: v.detach().double().cpu() for k, v in t.model.state_dict().items() if k.endswith('running_var')}
+                return {k: float(v) for k, v in list(gl.items()) + list(dl.items())}, sd, t
+            finally:
+                for k, v in old.items():
+                    os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        fused, rv_f, t_f = run({})
+        shapes_G = {k: list(v.shape) for k, v in t_f.model.state_dict().items()}
+        shapes_D = {k: list(v.shape) for k, v in t_f.discriminator.img_discriminator.state_dict().items()}
+        del t_f
+        plain, rv_p, t_p = run({'AG2V_NO_BN_PYRAMID': '1', 'AG2V_NO_SPADE_PAIR': '1', 'AG2V_NO_SPLIT_GRAD': '1'})
+        del t_p
+        D.set_sync_bn(False)
+        K.SYNC_BN = True
+        try:
+            orc = OracleTrainer(opt_s, shapes_G, shapes_D, 5)
+            _, GLo, DLo = orc.gd_step(sclip)
+        finally:
+            K.SYNC_BN = False
+        ref = {k: float(v) for k, v in list(GLo.items()) + list(DLo.items())}
+        rv_o = {k: v.detach().double() for k, v in orc.G.items() if k.endswith('running_var')}
+        sync_step = {'loss_vs_oracle': max(abs(fused[k] - ref[k]) / max(1.0, abs(ref[k])) for k in ref),
+                     'loss_fused_vs_plain': max(abs(fused[k] - plain[k]) / max(1.0, abs(plain[k])) for k in plain),
+                     'running_var_vs_oracle': max(float(((rv_f[k] - rv_o[k]).abs() / rv_o[k].abs().clamp(min=1e-6)).max()) for k in rv_o),
+                     'running_var_fused_vs_plain': max(float(((rv_f[k] - rv_p[k]).abs() / rv_p[k].abs().clamp(min=1e-6)).max()) for k in rv_p),
+                     'n_running_var': len(rv_o)}
+    D.set_sync_bn(False)
     skip = D.any_rank(False, dev), D.any_rank(rank == 0, dev)
     torch.distributed.barrier()
     mx = D.max_over_ranks(float(rank + 1), dev)
@@ -90,7 +146,7 @@ def main(out_path):
                                ts.optimizer_graph.flat_grad.numel()],
            'G': {k: float(v) for k, v in GL.items()}, 'D': {k: float(v) for k, v in DL.items()},
            'G0': {k: float(v) for k, v in GL0.items()}, 'graph': {k: float(v) for k, v in GG.items()},
-           'skip_flags': list(skip), 'sync_bn_err': sync_bn_err, 'max_over_ranks': mx, 'param_checksums': [float(t) for t in gathered]}
+           'skip_flags': list(skip), 'held_step': held_step, 'sync_bn_err': sync_bn_err, 'sync_step': sync_step, 'max_over_ranks': mx, 'param_checksums': [float(t) for t in gathered]}
     if rank == 0:
         json.dump(res, open(out_path, 'w'))
     D.shutdown()

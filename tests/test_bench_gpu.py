@@ -46,17 +46,21 @@ def test_library_reports_the_launched_kernel(device):
     w = torch.randn(160, 16, 3, 3, device=device)
     ops.conv2d(x, w, None, 1, 1)
     assert b'conv_igemm_bf16x3_ws_kernel' in _lib.query('ag2v_last_conv_kernel')
+    # the row threshold travels with the call (ag2v_conv_opts::min_rows): the host never consults the library's per-device default
     old = _lib.query('ag2v_get_bf16x3_min_rows')
     try:
-        _lib.call('ag2v_set_bf16x3_min_rows', 512)
+        _lib.call('ag2v_set_bf16x3_min_rows', 512)      # deprecated shim: edits the current device's default only ...
         ops.conv2d(x, w, None, 1, 1)
-        assert _lib.query('ag2v_last_conv_kernel').startswith(b'conv_igemm_f32_ws_kernel<128')      # exact arithmetic, >= 128 rows
-        ops.conv2d(x, w[:96], None, 1, 1)
-        assert _lib.query('ag2v_last_conv_kernel').startswith(b'conv_igemm_kernel<128')             # ... fewer rows
+        assert b'conv_igemm_bf16x3_ws_kernel' in _lib.query('ag2v_last_conv_kernel')                # ... which ops.py does not read
         with pytest.raises(RuntimeError):
             _lib.call('ag2v_set_bf16x3_min_rows', 0)
     finally:
         _lib.call('ag2v_set_bf16x3_min_rows', old)
+    with ops.bf16x3_min_rows(512):
+        ops.conv2d(x, w, None, 1, 1)
+        assert _lib.query('ag2v_last_conv_kernel').startswith(b'conv_igemm_f32_ws_kernel<128')      # exact arithmetic, >= 128 rows
+        ops.conv2d(x, w[:96], None, 1, 1)
+        assert _lib.query('ag2v_last_conv_kernel').startswith(b'conv_igemm_kernel<128')             # ... fewer rows
 
 
 def test_build_then_smoke_in_one_process():

@@ -10,16 +10,17 @@
   so they go through the size-independent property set of tests/test_fullsize_gpu.py at THEIR layer sizes (oracle on crops,
   adjoint identities) plus one finite training step with the documented keys.
 """
+import json
+import os
+import time
+
 import numpy as np
 import pytest
 import torch
 
+import _cases as C
+
 pytestmark = pytest.mark.gpu
-
-
-def _stats(t):
-    t = t.detach().double().cpu()
-    return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().sqrt().item()])
 
 
 def _rand(*shape, seed=0, device='cpu', scale=1.0):
@@ -27,94 +28,116 @@ def _rand(*shape, seed=0, device='cpu', scale=1.0):
     return (torch.randn(*shape, generator=g) * scale).to(device)
 
 
-# ---- GPU step against the CPU oracle at default widths.  name: (image side, frames, batch).  c1 is BASELINE.json's configs[0];
-# c2p / c3p are the resolutions of c2 / c3 at the smallest clip that keeps their structure (batch 1; 3 / 4 frames: two / three
-# generated frames, i.e. T > 1 frame groups): the 128^2 / 256^2 layer stack -- up_2 / up_3, the full-resolution flow network and
-# warp, the discriminators at 129^2 / 65^2, the 6-level segmentation pyramid -- compared with the oracle AS A STACK (VERDICT r02
-# weak #1).  The oracle side of c3p is bench.py's c3' cpu_baseline leg (~16 s on the GPU box's host cores).
-# c5p / c5pT: c5's geometry -- Something-Else vocabulary (ONE attribute => 128 layout channels, 2-3 objects with the
-# hand last, 9 predicates / 9 action classes: reference data/smth.py:85-104), 224 x 224 = 7 * 32 (the non-power-of-two pyramid 7, 14,
-# ..., 224 of spade_generator.py:53-81; discriminator maps 113^2 / 57^2) -- as a full default-width iteration against the oracle;
-# c5pT adds --temporal_D 1 --frames_per_action 4 (the reference's MultiscaleDiscriminatorT, discriminator.py:16-59, over one window of
-# 4 generated frames: 5 frames).
-STEP_CASES = {'c1': (64, 4, 1), 'c2p': (128, 3, 1), 'c3p': (256, 4, 1), 'c5p': (224, 3, 1), 'c5pT': (224, 5, 1)}
+# ---- GPU step against the CPU oracle at default widths (cases: tests/_cases.py).
+#
+# What is compared with what.  The oracle runs twice per case: in fp32 (o32: the restatement of the reference,
+# pinned to it bit-for-bit by tests/test_oracle_golden.py) and in fp64 on the SAME fp32 weights and clip (o64).  o64 is the exact result
+# of the graph to ~1e-13 and does not depend on the host (thread count, MKL-DNN blocking); o32 does: two thread counts of the same fp32
+# oracle differ by 2-8e-4 of max|imgs_pred| at c1 / c2p / c3p (tests/golden/noise_floor.json, `threads_1_vs_n`).  That file -- written by
+# tests/golden/make_noise_floor.py, CPU only -- holds the distance of o32 from o64 for every statistic bounded here, i.e. how far the
+# REFERENCE ARITHMETIC itself sits from the exact result in that norm:
+#     imgs_pred   max-norm 4.1e-4 (c1) 4.2e-4 (c2p) 8.9e-4 (c3p) 1.14e-3 (c5p) 9.9e-4 (c5pT);  relative L2 0.7-1.2e-4 everywhere
+#     flows_pred  max-norm 3-6e-6; boxes 1-3e-7; losses <= 1.1e-6; post-step buffers <= 1.7e-5
+#     gradient abs-sum, worst parameter per group: front 0.2-2.2e-2, decoder 2-4e-3, D / T 0.6-5e-3
+# The max-norm of imgs_pred is a maximum over 10^5-10^6 pixels of white-noise frames warped by a flow that carries an fp32-rounding-level
+# error: fp32 itself does not hold 1e-3 in that norm at 224^2 / 256^2, so no fp32-class implementation can be asked to.
+# And one evaluation's max-norm is only defined to within a factor: the fp32 oracle's OWN samples (1 / 2 / 4 / 8 threads = four summation
+# orders of the same arithmetic, `imgs_pred_o32_samples_vs_o64`) span 2.5-4.3e-4 at c1, 0.89-1.16e-3 at c3p, with the SAME relative L2
+# (+-3 %) -- a bound of 1.5 x one sample would fail the reference against itself (c1: 4.3e-4 > 1.5 x 2.5e-4).
+# Gates on imgs_pred (floor_max / floor_l2 = the LARGEST of the oracle's samples for the case, committed in noise_floor.json):
+#     relative L2 against o64     <= 2 x floor_l2(case)       (1.4-2.4e-4: the tight, low-variance gate -- HIP's error energy within 2x
+#                                                              of the fp32 reference's own; measured 1.0-1.5x, the 1.5 on the exact-
+#                                                              fp32 deterministic path whose 9216-term chains are summed sequentially)
+#     relative L2 against o32     <= 1e-3                     (north_star's bound against the reference arithmetic itself)
+#     max-norm against o64        <= max(1e-3, 2 x floor_max(case))     (1.5 for the L2 ratio x 1.3 for one sample's spread)
+#     max-norm against o32        <= max(1e-3, 3 x floor_max(case))     (triangle: HIP-o32 <= HIP-o64 + o64-o32)
+# boxes / flows / losses / buffers: 1e-3 against both, as before.  Gradient statistics: the bounds of tests/test_step_gpu.py (front 5e-2,
+# decoder / D / T 2e-2), >= 2.2 x the measured floors above, against both oracles.
+# The step runs under ops.deterministic(): a result is then a property of the build, not of the launch (split-K atomics order).  The
+# default, non-deterministic path is run once more per case as a SPREAD REPORT (printed) and gated only on the relative L2 gates.
 _ORACLE_CACHE = {}
-# imgs_pred bound per case (everything else: 1e-3).  The image error is the flow's fp32-rounding-level error (3e-6 of max in every case
-# and BOTH arithmetics) amplified by the warp of white-noise frames and the decoder behind it, and it is a maximum over
-# all pixels of all generated frames.  Measured over repeated runs (atomics order varies): c3p 7.1-7.4e-4; c5p 7.8-9.3e-4 (bf16x3) and
-# 7.2-8.8e-4 (exact fp32); c5pT -- 4 generated frames instead of 2, i.e. the maximum over twice the pixels -- 9.0e-4 ... 1.24e-3.  The
-# exact-fp32 mode sits at the same level, so this is the conditioning of the input, not the arithmetic: c5pT holds 1.5e-3, the others 1e-3.
-IMG_BOUND = {'c5pT': 1.5e-3}
+FLOOR = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'noise_floor.json')))
 
 
-def _case_opt(case):
-    import bench
-    side, frames, batch = STEP_CASES[case]
-    if case.startswith('c5'):
-        from ag2video_amd.data.args import make_opt
-        from ag2video_amd.data.vocab import smth_vocab
-        flags = ['--no_vgg_loss', '--image_size', '%d,%d' % (side, side), '--batch_size', str(batch), '--gpu_ids', '0', '--dataset', 'smth_else']
-        if case.endswith('T'):
-            flags += ['--temporal_D', '1', '--frames_per_action', '4']
-        return make_opt(smth_vocab(), flags), side, frames, batch
-    opt, _, _, _ = bench.make_opt('c1')
-    opt.image_size = (side, side)
-    opt.batch_size = batch
-    opt.gpu_ids = [0]
-    return opt, side, frames, batch
+def _img_floor(case):
+    smp = FLOOR[case]['imgs_pred_o32_samples_vs_o64'].values()
+    return max(v['max'] for v in smp), max(v['l2'] for v in smp)
 
 
-def _case_clip(case, opt, batch, frames, side, seed):
-    from ag2video_amd.data.synthetic import make_clip_batch
-    if case.startswith('c5'):        # bench.make_clip's Something-Else shape: 2-3 objects (the hand last), <= 2 actions
-        return make_clip_batch(opt.vocab, batch, frames, (side, side), seed=seed, min_objs=2, max_objs=3, max_actions=2)
-    return make_clip_batch(opt.vocab, batch, frames, (side, side), seed=seed)
+def _img_bounds(case):
+    """(max-norm bound against o64, against o32, relative-L2 bound against o64)."""
+    fmax, fl2 = _img_floor(case)
+    return max(1e-3, 2.0 * fmax), max(1e-3, 3.0 * fmax), 2.0 * fl2
+
+
+def _oracle_steps(case, shapes_G, shapes_D, shapes_T=None):
+    """o32 and o64 iterations of a case, computed once per session."""
+    if case not in _ORACLE_CACHE:
+        torch.set_num_threads(min(16, torch.get_num_threads()))
+        t0 = time.time()
+        o32 = C.oracle_step(case, shapes_G, shapes_D, shapes_T, torch.float32)
+        t1 = time.time()
+        o64 = C.oracle_step(case, shapes_G, shapes_D, shapes_T, torch.float64)
+        print('%s oracle: fp32 %.0f s, fp64 %.0f s on %d threads' % (case, t1 - t0, time.time() - t1, torch.get_num_threads()))
+        _ORACLE_CACHE[case] = {'o32': o32, 'o64': o64}
+    return _ORACLE_CACHE[case]
 
 
 def _oracle_step(case, shapes_G, shapes_D, shapes_T=None):
-    """One oracle iteration (G step, D step, graph step) of a case, computed once per session and kept as what the checks need:
-    outputs, losses, per-parameter gradient statistics, post-step state statistics + buffers."""
-    if case in _ORACLE_CACHE:
-        return _ORACLE_CACHE[case]
-    from ag2video_amd.data.synthetic import make_clip_batch
-    from oracle.step import OracleTrainer
-    torch.set_num_threads(min(16, torch.get_num_threads()))
-    opt, side, frames, batch = _case_opt(case)
-    orc = OracleTrainer(opt, shapes_G, shapes_D, 1, key_shapes_T=shapes_T)
-    clip = _case_clip(case, opt, batch, frames, side, 1234)
-    mo_r, GL_r, DL_r = orc.gd_step(clip)
-    res = {'out': [mo_r[i].detach().clone() for i in range(4)],
-           'GL': {k: float(v) for k, v in GL_r.items()}, 'DL': {k: float(v) for k, v in DL_r.items()},
-           'G_grads': {n: (None if g is None else _stats(g)) for n, g in orc.last_G_grads.items()},
-           'D_grads': {n: (None if g is None else _stats(g)) for n, g in orc.last_D_grads.items()}}
-    if shapes_T:
-        res['T_grads'] = {n: (None if g is None else _stats(g)) for n, g in orc.last_T_grads.items()}
-    gclip = _case_clip(case, opt, batch, 4 * frames, side, 4321)
-    bp_r, GG_r = orc.graph_step(gclip)
-    res['bp'] = bp_r.detach().clone()
-    res['GG'] = {k: float(v) for k, v in GG_r.items()}
-    state = {}
-    for tag, sd in (('G', orc.G), ('D', orc.D)):
-        for k, v in sd.items():
-            r = v.detach()
-            buf = (not v.requires_grad) and r.is_floating_point()
-            state[(tag, k)] = (_stats(r.float()), r.numel(), r.clone() if buf else None)
-    res['state'] = state
-    del orc
-    _ORACLE_CACHE[case] = res
-    return res
+    return _oracle_steps(case, shapes_G, shapes_D, shapes_T)['o32']
+
+
+def _check_outputs(case, prec, mo, refs, label, gate_max=True):
+    """imgs / boxes / flows / conf of one step against o32 and o64; returns the measured figures."""
+    b64, b32, bl2 = _img_bounds(case)
+    got = {}
+    for tag, bound_img in (('o64', b64), ('o32', b32)):
+        ref = refs[tag]
+        for i, name in enumerate(('imgs_pred', 'boxes_pred', 'flows_pred')):
+            mx, l2 = C.out_errors(mo[i], ref['out'][i])
+            got[(tag, name)] = (mx, l2)
+            l2_bound = bl2 if (tag == 'o64' and name == 'imgs_pred') else 1e-3
+            assert l2 <= l2_bound, (case, prec, label, tag, name, 'relative L2', l2, 'bound', l2_bound)
+            if gate_max:
+                bound = bound_img if name == 'imgs_pred' else 1e-3
+                assert mx <= bound, (case, prec, label, tag, name, 'max-norm', mx, 'bound', bound)
+        assert np.mean(mo[3].cpu().numpy() != ref['out'][3].float().numpy()) < 2e-3
+    print('%s [%s] %s: (max-norm / max|ref|, relative L2) %s; imgs_pred bounds: max-norm o64 %.2e o32 %.2e, L2 o64 %.2e (oracle floors %.2e / %.2e)'
+          % ((case, prec, label, {'%s.%s' % k: ('%.2e' % v[0], '%.2e' % v[1]) for k, v in got.items()}, b64, b32, bl2) + _img_floor(case)))
+    return got
+
+
+def _grad_report(named_params, ref_stats, rel_of, allow_missing=()):
+    """Worst deviation of sum|g| per group against one oracle's statistics; returns (bad list, worst per group)."""
+    bad, worst = [], {}
+    for n, prm in named_params:
+        g_ref = ref_stats.get(n)
+        if g_ref is None:
+            assert prm.grad is None or float(prm.grad.abs().sum()) == 0.0 or n.startswith(allow_missing), n
+            continue
+        if prm.grad is None:
+            bad.append((n, None, g_ref[1]))
+            continue
+        got = C.stats(prm.grad)
+        grp, rel = rel_of(n)
+        dev = abs(got[1] - g_ref[1]) / max(abs(g_ref[1]), 1e-30)
+        if abs(g_ref[1]) > 2e-6 * prm.numel() and dev > worst.get(grp, (0.0, ''))[0]:
+            worst[grp] = (dev, n)
+        if abs(got[1] - g_ref[1]) > rel * abs(g_ref[1]) + 2e-6 * prm.numel():
+            bad.append((n, got[1], g_ref[1]))
+    return bad, worst
 
 
 def _step_vs_oracle(case, prec, device):
     from ag2video_amd import ops
-    from ag2video_amd.data.synthetic import make_clip_batch
     from ag2video_amd.engine import TrainStep
     old = ops.get_conv_precision()
     ops.set_conv_precision(prec)
     try:
-        opt, side, frames, batch = _case_opt(case)
+        opt, side, frames, batch = C.case_opt(case)
         assert (opt.ngf, opt.ndf, opt.nff, opt.gconv_hidden_dim) == (64, 64, 32, 512)
-        ts = TrainStep(opt, device, weights_seed=1)
+        with ops.deterministic():
+            ts = TrainStep(opt, device, weights_seed=C.WEIGHTS_SEED)
         shapes_G = {k: list(v.shape) for k, v in ts.model.state_dict().items()}
         shapes_D = {k: list(v.shape) for k, v in ts.discriminator.img_discriminator.state_dict().items()}
         dtmp = getattr(ts.discriminator, 'temporal_discriminator', None)
@@ -122,96 +145,79 @@ def _step_vs_oracle(case, prec, device):
         assert (dtmp is not None) == case.endswith('T')
         if case.startswith('c5'):
             assert opt.semantic_nc == 128 and len(opt.vocab['attributes']) == 1        # one attribute => 128 layout channels
-        ref = _oracle_step(case, shapes_G, shapes_D, shapes_T)
-        clip = _case_clip(case, opt, batch, frames, side, 1234)
-        mo, GL, DL = ts.gd_step(ts.to_device(clip))
+        refs = _oracle_steps(case, shapes_G, shapes_D, shapes_T)
+        clip = C.case_clip(case, opt, batch, frames, side, C.CLIP_SEED)
+        with ops.deterministic():
+            mo, GL, DL = ts.gd_step(ts.to_device(clip))
         if dtmp is not None:
             assert set(GL) >= {'GAN_Tmp', 'GAN_Tmp_Feat'} and set(DL) >= {'D_tmp_fake', 'D_tmp_real'}
-        for got, rf in ((GL, ref['GL']), (DL, ref['DL'])):
-            assert set(got) == set(rf)
-            for k in rf:
-                assert abs(got[k].item() - rf[k]) <= 1e-3 * max(1.0, abs(rf[k])), (k, got[k].item(), rf[k])
-        worst = {}
-        for i, name in enumerate(('imgs_pred', 'boxes_pred', 'flows_pred')):
-            r = ref['out'][i].numpy()
-            err = np.abs(mo[i].detach().cpu().numpy() - r).max()
-            worst[name] = err / np.abs(r).max()
-        print('%s [%s] output errors relative to max:' % (case, prec), worst)
-        for i, name in enumerate(('imgs_pred', 'boxes_pred', 'flows_pred')):
-            assert worst[name] <= (IMG_BOUND.get(case, 1e-3) if name == 'imgs_pred' else 1e-3), (name, worst)
-        assert np.mean(mo[3].cpu().numpy() != ref['out'][3].numpy()) < 2e-3
-        # gradients: abs-sum of every parameter's gradient (bounds: module docstring of tests/test_step_gpu.py)
-        bad, worst_g = [], {'front': (0.0, ''), 'decoder': (0.0, '')}
-        for n, prm in ts.model.named_parameters():
-            g_ref = ref['G_grads'].get(n)
-            if g_ref is None:
-                assert prm.grad is None or float(prm.grad.abs().sum()) == 0.0 or n.startswith('acts_to_boxes'), n
-                continue
-            assert prm.grad is not None, n
-            got = _stats(prm.grad)
-            front = 'flows_network' in n or n.startswith('acts_to_objs')
-            # tensors in FRONT of the whole generator (flow network, appearance graph net): their gradient sums thousands of decoder paths
-            # whose ReLU / hinge branches sit within fp32 rounding of zero, and the 4-element `acts_to_objs...box_net.2.bias` moves by
-            # 2.7 ... 5.4 % between runs of the SAME build (atomics order; measured over 9 runs at 256^2, both arithmetics and both
-            # weight-gradient kernels) -- 7e-2 there; decoder tensors measure 0.2 ... 0.7 % under their 2e-2.  Correctness of these
-            # gradients is pinned by tests/test_gradcheck_gpu.py (central differences), not by this statistic.
-            rel = 7e-2 if front else 2e-2
-            dev = abs(got[1] - g_ref[1]) / max(abs(g_ref[1]), 1e-30)
-            if abs(g_ref[1]) > 2e-6 * prm.numel() and dev > worst_g['front' if front else 'decoder'][0]:
-                worst_g['front' if front else 'decoder'] = (dev, n)
-            if abs(got[1] - g_ref[1]) > rel * abs(g_ref[1]) + 2e-6 * prm.numel():
-                bad.append((n, got[1], g_ref[1]))
-        print('%s [%s] worst gradient abs-sum deviations:' % (case, prec), worst_g)
-        assert not bad, (len(bad), bad[:10])
-        badd = []
-        for n, prm in ts.discriminator.img_discriminator.named_parameters():
-            g_ref = ref['D_grads'].get(n)
-            if g_ref is None or prm.grad is None:
-                continue
-            got = _stats(prm.grad)
-            if abs(got[1] - g_ref[1]) > 2e-2 * abs(g_ref[1]) + 2e-6 * prm.numel():
-                badd.append((n, got[1], g_ref[1]))
-        assert not badd, (len(badd), badd[:10])
-        if dtmp is not None:
-            badt = []
-            for n, prm in dtmp.named_parameters():
-                g_ref = ref['T_grads'].get(n)
-                if g_ref is None or prm.grad is None:
-                    continue
-                got = _stats(prm.grad)
-                if abs(got[1] - g_ref[1]) > 2e-2 * abs(g_ref[1]) + 2e-6 * prm.numel():
-                    badt.append((n, got[1], g_ref[1]))
-            assert not badt, (len(badt), badt[:10])
+        for tag in ('o64', 'o32'):
+            for got, rf in ((GL, refs[tag]['GL']), (DL, refs[tag]['DL'])):
+                assert set(got) == set(rf)
+                for k in rf:
+                    assert abs(got[k].item() - rf[k]) <= 1e-3 * max(1.0, abs(rf[k])), (tag, k, got[k].item(), rf[k])
+        got = _check_outputs(case, prec, mo, refs, 'deterministic')
+        worst = {name: got[('o32', name)][0] for name in ('imgs_pred', 'boxes_pred', 'flows_pred')}
+        # gradients: abs-sum of every parameter's gradient, against both oracles (bounds: header above and tests/test_step_gpu.py;
+        # correctness of the gradients themselves is pinned by tests/test_gradcheck_gpu.py (central differences) and the kernel tests)
+        for tag in ('o64', 'o32'):
+            ref = refs[tag]
+            bad, worst_g = _grad_report(ts.model.named_parameters(), ref['G_grads'],
+                                        lambda n: ('front', 5e-2) if C.is_front(n) else ('decoder', 2e-2), allow_missing='acts_to_boxes')
+            badd, worst_d = _grad_report(ts.discriminator.img_discriminator.named_parameters(), ref['D_grads'], lambda n: ('D', 2e-2))
+            worst_g.update(worst_d)
+            if dtmp is not None:
+                badt, worst_t = _grad_report(dtmp.named_parameters(), ref['T_grads'], lambda n: ('T', 2e-2))
+                worst_g.update(worst_t)
+                badd += badt
+            print('%s [%s] worst gradient abs-sum deviations against %s:' % (case, prec, tag), worst_g)
+            assert not bad, (tag, len(bad), bad[:10])
+            assert not badd, (tag, len(badd), badd[:10])
         # graph step on a 4x longer clip (train.py:471-493)
-        gclip = _case_clip(case, opt, batch, 4 * frames, side, 4321)
-        bp, GG = ts.graph_step(ts.to_device(gclip))
-        for k, v in ref['GG'].items():
-            assert abs(GG[k].item() - v) <= 1e-3 * max(1.0, abs(v)), (k, GG[k].item(), v)
-        bp_r = ref['bp'].numpy()
-        assert np.abs(bp.detach().cpu().numpy() - bp_r).max() <= 1e-3 * np.abs(bp_r).max()
+        gclip = C.case_clip(case, opt, batch, 4 * frames, side, C.GRAPH_CLIP_SEED)
+        with ops.deterministic():
+            bp, GG = ts.graph_step(ts.to_device(gclip))
+        for tag in ('o64', 'o32'):
+            ref = refs[tag]
+            for k, v in ref['GG'].items():
+                assert abs(GG[k].item() - v) <= 1e-3 * max(1.0, abs(v)), (tag, k, GG[k].item(), v)
+            assert C.out_errors(bp, ref['bp'])[0] <= 1e-3, tag
         # every state tensor after the three optimizer steps: buffers (spectral-norm u / v, running statistics) element-wise at
         # 1e-3 of their max; parameters through (abs-sum, L2) at 1e-3 + Adam's first-step floor lr per element (a parameter whose
         # true gradient is zero moves by +-lr in a rounding-determined direction)
         floor = 1.2 * opt.learning_rate
-        bad_state, n_keys = [], 0
-        for tag, sd in (('G', ts.model.state_dict()), ('D', ts.discriminator.img_discriminator.state_dict())):
-            assert set(sd) == set(k for (t, k) in ref['state'] if t == tag)
-            for k, v in sd.items():
-                rstat, n, rbuf = ref['state'][(tag, k)]
-                n_keys += 1
-                if rbuf is not None:
-                    err = (v.detach().cpu() - rbuf).abs().max().item()
-                    if err > 1e-3 * max(rbuf.abs().max().item(), 1e-6):
-                        bad_state.append((k, 'buffer', err, rbuf.abs().max().item()))
-                got = _stats(v.float())
-                for i, fl in ((1, floor * n), (2, floor * n ** 0.5)):
-                    if abs(got[i] - rstat[i]) > 1e-3 * abs(rstat[i]) + fl:
-                        bad_state.append((k, i, got[i], rstat[i]))
-        # (CATER: 4 attributes => the reference's 492 + 56 keys; one attribute: AttributeEmbeddings has no mixing Linear,
-        # attribute_embed.py:29-46 -- the key sets were compared with the oracle's above either way)
-        assert n_keys == (492 + 56 if not case.startswith('c5') else len(ref['state'])) and n_keys >= 500
-        assert not bad_state, (len(bad_state), bad_state[:10])
-        print('%s default widths [%s]: worst output errors relative to max:' % (case, prec), worst)
+        for tag in ('o64', 'o32'):
+            ref = refs[tag]
+            bad_state, n_keys = [], 0
+            for t, sd in (('G', ts.model.state_dict()), ('D', ts.discriminator.img_discriminator.state_dict())):
+                assert set(sd) == set(k for (tt, k) in ref['state'] if tt == t)
+                for k, v in sd.items():
+                    rstat, n, rbuf = ref['state'][(t, k)]
+                    n_keys += 1
+                    if rbuf is not None:
+                        err = (v.detach().cpu().double() - rbuf.double()).abs().max().item()
+                        if err > 1e-3 * max(rbuf.abs().max().item(), 1e-6):
+                            bad_state.append((k, 'buffer', err, rbuf.abs().max().item()))
+                    gotst = C.stats(v.float())
+                    for i, fl in ((1, floor * n), (2, floor * n ** 0.5)):
+                        if abs(gotst[i] - rstat[i]) > 1e-3 * abs(rstat[i]) + fl:
+                            bad_state.append((k, i, gotst[i], rstat[i]))
+            # (CATER: 4 attributes => the reference's 492 + 56 keys; one attribute: AttributeEmbeddings has no mixing Linear,
+            # attribute_embed.py:29-46 -- the key sets were compared with the oracle's above either way)
+            assert n_keys == (492 + 56 if not case.startswith('c5') else len(ref['state'])) and n_keys >= 500
+            assert not bad_state, (tag, len(bad_state), bad_state[:10])
+        del ts
+        # the default (non-deterministic) path, once: same weights, same clip, forward + losses.  Reported; gated on relative L2 and on
+        # the losses only -- its max-norm varies from launch to launch with the order of the split-K atomics
+        ts2 = TrainStep(opt, device, weights_seed=C.WEIGHTS_SEED)
+        mo2, GL2, DL2 = ts2.gd_step(ts2.to_device(clip))
+        for got2, rf in ((GL2, refs['o64']['GL']), (DL2, refs['o64']['DL'])):
+            for k in rf:
+                assert abs(got2[k].item() - rf[k]) <= 1e-3 * max(1.0, abs(rf[k])), ('default path', k, got2[k].item(), rf[k])
+        _check_outputs(case, prec, mo2, refs, 'default path (spread report)', gate_max=False)
+        det_vs_default = C.out_errors(mo2[0], mo[0])
+        print('%s [%s] default path against deterministic path, imgs_pred (max-norm, relative L2): %.2e %.2e' % ((case, prec) + det_vs_default))
+        del ts2
         return worst
     finally:
         ops.set_conv_precision(old)
@@ -236,35 +242,34 @@ def test_step_c3prime_default_widths_matches_oracle(prec, device):
 
 
 def test_c3prime_flow_forward_margin(device):
-    """How much of the 1e-3 output bound the flow network's forward arithmetic uses at 256 x 256: imgs_pred / flows_pred against the
-    oracle with that forward on (a) the fp16 3-term split -- the product's policy since round 3, must hold 1e-3 --, (b) the exact fp32
+    """How much of the output bound the flow network's forward arithmetic uses at 256 x 256: imgs_pred / flows_pred against the fp64
+    oracle (deterministic mode) with that forward on (a) the fp16 3-term split -- the product's policy since round 3, must hold the step test's bound --, (b) the exact fp32
     tiles (rounds 1-2), (c) the bf16 3-term split (AG2V_FLOW_FWD diagnostic switch).  (b) and (c) are reported; (c) is asserted only to
     stay a small error (< 1e-2): it documents why the bf16 split is not used there."""
     import os
     from ag2video_amd import ops
     from ag2video_amd.data.synthetic import make_clip_batch
     from ag2video_amd.engine import TrainStep
-    opt, side, frames, batch = _case_opt('c3p')
+    opt, side, frames, batch = C.case_opt('c3p')
     errs = {}
     for label in ('h16', 'exact', 'bf16'):
         os.environ['AG2V_FLOW_FWD'] = label
         try:
-            with ops.conv_precision('bf16x3'):
+            with ops.conv_precision('bf16x3'), ops.deterministic():
                 ts = TrainStep(opt, device, weights_seed=1)
                 shapes_G = {k: list(v.shape) for k, v in ts.model.state_dict().items()}
                 shapes_D = {k: list(v.shape) for k, v in ts.discriminator.img_discriminator.state_dict().items()}
-                ref = _oracle_step('c3p', shapes_G, shapes_D)
+                ref = _oracle_steps('c3p', shapes_G, shapes_D)['o64']
                 clip = ts.to_device(make_clip_batch(opt.vocab, batch, frames, (side, side), seed=1234))
                 with torch.no_grad():
                     mo = ts.model(clip[0], clip[1], clip[3], clip[4], boxes_gt=clip[2], test_mode=False, use_gt=True)
             for i, name in ((0, 'imgs_pred'), (2, 'flows_pred')):
-                r = ref['out'][i].numpy()
-                errs[(label, name)] = float(np.abs(mo[i].detach().cpu().numpy() - r).max() / np.abs(r).max())
+                errs[(label, name)] = C.out_errors(mo[i], ref['out'][i])[0]
             del ts
         finally:
             os.environ.pop('AG2V_FLOW_FWD', None)
     print('c3p flow-forward margin (error / max|ref|):', errs)
-    assert errs[('h16', 'imgs_pred')] <= 1e-3, errs
+    assert errs[('h16', 'imgs_pred')] <= _img_bounds('c3p')[0], errs
     assert errs[('h16', 'flows_pred')] <= 2.0 * errs[('exact', 'flows_pred')] + 1e-6, errs       # fp32-class
     assert errs[('bf16', 'imgs_pred')] <= 1e-2, errs
 

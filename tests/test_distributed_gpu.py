@@ -52,6 +52,13 @@ def test_rccl_path_on_gpu_matches_single_process(device, tmp_path):
     assert len(set(res['param_checksums'])) == 1
     e = res['sync_bn_err']                                           # synchronised batch norm vs an fp64 evaluation of the formula:
     assert e[0] <= 1e-5 and e[1] <= 5e-4 and e[2] <= 1e-6 and e[3] <= 1e-5, e          # y, dx, running_mean, running_var
+    import math
+    assert res['held_step'] and all(math.isfinite(v) for v in res['held_step'].values()), res['held_step']      # 64 CUs held by another stream
+    if n == 1:      # a whole --sync_bn 1 step on the fused paths: against the oracle's multi-device formula, and against the unfused paths
+        ss = res['sync_step']
+        assert ss['n_running_var'] >= 20, ss
+        assert ss['loss_vs_oracle'] <= 1e-3 and ss['running_var_vs_oracle'] <= 1e-3, ss
+        assert ss['loss_fused_vs_plain'] <= 1e-4 and ss['running_var_fused_vs_plain'] <= 1e-5, ss
     # the same step without torch.distributed, in this process
     flags = ['--no_vgg_loss', '--image_size', '64,64', '--batch_size', '2', '--ngf', '8', '--ndf', '8', '--nff', '8',
              '--gconv_hidden_dim', '64', '--gpu_ids', '0']

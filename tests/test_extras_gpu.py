@@ -9,6 +9,17 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _deterministic_reductions():
+    """Every comparison with the reference golden / the oracle in this file runs with ops.deterministic(): the compared value is then
+    a property of the build, not of one launch's split-K atomics order (VERDICT r04 next #1b).  The default path's kernels are pinned
+    one by one in tests/test_ops_gpu.py, test_halo_gpu.py, test_grad_slots_gpu.py and, as a step, by the spread report of
+    tests/test_configs_gpu.py."""
+    from ag2video_amd import ops
+    with ops.deterministic():
+        yield
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
@@ -52,13 +63,14 @@ def test_vgg_loss_matches_reference_golden(prec, gold, device):
         loss.backward()
         ref = float(gold['vgg.loss'])
         assert abs(loss.item() - ref) <= 1e-3 * abs(ref), (loss.item(), ref)
-        # d|a - b| is a sign function: a feature pair closer than the arithmetic's rounding flips its whole term, so single
-        # elements are held to 3e-2 of the largest gradient (fp32: 2e-3 measured; bf16x3: 6e-2 -- which pairs flip varies with the
-        # summation order of split-K launches, 1 run in ~10 exceeded 3e-2) and the mean deviation to 2e-3.  bf16x3, 40 runs in one process
-        # (tools/debug_vgg_grad_spread.py): max deviation 2.13e-2 of the largest gradient in every run; mean deviation 3.05e-4 of the mean
-        # in 39 runs and 2.36e-3 in one (one flipped term); relative L2 2.9e-3 / 5.1e-3 -> bounds 6e-2, 1e-2, 2e-2
+        # d|a - b| is a sign function: a feature pair closer than the arithmetic's rounding flips its whole term.  The reference golden
+        # sits 5e-7 from the fp64 oracle here (tests/golden/noise_floor.json `vgg_grad`): fp32 on the CPU flips no term on this input, so
+        # every flipped term is this implementation's -- its summation order (fp32 mode: 2e-3 of the largest gradient) or the 2^-17
+        # product error of the 3-term bf16 split (2.1e-2 of the largest gradient = one term; mean deviation 3e-4 of the mean).  Single
+        # elements are therefore held to 3e-2 / 6e-2 of the largest gradient (one term), the MEAN deviation to 2e-3 and the relative L2
+        # to 2e-2, in deterministic mode (the fixture above) where the set of flipped terms is a property of the build
         rg, gg = gold['vgg.grad_x'], x.grad.cpu().numpy()
-        tol_max, tol_mean = (3e-2, 2e-3) if prec == 'fp32' else (6e-2, 1e-2)
+        tol_max, tol_mean = (3e-2, 2e-3) if prec == 'fp32' else (6e-2, 2e-3)
         assert np.abs(gg - rg).max() <= tol_max * np.abs(rg).max() and np.abs(gg - rg).mean() <= tol_mean * np.abs(rg).mean()
         assert np.linalg.norm(gg - rg) <= 2e-2 * np.linalg.norm(rg)
     finally:

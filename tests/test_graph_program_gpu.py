@@ -11,6 +11,7 @@ differently, and in the default-width case ONE ReLU of (step 10, layer 2) sits w
 -- the paths take different sides, which moves that step's gradient by 1e-2 and every parameter gradient by 3e-3 (tools/
 debug_graph_hooks.py localises it; the oracle run in fp64 on the CPU sides with one path, fp64 autograd on the GPU inputs with the
 other).  A wiring error (a missing term, a wrong time index) is O(1) in this norm."""
+import ctypes
 import os
 
 import pytest
@@ -318,3 +319,40 @@ def test_timeout_flags_are_read_back(device):
         gp.check_timeouts()
     assert not gp._ring['pending']
     gp._ring['host'][slot] = 0
+
+
+@pytest.mark.parametrize("held,ms", [(64, 60.0), (192, 100.0), (256, 40.0)], ids=['64cus_whole_run', '192cus_100ms', 'all_cus_40ms'])
+def test_program_finishes_when_another_stream_holds_cus(held, ms, device):
+    """the programs' grid barriers need all 128 workgroups resident, and at > 1 rank another stream (RCCL's
+    all-reduce, a persistent convolution on the side stream) holds CUs while they run.  ag2v_debug_hold_cus occupies `held` CUs (1024
+    threads + 128 KB of LDS each: no program workgroup can share them) for `ms` milliseconds on a second stream, launched FIRST; the
+    program -- 6 dependent operators, a grid barrier behind each -- must complete with correct results and no timeout flag: with 64
+    CUs held the rest of the chip takes it at once, with 192 or all of them held its workgroups become resident as the holders retire,
+    far inside the barrier's 2 s wall-clock limit."""
+    from ag2video_amd import _lib
+    from ag2video_amd import graph_program as gp
+    gp.check_timeouts()
+    P = gp.Program(device)
+    a = torch.randn(96, 64, device=device) * 0.2
+    w = torch.randn(64, 64, device=device) * 0.2
+    bufs = [P.new(96, 64) for _ in range(6)]
+    P.gemm(P.ext(a), P.ext(w), bufs[0], relu=True)
+    for i in range(1, 6):
+        P.gemm(bufs[i - 1], P.ext(w), bufs[i], relu=True)       # each operator reads every tile of the previous one
+    P.finalize()
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+    t0.record()
+    with torch.cuda.stream(side):
+        _lib.call('ag2v_debug_hold_cus', held, float(ms), ctypes.c_void_p(side.cuda_stream))
+    P.run()
+    t1.record()
+    torch.cuda.synchronize()
+    assert not P.timed_out()
+    gp.check_timeouts()
+    y = torch.relu(a @ w.t())
+    for i in range(1, 6):
+        y = torch.relu(y @ w.t())
+    assert (P.tensor(bufs[5]) - y).abs().max().item() <= 1e-5 * y.abs().max().item()
+    print('program beside %d held CUs (%.0f ms): %.1f ms' % (held, ms, t0.elapsed_time(t1)))     # (which kernel's workgroups land first is the dispatcher's choice)

@@ -4,7 +4,8 @@ split words' exact values, and against the wave-specialised kernels they replace
 every patch geometry (TW x TH = 128x2, 64x4, 32x8 for the 64- / 128-row tiles; 128x1, 64x2, 32x4 for the 256-row tile), row counts
 that do not fill the last row tile, every epilogue (bias, ReLU, residual, per-group scale, ReLU mask, split-word output), the data
 gradient, image borders on all four sides and several images per launch.  AG2V_HALO_MIN_TILES=1 lets these small shapes take the
-kernels (the product only sends launches with >= 512 tiles there)."""
+kernels (the product only sends launches with >= ag2v_halo_min_tiles() = 384 tiles there).  The switches are cached by the library:
+ag2v_halo_reload_env() after every change."""
 import os
 
 import pytest
@@ -25,6 +26,12 @@ def _from_split_words(t):
     return (wd & -65536).view(torch.float32) + (wd << 16).view(torch.float32)
 
 
+def _reload():
+    from ag2video_amd import _lib
+    torch.cuda.synchronize()
+    _lib.call('ag2v_halo_reload_env')
+
+
 class _halo(object):
     """on: False = the previous kernels; True / '16' = the 16x16x32 halo kernels (the default); '32' = the 32x32x16 halo kernels."""
 
@@ -41,6 +48,7 @@ class _halo(object):
                 os.environ['AG2V_HALO_MFMA32'] = '1'
         else:
             os.environ['AG2V_NO_HALO'] = '1'
+        _reload()
 
     def __exit__(self, *exc):
         for k, v in self.old.items():
@@ -48,6 +56,7 @@ class _halo(object):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+        _reload()
         return False
 
 

@@ -180,3 +180,27 @@ def test_inference_driver_scripted_edits():
     init = [k for k in e3 if k not in ('up', 'down', 'left', 'right', 'down_left', 'right_up')]
     assert len(init) == 1 and tuple(e3[init[0]]['now'].shape) == (1, 2, 7)      # every row of the clip, re-timed
     assert e3[init[0]]['now'][0, :, 4].tolist() == pytest.approx([1.1, 1.1])
+
+
+def test_grad_slots_only_hold_slices_written_in_this_pass():
+    """ops._GradSlots: a channel slice of the shared gradient buffer counts as the consumer's gradient only after that
+    consumer's backward of THIS pass has marked it written; a re-taken view, a re-allocated buffer or a dropped one un-marks it."""
+    import torch
+    from ag2video_amd.ops import _GradSlots
+    s = _GradSlots([3, 5])
+    cpu = torch.device('cpu')
+    a = s.view(0, 2, 4, 4, cpu)
+    b = s.view(1, 2, 4, 4, cpu)
+    assert tuple(a.shape) == (2, 3, 4, 4) and tuple(b.shape) == (2, 5, 4, 4) and a.data_ptr() == s.buf.data_ptr()
+    assert not s.holds(0, a) and not s.holds(1, b)              # nothing launched yet
+    s.mark(0)
+    assert s.holds(0, a) and not s.holds(1, b)
+    s.mark(1)
+    assert s.holds(1, b) and not s.holds(1, a) and not s.holds(0, torch.zeros(2, 3, 4, 4))
+    a2 = s.view(0, 2, 4, 4, cpu)                                  # the consumer's backward runs again (retain_graph): unwritten until marked
+    assert a2.data_ptr() == a.data_ptr() and not s.holds(0, a2) and s.holds(1, b)
+    s.view(0, 3, 4, 4, cpu)                                       # another batch size: a new buffer, nothing written
+    assert not s.holds(1, b) and s.written == set()
+    s.mark(0)
+    s.drop()
+    assert s.buf is None and not s.holds(0, a)

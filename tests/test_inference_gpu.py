@@ -15,6 +15,17 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _deterministic_reductions():
+    """Every comparison with the reference golden / the oracle in this file runs with ops.deterministic(): the compared value is then
+    a property of the build, not of one launch's split-K atomics order (VERDICT r04 next #1b).  The default path's kernels are pinned
+    one by one in tests/test_ops_gpu.py, test_halo_gpu.py, test_grad_slots_gpu.py and, as a step, by the spread report of
+    tests/test_configs_gpu.py."""
+    from ag2video_amd import ops
+    with ops.deterministic():
+        yield
 HERE = os.path.dirname(os.path.abspath(__file__))
 TOY = ['--image_size', '64,64', '--batch_size', '2', '--ngf', '8', '--ndf', '8', '--nff', '8', '--gconv_hidden_dim', '64']
 

@@ -131,3 +131,41 @@ def test_oracle_matches_reference_two_iterations(gold):
             _close_stats(p + 'G_state.' + n, _stats(t.float()), gold[p + 'G_state.' + n], srel, t.numel(), adam_floor)
         for n, t in tr.D.items():
             _close_stats(p + 'D_state.' + n, _stats(t.float()), gold[p + 'D_state.' + n], srel, t.numel(), adam_floor)
+
+
+def test_oracle_fp64_mode_and_committed_noise_floor():
+    """oracle/step.py dtype=torch.float64 (the exact-arithmetic run of the SAME fp32 weights and clip that the GPU step tests compare with
+    beside the fp32 oracle) on the toy configuration: every tensor of the iteration is double, the fp32 oracle sits within fp32 rounding of
+    it, and tests/golden/noise_floor.json (tests/golden/make_noise_floor.py) holds a floor for every step case the GPU tests gate."""
+    import json
+    import sys
+    sys.path.insert(0, HERE)
+    import _cases as C
+    from ag2video_amd.data.args import make_opt
+    from ag2video_amd.data.synthetic import make_clip_batch
+    from ag2video_amd.data.vocab import cater_vocab
+    from oracle.step import OracleTrainer, toy_key_shapes
+    gold = np.load(os.path.join(HERE, 'golden', 'toy64_step.npz'), allow_pickle=False)
+    opt = make_opt(cater_vocab(), json.loads(str(gold['meta.flags'])))
+    toy = json.loads(str(gold['meta.toy']))
+    sG, sD, _ = toy_key_shapes()
+    clip = make_clip_batch(opt.vocab, toy['batch'], toy['frames'], tuple(toy['size']), seed=toy['seed'])
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        tr = OracleTrainer(opt, sG, sD, toy['wseed'], dtype=dt)
+        mo, GL, DL = tr.gd_step(clip)
+        assert all(t.dtype == dt for t in mo[:4]) and all(v.dtype == dt for v in GL.values())
+        assert all(t.dtype == dt for t in tr.G.values() if t.is_floating_point())
+        res[dt] = (mo, GL, DL)
+    assert torch.get_default_dtype() == torch.float32                   # the fp64 run restores the default dtype
+    for i in range(3):
+        mx, l2 = C.out_errors(res[torch.float32][0][i], res[torch.float64][0][i])
+        assert mx <= 1e-3 and l2 <= 3e-4, (i, mx, l2)
+    for k, v in res[torch.float64][1].items():
+        assert abs(float(res[torch.float32][1][k]) - float(v)) <= 1e-5 * max(1.0, abs(float(v))), k
+    floor = json.load(open(os.path.join(HERE, 'golden', 'noise_floor.json')))
+    for case in C.STEP_CASES:
+        smp = floor[case]['imgs_pred_o32_samples_vs_o64']
+        assert len(smp) >= 3 and all(0 < v['l2'] < 1e-3 and 0 < v['max'] < 5e-3 for v in smp.values()), (case, smp)
+        assert set(floor[case]['o32_vs_o64']['grad']) >= {'front', 'decoder', 'D'}
+    assert floor['vgg_grad']['reference_golden_vs_o64']['l2'] < 1e-5

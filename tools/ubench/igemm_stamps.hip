@@ -4,8 +4,9 @@
 #define AG2V_STAMPS 1
 #endif
 #include "../../ag2video_amd/csrc/conv_bf16x3.hip"
+#include "../../ag2video_amd/csrc/conv_halo.hip"      // launch_igemm_bf16x3 hands 3x3 stride-1 split-word launches to these (AG2V_NO_HALO=1 keeps the stamped kernel)
 void set_last_conv_kernel(const char*) {}
-int launch_act_mask(float*, const float*, long long, int, hipStream_t) { return 0; }
+int launch_act_mask(float*, const float*, long long, int, hipStream_t, int) { return 0; }
 #include <stdio.h>
 #include <vector>
 int main(int argc, char** argv) {
