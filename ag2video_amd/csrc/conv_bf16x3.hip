@@ -1456,6 +1456,7 @@ int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed) {
 }
 
 void plan_wgrad_bf16x3(ConvArgs& a) {
+    if (wgrad_halo_ok(a)) { plan_wgrad_halo(a); return; }
     const bool tall = a.M >= 192 && ceil_div(a.M, 256) * 256 <= ceil_div(a.M, 128) * 128;     // see launch_igemm_bf16x3
     const int bm = tall ? 256 : 128, bn = tall ? 128 : 256;
     a.tiles_m = ceil_div(a.M, bm);
@@ -1480,6 +1481,7 @@ bool wgrad_f32_ws_ok(const ConvArgs& a) {
 }
 
 int launch_wgrad_bf16x3(ConvArgs& a, hipStream_t st) {
+    if (wgrad_halo_ok(a)) return launch_wgrad_halo(a, st);
     plan_wgrad_bf16x3(a);
     const bool tall = a.M >= 192 && ceil_div(a.M, 256) * 256 <= ceil_div(a.M, 128) * 128;
     const int tiles = a.tiles_m * a.tiles_n;

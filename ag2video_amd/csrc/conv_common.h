@@ -187,6 +187,10 @@ bool igemm_halo_ok(const ConvArgs& a);
 int launch_igemm_halo(ConvArgs& a, hipStream_t st);
 void plan_wgrad_bf16x3(ConvArgs& a);      // tiles, pixel-range splits per group (a.spg), a.splitk, a.kchunk -- what the launch will use
 int launch_wgrad_bf16x3(ConvArgs& a, hipStream_t st);
+// conv_wgrad_halo.hip: 3x3 stride-1 weight gradients on split-word operands, both staged by LDS-DMA (plan_ / launch_wgrad_bf16x3 ask first)
+bool wgrad_halo_ok(const ConvArgs& a);
+void plan_wgrad_halo(ConvArgs& a);
+int launch_wgrad_halo(ConvArgs& a, hipStream_t st);
 bool wgrad_f32_ws_ok(const ConvArgs& a);   // exact-fp32 weight gradient on the 16-byte-load pipeline (ConvArgs::f32 = 1, a_bytes / b_bytes set)
 // dw[g][i] = (accumulate ? dw[g][i] : 0) + sum_{sl < spg, in order} slabs[(g * spg + sl) * mn + i]   (conv_igemm.hip)
 int launch_wgrad_det_reduce(const float* slabs, float* dw, long long mn, int groups, int spg, int accumulate, hipStream_t st);

@@ -835,7 +835,7 @@ static bool halo_geometry(int BN, int OH, int OW, int& TW, int& TH) {
 // not thread-safe, and the autograd thread launches kernels while the main thread may be editing os.environ -- ADVICE r04) and again
 // only when ag2v_halo_reload_env() is called (tests and tools/halo_bench.py call it after changing the variables, with no launch in
 // flight).  None of them changes results beyond the summation order of the kernel family selected.
-struct HaloSwitches { int no_halo, tall, mfma32, no_h16, no_f32in, min_tiles; };
+struct HaloSwitches { int no_halo, tall, mfma32, no_h16, no_f32in, min_tiles, no_wgrad_halo; };
 static HaloSwitches read_halo_switches() {
     HaloSwitches h;
     h.no_halo = getenv("AG2V_NO_HALO") != nullptr;
@@ -843,6 +843,7 @@ static HaloSwitches read_halo_switches() {
     h.mfma32 = getenv("AG2V_HALO_MFMA32") != nullptr;
     h.no_h16 = getenv("AG2V_NO_HALO_H16") != nullptr;
     h.no_f32in = getenv("AG2V_NO_HALO_F32IN") != nullptr;
+    h.no_wgrad_halo = getenv("AG2V_NO_WGRAD_HALO") != nullptr;      // (conv_wgrad_halo.hip: weight gradients on the previous kernels)
     const char* mt = getenv("AG2V_HALO_MIN_TILES");                 // (tests run small shapes through these kernels)
     h.min_tiles = mt ? atoi(mt) : 384;                              // small maps: the split-K kernels fill the chip better
     return h;
@@ -853,6 +854,7 @@ extern "C" int ag2v_halo_reload_env(void) {
     return AG2V_OK;
 }
 extern "C" int ag2v_halo_min_tiles(void) { return g_halo_sw.min_tiles; }
+bool wgrad_halo_switched_off() { return g_halo_sw.no_wgrad_halo != 0; }
 
 // 256-row tile (128 pixels) when there are enough rows and it pads no more rows than the 128-row tile (256 pixels) does
 static bool halo_tall(int M) {

@@ -1,0 +1,121 @@
+"""The LDS-DMA weight-gradient kernel (csrc/conv_wgrad_halo.hip: 3x3 stride-1 weight gradients whose operands are split words -- the
+SPADE decoder's mlp_shared / gamma | beta / conv_0 / conv_1 layers, reference normalization.py:90-94, architecture.py:29-32) against
+(a) fp64 autograd of nn.Conv2d on the split words' exact values (2e-5 of max: bf16x3 products, another summation order) and (b) the
+wave-specialised 16-byte-load kernels it replaces (AG2V_NO_WGRAD_HALO=1: the same products, 1e-5): every strip position (left / interior /
+right image edge, one-strip-wide maps), rows beyond M in the last row tile, several images per workgroup and strips split over workgroups,
+sample groups (per-frame-group gradients), accumulation onto an existing gradient, and the deterministic mode (bit-identical runs)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _to_split_words(x):
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    w = (hi.view(torch.int16).to(torch.int32) << 16) | (lo.view(torch.int16).to(torch.int32) & 0xFFFF)
+    return w.view(torch.float32)
+
+
+def _from_split_words(t):
+    wd = t.view(torch.int32)
+    return (wd & -65536).view(torch.float32) + (wd << 16).view(torch.float32)
+
+
+class _wgrad_halo(object):
+    def __init__(self, on):
+        self.on = on
+
+    def _set(self, off):
+        from ag2video_amd import _lib
+        if off:
+            os.environ['AG2V_NO_WGRAD_HALO'] = '1'
+        else:
+            os.environ.pop('AG2V_NO_WGRAD_HALO', None)
+        torch.cuda.synchronize()
+        _lib.call('ag2v_halo_reload_env')
+
+    def __enter__(self):
+        self.old = os.environ.get('AG2V_NO_WGRAD_HALO')
+        self._set(not self.on)
+
+    def __exit__(self, *exc):
+        self._set(self.old is not None)
+        return False
+
+
+def _wgrad(dys, xs, K, groups=1, acc_into=None):
+    from ag2video_amd import _lib, ops
+    C = xs.shape[1]
+    shape = ((groups,) if groups > 1 else ()) + (K, C, 3, 3)
+    dw = acc_into.clone() if acc_into is not None else torch.full(shape, float('nan'), device=xs.device)
+    with ops.conv_precision('bf16x3'), torch.no_grad():
+        ops._conv_wgrad_launch(32, dys, xs, dw, K, 3, 3, 1, 1, 1 if acc_into is not None else 0, groups=groups, in_split=True, dy_split=True)
+    return dw, _lib.query('ag2v_last_conv_kernel')
+
+
+def _ref64(dys, xs, K, groups=1):
+    x = _from_split_words(xs).double()
+    dy = _from_split_words(dys).double()
+    N = x.shape[0]
+    outs = []
+    for g in range(groups):
+        sl = slice(g * (N // groups), (g + 1) * (N // groups))
+        w = torch.zeros(K, x.shape[1], 3, 3, dtype=torch.float64, device=x.device, requires_grad=True)
+        y = torch.nn.functional.conv2d(x[sl], w, None, 1, 1)
+        y.backward(dy[sl])
+        outs.append(w.grad)
+    return torch.stack(outs) if groups > 1 else outs[0]
+
+
+# (N, C, H, W, K, groups)
+CASES = [(2, 64, 16, 32, 128, 1),        # one strip per image row: left AND right edge in one strip
+         (3, 64, 32, 64, 128, 1),        # two strips: a left and a right one
+         (2, 128, 16, 128, 96, 1),       # four strips (interior ones), two channel tiles, 96 rows on a 128-row tile
+         (5, 64, 24, 96, 200, 1),        # W = 3 strips, H not a power of two, 200 rows = two row tiles (the second with 72 rows)
+         (6, 64, 16, 64, 128, 3),        # three sample groups
+         (16, 128, 64, 64, 384, 1),      # enough strips for several workgroups per tile
+         (2, 64, 224, 224, 128, 1)]      # c5's 224 = 7 strips
+
+
+@pytest.mark.parametrize("cfg", CASES, ids=str)
+def test_wgrad_halo_matches_fp64_and_previous_kernels(cfg, device):
+    N, C, H, W, K, groups = cfg
+    g = torch.Generator().manual_seed(7)
+    xs = _to_split_words(torch.randn(N, C, H, W, generator=g).to(device))
+    dys = _to_split_words(torch.randn(N, K, H, W, generator=g).to(device))
+    ref = _ref64(dys, xs, K, groups)
+    with _wgrad_halo(True):
+        new, name = _wgrad(dys, xs, K, groups)
+        assert name == b'conv_wgrad_halo_bf16x3_kernel', name
+    with _wgrad_halo(False):
+        old, name_o = _wgrad(dys, xs, K, groups)
+        assert name_o.startswith(b'conv_wgrad_bf16x3_v'), name_o
+    scale = ref.abs().max().item()
+    assert torch.isfinite(new).all()
+    assert (new.double() - ref).abs().max().item() <= 2e-5 * scale, ((new.double() - ref).abs().max().item() / scale)
+    assert (new - old).abs().max().item() <= 1e-5 * scale, ((new - old).abs().max().item() / scale)
+
+
+def test_wgrad_halo_accumulates_and_is_deterministic_on_request(device):
+    from ag2video_amd import ops
+    N, C, H, W, K = 8, 64, 32, 64, 128
+    g = torch.Generator().manual_seed(11)
+    xs = _to_split_words(torch.randn(N, C, H, W, generator=g).to(device))
+    dys = _to_split_words(torch.randn(N, K, H, W, generator=g).to(device))
+    base = torch.randn(K, C, 3, 3, generator=g).to(device)
+    ref = _ref64(dys, xs, K)
+    with _wgrad_halo(True):
+        acc, name = _wgrad(dys, xs, K, acc_into=base)
+        assert name == b'conv_wgrad_halo_bf16x3_kernel'
+        assert (acc.double() - (ref + base.double())).abs().max().item() <= 2e-5 * ref.abs().max().item()
+        with ops.deterministic():
+            d1, name = _wgrad(dys, xs, K)
+            d2, _ = _wgrad(dys, xs, K)
+            d3, _ = _wgrad(dys, xs, K, acc_into=base)
+        assert name == b'conv_wgrad_halo_bf16x3_kernel'
+        assert torch.equal(d1, d2)
+        assert (d1.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+        assert (d3.double() - (ref + base.double())).abs().max().item() <= 2e-5 * ref.abs().max().item()

@@ -1,0 +1,56 @@
+"""conv_wgrad_halo_bf16x3_kernel against the 16-byte-load weight-gradient kernels it replaces, on c3 layer shapes (frame-batched chunk
+sizes), alternating in one process: time / TF-equivalent, and the difference of the results.  usage: wgrad_halo_bench.py [reps]"""
+import os
+import sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ag2video_amd import ops, _lib
+
+SHAPES = [(21, 512, 256, 256, 384), (60, 128, 256, 256, 256), (120, 128, 128, 128, 512), (120, 512, 128, 128, 384), (60, 128, 256, 256, 128),
+          (120, 128, 64, 64, 1024), (120, 512, 64, 64, 384), (120, 256, 128, 128, 128)]
+
+
+def to_split(x):
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    return ((hi.view(torch.int16).to(torch.int32) << 16) | (lo.view(torch.int16).to(torch.int32) & 0xFFFF)).view(torch.float32)
+
+
+def mode(new):
+    if new:
+        os.environ.pop('AG2V_NO_WGRAD_HALO', None)
+    else:
+        os.environ['AG2V_NO_WGRAD_HALO'] = '1'
+    torch.cuda.synchronize()
+    _lib.call('ag2v_halo_reload_env')
+
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+dev = torch.device('cuda')
+for (N, C, H, W, K) in SHAPES:
+    xs = to_split(torch.randn(N, C, H, W, device=dev))
+    dys = to_split(torch.randn(N, K, H, W, device=dev))
+    dw = {True: torch.empty(K, C, 3, 3, device=dev), False: torch.empty(K, C, 3, 3, device=dev)}
+    best, names = {True: 1e9, False: 1e9}, {}
+    with ops.conv_precision('bf16x3'), torch.no_grad():
+        for rnd in range(3):
+            for new in (False, True):
+                mode(new)
+                run = lambda: ops._conv_wgrad_launch(32, dys, xs, dw[new], K, 3, 3, 1, 1, 0, in_split=True, dy_split=True)
+                run()
+                names[new] = _lib.query('ag2v_last_conv_kernel').decode()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(reps):
+                    run()
+                b.record()
+                torch.cuda.synchronize()
+                best[new] = min(best[new], a.elapsed_time(b) / reps)
+    mode(True)
+    fl = 2.0 * N * K * H * W * C * 9
+    err = float((dw[True] - dw[False]).abs().max() / dw[False].abs().max())
+    print('wgrad %-28s old %7.3f ms %6.1f TF | new %7.3f ms %6.1f TF (%+.1f %%) | new-vs-old %.1e | %s | %s'
+          % ((N, C, H, W, K), best[False], fl / best[False] / 1e9, best[True], fl / best[True] / 1e9, (best[False] / best[True] - 1) * 100, err,
+             names[True], names[False].split('<')[0]), flush=True)
+    del xs, dys
+    torch.cuda.empty_cache()
