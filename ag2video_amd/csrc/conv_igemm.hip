@@ -1525,11 +1525,19 @@ static int wgrad_launch(const float* dy, const float* x, float* dw, int N, int C
         spg = (int)((Qg + kchunk - 1) / kchunk);
         a.spg = spg; a.splitk = spg * groups; a.kchunk = kchunk;
     }
-    const bool slabs = det && a.spg > 1;
+    // The pixel-range splits of a launch meet either in fp32 atomics on dW or -- deterministic mode, and ALWAYS for the LDS-DMA kernel
+    // (conv_wgrad_halo.hip) when the caller provides the workspace -- as slabs that an ordered pass adds: that kernel's workgroups end
+    // together and their 74 k atomics per workgroup onto the same tile cost 6-16 % of the launch (tools/wgrad_halo_bench.py, WGH_DET).
+    static const bool halo_atomics = getenv("AG2V_WGH_ATOMIC") != nullptr;      // (A/B aid)
+    const bool halo = split && !a.f32 && wgrad_halo_ok(a);
+    bool slabs = (det || (halo && !halo_atomics)) && a.spg > 1;
     const size_t slab_floats = slabs ? (size_t)groups * a.spg * (size_t)mn : 0;
     if (need) { *need = slab_floats; return AG2V_OK; }
+    if (slabs && (!det_ws || det_ws_floats < slab_floats)) {
+        if (det) return AG2V_EINVAL;                                         // ag2v_conv2d_wgrad_det_workspace_floats()
+        slabs = false;                                                       // no workspace: the atomic form
+    }
     if (slabs) {
-        if (!det_ws || det_ws_floats < slab_floats) return AG2V_EINVAL;      // ag2v_conv2d_wgrad_det_workspace_floats()
         a.det = 1;
         a.out = det_ws;
     }
@@ -1601,13 +1609,13 @@ extern "C" int ag2v_conv2d_wgrad_ex(const float* dy, const float* x, float* dw, 
     if (rc == AG2V_OK && o) o->kernel = g_last_conv_kernel;
     return rc;
 }
-// Floats of ag2v_conv_opts::det_workspace a deterministic ag2v_conv2d_wgrad_ex call with these arguments and options needs
-// (0: the launch does not split its pixel range, or the arguments are invalid).  Same planning code as the call itself.
+// Floats of ag2v_conv_opts::det_workspace an ag2v_conv2d_wgrad_ex call with these arguments and options (o->deterministic included) can
+// use: the slabs of a deterministic call, or of a call that takes the LDS-DMA kernel, which adds its splits through slabs in either mode
+// when it is given them (0: atomics or no split, or the arguments are invalid).  Same planning code as the call itself.
 extern "C" size_t ag2v_conv2d_wgrad_det_workspace_floats(int N, int C, int H, int W, int K, int R, int S, int stride, int pad,
                                                          int groups, const ag2v_conv_opts* o) {
     if (N <= 0 || C <= 0 || K <= 0 || stride <= 0 || groups <= 0 || N % groups != 0) return 0;
-    ConvCfg cfg = conv_cfg(o);
-    cfg.det = 1;
+    ConvCfg cfg = conv_cfg(o);         // (o->deterministic as the call will pass it: the LDS-DMA kernel wants slabs in either mode)
     size_t need = 0;
     if (wgrad_ex_impl(nullptr, nullptr, nullptr, N, C, H, W, K, R, S, stride, pad, 0, groups, nullptr, cfg, &need) != AG2V_OK) return 0;
     return need;

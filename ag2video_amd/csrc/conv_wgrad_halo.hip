@@ -37,7 +37,7 @@ typedef __attribute__((address_space(3))) void* lds_vptr;
 namespace wgh {
 constexpr int RM = 4;                               // 16-row blocks per wave
 constexpr int BM = 2 * RM * 16, CB = 64, TW = 32;   // dY channels / x channels per workgroup, pixels per step
-constexpr int A_BUF = BM * TW * 4;                  // dY raw buffer: [row][8 quads], quad' = quad ^ ((row >> 1) & 7)
+constexpr int A_BUF = BM * TW * 4;                  // dY raw buffer: [row][8 quads], quad' = quad ^ wgh_aswz(row)
 constexpr int XR_ROW = (TW + 8) * 4;                // x raw: [channel][10 quads] = pixels x0 - 4 .. x0 + 35
 constexpr int XR_BUF = CB * XR_ROW;
 constexpr int PL_BLK = CB * TW * 2 + 128;           // one (shift, plane) block [channel][4 octets of 8 bf16]; + 128 B: consecutive blocks start
@@ -49,6 +49,16 @@ constexpr unsigned kOut = 0xFFFFFFF0u;              // an out-of-range buffer of
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
+// Quad swizzle of the dY raw rows (8 quads of 16 bytes per row, two rows per 256-byte bank row): a 16-lane group of a ds_read_b128 is
+// {rows 0-3, 12-15 at k group g} + {rows 4-11 at k group g + 1}, whose quads differ by 2.  With f = 2 idx + [row in 4..11] (idx: the
+// position of row / 2 among the four row pairs of its set) the first set lands on even quads, the second on odd ones: 16 distinct
+// bank quads.  (quad ^ ((row >> 1) & 7), the first form, was 2-way on every read: SQ_LDS_BANK_CONFLICT 37 % of the LDS cycles.)
+__device__ __forceinline__ int wgh_aswz(int row) {
+    const int t = (row >> 1) & 7;
+    const int in1 = ((t + 2) >> 2) & 1;
+    const int idx = in1 ? (t - 2) : ((t & 1) | ((t >> 2) << 1));
+    return 2 * idx + in1;
+}
 template <int N>
 __device__ __forceinline__ void wgh_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -217,7 +227,11 @@ struct WgradHaloBody {
     template <int PH, bool MM>
     __device__ __forceinline__ void step() {
         tap<PH, 0, MM>(); tap<PH, 1, MM>(); tap<PH, 2, MM>();
+#ifdef AG2V_WGH_LOOSE_WAIT       // TIMING EXPERIMENT ONLY (races): is the counted wait -- DMA latency -- what the waves park on?
+        wgh_wait_vmcnt<4 + AG2V_WGH_LOOSE_WAIT>();
+#else
         wgh_wait_vmcnt<4>();                                  // the 4 pieces of step jg - 1 may stay in flight
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's plane stores of step jg - 1
         __builtin_amdgcn_s_barrier();
         tap<PH, 3, MM>(); tap<PH, 4, MM>(); tap<PH, 5, MM>();
@@ -250,7 +264,7 @@ struct WgradHaloBody {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int pa = wave + 8 * k;
-            const int row = 8 * pa + (lane >> 3), qs = lane & 7, q = qs ^ ((row >> 1) & 7);
+            const int row = 8 * pa + (lane >> 3), qs = lane & 7, q = qs ^ wgh_aswz(row);
             vA[k] = (m0 + row < M) ? (unsigned)(m0 + row) * (unsigned)HW * 4u + (unsigned)q * 16u : wgh::kOut;
             const int Q = 64 * pa + lane, c = Q / 10, qq = Q - 10 * c;
             vX[k] = (unsigned)c * (unsigned)HW * 4u + (unsigned)qq * 16u;
@@ -261,7 +275,7 @@ struct WgradHaloBody {
         // ---- fragment / regroup addresses
         const int wm = wave >> 2, wn = wave & 3;
         const int ml = lane & 15, g = lane >> 4;
-        const int arow = wm * 64 + ml, fsw = (arow >> 1) & 7;
+        const int arow = wm * 64 + ml, fsw = wgh_aswz(arow);
         a_q0 = (unsigned)(wgh::A_OFF + arow * 128 + (((2 * g) ^ fsw) * 16));
         a_q1 = (unsigned)(wgh::A_OFF + arow * 128 + (((2 * g + 1) ^ fsw) * 16));
         const int cc = wn * 16 + ml;
@@ -354,11 +368,21 @@ void plan_wgrad_halo(ConvArgs& a) {
     const int tiles = a.tiles_m * a.tiles_n;
     if (a.groups < 1) { a.groups = 1; a.gq = a.KG; a.out_gstride = (long long)a.M * a.NG; }
     const int strips_g = (a.gq / (a.H * a.W)) * (a.W / wgh::TW);
+    // Workgroups that read the same dY / x rows (the tiles of one split) only find each other's lines in their XCD's L2 while they walk
+    // in step; over thousands of steps they drift apart (FETCH_SIZE x4.1 of the algorithmic bytes with one 4 400-step workgroup per CU,
+    // x2.0 on a short launch -- tools/pmc_fetch_wgrad.sh).  Shorter workgroups are re-aligned by the dispatcher every round: a split
+    // walks at most max_steps rows.
+    static int max_steps = 0;
+    if (max_steps == 0) {
+        const char* e = getenv("AG2V_WGH_MAX_STEPS");
+        max_steps = (e && atoi(e) > 0) ? atoi(e) : (1 << 30);
+    }
     int best = 1;
     long long best_cost = -1;
-    for (int spg = 1; spg <= strips_g && spg <= 512; ++spg) {
+    for (int spg = 1; spg <= strips_g && spg <= 4096; ++spg) {
         const int chunk = (strips_g + spg - 1) / spg;
         if ((strips_g + chunk - 1) / chunk != spg) continue;
+        if (chunk > 1 && (long long)chunk * (a.H + 1) > max_steps) continue;
         const long long wgs = (long long)tiles * a.groups * spg;
         const long long rounds = (wgs + 255) / 256;                 // one workgroup per CU (LDS)
         const long long cost = rounds * ((long long)chunk * (a.H + 1) + 8);

@@ -277,7 +277,8 @@ def _conv_launch(min_rows, name, label, flops, *args, shape=None, gscale=None, g
                          int(group_n), None, 1 if in_split else 0, 1 if dy_split else 0, 1 if out_split else 0,
                          1 if _DETERMINISTIC[0] else 0, None, 0, int(out_nstride))
     det_ws = None
-    if _DETERMINISTIC[0] and det_ws_query is not None:      # weight gradient: slabs for the ordered reduction of its pixel-range splits
+    if det_ws_query is not None:      # weight gradient: slabs for the ordered reduction of its pixel-range splits (deterministic mode;
+        # in either mode for the LDS-DMA kernel, whose atomic epilogue costs 6-16 % of a launch)
         dev, qargs = det_ws_query
         n = _lib.query('ag2v_conv2d_wgrad_det_workspace_floats', *qargs, ctypes.byref(opts))
         if n:

@@ -58,8 +58,10 @@ extern "C" {
  *              launch stores its partial gradient into det_workspace and an ordered pass adds the partials (and, when accumulating,
  *              the previous dw) in split order.  The default (0) accumulates split partials with fp32 atomics, whose order varies
  *              from run to run (~1e-7 relative per sum);
- *   det_workspace / det_workspace_floats: (weight gradient, deterministic) caller scratch of at least
- *              ag2v_conv2d_wgrad_det_workspace_floats(...) floats (may be NULL when that returns 0);
+ *   det_workspace / det_workspace_floats: (weight gradient) caller scratch of at least ag2v_conv2d_wgrad_det_workspace_floats(...)
+ *              floats (may be NULL when that returns 0): required in deterministic mode; in the default mode the LDS-DMA kernel
+ *              (3x3 stride-1 on split words) uses it for the same slab reduction when given -- results are then bit-reproducible for
+ *              that launch too -- and falls back to atomics without it;
  *   out_nstride: (data gradient, stride 1, not accumulating, more than 4 input channels) floats between consecutive samples of dx;
  *              0 = C * H * W, the dense tensor.  Larger: dx is the channel slice [:, c0 : c0 + C] of a wider [N, Ctot, H, W] buffer
  *              (out_nstride = Ctot * H * W, dx = buffer + c0 * H * W) -- the gradients of several convolutions that share a

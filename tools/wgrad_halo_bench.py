@@ -26,15 +26,20 @@ def mode(new):
 
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+if os.environ.get('WGH_SHAPES'):          # e.g. WGH_SHAPES=0,1: a subset (counter runs)
+    SHAPES = [SHAPES[int(i)] for i in os.environ['WGH_SHAPES'].split(',')]
+ONLY_NEW = os.environ.get('WGH_ONLY_NEW') is not None
+if os.environ.get('WGH_CUSTOM'):          # e.g. WGH_CUSTOM='64,512,256,256,384;40,512,128,128,384'
+    SHAPES = [tuple(int(v) for v in t.split(',')) for t in os.environ['WGH_CUSTOM'].split(';')]
 dev = torch.device('cuda')
 for (N, C, H, W, K) in SHAPES:
     xs = to_split(torch.randn(N, C, H, W, device=dev))
     dys = to_split(torch.randn(N, K, H, W, device=dev))
     dw = {True: torch.empty(K, C, 3, 3, device=dev), False: torch.empty(K, C, 3, 3, device=dev)}
     best, names = {True: 1e9, False: 1e9}, {}
-    with ops.conv_precision('bf16x3'), torch.no_grad():
+    with ops.conv_precision('bf16x3'), torch.no_grad(), ops.deterministic(os.environ.get('WGH_DET') is not None):
         for rnd in range(3):
-            for new in (False, True):
+            for new in ((True,) if ONLY_NEW else (False, True)):
                 mode(new)
                 run = lambda: ops._conv_wgrad_launch(32, dys, xs, dw[new], K, 3, 3, 1, 1, 0, in_split=True, dy_split=True)
                 run()
@@ -48,6 +53,8 @@ for (N, C, H, W, K) in SHAPES:
                 best[new] = min(best[new], a.elapsed_time(b) / reps)
     mode(True)
     fl = 2.0 * N * K * H * W * C * 9
+    if ONLY_NEW:
+        dw[False], best[False], names[False] = dw[True], best[True], names[True]
     err = float((dw[True] - dw[False]).abs().max() / dw[False].abs().max())
     print('wgrad %-28s old %7.3f ms %6.1f TF | new %7.3f ms %6.1f TF (%+.1f %%) | new-vs-old %.1e | %s | %s'
           % ((N, C, H, W, K), best[False], fl / best[False] / 1e9, best[True], fl / best[True] / 1e9, (best[False] / best[True] - 1) * 100, err,
