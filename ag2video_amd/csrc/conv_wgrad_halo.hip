@@ -64,6 +64,8 @@ __device__ __forceinline__ void wgh_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// AS / XS: dY / x hold split words (false: fp32 -- the regrouping step then also performs the 3-term split's hi / lo decomposition)
+template <bool AS, bool XS>
 struct WgradHaloBody {
     typedef float f32x4v __attribute__((ext_vector_type(4)));
     const ConvArgs& p;
@@ -140,12 +142,32 @@ struct WgradHaloBody {
         rw[9] = *reinterpret_cast<const unsigned*>(xr + 48);
         rw[1] = qa[0]; rw[2] = qa[1]; rw[3] = qa[2]; rw[4] = qa[3];
         rw[5] = qb[0]; rw[6] = qb[1]; rw[7] = qb[2]; rw[8] = qb[3];
+        if constexpr (!XS) {
+            // fp32 words: this thread's plane takes bf16(v) (hi) or bf16(v - bf16(v)) (lo) of every value; the values it will pack are
+            // prepared once here (the residuals for a lo thread), the three shifts then cost one v_cvt_pk each per pair
+#pragma unroll
+            for (int k = 0; k < 10; k += 2) {
+                unsigned h_, l_;
+                split2(__uint_as_float(rw[k]), __uint_as_float(rw[k + 1]), h_, l_);
+                // residuals as fp32 again (exact: a bf16 widened): lo thread packs them, hi thread packs the values themselves
+                const unsigned r0 = l_ << 16, r1 = l_ & 0xFFFF0000u;
+                rw[k] = psel == 0x05040100u ? r0 : rw[k];
+                rw[k + 1] = psel == 0x05040100u ? r1 : rw[k + 1];
+            }
+        }
     }
     template <int SLOT, int S>
     __device__ __forceinline__ void regroup_shift() {
         u32x4 o;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) o[q] = __builtin_amdgcn_perm(rw[S + 2 * q + 1], rw[S + 2 * q], psel);
+        for (int q = 0; q < 4; ++q) {
+            if constexpr (XS) {
+                o[q] = __builtin_amdgcn_perm(rw[S + 2 * q + 1], rw[S + 2 * q], psel);
+            } else {       // (hi thread: rounds the values; lo thread: its residuals are bf16 values already -- the conversion is exact)
+                const f32x2 v = {__uint_as_float(rw[S + 2 * q]), __uint_as_float(rw[S + 2 * q + 1])};
+                o[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+            }
+        }
         *reinterpret_cast<u32x4*>(smem + pl_wr + SLOT * wgh::PL_SLOT + S * 2 * wgh::PL_BLK) = o;
     }
     // dY fragments of the row in raw buffer BUF -> register set SET: reads, then the hi / lo regrouping in two halves
@@ -159,10 +181,18 @@ struct WgradHaloBody {
     __device__ __forceinline__ void a_regroup(int i) {
         const u32x4 qa = araw[i][0], qb = araw[i][1];
         u32x4 hv, lv;
-        hv[0] = __builtin_amdgcn_perm(qa[1], qa[0], 0x07060302u); lv[0] = __builtin_amdgcn_perm(qa[1], qa[0], 0x05040100u);
-        hv[1] = __builtin_amdgcn_perm(qa[3], qa[2], 0x07060302u); lv[1] = __builtin_amdgcn_perm(qa[3], qa[2], 0x05040100u);
-        hv[2] = __builtin_amdgcn_perm(qb[1], qb[0], 0x07060302u); lv[2] = __builtin_amdgcn_perm(qb[1], qb[0], 0x05040100u);
-        hv[3] = __builtin_amdgcn_perm(qb[3], qb[2], 0x07060302u); lv[3] = __builtin_amdgcn_perm(qb[3], qb[2], 0x05040100u);
+        if constexpr (AS) {
+            hv[0] = __builtin_amdgcn_perm(qa[1], qa[0], 0x07060302u); lv[0] = __builtin_amdgcn_perm(qa[1], qa[0], 0x05040100u);
+            hv[1] = __builtin_amdgcn_perm(qa[3], qa[2], 0x07060302u); lv[1] = __builtin_amdgcn_perm(qa[3], qa[2], 0x05040100u);
+            hv[2] = __builtin_amdgcn_perm(qb[1], qb[0], 0x07060302u); lv[2] = __builtin_amdgcn_perm(qb[1], qb[0], 0x05040100u);
+            hv[3] = __builtin_amdgcn_perm(qb[3], qb[2], 0x07060302u); lv[3] = __builtin_amdgcn_perm(qb[3], qb[2], 0x05040100u);
+        } else {
+            unsigned h_, l_;
+            split2(__uint_as_float(qa[0]), __uint_as_float(qa[1]), h_, l_); hv[0] = h_; lv[0] = l_;
+            split2(__uint_as_float(qa[2]), __uint_as_float(qa[3]), h_, l_); hv[1] = h_; lv[1] = l_;
+            split2(__uint_as_float(qb[0]), __uint_as_float(qb[1]), h_, l_); hv[2] = h_; lv[2] = l_;
+            split2(__uint_as_float(qb[2]), __uint_as_float(qb[3]), h_, l_); hv[3] = h_; lv[3] = l_;
+        }
         // (pinned: the fragments are first used in the NEXT step, and the compiler would otherwise sink the v_perms there -- in front of
         // that step's first MFMA instead of into this step's MFMA shadow)
         asm volatile("" : "+v"(hv), "+v"(lv));
@@ -343,10 +373,11 @@ struct WgradHaloBody {
 };
 #endif
 
+template <bool AS, bool XS>
 __global__ __launch_bounds__(512) void conv_wgrad_halo_bf16x3_kernel(ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(1024))) char wgh_smem[wgh::LDS_BYTES];
-    WgradHaloBody b(p, wgh_smem);
+    WgradHaloBody<AS, XS> b(p, wgh_smem);
     b.run();
 #endif
 }
@@ -354,9 +385,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_halo_bf16x3_kernel(ConvArgs p)
 // ---------------------------------------------------------------------------------------------------------------- host side
 bool wgrad_halo_switched_off();       // conv_halo.hip: AG2V_NO_WGRAD_HALO, read with the other A/B switches (ag2v_halo_reload_env)
 bool wgrad_halo_ok(const ConvArgs& a) {
-    if (wgrad_halo_switched_off() || a.f32 || !a.a_split || !a.b_split) return false;
+    if (wgrad_halo_switched_off() || a.f32 || (!a.a_split && !a.b_split)) return false;      // (at least one operand as split words)
     if (a.R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1 || a.OH != a.H || a.OW != a.W) return false;
-    if (a.W % wgh::TW || a.H < 16 || a.C % wgh::CB || a.M < 96) return false;
+    if (a.W % wgh::TW || a.H < 16 || a.C % wgh::CB || a.M < 48) return false;       // (a 64-row layer fills half of a row tile: still ahead of the 16-byte-load kernels, which pad the same way)
     if (a.groups < 1 || a.gq % (a.H * a.W)) return false;
     if (a.a_bytes == 0 || a.b_bytes == 0) return false;
     return true;
@@ -399,8 +430,16 @@ int launch_wgrad_halo(ConvArgs& a, hipStream_t st) {
         if (hipMemsetAsync(a.out, 0, (size_t)a.M * a.NG * a.groups * sizeof(float), st) != hipSuccess) return AG2V_EHIP;
     }
     const dim3 grid((unsigned)(a.tiles_m * a.tiles_n * a.splitk));
-    set_last_conv_kernel("conv_wgrad_halo_bf16x3_kernel");
-    hipLaunchKernelGGL(conv_wgrad_halo_bf16x3_kernel, grid, dim3(512), 0, st, a);
+    if (a.a_split && a.b_split) {
+        set_last_conv_kernel("conv_wgrad_halo_bf16x3_kernel<true, true>");
+        hipLaunchKernelGGL((conv_wgrad_halo_bf16x3_kernel<true, true>), grid, dim3(512), 0, st, a);
+    } else if (a.a_split) {
+        set_last_conv_kernel("conv_wgrad_halo_bf16x3_kernel<true, false>");
+        hipLaunchKernelGGL((conv_wgrad_halo_bf16x3_kernel<true, false>), grid, dim3(512), 0, st, a);
+    } else {
+        set_last_conv_kernel("conv_wgrad_halo_bf16x3_kernel<false, true>");
+        hipLaunchKernelGGL((conv_wgrad_halo_bf16x3_kernel<false, true>), grid, dim3(512), 0, st, a);
+    }
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
 }

@@ -46,13 +46,13 @@ class _wgrad_halo(object):
         return False
 
 
-def _wgrad(dys, xs, K, groups=1, acc_into=None):
+def _wgrad(dys, xs, K, groups=1, acc_into=None, x_split=True, dy_split=True):
     from ag2video_amd import _lib, ops
     C = xs.shape[1]
     shape = ((groups,) if groups > 1 else ()) + (K, C, 3, 3)
     dw = acc_into.clone() if acc_into is not None else torch.full(shape, float('nan'), device=xs.device)
     with ops.conv_precision('bf16x3'), torch.no_grad():
-        ops._conv_wgrad_launch(32, dys, xs, dw, K, 3, 3, 1, 1, 1 if acc_into is not None else 0, groups=groups, in_split=True, dy_split=True)
+        ops._conv_wgrad_launch(32, dys, xs, dw, K, 3, 3, 1, 1, 1 if acc_into is not None else 0, groups=groups, in_split=x_split, dy_split=dy_split)
     return dw, _lib.query('ag2v_last_conv_kernel')
 
 
@@ -89,9 +89,36 @@ def test_wgrad_halo_matches_fp64_and_previous_kernels(cfg, device):
     ref = _ref64(dys, xs, K, groups)
     with _wgrad_halo(True):
         new, name = _wgrad(dys, xs, K, groups)
-        assert name == b'conv_wgrad_halo_bf16x3_kernel', name
+        assert name == b'conv_wgrad_halo_bf16x3_kernel<true, true>', name
     with _wgrad_halo(False):
         old, name_o = _wgrad(dys, xs, K, groups)
+        assert name_o.startswith(b'conv_wgrad_bf16x3_v'), name_o
+    scale = ref.abs().max().item()
+    assert torch.isfinite(new).all()
+    assert (new.double() - ref).abs().max().item() <= 2e-5 * scale, ((new.double() - ref).abs().max().item() / scale)
+    assert (new - old).abs().max().item() <= 1e-5 * scale, ((new - old).abs().max().item() / scale)
+
+
+@pytest.mark.parametrize("x_split,dy_split", [(True, False), (False, True)], ids=['x_split_dy_fp32', 'x_fp32_dy_split'])
+@pytest.mark.parametrize("cfg", [(3, 64, 32, 64, 128, 1), (5, 64, 24, 96, 200, 1), (6, 128, 16, 64, 128, 3)], ids=str)
+def test_wgrad_halo_with_one_fp32_operand(cfg, x_split, dy_split, device):
+    """conv_0 / conv_1 / conv_s of the decoder blocks hand over x as split words and dy as fp32 (the gradient of a residual sum), other
+    layers the reverse: the kernel's regrouping step then performs the hi / lo decomposition of the fp32 operand itself (the arithmetic
+    of conv_common.h split2, as in the kernels it replaces)."""
+    N, C, H, W, K, groups = cfg
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(N, C, H, W, generator=g).to(device)
+    dy = torch.randn(N, K, H, W, generator=g).to(device)
+    xs, dys = (_to_split_words(x) if x_split else x), (_to_split_words(dy) if dy_split else dy)
+    # fp64 reference on the values the kernel sees: a split-word operand carries hi + lo (16 + 8 bits), an fp32 one is split inside
+    xe = _from_split_words(xs) if x_split else _from_split_words(_to_split_words(x))
+    dye = _from_split_words(dys) if dy_split else _from_split_words(_to_split_words(dy))
+    ref = _ref64(_to_split_words(dye), _to_split_words(xe), K, groups)
+    with _wgrad_halo(True):
+        new, name = _wgrad(dys, xs, K, groups, x_split=x_split, dy_split=dy_split)
+        assert name == ('conv_wgrad_halo_bf16x3_kernel<%s, %s>' % (str(dy_split).lower(), str(x_split).lower())).encode(), name
+    with _wgrad_halo(False):
+        old, name_o = _wgrad(dys, xs, K, groups, x_split=x_split, dy_split=dy_split)
         assert name_o.startswith(b'conv_wgrad_bf16x3_v'), name_o
     scale = ref.abs().max().item()
     assert torch.isfinite(new).all()
@@ -109,13 +136,13 @@ def test_wgrad_halo_accumulates_and_is_deterministic_on_request(device):
     ref = _ref64(dys, xs, K)
     with _wgrad_halo(True):
         acc, name = _wgrad(dys, xs, K, acc_into=base)
-        assert name == b'conv_wgrad_halo_bf16x3_kernel'
+        assert name == b'conv_wgrad_halo_bf16x3_kernel<true, true>'
         assert (acc.double() - (ref + base.double())).abs().max().item() <= 2e-5 * ref.abs().max().item()
         with ops.deterministic():
             d1, name = _wgrad(dys, xs, K)
             d2, _ = _wgrad(dys, xs, K)
             d3, _ = _wgrad(dys, xs, K, acc_into=base)
-        assert name == b'conv_wgrad_halo_bf16x3_kernel'
+        assert name == b'conv_wgrad_halo_bf16x3_kernel<true, true>'
         assert torch.equal(d1, d2)
         assert (d1.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
         assert (d3.double() - (ref + base.double())).abs().max().item() <= 2e-5 * ref.abs().max().item()
