@@ -385,7 +385,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_halo_bf16x3_kernel(ConvArgs p)
 // ---------------------------------------------------------------------------------------------------------------- host side
 bool wgrad_halo_switched_off();       // conv_halo.hip: AG2V_NO_WGRAD_HALO, read with the other A/B switches (ag2v_halo_reload_env)
 bool wgrad_halo_ok(const ConvArgs& a) {
-    if (wgrad_halo_switched_off() || a.f32 || (!a.a_split && !a.b_split)) return false;      // (at least one operand as split words)
+    if (wgrad_halo_switched_off() || a.f32) return false;
     if (a.R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1 || a.OH != a.H || a.OW != a.W) return false;
     if (a.W % wgh::TW || a.H < 16 || a.C % wgh::CB || a.M < 48) return false;       // (a 64-row layer fills half of a row tile: still ahead of the 16-byte-load kernels, which pad the same way)
     if (a.groups < 1 || a.gq % (a.H * a.W)) return false;
@@ -436,9 +436,12 @@ int launch_wgrad_halo(ConvArgs& a, hipStream_t st) {
     } else if (a.a_split) {
         set_last_conv_kernel("conv_wgrad_halo_bf16x3_kernel<true, false>");
         hipLaunchKernelGGL((conv_wgrad_halo_bf16x3_kernel<true, false>), grid, dim3(512), 0, st, a);
-    } else {
+    } else if (a.b_split) {
         set_last_conv_kernel("conv_wgrad_halo_bf16x3_kernel<false, true>");
         hipLaunchKernelGGL((conv_wgrad_halo_bf16x3_kernel<false, true>), grid, dim3(512), 0, st, a);
+    } else {
+        set_last_conv_kernel("conv_wgrad_halo_bf16x3_kernel<false, false>");
+        hipLaunchKernelGGL((conv_wgrad_halo_bf16x3_kernel<false, false>), grid, dim3(512), 0, st, a);
     }
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;

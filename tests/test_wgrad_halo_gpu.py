@@ -99,11 +99,11 @@ def test_wgrad_halo_matches_fp64_and_previous_kernels(cfg, device):
     assert (new - old).abs().max().item() <= 1e-5 * scale, ((new - old).abs().max().item() / scale)
 
 
-@pytest.mark.parametrize("x_split,dy_split", [(True, False), (False, True)], ids=['x_split_dy_fp32', 'x_fp32_dy_split'])
+@pytest.mark.parametrize("x_split,dy_split", [(True, False), (False, True), (False, False)], ids=['x_split_dy_fp32', 'x_fp32_dy_split', 'both_fp32'])
 @pytest.mark.parametrize("cfg", [(3, 64, 32, 64, 128, 1), (5, 64, 24, 96, 200, 1), (6, 128, 16, 64, 128, 3)], ids=str)
 def test_wgrad_halo_with_one_fp32_operand(cfg, x_split, dy_split, device):
     """conv_0 / conv_1 / conv_s of the decoder blocks hand over x as split words and dy as fp32 (the gradient of a residual sum), other
-    layers the reverse: the kernel's regrouping step then performs the hi / lo decomposition of the fp32 operand itself (the arithmetic
+    layers the reverse, the flow network's residual blocks both as fp32: the kernel's regrouping step then performs the hi / lo decomposition of the fp32 operand itself (the arithmetic
     of conv_common.h split2, as in the kernels it replaces)."""
     N, C, H, W, K, groups = cfg
     g = torch.Generator().manual_seed(9)
