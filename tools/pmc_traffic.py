@@ -20,7 +20,7 @@ def split_words(t):
     return ops.mark_split(w.view(torch.float32))
 
 
-def conv_case(tag, N, C, H, K, what, split=False):
+def conv_case(tag, N, C, H, K, what, split=False, precision=None):
     """what: 'fwd' | 'dgrad' | 'wgrad' of a 3x3 stride-1 convolution x[N,C,H,H] -> y[N,K,H,H], with the decoder's row threshold.
     split: the operands the step hands over as split words are split words here too (x in fwd / wgrad, dy in dgrad / wgrad): the
     *_ps / *_vps kernels."""
@@ -29,7 +29,8 @@ def conv_case(tag, N, C, H, K, what, split=False):
         x = split_words(x)
     w = (torch.randn(K, C, 3, 3, device=dev) * 0.01)
     xb, yb, wb = N * C * H * H * 4, N * K * H * H * 4, K * C * 9 * 4
-    with ops.bf16x3_min_rows(48):
+    import contextlib
+    with ops.bf16x3_min_rows(48), (ops.conv_precision(precision) if precision else contextlib.nullcontext()):
         if what == 'fwd':
             for _ in range(REPS):
                 ops.conv2d(x, w, None, 1, 1)
@@ -61,6 +62,11 @@ CASES = {
     'mlp_shared_dgrad_merged_ps': lambda: conv_case('mlp_shared_dgrad_merged_ps', 40, 512, 256, 384, 'dgrad', True),
     'mlp_shared_wgrad_merged_ps': lambda: conv_case('mlp_shared_wgrad_merged_ps', 21, 512, 256, 384, 'wgrad', True),
     'conv_256_wgrad_128px_ps': lambda: conv_case('conv_256_wgrad_128px_ps', 120, 256, 128, 256, 'wgrad', True),
+    # round 5: the exact-fp32 leg's largest kernel, and the gamma | beta layer's passes at full resolution
+    'mlp_shared_wgrad_merged_fp32': lambda: conv_case('mlp_shared_wgrad_merged_fp32', 21, 512, 256, 384, 'wgrad', False, 'fp32'),
+    'gamma_beta_wgrad_ps': lambda: conv_case('gamma_beta_wgrad_ps', 60, 128, 256, 256, 'wgrad', True),
+    'gamma_beta_dgrad_ps': lambda: conv_case('gamma_beta_dgrad_ps', 60, 128, 256, 256, 'dgrad', True),
+    'gamma_beta_fwd_ps': lambda: conv_case('gamma_beta_fwd_ps', 60, 128, 256, 256, 'fwd', True),
 }
 
 
