@@ -83,10 +83,12 @@ struct WgradHaloBody {
     unsigned xr_rd, pl_wr, psel;     // regroup unit of this thread: raw row / plane destination / v_perm selector (hi or lo plane)
     // ---- row stream (wave-uniform)
     int H, W, HW, M, C, c0, m0, spr; // spr: strips per image row
-    int nstrips;                     // strips of this workgroup
-    struct Row { int data; unsigned offA, offX; int left, right; };
+    // A workgroup owns ring rows [g0, g1) of its sample group's row stream (strips x (H + 1) rows: every strip's rows behind one zero
+    // row).  Its cursor starts one row earlier and runs past g1: the neighbouring rows' x is needed (as tap rows), their dY is not.
+    struct Row { int data, own; unsigned offA, offX; int left, right; };      // data: a real image row; own: its dY belongs to this workgroup
     Row rows[5];                     // ring rows jg .. jg + 4
-    int cst, cy, cn, cxs, lead;      // cursor of the row entering at jg + 4: strip number, y (-1: the zero row), image, strip column
+    int cst, cy, cn, cxs, cr;        // cursor of the row entering at jg + 4: strip number, y (-1: the zero row), image, strip column, ring row
+    int g0, g1, nst_g;               // owned ring rows, strips of the group
     // ---- fragments
     bf16x8 ah[2][wgh::RM], al[2][wgh::RM];
     f32x4v acc[wgh::RM][9];
@@ -96,12 +98,14 @@ struct WgradHaloBody {
     // the row the cursor points at, then advance it
     __device__ __forceinline__ Row next_row() {
         Row r;
-        if (lead > 0) {               // (the rows in front of the first strip)
-            --lead;
-            r.data = 0; r.offA = 0u; r.offX = 0u; r.left = 0; r.right = 0;
+        if (cr < 0) {                 // (the row in front of the group's first strip)
+            ++cr;
+            r.data = 0; r.own = 0; r.offA = 0u; r.offX = 0u; r.left = 0; r.right = 0;
             return r;
         }
-        r.data = (cst < nstrips && cy >= 0) ? 1 : 0;
+        r.data = (cst < nst_g && cy >= 0) ? 1 : 0;
+        r.own = (r.data && cr >= g0 && cr < g1) ? 1 : 0;
+        ++cr;
         const int x0 = cxs * wgh::TW;
         r.left = (x0 == 0) ? 1 : 0;
         r.right = (x0 + wgh::TW == W) ? 1 : 0;
@@ -118,8 +122,8 @@ struct WgradHaloBody {
     // ---- the pieces of a step, issued in the shadow of its MFMAs (filler<T, I>: behind the three MFMAs of row block I of tap T)
     template <int BUF, int K>
     __device__ __forceinline__ void dma_a(const Row& r) {
-        const unsigned v = r.data ? vA[K] : wgh::kOut;
-        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)(r.data ? r.offA : 0u));
+        const unsigned v = r.own ? vA[K] : wgh::kOut;           // (rows of other workgroups / zero rows: zeros, their MFMAs add nothing)
+        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)(r.own ? r.offA : 0u));
         const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane(wgh::A_OFF + BUF * wgh::A_BUF + (wave + 8 * K) * 1024);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (lds_vptr)(smem + dst), 16, v, soff, 0, 0);
     }
@@ -284,12 +288,12 @@ struct WgradHaloBody {
         m0 = tile_m * wgh::BM;
         c0 = tile_c * wgh::CB;
         const int grp = split / p.spg, sl = split - grp * p.spg;
-        const int strips_g = (p.gq / HW) * spr;               // strips of a sample group
-        const int st0 = sl * p.kchunk;                         // (kchunk: strips per split)
-        nstrips = min(p.kchunk, strips_g - st0);
+        nst_g = (p.gq / HW) * spr;                             // strips of a sample group
+        g0 = sl * p.kchunk;                                    // (kchunk: ring rows per split)
+        g1 = min(g0 + p.kchunk, nst_g * (H + 1));
         float* const outg = p.det ? p.out + (size_t)split * ((size_t)p.M * p.NG) : p.out + (size_t)grp * p.out_gstride;
         const bool atomic_out = !p.det && (p.spg > 1 || p.accumulate);
-        if (nstrips <= 0) return;
+        if (g1 <= g0) return;
         // ---- DMA source offsets
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -318,15 +322,15 @@ struct WgradHaloBody {
         pl_wr = (unsigned)(wgh::PL_OFF + up * wgh::PL_BLK + uc * 64 + ((uo ^ sig_w) * 16));
         psel = up ? 0x05040100u : 0x07060302u;
         asm volatile("" : "+v"(a_q0), "+v"(a_q1), "+v"(pl_rd[0]), "+v"(pl_rd[1]), "+v"(pl_rd[2]), "+v"(xr_rd), "+v"(pl_wr));
-        // ---- row stream: the workgroup's strips st0 .. st0 + nstrips - 1 of group grp; the cursor starts 5 + 4 rows in front of the
-        // first strip's zero row (those rows are "not data": zeros)
+        // ---- row stream: the cursor starts at ring row g0 - 1 (its x is the first owned row's upper tap row; -1: in front of the group)
         {
-            const int sabs = st0;                            // strip number inside the group
+            cr = g0 - 1;
+            const int rr = cr < 0 ? 0 : cr;
+            const int sabs = rr / (H + 1);                   // strip number inside the group
+            cst = sabs;
+            cy = rr - sabs * (H + 1) - 1;
             cn = grp * (p.gq / HW) + sabs / spr;
             cxs = sabs % spr;
-            cst = 0;
-            cy = -1;
-            lead = 1;                                        // the shift inside the first fill step brings in row J0 - 1
         }
         // rows jg = J0 - 5 .. J0 - 1 do not exist: five zero rows in front of the cursor
         Row zero = {0, 0u, 0u, 0, 0};
@@ -341,8 +345,8 @@ struct WgradHaloBody {
                 for (int r = 0; r < 4; ++r) acc[i][t][r] = 0.f;
         // pipeline fill: steps J0 - 5 .. J0 - 1 (phases 1 .. 5, so that J0 is phase 0)
         step<1, false>(); step<2, false>(); step<3, false>(); step<4, false>(); step<5, false>();
-        // rows[0] is now J0 (the first zero row): total steps = nstrips * (H + 1)
-        const int total = nstrips * (H + 1);
+        // rows[0] is now ring row g0: one step per owned row
+        const int total = g1 - g0;
         int done = 0;
         while (true) {
             step<0, true>(); if (++done == total) break;
@@ -398,11 +402,12 @@ void plan_wgrad_halo(ConvArgs& a) {
     a.tiles_n = a.C / wgh::CB;
     const int tiles = a.tiles_m * a.tiles_n;
     if (a.groups < 1) { a.groups = 1; a.gq = a.KG; a.out_gstride = (long long)a.M * a.NG; }
-    const int strips_g = (a.gq / (a.H * a.W)) * (a.W / wgh::TW);
-    // Workgroups that read the same dY / x rows (the tiles of one split) only find each other's lines in their XCD's L2 while they walk
-    // in step; over thousands of steps they drift apart (FETCH_SIZE x4.1 of the algorithmic bytes with one 4 400-step workgroup per CU,
-    // x2.0 on a short launch -- tools/pmc_fetch_wgrad.sh).  Shorter workgroups are re-aligned by the dispatcher every round: a split
-    // walks at most max_steps rows.
+    // ring rows of a sample group: its strips' rows, each strip behind one zero row; any split of them into equal runs is a valid
+    // partition (a run may start and end inside a strip), so every layer can fill all 256 CUs
+    const long long rows_g = (long long)(a.gq / (a.H * a.W)) * (a.W / wgh::TW) * (a.H + 1);
+    // (Workgroups that read the same dY / x rows -- the tiles of one split -- only find each other's lines in their XCD's L2 while they
+    // walk in step, and over thousands of steps they do not: FETCH_SIZE x3.6 of the algorithmic bytes on the merged mlp_shared shape,
+    // x1.03 on the 4-tile gamma | beta shape.  Shorter workgroups, AG2V_WGH_MAX_STEPS, do not restore it and cost 0.6-3 %.)
     static int max_steps = 0;
     if (max_steps == 0) {
         const char* e = getenv("AG2V_WGH_MAX_STEPS");
@@ -410,17 +415,17 @@ void plan_wgrad_halo(ConvArgs& a) {
     }
     int best = 1;
     long long best_cost = -1;
-    for (int spg = 1; spg <= strips_g && spg <= 4096; ++spg) {
-        const int chunk = (strips_g + spg - 1) / spg;
-        if ((strips_g + chunk - 1) / chunk != spg) continue;
-        if (chunk > 1 && (long long)chunk * (a.H + 1) > max_steps) continue;
+    for (int spg = 1; spg <= 4096 && spg <= rows_g; ++spg) {
+        const long long chunk = (rows_g + spg - 1) / spg;
+        if ((rows_g + chunk - 1) / chunk != spg) continue;
+        if (spg < 4096 && chunk > max_steps) continue;
         const long long wgs = (long long)tiles * a.groups * spg;
         const long long rounds = (wgs + 255) / 256;                 // one workgroup per CU (LDS)
-        const long long cost = rounds * ((long long)chunk * (a.H + 1) + 8);
+        const long long cost = rounds * (chunk + 8);
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = spg; }
     }
     a.spg = best;
-    a.kchunk = (strips_g + best - 1) / best;
+    a.kchunk = (int)((rows_g + best - 1) / best);
     a.splitk = best * a.groups;
 }
 void set_last_conv_kernel(const char* name);
