@@ -146,3 +146,26 @@ def test_wgrad_halo_accumulates_and_is_deterministic_on_request(device):
         assert torch.equal(d1, d2)
         assert (d1.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
         assert (d3.double() - (ref + base.double())).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+def test_wgrad_halo_at_the_benchmarked_layer_size(device):
+    """The merged mlp_shared weight gradient of a c3 step (512 -> 3 x 128 channels at 256 x 256; 6 images here): the partition into runs
+    of ring rows that start and end inside strips, 24 tiles x many splits, slab reduction -- against the 16-byte-load kernels (1e-5 of
+    max) and, on a window of the filter, fp64."""
+    N, C, H, W, K = 6, 512, 256, 256, 384
+    g = torch.Generator().manual_seed(3)
+    xs = _to_split_words(torch.randn(N, C, H, W, generator=g).to(device))
+    dys = _to_split_words(torch.randn(N, K, H, W, generator=g).to(device))
+    with _wgrad_halo(True):
+        new, name = _wgrad(dys, xs, K)
+        assert name == b'conv_wgrad_halo_bf16x3_kernel<true, true>', name
+        new2, _ = _wgrad(dys, xs, K)
+        assert torch.equal(new, new2)              # (slab reduction: bit-reproducible in the default mode too)
+    with _wgrad_halo(False):
+        old, name_o = _wgrad(dys, xs, K)
+        assert name_o.startswith(b'conv_wgrad_bf16x3_vps'), name_o
+    scale = old.abs().max().item()
+    assert torch.isfinite(new).all()
+    assert (new - old).abs().max().item() <= 1e-5 * scale
+    ref = _ref64(dys[:, 5:9], xs[:, 100:108], 4)          # dW[5:9, 100:108]
+    assert (new[5:9, 100:108].double() - ref).abs().max().item() <= 2e-5 * scale
