@@ -21,6 +21,10 @@
 //   * the dY fragments (4 per wave and step, reused by all 9 taps) are regrouped by the wave that multiplies them (32 v_perm per step),
 //     one step ahead, into the other of two register sets.
 // One s_barrier and one counted s_waitcnt vmcnt per step; DMA runs two steps ahead (3 raw buffers per operand).
+// A sample group's strips form ONE stream of ring rows (every strip's rows behind a zero row); a workgroup owns a run [g0, g1) of it,
+// which may begin and end inside a strip: the rows around the run are loaded as tap rows (x) but contribute no dY.  The runs of a launch
+// are added through slabs + an ordered reduce pass when the caller hands over the workspace (conv_igemm.hip wgrad_launch), else by
+// fp32 atomics.  AS / XS = false: that operand is fp32 and the regrouping step performs the hi / lo decomposition (split2) itself.
 //
 // Step jg (ring row jg: a strip's rows preceded by ONE zero row, which also is the previous strip's bottom border):
 //     taps r = 0 (plane slot of row jg - 1)                                     36 MFMAs
