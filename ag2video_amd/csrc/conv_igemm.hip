@@ -1144,19 +1144,40 @@ __global__ __launch_bounds__(256) void pack_dgrad_s2_tap_kernel(const float* __r
     }
 }
 // dx[n, c, y, x] (+)= t[n, cls * C + c, (y - ay[py]) / 2, (x - ax[px]) / 2] for the class whose parity (y, x) has; mask as the epilogues
+// grid (N * C, ceil(H / 4)), block (64, 4): thread (tx, ty) writes the pixel pairs (2 t, 2 t + 1), t = tx, tx + 64, ..., of row
+// blockIdx.y * 4 + ty -- one value of each x class, both read along consecutive qx (no index divisions: the first form spent its time
+// in 64-bit div / mod chains, 4.5 ms per c3 step for 3 GB of traffic)
 __global__ __launch_bounds__(256) void depth_to_space_s2_kernel(const float* __restrict__ t, const float* __restrict__ mask, float* __restrict__ dx,
-                                                                long long total, int C, int H, int W, int Qy, int Qx, int ay0, int ax0, int acc) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int x = (int)(i % W);
-    const int y = (int)((i / W) % H);
-    const int c = (int)((i / ((long long)W * H)) % C);
-    const long long n = i / ((long long)W * H * C);
-    const int py = ((y - ay0) & 1), px = ((x - ax0) & 1);          // class 0 owns the rows of ay0's parity
-    const int qy = (y - (py ? 1 - ay0 : ay0)) >> 1, qx = (x - (px ? 1 - ax0 : ax0)) >> 1;
-    float v = t[(((size_t)n * 4 + (py * 2 + px)) * C + c) * ((size_t)Qy * Qx) + (size_t)qy * Qx + qx];
-    if (mask) v = (mask[i] > 0.f) ? v : 0.f;
-    dx[i] = acc ? dx[i] + v : v;
+                                                                int C, int H, int W, int Qy, int Qx, int ay0, int ax0, int acc) {
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (y >= H) return;
+    const int nc = blockIdx.x;
+    const int n = nc / C, c = nc - n * C;
+    const int py = ((y - ay0) & 1);                               // class 0 owns the rows of ay0's parity
+    const int qy = (y - (py ? 1 - ay0 : ay0)) >> 1;
+    const size_t plane = (size_t)Qy * Qx;
+    // x = 2 t + e: class px = (e - ax0) & 1, qx = (x - ax[px]) >> 1 with ax[0] = ax0, ax[1] = 1 - ax0
+    const int px_e0 = (0 - ax0) & 1, px_e1 = (1 - ax0) & 1;
+    const int a_e0 = px_e0 ? 1 - ax0 : ax0, a_e1 = px_e1 ? 1 - ax0 : ax0;
+    const float* r0 = t + (((size_t)n * 4 + (py * 2 + px_e0)) * C + c) * plane + (size_t)qy * Qx;
+    const float* r1 = t + (((size_t)n * 4 + (py * 2 + px_e1)) * C + c) * plane + (size_t)qy * Qx;
+    const size_t row = ((size_t)nc * H + y) * W;
+    for (int tt = threadIdx.x; 2 * tt < W; tt += 64) {
+        const int x0 = 2 * tt;
+        const bool two = x0 + 1 < W;
+        float v0 = r0[(x0 - a_e0) >> 1];
+        float v1 = two ? r1[(x0 + 1 - a_e1) >> 1] : 0.f;
+        if (mask) {
+            v0 = (mask[row + x0] > 0.f) ? v0 : 0.f;
+            if (two) v1 = (mask[row + x0 + 1] > 0.f) ? v1 : 0.f;
+        }
+        if (acc) {
+            v0 += dx[row + x0];
+            if (two) v1 += dx[row + x0 + 1];
+        }
+        dx[row + x0] = v0;
+        if (two) dx[row + x0 + 1] = v1;
+    }
 }
 static bool s2_unified_ok(const ConvCfg& cfg, int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int OH, int OW) {
     static const bool on = getenv("AG2V_NO_S2_UNIFIED") == nullptr;
@@ -1263,9 +1284,8 @@ extern "C" int ag2v_conv2d_dgrad_ex(const float* dy, const float* w, const float
                 f.det = cfg.det;
                 const int rc = launch_igemm(f, st, false, true);
                 if (rc != AG2V_OK) return rc;
-                const long long total = (long long)nc * C * H * W;
-                hipLaunchKernelGGL(depth_to_space_s2_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, tmp,
-                                   mask ? mask + (size_t)n0 * dxs : nullptr, dx + (size_t)n0 * dxs, total, C, H, W, gy.Q, gx.Q, gy.ay[0], gx.ay[0],
+                hipLaunchKernelGGL(depth_to_space_s2_kernel, dim3((unsigned)(nc * C), (unsigned)ceil_div(H, 4)), dim3(64, 4), 0, st, tmp,
+                                   mask ? mask + (size_t)n0 * dxs : nullptr, dx + (size_t)n0 * dxs, C, H, W, gy.Q, gx.Q, gy.ay[0], gx.ay[0],
                                    accumulate ? 1 : 0);
                 if (hipGetLastError() != hipSuccess) return AG2V_EHIP;
             }

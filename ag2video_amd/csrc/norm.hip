@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
         float dg[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) dg[i] = g[i] * xv[i];
-        if (dgb_split) {        // dgamma | dbeta go to a bf16x3 data gradient + weight gradient only: stored as split words
+        if (dgb_split & 1) {    // dgamma | dbeta go to a bf16x3 data gradient + weight gradient only: stored as split words
             float ps[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) { dg[i] = pack_split(dg[i]); ps[i] = pack_split(g[i]); }
@@ -432,6 +432,10 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
         const float sc = is * (w ? w[c] : 1.f);
 #pragma unroll
         for (int i = 0; i < 16; ++i) g[i] = sc * (g[i] - m1 - xv[i] * m2);
+    }
+    if (dgb_split & 4) {        // dx goes to the data / weight gradient (+ bias sum) of the convolution that produced x, and nothing else
+#pragma unroll
+        for (int i = 0; i < 16; ++i) g[i] = pack_split(g[i]);
     }
     store16<VEC>(dx + off, cnt, g);
 }
@@ -630,7 +634,7 @@ __global__ __launch_bounds__(256) void spade_pair_bwd_apply_kernel(const float* 
             dg[i] = g[i] * xh[i];
             acc[i] += g[i] * (1.f + t[i]) - m1 - xh[i] * m2;
         }
-        if (dgb_split) {
+        if (dgb_split & 1) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) { dg[i] = pack_split(dg[i]); g[i] = pack_split(g[i]); }
         }
@@ -640,6 +644,10 @@ __global__ __launch_bounds__(256) void spade_pair_bwd_apply_kernel(const float* 
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] *= is;
     if (UP == 1) {
+        if (dgb_split & 4) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = pack_split(acc[i]);
+        }
         store16<true>(dxs + off, cnt, acc);
         return;
     }
@@ -661,7 +669,9 @@ __global__ __launch_bounds__(256) void spade_pair_bwd_apply_kernel(const float* 
         const int oy = o / W, ox = o - oy * W;
         if (oy & 1) continue;
         const float2 a = hsum[f], b = hsum[f + wq];
-        *reinterpret_cast<float2*>(dplane + (size_t)(oy >> 1) * Ws + (ox >> 1)) = make_float2(a.x + b.x, a.y + b.y);
+        float2 r = make_float2(a.x + b.x, a.y + b.y);
+        if (dgb_split & 4) r = make_float2(pack_split(r.x), pack_split(r.y));
+        *reinterpret_cast<float2*>(dplane + (size_t)(oy >> 1) * Ws + (ox >> 1)) = r;
     }
 }
 
@@ -867,7 +877,7 @@ static int norm_bwd_launch(int mode, bool do_reduce, bool do_apply, const float*
     }                                                                                                                                \
     if (do_apply)                                                                                                                    \
         hipLaunchKernelGGL((norm_bwd_apply_kernel<M, V>), g, t, 0, st, dy, y, x, gamma, w, mean, invstd, sums, dx, dgamma, dbeta, C, \
-                           HW, nchunk, inv_count, slope, gbx, Ng, dgb_split ? 1 : 0, bias, ggx);
+                           HW, nchunk, inv_count, slope, gbx, Ng, dgb_split & 5, bias, ggx);
     if (mode == 0) {
         if (v) { LAUNCH_BWD(0, true) } else { LAUNCH_BWD(0, false) }
     } else {
@@ -877,9 +887,9 @@ static int norm_bwd_launch(int mode, bool do_reduce, bool do_apply, const float*
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
 }
-// dgb_split != 0 (modes 1 / 2): dgamma / dbeta are written as split words (ag2v_conv_opts::dy_split) -- they are read by the data
-// gradient and the weight gradient of the convolution that produced gamma | beta and by nothing else (its bias gradient comes
-// from `sums`).
+// dgb_split (flag word), bit 0 (modes 1 / 2): dgamma / dbeta are written as split words (ag2v_conv_opts::dy_split) -- they are read by the
+// data gradient and the weight gradient of the convolution that produced gamma | beta and by nothing else (its bias gradient comes
+// from `sums`).  Bit 2 (value 4): dx is written as split words too -- for an x that one convolution produced and nothing else reads.
 // mode 0 with y == NULL: the LeakyReLU branch of every element is recomputed from x, w and `bias` (the affine pair the forward
 // pass applied: y = lrelu(xhat w + bias)) instead of being read from the forward output.
 // _p ("phased"): phase 0 = both passes (ag2v_norm_bwd_gs); 1 = the reduce pass only (sums written); 2 = the apply pass only (sums read).
@@ -1038,8 +1048,9 @@ extern "C" int ag2v_spade_pair_bwd_sp(const float* dy0, const float* y0, const f
     hipStream_t st = (hipStream_t)stream;
     // dgb_split is a flag word: 1 = dgb0 / dgb1 written as split words; 2 = gb0 / gb1 point at compact gamma copies [N, C, H, W]
     // (the backward never reads beta: a caller that keeps only gamma frees half of every gamma | beta tensor of the tape)
+    // 4 = dxs written as split words (xs produced by one convolution and read by this pair only)
     const int gcompact = (dgb_split >> 1) & 1;
-    dgb_split &= 1;
+    dgb_split &= 5;
     const int HW = H * W, nchunk = ceil_div(HW, CHUNK);
     const long long nblk = (long long)N * C * nchunk;
     if (nblk >= (1LL << 31)) return AG2V_EINVAL;
@@ -1057,7 +1068,7 @@ extern "C" int ag2v_spade_pair_bwd_sp(const float* dy0, const float* y0, const f
     }                                                                                                                                \
     if (phase != 1)                                                                                                                  \
         hipLaunchKernelGGL(spade_pair_bwd_apply_kernel<U>, g, t, 0, st, dy0, y0, dy1, y1, xs, gb0, gb1, mean, invstd, sums, dxs, dgb0, dgb1, \
-                           C, HW, W, nchunk, inv_count, slope0, slope1, Ng, dgb_split ? 1 : 0, gcompact);
+                           C, HW, W, nchunk, inv_count, slope0, slope1, Ng, dgb_split, gcompact);
     if (up == 1) { PAIR_BWD(1) } else { PAIR_BWD(2) }
 #undef PAIR_BWD
     AG2V_CHECK_LAUNCH();

@@ -24,9 +24,10 @@ class SPADEResnetBlock(nn.Module):
         if self.learned_shortcut:
             self.norm_s = SPADE(cfg, fin, opt.semantic_nc)
 
-    def forward(self, x, seg, up=1):
+    def forward(self, x, seg, up=1, x_single_reader=False):
         """up = 2: ``x`` is the block input BEFORE the nn.Upsample(scale_factor=2) that precedes this block in SPADEGenerator
-        (spade_generator.py:62-76); the block then works at twice x's resolution."""
+        (spade_generator.py:62-76); the block then works at twice x's resolution.
+        x_single_reader: the caller reads x nowhere else (its gradient may then come back as split words: ops.spade_pair)."""
         # norm_0, norm_1 (and norm_s) see the segmentation map at the same resolution (conv_0 keeps the size): their mlp_shared
         # convolutions run as one shared-input group, whose input gradient is accumulated in place (ops.conv2d_shared_input)
         norms = [self.norm_0, self.norm_1] + ([self.norm_s] if self.learned_shortcut else [])
@@ -61,7 +62,7 @@ class SPADEResnetBlock(nn.Module):
             # gradient -- and with up = 2 the upsampled tensor never exists (ops.spade_pair)
             y0, ys = ops.spade_pair(x, self.norm_0.gamma_beta(actv[0]), self.norm_s.gamma_beta(actv[2]), bn0.running_mean,
                                     bn0.running_var, bns.running_mean, bns.running_var, up, bn0.momentum, bn0.eps, 0.2, 1.0,
-                                    ops.current_frame_groups(), out_split=(s0, ss))
+                                    ops.current_frame_groups(), out_split=(s0, ss), xs_single_reader=x_single_reader)
             x_s = self.conv_s(ys)
             dx = self.conv_0(y0)
         else:
@@ -69,7 +70,10 @@ class SPADEResnetBlock(nn.Module):
                 x = ops.upsample2x(x)
             x_s = self.conv_s(self.norm_s(x, seg, actv=actv[2], out_split=ss)) if self.learned_shortcut else x
             dx = self.conv_0(self.norm_0(x, seg, slope=0.2, actv=actv[0], out_split=s0))
-        return self.conv_1(self.norm_1(dx, seg, slope=0.2, actv=actv[1], out_split=s1), residual=x_s)   # out = x_s + dx fused in the conv epilogue
+        # (dx = conv_0's output is read by norm_1 and nothing else: its gradient may come back as split words)
+        # (with a learned shortcut x_s = conv_s(...) is read here and nowhere else: a split-word d(out) passes through to it)
+        return self.conv_1(self.norm_1(dx, seg, slope=0.2, actv=actv[1], out_split=s1, x_single_reader=True),
+                           residual=x_s, residual_single_reader=self.learned_shortcut)                  # out = x_s + dx fused in the conv epilogue
 
 # torchvision.models.vgg19 "features" configuration ('E': 16 conv3x3 + ReLU layers, 'M' = MaxPool2d(2, 2)); the reference pins
 # torchvision 0.5.0 (README.md:23).  Module indices inside ``features`` are what the slices below are named after.

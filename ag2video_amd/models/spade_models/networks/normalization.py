@@ -47,14 +47,14 @@ class SpectralConv2d(nn.Module):
         return self.weight_orig, ops.spectral_scales(self.weight_orig, self.weight_u, self.weight_v, ops.current_frame_groups(),
                                                      self.training, self.eps)
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, residual_single_reader=False):
         # Training: ONE formulation for the frame-batched pass (T groups) and a single call (T = 1) -- the raw weight_orig in the
         # GEMM and 1 / sigma_t applied to the product in the epilogue.  (conv(x, W / sigma) and conv(x, W) / sigma differ in the last
         # bit; with both paths on the same form the frame-batched and the sequential generator agree bit for bit in deterministic
         # mode, tests/test_fullsize_gpu.py.)  Eval: W / sigma without a power iteration.
         if self.training or ops.current_frame_groups() > 1:
             w, scales = self.weight_and_scales()
-            return ops.conv2d(x, w, self.bias, self.stride, self.padding, residual, gscale=scales)
+            return ops.conv2d(x, w, self.bias, self.stride, self.padding, residual, gscale=scales, residual_single_reader=residual_single_reader)
         return ops.conv2d(x, self.effective_weight(), self.bias, self.stride, self.padding, residual)
 
 
@@ -143,19 +143,19 @@ class SPADE(nn.Module):
             return segmap.at(x.shape[2], x.shape[3])
         return ops.nearest_resize(segmap, x.shape[2], x.shape[3])
 
-    def forward(self, x, segmap, slope=1.0, actv=None, out_split=False):
+    def forward(self, x, segmap, slope=1.0, actv=None, out_split=False, x_single_reader=False):
         """slope: LeakyReLU fused behind the modulation (the caller's actvn, architecture.py:53-54); 1.0 = none.
         ``segmap`` may be a SegmapPyramid: every SPADE of a decoder pass resizes the same map to one of six sizes, so
         the nearest-neighbour resize (normalization.py:102) is done once per size instead of once per SPADE.
         ``actv``: relu(mlp_shared(resized segmap)) computed by the caller together with the other SPADEs that read the same map
-        (SPADEResnetBlock: ops.conv2d_shared_input)."""
+        (SPADEResnetBlock: ops.conv2d_shared_input).  ``x_single_reader``: nothing but this SPADE reads x (ops.spade_norm_fused)."""
         if actv is None:
             seg = self.resized_segmap(x, segmap)
             # mlp_shared = Conv2d + ReLU: the ReLU rides in the convolution's epilogue and its backward in the epilogue of the
             # gamma|beta convolution's data gradient (actv has no other consumer)
             sh = self.mlp_shared[0]
             actv = ops.conv2d(seg, sh.weight, sh.bias, sh.stride[0], sh.padding[0], relu=True, grad_premasked=True)
-        return self.param_free_norm.modulate_fused(x, self.gamma_beta(actv), slope, out_split=out_split)
+        return self.param_free_norm.modulate_fused(x, self.gamma_beta(actv), slope, out_split=out_split, x_single_reader=x_single_reader)
 
     def gamma_beta(self, actv):
         """gamma | beta as ONE [N, 2C, H, W] tensor: mlp_gamma and mlp_beta read the same activation, so they run as one convolution

@@ -76,7 +76,8 @@ class SPADEGenerator(nn.Module):
             x = ops.upsample2x(x)
         x = self.G_middle_1(x, layout)
         for blk in (self.up_0, self.up_1, self.up_2, self.up_3):
-            x = blk(x, layout, up=2)              # nn.Upsample(scale_factor=2) + block: the block reads x at its own resolution
+            # nn.Upsample(scale_factor=2) + block: the block reads x at its own resolution (and is x's only reader)
+            x = blk(x, layout, up=2, x_single_reader=True)
         if self.opt.num_upsampling_layers == 'most':
             x = self.up_4(x, layout, up=2)
         x = self.conv_img(ops.leaky_relu(x, 0.2))

@@ -61,7 +61,7 @@ class SynchronizedBatchNorm2d(nn.Module):
         return ops.spade_norm(x, gamma, beta, self.running_mean, self.running_var, self.training, self.momentum, self.eps,
                               slope, groups=ops.current_frame_groups())
 
-    def modulate_fused(self, x, gb, slope=1.0, out_split=False):
-        """modulate() with gamma | beta as the channel halves of one [N, 2C, H, W] tensor."""
+    def modulate_fused(self, x, gb, slope=1.0, out_split=False, x_single_reader=False):
+        """modulate() with gamma | beta as the channel halves of one [N, 2C, H, W] tensor.  x_single_reader: see ops.spade_norm_fused."""
         return ops.spade_norm_fused(x, gb, self.running_mean, self.running_var, self.training, self.momentum, self.eps, slope,
-                                    groups=ops.current_frame_groups(), out_split=out_split)
+                                    groups=ops.current_frame_groups(), out_split=out_split, x_single_reader=x_single_reader)

@@ -454,6 +454,7 @@ def _wsink_begin(task):
 
 _DIRECT_GRAD = os.environ.get('AG2V_NO_DIRECT_GRAD') is None
 _USE_CHANNEL_SUMS = os.environ.get('AG2V_NO_CHANNEL_SUMS') is None
+_SPLIT_NORM_DX = os.environ.get('AG2V_NO_SPLIT_NORM_DX') is None           # SPADE backwards write d(x) as split words for x's producer (A/B)
 _DIRECT_DEPTH = [0]
 _JOIN_AT_END = [True]
 
@@ -681,7 +682,7 @@ class _Conv2d(torch.autograd.Function):
         st = _stream()
         dys = is_split(dy_in)       # the gradient arrives as split words (written so by the SPADE backward: ops.conv_split_dy_ok)
         _check_taken_offer(ctx, 0, dy_in, "conv2d")
-        if dys and ((relu and not grad_premasked) or has_res or dy is not dy_in):
+        if dys and ((relu and not grad_premasked) or (has_res and not getattr(ctx, '_ag2v_res_linked', False)) or dy is not dy_in):
             raise RuntimeError("conv2d backward: a split-word gradient reached a convolution with a ReLU / residual epilogue")
         if relu and not grad_premasked:
             g = torch.empty_like(dy)
@@ -760,20 +761,24 @@ class _Conv2d(torch.autograd.Function):
                 else:
                     bbuf.copy_(pre)
             else:
-                if dys:
-                    raise RuntimeError("conv2d backward: split-word gradient without its channel sums")
-                _lib.call('ag2v_channel_sum_acc', _ptr(dy), _ptr(bbuf), N, K, dy.shape[2] * dy.shape[3], bacc | _det_bit(), st)
+                _lib.call('ag2v_channel_sum_acc_s', _ptr(dy), _ptr(bbuf), N, K, dy.shape[2] * dy.shape[3], bacc | _det_bit(), 1 if dys else 0, st)
         if has_res and ctx.needs_input_grad[3]:
-            dres = dy
+            dres = dy_in if dys else dy          # (split words: the very tensor, with its mark, for the residual's producer)
         return dx, dw, db, dres, dgs, None, None, None, None, None, None, None, None
 
 
-def conv2d(x, w, bias=None, stride=1, pad=0, residual=None, relu=False, grad_premasked=False, relu_input=False, gscale=None):
+def conv2d(x, w, bias=None, stride=1, pad=0, residual=None, relu=False, grad_premasked=False, relu_input=False, gscale=None,
+           residual_single_reader=False):
     """y = conv2d(x, w) [* gscale per sample group] + bias + residual   (NCHW, square stride/pad); relu=True: y = max(y, 0).
-    grad_premasked / relu_input: see _Conv2d (the pair fuses the ReLU's backward into the consumer's data gradient)."""
+    grad_premasked / relu_input: see _Conv2d (the pair fuses the ReLU's backward into the consumer's data gradient).
+    residual_single_reader: the caller states that nothing else reads `residual`.  When its producer offered to take its gradient as split
+    words, y makes the same offer: a split-word d(y) is this convolution's dy AND, unchanged, d(residual)."""
     if relu and residual is not None and grad_premasked:
         raise RuntimeError("conv2d: grad_premasked with a residual input is not supported (the residual's gradient would be masked)")
-    dy_ok = (not relu and residual is None and int(stride) == 1 and torch.is_grad_enabled() and _USE_CHANNEL_SUMS
+    res_offer = getattr(residual, '_ag2v_dy_split_ok', None) if (residual is not None and residual_single_reader and _SPLIT_NORM_DX) else None
+    if not (isinstance(res_offer, _DySplitOffer) and not res_offer.taken and res_offer.link is None and residual.requires_grad):
+        res_offer = None
+    dy_ok = (not relu and (residual is None or res_offer is not None) and int(stride) == 1 and torch.is_grad_enabled() and _USE_CHANNEL_SUMS
              and conv_split_dy_ok(x.shape, w.shape, stride, pad))
     # x = relu(...) whose producer takes its gradient as split words (conv2d_shared_input): this convolution's data gradient, which
     # applies that ReLU's mask in its epilogue, writes them
@@ -782,6 +787,9 @@ def conv2d(x, w, bias=None, stride=1, pad=0, residual=None, relu=False, grad_pre
                       is_split(x), dx_split, x._ag2v_dy_split_ok.slot if dx_split else None)
     if dy_ok and y.grad_fn is not None:
         _offer_dy_split(y)              # a SPADE backward that is y's only consumer may hand back d(y) as split words
+        if residual is not None:
+            res_offer.link = y._ag2v_dy_split_ok
+            y.grad_fn._ag2v_res_linked = True
     return y
 
 
@@ -808,11 +816,22 @@ class _DySplitOffer(object):
     """`t._ag2v_dy_split_ok` on an operator output t: the producer's backward accepts d(t) as split words.  The producing autograd
     node keeps the same object (`_ag2v_offers[output_nr]`), so its backward knows whether a consumer took the offer -- and then
     insists on receiving that consumer's split-word tensor (anything else means t had a second consumer)."""
-    __slots__ = ('taken', 'slot')
+    __slots__ = ('_taken', 'slot', 'link')
 
     def __init__(self):
-        self.taken = False
+        self._taken = False
         self.slot = None        # (_GradSlots, index): where the taker's backward writes d(t) (conv2d_shared_input)
+        # t is the residual input of a convolution that passes its own output gradient through unchanged (conv2d(residual=t,
+        # residual_single_reader=True)): d(t) is split words exactly when that convolution's offer (this field) was taken
+        self.link = None
+
+    @property
+    def taken(self):
+        return self._taken or (self.link is not None and self.link.taken)
+
+    @taken.setter
+    def taken(self, v):
+        self._taken = bool(v)
 
 
 class _GradSlots(object):
@@ -874,7 +893,7 @@ def _take_dy_split(*ts):
     if not offers or not all(isinstance(o, _DySplitOffer) for o in offers):
         return False
     for o, t in zip(offers, ts):
-        if o.taken:
+        if o.taken or o.link is not None:
             raise RuntimeError("ag2video_amd.ops: the gradient of a tensor (shape %s) was promised to one consumer as split words and a "
                                "second consumer reads the same tensor" % (tuple(t.shape),))
     for o in offers:
@@ -1330,7 +1349,7 @@ class _NormAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, mode, x, p0, p1, running_mean, running_var, training, momentum, eps, slope, groups, out_split=False,
-                dgb_split=False):
+                dgb_split=False, dx_split=False):
         from . import distributed as D
         x, p0, p1 = _c(x), _c(p0), _c(p1)
         _chk(x, p0, p1)
@@ -1362,6 +1381,7 @@ class _NormAct(torch.autograd.Function):
         ctx.save_for_backward(x, y if (slope != 1.0 and not sign_from_x) else None, keep0, mean, invstd, p1 if mode == 0 else None)
         ctx.cfg = (mode, training, slope, N, C, HW, Ng, world if sync else 0)
         ctx.dgb_split = bool(dgb_split) and mode == 2
+        ctx.dx_split = bool(dx_split) and mode == 2      # d(x) as split words: x's producer took the offer (spade_norm_fused)
         return y
 
     @staticmethod
@@ -1391,7 +1411,7 @@ class _NormAct(torch.autograd.Function):
         label = 'spade_norm_bwd' if mode == 2 else 'norm_bwd'
         nbytes = ((7.0 if y is not None or slope == 1.0 else 5.0) if mode == 0 else 11.0) * x.numel() * 4
         args = (kmode, _ptr(dy), _ptr(y), _ptr(x), _ptr(gam), _ptr(wgt), _ptr(bias0), _ptr(mean), _ptr(invstd), _ptr(dx), dg_ptr, db_ptr,
-                _ptr(sums), N, C, HW, Ng, float(slope), _ptr(ws), 1 if ctx.dgb_split else 0)
+                _ptr(sums), N, C, HW, Ng, float(slope), _ptr(ws), (1 if ctx.dgb_split else 0) | (4 if ctx.dx_split else 0))
         if sync_world:
             # (sum dxhat, sum dxhat * xhat) per (group, channel) over ALL ranks between the two passes (batchnorm.py backward of the
             # reduce / broadcast pair); the affine / bias gradients in `sums` stay per rank (averaged with all the others)
@@ -1401,12 +1421,14 @@ class _NormAct(torch.autograd.Function):
             sums = local
         else:
             _launch('ag2v_norm_bwd_gs', label, nbytes, *(args + (_stream(),)), shape=(N, C, HW))
+        if ctx.dx_split:
+            mark_split(dx)
         if mode == 0:
             dw = db = None
             if p0 is not None:
                 tot = sums.sum(dim=0) if G > 1 else sums[0]
                 dw, db = tot[:, 1].contiguous(), tot[:, 0].contiguous()
-            return (None, dx, dw, db) + none[:9]
+            return (None, dx, dw, db) + none[:10]
         if mode == 2:
             # the channel sums of dgamma | dbeta came out of the reduce pass: they ARE the bias gradient of the convolution that produced
             # gamma | beta (layout [N, 2C, H, W]: gamma channels first).  Handed to its backward on the gradient tensor itself (sync mode:
@@ -1415,8 +1437,8 @@ class _NormAct(torch.autograd.Function):
             _attach_channel_sums(dgb, torch.cat([tot[:, 3], tot[:, 2]]))
             if ctx.dgb_split:
                 mark_split(dgb)
-            return (None, dx, dgb, None) + none[:9]
-        return (None, dx, dgamma, dbeta) + none[:9]
+            return (None, dx, dgb, None) + none[:10]
+        return (None, dx, dgamma, dbeta) + none[:10]
 
 
 def batchnorm_act(x, weight, bias, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0, groups=1,
@@ -1567,12 +1589,17 @@ def spade_norm(x, gamma, beta, running_mean, running_var, training=True, momentu
                           float(slope), int(groups))
 
 
-def spade_norm_fused(x, gb, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0, groups=1, out_split=False):
+def spade_norm_fused(x, gb, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0, groups=1, out_split=False,
+                     x_single_reader=False):
     """spade_norm with gamma = gb[:, :C] and beta = gb[:, C:] read in place from the [N, 2C, H, W] output of one convolution
-    (and their gradients written in place into one [N, 2C, H, W] tensor)."""
+    (and their gradients written in place into one [N, 2C, H, W] tensor).
+    x_single_reader: the caller states that nothing else reads x; when x's producer (conv2d) offered to take its output gradient as
+    split words, d(x) is written so (its data / weight gradients then skip the fp32 -> (hi, lo) split of dy)."""
     take = bool(training) and gb.requires_grad and _take_dy_split(gb)
+    # x from a convolution that reads its output gradient as split words (conv2d's offer) and has no other reader: d(x) is written so
+    take_x = bool(training) and bool(x_single_reader) and x.requires_grad and _SPLIT_NORM_DX and _take_dy_split(x)
     y = _NormAct.apply(2, x, gb, None, running_mean, running_var, bool(training), float(momentum), float(eps),
-                       float(slope), int(groups), bool(out_split), take)
+                       float(slope), int(groups), bool(out_split), take, take_x)
     return mark_split(y) if out_split else y
 
 
@@ -1586,7 +1613,7 @@ class _SpadePair(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xs, gb0, gb1, rm0, rv0, rm1, rv1, up, momentum, eps, slope0, slope1, groups, dgb_split=False, split0=False,
-                split1=False):
+                split1=False, dxs_split=False):
         xs, gb0, gb1 = _c(xs), _c(gb0), _c(gb1)
         _chk(xs, gb0, gb1)
         N, C, Hs, Ws = xs.shape
@@ -1621,6 +1648,7 @@ class _SpadePair(torch.autograd.Function):
         ctx.save_for_backward(xs, k0, k1, y0 if slope0 != 1.0 else None, y1 if slope1 != 1.0 else None, mean, invstd)
         ctx.cfg = (up, slope0, slope1, N, C, H, W, Ng)
         ctx.dgb_split = bool(dgb_split)
+        ctx.dxs_split = bool(dxs_split)
         return y0, y1
 
     @staticmethod
@@ -1645,7 +1673,7 @@ class _SpadePair(torch.autograd.Function):
         nbytes = (3.0 * xs.numel() + (12.0 + 2.0 * ny) * dy0.numel()) * 4
         args = (_ptr(dy0), _ptr(y0), _ptr(dy1), _ptr(y1), _ptr(xs), _ptr(gb0), _ptr(gb1), _ptr(mean), _ptr(invstd), _ptr(dxs), _ptr(dgb0),
                 _ptr(dgb1), _ptr(sums), N, C, H, W, up, Ng, float(slope0), float(slope1), _ptr(ws),
-                (1 if ctx.dgb_split else 0) | (2 if ctx.gcompact else 0))
+                (1 if ctx.dgb_split else 0) | (2 if ctx.gcompact else 0) | (4 if ctx.dxs_split else 0))
         if ctx.sync_world:       # synchronised statistics: the reduce pass, the ranks' sums, the apply pass (see _sync_bwd_sums)
             _lib.call('ag2v_spade_pair_bwd_sp', *(args + (1, 0.0, _stream())))
             local = _sync_bwd_sums(sums, 2)
@@ -1659,15 +1687,20 @@ class _SpadePair(torch.autograd.Function):
         _attach_channel_sums(dgb1, torch.cat([tot[:, 7], tot[:, 6]]))
         if ctx.dgb_split:
             mark_split(dgb0); mark_split(dgb1)
-        return (dxs, dgb0, dgb1) + (None,) * 13
+        if ctx.dxs_split:
+            mark_split(dxs)
+        return (dxs, dgb0, dgb1) + (None,) * 14
 
 
-def spade_pair(xs, gb0, gb1, rm0, rv0, rm1, rv1, up=1, momentum=0.1, eps=1e-5, slope0=1.0, slope1=1.0, groups=1, out_split=(False, False)):
+def spade_pair(xs, gb0, gb1, rm0, rv0, rm1, rv1, up=1, momentum=0.1, eps=1e-5, slope0=1.0, slope1=1.0, groups=1, out_split=(False, False),
+               xs_single_reader=False):
     """Two SPADE modulations of one input (shared batch statistics; both running-stat pairs updated), the input optionally taken
-    before its 2x nearest upsampling (up = 2).  Training mode, batch statistics; requires spade_pair_supported(H, W, up)."""
+    before its 2x nearest upsampling (up = 2).  Training mode, batch statistics; requires spade_pair_supported(H, W, up).
+    xs_single_reader: nothing else reads xs; when its producer offered (conv2d), d(xs) is written as split words."""
     split = gb0.requires_grad and gb1.requires_grad and _take_dy_split(gb0, gb1)
+    take_xs = bool(xs_single_reader) and xs.requires_grad and _SPLIT_NORM_DX and _take_dy_split(xs)
     y0, y1 = _SpadePair.apply(xs, gb0, gb1, rm0, rv0, rm1, rv1, int(up), float(momentum), float(eps), float(slope0), float(slope1),
-                              int(groups), split, bool(out_split[0]), bool(out_split[1]))
+                              int(groups), split, bool(out_split[0]), bool(out_split[1]), take_xs)
     if out_split[0]:
         mark_split(y0)
     if out_split[1]:

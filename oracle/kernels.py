@@ -13,7 +13,8 @@ import torch
 import torch.nn.functional as F
 
 
-def conv2d(x, w, bias=None, stride=1, pad=0, residual=None, relu=False, grad_premasked=False, relu_input=False, gscale=None):
+def conv2d(x, w, bias=None, stride=1, pad=0, residual=None, relu=False, grad_premasked=False, relu_input=False, gscale=None,
+           residual_single_reader=False):
     """nn.Conv2d.forward (aten.convolution), e.g. generator.py:30, architecture.py:29-32, discriminator.py:368-379.
     relu: the nn.ReLU that follows SPADE's mlp_shared convolution (normalization.py:92-95).  grad_premasked / relu_input only tell
     the product where to apply that ReLU's backward; autograd does it here.
@@ -176,14 +177,16 @@ def spade_norm(x, gamma, beta, running_mean, running_var, training=True, momentu
     return _lrelu(n * (1 + gamma) + beta, slope)
 
 
-def spade_norm_fused(x, gb, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0, groups=1, out_split=False):
+def spade_norm_fused(x, gb, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0, groups=1, out_split=False,
+                     x_single_reader=False):
     """spade_norm with gamma | beta stacked along channels (the product runs mlp_gamma and mlp_beta, normalization.py:105-106,
     as one convolution)."""
     C = x.shape[1]
     return spade_norm(x, gb[:, :C], gb[:, C:], running_mean, running_var, training, momentum, eps, slope, groups)
 
 
-def spade_pair(xs, gb0, gb1, rm0, rv0, rm1, rv1, up=1, momentum=0.1, eps=1e-5, slope0=1.0, slope1=1.0, groups=1, out_split=(False, False)):
+def spade_pair(xs, gb0, gb1, rm0, rv0, rm1, rv1, up=1, momentum=0.1, eps=1e-5, slope0=1.0, slope1=1.0, groups=1, out_split=(False, False),
+               xs_single_reader=False):
     """Checker for ops.spade_pair: nn.Upsample(scale_factor=2) (spade_generator.py:62-76) followed by the block's two SPADE layers on
     the same input (norm_0 / norm_s, architecture.py:52-53,60-61), each with its own running buffers."""
     x = upsample2x(xs) if up == 2 else xs

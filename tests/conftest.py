@@ -23,7 +23,7 @@ def device():
 # Order of the GPU suite (the driver runs `pytest -m gpu -x`): kernel-level oracle tests and the reference-golden step first, then the
 # configuration steps, then full-size / RCCL-launcher / script tests -- so that whatever stops the run, the tests that pin each kernel
 # to the oracle have already reported.  Files not listed keep their alphabetical place after the listed ones.
-_GPU_FILE_ORDER = ['test_ops_gpu', 'test_halo_gpu', 'test_grad_slots_gpu', 'test_graph_program_gpu', 'test_step_gpu', 'test_gradcheck_gpu',
+_GPU_FILE_ORDER = ['test_ops_gpu', 'test_halo_gpu', 'test_grad_slots_gpu', 'test_split_norm_dx_gpu', 'test_wgrad_halo_gpu', 'test_graph_program_gpu', 'test_step_gpu', 'test_gradcheck_gpu',
                    'test_distributed_gpu', 'test_inference_gpu', 'test_extras_gpu', 'test_configs_gpu', 'test_fullsize_gpu', 'test_bench_gpu']
 
 
