@@ -67,6 +67,10 @@ _SIGS = {
     'ag2v_layout_render_bwd': (c_int, [_P, _P, _P, _P] + [c_int] * 5 + [_P]),
     'ag2v_layout_conv_fwd': (c_int, [_P, _P, _P, _P, _P] + [c_int] * 9 + [_P]),
     'ag2v_layout_conv_img_fwd': (c_int, [_P, _P, _P, _P, _P] + [c_int] * 9 + [_P, _P, _P, c_int, _P]),
+    'ag2v_layout_conv_img_fwd_stats': (c_int, [_P, _P, _P, _P, _P] + [c_int] * 9 + [_P, _P, _P, c_int, _P, c_int, _P]),
+    'ag2v_layout_conv_stats_supported': (c_int, [c_int] * 11),
+    'ag2v_layout_conv_stats_floats': (c_size_t, [c_int] * 3),
+    'ag2v_bn_finalize_partials': (c_int, [_P, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P]),
     'ag2v_layout_conv_bwd': (c_int, [_P, _P, _P, _P] + [c_int] * 9 + [_P]),
     'ag2v_flow_warp_fwd': (c_int, [_P, _P, _P] + [c_int] * 4 + [_P]),
     'ag2v_flow_warp_bwd': (c_int, [_P, _P, _P, _P, _P] + [c_int] * 4 + [_P]),

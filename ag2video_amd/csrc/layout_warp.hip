@@ -465,13 +465,33 @@ __global__ __launch_bounds__(256) void layout_conv_fwd_kernel(const float* __res
 //     loop walks the list (no per-slot LDS round trip + branch); an object's six profile values per lane are one 16-byte read + 2.
 // A row that touches more than ACT objects contracts the extra ones on the fly (correct, slower; c3 rows touch 2-5).
 typedef __attribute__((address_space(3))) void* lc_lds_vptr;
+// Sums of 16 per-lane values over the 64 lanes of a wave with 17 exchanges instead of 96: four halving steps (each lane keeps the half of
+// its values that its side of the exchange owns and adds the partner's), then two full steps.  Lane l returns the total of value (l >> 2) & 15.
+__device__ __forceinline__ float lc_wave_sum16(const float (&v)[16]) {
+    const int lane = threadIdx.x & 63;
+    float a[8], b[4], c[2];
+    const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8, h2 = lane & 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (h5 ? v[i + 8] : v[i]) + __shfl_xor(h5 ? v[i] : v[i + 8], 32, 64);      // value i + 8 bit5
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[i] = (h4 ? a[i + 4] : a[i]) + __shfl_xor(h4 ? a[i] : a[i + 4], 16, 64);      // i + 4 bit4 + 8 bit5
+#pragma unroll
+    for (int i = 0; i < 2; ++i) c[i] = (h3 ? b[i + 2] : b[i]) + __shfl_xor(h3 ? b[i] : b[i + 2], 8, 64);       // i + 2 bit3 + ...
+    float r = (h2 ? c[1] : c[0]) + __shfl_xor(h2 ? c[0] : c[1], 4, 64);                                        // bit2 + 2 bit3 + 4 bit4 + 8 bit5
+    r += __shfl_xor(r, 1, 64);
+    r += __shfl_xor(r, 2, 64);
+    return r;
+}
 template <int KPER>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void layout_conv_fwd3_kernel(const float* __restrict__ U, const float* __restrict__ boxes, const int* __restrict__ keep,
                              const float* __restrict__ residual, float* __restrict__ out, int J, int K, int H, int W,
-                             const float* __restrict__ img, const float* __restrict__ wimg, const float* __restrict__ iscale, int IC) {
+                             const float* __restrict__ img, const float* __restrict__ wimg, const float* __restrict__ iscale, int IC,
+                             float* __restrict__ stat_partial, int Ng) {
 #if defined(__HIP_DEVICE_COMPILE__)      // (the host pass only needs the stub; it rejects the LDS-DMA builtin)
     constexpr int R = 3, RR = 9, RRP = 12, TJ = LC_TJ, TW = LC_TW, ACT = 10, UB = KPER * RR, IR = R + 3, IWP = 272;
+    static_assert(KPER == 16, "the row statistics reduce 16 channels across the wave");
+    __shared__ float2 rowst[4][KPER];             // (mean, M2) of the wave's row for each channel of the block (stat_partial != null)
     constexpr int UPIECES = (TJ * UB * 4 + 1023) / 1024, WPIECES = (KPER * 3 * RR * 4 + 1023) / 1024;
     __shared__ float txp[TJ][TW];                 // column profiles; index x + 4 (x = -4 .. 259 for W <= 256)
     __shared__ float tyl[4][TJ][4];
@@ -543,8 +563,26 @@ void layout_conv_fwd3_kernel(const float* __restrict__ U, const float* __restric
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int xq = lane;
     const bool px_live = oy < H && xq * 4 < W;
+    // batch-norm statistics of the output (stat_partial != null): one Chan partial (count, mean, M2) per (sample, channel, 4-row band),
+    // laid out as bn_stats_finalize_kernel reads them -- the consumer's statistics pass over the [N, K, H, W] result is not needed
+    auto band_partial = [&](int kprev) {
+        if (threadIdx.x < KPER) {
+            float cnt = 0.f, mean = 0.f, m2 = 0.f;
+            for (int r = 0; r < 4 && oy0 + r < H; ++r) {
+                const float2 p = rowst[r][threadIdx.x];
+                const float nb = (float)W, nt = cnt + nb, d = p.x - mean;
+                mean += d * (nb / nt);
+                m2 += p.y + d * d * (cnt * nb / nt);
+                cnt = nt;
+            }
+            const int nbands = gridDim.x, g = n / Ng, nl = n - g * Ng;
+            float* o = stat_partial + (((size_t)g * K + kprev + threadIdx.x) * ((size_t)Ng * nbands) + (size_t)nl * nbands + blockIdx.x) * 3;
+            o[0] = cnt; o[1] = mean; o[2] = m2;
+        }
+    };
     for (int k0 = blockIdx.z * KPER; k0 < K; k0 += gridDim.z * KPER) {
         __syncthreads();          // the block's U / filter copies have landed (every wave waited for its pieces); csl / wl of the previous block are free
+        if (stat_partial && k0 != blockIdx.z * KPER) band_partial(k0 - gridDim.z * KPER);      // (rowst is rewritten behind the next barrier)
         const int na = actl[wave][0];
         for (int idx = lane; idx < min(na, ACT) * KPER; idx += 64) {
             const int a = idx / KPER, kk = idx - a * KPER;
@@ -641,6 +679,29 @@ void layout_conv_fwd3_kernel(const float* __restrict__ U, const float* __restric
                 *reinterpret_cast<float4*>(out + (((size_t)n * K + k0 + kk) * H + oy) * W + xq * 4) =
                     make_float4(acc[kk][0], acc[kk][1], acc[kk][2], acc[kk][3]);
         }
+        if (stat_partial && oy < H) {        // (wave-uniform) behind the stores: two passes over the row held in registers
+            float v[KPER];
+#pragma unroll
+            for (int kk = 0; kk < KPER; ++kk) v[kk] = px_live ? (acc[kk][0] + acc[kk][1]) + (acc[kk][2] + acc[kk][3]) : 0.f;
+            const float tot = lc_wave_sum16(v);               // lane l: channel (l >> 2) & 15
+            const float invw = 1.f / (float)W;
+            float mu[KPER];
+#pragma unroll
+            for (int kk = 0; kk < KPER; ++kk)                                                                // (wave-uniform: scalar registers)
+                mu[kk] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tot), 4 * kk)) * invw;
+#pragma unroll
+            for (int kk = 0; kk < KPER; ++kk) {
+                const float d0 = acc[kk][0] - mu[kk], d1 = acc[kk][1] - mu[kk], d2 = acc[kk][2] - mu[kk], d3 = acc[kk][3] - mu[kk];
+                v[kk] = px_live ? fmaf(d0, d0, d1 * d1) + fmaf(d2, d2, d3 * d3) : 0.f;
+            }
+            const float m2 = lc_wave_sum16(v);
+            if ((lane & 3) == 0) rowst[wave][lane >> 2] = make_float2(tot * invw, m2);      // (lane l holds channel l >> 2 of both sums)
+        }
+    }
+    if (stat_partial) {
+        __syncthreads();
+        const int nblk = (K / KPER - 1 - (int)blockIdx.z) / (int)gridDim.z;      // index of this workgroup's last channel block
+        band_partial((int)blockIdx.z * KPER + nblk * (int)gridDim.z * KPER);
     }
 #endif
 }
@@ -1007,9 +1068,23 @@ extern "C" int ag2v_layout_render_bwd(const float* dout, const float* boxes, con
     return AG2V_OK;
 }
 
-extern "C" int ag2v_layout_conv_img_fwd(const float* U, const float* boxes, const int* keep, const float* residual, float* out,
-                                        int NB, int J, int K, int H, int W, int R, int stride, int pad, int pool, const float* img,
-                                        const float* wimg, const float* iscale, int IC, void* stream) {
+// The launch conditions of layout_conv_fwd3_kernel that do not depend on addresses (U / wimg must also be 16-byte aligned)
+static bool lc_fwd3_shape_ok(int J, int K, int H, int W, int R, int stride, int pad, int pool, int IC, bool has_img) {
+    static const bool no_tables = getenv("AG2V_LC_GENERIC") != nullptr;       // A/B aids
+    static const bool no_fwd3 = getenv("AG2V_NO_LC_FWD3") != nullptr;
+    return J <= LC_TJ && W <= LC_TW && !no_tables && !no_fwd3 && R == 3 && pad == 1 && stride == 1 && pool == 0 && W <= 256 && (W & 3) == 0 &&
+           K % 16 == 0 && (!has_img || IC <= 3) && (size_t)J * K * 9 * 4 < 0xFFFFFFF0ull;
+}
+// 1 when ag2v_layout_conv_img_fwd_stats can write batch-norm partials for this call (16-byte aligned U / wimg provided)
+extern "C" int ag2v_layout_conv_stats_supported(int NB, int J, int K, int H, int W, int R, int stride, int pad, int pool, int IC, int Ng) {
+    static const bool off = getenv("AG2V_NO_LC_STATS") != nullptr;
+    return (!off && NB > 0 && Ng > 0 && NB % Ng == 0 && NB <= 65535 && lc_fwd3_shape_ok(J, K, H, W, R, stride, pad, pool, IC, IC > 0)) ? 1 : 0;
+}
+// floats of the partial buffer: [NB / Ng, K, Ng * ceil(H / 4), 3]
+extern "C" size_t ag2v_layout_conv_stats_floats(int NB, int K, int H) { return (size_t)NB * K * ceil_div(H, 4) * 3; }
+static int layout_conv_img_fwd_impl(const float* U, const float* boxes, const int* keep, const float* residual, float* out,
+                                    int NB, int J, int K, int H, int W, int R, int stride, int pad, int pool, const float* img,
+                                    const float* wimg, const float* iscale, int IC, float* stat_partial, int Ng, void* stream) {
     // J == 0 (with img): no layout term at all -- a same-size convolution of <= 8 dense channels to K outputs through the kernel's
     // image path (U / boxes / keep are not read): the data gradients of conv_img / conv_flow, whose gathered tensor has 3 / 2 channels
     if (!out || NB <= 0 || J < 0 || (J == 0 && !img) || (J > 0 && (!U || !boxes || !keep)) || K <= 0 || H <= 0 || W <= 0 || stride <= 0 ||
@@ -1031,17 +1106,34 @@ extern "C" int ag2v_layout_conv_img_fwd(const float* U, const float* boxes, cons
         const int nkb = ceil_div(K, KPER), wg = ceil_div(OH, 4) * NB;
         grid.z = wg >= 2048 ? 1 : std::min(nkb, ceil_div(2048, wg));
     }
-    static const bool no_fwd3 = getenv("AG2V_NO_LC_FWD3") != nullptr;       // A/B aid
-    if (tables && !no_fwd3 && R == 3 && pad == 1 && stride == 1 && pool == 0 && W <= 256 && (W & 3) == 0 && K % KPER == 0 && (!img || IC <= 3) &&
-        (size_t)J * K * 9 * 4 < 0xFFFFFFF0ull && (((uintptr_t)U | (uintptr_t)wimg) & 15) == 0) {
+    const bool fwd3 = tables && lc_fwd3_shape_ok(J, K, H, W, R, stride, pad, pool, IC, img != nullptr) &&
+                      (((uintptr_t)U | (uintptr_t)wimg) & 15) == 0;
+    if (stat_partial && (!fwd3 || Ng <= 0 || NB % Ng != 0)) return AG2V_EINVAL;      // statistics come out of that kernel only
+    if (fwd3) {
         hipLaunchKernelGGL((layout_conv_fwd3_kernel<KPER>), grid, dim3(256), 0, (hipStream_t)stream, U, boxes, keep, residual, out, J, K, H, W,
-                           img, wimg, iscale, IC);
+                           img, wimg, iscale, IC, stat_partial, Ng > 0 ? Ng : 1);
     } else
     if (tables) { if (R == 3) LC_LAUNCH(layout_conv_fwd_kernel, 3); else LC_LAUNCH(layout_conv_fwd_kernel, 4); }
     else        { if (R == 3) LC_LAUNCH(layout_conv_fwd_generic_kernel, 3); else LC_LAUNCH(layout_conv_fwd_generic_kernel, 4); }
 #undef LC_LAUNCH
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
+}
+extern "C" int ag2v_layout_conv_img_fwd(const float* U, const float* boxes, const int* keep, const float* residual, float* out,
+                                        int NB, int J, int K, int H, int W, int R, int stride, int pad, int pool, const float* img,
+                                        const float* wimg, const float* iscale, int IC, void* stream) {
+    return layout_conv_img_fwd_impl(U, boxes, keep, residual, out, NB, J, K, H, W, R, stride, pad, pool, img, wimg, iscale, IC, nullptr, 1, stream);
+}
+// ... and the batch-norm statistics of `out` as Chan partials (count, mean, M2) per (sample, channel, band of 4 rows), in the layout
+// ag2v_bn_finalize_partials reads: stat_partial[NB / Ng][K][Ng * ceil(H / 4)][3] (ag2v_layout_conv_stats_floats), for a batch norm whose
+// statistics are taken per group of Ng consecutive samples (generator.py:30 conv_dim_in -> SynchronizedBatchNorm2d).  Only where
+// ag2v_layout_conv_stats_supported() says so; AG2V_EINVAL otherwise.
+extern "C" int ag2v_layout_conv_img_fwd_stats(const float* U, const float* boxes, const int* keep, const float* residual, float* out,
+                                              int NB, int J, int K, int H, int W, int R, int stride, int pad, int pool, const float* img,
+                                              const float* wimg, const float* iscale, int IC, float* stat_partial, int Ng, void* stream) {
+    if (!stat_partial) return AG2V_EINVAL;
+    return layout_conv_img_fwd_impl(U, boxes, keep, residual, out, NB, J, K, H, W, R, stride, pad, pool, img, wimg, iscale, IC, stat_partial, Ng,
+                                    stream);
 }
 extern "C" int ag2v_layout_conv_fwd(const float* U, const float* boxes, const int* keep, const float* residual, float* out,
                                     int NB, int J, int K, int H, int W, int R, int stride, int pad, int pool, void* stream) {

@@ -799,6 +799,17 @@ extern "C" int ag2v_norm_apply_half(const float* x, const float* mean, const flo
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
 }
+// mean / invstd (and the running-statistics updates) of ag2v_bn_stats_g from partials another kernel wrote while it produced x
+// (ag2v_layout_conv_img_fwd_stats): partial[G][C][nparts][3] = Chan's (count, mean, M2) of disjoint element sets covering each (group, channel).
+extern "C" int ag2v_bn_finalize_partials(const float* partial, int G, int C, int nparts, float eps, float momentum, float* mean, float* invstd,
+                                         float* running_mean, float* running_var, void* stream) {
+    if (!partial || !mean || !invstd || G <= 0 || C <= 0 || nparts <= 0) return AG2V_EINVAL;
+    if (G > FIN_MAXG && running_mean) return AG2V_EINVAL;
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, (hipStream_t)stream, partial, G, C, nparts, eps,
+                       momentum, mean, invstd, running_mean, running_var);
+    AG2V_CHECK_LAUNCH();
+    return AG2V_OK;
+}
 extern "C" int ag2v_bn_stats(const float* x, int N, int C, int HW, float eps, float momentum, float* mean, float* invstd,
                              float* running_mean, float* running_var, float* workspace, void* stream) {
     return ag2v_bn_stats_g(x, N, C, HW, N, eps, momentum, mean, invstd, running_mean, running_var, workspace, stream);

@@ -1277,8 +1277,10 @@ class _SpectralScalesMulti(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------ batch norm family
-def _bn_stats(x, running_mean, running_var, training, momentum, eps, groups=1):
-    """-> mean, invstd ([groups * C]: sample n uses row n // (N / groups)), N, C, HW, samples per group."""
+def _bn_stats(x, running_mean, running_var, training, momentum, eps, groups=1, partials=None):
+    """-> mean, invstd ([groups * C]: sample n uses row n // (N / groups)), N, C, HW, samples per group.
+    partials (BNPartials, from _bn_partials_of(x, groups)): the statistics pass over x is replaced by the combination of the partials
+    x's producer wrote."""
     N, C = x.shape[0], x.shape[1]
     HW = x.numel() // (N * C)
     if N % groups != 0:
@@ -1287,6 +1289,10 @@ def _bn_stats(x, running_mean, running_var, training, momentum, eps, groups=1):
     if training:
         mean = torch.empty(groups * C, device=x.device, dtype=torch.float32)
         invstd = torch.empty(groups * C, device=x.device, dtype=torch.float32)
+        if partials is not None:
+            _lib.call('ag2v_bn_finalize_partials', _ptr(partials.buf), groups, C, partials.nparts, float(eps), float(momentum), _ptr(mean),
+                      _ptr(invstd), _ptr(running_mean), _ptr(running_var), _stream())
+            return mean, invstd, N, C, HW, Ng
         ws = torch.empty(_lib.query('ag2v_bn_workspace_floats', N, C, HW), device=x.device, dtype=torch.float32)
         _lib.call('ag2v_bn_stats_g', _ptr(x), N, C, HW, Ng, float(eps), float(momentum), _ptr(mean), _ptr(invstd),
                   _ptr(running_mean), _ptr(running_var), _ptr(ws), _stream())
@@ -1349,17 +1355,17 @@ class _NormAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, mode, x, p0, p1, running_mean, running_var, training, momentum, eps, slope, groups, out_split=False,
-                dgb_split=False, dx_split=False):
+                dgb_split=False, dx_split=False, partials=None):
         from . import distributed as D
         x, p0, p1 = _c(x), _c(p0), _c(p1)
         _chk(x, p0, p1)
         sync = training and D.sync_bn()
         world = 1
         if sync:
-            mean, invstd, N, C, HW, Ng = _bn_stats(x, None, None, True, momentum, eps, groups)
+            mean, invstd, N, C, HW, Ng = _bn_stats(x, None, None, True, momentum, eps, groups, partials)
             mean, invstd, world = _sync_combine(mean, invstd, groups, C, Ng * HW, eps, momentum, [(running_mean, running_var)])
         else:
-            mean, invstd, N, C, HW, Ng = _bn_stats(x, running_mean, running_var, training, momentum, eps, groups)
+            mean, invstd, N, C, HW, Ng = _bn_stats(x, running_mean, running_var, training, momentum, eps, groups, partials if training else None)
         y = torch.empty_like(x)
         if mode == 0:
             _lib.call('ag2v_norm_apply_gs', 0, _ptr(x), _ptr(mean), _ptr(invstd), _ptr(p0), _ptr(p1), None, None, _ptr(y),
@@ -1428,7 +1434,7 @@ class _NormAct(torch.autograd.Function):
             if p0 is not None:
                 tot = sums.sum(dim=0) if G > 1 else sums[0]
                 dw, db = tot[:, 1].contiguous(), tot[:, 0].contiguous()
-            return (None, dx, dw, db) + none[:10]
+            return (None, dx, dw, db) + none[:11]
         if mode == 2:
             # the channel sums of dgamma | dbeta came out of the reduce pass: they ARE the bias gradient of the convolution that produced
             # gamma | beta (layout [N, 2C, H, W]: gamma channels first).  Handed to its backward on the gradient tensor itself (sync mode:
@@ -1437,8 +1443,8 @@ class _NormAct(torch.autograd.Function):
             _attach_channel_sums(dgb, torch.cat([tot[:, 3], tot[:, 2]]))
             if ctx.dgb_split:
                 mark_split(dgb)
-            return (None, dx, dgb, None) + none[:10]
-        return (None, dx, dgamma, dbeta) + none[:10]
+            return (None, dx, dgb, None) + none[:11]
+        return (None, dx, dgamma, dbeta) + none[:11]
 
 
 def batchnorm_act(x, weight, bias, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, slope=1.0, groups=1,
@@ -1447,7 +1453,7 @@ def batchnorm_act(x, weight, bias, running_mean, running_var, training=True, mom
     out_split: the result is stored as split words (is_split) -- for a tensor that only bf16x3 convolutions read, which then skip
     their own fp32 -> (hi, lo) split; the caller checks conv_split_input_ok() for every reader first."""
     y = _NormAct.apply(0, x, weight, bias, running_mean, running_var, bool(training), float(momentum), float(eps),
-                       float(slope), int(groups), bool(out_split))
+                       float(slope), int(groups), bool(out_split), False, False, _bn_partials_of(x, groups) if training else None)
     return mark_split(y) if out_split else y
 
 
@@ -1458,15 +1464,16 @@ class _BNActPyramid(torch.autograd.Function):
     Returns one tensor per entry of ``sizes`` (the full size is the normalised tensor itself)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, slope, groups, sizes, out_split, recompute=None):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, slope, groups, sizes, out_split, recompute=None,
+                partials=None):
         x, weight, bias = _c(x), _c(weight), _c(bias)
         _chk(x, weight, bias)
         world = 0
         if training and _sync_world():
-            mean, invstd, N, C, HW, Ng = _bn_stats(x, None, None, True, momentum, eps, groups)
+            mean, invstd, N, C, HW, Ng = _bn_stats(x, None, None, True, momentum, eps, groups, partials)
             mean, invstd, world = _sync_combine(mean, invstd, groups, C, Ng * HW, eps, momentum, [(running_mean, running_var)])
         else:
-            mean, invstd, N, C, HW, Ng = _bn_stats(x, running_mean, running_var, training, momentum, eps, groups)
+            mean, invstd, N, C, HW, Ng = _bn_stats(x, running_mean, running_var, training, momentum, eps, groups, partials if training else None)
         ctx.sync_world = world
         H, W = x.shape[2], x.shape[3]
         y = torch.empty_like(x)
@@ -1560,7 +1567,7 @@ class _BNActPyramid(torch.autograd.Function):
         if weight is not None:
             tot = sums.sum(dim=0) if G > 1 else sums[0]
             dw, db = tot[:, 1].contiguous(), tot[:, 0].contiguous()
-        return (dx, dw, db) + (None,) * 10
+        return (dx, dw, db) + (None,) * 11
 
 
 def batchnorm_act_pyramid_supported(x_shape, sizes):
@@ -1576,7 +1583,7 @@ def batchnorm_act_pyramid(x, weight, bias, running_mean, running_var, sizes, tra
     sizes = tuple((int(h), int(w)) for (h, w) in sizes)
     rc = getattr(x, '_ag2v_recompute', None) if (_LEAN_TAPE[0] and training) else None
     outs = _BNActPyramid.apply(x, weight, bias, running_mean, running_var, bool(training), float(momentum), float(eps), float(slope),
-                               int(groups), sizes, bool(out_split), rc)
+                               int(groups), sizes, bool(out_split), rc, _bn_partials_of(x, groups) if training else None)
     if out_split:
         for o in outs:
             mark_split(o)
@@ -1809,9 +1816,11 @@ def layout_conv(U, boxes, keep, H, W, R=3, stride=1, pad=1, residual=None, pool=
     return _LayoutConv.apply(U, boxes, keep, residual, int(H), int(W), int(R), int(stride), int(pad), int(pool))
 
 
-def _layout_conv_img_run(U, boxes, keep, img, w_img, gscale, H, W, R, pad):
+def _layout_conv_img_run(U, boxes, keep, img, w_img, gscale, H, W, R, pad, stat_groups=0):
     """The forward launch of _LayoutConvImg on contiguous operands (keep: int32).  No atomics: a second call with the same operands
-    returns the same bits -- which is what the lean tape's recomputation relies on (_BNActPyramid)."""
+    returns the same bits -- which is what the lean tape's recomputation relies on (_BNActPyramid).
+    stat_groups > 0: also the batch-norm statistics of the result for `stat_groups` groups of consecutive samples, as partials
+    (ag2v_layout_conv_img_fwd_stats); returns (out, BNPartials or None)."""
     NB, J, K, RS = U.shape
     IC = img.shape[1]
     iscale = None
@@ -1819,9 +1828,35 @@ def _layout_conv_img_run(U, boxes, keep, img, w_img, gscale, H, W, R, pad):
         group_n = NB // gscale.numel()
         iscale = gscale.repeat_interleave(group_n) if group_n > 1 else gscale
     out = torch.empty((NB, K, H, W), device=U.device, dtype=torch.float32)
+    if stat_groups:
+        part = None
+        Ng = NB // stat_groups if NB % stat_groups == 0 else 0
+        if (Ng and _LC_STATS and U.data_ptr() % 16 == 0 and w_img.data_ptr() % 16 == 0
+                and _lib.query('ag2v_layout_conv_stats_supported', NB, J, K, H, W, R, 1, pad, 0, IC, Ng)):
+            part = torch.empty(_lib.query('ag2v_layout_conv_stats_floats', NB, K, H), device=U.device, dtype=torch.float32)
+            _lib.call('ag2v_layout_conv_img_fwd_stats', _ptr(U), _ptr(boxes), _ptr(keep), None, _ptr(out), NB, J, K, H, W, R, 1, pad, 0,
+                      _ptr(img), _ptr(w_img), _ptr(iscale), IC, _ptr(part), Ng, _stream())
+            return out, BNPartials(part, stat_groups, K, Ng * (-(-H // 4)))
     _lib.call('ag2v_layout_conv_img_fwd', _ptr(U), _ptr(boxes), _ptr(keep), None, _ptr(out), NB, J, K, H, W, R, 1, pad, 0,
               _ptr(img), _ptr(w_img), _ptr(iscale), IC, _stream())
-    return out
+    return (out, None) if stat_groups else out
+
+
+class BNPartials(object):
+    """Batch-norm statistics of a tensor as Chan partials [groups, C, nparts, 3], written by the kernel that produced the tensor; kept on the
+    tensor as `_ag2v_bn_partials` together with its version (a tensor modified since is not what the partials describe)."""
+    __slots__ = ('buf', 'groups', 'C', 'nparts', 'version')
+
+    def __init__(self, buf, groups, C, nparts):
+        self.buf, self.groups, self.C, self.nparts, self.version = buf, int(groups), int(C), int(nparts), None
+
+
+def _bn_partials_of(x, groups):
+    """The partials attached to x when they describe x as it is now, for this grouping; else None."""
+    p = getattr(x, '_ag2v_bn_partials', None)
+    if isinstance(p, BNPartials) and p.version == x._version and p.groups == int(groups) and p.C == x.shape[1]:
+        return p
+    return None
 
 
 class _LayoutConvImg(torch.autograd.Function):
@@ -1840,7 +1875,9 @@ class _LayoutConvImg(torch.autograd.Function):
         if RS != R * R or tuple(w_img.shape) != (K, IC, R, R) or tuple(img.shape) != (NB, IC, H, W):
             raise RuntimeError("layout_conv_img: inconsistent shapes")
         group_n = 1 if gscale is None else NB // gscale.numel()
-        out = _layout_conv_img_run(U, boxes, keep, img, w_img, gscale, H, W, R, pad)
+        # (inside ops.frame_groups(T): the batch norm that follows takes its statistics per frame group -- written by this launch)
+        out, part = _layout_conv_img_run(U, boxes, keep, img, w_img, gscale, H, W, R, pad, stat_groups=current_frame_groups())
+        _LC_LAST_PARTIALS[0] = part
         ctx.save_for_backward(boxes, keep, img, w_img, gscale)
         ctx.cfg = (NB, J, K, H, W, R, pad, group_n, _current_min_rows()[1])
         ctx.scope = _SCOPE[-1]
@@ -1891,7 +1928,12 @@ def layout_conv_img(U, boxes, keep, H, W, R, pad, img, w_img, gscale=None):
     channels of conv_dim_in / down_flow[0] (generator.py:66,74,82-83).  2 * pad must equal R - 1."""
     if 2 * pad != R - 1:
         raise RuntimeError("layout_conv_img: same-size convolutions only (2 * pad == R - 1)")
+    _LC_LAST_PARTIALS[0] = None
     out = _LayoutConvImg.apply(U, boxes, keep, img, w_img, gscale, int(H), int(W), int(R), int(pad))
+    part, _LC_LAST_PARTIALS[0] = _LC_LAST_PARTIALS[0], None
+    if part is not None:
+        part.version = out._version
+        out._ag2v_bn_partials = part
     if _LEAN_TAPE[0]:
         # how to produce this tensor again (detached operands, a few MB): a consumer that would otherwise keep the [N, K, H, W] result for
         # its backward may drop it and re-run the launch instead (batchnorm_act_pyramid)
@@ -1899,6 +1941,10 @@ def layout_conv_img(U, boxes, keep, H, W, R, pad, img, w_img, gscale=None):
             out._ag2v_recompute = (_c(U.detach()), _c(boxes.detach()), keep.to(torch.int32).contiguous(), _c(img.detach()),
                                    _c(w_img.detach()), None if gscale is None else _c(gscale.detach()), int(H), int(W), int(R), int(pad))
     return out
+
+
+_LC_STATS = os.environ.get('AG2V_NO_LC_STATS') is None       # layout_conv_img writes the following batch norm's statistics (A/B)
+_LC_LAST_PARTIALS = [None]
 
 
 class _FlowWarp(torch.autograd.Function):

@@ -177,6 +177,10 @@ int ag2v_norm_bwd(int mode, const float* dy, const float* y, const float* x, con
  * that produced them).  Ng == N is the plain form above. */
 int ag2v_bn_stats_g(const float* x, int N, int C, int HW, int Ng, float eps, float momentum, float* mean, float* invstd,
                     float* running_mean, float* running_var, float* workspace, void* stream);
+/* The second half of ag2v_bn_stats_g on partials written by the kernel that produced x: partial[G][C][nparts][3] = (count, mean, M2) of
+ * disjoint element sets covering each (group, channel) -- sync_batchnorm/batchnorm.py:63-68 F.batch_norm's statistics, combined in double. */
+int ag2v_bn_finalize_partials(const float* partial, int G, int C, int nparts, float eps, float momentum, float* mean, float* invstd,
+                              float* running_mean /*nullable*/, float* running_var /*nullable*/, void* stream);
 int ag2v_norm_apply_g(int mode, const float* x, const float* mean, const float* invstd, const float* w, const float* b,
                       const float* gamma, const float* beta, float* y, int N, int C, int HW, int Ng, float slope, void* stream);
 /* ag2v_norm_apply_g whose output is stored as split words when out_split != 0 (see ag2v_conv_opts::in_split): for a tensor that
@@ -285,6 +289,17 @@ int ag2v_layout_conv_fwd(const float* U, const float* boxes, const int* keep, co
 int ag2v_layout_conv_img_fwd(const float* U, const float* boxes, const int* keep, const float* residual /*nullable*/, float* out,
                              int NB, int J, int K, int H, int W, int R, int stride, int pad, int pool, const float* img,
                              const float* wimg, const float* iscale /*nullable*/, int IC, void* stream);
+/* ag2v_layout_conv_img_fwd that also writes the batch-norm statistics of `out` -- generator.py:30,66,74: conv_dim_in is followed by a
+ * SynchronizedBatchNorm2d whose statistics pass would otherwise re-read the [NB, K, H, W] result -- as Chan partials (count, mean, M2)
+ * per (sample, channel, band of 4 rows): stat_partial[NB / Ng][K][Ng * ceil(H / 4)][3] (ag2v_layout_conv_stats_floats floats), Ng = samples
+ * per statistics group.  ag2v_bn_finalize_partials turns them into what ag2v_bn_stats_g returns.  Only for calls
+ * ag2v_layout_conv_stats_supported() accepts (3 x 3, pad 1, stride 1, no pooling, W <= 256 in whole quads, K % 16 == 0, IC <= 3) with U and
+ * wimg 16-byte aligned: AG2V_EINVAL otherwise. */
+int ag2v_layout_conv_stats_supported(int NB, int J, int K, int H, int W, int R, int stride, int pad, int pool, int IC, int Ng);
+size_t ag2v_layout_conv_stats_floats(int NB, int K, int H);
+int ag2v_layout_conv_img_fwd_stats(const float* U, const float* boxes, const int* keep, const float* residual /*nullable*/, float* out,
+                                   int NB, int J, int K, int H, int W, int R, int stride, int pad, int pool, const float* img,
+                                   const float* wimg, const float* iscale /*nullable*/, int IC, float* stat_partial, int Ng, void* stream);
 int ag2v_layout_conv_bwd(const float* dout, const float* boxes, const int* keep, float* dU, int NB, int J, int K, int H, int W,
                          int R, int stride, int pad, int pool, void* stream);
 

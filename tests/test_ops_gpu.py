@@ -1193,6 +1193,44 @@ def test_layout_conv_img(cfg, device):
     _run_pair(ops.layout_conv_img, K.layout_conv_img, t, device, nondiff=('boxes',), name='layout_conv_img')
 
 
+@pytest.mark.parametrize("cfg", [(6, 14, 32, 22, 64, 3, 3), (4, 22, 48, 10, 256, 3, 2), (2, 5, 16, 256, 256, 3, 1)], ids=str)
+def test_layout_conv_img_writes_the_batch_norm_statistics(cfg, device, monkeypatch):
+    """conv_dim_in -> SynchronizedBatchNorm2d (generator.py:30,66,74): the layout convolution's launch also writes Chan partials of its
+    output per (sample, channel, 4-row band), and the batch norm that follows combines them instead of reading the [N, K, H, W] tensor
+    again.  The statistics must be those of the tensor (fp64 torch), and the normalised result / gradients / running buffers those of
+    the separate statistics pass (AG2V_NO_LC_STATS)."""
+    from ag2video_amd import ops
+    NB, J, Kc, H, W, R, G = cfg
+    boxes = _boxes(NB, J, 21).to(device)
+    keep = torch.ones(NB, J, dtype=torch.int32, device=device)
+    keep[:, J - 1] = 0
+    U0, img0, wimg0 = _rand(NB, J, Kc, R * R, seed=22), _rand(NB, 3, H, W, seed=23) + 0.3, _rand(Kc, 3, R, R, seed=24, scale=0.2)
+    gs0 = torch.linspace(0.6, 1.5, G)
+    head = _rand(NB, Kc, H, W, seed=31).to(device)
+    res = []
+    for on in (True, False):
+        monkeypatch.setattr(ops, '_LC_STATS', on)
+        U, img, wimg, gs = [t.clone().to(device).requires_grad_(True) for t in (U0, img0, wimg0, gs0)]
+        bw, bb = torch.linspace(0.5, 1.5, Kc, device=device).requires_grad_(True), torch.linspace(-0.2, 0.2, Kc, device=device).requires_grad_(True)
+        rm, rv = torch.zeros(Kc, device=device), torch.ones(Kc, device=device)
+        with ops.frame_groups(G):
+            y = ops.layout_conv_img(U, boxes, keep, H, W, R, 1, img, wimg, gs)
+            part = ops._bn_partials_of(y, G)
+            assert (part is not None) == on
+            if on:
+                mean, invstd = ops._bn_stats(y, None, None, True, 0.1, 1e-5, G, part)[:2]
+                yd = y.detach().double().view(G, NB // G, Kc, H * W).permute(0, 2, 1, 3).reshape(G * Kc, -1)
+                m64, v64 = yd.mean(1), yd.var(1, unbiased=False)
+                assert float((mean.double() - m64).abs().max()) <= 2e-6 * float(yd.abs().max())
+                assert float((invstd.double() * torch.sqrt(v64 + 1e-5) - 1).abs().max()) <= 2e-6
+            z = ops.batchnorm_act(y, bw, bb, rm, rv, True, 0.1, 1e-5, 0.2, groups=G)
+        (z * head).sum().backward()
+        res.append([z.detach(), U.grad, img.grad, wimg.grad, gs.grad, bw.grad, bb.grad, rm, rv])
+    for i, (a, b) in enumerate(zip(*res)):
+        err = float((a.double() - b.double()).norm()) / max(float(b.double().norm()), 1e-30)
+        assert err <= 1e-5, (i, err)
+
+
 # ------------------------------------------------------------------------------------------------ lean tape (ops.set_lean_tape)
 def _tape_bytes(fn):
     """Runs fn() under saved-tensor hooks; returns (result, bytes of unique device storages autograd kept for the backward)."""
