@@ -976,6 +976,33 @@ __global__ __launch_bounds__(256) void nearest_resize_fwd_kernel(const float* __
     const long long nc = r / OH;
     y[idx] = x[(size_t)nc * H * W + (size_t)nearest_src(oy, H, OH) * W + nearest_src(ox, W, OW)];
 }
+// Integer down-sampling factors (the decoder's segmentation-map pyramid, normalization.py:102: 128^2 -> 64^2 -> ... of a [120, 512, ., .]
+// tensor) and 2x up-sampling (fx < 0), output rows in whole quads: one thread per 4 outputs -- 32-bit index arithmetic, 16-byte loads / stores (the per-element form
+// above spent its time in 64-bit div / mod chains: 3.45 ms per c3 step for 7 GB of traffic).  Words are copied as they are (split words too).
+__global__ __launch_bounds__(256) void nearest_down_quads_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned total_q,
+                                                                 int H, int W, int OH, int OW, int fy, int fx) {
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= total_q) return;
+    const unsigned qw = (unsigned)OW >> 2, qp = (unsigned)OH * qw;
+    const unsigned nc = idx / qp, rem = idx - nc * qp;
+    const unsigned oy = rem / qw, q = rem - oy * qw;
+    float4 o;
+    if (fx < 0) {             // 2x up-sampling (the flow network's decoder, flows_generator.py: nn.Upsample(scale_factor=2)): two inputs per quad
+        const float2 a = *reinterpret_cast<const float2*>(x + (size_t)nc * H * W + (size_t)(oy >> 1) * W + (size_t)q * 2);
+        reinterpret_cast<float4*>(y)[idx] = make_float4(a.x, a.x, a.y, a.y);
+        return;
+    }
+    const float* src = x + (size_t)nc * H * W + (size_t)(oy * fy) * W + (size_t)q * 4 * fx;
+    if (fx == 1) {
+        o = *reinterpret_cast<const float4*>(src);
+    } else if (fx == 2) {
+        const float4 a = reinterpret_cast<const float4*>(src)[0], b = reinterpret_cast<const float4*>(src)[1];
+        o = make_float4(a.x, a.z, b.x, b.z);
+    } else {
+        o = make_float4(src[0], src[fx], src[2 * fx], src[3 * fx]);
+    }
+    reinterpret_cast<float4*>(y)[idx] = o;
+}
 // adjoint: dx[iy,ix] = sum of dy over all outputs that read (iy,ix).  One thread per INPUT element; the candidate outputs
 // are found by scanning the (small) preimage range, so no atomics and no memset are needed.
 __global__ __launch_bounds__(256) void nearest_resize_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, long long total,
@@ -1008,6 +1035,20 @@ __global__ __launch_bounds__(256) void nearest_resize_bwd_kernel(const float* __
             if (nearest_src(ox, W, OW) == ix) s += dp[oy * OW + ox];
     }
     dx[idx] = s;
+}
+
+// adjoint of the 2x up-sampling in pairs: dx[iy, 2 j .. 2 j + 1] from one 16-byte piece of each of the two output rows (same sums, same order
+// as the per-element form above)
+__global__ __launch_bounds__(256) void nearest_up2_bwd_pairs_kernel(const float* __restrict__ dy, float* __restrict__ dx, unsigned total_p,
+                                                                    int H, int W) {
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= total_p) return;
+    const unsigned pw = (unsigned)W >> 1, pp = (unsigned)H * pw;
+    const unsigned nc = idx / pp, rem = idx - nc * pp;
+    const unsigned iy = rem / pw, j = rem - iy * pw;
+    const float* q = dy + (size_t)nc * 4 * H * W + (size_t)(2 * iy) * (2 * W) + (size_t)j * 4;
+    const float4 a = *reinterpret_cast<const float4*>(q), b = *reinterpret_cast<const float4*>(q + 2 * W);
+    reinterpret_cast<float2*>(dx)[idx] = make_float2((a.x + a.y) + (b.x + b.y), (a.z + a.w) + (b.z + b.w));
 }
 
 // Adjoint of a nearest-neighbour pyramid: one full-resolution map x[NC,H,W] was down-sampled (integer factors) to up to 8
@@ -1253,6 +1294,15 @@ extern "C" int ag2v_avgpool3s2_bwd(const float* dy, float* dx, int NC, int H, in
 extern "C" int ag2v_nearest_resize_fwd(const float* x, float* y, int NC, int H, int W, int OH, int OW, void* stream) {
     if (!x || !y || NC <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return AG2V_EINVAL;
     const long long total = (long long)NC * OH * OW;
+    const bool down = OH <= H && OW <= W && H % OH == 0 && W % OW == 0, up2 = OH == 2 * H && OW == 2 * W;
+    if ((down || up2) && (OW & 3) == 0 && total / 4 < (1LL << 31) && (((uintptr_t)x | (uintptr_t)y) & 15) == 0 &&
+        getenv("AG2V_NO_RESIZE_QUADS") == nullptr) {
+        const unsigned tq = (unsigned)(total / 4);
+        hipLaunchKernelGGL(nearest_down_quads_kernel, dim3((tq + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, x, y, tq, H, W, OH, OW,
+                           up2 ? 0 : H / OH, up2 ? -2 : W / OW);
+        AG2V_CHECK_LAUNCH();
+        return AG2V_OK;
+    }
     hipLaunchKernelGGL(nearest_resize_fwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, total, H, W, OH, OW);
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
@@ -1261,6 +1311,13 @@ extern "C" int ag2v_nearest_resize_fwd(const float* x, float* y, int NC, int H, 
 extern "C" int ag2v_nearest_resize_bwd(const float* dy, float* dx, int NC, int H, int W, int OH, int OW, void* stream) {
     if (!dy || !dx || NC <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return AG2V_EINVAL;
     const long long total = (long long)NC * H * W;
+    if (OH == 2 * H && OW == 2 * W && (W & 1) == 0 && total / 2 < (1LL << 31) && (((uintptr_t)dy & 15) | ((uintptr_t)dx & 7)) == 0 &&
+        getenv("AG2V_NO_RESIZE_QUADS") == nullptr) {
+        const unsigned tp = (unsigned)(total / 2);
+        hipLaunchKernelGGL(nearest_up2_bwd_pairs_kernel, dim3((tp + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, dy, dx, tp, H, W);
+        AG2V_CHECK_LAUNCH();
+        return AG2V_OK;
+    }
     hipLaunchKernelGGL(nearest_resize_bwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, total, H, W, OH, OW);
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;

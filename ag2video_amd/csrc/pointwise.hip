@@ -31,10 +31,24 @@ __global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ 
 // dx = dy * f'(.)  expressed through the forward OUTPUT y: lrelu: y>0 ? 1 : slope ; tanh: 1 - y^2
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx,
                                                       long long n, int op, float slope) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float yy = y[i], g = dy[i];
-    dx[i] = (op == 0) ? (yy > 0.f ? g : g * slope) : g * (1.f - yy * yy);
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0) {
+        const float4 yy = *reinterpret_cast<const float4*>(y + i), g = *reinterpret_cast<const float4*>(dy + i);
+        float4 r;
+        if (op == 0) {
+            r.x = yy.x > 0.f ? g.x : g.x * slope; r.y = yy.y > 0.f ? g.y : g.y * slope;
+            r.z = yy.z > 0.f ? g.z : g.z * slope; r.w = yy.w > 0.f ? g.w : g.w * slope;
+        } else {
+            r.x = g.x * (1.f - yy.x * yy.x); r.y = g.y * (1.f - yy.y * yy.y);
+            r.z = g.z * (1.f - yy.z * yy.z); r.w = g.w * (1.f - yy.w * yy.w);
+        }
+        *reinterpret_cast<float4*>(dx + i) = r;
+    } else {
+        for (long long j = i; j < n && j < i + 4; ++j) {
+            const float yy = y[j], g = dy[j];
+            dx[j] = (op == 0) ? (yy > 0.f ? g : g * slope) : g * (1.f - yy * yy);
+        }
+    }
 }
 
 // ---------------------------------------------------------------- mean reductions
@@ -181,7 +195,7 @@ extern "C" int ag2v_act_fwd(int op, const float* x, float* y, long long n, float
 }
 extern "C" int ag2v_act_bwd(int op, const float* dy, const float* y, float* dx, long long n, float slope, void* stream) {
     if (!dy || !y || !dx || n <= 0 || op < 0 || op > 1) return AG2V_EINVAL;
-    hipLaunchKernelGGL(act_bwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, n, op, slope);
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(ceil_div(n, 1024)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, n, op, slope);
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
 }

@@ -430,7 +430,9 @@ def test_avgpool3s2(shape, device):
 
 
 @pytest.mark.parametrize("cfg", [((2, 6, 64, 64), 2, 2), ((2, 6, 64, 64), 32, 32), ((1, 3, 32, 32), 64, 64),
-                                 ((2, 4, 48, 48), 16, 16), ((1, 2, 30, 20), 7, 9)], ids=str)
+                                 ((2, 4, 48, 48), 16, 16), ((1, 2, 30, 20), 7, 9),
+                                 ((2, 3, 64, 128), 16, 32), ((1, 2, 32, 16), 16, 16), ((3, 2, 24, 40), 12, 20),
+                                 ((2, 3, 16, 24), 32, 48)], ids=str)      # quads: factors 4, (2, 1), 2; 2x up-sampling
 def test_nearest_resize(cfg, device):
     from ag2video_amd import ops
     from oracle import kernels as K
