@@ -1144,29 +1144,32 @@ __global__ __launch_bounds__(256) void pack_dgrad_s2_tap_kernel(const float* __r
     }
 }
 // dx[n, c, y, x] (+)= t[n, cls * C + c, (y - ay[py]) / 2, (x - ax[px]) / 2] for the class whose parity (y, x) has; mask as the epilogues
-// grid (N * C, ceil(H / 4)), block (64, 4): thread (tx, ty) writes the pixel pairs (2 t, 2 t + 1), t = tx, tx + 64, ..., of row
-// blockIdx.y * 4 + ty -- one value of each x class, both read along consecutive qx (no index divisions: the first form spent its time
-// in 64-bit div / mod chains, 4.5 ms per c3 step for 3 GB of traffic)
+// grid (N * C, ceil(H * ceil(W / 2) / 512)), 256 threads: a thread writes two pixel pairs (2 t, 2 t + 1) of the plane, 256 pairs apart -- one
+// value of each x class per pair, both read along consecutive qx.  32-bit index arithmetic (the first form spent its time in 64-bit
+// div / mod chains: 4.5 ms per c3 step for 3 GB of traffic); the pairs of a plane are flattened so that odd widths (129, 65, 33) fill the waves.
 __global__ __launch_bounds__(256) void depth_to_space_s2_kernel(const float* __restrict__ t, const float* __restrict__ mask, float* __restrict__ dx,
                                                                 int C, int H, int W, int Qy, int Qx, int ay0, int ax0, int acc) {
-    const int y = blockIdx.y * 4 + threadIdx.y;
-    if (y >= H) return;
-    const int nc = blockIdx.x;
-    const int n = nc / C, c = nc - n * C;
-    const int py = ((y - ay0) & 1);                               // class 0 owns the rows of ay0's parity
-    const int qy = (y - (py ? 1 - ay0 : ay0)) >> 1;
+    const unsigned nc = blockIdx.x;
+    const unsigned n = nc / (unsigned)C, c = nc - n * (unsigned)C;
+    const unsigned W2 = (unsigned)(W + 1) >> 1, P = (unsigned)H * W2;
     const size_t plane = (size_t)Qy * Qx;
-    // x = 2 t + e: class px = (e - ax0) & 1, qx = (x - ax[px]) >> 1 with ax[0] = ax0, ax[1] = 1 - ax0
+    // x = 2 t + e has the class of its parity: px = (e - ax0) & 1, and qx = t for both (the class's first column is e)
     const int px_e0 = (0 - ax0) & 1, px_e1 = (1 - ax0) & 1;
-    const int a_e0 = px_e0 ? 1 - ax0 : ax0, a_e1 = px_e1 ? 1 - ax0 : ax0;
-    const float* r0 = t + (((size_t)n * 4 + (py * 2 + px_e0)) * C + c) * plane + (size_t)qy * Qx;
-    const float* r1 = t + (((size_t)n * 4 + (py * 2 + px_e1)) * C + c) * plane + (size_t)qy * Qx;
-    const size_t row = ((size_t)nc * H + y) * W;
-    for (int tt = threadIdx.x; 2 * tt < W; tt += 64) {
-        const int x0 = 2 * tt;
-        const bool two = x0 + 1 < W;
-        float v0 = r0[(x0 - a_e0) >> 1];
-        float v1 = two ? r1[(x0 + 1 - a_e1) >> 1] : 0.f;
+    const float* tn = t + (size_t)n * 4 * C * plane + (size_t)c * plane;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const unsigned p = blockIdx.y * 512u + u * 256u + threadIdx.x;
+        if (p >= P) return;
+        const unsigned y = p / W2, tt = p - y * W2;
+        const int py = ((int)y - ay0) & 1;                        // class 0 owns the rows of ay0's parity
+        const int qy = ((int)y - (py ? 1 - ay0 : ay0)) >> 1;
+        const float* r0 = tn + (size_t)(py * 2 + px_e0) * C * plane + (size_t)qy * Qx;
+        const float* r1 = tn + (size_t)(py * 2 + px_e1) * C * plane + (size_t)qy * Qx;
+        const size_t row = ((size_t)nc * H + y) * W;
+        const unsigned x0 = 2 * tt;
+        const bool two = x0 + 1 < (unsigned)W;
+        float v0 = r0[tt];
+        float v1 = two ? r1[tt] : 0.f;
         if (mask) {
             v0 = (mask[row + x0] > 0.f) ? v0 : 0.f;
             if (two) v1 = (mask[row + x0 + 1] > 0.f) ? v1 : 0.f;
@@ -1284,7 +1287,7 @@ extern "C" int ag2v_conv2d_dgrad_ex(const float* dy, const float* w, const float
                 f.det = cfg.det;
                 const int rc = launch_igemm(f, st, false, true);
                 if (rc != AG2V_OK) return rc;
-                hipLaunchKernelGGL(depth_to_space_s2_kernel, dim3((unsigned)(nc * C), (unsigned)ceil_div(H, 4)), dim3(64, 4), 0, st, tmp,
+                hipLaunchKernelGGL(depth_to_space_s2_kernel, dim3((unsigned)(nc * C), (unsigned)ceil_div(H * ((W + 1) / 2), 512)), dim3(256), 0, st, tmp,
                                    mask ? mask + (size_t)n0 * dxs : nullptr, dx + (size_t)n0 * dxs, C, H, W, gy.Q, gx.Q, gy.ay[0], gx.ay[0],
                                    accumulate ? 1 : 0);
                 if (hipGetLastError() != hipSuccess) return AG2V_EHIP;
