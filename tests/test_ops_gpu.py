@@ -1215,7 +1215,7 @@ def test_layout_conv_img_writes_the_batch_norm_statistics(cfg, device, monkeypat
         U, img, wimg, gs = [t.clone().to(device).requires_grad_(True) for t in (U0, img0, wimg0, gs0)]
         bw, bb = torch.linspace(0.5, 1.5, Kc, device=device).requires_grad_(True), torch.linspace(-0.2, 0.2, Kc, device=device).requires_grad_(True)
         rm, rv = torch.zeros(Kc, device=device), torch.ones(Kc, device=device)
-        with ops.frame_groups(G):
+        with ops.frame_groups(G), ops.deterministic(True):      # (no atomics: what is left between the two runs is the statistics' rounding)
             y = ops.layout_conv_img(U, boxes, keep, H, W, R, 1, img, wimg, gs)
             part = ops._bn_partials_of(y, G)
             assert (part is not None) == on
@@ -1226,11 +1226,13 @@ def test_layout_conv_img_writes_the_batch_norm_statistics(cfg, device, monkeypat
                 assert float((mean.double() - m64).abs().max()) <= 2e-6 * float(yd.abs().max())
                 assert float((invstd.double() * torch.sqrt(v64 + 1e-5) - 1).abs().max()) <= 2e-6
             z = ops.batchnorm_act(y, bw, bb, rm, rv, True, 0.1, 1e-5, 0.2, groups=G)
-        (z * head).sum().backward()
-        res.append([z.detach(), U.grad, img.grad, wimg.grad, gs.grad, bw.grad, bb.grad, rm, rv])
+            (z * head).sum().backward()
+        res.append([z.detach(), rm, rv, U.grad, img.grad, wimg.grad, gs.grad, bw.grad, bb.grad])
+    # the two runs differ by the last bits of mean / inv-std; the batch norm's backward cancels (g - m1 - xhat m2), and the scale gradient is one
+    # global dot product on top: 1e-4 for the gradients (a partial that missed a row or a band would show at 1e-2)
     for i, (a, b) in enumerate(zip(*res)):
         err = float((a.double() - b.double()).norm()) / max(float(b.double().norm()), 1e-30)
-        assert err <= 1e-5, (i, err)
+        assert err <= (1e-5 if i < 3 else 1e-4), (i, err)
 
 
 # ------------------------------------------------------------------------------------------------ lean tape (ops.set_lean_tape)

@@ -4,8 +4,10 @@ True), ops.conv2d(residual_single_reader=True)).
 In a decoder block (reference architecture.py:40-62) conv_0's output is read by norm_1 only, a learned-shortcut block's output by the
 next block's norm_0 / norm_s pair only, and conv_s's output by conv_1's residual add only.  The backward kernels of those norms then
 write d(x) as split words (bf16 hi | bf16 lo), which conv_0 / conv_1 / conv_s read in their data and weight gradients without the
-fp32 -> (hi, lo) split in their producers.  Same products, same sums up to the 2^-17 rounding of the split: the gradients must equal
-those of the fp32 hand-over (AG2V_NO_SPLIT_NORM_DX) to 1e-4, and the split form must really be what the convolutions received."""
+fp32 -> (hi, lo) split in their producers.  The words are exactly what the kernels' own split of the fp32 value produces, so the products and
+sums are the same: in deterministic mode the weight / input gradients equal those of the fp32 hand-over (AG2V_NO_SPLIT_NORM_DX) to the bit
+(measured 0.0; bounded at 1e-6) -- only the bias sums in front of a parameter-free batch norm, whose true value is zero, see the rounded
+words.  And the split form must really be what the convolutions received."""
 import copy
 import types
 
@@ -85,7 +87,7 @@ def test_split_input_gradients_of_the_spade_backwards(cfg, device, monkeypatch):
         if n.endswith('conv_0.bias') or n.endswith('conv_1.bias'):
             continue
         worst = max(worst, err)
-        assert err <= 1e-4, (n, err)
+        assert err <= 1e-6, (n, err)
     print("split norm dx: %d more convolutions with a split-word dy, worst gradient deviation %.2e" % (n_split1 - n_split0, worst))
 
 
