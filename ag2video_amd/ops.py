@@ -397,6 +397,7 @@ _EXTRA_SINKS = os.environ.get('AG2V_NO_EXTRA_SINKS') is None
 _MERGE_SHARED_DGRAD = os.environ.get('AG2V_NO_MERGED_DGRAD') is None      # conv2d_shared_input: one data-gradient launch (A/B)
 _MERGE_SHARED_WGRAD = os.environ.get('AG2V_NO_MERGED_WGRAD') is None      # ... and one weight-gradient launch
 _GRAD_SLOTS = os.environ.get('AG2V_NO_GRAD_SLOTS') is None                # ... whose concatenated dy the consumers write in place (_GradSlots; A/B)
+_SLOTS_MIN_PIXELS = int(os.environ.get('AG2V_SLOTS_MIN_PIXELS', '65536'))  # ... on maps of at least this many pixels per batch (256 pixel tiles)
 _SWAP_FEW_WGRAD = os.environ.get('AG2V_NO_SWAPPED_WGRAD') is None         # <= 4-row weight gradients with swapped operands
 _SWAP_WIDE_WGRAD = os.environ.get('AG2V_NO_WIDE_SWAPPED_WGRAD') is None   # ... and layers with fewer output than input channels (A/B)
 # <= 4-row same-size weight gradients on the library's one-workgroup-per-input-channel kernel (conv_wgrad_fewrow_kernel) instead of the
@@ -1097,7 +1098,10 @@ def conv2d_shared_input(x, weights, biases, stride=1, pad=0, relu=False, grad_pr
             if o.grad_fn is not None:
                 _offer_dy_split(o)          # the consumers' data gradients may hand d(out) back as split words (all of them or none)
         node = outs[0].grad_fn
+        # (small maps -- 8 x 8, 16 x 16: 30 / 120 tiles of 128 x 256 -- keep dense gradients: a data gradient that writes a channel slice
+        # cannot split its reduction, and these launches need the splits to fill the chip; the concatenation there is a few MB)
         if (node is not None and len(outs) > 1 and _MERGE_SHARED_WGRAD and _GRAD_SLOTS and int(stride) == 1
+                and x.shape[0] * x.shape[2] * x.shape[3] >= _SLOTS_MIN_PIXELS
                 and all(o.grad_fn is node for o in outs) and len(set(tuple(w.shape[2:]) for w in weights)) == 1):
             # ... and write them into the slices of one buffer, which this call's backward reads as the concatenation (_GradSlots)
             node._ag2v_slots = _GradSlots([o.shape[1] for o in outs])

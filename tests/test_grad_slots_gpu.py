@@ -53,6 +53,7 @@ def test_gradient_slots_equal_the_concatenation(cfg, device, monkeypatch):
 
     def run(slots_on):
         monkeypatch.setattr(ops, '_GRAD_SLOTS', slots_on)
+        monkeypatch.setattr(ops, '_SLOTS_MIN_PIXELS', 0)          # (the product keeps dense gradients below 65 536 pixels per batch: split-K)
         leaves = [t.clone().requires_grad_(True) for t in ws + bs + gws + gbs]
         n = len(Ks)
         seg = ops.mark_split(words.clone()).requires_grad_(True)
