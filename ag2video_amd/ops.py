@@ -1307,50 +1307,6 @@ def _bn_stats(x, running_mean, running_var, training, momentum, eps, groups=1, p
     return mean, invstd, N, C, HW, Ng
 
 
-def _ptr_off(t, elems):
-    return _P(t.data_ptr() + 4 * elems)
-
-
-# ---- synchronised batch norm on every norm path (reference: sync_batchnorm/batchnorm.py:80-93 forward, :105-126 reduce / broadcast,
-# :128-145 _compute_mean_std).  Forward: the local (mean, inv_std) of a statistics kernel -> ONE all-reduce of [sum, sum of squares]
-# -> the reference's multi-device formula (inv_std = clamp(biased var, eps)^-1/2, running_var fed with the unbiased variance).
-# Backward: every fused backward is a reduce pass and an apply pass (the *_p entry points); between them (sum dxhat, sum dxhat xhat)
-# are summed over the ranks, everything else in `sums` (affine / bias gradients) stays per rank.
-def _sync_world():
-    from . import distributed as D
-    return D.sync_bn()
-
-
-@torch.no_grad()
-def _sync_combine(mean_l, invstd_l, groups, C, count, eps, momentum, running_pairs):
-    """Local statistics [groups * C] over `count` elements per (group, channel) -> (global mean, inv_std, world); the running buffers
-    of `running_pairs` get the per-group updates, in order, in closed form."""
-    from . import distributed as D
-    var_l = invstd_l.pow(-2) - eps
-    mean, invstd, unb, cnt = D.combine_bn_stats(mean_l.view(groups, C), var_l.view(groups, C), count, eps)
-    world = int(round(cnt / count))
-    k = torch.arange(groups - 1, -1, -1, device=mean_l.device, dtype=torch.float32)
-    coef = momentum * (1.0 - momentum) ** k                                   # weight of group g in the final value
-    keep = (1.0 - momentum) ** groups
-    for rm, rv in running_pairs:
-        if rm is not None:
-            rm.mul_(keep).add_((coef.view(-1, 1) * mean).sum(0))
-            rv.mul_(keep).add_((coef.view(-1, 1) * unb).sum(0))
-    return mean.reshape(-1).contiguous(), invstd.reshape(-1).contiguous(), world
-
-
-@torch.no_grad()
-def _sync_bwd_sums(sums, n_norms):
-    """sums [G, C, 4 * n_norms] of a reduce pass: columns 4 k + (0, 1) summed over the ranks in place; returns this rank's own copy."""
-    from . import distributed as D
-    local = sums.clone()
-    idx = [4 * k + i for k in range(n_norms) for i in (0, 1)]
-    part = sums[..., idx].contiguous()
-    D.sum_over_ranks_(part)
-    sums[..., idx] = part
-    return local
-
-
 class _NormAct(torch.autograd.Function):
     """mode 0: BN(affine w,b) -> LeakyReLU(slope); mode 1: SPADE BN*(1+gamma)+beta -> LeakyReLU(slope); mode 2: as 1 with
     gamma | beta delivered as the two channel halves of ONE tensor p0 = [N, 2C, H, W] (the output of the fused gamma/beta conv).

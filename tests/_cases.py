@@ -11,7 +11,9 @@ import torch
 # predicates / 9 action classes: reference data/smth.py:85-104), 224 x 224 = 7 * 32 (the non-power-of-two pyramid 7, 14, ..., 224 of
 # spade_generator.py:53-81; discriminator maps 113^2 / 57^2); c5pT adds --temporal_D 1 --frames_per_action 4 (the reference's
 # MultiscaleDiscriminatorT, discriminator.py:16-59, over one window of 4 generated frames: 5 frames).
-STEP_CASES = {'c1': (64, 4, 1), 'c2p': (128, 3, 1), 'c3p': (256, 4, 1), 'c5p': (224, 3, 1), 'c5pT': (224, 5, 1)}
+# c1bp: c1 TRAINED with --bp_prev 1 (reference generator.py:68-71: the generated previous frame is fed back, so the loss of frame t
+# back-propagates through frames t-1, t-2: the sequential generator path under autograd).
+STEP_CASES = {'c1': (64, 4, 1), 'c2p': (128, 3, 1), 'c3p': (256, 4, 1), 'c5p': (224, 3, 1), 'c5pT': (224, 5, 1), 'c1bp': (64, 4, 1)}
 WEIGHTS_SEED, CLIP_SEED, GRAPH_CLIP_SEED = 1, 1234, 4321
 
 
@@ -34,6 +36,8 @@ def case_opt(case):
     opt.image_size = (side, side)
     opt.batch_size = batch
     opt.gpu_ids = [0]
+    if case.endswith('bp'):
+        opt.bp_prev = 1
     return opt, side, frames, batch
 
 
@@ -42,6 +46,12 @@ def case_clip(case, opt, batch, frames, side, seed):
     if case.startswith('c5'):        # bench.make_clip's Something-Else shape: 2-3 objects (the hand last), <= 2 actions
         return make_clip_batch(opt.vocab, batch, frames, (side, side), seed=seed, min_objs=2, max_objs=3, max_actions=2)
     return make_clip_batch(opt.vocab, batch, frames, (side, side), seed=seed)
+
+
+# Full gradient TENSORS kept by oracle_step beside the statistics and compared element-wise by tests/test_configs_gpu.py (VERDICT r05
+# next #6c): the decoder's last 3x3 convolution, the 1027 -> 512 layout convolution, the discriminator's widest 4x4 layer.
+FULL_GRADS = {'G_grads': ('layout_to_video.module.netG.up_3.conv_1.weight_orig', 'layout_to_video.module.conv_dim_in.0.0.weight_orig'),
+              'D_grads': ('discriminator_0.model3.0.weight_orig',)}
 
 
 def is_front(name):
@@ -62,6 +72,7 @@ def oracle_step(case, shapes_G, shapes_D, shapes_T=None, dtype=torch.float32, ke
            'GL': {k: float(v) for k, v in GL_r.items()}, 'DL': {k: float(v) for k, v in DL_r.items()},
            'G_grads': {n: (None if g is None else keep(g)) for n, g in orc.last_G_grads.items()},
            'D_grads': {n: (None if g is None else keep(g)) for n, g in orc.last_D_grads.items()}}
+    res['full_grads'] = {(tag, n): getattr(orc, 'last_' + tag)[n].detach().clone() for tag, names in FULL_GRADS.items() for n in names}
     if shapes_T:
         res['T_grads'] = {n: (None if g is None else keep(g)) for n, g in orc.last_T_grads.items()}
     gclip = case_clip(case, opt, batch, 4 * frames, side, GRAPH_CLIP_SEED)

@@ -49,8 +49,11 @@ def _rand(*shape, seed=0, device='cpu', scale=1.0):
 #                                                              of the fp32 reference's own; measured 1.0-1.5x, the 1.5 on the exact-
 #                                                              fp32 deterministic path whose 9216-term chains are summed sequentially)
 #     relative L2 against o32     <= 1e-3                     (north_star's bound against the reference arithmetic itself)
-#     max-norm against o64        <= max(1e-3, 2 x floor_max(case))     (1.5 for the L2 ratio x 1.3 for one sample's spread)
-#     max-norm against o32        <= max(1e-3, 3 x floor_max(case))     (triangle: HIP-o32 <= HIP-o64 + o64-o32)
+#     max-norm against o64        <= max(1e-3, 1.3 x the value MEASURED for (case, arithmetic) in deterministic mode), capped by
+#     max-norm against o32           round 5's max(1e-3, 2 x / 3 x floor_max(case)); the measured values are committed in
+#                                    tests/golden/measured_max_norm.json (c3p: 1.18e-3 / 0.99e-3 bf16x3, 1.65e-3 / 1.22e-3 exact fp32) --
+#                                    a CHANGED ACCEPTANCE CRITERION against north_star's 1e-3, stated in DESIGN.md 12.1 / README: fp32
+#                                    itself does not hold 1e-3 in this norm at 224^2 / 256^2 (floors above)
 # boxes / flows / losses / buffers: 1e-3 against both, as before.  Gradient statistics: the bounds of tests/test_step_gpu.py (front 5e-2,
 # decoder / D / T 2e-2), >= 2.2 x the measured floors above, against both oracles.
 # The step runs under ops.deterministic(): a result is then a property of the build, not of the launch (split-K atomics order).  The
@@ -64,10 +67,40 @@ def _img_floor(case):
     return max(v['max'] for v in smp), max(v['l2'] for v in smp)
 
 
-def _img_bounds(case):
+# Measured max-norm of imgs_pred in DETERMINISTIC mode per (case, arithmetic, oracle): tests/golden/measured_max_norm.json, written by
+# tests/golden/update_measured.py from the 'MEASURED' lines this file prints on the GPU box.  The deterministic mode is reproducible
+# across boxes (bit-identical on two leases), so the measured value is a property of the build and the gate is
+# measured + 30 % (3 x floor left room for a regression that triples the worst pixel) -- never below north_star's
+# 1e-3, never above the floor-based bound.  A case without an entry yet (new case, first run) takes the floor-based bound.
+_MEASURED_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'measured_max_norm.json')
+MEASURED = json.load(open(_MEASURED_PATH)) if os.path.exists(_MEASURED_PATH) else {}
+
+
+def _floor_scaled(case, default, *path, k=3.0):
+    """max(default, k x the fp32 oracle's own distance from o64 for this statistic): a gate can only be as tight as the reference
+    arithmetic itself holds the statistic.  For every teacher-forced case the floors sit far below the defaults (the gate IS the
+    default); for c1bp -- the generated frame fed back through the warp of the ill-conditioned random-init decoder, twice -- the fp32
+    oracle itself sits 1e-2 (relative L2) / 5e-2 (max-norm) from fp64 in imgs_pred and 15-23 % in the worst gradient abs-sum
+    (tests/golden/noise_floor.json 'c1bp'), so that case's gates are the floors x k; its tight pin is the toy-width reference golden
+    (tests/test_step_gpu.py::test_train_step_bp_prev_matches_reference_golden, 1e-3)."""
+    v = FLOOR[case]['o32_vs_o64']
+    for key in path:
+        v = v.get(key, {}) if isinstance(v, dict) else {}
+    return max(default, k * float(v)) if isinstance(v, (int, float)) else default
+
+
+def _grad_bound(case, grp, default):
+    return _floor_scaled(case, default, 'grad', grp, 'abssum_dev', k=2.5)
+
+
+def _img_bounds(case, prec=None):
     """(max-norm bound against o64, against o32, relative-L2 bound against o64)."""
     fmax, fl2 = _img_floor(case)
-    return max(1e-3, 2.0 * fmax), max(1e-3, 3.0 * fmax), 2.0 * fl2
+    b64, b32 = max(1e-3, 2.0 * fmax), max(1e-3, 3.0 * fmax)
+    m = MEASURED.get(case, {}).get(prec)
+    if m:
+        b64, b32 = min(b64, max(1e-3, 1.3 * m['o64'])), min(b32, max(1e-3, 1.3 * m['o32']))
+    return b64, b32, 2.0 * fl2
 
 
 def _oracle_steps(case, shapes_G, shapes_D, shapes_T=None):
@@ -89,19 +122,21 @@ def _oracle_step(case, shapes_G, shapes_D, shapes_T=None):
 
 def _check_outputs(case, prec, mo, refs, label, gate_max=True):
     """imgs / boxes / flows / conf of one step against o32 and o64; returns the measured figures."""
-    b64, b32, bl2 = _img_bounds(case)
+    b64, b32, bl2 = _img_bounds(case, prec if gate_max else None)
     got = {}
     for tag, bound_img in (('o64', b64), ('o32', b32)):
         ref = refs[tag]
         for i, name in enumerate(('imgs_pred', 'boxes_pred', 'flows_pred')):
             mx, l2 = C.out_errors(mo[i], ref['out'][i])
             got[(tag, name)] = (mx, l2)
-            l2_bound = bl2 if (tag == 'o64' and name == 'imgs_pred') else 1e-3
+            l2_bound = bl2 if (tag == 'o64' and name == 'imgs_pred') else _floor_scaled(case, 1e-3, 'out', name, 'l2')
             assert l2 <= l2_bound, (case, prec, label, tag, name, 'relative L2', l2, 'bound', l2_bound)
             if gate_max:
-                bound = bound_img if name == 'imgs_pred' else 1e-3
+                bound = bound_img if name == 'imgs_pred' else _floor_scaled(case, 1e-3, 'out', name, 'max')
                 assert mx <= bound, (case, prec, label, tag, name, 'max-norm', mx, 'bound', bound)
-        assert np.mean(mo[3].cpu().numpy() != ref['out'][3].float().numpy()) < 2e-3
+        assert np.mean(mo[3].cpu().numpy() != ref['out'][3].float().numpy()) < _floor_scaled(case, 2e-3, 'out', 'conf_mismatch', k=10.0)
+    if gate_max:
+        print('MEASURED %s %s %.4e %.4e' % (case, prec, got[('o64', 'imgs_pred')][0], got[('o32', 'imgs_pred')][0]))
     print('%s [%s] %s: (max-norm / max|ref|, relative L2) %s; imgs_pred bounds: max-norm o64 %.2e o32 %.2e, L2 o64 %.2e (oracle floors %.2e / %.2e)'
           % ((case, prec, label, {'%s.%s' % k: ('%.2e' % v[0], '%.2e' % v[1]) for k, v in got.items()}, b64, b32, bl2) + _img_floor(case)))
     return got
@@ -163,8 +198,9 @@ def _step_vs_oracle(case, prec, device):
         for tag in ('o64', 'o32'):
             ref = refs[tag]
             bad, worst_g = _grad_report(ts.model.named_parameters(), ref['G_grads'],
-                                        lambda n: ('front', 5e-2) if C.is_front(n) else ('decoder', 2e-2), allow_missing='acts_to_boxes')
-            badd, worst_d = _grad_report(ts.discriminator.img_discriminator.named_parameters(), ref['D_grads'], lambda n: ('D', 2e-2))
+                                        lambda n: ('front', _grad_bound(case, 'front', 5e-2)) if C.is_front(n) else ('decoder', _grad_bound(case, 'decoder', 2e-2)),
+                                        allow_missing='acts_to_boxes')
+            badd, worst_d = _grad_report(ts.discriminator.img_discriminator.named_parameters(), ref['D_grads'], lambda n: ('D', _grad_bound(case, 'D', 2e-2)))
             worst_g.update(worst_d)
             if dtmp is not None:
                 badt, worst_t = _grad_report(dtmp.named_parameters(), ref['T_grads'], lambda n: ('T', 2e-2))
@@ -173,6 +209,18 @@ def _step_vs_oracle(case, prec, device):
             print('%s [%s] worst gradient abs-sum deviations against %s:' % (case, prec, tag), worst_g)
             assert not bad, (tag, len(bad), bad[:10])
             assert not badd, (tag, len(badd), badd[:10])
+        # three full gradient TENSORS element-wise against o64 (VERDICT r05 next #6c): 5e-3 of the tensor's max -- the bound the toy
+        # golden holds its full tensors to (tests/test_oracle_golden.py: the L1 / hinge / LeakyReLU derivatives are sign functions, so
+        # rounding-level forward differences flip individual terms)
+        gmods = {'G_grads': dict(ts.model.named_parameters()), 'D_grads': dict(ts.discriminator.img_discriminator.named_parameters())}
+        for (gtag, n), gref in refs['o64']['full_grads'].items():
+            g = gmods[gtag][n].grad.detach().double().cpu()
+            gref = gref.double()
+            emax = float((g - gref).abs().max() / gref.abs().max())
+            el2 = float((g - gref).pow(2).sum().sqrt() / gref.pow(2).sum().sqrt())
+            print('%s [%s] full gradient %s against o64: max-norm %.2e of max, relative L2 %.2e' % (case, prec, n, emax, el2))
+            if not case.endswith('bp'):      # (c1bp: the fp32 oracle's own gradients sit up to 0.5 from o64 in relative L2: reported only)
+                assert emax <= 5e-3, (case, prec, n, emax)
         # graph step on a 4x longer clip (train.py:471-493)
         gclip = C.case_clip(case, opt, batch, 4 * frames, side, C.GRAPH_CLIP_SEED)
         with ops.deterministic():
@@ -196,7 +244,7 @@ def _step_vs_oracle(case, prec, device):
                     n_keys += 1
                     if rbuf is not None:
                         err = (v.detach().cpu().double() - rbuf.double()).abs().max().item()
-                        if err > 1e-3 * max(rbuf.abs().max().item(), 1e-6):
+                        if err > _floor_scaled(case, 1e-3, 'state_buffers', 'max') * max(rbuf.abs().max().item(), 1e-6):
                             bad_state.append((k, 'buffer', err, rbuf.abs().max().item()))
                     gotst = C.stats(v.float())
                     for i, fl in ((1, floor * n), (2, floor * n ** 0.5)):
@@ -215,6 +263,28 @@ def _step_vs_oracle(case, prec, device):
             for k in rf:
                 assert abs(got2[k].item() - rf[k]) <= 1e-3 * max(1.0, abs(rf[k])), ('default path', k, got2[k].item(), rf[k])
         _check_outputs(case, prec, mo2, refs, 'default path (spread report)', gate_max=False)
+        # ... and its gradients + post-step buffers against o64 (the shipped default selects other kernels than the
+        # deterministic mode -- the h16 halo family for the flow network, atomics instead of ordered slab reduces -- and was gated on
+        # the forward only).  Same bounds as the deterministic step: the run-to-run spread of the atomics' order is inside them
+        # (measured deviations are printed; deterministic mode: front <= 2.2e-2, decoder <= 4.4e-3, D <= 8.7e-3 at c3p).
+        bad2, worst2 = _grad_report(ts2.model.named_parameters(), refs['o64']['G_grads'],
+                                    lambda n: ('front', _grad_bound(case, 'front', 5e-2)) if C.is_front(n) else ('decoder', _grad_bound(case, 'decoder', 2e-2)),
+                                    allow_missing='acts_to_boxes')
+        bad2d, worst2d = _grad_report(ts2.discriminator.img_discriminator.named_parameters(), refs['o64']['D_grads'], lambda n: ('D', _grad_bound(case, 'D', 2e-2)))
+        worst2.update(worst2d)
+        print('%s [%s] default path, worst gradient abs-sum deviations against o64:' % (case, prec), worst2)
+        assert not bad2 and not bad2d, ('default path gradients', len(bad2), bad2[:10], bad2d[:10])
+        bad_buf = []
+        for t, sd in (('G', ts2.model.state_dict()), ('D', ts2.discriminator.img_discriminator.state_dict())):
+            for k, v in sd.items():
+                rbuf = refs['o64']['state'][(t, k)][2]
+                if rbuf is None:
+                    continue
+                # (the oracle's state is the one after its graph step too; the graph net's buffers are none, so G / D buffers compare)
+                err = (v.detach().cpu().double() - rbuf.double()).abs().max().item()
+                if err > _floor_scaled(case, 1e-3, 'state_buffers', 'max') * max(rbuf.abs().max().item(), 1e-6):
+                    bad_buf.append((k, err, rbuf.abs().max().item()))
+        assert not bad_buf, ('default path post-step buffers', len(bad_buf), bad_buf[:10])
         det_vs_default = C.out_errors(mo2[0], mo[0])
         print('%s [%s] default path against deterministic path, imgs_pred (max-norm, relative L2): %.2e %.2e' % ((case, prec) + det_vs_default))
         del ts2
@@ -226,6 +296,15 @@ def _step_vs_oracle(case, prec, device):
 @pytest.mark.parametrize("prec", ['bf16x3', 'fp32'])
 def test_step_c1_default_widths_matches_oracle(prec, device):
     _step_vs_oracle('c1', prec, device)
+
+
+@pytest.mark.parametrize("prec", ['bf16x3', 'fp32'])
+def test_step_c1_bp_prev_default_widths_matches_oracle(prec, device):
+    """c1 TRAINED with --bp_prev 1 at the default widths (reference generator.py:68-71; the oracle's path is pinned to the imported
+    reference by tests/test_oracle_golden.py::test_oracle_matches_reference_bp_prev_training_step): the sequential generator under
+    autograd -- the loss of frame t reaches the weights through frames t-1 and t-2 as well -- against o32 and o64, same gates as c1
+    with the floors measured for THIS case (tests/golden/noise_floor.json 'c1bp')."""
+    _step_vs_oracle('c1bp', prec, device)
 
 
 @pytest.mark.parametrize("prec", ['bf16x3', 'fp32'])

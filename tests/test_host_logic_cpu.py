@@ -204,3 +204,71 @@ def test_grad_slots_only_hold_slices_written_in_this_pass():
     s.mark(0)
     s.drop()
     assert s.buf is None and not s.holds(0, a)
+
+
+def test_reference_import_names_resolve_to_the_product(tmp_path):
+    """INTEGRATION.md section 1 / VERDICT r05 missing #3: after ag2video_amd.dropin.install() the reference's OWN import statements
+    (scripts/train.py:15-20) bind this package's classes, the three objects of train.py:362-375 build through those names, and the
+    loop body of train.py:440-464 drives them (generator loss, backward, discriminator loss) -- on the CPU through the oracle shim."""
+    import sys
+    from ag2video_amd import dropin
+    from ag2video_amd.data.synthetic import make_clip_batch
+    gold, opt, toy = _setup()
+    prev = {k: sys.modules.get(k) for k in ('models', 'models.meta_models', 'data', 'data.args')}
+    names = dropin.install()
+    try:
+        assert 'models.meta_models' in names and 'models.spade_models.loss_model' in names and 'data.args' in names
+        ns = {}
+        # the reference's statements, verbatim (scripts/train.py:15,16,18,19,20 -- restricted to the names the hot path owns)
+        exec("from data.args import get_args, init_args\n"
+             "from models.meta_models import AG2VideoModel, MetaDiscriminatorModel\n"
+             "from models.spade_models.loss_model import LossModel\n"
+             "from models.utils import batch_to\n"
+             "from models.spade_models.networks.sync_batchnorm import DataParallelWithCallback\n", ns)
+        import ag2video_amd.models.meta_models as mm
+        import ag2video_amd.models.spade_models.loss_model as lm
+        assert ns['AG2VideoModel'] is mm.AG2VideoModel and ns['MetaDiscriminatorModel'] is mm.MetaDiscriminatorModel
+        assert ns['LossModel'] is lm.LossModel
+        assert sys.modules['models.meta_models'] is mm            # the same module object, not a second copy
+        # train.py:362-375
+        device = torch.device('cpu')
+        model = ns['AG2VideoModel'](opt, device)
+        optimizer_graph = torch.optim.Adam(model.acts_to_boxes.parameters(), lr=opt.learning_rate, betas=(opt.beta1, 0.999))
+        optimizer_generator = torch.optim.Adam(list(set(model.parameters()) - set(model.acts_to_boxes.parameters())),
+                                               lr=opt.learning_rate, betas=(opt.beta1, 0.999))
+        discriminator = ns['MetaDiscriminatorModel'](opt)
+        gans_model = ns['LossModel'](opt, discriminator=discriminator)
+        gans_model = ns['DataParallelWithCallback'](gans_model, device_ids=opt.gpu_ids).to(device)
+        ref = json.load(open(os.path.join(HERE, 'golden', 'toy64_state_keys.json')))
+        assert {k: list(v.shape) for k, v in model.state_dict().items()} == ref['model']
+        assert {k: list(v.shape) for k, v in discriminator.img_discriminator.state_dict().items()} == ref['d_img']
+        assert {k: list(v.shape) for k, v in gans_model.state_dict().items()} == ref['gans_model']
+        assert len(optimizer_graph.param_groups[0]['params']) > 0 and len(optimizer_generator.param_groups[0]['params']) > 0
+        # train.py:440-464 on one synthetic clip (the kernels are the oracle's here: this test is about names and wiring)
+        torch.set_num_threads(8)
+        with oracle_ops():
+            batch = ns['batch_to'](make_clip_batch(opt.vocab, toy['batch'], toy['frames'], tuple(toy['size']), seed=toy['seed']), device)
+            imgs, objs, boxes, triplets, actions, video_id = batch
+            model_out = model(imgs, objs, triplets, actions, boxes_gt=boxes, test_mode=False, use_gt=True)
+            G_losses = gans_model(batch, model_out, mode="compute_generator_loss")
+            G_losses = {k: v.mean() for k, v in G_losses.items()}
+            assert {'GAN_Img', 'GAN_Feat', 'loss_F_Warp', 'total_loss'} <= set(G_losses)
+            optimizer_generator.zero_grad()
+            G_losses["total_loss"].backward()
+            D_losses = gans_model(batch, model_out, mode="compute_discriminator_loss")
+            D_losses = {k: v.mean() for k, v in D_losses.items()}
+            assert {'D_img_fake', 'D_img_real', 'total_img_loss'} <= set(D_losses)
+        assert all(torch.isfinite(v) for v in list(G_losses.values()) + list(D_losses.values()))
+        # a second install is idempotent; something else already imported under a reference name is refused
+        assert dropin.install() == names
+    finally:
+        dropin.uninstall()
+    for k, v in prev.items():
+        assert sys.modules.get(k) is v, k
+    import types
+    sys.modules['models'] = types.ModuleType('models')
+    try:
+        with pytest.raises(RuntimeError, match="already imported"):
+            dropin.install()
+    finally:
+        del sys.modules['models']
