@@ -18,7 +18,6 @@ _SIGS = {
     'ag2v_last_conv_kernel': (c_char_p, []),
     'ag2v_set_bf16x3_min_rows': (c_int, [c_int]),
     'ag2v_get_bf16x3_min_rows': (c_int, []),
-    'ag2v_debug_hold_cus': (c_int, [c_int, c_float, _P]),
     'ag2v_halo_reload_env': (c_int, []),
     'ag2v_halo_min_tiles': (c_int, []),
     'ag2v_conv2d_workspace_floats': (c_size_t, [c_int] * 4),

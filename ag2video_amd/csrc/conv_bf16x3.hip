@@ -1350,7 +1350,7 @@ __global__ __launch_bounds__((NPW + CWM * CWN) * 64) void conv_wgrad_bf16x3_vps_
 // splits that minimises  rounds * (K-tiles per split + overhead)  -- overhead ~ 8 K-tiles for the exposed first loads, the
 // epilogue and (with splits) its atomics -- instead of a fixed "fill the chip" factor that can leave a nearly empty last round.
 static int pick_splits(int tiles, int nk, int max_splits) {
-    static const int forced = [] { const char* e = getenv("AG2V_FORCE_SPLITS"); return e ? atoi(e) : 0; }();   // tuning aid
+    constexpr int forced = 0;
     if (forced > 0) return forced < max_splits ? forced : (max_splits > 0 ? max_splits : 1);
     int best = 1;
     long long best_cost = -1;
@@ -1403,8 +1403,8 @@ int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed) {
     } while (0)
     // quad loads of the gathered operand on the 128 x 256 tile: stride-1 launches whose pixel rows are whole quads
     // (AG2V_NO_B4: A/B aid).  The 256 x 128 tile (8 of its 12 loads gather) was 4 % slower with them.
-    static const bool b4_off = getenv("AG2V_NO_B4") != nullptr;
-    static const bool b4_tall = getenv("AG2V_B4_TALL") != nullptr;
+    static const bool b4_off = false;
+    static const bool b4_tall = false;
     const bool b4 = a.tap_major && !b4_off && (!tall || b4_tall) && a.stride == 1 && a.OW % 4 == 0 && a.W >= 4 &&
                     (a.OH * a.OW) % 4 == 0 && a.pad_w <= 3;
     if (a.h16) {        // fp16 split (weights packed by the *_h kernels)
@@ -1438,7 +1438,7 @@ int launch_igemm_bf16x3(ConvArgs& a, hipStream_t st, bool out_zeroed) {
         // (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, tools/ubench/pmc_variants.sh; 32x32x16: 0 %) and leave the prioritised
         // MFMA waves' partners 8 instead of 24 free issue cycles per MFMA: with the TAPK producers the 32x32x16 shape is
         // 0.6 % of a c3 step faster (AG2V_TALL16 selects the other one for A/B runs).
-        static const bool tall16 = getenv("AG2V_TALL16") != nullptr;
+        static const bool tall16 = false;
         if (b4) AG2V_LAUNCH_IGEMM(256, 128, 4, 2, 8, false, true, true);
         else if (a.tap_major && !tall16) AG2V_LAUNCH_IGEMM(256, 128, 4, 2, 8, false, true, false);
         else if (a.tap_major) AG2V_LAUNCH_IGEMM(256, 128, 4, 2, 8, AG2V_TALL_MF16, true, false);
@@ -1475,7 +1475,7 @@ void plan_wgrad_bf16x3(ConvArgs& a) {
 // exact-fp32 weight gradients that the 16-byte-load pipeline takes (the others stay on conv_wgrad_kernel): stride 1, pixel rows of whole
 // 8-pixel runs, at least 128 rows (fewer rows: the 4-wave kernels' 32- / 64-row tiles pad less), dY within the 2^31-byte offset encoding
 bool wgrad_f32_ws_ok(const ConvArgs& a) {
-    static const bool off = getenv("AG2V_NO_F32_WGRAD_WS") != nullptr;
+    static const bool off = false;
     return !off && a.M >= 128 && a.stride == 1 && a.OW % 8 == 0 && a.W >= 8 && a.pad <= 3 && a.a_bytes != 0 && a.a_bytes <= 0x80000000u &&
            ((long long)a.N * a.OH * a.OW) % 8 == 0;
 }
@@ -1492,8 +1492,8 @@ int launch_wgrad_bf16x3(ConvArgs& a, hipStream_t st) {
     const dim3 grid(tiles * splitk);     // 1-D: the kernels decode (split, tile) themselves (XCD-aware)
     // 32x32x16 MFMAs: the 16x16x32 operand reads cost 49 % LDS bank-conflict cycles in these kernels (pmc_variants.sh) and the
     // step is 0.35 % faster without them (AG2V_WGRAD16 selects the 16x16x32 form for A/B runs)
-    static const bool wgrad32 = getenv("AG2V_WGRAD16") == nullptr;
-    static const int wnoprio = getenv("AG2V_WGRAD_NOPRIO") ? 1 : 0;     // A/B aid
+    static const bool wgrad32 = true;
+    static const int wnoprio = 0;
     a.diag_noprio = wnoprio;
     if (a.f32) {        // exact fp32 operands: the 16-byte-load kernels only (wgrad_f32_ws_ok)
         if (!wgrad_f32_ws_ok(a) || a.a_split || a.b_split) return AG2V_EINVAL;
@@ -1508,7 +1508,7 @@ int launch_wgrad_bf16x3(ConvArgs& a, hipStream_t st) {
         return AG2V_OK;
     }
     if (a.stride == 1 && a.OW % 8 == 0 && a.W >= 8 && a.a_bytes <= 0x80000000u && a.pad <= 3 &&
-        getenv("AG2V_WGRAD_SCALAR_LOADS") == nullptr) {
+        true) {
         // 16-byte loads along the pixel index (runs of 8 pixels never straddle an image row)
         if (a.b_split || a.a_split) {       // dy and / or x as split words: the 32x32x16 forms
 #define AG2V_VPS(BM_, BN_, WM_, WN_, PA_, PX_)                                                                                   \

@@ -173,7 +173,7 @@ void set_last_conv_kernel(const char* name);
 // 8 x 512 x 256 x 256 input 3.3 GB instead of 1.3 GB per launch (FETCH_SIZE: one pass over all channels per filter row, 48 MB per
 // XCD between reuses).
 static inline bool igemm_tap_major(int C, bool split) {
-    static const bool off = getenv("AG2V_NO_TAP_MAJOR") != nullptr;   // A/B aid: the c-major table path for every shape
+    static const bool off = false;   // A/B aid: the c-major table path for every shape
     return split && C % 32 == 0 && !off;
 }
 __host__ __device__ __forceinline__ int tap_major_row(int c, int r, int s, int R, int S) {

@@ -839,10 +839,10 @@ struct HaloSwitches { int no_halo, tall, mfma32, no_h16, no_f32in, min_tiles, no
 static HaloSwitches read_halo_switches() {
     HaloSwitches h;
     h.no_halo = getenv("AG2V_NO_HALO") != nullptr;
-    h.tall = getenv("AG2V_HALO_TALL") != nullptr;
+    h.tall = false;
     h.mfma32 = getenv("AG2V_HALO_MFMA32") != nullptr;
-    h.no_h16 = getenv("AG2V_NO_HALO_H16") != nullptr;
-    h.no_f32in = getenv("AG2V_NO_HALO_F32IN") != nullptr;
+    h.no_h16 = false;
+    h.no_f32in = false;
     h.no_wgrad_halo = getenv("AG2V_NO_WGRAD_HALO") != nullptr;      // (conv_wgrad_halo.hip: weight gradients on the previous kernels)
     const char* mt = getenv("AG2V_HALO_MIN_TILES");                 // (tests run small shapes through these kernels)
     h.min_tiles = mt ? atoi(mt) : 384;                              // small maps: the split-K kernels fill the chip better

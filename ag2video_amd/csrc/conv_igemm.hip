@@ -851,7 +851,7 @@ __global__ __launch_bounds__(256) void conv_fewrow2_kernel(ConvArgs p) {
 static bool g_fewrow2_last = false;      // which of the two forms the last few-row launch took (kernel name for the timing tables)
 template <int MR>
 static bool launch_fewrow2(const ConvArgs& a, hipStream_t st) {
-    static const bool on = getenv("AG2V_NO_FEWROW2") == nullptr;
+    static const bool on = true;
     g_fewrow2_last = false;
     if (!on || a.R != a.S || a.pad != a.pad_w) return false;
     g_fewrow2_last = (a.S == 3 && a.pad_w == 1) || (a.S == 4 && (a.pad_w == 2 || a.pad_w == 1)) || (a.S == 1 && a.pad_w == 0) ||
@@ -891,9 +891,9 @@ static int launch_igemm(ConvArgs& a, hipStream_t st, bool out_zeroed, bool split
     const bool dense_out = a.out_nstride == dense_nstride;
     if (split) return launch_igemm_bf16x3(a, st, out_zeroed);
     const bool mapped = !(a.o_mul == 1 && a.o_add_y == 0 && a.o_add_x == 0 && a.o_W == a.OW && a.o_H == a.OH);
-    static const bool fewrow_mapped = getenv("AG2V_NO_FEWROW_MAPPED") == nullptr;
+    static const bool fewrow_mapped = true;
     if (dense_out && a.M <= 4 && a.stride == 1 && (!mapped || (fewrow_mapped && a.S == 2 && a.R == 2 && a.pad == a.pad_w)) &&
-        (long long)a.C * a.H * a.W * 4 < 0x10000000LL && getenv("AG2V_NO_FEWROW") == nullptr) {
+        (long long)a.C * a.H * a.W * 4 < 0x10000000LL && true) {
         // The kernel flags an out-of-image tap by adding 0xF0000000 to its byte offset, which only stays out of range while the
         // valid part of the offset is below 0x10000000: at most 256 MB of input per launch (a frame-batched [120, 64, 256, 256]
         // input is 2 GB: beyond 256 MB the padding taps of the few-row kernel read real data) -> sample chunks.
@@ -1018,7 +1018,7 @@ extern "C" int ag2v_conv2d_fwd_ex(const float* x, const float* w, const float* b
     const long long abytes = (long long)KG * K * 4, xs = (long long)C * H * W, ys = (long long)K * OH * OW;
     // (a reduction shorter than two K-tiles is all epilogue: the exact kernels' smaller tiles keep every wave busy there --
     // D's first convolution, 3 image channels x 4x4 -> 64 rows with the layout term as residual)
-    static const bool short_exact = getenv("AG2V_NO_SHORT_K_EXACT") == nullptr;
+    static const bool short_exact = true;
     int nmax = N;
     bool split = use_bf16x3(cfg, K) && abytes < kBufMax && !(short_exact && KG < 64 && K < 128);
     // precision 2: fp16 3-term split for THIS forward (operands of O(1) magnitude: the flow network); same tiles as bf16x3
@@ -1030,7 +1030,7 @@ extern "C" int ag2v_conv2d_fwd_ex(const float* x, const float* w, const float* b
     }
     if ((cfg.in_split || cfg.out_split) && !split) return AG2V_EINVAL;   // split words: bf16x3 kernels only (ag2v_conv2d_split_input_ok)
     // exact arithmetic with >= 128 rows: the wave-specialised pipeline on fp32 operands (same chunking / descriptors as `split`)
-    static const bool f32ws_on = getenv("AG2V_NO_F32_WS") == nullptr;
+    static const bool f32ws_on = true;
     bool f32ws = !split && f32ws_on && K >= 128 && KG >= 64 && abytes < kBufMax;
     if (f32ws && xs * 4 * N >= chunk_limit()) {
         nmax = chunk_samples(xs * 4, 0, cfg.gscale ? cfg.group_n : 1);
@@ -1183,7 +1183,7 @@ __global__ __launch_bounds__(256) void depth_to_space_s2_kernel(const float* __r
     }
 }
 static bool s2_unified_ok(const ConvCfg& cfg, int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int OH, int OW) {
-    static const bool on = getenv("AG2V_NO_S2_UNIFIED") == nullptr;
+    static const bool on = true;
     if (!on || stride != 2 || R != S || cfg.out_nstride > 0 || cfg.out_split) return false;
     if (!use_bf16x3(cfg, C) || !igemm_tap_major(K, true) || C < 32) return false;
     const S2Geom gy = s2_geom(H, R, pad), gx = s2_geom(W, S, pad);
@@ -1200,7 +1200,7 @@ static bool s2_unified_ok(const ConvCfg& cfg, int N, int C, int H, int W, int K,
 // accumulate != 0: dx += (data gradient) instead of dx = : several convolutions that read the same tensor (the three SPADE
 // mlp_shared convolutions of a residual block) sum their input gradients without a separate pass per pair.  Not with a mask.
 static bool few_channel_dgrad(int N, int C, int K, int R, int S, int OH, int OW, int stride, bool mask) {
-    return C <= 4 && stride == 1 && !mask && K >= 64 && C * R * S <= 64 && getenv("AG2V_NO_FEW_DGRAD_GEMM") == nullptr;
+    return C <= 4 && stride == 1 && !mask && K >= 64 && C * R * S <= 64 && true;
 }
 extern "C" size_t ag2v_conv2d_dgrad_workspace_floats(int N, int C, int H, int W, int K, int R, int S, int stride, int pad) {
     const int OH = conv_out_dim(H, R, stride, pad), OW = conv_out_dim(W, S, stride, pad);
@@ -1320,7 +1320,7 @@ extern "C" int ag2v_conv2d_dgrad_ex(const float* dy, const float* w, const float
             }
             if ((cfg.dy_split || cfg.out_split) && !split) return AG2V_EINVAL;
             // exact arithmetic with >= 128 rows: conv_igemm_f32_ws_kernel (see ag2v_conv2d_fwd_ex)
-            static const bool f32ws_on = getenv("AG2V_NO_F32_WS") == nullptr;
+            static const bool f32ws_on = true;
             bool f32ws = !split && f32ws_on && C >= 128 && K * Rc * Sc >= 64 && abytes < kBufMax;
             if (f32ws && dys * 4 * N >= chunk_limit()) {
                 nmax = chunk_samples(dys * 4, 0, cfg.gscale ? cfg.group_n : 1);
@@ -1477,7 +1477,7 @@ static bool launch_wgrad_fewrow_k(const ConvArgs& a, dim3 grid, hipStream_t st) 
     }
 }
 static bool wgrad_fewrow_ok(int K, int R, int S, int stride, int groups, int x_split, int dy_split) {
-    static const bool on = getenv("AG2V_NO_FEWROW_WGRAD") == nullptr;
+    static const bool on = true;
     return on && K <= 4 && R == S && (S == 1 || S == 3 || S == 4) && stride == 1 && groups >= 1 && groups <= 65535 && !x_split && !dy_split;
 }
 // det: one slice per channel (plain stores, a fixed summation order)
@@ -1551,9 +1551,8 @@ static int wgrad_launch(const float* dy, const float* x, float* dw, int N, int C
     // The pixel-range splits of a launch meet either in fp32 atomics on dW or -- deterministic mode, and ALWAYS for the LDS-DMA kernel
     // (conv_wgrad_halo.hip) when the caller provides the workspace -- as slabs that an ordered pass adds: that kernel's workgroups end
     // together and their 74 k atomics per workgroup onto the same tile cost 6-16 % of the launch (tools/wgrad_halo_bench.py, WGH_DET).
-    static const bool halo_atomics = getenv("AG2V_WGH_ATOMIC") != nullptr;      // (A/B aid)
     const bool halo = split && !a.f32 && wgrad_halo_ok(a);
-    bool slabs = (det || (halo && !halo_atomics)) && a.spg > 1;
+    bool slabs = (det || halo) && a.spg > 1;
     const size_t slab_floats = slabs ? (size_t)groups * a.spg * (size_t)mn : 0;
     if (need) { *need = slab_floats; return AG2V_OK; }
     if (slabs && (!det_ws || det_ws_floats < slab_floats)) {
@@ -1596,7 +1595,7 @@ static int wgrad_ex_impl(const float* dy, const float* x, float* dw, int N, int 
     // (dy at most 2 GiB per launch: the 16-byte-load weight-gradient kernels encode "past the range" as byte offset 2^31)
     int nmax = N;
     // exact fp32 on the 16-byte-load pipeline (conv_wgrad_f32_v_kernel) addresses through 32-bit buffer offsets as well: same chunks
-    bool f32ws = !split && K >= 128 && stride == 1 && OW % 8 == 0 && W >= 8 && pad <= 3 && getenv("AG2V_NO_F32_WGRAD_WS") == nullptr;
+    bool f32ws = !split && K >= 128 && stride == 1 && OW % 8 == 0 && W >= 8 && pad <= 3 && true;
     if ((split || f32ws) && (dys * 8 * N >= chunk_limit() || xs * 4 * N >= chunk_limit())) {
         nmax = chunk_samples(dys * 8, xs * 4, groups > 1 ? Ng : 1);
         if (nmax <= 0) nmax = chunk_samples(dys * 4, xs * 4, groups > 1 ? Ng : 1);
@@ -1657,12 +1656,12 @@ extern "C" int ag2v_conv2d_split_input_ok(int N, int C, int H, int W, int K, int
     if (OH <= 0 || OW <= 0) return 0;
     const int KG = C * R * S;
     const long long abytes = (long long)KG * K * 4, xs = (long long)C * H * W, dys = (long long)K * OH * OW;
-    static const bool short_exact = getenv("AG2V_NO_SHORT_K_EXACT") == nullptr;
+    static const bool short_exact = true;
     if (!(use_bf16x3(cf, K) && abytes < kBufMax && !(short_exact && KG < 64 && K < 128))) return 0;        // forward (ag2v_conv2d_fwd_ex)
     if (xs * 4 > chunk_limit()) return 0;                                                                   // one sample must fit a launch
     if (!use_bf16x3(cb, K)) return 0;                                                                      // weight gradient
     if (dys * 8 > chunk_limit() && dys * 4 > chunk_limit()) return 0;
-    if (!(stride == 1 && OW % 8 == 0 && W >= 8 && pad <= 3) || getenv("AG2V_WGRAD_SCALAR_LOADS") != nullptr) return 0;
+    if (!(stride == 1 && OW % 8 == 0 && W >= 8 && pad <= 3) || false) return 0;
     return 1;
 }
 // The same question for the OUTPUT gradient dy of the convolution (ag2v_conv_opts::dy_split): its data gradient (dy is the
@@ -1679,7 +1678,7 @@ extern "C" int ag2v_conv2d_split_dy_ok(int N, int C, int H, int W, int K, int R,
     if (!use_bf16x3(cb, C) || (long long)K * C * R * S * 4 >= kBufMax) return 0;          // data gradient: rows = input channels
     if (!use_bf16x3(cb, K)) return 0;                                                       // weight gradient: rows = output channels
     if (dys * 8 > chunk_limit()) return 0;
-    if (!(OW % 8 == 0 && W >= 8 && pad <= 3) || getenv("AG2V_WGRAD_SCALAR_LOADS") != nullptr) return 0;
+    if (!(OW % 8 == 0 && W >= 8 && pad <= 3) || false) return 0;
     return 1;
 }
 extern "C" int ag2v_conv2d_wgrad_acc(const float* dy, const float* x, float* dw, int N, int C, int H, int W, int K, int R, int S,

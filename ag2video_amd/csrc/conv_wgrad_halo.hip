@@ -414,8 +414,7 @@ void plan_wgrad_halo(ConvArgs& a) {
     // x1.03 on the 4-tile gamma | beta shape.  Shorter workgroups, AG2V_WGH_MAX_STEPS, do not restore it and cost 0.6-3 %.)
     static int max_steps = 0;
     if (max_steps == 0) {
-        const char* e = getenv("AG2V_WGH_MAX_STEPS");
-        max_steps = (e && atoi(e) > 0) ? atoi(e) : (1 << 30);
+        max_steps = 1 << 30;
     }
     int best = 1;
     long long best_cost = -1;

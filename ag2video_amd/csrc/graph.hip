@@ -361,7 +361,7 @@ extern "C" int ag2v_triple_pool_bwd(const float* dpooled, const float* dp_in, co
 extern "C" int ag2v_gemm_f32(const float* a, const float* b, const float* bias, float* c, int M, int N, int K, long long sam,
                              long long sak, long long sbk, long long sbn, int ldc, int relu, int accumulate, void* stream) {
     if (!a || !b || !c || M <= 0 || N <= 0 || K <= 0 || ldc < N) return AG2V_EINVAL;
-    static const int oneshot_mode = getenv("AG2V_GEMM_ONESHOT") ? atoi(getenv("AG2V_GEMM_ONESHOT")) : 1;   // 0: never (A/B aid)
+    constexpr int oneshot_mode = 1;
     const long long tiles32 = (long long)ceil_div(N, 32) * ceil_div(M, 32);
     if (oneshot_mode && K % 4 == 0 && K <= 16 * 72 && tiles32 <= 1024) {
         const int slice = ((ceil_div(K, 16) + 7) / 8) * 8;

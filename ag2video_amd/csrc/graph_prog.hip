@@ -75,12 +75,16 @@ __device__ __forceinline__ void grid_barrier(unsigned* ctr, unsigned target, uns
         __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
         unsigned long long t0 = 0;
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        // a barrier of this run has already given up (this workgroup's or another's): the results are invalid anyway -- do not wait
+        // up to the limit again at each of the remaining n_ops barriers before the host sees the flag
+        bool dead = __hip_atomic_load(timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+        while (!dead && __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(1);
-            if ((++spins & 1023u) == 0) {          // look at the clock every ~1 k polls
+            if ((++spins & 1023u) == 0) {          // look at the clock (and at the flag) every ~1 k polls
                 const unsigned long long now = __builtin_amdgcn_s_memrealtime();
                 if (t0 == 0) t0 = now;
                 else if (now - t0 > GP_BARRIER_TIMEOUT_TICKS) { __hip_atomic_store(timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                dead = __hip_atomic_load(timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
             }
         }
     }
@@ -324,27 +328,6 @@ __global__ __launch_bounds__(GP_THREADS) void graph_program_kernel(const GOp* __
         }
         if (k + 1 < n_ops) grid_barrier(sync, (unsigned)(k + 1) * (unsigned)G, sync + 1);
     }
-}
-
-// ---- TEST AID (tests/test_graph_program_gpu.py, tests/test_distributed_gpu.py): occupy `n_wgs` CUs -- 1024 threads and 128 KB of LDS
-// per workgroup, so nothing that needs a CU's LDS can share them -- for `ms` milliseconds of wall time (at most 500), the way another
-// stream's persistent kernel or a communication kernel would.  Bounded by the clock: it cannot hang.
-__global__ __launch_bounds__(1024) void hold_cus_kernel(unsigned long long ticks, unsigned* sink) {
-    __shared__ unsigned held[32768];
-    held[threadIdx.x] = threadIdx.x;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
-    }
-    __syncthreads();
-    if (sink && held[(threadIdx.x * 7) & 32767] == 0xFFFFFFFFu) *sink = 1;       // (keeps the LDS array alive)
-}
-extern "C" int ag2v_debug_hold_cus(int n_wgs, float ms, void* stream) {
-    if (n_wgs <= 0 || n_wgs > 256 || !(ms > 0.f) || ms > 500.f) return AG2V_EINVAL;
-    hipLaunchKernelGGL(hold_cus_kernel, dim3(n_wgs), dim3(1024), 0, (hipStream_t)stream, (unsigned long long)(ms * 1e5f), (unsigned*)nullptr);
-    AG2V_CHECK_LAUNCH();
-    return AG2V_OK;
 }
 
 extern "C" size_t ag2v_graph_op_bytes(void) { return sizeof(GOp); }

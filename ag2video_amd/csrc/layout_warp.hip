@@ -1111,8 +1111,8 @@ extern "C" int ag2v_layout_render_bwd(const float* dout, const float* boxes, con
 
 // The launch conditions of layout_conv_fwd3_kernel that do not depend on addresses (U / wimg must also be 16-byte aligned)
 static bool lc_fwd3_shape_ok(int J, int K, int H, int W, int R, int stride, int pad, int pool, int IC, bool has_img) {
-    static const bool no_tables = getenv("AG2V_LC_GENERIC") != nullptr;       // A/B aids
-    static const bool no_fwd3 = getenv("AG2V_NO_LC_FWD3") != nullptr;
+    static const bool no_tables = false;       // A/B aids
+    static const bool no_fwd3 = false;
     return J <= LC_TJ && W <= LC_TW && !no_tables && !no_fwd3 && R == 3 && pad == 1 && stride == 1 && pool == 0 && W <= 256 && (W & 3) == 0 &&
            K % 16 == 0 && (!has_img || IC <= 3) && (size_t)J * K * 9 * 4 < 0xFFFFFFF0ull;
 }
@@ -1139,7 +1139,7 @@ static int layout_conv_img_fwd_impl(const float* U, const float* boxes, const in
     }
     constexpr int KPER = 16;
     dim3 grid(ceil_div(OH, 4), NB, ceil_div(K, KPER));
-    static const bool no_tables = getenv("AG2V_LC_GENERIC") != nullptr;       // A/B aid
+    static const bool no_tables = false;       // A/B aid
     const bool tables = J <= LC_TJ && Wm <= LC_TW && !no_tables;
 #define LC_LAUNCH(KERNEL, RR) hipLaunchKernelGGL((KERNEL<RR, KPER>), grid, dim3(256), 0, (hipStream_t)stream, U, boxes, keep, residual, \
                                                  out, J, K, H, W, Hm, Wm, pool, OH, OW, stride, pad, img, wimg, iscale, IC)
@@ -1296,7 +1296,7 @@ extern "C" int ag2v_nearest_resize_fwd(const float* x, float* y, int NC, int H, 
     const long long total = (long long)NC * OH * OW;
     const bool down = OH <= H && OW <= W && H % OH == 0 && W % OW == 0, up2 = OH == 2 * H && OW == 2 * W;
     if ((down || up2) && (OW & 3) == 0 && total / 4 < (1LL << 31) && (((uintptr_t)x | (uintptr_t)y) & 15) == 0 &&
-        getenv("AG2V_NO_RESIZE_QUADS") == nullptr) {
+        true) {
         const unsigned tq = (unsigned)(total / 4);
         hipLaunchKernelGGL(nearest_down_quads_kernel, dim3((tq + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, x, y, tq, H, W, OH, OW,
                            up2 ? 0 : H / OH, up2 ? -2 : W / OW);
@@ -1312,7 +1312,7 @@ extern "C" int ag2v_nearest_resize_bwd(const float* dy, float* dx, int NC, int H
     if (!dy || !dx || NC <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return AG2V_EINVAL;
     const long long total = (long long)NC * H * W;
     if (OH == 2 * H && OW == 2 * W && (W & 1) == 0 && total / 2 < (1LL << 31) && (((uintptr_t)dy & 15) | ((uintptr_t)dx & 7)) == 0 &&
-        getenv("AG2V_NO_RESIZE_QUADS") == nullptr) {
+        true) {
         const unsigned tp = (unsigned)(total / 2);
         hipLaunchKernelGGL(nearest_up2_bwd_pairs_kernel, dim3((tp + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, dy, dx, tp, H, W);
         AG2V_CHECK_LAUNCH();

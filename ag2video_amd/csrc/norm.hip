@@ -265,7 +265,7 @@ __device__ __forceinline__ void pyramid_add16(float (&g)[16], const NormPyramid&
 // CHUNKs a workgroup of a pure-read reduce pass walks before its one block reduction: as many as keep >= 16 workgroups per CU in the
 // launch (AG2V_REDUCE_CPB overrides, for A/B runs)
 static int reduce_chunks_per_block(long long planes, int nchunk) {
-    static const int forced = [] { const char* e = getenv("AG2V_REDUCE_CPB"); return e ? atoi(e) : 0; }();
+    constexpr int forced = 0;
     if (forced > 0) return forced < nchunk ? forced : nchunk;
     int cpb = 1;
     while (cpb < 8 && cpb * 2 <= nchunk && planes * ceil_div(nchunk, cpb * 2) >= 16LL * 256) cpb *= 2;

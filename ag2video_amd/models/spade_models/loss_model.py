@@ -74,8 +74,7 @@ class LossModel(torch.nn.Module):
         inputs = [objs, r_boxes] + list(r_adata)
         shareable = (torch.is_grad_enabled() and getattr(self.opt, 'mlp_normalization', 'none') == 'none'
                      and not any(t.requires_grad for t in inputs if t.is_floating_point())
-                     and not getattr(self.opt, 'no_shared_layout_terms', False)
-                     and os.environ.get('AG2V_NO_SHARED_TERMS') is None)
+                     and not getattr(self.opt, 'no_shared_layout_terms', False))
         cached, self._terms_cache = getattr(self, '_terms_cache', None), None
         pre, self._terms_prefetch = getattr(self, '_terms_prefetch', None), None
         if not shareable:
@@ -106,7 +105,7 @@ class LossModel(torch.nn.Module):
         r_adata = [item[:, nc:] for item in actions_data]
         inputs = [objs, r_boxes] + list(r_adata)
         if (getattr(self.opt, 'mlp_normalization', 'none') != 'none' or getattr(self.opt, 'no_shared_layout_terms', False)
-                or os.environ.get('AG2V_NO_SHARED_TERMS') is not None or any(t.requires_grad for t in inputs if t.is_floating_point())):
+                or any(t.requires_grad for t in inputs if t.is_floating_point())):
             return
         main = torch.cuda.current_stream()
         if after is not None:       # an event on the caller's stream after which batch and parameters are final

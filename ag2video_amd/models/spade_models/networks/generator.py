@@ -54,8 +54,7 @@ class Layout2VidGenerator(nn.Module):
         nc = self.n_frames_G - 1
         # Teacher forcing (training: every frame pass reads GROUND-TRUTH previous frames, generator.py:71): the F - nc passes do
         # not depend on each other and run as one frame-major batch.  test_mode / bp_prev feed generated frames back: sequential.
-        batched = (low_rank and not test_mode and not opt.bp_prev and Fr - nc > 1 and getattr(opt, 'batch_frames', True)
-                   and os.environ.get('AG2V_NO_FRAME_BATCH') is None)
+        batched = (low_rank and not test_mode and not opt.bp_prev and Fr - nc > 1 and getattr(opt, 'batch_frames', True))
         if batched:
             gen, flows, confs = self._frames_batched(imgs_gt, vecs, layout, keep, nc)
         else:
@@ -86,7 +85,7 @@ class Layout2VidGenerator(nn.Module):
         keep_t = keep.unsqueeze(0).expand(T, B, keep.size(1)).reshape(T * B, keep.size(1))
         prev = [fm(imgs_gt, f) for f in range(nc)]               # ground-truth frames t-nc .. t-1
         conv, bn = self.conv_dim_in[0][0], self.conv_dim_in[0][1]
-        if self.training and os.environ.get('AG2V_NO_SN_BANK') is None:
+        if self.training:
             # the T power iterations of ALL spectral-norm layers up front, three launches per iteration (every layer below is called
             # exactly once per frame pass in the reference, so each consumes its T scales in this pass)
             if getattr(self, '_sn_bank', None) is None:

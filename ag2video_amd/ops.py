@@ -261,12 +261,23 @@ def _current_min_rows():
 
 
 def _current_fwd_h16():
-    return bool(_MIN_ROWS_STACK and _MIN_ROWS_STACK[-1][2] and _PRECISION[0] == 1 and os.environ.get('AG2V_NO_H16') is None)
+    return bool(_MIN_ROWS_STACK and _MIN_ROWS_STACK[-1][2] and _PRECISION[0] == 1)
 
 
 def _conv_label(mode, M, min_rows=None):
     """Placeholder label; _launch replaces conv labels by the name of the kernel the library actually launched."""
     return "conv_%s" % mode
+
+
+_DET_WS_FLOATS = {}
+
+
+def reload_kernel_switches():
+    """Tests / tools: after changing one of the library's diagnostic environment switches (AG2V_NO_HALO, AG2V_NO_WGRAD_HALO,
+    AG2V_HALO_MIN_TILES, AG2V_HALO_MFMA32), with no launch in flight -- the library re-reads them (it caches them: getenv beside a
+    concurrent putenv is not thread-safe) and the host forgets the workspace sizes it has cached per launch shape."""
+    _lib.call('ag2v_halo_reload_env')
+    _DET_WS_FLOATS.clear()
 
 
 def _conv_launch(min_rows, name, label, flops, *args, shape=None, gscale=None, group_n=1, in_split=False, dy_split=False,
@@ -280,7 +291,11 @@ def _conv_launch(min_rows, name, label, flops, *args, shape=None, gscale=None, g
     if det_ws_query is not None:      # weight gradient: slabs for the ordered reduction of its pixel-range splits (deterministic mode;
         # in either mode for the LDS-DMA kernel, whose atomic epilogue costs 6-16 % of a launch)
         dev, qargs = det_ws_query
-        n = _lib.query('ag2v_conv2d_wgrad_det_workspace_floats', *qargs, ctypes.byref(opts))
+        # (the size depends on the shape and on the per-call options only: one library query per distinct launch)
+        qkey = qargs + (opts.precision, opts.min_rows, opts.in_split, opts.dy_split, opts.deterministic)
+        n = _DET_WS_FLOATS.get(qkey)
+        if n is None:
+            n = _DET_WS_FLOATS[qkey] = int(_lib.query('ag2v_conv2d_wgrad_det_workspace_floats', *qargs, ctypes.byref(opts)))
         if n:
             det_ws = torch.empty(n, device=dev, dtype=torch.float32)
             opts.det_workspace, opts.det_workspace_floats = det_ws.data_ptr(), n
@@ -391,21 +406,21 @@ def kernel_timing_summary(by_shape=False, by_scope=False):
 # launches and as many zero-fills per step).  The registry is cleared by an engine callback at the end of every backward pass.
 
 # The same holds for spectral norm's weight_orig (one _SpectralWeight node per frame pass: 560 full-size adds per step without it)
-# and for convolution biases (AG2V_NO_EXTRA_SINKS switches these two off for A/B runs).
+# and for convolution biases.
 _WSINK = {}          # id(weight tensor) -> [weakref to it, sink tensor or None]
-_EXTRA_SINKS = os.environ.get('AG2V_NO_EXTRA_SINKS') is None
-_MERGE_SHARED_DGRAD = os.environ.get('AG2V_NO_MERGED_DGRAD') is None      # conv2d_shared_input: one data-gradient launch (A/B)
-_MERGE_SHARED_WGRAD = os.environ.get('AG2V_NO_MERGED_WGRAD') is None      # ... and one weight-gradient launch
+_EXTRA_SINKS = True
+_MERGE_SHARED_DGRAD = True      # conv2d_shared_input: one data-gradient launch
+_MERGE_SHARED_WGRAD = True      # ... and one weight-gradient launch
 _GRAD_SLOTS = os.environ.get('AG2V_NO_GRAD_SLOTS') is None                # ... whose concatenated dy the consumers write in place (_GradSlots; A/B)
-_SLOTS_MIN_PIXELS = int(os.environ.get('AG2V_SLOTS_MIN_PIXELS', '65536'))  # ... on maps of at least this many pixels per batch (256 pixel tiles)
-_SWAP_FEW_WGRAD = os.environ.get('AG2V_NO_SWAPPED_WGRAD') is None         # <= 4-row weight gradients with swapped operands
-_SWAP_WIDE_WGRAD = os.environ.get('AG2V_NO_WIDE_SWAPPED_WGRAD') is None   # ... and layers with fewer output than input channels (A/B)
+_SLOTS_MIN_PIXELS = 65536  # ... on maps of at least this many pixels per batch (256 pixel tiles)
+_SWAP_FEW_WGRAD = True         # <= 4-row weight gradients with swapped operands
+_SWAP_WIDE_WGRAD = True   # ... and layers with fewer output than input channels
 # <= 4-row same-size weight gradients on the library's one-workgroup-per-input-channel kernel (conv_wgrad_fewrow_kernel) instead of the
 # swapped GEMM: OFF -- on 256 x 256 maps its dword gathers lose to the GEMM (tools/fewrow_wgrad_bench.py: conv_img 3.17 vs 1.50 ms,
 # conv_flow 1.40 vs 1.26); the kernel serves the layers the swap does not cover (the discriminators' 4 x 4 last layer: 1.15 -> 0.35 ms)
-_FEWROW_WGRAD_DIRECT = os.environ.get('AG2V_DIRECT_FEW_WGRAD') is not None
-_PAD_WGRAD = os.environ.get('AG2V_NO_PADDED_WGRAD') is None                # odd-width stride-1 weight gradients on the 16-byte-load kernel via zero columns (A/B)
-_FEWIN_DGRAD = os.environ.get('AG2V_NO_FEWIN_DGRAD') is None              # data gradients of <= 4-row layers on the layout kernel's image path (A/B)
+_FEWROW_WGRAD_DIRECT = False
+_PAD_WGRAD = True                # odd-width stride-1 weight gradients on the 16-byte-load kernel via zero columns
+_FEWIN_DGRAD = True              # data gradients of <= 4-row layers on the layout kernel's image path
 _WSINK_CB = [None]   # graph-task id of the backward pass whose end-of-pass callback is queued (None: none; ids start at 0)
 
 
@@ -453,8 +468,8 @@ def _wsink_begin(task):
         _WSINK_CB[0] = task
 
 
-_DIRECT_GRAD = os.environ.get('AG2V_NO_DIRECT_GRAD') is None
-_USE_CHANNEL_SUMS = os.environ.get('AG2V_NO_CHANNEL_SUMS') is None
+_DIRECT_GRAD = True
+_USE_CHANNEL_SUMS = True
 _SPLIT_NORM_DX = os.environ.get('AG2V_NO_SPLIT_NORM_DX') is None           # SPADE backwards write d(x) as split words for x's producer (A/B)
 _DIRECT_DEPTH = [0]
 _JOIN_AT_END = [True]
@@ -568,13 +583,15 @@ def _conv_dgrad_launch(mr, dy, w, mask, dx, stride, pad, acc, gscale=None, group
                  out_nstride=onst)
 
 
-def _conv_wgrad_launch(mr, dy, x, dw, K, R, S, stride, pad, acc, groups=1, in_split=False, dy_split=False):
-    """dw (+)= weight gradient; groups > 1: dw is [groups, K, C, R, S], one gradient per group of N / groups samples."""
+def _conv_wgrad_launch(mr, dy, x, dw, K, R, S, stride, pad, acc, groups=1, in_split=False, dy_split=False, workspace=True):
+    """dw (+)= weight gradient; groups > 1: dw is [groups, K, C, R, S], one gradient per group of N / groups samples.
+    workspace=False (tests): no slab workspace is handed over -- the pixel-range splits then meet in fp32 atomics (the C ABI's
+    behaviour for a caller that passes none; refused in deterministic mode)."""
     N, C, H, W = x.shape
     _conv_launch(mr, 'ag2v_conv2d_wgrad_ex', 'conv_wgrad', 2.0 * N * K * dy.shape[2] * dy.shape[3] * C * R * S,
                  _ptr(dy), _ptr(x), _ptr(dw), N, C, H, W, K, R, S, stride, pad, 1 if acc else 0, int(groups), _stream(),
                  shape=(N, C, H, W, K, R, stride), in_split=in_split, dy_split=dy_split,
-                 det_ws_query=(x.device, (N, C, H, W, K, R, S, stride, pad, int(groups))))
+                 det_ws_query=(x.device, (N, C, H, W, K, R, S, stride, pad, int(groups))) if workspace else None)
 
 
 def _wgrad_tile_area(rows, cols):
@@ -931,7 +948,7 @@ def conv_split_dy_ok(x_shape, w_shape, stride, pad):
     K, _, R, S = [int(v) for v in w_shape]
     _, mr_b = _current_min_rows()
     return bool(_lib.query('ag2v_conv2d_split_dy_ok', N, C, H, W, K, R, S, int(stride), int(pad), int(mr_b or 0), _PRECISION[0])) \
-        and os.environ.get('AG2V_NO_SPLIT_ACT') is None and os.environ.get('AG2V_NO_SPLIT_GRAD') is None
+        and os.environ.get('AG2V_NO_SPLIT_GRAD') is None
 
 
 def conv_split_input_ok(x_shape, w_shape, stride, pad):
@@ -941,7 +958,7 @@ def conv_split_input_ok(x_shape, w_shape, stride, pad):
     K, _, R, S = [int(v) for v in w_shape]
     mr_f, mr_b = _current_min_rows()
     return bool(_lib.query('ag2v_conv2d_split_input_ok', N, C, H, W, K, R, S, int(stride), int(pad), int(mr_f or 0), int(mr_b or 0),
-                           _PRECISION[0])) and os.environ.get('AG2V_NO_SPLIT_ACT') is None
+                           _PRECISION[0]))
 
 
 class _ConvSharedInput(torch.autograd.Function):
@@ -1092,7 +1109,7 @@ def conv2d_shared_input(x, weights, biases, stride=1, pad=0, relu=False, grad_pr
         for o, f in zip(outs, flags):
             if f:
                 mark_split(o)
-    if (grad_split and relu and grad_premasked and torch.is_grad_enabled() and os.environ.get('AG2V_NO_SPLIT_DACTV') is None
+    if (grad_split and relu and grad_premasked and torch.is_grad_enabled()
             and conv_split_dy_ok(x.shape, (sum(int(w.shape[0]) for w in weights),) + tuple(weights[0].shape[1:]), stride, pad)):
         for o in outs:
             if o.grad_fn is not None:
@@ -1339,7 +1356,7 @@ class _NormAct(torch.autograd.Function):
             _launch('ag2v_norm_apply_gs', 'spade_norm_apply', 4.0 * x.numel() * 4, mode, _ptr(x), _ptr(mean), _ptr(invstd), None, None,
                     g_ptr, b_ptr, _ptr(y), N, C, HW, Ng, float(slope), 1 if out_split else 0, _stream(), shape=(N, C, HW))
         # mode 0 (affine batch norm): the backward recomputes the activation's sign from x, w, b -- y is not kept for it
-        sign_from_x = (mode == 0 and os.environ.get('AG2V_NORM_BWD_READ_Y') is None)
+        sign_from_x = mode == 0
         # lean tape, mode 2: only gamma is read by the backward -- keep a compact copy, let the [N, 2C, H, W] tensor go
         ctx.gcompact = bool(mode == 2 and _LEAN_TAPE[0])
         ctx.gb_shape = tuple(p0.shape) if mode == 2 else None
@@ -1438,7 +1455,7 @@ class _BNActPyramid(torch.autograd.Function):
         H, W = x.shape[2], x.shape[3]
         y = torch.empty_like(x)
         built = {(H, W): y}
-        if H % 2 == 0 and W % 8 == 0 and (H // 2, W // 2) in sizes and os.environ.get('AG2V_NO_APPLY_HALF') is None:
+        if H % 2 == 0 and W % 8 == 0 and (H // 2, W // 2) in sizes:
             # the half-size level comes out of the normalisation pass itself (3.1 ms of resize at c3 -> +0.7 ms of writes)
             yh = torch.empty((N, C, H // 2, W // 2), device=x.device, dtype=torch.float32)
             _lib.call('ag2v_norm_apply_half', _ptr(x), _ptr(mean), _ptr(invstd), _ptr(weight), _ptr(bias), _ptr(y), _ptr(yh),
@@ -1490,7 +1507,7 @@ class _BNActPyramid(torch.autograd.Function):
             else:
                 lv.append(g.data_ptr()); hs.append(h); ws_.append(w)
         G = N // Ng
-        if len(lv) > 2 and os.environ.get('AG2V_NO_PYRAMID_FOLD') is None:
+        if len(lv) > 2:
             # Nearest-neighbour grids nest (level h takes source rows i * H / h): the gradients of the small levels are first scattered into
             # the second-largest level (a pass over ~1 GB at c3), so the two full-size passes below gather from two levels instead of
             # five -- each further level was a dependent load behind a branch in both of them (19.2 -> 16 ms at 120 x 512 x 256 x 256)
@@ -1880,7 +1897,7 @@ class _LayoutConvImg(torch.autograd.Function):
 
 
 def layout_conv_img_supported(H, W, R, stride, pool, IC):
-    return stride == 1 and pool == 0 and W % 4 == 0 and 0 < IC <= 8 and R in (3, 4) and os.environ.get('AG2V_NO_LAYOUT_IMG') is None
+    return stride == 1 and pool == 0 and W % 4 == 0 and 0 < IC <= 8 and R in (3, 4)
 
 
 def layout_conv_img(U, boxes, keep, H, W, R, pad, img, w_img, gscale=None):

@@ -299,7 +299,7 @@ def main():
                     "backward, joined behind the discriminator phase); alone = the same buckets reduced with nothing else running; the "
                     "discriminator's all-reduce is synchronous (fully exposed)"})
     comm["sync_bn"] = bool(D.sync_bn())
-    if D.is_dist() and D.sync_bn() and world > 1:
+    if D.is_dist() and D.sync_bn():          # (world 1 under AG2V_FORCE_DIST=1 --sync-bn 1 as well: the one-GPU rehearsal of an 8-GPU rank)
         # the same step with PER-RANK batch statistics (F.batch_norm's formula; --sync-bn 0), beside the synchronised default
         D.set_sync_bn(False)
         ops.pause_kernel_timing(True)
@@ -406,9 +406,12 @@ def main():
                 "peak_basis": ("bf16 dense MFMA 2500 TF (2.4 GHz) / 3 MFMAs per fp32-equivalent product; the kernel's own cycle counter shows "
                                "1.53 GHz under this instruction mix (DESIGN.md 3.4), i.e. 531 TF MFMA-bound at the held clock"
                                if split else "v_mfma_f32_32x32x2_f32 dense peak"),
-                "launches": t['launches'], "avg_launch_ms": round(t['ms'] / t['launches'], 4),
-                "launches_cover": "one step (the last timed one)",
-                "flops_per_launch": t['flops'] / t['launches'], "passes": t['passes'],
+                # a CALL = one ag2v_conv2d_*_ex entry; the library cuts a call whose operands exceed 4 GiB into sample chunks, so rocprofv3
+                # counts more kernel LAUNCHES of this kernel than calls (c3: 25 calls = 38 launches per step).  achieved =
+                # FLOPs per call / time per call = FLOPs per launch / time per launch either way.
+                "calls": t['launches'], "avg_call_ms": round(t['ms'] / t['launches'], 4),
+                "calls_cover": "one step (the last timed one)",
+                "flops_per_call": t['flops'] / t['launches'], "passes": t['passes'],
                 "by_shape": (top_shapes(dom) if tm is timing else None),
                 "all_conv_kernels": {"achieved": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
                                      "share_of_step_time": round(conv_ms / wall_ms, 4),

@@ -415,9 +415,6 @@ int ag2v_spectral_sigmas_multi(const void* descs, int n_layers, int total_blocks
  *      a multiple of 4 floats (16-byte accesses).  The record builder (ag2video_amd/graph_program.py) refuses anything else.
  * sync: two device words {arrival counter, timeout flag}, BOTH zeroed by the call; the flag is set when a grid barrier gave up (the
  * workgroups were not co-resident): the results of THAT run are invalid and the caller must read the flag before it trusts them. */
-/* TEST AID: occupy n_wgs CUs (1024 threads + 128 KB of LDS each) for ms <= 500 milliseconds of wall time on `stream`, as another stream's
- * persistent kernel would; bounded by the clock.  Used to show that the graph-net programs' grid barriers survive late co-residency. */
-int ag2v_debug_hold_cus(int n_wgs, float ms, void* stream);
 size_t ag2v_graph_op_bytes(void);
 int ag2v_graph_program_grid(void);
 int ag2v_graph_program_max_edges(void);

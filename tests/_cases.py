@@ -51,7 +51,7 @@ def case_clip(case, opt, batch, frames, side, seed):
 # Full gradient TENSORS kept by oracle_step beside the statistics and compared element-wise by tests/test_configs_gpu.py (VERDICT r05
 # next #6c): the decoder's last 3x3 convolution, the 1027 -> 512 layout convolution, the discriminator's widest 4x4 layer.
 FULL_GRADS = {'G_grads': ('layout_to_video.module.netG.up_3.conv_1.weight_orig', 'layout_to_video.module.conv_dim_in.0.0.weight_orig'),
-              'D_grads': ('discriminator_0.model3.0.weight_orig',)}
+              'D_grads': ('discriminator_0.model3.0.0.weight_orig',)}
 
 
 def is_front(name):

@@ -27,7 +27,9 @@ def main(out_path):
     dev = torch.device('cuda', local)
     flags = ['--no_vgg_loss', '--image_size', '64,64', '--batch_size', '2', '--ngf', '8', '--ndf', '8', '--nff', '8',
              '--gconv_hidden_dim', '64', '--gpu_ids', str(local)]
-    opt = make_opt(cater_vocab(), flags)
+    # --sync_bn 0: per-rank statistics at every world size (the default -1 synchronises at > 1 rank and would add one all-reduce per
+    # batch-norm call to the count below; the synchronised paths have their own legs further down and in sync_bn_2rank_child.py)
+    opt = make_opt(cater_vocab(), flags + ['--sync_bn', '0'])
     torch.manual_seed(100 + rank)                     # rank-dependent default init: the broadcast must make ranks agree
     ts = TrainStep(opt, dev, weights_seed=None if os.environ.get('AG2V_TEST_RANDOM_INIT') else 5)
     calls = {'n': 0, 'elems': 0}
@@ -51,11 +53,11 @@ def main(out_path):
     _, GG = ts.graph_step(gclip)
     # the same step while ANOTHER stream holds 64 CUs from start to end (what RCCL's kernels or a persistent kernel on the side stream
     # do at > 1 rank): the graph-net programs' grid barriers must complete -- check_health() raises on a timeout flag
-    import ctypes
-    from ag2video_amd import _lib
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _test_aids import hold_cus
     hold = torch.cuda.Stream()
     with torch.cuda.stream(hold):
-        _lib.call('ag2v_debug_hold_cus', 64, 400.0, ctypes.c_void_p(hold.cuda_stream))
+        hold_cus(64, 400.0, hold)
     _, GLh, DLh = ts.gd_step(clip, apply_updates=False)
     ts.check_health()
     torch.cuda.synchronize()
@@ -132,6 +134,38 @@ def main(out_path):
                      'running_var_fused_vs_plain': max(float(((rv_f[k] - rv_p[k]).abs() / rv_p[k].abs().clamp(min=1e-6)).max()) for k in rv_p),
                      'n_running_var': len(rv_o)}
     D.set_sync_bn(False)
+    # BASELINE.json's c2 (128 x 128, 8 frames, batch 4, default widths) the way an 8-GPU rank runs it: collectives
+    # live (RCCL), synchronised batch norm on every fused path, the generator's gradient all-reduce in flight under the D phase -- and
+    # a second stream holding 64 CUs from before the step until after its D phase, as RCCL's kernels do at > 1 rank.  Deterministic
+    # mode: the held run must equal the unheld one bit for bit (co-residency may delay the graph-net programs, never change them).
+    c2_sync_held = None
+    if world == 1 and not os.environ.get('AG2V_TEST_SKIP_C2'):
+        import bench
+        opt2, side2, frames2, batch2 = bench.make_opt('c2')
+        opt2.sync_bn = 1
+        clip2 = bench.make_clip(opt2, 'c2', batch2, frames2, side2, seed=31)
+        runs = []
+        for held in (False, True):
+            with ops.deterministic():
+                t2 = TrainStep(opt2, dev, weights_seed=5)
+                assert D.sync_bn()
+                b2 = t2.to_device(clip2)
+                torch.cuda.synchronize()
+                if held:
+                    with torch.cuda.stream(hold):
+                        hold_cus(64, 450.0, hold)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                _, gl2, dl2 = t2.gd_step(b2)
+                e1.record()
+                t2.check_health()
+                torch.cuda.synchronize()
+            runs.append(({k: float(v) for k, v in list(gl2.items()) + list(dl2.items())}, e0.elapsed_time(e1),
+                         float(sum(p.detach().double().abs().sum() for p in t2.model.parameters()))))
+            del t2
+        D.set_sync_bn(False)
+        c2_sync_held = {'losses': runs[1][0], 'losses_equal': runs[0][0] == runs[1][0], 'params_equal': runs[0][2] == runs[1][2],
+                        'ms_unheld': runs[0][1], 'ms_held': runs[1][1]}
     skip = D.any_rank(False, dev), D.any_rank(rank == 0, dev)
     torch.distributed.barrier()
     mx = D.max_over_ranks(float(rank + 1), dev)
@@ -146,7 +180,7 @@ def main(out_path):
                                ts.optimizer_graph.flat_grad.numel()],
            'G': {k: float(v) for k, v in GL.items()}, 'D': {k: float(v) for k, v in DL.items()},
            'G0': {k: float(v) for k, v in GL0.items()}, 'graph': {k: float(v) for k, v in GG.items()},
-           'skip_flags': list(skip), 'held_step': held_step, 'sync_bn_err': sync_bn_err, 'sync_step': sync_step, 'max_over_ranks': mx, 'param_checksums': [float(t) for t in gathered]}
+           'skip_flags': list(skip), 'held_step': held_step, 'c2_sync_held': c2_sync_held, 'sync_bn_err': sync_bn_err, 'sync_step': sync_step, 'max_over_ranks': mx, 'param_checksums': [float(t) for t in gathered]}
     if rank == 0:
         json.dump(res, open(out_path, 'w'))
     D.shutdown()

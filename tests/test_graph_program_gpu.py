@@ -324,12 +324,12 @@ def test_timeout_flags_are_read_back(device):
 @pytest.mark.parametrize("held,ms", [(64, 60.0), (192, 100.0), (256, 40.0)], ids=['64cus_whole_run', '192cus_100ms', 'all_cus_40ms'])
 def test_program_finishes_when_another_stream_holds_cus(held, ms, device):
     """the programs' grid barriers need all 128 workgroups resident, and at > 1 rank another stream (RCCL's
-    all-reduce, a persistent convolution on the side stream) holds CUs while they run.  ag2v_debug_hold_cus occupies `held` CUs (1024
+    all-reduce, a persistent convolution on the side stream) holds CUs while they run.  tests/_test_aids.py hold_cus occupies `held` CUs (1024
     threads + 128 KB of LDS each: no program workgroup can share them) for `ms` milliseconds on a second stream, launched FIRST; the
     program -- 6 dependent operators, a grid barrier behind each -- must complete with correct results and no timeout flag: with 64
     CUs held the rest of the chip takes it at once, with 192 or all of them held its workgroups become resident as the holders retire,
     far inside the barrier's 2 s wall-clock limit."""
-    from ag2video_amd import _lib
+    from _test_aids import hold_cus
     from ag2video_amd import graph_program as gp
     gp.check_timeouts()
     P = gp.Program(device)
@@ -345,7 +345,7 @@ def test_program_finishes_when_another_stream_holds_cus(held, ms, device):
     t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
     t0.record()
     with torch.cuda.stream(side):
-        _lib.call('ag2v_debug_hold_cus', held, float(ms), ctypes.c_void_p(side.cuda_stream))
+        hold_cus(held, ms, side)
     P.run()
     t1.record()
     torch.cuda.synchronize()

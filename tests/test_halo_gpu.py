@@ -27,9 +27,9 @@ def _from_split_words(t):
 
 
 def _reload():
-    from ag2video_amd import _lib
+    from ag2video_amd import ops
     torch.cuda.synchronize()
-    _lib.call('ag2v_halo_reload_env')
+    ops.reload_kernel_switches()
 
 
 class _halo(object):

@@ -29,13 +29,13 @@ class _wgrad_halo(object):
         self.on = on
 
     def _set(self, off):
-        from ag2video_amd import _lib
+        from ag2video_amd import ops
         if off:
             os.environ['AG2V_NO_WGRAD_HALO'] = '1'
         else:
             os.environ.pop('AG2V_NO_WGRAD_HALO', None)
         torch.cuda.synchronize()
-        _lib.call('ag2v_halo_reload_env')
+        ops.reload_kernel_switches()
 
     def __enter__(self):
         self.old = os.environ.get('AG2V_NO_WGRAD_HALO')
@@ -46,13 +46,14 @@ class _wgrad_halo(object):
         return False
 
 
-def _wgrad(dys, xs, K, groups=1, acc_into=None, x_split=True, dy_split=True):
+def _wgrad(dys, xs, K, groups=1, acc_into=None, x_split=True, dy_split=True, workspace=True):
     from ag2video_amd import _lib, ops
     C = xs.shape[1]
     shape = ((groups,) if groups > 1 else ()) + (K, C, 3, 3)
     dw = acc_into.clone() if acc_into is not None else torch.full(shape, float('nan'), device=xs.device)
     with ops.conv_precision('bf16x3'), torch.no_grad():
-        ops._conv_wgrad_launch(32, dys, xs, dw, K, 3, 3, 1, 1, 1 if acc_into is not None else 0, groups=groups, in_split=x_split, dy_split=dy_split)
+        ops._conv_wgrad_launch(32, dys, xs, dw, K, 3, 3, 1, 1, 1 if acc_into is not None else 0, groups=groups, in_split=x_split, dy_split=dy_split,
+                               workspace=workspace)
     return dw, _lib.query('ag2v_last_conv_kernel')
 
 
@@ -169,3 +170,34 @@ def test_wgrad_halo_at_the_benchmarked_layer_size(device):
     assert (new - old).abs().max().item() <= 1e-5 * scale
     ref = _ref64(dys[:, 5:9], xs[:, 100:108], 4)          # dW[5:9, 100:108]
     assert (new[5:9, 100:108].double() - ref).abs().max().item() <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("cfg", [(8, 64, 32, 64, 128, 1), (6, 64, 16, 64, 128, 3), (16, 128, 64, 64, 200, 1)], ids=str)
+def test_wgrad_halo_atomic_epilogue_without_workspace(cfg, device):
+    """A caller of ag2v_conv2d_wgrad_ex that hands over NO slab workspace (the C ABI allows it outside deterministic mode): the
+    LDS-DMA kernel's pixel-range splits then meet in fp32 atomics on dW behind the launcher's memset -- per sample group, with and
+    without accumulation onto an existing gradient (this path had no test; the product itself always passes the
+    workspace).  Against fp64 and against the slab path; deterministic mode refuses the missing workspace."""
+    from ag2video_amd import ops
+    N, C, H, W, K, groups = cfg
+    g = torch.Generator().manual_seed(13)
+    xs = _to_split_words(torch.randn(N, C, H, W, generator=g).to(device))
+    dys = _to_split_words(torch.randn(N, K, H, W, generator=g).to(device))
+    base = torch.randn(*(((groups,) if groups > 1 else ()) + (K, C, 3, 3)), generator=g).to(device)
+    ref = _ref64(dys, xs, K, groups)
+    scale = ref.abs().max().item()
+    with _wgrad_halo(True):
+        slab, name = _wgrad(dys, xs, K, groups)
+        assert name == b'conv_wgrad_halo_bf16x3_kernel<true, true>', name
+        atom, name = _wgrad(dys, xs, K, groups, workspace=False)
+        assert name == b'conv_wgrad_halo_bf16x3_kernel<true, true>', name
+        atom_acc, _ = _wgrad(dys, xs, K, groups, acc_into=base, workspace=False)
+        assert torch.isfinite(atom).all()
+        assert (atom.double() - ref).abs().max().item() <= 2e-5 * scale
+        assert (atom - slab).abs().max().item() <= 1e-5 * scale
+        assert (atom_acc.double() - (ref + base.double())).abs().max().item() <= 2e-5 * scale
+        with ops.deterministic():
+            _wgrad(dys, xs, K, groups)
+            if any(v > 0 for k, v in ops._DET_WS_FLOATS.items() if k[:5] == (N, C, H, W, K) and k[-1] == 1):   # splits -> slabs needed
+                with pytest.raises(RuntimeError):
+                    _wgrad(dys, xs, K, groups, workspace=False)

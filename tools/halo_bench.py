@@ -50,7 +50,7 @@ def main():
                 os.environ.pop('AG2V_NO_HALO', None)
                 if mode == 'old':
                     os.environ['AG2V_NO_HALO' if os.environ.get('HALO_BASE') != '32' else 'AG2V_HALO_MFMA32'] = '1'
-                _lib.call('ag2v_halo_reload_env')          # the library caches the switches
+                ops.reload_kernel_switches()          # the library caches the switches
                 res[mode] = fwd()
                 names[mode] = _lib.query('ag2v_last_conv_kernel').decode()
                 os.environ.pop('AG2V_HALO_MFMA32', None)
@@ -69,11 +69,11 @@ def main():
                     os.environ.pop('AG2V_HALO_MFMA32', None)
                     if mode == 'old':
                         os.environ['AG2V_NO_HALO' if os.environ.get('HALO_BASE') != '32' else 'AG2V_HALO_MFMA32'] = '1'
-                    _lib.call('ag2v_halo_reload_env')
+                    ops.reload_kernel_switches()
                     fwd()
                     t[mode].append(timed(fwd, reps))
             os.environ.pop('AG2V_NO_HALO', None)
-            _lib.call('ag2v_halo_reload_env')
+            ops.reload_kernel_switches()
         mo, mn = min(t['old']), min(t['new'])
         print('fwd %-28s old %7.3f ms %6.1f TF | new %7.3f ms %6.1f TF (%+.1f %%) | new-vs-old %.1e, vs fp64: new %.1e old %.1e | %s | %s'
               % ((N, C, H, W, K), mo, flops / mo / 1e9, mn, flops / mn / 1e9, (mo / mn - 1) * 100, err, e64, e64o,

@@ -22,7 +22,7 @@ def mode(new):
     else:
         os.environ['AG2V_NO_WGRAD_HALO'] = '1'
     torch.cuda.synchronize()
-    _lib.call('ag2v_halo_reload_env')
+    ops.reload_kernel_switches()
 
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
