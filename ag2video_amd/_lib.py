@@ -34,6 +34,7 @@ _SIGS = {
     'ag2v_conv2d_wgrad_ex': (c_int, [_P, _P, _P] + [c_int] * 11 + [_P, _P]),
     'ag2v_conv2d_wgrad_det_workspace_floats': (c_size_t, [c_int] * 10 + [_P]),
     'ag2v_conv2d_split_input_ok': (c_int, [c_int] * 12),
+    'ag2v_conv2d_fwd_mtile_ok': (c_int, [c_int] * 14),
     'ag2v_conv2d_split_dy_ok': (c_int, [c_int] * 11),
     'ag2v_channel_sum': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     'ag2v_channel_sum_acc': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
@@ -119,7 +120,7 @@ class ConvOpts(ctypes.Structure):
     """ag2v_conv_opts (include/ag2v.h): per-call options of the *_ex convolution entry points."""
     _fields_ = [('precision', c_int), ('min_rows', c_int), ('gscale', c_void_p), ('group_n', c_int), ('kernel', c_char_p),
                 ('in_split', c_int), ('dy_split', c_int), ('out_split', c_int), ('deterministic', c_int), ('det_workspace', c_void_p),
-                ('det_workspace_floats', ctypes.c_size_t), ('out_nstride', ctypes.c_longlong)]
+                ('det_workspace_floats', ctypes.c_size_t), ('out_nstride', ctypes.c_longlong), ('out_mstride', ctypes.c_longlong)]
 
 _lib = None
 

@@ -44,6 +44,10 @@ struct ConvArgs {
                             //   by launch_igemm).  Larger: out is a channel slice of a wider [N, Ktot, H, W] buffer
                             //   (ag2v_conv_opts::out_nstride: data gradients written straight into the concatenation their consumer
                             //   reads); residual / mask keep the dense layout.  Such launches never split K.
+    long long out_mstride;  // halo kernels' epilogue (0 = off): floats between the outputs of consecutive 128-ROW TILES -- row tile i of the
+                            //   launch is its own dense [N, 128, H, W] tensor at out + i * out_mstride (out_nstride = 128 * H * W): ONE
+                            //   launch computes several convolutions of the same input (the SPADE mlp_shared group of a block,
+                            //   ag2v_conv_opts::out_mstride) and every consumer still reads a contiguous tensor
 #ifdef AG2V_STAMPS
     unsigned long long* stamps;   // diagnostic build only (tools/ubench/igemm_stamps.hip): per-wave phase clocks
 #endif

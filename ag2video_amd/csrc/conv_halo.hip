@@ -323,6 +323,8 @@ struct HaloBody {
             const size_t pxo = (size_t)(cur.y0 + ty) * p.OW + (cur.x0 + tx + l31);
             const size_t pix = (size_t)cur.n_img * p.M * plane + pxo;
             float* obase = p.out + (size_t)cur.n_img * p.out_nstride + pxo;
+            // (multi-output launch: this row tile's own tensor; rows are addressed by their absolute index below)
+            if (p.out_mstride) obase += (long long)(cur.m0 / G::BM) * p.out_mstride - (long long)cur.m0 * plane;
             const float* aux = aux0 ? aux0 + pix : nullptr;
             const float gs = (p.gscale ? p.gscale[cur.n_img / p.group_n] : 1.f) * (p.oscale != 0.f ? p.oscale : 1.f);
 #pragma unroll
@@ -672,6 +674,8 @@ struct HaloBody16 {
             const size_t pxo = (size_t)(cur.y0 + ty) * p.OW + (cur.x0 + tx + qpx);
             const size_t pix = (size_t)cur.n_img * p.M * plane + pxo;
             float* obase = p.out + (size_t)cur.n_img * p.out_nstride + pxo;
+            // (multi-output launch: this row tile's own tensor; rows are addressed by their absolute index below)
+            if (p.out_mstride) obase += (long long)(cur.m0 / G::BM) * p.out_mstride - (long long)cur.m0 * plane;
             const float* aux = aux0 ? aux0 + pix : nullptr;
             const float gs = (p.gscale ? p.gscale[cur.n_img / p.group_n] : 1.f) * (p.oscale != 0.f ? p.oscale : 1.f);
             typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
@@ -878,6 +882,7 @@ bool igemm_halo_ok(const ConvArgs& a) {
     if (a.residual == a.out && a.residual) return false;          // accumulating launches stay on the split-K capable kernels
     const bool tall = halo_tall(a.M);
     const int bn = tall ? 128 : 256, bm = tall ? 256 : (a.M <= 64 ? 64 : 128);
+    if (a.out_mstride && (bm != 128 || a.M % 128 || a.residual || a.mask)) return false;      // per-row-tile outputs: whole 128-row tiles
     int tw, th;
     if (!halo_geometry(bn, a.OH, a.OW, tw, th)) return false;
     const long long tiles = (long long)ceil_div(a.M, bm) * (a.NG / bn);

@@ -535,6 +535,7 @@ struct ag2v_conv_opts {
     float* det_workspace;
     size_t det_workspace_floats;
     long long out_nstride;
+    long long out_mstride;
 };
 struct ConvCfg {
     int precision, min_rows;
@@ -545,6 +546,7 @@ struct ConvCfg {
     float* det_ws;
     size_t det_ws_floats;
     long long out_nstride;
+    long long out_mstride;
 };
 static ConvCfg conv_cfg(const ag2v_conv_opts* o) {
     ConvCfg c;
@@ -559,6 +561,7 @@ static ConvCfg conv_cfg(const ag2v_conv_opts* o) {
     c.det_ws = o ? o->det_workspace : nullptr;
     c.det_ws_floats = o ? o->det_workspace_floats : 0;
     c.out_nstride = o ? o->out_nstride : 0;
+    c.out_mstride = o ? o->out_mstride : 0;
     return c;
 }
 static bool use_bf16x3(const ConvCfg& c, int M) { return c.precision >= 1 && M >= c.min_rows; }     // (2: fp16 split in the forward pass)
@@ -1048,10 +1051,27 @@ extern "C" int ag2v_conv2d_fwd_ex(const float* x, const float* w, const float* b
     else
         hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(KG, 32), ceil_div(K, 32)), dim3(256), 0, st, w, workspace, K, KG,
                            h16 ? 2 : (split ? 1 : 0));
+    // ag2v_conv_opts::out_mstride: every 128 output channels are their own dense [N, 128, OH, OW] tensor, out_mstride floats apart
+    // (several convolutions of ONE input as one launch).  Only the LDS-DMA kernels place their output so: refused before anything is
+    // launched when this call would not run on them (ag2v_conv2d_fwd_mtile_ok answers the same question up front)
+    const long long ms = cfg.out_mstride;
+    const long long ys_tile = 128LL * OH * OW;
+    if (ms < 0 || (ms > 0 && (residual || !split || !igemm_tap_major(C, split) || K % 128))) return AG2V_EINVAL;
+    if (ms > 0) {
+        for (int n0 = 0; n0 < N; n0 += nmax) {
+            ConvArgs t{};
+            t.N = (N - n0 < nmax) ? N - n0 : nmax; t.C = C; t.H = H; t.W = W; t.K = K; t.R = R; t.S = S; t.stride = stride; t.pad = pad; t.pad_w = pad;
+            t.OH = OH; t.OW = OW; t.M = K; t.NG = t.N * OH * OW; t.KG = KG; t.b_bytes = (unsigned)(xs * 4 * t.N); t.tap_major = 1;
+            t.b_split = cfg.in_split; t.out_split = cfg.out_split; t.det = cfg.det; t.h16 = h16 ? 1 : 0; t.o_mul = 1; t.o_H = OH; t.o_W = OW;
+            t.out_mstride = ms;
+            if (!igemm_halo_ok(t)) return AG2V_EINVAL;
+        }
+    }
     for (int n0 = 0; n0 < N; n0 += nmax) {
         const int nc = (N - n0 < nmax) ? N - n0 : nmax;
         ConvArgs a{};
-        a.b_src = x + (size_t)n0 * xs; a.out = y + (size_t)n0 * ys; a.bias = bias;
+        a.b_src = x + (size_t)n0 * xs; a.out = y + (size_t)n0 * (ms > 0 ? ys_tile : ys); a.bias = bias;
+        if (ms > 0) { a.out_mstride = ms; a.out_nstride = ys_tile; }
         a.residual = residual ? residual + (size_t)n0 * ys : nullptr; a.relu = relu ? 1 : 0;
         a.gscale = cfg.gscale ? cfg.gscale + n0 / cfg.group_n : nullptr; a.group_n = cfg.group_n;
         a.N = nc; a.C = C; a.H = H; a.W = W; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.pad_w = pad;
@@ -1065,11 +1085,50 @@ extern "C" int ag2v_conv2d_fwd_ex(const float* x, const float* w, const float* b
         a.det = cfg.det;
         a.h16 = h16 ? 1 : 0;
         a.oscale = h16 ? 1.0f / AG2V_H16_WSCALE : 0.f;
-        const int rc = launch_igemm(a, st, false, split || f32ws);
+        int rc;
+        if (ms > 0) {
+            a.o_mul = 1; a.o_H = OH; a.o_W = OW;
+            rc = launch_igemm_halo(a, st);
+        } else {
+            rc = launch_igemm(a, st, false, split || f32ws);
+        }
         if (rc != AG2V_OK) return rc;
     }
     if (o) o->kernel = g_last_conv_kernel;
     return AG2V_OK;
+}
+// 1 when ag2v_conv2d_fwd_ex accepts ag2v_conv_opts::out_mstride for this call (3x3 stride-1 convolution with K % 128 == 0 that runs on the
+// LDS-DMA kernels' 128-row tile in every sample chunk), else 0
+extern "C" int ag2v_conv2d_fwd_mtile_ok(int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int min_rows, int precision,
+                                        int in_split, int out_split, int deterministic) {
+    if (N <= 0 || C <= 0 || K <= 0 || K % 128 || stride <= 0 || R * S > 16) return 0;
+    ag2v_conv_opts o{};
+    o.precision = precision; o.min_rows = min_rows; o.in_split = in_split; o.out_split = out_split; o.deterministic = deterministic;
+    const ConvCfg cfg = conv_cfg(&o);
+    const int OH = conv_out_dim(H, R, stride, pad), OW = conv_out_dim(W, S, stride, pad);
+    if (OH <= 0 || OW <= 0) return 0;
+    const int KG = C * R * S;
+    const long long abytes = (long long)KG * K * 4, xs = (long long)C * H * W;
+    if (xs >= (1LL << 31) || (long long)K * OH * OW >= (1LL << 31)) return 0;
+    if (!(use_bf16x3(cfg, K) && abytes < kBufMax && !(KG < 64 && K < 128)) || !igemm_tap_major(C, true)) return 0;
+    const bool h16 = cfg.precision == 2;
+    if (h16 && (in_split || out_split)) return 0;
+    int nmax = N;
+    if (xs * 4 * N >= chunk_limit()) {
+        nmax = chunk_samples(xs * 4, 0, 1);
+        if (nmax <= 0) return 0;
+    }
+    if ((long long)nmax * OH * OW >= (1LL << 31)) nmax = (int)(((1LL << 31) - 1) / ((long long)OH * OW));
+    if (nmax <= 0) return 0;
+    for (int n0 = 0; n0 < N; n0 += nmax) {
+        ConvArgs t{};
+        t.N = (N - n0 < nmax) ? N - n0 : nmax; t.C = C; t.H = H; t.W = W; t.K = K; t.R = R; t.S = S; t.stride = stride; t.pad = pad; t.pad_w = pad;
+        t.OH = OH; t.OW = OW; t.M = K; t.NG = t.N * OH * OW; t.KG = KG; t.b_bytes = (unsigned)(xs * 4 * t.N); t.tap_major = 1;
+        t.b_split = in_split ? 1 : 0; t.out_split = out_split ? 1 : 0; t.det = deterministic ? 1 : 0; t.h16 = h16 ? 1 : 0;
+        t.o_mul = 1; t.o_H = OH; t.o_W = OW; t.out_mstride = 1;
+        if (!igemm_halo_ok(t)) return 0;
+    }
+    return 1;
 }
 extern "C" int ag2v_conv2d_fwd_act(const float* x, const float* w, const float* bias, const float* residual, float* y,
                                    int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int relu, float* workspace,

@@ -281,12 +281,12 @@ def reload_kernel_switches():
 
 
 def _conv_launch(min_rows, name, label, flops, *args, shape=None, gscale=None, group_n=1, in_split=False, dy_split=False,
-                 out_split=False, det_ws_query=None, precision=None, out_nstride=0):
+                 out_split=False, det_ws_query=None, precision=None, out_nstride=0, out_mstride=0):
     """One ag2v_conv2d_*_ex call.  Arithmetic (precision, bf16x3 row threshold: ``min_rows``, None = DEFAULT_MIN_ROWS) and the
     per-sample-group output scale travel as per-call options (ag2v_conv_opts): no process-wide switch is touched."""
     opts = _lib.ConvOpts(_PRECISION[0] if precision is None else int(precision), int(min_rows) if min_rows else DEFAULT_MIN_ROWS, None if gscale is None else gscale.data_ptr(),
                          int(group_n), None, 1 if in_split else 0, 1 if dy_split else 0, 1 if out_split else 0,
-                         1 if _DETERMINISTIC[0] else 0, None, 0, int(out_nstride))
+                         1 if _DETERMINISTIC[0] else 0, None, 0, int(out_nstride), int(out_mstride))
     det_ws = None
     if det_ws_query is not None:      # weight gradient: slabs for the ordered reduction of its pixel-range splits (deterministic mode;
         # in either mode for the LDS-DMA kernel, whose atomic epilogue costs 6-16 % of a launch)
@@ -553,15 +553,27 @@ def _wsink_take_group(keys, likes):
 
 
 # ------------------------------------------------------------------------------------------------ convolution
-def _conv_fwd_launch(mr, x, w, bias, residual, y, stride, pad, relu, gscale=None, group_n=1, in_split=False, out_split=False):
+def _conv_fwd_launch(mr, x, w, bias, residual, y, stride, pad, relu, gscale=None, group_n=1, in_split=False, out_split=False, out_mstride=0):
+    """out_mstride > 0: y is [n, N, 128, OH, OW] -- every 128 of w's n * 128 output channels form their own dense tensor
+    (ag2v_conv_opts::out_mstride; the caller has asked _fwd_mtile_ok)."""
     N, C, H, W = x.shape
     h16 = _current_fwd_h16() and not in_split and not out_split
     K, _, R, S = w.shape
     ws = torch.empty(_lib.query('ag2v_conv2d_workspace_floats', C, K, R, S), device=x.device, dtype=torch.float32)
-    _conv_launch(mr, 'ag2v_conv2d_fwd_ex', 'conv_fwd', 2.0 * N * K * y.shape[2] * y.shape[3] * C * R * S,
+    _conv_launch(mr, 'ag2v_conv2d_fwd_ex', 'conv_fwd', 2.0 * N * K * y.shape[-2] * y.shape[-1] * C * R * S,
                  _ptr(x), _ptr(w), _ptr(bias), _ptr(residual), _ptr(y), N, C, H, W, K, R, S, stride, pad, 1 if relu else 0,
                  _ptr(ws), _stream(), shape=(N, C, H, W, K, R, stride), gscale=gscale, group_n=group_n, in_split=in_split,
-                 out_split=out_split, precision=(2 if h16 else None))
+                 out_split=out_split, precision=(2 if h16 else None), out_mstride=out_mstride)
+
+
+_MERGE_SHARED_FWD = os.environ.get('AG2V_NO_MERGED_FWD') is None      # conv2d_shared_input: one forward launch (tests compare both sides)
+
+
+def _fwd_mtile_ok(mr, x, K, R, S, stride, pad, in_split, out_split):
+    N, C, H, W = x.shape
+    h16 = _current_fwd_h16() and not in_split and not out_split
+    return bool(_lib.query('ag2v_conv2d_fwd_mtile_ok', N, C, H, W, int(K), int(R), int(S), int(stride), int(pad), int(mr) if mr else DEFAULT_MIN_ROWS,
+                           2 if h16 else _PRECISION[0], 1 if in_split else 0, 1 if out_split else 0, 1 if _DETERMINISTIC[0] else 0))
 
 
 def _conv_dgrad_launch(mr, dy, w, mask, dx, stride, pad, acc, gscale=None, group_n=1, dy_split=False, out_split=False):
@@ -982,14 +994,36 @@ class _ConvSharedInput(torch.autograd.Function):
         outs = []
         if out_splits and not (relu and grad_premasked):
             raise RuntimeError("conv2d_shared_input: split-word outputs need relu=True, grad_premasked=True (the backward never reads them)")
+        for w in ws_:
+            if w.shape[1] != C:
+                raise RuntimeError("conv2d_shared_input: input has %d channels, weight expects %d" % (C, w.shape[1]))
+        # ONE launch for the whole group when every branch has 128 output channels, the same filter and the same output format, and the
+        # call runs on the LDS-DMA kernels (ag2v_conv_opts::out_mstride): the gathered map -- 16 GB at 256 x 256 -- is then staged once
+        # instead of once per branch, and every branch still gets its own contiguous tensor.  Same tiles, same products, same order:
+        # bit-identical to the separate launches (tests/test_halo_gpu.py).
+        osp = [bool(out_splits and out_splits[j]) for j in range(len(ws_))]
+        nb = len(ws_)
+        merged = (_MERGE_SHARED_FWD and nb > 1 and all(tuple(w.shape) == tuple(ws_[0].shape) for w in ws_) and ws_[0].shape[0] == 128
+                  and len(set(osp)) == 1 and len(set(b is None for b in bs_)) == 1
+                  and _fwd_mtile_ok(mr_f, x, 128 * nb, ws_[0].shape[2], ws_[0].shape[3], stride, pad, x_split, osp[0]))
+        if merged:
+            R, S = ws_[0].shape[2], ws_[0].shape[3]
+            OH = (H + 2 * pad - R) // stride + 1
+            OW = (W + 2 * pad - S) // stride + 1
+            ycat = torch.empty((nb, N, 128, OH, OW), device=x.device, dtype=torch.float32)
+            wcat = torch.cat(ws_, dim=0)
+            bcat = None if bs_[0] is None else torch.cat(bs_, dim=0)
+            _conv_fwd_launch(mr_f, x, wcat, bcat, None, ycat, stride, pad, relu, in_split=x_split, out_split=osp[0],
+                             out_mstride=N * 128 * OH * OW)
+            outs = list(ycat.unbind(0))
         for j, (w, b) in enumerate(zip(ws_, bs_)):
+            if merged:
+                break
             K, C2, R, S = w.shape
-            if C2 != C:
-                raise RuntimeError("conv2d_shared_input: input has %d channels, weight expects %d" % (C, C2))
             OH = (H + 2 * pad - R) // stride + 1
             OW = (W + 2 * pad - S) // stride + 1
             y = torch.empty((N, K, OH, OW), device=x.device, dtype=torch.float32)
-            _conv_fwd_launch(mr_f, x, w, b, None, y, stride, pad, relu, in_split=x_split, out_split=bool(out_splits and out_splits[j]))
+            _conv_fwd_launch(mr_f, x, w, b, None, y, stride, pad, relu, in_split=x_split, out_split=osp[j])
             outs.append(y)
         keep_y = relu and not grad_premasked
         ctx.save_for_backward(x, *ws_, *(outs if keep_y else []))

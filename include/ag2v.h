@@ -67,7 +67,13 @@ extern "C" {
  *              (out_nstride = Ctot * H * W, dx = buffer + c0 * H * W) -- the gradients of several convolutions that share a
  *              consumer are written straight into the concatenation that consumer's merged weight / data gradient reads
  *              (conv2d_shared_input: every SPADE's mlp_shared, normalization.py:90-94).  The mask keeps the dense layout.
- *              Anything else with a non-dense stride: AG2V_EINVAL. */
+ *              Anything else with a non-dense stride: AG2V_EINVAL;
+ *   out_mstride: (forward only; 0 = off) SEVERAL convolutions of one input as ONE launch: w / bias hold K = n * 128 output channels (the
+ *              n weight sets concatenated), and every 128 of them are written as their own dense [N, 128, OH, OW] tensor, out_mstride
+ *              floats apart (y + i * out_mstride; out_mstride >= N * 128 * OH * OW).  The SPADE layers of a residual block read the same
+ *              resized segmentation map through their own 128-channel mlp_shared convolution (normalization.py:90-94,
+ *              architecture.py:52-62): the gathered map is then staged once for all of them.  Only where ag2v_conv2d_fwd_mtile_ok()
+ *              says so (the LDS-DMA kernels' 128-row tile); otherwise AG2V_EINVAL, before anything is launched. */
 typedef struct ag2v_conv_opts {
     int precision;
     int min_rows;
@@ -81,6 +87,7 @@ typedef struct ag2v_conv_opts {
     float* det_workspace;
     size_t det_workspace_floats;
     long long out_nstride;
+    long long out_mstride;
 } ag2v_conv_opts;
 /* Defaults of calls that do not name precision / min_rows: a record per DEVICE, initialised from AG2V_CONV_PRECISION /
  * AG2V_BF16X3_MIN_M.  The setters are deprecated shims editing the calling thread's current device's record (the product passes both
@@ -139,6 +146,10 @@ size_t ag2v_conv2d_wgrad_det_workspace_floats(int N, int C, int H, int W, int K,
                                               const ag2v_conv_opts* opts);
 int ag2v_conv2d_split_input_ok(int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int min_rows_fwd,
                                int min_rows_bwd, int precision);
+/* 1 when ag2v_conv2d_fwd_ex accepts ag2v_conv_opts::out_mstride for this call (K % 128 == 0, 3x3 stride-1, every sample chunk on the
+ * LDS-DMA kernels' 128-row tile), else 0.  Reference call site: the mlp_shared convolutions of a block, normalization.py:90-94. */
+int ag2v_conv2d_fwd_mtile_ok(int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int min_rows, int precision,
+                             int in_split, int out_split, int deterministic);
 int ag2v_conv2d_split_dy_ok(int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int min_rows_bwd, int precision);
 /* accumulate != 0: dw += instead of dw = (a weight used by several forward calls of one step collects its gradient in one buffer). */
 int ag2v_conv2d_wgrad_acc(const float* dy, const float* x, float* dw, int N, int C, int H, int W, int K, int R, int S,

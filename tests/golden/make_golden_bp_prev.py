@@ -3,7 +3,8 @@
 With --bp_prev 1 the reference's generator feeds its own GENERATED frame back as the previous frame during training
 (models/spade_models/networks/generator.py:68-71), so the loss of frame t back-propagates through frames t-1, t-2, ...: the
 teacher-forced golden (make_golden.py, bp_prev 0) never exercises that path.  Same shims, toy widths, closed-form weights and
-seeded clip as make_golden.py, but 4 frames (three generated frames: two levels of feedback).  Stores data only ->
+seeded clip as make_golden.py (3 frames: frame 2 is generated from the GENERATED frame 1 -- one level of feedback; every further level
+amplifies fp32 rounding ~10x, and at 4 frames the reference's own fp32 result already sits 3.6e-2 from the exact one: tests/test_step_gpu.py).  Stores data only ->
 tests/golden/bp_prev.npz: outputs, generator / discriminator losses, gradient statistics of every parameter, five full gradient
 tensors.
 
@@ -21,7 +22,7 @@ sys.path.insert(0, HERE)
 from make_golden import REPO, TOY_FLAGS, install_shims, stats  # noqa: E402
 
 FLAGS = TOY_FLAGS + ['--bp_prev', '1']
-TOY = dict(batch=2, frames=4, size=(64, 64), seed=1234, wseed=7)
+TOY = dict(batch=2, frames=3, size=(64, 64), seed=1234, wseed=7)
 
 
 def main():

@@ -15,13 +15,16 @@ OUT = os.path.join(HERE, 'measured_max_norm.json')
 
 
 def main():
-    res = json.load(open(OUT)) if os.path.exists(OUT) else {}
+    # (start from scratch: the table describes ONE build -- pass every log of that build)
+    res = {}
     n = 0
     for path in sys.argv[1:]:
         for line in open(path, errors='replace'):
             m = re.search(r'MEASURED (\S+) (\S+) ([0-9.eE+-]+) ([0-9.eE+-]+)', line)
             if m:
                 case, prec, a, b = m.group(1), m.group(2), float(m.group(3)), float(m.group(4))
+                if case.endswith('bp'):          # chaotic feedback case: floor-scaled gates only (tests/test_configs_gpu.py)
+                    continue
                 cur = res.setdefault(case, {}).get(prec)
                 # several logs: keep the largest value seen (the bound must admit every run of the same build)
                 res[case][prec] = {'o64': max(a, cur['o64']) if cur else a, 'o32': max(b, cur['o32']) if cur else b}

@@ -209,3 +209,72 @@ def test_halo_forward_on_the_fp16_split(cfg, device):
     sc = float(ref.abs().max())
     assert float((outs[True].cpu() - ref).abs().max()) <= 3e-5 * sc
     assert float((outs[True] - outs[False]).abs().max()) <= 1e-5 * sc
+
+
+@pytest.mark.parametrize("cfg", [(3, 64, 64, 64, 3, True, True), (2, 32, 128, 128, 2, True, False), (2, 32, 32, 32, 3, False, False),
+                                 (1, 32, 224, 224, 2, True, True)], ids=str)
+def test_shared_input_group_as_one_launch_equals_separate_launches(cfg, device):
+    """conv2d_shared_input (the mlp_shared convolutions of a SPADE block: same resized segmentation map, 128 output channels each --
+    reference normalization.py:90-94, architecture.py:52-62) as ONE forward launch whose 128-row tiles write their own tensors
+    (ag2v_conv_opts::out_mstride): bit-identical to the separate launches (same tiles, same products, same order), against the oracle
+    at 2e-4, with split-word and fp32 inputs / outputs, in both MFMA shapes; the backward (merged gradients) is the same either way.
+    Shapes the LDS-DMA kernels do not take keep the separate launches."""
+    from ag2video_amd import _lib, ops
+    from oracle import kernels as K
+    N, C, H, W, nb, x_split, out_split = cfg
+    torch.manual_seed(5)
+    x = torch.randn(N, C, H, W, device=device)
+    xs = _to_split_words(x)
+    xin = xs if x_split else x
+    xv = _from_split_words(xs) if x_split else x
+    ws = [(torch.randn(128, C, 3, 3, device=device) * 0.05).requires_grad_(True) for _ in range(nb)]
+    bs = [torch.randn(128, device=device).requires_grad_(True) for _ in range(nb)]
+    cots = [torch.randn(N, 128, H, W, device=device) for _ in range(nb)]
+
+    def run(merged, fam):
+        ops._MERGE_SHARED_FWD = merged
+        with _halo(fam), ops.conv_precision('bf16x3'), ops.bf16x3_min_rows(32):
+            xi = xin.clone().requires_grad_(True)
+            if x_split:
+                ops.mark_split(xi)
+            outs = ops.conv2d_shared_input(xi, ws, bs, stride=1, pad=1, relu=True, grad_premasked=False)
+            name = _lib.query('ag2v_last_conv_kernel')
+            for w_ in ws + bs:
+                w_.grad = None
+            sum((o * c).sum() for o, c in zip(outs, cots)).backward()
+            return [o.detach().clone() for o in outs], xi.grad.clone(), [w_.grad.clone() for w_ in ws], name
+    try:
+        for fam in (True, '32'):
+            sep, dx_s, dw_s, _ = run(False, fam)
+            mer, dx_m, dw_m, name = run(True, fam)
+            assert name.startswith(b'conv_halo'), name
+            for a, b_ in zip(sep, mer):
+                assert b_.is_contiguous() and torch.equal(a, b_)
+            assert torch.equal(dx_s, dx_m) or float((dx_s - dx_m).abs().max()) <= 1e-6 * float(dx_s.abs().max())
+            for a, b_ in zip(dw_s, dw_m):
+                assert float((a - b_).abs().max()) <= 1e-6 * float(a.abs().max())
+            for j in range(nb):
+                ref = K.conv2d(xv.cpu(), ws[j].detach().cpu(), bs[j].detach().cpu(), 1, 1, relu=True)
+                assert float((mer[j].cpu() - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
+        # split-word outputs (relu + premasked gradient: what the SPADE blocks ask for) through the merged launch
+        if out_split:
+            res = {}
+            for merged in (False, True):
+                ops._MERGE_SHARED_FWD = merged
+                with _halo(True), ops.conv_precision('bf16x3'), ops.bf16x3_min_rows(32), torch.no_grad():
+                    xi = ops.mark_split(xin.clone()) if x_split else xin.clone()
+                    res[merged] = ops.conv2d_shared_input(xi, [w_.detach() for w_ in ws], [b_.detach() for b_ in bs], stride=1, pad=1, relu=True,
+                                                          grad_premasked=True, out_split=[True] * nb)
+            for a, b_ in zip(res[False], res[True]):
+                assert ops.is_split(a) and ops.is_split(b_) and torch.equal(a.view(torch.int32), b_.view(torch.int32))
+        # a map the LDS-DMA kernels do not take (16 x 16 at the default tile threshold): the group keeps its separate launches
+        ops._MERGE_SHARED_FWD = True
+        small = torch.randn(2, C, 16, 16, device=device)
+        with ops.conv_precision('bf16x3'), torch.no_grad():
+            assert not ops._fwd_mtile_ok(None, small, 128 * nb, 3, 3, 1, 1, False, False)
+            outs = ops.conv2d_shared_input(small, [w_.detach() for w_ in ws], [b_.detach() for b_ in bs], stride=1, pad=1, relu=True)
+            for j in range(nb):
+                ref = K.conv2d(small.cpu(), ws[j].detach().cpu(), bs[j].detach().cpu(), 1, 1, relu=True)
+                assert float((outs[j].cpu() - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
+    finally:
+        ops._MERGE_SHARED_FWD = True

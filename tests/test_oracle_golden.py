@@ -176,7 +176,7 @@ def test_oracle_fp64_mode_and_committed_noise_floor():
 def test_oracle_matches_reference_bp_prev_training_step():
     """--bp_prev 1 (reference generator.py:68-71: training feeds the GENERATED previous frame back, so frame t's loss back-propagates
     through frames t-1, t-2): the oracle against tests/golden/bp_prev.npz, written by tests/golden/make_golden_bp_prev.py from the
-    imported reference -- 4 frames, i.e. two levels of feedback.  Tolerances as in the teacher-forced test above; the fixture also records
+    imported reference -- 3 frames: frame 2 is generated from the generated frame 1.  Tolerances as in the teacher-forced test above; the fixture also records
     that the mode matters (imgs_pred differs from the teacher-forced pass by O(1))."""
     torch.set_num_threads(8)
     from ag2video_amd.data.args import make_opt
