@@ -70,16 +70,24 @@ class TrainStep(object):
         # Second HIP stream for the launch-latency-bound graph nets whose results nothing on the main stream waits for: the box
         # net's forward recurrence (AG2VideoModel.forward) and the discriminator's layout terms, forward here and backward at
         # the tail of the discriminator's backward pass (autograd runs a node on the stream its forward ran on).
-        self.side_stream = None
+        self.side_stream = self.side_stream_b = self.side_stream_d = None
         # (deterministic mode keeps everything on one stream: two streams accumulating gradients interleave in a varying order)
-        # Round 3: OFF by default (AG2V_SIDE_STREAM=1 enables it).  The convolution tiles fill every SIMD's register file, so side-stream
-        # kernels only ever ran in the gaps between convolution launches (same-box A/B: 790.0 vs 790.0 ms per step), and the graph
-        # nets are now persistent programs whose 128 workgroups meet at grid barriers: beside a convolution they would wait for CUs
-        # while holding others.
-        if (torch.device(device).type == 'cuda' and os.environ.get('AG2V_SIDE_STREAM') is not None
-                and os.environ.get('AG2V_NO_SIDE_STREAM') is None and not ops.is_deterministic()):
+        # Round 6: ON by default (AG2V_NO_SIDE_STREAM=1 turns it off).  The graph nets are persistent programs -- ONE launch each, 345
+        # dependent operators behind grid barriers, ~2.6 ms during which a program uses <= 128 CUs and nothing else runs: measured
+        # (tools/exp_graph_cost.py) 15.4 ms of the c3 step's wall time for the six launches.  The three FORWARD programs of a step (appearance
+        # net, box net, the discriminator's layout terms) depend on the batch and on parameters only: launched together at the start of the
+        # step on three streams with 64 workgroups each (graph_program.GRID) they run beside each other instead of one after the other.
+        # Rounds 3-5 had the switch off: the per-operator graph nets of round 2 only ever ran in the gaps between convolutions (790.0 vs
+        # 790.0 ms), and round 3's programs were queued BEHIND the generator's forward, where they wait for CUs the persistent
+        # convolutions hold.
+        if (torch.device(device).type == 'cuda' and os.environ.get('AG2V_NO_SIDE_STREAM') is None and not ops.is_deterministic()):
             self.side_stream = torch.cuda.Stream(device=device)
+            self.side_stream_b = torch.cuda.Stream(device=device)
+            self.side_stream_d = torch.cuda.Stream(device=device)
             self.model.side_stream = self.side_stream
+            self.model.side_stream_b = self.side_stream_b
+            from . import graph_program
+            graph_program.GRID[0] = 64
             # (graph-net parameters of D receive gradients from nodes of both streams)
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         dist_utils.broadcast_parameters(list(self.model.parameters()) + self._d_params +
@@ -105,11 +113,12 @@ class TrainStep(object):
         if self.side_stream is not None:
             adata = self.model.acts_to_boxes.module.actions_data(triplets, actions)      # (inputs only; a few small launches)
             step_start = torch.cuda.current_stream().record_event()
-        model_out = self.model(imgs, objs, triplets, actions, boxes_gt=boxes, test_mode=False, use_gt=True)
         if self.side_stream is not None:
-            # launched AFTER the generator's forward is queued (the graph net is issue-bound: its launches then reach a busy GPU),
-            # ordered only behind the start of this step
-            self.gans_model.module.prefetch_layout_terms(batch, adata, self.side_stream, after=step_start)
+            # the discriminator's layout terms (its graph-net program first) on their own stream, launched BEFORE the generator's forward
+            # is queued: the program then runs beside the appearance net's and the box net's (AG2VideoModel.forward), ordered only
+            # behind the start of this step
+            self.gans_model.module.prefetch_layout_terms(batch, adata, self.side_stream_d, after=step_start)
+        model_out = self.model(imgs, objs, triplets, actions, boxes_gt=boxes, test_mode=False, use_gt=True)
         G_losses = self.gans_model(batch, model_out, mode="compute_generator_loss")
         G_losses = {k: v.mean() for k, v in G_losses.items()}
         if nan_guard:
@@ -144,6 +153,7 @@ class TrainStep(object):
             D_losses["total_img_loss"].backward()
         if self.side_stream is not None:      # the layout terms' backward ran there; their gradients are written by the ops themselves
             torch.cuda.current_stream().wait_stream(self.side_stream)
+            torch.cuda.current_stream().wait_stream(self.side_stream_d)
         ops.join_direct_grad_streams()
         rec = self.comm_events is not None and dist_utils.is_dist() and torch.device(self.device).type == 'cuda'
         if deferred:

@@ -27,6 +27,14 @@ _OP_DTYPE = np.dtype([('type', '<i4'), ('M', '<i4'), ('N', '<i4'), ('K', '<i4'),
                       ('pad', '<i4', (3,))])
 
 
+# Workgroups per program launch (None: the library's default, 128).  engine.TrainStep sets 64 when it co-schedules the three forward
+# programs of a step on three streams: a program's workgroups must all be resident to pass its grid barriers (one 1024-thread
+# workgroup with 135 KB of LDS per CU), so three concurrent programs must fit the chip together -- 3 x 64 of 256 CUs, with room for
+# RCCL's kernels -- or two of them could hold each other's CUs (bounded by the barrier timeout, but a lost step).  The step time does
+# not depend on the grid between 48 and 128 (tools/ab_graph_grid.sh: the operators have <= 48 tiles; the barrier is the cost).
+GRID = [None]
+
+
 def enabled():
     return os.environ.get('AG2V_NO_GRAPH_PROGRAM') is None
 
@@ -227,7 +235,7 @@ class Program(object):
         return self
 
     def run(self):
-        grid = int(os.environ.get('AG2V_GRAPH_GRID', 0)) or _lib.query('ag2v_graph_program_grid')
+        grid = int(os.environ.get('AG2V_GRAPH_GRID', 0)) or GRID[0] or _lib.query('ag2v_graph_program_grid')
         _lib.call('ag2v_graph_program_run', ctypes.c_void_p(self.ops_dev.data_ptr()), self.n_ops, ctypes.c_void_p(self.sync.data_ptr()),
                   grid, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         _watch_flag(self)

@@ -25,23 +25,28 @@ class AG2VideoModel(nn.Module):
             self.acts_to_objs = DataParallelWithCallback(models[objs_model](opt), device_ids=ids).to(device)
         self.layout_to_video = DataParallelWithCallback(Layout2VidGenerator(opt), device_ids=ids).to(device)
         # engine.TrainStep sets a second HIP stream here: work whose result the rest of the forward pass does not read runs on it
-        self.side_stream = None
+        self.side_stream = self.side_stream_b = None
 
     def forward(self, imgs, objs, triplets, actions, boxes_gt=None, test_mode=False, use_gt=False, graph_only=False):
         """-> (imgs_pred, boxes_pred, flows_pred, conf_pred, actions_data), or boxes_pred when graph_only."""
         side = self.side_stream
         if side is not None and not graph_only and use_gt and not self.args.get("coupled_motion_apperance") and imgs.is_cuda:
             # Teacher forcing: the generator reads ground-truth boxes and the appearance net's vectors, so the box net's 15-step
-            # recurrence (~700 launches of 5-20 us on a handful of CUs) is only an OUTPUT of this call.  It runs beside the
-            # appearance net and the generator on the side stream; the caller's stream joins before this function returns.
-            # Issue order: the appearance net and the generator first, the box net after them -- the graph nets are issue-bound
-            # (~1 000 launches of 3-8 us), so their launches should reach the GPU while it has the generator's queue to work on.
-            # The side stream only waits for an event recorded at entry (the inputs), not for the generator.
+            # recurrence (one persistent program, ~2.6 ms on <= 64 CUs) is only an OUTPUT of this call: it runs on its own stream beside
+            # the appearance net's program; the caller's stream joins before this function returns.
             main = torch.cuda.current_stream()
             entry = main.record_event()
+            # Round 6: the box net's program is launched FIRST, on its own stream, so that it runs beside the appearance net's (and the
+            # discriminator's layout-term program, engine.gd_step) instead of behind the generator's forward, where it would wait for the
+            # CUs the persistent convolutions hold.  Both side streams only wait for an event recorded at entry (the inputs).
+            side_b = getattr(self, 'side_stream_b', None) or side
+            side_b.wait_event(entry)
+            with torch.cuda.stream(side_b):
+                _, boxes_pred, _ = self.acts_to_boxes(objs, triplets, actions, boxes_gt, test_mode=test_mode)
+                boxes_pred.record_stream(main)
             # The appearance net's FORWARD is on the critical path (the generator's first convolutions read its vectors), but it is
             # issued on the side stream as well: autograd runs a node's backward on the stream of its forward, so the net's 15-step
-            # BACKWARD recurrence -- the tail of the generator's backward pass, ~10 ms of 5 us kernels -- runs there, under the
+            # BACKWARD recurrence -- the tail of the generator's backward pass -- runs there, under the
             # discriminator phase that engine.gd_step queues next on the main stream (Adam(G) is applied after that phase).
             side.wait_event(entry)
             with torch.cuda.stream(side):
@@ -51,10 +56,7 @@ class AG2VideoModel(nn.Module):
             for t_ in [obj_vecs] + [a for a in actions_data if torch.is_tensor(a)]:
                 t_.record_stream(main)
             imgs_pred, flows_pred, conf_pred = self.layout_to_video(imgs, objs, obj_vecs, boxes_gt, test_mode=test_mode)
-            with torch.cuda.stream(side):
-                _, boxes_pred, _ = self.acts_to_boxes(objs, triplets, actions, boxes_gt, test_mode=test_mode)
-                boxes_pred.record_stream(main)
-            main.wait_stream(side)
+            main.wait_stream(side_b)
             return imgs_pred, boxes_pred, flows_pred, conf_pred, actions_data
         obj_vecs, boxes_pred, actions_data = self.acts_to_boxes(objs, triplets, actions, boxes_gt, test_mode=test_mode)
         if graph_only:

@@ -195,11 +195,14 @@ def _step_vs_oracle(case, prec, device):
         worst = {name: got[('o32', name)][0] for name in ('imgs_pred', 'boxes_pred', 'flows_pred')}
         # gradients: abs-sum of every parameter's gradient, against both oracles (bounds: header above and tests/test_step_gpu.py;
         # correctness of the gradients themselves is pinned by tests/test_gradcheck_gpu.py (central differences) and the kernel tests)
+        # (c1bp: the image gradient of flow_warp is a scatter-add even in deterministic mode, and the feedback amplifies: the rounding noise
+        # of an analytically-zero bias gradient measures 2.0e-6 per element there)
+        pe = 5e-6 if case.endswith('bp') else 2e-6
         for tag in ('o64', 'o32'):
             ref = refs[tag]
             bad, worst_g = _grad_report(ts.model.named_parameters(), ref['G_grads'],
                                         lambda n: ('front', _grad_bound(case, 'front', 5e-2)) if C.is_front(n) else ('decoder', _grad_bound(case, 'decoder', 2e-2)),
-                                        allow_missing='acts_to_boxes')
+                                        allow_missing='acts_to_boxes', per_elem=pe)
             badd, worst_d = _grad_report(ts.discriminator.img_discriminator.named_parameters(), ref['D_grads'], lambda n: ('D', _grad_bound(case, 'D', 2e-2)))
             worst_g.update(worst_d)
             if dtmp is not None:
