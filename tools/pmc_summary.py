@@ -37,6 +37,8 @@ MATCH = [('mlp_shared_fwd', 'mlp_shared_fwd', 'conv_igemm_bf16x3_ws_kernel<128, 
          ('gamma_beta_dgrad_ps', 'gamma_beta_dgrad_ps', 'conv_halo16_bf16x3_kernel<1, 8, 4, 128, 2, true>'),
          ('gamma_beta_fwd_ps', 'gamma_beta_fwd_ps', 'conv_halo16_bf16x3_kernel<1, 8, 4, 128, 2, true>'),
          ('mlp_shared_dgrad_merged_ps', 'mlp_shared_dgrad_merged_ps', 'conv_halo16_bf16x3_kernel<1, 8, 4, 128, 2, true>'),
+         # round 6: a block's three mlp_shared convolutions as one forward launch (ag2v_conv_opts::out_mstride)
+         ('mlp_shared_fwd_merged3_ps', 'mlp_shared_fwd_merged3_ps', 'conv_halo16_bf16x3_kernel<1, 8, 4, 128, 2, true>'),
          ('layout_conv', 'layout_conv_fwd', 'layout_conv_fwd3_kernel<16>'),
          ('flow_res_h16', 'flow_res_h16', 'conv_halo16_f16x3_kernel<1, 8, 4, 32, 8>'),
          ('flow_res_h16', 'flow_res_h16', 'conv_igemm_f16x3_ws_kernel<256, 128'),

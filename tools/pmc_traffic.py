@@ -50,6 +50,20 @@ def conv_case(tag, N, C, H, K, what, split=False, precision=None):
                    'algorithmic_bytes': alg, 'pass': what}
 
 
+def shared_fwd_case(tag, N, C, H, nb):
+    """Round 6: the nb mlp_shared convolutions of a SPADE block (128 output channels each, one input) as ONE forward launch
+    (ops.conv2d_shared_input, ag2v_conv_opts::out_mstride): the gathered map is staged once for all of them."""
+    x = split_words(torch.randn(N, C, H, H, device=dev))
+    ws = [torch.randn(128, C, 3, 3, device=dev) * 0.01 for _ in range(nb)]
+    bs = [torch.zeros(128, device=dev) for _ in range(nb)]
+    with ops.bf16x3_min_rows(48), torch.no_grad():
+        for _ in range(REPS):
+            ops.conv2d_shared_input(x, ws, bs, stride=1, pad=1, relu=True, grad_premasked=True, out_split=[True] * nb)
+    torch.cuda.synchronize()
+    expect[tag] = {'shape': 'fwd of %dx%dx%dx%d -> %d x 128 channels in one launch, 3x3, split-word operands' % (N, C, H, H, nb),
+                   'algorithmic_bytes': N * C * H * H * 4 + nb * N * 128 * H * H * 4 + nb * 128 * C * 9 * 4, 'pass': 'fwd'}
+
+
 # SPADE mlp_shared at full resolution: forward (128 x 256 tile, quad loads), merged data gradient of a block's three mlp_shared
 # convolutions (256 x 128 tile) and their merged weight gradient (128-row v kernel); sample counts = the chunks ag2v_conv2d_*_ex cuts
 CASES = {
@@ -67,6 +81,7 @@ CASES = {
     'gamma_beta_wgrad_ps': lambda: conv_case('gamma_beta_wgrad_ps', 60, 128, 256, 256, 'wgrad', True),
     'gamma_beta_dgrad_ps': lambda: conv_case('gamma_beta_dgrad_ps', 60, 128, 256, 256, 'dgrad', True),
     'gamma_beta_fwd_ps': lambda: conv_case('gamma_beta_fwd_ps', 60, 128, 256, 256, 'fwd', True),
+    'mlp_shared_fwd_merged3_ps': lambda: shared_fwd_case('mlp_shared_fwd_merged3_ps', 31, 512, 256, 3),
 }
 
 
