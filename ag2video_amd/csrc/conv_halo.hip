@@ -839,14 +839,11 @@ static bool halo_geometry(int BN, int OH, int OW, int& TW, int& TH) {
 // not thread-safe, and the autograd thread launches kernels while the main thread may be editing os.environ -- ADVICE r04) and again
 // only when ag2v_halo_reload_env() is called (tests and tools/halo_bench.py call it after changing the variables, with no launch in
 // flight).  None of them changes results beyond the summation order of the kernel family selected.
-struct HaloSwitches { int no_halo, tall, mfma32, no_h16, no_f32in, min_tiles, no_wgrad_halo; };
+struct HaloSwitches { int no_halo, mfma32, min_tiles, no_wgrad_halo; };
 static HaloSwitches read_halo_switches() {
     HaloSwitches h;
     h.no_halo = getenv("AG2V_NO_HALO") != nullptr;
-    h.tall = false;
     h.mfma32 = getenv("AG2V_HALO_MFMA32") != nullptr;
-    h.no_h16 = false;
-    h.no_f32in = false;
     h.no_wgrad_halo = getenv("AG2V_NO_WGRAD_HALO") != nullptr;      // (conv_wgrad_halo.hip: weight gradients on the previous kernels)
     const char* mt = getenv("AG2V_HALO_MIN_TILES");                 // (tests run small shapes through these kernels)
     h.min_tiles = mt ? atoi(mt) : 384;                              // small maps: the split-K kernels fill the chip better
@@ -860,28 +857,21 @@ extern "C" int ag2v_halo_reload_env(void) {
 extern "C" int ag2v_halo_min_tiles(void) { return g_halo_sw.min_tiles; }
 bool wgrad_halo_switched_off() { return g_halo_sw.no_wgrad_halo != 0; }
 
-// 256-row tile (128 pixels) when there are enough rows and it pads no more rows than the 128-row tile (256 pixels) does
-static bool halo_tall(int M) {
-    // 128-row tiles (256 pixels as 2 x 128: 2x row halo, 8 KB of weights per k-step) beat the 256-row tile (128 x 1 pixels: 3x row halo)
-    // on every shape measured (+1.9 % at C = 384, +4.5 % at C = 128): the 256-row form is kept for A/B runs (AG2V_HALO_TALL)
-    if (!g_halo_sw.tall) return false;
-    return M >= 192 && ceil_div(M, 256) * 256 <= ceil_div(M, 128) * 128;
-}
+// (A 256-row tile -- 128 x 1 / 64 x 2 / 32 x 4 pixels, 3x row halo -- was built and measured in round 4: the 128-row tile with 256 pixels as
+// 2 x 128 (2x row halo, 8 KB of weights per k-step) beat it on every shape, +1.9 % at C = 384, +4.5 % at C = 128; removed in round 6.)
 
 // Can this launch (as the callers of launch_igemm_bf16x3 describe it) run on the halo kernels?
 bool igemm_halo_ok(const ConvArgs& a) {
     if (g_halo_sw.no_halo || !a.tap_major || a.f32 || a.b_bytes == 0) return false;
-    // fp16 split: fp32 gathered tensor, plain output, the 16x16x32 form only (AG2V_NO_HALO_H16: A/B aid)
+    // fp16 split: fp32 gathered tensor, plain output, the 16x16x32 form only
     // (not in deterministic mode: there the flow network keeps ONE kernel family for every batch size, so that the frame-batched and
     // the sequential passes agree to the last bit in their flows -- tests/test_fullsize_gpu.py::test_full_size_deterministic_mode)
-    if (a.h16 && (a.b_split || a.out_split || a.det || g_halo_sw.mfma32 || g_halo_sw.no_h16)) return false;
-    if (!a.b_split && g_halo_sw.no_f32in) return false;       // (A/B aid: fp32 gathered tensors on the previous kernels)
+    if (a.h16 && (a.b_split || a.out_split || a.det || g_halo_sw.mfma32)) return false;
     if (a.R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1 || a.pad_w != 1 || a.OH != a.H || a.OW != a.W) return false;
     if (a.C % 32 || a.W % 4 || (a.o_mul != 1 && a.o_mul != 0) || a.o_add_y || a.o_add_x) return false;
     if ((a.o_H && a.o_H != a.OH) || (a.o_W && a.o_W != a.OW)) return false;
     if (a.residual == a.out && a.residual) return false;          // accumulating launches stay on the split-K capable kernels
-    const bool tall = halo_tall(a.M);
-    const int bn = tall ? 128 : 256, bm = tall ? 256 : (a.M <= 64 ? 64 : 128);
+    const int bn = 256, bm = a.M <= 64 ? 64 : 128;
     if (a.out_mstride && (bm != 128 || a.M % 128 || a.residual || a.mask)) return false;      // per-row-tile outputs: whole 128-row tiles
     int tw, th;
     if (!halo_geometry(bn, a.OH, a.OW, tw, th)) return false;
@@ -891,8 +881,7 @@ bool igemm_halo_ok(const ConvArgs& a) {
 
 int launch_igemm_halo(ConvArgs& a, hipStream_t st) {
     if (a.out_nstride == 0) a.out_nstride = (long long)a.M * a.OH * a.OW;       // (direct callers: the dense output)
-    const bool tall = halo_tall(a.M);
-    const int bn = tall ? 128 : 256, bm = tall ? 256 : (a.M <= 64 ? 64 : 128);
+    const int bn = 256, bm = a.M <= 64 ? 64 : 128;
     int tw, th;
     if (!halo_geometry(bn, a.OH, a.OW, tw, th)) return AG2V_EINVAL;
     a.tiles_m = ceil_div(a.M, bm);
@@ -929,11 +918,7 @@ int launch_igemm_halo(ConvArgs& a, hipStream_t st) {
             hipLaunchKernelGGL((conv_halo_bf16x3_kernel<WM_, WN_, EM_, TW_, TH_, false>), grid, dim3(512), 0, st, a);              \
         }                                                                                                                        \
     } while (0)
-    if (tall) {
-        if (tw == 128) AG2V_HALO(2, 4, 4, 128, 1);
-        else if (tw == 64) AG2V_HALO(2, 4, 4, 64, 2);
-        else AG2V_HALO(2, 4, 4, 32, 4);
-    } else if (bm == 128) {
+    if (bm == 128) {
         if (tw == 128) AG2V_HALO(1, 8, 4, 128, 2);
         else if (tw == 64) AG2V_HALO(1, 8, 4, 64, 4);
         else AG2V_HALO(1, 8, 4, 32, 8);
