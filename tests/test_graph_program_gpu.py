@@ -356,3 +356,55 @@ def test_program_finishes_when_another_stream_holds_cus(held, ms, device):
         y = torch.relu(y @ w.t())
     assert (P.tensor(bufs[5]) - y).abs().max().item() <= 1e-5 * y.abs().max().item()
     print('program beside %d held CUs (%.0f ms): %.1f ms' % (held, ms, t0.elapsed_time(t1)))     # (which kernel's workgroups land first is the dispatcher's choice)
+
+
+def test_step_with_coscheduled_programs_equals_single_stream_step(device):
+    """Round 6: by default (outside deterministic mode) TrainStep launches the three forward graph-net programs of a step -- appearance
+    net, box net, the discriminator's layout terms -- together on three streams with 64 workgroups each, and the appearance net's backward
+    program runs on its side stream (engine.TrainStep, AG2VideoModel.forward; reference meta_models.py:29-57 evaluates the same nets one
+    after the other).  Against AG2V_NO_SIDE_STREAM=1 (everything on one stream, 128 workgroups): losses, outputs and both flat gradient
+    buffers agree to the noise of the split-K atomics, several steps in a row (stream joins, plan reuse), no barrier timeout."""
+    from ag2video_amd import graph_program as gp
+    from ag2video_amd.data.args import make_opt
+    from ag2video_amd.data.synthetic import make_clip_batch
+    from ag2video_amd.data.vocab import cater_vocab
+    from ag2video_amd.engine import TrainStep
+    flags = ['--no_vgg_loss', '--image_size', '64,64', '--batch_size', '2', '--ngf', '16', '--ndf', '16', '--nff', '16',
+             '--gconv_hidden_dim', '64', '--gpu_ids', '0']
+    res = {}
+    old_env, old_grid = os.environ.get('AG2V_NO_SIDE_STREAM'), gp.GRID[0]
+    try:
+        for mode in ('side', 'single'):
+            if mode == 'single':
+                os.environ['AG2V_NO_SIDE_STREAM'] = '1'
+            else:
+                os.environ.pop('AG2V_NO_SIDE_STREAM', None)
+            gp.GRID[0] = None
+            opt = make_opt(cater_vocab(), flags)
+            ts = TrainStep(opt, device, weights_seed=5)
+            assert (ts.side_stream is not None) == (mode == 'side')
+            assert gp.GRID[0] == (64 if mode == 'side' else None)
+            steps = []
+            for it in range(3):
+                clip = ts.to_device(make_clip_batch(opt.vocab, 2, 4, (64, 64), seed=11 + it))
+                out, GL, DL = ts.gd_step(clip)
+                ts.check_health()
+                steps.append(({k: float(v) for k, v in list(GL.items()) + list(DL.items())}, out[0].detach().clone(), out[1].detach().clone(),
+                              ts.optimizer_generator.flat_grad.clone(), ts.discriminator.optimizer_d_img.flat_grad.clone()))
+            torch.cuda.synchronize()
+            res[mode] = steps
+    finally:
+        gp.GRID[0] = old_grid
+        if old_env is None:
+            os.environ.pop('AG2V_NO_SIDE_STREAM', None)
+        else:
+            os.environ['AG2V_NO_SIDE_STREAM'] = old_env
+    for it, (a, b) in enumerate(zip(res['side'], res['single'])):
+        tol = 1e-4 if it == 0 else 2e-2            # (later iterations: Adam's sign-like first steps amplify atomics-order noise, CHAOS note)
+        for k in b[0]:
+            assert abs(a[0][k] - b[0][k]) <= tol * max(1.0, abs(b[0][k])), (it, k, a[0][k], b[0][k])
+        if it == 0:
+            assert float((a[1] - b[1]).abs().max()) <= 1e-4 * float(b[1].abs().max())          # imgs_pred
+            assert float((a[2] - b[2]).abs().max()) <= 1e-5 * max(1.0, float(b[2].abs().max()))          # boxes_pred (box net on its own stream)
+            for i in (3, 4):
+                assert float((a[i] - b[i]).norm() / b[i].norm()) <= 1e-3, (i, float((a[i] - b[i]).norm() / b[i].norm()))
