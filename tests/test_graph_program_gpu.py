@@ -374,8 +374,8 @@ def test_step_with_coscheduled_programs_equals_single_stream_step(device):
     res = {}
     old_env, old_grid = os.environ.get('AG2V_NO_SIDE_STREAM'), gp.GRID[0]
     try:
-        for mode in ('side', 'single'):
-            if mode == 'single':
+        for mode in ('side', 'single', 'single2'):          # (single2: the single-stream step once more -- the run-to-run floor)
+            if mode != 'side':
                 os.environ['AG2V_NO_SIDE_STREAM'] = '1'
             else:
                 os.environ.pop('AG2V_NO_SIDE_STREAM', None)
@@ -399,12 +399,18 @@ def test_step_with_coscheduled_programs_equals_single_stream_step(device):
             os.environ.pop('AG2V_NO_SIDE_STREAM', None)
         else:
             os.environ['AG2V_NO_SIDE_STREAM'] = old_env
-    for it, (a, b) in enumerate(zip(res['side'], res['single'])):
+    for it, (a, b, b2) in enumerate(zip(res['side'], res['single'], res['single2'])):
         tol = 1e-4 if it == 0 else 2e-2            # (later iterations: Adam's sign-like first steps amplify atomics-order noise, CHAOS note)
         for k in b[0]:
             assert abs(a[0][k] - b[0][k]) <= tol * max(1.0, abs(b[0][k])), (it, k, a[0][k], b[0][k])
         if it == 0:
-            assert float((a[1] - b[1]).abs().max()) <= 1e-4 * float(b[1].abs().max())          # imgs_pred
+            # two runs of the SAME default path differ through the order of the split-K atomics (imgs_pred a few 1e-4 of max, the
+            # generator's gradient 1-2e-3 in relative L2): the bound is that floor, measured here, times 3
+            rel = lambda x, y: float((x - y).norm() / y.norm())
+            f_img = float((b2[1] - b[1]).abs().max() / b[1].abs().max())
+            assert float((a[1] - b[1]).abs().max()) <= max(1e-3, 3 * f_img) * float(b[1].abs().max())
             assert float((a[2] - b[2]).abs().max()) <= 1e-5 * max(1.0, float(b[2].abs().max()))          # boxes_pred (box net on its own stream)
             for i in (3, 4):
-                assert float((a[i] - b[i]).norm() / b[i].norm()) <= 1e-3, (i, float((a[i] - b[i]).norm() / b[i].norm()))
+                floor = rel(b2[i], b[i])
+                print('flat gradient %d: side streams vs single stream %.2e, single stream twice %.2e' % (i, rel(a[i], b[i]), floor))
+                assert rel(a[i], b[i]) <= max(1e-3, 3 * floor), (i, rel(a[i], b[i]), floor)
