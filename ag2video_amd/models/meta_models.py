@@ -52,6 +52,9 @@ class AG2VideoModel(nn.Module):
             with torch.cuda.stream(side):
                 obj_vecs, _, actions_data = self.acts_to_objs(objs, triplets, actions, boxes_gt, test_mode=test_mode)
                 ready = side.record_event()
+            # weights-only work of the generator (spectral norm's power iterations) goes to the main stream BEFORE it waits for the
+            # appearance net: it runs beside the three graph-net programs instead of behind them
+            self.layout_to_video.module.prefetch_spectral_scales(boxes_gt.size(1), test_mode=test_mode)
             main.wait_event(ready)
             for t_ in [obj_vecs] + [a for a in actions_data if torch.is_tensor(a)]:
                 t_.record_stream(main)

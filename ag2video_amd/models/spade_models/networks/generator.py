@@ -54,7 +54,7 @@ class Layout2VidGenerator(nn.Module):
         nc = self.n_frames_G - 1
         # Teacher forcing (training: every frame pass reads GROUND-TRUTH previous frames, generator.py:71): the F - nc passes do
         # not depend on each other and run as one frame-major batch.  test_mode / bp_prev feed generated frames back: sequential.
-        batched = (low_rank and not test_mode and not opt.bp_prev and Fr - nc > 1 and getattr(opt, 'batch_frames', True))
+        batched = self._takes_batched_path(Fr, test_mode)
         if batched:
             gen, flows, confs = self._frames_batched(imgs_gt, vecs, layout, keep, nc)
         else:
@@ -66,6 +66,31 @@ class Layout2VidGenerator(nn.Module):
         flow_prev = torch.stack([zf] * (nc - 1) + flows + [zf], dim=1)
         conf_prev = torch.stack([zc] * (nc - 1) + confs + [zc], dim=1)
         return imgs, flow_prev, conf_prev
+
+    def _takes_batched_path(self, Fr, test_mode):
+        opt = self.opt
+        return bool(getattr(opt, 'low_rank_layout', True) and not test_mode and not opt.bp_prev and Fr - (self.n_frames_G - 1) > 1
+                    and getattr(opt, 'batch_frames', True))
+
+    def _run_sn_bank(self, T):
+        """The T power iterations of ALL spectral-norm layers, three launches per iteration (every layer is called exactly once per frame
+        pass in the reference, so each consumes its T scales in the frame-batched pass)."""
+        if getattr(self, '_sn_bank', None) is None:
+            from .normalization import SpectralConv2d
+            self._sn_bank = ops.SpectralBank([m for m in self.modules() if isinstance(m, SpectralConv2d)])
+        for m, sc in zip(self._sn_bank.layers, self._sn_bank.scales(T)):
+            m._bank_scales = sc
+
+    def prefetch_spectral_scales(self, Fr, test_mode=False):
+        """Round 6: the power iterations depend on the weights only (~8 ms of memory-bound kernels per c3 step).  AG2VideoModel.forward
+        calls this BEFORE it waits for the appearance net's program, so they run beside the graph-net programs instead of behind them;
+        the frame-batched pass of the SAME forward call then finds them done.  No-op whenever that pass would not run them itself (the
+        iterations advance weight_u / weight_v: they must happen exactly once per step)."""
+        self._sn_ready_T = None
+        if self.training and torch.is_grad_enabled() and self._takes_batched_path(Fr, test_mode):
+            T = Fr - (self.n_frames_G - 1)
+            self._run_sn_bank(T)
+            self._sn_ready_T = T
 
     def _frames_batched(self, imgs_gt, vecs, layout, keep, nc):
         """All T = F - nc teacher-forced frame passes as ONE pass over the frame-major batch [T*B, ...] (sample t*B + b = pass
@@ -86,13 +111,10 @@ class Layout2VidGenerator(nn.Module):
         prev = [fm(imgs_gt, f) for f in range(nc)]               # ground-truth frames t-nc .. t-1
         conv, bn = self.conv_dim_in[0][0], self.conv_dim_in[0][1]
         if self.training:
-            # the T power iterations of ALL spectral-norm layers up front, three launches per iteration (every layer below is called
-            # exactly once per frame pass in the reference, so each consumes its T scales in this pass)
-            if getattr(self, '_sn_bank', None) is None:
-                from .normalization import SpectralConv2d
-                self._sn_bank = ops.SpectralBank([m for m in self.modules() if isinstance(m, SpectralConv2d)])
-            for m, sc in zip(self._sn_bank.layers, self._sn_bank.scales(T)):
-                m._bank_scales = sc
+            # the T power iterations of ALL spectral-norm layers up front -- unless this call's prefetch has run them already
+            ready, self._sn_ready_T = getattr(self, '_sn_ready_T', None), None
+            if ready != T:
+                self._run_sn_bank(T)
         with ops.frame_groups(T):
             spec = (vecs_list, boxes_list, keep_t, H)
             with _flow_precision():                               # forward on the fp16 split, backward on the bf16 one: see _frames_sequential
