@@ -110,10 +110,14 @@ class TrainStep(object):
         iteration.  The decision is COLLECTIVE (distributed.any_rank): every rank skips or none does, so the gradient
         all-reduces below always pair up across ranks.  Returns (model_out, G_losses, D_losses); D_losses is None when skipped."""
         imgs, objs, boxes, triplets, actions, video_id = batch
-        if self.side_stream is not None:
+        # (a trainer built outside deterministic mode and stepped inside it keeps this step on one stream: two streams accumulating
+        # gradients interleave in a varying order)
+        side_on = self.side_stream is not None and not ops.is_deterministic()
+        self.model.side_stream = self.side_stream if side_on else None
+        if side_on:
             adata = self.model.acts_to_boxes.module.actions_data(triplets, actions)      # (inputs only; a few small launches)
             step_start = torch.cuda.current_stream().record_event()
-        if self.side_stream is not None:
+        if side_on:
             # the discriminator's layout terms (its graph-net program first) on their own stream, launched BEFORE the generator's forward
             # is queued: the program then runs beside the appearance net's and the box net's (AG2VideoModel.forward), ordered only
             # behind the start of this step
@@ -134,7 +138,7 @@ class TrainStep(object):
         self.optimizer_generator.zero_grad()
         # single process with a side stream: the appearance net's backward (side stream) keeps running under the discriminator phase;
         # this stream joins it before Adam(G) below.  With collectives the all-reduce launched next must see complete gradients.
-        overlap_tail = self.side_stream is not None and not dist_utils.is_dist()
+        overlap_tail = side_on and not dist_utils.is_dist()
         with ops.accumulate_into_param_grads(join_streams=not overlap_tail):
             G_losses["total_loss"].backward()
         # One process per GPU: the generator's 500 MB gradient all-reduce is launched here and joined after the discriminator's
@@ -151,7 +155,7 @@ class TrainStep(object):
         self.discriminator.optimizer_d_img.zero_grad()
         with ops.accumulate_into_param_grads():
             D_losses["total_img_loss"].backward()
-        if self.side_stream is not None:      # the layout terms' backward ran there; their gradients are written by the ops themselves
+        if side_on:      # the layout terms' backward ran there; their gradients are written by the ops themselves
             torch.cuda.current_stream().wait_stream(self.side_stream)
             torch.cuda.current_stream().wait_stream(self.side_stream_d)
         ops.join_direct_grad_streams()
