@@ -14,6 +14,9 @@ import torch
 # c1bp: c1 TRAINED with --bp_prev 1 (reference generator.py:68-71: the generated previous frame is fed back, so the loss of frame t
 # back-propagates through frames t-1, t-2: the sequential generator path under autograd).
 STEP_CASES = {'c1': (64, 4, 1), 'c2p': (128, 3, 1), 'c3p': (256, 4, 1), 'c5p': (224, 3, 1), 'c5pT': (224, 5, 1), 'c1bp': (64, 4, 1)}
+# FULL-size cases whose oracle runs are committed as fixtures (tests/golden/make_oracle_c2.py -> oracle_c2.npz) instead of running
+# inside a test: c2 = BASELINE.json's configs[1], CATER 128 x 128, 8 frames, batch 4.
+FULL_CASES = {'c2': (128, 8, 4)}
 WEIGHTS_SEED, CLIP_SEED, GRAPH_CLIP_SEED = 1, 1234, 4321
 
 
@@ -24,7 +27,7 @@ def stats(t):
 
 def case_opt(case):
     import bench
-    side, frames, batch = STEP_CASES[case]
+    side, frames, batch = (STEP_CASES.get(case) or FULL_CASES[case])
     if case.startswith('c5'):
         from ag2video_amd.data.args import make_opt
         from ag2video_amd.data.vocab import smth_vocab

@@ -552,3 +552,97 @@ def test_step_c5prime_temporal_discriminator_matches_oracle(device):
     reference's MultiscaleDiscriminatorT, discriminator.py:16-59): the temporal loss keys, and the temporal discriminator's gradients
     beside everything the c5' step checks."""
     _step_vs_oracle('c5pT', 'bf16x3', device)
+
+
+@pytest.mark.parametrize("prec", ['bf16x3', 'fp32'])
+def test_step_c2_full_size_matches_oracle_fixture(prec, device):
+    """BASELINE.json's configs[1] at FULL size (CATER 128 x 128, 8 frames, batch 4, default widths): one whole iteration (G step, D step,
+    graph step) on the GPU in deterministic mode against the CPU oracle's fp32 and fp64 runs of the same clip and weights, committed as
+    tests/golden/oracle_c2.npz by tests/golden/make_oracle_c2.py (the oracle needs ~10 minutes for this step: too long to run inside a
+    test, which is the only reason the c2 / c3 tests before round 6 were property checks).  Compared: every loss (1e-3 against both
+    oracles), imgs_pred / flows_pred on the fixture's stride-4 pixel grid and boxes_pred in full, the abs-sum of every parameter's
+    gradient, (abs-sum, L2) of every post-step state tensor.  Gates as in _step_vs_oracle, the floors being o32 against o64 on the very
+    same statistic."""
+    from ag2video_amd import ops
+    from ag2video_amd.engine import TrainStep
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'oracle_c2.npz')
+    gold = np.load(path, allow_pickle=False)
+    meta = json.loads(str(gold['meta']))
+    case, st = meta['case'], int(meta['pixel_stride'])
+    assert (meta['weights_seed'], meta['clip_seed'], meta['graph_clip_seed']) == (C.WEIGHTS_SEED, C.CLIP_SEED, C.GRAPH_CLIP_SEED)
+    old = ops.get_conv_precision()
+    ops.set_conv_precision(prec)
+    try:
+        opt, side, frames, batch = C.case_opt(case)
+        assert [side, frames, batch] == meta['side_frames_batch'] == [128, 8, 4]
+        with ops.deterministic():
+            ts = TrainStep(opt, device, weights_seed=C.WEIGHTS_SEED)
+            clip = C.case_clip(case, opt, batch, frames, side, C.CLIP_SEED)
+            mo, GL, DL = ts.gd_step(ts.to_device(clip))
+        rep = {}
+        for tag in ('o64', 'o32'):
+            for grp, got in (('GL', GL), ('DL', DL)):
+                keys = [k[len(tag) + len(grp) + 2:] for k in gold.files if k.startswith('%s.%s.' % (tag, grp))]
+                assert set(keys) == set(got)
+                for k in keys:
+                    rf = float(gold['%s.%s.%s' % (tag, grp, k)])
+                    assert abs(got[k].item() - rf) <= 1e-3 * max(1.0, abs(rf)), (tag, grp, k, got[k].item(), rf)
+
+        def errs(a, b, scale=None):
+            d = a.astype(np.float64) - b
+            return float(np.abs(d).max() / (scale or np.abs(b).max())), float(np.linalg.norm(d) / np.linalg.norm(b))
+        imgs = mo[0].detach().double().cpu().numpy()[..., ::st, ::st]
+        flows = mo[2].detach().double().cpu().numpy()[..., ::st, ::st]
+        amax = float(gold['o64.imgs_absmax'])
+        f_img = errs(gold['o32.imgs_sub'], gold['o64.imgs_sub'], amax)          # the reference arithmetic's own distance from exact
+        f_flow = errs(gold['o32.flows_sub'], gold['o64.flows_sub'])
+        for tag, kmax in (('o64', 2.0), ('o32', 3.0)):
+            e_img, e_flow = errs(imgs, gold[tag + '.imgs_sub'], amax), errs(flows, gold[tag + '.flows_sub'])
+            e_box = errs(mo[1].detach().double().cpu().numpy(), gold[tag + '.boxes_pred'])
+            rep[tag] = dict(imgs=e_img, flows=e_flow, boxes=e_box)
+            assert e_img[1] <= (2.0 * f_img[1] if tag == 'o64' else 1e-3), (tag, 'imgs relative L2', e_img, f_img)
+            assert e_img[0] <= max(1e-3, kmax * f_img[0]), (tag, 'imgs max-norm', e_img, f_img)
+            assert e_flow[0] <= max(1e-3, 3.0 * f_flow[0]) and e_box[0] <= 1e-3, (tag, e_flow, e_box)
+            assert np.mean(mo[3].cpu().numpy()[..., ::st, ::st] != gold[tag + '.conf_sub']) < 2e-3
+        print('c2 full size [%s]: (max-norm / max, relative L2) against the oracle fixture %s; the fp32 oracle itself: imgs %s flows %s'
+              % (prec, rep, f_img, f_flow))
+        # gradient abs-sums: teacher-forced bounds, never tighter than 2.5 x the fp32 oracle's own deviation on that parameter's group
+        for gtag, params, groups in (('G_grads', ts.model.named_parameters(), None), ('D_grads', ts.discriminator.img_discriminator.named_parameters(), 'D')):
+            rows = []
+            for n, prm in params:
+                key = 'o64.%s.%s' % (gtag, n)
+                if key not in gold.files:
+                    assert prm.grad is None or float(prm.grad.abs().sum()) == 0.0 or n.startswith('acts_to_boxes'), n
+                    continue
+                exact, o32v = float(gold[key][1]), float(gold['o32.%s.%s' % (gtag, n)][1])
+                if exact <= 2e-6 * prm.numel():
+                    continue
+                grp = groups or ('front' if C.is_front(n) else 'decoder')
+                rows.append((n, grp, abs(C.stats(prm.grad)[1] - exact) / exact, abs(o32v - exact) / exact))
+            floor = {g: max(r[3] for r in rows if r[1] == g) for g in set(r[1] for r in rows)}
+            base = {'front': 5e-2, 'decoder': 2e-2, 'D': 2e-2}
+            bad = [r for r in rows if r[2] > max(base[r[1]], 2.5 * floor[r[1]])]
+            print('c2 full size [%s] %s: worst abs-sum deviation from o64 %s; the fp32 oracle itself %s'
+                  % (prec, gtag, {g: max((r[2], r[0]) for r in rows if r[1] == g) for g in floor}, floor))
+            assert len(rows) > (100 if gtag == 'G_grads' else 30) and not bad, (gtag, bad[:10])
+        # the graph step and every state tensor after the three optimizer steps
+        gclip = C.case_clip(case, opt, batch, 4 * frames, side, C.GRAPH_CLIP_SEED)
+        with ops.deterministic():
+            bp, GG = ts.graph_step(ts.to_device(gclip))
+        for k, v in GG.items():
+            rf = float(gold['o64.GG.' + k])
+            assert abs(v.item() - rf) <= 1e-3 * max(1.0, abs(rf)), (k, v.item(), rf)
+        assert errs(bp.detach().double().cpu().numpy(), gold['o64.graph_boxes'])[0] <= 1e-3
+        floor_lr = 1.2 * opt.learning_rate
+        bad_state, n_keys = [], 0
+        for t, sd in (('G', ts.model.state_dict()), ('D', ts.discriminator.img_discriminator.state_dict())):
+            for k, v in sd.items():
+                ref = gold['o64.state.%s.%s' % (t, k)]
+                n_keys += 1
+                got, n = C.stats(v.float()), float(ref[3])
+                for i, fl in ((1, floor_lr * n), (2, floor_lr * n ** 0.5)):
+                    if abs(got[i] - ref[i]) > 1e-3 * abs(ref[i]) + fl:
+                        bad_state.append((k, i, got[i], ref[i]))
+        assert n_keys == 492 + 56 and not bad_state, (n_keys, len(bad_state), bad_state[:10])
+    finally:
+        ops.set_conv_precision(old)
