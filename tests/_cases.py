@@ -16,7 +16,8 @@ import torch
 STEP_CASES = {'c1': (64, 4, 1), 'c2p': (128, 3, 1), 'c3p': (256, 4, 1), 'c5p': (224, 3, 1), 'c5pT': (224, 5, 1), 'c1bp': (64, 4, 1)}
 # FULL-size cases whose oracle runs are committed as fixtures (tests/golden/make_oracle_c2.py -> oracle_c2.npz) instead of running
 # inside a test: c2 = BASELINE.json's configs[1], CATER 128 x 128, 8 frames, batch 4.
-FULL_CASES = {'c2': (128, 8, 4)}
+# c3h: the benchmarked resolution with two samples per batch-norm statistic (256 x 256, 4 frames, batch 2).
+FULL_CASES = {'c2': (128, 8, 4), 'c3h': (256, 4, 2)}
 WEIGHTS_SEED, CLIP_SEED, GRAPH_CLIP_SEED = 1, 1234, 4321
 
 

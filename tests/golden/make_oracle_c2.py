@@ -5,7 +5,10 @@ the exact result of the same graph on the same fp32 weights and clip).  The orac
 beyond what a test may spend, so its results are committed as a fixture: tests/golden/oracle_c2.npz.  CPU only; nothing from
 /root/reference is read (the oracle is the checker the GPU tests use everywhere else, here run ahead of time).
 
-    python tests/golden/make_oracle_c2.py
+    python tests/golden/make_oracle_c2.py [c2 | c3h]          # -> tests/golden/oracle_<case>.npz
+
+c3h (round 6): the benchmarked resolution with MORE THAN ONE sample per batch-norm statistic -- 256 x 256, 4 frames, batch 2 (c3' is batch 1;
+the full c3 step would need ~150 GB and ~1.5 h on the CPU).
 
 Stored per oracle (o32 / o64): every loss of the G, D and graph steps; imgs_pred and flows_pred on a stride-4 pixel grid
 ([4, 8, C, 32, 32]: 1/16 of the pixels) and boxes_pred in full; (sum, abs-sum, L2) of every parameter's gradient; (sum, abs-sum, L2) of
@@ -28,10 +31,11 @@ import torch  # noqa: E402
 
 import _cases as C  # noqa: E402
 
-CASE, STRIDE = 'c2', 4
+STRIDE = 4
 
 
 def main():
+    CASE = sys.argv[1] if len(sys.argv) > 1 else 'c2'
     nthr = min(16, os.cpu_count() or 1)
     torch.set_num_threads(nthr)
     sG, sD, sT = C.cpu_key_shapes(CASE)
@@ -59,8 +63,9 @@ def main():
         for (t, k), (st, numel, buf) in r['state'].items():
             out['%s.state.%s.%s' % (tag, t, k)] = np.concatenate([st, [numel]])
         del r
-    np.savez_compressed(os.path.join(HERE, 'oracle_c2.npz'), **out)
-    print('wrote oracle_c2.npz: %d arrays, %.1f MB' % (len(out), os.path.getsize(os.path.join(HERE, 'oracle_c2.npz')) / 1e6))
+    path = os.path.join(HERE, 'oracle_%s.npz' % CASE)
+    np.savez_compressed(path, **out)
+    print('wrote %s: %d arrays, %.1f MB' % (path, len(out), os.path.getsize(path) / 1e6))
 
 
 if __name__ == '__main__':

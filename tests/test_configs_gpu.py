@@ -555,17 +555,19 @@ def test_step_c5prime_temporal_discriminator_matches_oracle(device):
 
 
 @pytest.mark.parametrize("prec", ['bf16x3', 'fp32'])
-def test_step_c2_full_size_matches_oracle_fixture(prec, device):
+@pytest.mark.parametrize("fixture", ['c2', 'c3h'])
+def test_step_c2_full_size_matches_oracle_fixture(fixture, prec, device):
     """BASELINE.json's configs[1] at FULL size (CATER 128 x 128, 8 frames, batch 4, default widths): one whole iteration (G step, D step,
     graph step) on the GPU in deterministic mode against the CPU oracle's fp32 and fp64 runs of the same clip and weights, committed as
     tests/golden/oracle_c2.npz by tests/golden/make_oracle_c2.py (the oracle needs ~10 minutes for this step: too long to run inside a
     test, which is the only reason the c2 / c3 tests before round 6 were property checks).  Compared: every loss (1e-3 against both
     oracles), imgs_pred / flows_pred on the fixture's stride-4 pixel grid and boxes_pred in full, the abs-sum of every parameter's
     gradient, (abs-sum, L2) of every post-step state tensor.  Gates as in _step_vs_oracle, the floors being o32 against o64 on the very
-    same statistic."""
+    same statistic.  Second fixture, c3h: the benchmarked resolution with two samples per batch-norm statistic (256 x 256, 4 frames,
+    batch 2; c3' is batch 1)."""
     from ag2video_amd import ops
     from ag2video_amd.engine import TrainStep
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'oracle_c2.npz')
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'oracle_%s.npz' % fixture)
     gold = np.load(path, allow_pickle=False)
     meta = json.loads(str(gold['meta']))
     case, st = meta['case'], int(meta['pixel_stride'])
@@ -574,7 +576,7 @@ def test_step_c2_full_size_matches_oracle_fixture(prec, device):
     ops.set_conv_precision(prec)
     try:
         opt, side, frames, batch = C.case_opt(case)
-        assert [side, frames, batch] == meta['side_frames_batch'] == [128, 8, 4]
+        assert [side, frames, batch] == meta['side_frames_batch'] == list(C.FULL_CASES[fixture]) and case == fixture
         with ops.deterministic():
             ts = TrainStep(opt, device, weights_seed=C.WEIGHTS_SEED)
             clip = C.case_clip(case, opt, batch, frames, side, C.CLIP_SEED)
@@ -604,8 +606,8 @@ def test_step_c2_full_size_matches_oracle_fixture(prec, device):
             assert e_img[0] <= max(1e-3, kmax * f_img[0]), (tag, 'imgs max-norm', e_img, f_img)
             assert e_flow[0] <= max(1e-3, 3.0 * f_flow[0]) and e_box[0] <= 1e-3, (tag, e_flow, e_box)
             assert np.mean(mo[3].cpu().numpy()[..., ::st, ::st] != gold[tag + '.conf_sub']) < 2e-3
-        print('c2 full size [%s]: (max-norm / max, relative L2) against the oracle fixture %s; the fp32 oracle itself: imgs %s flows %s'
-              % (prec, rep, f_img, f_flow))
+        print('%s full size [%s]: (max-norm / max, relative L2) against the oracle fixture %s; the fp32 oracle itself: imgs %s flows %s'
+              % (fixture, prec, rep, f_img, f_flow))
         # gradient abs-sums: teacher-forced bounds, never tighter than 2.5 x the fp32 oracle's own deviation on that parameter's group
         for gtag, params, groups in (('G_grads', ts.model.named_parameters(), None), ('D_grads', ts.discriminator.img_discriminator.named_parameters(), 'D')):
             rows = []
@@ -622,8 +624,8 @@ def test_step_c2_full_size_matches_oracle_fixture(prec, device):
             floor = {g: max(r[3] for r in rows if r[1] == g) for g in set(r[1] for r in rows)}
             base = {'front': 5e-2, 'decoder': 2e-2, 'D': 2e-2}
             bad = [r for r in rows if r[2] > max(base[r[1]], 2.5 * floor[r[1]])]
-            print('c2 full size [%s] %s: worst abs-sum deviation from o64 %s; the fp32 oracle itself %s'
-                  % (prec, gtag, {g: max((r[2], r[0]) for r in rows if r[1] == g) for g in floor}, floor))
+            print('%s full size [%s] %s: worst abs-sum deviation from o64 %s; the fp32 oracle itself %s'
+                  % (fixture, prec, gtag, {g: max((r[2], r[0]) for r in rows if r[1] == g) for g in floor}, floor))
             assert len(rows) > (100 if gtag == 'G_grads' else 30) and not bad, (gtag, bad[:10])
         # the graph step and every state tensor after the three optimizer steps
         gclip = C.case_clip(case, opt, batch, 4 * frames, side, C.GRAPH_CLIP_SEED)

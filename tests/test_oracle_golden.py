@@ -221,22 +221,24 @@ def test_oracle_matches_reference_bp_prev_training_step():
             _close_stats(key, _stats(g), gold[key], 2e-3, g.numel())
 
 
-def test_oracle_c2_full_size_fixture_is_consistent():
+@pytest.mark.parametrize("fixture", ['c2', 'c3h'])
+def test_oracle_c2_full_size_fixture_is_consistent(fixture):
     """tests/golden/oracle_c2.npz (tests/golden/make_oracle_c2.py: BASELINE.json's configs[1] at full size through the oracle, fp32 and
     fp64): complete -- every loss, the 492 + 56 state keys, gradient statistics of both nets, for both oracles -- and self-consistent:
     the fp32 oracle sits within fp32-level distance of the fp64 one (the floors the GPU test derives its gates from)."""
     import sys
     sys.path.insert(0, HERE)
     import _cases as C
-    gold = np.load(os.path.join(HERE, 'golden', 'oracle_c2.npz'), allow_pickle=False)
+    gold = np.load(os.path.join(HERE, 'golden', 'oracle_%s.npz' % fixture), allow_pickle=False)
     meta = json.loads(str(gold['meta']))
-    assert meta['side_frames_batch'] == list(C.FULL_CASES['c2']) == [128, 8, 4]
+    side, frames, batch = C.FULL_CASES[fixture]
+    assert meta['side_frames_batch'] == [side, frames, batch] and meta['case'] == fixture
     assert (meta['weights_seed'], meta['clip_seed'], meta['graph_clip_seed']) == (C.WEIGHTS_SEED, C.CLIP_SEED, C.GRAPH_CLIP_SEED)
     for tag in ('o32', 'o64'):
         assert sum(k.startswith(tag + '.state.G.') for k in gold.files) == 492 and sum(k.startswith(tag + '.state.D.') for k in gold.files) == 56
         assert sum(k.startswith(tag + '.G_grads.') for k in gold.files) > 250 and sum(k.startswith(tag + '.D_grads.') for k in gold.files) > 40
         assert {k.split('.', 2)[2] for k in gold.files if k.startswith(tag + '.GL.')} >= {'GAN_Img', 'GAN_Feat', 'loss_F_Warp', 'total_loss'}
-        assert gold[tag + '.imgs_sub'].shape == (4, 8, 3, 32, 32) and gold[tag + '.flows_sub'].shape == (4, 8, 2, 32, 32)
+        assert gold[tag + '.imgs_sub'].shape == (batch, frames, 3, side // 4, side // 4) and gold[tag + '.flows_sub'].shape == (batch, frames, 2, side // 4, side // 4)
     for k in gold.files:
         if k.startswith('o64.GL.') or k.startswith('o64.DL.') or k.startswith('o64.GG.'):
             a, b = float(gold['o32' + k[3:]]), float(gold[k])
