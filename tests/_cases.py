@@ -17,7 +17,8 @@ STEP_CASES = {'c1': (64, 4, 1), 'c2p': (128, 3, 1), 'c3p': (256, 4, 1), 'c5p': (
 # FULL-size cases whose oracle runs are committed as fixtures (tests/golden/make_oracle_c2.py -> oracle_c2.npz) instead of running
 # inside a test: c2 = BASELINE.json's configs[1], CATER 128 x 128, 8 frames, batch 4.
 # c3h: the benchmarked resolution with two samples per batch-norm statistic (256 x 256, 4 frames, batch 2).
-FULL_CASES = {'c2': (128, 8, 4), 'c3h': (256, 4, 2)}
+# c5h: c5's geometry (Something-Else vocabulary, 224 x 224) at batch 2, 4 frames.
+FULL_CASES = {'c2': (128, 8, 4), 'c3h': (256, 4, 2), 'c5h': (224, 4, 2)}
 WEIGHTS_SEED, CLIP_SEED, GRAPH_CLIP_SEED = 1, 1234, 4321
 
 

@@ -555,7 +555,7 @@ def test_step_c5prime_temporal_discriminator_matches_oracle(device):
 
 
 @pytest.mark.parametrize("prec", ['bf16x3', 'fp32'])
-@pytest.mark.parametrize("fixture", ['c2', 'c3h'])
+@pytest.mark.parametrize("fixture", ['c2', 'c3h', 'c5h'])
 def test_step_c2_full_size_matches_oracle_fixture(fixture, prec, device):
     """BASELINE.json's configs[1] at FULL size (CATER 128 x 128, 8 frames, batch 4, default widths): one whole iteration (G step, D step,
     graph step) on the GPU in deterministic mode against the CPU oracle's fp32 and fp64 runs of the same clip and weights, committed as
@@ -564,7 +564,7 @@ def test_step_c2_full_size_matches_oracle_fixture(fixture, prec, device):
     oracles), imgs_pred / flows_pred on the fixture's stride-4 pixel grid and boxes_pred in full, the abs-sum of every parameter's
     gradient, (abs-sum, L2) of every post-step state tensor.  Gates as in _step_vs_oracle, the floors being o32 against o64 on the very
     same statistic.  Second fixture, c3h: the benchmarked resolution with two samples per batch-norm statistic (256 x 256, 4 frames,
-    batch 2; c3' is batch 1)."""
+    batch 2; c3' is batch 1); third, c5h: c5's geometry (Something-Else vocabulary: one attribute => 128 layout channels, 224 x 224) at batch 2."""
     from ag2video_amd import ops
     from ag2video_amd.engine import TrainStep
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'oracle_%s.npz' % fixture)
@@ -645,6 +645,6 @@ def test_step_c2_full_size_matches_oracle_fixture(fixture, prec, device):
                 for i, fl in ((1, floor_lr * n), (2, floor_lr * n ** 0.5)):
                     if abs(got[i] - ref[i]) > 1e-3 * abs(ref[i]) + fl:
                         bad_state.append((k, i, got[i], ref[i]))
-        assert n_keys == 492 + 56 and not bad_state, (n_keys, len(bad_state), bad_state[:10])
+        assert (n_keys == 492 + 56 or fixture.startswith('c5')) and n_keys >= 500 and not bad_state, (n_keys, len(bad_state), bad_state[:10])
     finally:
         ops.set_conv_precision(old)

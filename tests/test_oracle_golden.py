@@ -221,7 +221,7 @@ def test_oracle_matches_reference_bp_prev_training_step():
             _close_stats(key, _stats(g), gold[key], 2e-3, g.numel())
 
 
-@pytest.mark.parametrize("fixture", ['c2', 'c3h'])
+@pytest.mark.parametrize("fixture", ['c2', 'c3h', 'c5h'])
 def test_oracle_c2_full_size_fixture_is_consistent(fixture):
     """tests/golden/oracle_c2.npz (tests/golden/make_oracle_c2.py: BASELINE.json's configs[1] at full size through the oracle, fp32 and
     fp64): complete -- every loss, the 492 + 56 state keys, gradient statistics of both nets, for both oracles -- and self-consistent:
@@ -235,8 +235,10 @@ def test_oracle_c2_full_size_fixture_is_consistent(fixture):
     assert meta['side_frames_batch'] == [side, frames, batch] and meta['case'] == fixture
     assert (meta['weights_seed'], meta['clip_seed'], meta['graph_clip_seed']) == (C.WEIGHTS_SEED, C.CLIP_SEED, C.GRAPH_CLIP_SEED)
     for tag in ('o32', 'o64'):
-        assert sum(k.startswith(tag + '.state.G.') for k in gold.files) == 492 and sum(k.startswith(tag + '.state.D.') for k in gold.files) == 56
-        assert sum(k.startswith(tag + '.G_grads.') for k in gold.files) > 250 and sum(k.startswith(tag + '.D_grads.') for k in gold.files) > 40
+        nG, nD = sum(k.startswith(tag + '.state.G.') for k in gold.files), sum(k.startswith(tag + '.state.D.') for k in gold.files)
+        # (CATER: 4 attributes => the reference's 492 + 56 keys; Something-Else: one attribute, AttributeEmbeddings has no mixing Linear)
+        assert (nG, nD) == (492, 56) if not fixture.startswith('c5') else (nG >= 470 and nD >= 50), (nG, nD)
+        assert sum(k.startswith(tag + '.G_grads.') for k in gold.files) > 240 and sum(k.startswith(tag + '.D_grads.') for k in gold.files) > 35
         assert {k.split('.', 2)[2] for k in gold.files if k.startswith(tag + '.GL.')} >= {'GAN_Img', 'GAN_Feat', 'loss_F_Warp', 'total_loss'}
         assert gold[tag + '.imgs_sub'].shape == (batch, frames, 3, side // 4, side // 4) and gold[tag + '.flows_sub'].shape == (batch, frames, 2, side // 4, side // 4)
     for k in gold.files:
