@@ -646,5 +646,34 @@ def test_step_c2_full_size_matches_oracle_fixture(fixture, prec, device):
                     if abs(got[i] - ref[i]) > 1e-3 * abs(ref[i]) + fl:
                         bad_state.append((k, i, got[i], ref[i]))
         assert (n_keys == 492 + 56 or fixture.startswith('c5')) and n_keys >= 500 and not bad_state, (n_keys, len(bad_state), bad_state[:10])
+        del ts
+        # the SHIPPED default path at this size -- atomics, the co-scheduled graph-net programs on their side streams, the hoisted power
+        # iterations (engine.TrainStep outside deterministic mode) -- against the same fixture: losses, imgs_pred in relative L2, gradient
+        # abs-sums (per-element floor 5e-6: _step_vs_oracle's default-path leg)
+        ts2 = TrainStep(opt, device, weights_seed=C.WEIGHTS_SEED)
+        assert ts2.side_stream is not None
+        mo2, GL2, DL2 = ts2.gd_step(ts2.to_device(clip))
+        ts2.check_health()
+        for grp, got in (('GL', GL2), ('DL', DL2)):
+            for k, v in got.items():
+                rf = float(gold['o64.%s.%s' % (grp, k)])
+                assert abs(v.item() - rf) <= 1e-3 * max(1.0, abs(rf)), ('default path', grp, k, v.item(), rf)
+        e2 = errs(mo2[0].detach().double().cpu().numpy()[..., ::st, ::st], gold['o64.imgs_sub'], amax)
+        assert e2[1] <= 2.0 * f_img[1] and errs(mo2[1].detach().double().cpu().numpy(), gold['o64.boxes_pred'])[0] <= 1e-3, ('default path', e2, f_img)
+        worst2 = {}
+        for gtag, params, groups in (('G_grads', ts2.model.named_parameters(), None), ('D_grads', ts2.discriminator.img_discriminator.named_parameters(), 'D')):
+            for n, prm in params:
+                key = 'o64.%s.%s' % (gtag, n)
+                if key not in gold.files or prm.grad is None:
+                    continue
+                exact, o32v = float(gold[key][1]), float(gold['o32.%s.%s' % (gtag, n)][1])
+                grp = groups or ('front' if C.is_front(n) else 'decoder')
+                dev_abs = abs(C.stats(prm.grad)[1] - exact)
+                bound = max({'front': 5e-2, 'decoder': 2e-2, 'D': 2e-2}[grp] * exact, 2.5 * abs(o32v - exact)) + 5e-6 * prm.numel()
+                if exact > 5e-6 * prm.numel():
+                    worst2[grp] = max(worst2.get(grp, 0.0), dev_abs / exact)
+                assert dev_abs <= bound, ('default path', gtag, n, dev_abs / max(exact, 1e-30))
+        print('%s full size [%s] default path (side streams): imgs (max-norm, relative L2) %s, worst gradient abs-sum deviations %s' % (fixture, prec, e2, worst2))
+        del ts2
     finally:
         ops.set_conv_precision(old)
