@@ -33,9 +33,13 @@ typedef __attribute__((address_space(3))) void* lds_vptr;
 #define AG2V_HALO_NA 6          // A ring slots (divides the 18-step unrolled body)
 #endif
 
-template <int WM, int WN, int EM, int TW, int TH, bool MF16 = false>
+template <int WM, int WN, int EM, int TW, int TH, bool MF16 = false, int CB = 2>
 struct HaloCfg {
-    static constexpr int BM = WM * EM * 32, BN = WN * 32;
+    // CB: 16-pixel column blocks per wave (MF16 only).  2: the wave owns 32 pixels; 4 (round 6, the 64-row tile): 64 pixels -- a 64-row
+    // wave with 32 pixels reads as many B words per MFMA as a 128-row wave reads A and B together and is bound by them (matrix pipe
+    // 47 % busy); with 64 pixels per wave the 64-row tile has the 128-row tile's operand traffic per MFMA
+    static constexpr int BM = WM * EM * 32, BN = WN * 16 * CB;
+    static_assert(CB == 2 || (CB == 4 && MF16 && TW % 64 == 0), "column blocks per wave");
     static_assert(WM * WN == 8, "8 waves");
     static_assert(TW * TH == BN && TW % 32 == 0, "pixel patch");
     static constexpr int CH = 16;                         // channels per stage = one MFMA k-step
@@ -54,7 +58,7 @@ struct HaloCfg {
     static constexpr int APW = (APS + 7) / 8;
     static constexpr int NA = AG2V_HALO_NA;
     static constexpr int A_OFF = 0, B_OFF = NA * ASZ, DUMMY_OFF = B_OFF + 2 * BBYTES, LDS_BYTES = DUMMY_OFF + 1024;
-    static_assert(PPW <= (MF16 ? 5 : 6), "a stage's pieces must be certified before the next stage's first prefetch");
+    static_assert(PPW <= (MF16 ? 7 : 6), "a stage's pieces must be certified before the next stage's first prefetch");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     static_assert((7 * CHP + 2 * RP + 2) * 4 < 65536 && (2 * ASZ + 3 * BM * 16 + EM * 512) < 65536, "ds_read immediate offsets");
 };
@@ -374,10 +378,10 @@ struct HaloBody {
 // in the lane's base address.  One barrier, one counted wait per DOUBLE-step (48 MFMAs per wave at EM = 4).
 // H16 (with PS = false): the fp16 3-term split of the forward passes that need fp32-class products (ConvArgs::h16: the flow network,
 // conv_common.h split2_h) -- v_mfma_f32_16x16x32_f16 on planes the *_h pack kernels wrote; the epilogue's oscale undoes their scale
-template <int WM, int WN, int EM, int TW, int TH, bool PS, bool H16 = false>
+template <int WM, int WN, int EM, int TW, int TH, bool PS, bool H16 = false, int CB = 2>
 struct HaloBody16 {
     static_assert(!(PS && H16), "split words are bf16 pairs");
-    typedef HaloCfg<WM, WN, EM, TW, TH, true> G;
+    typedef HaloCfg<WM, WN, EM, TW, TH, true, CB> G;
     static constexpr unsigned kOut = 0xFFFFFFF0u;
     static constexpr int RB = 2 * EM;                    // 16-row blocks of a wave's EM * 32 rows
     // HALFWIN (EM = 4): the A fragments of a double-step are fetched in two halves -- row blocks 0 .. RB/2 - 1 during the previous
@@ -399,17 +403,28 @@ struct HaloBody16 {
     int dma_g;                           // MFMA group behind which this wave issues its DMA pieces (0, or RB / 2 for waves 4..7)
     unsigned baseA[3];                   // per slot pair (2 q, 2 q + 1): lanes of the second k half point into the odd slot
     unsigned baseB[5];                   // per (buffer, offset between the two taps of a double-step): see kidx()
-    bf16x8 ah[RB], al[RB], bh[2], bl[2];
-    unsigned bw[16];
-    f32x4 acc[RB][2];
+    bf16x8 ah[RB], al[RB], bh[CB], bl[CB];
+    unsigned bw[8 * CB];
+    f32x4 acc[RB][CB];
 
     __device__ __forceinline__ HaloBody16(const ConvArgs& p_, char* s) : p(p_), smem(s) {}
 
     // image offset (words) of step u of a stage pair: buffer (u / 9) & 1, tap u % 9
     static constexpr int tapoff(int u) { return ((u % 9) / 3) * G::RP + (u % 9) % 3; }
     static constexpr int kidx(int D) { return D == 0 ? 0 : D == 1 ? 1 : D == 2 ? 0 : D == 3 ? 0 : D == 4 ? 2 : D == 5 ? 3 : D == 6 ? 3 : D == 7 ? 4 : 3; }
-    static constexpr int nB(int D) {     // image pieces issued per wave in double-step D: rounds {0,1,2} at D = 0 / 5, {3,4} at D = 1 / 6
-        return (D == 0 || D == 5) ? (G::PPW < 3 ? G::PPW : 3) : (D == 1 || D == 6) ? (G::PPW > 3 ? G::PPW - 3 : 0) : 0;
+    // image pieces issued per wave in double-step D: the stage's rounds in two halves, [0, NB1) at D = 0 / 5, [NB1, PPW) at D = 1 / 6
+    // (3 | 2 of 5 rounds; 4 | 3 of the 7 rounds of a 512-pixel tile).  A buffer is free for two double-steps before its first reader's
+    // prefetch needs it certified, so there is no third slot.
+    static constexpr int NB1 = G::PPW <= 3 ? G::PPW : (G::PPW <= 5 ? 3 : 4);
+    static constexpr int nB(int D) {
+        return (D == 0 || D == 5) ? NB1 : (D == 1 || D == 6) ? G::PPW - NB1 : 0;
+    }
+    template <int K0, int K1, int BUF>
+    __device__ __forceinline__ void dma_b_rounds(int st) {      // rounds [K0, K1) of stage st
+        if constexpr (K0 < K1) {
+            dma_b_round<K0, BUF>(st);
+            dma_b_rounds<K0 + 1, K1, BUF>(st);
+        }
     }
 
     template <int U3>
@@ -456,7 +471,7 @@ struct HaloBody16 {
     __device__ __forceinline__ void regroup() {
         typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < CB; ++c) {
             u32x4v hv, lv;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -480,7 +495,7 @@ struct HaloBody16 {
 #pragma unroll
         for (int i = 0; i < (HALFWIN ? RB / 2 : RB); ++i) load_a<D1>(i);       // (HALFWIN: the second half follows inside the double-step)
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < CB; ++c)
 #pragma unroll
             for (int j = 0; j < 8; ++j) bw[8 * c + j] = load_bw<D1>(c, j);
         regroup();
@@ -494,12 +509,12 @@ struct HaloBody16 {
         wait_vmcnt<2 * G::APW + nB(PD)>();
 #endif
         __builtin_amdgcn_s_barrier();
-        constexpr int WPG = 16 / RB;                 // B words of the next double-step fetched per row-block group
+        constexpr int WPG = (8 * CB) / RB;           // B words of the next double-step fetched per row-block group
 #pragma unroll
         for (int g = 0; g < RB; ++g) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
+            for (int c = 0; c < CB; ++c) {
                 if constexpr (H16) {
                     acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, al[g]), __builtin_bit_cast(f16x8, bh[c]), acc[g][c], 0, 0, 0);
                     acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah[g]), __builtin_bit_cast(f16x8, bl[c]), acc[g][c], 0, 0, 0);
@@ -515,10 +530,10 @@ struct HaloBody16 {
             if (g == dma_g) {
                 // image pieces: the pair's second stage (buffer 1) during double-steps 0, 1; the NEXT pair's (or tile's) first stage
                 // (buffer 0, free once step 8 has been fetched: after barrier 4) during double-steps 5, 6
-                if constexpr (D == 0) { dma_b_round<0, 1>(2 * P + 1); dma_b_round<1, 1>(2 * P + 1); dma_b_round<2, 1>(2 * P + 1); }
-                if constexpr (D == 1) { dma_b_round<3, 1>(2 * P + 1); dma_b_round<4, 1>(2 * P + 1); }
-                if constexpr (D == 5) { dma_b_round<0, 0>(2 * P + 2); dma_b_round<1, 0>(2 * P + 2); dma_b_round<2, 0>(2 * P + 2); }
-                if constexpr (D == 6) { dma_b_round<3, 0>(2 * P + 2); dma_b_round<4, 0>(2 * P + 2); }
+                if constexpr (D == 0) dma_b_rounds<0, NB1, 1>(2 * P + 1);
+                if constexpr (D == 1) dma_b_rounds<NB1, G::PPW, 1>(2 * P + 1);
+                if constexpr (D == 5) dma_b_rounds<0, NB1, 0>(2 * P + 2);
+                if constexpr (D == 6) dma_b_rounds<NB1, G::PPW, 0>(2 * P + 2);
                 if (HALFWIN && lateA) dma_a_ahead<U + 4>();
                 else dma_a_ahead<U + 6>();
                 __builtin_amdgcn_sched_barrier(0);
@@ -599,7 +614,7 @@ struct HaloBody16 {
         }
         const int wm = wave / WN, wn = wave % WN;
         const int wm0 = wm * EM * 32;
-        const int pb = wn * 32, ty = pb / TW, tx = pb % TW;
+        const int pb = wn * 16 * CB, ty = pb / TW, tx = pb % TW;
         const int l15 = lane & 15, kq = lane >> 4, kg = kq & 1, sub = kq >> 1;
         // piece a = wave (+ 8): 64 consecutive rows of one (plane, k group); rows [64 h, 64 h + 64) are the early (h even) / late (h odd)
         // row blocks of the waves that own rows [128 (h / 2), + 128)
@@ -623,7 +638,7 @@ struct HaloBody16 {
         {   // first tile: its stage 0 (as "the next tile's") and A steps 0..5
             const int keepNS = NS;
             NS = 0;                       // every stage index counts as "beyond": dma_b_round takes vBn with offset 0
-            dma_b_round<0, 0>(0); dma_b_round<1, 0>(0); dma_b_round<2, 0>(0); dma_b_round<3, 0>(0); dma_b_round<4, 0>(0);
+            dma_b_rounds<0, G::PPW, 0>(0);
             NS = keepNS;
         }
         dma_a<0>(0, vAn); dma_a<1>(0, vAn); dma_a<2>(0, vAn); dma_a<3>(0, vAn);
@@ -649,14 +664,14 @@ struct HaloBody16 {
 #pragma unroll
             for (int i = 0; i < RB; ++i)
 #pragma unroll
-                for (int c = 0; c < 2; ++c)
+                for (int c = 0; c < CB; ++c)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[i][c][r] = 0.f;
             // this tile's stage 0 and A steps 0..5 (issued by the previous tile's tail, or just above) have landed.  They are OLDER than
             // the previous tile's 2 RB epilogue stores, which may stay in flight (vmcnt counts in issue order); a tile whose last row block
             // is partly outside M issues fewer stores, so it waits for everything.
             if (first || !full_prev) wait_vmcnt<0>();
-            else wait_vmcnt<2 * RB>();
+            else wait_vmcnt<RB * CB>();
             first = false;
             full_prev = cur.m0 + G::BM <= p.M;
             __builtin_amdgcn_s_barrier();
@@ -715,53 +730,62 @@ struct HaloBody16 {
             const float* bsrc = has_bias ? p.bias : p.out;
             const float* asrc = has_aux ? aux : p.out;
             const size_t astride = has_aux ? (size_t)plane : 0;
+            // CP pairs of column blocks per wave (CB / 2): pair cp holds the 32 pixels at offset 32 cp of the wave's run -- each batch
+            // loads, finishes and stores both pairs, so that the load / store order above holds for any CB
+            constexpr int CP = CB / 2;
             float bv[HB];
-            float4 axs[HB], ays[HB], ox[HB], oy[HB];
+            float4 axs[HB][CP], ays[HB][CP], ox[HB][CP], oy[HB][CP];
             auto loads = [&](int h) {
 #pragma unroll
                 for (int k = 0; k < HB; ++k) {
                     const int mblk = cur.m0 + wm0 + (h * HB + k) * 16;
                     const int mb = min(mblk + l15, p.M - 1), mxc = min(mblk + rx, p.M - 1), myc = min(mblk + ry, p.M - 1);
                     bv[k] = bsrc[has_bias ? mb : 0];
-                    axs[k] = *reinterpret_cast<const float4*>(asrc + (size_t)mxc * astride);
-                    ays[k] = *reinterpret_cast<const float4*>(asrc + (size_t)myc * astride);
+#pragma unroll
+                    for (int cp = 0; cp < CP; ++cp) {
+                        axs[k][cp] = *reinterpret_cast<const float4*>(asrc + (size_t)mxc * astride + (has_aux ? 32 * cp : 0));
+                        ays[k][cp] = *reinterpret_cast<const float4*>(asrc + (size_t)myc * astride + (has_aux ? 32 * cp : 0));
+                    }
                 }
             };
             auto results = [&](int h) {
 #pragma unroll
                 for (int k = 0; k < HB; ++k) {
                     const int i = h * HB + k;
-                    float X[4], Y[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const u32x2v t = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[i][0][r]), __float_as_uint(acc[i][1][r]), false, false);
-                        X[r] = __uint_as_float(t[0]);
-                        Y[r] = __uint_as_float(t[1]);
-                    }
-                    transpose4(X);
-                    transpose4(Y);
                     // this lane's rows: X -> 16 i + qrow + 8 up, Y -> + 4; the bias values sit in lanes (row index) of bv[k]
                     const float b_ = has_bias ? bv[k] : 0.f;
                     const float bx = __uint_as_float(__builtin_amdgcn_ds_bpermute(rx * 4, __float_as_uint(b_)));
                     const float by = __uint_as_float(__builtin_amdgcn_ds_bpermute(ry * 4, __float_as_uint(b_)));
-                    const float4 ax4 = has_aux ? axs[k] : make_float4(0.f, 0.f, 0.f, 0.f), ay4 = has_aux ? ays[k] : make_float4(0.f, 0.f, 0.f, 0.f);
-                    const float axv[4] = {ax4.x, ax4.y, ax4.z, ax4.w}, ayv[4] = {ay4.x, ay4.y, ay4.z, ay4.w};
-                    float vx[4], vy[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float x = fmaf(X[j], gs, bx);
-                        x = fmaf(axv[j], rmul, x);
-                        x = fmaxf(x, relu_floor);
-                        x = (axv[j] > mask_thr) ? x : 0.f;
-                        vx[j] = osplit ? pack_split(x) : x;
-                        float y = fmaf(Y[j], gs, by);
-                        y = fmaf(ayv[j], rmul, y);
-                        y = fmaxf(y, relu_floor);
-                        y = (ayv[j] > mask_thr) ? y : 0.f;
-                        vy[j] = osplit ? pack_split(y) : y;
+                    for (int cp = 0; cp < CP; ++cp) {
+                        float X[4], Y[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const u32x2v t = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[i][2 * cp][r]), __float_as_uint(acc[i][2 * cp + 1][r]), false, false);
+                            X[r] = __uint_as_float(t[0]);
+                            Y[r] = __uint_as_float(t[1]);
+                        }
+                        transpose4(X);
+                        transpose4(Y);
+                        const float4 ax4 = has_aux ? axs[k][cp] : make_float4(0.f, 0.f, 0.f, 0.f), ay4 = has_aux ? ays[k][cp] : make_float4(0.f, 0.f, 0.f, 0.f);
+                        const float axv[4] = {ax4.x, ax4.y, ax4.z, ax4.w}, ayv[4] = {ay4.x, ay4.y, ay4.z, ay4.w};
+                        float vx[4], vy[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float x = fmaf(X[j], gs, bx);
+                            x = fmaf(axv[j], rmul, x);
+                            x = fmaxf(x, relu_floor);
+                            x = (axv[j] > mask_thr) ? x : 0.f;
+                            vx[j] = osplit ? pack_split(x) : x;
+                            float y = fmaf(Y[j], gs, by);
+                            y = fmaf(ayv[j], rmul, y);
+                            y = fmaxf(y, relu_floor);
+                            y = (ayv[j] > mask_thr) ? y : 0.f;
+                            vy[j] = osplit ? pack_split(y) : y;
+                        }
+                        ox[k][cp] = make_float4(vx[0], vx[1], vx[2], vx[3]);
+                        oy[k][cp] = make_float4(vy[0], vy[1], vy[2], vy[3]);
                     }
-                    ox[k] = make_float4(vx[0], vx[1], vx[2], vx[3]);
-                    oy[k] = make_float4(vy[0], vy[1], vy[2], vy[3]);
                 }
             };
             auto stores = [&](int h) {
@@ -769,8 +793,11 @@ struct HaloBody16 {
                 for (int k = 0; k < HB; ++k) {
                     const int mblk = cur.m0 + wm0 + (h * HB + k) * 16;
                     const int mx = mblk + rx, my = mblk + ry;
-                    if (mx < p.M) *reinterpret_cast<float4*>(obase + (size_t)mx * plane) = ox[k];
-                    if (my < p.M) *reinterpret_cast<float4*>(obase + (size_t)my * plane) = oy[k];
+#pragma unroll
+                    for (int cp = 0; cp < CP; ++cp) {
+                        if (mx < p.M) *reinterpret_cast<float4*>(obase + (size_t)mx * plane + 32 * cp) = ox[k][cp];
+                        if (my < p.M) *reinterpret_cast<float4*>(obase + (size_t)my * plane + 32 * cp) = oy[k][cp];
+                    }
                 }
             };
             loads(0);
@@ -800,22 +827,22 @@ __global__ __launch_bounds__(512) void conv_halo_bf16x3_kernel(ConvArgs p) {
     body.run();
 #endif
 }
-// the 16x16x32 form (HaloBody16)
-template <int WM, int WN, int EM, int TW, int TH, bool PS>
+// the 16x16x32 form (HaloBody16); CB: 16-pixel column blocks per wave (HaloCfg)
+template <int WM, int WN, int EM, int TW, int TH, bool PS, int CB = 2>
 __global__ __launch_bounds__(512) void conv_halo16_bf16x3_kernel(ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ __attribute__((aligned(1024))) char smem[HaloCfg<WM, WN, EM, TW, TH, true>::LDS_BYTES];
-    HaloBody16<WM, WN, EM, TW, TH, PS> body(p, smem);
+    __shared__ __attribute__((aligned(1024))) char smem[HaloCfg<WM, WN, EM, TW, TH, true, CB>::LDS_BYTES];
+    HaloBody16<WM, WN, EM, TW, TH, PS, false, CB> body(p, smem);
     body.run();
 #endif
 }
 
 // ... on the fp16 3-term split (fp32 gathered tensor, ConvArgs::h16)
-template <int WM, int WN, int EM, int TW, int TH>
+template <int WM, int WN, int EM, int TW, int TH, int CB = 2>
 __global__ __launch_bounds__(512) void conv_halo16_f16x3_kernel(ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ __attribute__((aligned(1024))) char smem[HaloCfg<WM, WN, EM, TW, TH, true>::LDS_BYTES];
-    HaloBody16<WM, WN, EM, TW, TH, false, true> body(p, smem);
+    __shared__ __attribute__((aligned(1024))) char smem[HaloCfg<WM, WN, EM, TW, TH, true, CB>::LDS_BYTES];
+    HaloBody16<WM, WN, EM, TW, TH, false, true, CB> body(p, smem);
     body.run();
 #endif
 }
@@ -839,11 +866,12 @@ static bool halo_geometry(int BN, int OH, int OW, int& TW, int& TH) {
 // not thread-safe, and the autograd thread launches kernels while the main thread may be editing os.environ -- ADVICE r04) and again
 // only when ag2v_halo_reload_env() is called (tests and tools/halo_bench.py call it after changing the variables, with no launch in
 // flight).  None of them changes results beyond the summation order of the kernel family selected.
-struct HaloSwitches { int no_halo, mfma32, min_tiles, no_wgrad_halo; };
+struct HaloSwitches { int no_halo, mfma32, min_tiles, no_wgrad_halo, no_wide; };
 static HaloSwitches read_halo_switches() {
     HaloSwitches h;
     h.no_halo = getenv("AG2V_NO_HALO") != nullptr;
     h.mfma32 = getenv("AG2V_HALO_MFMA32") != nullptr;
+    h.no_wide = getenv("AG2V_NO_HALO_WIDE") != nullptr;            // (tests: the 64-row layers on the 256-pixel tile, as before round 6)
     h.no_wgrad_halo = getenv("AG2V_NO_WGRAD_HALO") != nullptr;      // (conv_wgrad_halo.hip: weight gradients on the previous kernels)
     const char* mt = getenv("AG2V_HALO_MIN_TILES");                 // (tests run small shapes through these kernels)
     h.min_tiles = mt ? atoi(mt) : 384;                              // small maps: the split-K kernels fill the chip better
@@ -856,6 +884,20 @@ extern "C" int ag2v_halo_reload_env(void) {
 }
 extern "C" int ag2v_halo_min_tiles(void) { return g_halo_sw.min_tiles; }
 bool wgrad_halo_switched_off() { return g_halo_sw.no_wgrad_halo != 0; }
+
+// 64-row layers (up_3, the flow network's full-resolution layers): 512 pixels per workgroup -- 64 per wave (HaloCfg CB = 4) -- as 128 x 4 or
+// 64 x 8 patches, when the map allows it and the 16x16x32 form is on
+static bool halo_geometry_wide(int OH, int OW, int& TW, int& TH) {
+    if (g_halo_sw.mfma32 || g_halo_sw.no_wide) return false;
+    for (int tw = 128; tw >= 64; tw >>= 1) {
+        if (OW % tw) continue;
+        const int th = 512 / tw;
+        if (OH % th || th >= OH) continue;
+        TW = tw; TH = th;
+        return true;
+    }
+    return false;
+}
 
 // (A 256-row tile -- 128 x 1 / 64 x 2 / 32 x 4 pixels, 3x row halo -- was built and measured in round 4: the 128-row tile with 256 pixels as
 // 2 x 128 (2x row halo, 8 KB of weights per k-step) beat it on every shape, +1.9 % at C = 384, +4.5 % at C = 128; removed in round 6.)
@@ -871,19 +913,26 @@ bool igemm_halo_ok(const ConvArgs& a) {
     if (a.C % 32 || a.W % 4 || (a.o_mul != 1 && a.o_mul != 0) || a.o_add_y || a.o_add_x) return false;
     if ((a.o_H && a.o_H != a.OH) || (a.o_W && a.o_W != a.OW)) return false;
     if (a.residual == a.out && a.residual) return false;          // accumulating launches stay on the split-K capable kernels
-    const int bn = 256, bm = a.M <= 64 ? 64 : 128;
+    const int bm = a.M <= 64 ? 64 : 128;
     if (a.out_mstride && (bm != 128 || a.M % 128 || a.residual || a.mask)) return false;      // per-row-tile outputs: whole 128-row tiles
     int tw, th;
-    if (!halo_geometry(bn, a.OH, a.OW, tw, th)) return false;
-    const long long tiles = (long long)ceil_div(a.M, bm) * (a.NG / bn);
+    const bool wide = bm == 64 && halo_geometry_wide(a.OH, a.OW, tw, th);
+    const int bn = wide ? 512 : 256;
+    if (!wide && !halo_geometry(bn, a.OH, a.OW, tw, th)) return false;
+    // (the threshold counts 256-pixel tiles for the wide form too: WHICH launches take these kernels does not depend on the tile width --
+    // the frame-batched and the sequential generator keep choosing the same family for a layer)
+    (void)bn;
+    const long long tiles = (long long)ceil_div(a.M, bm) * (a.NG / 256);
     return tiles >= g_halo_sw.min_tiles;
 }
 
 int launch_igemm_halo(ConvArgs& a, hipStream_t st) {
     if (a.out_nstride == 0) a.out_nstride = (long long)a.M * a.OH * a.OW;       // (direct callers: the dense output)
-    const int bn = 256, bm = a.M <= 64 ? 64 : 128;
+    const int bm = a.M <= 64 ? 64 : 128;
     int tw, th;
-    if (!halo_geometry(bn, a.OH, a.OW, tw, th)) return AG2V_EINVAL;
+    const bool wide = bm == 64 && halo_geometry_wide(a.OH, a.OW, tw, th);
+    const int bn = wide ? 512 : 256;
+    if (!wide && !halo_geometry(bn, a.OH, a.OW, tw, th)) return AG2V_EINVAL;
     a.tiles_m = ceil_div(a.M, bm);
     a.tiles_n = a.NG / bn;
     a.splitk = 1;
@@ -918,7 +967,23 @@ int launch_igemm_halo(ConvArgs& a, hipStream_t st) {
             hipLaunchKernelGGL((conv_halo_bf16x3_kernel<WM_, WN_, EM_, TW_, TH_, false>), grid, dim3(512), 0, st, a);              \
         }                                                                                                                        \
     } while (0)
-    if (bm == 128) {
+#define AG2V_HALO_WIDE(TW_, TH_)                                                                                                 \
+    do {                                                                                                                         \
+        if (a.h16) {                                                                                                             \
+            set_last_conv_kernel("conv_halo16_f16x3_kernel<1, 8, 2, " #TW_ ", " #TH_ ", 4>");                                     \
+            hipLaunchKernelGGL((conv_halo16_f16x3_kernel<1, 8, 2, TW_, TH_, 4>), grid, dim3(512), 0, st, a);                      \
+        } else if (a.b_split) {                                                                                                  \
+            set_last_conv_kernel("conv_halo16_bf16x3_kernel<1, 8, 2, " #TW_ ", " #TH_ ", true, 4>");                              \
+            hipLaunchKernelGGL((conv_halo16_bf16x3_kernel<1, 8, 2, TW_, TH_, true, 4>), grid, dim3(512), 0, st, a);               \
+        } else {                                                                                                                 \
+            set_last_conv_kernel("conv_halo16_bf16x3_kernel<1, 8, 2, " #TW_ ", " #TH_ ", false, 4>");                             \
+            hipLaunchKernelGGL((conv_halo16_bf16x3_kernel<1, 8, 2, TW_, TH_, false, 4>), grid, dim3(512), 0, st, a);              \
+        }                                                                                                                        \
+    } while (0)
+    if (wide) {
+        if (tw == 128) AG2V_HALO_WIDE(128, 4);
+        else AG2V_HALO_WIDE(64, 8);
+    } else if (bm == 128) {
         if (tw == 128) AG2V_HALO(1, 8, 4, 128, 2);
         else if (tw == 64) AG2V_HALO(1, 8, 4, 64, 4);
         else AG2V_HALO(1, 8, 4, 32, 8);
@@ -928,6 +993,7 @@ int launch_igemm_halo(ConvArgs& a, hipStream_t st) {
         else AG2V_HALO(1, 8, 2, 32, 8);
     }
 #undef AG2V_HALO
+#undef AG2V_HALO_WIDE
     AG2V_CHECK_LAUNCH();
     return AG2V_OK;
 }

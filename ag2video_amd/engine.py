@@ -81,9 +81,15 @@ class TrainStep(object):
         # 790.0 ms), and round 3's programs were queued BEHIND the generator's forward, where they wait for CUs the persistent
         # convolutions hold.
         if (torch.device(device).type == 'cuda' and os.environ.get('AG2V_NO_SIDE_STREAM') is None and not ops.is_deterministic()):
-            self.side_stream = torch.cuda.Stream(device=device)
-            self.side_stream_b = torch.cuda.Stream(device=device)
-            self.side_stream_d = torch.cuda.Stream(device=device)
+            # HIGH-priority streams: a program passes its grid barriers only once ALL its workgroups are resident, so when CUs free up the
+            # dispatcher must hand them to a waiting program before it hands them to the thousands of workgroups a main-stream kernel has
+            # queued -- a program that stays partly resident holds its CUs idle AND leaves the persistent convolutions (one workgroup per
+            # CU) a second round of workgroups: seen as a single launch taking +20 ms in 2 of 6 bench runs before the priorities were set
+            # (AG2V_SIDE_PRIORITY=0: the default priority, for A/B runs).
+            prio = -1 if os.environ.get('AG2V_SIDE_PRIORITY', '-1') != '0' else 0
+            self.side_stream = torch.cuda.Stream(device=device, priority=prio)
+            self.side_stream_b = torch.cuda.Stream(device=device, priority=prio)
+            self.side_stream_d = torch.cuda.Stream(device=device, priority=prio)
             self.model.side_stream = self.side_stream
             self.model.side_stream_b = self.side_stream_b
             from . import graph_program

@@ -96,7 +96,7 @@ int ag2v_set_conv_precision(int mode);
 int ag2v_get_conv_precision(void);
 int ag2v_set_bf16x3_min_rows(int rows);
 int ag2v_get_bf16x3_min_rows(void);
-/* Diagnostic switches of the halo-tile launchers (AG2V_NO_HALO, AG2V_HALO_MFMA32, AG2V_HALO_MIN_TILES, AG2V_NO_WGRAD_HALO: which kernel
+/* Diagnostic switches of the halo-tile launchers (AG2V_NO_HALO, AG2V_HALO_MFMA32, AG2V_HALO_MIN_TILES, AG2V_NO_HALO_WIDE, AG2V_NO_WGRAD_HALO: which kernel
  * FAMILY takes a launch -- same products, another summation order; each has a test on its non-default side) are read
  * from the environment once at load time; ag2v_halo_reload_env() reads them again (tests / tools, with no launch in flight).
  * ag2v_halo_min_tiles(): the tile count from which a 3x3 stride-1 launch takes those kernels (384 unless AG2V_HALO_MIN_TILES). */

@@ -33,19 +33,23 @@ def _reload():
 
 
 class _halo(object):
-    """on: False = the previous kernels; True / '16' = the 16x16x32 halo kernels (the default); '32' = the 32x32x16 halo kernels."""
+    """on: False = the previous kernels; True / '16' = the 16x16x32 halo kernels (the default); '32' = the 32x32x16 halo kernels;
+    'narrow' = the default without the 512-pixel tile of the 64-row layers (AG2V_NO_HALO_WIDE: 32 pixels per wave, as before round 6)."""
 
     def __init__(self, on):
         self.on = on
 
     def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in ('AG2V_NO_HALO', 'AG2V_HALO_MIN_TILES', 'AG2V_HALO_MFMA32')}
+        self.old = {k: os.environ.get(k) for k in ('AG2V_NO_HALO', 'AG2V_HALO_MIN_TILES', 'AG2V_HALO_MFMA32', 'AG2V_NO_HALO_WIDE')}
         os.environ['AG2V_HALO_MIN_TILES'] = '1'
         os.environ.pop('AG2V_HALO_MFMA32', None)
+        os.environ.pop('AG2V_NO_HALO_WIDE', None)
         if self.on:
             os.environ.pop('AG2V_NO_HALO', None)
             if self.on == '32':
                 os.environ['AG2V_HALO_MFMA32'] = '1'
+            if self.on == 'narrow':
+                os.environ['AG2V_NO_HALO_WIDE'] = '1'
         else:
             os.environ['AG2V_NO_HALO'] = '1'
         _reload()
@@ -102,7 +106,7 @@ def test_halo_forward_matches_oracle_and_previous_kernels(cfg, device):
             with _halo(on):
                 outs[on] = ops.conv2d(x, w, b, 1, 1)
                 name = _lib.query('ag2v_last_conv_kernel')
-                assert (name.startswith(b'conv_halo') and name.endswith(b'false>')) == bool(on), name
+                assert (name.startswith(b'conv_halo') and (name.endswith(b'false>') or name.endswith(b'false, 4>'))) == bool(on), name
         ref = K.conv2d(x.cpu(), w.cpu(), b.cpu(), 1, 1)
         for fam in (True, '32'):
             assert float((outs[fam].cpu() - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
@@ -278,3 +282,85 @@ def test_shared_input_group_as_one_launch_equals_separate_launches(cfg, device):
                 assert float((outs[j].cpu() - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
     finally:
         ops._MERGE_SHARED_FWD = True
+
+
+def _is_wide(name):
+    """the CB = 4 instantiations carry one template argument more: <WM, WN, EM, TW, TH, PS, 4> / f16x3: <WM, WN, EM, TW, TH, 4>"""
+    return name.count(b',') == (5 if name.startswith(b'conv_halo16_f16x3') else 6)
+
+
+@pytest.mark.parametrize("cfg", [(3, 64, 64, 64, 64), (2, 32, 128, 128, 48), (2, 96, 256, 256, 64), (1, 32, 224, 128, 32), (2, 64, 64, 192, 64)], ids=str)
+def test_wide_tile_of_the_64_row_layers(cfg, device):
+    """Round 6: layers with <= 64 output (forward) / input (data gradient) channels -- the decoder's up_3 block, the flow network's
+    full-resolution layers: reference architecture.py:29-32, flows_generator.py:30-54 -- take 512 pixels per workgroup, 64 per wave
+    (conv_halo.hip HaloCfg CB = 4: 128 x 4 or 64 x 8 patches, seven DMA rounds per stage) where the map allows it.  Against the oracle
+    (2e-4) and against the 256-pixel tile they ran on before (AG2V_NO_HALO_WIDE: same products, same order per output -- 1e-6): forward
+    with every epilogue on split words and on fp32 words, the fp16-split forward, the masked data gradient; maps the wide tile does not
+    divide keep the narrow one."""
+    from ag2video_amd import _lib, ops
+    from oracle import kernels as K
+    N, C, H, W, Kout = cfg
+    torch.manual_seed(9)
+    x = torch.randn(N, C, H, W, device=device)
+    xs = _to_split_words(x)
+    xv = _from_split_words(xs)
+    w = torch.randn(Kout, C, 3, 3, device=device) * 0.05
+    b = torch.randn(Kout, device=device)
+    res = torch.randn(N, Kout, H, W, device=device)
+    gs = torch.linspace(0.5, 1.5, N, device=device)
+    wide_ok = (W % 64 == 0) and ((W % 128 == 0 and H % 4 == 0 and H > 4) or (H % 8 == 0 and H > 8))
+    with ops.conv_precision('bf16x3'), ops.bf16x3_min_rows(32), torch.no_grad():
+        for kw in (dict(bias=b, relu=True), dict(bias=None, residual=res), dict(bias=b, gscale=gs), dict(bias=b, relu=True, split_out=True)):
+            outs = {}
+            for on in (True, 'narrow'):
+                with _halo(on):
+                    xin = ops.mark_split(xs.clone())
+                    if kw.get('split_out'):
+                        outs[on] = ops.conv2d_shared_input(xin, [w], [b], stride=1, pad=1, relu=True, grad_premasked=True, out_split=[True])[0]
+                    else:
+                        outs[on] = ops.conv2d(xin, w, kw.get('bias'), 1, 1, residual=kw.get('residual'), relu=kw.get('relu', False), gscale=kw.get('gscale'))
+                    name = _lib.query('ag2v_last_conv_kernel')
+                    assert name.startswith(b'conv_halo16_bf16x3_kernel<1, 8, 2'), name
+                    assert _is_wide(name) == (on is True and wide_ok), (on, name)
+            a, n_ = outs[True], outs['narrow']
+            if kw.get('split_out'):
+                assert torch.equal(a.view(torch.int32), n_.view(torch.int32))
+                continue
+            ref = K.conv2d(xv.cpu(), w.cpu(), None if kw.get('bias') is None else b.cpu(), 1, 1,
+                           residual=None if kw.get('residual') is None else res.cpu(), relu=kw.get('relu', False),
+                           gscale=None if kw.get('gscale') is None else gs.cpu())
+            scale = float(ref.abs().max())
+            assert float((a.cpu() - ref).abs().max()) <= 2e-4 * scale, sorted(kw)
+            assert float((a - n_).abs().max()) <= 1e-6 * scale, sorted(kw)
+        # fp32 gathered words, and the fp16 3-term split of the flow network's forward
+        for h16 in (False, True):
+            outs = {}
+            for on in (True, 'narrow'):
+                with _halo(on):
+                    if h16:
+                        with ops.bf16x3_min_rows(32, fwd_h16=True):
+                            outs[on] = ops.conv2d(x, w, b, 1, 1)
+                    else:
+                        outs[on] = ops.conv2d(x, w, b, 1, 1)
+                    name = _lib.query('ag2v_last_conv_kernel')
+                    assert _is_wide(name) == (on is True and wide_ok), (on, h16, name)
+                    assert name.startswith(b'conv_halo16_f16x3_kernel' if h16 else b'conv_halo16_bf16x3_kernel'), name
+            ref = K.conv2d(x.cpu(), w.cpu(), b.cpu(), 1, 1)
+            assert float((outs[True].cpu() - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
+            assert float((outs[True] - outs['narrow']).abs().max()) <= 1e-6 * float(ref.abs().max())
+    # data gradient with the ReLU mask (rows = input channels <= 64): autograd through conv2d(relu_input=True)
+    if C <= 64:
+        wd = (torch.randn(128, C, 3, 3, device=device) * 0.05)
+        dy = _to_split_words(torch.randn(N, 128, H, W, device=device))
+        grads = {}
+        for on in (True, 'narrow'):
+            with _halo(on), ops.conv_precision('bf16x3'), ops.bf16x3_min_rows(32):
+                xi = torch.relu(x).clone().requires_grad_(True)
+                y = ops.conv2d(xi, wd, None, 1, 1, relu_input=True)
+                y.backward(_from_split_words(dy))
+                grads[on] = xi.grad.clone()
+        xr = torch.relu(x).double().cpu().requires_grad_(True)
+        torch.nn.functional.conv2d(xr, wd.double().cpu(), None, 1, 1).backward(_from_split_words(dy).double().cpu())
+        gref = xr.grad * (xr.detach() > 0)
+        assert float((grads[True].double().cpu() - gref).abs().max()) <= 2e-4 * float(gref.abs().max())
+        assert float((grads[True] - grads['narrow']).abs().max()) <= 1e-6 * float(gref.abs().max())

@@ -1,6 +1,7 @@
 """A/B of the halo-tile LDS-DMA convolution kernels (csrc/conv_halo.hip) against the wave-specialised split-word kernels they replace
 (conv_igemm_bf16x3_ps_kernel), in ONE process, alternating: forward and stride-1 data gradient on split-word operands.
-usage: halo_bench.py [reps] [shape ...]   shape = N,C,H,W,K      (GPU box only; HALO_BASE=32: "old" = the 32x32x16 halo kernels)"""
+usage: halo_bench.py [reps] [shape ...]   shape = N,C,H,W,K      (GPU box only; HALO_BASE=32: "old" = the 32x32x16 halo kernels;
+HALO_BASE=narrow: "old" = the 64-row layers on the 256-pixel tile, AG2V_NO_HALO_WIDE)"""
 import os
 import sys
 import torch
@@ -49,11 +50,12 @@ def main():
             for mode in ('old', 'new'):
                 os.environ.pop('AG2V_NO_HALO', None)
                 if mode == 'old':
-                    os.environ['AG2V_NO_HALO' if os.environ.get('HALO_BASE') != '32' else 'AG2V_HALO_MFMA32'] = '1'
+                    os.environ[{'32': 'AG2V_HALO_MFMA32', 'narrow': 'AG2V_NO_HALO_WIDE'}.get(os.environ.get('HALO_BASE'), 'AG2V_NO_HALO')] = '1'
                 ops.reload_kernel_switches()          # the library caches the switches
                 res[mode] = fwd()
                 names[mode] = _lib.query('ag2v_last_conv_kernel').decode()
                 os.environ.pop('AG2V_HALO_MFMA32', None)
+                os.environ.pop('AG2V_NO_HALO_WIDE', None)
             torch.cuda.synchronize()
             err = float((res['new'] - res['old']).abs().max() / res['old'].abs().max())
             # fp64 reference on a corner crop of image 0 and of the last image (padding taps included)
@@ -67,12 +69,14 @@ def main():
                 for mode in ('old', 'new'):
                     os.environ.pop('AG2V_NO_HALO', None)
                     os.environ.pop('AG2V_HALO_MFMA32', None)
+                    os.environ.pop('AG2V_NO_HALO_WIDE', None)
                     if mode == 'old':
-                        os.environ['AG2V_NO_HALO' if os.environ.get('HALO_BASE') != '32' else 'AG2V_HALO_MFMA32'] = '1'
+                        os.environ[{'32': 'AG2V_HALO_MFMA32', 'narrow': 'AG2V_NO_HALO_WIDE'}.get(os.environ.get('HALO_BASE'), 'AG2V_NO_HALO')] = '1'
                     ops.reload_kernel_switches()
                     fwd()
                     t[mode].append(timed(fwd, reps))
-            os.environ.pop('AG2V_NO_HALO', None)
+            for k_ in ('AG2V_NO_HALO', 'AG2V_HALO_MFMA32', 'AG2V_NO_HALO_WIDE'):
+                os.environ.pop(k_, None)
             ops.reload_kernel_switches()
         mo, mn = min(t['old']), min(t['new'])
         print('fwd %-28s old %7.3f ms %6.1f TF | new %7.3f ms %6.1f TF (%+.1f %%) | new-vs-old %.1e, vs fp64: new %.1e old %.1e | %s | %s'
