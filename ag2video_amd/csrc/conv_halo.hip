@@ -24,6 +24,7 @@
 // offsets: channel j, tap (r, s)), regroups them into the hi / lo bf16x8 operands (8 v_perm) and issues 3 EM MFMAs; the operands of
 // step t + 1 are requested during step t (B from the staged image, A from the ring slot certified by the barrier at the top of
 // step t), so the matrix pipe starts right behind each barrier.  One s_barrier and one counted s_waitcnt vmcnt per step.
+#include <type_traits>
 #include "conv_common.h"
 #include <stdlib.h>
 
@@ -57,7 +58,9 @@ struct HaloCfg {
     static constexpr int APS = ASZ / 1024;                // A pieces per step
     static constexpr int APW = (APS + 7) / 8;
     static constexpr int NA = AG2V_HALO_NA;
-    static constexpr int A_OFF = 0, B_OFF = NA * ASZ, DUMMY_OFF = B_OFF + 2 * BBYTES, LDS_BYTES = DUMMY_OFF + 1024;
+    // (16x16 form: the launch's bias vector, zero-padded to whole row tiles, behind the dummy piece -- at most BIAS_ROWS output channels)
+    static constexpr int BIAS_ROWS = MF16 ? 2048 + 128 : 0;
+    static constexpr int A_OFF = 0, B_OFF = NA * ASZ, DUMMY_OFF = B_OFF + 2 * BBYTES, BIAS_OFF = DUMMY_OFF + 1024, LDS_BYTES = BIAS_OFF + BIAS_ROWS * 4;
     static_assert(PPW <= (MF16 ? 7 : 6), "a stage's pieces must be certified before the next stage's first prefetch");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     static_assert((7 * CHP + 2 * RP + 2) * 4 < 65536 && (2 * ASZ + 3 * BM * 16 + EM * 512) < 65536, "ds_read immediate offsets");
@@ -515,14 +518,15 @@ struct HaloBody16 {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int c = 0; c < CB; ++c) {
+                // (image fragment first, weight fragment second: pixels down the accumulator registers -- see the epilogue)
                 if constexpr (H16) {
-                    acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, al[g]), __builtin_bit_cast(f16x8, bh[c]), acc[g][c], 0, 0, 0);
-                    acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah[g]), __builtin_bit_cast(f16x8, bl[c]), acc[g][c], 0, 0, 0);
-                    acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah[g]), __builtin_bit_cast(f16x8, bh[c]), acc[g][c], 0, 0, 0);
+                    acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bh[c]), __builtin_bit_cast(f16x8, al[g]), acc[g][c], 0, 0, 0);
+                    acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bl[c]), __builtin_bit_cast(f16x8, ah[g]), acc[g][c], 0, 0, 0);
+                    acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bh[c]), __builtin_bit_cast(f16x8, ah[g]), acc[g][c], 0, 0, 0);
                 } else {
-                    acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[g], bh[c], acc[g][c], 0, 0, 0);
-                    acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[g], bl[c], acc[g][c], 0, 0, 0);
-                    acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[g], bh[c], acc[g][c], 0, 0, 0);
+                    acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[c], al[g], acc[g][c], 0, 0, 0);
+                    acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[c], ah[g], acc[g][c], 0, 0, 0);
+                    acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[c], ah[g], acc[g][c], 0, 0, 0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -612,6 +616,11 @@ struct HaloBody16 {
             dummyB[k] = wave + 8 * k >= G::NPB;
             dstB0[k] = dummyB[k] ? (unsigned)G::DUMMY_OFF : (unsigned)(wave + 8 * k) * 1024u;
         }
+        {   // the bias vector -> LDS, zero-padded to whole row tiles (epilogue; the first tile's barrier publishes it)
+            float* lb = reinterpret_cast<float*>(smem + G::BIAS_OFF);
+            for (int i = tid; i < p.tiles_m * G::BM; i += 512) lb[i] = (p.bias && i < p.M) ? p.bias[i] : 0.f;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         const int wm = wave / WN, wn = wave % WN;
         const int wm0 = wm * EM * 32;
         const int pb = wn * 16 * CB, ty = pb / TW, tx = pb % TW;
@@ -674,143 +683,124 @@ struct HaloBody16 {
             else wait_vmcnt<RB * CB>();
             first = false;
             full_prev = cur.m0 + G::BM <= p.M;
+            // the tile's group scale (epilogue), through the scalar cache: a vector load would sit in the vmcnt queue
+            float gsv = 1.f;
+            if (p.gscale) {
+                const float* gp = p.gscale + cur.n_img / p.group_n;
+                asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(gsv) : "s"(gp) : "memory");
+            }
             __builtin_amdgcn_s_barrier();
             prefetch_all<0>();
             for (P = 0; P <= lastP; ++P) {
                 dstep<0>(); dstep<1>(); dstep<2>(); dstep<3>(); dstep<4>(); dstep<5>(); dstep<6>(); dstep<7>(); dstep<8>();
             }
-            // ---- epilogue.  Tile (i, c) register r: row 16 i + 4 (lane >> 4) + r, pixel 16 c + (lane & 15).  One v_permlane16_swap per
-            // register pair (c = 0, 1) gives X: row 16 i + r + 8 (lane >> 5), Y: row 16 i + 4 + r + 8 (lane >> 5), pixel lane & 31; a 4 x 4
-            // transpose between the four registers r and the four lanes of a quad (two DPP quad_perm exchange stages) then leaves every
-            // lane FOUR CONSECUTIVE PIXELS of row (lane & 3): 16-byte stores, 8 row runs of 128 bytes per instruction and a quarter of
-            // the store instructions -- the tile's 128 KB used to leave as 512 dword wave-stores, ~10 us of store ISSUE per tile with
-            // the matrix pipe idle (cdna_hip_programming.md T21; 19 k-steps' worth on a 128-row tile).
-            const int qrow = lane & 3, qpx = 4 * (l31 >> 2);
-            const size_t pxo = (size_t)(cur.y0 + ty) * p.OW + (cur.x0 + tx + qpx);
+            // ---- epilogue.  The MFMAs take the IMAGE fragment as their first operand and the weight fragment as their second (the two
+            // fragment layouts are the same: index lane & 15, k group lane >> 4), so tile (i, c) register r holds channel 16 i + (lane & 15),
+            // pixel 16 c + 4 (lane >> 4) + r: every lane owns FOUR CONSECUTIVE PIXELS of one output channel as it stands -- a 16-byte store
+            // per tile and lane (16 channel runs of 64 bytes per instruction), the bias is a per-lane value, residual / mask words are
+            // 16-byte loads at the same address pattern.  (Rounds 4-5 multiplied the other way round -- channels down the registers -- and
+            // paid a v_permlane16_swap + two DPP transpose stages + two bias bpermutes per register pair for the same stores: ~70 VALU
+            // instructions per accumulator tile pair instead of ~20, with both waves of a SIMD in their epilogues at once and the matrix
+            // pipe idle: 11 % of a 128-channel tile's time)
+            const int pq = 4 * (lane >> 4);
+            const size_t pxo = (size_t)(cur.y0 + ty) * p.OW + (cur.x0 + tx + pq);
             const size_t pix = (size_t)cur.n_img * p.M * plane + pxo;
             float* obase = p.out + (size_t)cur.n_img * p.out_nstride + pxo;
             // (multi-output launch: this row tile's own tensor; rows are addressed by their absolute index below)
             if (p.out_mstride) obase += (long long)(cur.m0 / G::BM) * p.out_mstride - (long long)cur.m0 * plane;
             const float* aux = aux0 ? aux0 + pix : nullptr;
-            const float gs = (p.gscale ? p.gscale[cur.n_img / p.group_n] : 1.f) * (p.oscale != 0.f ? p.oscale : 1.f);
-            typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
-            const bool odd1 = (lane & 1) != 0, odd2 = (lane & 2) != 0;
-            // 2 x 2 transposes of (register pair) x (lane pair): the even lane keeps e[r] and takes its partner's e[r] as e[r'], the odd lane
-            // takes its partner's e[r'] as e[r] and keeps e[r']
-            auto transpose4 = [&](float (&e)[4]) {       // e[r] of lane q  ->  e[j] = (old e[q] of lane j), within each quad of lanes
-                // stage 1 (lane bit 0 <-> register bit 0): pairs (0, 1), (2, 3)
+            const float gs = gsv * (p.oscale != 0.f ? p.oscale : 1.f);
+            // The bias vector sits in LDS since the start of the launch (zeros without one, and beyond row M) and the group scale came
+            // through the scalar cache at the top of the tile: an epilogue without a residual / mask issues no global load at all, so
+            // nothing in it waits on the vmcnt queue, where the next tile's first DMA pieces are in flight.
+            const float* lbias = reinterpret_cast<const float*>(smem + G::BIAS_OFF) + (cur.m0 + wm0 + l15);
+            // AUX: a residual / mask tensor is read; SPLIT: the output is written as split words -- both uniform over the launch: one of
+            // four straight-line instances runs (a select per VALUE on these flags was a scalar branch per value: 64 per lane and tile)
+            auto epilogue = [&](auto AUX, auto SPLIT) {
+                constexpr bool kAux = decltype(AUX)::value, kSplit = decltype(SPLIT)::value;
+                auto finish = [&](float a, float b_, float av) -> float {
+                    float x = fmaf(a, gs, b_);
+                    if constexpr (kAux) x = fmaf(av, rmul, x);
+                    x = fmaxf(x, relu_floor);
+                    if constexpr (kAux) x = (av > mask_thr) ? x : 0.f;
+                    if constexpr (kSplit) x = pack_split(x);
+                    return x;
+                };
+                if constexpr (!kAux) {
+                    // (most forward launches) row block by row block: results, then stores.  Until round 6 this case issued placeholder
+                    // loads of one cached line to keep a single branch-free instruction stream: two exposed round trips per tile.
 #pragma unroll
-                for (int r = 0; r < 4; r += 2) {
-                    const float t0 = __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(e[r + 1]), 0xB1, 0xF, 0xF, true));   // from lane ^ 1
-                    const float t1 = __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(e[r]), 0xB1, 0xF, 0xF, true));
-                    const float a = odd1 ? t0 : e[r], b = odd1 ? e[r + 1] : t1;
-                    e[r] = a; e[r + 1] = b;
-                }
-                // stage 2 (lane bit 1 <-> register bit 1): pairs (0, 2), (1, 3)
+                    for (int i = 0; i < RB; ++i) {
+                        const int m = cur.m0 + wm0 + i * 16 + l15;
+                        const float b_ = lbias[16 * i];
+                        float4 o[CB];
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const float t0 = __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(e[r + 2]), 0x4E, 0xF, 0xF, true));   // from lane ^ 2
-                    const float t1 = __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(e[r]), 0x4E, 0xF, 0xF, true));
-                    const float a = odd2 ? t0 : e[r], b = odd2 ? e[r + 2] : t1;
-                    e[r] = a; e[r + 2] = b;
-                }
-            };
-            // Residual / mask words and bias values are fetched by BRANCH-FREE loads (a null pointer is replaced by the output itself and
-            // the value discarded by a select; rows beyond M are clamped), in two batches of RB / 2 row blocks, ordered
-            //   loads 1 | results 1 | loads 2 | stores 1 | results 2 | stores 2
-            // so that no load is ever younger than a store it does not depend on: vmcnt counts in issue order, and a load under a condition
-            // (or behind stores) makes the wait for it cover those stores as well -- the first version of this epilogue had one such
-            // wait in front of each of its 2 RB stores, i.e. 2 RB serialised memory round trips per tile.  Two batches instead of one keep
-            // the epilogue within the register budget of the main loop (one batch: 64 more live registers, spilled loop invariants).
-            constexpr int HB = RB / 2;
-            const int rx = qrow + 8 * up, ry = rx + 4;
-            const bool has_bias = p.bias != nullptr, has_aux = aux0 != nullptr;
-            // (without a residual / mask the placeholder loads all read the first 16 bytes of the output: one cached line, not a pass
-            // over the tile's own output rows -- that version doubled the epilogue's memory traffic)
-            const float* bsrc = has_bias ? p.bias : p.out;
-            const float* asrc = has_aux ? aux : p.out;
-            const size_t astride = has_aux ? (size_t)plane : 0;
-            // CP pairs of column blocks per wave (CB / 2): pair cp holds the 32 pixels at offset 32 cp of the wave's run -- each batch
-            // loads, finishes and stores both pairs, so that the load / store order above holds for any CB
-            constexpr int CP = CB / 2;
-            float bv[HB];
-            float4 axs[HB][CP], ays[HB][CP], ox[HB][CP], oy[HB][CP];
-            auto loads = [&](int h) {
+                        for (int c = 0; c < CB; ++c)
+                            o[c] = make_float4(finish(acc[i][c][0], b_, 0.f), finish(acc[i][c][1], b_, 0.f), finish(acc[i][c][2], b_, 0.f),
+                                               finish(acc[i][c][3], b_, 0.f));
 #pragma unroll
-                for (int k = 0; k < HB; ++k) {
-                    const int mblk = cur.m0 + wm0 + (h * HB + k) * 16;
-                    const int mb = min(mblk + l15, p.M - 1), mxc = min(mblk + rx, p.M - 1), myc = min(mblk + ry, p.M - 1);
-                    bv[k] = bsrc[has_bias ? mb : 0];
-#pragma unroll
-                    for (int cp = 0; cp < CP; ++cp) {
-                        axs[k][cp] = *reinterpret_cast<const float4*>(asrc + (size_t)mxc * astride + (has_aux ? 32 * cp : 0));
-                        ays[k][cp] = *reinterpret_cast<const float4*>(asrc + (size_t)myc * astride + (has_aux ? 32 * cp : 0));
+                        for (int c = 0; c < CB; ++c)
+                            if (m < p.M) *reinterpret_cast<float4*>(obase + (size_t)m * plane + 16 * c) = o[c];
                     }
-                }
-            };
-            auto results = [&](int h) {
+                } else {
+                    // Residual / mask words are fetched by loads whose rows beyond M are clamped (no branch around a load), in two batches
+                    // of RB / 2 row blocks, ordered
+                    //   loads 1 | results 1 | loads 2 | stores 1 | results 2 | stores 2
+                    // so that no load is ever younger than a store it does not depend on: vmcnt counts in issue order, and a load behind
+                    // stores makes the wait for it cover those stores as well.  Two batches instead of one keep the epilogue within the
+                    // register budget of the main loop.
+                    constexpr int HB = RB / 2;
+                    float4 axs[HB][CB], ov[HB][CB];
+                    auto loads = [&](int h) {
 #pragma unroll
-                for (int k = 0; k < HB; ++k) {
-                    const int i = h * HB + k;
-                    // this lane's rows: X -> 16 i + qrow + 8 up, Y -> + 4; the bias values sit in lanes (row index) of bv[k]
-                    const float b_ = has_bias ? bv[k] : 0.f;
-                    const float bx = __uint_as_float(__builtin_amdgcn_ds_bpermute(rx * 4, __float_as_uint(b_)));
-                    const float by = __uint_as_float(__builtin_amdgcn_ds_bpermute(ry * 4, __float_as_uint(b_)));
+                        for (int k = 0; k < HB; ++k) {
+                            const int mc = min(cur.m0 + wm0 + (h * HB + k) * 16 + l15, p.M - 1);
 #pragma unroll
-                    for (int cp = 0; cp < CP; ++cp) {
-                        float X[4], Y[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const u32x2v t = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[i][2 * cp][r]), __float_as_uint(acc[i][2 * cp + 1][r]), false, false);
-                            X[r] = __uint_as_float(t[0]);
-                            Y[r] = __uint_as_float(t[1]);
+                            for (int c = 0; c < CB; ++c) axs[k][c] = *reinterpret_cast<const float4*>(aux + (size_t)mc * plane + 16 * c);
                         }
-                        transpose4(X);
-                        transpose4(Y);
-                        const float4 ax4 = has_aux ? axs[k][cp] : make_float4(0.f, 0.f, 0.f, 0.f), ay4 = has_aux ? ays[k][cp] : make_float4(0.f, 0.f, 0.f, 0.f);
-                        const float axv[4] = {ax4.x, ax4.y, ax4.z, ax4.w}, ayv[4] = {ay4.x, ay4.y, ay4.z, ay4.w};
-                        float vx[4], vy[4];
+                    };
+                    auto results = [&](int h) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            float x = fmaf(X[j], gs, bx);
-                            x = fmaf(axv[j], rmul, x);
-                            x = fmaxf(x, relu_floor);
-                            x = (axv[j] > mask_thr) ? x : 0.f;
-                            vx[j] = osplit ? pack_split(x) : x;
-                            float y = fmaf(Y[j], gs, by);
-                            y = fmaf(ayv[j], rmul, y);
-                            y = fmaxf(y, relu_floor);
-                            y = (ayv[j] > mask_thr) ? y : 0.f;
-                            vy[j] = osplit ? pack_split(y) : y;
+                        for (int k = 0; k < HB; ++k) {
+                            const int i = h * HB + k;
+                            const float b_ = lbias[16 * i];
+#pragma unroll
+                            for (int c = 0; c < CB; ++c) {
+                                const float4 a4 = axs[k][c];
+                                ov[k][c] = make_float4(finish(acc[i][c][0], b_, a4.x), finish(acc[i][c][1], b_, a4.y), finish(acc[i][c][2], b_, a4.z),
+                                                       finish(acc[i][c][3], b_, a4.w));
+                            }
                         }
-                        ox[k][cp] = make_float4(vx[0], vx[1], vx[2], vx[3]);
-                        oy[k][cp] = make_float4(vy[0], vy[1], vy[2], vy[3]);
-                    }
+                    };
+                    auto stores = [&](int h) {
+#pragma unroll
+                        for (int k = 0; k < HB; ++k) {
+                            const int m = cur.m0 + wm0 + (h * HB + k) * 16 + l15;
+#pragma unroll
+                            for (int c = 0; c < CB; ++c)
+                                if (m < p.M) *reinterpret_cast<float4*>(obase + (size_t)m * plane + 16 * c) = ov[k][c];
+                        }
+                    };
+                    loads(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    results(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    loads(1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    stores(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    results(1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    stores(1);
                 }
             };
-            auto stores = [&](int h) {
-#pragma unroll
-                for (int k = 0; k < HB; ++k) {
-                    const int mblk = cur.m0 + wm0 + (h * HB + k) * 16;
-                    const int mx = mblk + rx, my = mblk + ry;
-#pragma unroll
-                    for (int cp = 0; cp < CP; ++cp) {
-                        if (mx < p.M) *reinterpret_cast<float4*>(obase + (size_t)mx * plane + 32 * cp) = ox[k][cp];
-                        if (my < p.M) *reinterpret_cast<float4*>(obase + (size_t)my * plane + 32 * cp) = oy[k][cp];
-                    }
-                }
-            };
-            loads(0);
-            __builtin_amdgcn_sched_barrier(0);
-            results(0);
-            __builtin_amdgcn_sched_barrier(0);
-            loads(1);
-            __builtin_amdgcn_sched_barrier(0);
-            stores(0);
-            __builtin_amdgcn_sched_barrier(0);
-            results(1);
-            __builtin_amdgcn_sched_barrier(0);
-            stores(1);
+            typedef std::integral_constant<bool, true> Yes;
+            typedef std::integral_constant<bool, false> No;
+            if (aux0 == nullptr) {
+                if (osplit) epilogue(No{}, Yes{}); else epilogue(No{}, No{});
+            } else {
+                if (osplit) epilogue(Yes{}, Yes{}); else epilogue(Yes{}, No{});
+            }
             if (!more) break;
         }
         wait_vmcnt<0>();
@@ -913,6 +903,7 @@ bool igemm_halo_ok(const ConvArgs& a) {
     if (a.C % 32 || a.W % 4 || (a.o_mul != 1 && a.o_mul != 0) || a.o_add_y || a.o_add_x) return false;
     if ((a.o_H && a.o_H != a.OH) || (a.o_W && a.o_W != a.OW)) return false;
     if (a.residual == a.out && a.residual) return false;          // accumulating launches stay on the split-K capable kernels
+    if (a.M > 2048) return false;                                 // the bias vector's place in LDS (HaloCfg::BIAS_ROWS)
     const int bm = a.M <= 64 ? 64 : 128;
     if (a.out_mstride && (bm != 128 || a.M % 128 || a.residual || a.mask)) return false;      // per-row-tile outputs: whole 128-row tiles
     int tw, th;

@@ -1,7 +1,9 @@
 #!/bin/bash
-# A/B of two library builds on one box: build another revision's csrc/ to ag2video_amd/csrc/libag2v_prev.so first, e.g.
-#   git archive <rev> ag2video_amd/csrc | tar -x -C /tmp/prev && make -C /tmp/prev/ag2video_amd/csrc && cp /tmp/prev/ag2video_amd/csrc/libag2v.so ag2video_amd/csrc/libag2v_prev.so
-for i in 1 2 3; do
-  python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-fp32-leg --no-kernel-timing 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('new ', d['ms_per_step'])"
-  AG2V_LIB_PATH=$PWD/ag2video_amd/csrc/libag2v_prev.so python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-fp32-leg --no-kernel-timing 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('prev', d['ms_per_step'])"
+# c3 step time of two builds of the library, alternating in one lease: ab_lib.sh <other libag2v.so> [rounds]
+# (AG2V_LIB_PATH selects the build, ag2video_amd/_lib.py)
+other=$1; rounds=${2:-3}
+line() { python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-fp32-leg --no-kernel-timing 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1', d['ms_per_step'])"; }
+for i in $(seq $rounds); do
+  AG2V_LIB_PATH=$other line other
+  line head
 done
