@@ -68,7 +68,8 @@ class _halo(object):
 CASES = [(2, 32, 32, 32, 128), (2, 64, 64, 64, 128), (1, 32, 128, 128, 128), (3, 32, 256, 256, 96),        # 128-row tile: 32x8, 64x4, 128x2 (x2 patches per row)
          (2, 32, 32, 32, 256), (2, 32, 64, 64, 320), (1, 64, 128, 128, 256),                                  # 256-row tile: 32x4, 64x2, 128x1
          (2, 32, 64, 64, 64), (1, 32, 128, 128, 48), (2, 64, 32, 32, 64),                                     # 64-row tile
-         (1, 32, 224, 224, 128), (2, 96, 64, 64, 384)]                                                        # c5's 224 = 7 * 32; three 128-row tiles
+         (1, 32, 224, 224, 128), (2, 96, 64, 64, 384),                                                        # c5's 224 = 7 * 32; three 128-row tiles
+         (1, 32, 64, 64, 100), (1, 32, 64, 64, 40), (1, 64, 32, 32, 200)]                                     # ragged row counts: masked rows, zero-padded LDS bias
 
 
 @pytest.mark.parametrize("cfg", CASES, ids=str)
@@ -364,3 +365,23 @@ def test_wide_tile_of_the_64_row_layers(cfg, device):
         gref = xr.grad * (xr.detach() > 0)
         assert float((grads[True].double().cpu() - gref).abs().max()) <= 2e-4 * float(gref.abs().max())
         assert float((grads[True] - grads['narrow']).abs().max()) <= 1e-6 * float(gref.abs().max())
+
+
+def test_more_than_2048_output_channels_stay_off_the_halo_kernels(device):
+    """The halo kernels keep the launch's bias vector in LDS (HaloCfg::BIAS_ROWS = 2048 + 128 rows): a wider layer runs on the
+    wave-specialised kernels -- same result against the oracle."""
+    from ag2video_amd import _lib, ops
+    from oracle import kernels as K
+    torch.manual_seed(5)
+    x = torch.randn(1, 32, 32, 32, device=device)
+    w = torch.randn(2176, 32, 3, 3, device=device) * 0.05
+    b = torch.randn(2176, device=device)
+    with ops.conv_precision('bf16x3'), ops.bf16x3_min_rows(32), torch.no_grad(), _halo(True):
+        y = ops.conv2d(x, w, b, 1, 1, relu=True)
+        name = _lib.query('ag2v_last_conv_kernel')
+        assert not name.startswith(b'conv_halo'), name
+        y2 = ops.conv2d(x, w[:2048].contiguous(), b[:2048].contiguous(), 1, 1, relu=True)
+        assert _lib.query('ag2v_last_conv_kernel').startswith(b'conv_halo16'), _lib.query('ag2v_last_conv_kernel')
+    ref = K.conv2d(x.cpu(), w.cpu(), b.cpu(), 1, 1, relu=True)
+    assert float((y.cpu() - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
+    assert float((y2.cpu() - ref[:, :2048]).abs().max()) <= 2e-4 * float(ref.abs().max())
