@@ -120,7 +120,8 @@ class ConvOpts(ctypes.Structure):
     """ag2v_conv_opts (include/ag2v.h): per-call options of the *_ex convolution entry points."""
     _fields_ = [('precision', c_int), ('min_rows', c_int), ('gscale', c_void_p), ('group_n', c_int), ('kernel', c_char_p),
                 ('in_split', c_int), ('dy_split', c_int), ('out_split', c_int), ('deterministic', c_int), ('det_workspace', c_void_p),
-                ('det_workspace_floats', ctypes.c_size_t), ('out_nstride', ctypes.c_longlong), ('out_mstride', ctypes.c_longlong)]
+                ('det_workspace_floats', ctypes.c_size_t), ('out_nstride', ctypes.c_longlong), ('out_mstride', ctypes.c_longlong),
+                ('out_chan_sums', c_void_p), ('chan_sums_done', c_int)]
 
 _lib = None
 

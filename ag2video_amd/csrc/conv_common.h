@@ -48,6 +48,7 @@ struct ConvArgs {
                             //   launch is its own dense [N, 128, H, W] tensor at out + i * out_mstride (out_nstride = 128 * H * W): ONE
                             //   launch computes several convolutions of the same input (the SPADE mlp_shared group of a block,
                             //   ag2v_conv_opts::out_mstride) and every consumer still reads a contiguous tensor
+    float* chan_sums;       // halo16 kernels (0 = off): += per-row sums of the values the epilogue writes (ag2v_conv_opts::out_chan_sums)
 #ifdef AG2V_STAMPS
     unsigned long long* stamps;   // diagnostic build only (tools/ubench/igemm_stamps.hip): per-wave phase clocks
 #endif
@@ -168,6 +169,8 @@ int launch_act_mask(float* out, const float* mask, long long n, int relu, hipStr
 // name of the main kernel of the most recent convolution entry point (as rocprofv3 prints it), for bench.py's per-kernel
 // timing table: ag2v_last_conv_kernel()
 void set_last_conv_kernel(const char* name);
+void note_chan_sums_done(int v);
+bool halo_chan_sums_ok(ConvArgs a);     // conv_halo.hip: this launch would run on a kernel that adds ConvArgs::chan_sums in its epilogue
 
 // K ordering of the packed bf16x3 weight operand of an implicit-GEMM launch over C gathered channels (ConvArgs::tap_major):
 // K-tile ((c/32) * R + r) * S + s holds the 32 channels of chunk c/32 at tap (r, s).  One tap per K-tile lets the producers

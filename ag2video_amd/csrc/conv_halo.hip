@@ -60,7 +60,9 @@ struct HaloCfg {
     static constexpr int NA = AG2V_HALO_NA;
     // (16x16 form: the launch's bias vector, zero-padded to whole row tiles, behind the dummy piece -- at most BIAS_ROWS output channels)
     static constexpr int BIAS_ROWS = MF16 ? 2048 + 128 : 0;
-    static constexpr int A_OFF = 0, B_OFF = NA * ASZ, DUMMY_OFF = B_OFF + 2 * BBYTES, BIAS_OFF = DUMMY_OFF + 1024, LDS_BYTES = BIAS_OFF + BIAS_ROWS * 4;
+    // ... and, behind it, the per-row sums of what the workgroup's epilogues wrote (ConvArgs::chan_sums)
+    static constexpr int A_OFF = 0, B_OFF = NA * ASZ, DUMMY_OFF = B_OFF + 2 * BBYTES, BIAS_OFF = DUMMY_OFF + 1024, SUM_OFF = BIAS_OFF + BIAS_ROWS * 4,
+                         LDS_BYTES = SUM_OFF + BIAS_ROWS * 4;
     static_assert(PPW <= (MF16 ? 7 : 6), "a stage's pieces must be certified before the next stage's first prefetch");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     static_assert((7 * CHP + 2 * RP + 2) * 4 < 65536 && (2 * ASZ + 3 * BM * 16 + EM * 512) < 65536, "ds_read immediate offsets");
@@ -618,7 +620,11 @@ struct HaloBody16 {
         }
         {   // the bias vector -> LDS, zero-padded to whole row tiles (epilogue; the first tile's barrier publishes it)
             float* lb = reinterpret_cast<float*>(smem + G::BIAS_OFF);
-            for (int i = tid; i < p.tiles_m * G::BM; i += 512) lb[i] = (p.bias && i < p.M) ? p.bias[i] : 0.f;
+            float* ls = reinterpret_cast<float*>(smem + G::SUM_OFF);
+            for (int i = tid; i < p.tiles_m * G::BM; i += 512) {
+                lb[i] = (p.bias && i < p.M) ? p.bias[i] : 0.f;
+                ls[i] = 0.f;
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         const int wm = wave / WN, wn = wave % WN;
@@ -714,6 +720,8 @@ struct HaloBody16 {
             // through the scalar cache at the top of the tile: an epilogue without a residual / mask issues no global load at all, so
             // nothing in it waits on the vmcnt queue, where the next tile's first DMA pieces are in flight.
             const float* lbias = reinterpret_cast<const float*>(smem + G::BIAS_OFF) + (cur.m0 + wm0 + l15);
+            float* lsums = reinterpret_cast<float*>(smem + G::SUM_OFF) + (cur.m0 + wm0 + l15);
+            const bool want_sums = p.chan_sums != nullptr;
             // AUX: a residual / mask tensor is read; SPLIT: the output is written as split words -- both uniform over the launch: one of
             // four straight-line instances runs (a select per VALUE on these flags was a scalar branch per value: 64 per lane and tile)
             auto epilogue = [&](auto AUX, auto SPLIT) {
@@ -723,8 +731,21 @@ struct HaloBody16 {
                     if constexpr (kAux) x = fmaf(av, rmul, x);
                     x = fmaxf(x, relu_floor);
                     if constexpr (kAux) x = (av > mask_thr) ? x : 0.f;
-                    if constexpr (kSplit) x = pack_split(x);
                     return x;
+                };
+                auto word = [&](float x) -> float {          // the stored form of a value
+                    if constexpr (kSplit) return pack_split(x);
+                    else return x;
+                };
+                // ConvArgs::chan_sums: the row's sum over this wave's pixels (the four lanes that share lane & 15), added to the
+                // workgroup's LDS record of the launch's rows; the records go to memory once, when the workgroup has run out of tiles
+                auto row_sum = [&](int i, const float4 (&x4)[CB]) {
+                    float sx = 0.f;
+#pragma unroll
+                    for (int c = 0; c < CB; ++c) sx += (x4[c].x + x4[c].y) + (x4[c].z + x4[c].w);
+                    sx += __shfl_xor(sx, 16);
+                    sx += __shfl_xor(sx, 32);
+                    if (lane < 16) atomicAdd(lsums + 16 * i, sx);
                 };
                 if constexpr (!kAux) {
                     // (most forward launches) row block by row block: results, then stores.  Until round 6 this case issued placeholder
@@ -738,9 +759,11 @@ struct HaloBody16 {
                         for (int c = 0; c < CB; ++c)
                             o[c] = make_float4(finish(acc[i][c][0], b_, 0.f), finish(acc[i][c][1], b_, 0.f), finish(acc[i][c][2], b_, 0.f),
                                                finish(acc[i][c][3], b_, 0.f));
+                        if (want_sums) row_sum(i, o);
 #pragma unroll
                         for (int c = 0; c < CB; ++c)
-                            if (m < p.M) *reinterpret_cast<float4*>(obase + (size_t)m * plane + 16 * c) = o[c];
+                            if (m < p.M)
+                                *reinterpret_cast<float4*>(obase + (size_t)m * plane + 16 * c) = make_float4(word(o[c].x), word(o[c].y), word(o[c].z), word(o[c].w));
                     }
                 } else {
                     // Residual / mask words are fetched by loads whose rows beyond M are clamped (no branch around a load), in two batches
@@ -770,6 +793,9 @@ struct HaloBody16 {
                                 ov[k][c] = make_float4(finish(acc[i][c][0], b_, a4.x), finish(acc[i][c][1], b_, a4.y), finish(acc[i][c][2], b_, a4.z),
                                                        finish(acc[i][c][3], b_, a4.w));
                             }
+                            if (want_sums) row_sum(i, ov[k]);
+#pragma unroll
+                            for (int c = 0; c < CB; ++c) ov[k][c] = make_float4(word(ov[k][c].x), word(ov[k][c].y), word(ov[k][c].z), word(ov[k][c].w));
                         }
                     };
                     auto stores = [&](int h) {
@@ -804,6 +830,15 @@ struct HaloBody16 {
             if (!more) break;
         }
         wait_vmcnt<0>();
+        if (p.chan_sums) {      // the workgroup's row sums -> memory (one float atomic per row and workgroup)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const float* ls = reinterpret_cast<const float*>(smem + G::SUM_OFF);
+            for (int i = tid; i < p.M; i += 512) {
+                const float v_ = ls[i];
+                if (v_ != 0.f) atomicAdd(p.chan_sums + i, v_);
+            }
+        }
     }
 };
 #endif
@@ -917,6 +952,12 @@ bool igemm_halo_ok(const ConvArgs& a) {
     return tiles >= g_halo_sw.min_tiles;
 }
 
+bool halo_chan_sums_ok(ConvArgs a) {
+    if (a.o_mul == 0) { a.o_mul = 1; a.o_add_y = 0; a.o_add_x = 0; a.o_H = a.OH; a.o_W = a.OW; }      // (as launch_igemm_bf16x3 completes them)
+    if (a.out_nstride == 0) a.out_nstride = (long long)a.M * a.o_H * a.o_W;
+    return !g_halo_sw.mfma32 && igemm_halo_ok(a);
+}
+
 int launch_igemm_halo(ConvArgs& a, hipStream_t st) {
     if (a.out_nstride == 0) a.out_nstride = (long long)a.M * a.OH * a.OW;       // (direct callers: the dense output)
     const int bm = a.M <= 64 ? 64 : 128;
@@ -939,6 +980,8 @@ int launch_igemm_halo(ConvArgs& a, hipStream_t st) {
     const long long ntiles = (long long)a.tiles_m * a.tiles_n;
     const dim3 grid((unsigned)(ntiles < n_cu ? ntiles : n_cu));
     const bool mf16 = !g_halo_sw.mfma32;          // (A/B aid: the 32x32x16 form)
+    if (!(mf16 || a.h16 || wide)) a.chan_sums = nullptr;      // (the 32x32x16 form has no channel sums: the caller sums)
+    note_chan_sums_done(a.chan_sums != nullptr);
 #define AG2V_HALO(WM_, WN_, EM_, TW_, TH_)                                                                                       \
     do {                                                                                                                         \
         if (a.h16) {                                                                                                             \

@@ -466,6 +466,10 @@ __global__ __launch_bounds__(256) void pack_dgrad_tap_kernel(const float* __rest
 
 static thread_local const char* g_last_conv_kernel = "";
 void set_last_conv_kernel(const char* name) { g_last_conv_kernel = name; }
+// (ag2v_conv_opts::chan_sums_done: set by the launcher whose kernel adds the channel sums in its epilogue -- conv_halo.hip)
+static thread_local int g_chan_sums_done = 0;
+void note_chan_sums_done(int v) { g_chan_sums_done = v; }
+static int chan_sums_done() { return g_chan_sums_done; }
 extern "C" const char* ag2v_last_conv_kernel(void) { return g_last_conv_kernel; }
 
 static int conv_out_dim(int in, int k, int stride, int pad) { return (in + 2 * pad - k) / stride + 1; }
@@ -536,6 +540,8 @@ struct ag2v_conv_opts {
     size_t det_workspace_floats;
     long long out_nstride;
     long long out_mstride;
+    float* out_chan_sums;
+    int chan_sums_done;
 };
 struct ConvCfg {
     int precision, min_rows;
@@ -547,6 +553,7 @@ struct ConvCfg {
     size_t det_ws_floats;
     long long out_nstride;
     long long out_mstride;
+    float* chan_sums;
 };
 static ConvCfg conv_cfg(const ag2v_conv_opts* o) {
     ConvCfg c;
@@ -562,6 +569,7 @@ static ConvCfg conv_cfg(const ag2v_conv_opts* o) {
     c.det_ws_floats = o ? o->det_workspace_floats : 0;
     c.out_nstride = o ? o->out_nstride : 0;
     c.out_mstride = o ? o->out_mstride : 0;
+    c.chan_sums = o ? o->out_chan_sums : nullptr;
     return c;
 }
 static bool use_bf16x3(const ConvCfg& c, int M) { return c.precision >= 1 && M >= c.min_rows; }     // (2: fp16 split in the forward pass)
@@ -1282,6 +1290,8 @@ extern "C" int ag2v_conv2d_dgrad_ex(const float* dy, const float* w, const float
     if (accumulate && mask) return AG2V_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const ConvCfg cfg = conv_cfg(o);
+    note_chan_sums_done(0);
+    if (o) o->chan_sums_done = 0;
     const int OH = conv_out_dim(H, R, stride, pad), OW = conv_out_dim(W, S, stride, pad);
     if (OH <= 0 || OW <= 0) return AG2V_EINVAL;
     if ((long long)K * OH * OW >= (1LL << 31) || (long long)C * H * W >= (1LL << 31)) return AG2V_EINVAL;
@@ -1398,8 +1408,7 @@ extern "C" int ag2v_conv2d_dgrad_ex(const float* dy, const float* w, const float
             else
                 hipLaunchKernelGGL(dgrad_weight_prep_kernel, dim3(ceil_div(C, 64), K), dim3(256), 0, st, w, at, K, C, R, S, py, px,
                                    stride, Rc, Sc, split ? 1 : 0);
-            for (int n0 = 0; n0 < N; n0 += nmax) {
-                const int nc = (N - n0 < nmax) ? N - n0 : nmax;
+            auto chunk_args = [&](int n0, int nc) -> ConvArgs {
                 float* dxc = dx + (size_t)n0 * dxo;
                 ConvArgs f{};
                 f.out_nstride = dxo;
@@ -1420,12 +1429,31 @@ extern "C" int ag2v_conv2d_dgrad_ex(const float* dy, const float* w, const float
                 // back as the epilogue's residual term (each element is read and written by the same thread)
                 f.residual = accumulate ? dxc : nullptr;
                 f.det = cfg.det;
+                return f;
+            };
+            // channel sums from the epilogue (ag2v_conv_opts::out_chan_sums): one class, written once, and EVERY sample chunk on the kernels
+            // that add them -- decided before anything is launched (a launch that adds and one that does not cannot share the buffer)
+            bool sums = cfg.chan_sums && !multi && !accumulate && !cfg.det && split;
+            for (int n0 = 0; n0 < N && sums; n0 += nmax) {
+                ConvArgs t = chunk_args(n0, (N - n0 < nmax) ? N - n0 : nmax);
+                sums = halo_chan_sums_ok(t);
+            }
+            int sums_done = 0, chunks = 0;
+            for (int n0 = 0; n0 < N; n0 += nmax) {
+                const int nc = (N - n0 < nmax) ? N - n0 : nmax;
+                ConvArgs f = chunk_args(n0, nc);
+                f.chan_sums = sums ? cfg.chan_sums : nullptr;
+                note_chan_sums_done(0);
                 const int rc = launch_igemm(f, st, multi || accumulate != 0, split || f32ws);
                 if (rc != AG2V_OK) return rc;
+                sums_done += chan_sums_done();
+                ++chunks;
             }
+            if (sums && sums_done != chunks) return AG2V_EINVAL;      // (cannot happen: halo_chan_sums_ok is the launcher's own test)
+            note_chan_sums_done(sums ? 1 : 0);
             at += (size_t)K * C * Rc * Sc;
         }
-    if (o) o->kernel = g_last_conv_kernel;
+    if (o) { o->kernel = g_last_conv_kernel; o->chan_sums_done = g_chan_sums_done; }
     if (multi && mask) return launch_act_mask(dx, mask, (long long)N * C * H * W, 0, st);
     return AG2V_OK;
 }

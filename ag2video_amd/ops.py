@@ -281,12 +281,14 @@ def reload_kernel_switches():
 
 
 def _conv_launch(min_rows, name, label, flops, *args, shape=None, gscale=None, group_n=1, in_split=False, dy_split=False,
-                 out_split=False, det_ws_query=None, precision=None, out_nstride=0, out_mstride=0):
+                 out_split=False, det_ws_query=None, precision=None, out_nstride=0, out_mstride=0, chan_sums=None):
     """One ag2v_conv2d_*_ex call.  Arithmetic (precision, bf16x3 row threshold: ``min_rows``, None = DEFAULT_MIN_ROWS) and the
-    per-sample-group output scale travel as per-call options (ag2v_conv_opts): no process-wide switch is touched."""
+    per-sample-group output scale travel as per-call options (ag2v_conv_opts): no process-wide switch is touched.
+    Returns ag2v_conv_opts::chan_sums_done (data gradient with ``chan_sums``: the launch added the channel sums of dx to it)."""
     opts = _lib.ConvOpts(_PRECISION[0] if precision is None else int(precision), int(min_rows) if min_rows else DEFAULT_MIN_ROWS, None if gscale is None else gscale.data_ptr(),
                          int(group_n), None, 1 if in_split else 0, 1 if dy_split else 0, 1 if out_split else 0,
-                         1 if _DETERMINISTIC[0] else 0, None, 0, int(out_nstride), int(out_mstride))
+                         1 if _DETERMINISTIC[0] else 0, None, 0, int(out_nstride), int(out_mstride),
+                         None if chan_sums is None else chan_sums.data_ptr(), 0)
     det_ws = None
     if det_ws_query is not None:      # weight gradient: slabs for the ordered reduction of its pixel-range splits (deterministic mode;
         # in either mode for the LDS-DMA kernel, whose atomic epilogue costs 6-16 % of a launch)
@@ -302,7 +304,7 @@ def _conv_launch(min_rows, name, label, flops, *args, shape=None, gscale=None, g
     args = args + (ctypes.byref(opts),)
     if _TIMING is None or _PAUSED:
         _lib.call(name, *args)
-        return
+        return bool(opts.chan_sums_done)
     e0 = _EVENT_POOL.pop() if _EVENT_POOL else torch.cuda.Event(enable_timing=True)
     e1 = _EVENT_POOL.pop() if _EVENT_POOL else torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -311,6 +313,7 @@ def _conv_launch(min_rows, name, label, flops, *args, shape=None, gscale=None, g
     # key the record on the HIP kernel the library chose (tile shape / arithmetic / load path), as rocprofv3 names it; the
     # pass (fwd / dgrad / wgrad) stays in front because forward and data gradient share the implicit-GEMM kernels
     _TIMING.append(("%s:%s" % (label, (opts.kernel or b'?').decode()), flops, e0, e1, shape, _SCOPE[-1]))
+    return bool(opts.chan_sums_done)
 
 
 _PAUSED = False
@@ -567,6 +570,9 @@ def _conv_fwd_launch(mr, x, w, bias, residual, y, stride, pad, relu, gscale=None
 
 
 _MERGE_SHARED_FWD = os.environ.get('AG2V_NO_MERGED_FWD') is None      # conv2d_shared_input: one forward launch (tests compare both sides)
+# conv2d(relu_input=True) backward: the data-gradient launch adds dx's channel sums -- the bias gradient of the convolution behind the
+# ReLU -- in its epilogue (ag2v_conv_opts::out_chan_sums) instead of a pass over dx by the producer's backward (tests compare both sides)
+_CHAN_SUMS_IN_DGRAD = os.environ.get('AG2V_NO_DGRAD_SUMS') is None
 
 
 def _fwd_mtile_ok(mr, x, K, R, S, stride, pad, in_split, out_split):
@@ -576,10 +582,12 @@ def _fwd_mtile_ok(mr, x, K, R, S, stride, pad, in_split, out_split):
                            2 if h16 else _PRECISION[0], 1 if in_split else 0, 1 if out_split else 0, 1 if _DETERMINISTIC[0] else 0))
 
 
-def _conv_dgrad_launch(mr, dy, w, mask, dx, stride, pad, acc, gscale=None, group_n=1, dy_split=False, out_split=False):
+def _conv_dgrad_launch(mr, dy, w, mask, dx, stride, pad, acc, gscale=None, group_n=1, dy_split=False, out_split=False, chan_sums=None):
     """dx (+)= data gradient.  The workspace holds the re-ordered filters and, for <= 4 input channels, the intermediate of the
     1x1-GEMM form (caller memory: the library allocates nothing).  dx may be a channel slice of a wider [N, Ctot, H, W] buffer
-    (_GradSlots): the kernels then step Ctot * H * W floats between samples (ag2v_conv_opts::out_nstride)."""
+    (_GradSlots): the kernels then step Ctot * H * W floats between samples (ag2v_conv_opts::out_nstride).
+    chan_sums ([C] floats, initialised by the caller): -> True when the launch ADDED dx's per-channel sums to it from its epilogue
+    (ag2v_conv_opts::out_chan_sums: the LDS-DMA kernels outside deterministic mode); False: untouched, the caller sums dx."""
     N, C, H, W = dx.shape
     onst = 0
     if not dx.is_contiguous():
@@ -589,10 +597,10 @@ def _conv_dgrad_launch(mr, dy, w, mask, dx, stride, pad, acc, gscale=None, group
     K, _, R, S = w.shape
     nws = _lib.query('ag2v_conv2d_dgrad_workspace_floats', N, C, H, W, K, R, S, stride, pad)
     ws = torch.empty(nws, device=dy.device, dtype=torch.float32)
-    _conv_launch(mr, 'ag2v_conv2d_dgrad_ex', 'conv_dgrad', 2.0 * N * K * dy.shape[2] * dy.shape[3] * C * R * S,
-                 _ptr(dy), _ptr(w), _ptr(mask), _ptr(dx), N, C, H, W, K, R, S, stride, pad, 1 if acc else 0, _ptr(ws), nws, _stream(),
-                 shape=(N, C, H, W, K, R, stride), gscale=gscale, group_n=group_n, dy_split=dy_split, out_split=out_split,
-                 out_nstride=onst)
+    return _conv_launch(mr, 'ag2v_conv2d_dgrad_ex', 'conv_dgrad', 2.0 * N * K * dy.shape[2] * dy.shape[3] * C * R * S,
+                        _ptr(dy), _ptr(w), _ptr(mask), _ptr(dx), N, C, H, W, K, R, S, stride, pad, 1 if acc else 0, _ptr(ws), nws, _stream(),
+                        shape=(N, C, H, W, K, R, stride), gscale=gscale, group_n=group_n, dy_split=dy_split, out_split=out_split,
+                        out_nstride=onst, chan_sums=chan_sums)
 
 
 def _conv_wgrad_launch(mr, dy, x, dw, K, R, S, stride, pad, acc, groups=1, in_split=False, dy_split=False, workspace=True):
@@ -733,10 +741,17 @@ class _Conv2d(torch.autograd.Function):
             dx = ctx.dx_slot[0].view(ctx.dx_slot[1], N, H, W, x.device) if ctx.dx_slot is not None else torch.empty_like(x)
             if tuple(dx.shape) != tuple(x.shape):
                 raise RuntimeError("conv2d backward: gradient slot of shape %s for an input of shape %s" % (tuple(dx.shape), tuple(x.shape)))
-            _conv_dgrad_launch(mr, dy, w, x if relu_input else None, dx, stride, pad, 0, gscale, group_n, dy_split=dys,
-                               out_split=ctx.dx_split)
+            # relu_input: x = relu(a convolution's output) -- that convolution's bias gradient is the channel sum of this dx: the
+            # launch adds it up in its epilogue where it can (_CHAN_SUMS_IN_DGRAD; else the producer's backward sums dx as before)
+            csum = None
+            if relu_input and _CHAN_SUMS_IN_DGRAD and not _DETERMINISTIC[0]:
+                csum = ctx.dx_slot[0].sums_view(ctx.dx_slot[1]) if ctx.dx_slot is not None else torch.zeros(C, device=x.device, dtype=torch.float32)
+            done = _conv_dgrad_launch(mr, dy, w, x if relu_input else None, dx, stride, pad, 0, gscale, group_n, dy_split=dys,
+                                      out_split=ctx.dx_split, chan_sums=csum)
             if ctx.dx_slot is not None:
-                ctx.dx_slot[0].mark(ctx.dx_slot[1])
+                ctx.dx_slot[0].mark(ctx.dx_slot[1], summed=bool(done))
+            elif done:
+                _attach_channel_sums(dx, csum)
             if ctx.dx_split:
                 mark_split(dx)
         if gscale is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[4]):
@@ -872,27 +887,52 @@ class _GradSlots(object):
     c3 step).  Allocated by the first consumer's backward, dropped by the producer's.  A slice counts as the gradient only when a
     consumer's backward of THIS pass has launched its data gradient into it (`written`, set by mark() behind the launch and cleared
     with the buffer): a slice left over from a pass that stopped half way is never read as a gradient."""
-    __slots__ = ('ks', 'buf', 'written')
+    __slots__ = ('ks', 'buf', 'written', 'sums', 'summed', 'handed')
 
     def __init__(self, ks):
         self.ks = [int(k) for k in ks]
         self.buf = None
         self.written = set()
+        self.sums = None          # [sum K_i] channel sums of buf, slice i valid when i is in `summed` (added by the launch that wrote it)
+        self.summed = set()
+        self.handed = set()
 
     def view(self, i, N, H, W, device):
         if self.buf is None or tuple(self.buf.shape) != (N, sum(self.ks), H, W):
             self.buf = torch.empty((N, sum(self.ks), H, W), device=device, dtype=torch.float32)
             self.written = set()
+            self.sums = None
+            self.summed = set()
         self.written.discard(i)
+        self.summed.discard(i)
         off = sum(self.ks[:i])
         return self.buf[:, off:off + self.ks[i]]
 
-    def mark(self, i):
+    def sums_view(self, i):
+        """Zeroed slice i of the channel-sum record (call after view(i, ...))."""
+        if self.sums is None:
+            self.sums = torch.zeros(sum(self.ks), device=self.buf.device, dtype=torch.float32)
+            self.handed = set()
+        off = sum(self.ks[:i])
+        v = self.sums[off:off + self.ks[i]]
+        if i in self.handed:         # handed out before in this pass (a retried backward): start from zero again
+            v.zero_()
+        self.handed.add(i)
+        return v
+
+    def mark(self, i, summed=False):
         self.written.add(i)
+        if summed:
+            self.summed.add(i)
+
+    def all_summed(self):
+        return self.sums is not None and all(i in self.summed for i in range(len(self.ks)))
 
     def drop(self):
         self.buf = None
         self.written = set()
+        self.sums = None
+        self.summed = set()
 
     def holds(self, i, t):
         """t is exactly channel slice i of the buffer, and this pass wrote it."""
@@ -1081,6 +1121,8 @@ class _ConvSharedInput(torch.autograd.Function):
             if has_b[i] and ctx.needs_input_grad[8 + 2 * i]:
                 bbuf, bacc, db = _wsink_take(ctx.bkeys[i], ctx.w_alive[2 * i + 1])
                 if slotted:         # channel sums of the whole buffer, once; each bias takes its slice
+                    if slot_sums is None and slots.all_summed():
+                        slot_sums = slots.sums          # (every slice's data-gradient launch added its sums in its epilogue)
                     if slot_sums is None:
                         slot_sums = torch.empty(slots.buf.shape[1], device=dy.device, dtype=torch.float32)
                         _lib.call('ag2v_channel_sum_acc_s', _ptr(slots.buf), _ptr(slot_sums), N, slots.buf.shape[1], dy.shape[2] * dy.shape[3],
@@ -1091,7 +1133,15 @@ class _ConvSharedInput(torch.autograd.Function):
                     else:
                         bbuf.copy_(slot_sums[off:off + K])
                 else:
-                    _lib.call('ag2v_channel_sum_acc_s', _ptr(dy), _ptr(bbuf), N, K, dy.shape[2] * dy.shape[3], bacc | _det_bit(), 1 if dys_split else 0, st)
+                    # (a dense gradient whose producing launch added its channel sums in its epilogue carries them: _attach_channel_sums)
+                    pre = _channel_sums_of(dys[i]) if ys[i] is None else None
+                    if pre is not None and pre.numel() == K and _USE_CHANNEL_SUMS:
+                        if bacc:
+                            bbuf.add_(pre)
+                        else:
+                            bbuf.copy_(pre)
+                    else:
+                        _lib.call('ag2v_channel_sum_acc_s', _ptr(dy), _ptr(bbuf), N, K, dy.shape[2] * dy.shape[3], bacc | _det_bit(), 1 if dys_split else 0, st)
             grads += [dw, db]
         dyc = None
         if merged_w:

@@ -73,7 +73,13 @@ extern "C" {
  *              floats apart (y + i * out_mstride; out_mstride >= N * 128 * OH * OW).  The SPADE layers of a residual block read the same
  *              resized segmentation map through their own 128-channel mlp_shared convolution (normalization.py:90-94,
  *              architecture.py:52-62): the gathered map is then staged once for all of them.  Only where ag2v_conv2d_fwd_mtile_ok()
- *              says so (the LDS-DMA kernels' 128-row tile); otherwise AG2V_EINVAL, before anything is launched. */
+ *              says so (the LDS-DMA kernels' 128-row tile); otherwise AG2V_EINVAL, before anything is launched;
+ *   out_chan_sums / chan_sums_done: (data gradient) out_chan_sums, when not NULL, points at C floats the caller has initialised; a launch
+ *              that runs on the LDS-DMA kernels (3x3 stride-1, not deterministic) then ADDS the per-channel sums of the dx it writes
+ *              (over samples and pixels; of the values, also when dx is written as split words) from its epilogue -- the bias gradient of
+ *              the convolution that produced the data-gradient's input (reference: autograd's sum over dy for nn.Conv2d's bias) without
+ *              another pass over dx -- and sets chan_sums_done = 1.  Any other launch leaves the buffer untouched and sets
+ *              chan_sums_done = 0: the caller then sums dx itself (ag2v_channel_sum_acc_s).  Float atomics: ~1e-7 relative run to run. */
 typedef struct ag2v_conv_opts {
     int precision;
     int min_rows;
@@ -88,6 +94,8 @@ typedef struct ag2v_conv_opts {
     size_t det_workspace_floats;
     long long out_nstride;
     long long out_mstride;
+    float* out_chan_sums;
+    int chan_sums_done;
 } ag2v_conv_opts;
 /* Defaults of calls that do not name precision / min_rows: a record per DEVICE, initialised from AG2V_CONV_PRECISION /
  * AG2V_BF16X3_MIN_M.  The setters are deprecated shims editing the calling thread's current device's record (the product passes both

@@ -88,6 +88,93 @@ def test_gradient_slots_equal_the_concatenation(cfg, device, monkeypatch):
         assert float((a.double() - r).abs().max()) <= 3e-4 * float(r.abs().max())
 
 
+@pytest.mark.parametrize("cfg", [(4, 64, 64, 64, (128, 128, 128), 96), (2, 32, 128, 128, (128, 128), 192), (3, 64, 32, 32, (128, 64, 128), 96),
+                                 (2, 32, 64, 64, (100,), 64)], ids=str)
+@pytest.mark.parametrize("slots_on", [True, False], ids=['slots', 'dense'])
+def test_bias_gradient_from_the_data_gradient_epilogue(cfg, slots_on, device, monkeypatch):
+    """Round 6: the data gradient of conv2d(relu_input=True) -- dx = d relu(mlp_shared) -- adds dx's per-channel sums, i.e. the bias
+    gradient of the convolution behind the ReLU (autograd's dy.sum((0, 2, 3)) for nn.Conv2d's bias), in the epilogue of the LDS-DMA
+    kernel that writes dx (ag2v_conv_opts::out_chan_sums) instead of a pass over dx afterwards.  Both sides of ops._CHAN_SUMS_IN_DGRAD,
+    with gradient slots and with dense gradients: no channel-sum launch over the activation-sized gradient on the new side, the same
+    gradients (float atomics: 1e-5 of max), and the fp64 graph as reference; other kernel families and deterministic mode keep the pass."""
+    import os
+    from ag2video_amd import _lib, ops
+    N, C, H, W, Ks, G = cfg
+    torch.manual_seed(12)
+    seg0 = torch.randn(N, C, H, W, device=device)
+    hi = seg0.to(torch.bfloat16)
+    lo = (seg0 - hi.float()).to(torch.bfloat16)
+    words = ((hi.view(torch.int16).to(torch.int32) << 16) | (lo.view(torch.int16).to(torch.int32) & 0xFFFF)).view(torch.float32)
+    segv = hi.float() + lo.float()
+    n = len(Ks)
+    ws = [torch.randn(k, C, 3, 3, device=device) * 0.06 for k in Ks]
+    bs = [torch.randn(k, device=device) * 0.1 for k in Ks]
+    gws = [torch.randn(G, k, 3, 3, device=device) * 0.04 for k in Ks]
+    gbs = [torch.randn(G, device=device) * 0.1 for _ in Ks]
+    heads = [torch.randn(N, G, H, W, device=device) for _ in Ks]
+    big_sums = []
+    real_call = _lib.call
+
+    def counting_call(name, *a):
+        if name == 'ag2v_channel_sum_acc_s' and a[2] * a[4] == N * H * W and a[3] in (tuple(Ks) + (sum(Ks),)):     # (x, out, N, C, HW, ...): dx of a gamma | beta convolution
+            big_sums.append(a[3])
+        return real_call(name, *a)
+
+    def run(sums_on, det=False, halo=True):
+        monkeypatch.setattr(ops, '_GRAD_SLOTS', slots_on)
+        monkeypatch.setattr(ops, '_SLOTS_MIN_PIXELS', 0)
+        monkeypatch.setattr(ops, '_CHAN_SUMS_IN_DGRAD', sums_on)
+        old = {k: os.environ.get(k) for k in ('AG2V_HALO_MIN_TILES', 'AG2V_NO_HALO')}
+        os.environ['AG2V_HALO_MIN_TILES'] = '1'
+        if not halo:
+            os.environ['AG2V_NO_HALO'] = '1'
+        torch.cuda.synchronize()
+        ops.reload_kernel_switches()
+        try:
+            leaves = [t.clone().requires_grad_(True) for t in ws + bs + gws + gbs]
+            seg = ops.mark_split(words.clone()).requires_grad_(True)
+            ops.mark_split(seg)
+            del big_sums[:]
+            with ops.conv_precision('bf16x3'), ops.bf16x3_min_rows(32), ops.deterministic(det):
+                loss = _graph(ops, seg, leaves[:n], leaves[n:2 * n], leaves[2 * n:3 * n], leaves[3 * n:], heads)
+                monkeypatch.setattr(_lib, 'call', counting_call)
+                try:
+                    loss.backward()
+                finally:
+                    monkeypatch.setattr(_lib, 'call', real_call)
+            torch.cuda.synchronize()
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+            ops.reload_kernel_switches()
+        return [seg.grad] + [t.grad for t in leaves], list(big_sums)
+
+    g1, sums1 = run(True)
+    g0, sums0 = run(False)
+    assert not sums1, "no channel-sum pass over an activation-sized gradient: %s" % (sums1,)
+    assert sums0, "the other side sums dx in its own pass"
+    for a, b in zip(g1, g0):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+    _, sums_det = run(True, det=True)
+    assert sums_det, "deterministic mode keeps the ordered pass"
+    g_nh, sums_nh = run(True, halo=False)
+    assert sums_nh, "kernels without the epilogue sums: the caller's pass"
+    for a, b in zip(g_nh, g0):
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max())
+    leaves = [t.double().requires_grad_(True) for t in ws + bs + gws + gbs]
+    seg = segv.double().requires_grad_(True)
+    with torch.no_grad(), ops.conv_precision('bf16x3'), ops.bf16x3_min_rows(32):
+        actv = ops.conv2d_shared_input(ops.mark_split(words.clone()), ws, bs, 1, 1, relu=True, grad_premasked=True, out_split=[True] * n)
+        masks = [((a.view(torch.int32) & 0x7FFF0000) != 0).double() * (a.view(torch.int32) >= 0).double() for a in actv]
+    _ref64(seg, leaves[:n], leaves[n:2 * n], leaves[2 * n:3 * n], leaves[3 * n:], [h.double() for h in heads], masks).backward()
+    refs = [seg.grad] + [t.grad for t in leaves]
+    for a, r in zip(g1, refs):
+        assert float((a.double() - r).abs().max()) <= 3e-4 * float(r.abs().max())
+
+
 def test_strided_data_gradient_is_refused_where_no_kernel_writes_it(device):
     """out_nstride with a strided / accumulating / few-channel data gradient: AG2V_EINVAL, never a silently dense write."""
     from ag2video_amd import ops
