@@ -649,7 +649,6 @@ struct HaloBody16 {
         int v = blockIdx.x;
         Tile nxt = describe(v, vAn, vBn);
         P = lastP;
-        NS = NS;
         {   // first tile: its stage 0 (as "the next tile's") and A steps 0..5
             const int keepNS = NS;
             NS = 0;                       // every stage index counts as "beyond": dma_b_round takes vBn with offset 0
@@ -665,7 +664,6 @@ struct HaloBody16 {
         const float relu_floor = p.relu ? 0.f : ninf;
         const float mask_thr = (!p.residual && p.mask) ? 0.f : ninf;
         const bool osplit = p.out_split != 0;
-        const int l31 = lane & 31, up = lane >> 5;
         bool first = true, full_prev = false;
         while (true) {
             const Tile cur = nxt;
@@ -683,7 +681,7 @@ struct HaloBody16 {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[i][c][r] = 0.f;
             // this tile's stage 0 and A steps 0..5 (issued by the previous tile's tail, or just above) have landed.  They are OLDER than
-            // the previous tile's 2 RB epilogue stores, which may stay in flight (vmcnt counts in issue order); a tile whose last row block
+            // the previous tile's RB * CB epilogue stores, which may stay in flight (vmcnt counts in issue order); a tile whose last row block
             // is partly outside M issues fewer stores, so it waits for everything.
             if (first || !full_prev) wait_vmcnt<0>();
             else wait_vmcnt<RB * CB>();
