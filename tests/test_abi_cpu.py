@@ -18,6 +18,33 @@ def test_header_matches_binding():
     assert _declared() == list(_lib.EXPORTS)
 
 
+def _struct_fields(src, pattern):
+    """[(C type, name)] of the struct whose body `pattern` captures (comments and blank lines dropped)."""
+    body = re.search(pattern, src, re.S).group(1)
+    body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+    body = re.sub(r'//[^\n]*', '', body)
+    out = []
+    for decl in body.split(';'):
+        decl = ' '.join(decl.split())
+        if decl:
+            m = re.match(r'(.*?[\s\*])([A-Za-z_][A-Za-z0-9_]*)$', decl)
+            out.append((m.group(1).replace(' ', ''), m.group(2)))
+    return out
+
+
+def test_conv_opts_struct_has_one_layout():
+    """ag2v_conv_opts is declared three times -- include/ag2v.h (the contract), its mirror in csrc/conv_igemm.hip (the library is built
+    without the public header) and the ctypes binding: same fields, same order, same C types everywhere."""
+    import ctypes
+    from ag2video_amd import _lib
+    header = _struct_fields(open(os.path.join(REPO, 'include', 'ag2v.h')).read(), r'typedef struct ag2v_conv_opts \{(.*?)\} ag2v_conv_opts;')
+    mirror = _struct_fields(open(os.path.join(REPO, 'ag2video_amd', 'csrc', 'conv_igemm.hip')).read(), r'\nstruct ag2v_conv_opts \{(.*?)\n\};')
+    assert header == mirror
+    ctype_of = {'int': ctypes.c_int, 'constfloat*': ctypes.c_void_p, 'float*': ctypes.c_void_p, 'constchar*': ctypes.c_char_p,
+                'size_t': ctypes.c_size_t, 'longlong': ctypes.c_longlong}
+    assert [(ctype_of[t], n) for t, n in header] == [(t, n) for n, t in _lib.ConvOpts._fields_]
+
+
 def test_library_exports_every_symbol():
     from ag2video_amd import _lib
     if not os.path.exists(_lib.LIB_PATH):
