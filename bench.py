@@ -409,8 +409,9 @@ def main():
                                      pmc['algorithmic_bytes'] / 1e6,
                                      (pmc['fetch_bytes'] + pmc['write_bytes']) / pmc['algorithmic_bytes'])) if pmc
                                  else 'no PMC pass for this kernel under profiles/'),
-                "peak_basis": ("bf16 dense MFMA 2500 TF (2.4 GHz) / 3 MFMAs per fp32-equivalent product; the kernel's own cycle counter shows "
-                               "1.53 GHz under this instruction mix (DESIGN.md 3.4), i.e. 531 TF MFMA-bound at the held clock"
+                "peak_basis": ("bf16 dense MFMA 2500 TF (2.4 GHz) / 3 MFMAs per fp32-equivalent product; under this instruction mix the chip holds "
+                               "1.81 GHz on the LDS-DMA kernel (PMC, profiles/r06/pmc_halo_*_r06h.txt: matrix pipe 74 % busy), i.e. 628 TF "
+                               "MFMA-bound at the held clock"
                                if split else "v_mfma_f32_32x32x2_f32 dense peak"),
                 # a CALL = one ag2v_conv2d_*_ex entry; the library cuts a call whose operands exceed 4 GiB into sample chunks, so rocprofv3
                 # counts more kernel LAUNCHES of this kernel than calls (c3: 25 calls = 38 launches per step).  achieved =
